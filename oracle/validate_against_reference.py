@@ -1,0 +1,158 @@
+"""Pin the oracle against the reference itself  --  TEST INFRASTRUCTURE, build container only.
+
+Imports the reference from /root/reference (oracle/ref_import.py), loads the same
+seeded weights into it and into the oracle, runs both on the same seeded inputs and
+records the max-abs difference of every output in tests/golden/VALIDATION.json.
+
+    python -m oracle.validate_against_reference
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from mgsv_amd.config import MadeConfig, cfg_plumbing, cfg_native, cfg_headline  # noqa: E402
+from mgsv_amd import synth  # noqa: E402
+from oracle import made_oracle as O  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+
+def _maxabs(a, b) -> float:
+    a = a.detach().double() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
+    b = b.detach().double() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    return float((a - b).abs().max())
+
+
+def compare_forward(cfg: MadeConfig, B: int, T_v: int, T_a: int, tag: str) -> dict:
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, B, T_v, T_a, seed=1)
+    ref = ref_import.build_reference_model(cfg, sd)
+    P = O.to_torch_params(sd)
+    tin = {k: torch.from_numpy(v) for k, v in inp.items() if isinstance(v, np.ndarray)}
+    with torch.no_grad():
+        om, lm, fm, mm, im = ref(tin["frame_feats"].clone(), tin["segment_feats"].clone(),
+                                 tin["frame_masks"].clone(), tin["segment_masks"].clone(),
+                                 tin["spans_target"].clone(), v_duration=tin["v_duration"],
+                                 video_ids=inp["video_ids"], music_ids=inp["music_ids"], is_train=False)
+        r = O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"],
+                      inp["segment_masks"], inp["spans_target"], v_duration=inp["v_duration"],
+                      music_ids=inp["music_ids"])
+    d = {}
+    for k in ("pred_logits", "pred_spans", "proj_queries", "proj_vid_mem"):
+        if k in om:
+            d[k] = _maxabs(om[k], r[k])
+    for i, aux in enumerate(om.get("aux_outputs", [])):
+        for k in aux:
+            d[f"aux{i}.{k}"] = _maxabs(aux[k], r["aux_outputs"][i][k])
+    for k in ("video_feats", "music_feats", "frame_feats", "segment_feats"):
+        d[k] = _maxabs(fm[k], r[k])
+    d["retrieval_loss"] = _maxabs(lm["retrieval_loss"], r["retrieval_loss"])
+    d["localization_loss"] = _maxabs(lm["localization_loss"], r["localization_loss"])
+    for k, v in lm["localization_loss_dict"].items():
+        d["loss." + k] = _maxabs(v, r["loss_dict"][k])
+    assert set(lm["localization_loss_dict"]) == set(r["loss_dict"]), "loss key sets differ"
+    # weight dict
+    assert dict(ref.criterion.weight_dict) == O.criterion_weight_dict(cfg)
+    # matcher indices on the last layer
+    ref_idx = ref.criterion.matcher({"pred_logits": om["pred_logits"], "pred_spans": om["pred_spans"]}, tin["spans_target"])
+    for (ri, rj), (oi, oj) in zip(ref_idx, r["matcher_indices"]):
+        assert ri.tolist() == oi.tolist() and rj.tolist() == oj.tolist(), "matcher indices differ"
+    d["matcher_indices"] = 0.0
+    # X-Pool block called directly, as the drivers do (test-MaDe.py:392-395)
+    if "music" in cfg.vmr_fusion:
+        with torch.no_grad():
+            xa = ref.video_guided_to_music_pooling_cross_transformer(
+                fm["video_feats"], fm["segment_feats"], mm["segment_masks"] if cfg.fusion_mask == 1 else None)
+        d["music_feats_pooled"] = _maxabs(xa, r["music_feats_pooled"])
+        from modules.metrics import sim_matrix_music_pooling
+        d["sims_single"] = _maxabs(sim_matrix_music_pooling(fm["video_feats"], xa), r["sims_single"])
+    from modules.loss import cal_distance
+    d["sims_dual"] = _maxabs(cal_distance(fm["video_feats"], fm["music_feats"]), r["sims_dual"])
+    with torch.no_grad():
+        fus_mask = torch.cat([mm["frame_masks"], mm["segment_masks"]], 1) if "concat" in cfg.mml_fusion else mm["segment_masks"]
+        d["detr_pos"] = _maxabs(ref.music_position_embedding(None if False else torch.zeros(1), fus_mask), r["detr_pos"])
+    print(f"[{tag}] max over outputs = {max(d.values()):.3e}")
+    return d
+
+
+def compare_lsap(n_cases: int = 400) -> dict:
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(7)
+    worst = 0
+    for t in range(n_cases):
+        nr, nc = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        kind = t % 4
+        if kind == 0:
+            c = rng.standard_normal((nr, nc))
+        elif kind == 1:
+            c = rng.integers(0, 3, size=(nr, nc)).astype(np.float64)      # many ties
+        elif kind == 2:
+            c = rng.standard_normal((nr, nc)).astype(np.float32).astype(np.float64)
+        else:
+            c = np.round(rng.standard_normal((nr, nc)), 1)
+        a, b = linear_sum_assignment(c)
+        oa, ob = O.lsap(c)
+        assert a.tolist() == oa.tolist() and b.tolist() == ob.tolist(), (c, a, b, oa, ob)
+    for bad in (np.array([[np.nan, 1.0]]), np.array([[np.inf, np.inf]]), np.array([[-np.inf, 1.0]])):
+        for fn in (linear_sum_assignment, O.lsap):
+            try:
+                fn(bad)
+                raise AssertionError("expected ValueError")
+            except ValueError:
+                pass
+    return {"lsap_cases": n_cases, "mismatches": worst}
+
+
+def compare_retrieval(cfg: MadeConfig, N_v: int, N_m: int, S: int) -> dict:
+    sd = synth.make_state_dict(cfg, seed=0)
+    ref = ref_import.build_reference_model(cfg, sd)
+    P = O.to_torch_params(sd)
+    ri = synth.make_retrieval_inputs(N_v, N_m, S, cfg.D, seed=2)
+    from modules.metrics import sim_matrix_music_pooling
+    from modules.loss import cal_distance
+    with torch.no_grad():
+        v = torch.from_numpy(ri["video_embeds"]); s = torch.from_numpy(ri["segment_embeds"])
+        m = torch.from_numpy(ri["segment_masks"]); mu = torch.from_numpy(ri["music_embeds"])
+        pooled = ref.video_guided_to_music_pooling_cross_transformer(v, s, m)
+        ref_sim = sim_matrix_music_pooling(v, pooled) + cal_distance(v, mu)
+        ours = O.retrieval_sim_matrix(P, cfg, ri["video_embeds"], ri["segment_embeds"], ri["segment_masks"],
+                                      ri["music_embeds"], chunk_v=7)
+    return {"retrieval_sim": _maxabs(ref_sim, ours)}
+
+
+def main():
+    torch.manual_seed(0)
+    report = {"torch": torch.__version__, "numpy": np.__version__}
+    import scipy
+    report["scipy"] = scipy.__version__
+    report["cfg1_plumbing_B2"] = compare_forward(cfg_plumbing(), 2, 30, 200, "cfg1 B=2 Tv=30 Ta=200 D=256")
+    report["native_B8"] = compare_forward(cfg_native(), 8, 50, 96, "native B=8 Tv=50 Ta=96 D=256")
+    c = cfg_native(); c.num_moment_queries = 3
+    report["native_Q3_B4"] = compare_forward(c, 4, 50, 96, "native Q=3")
+    c = cfg_native(); c.mml_fusion = "CA"
+    report["native_CA_B4"] = compare_forward(c, 4, 50, 96, "native CA fusion")
+    c = cfg_native(); c.fb_label = "10"; c.audio_short_cut = 1; c.with_act_after_proj = 1
+    report["native_fb10_shortcut_B4"] = compare_forward(c, 4, 50, 96, "native fb10/short-cut/act")
+    c = cfg_headline()
+    report["cfg2_B4"] = compare_forward(c, 4, 30, 512, "cfg2 shape B=4 Tv=30 Ta=512 D=512")
+    report["lsap_vs_scipy"] = compare_lsap()
+    report["retrieval_N48x40_S96"] = compare_retrieval(cfg_native(), 48, 40, 96)
+    worst = max(v for k, sec in report.items() if isinstance(sec, dict) for v in sec.values() if isinstance(v, float))
+    report["worst_maxabs"] = worst
+    out = os.path.join(ROOT, "tests", "golden", "VALIDATION.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+    print("worst max-abs:", worst, "->", out)
+    assert worst < 2e-5, worst
+
+
+if __name__ == "__main__":
+    main()

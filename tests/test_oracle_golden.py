@@ -1,0 +1,120 @@
+"""CPU: the oracle (oracle/made_oracle.py) against the golden vectors the reference produced
+(tests/golden/*.npz, made by tests/golden/make_golden.py) and the reference's own known answers."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mgsv_amd import synth
+from mgsv_amd.config import cfg_native, cfg_plumbing
+from oracle import made_oracle as O
+
+SUB = (slice(None), slice(None, None, 7), slice(None, None, 5))
+TOL = 2e-5      # float32, torch CPU vs torch CPU (oracle/validate_against_reference.py measured <= 1.3e-5)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _cfg_for(name, fix):
+    cfg = cfg_plumbing() if "cfg1" in name else cfg_native()
+    for k, v in ast.literal_eval(str(fix["meta_cfg_overrides"])):
+        setattr(cfg, k, v)
+    return cfg
+
+
+@pytest.mark.parametrize("name", ["forward_cfg1_B2", "forward_native_Q3_B4"])
+def test_forward_matches_reference_golden(golden_dir, name):
+    fix = _load(golden_dir, name)
+    cfg = _cfg_for(name, fix)
+    B, T_v, T_a = int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"])
+    P = O.to_torch_params(synth.make_state_dict(cfg, seed=int(fix["meta_weight_seed"])))
+    inp = synth.make_inputs(cfg, B, T_v, T_a, seed=int(fix["meta_data_seed"]))
+    with torch.no_grad():
+        r = O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"],
+                      inp["spans_target"], v_duration=inp["v_duration"], music_ids=inp["music_ids"])
+    for k in ("pred_logits", "pred_spans", "proj_queries", "video_feats", "music_feats", "sims_single", "sims_dual"):
+        np.testing.assert_allclose(r[k].numpy(), fix[k], atol=TOL, rtol=0, err_msg=k)
+    np.testing.assert_allclose(r["proj_vid_mem"].numpy()[SUB], fix["proj_vid_mem"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(r["frame_feats"].numpy()[SUB], fix["frame_feats_sub"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(r["segment_feats"].numpy()[SUB], fix["segment_feats_sub"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(r["music_feats_pooled"].numpy()[:, :, ::5], fix["music_feats_pooled_sub"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(r["detr_pos"].numpy()[SUB], fix["detr_pos_sub"], atol=TOL, rtol=0)
+    for i, aux in enumerate(r["aux_outputs"]):
+        np.testing.assert_allclose(aux["pred_logits"].numpy(), fix[f"aux{i}_pred_logits"], atol=TOL, rtol=0)
+        np.testing.assert_allclose(aux["pred_spans"].numpy(), fix[f"aux{i}_pred_spans"], atol=TOL, rtol=0)
+    loss_keys = [k for k in fix.files if k.startswith("loss_")]
+    assert len(loss_keys) == 5 * cfg.detr_dec_layers            # 30 scalars at dec=6
+    for k in loss_keys:
+        np.testing.assert_allclose(float(r["loss_dict"][k[len("loss_"):]]), float(fix[k]), atol=5e-5, rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(float(r["retrieval_loss"]), float(fix["retrieval_loss"]), atol=5e-5)
+    np.testing.assert_allclose(float(r["localization_loss"]), float(fix["localization_loss"]), atol=2e-4, rtol=1e-5)
+    for b, (i, j) in enumerate(r["matcher_indices"]):            # bit-exact
+        assert i.tolist() == fix["matcher_pred_idx"][b].tolist()
+        assert j.tolist() == fix["matcher_tgt_idx"][b].tolist()
+
+
+def test_matcher_known_answer_and_random_cases(golden_dir):
+    fix = _load(golden_dir, "matcher")
+    # the reference's own example: music_detr/test_matcher.py:15-29, answer in its comment at :28
+    for fg in (0, 1):
+        (i, j), = O.hungarian_match(torch.from_numpy(fix["kat_logits"]), torch.from_numpy(fix["kat_spans"]),
+                                    torch.from_numpy(fix["kat_targets"]), fg)
+        assert i.tolist() == [0, 2] and j.tolist() == [1, 0]
+    for n in range(int(fix["n_cases"])):
+        res = O.hungarian_match(torch.from_numpy(fix[f"c{n}_logits"]), torch.from_numpy(fix[f"c{n}_spans"]),
+                                torch.from_numpy(fix[f"c{n}_targets"]), int(fix[f"c{n}_fg"]))
+        for b, (i, j) in enumerate(res):
+            assert i.tolist() == fix[f"c{n}_pred_idx"][b][:len(i)].tolist(), n
+            assert j.tolist() == fix[f"c{n}_tgt_idx"][b][:len(j)].tolist(), n
+            assert (fix[f"c{n}_pred_idx"][b][len(i):] == -1).all()
+
+
+def test_span_doctests(golden_dir):
+    # music_detr/span_utils.py:48-54 and :99-103
+    fix = _load(golden_dir, "matcher")
+    s1, s2 = torch.from_numpy(fix["doc_spans1"]), torch.from_numpy(fix["doc_spans2"])
+    iou, union = O.temporal_iou(s1, s2)
+    assert np.array_equal(iou.numpy(), fix["doc_iou"]) and np.array_equal(union.numpy(), fix["doc_union"])
+    assert np.array_equal(O.generalized_temporal_iou(s1, s2).numpy(), fix["doc_giou"])
+    np.testing.assert_allclose(fix["doc_giou"], [[0.6667, 0.2], [-0.2, 0.5]], atol=1e-4)
+
+
+def test_lsap_matches_scipy_and_raises():
+    scipy_opt = pytest.importorskip("scipy.optimize")
+    rng = np.random.default_rng(3)
+    for t in range(300):
+        nr, nc = int(rng.integers(1, 10)), int(rng.integers(1, 10))
+        c = rng.integers(0, 4, (nr, nc)).astype(np.float64) if t % 2 else rng.standard_normal((nr, nc))
+        a, b = scipy_opt.linear_sum_assignment(c)
+        oa, ob = O.lsap(c)
+        assert a.tolist() == oa.tolist() and b.tolist() == ob.tolist()
+    for bad in (np.array([[np.nan, 1.0]]), np.array([[np.inf, np.inf]]), np.array([[-np.inf, 0.0]])):
+        with pytest.raises(ValueError):
+            O.lsap(bad)
+    a, b = O.lsap(np.zeros((0, 3)))
+    assert len(a) == 0 and len(b) == 0
+
+
+def test_retrieval_matches_reference_golden(golden_dir):
+    fix = _load(golden_dir, "retrieval")
+    cfg = cfg_native()
+    P = O.to_torch_params(synth.make_state_dict(cfg, seed=0))
+    for tag in ("a", "b"):
+        N_v, N_m, S, D = [int(x) for x in fix[f"{tag}_shape"]]
+        ri = synth.make_retrieval_inputs(N_v, N_m, S, D, seed=2)
+        with torch.no_grad():
+            sim = O.retrieval_sim_matrix(P, cfg, ri["video_embeds"], ri["segment_embeds"], ri["segment_masks"],
+                                         ri["music_embeds"], chunk_v=29)
+        np.testing.assert_allclose(sim.numpy(), fix[f"{tag}_sim"], atol=TOL, rtol=0)
+
+
+def test_state_dict_layout_counts():
+    # SURVEY 5.4 [probe]: 199 tensors / 10.68 M elements at the native config (incl. two PE buffers)
+    sd = synth.make_state_dict(cfg_native(), seed=0)
+    assert len(sd) == 199
+    n = sum(int(np.prod(v.shape)) for v in sd.values())
+    assert abs(n - 10.68e6) < 0.02e6
