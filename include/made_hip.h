@@ -1,0 +1,210 @@
+/*
+ * made_hip.h -- C ABI of libmade_hip.so: the MI355X (gfx950) kernels behind the MaDe hot path.
+ *
+ * The reference (xxayt/MGSV) has NO native/FFI layer: every op on its hot path is a stock ATen
+ * call made from Python (SURVEY.md section 2 "Native components: none").  The drop-in boundary is
+ * therefore the Python class `Uni_model` (reference model/model_Uni.py:15,177) and this C ABI is
+ * the contract the build defines underneath it ("C-ABI level").  Each entry
+ * point cites the reference call sites whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every argument is POD: device pointers, int64 sizes/strides (in ELEMENTS), dtype enums;
+ *   - the caller allocates all outputs and workspaces; the library owns no memory;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns without
+ *     synchronising; return value 0 = OK, < 0 = error (text via made_last_error(), thread-local);
+ *   - nothing throws across the boundary; calls are re-entrant on distinct streams;
+ *   - masks are float32 with 1 = valid, 0 = padding, exactly as the reference's dataset emits them
+ *     (reference dataloaders/dataloader_MGSV_EC_feature.py:61,67).
+ */
+#ifndef MADE_HIP_H
+#define MADE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MADE_ABI_VERSION 1
+
+enum MadeDtype { MADE_F32 = 0, MADE_BF16 = 1 };
+
+enum MadeAct {
+    MADE_ACT_NONE = 0,
+    MADE_ACT_RELU = 1,       /* DETR FFN / MLP heads: reference music_detr/transformer.py:205,302,358 */
+    MADE_ACT_GELU = 2,       /* erf GELU, temporal block FFN: reference model/model_Base.py:72 */
+    MADE_ACT_QUICKGELU = 3,  /* x*sigmoid(1.702x): reference model/model_Base.py:17-20 */
+    MADE_ACT_SIGMOID = 4     /* span head: reference model/model_Uni.py:135 */
+};
+
+enum MadeStatus {
+    MADE_OK = 0,
+    MADE_ERR_INVALID_ARG = -1,
+    MADE_ERR_UNSUPPORTED = -2,
+    MADE_ERR_HIP = -3
+};
+
+int         made_abi_version(void);
+const char* made_last_error(void);
+/* fills name (<= name_len chars), compute-unit count and 1 if the device is gfx950 */
+int         made_device_info(char* name, int name_len, int* cu_count, int* is_gfx950);
+
+/* ------------------------------------------------------------------------------------------
+ * made_linear: out = act(A' W^T + bias) (+ R), the fused Linear of the path.
+ * Replaces: nn.Linear at reference model/model_Base.py:559,598 (vit_proj/ast_proj, with the
+ * masked_fill of :556,:595 as `a_row_mask` and the PE add of :533 as `R` with r_row_mod=T),
+ * :75-80,:81 (temporal FFN / final_linear, masked_fill :541 as `out_row_mask`), the packed in-proj
+ * and out-proj of every nn.MultiheadAttention (reference music_detr/transformer.py:153,229,230;
+ * model/model_Base.py:69) with the `with_pos_embed` adds of :193,:284,:293-294 as `A2`, FFN
+ * linears :205,:302, heads at reference model/model_Uni.py:131-146 and the X-Pool projections
+ * reference modules/transformer.py:96-103,122,176.
+ *
+ *   A' = (A + A2[row % a2_row_mod]) for column segments flagged use_a2, else A; rows of A whose
+ *   a_row_mask is 0 are read as zero.  W is [N,K] row-major (nn.Linear layout), K contiguous.
+ *   Compute type = w_dtype: MADE_BF16 -> v_mfma_f32_32x32x16_bf16, MADE_F32 -> v_mfma_f32_32x32x2_f32
+ *   (exact f32 FMA chain); accumulation is always f32.
+ *   The N columns are split into up to 4 segments, each with its own output tensor; a segment may
+ *   be written transposed per batch (out[b][n][t], t = row % rows_per_batch) which is the layout
+ *   made_attention wants for V.  `batch` > 1 runs independent problems (grid.z) with the given
+ *   element strides (used for the per-track QK^T / PV products of the X-Pool block).
+ */
+typedef struct MadeLinearSeg {
+    int64_t col_begin;         /* first column of this segment (multiple of 128 unless nseg == 1) */
+    void*   out;
+    int32_t out_dtype;         /* MadeDtype */
+    int32_t transposed;        /* 0: out[row*ldo + col]; 1: out[(row/rpb)*obs + col*ldo + row%rpb] */
+    int64_t ldo;
+    int64_t rows_per_batch;    /* rpb; 0 = plain rows */
+    int64_t out_batch_stride;  /* obs (elements), used when rows_per_batch > 0 */
+    int64_t out_z_stride;      /* per-problem stride when batch > 1 */
+    int32_t use_a2;
+    int32_t _pad;
+} MadeLinearSeg;
+
+typedef struct MadeLinearArgs {
+    const void*  A;  int32_t a_dtype; int32_t w_dtype;
+    int64_t      lda;
+    const void*  A2; int64_t lda2; int64_t a2_row_mod;      /* A2 has a_dtype; may be NULL */
+    const float* a_row_mask;                                /* [M] or NULL */
+    const void*  W;  int64_t ldw;
+    const float* bias;                                      /* [N] f32 or NULL */
+    int64_t      M, N, K;
+    int64_t      batch, a_z_stride, w_z_stride;             /* batch >= 1 */
+    int32_t      act; int32_t r_dtype;
+    const void*  R;  int64_t ldr; int64_t r_row_mod;        /* added after act; may be NULL */
+    const float* out_row_mask;                              /* [M] or NULL: masked rows -> 0 */
+    int32_t      nseg; int32_t _pad;
+    MadeLinearSeg seg[4];
+} MadeLinearArgs;
+
+int made_linear(const MadeLinearArgs* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * made_attention: fused multi-head attention core, softmax(Q K^T * scale + key mask) V, flash
+ * style (scores never touch HBM).  Replaces the inner part of nn.MultiheadAttention at reference
+ * model/model_Base.py:87 and music_detr/transformer.py:199,287,293-296
+ * and the CrossAttention core at reference model/model_Base.py:144-163.
+ *   Q  [B, Lq, H*hd]  element (b,i,h,d) at Q + b*q_bs + i*ldq + h*hd + d
+ *   K  [B, Lk, H*hd]  likewise with k_bs/ldk
+ *   Vt [B, H*hd, ldvt] TRANSPOSED values: element (b,j,h,d) at Vt + b*vt_bs + (h*hd+d)*ldvt + j;
+ *      ldvt >= round_up(Lk,64) and columns >= Lk must hold finite values (zeros)
+ *   key_mask [B, Lk] f32, 0 = padded key (-inf before the softmax), may be NULL
+ *   q_mask   [B, Lq] f32, 0 = output row forced to 0 AFTER the softmax (reference
+ *            model/model_Base.py:163), may be NULL
+ *   O  [B, Lq, H*hd] (dtype = compute dtype), element stride ldo / o_bs
+ * hd in {32, 64, 128}.  A query whose keys are all masked yields NaN like the reference.
+ */
+typedef struct MadeAttnArgs {
+    const void* Q; const void* K; const void* Vt; void* O;
+    int32_t dtype; int32_t hd;
+    int64_t B, H, Lq, Lk;
+    int64_t q_bs, ldq, k_bs, ldk, vt_bs, ldvt, o_bs, ldo;
+    const float* key_mask; const float* q_mask;
+    float scale; int32_t _pad;
+} MadeAttnArgs;
+
+int made_attention(const MadeAttnArgs* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row kernels (HBM-bound).                                                                   */
+
+/* y = LayerNorm(x) * gamma + beta, eps inside the sqrt; one wave per row, D <= 2048, D % 4 == 0.
+ * Replaces nn.LayerNorm at reference model/model_Base.py:83,85; music_detr/transformer.py:202,
+ * 209,290,300,306,136; modules/transformer.py:164-165,174,178. */
+int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                   void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+
+/* out[b, :] = sum_t x[b,t,:] * (mask[b,t] != 0) / sum_t mask[b,t]   (mask NULL: plain column sum,
+ * no division).  Replaces reference model/model_Base.py:579,615 and the sum over frames inside
+ * reference music_detr/loss_detr.py:116-117. */
+int made_masked_mean(const void* x, int32_t x_dtype, int64_t x_bs, int64_t ldx, const float* mask,
+                     float* out, int64_t B, int64_t T, int64_t D, void* stream);
+
+/* y = x / max(||x||_2, eps) per row (F.normalize): reference model/model_Base.py:580,616,
+ * model/model_Uni.py:142,146.  y_f32 and/or y_alt (dtype y_alt_dtype) may be NULL. */
+int made_l2norm_rows(const void* x, int32_t x_dtype, int64_t ldx, float* y_f32, void* y_alt, int32_t y_alt_dtype,
+                     int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+
+/* Mask-aware normalised sine position embedding: reference music_detr/position_encoding.py:51-71.
+ * mask [B,L] f32; dim_t [D] f32 (= 10000^(2*floor(i/2)/D), computed once by the host exactly as the
+ * reference does); out [B,L,D] in out_dtype. */
+int made_sine_pe(const float* mask, const float* dim_t, void* out, int32_t out_dtype,
+                 int64_t B, int64_t L, int64_t D, void* stream);
+
+/* In-place-capable masked softmax over the last axis of logits [M_outer, R, S] (f32, row stride
+ * lds_): p = softmax(logits*scale + (mask[m, s]==0 ? -inf : 0)); columns in [S, S_pad) are written
+ * as 0.  Output dtype out_dtype, row stride ldp.  The softmax over segments ("clips") of the
+ * X-Pool block: reference modules/transformer.py:110-117. */
+int made_masked_softmax(const float* logits, int64_t ld_logits, const float* mask, int64_t ld_mask,
+                        void* probs, int32_t out_dtype, int64_t ldp,
+                        int64_t M_outer, int64_t R, int64_t S, int64_t S_pad, float scale, void* stream);
+
+/* X-Pool tail: y [Nm*Nv, D] (the pre-LayerNorm3 sum, reference modules/transformer.py:177) ->
+ * LayerNorm3 -> (optional) pooled[m,n,:] -> cosine with video n -> sims[n*ld_sims + m].
+ * Fuses reference modules/transformer.py:178 with modules/metrics.py:19-24 so the pooled tensor
+ * need not be materialised.  video [Nv,D] f32. */
+int made_xpool_tail(const void* y, int32_t y_dtype, int64_t ldy, const float* gamma, const float* beta,
+                    const float* video, int64_t ld_video, float* pooled_out /* [Nm*Nv,D] or NULL */,
+                    float* sims, int64_t ld_sims, int64_t Nm, int64_t Nv, int64_t D, float eps, void* stream);
+
+/* Symmetric cross-entropy of reference modules/loss.py:5-24 (== InfoNCELoss with audio_id=None,
+ * :116-122): loss_out[0] (+)= weight * 0.5*(CE_rows + CE_cols) of sims*exp(*logit_scale).
+ * accumulate != 0 adds to loss_out[0] instead of overwriting.  n <= 4096. */
+int made_clip_loss(const float* sims, int64_t ld, int64_t n, const float* logit_scale, float weight,
+                   int32_t accumulate, float* loss_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hungarian matcher and set criterion (reference music_detr/matcher.py:36-92, loss_detr.py).   */
+
+/* Cost + assignment for NS = n_layers*B independent samples (sample s uses targets[s % B]).
+ *   pred_logits [NS,Q,2] f32, pred_spans [NS,Q,2] f32 (centre,width), targets [B,G,2] f32;
+ *   targets with width == 0 are dropped (reference matcher.py:59-61) and tgt indices refer to the
+ *   kept targets in order.  cost = w_span*L1 + w_giou*(-GIoU) + w_class*(-softmax(logits)[fg]) in
+ *   f32, evaluated left to right without FMA contraction (reference matcher.py:88); the assignment
+ *   is SciPy's rectangular LSAP on the f64-promoted block (reference matcher.py:91), same tie-break.
+ *   cost_ws [NS,Q,G] f32 workspace (holds the per-sample cost blocks on return).
+ *   out_pred_idx/out_tgt_idx [NS, min(Q,G)] int64, rows ascending in pred index, unused = -1;
+ *   out_count [NS] int32; status [1] int32: 0, or 1 if any cost was NaN/-inf or infeasible
+ *   (SciPy raises ValueError there).  Q, G <= 64. */
+int made_hungarian_match(const float* pred_logits, const float* pred_spans, const float* targets,
+                         int64_t NS, int64_t B, int64_t Q, int64_t G, int32_t fg_label,
+                         float w_span, float w_giou, float w_class,
+                         float* cost_ws, int64_t* out_pred_idx, int64_t* out_tgt_idx,
+                         int32_t* out_count, int32_t* status, void* stream);
+
+/* Set criterion for `n_layers` decoder layers at once (reference music_detr/loss_detr.py:74-169):
+ *   losses [n_layers, 5] f32 = {loss_span, loss_giou, loss_label, class_error, loss_contrastive_align}
+ *   per layer, and *total = sum_l sum_k weights[k]*losses[l,k] (class_error has weight 0).
+ *   proj_queries [n_layers,B,Q,Dc] f32 and vid_sum [B,Dc] f32 (= sum over frames of proj_vid_mem)
+ *   may be NULL (no contrastive term).  empty_weight [2] f32. */
+int made_set_criterion(const float* pred_logits, const float* pred_spans, const float* targets,
+                       const int64_t* pred_idx, const int64_t* tgt_idx, const int32_t* count,
+                       const float* proj_queries, const float* vid_sum, const float* empty_weight,
+                       int64_t n_layers, int64_t B, int64_t Q, int64_t G, int64_t Dc, int32_t fg_label,
+                       float temperature, const float* weights /* [5] */,
+                       float* losses, float* total, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADE_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of libmade_hip.so (include/made_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, `lib()` raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C mgsv_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmade_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+
+
+class MadeLinearSeg(C.Structure):
+    _fields_ = [("col_begin", i64), ("out", vp), ("out_dtype", i32), ("transposed", i32), ("ldo", i64),
+                ("rows_per_batch", i64), ("out_batch_stride", i64), ("out_z_stride", i64),
+                ("use_a2", i32), ("_pad", i32)]
+
+
+class MadeLinearArgs(C.Structure):
+    _fields_ = [("A", vp), ("a_dtype", i32), ("w_dtype", i32), ("lda", i64),
+                ("A2", vp), ("lda2", i64), ("a2_row_mod", i64),
+                ("a_row_mask", vp),
+                ("W", vp), ("ldw", i64),
+                ("bias", vp),
+                ("M", i64), ("N", i64), ("K", i64),
+                ("batch", i64), ("a_z_stride", i64), ("w_z_stride", i64),
+                ("act", i32), ("r_dtype", i32),
+                ("R", vp), ("ldr", i64), ("r_row_mod", i64),
+                ("out_row_mask", vp),
+                ("nseg", i32), ("_pad", i32),
+                ("seg", MadeLinearSeg * 4)]
+
+
+class MadeAttnArgs(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("Vt", vp), ("O", vp),
+                ("dtype", i32), ("hd", i32),
+                ("B", i64), ("H", i64), ("Lq", i64), ("Lk", i64),
+                ("q_bs", i64), ("ldq", i64), ("k_bs", i64), ("ldk", i64),
+                ("vt_bs", i64), ("ldvt", i64), ("o_bs", i64), ("ldo", i64),
+                ("key_mask", vp), ("q_mask", vp),
+                ("scale", f32), ("_pad", i32)]
+
+
+# name -> (restype, argtypes); every symbol include/made_hip.h declares
+SIGNATURES = {
+    "made_abi_version": (C.c_int, []),
+    "made_last_error": (C.c_char_p, []),
+    "made_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "made_linear": (C.c_int, [C.POINTER(MadeLinearArgs), vp]),
+    "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
+    "made_layernorm": (C.c_int, [vp, i32, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp]),
+    "made_masked_mean": (C.c_int, [vp, i32, i64, i64, vp, vp, i64, i64, i64, vp]),
+    "made_l2norm_rows": (C.c_int, [vp, i32, i64, vp, vp, i32, i64, i64, i64, f32, vp]),
+    "made_sine_pe": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, vp]),
+    "made_masked_softmax": (C.c_int, [vp, i64, vp, i64, vp, i32, i64, i64, i64, i64, i64, f32, vp]),
+    "made_xpool_tail": (C.c_int, [vp, i32, i64, vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, f32, vp]),
+    "made_clip_loss": (C.c_int, [vp, i64, i64, vp, f32, i32, vp, vp]),
+    "made_hungarian_match": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp]),
+    "made_set_criterion": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class MadeError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libmade_hip.so (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise MadeError(f"{LIB_PATH} not found: build the HIP library first (make -C mgsv_amd/csrc); "
+                            "the MaDe hot path has no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if l.made_abi_version() != 1:
+            raise MadeError(f"ABI version mismatch: library {l.made_abi_version()} != binding 1")
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().made_last_error().decode("utf-8", "replace")
+        raise MadeError(f"{what or 'libmade_hip'} failed (status {status}): {msg}")
+
+
+def device_info():
+    l = lib()
+    name = C.create_string_buffer(64)
+    cu, is950 = C.c_int(0), C.c_int(0)
+    check(l.made_device_info(name, 64, C.byref(cu), C.byref(is950)), "made_device_info")
+    return name.value.decode(), cu.value, bool(is950.value)

@@ -1,0 +1,265 @@
+// made_attention: fused multi-head attention core (flash style) on MFMA, gfx950.
+//
+// One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.  Keys are
+// consumed in tiles of 64.  The score product is computed SWAPPED, S^T = K Q^T, so that in the
+// 32x32 accumulator layout the query sits on the lane and the keys of a tile sit in the lane's
+// registers: the softmax row reductions are in-lane plus one cross-half exchange, the running
+// (max, sum) are per-lane scalars, and P^T is already the B operand of the second product
+// O^T += V^T P^T (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's
+// operand").  V arrives TRANSPOSED ([d][key], written that way by made_linear) so its A-operand
+// fragments are plain row reads.  K and V^T tiles are staged global -> registers -> LDS with the
+// next tile's loads in flight during the current tile's MFMAs; scores never touch HBM.
+//   bf16 : v_mfma_f32_32x32x16_bf16,  f32 : v_mfma_f32_32x32x2_f32 (exact f32, used for parity)
+#include "common.h"
+
+namespace {
+
+constexpr int BQ = 128;       // queries per workgroup
+constexpr int BKEY = 64;      // keys per tile
+constexpr int NTHREADS = 256;
+
+template <typename TC> struct Frag;
+template <> struct Frag<float>  { typedef f32x4  type; };
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+
+template <typename TC, int HD>
+__global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs a) {
+    typedef typename Frag<TC>::type frag_t;
+    constexpr int SZ = (int)sizeof(TC);
+    constexpr int PER16 = 16 / SZ;
+    constexpr int K_ROW = HD * SZ + 16;          // bytes, padded (conflict-free 16-byte row reads)
+    constexpr int VT_ROW = BKEY * SZ + 16;       // bytes, padded
+    constexpr int K_CPR = HD * SZ / 16;          // 16-byte chunks per K row
+    constexpr int V_CPR = BKEY * SZ / 16;        // 16-byte chunks per V^T row
+    constexpr int NCH = BKEY * K_CPR / NTHREADS; // chunks per thread (same count for K and V^T)
+    static_assert(BKEY * K_CPR % NTHREADS == 0 && HD * V_CPR == BKEY * K_CPR, "staging split");
+    constexpr int NQF = HD * SZ / 32;            // Q fragments (k-steps of the score product)
+    constexpr int NDT = HD / 32;                 // 32-row tiles of O^T
+    constexpr bool IS_BF16 = SZ == 2;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BKEY * K_ROW + HD * VT_ROW + BKEY * 4];
+    unsigned char* lds_k = lds;
+    unsigned char* lds_v = lds + BKEY * K_ROW;
+    float* lds_bias = (float*)(lds + BKEY * K_ROW + HD * VT_ROW);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t q0 = (int64_t)blockIdx.x * BQ + wave * 32;
+    const bool wave_active = q0 < a.Lq;
+
+    const TC* Kg = (const TC*)a.K + b * a.k_bs + h * HD;
+    const TC* Vg = (const TC*)a.Vt + b * a.vt_bs + h * HD * a.ldvt;
+    const float* maskg = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[q0+r][ks*2*PER16 + hh*PER16 ..]
+    frag_t qf[NQF];
+    {
+        int64_t q = q0 + r;
+        if (q >= a.Lq) q = a.Lq - 1;
+        const TC* qp = (const TC*)a.Q + b * a.q_bs + q * a.ldq + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) qf[ks] = *(const frag_t*)(qp + ks * 2 * PER16 + hh * PER16);
+    }
+
+    // ---- staging registers
+    frag_t rk[NCH], rv[NCH];
+    float rbias = 0.f;
+    auto load_tile = [&](int64_t key0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NTHREADS;
+            int krow = c / K_CPR, kc = c % K_CPR;
+            int64_t key = key0 + krow;
+            if (key < a.Lk) {
+                rk[i] = *(const frag_t*)(Kg + key * a.ldk + kc * PER16);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PER16; ++j) rk[i][j] = (TC)0.f;
+            }
+            int vrow = c / V_CPR, vc = c % V_CPR;
+            rv[i] = *(const frag_t*)(Vg + (int64_t)vrow * a.ldvt + key0 + vc * PER16);
+        }
+        if (tid < BKEY) {
+            int64_t key = key0 + tid;
+            bool valid = key < a.Lk && (maskg == nullptr || maskg[key] != 0.f);
+            rbias = valid ? 0.f : -INFINITY;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NTHREADS;
+            *(frag_t*)(lds_k + (c / K_CPR) * K_ROW + (c % K_CPR) * 16) = rk[i];
+            *(frag_t*)(lds_v + (c / V_CPR) * VT_ROW + (c % V_CPR) * 16) = rv[i];
+        }
+        if (tid < BKEY) lds_bias[tid] = rbias;
+    };
+
+    f32x16 o[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int64_t ntiles = (a.Lk + BKEY - 1) / BKEY;
+    load_tile(0);
+    for (int64_t t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile((t + 1) * BKEY);
+        if (!wave_active) continue;
+
+        // ---- S^T tile [64 keys x 32 queries] = two 32x32 accumulators
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                frag_t kf = *(const frag_t*)(lds_k + (kt * 32 + r) * K_ROW + ks * 32 + hh * 16);
+                if constexpr (IS_BF16) {
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[ks][e], s[kt], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- online softmax (per query = per lane column; the two lane halves hold different keys)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = s[kt][e] * a.scale + lds_bias[kt * 32 + acc_row(e, hh)];
+                s[kt][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = IS_BF16 ? __expf(m_run - m_use) : expf(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float p = IS_BF16 ? __expf(s[kt][e] - m_use) : expf(s[kt][e] - m_use);
+                s[kt][e] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+
+        // ---- O^T += V^T P^T
+        if constexpr (IS_BF16) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[kt][8 * s2 + j];
+                    const int keyoff = kt * 32 + 16 * s2 + 4 * hh;
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        const unsigned char* vp = lds_v + (d * 32 + r) * VT_ROW + keyoff * 2;
+                        bf16x4 lo = *(const bf16x4*)vp;
+                        bf16x4 hi = *(const bf16x4*)(vp + 16);
+                        bf16x8 vf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int keyoff = kt * 32 + 8 * g + 4 * hh;
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        f32x4 vf = *(const f32x4*)(lds_v + (d * 32 + r) * VT_ROW + keyoff * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[kt][4 * g + e], o[d], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float inv = 1.f / l_tot;
+    const int64_t q = q0 + r;
+    if (q >= a.Lq) return;
+    bool zero_row = a.q_mask != nullptr && a.q_mask[b * a.Lq + q] == 0.f;
+    TC* op = (TC*)a.O + b * a.o_bs + q * a.ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v0 = o[d][4 * g + 0] * inv, v1 = o[d][4 * g + 1] * inv;
+            float v2 = o[d][4 * g + 2] * inv, v3 = o[d][4 * g + 3] * inv;
+            if (zero_row) { v0 = v1 = v2 = v3 = 0.f; }
+            TC* dst = op + d * 32 + 8 * g + 4 * hh;
+            if constexpr (IS_BF16) {
+                bf16x4 pk;
+                pk[0] = (bf16_t)v0; pk[1] = (bf16_t)v1; pk[2] = (bf16_t)v2; pk[3] = (bf16_t)v3;
+                *(bf16x4*)dst = pk;
+            } else {
+                f32x4 pk;
+                pk[0] = v0; pk[1] = v1; pk[2] = v2; pk[3] = v3;
+                *(f32x4*)dst = pk;
+            }
+        }
+}
+
+template <typename TC>
+int launch_attention(const MadeAttnArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)((a.Lq + BQ - 1) / BQ), (unsigned)a.H, (unsigned)a.B), block(NTHREADS);
+    switch (a.hd) {
+        case 32: hipLaunchKernelGGL((attention_kernel<TC, 32>), grid, block, 0, st, a); break;
+        case 64: hipLaunchKernelGGL((attention_kernel<TC, 64>), grid, block, 0, st, a); break;
+        case 128: hipLaunchKernelGGL((attention_kernel<TC, 128>), grid, block, 0, st, a); break;
+        default:
+            made_set_error("made_attention: head dim %d not in {32,64,128}", a.hd);
+            return MADE_ERR_UNSUPPORTED;
+    }
+    return made_check_launch("made_attention");
+}
+
+}  // namespace
+
+extern "C" int made_attention(const MadeAttnArgs* args, void* stream) {
+    MADE_REQUIRE(args != nullptr, "made_attention: null args");
+    const MadeAttnArgs& a = *args;
+    MADE_REQUIRE(a.Q && a.K && a.Vt && a.O, "made_attention: null tensor");
+    MADE_REQUIRE(a.B >= 0 && a.H > 0 && a.Lq >= 0 && a.Lk > 0, "made_attention: bad dims");
+    MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention: bad dtype %d", a.dtype);
+    MADE_UNSUPPORTED(a.B <= 65535 && a.H <= 65535, "made_attention: B/H too large for the grid");
+    const int per16 = a.dtype == MADE_F32 ? 4 : 8;
+    MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldvt % per16 == 0 && a.ldo % 4 == 0 &&
+                     a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.vt_bs % per16 == 0 && a.o_bs % 4 == 0,
+                     "made_attention: strides must keep 16-byte alignment");
+    MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.Vt % 16) == 0 && ((uintptr_t)a.O % 16) == 0,
+                     "made_attention: base pointers must be 16-byte aligned");
+    MADE_REQUIRE(a.ldvt >= ((a.Lk + BKEY - 1) / BKEY) * BKEY, "made_attention: ldvt=%lld must be >= round_up(Lk=%lld, 64)",
+                 (long long)a.ldvt, (long long)a.Lk);
+    if (a.B == 0 || a.Lq == 0) return MADE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return a.dtype == MADE_BF16 ? launch_attention<bf16_t>(a, st) : launch_attention<float>(a, st);
+}

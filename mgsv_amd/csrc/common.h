@@ -1,0 +1,84 @@
+// Shared device/host helpers for libmade_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/made_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WAVE 64
+
+// ---- error plumbing (host) -----------------------------------------------------------------
+void made_set_error(const char* fmt, ...);
+
+#define MADE_REQUIRE(cond, ...)                                                   \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            made_set_error(__VA_ARGS__);                                          \
+            return MADE_ERR_INVALID_ARG;                                          \
+        }                                                                         \
+    } while (0)
+
+#define MADE_UNSUPPORTED(cond, ...)                                               \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            made_set_error(__VA_ARGS__);                                          \
+            return MADE_ERR_UNSUPPORTED;                                          \
+        }                                                                         \
+    } while (0)
+
+static inline int made_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        made_set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+        return MADE_ERR_HIP;
+    }
+    return MADE_OK;
+}
+
+// ---- device helpers ------------------------------------------------------------------------
+// Row index inside a 32x32 MFMA accumulator tile held by (reg r in [0,16), lane half hh):
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * hh   (cdna_hip_programming.md section 3).
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+template <typename T> struct elem_traits;
+template <> struct elem_traits<float> {
+    static constexpr int per16 = 4;      // elements per 16-byte fragment
+};
+template <> struct elem_traits<bf16_t> {
+    static constexpr int per16 = 8;
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// load one element of runtime dtype as f32 / store f32 as runtime dtype
+__device__ __forceinline__ float load_as_f32(const void* p, int dtype, int64_t idx) {
+    return dtype == MADE_F32 ? ((const float*)p)[idx] : (float)((const bf16_t*)p)[idx];
+}
+__device__ __forceinline__ void store_from_f32(void* p, int dtype, int64_t idx, float v) {
+    if (dtype == MADE_F32) ((float*)p)[idx] = v;
+    else ((bf16_t*)p)[idx] = (bf16_t)v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,288 @@
+// Hungarian matcher (cost + rectangular LSAP) and the DETR set criterion, on device.
+//
+// The reference moves the cost matrix to the host and calls SciPy once per sample and decoder layer
+// (music_detr/matcher.py:89-91: 6 D2H syncs per forward).  Here one launch handles all
+// n_layers*B samples: a wave computes the sample's cost block in f32 with the reference's operation
+// order (explicit *_rn intrinsics, so hipcc cannot contract mul+add into FMA and change the bits),
+// then lane 0 runs the shortest-augmenting-path LSAP (Crouse 2016, as SciPy implements it, same
+// tie-break) on the f64-promoted block.  Q, G <= 64, so all solver state lives in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXN = 64;
+
+__device__ __forceinline__ float giou_se(float s1, float e1, float s2, float e2) {
+    // reference music_detr/span_utils.py:39-66, :86-115 (f32, left to right)
+    float a1 = __fsub_rn(e1, s1), a2 = __fsub_rn(e2, s2);
+    float inter = fmaxf(__fsub_rn(fminf(e1, e2), fmaxf(s1, s2)), 0.f);
+    float uni = __fsub_rn(__fadd_rn(a1, a2), inter);
+    float iou = __fdiv_rn(inter, uni);
+    float enc = fmaxf(__fsub_rn(fmaxf(e1, e2), fminf(s1, s2)), 0.f);
+    return __fsub_rn(iou, __fdiv_rn(__fsub_rn(enc, uni), enc));
+}
+
+__device__ __forceinline__ void cw_to_se(float c, float w, float& s, float& e) {
+    float hw = __fmul_rn(0.5f, w);                     // reference span_utils.py:22-23
+    s = __fsub_rn(c, hw);
+    e = __fadd_rn(c, hw);
+}
+
+__global__ __launch_bounds__(64) void hungarian_kernel(const float* logits, const float* spans, const float* targets,
+                                                       int B, int Q, int G, int fg, float w_span, float w_giou, float w_class,
+                                                       float* cost_ws, int64_t* out_pred, int64_t* out_tgt, int32_t* out_count,
+                                                       int32_t* status) {
+    __shared__ int kept[MAXN];
+    __shared__ int n_kept;
+    __shared__ double u[MAXN], v[MAXN], spc[MAXN];
+    __shared__ int path[MAXN], col4row[MAXN], row4col[MAXN], remaining[MAXN];
+    __shared__ unsigned char SR[MAXN], SC[MAXN];
+    __shared__ int bad;
+
+    const int s = blockIdx.x, b = s % B, lane = threadIdx.x;
+    const float* tg = targets + (int64_t)b * G * 2;
+    if (lane == 0) {
+        int k = 0;
+        for (int g = 0; g < G; ++g)
+            if (tg[2 * g + 1] != 0.f) kept[k++] = g;      // reference matcher.py:59-61
+        n_kept = k;
+        bad = 0;
+    }
+    __syncthreads();
+    const int Gk = n_kept;
+    float* C = cost_ws + (int64_t)s * Q * G;
+    const float* lg = logits + (int64_t)s * Q * 2;
+    const float* sp = spans + (int64_t)s * Q * 2;
+    for (int idx = lane; idx < Q * Gk; idx += 64) {
+        int q = idx / Gk, j = idx % Gk, g = kept[j];
+        float l0 = lg[2 * q], l1 = lg[2 * q + 1];
+        float mx = fmaxf(l0, l1);
+        float e0 = expf(__fsub_rn(l0, mx)), e1 = expf(__fsub_rn(l1, mx));
+        float p = __fdiv_rn(fg == 0 ? e0 : e1, __fadd_rn(e0, e1));
+        float pc = sp[2 * q], pw = sp[2 * q + 1], tc = tg[2 * g], tw = tg[2 * g + 1];
+        float cost_span = __fadd_rn(fabsf(__fsub_rn(pc, tc)), fabsf(__fsub_rn(pw, tw)));
+        float ps, pe, ts, te;
+        cw_to_se(pc, pw, ps, pe);
+        cw_to_se(tc, tw, ts, te);
+        float cost_giou = -giou_se(ps, pe, ts, te);
+        float cost_class = -p;
+        float c = __fadd_rn(__fadd_rn(__fmul_rn(w_span, cost_span), __fmul_rn(w_giou, cost_giou)), __fmul_rn(w_class, cost_class));
+        C[q * G + j] = c;
+        if (c != c || c == -INFINITY) bad = 1;
+    }
+    __syncthreads();
+
+    const int cnt = Q < Gk ? Q : Gk;
+    const int width = Q < G ? Q : G;
+    int64_t* op = out_pred + (int64_t)s * width;
+    int64_t* ot = out_tgt + (int64_t)s * width;
+    for (int i = lane; i < width; i += 64) { op[i] = -1; ot[i] = -1; }
+    __syncthreads();
+    if (lane != 0) return;
+    out_count[s] = cnt;
+    if (cnt == 0) return;
+    if (bad) { atomicExch(status, 1); out_count[s] = 0; return; }
+
+    const bool tr = Gk < Q;                               // SciPy transposes when nc < nr
+    const int nr = tr ? Gk : Q, nc = tr ? Q : Gk;
+    auto cost = [&](int i, int j) -> double { return (double)(tr ? C[j * G + i] : C[i * G + j]); };
+    for (int i = 0; i < nr; ++i) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = 0; j < nc; ++j) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
+    const double INF = 1.0 / 0.0;
+    for (int cur = 0; cur < nr; ++cur) {
+        double min_val = 0.0;
+        int i = cur, num_remaining = nc, sink = -1;
+        for (int it = 0; it < nc; ++it) { remaining[it] = nc - it - 1; spc[it] = INF; SC[it] = 0; }
+        for (int it = 0; it < nr; ++it) SR[it] = 0;
+        while (sink == -1) {
+            int index = -1;
+            double lowest = INF;
+            SR[i] = 1;
+            for (int it = 0; it < num_remaining; ++it) {
+                int j = remaining[it];
+                double rr = min_val + cost(i, j) - u[i] - v[j];
+                if (rr < spc[j]) { path[j] = i; spc[j] = rr; }
+                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+            }
+            min_val = lowest;
+            if (min_val == INF) { atomicExch(status, 1); out_count[s] = 0; return; }   // infeasible
+            int j = remaining[index];
+            if (row4col[j] == -1) sink = j; else i = row4col[j];
+            SC[j] = 1;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += min_val;
+        for (int i2 = 0; i2 < nr; ++i2)
+            if (SR[i2] && i2 != cur) u[i2] += min_val - spc[col4row[i2]];
+        for (int j2 = 0; j2 < nc; ++j2)
+            if (SC[j2]) v[j2] -= min_val - spc[j2];
+        int j = sink;
+        while (true) {
+            int i2 = path[j];
+            row4col[j] = i2;
+            int tmp = col4row[i2]; col4row[i2] = j; j = tmp;
+            if (i2 == cur) break;
+        }
+    }
+    if (!tr) {
+        for (int i = 0; i < nr; ++i) { op[i] = i; ot[i] = col4row[i]; }
+    } else {
+        // rows of the transposed problem are targets: emit pairs sorted by prediction index
+        int done = 0, last = -1;
+        while (done < nr) {
+            int best = -1;
+            for (int t = 0; t < nr; ++t)
+                if (col4row[t] > last && (best < 0 || col4row[t] < col4row[best])) best = t;
+            op[done] = col4row[best]; ot[done] = best; last = col4row[best]; ++done;
+        }
+    }
+}
+
+// ---- set criterion ---------------------------------------------------------------------------------
+constexpr int CRIT_THREADS = 256;
+constexpr int CRIT_MAX_BQ = 4096;
+
+__device__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = (red[0] + red[1]) + (red[2] + red[3]);
+    return t;
+}
+
+__device__ __forceinline__ int kth_kept(const float* tg, int G, int k) {
+    int seen = 0;
+    for (int g = 0; g < G; ++g)
+        if (tg[2 * g + 1] != 0.f) { if (seen == k) return g; ++seen; }
+    return 0;
+}
+
+__global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(const float* logits, const float* spans, const float* targets,
+                                                                 const int64_t* pred_idx, const int64_t* tgt_idx, const int32_t* count,
+                                                                 const float* proj_q, const float* vid_sum, const float* empty_w,
+                                                                 int n_layers, int B, int Q, int G, int Dc, int fg, float temperature,
+                                                                 const float* weights, float* losses, float* total) {
+    __shared__ unsigned char matched[CRIT_MAX_BQ];
+    __shared__ float lgt[CRIT_MAX_BQ];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int width = Q < G ? Q : G;
+    const int bg = 1 - fg;
+    float total_acc = 0.f;
+    for (int l = 0; l < n_layers; ++l) {
+        const float* lg = logits + (int64_t)l * B * Q * 2;
+        const float* sp = spans + (int64_t)l * B * Q * 2;
+        for (int i = tid; i < B * Q; i += CRIT_THREADS) matched[i] = 0;
+        __syncthreads();
+        // matched pairs: one thread per (b, slot)
+        float span_sum = 0.f, giou_sum = 0.f, correct = 0.f, npairs = 0.f;
+        for (int i = tid; i < B * width; i += CRIT_THREADS) {
+            int b = i / width, slot = i % width;
+            int s = l * B + b;
+            if (slot < count[s]) {
+                int q = (int)pred_idx[(int64_t)s * width + slot];
+                int g = kth_kept(targets + (int64_t)b * G * 2, G, (int)tgt_idx[(int64_t)s * width + slot]);
+                float pc = sp[(b * Q + q) * 2], pw = sp[(b * Q + q) * 2 + 1];
+                float tc = targets[((int64_t)b * G + g) * 2], tw = targets[((int64_t)b * G + g) * 2 + 1];
+                span_sum += fabsf(pc - tc) + fabsf(pw - tw);
+                float ps, pe, ts, te;
+                cw_to_se(pc, pw, ps, pe);
+                cw_to_se(tc, tw, ts, te);
+                giou_sum += 1.f - giou_se(ps, pe, ts, te);
+                float l0 = lg[(b * Q + q) * 2], l1 = lg[(b * Q + q) * 2 + 1];
+                int top = l1 > l0 ? 1 : 0;
+                correct += (top == fg) ? 1.f : 0.f;
+                npairs += 1.f;
+                matched[b * Q + q] = 1;
+            }
+        }
+        span_sum = block_sum(span_sum, red);
+        giou_sum = block_sum(giou_sum, red);
+        correct = block_sum(correct, red);
+        npairs = block_sum(npairs, red);          // also orders the matched[] writes
+        // classification: weighted NLL, plain mean over B*Q (reference loss_detr.py:101-105)
+        float label_sum = 0.f;
+        for (int i = tid; i < B * Q; i += CRIT_THREADS) {
+            int cls = matched[i] ? fg : bg;
+            float l0 = lg[i * 2], l1 = lg[i * 2 + 1];
+            float mx = fmaxf(l0, l1);
+            float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+            label_sum += empty_w[cls] * (lse - (cls == 0 ? l0 : l1));
+        }
+        label_sum = block_sum(label_sum, red);
+        // contrastive align (reference loss_detr.py:112-128)
+        float contr = 0.f;
+        if (proj_q && vid_sum) {
+            for (int i = wave; i < B * Q; i += CRIT_THREADS / 64) {
+                int b = i / Q;
+                const float* pq = proj_q + ((int64_t)l * B * Q + i) * Dc;
+                const float* vs = vid_sum + (int64_t)b * Dc;
+                float d = 0.f;
+                for (int k = lane; k < Dc; k += 64) d += pq[k] * vs[k];
+                d = wave_sum(d);
+                if (lane == 0) lgt[i] = d / temperature;
+            }
+            __syncthreads();
+            float csum = 0.f;
+            for (int b = tid; b < B; b += CRIT_THREADS) {
+                float mx = -INFINITY, pos = 0.f, npos = 0.f;
+                for (int q = 0; q < Q; ++q) {
+                    float z = lgt[b * Q + q];
+                    mx = fmaxf(mx, z);
+                    if (matched[b * Q + q]) { pos += z; npos += 1.f; }
+                }
+                float se = 0.f;
+                for (int q = 0; q < Q; ++q) se += expf(lgt[b * Q + q] - mx);
+                csum += -pos / npos + (mx + logf(se));
+            }
+            contr = block_sum(csum, red) / (float)B;
+        }
+        if (tid == 0) {
+            float ls = span_sum / (2.f * npairs);
+            float lgi = giou_sum / npairs;
+            float ll = label_sum / (float)(B * Q);
+            float ce = 100.f - correct * (100.f / npairs);
+            float* o = losses + l * 5;
+            o[0] = ls; o[1] = lgi; o[2] = ll; o[3] = ce; o[4] = contr;
+            total_acc += weights[0] * ls + weights[1] * lgi + weights[2] * ll + weights[4] * contr;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && total) total[0] = total_acc;
+}
+
+}  // namespace
+
+extern "C" int made_hungarian_match(const float* pred_logits, const float* pred_spans, const float* targets,
+                                    int64_t NS, int64_t B, int64_t Q, int64_t G, int32_t fg_label,
+                                    float w_span, float w_giou, float w_class,
+                                    float* cost_ws, int64_t* out_pred_idx, int64_t* out_tgt_idx,
+                                    int32_t* out_count, int32_t* status, void* stream) {
+    MADE_REQUIRE(pred_logits && pred_spans && targets && cost_ws && out_pred_idx && out_tgt_idx && out_count && status,
+                 "made_hungarian_match: null pointer");
+    MADE_REQUIRE(NS >= 0 && B > 0 && NS % B == 0, "made_hungarian_match: NS=%lld must be a multiple of B=%lld", (long long)NS, (long long)B);
+    MADE_REQUIRE(fg_label == 0 || fg_label == 1, "made_hungarian_match: fg_label must be 0 or 1");
+    MADE_UNSUPPORTED(Q >= 1 && G >= 1 && Q <= MAXN && G <= MAXN, "made_hungarian_match: Q=%lld, G=%lld must be in [1,%d]",
+                     (long long)Q, (long long)G, MAXN);
+    if (NS == 0) return MADE_OK;
+    hipLaunchKernelGGL(hungarian_kernel, dim3((unsigned)NS), dim3(64), 0, (hipStream_t)stream, pred_logits, pred_spans, targets,
+                       (int)B, (int)Q, (int)G, (int)fg_label, w_span, w_giou, w_class, cost_ws, out_pred_idx, out_tgt_idx,
+                       out_count, status);
+    return made_check_launch("made_hungarian_match");
+}
+
+extern "C" int made_set_criterion(const float* pred_logits, const float* pred_spans, const float* targets,
+                                  const int64_t* pred_idx, const int64_t* tgt_idx, const int32_t* count,
+                                  const float* proj_queries, const float* vid_sum, const float* empty_weight,
+                                  int64_t n_layers, int64_t B, int64_t Q, int64_t G, int64_t Dc, int32_t fg_label,
+                                  float temperature, const float* weights, float* losses, float* total, void* stream) {
+    MADE_REQUIRE(pred_logits && pred_spans && targets && pred_idx && tgt_idx && count && empty_weight && weights && losses,
+                 "made_set_criterion: null pointer");
+    MADE_REQUIRE(n_layers >= 1 && B >= 1 && Q >= 1 && G >= 1, "made_set_criterion: bad dims");
+    MADE_UNSUPPORTED(B * Q <= CRIT_MAX_BQ, "made_set_criterion: B*Q=%lld exceeds %d", (long long)(B * Q), CRIT_MAX_BQ);
+    hipLaunchKernelGGL(criterion_kernel, dim3(1), dim3(CRIT_THREADS), 0, (hipStream_t)stream, pred_logits, pred_spans, targets,
+                       pred_idx, tgt_idx, count, proj_queries, vid_sum, empty_weight, (int)n_layers, (int)B, (int)Q, (int)G,
+                       (int)Dc, (int)fg_label, temperature, weights, losses, total);
+    return made_check_launch("made_set_criterion");
+}

@@ -1,0 +1,367 @@
+// Row kernels of the MaDe hot path (HBM-bound): LayerNorm, masked mean, L2 normalise, the
+// mask-aware sine position embedding, the masked softmax over segments, the X-Pool tail
+// (LayerNorm3 + cosine with the video), and the symmetric cross-entropy.  One wave (64 lanes)
+// per row with 16-byte loads wherever a row is contiguous; reductions by wave shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int ROW_THREADS = 256;           // 4 waves = 4 rows per workgroup
+constexpr int MAX_VEC = 8;                 // 8 x 4 elements per lane -> D <= 2048
+
+// load 4 consecutive elements of runtime dtype as f32
+__device__ __forceinline__ f32x4 load4(const void* p, int dtype, int64_t idx) {
+    f32x4 v;
+    if (dtype == MADE_F32) {
+        v = *(const f32x4*)((const float*)p + idx);
+    } else {
+        bf16x4 t = *(const bf16x4*)((const bf16_t*)p + idx);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    return v;
+}
+__device__ __forceinline__ void store4(void* p, int dtype, int64_t idx, f32x4 v) {
+    if (dtype == MADE_F32) {
+        *(f32x4*)((float*)p + idx) = v;
+    } else {
+        bf16x4 t;
+        t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+        *(bf16x4*)((bf16_t*)p + idx) = t;
+    }
+}
+
+// ---- LayerNorm -----------------------------------------------------------------------------
+// Two-pass (mean, then centred variance) in registers: the row is read from HBM once.
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_kernel(const void* x, int xdt, int64_t ldx,
+                                                                const float* gamma, const float* beta,
+                                                                void* y, int ydt, int64_t ldy,
+                                                                int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[MAX_VEC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            v[i] = load4(x, xdt, row * ldx + c);
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c), o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+            store4(y, ydt, row * ldy + c, o);
+        }
+    }
+}
+
+// ---- masked mean over the sequence axis -------------------------------------------------------
+// grid (D/64 column groups, B); 256 threads = 64 columns x 4 row phases; LDS combine.
+__global__ __launch_bounds__(ROW_THREADS) void masked_mean_kernel(const void* x, int xdt, int64_t x_bs, int64_t ldx,
+                                                                  const float* mask, float* out,
+                                                                  int64_t T, int D) {
+    __shared__ float part[4][64];
+    __shared__ float cnt[4];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int phase = threadIdx.x >> 6;
+    const int64_t b = blockIdx.y;
+    float acc = 0.f, n = 0.f;
+    for (int64_t t = phase; t < T; t += 4) {
+        float mk = mask ? mask[b * T + t] : 1.f;
+        n += mk;
+        if (mk != 0.f && col < D) acc += load_as_f32(x, xdt, b * x_bs + t * ldx + col);
+    }
+    part[phase][threadIdx.x & 63] = acc;
+    if ((threadIdx.x & 63) == 0) cnt[phase] = n;
+    __syncthreads();
+    if (phase == 0 && col < D) {
+        float s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (mask) s = s / ((cnt[0] + cnt[1]) + (cnt[2] + cnt[3]));
+        out[b * D + col] = s;
+    }
+}
+
+// ---- L2 normalise rows -------------------------------------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void l2norm_kernel(const void* x, int xdt, int64_t ldx, float* y32,
+                                                             void* yalt, int yadt, int64_t ldy,
+                                                             int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[MAX_VEC];
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            v[i] = load4(x, xdt, row * ldx + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sq += v[i][j] * v[i][j];
+        }
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(sq)), eps);
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = v[i][j] / nrm;
+            if (y32) *(f32x4*)(y32 + row * ldy + c) = o;
+            if (yalt) store4(yalt, yadt, row * ldy + c, o);
+        }
+    }
+}
+
+// ---- mask-aware sine position embedding --------------------------------------------------------
+// grid (ceil(L/PE_ROWS), B).  Every workgroup re-reduces its batch row's mask (L floats) to get the
+// running count before its rows and the total, then writes PE_ROWS x D outputs.
+constexpr int PE_ROWS = 4;
+__global__ __launch_bounds__(ROW_THREADS) void sine_pe_kernel(const float* mask, const float* dim_t, void* out, int odt,
+                                                              int L, int D) {
+    __shared__ float red_before[4], red_total[4];
+    const int64_t b = blockIdx.y;
+    const int t0 = blockIdx.x * PE_ROWS;
+    const float* mrow = mask + b * L;
+    float before = 0.f, total = 0.f;
+    for (int t = threadIdx.x; t < L; t += ROW_THREADS) {
+        float mk = mrow[t];
+        total += mk;
+        if (t < t0) before += mk;
+    }
+    before = wave_sum(before);
+    total = wave_sum(total);
+    if ((threadIdx.x & 63) == 0) { red_before[threadIdx.x >> 6] = before; red_total[threadIdx.x >> 6] = total; }
+    __syncthreads();
+    before = (red_before[0] + red_before[1]) + (red_before[2] + red_before[3]);
+    total = (red_total[0] + red_total[1]) + (red_total[2] + red_total[3]);
+    const float denom = total + 1e-6f;
+    const float two_pi = 6.283185307179586f;
+    float c = before;
+    for (int rr = 0; rr < PE_ROWS; ++rr) {
+        int t = t0 + rr;
+        if (t >= L) break;
+        c += mrow[t];                                   // inclusive cumsum (counts are exact in f32)
+        const float xe = __fmul_rn(__fdiv_rn(c, denom), two_pi);
+        for (int i = threadIdx.x; i < D; i += ROW_THREADS) {
+            float ang = __fdiv_rn(xe, dim_t[i]);
+            float v = (i & 1) ? cosf(ang) : sinf(ang);
+            store_from_f32(out, odt, (b * L + t) * (int64_t)D + i, v);
+        }
+    }
+}
+
+// ---- masked softmax over segments ---------------------------------------------------------------
+// logits [M_outer, R, S] f32; one wave per (m, r) row; S <= 64*MAXS.
+__global__ __launch_bounds__(ROW_THREADS) void masked_softmax_kernel(const float* logits, int64_t ldl, const float* mask,
+                                                                     int64_t ldm, void* probs, int pdt, int64_t ldp,
+                                                                     int64_t rows, int64_t R, int S, int S_pad, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t m = row / R;
+    const float* lp = logits + row * ldl;
+    const float* mp = mask ? mask + m * ldm : nullptr;
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += WAVE) {
+        float v = (mp && mp[s] == 0.f) ? -INFINITY : lp[s] * scale;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += WAVE) {
+        float v = (mp && mp[s] == 0.f) ? -INFINITY : lp[s] * scale;
+        sum += expf(v - mx);
+    }
+    sum = wave_sum(sum);
+    for (int s = lane; s < S_pad; s += WAVE) {
+        float p = 0.f;
+        if (s < S) {
+            float v = (mp && mp[s] == 0.f) ? -INFINITY : lp[s] * scale;
+            p = expf(v - mx) / sum;                     // all-masked row: exp(nan) -> NaN like the reference
+        }
+        store_from_f32(probs, pdt, row * ldp + s, p);
+    }
+}
+
+// ---- X-Pool tail: LayerNorm3 + cosine with the video --------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void xpool_tail_kernel(const void* y, int ydt, int64_t ldy, const float* gamma,
+                                                                 const float* beta, const float* video, int64_t ldv,
+                                                                 float* pooled, float* sims, int64_t lds_, int64_t rows,
+                                                                 int64_t Nv, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t m = row / Nv, n = row % Nv;
+    f32x4 v[MAX_VEC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            v[i] = load4(y, ydt, row * ldy + c);
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+    float pp = 0.f, vv = 0.f, pv = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c), o;
+            f32x4 vid = *(const f32x4*)(video + n * ldv + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+                pp += o[j] * o[j];
+                vv += vid[j] * vid[j];
+                pv += o[j] * vid[j];
+            }
+            if (pooled) *(f32x4*)(pooled + row * (int64_t)D + c) = o;
+        }
+    }
+    pp = wave_sum(pp); vv = wave_sum(vv); pv = wave_sum(pv);
+    if (lane == 0) sims[n * lds_ + m] = pv / (sqrtf(pp) * sqrtf(vv));
+}
+
+// ---- symmetric cross entropy ----------------------------------------------------------------------
+// One workgroup of 1024 threads; rows then columns, each wave strides over lines.
+__global__ __launch_bounds__(1024) void clip_loss_kernel(const float* sims, int64_t ld, int n, const float* logit_scale,
+                                                         float weight, int accumulate, float* loss_out) {
+    __shared__ float partial[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const float gsc = expf(logit_scale[0]);
+    float acc = 0.f;                       // sum over lines of (lse - z_ii), both directions
+    for (int dir = 0; dir < 2; ++dir) {
+        for (int i = wave; i < n; i += nwaves) {
+            float mx = -INFINITY;
+            for (int j = lane; j < n; j += WAVE) {
+                float z = (dir == 0 ? sims[(int64_t)i * ld + j] : sims[(int64_t)j * ld + i]) * gsc;
+                mx = fmaxf(mx, z);
+            }
+            mx = wave_max(mx);
+            float se = 0.f;
+            for (int j = lane; j < n; j += WAVE) {
+                float z = (dir == 0 ? sims[(int64_t)i * ld + j] : sims[(int64_t)j * ld + i]) * gsc;
+                se += expf(z - mx);
+            }
+            se = wave_sum(se);
+            if (lane == 0) acc += (mx + logf(se)) - sims[(int64_t)i * ld + i] * gsc;
+        }
+    }
+    if (lane == 0) partial[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += partial[w];
+        float loss = weight * 0.5f * (t / (float)n);
+        loss_out[0] = accumulate ? loss_out[0] + loss : loss;
+    }
+}
+
+inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
+
+}  // namespace
+
+extern "C" int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                              void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream) {
+    MADE_REQUIRE(x && y && gamma && beta, "made_layernorm: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC, "made_layernorm: D=%lld must be a multiple of 4 and <= %d",
+                     (long long)D, 64 * 4 * MAX_VEC);
+    MADE_UNSUPPORTED(ldx % 4 == 0 && ldy % 4 == 0, "made_layernorm: row strides must be multiples of 4");
+    if (rows <= 0) return MADE_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, (int)D, eps);
+    return made_check_launch("made_layernorm");
+}
+
+extern "C" int made_masked_mean(const void* x, int32_t x_dtype, int64_t x_bs, int64_t ldx, const float* mask,
+                                float* out, int64_t B, int64_t T, int64_t D, void* stream) {
+    MADE_REQUIRE(x && out, "made_masked_mean: null pointer");
+    MADE_REQUIRE(B >= 0 && T > 0 && D > 0 && B <= 65535, "made_masked_mean: bad dims");
+    if (B == 0) return MADE_OK;
+    hipLaunchKernelGGL(masked_mean_kernel, dim3((unsigned)((D + 63) / 64), (unsigned)B), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, x, x_dtype, x_bs, ldx, mask, out, T, (int)D);
+    return made_check_launch("made_masked_mean");
+}
+
+extern "C" int made_l2norm_rows(const void* x, int32_t x_dtype, int64_t ldx, float* y_f32, void* y_alt, int32_t y_alt_dtype,
+                                int64_t ldy, int64_t rows, int64_t D, float eps, void* stream) {
+    MADE_REQUIRE(x && (y_f32 || y_alt), "made_l2norm_rows: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldx % 4 == 0 && ldy % 4 == 0, "made_l2norm_rows: bad D/strides");
+    if (rows <= 0) return MADE_OK;
+    hipLaunchKernelGGL(l2norm_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       x, x_dtype, ldx, y_f32, y_alt, y_alt_dtype, ldy, rows, (int)D, eps);
+    return made_check_launch("made_l2norm_rows");
+}
+
+extern "C" int made_sine_pe(const float* mask, const float* dim_t, void* out, int32_t out_dtype,
+                            int64_t B, int64_t L, int64_t D, void* stream) {
+    MADE_REQUIRE(mask && dim_t && out, "made_sine_pe: null pointer");
+    MADE_REQUIRE(B >= 0 && L > 0 && D > 0 && B <= 65535 && L < (1 << 30), "made_sine_pe: bad dims");
+    if (B == 0) return MADE_OK;
+    hipLaunchKernelGGL(sine_pe_kernel, dim3((unsigned)((L + PE_ROWS - 1) / PE_ROWS), (unsigned)B), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, mask, dim_t, out, out_dtype, (int)L, (int)D);
+    return made_check_launch("made_sine_pe");
+}
+
+extern "C" int made_masked_softmax(const float* logits, int64_t ld_logits, const float* mask, int64_t ld_mask,
+                                   void* probs, int32_t out_dtype, int64_t ldp,
+                                   int64_t M_outer, int64_t R, int64_t S, int64_t S_pad, float scale, void* stream) {
+    MADE_REQUIRE(logits && probs, "made_masked_softmax: null pointer");
+    MADE_REQUIRE(S > 0 && S_pad >= S && ldp >= S_pad && ld_logits >= S, "made_masked_softmax: bad S/S_pad/strides");
+    const int64_t rows = M_outer * R;
+    if (rows <= 0) return MADE_OK;
+    hipLaunchKernelGGL(masked_softmax_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       logits, ld_logits, mask, ld_mask, probs, out_dtype, ldp, rows, R, (int)S, (int)S_pad, scale);
+    return made_check_launch("made_masked_softmax");
+}
+
+extern "C" int made_xpool_tail(const void* y, int32_t y_dtype, int64_t ldy, const float* gamma, const float* beta,
+                               const float* video, int64_t ld_video, float* pooled_out, float* sims, int64_t ld_sims,
+                               int64_t Nm, int64_t Nv, int64_t D, float eps, void* stream) {
+    MADE_REQUIRE(y && gamma && beta && video && sims, "made_xpool_tail: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldy % 4 == 0 && ld_video % 4 == 0, "made_xpool_tail: bad D/strides");
+    const int64_t rows = Nm * Nv;
+    if (rows <= 0) return MADE_OK;
+    hipLaunchKernelGGL(xpool_tail_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       y, y_dtype, ldy, gamma, beta, video, ld_video, pooled_out, sims, ld_sims, rows, Nv, (int)D, eps);
+    return made_check_launch("made_xpool_tail");
+}
+
+extern "C" int made_clip_loss(const float* sims, int64_t ld, int64_t n, const float* logit_scale, float weight,
+                              int32_t accumulate, float* loss_out, void* stream) {
+    MADE_REQUIRE(sims && logit_scale && loss_out, "made_clip_loss: null pointer");
+    MADE_REQUIRE(n > 0 && n <= 4096 && ld >= n, "made_clip_loss: n=%lld out of range", (long long)n);
+    hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale,
+                       weight, accumulate, loss_out);
+    return made_check_launch("made_clip_loss");
+}

@@ -1,0 +1,253 @@
+"""Tensor-level wrappers over the C ABI (include/made_hip.h).
+
+PyTorch is used for device memory and the current stream only; every op here enqueues one
+hand-written HIP kernel from libmade_hip.so and nothing falls back to ATen.  All tensors must live
+on the GPU; shapes/strides are validated by the library (negative status -> MadeError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, BF16, F32,  # noqa: F401
+                   MadeAttnArgs, MadeLinearArgs, MadeLinearSeg, check, lib)
+
+Tensor = torch.Tensor
+
+
+def dt_of(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(code: int):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def _p(t: Optional[Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.MadeError("libmade_hip ops need GPU tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous float32 tensor")
+    return t
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Seg:
+    """One column segment of made_linear's output (include/made_hip.h: MadeLinearSeg)."""
+    out: Tensor
+    col_begin: int = 0
+    ldo: Optional[int] = None          # default: out.stride(-2)
+    transposed: bool = False
+    rows_per_batch: int = 0
+    out_batch_stride: int = 0
+    out_z_stride: int = 0
+    use_a2: bool = False
+
+
+def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,
+           segs: Optional[Sequence[Seg]] = None, A2: Optional[Tensor] = None, a2_row_mod: int = 0,
+           a_row_mask: Optional[Tensor] = None, act: int = ACT_NONE, R: Optional[Tensor] = None,
+           r_row_mod: int = 0, out_row_mask: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+           batch: int = 1, a_z_stride: int = 0, w_z_stride: int = 0, M: Optional[int] = None,
+           N: Optional[int] = None, K: Optional[int] = None) -> Tensor:
+    """out = act(A' W^T + bias) (+R).  A [M,K] (row stride free, unit inner stride), W [N,K]."""
+    assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = W.shape[0] if N is None else N
+    a = MadeLinearArgs()
+    a.A, a.a_dtype, a.w_dtype, a.lda = _p(A), dt_of(A), dt_of(W), A.stride(0)
+    if A2 is not None:
+        assert A2.dim() == 2 and A2.stride(1) == 1 and A2.dtype == A.dtype
+        a.A2, a.lda2, a.a2_row_mod = _p(A2), A2.stride(0), a2_row_mod
+    a.a_row_mask = _p(_f32(a_row_mask, "a_row_mask"))
+    a.W, a.ldw = _p(W), W.stride(0)
+    a.bias = _p(_f32(bias, "bias"))
+    a.M, a.N, a.K = M, N, K
+    a.batch, a.a_z_stride, a.w_z_stride = batch, a_z_stride, w_z_stride
+    a.act = act
+    if R is not None:
+        assert R.dim() == 2 and R.stride(1) == 1
+        a.R, a.r_dtype, a.ldr, a.r_row_mod = _p(R), dt_of(R), R.stride(0), r_row_mod
+    a.out_row_mask = _p(_f32(out_row_mask, "out_row_mask"))
+    if segs is None:
+        if out is None:
+            out = torch.empty((M, N) if batch == 1 else (batch, M, N), device=A.device,
+                              dtype=out_dtype or W.dtype)
+        segs = [Seg(out=out, out_z_stride=(out.stride(0) if (batch > 1 and out.dim() == 3) else 0))]
+    a.nseg = len(segs)
+    for i, s in enumerate(segs):
+        sg = a.seg[i]
+        sg.col_begin, sg.out, sg.out_dtype = s.col_begin, _p(s.out), dt_of(s.out)
+        sg.transposed = 1 if s.transposed else 0
+        sg.ldo = s.ldo if s.ldo is not None else s.out.stride(-2)
+        sg.rows_per_batch, sg.out_batch_stride, sg.out_z_stride = s.rows_per_batch, s.out_batch_stride, s.out_z_stride
+        sg.use_a2 = 1 if s.use_a2 else 0
+    check(lib().made_linear(C.byref(a), _stream()), "made_linear")
+    return segs[0].out
+
+
+def attention(Q: Tensor, K: Tensor, Vt: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,
+              q_mask: Optional[Tensor] = None, scale: Optional[float] = None, Lk: Optional[int] = None) -> Tensor:
+    """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K [B,Lk,H*hd], Vt [B,H*hd,ldvt], O [B,Lq,H*hd]
+    (any batch/row strides, unit inner stride).  Lk defaults to K.shape[1]."""
+    assert Q.dim() == 3 and K.dim() == 3 and Vt.dim() == 3 and O.dim() == 3
+    assert Q.stride(2) == 1 and K.stride(2) == 1 and Vt.stride(2) == 1 and O.stride(2) == 1
+    assert Q.dtype == K.dtype == Vt.dtype == O.dtype
+    B, Lq, D = Q.shape
+    hd = D // H
+    a = MadeAttnArgs()
+    a.Q, a.K, a.Vt, a.O = _p(Q), _p(K), _p(Vt), _p(O)
+    a.dtype, a.hd = dt_of(Q), hd
+    a.B, a.H, a.Lq, a.Lk = B, H, Lq, (K.shape[1] if Lk is None else Lk)
+    a.q_bs, a.ldq = Q.stride(0), Q.stride(1)
+    a.k_bs, a.ldk = K.stride(0), K.stride(1)
+    a.vt_bs, a.ldvt = Vt.stride(0), Vt.stride(1)
+    a.o_bs, a.ldo = O.stride(0), O.stride(1)
+    a.key_mask = _p(_f32(key_mask, "key_mask"))
+    a.q_mask = _p(_f32(q_mask, "q_mask"))
+    a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
+    check(lib().made_attention(C.byref(a), _stream()), "made_attention")
+    return O
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, out: Optional[Tensor] = None, eps: float = 1e-5,
+              out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """LayerNorm over the last axis of a 2-D (row-strided) tensor."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    assert out.dim() == 2 and out.stride(1) == 1
+    check(lib().made_layernorm(_p(x), dt_of(x), x.stride(0), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
+                               _p(out), dt_of(out), out.stride(0), x.shape[0], x.shape[1], eps, _stream()),
+          "made_layernorm")
+    return out
+
+
+def masked_mean(x: Tensor, mask: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    """x [B,T,D] (unit inner stride), mask [B,T] or None (plain sum) -> [B,D] f32."""
+    assert x.dim() == 3 and x.stride(2) == 1
+    B, T, D = x.shape
+    if out is None:
+        out = torch.empty((B, D), device=x.device, dtype=torch.float32)
+    check(lib().made_masked_mean(_p(x), dt_of(x), x.stride(0), x.stride(1), _p(_f32(mask, "mask")), _p(_f32(out, "out")),
+                                 B, T, D, _stream()), "made_masked_mean")
+    return out
+
+
+def l2norm_rows(x: Tensor, out_f32: Optional[Tensor] = None, out_alt: Optional[Tensor] = None, eps: float = 1e-12):
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, D = x.shape
+    if out_f32 is None and out_alt is None:
+        out_f32 = torch.empty((rows, D), device=x.device, dtype=torch.float32)
+    ldy = (out_f32 if out_f32 is not None else out_alt).stride(0)
+    if out_f32 is not None and out_alt is not None:
+        assert out_f32.stride(0) == out_alt.stride(0)
+    check(lib().made_l2norm_rows(_p(x), dt_of(x), x.stride(0), _p(out_f32), _p(out_alt),
+                                 dt_of(out_alt) if out_alt is not None else F32, ldy, rows, D, eps, _stream()),
+          "made_l2norm_rows")
+    return out_f32 if out_f32 is not None else out_alt
+
+
+def sine_pe(mask: Tensor, dim_t: Tensor, out: Optional[Tensor] = None, out_dtype=torch.float32) -> Tensor:
+    B, L = mask.shape
+    D = dim_t.shape[0]
+    if out is None:
+        out = torch.empty((B, L, D), device=mask.device, dtype=out_dtype)
+    assert out.is_contiguous()
+    check(lib().made_sine_pe(_p(_f32(mask, "mask")), _p(_f32(dim_t, "dim_t")), _p(out), dt_of(out), B, L, D, _stream()),
+          "made_sine_pe")
+    return out
+
+
+def masked_softmax(logits: Tensor, mask: Optional[Tensor], probs: Tensor, S: int, scale: float) -> Tensor:
+    """logits [M_outer,R,>=S] f32 -> probs [M_outer,R,S_pad] (pad columns zeroed); mask [M_outer,S]."""
+    assert logits.dim() == 3 and probs.dim() == 3 and logits.dtype == torch.float32
+    assert logits.stride(2) == 1 and probs.stride(2) == 1
+    Mo, R = logits.shape[0], logits.shape[1]
+    assert logits.stride(0) == R * logits.stride(1) and probs.stride(0) == R * probs.stride(1)
+    S_pad = probs.shape[2]
+    check(lib().made_masked_softmax(_p(logits), logits.stride(1), _p(_f32(mask, "mask")), mask.stride(0) if mask is not None else 0,
+                                    _p(probs), dt_of(probs), probs.stride(1), Mo, R, S, S_pad, scale, _stream()),
+          "made_masked_softmax")
+    return probs
+
+
+def xpool_tail(y: Tensor, gamma: Tensor, beta: Tensor, video: Tensor, sims: Tensor, Nm: int, Nv: int,
+               pooled_out: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+    """y [Nm*Nv,D] -> LayerNorm3 -> cosine with video[n] -> sims[n, m] (sims: [Nv, >=Nm] f32)."""
+    assert y.dim() == 2 and y.stride(1) == 1 and video.dim() == 2 and video.stride(1) == 1
+    D = y.shape[1]
+    if pooled_out is not None:
+        assert pooled_out.is_contiguous() and pooled_out.dtype == torch.float32
+    check(lib().made_xpool_tail(_p(y), dt_of(y), y.stride(0), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
+                                _p(video), video.stride(0), _p(pooled_out), _p(sims), sims.stride(0), Nm, Nv, D, eps, _stream()),
+          "made_xpool_tail")
+    return sims
+
+
+def clip_loss(sims: Tensor, logit_scale: Tensor, loss_out: Tensor, weight: float = 1.0, accumulate: bool = False) -> Tensor:
+    assert sims.dim() == 2 and sims.shape[0] == sims.shape[1] and sims.stride(1) == 1 and sims.dtype == torch.float32
+    check(lib().made_clip_loss(_p(sims), sims.stride(0), sims.shape[0], _p(logit_scale), weight, 1 if accumulate else 0,
+                               _p(loss_out), _stream()), "made_clip_loss")
+    return loss_out
+
+
+def hungarian_match(pred_logits: Tensor, pred_spans: Tensor, targets: Tensor, fg_label: int,
+                    w_span: float = 10.0, w_giou: float = 1.0, w_class: float = 4.0):
+    """pred_* [NS,Q,2] (NS = layers*B), targets [B,G,2] -> (pred_idx [NS,min(Q,G)] i64, tgt_idx, count [NS] i32,
+    status [1] i32, cost [NS,Q,G] f32).  No host sync: inspect `status` later (1 = SciPy would raise)."""
+    NS, Q, _ = pred_logits.shape
+    B, G, _ = targets.shape
+    dev = pred_logits.device
+    width = min(Q, G)
+    cost = torch.empty((NS, Q, G), device=dev, dtype=torch.float32)
+    pi = torch.empty((NS, width), device=dev, dtype=torch.int64)
+    ti = torch.empty((NS, width), device=dev, dtype=torch.int64)
+    cnt = torch.empty((NS,), device=dev, dtype=torch.int32)
+    status = torch.zeros((1,), device=dev, dtype=torch.int32)
+    check(lib().made_hungarian_match(_p(_f32(pred_logits, "pred_logits")), _p(_f32(pred_spans, "pred_spans")),
+                                     _p(_f32(targets, "targets")), NS, B, Q, G, fg_label, w_span, w_giou, w_class,
+                                     _p(cost), _p(pi), _p(ti), _p(cnt), _p(status), _stream()), "made_hungarian_match")
+    return pi, ti, cnt, status, cost
+
+
+def set_criterion(pred_logits: Tensor, pred_spans: Tensor, targets: Tensor, pred_idx: Tensor, tgt_idx: Tensor,
+                  count: Tensor, proj_queries: Optional[Tensor], vid_sum: Optional[Tensor], empty_weight: Tensor,
+                  fg_label: int, weights: Tensor, temperature: float = 0.07):
+    """-> (losses [n_layers,5] f32, total [1] f32)."""
+    nl, B, Q, _ = pred_logits.shape
+    G = targets.shape[1]
+    Dc = proj_queries.shape[-1] if proj_queries is not None else 0
+    dev = pred_logits.device
+    losses = torch.empty((nl, 5), device=dev, dtype=torch.float32)
+    total = torch.empty((1,), device=dev, dtype=torch.float32)
+    check(lib().made_set_criterion(_p(_f32(pred_logits, "pred_logits")), _p(_f32(pred_spans, "pred_spans")),
+                                   _p(_f32(targets, "targets")), _p(pred_idx), _p(tgt_idx), _p(count),
+                                   _p(_f32(proj_queries, "proj_queries")), _p(_f32(vid_sum, "vid_sum")),
+                                   _p(_f32(empty_weight, "empty_weight")), nl, B, Q, G, Dc, fg_label, temperature,
+                                   _p(_f32(weights, "weights")), _p(losses), _p(total), _stream()), "made_set_criterion")
+    return losses, total

@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library loads and exports every symbol include/made_hip.h declares; argument
+validation works without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mgsv_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "made_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(made_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    names = _declared_symbols()
+    assert len(names) >= 14
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in made_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+    assert _lib.lib().made_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    # sizes the C compiler gives the two argument structs (checked against ctypes' own layout)
+    import subprocess, tempfile, textwrap
+    src = textwrap.dedent('''
+        #include <stdio.h>
+        #include "made_hip.h"
+        int main(void){ printf("%zu %zu %zu", sizeof(MadeLinearSeg), sizeof(MadeLinearArgs), sizeof(MadeAttnArgs)); return 0; }
+    ''')
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "s.c")
+        open(p, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert sizes == [C.sizeof(_lib.MadeLinearSeg), C.sizeof(_lib.MadeLinearArgs), C.sizeof(_lib.MadeAttnArgs)]
+
+
+def test_argument_validation_without_gpu():
+    l = _lib.lib()
+    assert l.made_linear(None, None) == -1
+    assert b"null args" in l.made_last_error()
+    a = _lib.MadeAttnArgs()
+    assert l.made_attention(C.byref(a), None) == -1
+    with pytest.raises(_lib.MadeError):
+        _lib.check(-1, "x")
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from mgsv_amd import ops
+    with pytest.raises(_lib.MadeError):
+        ops.layernorm(torch.zeros(4, 256), torch.ones(256), torch.zeros(256))

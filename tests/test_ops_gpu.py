@@ -1,0 +1,403 @@
+"""GPU parity of every kernel behind the C ABI against the CPU oracle / plain f32 math.
+
+Tolerances: f32 kernels (exact-f32 MFMA, f32 accumulate) <= 1e-4 absolute on O(1) values (the
+north_star's bar for logits/spans); bf16 kernels are compared with the same math evaluated in f32
+on bf16-rounded inputs, tolerance 2e-2 (bf16 has 8 significant bits; outputs are O(1)).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mgsv_amd import ops  # noqa: E402
+from mgsv_amd.ops import Seg  # noqa: E402
+from oracle import made_oracle as O  # noqa: E402
+
+F32_TOL = 1e-4
+BF16_TOL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    name, cus, is950 = __import__("mgsv_amd._lib", fromlist=["device_info"]).device_info()
+    assert is950, f"expected gfx950, got {name}"
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bf(x):  # round to bf16 and back (what a bf16 kernel sees)
+    return x.to(torch.bfloat16).float()
+
+
+def act_ref(x, act):
+    if act == ops.ACT_RELU:
+        return torch.relu(x)
+    if act == ops.ACT_GELU:
+        return O.gelu_erf(x)
+    if act == ops.ACT_QUICKGELU:
+        return O.quick_gelu(x)
+    if act == ops.ACT_SIGMOID:
+        return torch.sigmoid(x)
+    return x
+
+
+# ------------------------------------------------------------------------------------ made_linear
+@pytest.mark.parametrize("mode", ["f32", "f32_to_bf16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 96), (128, 128, 64), (33, 2, 256), (300, 130, 40), (1920, 512, 512)])
+@pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU, ops.ACT_QUICKGELU, ops.ACT_SIGMOID])
+def test_linear_basic(dev, mode, M, N, K, act):
+    if act not in (ops.ACT_NONE, ops.ACT_RELU) and (M, N, K) != (200, 192, 96):
+        pytest.skip("activation variants on one shape")
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3) * 0.1
+    if mode == "f32":
+        Ad, Wd, Ar, Wr, tol = A.to(dev), W.to(dev), A, W, F32_TOL
+    elif mode == "f32_to_bf16":
+        Ad, Wd, Ar, Wr, tol = A.to(dev), W.to(dev).bfloat16(), bf(A), bf(W), 2e-3
+    else:
+        Ad, Wd, Ar, Wr, tol = A.to(dev).bfloat16(), W.to(dev).bfloat16(), bf(A), bf(W), 2e-3
+    out = ops.linear(Ad, Wd, b.to(dev), act=act, out_dtype=torch.float32)
+    ref = act_ref(Ar @ Wr.t() + b, act)
+    torch.cuda.synchronize()
+    assert out.shape == (M, N)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
+    if mode != "f32":                       # bf16 output store
+        outb = ops.linear(Ad, Wd, b.to(dev), act=act, out_dtype=torch.bfloat16)
+        np.testing.assert_allclose(outb.float().cpu().numpy(), ref.numpy(), atol=BF16_TOL, rtol=2e-2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_linear_prologue_epilogue(dev, mode):
+    """row mask on A, +A2 with row modulo, residual table with row modulo, output row mask."""
+    M, N, K, T = 180, 256, 128, 30
+    A, A2, W, b = rnd(M, K, seed=1), rnd(7, K, seed=4), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3) * 0.1
+    R = rnd(T, N, seed=5)
+    amask = (torch.arange(M) % 5 != 0).float()
+    omask = (torch.arange(M) % 7 != 0).float()
+    cast = (lambda t: t) if mode == "f32" else (lambda t: t.bfloat16())
+    rr = (lambda t: t) if mode == "f32" else bf
+    tol = F32_TOL if mode == "f32" else 4e-3
+    out = ops.linear(cast(A.to(dev)), cast(W.to(dev)), b.to(dev), A2=cast(A2.to(dev)), a2_row_mod=7,
+                     a_row_mask=amask.to(dev), act=ops.ACT_RELU, R=R.to(dev), r_row_mod=T,
+                     out_row_mask=omask.to(dev), out_dtype=torch.float32,
+                     segs=[Seg(out=torch.empty(M, N, device=dev), use_a2=True)])
+    if mode == "f32":
+        Ap = (A + A2[torch.arange(M) % 7]) * amask[:, None]
+    else:
+        Ap = bf(bf(A) + bf(A2)[torch.arange(M) % 7]) * amask[:, None]     # kernel adds in f32, rounds once
+    ref = (torch.relu(Ap @ rr(W).t() + b) + R[torch.arange(M) % T]) * omask[:, None]
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_linear_segments_and_transposed(dev, mode):
+    """three column segments: plain, plain with +A2, transposed per batch (the V^T layout)."""
+    B, T, K, D = 3, 30, 64, 128
+    M, N = B * T, 3 * D
+    Tpad = 64
+    A, P, W, b = rnd(M, K, seed=1), rnd(M, K, seed=6), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3) * 0.1
+    cast = (lambda t: t) if mode == "f32" else (lambda t: t.bfloat16())
+    rr = (lambda t: t) if mode == "f32" else bf
+    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+    tol = F32_TOL if mode == "f32" else BF16_TOL
+    q = torch.zeros(M, D, device=dev, dtype=tdt)
+    k = torch.zeros(M, D, device=dev, dtype=tdt)
+    vt = torch.zeros(B, D, Tpad, device=dev, dtype=tdt)
+    ops.linear(cast(A.to(dev)), cast(W.to(dev)), b.to(dev), A2=cast(P.to(dev)),
+               segs=[Seg(out=q, col_begin=0), Seg(out=k, col_begin=D, use_a2=True),
+                     Seg(out=vt, col_begin=2 * D, transposed=True, ldo=Tpad, rows_per_batch=T, out_batch_stride=D * Tpad)])
+    torch.cuda.synchronize()
+    Ar, Pr, Wr = rr(A), rr(P), rr(W)
+    AP = Ar + Pr if mode == "f32" else bf(Ar + Pr)
+    np.testing.assert_allclose(q.float().cpu().numpy(), (Ar @ Wr[:D].t() + b[:D]).numpy(), atol=tol, rtol=tol)
+    np.testing.assert_allclose(k.float().cpu().numpy(), (AP @ Wr[D:2 * D].t() + b[D:2 * D]).numpy(), atol=tol, rtol=tol)
+    vref = (Ar @ Wr[2 * D:].t() + b[2 * D:]).view(B, T, D).transpose(1, 2)
+    np.testing.assert_allclose(vt.float().cpu().numpy()[:, :, :T], vref.numpy(), atol=tol, rtol=tol)
+    assert (vt[:, :, T:] == 0).all()                   # pad columns untouched
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_linear_batched(dev, mode):
+    """grid.z problems: shared A with per-problem W (the per-track QK^T of the X-Pool block)."""
+    Z, M, N, K = 5, 70, 96, 64
+    A, W = rnd(M, K, seed=1), rnd(Z, N, K, seed=2) / math.sqrt(K)
+    cast = (lambda t: t) if mode == "f32" else (lambda t: t.bfloat16())
+    rr = (lambda t: t) if mode == "f32" else bf
+    out = torch.empty(Z, M, N, device=dev)
+    ops.linear(cast(A.to(dev)), cast(W.to(dev)).view(Z * N, K), None, batch=Z, a_z_stride=0, w_z_stride=N * K,
+               N=N, segs=[Seg(out=out, ldo=N, out_z_stride=M * N)])
+    torch.cuda.synchronize()
+    ref = torch.einsum("mk,znk->zmn", rr(A), rr(W))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=F32_TOL if mode == "f32" else 3e-3, rtol=0)
+
+
+def test_linear_rejects_bad_arguments(dev):
+    A, W = torch.zeros(8, 12, device=dev), torch.zeros(8, 12, device=dev).bfloat16()
+    with pytest.raises(Exception, match="multiple of"):
+        ops.linear(A, W)                                # K=12 not a multiple of 8 for bf16
+    with pytest.raises(Exception, match="not supported"):
+        ops.linear(A.bfloat16(), torch.zeros(8, 12, device=dev))
+
+
+# --------------------------------------------------------------------------------- made_attention
+def attn_ref(q, k, v, H, key_mask, q_mask, scale=None):
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    hd = D // H
+    scale = 1 / math.sqrt(hd) if scale is None else scale
+    qh = q.view(B, Lq, H, hd).transpose(1, 2)
+    kh = k.view(B, Lk, H, hd).transpose(1, 2)
+    vh = v.view(B, Lk, H, hd).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if key_mask is not None:
+        s = s.masked_fill((key_mask == 0)[:, None, None, :], float("-inf"))
+    a = torch.softmax(s, -1)
+    if q_mask is not None:
+        a = a.masked_fill((q_mask == 0)[:, None, :, None], 0)
+    return (a @ vh).transpose(1, 2).reshape(B, Lq, D)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,H,hd,Lq,Lk", [(3, 8, 64, 30, 30), (2, 8, 64, 542, 542), (4, 8, 32, 146, 146),
+                                            (5, 8, 64, 1, 542), (2, 8, 128, 96, 50), (2, 4, 64, 3, 3), (1, 2, 32, 200, 65)])
+def test_attention(dev, mode, B, H, hd, Lq, Lk):
+    D = H * hd
+    q, k, v = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3)
+    lens = torch.tensor([max(1, Lk - 7 * i) for i in range(B)])
+    key_mask = (torch.arange(Lk)[None] < lens[:, None]).float()
+    if B > 1:
+        key_mask[1, ::3] = 0          # non-prefix pattern
+        key_mask[1, 1] = 1
+    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+    rr = (lambda t: t) if mode == "f32" else bf
+    ldvt = ops.round_up(Lk, 64)
+    # Q and K live in one packed [B, L, 2D] buffer when Lq == Lk (strided views), else separate
+    if Lq == Lk:
+        qk = torch.cat([q, k], -1).to(dev).to(tdt)
+        Qd, Kd = qk[:, :, :D], qk[:, :, D:]
+    else:
+        Qd, Kd = q.to(dev).to(tdt), k.to(dev).to(tdt)
+    Vt = torch.zeros(B, D, ldvt, device=dev, dtype=tdt)
+    Vt[:, :, :Lk] = v.transpose(1, 2).to(dev).to(tdt)
+    Od = torch.full((B, Lq, D), float("nan"), device=dev, dtype=tdt)
+    ops.attention(Qd, Kd, Vt, Od, H, key_mask=key_mask.to(dev), Lk=Lk)
+    torch.cuda.synchronize()
+    ref = attn_ref(rr(q), rr(k), rr(v), H, key_mask, None)
+    np.testing.assert_allclose(Od.float().cpu().numpy(), ref.numpy(), atol=F32_TOL if mode == "f32" else BF16_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_attention_qmask_nomask_and_all_masked(dev, mode):
+    B, H, hd, Lq, Lk = 2, 8, 64, 40, 70
+    D = H * hd
+    q, k, v = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3)
+    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+    rr = (lambda t: t) if mode == "f32" else bf
+    tol = F32_TOL if mode == "f32" else BF16_TOL
+    Vt = torch.zeros(B, D, 128, device=dev, dtype=tdt)
+    Vt[:, :, :Lk] = v.transpose(1, 2).to(dev).to(tdt)
+    q_mask = (torch.arange(Lq)[None] < torch.tensor([[25], [40]])).float()
+    Od = torch.empty(B, Lq, D, device=dev, dtype=tdt)
+    ops.attention(q.to(dev).to(tdt), k.to(dev).to(tdt), Vt, Od, H, q_mask=q_mask.to(dev), scale=0.3)
+    torch.cuda.synchronize()
+    ref = attn_ref(rr(q), rr(k), rr(v), H, None, q_mask, scale=0.3)
+    np.testing.assert_allclose(Od.float().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
+    # a batch row whose keys are all masked gives NaN, like the reference's softmax over -inf
+    km = torch.ones(B, Lk)
+    km[1] = 0
+    ops.attention(q.to(dev).to(tdt), k.to(dev).to(tdt), Vt, Od, H, key_mask=km.to(dev))
+    torch.cuda.synchronize()
+    assert torch.isnan(Od[1].float()).all() and not torch.isnan(Od[0].float()).any()
+
+
+def test_attention_online_softmax_rescale(dev):
+    """cdna guide rule 26: force the running-max rescale with a late spike in the scores."""
+    B, H, hd, Lq, Lk = 1, 1, 64, 32, 256
+    q, k, v = rnd(B, Lq, hd, seed=1), rnd(B, Lk, hd, seed=2), rnd(B, Lk, hd, seed=3)
+    k[0, 200] = q[0, 5] * 6.0           # query 5 meets a huge score in the 4th key tile
+    k[0, 70] = q[0, 9] * 4.0
+    Vt = torch.zeros(B, hd, 256, device=dev)
+    Vt[:] = v.transpose(1, 2).to(dev)
+    Od = torch.empty(B, Lq, hd, device=dev)
+    ops.attention(q.to(dev), k.to(dev), Vt, Od, H)
+    torch.cuda.synchronize()
+    ref = attn_ref(q.double(), k.double(), v.double(), H, None, None).float()
+    np.testing.assert_allclose(Od.cpu().numpy(), ref.numpy(), atol=F32_TOL, rtol=0)
+
+
+# ------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("D", [256, 512, 768, 1024])
+@pytest.mark.parametrize("io", ["f32->f32", "bf16->bf16", "f32->bf16"])
+def test_layernorm(dev, D, io):
+    rows = 131
+    x = rnd(rows, D, seed=1) * 2 + 0.5
+    g, b = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    idt, odt = [torch.float32 if s == "f32" else torch.bfloat16 for s in io.split("->")]
+    xin = x.to(idt)
+    buf = torch.zeros(rows, D + 8, device=dev, dtype=idt)           # strided rows
+    buf[:, :D] = xin.to(dev)
+    out = ops.layernorm(buf[:, :D], g.to(dev), b.to(dev), out_dtype=odt)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(xin.float(), (D,), g, b, 1e-5)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=2e-5 if odt == torch.float32 else 3e-2, rtol=0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_masked_mean_and_l2norm(dev, dt):
+    B, T, D = 5, 77, 256
+    x = rnd(B, T, D, seed=1).to(dt)
+    lens = torch.tensor([77, 1, 30, 12, 50])
+    mask = (torch.arange(T)[None] < lens[:, None]).float()
+    mean = ops.masked_mean(x.to(dev), mask.to(dev))
+    plain = ops.masked_mean(x.to(dev), None)
+    nrm = ops.l2norm_rows(mean)
+    torch.cuda.synchronize()
+    xr = x.float()
+    ref = (xr * mask[:, :, None]).sum(1) / mask.sum(1, keepdim=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(plain.cpu().numpy(), xr.sum(1).numpy(), atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(nrm.cpu().numpy(), O.l2_normalize(ref).numpy(), atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,L,D", [(3, 146, 256), (4, 542, 512), (2, 5, 256)])
+def test_sine_pe(dev, B, L, D):
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.rand(B, L, generator=g) > 0.3).float()
+    mask[:, 0] = 1
+    mask[0] = 1
+    dim_t = O.sine_pe_dim_t(D)
+    out = ops.sine_pe(mask.to(dev), dim_t.to(dev))
+    outb = ops.sine_pe(mask.to(dev), dim_t.to(dev), out_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    ref = O.sine_position_embedding(mask, D)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(outb.float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=0)
+
+
+@pytest.mark.parametrize("pdt", [torch.float32, torch.bfloat16])
+def test_masked_softmax(dev, pdt):
+    Mo, R, S, S_pad = 6, 37, 96, 104
+    logits = rnd(Mo, R, S_pad, seed=1) * 3
+    lens = torch.tensor([96, 12, 50, 1, 96, 77])
+    mask = (torch.arange(S)[None] < lens[:, None]).float()
+    probs = torch.full((Mo, R, S_pad), float("nan"), device=dev, dtype=pdt)
+    ops.masked_softmax(logits.to(dev), mask.to(dev), probs, S, 0.25)
+    torch.cuda.synchronize()
+    ref = torch.softmax((logits[:, :, :S] * 0.25).masked_fill((mask == 0)[:, None, :], float("-inf")), -1)
+    np.testing.assert_allclose(probs.float().cpu().numpy()[:, :, :S], ref.numpy(), atol=1e-6 if pdt == torch.float32 else 4e-3, rtol=0)
+    assert (probs[:, :, S:] == 0).all()
+
+
+def test_xpool_tail_and_clip_loss(dev):
+    Nm, Nv, D = 9, 13, 256
+    y = rnd(Nm * Nv, D, seed=1)
+    g, b = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    video = O.l2_normalize(rnd(Nv, D, seed=4))
+    sims = torch.empty(Nv, Nm, device=dev)
+    pooled = torch.empty(Nm * Nv, D, device=dev)
+    ops.xpool_tail(y.to(dev), g.to(dev), b.to(dev), video.to(dev), sims, Nm, Nv, pooled_out=pooled)
+    torch.cuda.synchronize()
+    pref = torch.nn.functional.layer_norm(y, (D,), g, b, 1e-5).view(Nm, Nv, D)
+    np.testing.assert_allclose(pooled.cpu().numpy(), pref.view(-1, D).numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(sims.cpu().numpy(), O.sim_music_pooling(video, pref).numpy(), atol=2e-6, rtol=0)
+    for n in (64, 13, 200):
+        s = torch.tanh(rnd(n, n, seed=7))
+        ls = torch.tensor(math.log(1 / 0.03))
+        out = torch.zeros(1, device=dev)
+        ops.clip_loss(s.to(dev), ls.to(dev).view(1), out)
+        ops.clip_loss(s.to(dev), ls.to(dev).view(1), out, weight=0.5, accumulate=True)
+        torch.cuda.synchronize()
+        ref = float(O.clip_loss(s, ls))
+        np.testing.assert_allclose(float(out.cpu()), 1.5 * ref, rtol=2e-5, atol=1e-5)
+
+
+# -------------------------------------------------------------------------------- matcher + criterion
+def test_matcher_golden_fixture_bit_exact(dev, golden_dir):
+    fix = np.load(os.path.join(golden_dir, "matcher.npz"))
+    lg, sp, tg = (torch.from_numpy(fix[k]).to(dev) for k in ("kat_logits", "kat_spans", "kat_targets"))
+    for fg in (0, 1):       # the reference's own example: music_detr/test_matcher.py:15-29
+        pi, ti, cnt, status, _ = ops.hungarian_match(lg, sp, tg, fg, 1.0, 1.0, 1.0)
+        torch.cuda.synchronize()
+        assert pi.cpu().tolist() == [[0, 2]] and ti.cpu().tolist() == [[1, 0]] and int(status) == 0
+    for n in range(int(fix["n_cases"])):
+        lg, sp, tg = (torch.from_numpy(fix[f"c{n}_{k}"]).to(dev) for k in ("logits", "spans", "targets"))
+        pi, ti, cnt, status, cost = ops.hungarian_match(lg, sp, tg, int(fix[f"c{n}_fg"]))
+        torch.cuda.synchronize()
+        w = pi.shape[1]
+        assert int(status) == 0
+        assert np.array_equal(pi.cpu().numpy(), fix[f"c{n}_pred_idx"][:, :w]), n
+        assert np.array_equal(ti.cpu().numpy(), fix[f"c{n}_tgt_idx"][:, :w]), n
+        # cost block equals the oracle's f32 cost bit for bit wherever exp() agrees; allow 1 ulp-ish
+        for b_ in range(lg.shape[0]):
+            keep = fix[f"c{n}_targets"][b_, :, 1] != 0
+            C = O.matcher_cost(torch.from_numpy(fix[f"c{n}_logits"][b_]), torch.from_numpy(fix[f"c{n}_spans"][b_]),
+                               torch.from_numpy(fix[f"c{n}_targets"][b_][keep]), int(fix[f"c{n}_fg"]))
+            np.testing.assert_allclose(cost[b_, :, :int(keep.sum())].cpu().numpy(), C.numpy(), atol=2e-6, rtol=0)
+
+
+def test_matcher_layers_ties_and_invalid(dev):
+    rng = np.random.default_rng(5)
+    nl, B, Q, G = 6, 7, 5, 3
+    lg = torch.from_numpy(rng.standard_normal((nl * B, Q, 2)).astype(np.float32))
+    sp = torch.from_numpy(np.concatenate([rng.uniform(.1, .9, (nl * B, Q, 1)), rng.uniform(.01, .5, (nl * B, Q, 1))], -1).astype(np.float32))
+    tg = torch.from_numpy(np.concatenate([rng.uniform(.1, .9, (B, G, 1)), rng.uniform(.02, .4, (B, G, 1))], -1).astype(np.float32))
+    tg[2, 1, 1] = 0
+    sp[3] = sp[3, :1]                      # all predictions identical: pure tie-break
+    lg[3] = lg[3, :1]
+    pi, ti, cnt, status, _ = ops.hungarian_match(lg.to(dev), sp.to(dev), tg.to(dev), 0)
+    torch.cuda.synchronize()
+    for s in range(nl * B):
+        i, j = O.hungarian_match(lg[s:s + 1], sp[s:s + 1], tg[s % B:s % B + 1], 0)[0]
+        n = int(cnt[s])
+        assert n == len(i) and pi[s, :n].cpu().tolist() == i.tolist() and ti[s, :n].cpu().tolist() == j.tolist()
+        assert (pi[s, n:] == -1).all()
+    assert int(status) == 0
+    bad = sp.clone()
+    bad[4, 0, 0] = float("nan")            # SciPy raises ValueError on NaN costs
+    *_, status, _ = ops.hungarian_match(lg.to(dev), bad.to(dev), tg.to(dev), 0)
+    torch.cuda.synchronize()
+    assert int(status) == 1
+
+
+@pytest.mark.parametrize("Q,G", [(1, 1), (4, 2), (3, 5)])
+def test_set_criterion(dev, Q, G):
+    from mgsv_amd.config import cfg_native
+    rng = np.random.default_rng(9)
+    cfg = cfg_native()
+    nl, B, Dc, Tv = cfg.detr_dec_layers, 6, 256, 20
+    lg = torch.from_numpy(rng.standard_normal((nl, B, Q, 2)).astype(np.float32))
+    sp = torch.from_numpy(np.concatenate([rng.uniform(.1, .9, (nl, B, Q, 1)), rng.uniform(.01, .5, (nl, B, Q, 1))], -1).astype(np.float32))
+    tg = torch.from_numpy(np.concatenate([rng.uniform(.1, .9, (B, G, 1)), rng.uniform(.02, .4, (B, G, 1))], -1).astype(np.float32))
+    if G > 1:
+        tg[1, 0, 1] = 0
+    pq = O.l2_normalize(torch.from_numpy(rng.standard_normal((nl, B, Q, Dc)).astype(np.float32)))
+    pv = O.l2_normalize(torch.from_numpy(rng.standard_normal((B, Tv, Dc)).astype(np.float32)))
+    P = {"criterion.empty_weight": torch.tensor([1.0, 0.1])}
+    outputs = {"pred_logits": lg[-1], "pred_spans": sp[-1], "proj_queries": pq[-1], "proj_vid_mem": pv,
+               "aux_outputs": [{"pred_logits": lg[i], "pred_spans": sp[i], "proj_queries": pq[i], "proj_vid_mem": pv} for i in range(nl - 1)]}
+    ref = O.set_criterion(outputs, tg, P, cfg)
+    wd = O.criterion_weight_dict(cfg)
+    ref_total = float(sum(ref[k] * wd[k] for k in ref if k in wd))
+
+    pi, ti, cnt, status, _ = ops.hungarian_match(lg.view(nl * B, Q, 2).to(dev), sp.view(nl * B, Q, 2).to(dev), tg.to(dev), 0)
+    vid_sum = ops.masked_mean(pv.to(dev), None)
+    weights = torch.tensor([4.0, 1.0, 0.8, 0.0, 0.2], device=dev)
+    losses, total = ops.set_criterion(lg.to(dev), sp.to(dev), tg.to(dev), pi, ti, cnt, pq.to(dev), vid_sum,
+                                      P["criterion.empty_weight"].to(dev), 0, weights)
+    torch.cuda.synchronize()
+    losses = losses.cpu().numpy()
+    names = ["loss_span", "loss_giou", "loss_label", "class_error", "loss_contrastive_align"]
+    for l in range(nl):
+        suffix = "" if l == nl - 1 else f"_{l}"
+        for k, nme in enumerate(names):
+            np.testing.assert_allclose(losses[l, k], float(ref[nme + suffix]), rtol=2e-5, atol=2e-5, err_msg=f"{nme}{suffix}")
+    np.testing.assert_allclose(float(total.cpu()), ref_total, rtol=2e-5, atol=1e-4)
