@@ -129,9 +129,12 @@ int made_attention(const MadeAttnArgs* args, void* stream);
  * Row kernels (HBM-bound).                                                                   */
 
 /* y = LayerNorm(x) * gamma + beta, eps inside the sqrt; one wave per row, D <= 2048, D % 4 == 0.
+ * Input row r sits at x + (r / rpb) * x_batch_stride + (r % rpb) * ldx when rpb = x_rows_per_batch > 0
+ * (a [B,T,D] view of a larger buffer), else at x + r * ldx; output rows are y + r * ldy.
  * Replaces nn.LayerNorm at reference model/model_Base.py:83,85; music_detr/transformer.py:202,
  * 209,290,300,306,136; modules/transformer.py:164-165,174,178. */
-int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
+int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
+                   const float* gamma, const float* beta,
                    void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
 
 /* out[b, :] = sum_t x[b,t,:] * (mask[b,t] != 0) / sum_t mask[b,t]   (mask NULL: plain column sum,
@@ -182,14 +185,18 @@ int made_clip_loss(const float* sims, int64_t ld, int64_t n, const float* logit_
  *   kept targets in order.  cost = w_span*L1 + w_giou*(-GIoU) + w_class*(-softmax(logits)[fg]) in
  *   f32, evaluated left to right without FMA contraction (reference matcher.py:88); the assignment
  *   is SciPy's rectangular LSAP on the f64-promoted block (reference matcher.py:91), same tie-break.
- *   cost_ws [NS,Q,G] f32 workspace (holds the per-sample cost blocks on return).
+ *   cost_ws [NS,Q,G] f32 workspace (holds the per-sample cost blocks on return).  With
+ *   cost_is_input != 0 the cost step is skipped and cost_ws is taken as given (block of sample s =
+ *   cost_ws[s, :Q, :kept targets of s]); used to check the assignment bit-for-bit on identical costs:
+ *   the class term goes through exp(), whose last bit differs between libms, and a 1-ulp change can
+ *   flip an assignment whose two best solutions tie to ~1e-7 (both are then optimal).
  *   out_pred_idx/out_tgt_idx [NS, min(Q,G)] int64, rows ascending in pred index, unused = -1;
  *   out_count [NS] int32; status [1] int32: 0, or 1 if any cost was NaN/-inf or infeasible
  *   (SciPy raises ValueError there).  Q, G <= 64. */
 int made_hungarian_match(const float* pred_logits, const float* pred_spans, const float* targets,
                          int64_t NS, int64_t B, int64_t Q, int64_t G, int32_t fg_label,
                          float w_span, float w_giou, float w_class,
-                         float* cost_ws, int64_t* out_pred_idx, int64_t* out_tgt_idx,
+                         float* cost_ws, int32_t cost_is_input, int64_t* out_pred_idx, int64_t* out_tgt_idx,
                          int32_t* out_count, int32_t* status, void* stream);
 
 /* Set criterion for `n_layers` decoder layers at once (reference music_detr/loss_detr.py:74-169):

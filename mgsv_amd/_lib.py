@@ -55,14 +55,14 @@ SIGNATURES = {
     "made_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "made_linear": (C.c_int, [C.POINTER(MadeLinearArgs), vp]),
     "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
-    "made_layernorm": (C.c_int, [vp, i32, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp]),
+    "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp]),
     "made_masked_mean": (C.c_int, [vp, i32, i64, i64, vp, vp, i64, i64, i64, vp]),
     "made_l2norm_rows": (C.c_int, [vp, i32, i64, vp, vp, i32, i64, i64, i64, f32, vp]),
     "made_sine_pe": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, vp]),
     "made_masked_softmax": (C.c_int, [vp, i64, vp, i64, vp, i32, i64, i64, i64, i64, i64, f32, vp]),
     "made_xpool_tail": (C.c_int, [vp, i32, i64, vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, f32, vp]),
     "made_clip_loss": (C.c_int, [vp, i64, i64, vp, f32, i32, vp, vp]),
-    "made_hungarian_match": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp]),
+    "made_hungarian_match": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp]),
     "made_set_criterion": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp, vp, vp]),
 }
 

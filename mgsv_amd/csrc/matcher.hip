@@ -30,8 +30,8 @@ __device__ __forceinline__ void cw_to_se(float c, float w, float& s, float& e) {
 
 __global__ __launch_bounds__(64) void hungarian_kernel(const float* logits, const float* spans, const float* targets,
                                                        int B, int Q, int G, int fg, float w_span, float w_giou, float w_class,
-                                                       float* cost_ws, int64_t* out_pred, int64_t* out_tgt, int32_t* out_count,
-                                                       int32_t* status) {
+                                                       float* cost_ws, int cost_is_input, int64_t* out_pred, int64_t* out_tgt,
+                                                       int32_t* out_count, int32_t* status) {
     __shared__ int kept[MAXN];
     __shared__ int n_kept;
     __shared__ double u[MAXN], v[MAXN], spc[MAXN];
@@ -55,6 +55,11 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float* logits, cons
     const float* sp = spans + (int64_t)s * Q * 2;
     for (int idx = lane; idx < Q * Gk; idx += 64) {
         int q = idx / Gk, j = idx % Gk, g = kept[j];
+        if (cost_is_input) {
+            float c = C[q * G + j];
+            if (c != c || c == -INFINITY) bad = 1;
+            continue;
+        }
         float l0 = lg[2 * q], l1 = lg[2 * q + 1];
         float mx = fmaxf(l0, l1);
         float e0 = expf(__fsub_rn(l0, mx)), e1 = expf(__fsub_rn(l1, mx));
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(const float* lo
 extern "C" int made_hungarian_match(const float* pred_logits, const float* pred_spans, const float* targets,
                                     int64_t NS, int64_t B, int64_t Q, int64_t G, int32_t fg_label,
                                     float w_span, float w_giou, float w_class,
-                                    float* cost_ws, int64_t* out_pred_idx, int64_t* out_tgt_idx,
+                                    float* cost_ws, int32_t cost_is_input, int64_t* out_pred_idx, int64_t* out_tgt_idx,
                                     int32_t* out_count, int32_t* status, void* stream) {
     MADE_REQUIRE(pred_logits && pred_spans && targets && cost_ws && out_pred_idx && out_tgt_idx && out_count && status,
                  "made_hungarian_match: null pointer");
@@ -267,7 +272,7 @@ extern "C" int made_hungarian_match(const float* pred_logits, const float* pred_
                      (long long)Q, (long long)G, MAXN);
     if (NS == 0) return MADE_OK;
     hipLaunchKernelGGL(hungarian_kernel, dim3((unsigned)NS), dim3(64), 0, (hipStream_t)stream, pred_logits, pred_spans, targets,
-                       (int)B, (int)Q, (int)G, (int)fg_label, w_span, w_giou, w_class, cost_ws, out_pred_idx, out_tgt_idx,
+                       (int)B, (int)Q, (int)G, (int)fg_label, w_span, w_giou, w_class, cost_ws, (int)cost_is_input, out_pred_idx, out_tgt_idx,
                        out_count, status);
     return made_check_launch("made_hungarian_match");
 }

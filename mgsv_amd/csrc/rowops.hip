@@ -32,20 +32,21 @@ __device__ __forceinline__ void store4(void* p, int dtype, int64_t idx, f32x4 v)
 
 // ---- LayerNorm -----------------------------------------------------------------------------
 // Two-pass (mean, then centred variance) in registers: the row is read from HBM once.
-__global__ __launch_bounds__(ROW_THREADS) void layernorm_kernel(const void* x, int xdt, int64_t ldx,
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_kernel(const void* x, int xdt, int64_t ldx, int64_t rpb, int64_t xbs,
                                                                 const float* gamma, const float* beta,
                                                                 void* y, int ydt, int64_t ldy,
                                                                 int64_t rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
     if (row >= rows) return;
+    const int64_t xoff = rpb > 0 ? (row / rpb) * xbs + (row % rpb) * ldx : row * ldx;
     f32x4 v[MAX_VEC];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < MAX_VEC; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
-            v[i] = load4(x, xdt, row * ldx + c);
+            v[i] = load4(x, xdt, xoff + c);
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -291,15 +292,17 @@ inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
 
 }  // namespace
 
-extern "C" int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
+extern "C" int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
+                              const float* gamma, const float* beta,
                               void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream) {
     MADE_REQUIRE(x && y && gamma && beta, "made_layernorm: null pointer");
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC, "made_layernorm: D=%lld must be a multiple of 4 and <= %d",
                      (long long)D, 64 * 4 * MAX_VEC);
-    MADE_UNSUPPORTED(ldx % 4 == 0 && ldy % 4 == 0, "made_layernorm: row strides must be multiples of 4");
+    MADE_UNSUPPORTED(ldx % 4 == 0 && ldy % 4 == 0 && x_batch_stride % 4 == 0, "made_layernorm: row strides must be multiples of 4");
+    MADE_REQUIRE(x_rows_per_batch >= 0, "made_layernorm: negative x_rows_per_batch");
     if (rows <= 0) return MADE_OK;
     hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                       x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, (int)D, eps);
+                       x, x_dtype, ldx, x_rows_per_batch, x_batch_stride, gamma, beta, y, y_dtype, ldy, rows, (int)D, eps);
     return made_check_launch("made_layernorm");
 }
 

@@ -1,0 +1,492 @@
+"""Forward executor of the MaDe hot path on MI355X.
+
+`MadeEngine` owns the packed device weights and a shape-keyed workspace and runs the
+reference's `Uni_model.forward` (reference model/model_Uni.py:177-322, eval mode) plus the
+all-pairs retrieval scoring of reference test-MaDe.py:386-403 as a fixed sequence of kernels
+from libmade_hip.so, all on the current HIP stream with no host synchronisation (so the whole
+step can be captured in a HIP graph).  PyTorch only provides device memory and the stream.
+
+Data layout in HBM (B = batch, L = T_v + T_a under concat fusion, D = dim_input):
+  * activations are row-major [rows, D] in the compute dtype (f32 or bf16), one row per token;
+  * the DETR input `fus` [B, L, D] is written in place by the two temporal encoders' last GEMMs
+    (frame rows 0..T_v-1, segment rows T_v..L-1) -- the reference's torch.cat never happens;
+  * attention values are produced TRANSPOSED per batch ([B, D, L_pad], L_pad = round_up(L, 64))
+    by the projection GEMM's epilogue, the layout made_attention's second MFMA product wants;
+  * the 6 decoder layers' memory K / V projections are one GEMM against [2*dec*D, D] packed
+    weights (25 % of the forward flops in one launch).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import MadeConfig
+from .ops import Seg, round_up
+
+Tensor = torch.Tensor
+
+
+class MadeEngine:
+    def __init__(self, cfg: MadeConfig, state_dict: Dict[str, object], device="cuda:0", dtype: str = "f32"):
+        assert dtype in ("f32", "bf16")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.tc = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.dtype_name = dtype
+        self._check_supported()
+        self._ws: Dict[tuple, Dict[str, Tensor]] = {}
+        self.load_state_dict(state_dict)
+
+    # ------------------------------------------------------------------ config support
+    def _check_supported(self):
+        c = self.cfg
+        unsupported = []
+        if c.video_transformer_depth < 1 or c.audio_transformer_depth < 1:
+            unsupported.append("temporal transformer depth 0 (agg_module != transf)")
+        if "concat" not in c.mml_fusion:
+            unsupported.append(f"mml_fusion={c.mml_fusion}")
+        if c.vmr_fusion != "XA-music":
+            unsupported.append(f"vmr_fusion={c.vmr_fusion}")
+        if c.fusion_mask != 1:
+            unsupported.append("fusion_mask=0")
+        if c.mml_localization != "detr":
+            unsupported.append(f"mml_localization={c.mml_localization}")
+        if c.predict_center != 0 or c.audio_short_cut != 0 or c.moment_loss != 0:
+            unsupported.append("predict_center/audio_short_cut/moment_loss")
+        if c.moment_query_type not in ("video", "music"):
+            unsupported.append(f"moment_query_type={c.moment_query_type}")
+        if c.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse"):
+            unsupported.append(f"vmr_loss={c.vmr_loss}")
+        if c.detr_dec_layers < 1:
+            unsupported.append("detr_dec_layers=0")
+        if c.D % 64 != 0:
+            unsupported.append(f"dim_input={c.D} not a multiple of 64")
+        if unsupported:
+            raise NotImplementedError("MadeEngine (HIP path) does not cover yet: " + "; ".join(unsupported))
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, object]):
+        """Pack reference-layout weights for the kernels: matrices in the compute dtype,
+        biases / LayerNorm parameters / tables in f32."""
+        dev, tc = self.device, self.tc
+        c = self.cfg
+        D = c.D
+
+        def T(name) -> Tensor:
+            v = sd[name]
+            t = v.detach().clone() if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v).copy())
+            return t.to(dev, torch.float32)
+
+        P: Dict[str, Tensor] = {}
+
+        def mat(key, t: Tensor):
+            P[key] = t.to(tc).contiguous()
+
+        def vec(key, t: Tensor):
+            P[key] = t.to(torch.float32).contiguous()
+
+        def lin(key, name):
+            mat(key + ".w", T(name + ".weight"))
+            vec(key + ".b", T(name + ".bias"))
+
+        def ln(key, name):
+            vec(key + ".g", T(name + ".weight"))
+            vec(key + ".b", T(name + ".bias"))
+
+        lin("vit_proj", "vit_proj")
+        lin("ast_proj", "ast_proj")
+        vec("pe_video", T("video_position_embedding.pe")[0])
+        vec("pe_audio", T("audio_position_embedding.pe")[0])
+        for mod, depth in (("video_transformer", c.video_transformer_depth), ("audio_transformer", c.audio_transformer_depth)):
+            for l in range(depth):
+                p = f"{mod}.layers.{l}"
+                ln(p + ".ln1", p + ".0")
+                mat(p + ".in.w", T(p + ".1.in_proj_weight")); vec(p + ".in.b", T(p + ".1.in_proj_bias"))
+                lin(p + ".out", p + ".1.out_proj")
+                ln(p + ".ln2", p + ".2")
+                lin(p + ".ff1", p + ".3.0")
+                lin(p + ".ff2", p + ".3.3")
+            lin(mod + ".final", mod + ".final_linear")
+        xa = "video_guided_to_music_pooling_cross_transformer"
+        ln("xa.ln1", xa + ".layer_norm1"); ln("xa.ln2", xa + ".layer_norm2"); ln("xa.ln3", xa + ".layer_norm3")
+        lin("xa.q", xa + ".cross_attn.q_proj")
+        mat("xa.kv.w", torch.cat([T(xa + ".cross_attn.k_proj.weight"), T(xa + ".cross_attn.v_proj.weight")], 0))
+        vec("xa.kv.b", torch.cat([T(xa + ".cross_attn.k_proj.bias"), T(xa + ".cross_attn.v_proj.bias")], 0))
+        lin("xa.out", xa + ".cross_attn.out_proj")
+        lin("xa.lin", xa + ".linear_proj")
+        vec("logit_scale", T("logit_scale").view(1))
+        for l in range(c.detr_enc_layers):
+            p = f"detr_transformer.encoder.layers.{l}"
+            mat(p + ".in.w", T(p + ".self_attn.in_proj_weight")); vec(p + ".in.b", T(p + ".self_attn.in_proj_bias"))
+            lin(p + ".out", p + ".self_attn.out_proj")
+            lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
+            ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2")
+        wk, wv, bk, bv = [], [], [], []
+        for l in range(c.detr_dec_layers):
+            p = f"detr_transformer.decoder.layers.{l}"
+            mat(p + ".sa.in.w", T(p + ".self_attn.in_proj_weight")); vec(p + ".sa.in.b", T(p + ".self_attn.in_proj_bias"))
+            lin(p + ".sa.out", p + ".self_attn.out_proj")
+            w, b = T(p + ".multihead_attn.in_proj_weight"), T(p + ".multihead_attn.in_proj_bias")
+            mat(p + ".ca.q.w", w[:D]); vec(p + ".ca.q.b", b[:D])
+            wk.append(w[D:2 * D]); wv.append(w[2 * D:]); bk.append(b[D:2 * D]); bv.append(b[2 * D:])
+            lin(p + ".ca.out", p + ".multihead_attn.out_proj")
+            lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
+            ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2"); ln(p + ".ln3", p + ".norm3")
+        mat("dec.kv_all.w", torch.cat(wk + wv, 0))                     # [2*dec*D, D]
+        vec("dec.kv_all.b", torch.cat(bk + bv, 0))
+        ln("dec.norm", "detr_transformer.decoder.norm")
+        mat("query_embed", T("decoder_query_embed.weight"))
+        lin("class_embed", "class_embed")
+        for i in range(3):
+            lin(f"span_embed.{i}", f"span_embed.layers.{i}")
+        if c.contrastive_align_loss:
+            lin("proj_q", "contrastive_align_projection_query")
+            lin("proj_v", "contrastive_align_projection_vid")
+        vec("empty_weight", T("criterion.empty_weight"))
+        # constants
+        i = torch.arange(D, dtype=torch.float32)
+        vec("dim_t", (10000.0 ** (2 * torch.div(i, 2, rounding_mode="floor") / D)).to(dev))
+        w_contr = 0.2 if c.contrastive_align_loss else 0.0
+        vec("crit_weights", torch.tensor([4.0 if c.l1_loss else 0.0, 1.0, 0.8, 0.0, w_contr], device=dev))
+        self.P = P
+
+    # ------------------------------------------------------------------ workspace
+    def _buffers(self, B: int, Tv: int, Ta: int) -> Dict[str, Tensor]:
+        key = (B, Tv, Ta)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        c, dev, tc = self.cfg, self.device, self.tc
+        D, L, Q = c.D, Tv + Ta, c.num_moment_queries
+        F_t, F_d, nd = c.temporal_ffn_dim, c.detr_dim_feedforward, c.detr_dec_layers
+        Lmax = max(L, Ta, Tv)
+        Lpad = round_up(Lmax, 64)
+        rows = B * Lmax
+
+        def E(*shape, dtype=None):
+            return torch.empty(shape, device=dev, dtype=dtype or tc)
+
+        def Z(*shape, dtype=None):
+            return torch.zeros(shape, device=dev, dtype=dtype or tc)
+
+        ws = dict(
+            fus=E(B, L, D), fus_mask=E(B, L, dtype=torch.float32), pos=E(B, L, D),
+            x0=E(rows, D), x1=E(rows, D), x2=E(rows, D), x3=E(rows, D),
+            qk=E(rows, 2 * D), vt=Z(B, D, Lpad), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
+            k_all=E(B * L, nd * D), vt_all=Z(B, nd * D, round_up(L, 64)),
+            vmean=E(B, D, dtype=torch.float32), mmean=E(B, D, dtype=torch.float32),
+            video=E(B, D, dtype=torch.float32), music=E(B, D, dtype=torch.float32),
+            tgt=E(B * Q, D), t1=E(B * Q, D), t2=E(B * Q, D), tx=E(B * Q, D),
+            dqk=E(B * Q, 2 * D), dq=E(B * Q, D), dvt=Z(B, D, 64 * ((Q + 63) // 64)), datt=E(B * Q, D),
+            dffn=E(B * Q, F_d), hs=E(nd, B * Q, D),
+            logits=E(nd, B, Q, 2, dtype=torch.float32), spans=E(nd, B, Q, 2, dtype=torch.float32),
+            h1=E(nd * B * Q, D), h2=E(nd * B * Q, D),
+            sims_single=E(B, B, dtype=torch.float32), sims_dual=E(B, B, dtype=torch.float32),
+            ret_loss=E(1, dtype=torch.float32),
+        )
+        if c.contrastive_align_loss:
+            Dc = c.contrastive_hdim
+            ws.update(pq_raw=E(nd * B * Q, Dc, dtype=torch.float32), pq=E(nd, B, Q, Dc, dtype=torch.float32),
+                      pv_raw=E(B * Tv, Dc, dtype=torch.float32), pv=E(B, Tv, Dc, dtype=torch.float32),
+                      vid_sum=E(B, Dc, dtype=torch.float32))
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ building blocks
+    def _mha_block(self, x: Tensor, B: int, T: int, w_in: Tensor, b_in: Tensor, key_mask: Optional[Tensor],
+                   ws: Dict[str, Tensor], H: int, pos: Optional[Tensor] = None) -> Tensor:
+        """packed in-proj -> flash attention; x [B*T, D]; q,k from (x + pos), v from x; returns att [B*T, D]."""
+        D = self.cfg.D
+        qk = ws["qk"][:B * T]
+        vt = ws["vt"]
+        ops.linear(x, w_in, b_in, A2=pos,
+                   segs=[Seg(out=qk, col_begin=0, use_a2=pos is not None),
+                         Seg(out=vt, col_begin=2 * D, transposed=True, ldo=vt.stride(1), rows_per_batch=T,
+                             out_batch_stride=vt.stride(0))])
+        qk3 = qk.view(B, T, 2 * D)
+        att = ws["att"][:B * T]
+        ops.attention(qk3[:, :, :D], qk3[:, :, D:], vt, att.view(B, T, D), H, key_mask=key_mask, Lk=T)
+        return att
+
+    def _encode(self, feats: Tensor, mask: Tensor, which: str, ws: Dict[str, Tensor], row_off: int) -> None:
+        """reference model/model_Base.py:544-617 -> writes fus[:, row_off:row_off+T] and mean/normalised vector."""
+        c, P = self.cfg, self.P
+        B, T, Kin = feats.shape
+        D = c.D
+        proj, mod, pe, depth = (("vit_proj", "video_transformer", "pe_video", c.video_transformer_depth) if which == "video"
+                                else ("ast_proj", "audio_transformer", "pe_audio", c.audio_transformer_depth))
+        if P[pe].shape[0] < T:
+            raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < T={T} "
+                             "(reference model/model_Base.py:533 raises here too)")
+        rows = B * T
+        mflat = mask.reshape(-1)
+        x = ops.linear(feats.view(rows, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat,
+                       act=ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE,
+                       R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows])
+        for l in range(depth):
+            p = f"{mod}.layers.{l}"
+            x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x1"][:rows])
+            att = self._mha_block(x1, B, T, P[p + ".in.w"], P[p + ".in.b"], mask, ws, c.SA_temporal_heads)
+            x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=ws["x2"][:rows])
+            x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3"][:rows])
+            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=ws["ffn"][:rows, :c.temporal_ffn_dim])
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=ws["x0"][:rows])
+        fus = ws["fus"]
+        local = fus[:, row_off:row_off + T]                              # [B, T, D] view
+        ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat,
+                   segs=[Seg(out=local, ldo=fus.stride(1), rows_per_batch=T, out_batch_stride=fus.stride(0))])
+        mean, vec = (ws["vmean"], ws["video"]) if which == "video" else (ws["mmean"], ws["music"])
+        ops.masked_mean(local, mask, out=mean)
+        ops.l2norm_rows(mean, out_f32=vec)
+
+    # ------------------------------------------------------------------ X-Pool scoring
+    def xpool_sims(self, video: Tensor, seg: Tensor, seg_mask: Tensor, sims_out: Optional[Tensor] = None,
+                   pooled_out: Optional[Tensor] = None, chunk_m: Optional[int] = None) -> Tensor:
+        """sims[n, m] = <v_n/|v_n|, XA(v, seg, mask)[m, n]/|.|>: reference modules/transformer.py:156-180 +
+        modules/metrics.py:10-24.  video [Nv, D] f32; seg [Nm, S, D] (compute dtype, strided ok); mask [Nm, S].
+        Music tracks are processed in chunks so the per-pair intermediates stay bounded."""
+        P, tc, dev = self.P, self.tc, self.device
+        Nv, D = video.shape
+        Nm, S, _ = seg.shape
+        Spad = round_up(S, 64)
+        if sims_out is None:
+            sims_out = torch.empty(Nv, Nm, device=dev, dtype=torch.float32)
+        if chunk_m is None:
+            budget = 6 << 30                                             # bytes of per-pair intermediates per chunk
+            per_m = Nv * (Spad * (4 + tc.itemsize) + 4 * D * tc.itemsize)
+            chunk_m = max(1, min(Nm, budget // max(per_m, 1)))
+        v1 = ops.layernorm(video, P["xa.ln1.g"], P["xa.ln1.b"], out_dtype=tc)
+        q = ops.linear(v1, P["xa.q.w"], P["xa.q.b"])
+        hoist = Nv > S          # out_proj commutes with the softmax-weighted sum (rows sum to 1): apply it to U instead
+        cm = min(chunk_m, Nm)
+        s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
+        kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
+        ubuf = torch.empty(cm * S, D, device=dev, dtype=tc) if hoist else None
+        ut = torch.zeros(cm, D, Spad, device=dev, dtype=tc)
+        logits = torch.empty(cm, Nv, Spad, device=dev, dtype=torch.float32)
+        probs = torch.empty(cm, Nv, Spad, device=dev, dtype=tc)
+        o = torch.empty(cm * Nv, D, device=dev, dtype=tc)
+        o2 = torch.empty(cm * Nv, D, device=dev, dtype=tc)
+        o3 = torch.empty(cm * Nv, D, device=dev, dtype=tc)
+        scale = 1.0 / math.sqrt(D)
+        for m0 in range(0, Nm, cm):
+            n = min(cm, Nm - m0)
+            segc = seg[m0:m0 + n]
+            ops.layernorm(segc, P["xa.ln1.g"], P["xa.ln1.b"], out=s1[:n * S])   # [n,S,D] view -> compact rows
+            ut_seg = Seg(out=ut, col_begin=D, transposed=True, ldo=Spad, rows_per_batch=S, out_batch_stride=D * Spad)
+            if hoist:
+                ops.linear(s1[:n * S], P["xa.kv.w"], P["xa.kv.b"],
+                           segs=[Seg(out=kbuf, col_begin=0), Seg(out=ubuf, col_begin=D)])
+                ops.linear(ubuf[:n * S], P["xa.out.w"], P["xa.out.b"],
+                           segs=[Seg(out=ut, transposed=True, ldo=Spad, rows_per_batch=S, out_batch_stride=D * Spad)])
+            else:
+                ops.linear(s1[:n * S], P["xa.kv.w"], P["xa.kv.b"], segs=[Seg(out=kbuf, col_begin=0), ut_seg])
+            # logits[m] = q K_m^T  (f32 out), softmax over segments, o[m] = P_m U_m
+            ops.linear(q, kbuf, None, N=S, batch=n, a_z_stride=0, w_z_stride=S * D,
+                       segs=[Seg(out=logits, ldo=Spad, out_z_stride=Nv * Spad)])
+            ops.masked_softmax(logits[:n], seg_mask[m0:m0 + n], probs[:n], S, scale)
+            ops.linear(probs.view(cm * Nv, Spad), ut.view(cm * D, Spad), None, M=Nv, N=D, K=Spad, batch=n,
+                       a_z_stride=Nv * Spad, w_z_stride=D * Spad, segs=[Seg(out=o, ldo=D, out_z_stride=Nv * D)])
+            rows = n * Nv
+            if hoist:
+                a2 = o[:rows]
+            else:
+                a2 = ops.linear(o[:rows], P["xa.out.w"], P["xa.out.b"], out=o2[:rows])
+            a3 = ops.layernorm(a2, P["xa.ln2.g"], P["xa.ln2.b"], out=o3[:rows])
+            y = ops.linear(a3, P["xa.lin.w"], P["xa.lin.b"], R=a3, out=o2[:rows] if hoist else o[:rows])
+            ops.xpool_tail(y, P["xa.ln3.g"], P["xa.ln3.b"], video, sims_out[:, m0:m0 + n], n, Nv,
+                           pooled_out=pooled_out[m0 * Nv:(m0 + n) * Nv] if pooled_out is not None else None)
+        return sims_out
+
+    def dual_sims(self, video: Tensor, music: Tensor, out: Optional[Tensor] = None, add: Optional[Tensor] = None) -> Tensor:
+        """cos(v, m) (reference modules/loss.py:52-56), always with the exact-f32 MFMA; `add` is summed in."""
+        vn = ops.l2norm_rows(video)
+        mn = ops.l2norm_rows(music)
+        return ops.linear(vn, mn, None, R=add, out=out, out_dtype=torch.float32)
+
+    def retrieval_sim_matrix(self, video_embeds: Tensor, segment_embeds: Tensor, segment_masks: Tensor,
+                             music_embeds: Tensor, chunk_m: Optional[int] = None) -> Tensor:
+        """reference test-MaDe.py:386-403: sim[Nv, Nm] = single (X-Pool) + dual (cosine)."""
+        seg = segment_embeds.to(self.tc) if segment_embeds.dtype != self.tc else segment_embeds
+        single = self.xpool_sims(video_embeds, seg, segment_masks, chunk_m=chunk_m)
+        return self.dual_sims(video_embeds, music_embeds, add=single)
+
+    # ------------------------------------------------------------------ full forward
+    @torch.no_grad()
+    def forward(self, frame_feats: Tensor, segment_feats: Tensor, frame_masks: Tensor, segment_masks: Tensor,
+                spans_target: Tensor, with_losses: bool = True, want_pooled: bool = False) -> Dict[str, Tensor]:
+        c, P = self.cfg, self.P
+        B, Tv, _ = frame_feats.shape
+        Ta = segment_feats.shape[1]
+        D, L, Q, nd = c.D, Tv + Ta, c.num_moment_queries, c.detr_dec_layers
+        H = c.detr_nheads
+        ws = self._buffers(B, Tv, Ta)
+        fm, sm = frame_masks.contiguous(), segment_masks.contiguous()
+
+        # ---- temporal encoders (K1-K4) write straight into the fused DETR input
+        self._encode(frame_feats.contiguous(), fm, "video", ws, 0)
+        self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv)
+        fus, fus_mask = ws["fus"], ws["fus_mask"]
+        fus_mask[:, :Tv].copy_(fm)
+        fus_mask[:, Tv:].copy_(sm)
+        frame, seg = fus[:, :Tv], fus[:, Tv:]
+        video, music = ws["video"], ws["music"]
+        out: Dict[str, Tensor] = dict(video_feats=video, music_feats=music, frame_feats=frame, segment_feats=seg)
+
+        # ---- X-Pool similarities (K5-K7)
+        pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if want_pooled else None
+        self.xpool_sims(video, seg, sm, sims_out=ws["sims_single"], pooled_out=pooled)
+        self.dual_sims(video, music, out=ws["sims_dual"])
+        out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"])
+        if pooled is not None:
+            out["music_feats_pooled"] = pooled.view(B, B, D)
+
+        # ---- DETR encoder (K8, K9)
+        pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
+        rows = B * L
+        src = fus.view(rows, D)
+        pos2 = pos.view(rows, D)
+        for l in range(c.detr_enc_layers):
+            p = f"detr_transformer.encoder.layers.{l}"
+            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=pos2)
+            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows])
+            s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x2"][:rows])
+            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward])
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=ws["x1"][:rows])
+            src = ops.layernorm(x, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3" if l % 2 == 0 else "x0"][:rows])
+        memory = src
+        out["memory"] = memory.view(B, L, D)
+
+        # ---- DETR decoder (K10): all layers' memory K / V^T in one GEMM
+        k_all, vt_all = ws["k_all"], ws["vt_all"]
+        ops.linear(memory, P["dec.kv_all.w"], P["dec.kv_all.b"], A2=pos2,
+                   segs=[Seg(out=k_all, col_begin=0, use_a2=True),
+                         Seg(out=vt_all, col_begin=nd * D, transposed=True, ldo=vt_all.stride(1), rows_per_batch=L,
+                             out_batch_stride=vt_all.stride(0))])
+        k3 = k_all.view(B, L, nd * D)
+        tgt = ws["tgt"]
+        src_vec = video if c.moment_query_type == "video" else music
+        tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        qp = P["query_embed"]
+        hs = ws["hs"]
+        dvt = ws["dvt"]
+        for l in range(nd):
+            p = f"detr_transformer.decoder.layers.{l}"
+            dqk = ws["dqk"]
+            ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=qp, a2_row_mod=Q,
+                       segs=[Seg(out=dqk, col_begin=0, use_a2=True),
+                             Seg(out=dvt, col_begin=2 * D, transposed=True, ldo=dvt.stride(1), rows_per_batch=Q,
+                                 out_batch_stride=dvt.stride(0))])
+            dqk3 = dqk.view(B, Q, 2 * D)
+            ops.attention(dqk3[:, :, :D], dqk3[:, :, D:], dvt, ws["datt"].view(B, Q, D), H, Lk=Q)
+            x = ops.linear(ws["datt"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=ws["tx"])
+            t1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["t1"])
+            dq = ops.linear(t1, P[p + ".ca.q.w"], P[p + ".ca.q.b"], A2=qp, a2_row_mod=Q,
+                            segs=[Seg(out=ws["dq"], use_a2=True)])
+            ops.attention(dq.view(B, Q, D), k3[:, :, l * D:(l + 1) * D], vt_all[:, l * D:(l + 1) * D, :],
+                          ws["datt"].view(B, Q, D), H, key_mask=fus_mask, Lk=L)
+            x = ops.linear(ws["datt"], P[p + ".ca.out.w"], P[p + ".ca.out.b"], R=t1, out=ws["tx"])
+            t2 = ops.layernorm(x, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["t2"])
+            h = ops.linear(t2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["dffn"])
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=t2, out=ws["tx"])
+            tgt = ops.layernorm(x, P[p + ".ln3.g"], P[p + ".ln3.b"], out=ws["tgt"])
+            ops.layernorm(tgt, P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
+        out["hs"] = hs.view(nd, B, Q, D)
+
+        # ---- heads (K11) on all decoder layers at once
+        hs2 = hs.view(nd * B * Q, D)
+        logits, spans = ws["logits"], ws["spans"]
+        ops.linear(hs2, P["class_embed.w"], P["class_embed.b"], out=logits.view(-1, 2))
+        h1 = ops.linear(hs2, P["span_embed.0.w"], P["span_embed.0.b"], act=ops.ACT_RELU, out=ws["h1"])
+        h2 = ops.linear(h1, P["span_embed.1.w"], P["span_embed.1.b"], act=ops.ACT_RELU, out=ws["h2"])
+        ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, out=spans.view(-1, 2))
+        out.update(pred_logits=logits[-1], pred_spans=spans[-1], logits_all=logits, spans_all=spans)
+        pq = vid_sum = None
+        if c.contrastive_align_loss:
+            ops.linear(hs2, P["proj_q.w"], P["proj_q.b"], out=ws["pq_raw"])
+            pq = ws["pq"]
+            ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
+            Dc = pq.shape[-1]
+            self._frame_rows_linear(frame, P["proj_v.w"], P["proj_v.b"], ws["pv_raw"], B, Tv)
+            pv = ws["pv"]
+            ops.l2norm_rows(ws["pv_raw"], out_f32=pv.view(B * Tv, Dc))
+            vid_sum = ops.masked_mean(pv, None, out=ws["vid_sum"])
+            out.update(proj_queries=pq[-1], proj_vid_mem=pv, proj_queries_all=pq)
+
+        if not with_losses:
+            return out
+        # ---- retrieval loss (K7), reference model/model_Uni.py:236-275
+        rl = ws["ret_loss"]
+        ls = P["logit_scale"]
+        wgt = float(c.dual_single_loss_weight)
+        if c.vmr_loss == "dual":
+            ops.clip_loss(ws["sims_dual"], ls, rl, weight=wgt)
+        elif c.vmr_loss == "single":
+            ops.clip_loss(ws["sims_single"], ls, rl, weight=wgt)
+        elif c.vmr_loss == "dual_single_loss_fuse":
+            ops.clip_loss(ws["sims_dual"], ls, rl, weight=1.0)
+            ops.clip_loss(ws["sims_single"], ls, rl, weight=1.0, accumulate=True)
+        else:                                                            # dual_single_sim_fuse
+            both = self.dual_sims(video, music, add=ws["sims_single"])
+            ops.clip_loss(both, ls, rl, weight=wgt)
+        out["retrieval_loss"] = rl
+        # ---- matcher + set criterion (K12-K14), all layers in one launch each
+        tg = spans_target.contiguous()
+        pi, ti, cnt, status, cost = ops.hungarian_match(logits.view(nd * B, Q, 2), spans.view(nd * B, Q, 2), tg, c.foreground_label)
+        losses, total = ops.set_criterion(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"],
+                                          c.foreground_label, P["crit_weights"])
+        out.update(matcher_pred_idx=pi.view(nd, B, -1), matcher_tgt_idx=ti.view(nd, B, -1), matcher_count=cnt.view(nd, B),
+                   matcher_status=status, criterion_losses=losses, localization_loss=total)
+        return out
+
+    def _frame_rows_linear(self, frame: Tensor, w: Tensor, b: Tensor, out: Tensor, B: int, Tv: int) -> None:
+        """Linear over the frame rows of `fus` ([B, Tv, D] view with batch stride L*D): one launch per batch
+        row block would waste launches, so express the view as A with rows_per_batch addressing on the OUTPUT
+        side only when possible; here rows are gathered by a batched launch (grid.z = B)."""
+        D = frame.shape[2]
+        ops.linear(frame[0], w, b, M=Tv, batch=B, a_z_stride=frame.stride(0), w_z_stride=0,
+                   segs=[Seg(out=out, ldo=out.stride(0), out_z_stride=Tv * out.stride(0))])
+
+    # ------------------------------------------------------------------ conveniences
+    def loss_dict(self, out: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """criterion_losses [dec,5] -> the reference's 30-entry dict (main = last layer, `_i` = layer i)."""
+        names = ["loss_span", "loss_giou", "loss_label", "class_error", "loss_contrastive_align"]
+        nd = self.cfg.detr_dec_layers
+        L = out["criterion_losses"]
+        d = {}
+        for l in range(nd):
+            suffix = "" if l == nd - 1 else f"_{l}"
+            for k, n in enumerate(names):
+                if n == "loss_contrastive_align" and not self.cfg.contrastive_align_loss:
+                    continue
+                if n == "loss_span" and not self.cfg.l1_loss:
+                    continue
+                if suffix and not self.cfg.aux_loss:
+                    continue
+                d[n + suffix] = L[l, k]
+        return d
+
+    def forward_numpy(self, inp: dict, with_losses: bool = True, want_pooled: bool = True) -> dict:
+        """Host-facing helper for tests/smoke: numpy in, numpy out (synchronises)."""
+        dev = self.device
+        t = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
+        o = self.forward(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
+                         with_losses=with_losses, want_pooled=want_pooled)
+        torch.cuda.synchronize()
+        r = {k: v.float().cpu().numpy() for k, v in o.items() if isinstance(v, torch.Tensor) and v.dtype in (torch.float32, torch.bfloat16)}
+        if with_losses:
+            if int(o["matcher_status"].cpu()) != 0:
+                raise ValueError("matrix contains invalid numeric entries")   # what SciPy raises in the reference
+            nd = self.cfg.detr_dec_layers
+            cnt = o["matcher_count"].cpu().numpy()
+            pi, ti = o["matcher_pred_idx"].cpu().numpy(), o["matcher_tgt_idx"].cpu().numpy()
+            r["matcher_indices"] = [(pi[nd - 1, b, :cnt[nd - 1, b]], ti[nd - 1, b, :cnt[nd - 1, b]]) for b in range(pi.shape[1])]
+            r["matcher_indices_all"] = [[(pi[l, b, :cnt[l, b]], ti[l, b, :cnt[l, b]]) for b in range(pi.shape[1])] for l in range(nd)]
+            r["loss_dict"] = {k: float(v.cpu()) for k, v in self.loss_dict(o).items()}
+            r["retrieval_loss"] = float(o["retrieval_loss"].cpu())
+            r["localization_loss"] = float(o["localization_loss"].cpu())
+        return r

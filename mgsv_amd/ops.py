@@ -136,13 +136,20 @@ def attention(Q: Tensor, K: Tensor, Vt: Tensor, O: Tensor, H: int, *, key_mask: 
 
 def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, out: Optional[Tensor] = None, eps: float = 1e-5,
               out_dtype: Optional[torch.dtype] = None) -> Tensor:
-    """LayerNorm over the last axis of a 2-D (row-strided) tensor."""
-    assert x.dim() == 2 and x.stride(1) == 1
+    """LayerNorm over the last axis.  x: [rows, D] (row stride free) or a [B, T, D] view of a larger buffer
+    (batch and row strides free); out: [rows, D] / [B*T, D] with free row stride."""
+    assert x.dim() in (2, 3) and x.stride(-1) == 1
+    if x.dim() == 3:
+        rows, D = x.shape[0] * x.shape[1], x.shape[2]
+        ldx, rpb, xbs = x.stride(1), x.shape[1], x.stride(0)
+    else:
+        rows, D = x.shape
+        ldx, rpb, xbs = x.stride(0), 0, 0
     if out is None:
-        out = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
-    assert out.dim() == 2 and out.stride(1) == 1
-    check(lib().made_layernorm(_p(x), dt_of(x), x.stride(0), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
-                               _p(out), dt_of(out), out.stride(0), x.shape[0], x.shape[1], eps, _stream()),
+        out = torch.empty((rows, D), device=x.device, dtype=out_dtype or x.dtype)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= rows
+    check(lib().made_layernorm(_p(x), dt_of(x), ldx, rpb, xbs, _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
+                               _p(out), dt_of(out), out.stride(0), rows, D, eps, _stream()),
           "made_layernorm")
     return out
 
@@ -217,21 +224,25 @@ def clip_loss(sims: Tensor, logit_scale: Tensor, loss_out: Tensor, weight: float
 
 
 def hungarian_match(pred_logits: Tensor, pred_spans: Tensor, targets: Tensor, fg_label: int,
-                    w_span: float = 10.0, w_giou: float = 1.0, w_class: float = 4.0):
+                    w_span: float = 10.0, w_giou: float = 1.0, w_class: float = 4.0, cost_in: Optional[Tensor] = None):
     """pred_* [NS,Q,2] (NS = layers*B), targets [B,G,2] -> (pred_idx [NS,min(Q,G)] i64, tgt_idx, count [NS] i32,
     status [1] i32, cost [NS,Q,G] f32).  No host sync: inspect `status` later (1 = SciPy would raise)."""
     NS, Q, _ = pred_logits.shape
     B, G, _ = targets.shape
     dev = pred_logits.device
     width = min(Q, G)
-    cost = torch.empty((NS, Q, G), device=dev, dtype=torch.float32)
+    if cost_in is not None:
+        assert cost_in.shape == (NS, Q, G) and cost_in.dtype == torch.float32 and cost_in.is_contiguous()
+        cost = cost_in
+    else:
+        cost = torch.empty((NS, Q, G), device=dev, dtype=torch.float32)
     pi = torch.empty((NS, width), device=dev, dtype=torch.int64)
     ti = torch.empty((NS, width), device=dev, dtype=torch.int64)
     cnt = torch.empty((NS,), device=dev, dtype=torch.int32)
     status = torch.zeros((1,), device=dev, dtype=torch.int32)
     check(lib().made_hungarian_match(_p(_f32(pred_logits, "pred_logits")), _p(_f32(pred_spans, "pred_spans")),
                                      _p(_f32(targets, "targets")), NS, B, Q, G, fg_label, w_span, w_giou, w_class,
-                                     _p(cost), _p(pi), _p(ti), _p(cnt), _p(status), _stream()), "made_hungarian_match")
+                                     _p(cost), 1 if cost_in is not None else 0, _p(pi), _p(ti), _p(cnt), _p(status), _stream()), "made_hungarian_match")
     return pi, ti, cnt, status, cost
 
 
