@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MaDe hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one eval-mode `Uni_model.forward` (reference model/model_Uni.py:177-322: both temporal
+encoders, X-Pool similarities, DETR encoder/decoder, heads, retrieval loss, Hungarian matcher and set
+criterion) over one batch of B=64 synthetic video-music pairs at BASELINE.json configs[1]
+(T_v=30, T_a=512, D=512), inputs resident in HBM.  N>1: every rank runs its own batch (pairs are
+independent; no data-path collective), value = all pairs / max-over-ranks time ("weak").
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mgsv_amd import ops, synth  # noqa: E402
+from mgsv_amd.config import cfg_headline  # noqa: E402
+from mgsv_amd.engine import MadeEngine  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    p.add_argument("--batch", type=int, default=64)
+    p.add_argument("--launch", choices=["graph", "eager"], default="graph")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=2)
+    return p.parse_args()
+
+
+def cpu_baseline(cfg, sd, inp, steps: int):
+    """The oracle (CPU restatement validated against the reference) on this box's host cores."""
+    from oracle import made_oracle as O
+    P = O.to_torch_params(sd)
+    n = torch.get_num_threads()
+
+    def one():
+        with torch.no_grad():
+            O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"],
+                      inp["spans_target"], v_duration=inp["v_duration"])
+
+    one()                                            # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    B = inp["frame_feats"].shape[0]
+    return dict(value=B / dt, unit="pairs/s", cores=n, kind="port",
+                sample=f"{steps} eval forwards of the same B={B} batch (oracle/made_oracle.py, torch CPU f32, {n} threads), {dt:.2f} s each")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL on ROCm
+
+    cfg = cfg_headline()
+    B, Tv, Ta = args.batch, cfg.max_v_frames, cfg.max_snippet_num
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, B, Tv, Ta, seed=1 + rank)
+    dev = torch.device("cuda", local)
+    eng = MadeEngine(cfg, sd, device=dev, dtype=args.dtype)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
+
+    def step():
+        return eng.forward(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = step()                                     # allocates the workspace
+    torch.cuda.synchronize()
+    launch = args.launch
+    graph = None
+    if launch == "graph":
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+            run = graph.replay
+        except Exception as ex:                      # report, do not hide: fall back to eager launches
+            print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); using eager launches", file=sys.stderr)
+            launch, graph, run = "eager", None, step
+    else:
+        run = step
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    ms = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # sanity: the step really produced finite losses and a valid matching
+    torch.cuda.synchronize()
+    assert int(out["matcher_status"].cpu()) == 0
+    assert bool(torch.isfinite(out["localization_loss"]).all()) and bool(torch.isfinite(out["retrieval_loss"]).all())
+
+    # ---- roofline leg: HIP events around every launch of the dominant kernel, same stream, same step
+    roof = None
+    per_kernel = {}
+    if rank == 0:
+        with ops.KernelTimer() as kt:
+            for _ in range(3):
+                step()
+        summ = kt.summary()
+        dom = "linear_" + args.dtype if ("linear_" + args.dtype) in summ else max(summ, key=lambda k: summ[k]["ms"])
+        d = summ[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.isfile(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = dict(bound="mfma", kernel=f"linear_kernel<{args.dtype}> (made_linear)", achieved=round(achieved, 2), peak=peak,
+                    unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
+                    launches_per_step=d["launches"] // 3, avg_launch_us=round(d["ms"] / d["launches"] * 1e3, 2),
+                    algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
+                    algorithmic_mb_per_launch=round(d["bytes"] / d["launches"] / 1e6, 3))
+        for k, v in summ.items():
+            per_kernel[k] = dict(launches_per_step=v["launches"] // 3, ms_per_step=round(v["ms"] / 3, 4),
+                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                 gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, sd, inp, args.cpu_steps)
+
+    if rank == 0:
+        line = {
+            "metric": "video-music pairs/s, eval forward (cross-modal transformer + DETR + matcher), B=64",
+            "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: B={B}, T_v={Tv}, T_a={Ta}, D={cfg.D}, enc={cfg.detr_enc_layers}, "
+                                   f"dec={cfg.detr_dec_layers}, Q={cfg.num_moment_queries}, concat fusion, fwd-only",
+                       "global_batch": world * B, "launch": launch, "parallelism": f"dp{world} (independent batches, no collective)",
+                       "accumulate": "f32", "activations": args.dtype},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": per_kernel,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,9 +3,12 @@
 // Tile: 128 x 128 outputs per 256-thread workgroup (4 waves, 2 x 2, each 64 x 64 = 2 x 2 MFMA
 // 32x32 tiles), K consumed in 128-byte slabs (64 bf16 / 32 f32 per row).  Both operands are
 // K-contiguous ([M,K] activations, [N,K] nn.Linear weights), staged global -> registers -> LDS
-// (the activation prologue: row mask, +A2, f32->bf16 conversion happens in registers), one slab
-// prefetched in registers while the previous one is multiplied.  LDS rows are padded to 144 B so
-// the 16-byte fragment reads of a wave are bank-conflict free.
+// (the activation prologue: row mask, +A2, f32->bf16 conversion happens in registers) into a
+// two-stage LDS ring: the next slab's global loads are in flight during the current slab's MFMAs
+// and there is one barrier per slab.  LDS rows are padded to 144 B so the 16-byte fragment reads
+// of a wave are bank-conflict free.  The epilogue parks the accumulators in LDS as an f32 tile and
+// streams it out row-contiguously with 16-byte loads/stores (bias, activation, residual, row mask,
+// per-batch addressing), so the output side is coalesced whatever the MFMA register layout.
 //   bf16 : v_mfma_f32_32x32x16_bf16, one per 16-byte fragment pair
 //   f32  : v_mfma_f32_32x32x2_f32, four per fragment pair (exact f32 FMA chain)
 // Transposed output segments swap the MFMA operands so that lanes run along the row (time) axis
@@ -31,14 +34,11 @@ __device__ __forceinline__ typename Frag<TC>::type zero_frag() {
     return z;
 }
 
-// Load one 16-byte compute-type fragment of A' = (A [+ A2]) at (row gm, element k).
+// Load one 16-byte compute-type fragment of A' = (A [+ A2]); p / p2 point at its first element.
 template <typename TA, typename TC>
-__device__ __forceinline__ typename Frag<TC>::type load_a_frag(const TA* __restrict__ A, int64_t lda,
-                                                               const TA* __restrict__ A2, int64_t lda2,
-                                                               int64_t a2_row_mod, int64_t gm, int64_t k) {
+__device__ __forceinline__ typename Frag<TC>::type load_a_frag(const TA* __restrict__ p, const TA* __restrict__ p2) {
     constexpr int n = elem_traits<TC>::per16;
     float v[n];
-    const TA* p = A + gm * lda + k;
     if constexpr (sizeof(TA) == 4) {
 #pragma unroll
         for (int i = 0; i < n; i += 4) {
@@ -48,12 +48,11 @@ __device__ __forceinline__ typename Frag<TC>::type load_a_frag(const TA* __restr
     } else {
         static_assert(n == 8, "bf16 activations need bf16 compute");
         bf16x8 t = *(const bf16x8*)p;
+        if (!p2) return t;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
     }
-    if (A2) {
-        int64_t r2 = a2_row_mod > 0 ? gm % a2_row_mod : gm;
-        const TA* p2 = A2 + r2 * lda2 + k;
+    if (p2) {
         if constexpr (sizeof(TA) == 4) {
 #pragma unroll
             for (int i = 0; i < n; i += 4) {
@@ -82,24 +81,46 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     }
 }
 
+// 8 consecutive f32 -> output dtype, vector store when `vec_ok`
+__device__ __forceinline__ void store8(void* out, int odt, int64_t off, const float* v, int nvalid, bool vec_ok) {
+    if (vec_ok && nvalid == 8) {
+        if (odt == MADE_F32) {
+            f32x4 a, b;
+            a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+            b[0] = v[4]; b[1] = v[5]; b[2] = v[6]; b[3] = v[7];
+            *(f32x4*)((float*)out + off) = a;
+            *(f32x4*)((float*)out + off + 4) = b;
+        } else {
+            bf16x8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[j];
+            *(bf16x8*)((bf16_t*)out + off) = t;
+        }
+    } else {
+        for (int j = 0; j < nvalid; ++j) store_from_f32(out, odt, off + j, v[j]);
+    }
+}
+
 template <typename TA, typename TC>
 __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int PER16 = elem_traits<TC>::per16;
     constexpr int KE = KB / (int)sizeof(TC);          // elements of K per stage
+    constexpr int STAGE = 2 * BM * LDS_ROW;           // bytes of one (A, W) stage
+    constexpr int CT_LD = BN + 4;                     // f32 row stride of the epilogue tile
+    static_assert(BM * CT_LD * 4 <= 2 * STAGE, "epilogue tile must fit in the staging LDS");
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * LDS_ROW];
-    unsigned char* lds_a = lds;
-    unsigned char* lds_w = lds + BM * LDS_ROW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int64_t n_tiles = (a.N + BN - 1) / BN;
-    const int64_t tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
-    const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
+    const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+    const int n_tiles = (N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int64_t z = blockIdx.z;
 
     // segment of this column tile
@@ -110,39 +131,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
     const MadeLinearSeg seg = a.seg[si];
     const bool transposed = seg.transposed != 0;
 
-    const TA* A = (const TA*)a.A + z * a.a_z_stride;
-    const TA* A2 = (seg.use_a2 && a.A2) ? (const TA*)a.A2 : nullptr;
-    const TC* W = (const TC*)a.W + z * a.w_z_stride;
-
-    // staging assignment: 4 chunks of A and 4 of W per thread
-    frag_t ra[4], rw[4];
-    int srow[4], skc[4];
-    bool a_ok[4], w_ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = tid + i * NTHREADS;
-        srow[i] = c >> 3;
-        skc[i] = c & 7;
-        int64_t gm = m0 + srow[i];
-        a_ok[i] = gm < a.M && (a.a_row_mask == nullptr || a.a_row_mask[gm] != 0.f);
-        w_ok[i] = (n0 + srow[i]) < a.N;
-    }
-
-    auto load_stage = [&](int64_t k0) {
+    // ---- staging assignment: thread owns 16-byte chunk kc of rows srow0 + 32*i (i = 0..3) of A and of W.
+    // All row-dependent address math is done once here, not per K slab.
+    const int kc = tid & 7, srow0 = tid >> 3;
+    const TA* pa[4];
+    const TA* pa2[4];
+    const TC* pw[4];
+    {
+        const TA* A = (const TA*)a.A + z * a.a_z_stride;
+        const TA* A2 = (seg.use_a2 && a.A2) ? (const TA*)a.A2 : nullptr;
+        const TC* W = (const TC*)a.W + z * a.w_z_stride;
+        const int a2mod = (int)a.a2_row_mod;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int64_t k = k0 + skc[i] * PER16;
-            bool kin = k < a.K;
-            ra[i] = (a_ok[i] && kin) ? load_a_frag<TA, TC>(A, a.lda, A2, a.lda2, a.a2_row_mod, m0 + srow[i], k)
-                                     : zero_frag<TC>();
-            rw[i] = (w_ok[i] && kin) ? *(const frag_t*)(W + (n0 + srow[i]) * a.ldw + k) : zero_frag<TC>();
+            int gm = m0 + srow0 + 32 * i, gn = n0 + srow0 + 32 * i;
+            bool ok = gm < M && (a.a_row_mask == nullptr || a.a_row_mask[gm] != 0.f);
+            pa[i] = ok ? A + (int64_t)gm * a.lda + kc * PER16 : nullptr;
+            pa2[i] = (ok && A2) ? A2 + (int64_t)(a2mod > 0 ? gm % a2mod : gm) * a.lda2 + kc * PER16 : nullptr;
+            pw[i] = gn < N ? W + (int64_t)gn * a.ldw + kc * PER16 : nullptr;
+        }
+    }
+    frag_t ra[4], rw[4];
+    auto load_stage = [&](int k0) {
+        const bool kin = k0 + kc * PER16 < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (pa[i] && kin) ? load_a_frag<TA, TC>(pa[i] + k0, pa2[i] ? pa2[i] + k0 : nullptr) : zero_frag<TC>();
+            rw[i] = (pw[i] && kin) ? *(const frag_t*)(pw[i] + k0) : zero_frag<TC>();
         }
     };
-    auto store_stage = [&]() {
+    auto store_stage = [&](unsigned char* st) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(frag_t*)(lds_a + srow[i] * LDS_ROW + skc[i] * 16) = ra[i];
-            *(frag_t*)(lds_w + srow[i] * LDS_ROW + skc[i] * 16) = rw[i];
+            *(frag_t*)(st + (srow0 + 32 * i) * LDS_ROW + kc * 16) = ra[i];
+            *(frag_t*)(st + BM * LDS_ROW + (srow0 + 32 * i) * LDS_ROW + kc * 16) = rw[i];
         }
     };
 
@@ -154,19 +176,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int64_t nk = (a.K + KE - 1) / KE;
+    // ---- main loop: two LDS stages, next slab's global loads in flight during the MFMAs, one barrier per slab
+    const int nk = (K + KE - 1) / KE;
     load_stage(0);
-    store_stage();
+    store_stage(lds);
     __syncthreads();
-    for (int64_t kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* cur = lds + (kt & 1) * STAGE;
         if (kt + 1 < nk) load_stage((kt + 1) * KE);
+        const unsigned char* la = cur + (wm * 64 + r) * LDS_ROW + hh * 16;
+        const unsigned char* lw = cur + BM * LDS_ROW + (wn * 64 + r) * LDS_ROW + hh * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             frag_t fa[2], fw[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fa[t] = *(const frag_t*)(lds_a + (wm * 64 + t * 32 + r) * LDS_ROW + ks * 32 + hh * 16);
-                fw[t] = *(const frag_t*)(lds_w + (wn * 64 + t * 32 + r) * LDS_ROW + ks * 32 + hh * 16);
+                fa[t] = *(const frag_t*)(la + t * 32 * LDS_ROW + ks * 32);
+                fw[t] = *(const frag_t*)(lw + t * 32 * LDS_ROW + ks * 32);
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -188,77 +214,109 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
                     }
                 }
         }
+        if (kt + 1 < nk) store_stage(lds + ((kt + 1) & 1) * STAGE);   // other stage: nobody reads it now
         __syncthreads();
-        if (kt + 1 < nk) {
-            store_stage();
-            __syncthreads();
-        }
     }
 
-    // ---- epilogue -------------------------------------------------------------------------
-    // acc[mt][nt][e]: normal     -> row m = (mt, e, hh), col n = (nt, lane)
-    //                 transposed -> row m = (mt, lane),  col n = (nt, e, hh)
-    unsigned char* outp = (unsigned char*)seg.out;
-    const int64_t out_z = z * seg.out_z_stride;
-    const int M = (int)a.M, N = (int)a.N;
-    const int mbase = (int)m0 + wm * 64, nbase = (int)n0 + wn * 64;
-    const int rpb = (int)seg.rows_per_batch, rmod = (int)a.r_row_mod;
-    const int colb = (int)seg.col_begin;
-
-    // per-row quantities: validity, output row offset, residual row offset
-    auto row_info = [&](int m, bool& ok, bool& zero, int64_t& orow, int64_t& rrow) {
-        ok = m < M;
-        zero = false; orow = 0; rrow = 0;
-        if (!ok) return;
-        zero = a.out_row_mask != nullptr && a.out_row_mask[m] == 0.f;
-        if (rpb > 0) {
-            int b = m / rpb, t = m - b * rpb;
-            orow = transposed ? (int64_t)b * seg.out_batch_stride + t
-                              : (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo;
-        } else {
-            orow = transposed ? (int64_t)m : (int64_t)m * seg.ldo;
-        }
-        int rr = rmod > 0 ? m % rmod : m;
-        rrow = (int64_t)rr * a.ldr;
-    };
-    auto finish = [&](float v, int n, bool zero, int64_t orow, int64_t rrow) {
-        if (a.bias) v += a.bias[n];
-        v = apply_act(v, a.act);
-        if (a.R) v += load_as_f32(a.R, a.r_dtype, rrow + n);
-        if (zero) v = 0.f;
-        int col = n - colb;
-        int64_t off = transposed ? orow + (int64_t)col * seg.ldo : orow + col;
-        store_from_f32(outp, seg.out_dtype, out_z + off, v);
-    };
-
-    if (!transposed) {
+    // ---- epilogue: accumulators -> LDS tile (f32) -> row-contiguous, vectorised global I/O ----------
+    // normal:     Ct[row = m_local][col = n_local]
+    // transposed: Ct[row = n_local][col = m_local]   (MFMA operands were swapped above)
+    float* Ct = (float*)lds;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                bool ok, zero; int64_t orow, rrow;
-                row_info(mbase + mt * 32 + acc_row(e, hh), ok, zero, orow, rrow);
-                if (ok) {
+                int row, col;
+                if (transposed) { row = wn * 64 + nt * 32 + acc_row(e, hh); col = wm * 64 + mt * 32 + r; }
+                else            { row = wm * 64 + mt * 32 + acc_row(e, hh); col = wn * 64 + nt * 32 + r; }
+                Ct[row * CT_LD + col] = acc[mt][nt][e];
+            }
+    __syncthreads();
+
+    unsigned char* outp = (unsigned char*)seg.out;
+    const int64_t out_z = z * seg.out_z_stride;
+    const int rpb = (int)seg.rows_per_batch, rmod = (int)a.r_row_mod;
+    const int colb = (int)seg.col_begin;
+    const int odt = seg.out_dtype;
+
+    if (!transposed) {
+        const int cc = tid & 15;                       // 8-column chunk inside the tile row
+        const int n = n0 + cc * 8;
+        int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+        if (nvalid > 0) {
+            float bv[8];
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        int n = nbase + nt * 32 + r;
-                        if (n < N) finish(acc[mt][nt][e], n, zero, orow, rrow);
+            for (int j = 0; j < 8; ++j) bv[j] = (a.bias && j < nvalid) ? a.bias[n + j] : 0.f;
+            const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
+                                 (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
+            const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+#pragma unroll 2
+            for (int i = 0; i < 8; ++i) {
+                const int row = (tid >> 4) + 16 * i;
+                const int m = m0 + row;
+                if (m >= M) break;
+                const float* cp = Ct + row * CT_LD + cc * 8;
+                f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+                float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], a.act);
+                if (a.R) {
+                    const int rr = rmod > 0 ? m % rmod : m;
+                    const int64_t ro = (int64_t)rr * a.ldr + n;
+                    if (r_vec && nvalid == 8) {
+                        if (a.r_dtype == MADE_F32) {
+                            f32x4 r0 = *(const f32x4*)((const float*)a.R + ro), r1 = *(const f32x4*)((const float*)a.R + ro + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
+                        } else {
+                            bf16x8 rb = *(const bf16x8*)((const bf16_t*)a.R + ro);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)rb[j];
+                        }
+                    } else {
+                        for (int j = 0; j < nvalid; ++j) v[j] += load_as_f32(a.R, a.r_dtype, ro + j);
                     }
                 }
+                if (a.out_row_mask && a.out_row_mask[m] == 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+                }
+                int64_t orow;
+                if (rpb > 0) {
+                    const int b = m / rpb, t = m - b * rpb;
+                    orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo;
+                } else {
+                    orow = (int64_t)m * seg.ldo;
+                }
+                store8(outp, odt, out_z + orow + (n - colb), v, nvalid, out_vec);
             }
+        }
     } else {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            bool ok, zero; int64_t orow, rrow;
-            row_info(mbase + mt * 32 + r, ok, zero, orow, rrow);
-            if (ok) {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        int n = nbase + nt * 32 + acc_row(e, hh);
-                        if (n < N) finish(acc[mt][nt][e], n, zero, orow, rrow);
-                    }
+        // lanes run along m (the time axis of the transposed output): coalesced element stores
+        const int col = tid & 127;                     // m_local
+        const int m = m0 + col;
+        if (m < M) {
+            int64_t obase;
+            if (rpb > 0) {
+                const int b = m / rpb, t = m - b * rpb;
+                obase = (int64_t)b * seg.out_batch_stride + t;
+            } else {
+                obase = m;
+            }
+            const bool zero = a.out_row_mask != nullptr && a.out_row_mask[m] == 0.f;
+            const int rr = rmod > 0 ? m % rmod : m;
+            for (int i = 0; i < 64; ++i) {
+                const int row = (tid >> 7) + 2 * i;    // n_local
+                const int n = n0 + row;
+                if (n >= N) break;
+                float v = Ct[row * CT_LD + col];
+                if (a.bias) v += a.bias[n];
+                v = apply_act(v, a.act);
+                if (a.R) v += load_as_f32(a.R, a.r_dtype, (int64_t)rr * a.ldr + n);
+                if (zero) v = 0.f;
+                store_from_f32(outp, odt, out_z + obase + (int64_t)(n - colb) * seg.ldo, v);
             }
         }
     }

@@ -54,6 +54,49 @@ def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+    `with KernelTimer() as kt: engine.forward(...)` brackets every made_linear / made_attention launch
+    with a pair of events; `kt.summary()` synchronises and returns per-kind totals."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _timer
+        self._prev, _timer = _timer, self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = self._prev
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, s, e, flops, nbytes, _desc in self.records:
+            d = out.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def _timed(kind: str, flops: float, nbytes: float, launch, desc: str = ""):
+    if _timer is None:
+        return launch()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = launch()
+    e.record()
+    _timer.records.append((kind, s, e, flops, nbytes, desc))
+    return r
+
+
 @dataclass
 class Seg:
     """One column segment of made_linear's output (include/made_hip.h: MadeLinearSeg)."""
@@ -106,7 +149,12 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
         sg.ldo = s.ldo if s.ldo is not None else s.out.stride(-2)
         sg.rows_per_batch, sg.out_batch_stride, sg.out_z_stride = s.rows_per_batch, s.out_batch_stride, s.out_z_stride
         sg.use_a2 = 1 if s.use_a2 else 0
-    check(lib().made_linear(C.byref(a), _stream()), "made_linear")
+    esz = 4 if a.w_dtype == F32 else 2
+    kind = "linear_" + ("f32" if a.w_dtype == F32 else ("bf16" if a.a_dtype == BF16 else "f32in_bf16"))
+    flops = 2.0 * M * N * K * batch
+    nbytes = batch * (M * K * (4 if a.a_dtype == F32 else 2) + N * K * esz + M * N * esz)
+    _timed(kind, flops, nbytes, lambda: check(lib().made_linear(C.byref(a), _stream()), "made_linear"),
+           f"M={M} N={N} K={K} z={batch} nseg={len(segs)} a2={int(A2 is not None)} R={int(R is not None)} act={act} tr={int(any(s_.transposed for s_ in segs))}")
     return segs[0].out
 
 
@@ -130,7 +178,11 @@ def attention(Q: Tensor, K: Tensor, Vt: Tensor, O: Tensor, H: int, *, key_mask: 
     a.key_mask = _p(_f32(key_mask, "key_mask"))
     a.q_mask = _p(_f32(q_mask, "q_mask"))
     a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
-    check(lib().made_attention(C.byref(a), _stream()), "made_attention")
+    esz = 4 if a.dtype == F32 else 2
+    flops = 4.0 * B * H * Lq * a.Lk * hd
+    nbytes = esz * B * D * (2 * Lq + 2 * a.Lk)
+    _timed("attention_" + ("f32" if a.dtype == F32 else "bf16"), flops, nbytes,
+           lambda: check(lib().made_attention(C.byref(a), _stream()), "made_attention"), f"B={B} H={H} hd={hd} Lq={Lq} Lk={a.Lk}")
     return O
 
 
