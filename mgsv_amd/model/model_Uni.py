@@ -1,0 +1,186 @@
+"""Drop-in `Uni_model` for the reference's drivers (reference model/model_Uni.py:14-322).
+
+Same constructor `Uni_model(args, device=None, logger=None)`, same `forward(...)` signature and
+5-dict return value, same parameter-group getters, same attributes the drivers poke
+(`criterion.foreground_label`, `criterion.weight_dict`, `video_guided_to_music_pooling_cross_transformer`)
+and the same `state_dict()` key layout, so a reference checkpoint loads (the frozen `vit_model.*` /
+`ast_model.*` tensors a real checkpoint also carries are ignored: they are never used on the feature
+path).  Underneath, every op runs as a hand-written HIP kernel through
+libmade_hip.so (mgsv_amd/engine.py); there is no ATen fallback -- on a box without the library or a
+GPU the model raises.
+
+Scope of this round: inference (`torch.no_grad()` / `model.eval()`): the full forward including the
+retrieval loss, Hungarian matcher and set criterion values.  Backward kernels are not written yet, so
+calling forward with autograd enabled in train mode raises NotImplementedError instead of silently
+returning losses that cannot be differentiated.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import synth
+from ..config import MadeConfig
+from ..engine import MadeEngine
+
+_FROZEN_PREFIXES = ("vit_model.", "ast_model.")
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+class _Criterion(nn.Module):
+    """Holds what the drivers read from `model.criterion` (reference music_detr/loss_detr.py:36-57)."""
+
+    def __init__(self, cfg: MadeConfig):
+        super().__init__()
+        from ..music_detr.loss_detr import weight_dict
+        self.foreground_label = cfg.foreground_label
+        self.background_label = cfg.background_label
+        self.weight_dict = weight_dict(cfg)
+
+
+class _XPoolModule(nn.Module):
+    """`model.video_guided_to_music_pooling_cross_transformer`: the drivers call it directly on the
+    whole split (reference train-MaDe.py:588-591, test-MaDe.py:392-395).  `.cpu()` / `.to()` are accepted
+    and ignored: the computation always runs on the GPU in track chunks."""
+
+    def __init__(self, owner: "Uni_model"):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, video_embeds, music_embeds, music_mask=None):
+        if music_mask is None:
+            raise NotImplementedError("fusion_mask=0 (unmasked X-Pool attention) is not on the HIP path yet")
+        eng = self._owner._engine_ready()
+        dev = eng.device
+        v = video_embeds.to(dev, torch.float32).contiguous()
+        s = music_embeds.to(dev).to(eng.tc).contiguous()
+        m = music_mask.to(dev, torch.float32).contiguous()
+        Nm, Nv, D = s.shape[0], v.shape[0], v.shape[1]
+        pooled = torch.empty(Nm * Nv, D, device=dev, dtype=torch.float32)
+        eng.xpool_sims(v, s, m, pooled_out=pooled)
+        return pooled.view(Nm, Nv, D).to(video_embeds.device)
+
+    def cpu(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+
+class Uni_model(nn.Module):
+    def __init__(self, args, device=None, logger=None, compute_dtype: Optional[str] = None):
+        super().__init__()
+        self.args = args
+        self.device = torch.device(device) if device is not None else torch.device("cuda:0")
+        self.logger = logger
+        assert args.hidden_dim == args.dim_input, "hidden_dim must equal to dim_input"
+        self.cfg = MadeConfig.from_args(args)
+        self.dim_input = self.cfg.D
+        self.num_moment_queries = self.cfg.num_moment_queries
+        self.aux_loss = self.cfg.aux_loss
+        self.compute_dtype = compute_dtype or getattr(args, "compute_dtype", "f32")
+        # parameters and persistent buffers with the reference's names and shapes
+        sd = synth.make_state_dict(self.cfg, seed=0)
+        xa = "video_guided_to_music_pooling_cross_transformer"
+        xpool = _XPoolModule(self)
+        for name, arr in sd.items():
+            t = torch.from_numpy(arr.copy())
+            is_buf = name.endswith(".pe") or name == "criterion.empty_weight"
+            if name.startswith("criterion."):
+                continue
+            target, rel = (xpool, name[len(xa) + 1:]) if name.startswith(xa + ".") else (self, name)
+            _attach(target, rel, t, is_buf)
+        self.add_module(xa, xpool)
+        self.criterion = _Criterion(self.cfg)
+        self.criterion.register_buffer("empty_weight", torch.from_numpy(sd["criterion.empty_weight"].copy()))
+        self._engine: Optional[MadeEngine] = None
+        self._engine_stamp = None
+
+    # ---- parameter groups (reference model/model_Uni.py:73-114, model_Base.py:379-404)
+    def _params(self, prefixes) -> List[nn.Parameter]:
+        return [p for n, p in self.named_parameters() if n.startswith(tuple(prefixes))]
+
+    def get_temporal_parameter(self):
+        return self._params(["vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer."])
+
+    def get_matching_parameter(self):
+        return self._params(["video_guided_to_music_pooling_cross_transformer."]) + [self.logit_scale]
+
+    def get_detection_parameter(self):
+        return self._params(["detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_"])
+
+    # ---- state handling
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        filtered = {k: v for k, v in state_dict.items() if not k.startswith(_FROZEN_PREFIXES)}
+        res = super().load_state_dict(filtered, strict=strict, **kw)
+        self._engine_stamp = None
+        return res
+
+    def _stamp(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _engine_ready(self) -> MadeEngine:
+        stamp = self._stamp()
+        if self._engine is None:
+            self._engine = MadeEngine(self.cfg, self.state_dict(), device=self.device, dtype=self.compute_dtype)
+        elif stamp != self._engine_stamp:
+            self._engine.load_state_dict(self.state_dict())
+        self._engine_stamp = stamp
+        return self._engine
+
+    # ---- forward (reference model/model_Uni.py:177-322)
+    def forward(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, v_duration=None,
+                video_ids=None, music_ids=None, is_train=False):
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("training (backward kernels) is not implemented on the HIP path yet; "
+                                      "use model.eval() / torch.no_grad() for inference")
+        if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse") or "XA" not in self.cfg.vmr_fusion:
+            raise ValueError(f"Error: vmr_loss={self.cfg.vmr_loss} and vmr_fusion={self.cfg.vmr_fusion} is not supported in VMR_model")
+        eng = self._engine_ready()
+        dev = eng.device
+        f32 = torch.float32
+        o = eng.forward(frame_feats.to(dev, f32), segment_feats.to(dev, f32), frame_masks.to(dev, f32),
+                        segment_masks.to(dev, f32), spans_target.to(dev, f32))
+        nd, cfg = self.cfg.detr_dec_layers, self.cfg
+        output_map: Dict[str, object] = {"pred_logits": o["pred_logits"], "pred_spans": o["pred_spans"]}
+        if cfg.contrastive_align_loss:
+            output_map.update(proj_queries=o["proj_queries"], proj_vid_mem=o["proj_vid_mem"])
+        if cfg.aux_loss:
+            aux = []
+            for i in range(nd - 1):
+                d = {"pred_logits": o["logits_all"][i], "pred_spans": o["spans_all"][i]}
+                if cfg.contrastive_align_loss:
+                    d.update(proj_queries=o["proj_queries_all"][i], proj_vid_mem=o["proj_vid_mem"])
+                aux.append(d)
+            output_map["aux_outputs"] = aux
+        loss_map = {"retrieval_loss": o["retrieval_loss"][0], "localization_loss": o["localization_loss"][0],
+                    "localization_loss_dict": eng.loss_dict(o)}
+        feat_map = {"video_feats": o["video_feats"], "music_feats": o["music_feats"],
+                    "frame_feats": o["frame_feats"].float(), "segment_feats": o["segment_feats"].float()}
+        mask_map = {"frame_masks": frame_masks, "segment_masks": segment_masks}
+        id_map = {"video_ids": video_ids, "music_ids": music_ids}
+        self.last_matcher = {k: o[k] for k in ("matcher_pred_idx", "matcher_tgt_idx", "matcher_count", "matcher_status")}
+        return output_map, loss_map, feat_map, mask_map, id_map
+
+    # ---- retrieval assembly (reference test-MaDe.py:386-403) as one call
+    @torch.no_grad()
+    def retrieval_sim_matrix(self, video_embeds, segment_embeds, segment_masks, music_embeds):
+        eng = self._engine_ready()
+        dev = eng.device
+        return eng.retrieval_sim_matrix(video_embeds.to(dev, torch.float32).contiguous(), segment_embeds.to(dev).contiguous(),
+                                        segment_masks.to(dev, torch.float32).contiguous(),
+                                        music_embeds.to(dev, torch.float32).contiguous())

@@ -1,0 +1,64 @@
+"""GPU: the drop-in `Uni_model` (same ctor / forward signature / state_dict layout as the reference's
+model/model_Uni.py) against the reference's golden vectors."""
+import ast
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mgsv_amd import synth  # noqa: E402
+from mgsv_amd.config import cfg_native, cfg_plumbing  # noqa: E402
+from mgsv_amd.model import Uni_model  # noqa: E402
+
+
+def test_dropin_forward_and_state_dict(golden_dir):
+    fix = np.load(os.path.join(golden_dir, "forward_native_Q3_B4.npz"))
+    cfg = cfg_native()
+    for k, v in ast.literal_eval(str(fix["meta_cfg_overrides"])):
+        setattr(cfg, k, v)
+    args = cfg.to_args(local_rank=0)
+    model = Uni_model(args, device=torch.device("cuda:0"), logger=logging.getLogger("t"))
+    sd_np = synth.make_state_dict(cfg, seed=0)
+    assert set(model.state_dict().keys()) == set(sd_np.keys())            # the reference's key layout
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    sd["vit_model.visual.proj"] = torch.zeros(3)                          # frozen-encoder keys of a real checkpoint are tolerated
+    model.load_state_dict(sd)
+    model.eval()
+    inp = synth.make_inputs(cfg, int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"]), seed=1)
+    t = {k: torch.from_numpy(v) for k, v in inp.items() if isinstance(v, np.ndarray)}      # CPU tensors, like a DataLoader batch
+    with torch.no_grad():
+        om, lm, fm, mm, im = model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
+                                   v_duration=t["v_duration"], video_ids=inp["video_ids"], music_ids=inp["music_ids"], is_train=False)
+    torch.cuda.synchronize()
+    for k in ("pred_logits", "pred_spans", "proj_queries"):
+        np.testing.assert_allclose(om[k].cpu().numpy(), fix[k], atol=1e-4, rtol=0, err_msg=k)
+    assert len(om["aux_outputs"]) == cfg.detr_dec_layers - 1
+    for i, aux in enumerate(om["aux_outputs"]):
+        np.testing.assert_allclose(aux["pred_spans"].cpu().numpy(), fix[f"aux{i}_pred_spans"], atol=1e-4, rtol=0)
+    for k in ("video_feats", "music_feats"):
+        np.testing.assert_allclose(fm[k].cpu().numpy(), fix[k], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(float(lm["retrieval_loss"]), float(fix["retrieval_loss"]), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(float(lm["localization_loss"]), float(fix["localization_loss"]), rtol=2e-4, atol=5e-4)
+    assert set(lm["localization_loss_dict"]) == {k[5:] for k in fix.files if k.startswith("loss_")}
+    wd = model.criterion.weight_dict
+    total = sum(float(lm["localization_loss_dict"][k]) * wd[k] for k in lm["localization_loss_dict"] if k in wd)
+    np.testing.assert_allclose(total, float(fix["localization_loss"]), rtol=2e-4, atol=5e-4)
+    assert model.criterion.foreground_label == 0
+    # parameter groups as the reference's optimizer builds them; decoder_query_embed is in none
+    n_groups = sum(p.numel() for g in (model.get_temporal_parameter(), model.get_matching_parameter(), model.get_detection_parameter()) for p in g)
+    n_all = sum(p.numel() for p in model.parameters())
+    assert n_all - n_groups == model.decoder_query_embed.weight.numel()
+    # the X-Pool block called directly on "the whole split", as test-MaDe.py:392-395 does
+    xa = model.video_guided_to_music_pooling_cross_transformer
+    xa.cpu()
+    pooled = xa(fm["video_feats"].cpu(), fm["segment_feats"].cpu(), mm["segment_masks"])
+    xa.to(torch.device("cuda:0"))
+    np.testing.assert_allclose(pooled.numpy()[:, :, ::5], fix["music_feats_pooled_sub"], atol=1e-4, rtol=0)
+    # training mode with autograd is refused loudly (no silent non-differentiable losses)
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
