@@ -126,6 +126,32 @@ typedef struct MadeAttnArgs {
 int made_attention(const MadeAttnArgs* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * made_attention_wide: single-head attention with head dimension = model width D (256 or 512),
+ * keys and values ROW-major, flash style.  O[b, nq, :] = softmax_t(<Q[b,nq], K[b,t]+Kadd[b,t]>*scale
+ * + key mask) . V[b, t, :].
+ * Replaces (a) the X-Pool attention core, reference modules/transformer.py:110-119 (queries = all
+ * videos, shared by every track: q_bs = 0), and (b) the DETR decoder cross-attention of reference
+ * music_detr/transformer.py:293-296 evaluated in memory space: with W_k moved onto the query and
+ * W_v onto the pooled rows, keys = memory + pos (Kadd), values = memory, and the H*Q rows
+ * q'_{h,q} = W_k,h^T q_h are the "queries" -- this removes the [B*L, D] x [D, 2*dec*D] projection of
+ * the memory (25 % of the forward flops) for the small Q the model uses.
+ *   query index nq = i1*NQ2 + i2 addresses Q at b*q_bs + i1*q_s1 + i2*q_s2 and O at
+ *   b*o_bs + i1*o_s1 + i2*o_s2; K/Kadd/V rows at b*{k,kadd,v}_bs + t*ld{k,kadd,v}.
+ *   Kadd may be NULL; V may alias K (then loaded once).  key_mask [B, L] f32 or NULL.
+ *   dtype = compute dtype of Q/K/Kadd/V; o_dtype = dtype of O.  All-masked rows give NaN.
+ */
+typedef struct MadeWideAttnArgs {
+    const void* Q; const void* K; const void* Kadd; const void* V; void* O;
+    const float* key_mask;
+    int32_t dtype; int32_t o_dtype;
+    int64_t B, NQ1, NQ2, L, D;
+    int64_t q_bs, q_s1, q_s2, k_bs, ldk, kadd_bs, ldkadd, v_bs, ldv, o_bs, o_s1, o_s2;
+    float scale; int32_t _pad;
+} MadeWideAttnArgs;
+
+int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).                                                                   */
 
 /* y = LayerNorm(x) * gamma + beta, eps inside the sqrt; one wave per row, D <= 2048, D % 4 == 0.

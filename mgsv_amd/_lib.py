@@ -48,6 +48,15 @@ class MadeAttnArgs(C.Structure):
                 ("scale", f32), ("_pad", i32)]
 
 
+class MadeWideAttnArgs(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("Kadd", vp), ("V", vp), ("O", vp), ("key_mask", vp),
+                ("dtype", i32), ("o_dtype", i32),
+                ("B", i64), ("NQ1", i64), ("NQ2", i64), ("L", i64), ("D", i64),
+                ("q_bs", i64), ("q_s1", i64), ("q_s2", i64), ("k_bs", i64), ("ldk", i64), ("kadd_bs", i64), ("ldkadd", i64),
+                ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("o_s1", i64), ("o_s2", i64),
+                ("scale", f32), ("_pad", i32)]
+
+
 # name -> (restype, argtypes); every symbol include/made_hip.h declares
 SIGNATURES = {
     "made_abi_version": (C.c_int, []),
@@ -55,6 +64,7 @@ SIGNATURES = {
     "made_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "made_linear": (C.c_int, [C.POINTER(MadeLinearArgs), vp]),
     "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
+    "made_attention_wide": (C.c_int, [C.POINTER(MadeWideAttnArgs), vp]),
     "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp]),
     "made_masked_mean": (C.c_int, [vp, i32, i64, i64, vp, vp, i64, i64, i64, vp]),
     "made_l2norm_rows": (C.c_int, [vp, i32, i64, vp, vp, i32, i64, i64, i64, f32, vp]),

@@ -1,0 +1,270 @@
+// made_attention_wide: single-head attention whose head dimension is the whole model width D
+// (256 or 512), keys / values row-major, scores never in HBM.  gfx950.
+//
+// Two users on the MaDe path:
+//   * the X-Pool block (reference modules/transformer.py:87-123): queries = all videos (shared by
+//     every batch entry = music track), keys/values = that track's projected segments;
+//   * the DETR decoder's cross-attention evaluated in MEMORY SPACE: for few queries per sample it is
+//     cheaper to move W_k onto the query (q' = W_k,h^T q_h, one row of width D per head) and W_v onto
+//     the pooled result than to project all L memory rows for all 6 layers -- then keys = memory + pos,
+//     values = memory, "queries" = H*Q rows of width D per sample.
+//
+// One workgroup = 4 waves = 32 queries of one batch entry.  The four waves SPLIT D: wave w contracts
+// its quarter of D in S^T = K Q^T (swapped product: query on the lane, keys in the registers), the four
+// partial 32x32 tiles are summed through LDS so every wave holds the full scores, does the online
+// softmax redundantly (cheap) and accumulates ITS quarter of O^T += V^T P^T, reading the row-major V
+// tile as an MFMA A operand with ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32: lane = d).
+// Keys are consumed 32 at a time; K (+Kadd) and V tiles are staged global -> registers -> LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int WQ = 32;        // queries per workgroup
+constexpr int WKEY = 32;      // keys per tile
+constexpr int NTHREADS = 256;
+
+template <typename TC> struct Frag;
+template <> struct Frag<float>  { typedef f32x4  type; };
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+
+
+template <typename TC, int D>
+__global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWideAttnArgs a) {
+    typedef typename Frag<TC>::type frag_t;
+    constexpr int SZ = (int)sizeof(TC);
+    constexpr bool IS_BF16 = SZ == 2;
+    constexpr int PER16 = 16 / SZ;
+    constexpr int DS = D / 4;                       // this wave's slice of D
+    constexpr int K_ROW = D * SZ + 16;              // padded: conflict-free 16-byte row reads
+    constexpr int V_ROW = D * SZ + (IS_BF16 ? 64 : 16);   // bf16: 4 consecutive rows land on disjoint bank quarters (tr reads)
+    constexpr int CPR = D * SZ / 16;                // 16-byte chunks per row
+    constexpr int NCH = WKEY * CPR / NTHREADS;      // chunks per thread per tensor
+    static_assert(WKEY * CPR % NTHREADS == 0, "staging split");
+    constexpr int NQF = DS * SZ / 32;               // k-steps (16-byte fragment pairs) of this wave's QK slice
+    constexpr int NDT = DS / 32;                    // 32-row tiles of this wave's O^T slice
+    constexpr bool PREFETCH = IS_BF16;              // f32 (parity mode) has no registers to spare
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* lds_k = lds;
+    unsigned char* lds_v = lds + WKEY * K_ROW;
+    float* lds_s = (float*)(lds + WKEY * K_ROW + WKEY * V_ROW);      // [4][32*32] partial score tiles
+    float* lds_bias = lds_s + 4 * 1024;                               // [32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int64_t b = blockIdx.y;
+    const int64_t nq_total = a.NQ1 * a.NQ2;
+    const int64_t nq0 = (int64_t)blockIdx.x * WQ;
+
+    const TC* Kg = (const TC*)a.K + b * a.k_bs;
+    const TC* Ag = a.Kadd ? (const TC*)a.Kadd + b * a.kadd_bs : nullptr;
+    const TC* Vg = (const TC*)a.V + b * a.v_bs;
+    const bool v_is_k = (a.V == a.K) && a.v_bs == a.k_bs && a.ldv == a.ldk;
+    const float* maskg = a.key_mask ? a.key_mask + b * a.L : nullptr;
+
+    // ---- Q fragments of this wave's D slice: lane (r, hh) holds Q[nq0 + r][w*DS + ks*2*PER16 + hh*PER16 ..]
+    frag_t qf[NQF];
+    int64_t my_q = nq0 + r;
+    {
+        int64_t q = my_q < nq_total ? my_q : nq_total - 1;
+        const TC* qp = (const TC*)a.Q + b * a.q_bs + (q / a.NQ2) * a.q_s1 + (q % a.NQ2) * a.q_s2 + wave * DS;
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) qf[ks] = *(const frag_t*)(qp + ks * 2 * PER16 + hh * PER16);
+    }
+
+    frag_t rk[NCH], rv[NCH];
+    float rbias = 0.f;
+    auto load_tile = [&](int64_t key0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NTHREADS;
+            int row = c / CPR, cc = c % CPR;
+            int64_t key = key0 + row;
+            if (key < a.L) {
+                frag_t kv = *(const frag_t*)(Kg + key * a.ldk + cc * PER16);
+                rv[i] = v_is_k ? kv : *(const frag_t*)(Vg + key * a.ldv + cc * PER16);
+                if (Ag) {
+                    frag_t av = *(const frag_t*)(Ag + key * a.ldkadd + cc * PER16);
+#pragma unroll
+                    for (int j = 0; j < PER16; ++j) kv[j] = from_f32<TC>(to_f32(kv[j]) + to_f32(av[j]));
+                }
+                rk[i] = kv;
+            } else {
+#pragma unroll
+                for (int j = 0; j < PER16; ++j) { rk[i][j] = (TC)0.f; rv[i][j] = (TC)0.f; }
+            }
+        }
+        if (tid < WKEY) {
+            int64_t key = key0 + tid;
+            bool valid = key < a.L && (maskg == nullptr || maskg[key] != 0.f);
+            rbias = valid ? 0.f : -INFINITY;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NTHREADS;
+            *(frag_t*)(lds_k + (c / CPR) * K_ROW + (c % CPR) * 16) = rk[i];
+            *(frag_t*)(lds_v + (c / CPR) * V_ROW + (c % CPR) * 16) = rv[i];
+        }
+        if (tid < WKEY) lds_bias[tid] = rbias;
+    };
+
+    f32x16 o[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int64_t ntiles = (a.L + WKEY - 1) / WKEY;
+    if (PREFETCH) load_tile(0);
+    for (int64_t t = 0; t < ntiles; ++t) {
+        if (!PREFETCH) load_tile(t * WKEY);
+        __syncthreads();                                  // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (PREFETCH && t + 1 < ntiles) load_tile((t + 1) * WKEY);
+
+        // ---- partial S^T [32 keys x 32 queries] over this wave's D slice
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) {
+            frag_t kf = *(const frag_t*)(lds_k + r * K_ROW + wave * DS * SZ + ks * 32 + hh * 16);
+            if constexpr (IS_BF16) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[ks][e], s, 0, 0, 0);
+            }
+        }
+        // ---- sum the four partial tiles through LDS; every wave ends with the full tile
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lds_s[wave * 1024 + acc_row(e, hh) * 32 + r] = s[e];
+        __syncthreads();
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int idx = acc_row(e, hh) * 32 + r;
+            float v = (lds_s[idx] + lds_s[1024 + idx]) + (lds_s[2048 + idx] + lds_s[3072 + idx]);
+            v = v * a.scale + lds_bias[acc_row(e, hh)];
+            s[e] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = IS_BF16 ? __expf(m_run - m_use) : expf(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float p = IS_BF16 ? __expf(s[e] - m_use) : expf(s[e] - m_use);
+            s[e] = p;
+            psum += p;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+
+        // ---- O^T[slice] += V^T[slice x keys] P^T[keys x queries]
+        if constexpr (IS_BF16) {
+            const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[8 * s2 + j];
+                // block rows = keys kb + (0..3) [+8 for the second read], block cols = 16 d's of this lane group
+                const int kb = 16 * s2 + 4 * (g >> 1);
+#pragma unroll
+                for (int d = 0; d < NDT; ++d) {
+                    const int dcol = wave * DS + d * 32 + (g & 1) * 16 + 4 * (i & 3);
+                    const unsigned char* vp = lds_v + (kb + (i >> 2)) * V_ROW + dcol * 2;
+                    // (the _v4i16 flavour + per-element casts miscompiles on ROCm 7.2: keep whole-vector bf16 types)
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)vp);
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp + 8 * V_ROW));
+                    bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = acc_row(e, hh);
+#pragma unroll
+                for (int d = 0; d < NDT; ++d) {
+                    float vv = *(const float*)(lds_v + key * V_ROW + (wave * DS + d * 32 + r) * 4);
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[e], o[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (my_q >= nq_total) return;
+    const int64_t obase = b * a.o_bs + (my_q / a.NQ2) * a.o_s1 + (my_q % a.NQ2) * a.o_s2 + wave * DS;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int64_t off = obase + d * 32 + 8 * g4 + 4 * hh;
+            float v0 = o[d][4 * g4] * inv, v1 = o[d][4 * g4 + 1] * inv, v2 = o[d][4 * g4 + 2] * inv, v3 = o[d][4 * g4 + 3] * inv;
+            if (a.o_dtype == MADE_F32) {
+                f32x4 pk; pk[0] = v0; pk[1] = v1; pk[2] = v2; pk[3] = v3;
+                *(f32x4*)((float*)a.O + off) = pk;
+            } else {
+                bf16x4 pk; pk[0] = (bf16_t)v0; pk[1] = (bf16_t)v1; pk[2] = (bf16_t)v2; pk[3] = (bf16_t)v3;
+                *(bf16x4*)((bf16_t*)a.O + off) = pk;
+            }
+        }
+}
+
+template <typename TC, int D>
+int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
+    constexpr int SZ = (int)sizeof(TC);
+    constexpr int K_ROW = D * SZ + 16, V_ROW = D * SZ + (SZ == 2 ? 64 : 16);
+    const size_t lds_bytes = (size_t)WKEY * K_ROW + (size_t)WKEY * V_ROW + 4 * 1024 * 4 + 32 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) {
+            made_set_error("made_attention_wide: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+            return MADE_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    const int64_t nq = a.NQ1 * a.NQ2;
+    dim3 grid((unsigned)((nq + WQ - 1) / WQ), (unsigned)a.B), block(NTHREADS);
+    hipLaunchKernelGGL((attention_wide_kernel<TC, D>), grid, block, lds_bytes, st, a);
+    return made_check_launch("made_attention_wide");
+}
+
+}  // namespace
+
+extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
+    MADE_REQUIRE(args != nullptr, "made_attention_wide: null args");
+    const MadeWideAttnArgs& a = *args;
+    MADE_REQUIRE(a.Q && a.K && a.V && a.O, "made_attention_wide: null tensor");
+    MADE_REQUIRE(a.B >= 0 && a.NQ1 >= 0 && a.NQ2 > 0 && a.L > 0, "made_attention_wide: bad dims");
+    MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention_wide: bad dtype %d", a.dtype);
+    MADE_REQUIRE(a.o_dtype == MADE_F32 || a.o_dtype == MADE_BF16, "made_attention_wide: bad o_dtype %d", a.o_dtype);
+    MADE_UNSUPPORTED(a.D == 256 || a.D == 512, "made_attention_wide: D=%lld not in {256, 512}", (long long)a.D);
+    MADE_UNSUPPORTED(a.B <= 65535, "made_attention_wide: B too large for the grid");
+    const int per16 = a.dtype == MADE_F32 ? 4 : 8;
+    MADE_UNSUPPORTED(a.q_bs % per16 == 0 && a.q_s1 % per16 == 0 && a.q_s2 % per16 == 0 && a.k_bs % per16 == 0 && a.ldk % per16 == 0 &&
+                     a.v_bs % per16 == 0 && a.ldv % per16 == 0 && a.kadd_bs % per16 == 0 && a.ldkadd % per16 == 0 &&
+                     a.o_bs % 4 == 0 && a.o_s1 % 4 == 0 && a.o_s2 % 4 == 0,
+                     "made_attention_wide: strides must keep 16-byte alignment");
+    MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && ((uintptr_t)a.O % 16) == 0 &&
+                     ((uintptr_t)a.Kadd % 16) == 0, "made_attention_wide: base pointers must be 16-byte aligned");
+    if (a.B == 0 || a.NQ1 == 0) return MADE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.dtype == MADE_BF16) return a.D == 512 ? launch_wide<bf16_t, 512>(a, st) : launch_wide<bf16_t, 256>(a, st);
+    return a.D == 512 ? launch_wide<float, 512>(a, st) : launch_wide<float, 256>(a, st);
+}

@@ -12,8 +12,9 @@ Data layout in HBM (B = batch, L = T_v + T_a under concat fusion, D = dim_input)
     (frame rows 0..T_v-1, segment rows T_v..L-1) -- the reference's torch.cat never happens;
   * attention values are produced TRANSPOSED per batch ([B, D, L_pad], L_pad = round_up(L, 64))
     by the projection GEMM's epilogue, the layout made_attention's second MFMA product wants;
-  * the 6 decoder layers' memory K / V projections are one GEMM against [2*dec*D, D] packed
-    weights (25 % of the forward flops in one launch).
+  * the decoder never projects the L memory rows: its cross-attention runs in memory space
+    (made_attention_wide over memory + pos) with W_k folded onto the query and W_v / out_proj folded
+    into one Linear on the pooled rows (removes 25 % of the forward flops).
 """
 from __future__ import annotations
 
@@ -63,8 +64,8 @@ class MadeEngine:
             unsupported.append(f"vmr_loss={c.vmr_loss}")
         if c.detr_dec_layers < 1:
             unsupported.append("detr_dec_layers=0")
-        if c.D % 64 != 0:
-            unsupported.append(f"dim_input={c.D} not a multiple of 64")
+        if c.D not in (256, 512):
+            unsupported.append(f"dim_input={c.D} (the wide-head attention kernel is built for 256 and 512)")
         if unsupported:
             raise NotImplementedError("MadeEngine (HIP path) does not cover yet: " + "; ".join(unsupported))
 
@@ -125,19 +126,28 @@ class MadeEngine:
             lin(p + ".out", p + ".self_attn.out_proj")
             lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
             ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2")
-        wk, wv, bk, bv = [], [], [], []
+        H, hd = c.detr_nheads, D // c.detr_nheads
         for l in range(c.detr_dec_layers):
             p = f"detr_transformer.decoder.layers.{l}"
             mat(p + ".sa.in.w", T(p + ".self_attn.in_proj_weight")); vec(p + ".sa.in.b", T(p + ".self_attn.in_proj_bias"))
             lin(p + ".sa.out", p + ".self_attn.out_proj")
-            w, b = T(p + ".multihead_attn.in_proj_weight"), T(p + ".multihead_attn.in_proj_bias")
-            mat(p + ".ca.q.w", w[:D]); vec(p + ".ca.q.b", b[:D])
-            wk.append(w[D:2 * D]); wv.append(w[2 * D:]); bk.append(b[D:2 * D]); bv.append(b[2 * D:])
-            lin(p + ".ca.out", p + ".multihead_attn.out_proj")
+            # one query and one key: softmax == 1, so self-attention is out_proj(v_proj(x)); fold both
+            # Linears (float64 on the host, once per load)
+            sw, sb = T(p + ".self_attn.in_proj_weight").double().cpu(), T(p + ".self_attn.in_proj_bias").double().cpu()
+            so, sob = T(p + ".self_attn.out_proj.weight").double().cpu(), T(p + ".self_attn.out_proj.bias").double().cpu()
+            mat(p + ".sa.fold.w", (so @ sw[2 * D:]).float().to(dev)); vec(p + ".sa.fold.b", (so @ sb[2 * D:] + sob).float().to(dev))
+            # cross-attention in memory space: move W_k onto the query and W_v (with out_proj) onto the pooled rows.
+            #   q'_h = W_k,h^T (W_q,h x + b_q,h)            -> one Linear  D -> H*D   (b_k shifts all keys alike: no effect)
+            #   out  = sum_h W_o[:, h] W_v,h pooled_h + W_o b_v + b_o -> one Linear H*D -> D
+            w, b = T(p + ".multihead_attn.in_proj_weight").double().cpu(), T(p + ".multihead_attn.in_proj_bias").double().cpu()
+            wo, bo = T(p + ".multihead_attn.out_proj.weight").double().cpu(), T(p + ".multihead_attn.out_proj.bias").double().cpu()
+            wq_h, wk_h, wv_h = w[:D].view(H, hd, D), w[D:2 * D].view(H, hd, D), w[2 * D:].view(H, hd, D)
+            mat(p + ".ca.qk.w", torch.einsum("hjn,hjk->hnk", wk_h, wq_h).reshape(H * D, D).float().to(dev))
+            vec(p + ".ca.qk.b", torch.einsum("hjn,hj->hn", wk_h, b[:D].view(H, hd)).reshape(H * D).float().to(dev))
+            mat(p + ".ca.vo.w", torch.einsum("mhj,hjn->mhn", wo.view(D, H, hd), wv_h).reshape(D, H * D).float().to(dev))
+            vec(p + ".ca.vo.b", (wo @ b[2 * D:] + bo).float().to(dev))
             lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
             ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2"); ln(p + ".ln3", p + ".norm3")
-        mat("dec.kv_all.w", torch.cat(wk + wv, 0))                     # [2*dec*D, D]
-        vec("dec.kv_all.b", torch.cat(bk + bv, 0))
         ln("dec.norm", "detr_transformer.decoder.norm")
         mat("query_embed", T("decoder_query_embed.weight"))
         lin("class_embed", "class_embed")
@@ -177,7 +187,7 @@ class MadeEngine:
             fus=E(B, L, D), fus_mask=E(B, L, dtype=torch.float32), pos=E(B, L, D),
             x0=E(rows, D), x1=E(rows, D), x2=E(rows, D), x3=E(rows, D),
             qk=E(rows, 2 * D), vt=Z(B, D, Lpad), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
-            k_all=E(B * L, nd * D), vt_all=Z(B, nd * D, round_up(L, 64)),
+            dq_all=E(B * Q, c.detr_nheads * D), dpool=E(B * Q, c.detr_nheads * D),
             vmean=E(B, D, dtype=torch.float32), mmean=E(B, D, dtype=torch.float32),
             video=E(B, D, dtype=torch.float32), music=E(B, D, dtype=torch.float32),
             tgt=E(B * Q, D), t1=E(B * Q, D), t2=E(B * Q, D), tx=E(B * Q, D),
@@ -252,12 +262,11 @@ class MadeEngine:
         P, tc, dev = self.P, self.tc, self.device
         Nv, D = video.shape
         Nm, S, _ = seg.shape
-        Spad = round_up(S, 64)
         if sims_out is None:
             sims_out = torch.empty(Nv, Nm, device=dev, dtype=torch.float32)
         if chunk_m is None:
             budget = 6 << 30                                             # bytes of per-pair intermediates per chunk
-            per_m = Nv * (Spad * (4 + tc.itemsize) + 4 * D * tc.itemsize)
+            per_m = Nv * 3 * D * tc.itemsize + 4 * S * D * tc.itemsize
             chunk_m = max(1, min(Nm, budget // max(per_m, 1)))
         v1 = ops.layernorm(video, P["xa.ln1.g"], P["xa.ln1.b"], out_dtype=tc)
         q = ops.linear(v1, P["xa.q.w"], P["xa.q.b"])
@@ -265,32 +274,22 @@ class MadeEngine:
         cm = min(chunk_m, Nm)
         s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
         kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
-        ubuf = torch.empty(cm * S, D, device=dev, dtype=tc) if hoist else None
-        ut = torch.zeros(cm, D, Spad, device=dev, dtype=tc)
-        logits = torch.empty(cm, Nv, Spad, device=dev, dtype=torch.float32)
-        probs = torch.empty(cm, Nv, Spad, device=dev, dtype=tc)
+        ubuf = torch.empty(cm * S, D, device=dev, dtype=tc)
+        ubuf2 = torch.empty(cm * S, D, device=dev, dtype=tc) if hoist else None
         o = torch.empty(cm * Nv, D, device=dev, dtype=tc)
         o2 = torch.empty(cm * Nv, D, device=dev, dtype=tc)
         o3 = torch.empty(cm * Nv, D, device=dev, dtype=tc)
         scale = 1.0 / math.sqrt(D)
         for m0 in range(0, Nm, cm):
             n = min(cm, Nm - m0)
-            segc = seg[m0:m0 + n]
-            ops.layernorm(segc, P["xa.ln1.g"], P["xa.ln1.b"], out=s1[:n * S])   # [n,S,D] view -> compact rows
-            ut_seg = Seg(out=ut, col_begin=D, transposed=True, ldo=Spad, rows_per_batch=S, out_batch_stride=D * Spad)
+            ops.layernorm(seg[m0:m0 + n], P["xa.ln1.g"], P["xa.ln1.b"], out=s1[:n * S])   # [n,S,D] view -> compact rows
+            ops.linear(s1[:n * S], P["xa.kv.w"], P["xa.kv.b"], segs=[Seg(out=kbuf, col_begin=0), Seg(out=ubuf, col_begin=D)])
+            u = ubuf
             if hoist:
-                ops.linear(s1[:n * S], P["xa.kv.w"], P["xa.kv.b"],
-                           segs=[Seg(out=kbuf, col_begin=0), Seg(out=ubuf, col_begin=D)])
-                ops.linear(ubuf[:n * S], P["xa.out.w"], P["xa.out.b"],
-                           segs=[Seg(out=ut, transposed=True, ldo=Spad, rows_per_batch=S, out_batch_stride=D * Spad)])
-            else:
-                ops.linear(s1[:n * S], P["xa.kv.w"], P["xa.kv.b"], segs=[Seg(out=kbuf, col_begin=0), ut_seg])
-            # logits[m] = q K_m^T  (f32 out), softmax over segments, o[m] = P_m U_m
-            ops.linear(q, kbuf, None, N=S, batch=n, a_z_stride=0, w_z_stride=S * D,
-                       segs=[Seg(out=logits, ldo=Spad, out_z_stride=Nv * Spad)])
-            ops.masked_softmax(logits[:n], seg_mask[m0:m0 + n], probs[:n], S, scale)
-            ops.linear(probs.view(cm * Nv, Spad), ut.view(cm * D, Spad), None, M=Nv, N=D, K=Spad, batch=n,
-                       a_z_stride=Nv * Spad, w_z_stride=D * Spad, segs=[Seg(out=o, ldo=D, out_z_stride=Nv * D)])
+                u = ops.linear(ubuf[:n * S], P["xa.out.w"], P["xa.out.b"], out=ubuf2[:n * S])
+            # all videos attend to each track's segments: softmax over segments, scores never leave the chip
+            ops.attention_wide(q.view(1, Nv, 1, D), kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D),
+                               o[:n * Nv].view(n, Nv, 1, D), scale=scale, key_mask=seg_mask[m0:m0 + n], shared_q=True)
             rows = n * Nv
             if hoist:
                 a2 = o[:rows]
@@ -361,35 +360,36 @@ class MadeEngine:
         memory = src
         out["memory"] = memory.view(B, L, D)
 
-        # ---- DETR decoder (K10): all layers' memory K / V^T in one GEMM
-        k_all, vt_all = ws["k_all"], ws["vt_all"]
-        ops.linear(memory, P["dec.kv_all.w"], P["dec.kv_all.b"], A2=pos2,
-                   segs=[Seg(out=k_all, col_begin=0, use_a2=True),
-                         Seg(out=vt_all, col_begin=nd * D, transposed=True, ldo=vt_all.stride(1), rows_per_batch=L,
-                             out_batch_stride=vt_all.stride(0))])
-        k3 = k_all.view(B, L, nd * D)
+        # ---- DETR decoder (K10).  Cross-attention runs in memory space (made_attention_wide): no projection of
+        # the L memory rows at all; self-attention collapses to one folded Linear when there is a single query.
+        mem3, pos3 = memory.view(B, L, D), pos
         tgt = ws["tgt"]
         src_vec = video if c.moment_query_type == "video" else music
         tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
         qp = P["query_embed"]
         hs = ws["hs"]
         dvt = ws["dvt"]
+        ca_scale = 1.0 / math.sqrt(D // H)
+        dq_all, dpool = ws["dq_all"], ws["dpool"]
+        dq4 = dq_all.view(B, Q, H, D).permute(0, 2, 1, 3)               # [B, H, Q, D] view: row (b,q), head-major columns
+        dp4 = dpool.view(B, Q, H, D).permute(0, 2, 1, 3)
         for l in range(nd):
             p = f"detr_transformer.decoder.layers.{l}"
-            dqk = ws["dqk"]
-            ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=qp, a2_row_mod=Q,
-                       segs=[Seg(out=dqk, col_begin=0, use_a2=True),
-                             Seg(out=dvt, col_begin=2 * D, transposed=True, ldo=dvt.stride(1), rows_per_batch=Q,
-                                 out_batch_stride=dvt.stride(0))])
-            dqk3 = dqk.view(B, Q, 2 * D)
-            ops.attention(dqk3[:, :, :D], dqk3[:, :, D:], dvt, ws["datt"].view(B, Q, D), H, Lk=Q)
-            x = ops.linear(ws["datt"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=ws["tx"])
+            if Q == 1:
+                x = ops.linear(tgt, P[p + ".sa.fold.w"], P[p + ".sa.fold.b"], R=tgt, out=ws["tx"])
+            else:
+                dqk = ws["dqk"]
+                ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=qp, a2_row_mod=Q,
+                           segs=[Seg(out=dqk, col_begin=0, use_a2=True),
+                                 Seg(out=dvt, col_begin=2 * D, transposed=True, ldo=dvt.stride(1), rows_per_batch=Q,
+                                     out_batch_stride=dvt.stride(0))])
+                dqk3 = dqk.view(B, Q, 2 * D)
+                ops.attention(dqk3[:, :, :D], dqk3[:, :, D:], dvt, ws["datt"].view(B, Q, D), H, Lk=Q)
+                x = ops.linear(ws["datt"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=ws["tx"])
             t1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["t1"])
-            dq = ops.linear(t1, P[p + ".ca.q.w"], P[p + ".ca.q.b"], A2=qp, a2_row_mod=Q,
-                            segs=[Seg(out=ws["dq"], use_a2=True)])
-            ops.attention(dq.view(B, Q, D), k3[:, :, l * D:(l + 1) * D], vt_all[:, l * D:(l + 1) * D, :],
-                          ws["datt"].view(B, Q, D), H, key_mask=fus_mask, Lk=L)
-            x = ops.linear(ws["datt"], P[p + ".ca.out.w"], P[p + ".ca.out.b"], R=t1, out=ws["tx"])
+            ops.linear(t1, P[p + ".ca.qk.w"], P[p + ".ca.qk.b"], A2=qp, a2_row_mod=Q, segs=[Seg(out=dq_all, use_a2=True)])
+            ops.attention_wide(dq4, mem3, mem3, dp4, scale=ca_scale, Kadd=pos3, key_mask=fus_mask)
+            x = ops.linear(dpool, P[p + ".ca.vo.w"], P[p + ".ca.vo.b"], R=t1, out=ws["tx"])
             t2 = ops.layernorm(x, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["t2"])
             h = ops.linear(t2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["dffn"])
             x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=t2, out=ws["tx"])

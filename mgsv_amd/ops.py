@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, BF16, F32,  # noqa: F401
-                   MadeAttnArgs, MadeLinearArgs, MadeLinearSeg, check, lib)
+                   MadeAttnArgs, MadeLinearArgs, MadeLinearSeg, MadeWideAttnArgs, check, lib)
 
 Tensor = torch.Tensor
 
@@ -183,6 +183,36 @@ def attention(Q: Tensor, K: Tensor, Vt: Tensor, O: Tensor, H: int, *, key_mask: 
     nbytes = esz * B * D * (2 * Lq + 2 * a.Lk)
     _timed("attention_" + ("f32" if a.dtype == F32 else "bf16"), flops, nbytes,
            lambda: check(lib().made_attention(C.byref(a), _stream()), "made_attention"), f"B={B} H={H} hd={hd} Lq={Lq} Lk={a.Lk}")
+    return O
+
+
+def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, Kadd: Optional[Tensor] = None,
+                   key_mask: Optional[Tensor] = None, shared_q: bool = False) -> Tensor:
+    """Single-head attention with head dim = D.  Q [B|1, NQ1, NQ2, D], K/Kadd/V [B, L, D], O [B, NQ1, NQ2, D]
+    (strided views fine, unit inner stride).  shared_q: the same queries for every batch entry (Q.shape[0] == 1)."""
+    assert Q.dim() == 4 and O.dim() == 4 and K.dim() == 3 and V.dim() == 3
+    assert Q.stride(3) == 1 and O.stride(3) == 1 and K.stride(2) == 1 and V.stride(2) == 1
+    assert Q.dtype == K.dtype == V.dtype
+    B, L, D = K.shape
+    a = MadeWideAttnArgs()
+    a.Q, a.K, a.V, a.O = _p(Q), _p(K), _p(V), _p(O)
+    a.key_mask = _p(_f32(key_mask, "key_mask"))
+    a.dtype, a.o_dtype = dt_of(Q), dt_of(O)
+    a.B, a.NQ1, a.NQ2, a.L, a.D = B, O.shape[1], O.shape[2], L, D
+    a.q_bs, a.q_s1, a.q_s2 = (0 if shared_q else Q.stride(0)), Q.stride(1), Q.stride(2)
+    a.k_bs, a.ldk = K.stride(0), K.stride(1)
+    a.v_bs, a.ldv = V.stride(0), V.stride(1)
+    if Kadd is not None:
+        assert Kadd.dim() == 3 and Kadd.stride(2) == 1 and Kadd.dtype == K.dtype
+        a.Kadd, a.kadd_bs, a.ldkadd = _p(Kadd), Kadd.stride(0), Kadd.stride(1)
+    a.o_bs, a.o_s1, a.o_s2 = O.stride(0), O.stride(1), O.stride(2)
+    a.scale = scale
+    nq = a.NQ1 * a.NQ2
+    esz = 4 if a.dtype == F32 else 2
+    _timed("attention_wide_" + ("f32" if a.dtype == F32 else "bf16"), 4.0 * B * nq * L * D,
+           esz * B * (2 * L * D + 2 * nq * D),
+           lambda: check(lib().made_attention_wide(C.byref(a), _stream()), "made_attention_wide"),
+           f"B={B} NQ={nq} L={L} D={D} kadd={int(Kadd is not None)}")
     return O
 
 

@@ -234,6 +234,44 @@ def test_attention_online_softmax_rescale(dev):
     np.testing.assert_allclose(Od.cpu().numpy(), ref.numpy(), atol=F32_TOL, rtol=0)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,NQ1,NQ2,L,D,shared,kadd,alias", [
+    (3, 8, 1, 542, 512, False, True, True),       # decoder cross-attention in memory space: K = mem + pos, V = mem
+    (5, 70, 1, 96, 256, True, False, False),      # X-Pool: all videos attend to each track's segments
+    (2, 8, 3, 50, 256, False, True, False),       # two-level query index (head, query)
+    (4, 33, 1, 7, 512, True, False, False),       # fewer keys than one tile
+])
+def test_attention_wide(dev, mode, B, NQ1, NQ2, L, D, shared, kadd, alias):
+    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+    rr = (lambda t: t) if mode == "f32" else bf
+    q = rnd(1 if shared else B, NQ1, NQ2, D, seed=1)
+    k = rnd(B, L, D, seed=2)
+    ka = rnd(B, L, D, seed=3) if kadd else None
+    v = k if alias else rnd(B, L, D, seed=4)
+    lens = torch.tensor([max(1, L - 9 * i) for i in range(B)])
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    if B > 1 and L > 4:
+        mask[1, ::3] = 0
+        mask[1, 1] = 1
+    scale = 0.125
+    # reference (f32 math on the rounded operands; K + Kadd is rounded once like the kernel does)
+    kr = rr(k) if ka is None else rr(rr(k) + rr(ka))
+    sc = torch.einsum("bxyd,bld->bxyl", rr(q).expand(B, -1, -1, -1), kr) * scale
+    sc = sc.masked_fill((mask == 0)[:, None, None, :], float("-inf"))
+    ref = torch.einsum("bxyl,bld->bxyd", torch.softmax(sc, -1), rr(v))
+    # strided placements: Q and O as [B*NQ2, NQ1*D]-style buffers (row = (b, i2), head-major columns), as the decoder uses them
+    Qd = torch.empty(q.shape[0], NQ2, NQ1, D, device=dev, dtype=tdt).permute(0, 2, 1, 3)
+    Qd.copy_(q.to(dev).to(tdt))
+    Kd = k.to(dev).to(tdt)
+    Vd = Kd if alias else v.to(dev).to(tdt)
+    for odt in ([tdt] if mode == "f32" else [tdt, torch.float32]):
+        Od = torch.full((B, NQ2, NQ1, D), float("nan"), device=dev, dtype=odt).permute(0, 2, 1, 3)
+        ops.attention_wide(Qd, Kd, Vd, Od, scale=scale, Kadd=ka.to(dev).to(tdt) if kadd else None,
+                           key_mask=mask.to(dev), shared_q=shared)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(Od.float().cpu().numpy(), ref.numpy(), atol=F32_TOL if mode == "f32" else BF16_TOL, rtol=0)
+
+
 # ------------------------------------------------------------------------------------ row kernels
 @pytest.mark.parametrize("D", [256, 512, 768, 1024])
 @pytest.mark.parametrize("io", ["f32->f32", "bf16->bf16", "f32->bf16"])
