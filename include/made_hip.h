@@ -67,6 +67,9 @@ int         made_device_info(char* name, int name_len, int* cu_count, int* is_gf
  *   be written transposed per batch (out[b][n][t], t = row % rows_per_batch) which is the layout
  *   made_attention wants for V.  `batch` > 1 runs independent problems (grid.z) with the given
  *   element strides (used for the per-track QK^T / PV products of the X-Pool block).
+ *   split_k > 1 (skinny problems: the decoder's M = B*Q rows): grid.z splits K, every block writes its raw
+ *   f32 partial tile to split_ws[split][M][N] and NO epilogue runs; made_splitk_finish sums the splits and
+ *   applies bias / act / residual (and optionally LayerNorm), so a 64-row GEMM fills the chip.
  */
 typedef struct MadeLinearSeg {
     int64_t col_begin;         /* first column of this segment (multiple of 128 unless nseg == 1) */
@@ -93,11 +96,28 @@ typedef struct MadeLinearArgs {
     int32_t      act; int32_t r_dtype;
     const void*  R;  int64_t ldr; int64_t r_row_mod;        /* added after act; may be NULL */
     const float* out_row_mask;                              /* [M] or NULL: masked rows -> 0 */
-    int32_t      nseg; int32_t _pad;
+    int32_t      nseg; int32_t split_k;                     /* split_k > 1: see below */
+    float*       split_ws;                                  /* [split_k, M, N] f32 workspace or NULL */
     MadeLinearSeg seg[4];
 } MadeLinearArgs;
 
 int made_linear(const MadeLinearArgs* args, void* stream);
+
+/* y = act(sum_s ws[s] + bias) + R[row % r_row_mod]  -> out (any dtype, may be NULL);
+ * then optionally z1 = LayerNorm(y; ln1) -> ln1_out, and z2 = LayerNorm(z1; ln2) -> ln2_out (the decoder's
+ * per-layer norm followed by the shared output norm, reference music_detr/transformer.py:306,136).
+ * One wave per row; the LayerNorm variants need N <= 2048.  ws is [split_k, M, N] f32. */
+typedef struct MadeFinishArgs {
+    const float* ws; int64_t split_k, M, N;
+    const float* bias; int32_t act; int32_t r_dtype;
+    const void*  R; int64_t ldr; int64_t r_row_mod;
+    void* out; int32_t out_dtype; int32_t _pad0; int64_t ldo;
+    const float* ln1_g; const float* ln1_b; void* ln1_out; int32_t ln1_dtype; int32_t _pad1; int64_t ln1_ld;
+    const float* ln2_g; const float* ln2_b; void* ln2_out; int32_t ln2_dtype; int32_t _pad2; int64_t ln2_ld;
+    float eps; int32_t _pad3;
+} MadeFinishArgs;
+
+int made_splitk_finish(const MadeFinishArgs* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * made_attention: fused multi-head attention core, softmax(Q K^T * scale + key mask) V, flash
@@ -147,6 +167,9 @@ typedef struct MadeWideAttnArgs {
     int64_t B, NQ1, NQ2, L, D;
     int64_t q_bs, q_s1, q_s2, k_bs, ldk, kadd_bs, ldkadd, v_bs, ldv, o_bs, o_s1, o_s2;
     float scale; int32_t _pad;
+    int64_t n_split;           /* > 1: keys are split over grid.z (few queries, long memory: fills the chip) and */
+    float*  part_o;            /*      the slices are merged by a second launch; [B, n_split, NQ, D] f32 */
+    float*  part_ml;           /*      [B, n_split, NQ, 2] f32 (running max, sum) */
 } MadeWideAttnArgs;
 
 int made_attention_wide(const MadeWideAttnArgs* args, void* stream);

@@ -34,8 +34,19 @@ class MadeLinearArgs(C.Structure):
                 ("act", i32), ("r_dtype", i32),
                 ("R", vp), ("ldr", i64), ("r_row_mod", i64),
                 ("out_row_mask", vp),
-                ("nseg", i32), ("_pad", i32),
+                ("nseg", i32), ("split_k", i32),
+                ("split_ws", vp),
                 ("seg", MadeLinearSeg * 4)]
+
+
+class MadeFinishArgs(C.Structure):
+    _fields_ = [("ws", vp), ("split_k", i64), ("M", i64), ("N", i64),
+                ("bias", vp), ("act", i32), ("r_dtype", i32),
+                ("R", vp), ("ldr", i64), ("r_row_mod", i64),
+                ("out", vp), ("out_dtype", i32), ("_pad0", i32), ("ldo", i64),
+                ("ln1_g", vp), ("ln1_b", vp), ("ln1_out", vp), ("ln1_dtype", i32), ("_pad1", i32), ("ln1_ld", i64),
+                ("ln2_g", vp), ("ln2_b", vp), ("ln2_out", vp), ("ln2_dtype", i32), ("_pad2", i32), ("ln2_ld", i64),
+                ("eps", f32), ("_pad3", i32)]
 
 
 class MadeAttnArgs(C.Structure):
@@ -54,7 +65,8 @@ class MadeWideAttnArgs(C.Structure):
                 ("B", i64), ("NQ1", i64), ("NQ2", i64), ("L", i64), ("D", i64),
                 ("q_bs", i64), ("q_s1", i64), ("q_s2", i64), ("k_bs", i64), ("ldk", i64), ("kadd_bs", i64), ("ldkadd", i64),
                 ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("o_s1", i64), ("o_s2", i64),
-                ("scale", f32), ("_pad", i32)]
+                ("scale", f32), ("_pad", i32),
+                ("n_split", i64), ("part_o", vp), ("part_ml", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/made_hip.h declares
@@ -63,6 +75,7 @@ SIGNATURES = {
     "made_last_error": (C.c_char_p, []),
     "made_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "made_linear": (C.c_int, [C.POINTER(MadeLinearArgs), vp]),
+    "made_splitk_finish": (C.c_int, [C.POINTER(MadeFinishArgs), vp]),
     "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
     "made_attention_wide": (C.c_int, [C.POINTER(MadeWideAttnArgs), vp]),
     "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp]),

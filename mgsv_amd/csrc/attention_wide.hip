@@ -117,14 +117,20 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
         for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int64_t ntiles = (a.L + WKEY - 1) / WKEY;
-    if (PREFETCH) load_tile(0);
-    for (int64_t t = 0; t < ntiles; ++t) {
+    // keys of this workgroup: all of them, or the blockIdx.z-th slice when the keys are split over workgroups
+    const int64_t nsplit = a.n_split > 1 ? a.n_split : 1;
+    const int64_t tiles_all = (a.L + WKEY - 1) / WKEY;
+    const int64_t tiles_per = (tiles_all + nsplit - 1) / nsplit;
+    const int64_t tile0 = (int64_t)blockIdx.z * tiles_per;
+    const int64_t ntiles = tile0 >= tiles_all ? 0 : (tile0 + tiles_per <= tiles_all ? tiles_per : tiles_all - tile0);
+    if (PREFETCH && ntiles > 0) load_tile(tile0 * WKEY);
+    for (int64_t tt = 0; tt < ntiles; ++tt) {
+        const int64_t t = tile0 + tt;
         if (!PREFETCH) load_tile(t * WKEY);
         __syncthreads();                                  // previous tile fully consumed
         store_tile();
         __syncthreads();
-        if (PREFETCH && t + 1 < ntiles) load_tile((t + 1) * WKEY);
+        if (PREFETCH && tt + 1 < ntiles) load_tile((t + 1) * WKEY);
 
         // ---- partial S^T [32 keys x 32 queries] over this wave's D slice
         f32x16 s;
@@ -208,6 +214,20 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
     if (my_q >= nq_total) return;
+    if (nsplit > 1) {
+        // un-normalised partial result of this key slice; made_attention_wide_combine merges the slices
+        const int64_t prow = (b * nsplit + blockIdx.z) * nq_total + my_q;
+        float* po = a.part_o + prow * D + wave * DS;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 pk; pk[0] = o[d][4 * g4]; pk[1] = o[d][4 * g4 + 1]; pk[2] = o[d][4 * g4 + 2]; pk[3] = o[d][4 * g4 + 3];
+                *(f32x4*)(po + d * 32 + 8 * g4 + 4 * hh) = pk;
+            }
+        if (wave == 0 && hh == 0) { a.part_ml[prow * 2] = m_run; a.part_ml[prow * 2 + 1] = l_tot; }
+        return;
+    }
     const int64_t obase = b * a.o_bs + (my_q / a.NQ2) * a.o_s1 + (my_q % a.NQ2) * a.o_s2 + wave * DS;
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
@@ -225,6 +245,53 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
         }
 }
 
+// merge the key slices: O = sum_s O_s e^{m_s - M} / sum_s l_s e^{m_s - M}; one wave per (batch, query)
+__global__ __launch_bounds__(NTHREADS) void attention_wide_combine_kernel(const MadeWideAttnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nq_total = a.NQ1 * a.NQ2;
+    const int64_t row = (int64_t)blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6);
+    if (row >= a.B * nq_total) return;
+    const int64_t b = row / nq_total, q = row % nq_total;
+    const int D = (int)a.D;
+    float M = -INFINITY;
+    for (int64_t s = 0; s < a.n_split; ++s) M = fmaxf(M, a.part_ml[((b * a.n_split + s) * nq_total + q) * 2]);
+    const float Muse = (M == -INFINITY) ? 0.f : M;
+    float Lsum = 0.f;
+    f32x4 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
+    for (int64_t s = 0; s < a.n_split; ++s) {
+        const int64_t prow = (b * a.n_split + s) * nq_total + q;
+        const float w = expf(a.part_ml[prow * 2] - Muse);
+        Lsum += a.part_ml[prow * 2 + 1] * w;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 t = *(const f32x4*)(a.part_o + prow * D + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += t[j] * w;
+            }
+        }
+    }
+    const float inv = 1.f / Lsum;
+    const int64_t obase = b * a.o_bs + (q / a.NQ2) * a.o_s1 + (q % a.NQ2) * a.o_s2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            if (a.o_dtype == MADE_F32) {
+                f32x4 pk; pk[0] = acc[i][0] * inv; pk[1] = acc[i][1] * inv; pk[2] = acc[i][2] * inv; pk[3] = acc[i][3] * inv;
+                *(f32x4*)((float*)a.O + obase + c) = pk;
+            } else {
+                bf16x4 pk; pk[0] = (bf16_t)(acc[i][0] * inv); pk[1] = (bf16_t)(acc[i][1] * inv);
+                pk[2] = (bf16_t)(acc[i][2] * inv); pk[3] = (bf16_t)(acc[i][3] * inv);
+                *(bf16x4*)((bf16_t*)a.O + obase + c) = pk;
+            }
+        }
+    }
+}
+
 template <typename TC, int D>
 int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     constexpr int SZ = (int)sizeof(TC);
@@ -240,9 +307,14 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
         attr_done = true;
     }
     const int64_t nq = a.NQ1 * a.NQ2;
-    dim3 grid((unsigned)((nq + WQ - 1) / WQ), (unsigned)a.B), block(NTHREADS);
+    const int64_t nsplit = a.n_split > 1 ? a.n_split : 1;
+    dim3 grid((unsigned)((nq + WQ - 1) / WQ), (unsigned)a.B, (unsigned)nsplit), block(NTHREADS);
     hipLaunchKernelGGL((attention_wide_kernel<TC, D>), grid, block, lds_bytes, st, a);
-    return made_check_launch("made_attention_wide");
+    int rc = made_check_launch("made_attention_wide");
+    if (rc != MADE_OK || nsplit == 1) return rc;
+    const int64_t rows = a.B * nq;
+    hipLaunchKernelGGL(attention_wide_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTHREADS), 0, st, a);
+    return made_check_launch("made_attention_wide(combine)");
 }
 
 }  // namespace
@@ -263,6 +335,10 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
                      "made_attention_wide: strides must keep 16-byte alignment");
     MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && ((uintptr_t)a.O % 16) == 0 &&
                      ((uintptr_t)a.Kadd % 16) == 0, "made_attention_wide: base pointers must be 16-byte aligned");
+    if (a.n_split > 1) {
+        MADE_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr, "made_attention_wide: n_split > 1 needs part_o / part_ml");
+        MADE_UNSUPPORTED(a.n_split <= 64, "made_attention_wide: n_split <= 64");
+    }
     if (a.B == 0 || a.NQ1 == 0) return MADE_OK;
     hipStream_t st = (hipStream_t)stream;
     if (a.dtype == MADE_BF16) return a.D == 512 ? launch_wide<bf16_t, 512>(a, st) : launch_wide<bf16_t, 256>(a, st);

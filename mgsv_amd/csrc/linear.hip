@@ -121,7 +121,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
     const int n_tiles = (N + BN - 1) / BN;
     const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int64_t z = blockIdx.z;
+    const int splitk = a.split_k > 1 ? a.split_k : 1;
+    const int64_t z = splitk > 1 ? 0 : blockIdx.z;         // grid.z = K split index when split_k > 1, else problem index
 
     // segment of this column tile
     int si = 0;
@@ -177,13 +178,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // ---- main loop: two LDS stages, next slab's global loads in flight during the MFMAs, one barrier per slab
-    const int nk = (K + KE - 1) / KE;
-    load_stage(0);
+    const int nk_all = (K + KE - 1) / KE;
+    const int per_split = (nk_all + splitk - 1) / splitk;
+    const int kt0 = splitk > 1 ? (int)blockIdx.z * per_split : 0;
+    const int nk = splitk > 1 ? (kt0 + per_split < nk_all ? per_split : (nk_all > kt0 ? nk_all - kt0 : 0)) : nk_all;
+    load_stage(kt0 * KE);
     store_stage(lds);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned char* cur = lds + (kt & 1) * STAGE;
-        if (kt + 1 < nk) load_stage((kt + 1) * KE);
+        if (kt + 1 < nk) load_stage((kt0 + kt + 1) * KE);
         const unsigned char* la = cur + (wm * 64 + r) * LDS_ROW + hh * 16;
         const unsigned char* lw = cur + BM * LDS_ROW + (wn * 64 + r) * LDS_ROW + hh * 16;
 #pragma unroll
@@ -235,6 +239,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
             }
     __syncthreads();
 
+    if (splitk > 1) {
+        // raw f32 partial sums -> split_ws[split][M][N]; made_splitk_finish adds them up and runs the epilogue
+        float* wsp = a.split_ws + (int64_t)blockIdx.z * M * N;
+        const int cc = tid & 15;
+        const int n = n0 + cc * 8;
+        const bool vec = (N % 4 == 0);
+        for (int i = 0; i < 8; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            const int m = m0 + row;
+            if (m >= M) break;
+            const float* cp = Ct + row * CT_LD + cc * 8;
+            if (vec && n + 8 <= N) {
+                *(f32x4*)(wsp + (int64_t)m * N + n) = *(const f32x4*)cp;
+                *(f32x4*)(wsp + (int64_t)m * N + n + 4) = *(const f32x4*)(cp + 4);
+            } else {
+                for (int j = 0; j < 8 && n + j < N; ++j) wsp[(int64_t)m * N + n + j] = cp[j];
+            }
+        }
+        return;
+    }
     unsigned char* outp = (unsigned char*)seg.out;
     const int64_t out_z = z * seg.out_z_stride;
     const int rpb = (int)seg.rows_per_batch, rmod = (int)a.r_row_mod;
@@ -357,7 +381,12 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
     if (a.M == 0) return MADE_OK;
     const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     MADE_UNSUPPORTED(tiles < (1LL << 31), "made_linear: too many tiles");
-    dim3 grid((unsigned)tiles, 1, (unsigned)a.batch), block(NTHREADS);
+    if (a.split_k > 1) {
+        MADE_REQUIRE(a.split_ws != nullptr, "made_linear: split_k > 1 needs split_ws");
+        MADE_UNSUPPORTED(a.batch == 1 && a.nseg == 1 && !a.seg[0].transposed && a.split_k <= 256,
+                         "made_linear: split-K needs batch == 1, one plain segment and split_k <= 256");
+    }
+    dim3 grid((unsigned)tiles, 1, (unsigned)(a.split_k > 1 ? a.split_k : a.batch)), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
     if (a.w_dtype == MADE_BF16) {
         if (a.a_dtype == MADE_F32) hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a);

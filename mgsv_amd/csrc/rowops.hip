@@ -288,6 +288,105 @@ __global__ __launch_bounds__(1024) void clip_loss_kernel(const float* sims, int6
     }
 }
 
+
+// ---- split-K finish: sum partials + bias/act/residual (+ LayerNorm, + second LayerNorm) -----------
+__device__ __forceinline__ float finish_act(float x, int act) {
+    switch (act) {
+        case MADE_ACT_RELU: return fmaxf(x, 0.f);
+        case MADE_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+        case MADE_ACT_QUICKGELU: return x / (1.f + expf(-1.702f * x));
+        case MADE_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ void wave_layernorm(f32x4 (&v)[MAX_VEC], int D, int lane, const float* g, const float* b, float eps) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i)
+        if ((i * WAVE + lane) * 4 < D) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i)
+        if ((i * WAVE + lane) * 4 < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; sq += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAX_VEC; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(b + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+        }
+    }
+}
+
+template <bool WITH_LN>
+__global__ __launch_bounds__(ROW_THREADS) void splitk_finish_kernel(const MadeFinishArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const int N = (int)a.N;
+    const int64_t rr = a.r_row_mod > 0 ? row % a.r_row_mod : row;
+    f32x4 keep[WITH_LN ? MAX_VEC : 1];
+    const int nchunks = (N + 255) / 256;
+    for (int i = 0; i < nchunks; ++i) {
+        const int c = (i * WAVE + lane) * 4;
+        if (c >= N) continue;
+        f32x4 acc = *(const f32x4*)(a.ws + row * N + c);
+        for (int64_t s = 1; s < a.split_k; ++s) {
+            f32x4 t = *(const f32x4*)(a.ws + (s * a.M + row) * N + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += t[j];
+        }
+        if (a.bias) {
+            f32x4 bb = *(const f32x4*)(a.bias + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += bb[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = finish_act(acc[j], a.act);
+        if (a.R) {
+            f32x4 t = load4(a.R, a.r_dtype, rr * a.ldr + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += t[j];
+        }
+        if (a.out) store4(a.out, a.out_dtype, row * a.ldo + c, acc);
+        if constexpr (WITH_LN) {
+#pragma unroll
+            for (int k = 0; k < MAX_VEC; ++k)
+                if (k == i) keep[k] = acc;
+        }
+    }
+    if constexpr (WITH_LN) {
+        wave_layernorm(keep, N, lane, a.ln1_g, a.ln1_b, a.eps);
+#pragma unroll
+        for (int i = 0; i < MAX_VEC; ++i) {
+            int c = (i * WAVE + lane) * 4;
+            if (c < N && a.ln1_out) store4(a.ln1_out, a.ln1_dtype, row * a.ln1_ld + c, keep[i]);
+        }
+        if (a.ln2_g) {
+            // the second norm sees what the first one STORED (rounded to its dtype), like a separate kernel would
+            if (a.ln1_out && a.ln1_dtype == MADE_BF16) {
+#pragma unroll
+                for (int i = 0; i < MAX_VEC; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) keep[i][j] = (float)(bf16_t)keep[i][j];
+            }
+            wave_layernorm(keep, N, lane, a.ln2_g, a.ln2_b, a.eps);
+#pragma unroll
+            for (int i = 0; i < MAX_VEC; ++i) {
+                int c = (i * WAVE + lane) * 4;
+                if (c < N) store4(a.ln2_out, a.ln2_dtype, row * a.ln2_ld + c, keep[i]);
+            }
+        }
+    }
+}
+
 inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
 
 }  // namespace
@@ -367,4 +466,25 @@ extern "C" int made_clip_loss(const float* sims, int64_t ld, int64_t n, const fl
     hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale,
                        weight, accumulate, loss_out);
     return made_check_launch("made_clip_loss");
+}
+
+extern "C" int made_splitk_finish(const MadeFinishArgs* args, void* stream) {
+    MADE_REQUIRE(args != nullptr && args->ws != nullptr, "made_splitk_finish: null args/ws");
+    const MadeFinishArgs& a = *args;
+    MADE_REQUIRE(a.split_k >= 1 && a.M >= 0 && a.N > 0, "made_splitk_finish: bad dims");
+    MADE_UNSUPPORTED(a.N % 4 == 0 && a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.ln1_ld % 4 == 0 && a.ln2_ld % 4 == 0,
+                     "made_splitk_finish: N and row strides must be multiples of 4");
+    const bool ln = a.ln1_g != nullptr;
+    MADE_REQUIRE(a.out != nullptr || ln, "made_splitk_finish: nothing to write");
+    if (ln) {
+        MADE_REQUIRE(a.ln1_b != nullptr && (a.ln1_out != nullptr || a.ln2_g != nullptr), "made_splitk_finish: incomplete ln1 arguments");
+        MADE_UNSUPPORTED(a.N <= 64 * 4 * MAX_VEC, "made_splitk_finish: LayerNorm variant needs N <= %d", 64 * 4 * MAX_VEC);
+        if (a.ln2_g) MADE_REQUIRE(a.ln2_b != nullptr && a.ln2_out != nullptr, "made_splitk_finish: incomplete ln2 arguments");
+    } else {
+        MADE_REQUIRE(a.ln2_g == nullptr, "made_splitk_finish: ln2 without ln1");
+    }
+    if (a.M == 0) return MADE_OK;
+    if (ln) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
+    return made_check_launch("made_splitk_finish");
 }

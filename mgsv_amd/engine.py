@@ -188,6 +188,8 @@ class MadeEngine:
             x0=E(rows, D), x1=E(rows, D), x2=E(rows, D), x3=E(rows, D),
             qk=E(rows, 2 * D), vt=Z(B, D, Lpad), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
             dq_all=E(B * Q, c.detr_nheads * D), dpool=E(B * Q, c.detr_nheads * D),
+            dws=E(32 * B * Q * max(D, 256) * 4, dtype=torch.float32),          # split-K partials of the skinny decoder GEMMs
+            part_o=E(B * 8 * c.detr_nheads * Q * D, dtype=torch.float32), part_ml=E(B * 8 * c.detr_nheads * Q * 2, dtype=torch.float32),
             vmean=E(B, D, dtype=torch.float32), mmean=E(B, D, dtype=torch.float32),
             video=E(B, D, dtype=torch.float32), music=E(B, D, dtype=torch.float32),
             tgt=E(B * Q, D), t1=E(B * Q, D), t2=E(B * Q, D), tx=E(B * Q, D),
@@ -373,10 +375,24 @@ class MadeEngine:
         dq_all, dpool = ws["dq_all"], ws["dpool"]
         dq4 = dq_all.view(B, Q, H, D).permute(0, 2, 1, 3)               # [B, H, Q, D] view: row (b,q), head-major columns
         dp4 = dpool.view(B, Q, H, D).permute(0, 2, 1, 3)
+        dws = ws["dws"]
+        slab = 64 if self.tc == torch.bfloat16 else 32
+
+        def skinny(A, wkey, **kw):
+            """Linear on the B*Q decoder rows: K split over workgroups so the launch fills the chip."""
+            W = P[wkey + ".w"]
+            N, K = W.shape
+            tiles = ((A.shape[0] + 127) // 128) * ((N + 127) // 128)
+            split = max(2, min(192 // max(tiles, 1), (K + slab - 1) // slab, 32, dws.numel() // (A.shape[0] * N)))
+            ops.linear_splitk(A, W, P[wkey + ".b"], dws, split, **kw)
+
+        n_split = max(1, min(8, 256 // max(B, 1)))
         for l in range(nd):
             p = f"detr_transformer.decoder.layers.{l}"
+            ln1, ln2, ln3 = [(P[p + f".ln{i}.g"], P[p + f".ln{i}.b"]) for i in (1, 2, 3)]
+            t1, t2 = ws["t1"], ws["t2"]
             if Q == 1:
-                x = ops.linear(tgt, P[p + ".sa.fold.w"], P[p + ".sa.fold.b"], R=tgt, out=ws["tx"])
+                skinny(tgt, p + ".sa.fold", R=tgt, ln1=ln1, ln1_out=t1)
             else:
                 dqk = ws["dqk"]
                 ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=qp, a2_row_mod=Q,
@@ -385,16 +401,13 @@ class MadeEngine:
                                      out_batch_stride=dvt.stride(0))])
                 dqk3 = dqk.view(B, Q, 2 * D)
                 ops.attention(dqk3[:, :, :D], dqk3[:, :, D:], dvt, ws["datt"].view(B, Q, D), H, Lk=Q)
-                x = ops.linear(ws["datt"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=ws["tx"])
-            t1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["t1"])
-            ops.linear(t1, P[p + ".ca.qk.w"], P[p + ".ca.qk.b"], A2=qp, a2_row_mod=Q, segs=[Seg(out=dq_all, use_a2=True)])
-            ops.attention_wide(dq4, mem3, mem3, dp4, scale=ca_scale, Kadd=pos3, key_mask=fus_mask)
-            x = ops.linear(dpool, P[p + ".ca.vo.w"], P[p + ".ca.vo.b"], R=t1, out=ws["tx"])
-            t2 = ops.layernorm(x, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["t2"])
-            h = ops.linear(t2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["dffn"])
-            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=t2, out=ws["tx"])
-            tgt = ops.layernorm(x, P[p + ".ln3.g"], P[p + ".ln3.b"], out=ws["tgt"])
-            ops.layernorm(tgt, P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
+                skinny(ws["datt"], p + ".sa.out", R=tgt, ln1=ln1, ln1_out=t1)
+            skinny(t1, p + ".ca.qk", A2=qp, a2_row_mod=Q, out=dq_all)
+            ops.attention_wide(dq4, mem3, mem3, dp4, scale=ca_scale, Kadd=pos3, key_mask=fus_mask,
+                               n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
+            skinny(dpool, p + ".ca.vo", R=t1, ln1=ln2, ln1_out=t2)
+            skinny(t2, p + ".ff1", act=ops.ACT_RELU, out=ws["dffn"])
+            skinny(ws["dffn"], p + ".ff2", R=t2, ln1=ln3, ln1_out=tgt, ln2=(P["dec.norm.g"], P["dec.norm.b"]), ln2_out=hs[l])
         out["hs"] = hs.view(nd, B, Q, D)
 
         # ---- heads (K11) on all decoder layers at once

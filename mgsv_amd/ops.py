@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, BF16, F32,  # noqa: F401
-                   MadeAttnArgs, MadeLinearArgs, MadeLinearSeg, MadeWideAttnArgs, check, lib)
+                   MadeAttnArgs, MadeFinishArgs, MadeLinearArgs, MadeLinearSeg, MadeWideAttnArgs, check, lib)
 
 Tensor = torch.Tensor
 
@@ -158,6 +158,50 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     return segs[0].out
 
 
+def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, split_k: int, *, A2: Optional[Tensor] = None,
+                  a2_row_mod: int = 0, act: int = ACT_NONE, R: Optional[Tensor] = None, r_row_mod: int = 0,
+                  out: Optional[Tensor] = None, ln1=None, ln1_out: Optional[Tensor] = None, ln2=None,
+                  ln2_out: Optional[Tensor] = None, eps: float = 1e-5) -> None:
+    """Skinny Linear (few rows, e.g. the decoder's B*Q): K is split over grid.z so the launch fills the chip, the raw f32
+    partials land in `ws` ([>= split_k*M*N] f32) and made_splitk_finish sums them and applies bias / act / residual, then
+    optionally LayerNorm (ln1 = (gamma, beta)) and a second LayerNorm on top (ln2)."""
+    assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
+    M, K = A.shape
+    N = W.shape[0]
+    assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.numel() >= split_k * M * N
+    a = MadeLinearArgs()
+    a.A, a.a_dtype, a.w_dtype, a.lda = _p(A), dt_of(A), dt_of(W), A.stride(0)
+    use_a2 = A2 is not None
+    if use_a2:
+        a.A2, a.lda2, a.a2_row_mod = _p(A2), A2.stride(0), a2_row_mod
+    a.W, a.ldw = _p(W), W.stride(0)
+    a.M, a.N, a.K = M, N, K
+    a.batch = 1
+    a.nseg, a.split_k, a.split_ws = 1, max(split_k, 2), _p(ws)
+    sg = a.seg[0]
+    sg.col_begin, sg.out, sg.out_dtype, sg.ldo, sg.use_a2 = 0, _p(ws), F32, N, 1 if use_a2 else 0
+    esz = 4 if a.w_dtype == F32 else 2
+    _timed("linear_splitk_" + ("f32" if a.w_dtype == F32 else "bf16"), 2.0 * M * N * K, M * K * esz + N * K * esz + M * N * 4 * a.split_k,
+           lambda: check(lib().made_linear(C.byref(a), _stream()), "made_linear(split_k)"), f"M={M} N={N} K={K} split={a.split_k}")
+    f = MadeFinishArgs()
+    f.ws, f.split_k, f.M, f.N = _p(ws), a.split_k, M, N
+    f.bias, f.act = _p(_f32(bias, "bias")), act
+    if R is not None:
+        assert R.dim() == 2 and R.stride(1) == 1
+        f.R, f.r_dtype, f.ldr, f.r_row_mod = _p(R), dt_of(R), R.stride(0), r_row_mod
+    if out is not None:
+        f.out, f.out_dtype, f.ldo = _p(out), dt_of(out), out.stride(0)
+    if ln1 is not None:
+        f.ln1_g, f.ln1_b = _p(_f32(ln1[0], "ln1.g")), _p(_f32(ln1[1], "ln1.b"))
+        if ln1_out is not None:
+            f.ln1_out, f.ln1_dtype, f.ln1_ld = _p(ln1_out), dt_of(ln1_out), ln1_out.stride(0)
+    if ln2 is not None:
+        f.ln2_g, f.ln2_b = _p(_f32(ln2[0], "ln2.g")), _p(_f32(ln2[1], "ln2.b"))
+        f.ln2_out, f.ln2_dtype, f.ln2_ld = _p(ln2_out), dt_of(ln2_out), ln2_out.stride(0)
+    f.eps = eps
+    check(lib().made_splitk_finish(C.byref(f), _stream()), "made_splitk_finish")
+
+
 def attention(Q: Tensor, K: Tensor, Vt: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,
               q_mask: Optional[Tensor] = None, scale: Optional[float] = None, Lk: Optional[int] = None) -> Tensor:
     """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K [B,Lk,H*hd], Vt [B,H*hd,ldvt], O [B,Lq,H*hd]
@@ -187,7 +231,8 @@ def attention(Q: Tensor, K: Tensor, Vt: Tensor, O: Tensor, H: int, *, key_mask: 
 
 
 def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, Kadd: Optional[Tensor] = None,
-                   key_mask: Optional[Tensor] = None, shared_q: bool = False) -> Tensor:
+                   key_mask: Optional[Tensor] = None, shared_q: bool = False, n_split: int = 1,
+                   part_o: Optional[Tensor] = None, part_ml: Optional[Tensor] = None) -> Tensor:
     """Single-head attention with head dim = D.  Q [B|1, NQ1, NQ2, D], K/Kadd/V [B, L, D], O [B, NQ1, NQ2, D]
     (strided views fine, unit inner stride).  shared_q: the same queries for every batch entry (Q.shape[0] == 1)."""
     assert Q.dim() == 4 and O.dim() == 4 and K.dim() == 3 and V.dim() == 3
@@ -208,6 +253,12 @@ def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, 
     a.o_bs, a.o_s1, a.o_s2 = O.stride(0), O.stride(1), O.stride(2)
     a.scale = scale
     nq = a.NQ1 * a.NQ2
+    if n_split > 1:
+        if part_o is None:
+            part_o = torch.empty(B * n_split * nq * D, device=Q.device, dtype=torch.float32)
+            part_ml = torch.empty(B * n_split * nq * 2, device=Q.device, dtype=torch.float32)
+        assert part_o.numel() >= B * n_split * nq * D and part_ml.numel() >= B * n_split * nq * 2
+        a.n_split, a.part_o, a.part_ml = n_split, _p(_f32(part_o, "part_o")), _p(_f32(part_ml, "part_ml"))
     esz = 4 if a.dtype == F32 else 2
     _timed("attention_wide_" + ("f32" if a.dtype == F32 else "bf16"), 4.0 * B * nq * L * D,
            esz * B * (2 * L * D + 2 * nq * D),

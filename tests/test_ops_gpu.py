@@ -140,6 +140,34 @@ def test_linear_batched(dev, mode):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=F32_TOL if mode == "f32" else 3e-3, rtol=0)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K,split", [(64, 512, 4096, 16), (64, 4096, 512, 4), (192, 512, 1024, 8), (37, 256, 512, 3)])
+def test_linear_splitk_finish_with_layernorms(dev, mode, M, N, K, split):
+    A, A2, W, b, R = rnd(M, K, seed=1), rnd(3, K, seed=4), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3) * 0.1, rnd(M, N, seed=5)
+    g1, b1, g2, b2 = 1 + 0.1 * rnd(N, seed=6), 0.1 * rnd(N, seed=7), 1 + 0.1 * rnd(N, seed=8), 0.1 * rnd(N, seed=9)
+    cast = (lambda t: t) if mode == "f32" else (lambda t: t.bfloat16())
+    rr = (lambda t: t) if mode == "f32" else bf
+    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+    ws = torch.empty(split * M * N, device=dev)
+    out = torch.empty(M, N, device=dev, dtype=tdt)
+    l1 = torch.empty(M, N, device=dev, dtype=tdt)
+    l2 = torch.empty(M, N, device=dev, dtype=tdt)
+    with_ln = N <= 2048
+    ops.linear_splitk(cast(A.to(dev)), cast(W.to(dev)), b.to(dev), ws, split, A2=cast(A2.to(dev)), a2_row_mod=3, act=ops.ACT_RELU,
+                      R=cast(R.to(dev)), out=out, ln1=(g1.to(dev), b1.to(dev)) if with_ln else None, ln1_out=l1 if with_ln else None,
+                      ln2=(g2.to(dev), b2.to(dev)) if with_ln else None, ln2_out=l2 if with_ln else None)
+    torch.cuda.synchronize()
+    Ap = A + A2[torch.arange(M) % 3] if mode == "f32" else bf(bf(A) + bf(A2)[torch.arange(M) % 3])
+    y = torch.relu(Ap @ rr(W).t() + b) + rr(R)
+    tol = F32_TOL if mode == "f32" else 3e-2
+    np.testing.assert_allclose(out.float().cpu().numpy(), y.numpy(), atol=tol, rtol=tol)
+    if with_ln:
+        z1 = torch.nn.functional.layer_norm(y, (N,), g1, b1, 1e-5)
+        z2 = torch.nn.functional.layer_norm(rr(z1), (N,), g2, b2, 1e-5)
+        np.testing.assert_allclose(l1.float().cpu().numpy(), z1.numpy(), atol=tol, rtol=tol)
+        np.testing.assert_allclose(l2.float().cpu().numpy(), z2.numpy(), atol=tol, rtol=tol)
+
+
 def test_linear_rejects_bad_arguments(dev):
     A, W = torch.zeros(8, 12, device=dev), torch.zeros(8, 12, device=dev).bfloat16()
     with pytest.raises(Exception, match="multiple of"):
@@ -265,11 +293,13 @@ def test_attention_wide(dev, mode, B, NQ1, NQ2, L, D, shared, kadd, alias):
     Kd = k.to(dev).to(tdt)
     Vd = Kd if alias else v.to(dev).to(tdt)
     for odt in ([tdt] if mode == "f32" else [tdt, torch.float32]):
-        Od = torch.full((B, NQ2, NQ1, D), float("nan"), device=dev, dtype=odt).permute(0, 2, 1, 3)
-        ops.attention_wide(Qd, Kd, Vd, Od, scale=scale, Kadd=ka.to(dev).to(tdt) if kadd else None,
-                           key_mask=mask.to(dev), shared_q=shared)
-        torch.cuda.synchronize()
-        np.testing.assert_allclose(Od.float().cpu().numpy(), ref.numpy(), atol=F32_TOL if mode == "f32" else BF16_TOL, rtol=0)
+        for n_split in (1, 4, 7):          # keys split over workgroups + merge launch must give the same answer
+            Od = torch.full((B, NQ2, NQ1, D), float("nan"), device=dev, dtype=odt).permute(0, 2, 1, 3)
+            ops.attention_wide(Qd, Kd, Vd, Od, scale=scale, Kadd=ka.to(dev).to(tdt) if kadd else None,
+                               key_mask=mask.to(dev), shared_q=shared, n_split=n_split)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(Od.float().cpu().numpy(), ref.numpy(), atol=F32_TOL if mode == "f32" else BF16_TOL, rtol=0,
+                                       err_msg=f"n_split={n_split}")
 
 
 # ------------------------------------------------------------------------------------ row kernels
