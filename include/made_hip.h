@@ -126,8 +126,7 @@ int made_splitk_finish(const MadeFinishArgs* args, void* stream);
  * and the CrossAttention core at reference model/model_Base.py:144-163.
  *   Q  [B, Lq, H*hd]  element (b,i,h,d) at Q + b*q_bs + i*ldq + h*hd + d
  *   K  [B, Lk, H*hd]  likewise with k_bs/ldk
- *   Vt [B, H*hd, ldvt] TRANSPOSED values: element (b,j,h,d) at Vt + b*vt_bs + (h*hd+d)*ldvt + j;
- *      ldvt >= round_up(Lk,64) and columns >= Lk must hold finite values (zeros)
+ *   V  [B, Lk, H*hd]  likewise with v_bs/ldv (row-major; transposed on the fly by ds_read_b64_tr_b16)
  *   key_mask [B, Lk] f32, 0 = padded key (-inf before the softmax), may be NULL
  *   q_mask   [B, Lq] f32, 0 = output row forced to 0 AFTER the softmax (reference
  *            model/model_Base.py:163), may be NULL
@@ -135,10 +134,10 @@ int made_splitk_finish(const MadeFinishArgs* args, void* stream);
  * hd in {32, 64, 128}.  A query whose keys are all masked yields NaN like the reference.
  */
 typedef struct MadeAttnArgs {
-    const void* Q; const void* K; const void* Vt; void* O;
+    const void* Q; const void* K; const void* V; void* O;
     int32_t dtype; int32_t hd;
     int64_t B, H, Lq, Lk;
-    int64_t q_bs, ldq, k_bs, ldk, vt_bs, ldvt, o_bs, ldo;
+    int64_t q_bs, ldq, k_bs, ldk, v_bs, ldv, o_bs, ldo;
     const float* key_mask; const float* q_mask;
     float scale; int32_t _pad;
 } MadeAttnArgs;

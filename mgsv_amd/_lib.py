@@ -50,11 +50,11 @@ class MadeFinishArgs(C.Structure):
 
 
 class MadeAttnArgs(C.Structure):
-    _fields_ = [("Q", vp), ("K", vp), ("Vt", vp), ("O", vp),
+    _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp),
                 ("dtype", i32), ("hd", i32),
                 ("B", i64), ("H", i64), ("Lq", i64), ("Lk", i64),
                 ("q_bs", i64), ("ldq", i64), ("k_bs", i64), ("ldk", i64),
-                ("vt_bs", i64), ("ldvt", i64), ("o_bs", i64), ("ldo", i64),
+                ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("ldo", i64),
                 ("key_mask", vp), ("q_mask", vp),
                 ("scale", f32), ("_pad", i32)]
 

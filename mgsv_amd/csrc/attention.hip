@@ -6,9 +6,11 @@
 // registers: the softmax row reductions are in-lane plus one cross-half exchange, the running
 // (max, sum) are per-lane scalars, and P^T is already the B operand of the second product
 // O^T += V^T P^T (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's
-// operand").  V arrives TRANSPOSED ([d][key], written that way by made_linear) so its A-operand
-// fragments are plain row reads.  K and V^T tiles are staged global -> registers -> LDS with the
-// next tile's loads in flight during the current tile's MFMAs; scores never touch HBM.
+// operand").  V stays ROW-major ([key][d], as the projection GEMM writes it): its A-operand fragments
+// (d on the lane, keys along k) come out of LDS through ds_read_b64_tr_b16, the hardware transposing
+// read (bf16), or plain ds_read_b32 with the lane on d (f32).  K and V tiles are staged
+// global -> registers -> LDS with the next tile's loads in flight during the current tile's MFMAs;
+// scores never touch HBM.
 //   bf16 : v_mfma_f32_32x32x16_bf16,  f32 : v_mfma_f32_32x32x2_f32 (exact f32, used for parity)
 #include "common.h"
 
@@ -28,19 +30,19 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     constexpr int SZ = (int)sizeof(TC);
     constexpr int PER16 = 16 / SZ;
     constexpr int K_ROW = HD * SZ + 16;          // bytes, padded (conflict-free 16-byte row reads)
-    constexpr int VT_ROW = BKEY * SZ + 16;       // bytes, padded
-    constexpr int K_CPR = HD * SZ / 16;          // 16-byte chunks per K row
-    constexpr int V_CPR = BKEY * SZ / 16;        // 16-byte chunks per V^T row
-    constexpr int NCH = BKEY * K_CPR / NTHREADS; // chunks per thread (same count for K and V^T)
-    static_assert(BKEY * K_CPR % NTHREADS == 0 && HD * V_CPR == BKEY * K_CPR, "staging split");
+    // V rows: bf16 -> 4 consecutive rows must fall on disjoint quarters of the 64 banks (transposing reads)
+    constexpr int V_ROW = SZ == 2 ? HD * 2 + (HD == 32 ? 0 : 64) : HD * 4 + 16;
+    constexpr int K_CPR = HD * SZ / 16;          // 16-byte chunks per K / V row
+    constexpr int NCH = BKEY * K_CPR / NTHREADS; // chunks per thread (same count for K and V)
+    static_assert(BKEY * K_CPR % NTHREADS == 0, "staging split");
     constexpr int NQF = HD * SZ / 32;            // Q fragments (k-steps of the score product)
     constexpr int NDT = HD / 32;                 // 32-row tiles of O^T
     constexpr bool IS_BF16 = SZ == 2;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BKEY * K_ROW + HD * VT_ROW + BKEY * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BKEY * K_ROW + BKEY * V_ROW + BKEY * 4];
     unsigned char* lds_k = lds;
     unsigned char* lds_v = lds + BKEY * K_ROW;
-    float* lds_bias = (float*)(lds + BKEY * K_ROW + HD * VT_ROW);
+    float* lds_bias = (float*)(lds + BKEY * K_ROW + BKEY * V_ROW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     const bool wave_active = q0 < a.Lq;
 
     const TC* Kg = (const TC*)a.K + b * a.k_bs + h * HD;
-    const TC* Vg = (const TC*)a.Vt + b * a.vt_bs + h * HD * a.ldvt;
+    const TC* Vg = (const TC*)a.V + b * a.v_bs + h * HD;
     const float* maskg = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[q0+r][ks*2*PER16 + hh*PER16 ..]
@@ -73,12 +75,11 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
             int64_t key = key0 + krow;
             if (key < a.Lk) {
                 rk[i] = *(const frag_t*)(Kg + key * a.ldk + kc * PER16);
+                rv[i] = *(const frag_t*)(Vg + key * a.ldv + kc * PER16);
             } else {
 #pragma unroll
-                for (int j = 0; j < PER16; ++j) rk[i][j] = (TC)0.f;
+                for (int j = 0; j < PER16; ++j) { rk[i][j] = (TC)0.f; rv[i][j] = (TC)0.f; }
             }
-            int vrow = c / V_CPR, vc = c % V_CPR;
-            rv[i] = *(const frag_t*)(Vg + (int64_t)vrow * a.ldvt + key0 + vc * PER16);
         }
         if (tid < BKEY) {
             int64_t key = key0 + tid;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;
             *(frag_t*)(lds_k + (c / K_CPR) * K_ROW + (c % K_CPR) * 16) = rk[i];
-            *(frag_t*)(lds_v + (c / V_CPR) * VT_ROW + (c % V_CPR) * 16) = rv[i];
+            *(frag_t*)(lds_v + (c / K_CPR) * V_ROW + (c % K_CPR) * 16) = rv[i];
         }
         if (tid < BKEY) lds_bias[tid] = rbias;
     };
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
 
         // ---- O^T += V^T P^T
         if constexpr (IS_BF16) {
+            const int g = lane >> 4, i = lane & 15;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -172,15 +174,15 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
                     bf16x8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[kt][8 * s2 + j];
-                    const int keyoff = kt * 32 + 16 * s2 + 4 * hh;
+                    // transposing read: the 16 lanes of group g fetch a 4-key x 16-d block; lane 4q+p supplies the
+                    // address of key row kb+q, d columns 4p..4p+3 and receives column (lane & 15) of the 4 rows
+                    const int kb = kt * 32 + 16 * s2 + 4 * (g >> 1);
 #pragma unroll
                     for (int d = 0; d < NDT; ++d) {
-                        const unsigned char* vp = lds_v + (d * 32 + r) * VT_ROW + keyoff * 2;
-                        bf16x4 lo = *(const bf16x4*)vp;
-                        bf16x4 hi = *(const bf16x4*)(vp + 16);
-                        bf16x8 vf;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                        const unsigned char* vp = lds_v + (kb + (i >> 2)) * V_ROW + (d * 32 + (g & 1) * 16 + 4 * (i & 3)) * 2;
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)vp);
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp + 8 * V_ROW));
+                        bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                     }
                 }
@@ -188,14 +190,12 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int keyoff = kt * 32 + 8 * g + 4 * hh;
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * 32 + acc_row(e, hh);
 #pragma unroll
                     for (int d = 0; d < NDT; ++d) {
-                        f32x4 vf = *(const f32x4*)(lds_v + (d * 32 + r) * VT_ROW + keyoff * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[kt][4 * g + e], o[d], 0, 0, 0);
+                        float vv = *(const float*)(lds_v + key * V_ROW + (d * 32 + r) * 4);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[kt][e], o[d], 0, 0, 0);
                     }
                 }
         }
@@ -247,18 +247,16 @@ int launch_attention(const MadeAttnArgs& a, hipStream_t st) {
 extern "C" int made_attention(const MadeAttnArgs* args, void* stream) {
     MADE_REQUIRE(args != nullptr, "made_attention: null args");
     const MadeAttnArgs& a = *args;
-    MADE_REQUIRE(a.Q && a.K && a.Vt && a.O, "made_attention: null tensor");
+    MADE_REQUIRE(a.Q && a.K && a.V && a.O, "made_attention: null tensor");
     MADE_REQUIRE(a.B >= 0 && a.H > 0 && a.Lq >= 0 && a.Lk > 0, "made_attention: bad dims");
     MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention: bad dtype %d", a.dtype);
     MADE_UNSUPPORTED(a.B <= 65535 && a.H <= 65535, "made_attention: B/H too large for the grid");
     const int per16 = a.dtype == MADE_F32 ? 4 : 8;
-    MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldvt % per16 == 0 && a.ldo % 4 == 0 &&
-                     a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.vt_bs % per16 == 0 && a.o_bs % 4 == 0,
+    MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.ldo % 4 == 0 &&
+                     a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.v_bs % per16 == 0 && a.o_bs % 4 == 0,
                      "made_attention: strides must keep 16-byte alignment");
-    MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.Vt % 16) == 0 && ((uintptr_t)a.O % 16) == 0,
+    MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && ((uintptr_t)a.O % 16) == 0,
                      "made_attention: base pointers must be 16-byte aligned");
-    MADE_REQUIRE(a.ldvt >= ((a.Lk + BKEY - 1) / BKEY) * BKEY, "made_attention: ldvt=%lld must be >= round_up(Lk=%lld, 64)",
-                 (long long)a.ldvt, (long long)a.Lk);
     if (a.B == 0 || a.Lq == 0) return MADE_OK;
     hipStream_t st = (hipStream_t)stream;
     return a.dtype == MADE_BF16 ? launch_attention<bf16_t>(a, st) : launch_attention<float>(a, st);

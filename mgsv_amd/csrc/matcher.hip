@@ -174,8 +174,8 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(const float* lo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int width = Q < G ? Q : G;
     const int bg = 1 - fg;
-    float total_acc = 0.f;
-    for (int l = 0; l < n_layers; ++l) {
+    {
+        const int l = blockIdx.x;                      // one workgroup per decoder layer
         const float* lg = logits + (int64_t)l * B * Q * 2;
         const float* sp = spans + (int64_t)l * B * Q * 2;
         for (int i = tid; i < B * Q; i += CRIT_THREADS) matched[i] = 0;
@@ -250,11 +250,19 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(const float* lo
             float ce = 100.f - correct * (100.f / npairs);
             float* o = losses + l * 5;
             o[0] = ls; o[1] = lgi; o[2] = ll; o[3] = ce; o[4] = contr;
-            total_acc += weights[0] * ls + weights[1] * lgi + weights[2] * ll + weights[4] * contr;
         }
-        __syncthreads();
     }
-    if (tid == 0 && total) total[0] = total_acc;
+}
+
+// total = sum_l sum_k weights[k] * losses[l][k], fixed order (deterministic)
+__global__ void criterion_total_kernel(const float* losses, const float* weights, int n_layers, float* total) {
+    if (threadIdx.x != 0) return;
+    float t = 0.f;
+    for (int l = 0; l < n_layers; ++l) {
+        const float* o = losses + l * 5;
+        t += weights[0] * o[0] + weights[1] * o[1] + weights[2] * o[2] + weights[4] * o[4];
+    }
+    total[0] = t;
 }
 
 }  // namespace
@@ -285,9 +293,12 @@ extern "C" int made_set_criterion(const float* pred_logits, const float* pred_sp
     MADE_REQUIRE(pred_logits && pred_spans && targets && pred_idx && tgt_idx && count && empty_weight && weights && losses,
                  "made_set_criterion: null pointer");
     MADE_REQUIRE(n_layers >= 1 && B >= 1 && Q >= 1 && G >= 1, "made_set_criterion: bad dims");
-    MADE_UNSUPPORTED(B * Q <= CRIT_MAX_BQ, "made_set_criterion: B*Q=%lld exceeds %d", (long long)(B * Q), CRIT_MAX_BQ);
-    hipLaunchKernelGGL(criterion_kernel, dim3(1), dim3(CRIT_THREADS), 0, (hipStream_t)stream, pred_logits, pred_spans, targets,
+    MADE_UNSUPPORTED(n_layers <= 65535 && B * Q <= CRIT_MAX_BQ, "made_set_criterion: B*Q=%lld exceeds %d", (long long)(B * Q), CRIT_MAX_BQ);
+    hipLaunchKernelGGL(criterion_kernel, dim3((unsigned)n_layers), dim3(CRIT_THREADS), 0, (hipStream_t)stream, pred_logits, pred_spans, targets,
                        pred_idx, tgt_idx, count, proj_queries, vid_sum, empty_weight, (int)n_layers, (int)B, (int)Q, (int)G,
                        (int)Dc, (int)fg_label, temperature, weights, losses, total);
-    return made_check_launch("made_set_criterion");
+    int rc = made_check_launch("made_set_criterion");
+    if (rc != MADE_OK || total == nullptr) return rc;
+    hipLaunchKernelGGL(criterion_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, weights, (int)n_layers, total);
+    return made_check_launch("made_set_criterion(total)");
 }

@@ -32,7 +32,8 @@ __device__ __forceinline__ void store4(void* p, int dtype, int64_t idx, f32x4 v)
 
 // ---- LayerNorm -----------------------------------------------------------------------------
 // Two-pass (mean, then centred variance) in registers: the row is read from HBM once.
-__global__ __launch_bounds__(ROW_THREADS) void layernorm_kernel(const void* x, int xdt, int64_t ldx, int64_t rpb, int64_t xbs,
+template <int NV>
+__global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_kernel(const void* x, int xdt, int64_t ldx, int64_t rpb, int64_t xbs,
                                                                 const float* gamma, const float* beta,
                                                                 void* y, int ydt, int64_t ldy,
                                                                 int64_t rows, int D, float eps) {
@@ -40,10 +41,10 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_kernel(const void* x, i
     const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t xoff = rpb > 0 ? (row / rpb) * xbs + (row % rpb) * ldx : row * ldx;
-    f32x4 v[MAX_VEC];
+    f32x4 v[NV];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
             v[i] = load4(x, xdt, xoff + c);
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_kernel(const void* x, i
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
 #pragma unroll
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_kernel(const void* x, i
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
             f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c), o;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(ROW_THREADS) void masked_mean_kernel(const void* x,
     const int phase = threadIdx.x >> 6;
     const int64_t b = blockIdx.y;
     float acc = 0.f, n = 0.f;
+#pragma unroll 8
     for (int64_t t = phase; t < T; t += 4) {
         float mk = mask ? mask[b * T + t] : 1.f;
         n += mk;
@@ -100,16 +102,17 @@ __global__ __launch_bounds__(ROW_THREADS) void masked_mean_kernel(const void* x,
 }
 
 // ---- L2 normalise rows -------------------------------------------------------------------------
-__global__ __launch_bounds__(ROW_THREADS) void l2norm_kernel(const void* x, int xdt, int64_t ldx, float* y32,
+template <int NV>
+__global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void l2norm_kernel(const void* x, int xdt, int64_t ldx, float* y32,
                                                              void* yalt, int yadt, int64_t ldy,
                                                              int64_t rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
     if (row >= rows) return;
-    f32x4 v[MAX_VEC];
+    f32x4 v[NV];
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
             v[i] = load4(x, xdt, row * ldx + c);
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(ROW_THREADS) void l2norm_kernel(const void* x, int 
     }
     const float nrm = fmaxf(sqrtf(wave_sum(sq)), eps);
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
             f32x4 o;
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(ROW_THREADS) void masked_softmax_kernel(const float
 }
 
 // ---- X-Pool tail: LayerNorm3 + cosine with the video --------------------------------------------
-__global__ __launch_bounds__(ROW_THREADS) void xpool_tail_kernel(const void* y, int ydt, int64_t ldy, const float* gamma,
+template <int NV>
+__global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void xpool_tail_kernel(const void* y, int ydt, int64_t ldy, const float* gamma,
                                                                  const float* beta, const float* video, int64_t ldv,
                                                                  float* pooled, float* sims, int64_t lds_, int64_t rows,
                                                                  int64_t Nv, int D, float eps) {
@@ -211,10 +215,10 @@ __global__ __launch_bounds__(ROW_THREADS) void xpool_tail_kernel(const void* y, 
     const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t m = row / Nv, n = row % Nv;
-    f32x4 v[MAX_VEC];
+    f32x4 v[NV];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
             v[i] = load4(y, ydt, row * ldy + c);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(ROW_THREADS) void xpool_tail_kernel(const void* y, 
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
 #pragma unroll
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(ROW_THREADS) void xpool_tail_kernel(const void* y, 
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
     float pp = 0.f, vv = 0.f, pv = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
             f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c), o;
@@ -300,22 +304,23 @@ __device__ __forceinline__ float finish_act(float x, int act) {
     }
 }
 
-__device__ __forceinline__ void wave_layernorm(f32x4 (&v)[MAX_VEC], int D, int lane, const float* g, const float* b, float eps) {
+template <int NV>
+__device__ __forceinline__ void wave_layernorm(f32x4 (&v)[NV], int D, int lane, const float* g, const float* b, float eps) {
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i)
+    for (int i = 0; i < NV; ++i)
         if ((i * WAVE + lane) * 4 < D) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i)
+    for (int i = 0; i < NV; ++i)
         if ((i * WAVE + lane) * 4 < D) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; sq += d * d; }
         }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
 #pragma unroll
-    for (int i = 0; i < MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
         if (c < D) {
             f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(b + c);
@@ -325,20 +330,30 @@ __device__ __forceinline__ void wave_layernorm(f32x4 (&v)[MAX_VEC], int D, int l
     }
 }
 
-template <bool WITH_LN>
-__global__ __launch_bounds__(ROW_THREADS) void splitk_finish_kernel(const MadeFinishArgs a) {
+template <bool WITH_LN, int NV>
+__global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_kernel(const MadeFinishArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const int N = (int)a.N;
     const int64_t rr = a.r_row_mod > 0 ? row % a.r_row_mod : row;
-    f32x4 keep[WITH_LN ? MAX_VEC : 1];
+    f32x4 keep[WITH_LN ? NV : 1];
     const int nchunks = (N + 255) / 256;
+#pragma unroll 1
     for (int i = 0; i < nchunks; ++i) {
         const int c = (i * WAVE + lane) * 4;
         if (c >= N) continue;
         f32x4 acc = *(const f32x4*)(a.ws + row * N + c);
-        for (int64_t s = 1; s < a.split_k; ++s) {
+        int64_t s = 1;
+        for (; s + 4 <= a.split_k; s += 4) {              // four independent loads in flight
+            f32x4 t0 = *(const f32x4*)(a.ws + ((s + 0) * a.M + row) * N + c);
+            f32x4 t1 = *(const f32x4*)(a.ws + ((s + 1) * a.M + row) * N + c);
+            f32x4 t2 = *(const f32x4*)(a.ws + ((s + 2) * a.M + row) * N + c);
+            f32x4 t3 = *(const f32x4*)(a.ws + ((s + 3) * a.M + row) * N + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += (t0[j] + t1[j]) + (t2[j] + t3[j]);
+        }
+        for (; s < a.split_k; ++s) {
             f32x4 t = *(const f32x4*)(a.ws + (s * a.M + row) * N + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] += t[j];
@@ -358,14 +373,14 @@ __global__ __launch_bounds__(ROW_THREADS) void splitk_finish_kernel(const MadeFi
         if (a.out) store4(a.out, a.out_dtype, row * a.ldo + c, acc);
         if constexpr (WITH_LN) {
 #pragma unroll
-            for (int k = 0; k < MAX_VEC; ++k)
+            for (int k = 0; k < NV; ++k)
                 if (k == i) keep[k] = acc;
         }
     }
     if constexpr (WITH_LN) {
         wave_layernorm(keep, N, lane, a.ln1_g, a.ln1_b, a.eps);
 #pragma unroll
-        for (int i = 0; i < MAX_VEC; ++i) {
+        for (int i = 0; i < NV; ++i) {
             int c = (i * WAVE + lane) * 4;
             if (c < N && a.ln1_out) store4(a.ln1_out, a.ln1_dtype, row * a.ln1_ld + c, keep[i]);
         }
@@ -373,13 +388,13 @@ __global__ __launch_bounds__(ROW_THREADS) void splitk_finish_kernel(const MadeFi
             // the second norm sees what the first one STORED (rounded to its dtype), like a separate kernel would
             if (a.ln1_out && a.ln1_dtype == MADE_BF16) {
 #pragma unroll
-                for (int i = 0; i < MAX_VEC; ++i)
+                for (int i = 0; i < NV; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) keep[i][j] = (float)(bf16_t)keep[i][j];
             }
             wave_layernorm(keep, N, lane, a.ln2_g, a.ln2_b, a.eps);
 #pragma unroll
-            for (int i = 0; i < MAX_VEC; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 int c = (i * WAVE + lane) * 4;
                 if (c < N) store4(a.ln2_out, a.ln2_dtype, row * a.ln2_ld + c, keep[i]);
             }
@@ -388,6 +403,13 @@ __global__ __launch_bounds__(ROW_THREADS) void splitk_finish_kernel(const MadeFi
 }
 
 inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
+inline int nv_for(int64_t D) { return D <= 512 ? 2 : (D <= 1024 ? 4 : 8); }
+#define DISPATCH_NV(D, CALL)                      \
+    switch (nv_for(D)) {                          \
+        case 2: { constexpr int NV = 2; CALL; } break; \
+        case 4: { constexpr int NV = 4; CALL; } break; \
+        default: { constexpr int NV = 8; CALL; } break; \
+    }
 
 }  // namespace
 
@@ -400,8 +422,8 @@ extern "C" int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64
     MADE_UNSUPPORTED(ldx % 4 == 0 && ldy % 4 == 0 && x_batch_stride % 4 == 0, "made_layernorm: row strides must be multiples of 4");
     MADE_REQUIRE(x_rows_per_batch >= 0, "made_layernorm: negative x_rows_per_batch");
     if (rows <= 0) return MADE_OK;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                       x, x_dtype, ldx, x_rows_per_batch, x_batch_stride, gamma, beta, y, y_dtype, ldy, rows, (int)D, eps);
+    DISPATCH_NV(D, hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       x, x_dtype, ldx, x_rows_per_batch, x_batch_stride, gamma, beta, y, y_dtype, ldy, rows, (int)D, eps));
     return made_check_launch("made_layernorm");
 }
 
@@ -420,8 +442,8 @@ extern "C" int made_l2norm_rows(const void* x, int32_t x_dtype, int64_t ldx, flo
     MADE_REQUIRE(x && (y_f32 || y_alt), "made_l2norm_rows: null pointer");
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldx % 4 == 0 && ldy % 4 == 0, "made_l2norm_rows: bad D/strides");
     if (rows <= 0) return MADE_OK;
-    hipLaunchKernelGGL(l2norm_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                       x, x_dtype, ldx, y_f32, y_alt, y_alt_dtype, ldy, rows, (int)D, eps);
+    DISPATCH_NV(D, hipLaunchKernelGGL(l2norm_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       x, x_dtype, ldx, y_f32, y_alt, y_alt_dtype, ldy, rows, (int)D, eps));
     return made_check_launch("made_l2norm_rows");
 }
 
@@ -454,8 +476,8 @@ extern "C" int made_xpool_tail(const void* y, int32_t y_dtype, int64_t ldy, cons
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldy % 4 == 0 && ld_video % 4 == 0, "made_xpool_tail: bad D/strides");
     const int64_t rows = Nm * Nv;
     if (rows <= 0) return MADE_OK;
-    hipLaunchKernelGGL(xpool_tail_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                       y, y_dtype, ldy, gamma, beta, video, ld_video, pooled_out, sims, ld_sims, rows, Nv, (int)D, eps);
+    DISPATCH_NV(D, hipLaunchKernelGGL(xpool_tail_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       y, y_dtype, ldy, gamma, beta, video, ld_video, pooled_out, sims, ld_sims, rows, Nv, (int)D, eps));
     return made_check_launch("made_xpool_tail");
 }
 
@@ -484,7 +506,7 @@ extern "C" int made_splitk_finish(const MadeFinishArgs* args, void* stream) {
         MADE_REQUIRE(a.ln2_g == nullptr, "made_splitk_finish: ln2 without ln1");
     }
     if (a.M == 0) return MADE_OK;
-    if (ln) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
+    if (ln) { DISPATCH_NV(a.N, hipLaunchKernelGGL((splitk_finish_kernel<true, NV>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a)); }
+    else hipLaunchKernelGGL((splitk_finish_kernel<false, 2>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
     return made_check_launch("made_splitk_finish");
 }

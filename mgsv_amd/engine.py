@@ -10,8 +10,8 @@ Data layout in HBM (B = batch, L = T_v + T_a under concat fusion, D = dim_input)
   * activations are row-major [rows, D] in the compute dtype (f32 or bf16), one row per token;
   * the DETR input `fus` [B, L, D] is written in place by the two temporal encoders' last GEMMs
     (frame rows 0..T_v-1, segment rows T_v..L-1) -- the reference's torch.cat never happens;
-  * attention values are produced TRANSPOSED per batch ([B, D, L_pad], L_pad = round_up(L, 64))
-    by the projection GEMM's epilogue, the layout made_attention's second MFMA product wants;
+  * q | k | v of every attention live side by side in one [rows, 3D] buffer written by one GEMM; the
+    attention kernels read V row-major and transpose it on the fly (ds_read_b64_tr_b16);
   * the decoder never projects the L memory rows: its cross-attention runs in memory space
     (made_attention_wide over memory + pos) with W_k folded onto the query and W_v / out_proj folded
     into one Linear on the pooled rows (removes 25 % of the forward flops).
@@ -186,14 +186,14 @@ class MadeEngine:
         ws = dict(
             fus=E(B, L, D), fus_mask=E(B, L, dtype=torch.float32), pos=E(B, L, D),
             x0=E(rows, D), x1=E(rows, D), x2=E(rows, D), x3=E(rows, D),
-            qk=E(rows, 2 * D), vt=Z(B, D, Lpad), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
+            qkv=E(rows, 3 * D), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
             dq_all=E(B * Q, c.detr_nheads * D), dpool=E(B * Q, c.detr_nheads * D),
             dws=E(32 * B * Q * max(D, 256) * 4, dtype=torch.float32),          # split-K partials of the skinny decoder GEMMs
             part_o=E(B * 8 * c.detr_nheads * Q * D, dtype=torch.float32), part_ml=E(B * 8 * c.detr_nheads * Q * 2, dtype=torch.float32),
             vmean=E(B, D, dtype=torch.float32), mmean=E(B, D, dtype=torch.float32),
             video=E(B, D, dtype=torch.float32), music=E(B, D, dtype=torch.float32),
             tgt=E(B * Q, D), t1=E(B * Q, D), t2=E(B * Q, D), tx=E(B * Q, D),
-            dqk=E(B * Q, 2 * D), dq=E(B * Q, D), dvt=Z(B, D, 64 * ((Q + 63) // 64)), datt=E(B * Q, D),
+            dqkv=E(B * Q, 3 * D), datt=E(B * Q, D),
             dffn=E(B * Q, F_d), hs=E(nd, B * Q, D),
             logits=E(nd, B, Q, 2, dtype=torch.float32), spans=E(nd, B, Q, 2, dtype=torch.float32),
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D),
@@ -213,15 +213,15 @@ class MadeEngine:
                    ws: Dict[str, Tensor], H: int, pos: Optional[Tensor] = None) -> Tensor:
         """packed in-proj -> flash attention; x [B*T, D]; q,k from (x + pos), v from x; returns att [B*T, D]."""
         D = self.cfg.D
-        qk = ws["qk"][:B * T]
-        vt = ws["vt"]
-        ops.linear(x, w_in, b_in, A2=pos,
-                   segs=[Seg(out=qk, col_begin=0, use_a2=pos is not None),
-                         Seg(out=vt, col_begin=2 * D, transposed=True, ldo=vt.stride(1), rows_per_batch=T,
-                             out_batch_stride=vt.stride(0))])
-        qk3 = qk.view(B, T, 2 * D)
+        qkv = ws["qkv"][:B * T]
+        if pos is None:
+            ops.linear(x, w_in, b_in, out=qkv)
+        else:                                       # the position embedding goes into q and k only
+            ops.linear(x, w_in, b_in, A2=pos, segs=[Seg(out=qkv, col_begin=0, use_a2=True),
+                                                    Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
+        q3 = qkv.view(B, T, 3 * D)
         att = ws["att"][:B * T]
-        ops.attention(qk3[:, :, :D], qk3[:, :, D:], vt, att.view(B, T, D), H, key_mask=key_mask, Lk=T)
+        ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), H, key_mask=key_mask)
         return att
 
     def _encode(self, feats: Tensor, mask: Tensor, which: str, ws: Dict[str, Tensor], row_off: int) -> None:
@@ -307,6 +307,14 @@ class MadeEngine:
         """cos(v, m) (reference modules/loss.py:52-56), always with the exact-f32 MFMA; `add` is summed in."""
         vn = ops.l2norm_rows(video)
         mn = ops.l2norm_rows(music)
+        Nv, Nm, D = vn.shape[0], mn.shape[0], vn.shape[1]
+        if Nv <= 256 and Nm <= 256 and Nm % 4 == 0 and (add is None or add.stride(0) % 4 == 0):   # in-batch: one output tile -> split K over workgroups
+            if out is None:
+                out = torch.empty(Nv, Nm, device=vn.device, dtype=torch.float32)
+            split = max(2, min(16, D // 32))
+            wsp = torch.empty(split * Nv * Nm, device=vn.device, dtype=torch.float32)
+            ops.linear_splitk(vn, mn, None, wsp, split, R=add, out=out)
+            return out
         return ops.linear(vn, mn, None, R=add, out=out, out_dtype=torch.float32)
 
     def retrieval_sim_matrix(self, video_embeds: Tensor, segment_embeds: Tensor, segment_masks: Tensor,
@@ -370,7 +378,6 @@ class MadeEngine:
         tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
         qp = P["query_embed"]
         hs = ws["hs"]
-        dvt = ws["dvt"]
         ca_scale = 1.0 / math.sqrt(D // H)
         dq_all, dpool = ws["dq_all"], ws["dpool"]
         dq4 = dq_all.view(B, Q, H, D).permute(0, 2, 1, 3)               # [B, H, Q, D] view: row (b,q), head-major columns
@@ -394,13 +401,12 @@ class MadeEngine:
             if Q == 1:
                 skinny(tgt, p + ".sa.fold", R=tgt, ln1=ln1, ln1_out=t1)
             else:
-                dqk = ws["dqk"]
+                dqkv = ws["dqkv"]
                 ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=qp, a2_row_mod=Q,
-                           segs=[Seg(out=dqk, col_begin=0, use_a2=True),
-                                 Seg(out=dvt, col_begin=2 * D, transposed=True, ldo=dvt.stride(1), rows_per_batch=Q,
-                                     out_batch_stride=dvt.stride(0))])
-                dqk3 = dqk.view(B, Q, 2 * D)
-                ops.attention(dqk3[:, :, :D], dqk3[:, :, D:], dvt, ws["datt"].view(B, Q, D), H, Lk=Q)
+                           segs=[Seg(out=dqkv, col_begin=0, use_a2=True),
+                                 Seg(out=dqkv[:, 2 * D:], col_begin=2 * D, ldo=dqkv.stride(0))])
+                d3 = dqkv.view(B, Q, 3 * D)
+                ops.attention(d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:], ws["datt"].view(B, Q, D), H)
                 skinny(ws["datt"], p + ".sa.out", R=tgt, ln1=ln1, ln1_out=t1)
             skinny(t1, p + ".ca.qk", A2=qp, a2_row_mod=Q, out=dq_all)
             ops.attention_wide(dq4, mem3, mem3, dp4, scale=ca_scale, Kadd=pos3, key_mask=fus_mask,

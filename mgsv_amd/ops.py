@@ -202,22 +202,22 @@ def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, spli
     check(lib().made_splitk_finish(C.byref(f), _stream()), "made_splitk_finish")
 
 
-def attention(Q: Tensor, K: Tensor, Vt: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,
+def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,
               q_mask: Optional[Tensor] = None, scale: Optional[float] = None, Lk: Optional[int] = None) -> Tensor:
-    """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K [B,Lk,H*hd], Vt [B,H*hd,ldvt], O [B,Lq,H*hd]
+    """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K / V [B,Lk,H*hd], O [B,Lq,H*hd]
     (any batch/row strides, unit inner stride).  Lk defaults to K.shape[1]."""
-    assert Q.dim() == 3 and K.dim() == 3 and Vt.dim() == 3 and O.dim() == 3
-    assert Q.stride(2) == 1 and K.stride(2) == 1 and Vt.stride(2) == 1 and O.stride(2) == 1
-    assert Q.dtype == K.dtype == Vt.dtype == O.dtype
+    assert Q.dim() == 3 and K.dim() == 3 and V.dim() == 3 and O.dim() == 3
+    assert Q.stride(2) == 1 and K.stride(2) == 1 and V.stride(2) == 1 and O.stride(2) == 1
+    assert Q.dtype == K.dtype == V.dtype == O.dtype
     B, Lq, D = Q.shape
     hd = D // H
     a = MadeAttnArgs()
-    a.Q, a.K, a.Vt, a.O = _p(Q), _p(K), _p(Vt), _p(O)
+    a.Q, a.K, a.V, a.O = _p(Q), _p(K), _p(V), _p(O)
     a.dtype, a.hd = dt_of(Q), hd
     a.B, a.H, a.Lq, a.Lk = B, H, Lq, (K.shape[1] if Lk is None else Lk)
     a.q_bs, a.ldq = Q.stride(0), Q.stride(1)
     a.k_bs, a.ldk = K.stride(0), K.stride(1)
-    a.vt_bs, a.ldvt = Vt.stride(0), Vt.stride(1)
+    a.v_bs, a.ldv = V.stride(0), V.stride(1)
     a.o_bs, a.ldo = O.stride(0), O.stride(1)
     a.key_mask = _p(_f32(key_mask, "key_mask"))
     a.q_mask = _p(_f32(q_mask, "q_mask"))

@@ -207,17 +207,14 @@ def test_attention(dev, mode, B, H, hd, Lq, Lk):
         key_mask[1, 1] = 1
     tdt = torch.float32 if mode == "f32" else torch.bfloat16
     rr = (lambda t: t) if mode == "f32" else bf
-    ldvt = ops.round_up(Lk, 64)
-    # Q and K live in one packed [B, L, 2D] buffer when Lq == Lk (strided views), else separate
+    # q | k | v live in one packed [B, L, 3D] buffer when Lq == Lk (strided views, as the engine uses them), else separate
     if Lq == Lk:
-        qk = torch.cat([q, k], -1).to(dev).to(tdt)
-        Qd, Kd = qk[:, :, :D], qk[:, :, D:]
+        qkv = torch.cat([q, k, v], -1).to(dev).to(tdt)
+        Qd, Kd, Vd = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
     else:
-        Qd, Kd = q.to(dev).to(tdt), k.to(dev).to(tdt)
-    Vt = torch.zeros(B, D, ldvt, device=dev, dtype=tdt)
-    Vt[:, :, :Lk] = v.transpose(1, 2).to(dev).to(tdt)
+        Qd, Kd, Vd = q.to(dev).to(tdt), k.to(dev).to(tdt), v.to(dev).to(tdt)
     Od = torch.full((B, Lq, D), float("nan"), device=dev, dtype=tdt)
-    ops.attention(Qd, Kd, Vt, Od, H, key_mask=key_mask.to(dev), Lk=Lk)
+    ops.attention(Qd, Kd, Vd, Od, H, key_mask=key_mask.to(dev), Lk=Lk)
     torch.cuda.synchronize()
     ref = attn_ref(rr(q), rr(k), rr(v), H, key_mask, None)
     np.testing.assert_allclose(Od.float().cpu().numpy(), ref.numpy(), atol=F32_TOL if mode == "f32" else BF16_TOL, rtol=0)
@@ -231,8 +228,7 @@ def test_attention_qmask_nomask_and_all_masked(dev, mode):
     tdt = torch.float32 if mode == "f32" else torch.bfloat16
     rr = (lambda t: t) if mode == "f32" else bf
     tol = F32_TOL if mode == "f32" else BF16_TOL
-    Vt = torch.zeros(B, D, 128, device=dev, dtype=tdt)
-    Vt[:, :, :Lk] = v.transpose(1, 2).to(dev).to(tdt)
+    Vt = v.to(dev).to(tdt)
     q_mask = (torch.arange(Lq)[None] < torch.tensor([[25], [40]])).float()
     Od = torch.empty(B, Lq, D, device=dev, dtype=tdt)
     ops.attention(q.to(dev).to(tdt), k.to(dev).to(tdt), Vt, Od, H, q_mask=q_mask.to(dev), scale=0.3)
@@ -253,8 +249,7 @@ def test_attention_online_softmax_rescale(dev):
     q, k, v = rnd(B, Lq, hd, seed=1), rnd(B, Lk, hd, seed=2), rnd(B, Lk, hd, seed=3)
     k[0, 200] = q[0, 5] * 6.0           # query 5 meets a huge score in the 4th key tile
     k[0, 70] = q[0, 9] * 4.0
-    Vt = torch.zeros(B, hd, 256, device=dev)
-    Vt[:] = v.transpose(1, 2).to(dev)
+    Vt = v.to(dev)
     Od = torch.empty(B, Lq, hd, device=dev)
     ops.attention(q.to(dev), k.to(dev), Vt, Od, H)
     torch.cuda.synchronize()
