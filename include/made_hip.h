@@ -59,8 +59,8 @@ int         made_device_info(char* name, int name_len, int* cu_count, int* is_gf
  * linears :205,:302, heads at reference model/model_Uni.py:131-146 and the X-Pool projections
  * reference modules/transformer.py:96-103,122,176.
  *
- *   A' = (A + A2[row % a2_row_mod]) for column segments flagged use_a2, else A; rows of A whose
- *   a_row_mask is 0 are read as zero.  W is [N,K] row-major (nn.Linear layout), K contiguous.
+ *   A' = (A + A2[row % a2_row_mod]) for column segments flagged use_a2 (or A2 itself when a2_replace is set),
+ *   else A; rows of A whose a_row_mask is 0 are read as zero.  W is [N,K] row-major (nn.Linear layout), K contiguous.
  *   Compute type = w_dtype: MADE_BF16 -> v_mfma_f32_32x32x16_bf16, MADE_F32 -> v_mfma_f32_32x32x2_f32
  *   (exact f32 FMA chain); accumulation is always f32.
  *   The N columns are split into up to 4 segments, each with its own output tensor; a segment may
@@ -88,6 +88,7 @@ typedef struct MadeLinearArgs {
     const void*  A;  int32_t a_dtype; int32_t w_dtype;
     int64_t      lda;
     const void*  A2; int64_t lda2; int64_t a2_row_mod;      /* A2 has a_dtype; may be NULL */
+    int32_t      a2_replace; int32_t _pad;                  /* 1: flagged segments read A2 INSTEAD of A (e.g. src+pos) */
     const float* a_row_mask;                                /* [M] or NULL */
     const void*  W;  int64_t ldw;
     const float* bias;                                      /* [N] f32 or NULL */
@@ -184,6 +185,14 @@ int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
 int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
                    const float* gamma, const float* beta,
                    void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+
+/* Same, plus a second output y2 = y + add (row r of `add` at add + r*ld_add; y2 has y's dtype and stride ldy2):
+ * the DETR layers need both src and src + pos (reference music_detr/transformer.py:193), so the norm that produces
+ * src also emits src + pos and the next projection reads it directly. gamma == NULL skips the normalisation
+ * (y = x), which turns the kernel into a fused copy/add for the first encoder layer. */
+int made_layernorm_add(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                       void* y, int32_t y_dtype, int64_t ldy, const void* add, int32_t add_dtype, int64_t ld_add,
+                       void* y2, int64_t ldy2, int64_t rows, int64_t D, float eps, void* stream);
 
 /* out[b, :] = sum_t x[b,t,:] * (mask[b,t] != 0) / sum_t mask[b,t]   (mask NULL: plain column sum,
  * no division).  Replaces reference model/model_Base.py:579,615 and the sum over frames inside

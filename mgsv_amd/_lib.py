@@ -26,6 +26,7 @@ class MadeLinearSeg(C.Structure):
 class MadeLinearArgs(C.Structure):
     _fields_ = [("A", vp), ("a_dtype", i32), ("w_dtype", i32), ("lda", i64),
                 ("A2", vp), ("lda2", i64), ("a2_row_mod", i64),
+                ("a2_replace", i32), ("_pad", i32),
                 ("a_row_mask", vp),
                 ("W", vp), ("ldw", i64),
                 ("bias", vp),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
     "made_attention_wide": (C.c_int, [C.POINTER(MadeWideAttnArgs), vp]),
     "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp]),
+    "made_layernorm_add": (C.c_int, [vp, i32, i64, vp, vp, vp, i32, i64, vp, i32, i64, vp, i64, i64, i64, f32, vp]),
     "made_masked_mean": (C.c_int, [vp, i32, i64, i64, vp, vp, i64, i64, i64, vp]),
     "made_l2norm_rows": (C.c_int, [vp, i32, i64, vp, vp, i32, i64, i64, i64, f32, vp]),
     "made_sine_pe": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, vp]),

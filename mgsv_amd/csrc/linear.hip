@@ -149,6 +149,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
             bool ok = gm < M && (a.a_row_mask == nullptr || a.a_row_mask[gm] != 0.f);
             pa[i] = ok ? A + (int64_t)gm * a.lda + kc * PER16 : nullptr;
             pa2[i] = (ok && A2) ? A2 + (int64_t)(a2mod > 0 ? gm % a2mod : gm) * a.lda2 + kc * PER16 : nullptr;
+            if (a.a2_replace && pa2[i]) { pa[i] = pa2[i]; pa2[i] = nullptr; }
             pw[i] = gn < N ? W + (int64_t)gn * a.ldw + kc * PER16 : nullptr;
         }
     }
@@ -346,6 +347,176 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
     }
 }
 
+
+// =================================================================================================
+// Fast path: bf16 activations and weights, no register prologue (no row mask, no additive A2).
+// Operands go global -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging), the LDS image
+// is unpadded 128-byte rows with an XOR swizzle applied on the SOURCE side (lane picks which 16-byte
+// chunk of the row it fetches) and undone on the fragment reads, so ds_read_b128 stays conflict-free.
+// One 32 KB stage, two barriers per slab; latency is hidden by running 4 workgroups per CU (about 100
+// VGPRs, 34 KB LDS).  The epilogue streams the tile out in two 64-row halves through the same LDS.
+constexpr int G_STAGE = 2 * BM * KB;                 // 32 KB: A rows then W rows, 128 B each
+constexpr int G_CT_LD = BN + 4;
+constexpr int G_LDS = (64 * G_CT_LD * 4 > G_STAGE) ? 64 * G_CT_LD * 4 : G_STAGE;
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+__global__ __launch_bounds__(NTHREADS, 4) void linear_glds_kernel(const MadeLinearArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G_LDS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+    const int n_tiles = (N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int64_t z = blockIdx.z;
+
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+        if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
+    const MadeLinearSeg seg = a.seg[si];
+
+    // ---- per-lane source pointers: wave w issues 1 KB pieces j = 4w+i (i = 0..3) of A and of W; piece j = rows
+    // 8j..8j+7; lane l -> row 8j + l/8, LDS slot l%8 holding global chunk (l%8) ^ swz(row)
+    const bf16_t* Abase = ((seg.use_a2 && a.A2 && a.a2_replace) ? (const bf16_t*)a.A2 : (const bf16_t*)a.A) + z * a.a_z_stride;
+    const int64_t lda = (seg.use_a2 && a.A2 && a.a2_replace) ? a.lda2 : a.lda;
+    const bf16_t* Wbase = (const bf16_t*)a.W + z * a.w_z_stride;
+    const bf16_t* pa[4];
+    const bf16_t* pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (4 * wave + i) + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gm = m0 + row; gm = gm < M ? gm : M - 1;          // rows past the edge are fetched from a valid row and never stored
+        int gn = n0 + row; gn = gn < N ? gn : N - 1;
+        pa[i] = Abase + (int64_t)gm * lda + chunk * 8;
+        pw[i] = Wbase + (int64_t)gn * a.ldw + chunk * 8;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment read offsets: row rr, 16-byte chunk c = 2*ks + hh -> rr*128 + ((c ^ swz(rr)) * 16)
+    int offa[2], offw[2], sa[2], sw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = wm * 64 + t * 32 + r, rw = wn * 64 + t * 32 + r;
+        offa[t] = ra * KB; sa[t] = swz(ra);
+        offw[t] = BM * KB + rw * KB; sw[t] = swz(rw);
+    }
+
+    const int nk = K / 64;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = 4 * wave + i;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(lds + BM * KB + piece * 1024), 16, 0, 0);
+        }
+        __syncthreads();                                   // waits for the LDS-DMA (vmcnt(0)) of every wave
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[2], fw[2];
+            const int c = 2 * ks + hh;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = *(const bf16x8*)(lds + offa[t] + ((c ^ sa[t]) << 4));
+                fw[t] = *(const bf16x8*)(lds + offw[t] + ((c ^ sw[t]) << 4));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fw[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();                                   // all fragment reads done before the stage is overwritten
+    }
+
+    // ---- epilogue, two 64-row halves through LDS ------------------------------------------------------
+    float* Ct = (float*)lds;
+    unsigned char* outp = (unsigned char*)seg.out;
+    const int64_t out_z = z * seg.out_z_stride;
+    const int rpb = (int)seg.rows_per_batch, rmod = (int)a.r_row_mod;
+    const int colb = (int)seg.col_begin;
+    const int odt = seg.out_dtype;
+    const int cc = tid & 15;
+    const int n = n0 + cc * 8;
+    int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (a.bias && j < nvalid) ? a.bias[n + j] : 0.f;
+    const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
+                         (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
+    const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Ct[(mt * 32 + acc_row(e, hh)) * G_CT_LD + wn * 64 + nt * 32 + r] = acc[mt][nt][e];
+        }
+        __syncthreads();
+        if (nvalid > 0) {
+#pragma unroll 2
+            for (int i = 0; i < 4; ++i) {
+                const int row = (tid >> 4) + 16 * i;
+                const int m = m0 + half * 64 + row;
+                if (m >= M) break;
+                const float* cp = Ct + row * G_CT_LD + cc * 8;
+                f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+                float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], a.act);
+                if (a.R) {
+                    const int rr = rmod > 0 ? m % rmod : m;
+                    const int64_t ro = (int64_t)rr * a.ldr + n;
+                    if (r_vec && nvalid == 8) {
+                        if (a.r_dtype == MADE_F32) {
+                            f32x4 r0 = *(const f32x4*)((const float*)a.R + ro), r1 = *(const f32x4*)((const float*)a.R + ro + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
+                        } else {
+                            bf16x8 rb = *(const bf16x8*)((const bf16_t*)a.R + ro);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)rb[j];
+                        }
+                    } else {
+                        for (int j = 0; j < nvalid; ++j) v[j] += load_as_f32(a.R, a.r_dtype, ro + j);
+                    }
+                }
+                if (a.out_row_mask && a.out_row_mask[m] == 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+                }
+                int64_t orow;
+                if (rpb > 0) {
+                    const int b = m / rpb, t = m - b * rpb;
+                    orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo;
+                } else {
+                    orow = (int64_t)m * seg.ldo;
+                }
+                store8(outp, odt, out_z + orow + (n - colb), v, nvalid, out_vec);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
@@ -389,7 +560,12 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
     dim3 grid((unsigned)tiles, 1, (unsigned)(a.split_k > 1 ? a.split_k : a.batch)), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
     if (a.w_dtype == MADE_BF16) {
-        if (a.a_dtype == MADE_F32) hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a);
+        bool fast = a.a_dtype == MADE_BF16 && a.K % 64 == 0 && a.a_row_mask == nullptr && a.split_k <= 1 &&
+                    (a.A2 == nullptr || a.a2_replace) && ((uintptr_t)a.A % 16 == 0) && (a.lda % 8 == 0);
+        for (int s = 0; s < a.nseg; ++s) fast = fast && !a.seg[s].transposed;
+        if (a.A2 && a.a2_replace) fast = fast && (a.a2_row_mod == 0) && (a.lda2 % 8 == 0);
+        if (fast) hipLaunchKernelGGL(linear_glds_kernel, grid, block, 0, st, a);
+        else if (a.a_dtype == MADE_F32) hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((linear_kernel<bf16_t, bf16_t>), grid, block, 0, st, a);
     } else {
         hipLaunchKernelGGL((linear_kernel<float, float>), grid, block, 0, st, a);

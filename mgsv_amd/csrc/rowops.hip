@@ -330,6 +330,41 @@ __device__ __forceinline__ void wave_layernorm(f32x4 (&v)[NV], int D, int lane, 
     }
 }
 
+
+// ---- LayerNorm with a second output y2 = y + add (gamma == nullptr: y = x) --------------------------
+template <int NV>
+__global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_add_kernel(const void* x, int xdt, int64_t ldx,
+                                                                const float* gamma, const float* beta, void* y, int ydt, int64_t ldy,
+                                                                const void* add, int adt, int64_t lda, void* y2, int64_t ldy2,
+                                                                int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) v[i] = load4(x, xdt, row * ldx + c);
+    }
+    if (gamma) wave_layernorm(v, D, lane, gamma, beta, eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            if (y) store4(y, ydt, row * ldy + c, v[i]);
+            f32x4 o = v[i];
+            if (ydt == MADE_BF16) {                       // y2 is built from the value y actually holds
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (float)(bf16_t)o[j];
+            }
+            f32x4 ad = load4(add, adt, row * lda + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += ad[j];
+            store4(y2, ydt, row * ldy2 + c, o);
+        }
+    }
+}
+
 template <bool WITH_LN, int NV>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_kernel(const MadeFinishArgs a) {
     const int lane = threadIdx.x & 63;
@@ -509,4 +544,16 @@ extern "C" int made_splitk_finish(const MadeFinishArgs* args, void* stream) {
     if (ln) { DISPATCH_NV(a.N, hipLaunchKernelGGL((splitk_finish_kernel<true, NV>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a)); }
     else hipLaunchKernelGGL((splitk_finish_kernel<false, 2>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
     return made_check_launch("made_splitk_finish");
+}
+
+extern "C" int made_layernorm_add(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                                  void* y, int32_t y_dtype, int64_t ldy, const void* add, int32_t add_dtype, int64_t ld_add,
+                                  void* y2, int64_t ldy2, int64_t rows, int64_t D, float eps, void* stream) {
+    MADE_REQUIRE(x && add && y2 && (gamma == nullptr || beta != nullptr), "made_layernorm_add: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldx % 4 == 0 && ldy % 4 == 0 && ld_add % 4 == 0 && ldy2 % 4 == 0,
+                     "made_layernorm_add: D and row strides must be multiples of 4 (D <= %d)", 64 * 4 * MAX_VEC);
+    if (rows <= 0) return MADE_OK;
+    DISPATCH_NV(D, hipLaunchKernelGGL(layernorm_add_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, add, add_dtype, ld_add, y2, ldy2, rows, (int)D, eps));
+    return made_check_launch("made_layernorm_add");
 }

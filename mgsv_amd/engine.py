@@ -184,7 +184,7 @@ class MadeEngine:
             return torch.zeros(shape, device=dev, dtype=dtype or tc)
 
         ws = dict(
-            fus=E(B, L, D), fus_mask=E(B, L, dtype=torch.float32), pos=E(B, L, D),
+            fus=E(B, L, D), fus_mask=E(B, L, dtype=torch.float32), pos=E(B, L, D), srcpos=E(B * L, D),
             x0=E(rows, D), x1=E(rows, D), x2=E(rows, D), x3=E(rows, D),
             qkv=E(rows, 3 * D), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
             dq_all=E(B * Q, c.detr_nheads * D), dpool=E(B * Q, c.detr_nheads * D),
@@ -216,9 +216,9 @@ class MadeEngine:
         qkv = ws["qkv"][:B * T]
         if pos is None:
             ops.linear(x, w_in, b_in, out=qkv)
-        else:                                       # the position embedding goes into q and k only
-            ops.linear(x, w_in, b_in, A2=pos, segs=[Seg(out=qkv, col_begin=0, use_a2=True),
-                                                    Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
+        else:                                       # q and k are projected from x + pos (given precomputed), v from x
+            ops.linear(x, w_in, b_in, A2=pos, a2_replace=True,
+                       segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
         q3 = qkv.view(B, T, 3 * D)
         att = ws["att"][:B * T]
         ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), H, key_mask=key_mask)
@@ -359,20 +359,24 @@ class MadeEngine:
         rows = B * L
         src = fus.view(rows, D)
         pos2 = pos.view(rows, D)
+        srcpos = ws["srcpos"]
+        ops.layernorm_add(src, None, None, pos2, None, srcpos)                 # layer 0: src + pos (no norm)
         for l in range(c.detr_enc_layers):
             p = f"detr_transformer.encoder.layers.{l}"
-            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=pos2)
+            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos)
             x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows])
             s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x2"][:rows])
             h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward])
             x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=ws["x1"][:rows])
-            src = ops.layernorm(x, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3" if l % 2 == 0 else "x0"][:rows])
+            # the norm that produces the next src also emits src + pos (next layer's q/k input, decoder's keys)
+            src = ws["x3" if l % 2 == 0 else "x0"][:rows]
+            ops.layernorm_add(x, P[p + ".ln2.g"], P[p + ".ln2.b"], pos2, src, srcpos)
         memory = src
         out["memory"] = memory.view(B, L, D)
 
         # ---- DETR decoder (K10).  Cross-attention runs in memory space (made_attention_wide): no projection of
         # the L memory rows at all; self-attention collapses to one folded Linear when there is a single query.
-        mem3, pos3 = memory.view(B, L, D), pos
+        mem3, mempos3 = memory.view(B, L, D), srcpos.view(B, L, D)
         tgt = ws["tgt"]
         src_vec = video if c.moment_query_type == "video" else music
         tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
@@ -409,7 +413,7 @@ class MadeEngine:
                 ops.attention(d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:], ws["datt"].view(B, Q, D), H)
                 skinny(ws["datt"], p + ".sa.out", R=tgt, ln1=ln1, ln1_out=t1)
             skinny(t1, p + ".ca.qk", A2=qp, a2_row_mod=Q, out=dq_all)
-            ops.attention_wide(dq4, mem3, mem3, dp4, scale=ca_scale, Kadd=pos3, key_mask=fus_mask,
+            ops.attention_wide(dq4, mempos3, mem3, dp4, scale=ca_scale, key_mask=fus_mask,
                                n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
             skinny(dpool, p + ".ca.vo", R=t1, ln1=ln2, ln1_out=t2)
             skinny(t2, p + ".ff1", act=ops.ACT_RELU, out=ws["dffn"])

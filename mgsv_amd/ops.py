@@ -112,7 +112,7 @@ class Seg:
 
 def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,
            segs: Optional[Sequence[Seg]] = None, A2: Optional[Tensor] = None, a2_row_mod: int = 0,
-           a_row_mask: Optional[Tensor] = None, act: int = ACT_NONE, R: Optional[Tensor] = None,
+           a2_replace: bool = False, a_row_mask: Optional[Tensor] = None, act: int = ACT_NONE, R: Optional[Tensor] = None,
            r_row_mod: int = 0, out_row_mask: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
            batch: int = 1, a_z_stride: int = 0, w_z_stride: int = 0, M: Optional[int] = None,
            N: Optional[int] = None, K: Optional[int] = None) -> Tensor:
@@ -126,6 +126,7 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     if A2 is not None:
         assert A2.dim() == 2 and A2.stride(1) == 1 and A2.dtype == A.dtype
         a.A2, a.lda2, a.a2_row_mod = _p(A2), A2.stride(0), a2_row_mod
+        a.a2_replace = 1 if a2_replace else 0
     a.a_row_mask = _p(_f32(a_row_mask, "a_row_mask"))
     a.W, a.ldw = _p(W), W.stride(0)
     a.bias = _p(_f32(bias, "bias"))
@@ -285,6 +286,20 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, out: Optional[Tensor] = No
                                _p(out), dt_of(out), out.stride(0), rows, D, eps, _stream()),
           "made_layernorm")
     return out
+
+
+def layernorm_add(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], add: Tensor, out: Optional[Tensor], out2: Tensor,
+                  eps: float = 1e-5) -> Tensor:
+    """out = LayerNorm(x) (or x when gamma is None; `out` may be None then), out2 = out + add.  All [rows, D]."""
+    assert x.dim() == 2 and add.dim() == 2 and out2.dim() == 2 and x.stride(1) == 1 and add.stride(1) == 1 and out2.stride(1) == 1
+    rows, D = x.shape
+    ydt = dt_of(out2)
+    if out is not None:
+        assert out.dtype == out2.dtype and out.stride(1) == 1
+    check(lib().made_layernorm_add(_p(x), dt_of(x), x.stride(0), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
+                                   _p(out), ydt, out.stride(0) if out is not None else 0, _p(add), dt_of(add), add.stride(0),
+                                   _p(out2), out2.stride(0), rows, D, eps, _stream()), "made_layernorm_add")
+    return out2
 
 
 def masked_mean(x: Tensor, mask: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
