@@ -194,6 +194,12 @@ int made_layernorm_add(const void* x, int32_t x_dtype, int64_t ldx, const float*
                        void* y, int32_t y_dtype, int64_t ldy, const void* add, int32_t add_dtype, int64_t ld_add,
                        void* y2, int64_t ldy2, int64_t rows, int64_t D, float eps, void* stream);
 
+/* y[r, :] = x[r, :] * (mask[r] != 0) converted to y_dtype: the masked_fill of reference model/model_Base.py:556,595
+ * fused with the f32 -> bf16 conversion of the pre-extracted features, so the input projection can use the
+ * direct-to-LDS GEMM path.  mask may be NULL. */
+int made_cast_mask_rows(const float* x, int64_t ldx, const float* mask, void* y, int32_t y_dtype, int64_t ldy,
+                        int64_t rows, int64_t D, void* stream);
+
 /* out[b, :] = sum_t x[b,t,:] * (mask[b,t] != 0) / sum_t mask[b,t]   (mask NULL: plain column sum,
  * no division).  Replaces reference model/model_Base.py:579,615 and the sum over frames inside
  * reference music_detr/loss_detr.py:116-117. */

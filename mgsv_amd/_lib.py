@@ -81,6 +81,7 @@ SIGNATURES = {
     "made_attention_wide": (C.c_int, [C.POINTER(MadeWideAttnArgs), vp]),
     "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp]),
     "made_layernorm_add": (C.c_int, [vp, i32, i64, vp, vp, vp, i32, i64, vp, i32, i64, vp, i64, i64, i64, f32, vp]),
+    "made_cast_mask_rows": (C.c_int, [vp, i64, vp, vp, i32, i64, i64, i64, vp]),
     "made_masked_mean": (C.c_int, [vp, i32, i64, i64, vp, vp, i64, i64, i64, vp]),
     "made_l2norm_rows": (C.c_int, [vp, i32, i64, vp, vp, i32, i64, i64, i64, f32, vp]),
     "made_sine_pe": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, vp]),

@@ -367,26 +367,27 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_add_ke
 
 template <bool WITH_LN, int NV>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_kernel(const MadeFinishArgs a) {
+    // WITH_LN: one wave per row, the NV chunks of the row live in registers (all partial loads in flight at once).
+    // !WITH_LN: one wave per (row, 256-column chunk): blockIdx.y = chunk.
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const int N = (int)a.N;
     const int64_t rr = a.r_row_mod > 0 ? row % a.r_row_mod : row;
-    f32x4 keep[WITH_LN ? NV : 1];
-    const int nchunks = (N + 255) / 256;
-#pragma unroll 1
-    for (int i = 0; i < nchunks; ++i) {
-        const int c = (i * WAVE + lane) * 4;
+    f32x4 keep[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = ((WITH_LN ? i : (int)blockIdx.y) * WAVE + lane) * 4;
         if (c >= N) continue;
         f32x4 acc = *(const f32x4*)(a.ws + row * N + c);
         int64_t s = 1;
-        for (; s + 4 <= a.split_k; s += 4) {              // four independent loads in flight
-            f32x4 t0 = *(const f32x4*)(a.ws + ((s + 0) * a.M + row) * N + c);
-            f32x4 t1 = *(const f32x4*)(a.ws + ((s + 1) * a.M + row) * N + c);
-            f32x4 t2 = *(const f32x4*)(a.ws + ((s + 2) * a.M + row) * N + c);
-            f32x4 t3 = *(const f32x4*)(a.ws + ((s + 3) * a.M + row) * N + c);
+        for (; s + 8 <= a.split_k; s += 8) {              // eight independent loads in flight
+            f32x4 t[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += (t0[j] + t1[j]) + (t2[j] + t3[j]);
+            for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(a.ws + ((s + u) * a.M + row) * N + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] += ((t[0][j] + t[1][j]) + (t[2][j] + t[3][j])) + ((t[4][j] + t[5][j]) + (t[6][j] + t[7][j]));
         }
         for (; s < a.split_k; ++s) {
             f32x4 t = *(const f32x4*)(a.ws + (s * a.M + row) * N + c);
@@ -406,11 +407,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_ke
             for (int j = 0; j < 4; ++j) acc[j] += t[j];
         }
         if (a.out) store4(a.out, a.out_dtype, row * a.ldo + c, acc);
-        if constexpr (WITH_LN) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-                if (k == i) keep[k] = acc;
-        }
+        keep[i] = acc;
     }
     if constexpr (WITH_LN) {
         wave_layernorm(keep, N, lane, a.ln1_g, a.ln1_b, a.eps);
@@ -435,6 +432,20 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_ke
             }
         }
     }
+}
+
+// ---- f32 rows -> compute dtype with the row mask applied (feeds the direct-to-LDS GEMM) -------------
+__global__ __launch_bounds__(ROW_THREADS) void cast_mask_rows_kernel(const float* x, int64_t ldx, const float* mask, void* y, int ydt,
+                                                                     int64_t ldy, int64_t rows, int D) {
+    const int64_t chunks_per_row = D / 8;
+    const int64_t idx = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (idx >= rows * chunks_per_row) return;
+    const int64_t row = idx / chunks_per_row;
+    const int c = (int)(idx % chunks_per_row) * 8;
+    f32x4 a0 = *(const f32x4*)(x + row * ldx + c), a1 = *(const f32x4*)(x + row * ldx + c + 4);
+    if (mask && mask[row] == 0.f) { a0[0] = a0[1] = a0[2] = a0[3] = 0.f; a1 = a0; }
+    store4(y, ydt, row * ldy + c, a0);
+    store4(y, ydt, row * ldy + c + 4, a1);
 }
 
 inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
@@ -542,7 +553,7 @@ extern "C" int made_splitk_finish(const MadeFinishArgs* args, void* stream) {
     }
     if (a.M == 0) return MADE_OK;
     if (ln) { DISPATCH_NV(a.N, hipLaunchKernelGGL((splitk_finish_kernel<true, NV>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a)); }
-    else hipLaunchKernelGGL((splitk_finish_kernel<false, 2>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((splitk_finish_kernel<false, 1>), dim3(row_blocks(a.M), (unsigned)((a.N + 255) / 256)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
     return made_check_launch("made_splitk_finish");
 }
 
@@ -556,4 +567,15 @@ extern "C" int made_layernorm_add(const void* x, int32_t x_dtype, int64_t ldx, c
     DISPATCH_NV(D, hipLaunchKernelGGL(layernorm_add_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, add, add_dtype, ld_add, y2, ldy2, rows, (int)D, eps));
     return made_check_launch("made_layernorm_add");
+}
+
+extern "C" int made_cast_mask_rows(const float* x, int64_t ldx, const float* mask, void* y, int32_t y_dtype, int64_t ldy,
+                                   int64_t rows, int64_t D, void* stream) {
+    MADE_REQUIRE(x && y, "made_cast_mask_rows: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0, "made_cast_mask_rows: D must be a multiple of 8, strides aligned");
+    if (rows <= 0) return MADE_OK;
+    const int64_t n = rows * (D / 8);
+    hipLaunchKernelGGL(cast_mask_rows_kernel, dim3((unsigned)((n + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       x, ldx, mask, y, y_dtype, ldy, rows, (int)D);
+    return made_check_launch("made_cast_mask_rows");
 }

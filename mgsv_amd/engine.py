@@ -185,10 +185,10 @@ class MadeEngine:
 
         ws = dict(
             fus=E(B, L, D), fus_mask=E(B, L, dtype=torch.float32), pos=E(B, L, D), srcpos=E(B * L, D),
-            x0=E(rows, D), x1=E(rows, D), x2=E(rows, D), x3=E(rows, D),
+            x0=E(rows, D), x1=E(rows, D), x2=E(rows, D), x3=E(rows, D), xin=E(B * max(Tv * c.vit_dim, Ta * c.ast_dim)),
             qkv=E(rows, 3 * D), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
             dq_all=E(B * Q, c.detr_nheads * D), dpool=E(B * Q, c.detr_nheads * D),
-            dws=E(32 * B * Q * max(D, 256) * 4, dtype=torch.float32),          # split-K partials of the skinny decoder GEMMs
+            dws=E(32 * B * Q * max(D, 256) * 4 * max(1, nd // 4), dtype=torch.float32),   # split-K partials of the skinny GEMMs
             part_o=E(B * 8 * c.detr_nheads * Q * D, dtype=torch.float32), part_ml=E(B * 8 * c.detr_nheads * Q * 2, dtype=torch.float32),
             vmean=E(B, D, dtype=torch.float32), mmean=E(B, D, dtype=torch.float32),
             video=E(B, D, dtype=torch.float32), music=E(B, D, dtype=torch.float32),
@@ -236,9 +236,13 @@ class MadeEngine:
                              "(reference model/model_Base.py:533 raises here too)")
         rows = B * T
         mflat = mask.reshape(-1)
-        x = ops.linear(feats.view(rows, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat,
-                       act=ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE,
-                       R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows])
+        act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE
+        if self.tc == torch.bfloat16:       # mask + f32->bf16 once, then the direct-to-LDS GEMM
+            xin = ops.cast_mask_rows(feats.view(rows, Kin), mflat, ws["xin"][:rows * Kin].view(rows, Kin))
+            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows])
+        else:
+            x = ops.linear(feats.view(rows, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act,
+                           R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows])
         for l in range(depth):
             p = f"{mod}.layers.{l}"
             x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x1"][:rows])
@@ -424,8 +428,13 @@ class MadeEngine:
         hs2 = hs.view(nd * B * Q, D)
         logits, spans = ws["logits"], ws["spans"]
         ops.linear(hs2, P["class_embed.w"], P["class_embed.b"], out=logits.view(-1, 2))
-        h1 = ops.linear(hs2, P["span_embed.0.w"], P["span_embed.0.b"], act=ops.ACT_RELU, out=ws["h1"])
-        h2 = ops.linear(h1, P["span_embed.1.w"], P["span_embed.1.b"], act=ops.ACT_RELU, out=ws["h2"])
+        if hs2.shape[0] <= 1024:
+            skinny(hs2, "span_embed.0", act=ops.ACT_RELU, out=ws["h1"])
+            skinny(ws["h1"], "span_embed.1", act=ops.ACT_RELU, out=ws["h2"])
+            h2 = ws["h2"]
+        else:
+            h1 = ops.linear(hs2, P["span_embed.0.w"], P["span_embed.0.b"], act=ops.ACT_RELU, out=ws["h1"])
+            h2 = ops.linear(h1, P["span_embed.1.w"], P["span_embed.1.b"], act=ops.ACT_RELU, out=ws["h2"])
         ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, out=spans.view(-1, 2))
         out.update(pred_logits=logits[-1], pred_spans=spans[-1], logits_all=logits, spans_all=spans)
         pq = vid_sum = None

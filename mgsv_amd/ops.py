@@ -302,6 +302,14 @@ def layernorm_add(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ad
     return out2
 
 
+def cast_mask_rows(x: Tensor, mask: Optional[Tensor], out: Tensor) -> Tensor:
+    """out[r] = x[r] * (mask[r] != 0), f32 -> out.dtype; x, out [rows, D]."""
+    assert x.dim() == 2 and out.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and out.stride(1) == 1
+    check(lib().made_cast_mask_rows(_p(x), x.stride(0), _p(_f32(mask, "mask")), _p(out), dt_of(out), out.stride(0),
+                                    x.shape[0], x.shape[1], _stream()), "made_cast_mask_rows")
+    return out
+
+
 def masked_mean(x: Tensor, mask: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
     """x [B,T,D] (unit inner stride), mask [B,T] or None (plain sum) -> [B,D] f32."""
     assert x.dim() == 3 and x.stride(2) == 1
