@@ -164,6 +164,11 @@ class MadeEngine:
         vec("crit_weights", torch.tensor([4.0 if c.l1_loss else 0.0, 1.0, 0.8, 0.0, w_contr], device=dev))
         self.P = P
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     # ------------------------------------------------------------------ workspace
     def _buffers(self, B: int, Tv: int, Ta: int) -> Dict[str, Tensor]:
         key = (B, Tv, Ta)
@@ -183,7 +188,11 @@ class MadeEngine:
         def Z(*shape, dtype=None):
             return torch.zeros(shape, device=dev, dtype=dtype or tc)
 
+        vr = B * Tv
         ws = dict(
+            # private scratch of the video branch (it runs on its own stream beside the audio branch)
+            v_x0=E(vr, D), v_x1=E(vr, D), v_x2=E(vr, D), v_x3=E(vr, D), v_xin=E(vr * c.vit_dim), v_qkv=E(vr, 3 * D),
+            v_att=E(vr, D), v_ffn=E(vr, F_t),
             fus=E(B, L, D), fus_mask=E(B, L, dtype=torch.float32), pos=E(B, L, D), srcpos=E(B * L, D),
             x0=E(rows, D), x1=E(rows, D), x2=E(rows, D), x3=E(rows, D), xin=E(B * max(Tv * c.vit_dim, Ta * c.ast_dim)),
             qkv=E(rows, 3 * D), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
@@ -224,9 +233,10 @@ class MadeEngine:
         ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), H, key_mask=key_mask)
         return att
 
-    def _encode(self, feats: Tensor, mask: Tensor, which: str, ws: Dict[str, Tensor], row_off: int) -> None:
+    def _encode(self, feats: Tensor, mask: Tensor, which: str, wsall: Dict[str, Tensor], row_off: int) -> None:
         """reference model/model_Base.py:544-617 -> writes fus[:, row_off:row_off+T] and mean/normalised vector."""
         c, P = self.cfg, self.P
+        ws = wsall if which == "audio" else {**wsall, **{k[2:]: v for k, v in wsall.items() if k.startswith("v_")}}
         B, T, Kin = feats.shape
         D = c.D
         proj, mod, pe, depth = (("vit_proj", "video_transformer", "pe_video", c.video_transformer_depth) if which == "video"
@@ -340,9 +350,15 @@ class MadeEngine:
         ws = self._buffers(B, Tv, Ta)
         fm, sm = frame_masks.contiguous(), segment_masks.contiguous()
 
-        # ---- temporal encoders (K1-K4) write straight into the fused DETR input
-        self._encode(frame_feats.contiguous(), fm, "video", ws, 0)
+        # ---- temporal encoders (K1-K4) write straight into the fused DETR input.  The video branch (B*T_v rows: every
+        # launch far smaller than the chip) runs on a second HIP stream beside the audio branch and joins before X-Pool.
+        cur = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._encode(frame_feats.contiguous(), fm, "video", ws, 0)
         self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv)
+        cur.wait_stream(side)
         fus, fus_mask = ws["fus"], ws["fus_mask"]
         fus_mask[:, :Tv].copy_(fm)
         fus_mask[:, Tv:].copy_(sm)
