@@ -42,6 +42,10 @@ def parse():
     p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--launch", choices=["graph", "eager"], default="graph")
+    p.add_argument("--workload", choices=["forward", "retrieval"], default="forward")
+    p.add_argument("--nv", type=int, default=53000)
+    p.add_argument("--nm", type=int, default=4000)
+    p.add_argument("--seg", type=int, default=96)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=2)
     return p.parse_args()
@@ -68,6 +72,59 @@ def cpu_baseline(cfg, sd, inp, steps: int):
                 sample=f"{steps} eval forwards of the same B={B} batch (oracle/made_oracle.py, torch CPU f32, {n} threads), {dt:.2f} s each")
 
 
+def retrieval_main(args, rank, world, local, dist):
+    """BASELINE.json configs[3]: all-pairs video x music similarity, videos row-sharded over the ranks, music side
+    all-gathered once per pass (RCCL).  A step = one full pass (exchange + scoring).  Strong scaling: the problem is fixed."""
+    from mgsv_amd.config import cfg_native
+    from mgsv_amd.retrieval import ShardedRetrieval, shard_rows
+    cfg = cfg_native()
+    dev = torch.device("cuda", local)
+    eng = MadeEngine(cfg, synth.make_state_dict(cfg, seed=0), device=dev, dtype=args.dtype)
+    N_v, N_m, S, D = args.nv, args.nm, args.seg, cfg.D
+    vlo, vhi = shard_rows(N_v, world, rank)
+    mlo, mhi = shard_rows(N_m, world, rank)
+    g = torch.Generator(device=dev).manual_seed(2 + rank)
+    v = torch.nn.functional.normalize(torch.randn(vhi - vlo, D, device=dev, generator=g), dim=-1)
+    seg = torch.randn(mhi - mlo, S, D, device=dev, generator=g)
+    lens = torch.randint(12, S + 1, (mhi - mlo,), device=dev, generator=g)
+    mask = (torch.arange(S, device=dev)[None] < lens[:, None]).float()
+    seg = (seg * mask[:, :, None]).to(eng.tc)
+    mu = torch.nn.functional.normalize(torch.randn(mhi - mlo, D, device=dev, generator=g), dim=-1)
+    sr = ShardedRetrieval(lambda a, b, c, d: eng.retrieval_sim_matrix(a, b, c, d))
+
+    def step():
+        return sr.sim_rows(v, seg, mask, mu)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        rows = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    assert rows.shape == (vhi - vlo, N_m) and bool(torch.isfinite(rows).all())
+    alg_bytes = 4.0 * (N_m * S * D + N_m * S + N_v * D + N_m * D + N_v * N_m)      # SURVEY 8(d): inputs once + sim matrix once
+    pairs = float(N_v) * N_m
+    if rank == 0:
+        sec = elapsed / args.steps
+        print(json.dumps({
+            "metric": "retrieval sim-matrix GB/s (all-pairs video x music, X-Pool + dual tower)", "value": round(alg_bytes / sec / 1e9, 3),
+            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[3]: N_v={N_v}, N_m={N_m}, S={S}, D={D}; videos row-sharded, music all-gathered",
+                       "pairs_per_s": round(pairs / sec, 1), "algorithmic_gb": round(alg_bytes / 1e9, 3)}}))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -80,6 +137,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL on ROCm
+
+    if args.workload == "retrieval":
+        retrieval_main(args, rank, world, local, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     cfg = cfg_headline()
     B, Tv, Ta = args.batch, cfg.max_v_frames, cfg.max_snippet_num
