@@ -370,7 +370,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_glds_kernel(const MadeLine
 
     const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
     const int n_tiles = (N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+    // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2); give each XCD a contiguous run of
+    // tiles so the n-tiles of one 128-row activation panel hit the same L2 (bijective for any tile count)
+    int tile_id;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
+        tile_id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+    }
+    const int tile_m = tile_id / n_tiles, tile_n = tile_id % n_tiles;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int64_t z = blockIdx.z;
 
