@@ -366,13 +366,20 @@ class MadeEngine:
         video, music = ws["video"], ws["music"]
         out: Dict[str, Tensor] = dict(video_feats=video, music_feats=music, frame_feats=frame, segment_feats=seg)
 
-        # ---- X-Pool similarities (K5-K7)
-        pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if want_pooled else None
-        self.xpool_sims(video, seg, sm, sims_out=ws["sims_single"], pooled_out=pooled)
-        self.dual_sims(video, music, out=ws["sims_dual"])
+        # ---- X-Pool similarities + retrieval loss (K5-K7): independent of the DETR branch, so they run on the side stream
+        # beside the (latency-bound) decoder and join at the end of the step
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if want_pooled else None
+            self.xpool_sims(video, seg, sm, sims_out=ws["sims_single"], pooled_out=pooled)
+            self.dual_sims(video, music, out=ws["sims_dual"])
+            if with_losses:
+                self._retrieval_loss(ws, video, music)
         out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"])
         if pooled is not None:
             out["music_feats_pooled"] = pooled.view(B, B, D)
+        if with_losses:
+            out["retrieval_loss"] = ws["ret_loss"]
 
         # ---- DETR encoder (K8, K9)
         pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
@@ -466,8 +473,21 @@ class MadeEngine:
             out.update(proj_queries=pq[-1], proj_vid_mem=pv, proj_queries_all=pq)
 
         if not with_losses:
+            cur.wait_stream(side)
             return out
-        # ---- retrieval loss (K7), reference model/model_Uni.py:236-275
+        # ---- matcher + set criterion (K12-K14), all layers in one launch each
+        tg = spans_target.contiguous()
+        pi, ti, cnt, status, cost = ops.hungarian_match(logits.view(nd * B, Q, 2), spans.view(nd * B, Q, 2), tg, c.foreground_label)
+        losses, total = ops.set_criterion(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"],
+                                          c.foreground_label, P["crit_weights"])
+        out.update(matcher_pred_idx=pi.view(nd, B, -1), matcher_tgt_idx=ti.view(nd, B, -1), matcher_count=cnt.view(nd, B),
+                   matcher_status=status, criterion_losses=losses, localization_loss=total)
+        cur.wait_stream(side)
+        return out
+
+    def _retrieval_loss(self, ws: Dict[str, Tensor], video: Tensor, music: Tensor) -> None:
+        """reference model/model_Uni.py:236-275 -> ws["ret_loss"]"""
+        c, P = self.cfg, self.P
         rl = ws["ret_loss"]
         ls = P["logit_scale"]
         wgt = float(c.dual_single_loss_weight)
@@ -481,15 +501,6 @@ class MadeEngine:
         else:                                                            # dual_single_sim_fuse
             both = self.dual_sims(video, music, add=ws["sims_single"])
             ops.clip_loss(both, ls, rl, weight=wgt)
-        out["retrieval_loss"] = rl
-        # ---- matcher + set criterion (K12-K14), all layers in one launch each
-        tg = spans_target.contiguous()
-        pi, ti, cnt, status, cost = ops.hungarian_match(logits.view(nd * B, Q, 2), spans.view(nd * B, Q, 2), tg, c.foreground_label)
-        losses, total = ops.set_criterion(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"],
-                                          c.foreground_label, P["crit_weights"])
-        out.update(matcher_pred_idx=pi.view(nd, B, -1), matcher_tgt_idx=ti.view(nd, B, -1), matcher_count=cnt.view(nd, B),
-                   matcher_status=status, criterion_losses=losses, localization_loss=total)
-        return out
 
     def _frame_rows_linear(self, frame: Tensor, w: Tensor, b: Tensor, out: Tensor, B: int, Tv: int) -> None:
         """Linear over the frame rows of `fus` ([B, Tv, D] view with batch stride L*D): one launch per batch
