@@ -39,15 +39,25 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     constexpr int NDT = HD / 32;                 // 32-row tiles of O^T
     constexpr bool IS_BF16 = SZ == 2;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BKEY * K_ROW + BKEY * V_ROW + BKEY * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BKEY * K_ROW + BKEY * V_ROW + BKEY * 4 + 16];
     unsigned char* lds_k = lds;
     unsigned char* lds_v = lds + BKEY * K_ROW;
     float* lds_bias = (float*)(lds + BKEY * K_ROW + BKEY * V_ROW);
+    int* lds_flag = (int*)(lds + BKEY * K_ROW + BKEY * V_ROW + BKEY * 4);     // != 0: this tile has a masked / out-of-range key
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int64_t b = blockIdx.z, h = blockIdx.y;
-    const int64_t q0 = (int64_t)blockIdx.x * BQ + wave * 32;
+    // 1-D grid, XCD-aware order: workgroups b, b+8, ... share an XCD; give each XCD a contiguous run of (batch, head,
+    // q-tile) triples so the q-tiles of one (batch, head) re-read its K / V from that XCD's L2 instead of HBM
+    const int qtiles = (int)((a.Lq + BQ - 1) / BQ);
+    int wg;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
+        wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+    }
+    const int qt = wg % qtiles;
+    const int64_t h = (wg / qtiles) % a.H, b = wg / (qtiles * a.H);
+    const int64_t q0 = (int64_t)qt * BQ + wave * 32;
     const bool wave_active = q0 < a.Lq;
 
     const TC* Kg = (const TC*)a.K + b * a.k_bs + h * HD;
@@ -67,6 +77,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     // ---- staging registers
     frag_t rk[NCH], rv[NCH];
     float rbias = 0.f;
+    int rflag = 0;
     auto load_tile = [&](int64_t key0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -85,6 +96,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
             int64_t key = key0 + tid;
             bool valid = key < a.Lk && (maskg == nullptr || maskg[key] != 0.f);
             rbias = valid ? 0.f : -INFINITY;
+            rflag = __any(!valid) ? 1 : 0;                 // tid < 64 is exactly wave 0
         }
     };
     auto store_tile = [&]() {
@@ -95,6 +107,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
             *(frag_t*)(lds_v + (c / K_CPR) * V_ROW + (c % K_CPR) * 16) = rv[i];
         }
         if (tid < BKEY) lds_bias[tid] = rbias;
+        if (tid == 0) lds_flag[0] = rflag;
     };
 
     f32x16 o[NDT];
@@ -135,34 +148,74 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
         }
 
         // ---- online softmax (per query = per lane column; the two lane halves hold different keys)
-        float mx = -INFINITY;
+        if constexpr (IS_BF16) {
+            // VALU diet: scores stay raw; exp2 with one FMA per element (scale*log2e folded), the key-mask bias only on
+            // tiles that contain a masked key, the O / l rescale only when some lane's running max moved (wave-uniform)
+            const float c = a.scale * 1.4426950408889634f;
+            if (lds_flag[0] != 0) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = s[kt][e] * a.scale + lds_bias[kt * 32 + acc_row(e, hh)];
-                s[kt][e] = v;
-                mx = fmaxf(mx, v);
+                    for (int e = 0; e < 16; ++e) s[kt][e] += lds_bias[kt * 32 + acc_row(e, hh)];
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = IS_BF16 ? __expf(m_run - m_use) : expf(m_run - m_use);
-        float psum = 0.f;
+            float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float p = IS_BF16 ? __expf(s[kt][e] - m_use) : expf(s[kt][e] - m_use);
-                s[kt][e] = p;
-                psum += p;
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            if (!__all(m_new == m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+                m_run = m_new;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+            const float mc = m_use * c;
+            float psum = 0.f;
 #pragma unroll
-        for (int d = 0; d < NDT; ++d)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+                for (int e = 0; e < 16; ++e) {
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c, -mc));
+                    s[kt][e] = p;
+                    psum += p;
+                }
+            l_run += psum;
+        } else {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = s[kt][e] * a.scale + lds_bias[kt * 32 + acc_row(e, hh)];
+                    s[kt][e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = expf(m_run - m_use);
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float p = expf(s[kt][e] - m_use);
+                    s[kt][e] = p;
+                    psum += p;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        }
 
         // ---- O^T += V^T P^T
         if constexpr (IS_BF16) {
@@ -230,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
 
 template <typename TC>
 int launch_attention(const MadeAttnArgs& a, hipStream_t st) {
-    dim3 grid((unsigned)((a.Lq + BQ - 1) / BQ), (unsigned)a.H, (unsigned)a.B), block(NTHREADS);
+    dim3 grid((unsigned)(((a.Lq + BQ - 1) / BQ) * a.H * a.B)), block(NTHREADS);
     switch (a.hd) {
         case 32: hipLaunchKernelGGL((attention_kernel<TC, 32>), grid, block, 0, st, a); break;
         case 64: hipLaunchKernelGGL((attention_kernel<TC, 64>), grid, block, 0, st, a); break;
@@ -250,7 +303,7 @@ extern "C" int made_attention(const MadeAttnArgs* args, void* stream) {
     MADE_REQUIRE(a.Q && a.K && a.V && a.O, "made_attention: null tensor");
     MADE_REQUIRE(a.B >= 0 && a.H > 0 && a.Lq >= 0 && a.Lk > 0, "made_attention: bad dims");
     MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention: bad dtype %d", a.dtype);
-    MADE_UNSUPPORTED(a.B <= 65535 && a.H <= 65535, "made_attention: B/H too large for the grid");
+    MADE_UNSUPPORTED(((a.Lq + BQ - 1) / BQ) * a.H * a.B < (1LL << 31), "made_attention: too many workgroups");
     const int per16 = a.dtype == MADE_F32 ? 4 : 8;
     MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.ldo % 4 == 0 &&
                      a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.v_bs % per16 == 0 && a.o_bs % 4 == 0,
