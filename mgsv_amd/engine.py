@@ -48,17 +48,15 @@ class MadeEngine:
         unsupported = []
         if c.video_transformer_depth < 1 or c.audio_transformer_depth < 1:
             unsupported.append("temporal transformer depth 0 (agg_module != transf)")
-        if "concat" not in c.mml_fusion:
+        if "concat" not in c.mml_fusion and "CA" not in c.mml_fusion:
             unsupported.append(f"mml_fusion={c.mml_fusion}")
         if c.vmr_fusion != "XA-music":
             unsupported.append(f"vmr_fusion={c.vmr_fusion}")
-        if c.fusion_mask != 1:
-            unsupported.append("fusion_mask=0")
         if c.mml_localization != "detr":
             unsupported.append(f"mml_localization={c.mml_localization}")
         if c.predict_center != 0 or c.audio_short_cut != 0 or c.moment_loss != 0:
             unsupported.append("predict_center/audio_short_cut/moment_loss")
-        if c.moment_query_type not in ("video", "music"):
+        if c.moment_query_type not in ("video", "music", "zero", "random"):
             unsupported.append(f"moment_query_type={c.moment_query_type}")
         if c.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse"):
             unsupported.append(f"vmr_loss={c.vmr_loss}")
@@ -120,6 +118,17 @@ class MadeEngine:
         lin("xa.out", xa + ".cross_attn.out_proj")
         lin("xa.lin", xa + ".linear_proj")
         vec("logit_scale", T("logit_scale").view(1))
+        if "CA" in c.mml_fusion:                                          # reference model/model_Base.py:99-213
+            ca = "video_music_fusion_cross_transformer"
+            mat("ca.q.w", T(ca + ".layers.0.0.to_q.weight"))
+            mat("ca.kv.w", T(ca + ".layers.0.0.to_kv.weight"))
+            lin("ca.out", ca + ".layers.0.0.to_out.0")
+            lin("ca.ff1", ca + ".layers.0.1.net.0")
+            lin("ca.ff2", ca + ".layers.0.1.net.3")
+            ln("ca.lnq", ca + ".attention_query_layer_norms.0")
+            ln("ca.lnc", ca + ".attention_context_layer_norms.0")
+            ln("ca.lnf", ca + ".ff_layer_norms.0")
+            lin("ca.final", ca + ".final_linear")
         for l in range(c.detr_enc_layers):
             p = f"detr_transformer.encoder.layers.{l}"
             mat(p + ".in.w", T(p + ".self_attn.in_proj_weight")); vec(p + ".in.b", T(p + ".self_attn.in_proj_bias"))
@@ -176,7 +185,8 @@ class MadeEngine:
         if ws is not None:
             return ws
         c, dev, tc = self.cfg, self.device, self.tc
-        D, L, Q = c.D, Tv + Ta, c.num_moment_queries
+        concat = "concat" in c.mml_fusion
+        D, L, Q = c.D, (Tv + Ta if concat else Ta), c.num_moment_queries
         F_t, F_d, nd = c.temporal_ffn_dim, c.detr_dim_feedforward, c.detr_dec_layers
         Lmax = max(L, Ta, Tv)
         Lpad = round_up(Lmax, 64)
@@ -214,6 +224,11 @@ class MadeEngine:
             ws.update(pq_raw=E(nd * B * Q, Dc, dtype=torch.float32), pq=E(nd, B, Q, Dc, dtype=torch.float32),
                       pv_raw=E(B * Tv, Dc, dtype=torch.float32), pv=E(B, Tv, Dc, dtype=torch.float32),
                       vid_sum=E(B, Dc, dtype=torch.float32))
+        if not concat:                      # CA fusion: encoders write their own buffers, the fusion block writes `fus`
+            inner = c.ca_heads * c.ca_dim_head
+            ws.update(frame_buf=E(B, Tv, D), seg_buf=E(B, Ta, D), ca_nx=E(B * Ta, D), ca_nc=E(B * Tv, D),
+                      ca_q=E(B * Ta, inner), ca_kv=E(B * Tv, 2 * inner), ca_att=E(B * Ta, inner),
+                      ca_x=E(B * Ta, D), ca_h=E(B * Ta, c.ca_ffn_dim), ca_y=E(B * Ta, D))
         self._ws[key] = ws
         return ws
 
@@ -261,10 +276,13 @@ class MadeEngine:
             x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3"][:rows])
             h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=ws["ffn"][:rows, :c.temporal_ffn_dim])
             x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=ws["x0"][:rows])
-        fus = ws["fus"]
-        local = fus[:, row_off:row_off + T]                              # [B, T, D] view
+        if "concat" in c.mml_fusion:
+            fus = ws["fus"]
+            local = fus[:, row_off:row_off + T]                          # [B, T, D] view
+        else:
+            local = ws["frame_buf"] if which == "video" else ws["seg_buf"]
         ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat,
-                   segs=[Seg(out=local, ldo=fus.stride(1), rows_per_batch=T, out_batch_stride=fus.stride(0))])
+                   segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
         mean, vec = (ws["vmean"], ws["video"]) if which == "video" else (ws["mmean"], ws["music"])
         ops.masked_mean(local, mask, out=mean)
         ops.l2norm_rows(mean, out_f32=vec)
@@ -305,7 +323,8 @@ class MadeEngine:
                 u = ops.linear(ubuf[:n * S], P["xa.out.w"], P["xa.out.b"], out=ubuf2[:n * S])
             # all videos attend to each track's segments: softmax over segments, scores never leave the chip
             ops.attention_wide(q.view(1, Nv, 1, D), kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D),
-                               o[:n * Nv].view(n, Nv, 1, D), scale=scale, key_mask=seg_mask[m0:m0 + n], shared_q=True)
+                               o[:n * Nv].view(n, Nv, 1, D), scale=scale,
+                               key_mask=seg_mask[m0:m0 + n] if seg_mask is not None else None, shared_q=True)
             rows = n * Nv
             if hoist:
                 a2 = o[:rows]
@@ -335,7 +354,7 @@ class MadeEngine:
                              music_embeds: Tensor, chunk_m: Optional[int] = None) -> Tensor:
         """reference test-MaDe.py:386-403: sim[Nv, Nm] = single (X-Pool) + dual (cosine)."""
         seg = segment_embeds.to(self.tc) if segment_embeds.dtype != self.tc else segment_embeds
-        single = self.xpool_sims(video_embeds, seg, segment_masks, chunk_m=chunk_m)
+        single = self.xpool_sims(video_embeds, seg, segment_masks if self.cfg.fusion_mask == 1 else None, chunk_m=chunk_m)
         return self.dual_sims(video_embeds, music_embeds, add=single)
 
     # ------------------------------------------------------------------ full forward
@@ -345,7 +364,8 @@ class MadeEngine:
         c, P = self.cfg, self.P
         B, Tv, _ = frame_feats.shape
         Ta = segment_feats.shape[1]
-        D, L, Q, nd = c.D, Tv + Ta, c.num_moment_queries, c.detr_dec_layers
+        concat = "concat" in c.mml_fusion
+        D, L, Q, nd = c.D, (Tv + Ta if concat else Ta), c.num_moment_queries, c.detr_dec_layers
         H = c.detr_nheads
         ws = self._buffers(B, Tv, Ta)
         fm, sm = frame_masks.contiguous(), segment_masks.contiguous()
@@ -360,9 +380,14 @@ class MadeEngine:
         self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv)
         cur.wait_stream(side)
         fus, fus_mask = ws["fus"], ws["fus_mask"]
-        fus_mask[:, :Tv].copy_(fm)
-        fus_mask[:, Tv:].copy_(sm)
-        frame, seg = fus[:, :Tv], fus[:, Tv:]
+        if concat:
+            fus_mask[:, :Tv].copy_(fm)
+            fus_mask[:, Tv:].copy_(sm)
+            frame, seg = fus[:, :Tv], fus[:, Tv:]
+        else:
+            fus_mask.copy_(sm)
+            frame, seg = ws["frame_buf"], ws["seg_buf"]
+            self._ca_fusion(ws, frame, seg, fm, sm, B, Tv, Ta)
         video, music = ws["video"], ws["music"]
         out: Dict[str, Tensor] = dict(video_feats=video, music_feats=music, frame_feats=frame, segment_feats=seg)
 
@@ -371,7 +396,7 @@ class MadeEngine:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if want_pooled else None
-            self.xpool_sims(video, seg, sm, sims_out=ws["sims_single"], pooled_out=pooled)
+            self.xpool_sims(video, seg, sm if c.fusion_mask == 1 else None, sims_out=ws["sims_single"], pooled_out=pooled)
             self.dual_sims(video, music, out=ws["sims_dual"])
             if with_losses:
                 self._retrieval_loss(ws, video, music)
@@ -405,8 +430,11 @@ class MadeEngine:
         # the L memory rows at all; self-attention collapses to one folded Linear when there is a single query.
         mem3, mempos3 = memory.view(B, L, D), srcpos.view(B, L, D)
         tgt = ws["tgt"]
-        src_vec = video if c.moment_query_type == "video" else music
-        tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        if c.moment_query_type in ("video", "music"):
+            src_vec = video if c.moment_query_type == "video" else music
+            tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        else:                                                            # "zero" / "random": reference transformer.py:73-74
+            tgt.zero_()
         qp = P["query_embed"]
         hs = ws["hs"]
         ca_scale = 1.0 / math.sqrt(D // H)
@@ -484,6 +512,27 @@ class MadeEngine:
                    matcher_status=status, criterion_losses=losses, localization_loss=total)
         cur.wait_stream(side)
         return out
+
+    def _ca_fusion(self, ws, frame: Tensor, seg: Tensor, fm: Tensor, sm: Tensor, B: int, Tv: int, Ta: int) -> None:
+        """reference model/model_Base.py:194-213 + :130-167 + :22-45 (depth 1) followed by the masked_fill of
+        model/model_Uni.py:211: pre-LN cross-attention (query = segments, context = frames, 8 heads x 128, bias-free q/kv,
+        kv-mask before the softmax and q-mask after it), residual, pre-LN GELU FFN with residual, final Linear -> ws["fus"]."""
+        c, P = self.cfg, self.P
+        D, Hc = c.D, c.ca_heads
+        inner = Hc * c.ca_dim_head
+        x = seg.reshape(B * Ta, D)
+        nx = ops.layernorm(x, P["ca.lnq.g"], P["ca.lnq.b"], out=ws["ca_nx"])
+        nc = ops.layernorm(frame.reshape(B * Tv, D), P["ca.lnc.g"], P["ca.lnc.b"], out=ws["ca_nc"])
+        q = ops.linear(nx, P["ca.q.w"], None, out=ws["ca_q"])
+        kv = ops.linear(nc, P["ca.kv.w"], None, out=ws["ca_kv"])
+        kv3 = kv.view(B, Tv, 2 * inner)
+        ops.attention(q.view(B, Ta, inner), kv3[:, :, :inner], kv3[:, :, inner:], ws["ca_att"].view(B, Ta, inner), Hc,
+                      key_mask=fm, q_mask=sm, scale=c.ca_dim_head ** -0.5)
+        ax = ops.linear(ws["ca_att"], P["ca.out.w"], P["ca.out.b"], R=x, out=ws["ca_x"])
+        nf = ops.layernorm(ax, P["ca.lnf.g"], P["ca.lnf.b"], out=ws["ca_nx"])
+        h = ops.linear(nf, P["ca.ff1.w"], P["ca.ff1.b"], act=ops.ACT_GELU, out=ws["ca_h"])
+        y = ops.linear(h, P["ca.ff2.w"], P["ca.ff2.b"], R=ax, out=ws["ca_y"])
+        ops.linear(y, P["ca.final.w"], P["ca.final.b"], out_row_mask=sm.reshape(-1), out=ws["fus"].view(B * Ta, D))
 
     def _retrieval_loss(self, ws: Dict[str, Tensor], video: Tensor, music: Tensor) -> None:
         """reference model/model_Uni.py:236-275 -> ws["ret_loss"]"""

@@ -62,13 +62,11 @@ class _XPoolModule(nn.Module):
         object.__setattr__(self, "_owner", owner)
 
     def forward(self, video_embeds, music_embeds, music_mask=None):
-        if music_mask is None:
-            raise NotImplementedError("fusion_mask=0 (unmasked X-Pool attention) is not on the HIP path yet")
         eng = self._owner._engine_ready()
         dev = eng.device
         v = video_embeds.to(dev, torch.float32).contiguous()
         s = music_embeds.to(dev).to(eng.tc).contiguous()
-        m = music_mask.to(dev, torch.float32).contiguous()
+        m = music_mask.to(dev, torch.float32).contiguous() if music_mask is not None else None
         Nm, Nv, D = s.shape[0], v.shape[0], v.shape[1]
         pooled = torch.empty(Nm * Nv, D, device=dev, dtype=torch.float32)
         eng.xpool_sims(v, s, m, pooled_out=pooled)

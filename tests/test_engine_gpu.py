@@ -32,7 +32,11 @@ def _cases():
     c3 = cfg_native(); c3.num_moment_queries = 3
     c4 = cfg_native(); c4.fb_label = "10"; c4.with_act_after_proj = 1; c4.vmr_loss = "dual_single_sim_fuse"
     c5 = cfg_native(); c5.moment_query_type = "music"; c5.contrastive_align_loss = 0; c5.vmr_loss = "single"
+    c6 = cfg_native(); c6.mml_fusion = "CA"
+    c7 = cfg_native(); c7.fusion_mask = 0; c7.moment_query_type = "zero"; c7.aux_loss = 1
     return {
+        "native_CA_fusion_B4": (c6, 4, 50, 96),
+        "native_nomask_zeroquery_B4": (c7, 4, 50, 96),
         "cfg1_B2": (cfg_plumbing(), 2, 30, 200),
         "native_B8": (cfg_native(), 8, 50, 96),
         "native_Q3_B4": (c3, 4, 50, 96),
@@ -148,7 +152,7 @@ def test_retrieval_matches_reference_golden_and_oracle(golden_dir):
 
 
 def test_engine_rejects_unsupported_configs_loudly():
-    cfg = cfg_native(); cfg.mml_fusion = "CA"
+    cfg = cfg_native(); cfg.vmr_fusion = "XA-music-video"
     with pytest.raises(NotImplementedError):
         MadeEngine(cfg, synth.make_state_dict(cfg, seed=0), dtype="f32")
     cfg = cfg_headline(); cfg.audio_attention_seqlen = 300
