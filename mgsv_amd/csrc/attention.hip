@@ -39,7 +39,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     constexpr int NDT = HD / 32;                 // 32-row tiles of O^T
     constexpr bool IS_BF16 = SZ == 2;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BKEY * K_ROW + BKEY * V_ROW + BKEY * 4 + 16];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BKEY * K_ROW + BKEY * V_ROW + BKEY * 4 + 32];
     unsigned char* lds_k = lds;
     unsigned char* lds_v = lds + BKEY * K_ROW;
     float* lds_bias = (float*)(lds + BKEY * K_ROW + BKEY * V_ROW);
@@ -117,8 +117,20 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
         for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int64_t ntiles = (a.Lk + BKEY - 1) / BKEY;
-    load_tile(0);
+    // keys after the last valid one contribute exactly 0: stop there (padding is a suffix in the dataset's masks)
+    int64_t lk_eff = a.Lk;
+    if (maskg) {
+        int last = -1;
+        for (int j = tid; j < (int)a.Lk; j += NTHREADS)
+            if (maskg[j] != 0.f) last = j;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
+        if (lane == 0) lds_flag[1 + wave] = last;
+        __syncthreads();
+        lk_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
+    }
+    const int64_t ntiles = (lk_eff + BKEY - 1) / BKEY;
+    if (ntiles > 0) load_tile(0);
     for (int64_t t = 0; t < ntiles; ++t) {
         __syncthreads();
         store_tile();

@@ -118,8 +118,22 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     float m_run = -INFINITY, l_run = 0.f;
 
     // keys of this workgroup: all of them, or the blockIdx.z-th slice when the keys are split over workgroups
+    // keys after the last valid one contribute exactly 0: stop there (padding is a suffix in the dataset's masks)
+    int64_t l_eff = a.L;
+    if (maskg) {
+        int last = -1;
+        for (int j = tid; j < (int)a.L; j += NTHREADS)
+            if (maskg[j] != 0.f) last = j;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
+        int* red = (int*)lds_s;
+        if (lane == 0) red[wave] = last;
+        __syncthreads();
+        l_eff = max(max(red[0], red[1]), max(red[2], red[3])) + 1;
+        __syncthreads();
+    }
     const int64_t nsplit = a.n_split > 1 ? a.n_split : 1;
-    const int64_t tiles_all = (a.L + WKEY - 1) / WKEY;
+    const int64_t tiles_all = (l_eff + WKEY - 1) / WKEY;
     const int64_t tiles_per = (tiles_all + nsplit - 1) / nsplit;
     const int64_t tile0 = (int64_t)blockIdx.z * tiles_per;
     const int64_t ntiles = tile0 >= tiles_all ? 0 : (tile0 + tiles_per <= tiles_all ? tiles_per : tiles_all - tile0);
