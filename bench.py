@@ -225,7 +225,9 @@ def main():
                     unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                     launches_per_step=d["launches"] // 3, avg_launch_us=round(d["ms"] / d["launches"] * 1e3, 2),
                     algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
-                    algorithmic_mb_per_launch=round(d["bytes"] / d["launches"] / 1e6, 3))
+                    algorithmic_mb_per_launch=round(d["bytes"] / d["launches"] / 1e6, 3),
+                    note="flops/bytes count executed 128-row tiles only: tiles made of padded tokens are skipped "
+                         f"({100 * (1 - d['flops'] / max(d['flops_nominal'], 1)):.0f}% of the nominal work)")
         for k, v in summ.items():
             per_kernel[k] = dict(launches_per_step=v["launches"] // 3, ms_per_step=round(v["ms"] / 3, 4),
                                  tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),

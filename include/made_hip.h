@@ -97,6 +97,10 @@ typedef struct MadeLinearArgs {
     int32_t      act; int32_t r_dtype;
     const void*  R;  int64_t ldr; int64_t r_row_mod;        /* added after act; may be NULL */
     const float* out_row_mask;                              /* [M] or NULL: masked rows -> 0 */
+    const float* tile_skip_mask;                            /* [M] or NULL: a tile whose rows are ALL 0 here is not computed
+                                                               (its rows are left untouched, or zeroed when out_row_mask is
+                                                               set): padded tokens cost nothing.  Rows are independent, so
+                                                               valid rows are unaffected. */
     int32_t      nseg; int32_t split_k;                     /* split_k > 1: see below */
     float*       split_ws;                                  /* [split_k, M, N] f32 workspace or NULL */
     MadeLinearSeg seg[4];
@@ -141,6 +145,8 @@ typedef struct MadeAttnArgs {
     int64_t q_bs, ldq, k_bs, ldk, v_bs, ldv, o_bs, ldo;
     const float* key_mask; const float* q_mask;
     float scale; int32_t _pad;
+    const float* q_skip_mask;  /* [B, Lq] or NULL: queries that are 0 here are padding whose output nobody reads; 32-query
+                                  groups (and whole workgroups) made only of them are skipped and their O rows left untouched */
 } MadeAttnArgs;
 
 int made_attention(const MadeAttnArgs* args, void* stream);
@@ -180,11 +186,13 @@ int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
 /* y = LayerNorm(x) * gamma + beta, eps inside the sqrt; one wave per row, D <= 2048, D % 4 == 0.
  * Input row r sits at x + (r / rpb) * x_batch_stride + (r % rpb) * ldx when rpb = x_rows_per_batch > 0
  * (a [B,T,D] view of a larger buffer), else at x + r * ldx; output rows are y + r * ldy.
+ * (rows are independent, so skipping padded rows leaves every valid row bit-identical.)
  * Replaces nn.LayerNorm at reference model/model_Base.py:83,85; music_detr/transformer.py:202,
  * 209,290,300,306,136; modules/transformer.py:164-165,174,178. */
 int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
                    const float* gamma, const float* beta,
-                   void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+                   void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps,
+                   const float* row_skip /* [rows] f32 or NULL: rows that are 0 here (padding) are not computed */, void* stream);
 
 /* Same, plus a second output y2 = y + add (row r of `add` at add + r*ld_add; y2 has y's dtype and stride ldy2):
  * the DETR layers need both src and src + pos (reference music_detr/transformer.py:193), so the norm that produces
@@ -192,7 +200,7 @@ int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_p
  * (y = x), which turns the kernel into a fused copy/add for the first encoder layer. */
 int made_layernorm_add(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
                        void* y, int32_t y_dtype, int64_t ldy, const void* add, int32_t add_dtype, int64_t ld_add,
-                       void* y2, int64_t ldy2, int64_t rows, int64_t D, float eps, void* stream);
+                       void* y2, int64_t ldy2, int64_t rows, int64_t D, float eps, const float* row_skip, void* stream);
 
 /* y[r, :] = x[r, :] * (mask[r] != 0) converted to y_dtype: the masked_fill of reference model/model_Base.py:556,595
  * fused with the f32 -> bf16 conversion of the pre-extracted features, so the input projection can use the

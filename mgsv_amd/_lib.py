@@ -35,6 +35,7 @@ class MadeLinearArgs(C.Structure):
                 ("act", i32), ("r_dtype", i32),
                 ("R", vp), ("ldr", i64), ("r_row_mod", i64),
                 ("out_row_mask", vp),
+                ("tile_skip_mask", vp),
                 ("nseg", i32), ("split_k", i32),
                 ("split_ws", vp),
                 ("seg", MadeLinearSeg * 4)]
@@ -57,7 +58,8 @@ class MadeAttnArgs(C.Structure):
                 ("q_bs", i64), ("ldq", i64), ("k_bs", i64), ("ldk", i64),
                 ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("ldo", i64),
                 ("key_mask", vp), ("q_mask", vp),
-                ("scale", f32), ("_pad", i32)]
+                ("scale", f32), ("_pad", i32),
+                ("q_skip_mask", vp)]
 
 
 class MadeWideAttnArgs(C.Structure):
@@ -79,8 +81,8 @@ SIGNATURES = {
     "made_splitk_finish": (C.c_int, [C.POINTER(MadeFinishArgs), vp]),
     "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
     "made_attention_wide": (C.c_int, [C.POINTER(MadeWideAttnArgs), vp]),
-    "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp]),
-    "made_layernorm_add": (C.c_int, [vp, i32, i64, vp, vp, vp, i32, i64, vp, i32, i64, vp, i64, i64, i64, f32, vp]),
+    "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp, vp]),
+    "made_layernorm_add": (C.c_int, [vp, i32, i64, vp, vp, vp, i32, i64, vp, i32, i64, vp, i64, i64, i64, f32, vp, vp]),
     "made_cast_mask_rows": (C.c_int, [vp, i64, vp, vp, i32, i64, i64, i64, vp]),
     "made_masked_mean": (C.c_int, [vp, i32, i64, i64, vp, vp, i64, i64, i64, vp]),
     "made_l2norm_rows": (C.c_int, [vp, i32, i64, vp, vp, i32, i64, i64, i64, f32, vp]),

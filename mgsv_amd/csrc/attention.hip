@@ -58,7 +58,15 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     const int qt = wg % qtiles;
     const int64_t h = (wg / qtiles) % a.H, b = wg / (qtiles * a.H);
     const int64_t q0 = (int64_t)qt * BQ + wave * 32;
-    const bool wave_active = q0 < a.Lq;
+    bool wave_active = q0 < a.Lq;
+    if (a.q_skip_mask) {
+        // 32-query groups made only of padded queries are not computed (nobody reads their rows); a workgroup made only
+        // of such groups exits before touching K / V
+        const int64_t q = q0 + (lane & 31);
+        const bool mine = wave_active && q < a.Lq && a.q_skip_mask[b * a.Lq + q] != 0.f;
+        wave_active = __any(mine);
+        if (!__syncthreads_or(wave_active ? 1 : 0)) return;
+    }
 
     const TC* Kg = (const TC*)a.K + b * a.k_bs + h * HD;
     const TC* Vg = (const TC*)a.V + b * a.v_bs + h * HD;
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
             int c = tid + i * NTHREADS;
             int krow = c / K_CPR, kc = c % K_CPR;
             int64_t key = key0 + krow;
-            if (key < a.Lk) {
+            if (key < a.Lk && (maskg == nullptr || maskg[key] != 0.f)) {      // masked keys read as zero rows: P is 0 there and 0*garbage must stay 0
                 rk[i] = *(const frag_t*)(Kg + key * a.ldk + kc * PER16);
                 rv[i] = *(const frag_t*)(Vg + key * a.ldv + kc * PER16);
             } else {

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
             int c = tid + i * NTHREADS;
             int row = c / CPR, cc = c % CPR;
             int64_t key = key0 + row;
-            if (key < a.L) {
+            if (key < a.L && (maskg == nullptr || maskg[key] != 0.f)) {          // masked keys read as zero rows
                 frag_t kv = *(const frag_t*)(Kg + key * a.ldk + cc * PER16);
                 rv[i] = v_is_k ? kv : *(const frag_t*)(Vg + key * a.ldv + cc * PER16);
                 if (Ag) {

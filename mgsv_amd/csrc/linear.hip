@@ -132,6 +132,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
     const MadeLinearSeg seg = a.seg[si];
     const bool transposed = seg.transposed != 0;
 
+    // ---- padded tiles: if every row of this tile is padding, there is nothing to compute
+    if (a.tile_skip_mask) {
+        int any_valid = 0;
+        if (tid < BM) {
+            const int gm = m0 + tid;
+            any_valid = (gm < M && a.tile_skip_mask[gm] != 0.f) ? 1 : 0;
+        }
+        if (!__syncthreads_or(any_valid)) {
+            if (a.out_row_mask && !seg.transposed && (a.split_k <= 1)) {       // consumers expect zeros in masked rows
+                const int rpb0 = (int)seg.rows_per_batch;
+                for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {
+                    const int row = idx / (BN / 8), c8 = idx % (BN / 8);
+                    const int m = m0 + row, n = n0 + c8 * 8;
+                    if (m >= M || n >= N) continue;
+                    int64_t orow;
+                    if (rpb0 > 0) { const int b = m / rpb0, t = m - b * rpb0; orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo; }
+                    else orow = (int64_t)m * seg.ldo;
+                    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    int nv = N - n; nv = nv > 8 ? 8 : nv;
+                    store8(seg.out, seg.out_dtype, blockIdx.z * seg.out_z_stride + orow + (n - (int)seg.col_begin), zero8, nv, false);
+                }
+            }
+            return;
+        }
+    }
+
     // ---- staging assignment: thread owns 16-byte chunk kc of rows srow0 + 32*i (i = 0..3) of A and of W.
     // All row-dependent address math is done once here, not per K slab.
     const int kc = tid & 7, srow0 = tid >> 3;
@@ -386,6 +412,33 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_glds_kernel(const MadeLine
     for (int s = 1; s < 4; ++s)
         if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
     const MadeLinearSeg seg = a.seg[si];
+
+
+    // ---- padded tiles: if every row of this tile is padding, there is nothing to compute
+    if (a.tile_skip_mask) {
+        int any_valid = 0;
+        if (tid < BM) {
+            const int gm = m0 + tid;
+            any_valid = (gm < M && a.tile_skip_mask[gm] != 0.f) ? 1 : 0;
+        }
+        if (!__syncthreads_or(any_valid)) {
+            if (a.out_row_mask && !seg.transposed && (a.split_k <= 1)) {       // consumers expect zeros in masked rows
+                const int rpb0 = (int)seg.rows_per_batch;
+                for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {
+                    const int row = idx / (BN / 8), c8 = idx % (BN / 8);
+                    const int m = m0 + row, n = n0 + c8 * 8;
+                    if (m >= M || n >= N) continue;
+                    int64_t orow;
+                    if (rpb0 > 0) { const int b = m / rpb0, t = m - b * rpb0; orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo; }
+                    else orow = (int64_t)m * seg.ldo;
+                    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    int nv = N - n; nv = nv > 8 ? 8 : nv;
+                    store8(seg.out, seg.out_dtype, blockIdx.z * seg.out_z_stride + orow + (n - (int)seg.col_begin), zero8, nv, false);
+                }
+            }
+            return;
+        }
+    }
 
     // ---- per-lane source pointers: wave w issues 1 KB pieces j = 4w+i (i = 0..3) of A and of W; piece j = rows
     // 8j..8j+7; lane l -> row 8j + l/8, LDS slot l%8 holding global chunk (l%8) ^ swz(row)

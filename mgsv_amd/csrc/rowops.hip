@@ -36,10 +36,11 @@ template <int NV>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_kernel(const void* x, int xdt, int64_t ldx, int64_t rpb, int64_t xbs,
                                                                 const float* gamma, const float* beta,
                                                                 void* y, int ydt, int64_t ldy,
-                                                                int64_t rows, int D, float eps) {
+                                                                int64_t rows, int D, float eps, const float* row_skip) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (row_skip && row_skip[row] == 0.f) return;
     const int64_t xoff = rpb > 0 ? (row / rpb) * xbs + (row % rpb) * ldx : row * ldx;
     f32x4 v[NV];
     float sum = 0.f;
@@ -336,10 +337,11 @@ template <int NV>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_add_kernel(const void* x, int xdt, int64_t ldx,
                                                                 const float* gamma, const float* beta, void* y, int ydt, int64_t ldy,
                                                                 const void* add, int adt, int64_t lda, void* y2, int64_t ldy2,
-                                                                int64_t rows, int D, float eps) {
+                                                                int64_t rows, int D, float eps, const float* row_skip) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (row_skip && row_skip[row] == 0.f) return;
     f32x4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -461,7 +463,8 @@ inline int nv_for(int64_t D) { return D <= 512 ? 2 : (D <= 1024 ? 4 : 8); }
 
 extern "C" int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
                               const float* gamma, const float* beta,
-                              void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream) {
+                              void* y, int32_t y_dtype, int64_t ldy, int64_t rows, int64_t D, float eps,
+                              const float* row_skip, void* stream) {
     MADE_REQUIRE(x && y && gamma && beta, "made_layernorm: null pointer");
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC, "made_layernorm: D=%lld must be a multiple of 4 and <= %d",
                      (long long)D, 64 * 4 * MAX_VEC);
@@ -469,7 +472,7 @@ extern "C" int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64
     MADE_REQUIRE(x_rows_per_batch >= 0, "made_layernorm: negative x_rows_per_batch");
     if (rows <= 0) return MADE_OK;
     DISPATCH_NV(D, hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                       x, x_dtype, ldx, x_rows_per_batch, x_batch_stride, gamma, beta, y, y_dtype, ldy, rows, (int)D, eps));
+                       x, x_dtype, ldx, x_rows_per_batch, x_batch_stride, gamma, beta, y, y_dtype, ldy, rows, (int)D, eps, row_skip));
     return made_check_launch("made_layernorm");
 }
 
@@ -559,13 +562,13 @@ extern "C" int made_splitk_finish(const MadeFinishArgs* args, void* stream) {
 
 extern "C" int made_layernorm_add(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
                                   void* y, int32_t y_dtype, int64_t ldy, const void* add, int32_t add_dtype, int64_t ld_add,
-                                  void* y2, int64_t ldy2, int64_t rows, int64_t D, float eps, void* stream) {
+                                  void* y2, int64_t ldy2, int64_t rows, int64_t D, float eps, const float* row_skip, void* stream) {
     MADE_REQUIRE(x && add && y2 && (gamma == nullptr || beta != nullptr), "made_layernorm_add: null pointer");
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldx % 4 == 0 && ldy % 4 == 0 && ld_add % 4 == 0 && ldy2 % 4 == 0,
                      "made_layernorm_add: D and row strides must be multiples of 4 (D <= %d)", 64 * 4 * MAX_VEC);
     if (rows <= 0) return MADE_OK;
     DISPATCH_NV(D, hipLaunchKernelGGL(layernorm_add_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                       x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, add, add_dtype, ld_add, y2, ldy2, rows, (int)D, eps));
+                       x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, add, add_dtype, ld_add, y2, ldy2, rows, (int)D, eps, row_skip));
     return made_check_launch("made_layernorm_add");
 }
 

@@ -234,18 +234,19 @@ class MadeEngine:
 
     # ------------------------------------------------------------------ building blocks
     def _mha_block(self, x: Tensor, B: int, T: int, w_in: Tensor, b_in: Tensor, key_mask: Optional[Tensor],
-                   ws: Dict[str, Tensor], H: int, pos: Optional[Tensor] = None) -> Tensor:
+                   ws: Dict[str, Tensor], H: int, pos: Optional[Tensor] = None, skip: Optional[Tensor] = None) -> Tensor:
         """packed in-proj -> flash attention; x [B*T, D]; q,k from (x + pos), v from x; returns att [B*T, D]."""
         D = self.cfg.D
         qkv = ws["qkv"][:B * T]
         if pos is None:
-            ops.linear(x, w_in, b_in, out=qkv)
+            ops.linear(x, w_in, b_in, out=qkv, tile_skip_mask=skip)
         else:                                       # q and k are projected from x + pos (given precomputed), v from x
-            ops.linear(x, w_in, b_in, A2=pos, a2_replace=True,
+            ops.linear(x, w_in, b_in, A2=pos, a2_replace=True, tile_skip_mask=skip,
                        segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
         q3 = qkv.view(B, T, 3 * D)
         att = ws["att"][:B * T]
-        ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), H, key_mask=key_mask)
+        ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), H, key_mask=key_mask,
+                      q_skip_mask=key_mask if skip is not None else None)
         return att
 
     def _encode(self, feats: Tensor, mask: Tensor, which: str, wsall: Dict[str, Tensor], row_off: int) -> None:
@@ -264,24 +265,27 @@ class MadeEngine:
         act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE
         if self.tc == torch.bfloat16:       # mask + f32->bf16 once, then the direct-to-LDS GEMM
             xin = ops.cast_mask_rows(feats.view(rows, Kin), mflat, ws["xin"][:rows * Kin].view(rows, Kin))
-            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows])
+            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows],
+                           tile_skip_mask=mflat)
         else:
             x = ops.linear(feats.view(rows, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act,
-                           R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows])
+                           R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows], tile_skip_mask=mflat)
         for l in range(depth):
             p = f"{mod}.layers.{l}"
-            x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x1"][:rows])
-            att = self._mha_block(x1, B, T, P[p + ".in.w"], P[p + ".in.b"], mask, ws, c.SA_temporal_heads)
-            x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=ws["x2"][:rows])
-            x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3"][:rows])
-            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=ws["ffn"][:rows, :c.temporal_ffn_dim])
-            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=ws["x0"][:rows])
+            # padded tokens (mask 0) are never read by a valid token, so whole tiles / rows / query groups of them are skipped
+            x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x1"][:rows], row_skip=mflat)
+            att = self._mha_block(x1, B, T, P[p + ".in.w"], P[p + ".in.b"], mask, ws, c.SA_temporal_heads, skip=mflat)
+            x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=ws["x2"][:rows], tile_skip_mask=mflat)
+            x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3"][:rows], row_skip=mflat)
+            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=ws["ffn"][:rows, :c.temporal_ffn_dim],
+                           tile_skip_mask=mflat)
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=ws["x0"][:rows], tile_skip_mask=mflat)
         if "concat" in c.mml_fusion:
             fus = ws["fus"]
             local = fus[:, row_off:row_off + T]                          # [B, T, D] view
         else:
             local = ws["frame_buf"] if which == "video" else ws["seg_buf"]
-        ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat,
+        ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat, tile_skip_mask=mflat,
                    segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
         mean, vec = (ws["vmean"], ws["video"]) if which == "video" else (ws["mmean"], ws["music"])
         ops.masked_mean(local, mask, out=mean)
@@ -316,11 +320,13 @@ class MadeEngine:
         scale = 1.0 / math.sqrt(D)
         for m0 in range(0, Nm, cm):
             n = min(cm, Nm - m0)
-            ops.layernorm(seg[m0:m0 + n], P["xa.ln1.g"], P["xa.ln1.b"], out=s1[:n * S])   # [n,S,D] view -> compact rows
-            ops.linear(s1[:n * S], P["xa.kv.w"], P["xa.kv.b"], segs=[Seg(out=kbuf, col_begin=0), Seg(out=ubuf, col_begin=D)])
+            skip = seg_mask[m0:m0 + n].reshape(-1) if seg_mask is not None else None    # masked segments are never attended to
+            ops.layernorm(seg[m0:m0 + n], P["xa.ln1.g"], P["xa.ln1.b"], out=s1[:n * S], row_skip=skip)   # [n,S,D] view -> compact rows
+            ops.linear(s1[:n * S], P["xa.kv.w"], P["xa.kv.b"], tile_skip_mask=skip,
+                       segs=[Seg(out=kbuf, col_begin=0), Seg(out=ubuf, col_begin=D)])
             u = ubuf
             if hoist:
-                u = ops.linear(ubuf[:n * S], P["xa.out.w"], P["xa.out.b"], out=ubuf2[:n * S])
+                u = ops.linear(ubuf[:n * S], P["xa.out.w"], P["xa.out.b"], out=ubuf2[:n * S], tile_skip_mask=skip)
             # all videos attend to each track's segments: softmax over segments, scores never leave the chip
             ops.attention_wide(q.view(1, Nv, 1, D), kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D),
                                o[:n * Nv].view(n, Nv, 1, D), scale=scale,
@@ -374,18 +380,22 @@ class MadeEngine:
         # launch far smaller than the chip) runs on a second HIP stream beside the audio branch and joins before X-Pool.
         cur = torch.cuda.current_stream()
         side = self._side_stream()
+        fus, fus_mask = ws["fus"], ws["fus_mask"]
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            # the DETR mask and its sine position embedding depend on the masks only: off the critical path
+            if concat:
+                fus_mask[:, :Tv].copy_(fm)
+                fus_mask[:, Tv:].copy_(sm)
+            else:
+                fus_mask.copy_(sm)
+            pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
             self._encode(frame_feats.contiguous(), fm, "video", ws, 0)
         self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv)
         cur.wait_stream(side)
-        fus, fus_mask = ws["fus"], ws["fus_mask"]
         if concat:
-            fus_mask[:, :Tv].copy_(fm)
-            fus_mask[:, Tv:].copy_(sm)
             frame, seg = fus[:, :Tv], fus[:, Tv:]
         else:
-            fus_mask.copy_(sm)
             frame, seg = ws["frame_buf"], ws["seg_buf"]
             self._ca_fusion(ws, frame, seg, fm, sm, B, Tv, Ta)
         video, music = ws["video"], ws["music"]
@@ -407,22 +417,23 @@ class MadeEngine:
             out["retrieval_loss"] = ws["ret_loss"]
 
         # ---- DETR encoder (K8, K9)
-        pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
         rows = B * L
         src = fus.view(rows, D)
         pos2 = pos.view(rows, D)
         srcpos = ws["srcpos"]
-        ops.layernorm_add(src, None, None, pos2, None, srcpos)                 # layer 0: src + pos (no norm)
+        fskip = fus_mask.view(-1)             # padded tokens of the fused sequence: skipped everywhere below
+        ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)      # layer 0: src + pos (no norm)
         for l in range(c.detr_enc_layers):
             p = f"detr_transformer.encoder.layers.{l}"
-            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos)
-            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows])
-            s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x2"][:rows])
-            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward])
-            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=ws["x1"][:rows])
+            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip)
+            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows], tile_skip_mask=fskip)
+            s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x2"][:rows], row_skip=fskip)
+            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward],
+                           tile_skip_mask=fskip)
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=ws["x1"][:rows], tile_skip_mask=fskip)
             # the norm that produces the next src also emits src + pos (next layer's q/k input, decoder's keys)
             src = ws["x3" if l % 2 == 0 else "x0"][:rows]
-            ops.layernorm_add(x, P[p + ".ln2.g"], P[p + ".ln2.b"], pos2, src, srcpos)
+            ops.layernorm_add(x, P[p + ".ln2.g"], P[p + ".ln2.b"], pos2, src, srcpos, row_skip=fskip)
         memory = src
         out["memory"] = memory.view(B, L, D)
 

@@ -74,12 +74,24 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, s, e, flops, nbytes, _desc in self.records:
-            d = out.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        frac_cache = {}
+        for kind, s, e, flops, nbytes, desc in self.records:
+            d = out.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, flops_nominal=0.0))
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
-            d["flops"] += flops
-            d["bytes"] += nbytes
+            frac = 1.0
+            if isinstance(desc, tuple):                 # (text, skip mask, rows per tile): count only tiles that were executed
+                _, mask, tile = desc
+                key = (mask.data_ptr(), mask.numel(), tile)
+                if key not in frac_cache:
+                    n = mask.numel()
+                    pad = (-n) % tile
+                    m = torch.nn.functional.pad(mask.reshape(-1) != 0, (0, pad)).view(-1, tile)
+                    frac_cache[key] = float(m.any(dim=1).float().mean().item())
+                frac = frac_cache[key]
+            d["flops"] += flops * frac
+            d["bytes"] += nbytes * frac
+            d["flops_nominal"] += flops
         return out
 
 
@@ -114,7 +126,7 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
            segs: Optional[Sequence[Seg]] = None, A2: Optional[Tensor] = None, a2_row_mod: int = 0,
            a2_replace: bool = False, a_row_mask: Optional[Tensor] = None, act: int = ACT_NONE, R: Optional[Tensor] = None,
            r_row_mod: int = 0, out_row_mask: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-           batch: int = 1, a_z_stride: int = 0, w_z_stride: int = 0, M: Optional[int] = None,
+           tile_skip_mask: Optional[Tensor] = None, batch: int = 1, a_z_stride: int = 0, w_z_stride: int = 0, M: Optional[int] = None,
            N: Optional[int] = None, K: Optional[int] = None) -> Tensor:
     """out = act(A' W^T + bias) (+R).  A [M,K] (row stride free, unit inner stride), W [N,K]."""
     assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
@@ -137,6 +149,7 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
         assert R.dim() == 2 and R.stride(1) == 1
         a.R, a.r_dtype, a.ldr, a.r_row_mod = _p(R), dt_of(R), R.stride(0), r_row_mod
     a.out_row_mask = _p(_f32(out_row_mask, "out_row_mask"))
+    a.tile_skip_mask = _p(_f32(tile_skip_mask, "tile_skip_mask"))
     if segs is None:
         if out is None:
             out = torch.empty((M, N) if batch == 1 else (batch, M, N), device=A.device,
@@ -154,8 +167,9 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     kind = "linear_" + ("f32" if a.w_dtype == F32 else ("bf16" if a.a_dtype == BF16 else "f32in_bf16"))
     flops = 2.0 * M * N * K * batch
     nbytes = batch * (M * K * (4 if a.a_dtype == F32 else 2) + N * K * esz + M * N * esz)
+    desc = f"M={M} N={N} K={K} z={batch} nseg={len(segs)} a2={int(A2 is not None)} R={int(R is not None)} act={act} tr={int(any(s_.transposed for s_ in segs))}"
     _timed(kind, flops, nbytes, lambda: check(lib().made_linear(C.byref(a), _stream()), "made_linear"),
-           f"M={M} N={N} K={K} z={batch} nseg={len(segs)} a2={int(A2 is not None)} R={int(R is not None)} act={act} tr={int(any(s_.transposed for s_ in segs))}")
+           (desc, tile_skip_mask, 128) if tile_skip_mask is not None else desc)
     return segs[0].out
 
 
@@ -204,7 +218,8 @@ def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, spli
 
 
 def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,
-              q_mask: Optional[Tensor] = None, scale: Optional[float] = None, Lk: Optional[int] = None) -> Tensor:
+              q_mask: Optional[Tensor] = None, scale: Optional[float] = None, Lk: Optional[int] = None,
+              q_skip_mask: Optional[Tensor] = None) -> Tensor:
     """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K / V [B,Lk,H*hd], O [B,Lq,H*hd]
     (any batch/row strides, unit inner stride).  Lk defaults to K.shape[1]."""
     assert Q.dim() == 3 and K.dim() == 3 and V.dim() == 3 and O.dim() == 3
@@ -222,6 +237,7 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
     a.o_bs, a.ldo = O.stride(0), O.stride(1)
     a.key_mask = _p(_f32(key_mask, "key_mask"))
     a.q_mask = _p(_f32(q_mask, "q_mask"))
+    a.q_skip_mask = _p(_f32(q_skip_mask, "q_skip_mask"))
     a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
     esz = 4 if a.dtype == F32 else 2
     flops = 4.0 * B * H * Lq * a.Lk * hd
@@ -269,7 +285,7 @@ def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, 
 
 
 def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, out: Optional[Tensor] = None, eps: float = 1e-5,
-              out_dtype: Optional[torch.dtype] = None) -> Tensor:
+              out_dtype: Optional[torch.dtype] = None, row_skip: Optional[Tensor] = None) -> Tensor:
     """LayerNorm over the last axis.  x: [rows, D] (row stride free) or a [B, T, D] view of a larger buffer
     (batch and row strides free); out: [rows, D] / [B*T, D] with free row stride."""
     assert x.dim() in (2, 3) and x.stride(-1) == 1
@@ -283,13 +299,13 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, out: Optional[Tensor] = No
         out = torch.empty((rows, D), device=x.device, dtype=out_dtype or x.dtype)
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= rows
     check(lib().made_layernorm(_p(x), dt_of(x), ldx, rpb, xbs, _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
-                               _p(out), dt_of(out), out.stride(0), rows, D, eps, _stream()),
+                               _p(out), dt_of(out), out.stride(0), rows, D, eps, _p(_f32(row_skip, "row_skip")), _stream()),
           "made_layernorm")
     return out
 
 
 def layernorm_add(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], add: Tensor, out: Optional[Tensor], out2: Tensor,
-                  eps: float = 1e-5) -> Tensor:
+                  eps: float = 1e-5, row_skip: Optional[Tensor] = None) -> Tensor:
     """out = LayerNorm(x) (or x when gamma is None; `out` may be None then), out2 = out + add.  All [rows, D]."""
     assert x.dim() == 2 and add.dim() == 2 and out2.dim() == 2 and x.stride(1) == 1 and add.stride(1) == 1 and out2.stride(1) == 1
     rows, D = x.shape
@@ -298,7 +314,7 @@ def layernorm_add(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ad
         assert out.dtype == out2.dtype and out.stride(1) == 1
     check(lib().made_layernorm_add(_p(x), dt_of(x), x.stride(0), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
                                    _p(out), ydt, out.stride(0) if out is not None else 0, _p(add), dt_of(add), add.stride(0),
-                                   _p(out2), out2.stride(0), rows, D, eps, _stream()), "made_layernorm_add")
+                                   _p(out2), out2.stride(0), rows, D, eps, _p(_f32(row_skip, "row_skip")), _stream()), "made_layernorm_add")
     return out2
 
 

@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 tot = {}
 for kind, s, e, fl, nb, desc in kt.records:
     ms = s.elapsed_time(e)
-    key = (kind, desc)
+    key = (kind, desc[0] + ' skip' if isinstance(desc, tuple) else desc)
     d = tot.setdefault(key, [0, 0.0, fl])
     d[0] += 1; d[1] += ms
 for (kind, desc), (n, ms, fl) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
