@@ -14,6 +14,8 @@
 //   bf16 : v_mfma_f32_32x32x16_bf16,  f32 : v_mfma_f32_32x32x2_f32 (exact f32, used for parity)
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int BQ = 128;       // queries per workgroup
@@ -86,28 +88,40 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     frag_t rk[NCH], rv[NCH];
     float rbias = 0.f;
     int rflag = 0;
-    auto load_tile = [&](int64_t key0) {
+    auto load_tile_impl = [&](int64_t key0, auto has_mask) __attribute__((always_inline)) {
+        // branch-free: every lane always loads (row index clamped into the tensor), masking happens on the registers
+        float mk[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;
             int krow = c / K_CPR, kc = c % K_CPR;
             int64_t key = key0 + krow;
-            if (key < a.Lk && (maskg == nullptr || maskg[key] != 0.f)) {      // masked keys read as zero rows: P is 0 there and 0*garbage must stay 0
-                rk[i] = *(const frag_t*)(Kg + key * a.ldk + kc * PER16);
-                rv[i] = *(const frag_t*)(Vg + key * a.ldv + kc * PER16);
-            } else {
+            const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
+            rk[i] = *(const frag_t*)(Kg + kcl * a.ldk + kc * PER16);
+            rv[i] = *(const frag_t*)(Vg + kcl * a.ldv + kc * PER16);
+            if constexpr (decltype(has_mask)::value) mk[i] = maskg[kcl]; else mk[i] = 1.f;
+        }
 #pragma unroll
-                for (int j = 0; j < PER16; ++j) { rk[i][j] = (TC)0.f; rv[i][j] = (TC)0.f; }
-            }
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NTHREADS;
+            const bool keep = (key0 + c / K_CPR) < a.Lk && mk[i] != 0.f;   // masked keys read as zero rows: 0*garbage must stay 0
+            rk[i] = keep_or_zero(rk[i], keep);
+            rv[i] = keep_or_zero(rv[i], keep);
         }
         if (tid < BKEY) {
             int64_t key = key0 + tid;
-            bool valid = key < a.Lk && (maskg == nullptr || maskg[key] != 0.f);
+            const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
+            float mkb = 1.f;
+            if constexpr (decltype(has_mask)::value) mkb = maskg[kcl];
+            const bool valid = key < a.Lk && mkb != 0.f;
             rbias = valid ? 0.f : -INFINITY;
             rflag = __any(!valid) ? 1 : 0;                 // tid < 64 is exactly wave 0
         }
     };
-    auto store_tile = [&]() {
+    auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
+        if (maskg) load_tile_impl(key0, std::true_type{}); else load_tile_impl(key0, std::false_type{});
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;

@@ -17,6 +17,8 @@
 // Keys are consumed 32 at a time; K (+Kadd) and V tiles are staged global -> registers -> LDS.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int WQ = 32;        // queries per workgroup
@@ -42,13 +44,12 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     static_assert(WKEY * CPR % NTHREADS == 0, "staging split");
     constexpr int NQF = DS * SZ / 32;               // k-steps (16-byte fragment pairs) of this wave's QK slice
     constexpr int NDT = DS / 32;                    // 32-row tiles of this wave's O^T slice
-    constexpr bool PREFETCH = IS_BF16;              // f32 (parity mode) has no registers to spare
+    constexpr int KV_STAGE = WKEY * K_ROW + WKEY * V_ROW;
+    constexpr int NSTAGE = IS_BF16 ? 2 : 1;         // bf16: two K/V stages (one barrier less per tile, loads overlap the MFMAs)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* lds_k = lds;
-    unsigned char* lds_v = lds + WKEY * K_ROW;
-    float* lds_s = (float*)(lds + WKEY * K_ROW + WKEY * V_ROW);      // [4][32*32] partial score tiles
-    float* lds_bias = lds_s + 4 * 1024;                               // [32]
+    float* lds_s = (float*)(lds + NSTAGE * KV_STAGE);                 // [4][32*32] partial score tiles
+    float* lds_bias_all = lds_s + 4 * 1024;                           // [NSTAGE][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -59,7 +60,6 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     const TC* Kg = (const TC*)a.K + b * a.k_bs;
     const TC* Ag = a.Kadd ? (const TC*)a.Kadd + b * a.kadd_bs : nullptr;
     const TC* Vg = (const TC*)a.V + b * a.v_bs;
-    const bool v_is_k = (a.V == a.K) && a.v_bs == a.k_bs && a.ldv == a.ldk;
     const float* maskg = a.key_mask ? a.key_mask + b * a.L : nullptr;
 
     // ---- Q fragments of this wave's D slice: lane (r, hh) holds Q[nq0 + r][w*DS + ks*2*PER16 + hh*PER16 ..]
@@ -74,40 +74,63 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
 
     frag_t rk[NCH], rv[NCH];
     float rbias = 0.f;
-    auto load_tile = [&](int64_t key0) {
+    auto load_tile_impl = [&](int64_t key0, auto has_mask) __attribute__((always_inline)) {
+        // branch-free: every lane always loads (row index clamped into the tensor), masking happens on the registers
+        bool keep[NCH];
+        float mk[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;
             int row = c / CPR, cc = c % CPR;
             int64_t key = key0 + row;
-            if (key < a.L && (maskg == nullptr || maskg[key] != 0.f)) {          // masked keys read as zero rows
-                frag_t kv = *(const frag_t*)(Kg + key * a.ldk + cc * PER16);
-                rv[i] = v_is_k ? kv : *(const frag_t*)(Vg + key * a.ldv + cc * PER16);
-                if (Ag) {
-                    frag_t av = *(const frag_t*)(Ag + key * a.ldkadd + cc * PER16);
-#pragma unroll
-                    for (int j = 0; j < PER16; ++j) kv[j] = from_f32<TC>(to_f32(kv[j]) + to_f32(av[j]));
-                }
-                rk[i] = kv;
-            } else {
-#pragma unroll
-                for (int j = 0; j < PER16; ++j) { rk[i][j] = (TC)0.f; rv[i][j] = (TC)0.f; }
-            }
+            const int64_t kcl = key < a.L ? key : a.L - 1;
+            rk[i] = *(const frag_t*)(Kg + kcl * a.ldk + cc * PER16);
+            rv[i] = *(const frag_t*)(Vg + kcl * a.ldv + cc * PER16);
+            if constexpr (decltype(has_mask)::value) mk[i] = maskg[kcl]; else mk[i] = 1.f;
         }
-        if (tid < WKEY) {
-            int64_t key = key0 + tid;
-            bool valid = key < a.L && (maskg == nullptr || maskg[key] != 0.f);
-            rbias = valid ? 0.f : -INFINITY;
-        }
-    };
-    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;
-            *(frag_t*)(lds_k + (c / CPR) * K_ROW + (c % CPR) * 16) = rk[i];
-            *(frag_t*)(lds_v + (c / CPR) * V_ROW + (c % CPR) * 16) = rv[i];
+            keep[i] = (key0 + c / CPR) < a.L && mk[i] != 0.f;
         }
-        if (tid < WKEY) lds_bias[tid] = rbias;
+        if (Ag) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                int c = tid + i * NTHREADS;
+                int row = c / CPR, cc = c % CPR;
+                int64_t key = key0 + row;
+                const int64_t kcl = key < a.L ? key : a.L - 1;
+                frag_t av = *(const frag_t*)(Ag + kcl * a.ldkadd + cc * PER16);
+#pragma unroll
+                for (int j = 0; j < PER16; ++j) rk[i][j] = from_f32<TC>(to_f32(rk[i][j]) + to_f32(av[j]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {                      // masked / out-of-range keys read as zero rows
+            rk[i] = keep_or_zero(rk[i], keep[i]);
+            rv[i] = keep_or_zero(rv[i], keep[i]);
+        }
+        if (tid < WKEY) {
+            int64_t key = key0 + tid;
+            const int64_t kcl = key < a.L ? key : a.L - 1;
+            float mkb = 1.f;
+            if constexpr (decltype(has_mask)::value) mkb = maskg[kcl];
+            rbias = (key < a.L && mkb != 0.f) ? 0.f : -INFINITY;
+        }
+    };
+    auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
+        if (maskg) load_tile_impl(key0, std::true_type{}); else load_tile_impl(key0, std::false_type{});
+    };
+    auto store_tile = [&](int stage) __attribute__((always_inline)) {
+        unsigned char* sk = lds + stage * KV_STAGE;
+        unsigned char* sv = sk + WKEY * K_ROW;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NTHREADS;
+            *(frag_t*)(sk + (c / CPR) * K_ROW + (c % CPR) * 16) = rk[i];
+            *(frag_t*)(sv + (c / CPR) * V_ROW + (c % CPR) * 16) = rv[i];
+        }
+        if (tid < WKEY) lds_bias_all[stage * WKEY + tid] = rbias;
     };
 
     f32x16 o[NDT];
@@ -137,14 +160,25 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     const int64_t tiles_per = (tiles_all + nsplit - 1) / nsplit;
     const int64_t tile0 = (int64_t)blockIdx.z * tiles_per;
     const int64_t ntiles = tile0 >= tiles_all ? 0 : (tile0 + tiles_per <= tiles_all ? tiles_per : tiles_all - tile0);
-    if (PREFETCH && ntiles > 0) load_tile(tile0 * WKEY);
+    if (NSTAGE == 2 && ntiles > 0) {
+        load_tile(tile0 * WKEY);
+        store_tile(0);
+        __syncthreads();
+    }
     for (int64_t tt = 0; tt < ntiles; ++tt) {
         const int64_t t = tile0 + tt;
-        if (!PREFETCH) load_tile(t * WKEY);
-        __syncthreads();                                  // previous tile fully consumed
-        store_tile();
-        __syncthreads();
-        if (PREFETCH && tt + 1 < ntiles) load_tile((t + 1) * WKEY);
+        const int cur = NSTAGE == 2 ? (int)(tt & 1) : 0;
+        if (NSTAGE == 2) {
+            if (tt + 1 < ntiles) load_tile((t + 1) * WKEY);   // in flight during this tile's MFMAs; stored at the end of the tile
+        } else {
+            load_tile(t * WKEY);
+            __syncthreads();                                  // previous tile fully consumed
+            store_tile(0);
+            __syncthreads();
+        }
+        const unsigned char* lds_k = lds + cur * KV_STAGE;
+        const unsigned char* lds_v = lds_k + WKEY * K_ROW;
+        const float* lds_bias = lds_bias_all + cur * WKEY;
 
         // ---- partial S^T [32 keys x 32 queries] over this wave's D slice
         f32x16 s;
@@ -163,7 +197,8 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
         // ---- sum the four partial tiles through LDS; every wave ends with the full tile
 #pragma unroll
         for (int e = 0; e < 16; ++e) lds_s[wave * 1024 + acc_row(e, hh) * 32 + r] = s[e];
-        __syncthreads();
+        // LDS-only wait + raw barrier: __syncthreads() would also drain vmcnt and stall on the prefetched tile
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         float mx = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -222,6 +257,10 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[e], o[d], 0, 0, 0);
                 }
             }
+        }
+        if (NSTAGE == 2) {
+            if (tt + 1 < ntiles) store_tile(cur ^ 1);          // the other stage: nobody reads it during this tile
+            __syncthreads();
         }
     }
 
@@ -310,7 +349,8 @@ template <typename TC, int D>
 int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     constexpr int SZ = (int)sizeof(TC);
     constexpr int K_ROW = D * SZ + 16, V_ROW = D * SZ + (SZ == 2 ? 64 : 16);
-    const size_t lds_bytes = (size_t)WKEY * K_ROW + (size_t)WKEY * V_ROW + 4 * 1024 * 4 + 32 * 4;
+    constexpr int NSTAGE = SZ == 2 ? 2 : 1;
+    const size_t lds_bytes = (size_t)NSTAGE * (WKEY * K_ROW + WKEY * V_ROW) + 4 * 1024 * 4 + NSTAGE * 32 * 4;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -72,6 +72,16 @@ __device__ __forceinline__ void store_from_f32(void* p, int dtype, int64_t idx, 
     else ((bf16_t*)p)[idx] = (bf16_t)v;
 }
 
+// keep ? x : 0 on a 16-byte fragment without control flow (conditional LOADS make hipcc branch around every load and
+// wait for each one in turn -- cdna_hip_programming.md, "three .s-level traps" (c); load always, mask afterwards)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <typename F> __device__ __forceinline__ F keep_or_zero(F x, bool keep) {
+    u32x4 b = __builtin_bit_cast(u32x4, x);
+    const unsigned int m = keep ? 0xFFFFFFFFu : 0u;
+    b[0] &= m; b[1] &= m; b[2] &= m; b[3] &= m;
+    return __builtin_bit_cast(F, b);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -164,28 +164,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
     const TA* pa[4];
     const TA* pa2[4];
     const TC* pw[4];
+    bool ka[4], kw[4];                                 // keep flags: rows past the edge / masked rows are zeroed AFTER the load
+    const bool has_a2 = seg.use_a2 && a.A2 && !a.a2_replace;
     {
-        const TA* A = (const TA*)a.A + z * a.a_z_stride;
-        const TA* A2 = (seg.use_a2 && a.A2) ? (const TA*)a.A2 : nullptr;
+        const bool repl = seg.use_a2 && a.A2 && a.a2_replace;
+        const TA* A = (repl ? (const TA*)a.A2 : (const TA*)a.A) + z * a.a_z_stride;
+        const int64_t lda = repl ? a.lda2 : a.lda;
+        const TA* A2 = has_a2 ? (const TA*)a.A2 : nullptr;
         const TC* W = (const TC*)a.W + z * a.w_z_stride;
         const int a2mod = (int)a.a2_row_mod;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int gm = m0 + srow0 + 32 * i, gn = n0 + srow0 + 32 * i;
-            bool ok = gm < M && (a.a_row_mask == nullptr || a.a_row_mask[gm] != 0.f);
-            pa[i] = ok ? A + (int64_t)gm * a.lda + kc * PER16 : nullptr;
-            pa2[i] = (ok && A2) ? A2 + (int64_t)(a2mod > 0 ? gm % a2mod : gm) * a.lda2 + kc * PER16 : nullptr;
-            if (a.a2_replace && pa2[i]) { pa[i] = pa2[i]; pa2[i] = nullptr; }
-            pw[i] = gn < N ? W + (int64_t)gn * a.ldw + kc * PER16 : nullptr;
+            const int gm = m0 + srow0 + 32 * i, gn = n0 + srow0 + 32 * i;
+            const int gmc = gm < M ? gm : M - 1, gnc = gn < N ? gn : N - 1;       // clamped: every lane always loads
+            ka[i] = gm < M && (a.a_row_mask == nullptr || a.a_row_mask[gmc] != 0.f);
+            kw[i] = gn < N;
+            pa[i] = A + (int64_t)gmc * lda + kc * PER16;
+            pa2[i] = A2 ? A2 + (int64_t)(a2mod > 0 ? gmc % a2mod : gmc) * a.lda2 + kc * PER16 : nullptr;
+            pw[i] = W + (int64_t)gnc * a.ldw + kc * PER16;
         }
     }
     frag_t ra[4], rw[4];
+    // branch-free staging loads (conditional loads make hipcc wait for each load in turn): the K offset is clamped into
+    // the row, out-of-range pieces are zeroed on the registers
     auto load_stage = [&](int k0) {
         const bool kin = k0 + kc * PER16 < K;
+        const int kofs = kin ? k0 : 0;
+        if (has_a2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = load_a_frag<TA, TC>(pa[i] + kofs, pa2[i] + kofs);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = load_a_frag<TA, TC>(pa[i] + kofs, nullptr);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[i] = *(const frag_t*)(pw[i] + kofs);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = (pa[i] && kin) ? load_a_frag<TA, TC>(pa[i] + k0, pa2[i] ? pa2[i] + k0 : nullptr) : zero_frag<TC>();
-            rw[i] = (pw[i] && kin) ? *(const frag_t*)(pw[i] + k0) : zero_frag<TC>();
+            ra[i] = keep_or_zero(ra[i], ka[i] && kin);
+            rw[i] = keep_or_zero(rw[i], kw[i] && kin);
         }
     };
     auto store_stage = [&](unsigned char* st) {
