@@ -32,7 +32,7 @@ __device__ __forceinline__ void store4(void* p, int dtype, int64_t idx, f32x4 v)
 
 // ---- LayerNorm -----------------------------------------------------------------------------
 // Two-pass (mean, then centred variance) in registers: the row is read from HBM once.
-template <int NV>
+template <int NV, bool FULL>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_kernel(const void* x, int xdt, int64_t ldx, int64_t rpb, int64_t xbs,
                                                                 const float* gamma, const float* beta,
                                                                 void* y, int ydt, int64_t ldy,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_kernel
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
             v[i] = load4(x, xdt, xoff + c);
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_kernel
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; sq += d * d; }
         }
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_kernel
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
             f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c), o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
@@ -86,11 +86,13 @@ __global__ __launch_bounds__(ROW_THREADS) void masked_mean_kernel(const void* x,
     const int phase = threadIdx.x >> 6;
     const int64_t b = blockIdx.y;
     float acc = 0.f, n = 0.f;
+    const int colc = col < D ? col : D - 1;            // every lane always loads; the mask is applied on the value
 #pragma unroll 8
     for (int64_t t = phase; t < T; t += 4) {
         float mk = mask ? mask[b * T + t] : 1.f;
         n += mk;
-        if (mk != 0.f && col < D) acc += load_as_f32(x, xdt, b * x_bs + t * ldx + col);
+        float xv = load_as_f32(x, xdt, b * x_bs + t * ldx + colc);
+        acc += (mk != 0.f) ? xv : 0.f;
     }
     part[phase][threadIdx.x & 63] = acc;
     if ((threadIdx.x & 63) == 0) cnt[phase] = n;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(ROW_THREADS) void masked_mean_kernel(const void* x,
 }
 
 // ---- L2 normalise rows -------------------------------------------------------------------------
-template <int NV>
+template <int NV, bool FULL>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void l2norm_kernel(const void* x, int xdt, int64_t ldx, float* y32,
                                                              void* yalt, int yadt, int64_t ldy,
                                                              int64_t rows, int D, float eps) {
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void l2norm_kernel(co
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
             v[i] = load4(x, xdt, row * ldx + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) sq += v[i][j] * v[i][j];
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void l2norm_kernel(co
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = v[i][j] / nrm;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(ROW_THREADS) void masked_softmax_kernel(const float
 }
 
 // ---- X-Pool tail: LayerNorm3 + cosine with the video --------------------------------------------
-template <int NV>
+template <int NV, bool FULL>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void xpool_tail_kernel(const void* y, int ydt, int64_t ldy, const float* gamma,
                                                                  const float* beta, const float* video, int64_t ldv,
                                                                  float* pooled, float* sims, int64_t lds_, int64_t rows,
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void xpool_tail_kerne
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
             v[i] = load4(y, ydt, row * ldy + c);
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void xpool_tail_kerne
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; sq += d * d; }
         }
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void xpool_tail_kerne
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
             f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c), o;
             f32x4 vid = *(const f32x4*)(video + n * ldv + c);
 #pragma unroll
@@ -305,17 +307,17 @@ __device__ __forceinline__ float finish_act(float x, int act) {
     }
 }
 
-template <int NV>
+template <int NV, bool FULL>
 __device__ __forceinline__ void wave_layernorm(f32x4 (&v)[NV], int D, int lane, const float* g, const float* b, float eps) {
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        if ((i * WAVE + lane) * 4 < D) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        if (FULL || (i * WAVE + lane) * 4 < D) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        if ((i * WAVE + lane) * 4 < D) {
+        if (FULL || (i * WAVE + lane) * 4 < D) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; sq += d * d; }
         }
@@ -323,7 +325,7 @@ __device__ __forceinline__ void wave_layernorm(f32x4 (&v)[NV], int D, int lane, 
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
             f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(b + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
@@ -333,7 +335,7 @@ __device__ __forceinline__ void wave_layernorm(f32x4 (&v)[NV], int D, int lane, 
 
 
 // ---- LayerNorm with a second output y2 = y + add (gamma == nullptr: y = x) --------------------------
-template <int NV>
+template <int NV, bool FULL>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_add_kernel(const void* x, int xdt, int64_t ldx,
                                                                 const float* gamma, const float* beta, void* y, int ydt, int64_t ldy,
                                                                 const void* add, int adt, int64_t lda, void* y2, int64_t ldy2,
@@ -346,13 +348,13 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_add_ke
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) v[i] = load4(x, xdt, row * ldx + c);
+        if (FULL || c < D) v[i] = load4(x, xdt, row * ldx + c);
     }
-    if (gamma) wave_layernorm(v, D, lane, gamma, beta, eps);
+    if (gamma) wave_layernorm<NV, FULL>(v, D, lane, gamma, beta, eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * WAVE + lane) * 4;
-        if (c < D) {
+        if (FULL || c < D) {
             if (y) store4(y, ydt, row * ldy + c, v[i]);
             f32x4 o = v[i];
             if (ydt == MADE_BF16) {                       // y2 is built from the value y actually holds
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_add_ke
     }
 }
 
-template <bool WITH_LN, int NV>
+template <bool WITH_LN, int NV, bool FULL>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_kernel(const MadeFinishArgs a) {
     // WITH_LN: one wave per row, the NV chunks of the row live in registers (all partial loads in flight at once).
     // !WITH_LN: one wave per (row, 256-column chunk): blockIdx.y = chunk.
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_ke
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = ((WITH_LN ? i : (int)blockIdx.y) * WAVE + lane) * 4;
-        if (c >= N) continue;
+        if (!FULL && c >= N) continue;
         f32x4 acc = *(const f32x4*)(a.ws + row * N + c);
         int64_t s = 1;
         for (; s + 8 <= a.split_k; s += 8) {              // eight independent loads in flight
@@ -412,11 +414,11 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_ke
         keep[i] = acc;
     }
     if constexpr (WITH_LN) {
-        wave_layernorm(keep, N, lane, a.ln1_g, a.ln1_b, a.eps);
+        wave_layernorm<NV, FULL>(keep, N, lane, a.ln1_g, a.ln1_b, a.eps);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int c = (i * WAVE + lane) * 4;
-            if (c < N && a.ln1_out) store4(a.ln1_out, a.ln1_dtype, row * a.ln1_ld + c, keep[i]);
+            if ((FULL || c < N) && a.ln1_out) store4(a.ln1_out, a.ln1_dtype, row * a.ln1_ld + c, keep[i]);
         }
         if (a.ln2_g) {
             // the second norm sees what the first one STORED (rounded to its dtype), like a separate kernel would
@@ -426,11 +428,11 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_ke
 #pragma unroll
                     for (int j = 0; j < 4; ++j) keep[i][j] = (float)(bf16_t)keep[i][j];
             }
-            wave_layernorm(keep, N, lane, a.ln2_g, a.ln2_b, a.eps);
+            wave_layernorm<NV, FULL>(keep, N, lane, a.ln2_g, a.ln2_b, a.eps);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 int c = (i * WAVE + lane) * 4;
-                if (c < N) store4(a.ln2_out, a.ln2_dtype, row * a.ln2_ld + c, keep[i]);
+                if (FULL || c < N) store4(a.ln2_out, a.ln2_dtype, row * a.ln2_ld + c, keep[i]);
             }
         }
     }
@@ -452,11 +454,13 @@ __global__ __launch_bounds__(ROW_THREADS) void cast_mask_rows_kernel(const float
 
 inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
 inline int nv_for(int64_t D) { return D <= 512 ? 2 : (D <= 1024 ? 4 : 8); }
-#define DISPATCH_NV(D, CALL)                      \
-    switch (nv_for(D)) {                          \
-        case 2: { constexpr int NV = 2; CALL; } break; \
-        case 4: { constexpr int NV = 4; CALL; } break; \
-        default: { constexpr int NV = 8; CALL; } break; \
+// NV = 16-byte vectors per lane; FULL = the row fills them exactly (D == 256*NV), so the bounds checks fold away and the
+// loads are unconditional (conditional loads get serialised by hipcc: one s_waitcnt per load)
+#define DISPATCH_NV(D, CALL)                                                      \
+    switch (nv_for(D)) {                                                          \
+        case 2: { constexpr int NV = 2; if ((D) == 512) { constexpr bool FULL = true; CALL; } else { constexpr bool FULL = false; CALL; } } break; \
+        case 4: { constexpr int NV = 4; if ((D) == 1024) { constexpr bool FULL = true; CALL; } else { constexpr bool FULL = false; CALL; } } break; \
+        default: { constexpr int NV = 8; constexpr bool FULL = false; CALL; } break; \
     }
 
 }  // namespace
@@ -471,7 +475,7 @@ extern "C" int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64
     MADE_UNSUPPORTED(ldx % 4 == 0 && ldy % 4 == 0 && x_batch_stride % 4 == 0, "made_layernorm: row strides must be multiples of 4");
     MADE_REQUIRE(x_rows_per_batch >= 0, "made_layernorm: negative x_rows_per_batch");
     if (rows <= 0) return MADE_OK;
-    DISPATCH_NV(D, hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_kernel<NV, FULL>), dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        x, x_dtype, ldx, x_rows_per_batch, x_batch_stride, gamma, beta, y, y_dtype, ldy, rows, (int)D, eps, row_skip));
     return made_check_launch("made_layernorm");
 }
@@ -491,7 +495,7 @@ extern "C" int made_l2norm_rows(const void* x, int32_t x_dtype, int64_t ldx, flo
     MADE_REQUIRE(x && (y_f32 || y_alt), "made_l2norm_rows: null pointer");
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldx % 4 == 0 && ldy % 4 == 0, "made_l2norm_rows: bad D/strides");
     if (rows <= 0) return MADE_OK;
-    DISPATCH_NV(D, hipLaunchKernelGGL(l2norm_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+    DISPATCH_NV(D, hipLaunchKernelGGL((l2norm_kernel<NV, FULL>), dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        x, x_dtype, ldx, y_f32, y_alt, y_alt_dtype, ldy, rows, (int)D, eps));
     return made_check_launch("made_l2norm_rows");
 }
@@ -525,7 +529,7 @@ extern "C" int made_xpool_tail(const void* y, int32_t y_dtype, int64_t ldy, cons
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldy % 4 == 0 && ld_video % 4 == 0, "made_xpool_tail: bad D/strides");
     const int64_t rows = Nm * Nv;
     if (rows <= 0) return MADE_OK;
-    DISPATCH_NV(D, hipLaunchKernelGGL(xpool_tail_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+    DISPATCH_NV(D, hipLaunchKernelGGL((xpool_tail_kernel<NV, FULL>), dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        y, y_dtype, ldy, gamma, beta, video, ld_video, pooled_out, sims, ld_sims, rows, Nv, (int)D, eps));
     return made_check_launch("made_xpool_tail");
 }
@@ -555,8 +559,9 @@ extern "C" int made_splitk_finish(const MadeFinishArgs* args, void* stream) {
         MADE_REQUIRE(a.ln2_g == nullptr, "made_splitk_finish: ln2 without ln1");
     }
     if (a.M == 0) return MADE_OK;
-    if (ln) { DISPATCH_NV(a.N, hipLaunchKernelGGL((splitk_finish_kernel<true, NV>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a)); }
-    else hipLaunchKernelGGL((splitk_finish_kernel<false, 1>), dim3(row_blocks(a.M), (unsigned)((a.N + 255) / 256)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
+    if (ln) { DISPATCH_NV(a.N, hipLaunchKernelGGL((splitk_finish_kernel<true, NV, FULL>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a)); }
+    else if (a.N % 256 == 0) hipLaunchKernelGGL((splitk_finish_kernel<false, 1, true>), dim3(row_blocks(a.M), (unsigned)(a.N / 256)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((splitk_finish_kernel<false, 1, false>), dim3(row_blocks(a.M), (unsigned)((a.N + 255) / 256)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
     return made_check_launch("made_splitk_finish");
 }
 
@@ -567,7 +572,7 @@ extern "C" int made_layernorm_add(const void* x, int32_t x_dtype, int64_t ldx, c
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAX_VEC && ldx % 4 == 0 && ldy % 4 == 0 && ld_add % 4 == 0 && ldy2 % 4 == 0,
                      "made_layernorm_add: D and row strides must be multiples of 4 (D <= %d)", 64 * 4 * MAX_VEC);
     if (rows <= 0) return MADE_OK;
-    DISPATCH_NV(D, hipLaunchKernelGGL(layernorm_add_kernel<NV>, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_add_kernel<NV, FULL>), dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, add, add_dtype, ld_add, y2, ldy2, rows, (int)D, eps, row_skip));
     return made_check_launch("made_layernorm_add");
 }
