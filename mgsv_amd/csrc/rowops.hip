@@ -371,33 +371,60 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void layernorm_add_ke
 
 template <bool WITH_LN, int NV, bool FULL>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void splitk_finish_kernel(const MadeFinishArgs a) {
-    // WITH_LN: one wave per row, the NV chunks of the row live in registers (all partial loads in flight at once).
+    // WITH_LN: one WORKGROUP per row: the 4 waves each sum a quarter of the K-splits (all their partial loads in flight
+    //          at once), the quarters meet in LDS and wave 0 applies bias / act / residual and the LayerNorm(s).
     // !WITH_LN: one wave per (row, 256-column chunk): blockIdx.y = chunk.
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
+    __shared__ f32x4 part[WITH_LN ? 3 * NV * WAVE : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = WITH_LN ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + wave;
     if (row >= a.M) return;
     const int N = (int)a.N;
     const int64_t rr = a.r_row_mod > 0 ? row % a.r_row_mod : row;
+    const int64_t s_begin = WITH_LN ? wave : 0, s_step = WITH_LN ? 4 : 1;
     f32x4 keep[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = ((WITH_LN ? i : (int)blockIdx.y) * WAVE + lane) * 4;
+        f32x4 acc; acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+        if (FULL || c < N) {
+            int64_t s = s_begin;
+            for (; s + 7 * s_step < a.split_k; s += 8 * s_step) {           // eight independent loads in flight
+                f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(a.ws + ((s + u * s_step) * a.M + row) * N + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] += ((t[0][j] + t[1][j]) + (t[2][j] + t[3][j])) + ((t[4][j] + t[5][j]) + (t[6][j] + t[7][j]));
+            }
+            for (; s < a.split_k; s += s_step) {
+                f32x4 t = *(const f32x4*)(a.ws + (s * a.M + row) * N + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += t[j];
+            }
+        }
+        keep[i] = acc;
+    }
+    if constexpr (WITH_LN) {
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) part[((wave - 1) * NV + i) * WAVE + lane] = keep[i];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                f32x4 t = part[(w * NV + i) * WAVE + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) keep[i][j] += t[j];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = ((WITH_LN ? i : (int)blockIdx.y) * WAVE + lane) * 4;
         if (!FULL && c >= N) continue;
-        f32x4 acc = *(const f32x4*)(a.ws + row * N + c);
-        int64_t s = 1;
-        for (; s + 8 <= a.split_k; s += 8) {              // eight independent loads in flight
-            f32x4 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(a.ws + ((s + u) * a.M + row) * N + c);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j] += ((t[0][j] + t[1][j]) + (t[2][j] + t[3][j])) + ((t[4][j] + t[5][j]) + (t[6][j] + t[7][j]));
-        }
-        for (; s < a.split_k; ++s) {
-            f32x4 t = *(const f32x4*)(a.ws + (s * a.M + row) * N + c);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += t[j];
-        }
+        f32x4 acc = keep[i];
         if (a.bias) {
             f32x4 bb = *(const f32x4*)(a.bias + c);
 #pragma unroll
@@ -559,7 +586,7 @@ extern "C" int made_splitk_finish(const MadeFinishArgs* args, void* stream) {
         MADE_REQUIRE(a.ln2_g == nullptr, "made_splitk_finish: ln2 without ln1");
     }
     if (a.M == 0) return MADE_OK;
-    if (ln) { DISPATCH_NV(a.N, hipLaunchKernelGGL((splitk_finish_kernel<true, NV, FULL>), dim3(row_blocks(a.M)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a)); }
+    if (ln) { DISPATCH_NV(a.N, hipLaunchKernelGGL((splitk_finish_kernel<true, NV, FULL>), dim3((unsigned)a.M), dim3(ROW_THREADS), 0, (hipStream_t)stream, a)); }
     else if (a.N % 256 == 0) hipLaunchKernelGGL((splitk_finish_kernel<false, 1, true>), dim3(row_blocks(a.M), (unsigned)(a.N / 256)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((splitk_finish_kernel<false, 1, false>), dim3(row_blocks(a.M), (unsigned)((a.N + 255) / 256)), dim3(ROW_THREADS), 0, (hipStream_t)stream, a);
     return made_check_launch("made_splitk_finish");
