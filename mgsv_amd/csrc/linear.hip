@@ -132,14 +132,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
     const MadeLinearSeg seg = a.seg[si];
     const bool transposed = seg.transposed != 0;
 
-    // ---- padded tiles: if every row of this tile is padding, there is nothing to compute
+    // ---- padded tiles: if every row of this tile is padding, there is nothing to compute.  Every wave looks at all 128
+    // rows itself (2 per lane), so the answer is wave-uniform and identical in the 4 waves: no barrier on this path.
     if (a.tile_skip_mask) {
-        int any_valid = 0;
-        if (tid < BM) {
-            const int gm = m0 + tid;
-            any_valid = (gm < M && a.tile_skip_mask[gm] != 0.f) ? 1 : 0;
-        }
-        if (!__syncthreads_or(any_valid)) {
+        const int g0 = m0 + lane, g1 = m0 + 64 + lane;
+        const float v0 = g0 < M ? a.tile_skip_mask[g0] : 0.f, v1 = g1 < M ? a.tile_skip_mask[g1] : 0.f;
+        if (!__any(v0 != 0.f || v1 != 0.f)) {
             if (a.out_row_mask && !seg.transposed && (a.split_k <= 1)) {       // consumers expect zeros in masked rows
                 const int rpb0 = (int)seg.rows_per_batch;
                 for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {
@@ -431,14 +429,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_glds_kernel(const MadeLine
     const MadeLinearSeg seg = a.seg[si];
 
 
-    // ---- padded tiles: if every row of this tile is padding, there is nothing to compute
+    // ---- padded tiles: if every row of this tile is padding, there is nothing to compute.  Every wave looks at all 128
+    // rows itself (2 per lane), so the answer is wave-uniform and identical in the 4 waves: no barrier on this path.
     if (a.tile_skip_mask) {
-        int any_valid = 0;
-        if (tid < BM) {
-            const int gm = m0 + tid;
-            any_valid = (gm < M && a.tile_skip_mask[gm] != 0.f) ? 1 : 0;
-        }
-        if (!__syncthreads_or(any_valid)) {
+        const int g0 = m0 + lane, g1 = m0 + 64 + lane;
+        const float v0 = g0 < M ? a.tile_skip_mask[g0] : 0.f, v1 = g1 < M ? a.tile_skip_mask[g1] : 0.f;
+        if (!__any(v0 != 0.f || v1 != 0.f)) {
             if (a.out_row_mask && !seg.transposed && (a.split_k <= 1)) {       // consumers expect zeros in masked rows
                 const int rpb0 = (int)seg.rows_per_batch;
                 for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {

@@ -297,6 +297,69 @@ def test_attention_wide(dev, mode, B, NQ1, NQ2, L, D, shared, kadd, alias):
                                        err_msg=f"n_split={n_split}")
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_padding_skips_leave_valid_rows_bit_identical(dev, mode):
+    """tile_skip_mask (GEMM), row_skip (LayerNorm) and q_skip_mask (attention): rows that are padding are not computed,
+    every valid row must come out bit-for-bit as without the skip."""
+    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+    B, T, D, H = 6, 300, 256, 8
+    M = B * T
+    lens = torch.tensor([300, 1, 129, 128, 40, 257])
+    mask = (torch.arange(T)[None] < lens[:, None]).float().to(dev)
+    mflat = mask.reshape(-1)
+    valid = (mflat != 0).cpu()
+    A = rnd(M, D, seed=1).to(dev).to(tdt)
+    W = (rnd(3 * D, D, seed=2) / math.sqrt(D)).to(dev).to(tdt)
+    b = (rnd(3 * D, seed=3) * 0.1).to(dev)
+    R = rnd(M, 3 * D, seed=4).to(dev).to(tdt)
+    full = ops.linear(A, W, b, act=ops.ACT_RELU, R=R)
+    out = torch.full((M, 3 * D), float("nan"), device=dev, dtype=tdt)
+    ops.linear(A, W, b, act=ops.ACT_RELU, R=R, out=out, tile_skip_mask=mflat)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu()[valid], full.cpu()[valid])
+    assert torch.isnan(out.float().cpu()[~valid]).any()             # whole tiles of padding were really skipped
+    # with out_row_mask the skipped tiles are zero-filled (what the encoders' last GEMM needs)
+    out0 = torch.full((M, 3 * D), float("nan"), device=dev, dtype=tdt)
+    ops.linear(A, W, b, out=out0, tile_skip_mask=mflat, out_row_mask=mflat)
+    torch.cuda.synchronize()
+    ref0 = ops.linear(A, W, b, out_row_mask=mflat)
+    assert torch.equal(out0.cpu(), ref0.cpu()) and (out0.cpu()[~valid] == 0).all()
+    # LayerNorm rows
+    g, be = (1 + 0.1 * rnd(D, seed=5)).to(dev), (0.1 * rnd(D, seed=6)).to(dev)
+    ln_full = ops.layernorm(A, g, be)
+    ln_skip = torch.full((M, D), float("nan"), device=dev, dtype=tdt)
+    ops.layernorm(A, g, be, out=ln_skip, row_skip=mflat)
+    add = rnd(M, D, seed=7).to(dev).to(tdt)
+    y2 = torch.full((M, D), float("nan"), device=dev, dtype=tdt)
+    y1 = torch.empty(M, D, device=dev, dtype=tdt)
+    ops.layernorm_add(A, g, be, add, y1, y2, row_skip=mflat)
+    torch.cuda.synchronize()
+    assert torch.equal(ln_skip.cpu()[valid], ln_full.cpu()[valid]) and torch.isnan(ln_skip.float().cpu()[~valid]).all()
+    np.testing.assert_allclose(y2.float().cpu()[valid].numpy(), (ln_full.float() + add.float()).cpu()[valid].numpy(),
+                               atol=1e-6 if mode == "f32" else 2e-2, rtol=0)
+    # attention: garbage (NaN) in padded K/V/Q rows must not leak into valid queries, padded query groups are skipped
+    qkv = rnd(B, T, 3 * D, seed=8).to(dev).to(tdt)
+    o_full = torch.empty(B, T, D, device=dev, dtype=tdt)
+    ops.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o_full, H, key_mask=mask)
+    dirty = qkv.clone()
+    dirty.view(M, 3 * D)[(mflat == 0)] = float("nan")
+    o_skip = torch.full((B, T, D), 7.0, device=dev, dtype=tdt)
+    ops.attention(dirty[:, :, :D], dirty[:, :, D:2 * D], dirty[:, :, 2 * D:], o_skip, H, key_mask=mask, q_skip_mask=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(o_skip.view(M, D).cpu()[valid], o_full.view(M, D).cpu()[valid])
+    assert (o_skip[1, 128:] == 7.0).all()                            # batch 1 has one valid token: later query groups untouched
+
+
+def test_cast_mask_rows(dev):
+    x = rnd(37, 768, seed=1)
+    mask = (torch.arange(37) % 3 != 0).float()
+    for odt in (torch.bfloat16, torch.float32):
+        out = torch.empty(37, 768, device=dev, dtype=odt)
+        ops.cast_mask_rows(x.to(dev), mask.to(dev), out)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), (x * mask[:, None]).to(odt))
+
+
 # ------------------------------------------------------------------------------------ row kernels
 @pytest.mark.parametrize("D", [256, 512, 768, 1024])
 @pytest.mark.parametrize("io", ["f32->f32", "bf16->bf16", "f32->bf16"])
