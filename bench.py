@@ -134,9 +134,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:           # launched by torch.distributed.run: one process per GPU, RCCL
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL on ROCm
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # backend "nccl" is RCCL on ROCm
 
     if args.workload == "retrieval":
         retrieval_main(args, rank, world, local, dist)

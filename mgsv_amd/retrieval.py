@@ -52,7 +52,7 @@ class ShardedRetrieval:
 
     def gather_music_side(self, seg_local: Tensor, mask_local: Tensor, music_local: Tensor):
         """One exchange step: every rank ends up with all tracks, in rank order."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return seg_local, mask_local, music_local
         seg_all, _ = _all_gather_ragged(seg_local, self.group)
         mask_all, _ = _all_gather_ragged(mask_local, self.group)
