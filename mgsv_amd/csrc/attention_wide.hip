@@ -30,7 +30,7 @@ template <> struct Frag<float>  { typedef f32x4  type; };
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 
 
-template <typename TC, int D>
+template <typename TC, int D, bool DB>
 __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWideAttnArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     constexpr int NQF = DS * SZ / 32;               // k-steps (16-byte fragment pairs) of this wave's QK slice
     constexpr int NDT = DS / 32;                    // 32-row tiles of this wave's O^T slice
     constexpr int KV_STAGE = WKEY * K_ROW + WKEY * V_ROW;
-    constexpr int NSTAGE = IS_BF16 ? 2 : 1;         // bf16: two K/V stages (one barrier less per tile, loads overlap the MFMAs)
+    constexpr int NSTAGE = DB ? 2 : 1;              // two K/V stages: one barrier less per tile and the loads overlap the MFMAs (few, latency-bound
+                                                    // workgroups: the decoder); one stage leaves room for 3 workgroups per CU (many query tiles: X-Pool)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* lds_s = (float*)(lds + NSTAGE * KV_STAGE);                 // [4][32*32] partial score tiles
@@ -345,15 +346,15 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_combine_kernel(const 
     }
 }
 
-template <typename TC, int D>
+template <typename TC, int D, bool DB>
 int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     constexpr int SZ = (int)sizeof(TC);
     constexpr int K_ROW = D * SZ + 16, V_ROW = D * SZ + (SZ == 2 ? 64 : 16);
-    constexpr int NSTAGE = SZ == 2 ? 2 : 1;
+    constexpr int NSTAGE = DB ? 2 : 1;
     const size_t lds_bytes = (size_t)NSTAGE * (WKEY * K_ROW + WKEY * V_ROW) + 4 * 1024 * 4 + NSTAGE * 32 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {
             made_set_error("made_attention_wide: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
             return MADE_ERR_HIP;
@@ -363,7 +364,7 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     const int64_t nq = a.NQ1 * a.NQ2;
     const int64_t nsplit = a.n_split > 1 ? a.n_split : 1;
     dim3 grid((unsigned)((nq + WQ - 1) / WQ), (unsigned)a.B, (unsigned)nsplit), block(NTHREADS);
-    hipLaunchKernelGGL((attention_wide_kernel<TC, D>), grid, block, lds_bytes, st, a);
+    hipLaunchKernelGGL((attention_wide_kernel<TC, D, DB>), grid, block, lds_bytes, st, a);
     int rc = made_check_launch("made_attention_wide");
     if (rc != MADE_OK || nsplit == 1) return rc;
     const int64_t rows = a.B * nq;
@@ -395,6 +396,10 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
     }
     if (a.B == 0 || a.NQ1 == 0) return MADE_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (a.dtype == MADE_BF16) return a.D == 512 ? launch_wide<bf16_t, 512>(a, st) : launch_wide<bf16_t, 256>(a, st);
-    return a.D == 512 ? launch_wide<float, 512>(a, st) : launch_wide<float, 256>(a, st);
+    if (a.dtype == MADE_BF16) {
+        const bool few = a.NQ1 * a.NQ2 <= 64;           // few query tiles per batch entry: latency-bound, use the two-stage variant
+        if (a.D == 512) return few ? launch_wide<bf16_t, 512, true>(a, st) : launch_wide<bf16_t, 512, false>(a, st);
+        return few ? launch_wide<bf16_t, 256, true>(a, st) : launch_wide<bf16_t, 256, false>(a, st);
+    }
+    return a.D == 512 ? launch_wide<float, 512, false>(a, st) : launch_wide<float, 256, false>(a, st);
 }
