@@ -72,8 +72,29 @@ def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
     return x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
 
 
+class Drop:
+    """Train-mode dropout with the build's stateless masks (mgsv_amd/dropout.py): keep(seed, site, flat index).
+    The reference draws from torch's global generator instead; value semantics (zero or x/(1-p)) are the same
+    (torch.nn.Dropout / the attention-weight dropout inside nn.MultiheadAttention)."""
+
+    def __init__(self, seed: int, p_detr: float = 0.1, p_temporal: float = 0.8, p_xpool: float = 0.3):
+        self.seed, self.p_detr, self.p_temporal, self.p_xpool = int(seed), p_detr, p_temporal, p_xpool
+
+    def __call__(self, x: Tensor, site: str, p: float) -> Tensor:
+        """x in the site's logical layout (contiguous order = flat index)."""
+        if p <= 0.0:
+            return x
+        from mgsv_amd import dropout as dr
+        keep = dr.keep_mask(self.seed, dr.site_id(site), p, x.numel()).reshape(tuple(x.shape))
+        return x * torch.from_numpy(keep).to(x.dtype) * (1.0 / (1.0 - p))
+
+
+def _drop(drop: Optional["Drop"], x: Tensor, site: str, p: float) -> Tensor:
+    return x if drop is None else drop(x, site, p)
+
+
 def mha(xq: Tensor, xk: Tensor, xv: Tensor, P, name: str, H: int,
-        key_is_pad: Optional[Tensor]) -> Tensor:
+        key_is_pad: Optional[Tensor], drop: Optional[Drop] = None, site: str = "", p: float = 0.0) -> Tensor:
     """torch.nn.MultiheadAttention as the reference uses it, batch-first here.
 
     xq [B,Lq,D], xk/xv [B,Lk,D], key_is_pad [B,Lk] bool (True = padded key)."""
@@ -91,27 +112,31 @@ def mha(xq: Tensor, xk: Tensor, xv: Tensor, P, name: str, H: int,
     s = q @ k.transpose(-1, -2)                                   # [B,H,Lq,Lk]
     if key_is_pad is not None:
         s = s.masked_fill(key_is_pad[:, None, None, :], float("-inf"))
-    a = torch.softmax(s, dim=-1)
+    a = _drop(drop, torch.softmax(s, dim=-1), site, p)            # dropout on the attention weights ([B,H,Lq,Lk])
     o = (a @ v).transpose(1, 2).reshape(B, Lq, D)
     return linear(o, P, name + ".out_proj")
 
 
 # ------------------------------------------------------------ K1-K4: feature encoders
-def temporal_block(x: Tensor, mask: Tensor, P, mod: str, depth: int, H: int) -> Tensor:
+def temporal_block(x: Tensor, mask: Tensor, P, mod: str, depth: int, H: int, drop: Optional[Drop] = None) -> Tensor:
     """reference: model/model_Base.py:82-91 (Transformer_enhancement.forward), SURVEY A4.
-    Residuals are taken onto the *normalised* tensors; erf-GELU FFN; final Linear."""
+    Residuals are taken onto the *normalised* tensors; erf-GELU FFN; final Linear.
+    Train mode: dropout (p = 0.8, model_Uni.py:41) on the attention weights, after the GELU and after the second
+    Linear (model_Base.py:69-75)."""
     pad = ~(mask.bool())
+    pt = drop.p_temporal if drop is not None else 0.0
+    tag = "video" if mod.startswith("video") else "audio"
     for l in range(depth):
         p = f"{mod}.layers.{l}"
         x = layer_norm(x, P, p + ".0")
-        x = mha(x, x, x, P, p + ".1", H, pad) + x
+        x = mha(x, x, x, P, p + ".1", H, pad, drop, f"{tag}.{l}.attn", pt) + x
         x = layer_norm(x, P, p + ".2")
-        h = gelu_erf(linear(x, P, p + ".3.0"))
-        x = linear(h, P, p + ".3.3") + x
+        h = _drop(drop, gelu_erf(linear(x, P, p + ".3.0")), f"{tag}.{l}.ffn_act", pt)
+        x = _drop(drop, linear(h, P, p + ".3.3"), f"{tag}.{l}.ffn_out", pt) + x
     return linear(x, P, mod + ".final_linear")
 
 
-def encode_features(feats: Tensor, mask: Tensor, P, cfg, which: str) -> Tuple[Tensor, Tensor]:
+def encode_features(feats: Tensor, mask: Tensor, P, cfg, which: str, drop: Optional[Drop] = None) -> Tuple[Tensor, Tensor]:
     """reference: model/model_Base.py:544-581 (video) / :583-617 (audio) with
     temporal_transformer :520-542.  Returns (local_feats [B,T,D], global_feats [B,D])."""
     proj, mod, pe, depth = (("vit_proj", "video_transformer", "video_position_embedding.pe",
@@ -129,7 +154,7 @@ def encode_features(feats: Tensor, mask: Tensor, P, cfg, which: str) -> Tuple[Te
         if table.shape[1] < T:
             raise ValueError(f"{pe} holds {table.shape[1]} positions < T={T} (model_Base.py:533)")
         x = x + table[:, :T]
-        x = temporal_block(x, mask, P, mod, depth, cfg.SA_temporal_heads)
+        x = temporal_block(x, mask, P, mod, depth, cfg.SA_temporal_heads, drop)
         x = x * valid
     g = x.sum(1) / mask.sum(1, keepdim=True)
     return x, l2_normalize(g)
@@ -137,7 +162,7 @@ def encode_features(feats: Tensor, mask: Tensor, P, cfg, which: str) -> Tuple[Te
 
 # ------------------------------------------------------- K5/K6: X-Pool + similarities
 def xpool(video_embeds: Tensor, seg_embeds: Tensor, seg_masks: Optional[Tensor], P,
-          xa: str = "video_guided_to_music_pooling_cross_transformer") -> Tensor:
+          xa: str = "video_guided_to_music_pooling_cross_transformer", drop: Optional[Drop] = None) -> Tensor:
     """reference: modules/transformer.py:156-180 with :87-123 (masked) / :27-70 (unmasked).
     video_embeds [Nv,D], seg_embeds [Nm,S,D], seg_masks [Nm,S] -> pooled [Nm,Nv,D]  (SURVEY A5)."""
     D = video_embeds.shape[-1]
@@ -153,7 +178,8 @@ def xpool(video_embeds: Tensor, seg_embeds: Tensor, seg_masks: Optional[Tensor],
     o = torch.einsum("mns,msd->mnd", a, u)
     o = linear(o, P, xa + ".cross_attn.out_proj")
     o = layer_norm(o, P, xa + ".layer_norm2")                    # no residual (:172-174)
-    o = layer_norm(o + linear(o, P, xa + ".linear_proj"), P, xa + ".layer_norm3")
+    lin = _drop(drop, linear(o, P, xa + ".linear_proj"), "xa.linear_out", drop.p_xpool if drop is not None else 0.0)
+    o = layer_norm(o + lin, P, xa + ".layer_norm3")                # dropout 0.3 on linear_out only (:133,:177)
     return o
 
 
@@ -220,38 +246,47 @@ def sine_pe_dim_t(D: int, temperature: float = 10000.0) -> Tensor:
 
 
 # ------------------------------------------------------------------ K9/K10: DETR stack
-def detr_encoder_layer(x: Tensor, pos: Tensor, pad: Tensor, P, p: str, H: int) -> Tensor:
-    """reference: music_detr/transformer.py:191-210 (forward_post, ReLU FFN), SURVEY A8."""
+def detr_encoder_layer(x: Tensor, pos: Tensor, pad: Tensor, P, p: str, H: int, drop: Optional[Drop] = None, tag: str = "") -> Tensor:
+    """reference: music_detr/transformer.py:191-210 (forward_post, ReLU FFN), SURVEY A8.
+    Train mode: attention-weight dropout, dropout1 on the attention branch, dropout inside the FFN, dropout2 (:153-162)."""
+    pd = drop.p_detr if drop is not None else 0.0
     qk = x + pos
-    x = layer_norm(x + mha(qk, qk, x, P, p + ".self_attn", H, pad), P, p + ".norm1")
-    h = torch.relu(linear(x, P, p + ".linear1"))
-    return layer_norm(x + linear(h, P, p + ".linear2"), P, p + ".norm2")
+    a = _drop(drop, mha(qk, qk, x, P, p + ".self_attn", H, pad, drop, tag + ".attn", pd), tag + ".drop1", pd)
+    x = layer_norm(x + a, P, p + ".norm1")
+    h = _drop(drop, torch.relu(linear(x, P, p + ".linear1")), tag + ".ffn_act", pd)
+    return layer_norm(x + _drop(drop, linear(h, P, p + ".linear2"), tag + ".drop2", pd), P, p + ".norm2")
 
 
-def detr_decoder_layer(t: Tensor, qp: Tensor, mem: Tensor, pos: Tensor, pad: Tensor, P, p: str, H: int) -> Tensor:
+def detr_decoder_layer(t: Tensor, qp: Tensor, mem: Tensor, pos: Tensor, pad: Tensor, P, p: str, H: int,
+                       drop: Optional[Drop] = None, tag: str = "") -> Tensor:
     """reference: music_detr/transformer.py:273-307 (forward_post; the self-attention
-    branch always runs because build_transformer never forwards args, :325-335), SURVEY A9."""
+    branch always runs because build_transformer never forwards args, :325-335), SURVEY A9.
+    Train mode: dropout on both attentions' weights, dropout1/2/3 on the three branches, dropout inside the FFN (:229-241)."""
+    pd = drop.p_detr if drop is not None else 0.0
     q = t + qp
-    t = layer_norm(t + mha(q, q, t, P, p + ".self_attn", H, None), P, p + ".norm1")
-    t = layer_norm(t + mha(t + qp, mem + pos, mem, P, p + ".multihead_attn", H, pad), P, p + ".norm2")
-    h = torch.relu(linear(t, P, p + ".linear1"))
-    return layer_norm(t + linear(h, P, p + ".linear2"), P, p + ".norm3")
+    t = layer_norm(t + _drop(drop, mha(q, q, t, P, p + ".self_attn", H, None, drop, tag + ".sa_attn", pd), tag + ".drop1", pd),
+                   P, p + ".norm1")
+    c = mha(t + qp, mem + pos, mem, P, p + ".multihead_attn", H, pad, drop, tag + ".ca_attn", pd)
+    t = layer_norm(t + _drop(drop, c, tag + ".drop2", pd), P, p + ".norm2")
+    h = _drop(drop, torch.relu(linear(t, P, p + ".linear1")), tag + ".ffn_act", pd)
+    return layer_norm(t + _drop(drop, linear(h, P, p + ".linear2"), tag + ".drop3", pd), P, p + ".norm3")
 
 
-def detr_transformer(src: Tensor, mask: Tensor, pos: Tensor, target: Optional[Tensor], P, cfg) -> Tuple[Tensor, Tensor]:
+def detr_transformer(src: Tensor, mask: Tensor, pos: Tensor, target: Optional[Tensor], P, cfg,
+                     drop: Optional[Drop] = None) -> Tuple[Tensor, Tensor]:
     """reference: music_detr/transformer.py:51-81, :92-107, :119-145.
     src [B,L,D], mask [B,L] (1 valid), target [B,Q,D] -> hs [dec,B,Q,D], memory [B,L,D]."""
     pad = ~(mask.bool())
     H = cfg.detr_nheads
     mem = src
     for l in range(cfg.detr_enc_layers):
-        mem = detr_encoder_layer(mem, pos, pad, P, f"detr_transformer.encoder.layers.{l}", H)
+        mem = detr_encoder_layer(mem, pos, pad, P, f"detr_transformer.encoder.layers.{l}", H, drop, f"enc.{l}")
     B = src.shape[0]
     qp = P["decoder_query_embed.weight"][None].expand(B, -1, -1)
     t = torch.zeros_like(qp) if target is None else target
     hs = []
     for l in range(cfg.detr_dec_layers):
-        t = detr_decoder_layer(t, qp, mem, pos, pad, P, f"detr_transformer.decoder.layers.{l}", H)
+        t = detr_decoder_layer(t, qp, mem, pos, pad, P, f"detr_transformer.decoder.layers.{l}", H, drop, f"dec.{l}")
         hs.append(layer_norm(t, P, "detr_transformer.decoder.norm"))
     return torch.stack(hs), mem
 
@@ -489,24 +524,27 @@ def calc_output(hs: Tensor, frame_feats: Tensor, music_feats: Tensor, P, cfg,
 
 # --------------------------------------------------------------------- full forward
 def forward(P, cfg, frame_feats, segment_feats, frame_masks, segment_masks, spans_target,
-            v_duration=None, music_ids=None, is_train: bool = False, with_losses: bool = True) -> dict:
-    """reference: model/model_Uni.py:177-322 in eval mode (all dropouts off).
+            v_duration=None, music_ids=None, is_train: bool = False, with_losses: bool = True,
+            drop: Optional[Drop] = None) -> dict:
+    """reference: model/model_Uni.py:177-322; eval mode (all dropouts off) unless `drop` is given (model.train()).
+    All tensors stay on the autograd tape: call .backward() on the losses for reference gradients.
 
     Returns a flat dict: the reference's output_map entries, feat_map entries,
     `music_feats_pooled`, `sims_single`, `sims_dual`, `detr_pos`, `memory`, `hs`,
     `retrieval_loss`, `localization_loss`, `loss_dict`, `matcher_indices`."""
-    ff, sf = _t(frame_feats).float(), _t(segment_feats).float()
-    fm, sm = _t(frame_masks).float(), _t(segment_masks).float()
-    tg = _t(spans_target).float()
+    dt = P["vit_proj.weight"].dtype                 # float32; float64 only when the validation script asks for it
+    ff, sf = _t(frame_feats).to(dt), _t(segment_feats).to(dt)
+    fm, sm = _t(frame_masks).to(dt), _t(segment_masks).to(dt)
+    tg = _t(spans_target).to(dt)
     D = cfg.D
     r: dict = {}
-    frame, video = encode_features(ff, fm, P, cfg, "video")
-    seg, music = encode_features(sf, sm, P, cfg, "audio")
+    frame, video = encode_features(ff, fm, P, cfg, "video", drop)
+    seg, music = encode_features(sf, sm, P, cfg, "audio", drop)
     r.update(frame_feats=frame, video_feats=video, segment_feats=seg, music_feats=music)
 
     pooled = None
     if "XA" in cfg.vmr_fusion and "music" in cfg.vmr_fusion:
-        pooled = xpool(video, seg, sm if cfg.fusion_mask == 1 else None, P)
+        pooled = xpool(video, seg, sm if cfg.fusion_mask == 1 else None, P, drop=drop)
         r["music_feats_pooled"] = pooled
     pooled_v = None
     if "XA" in cfg.vmr_fusion and "video" in cfg.vmr_fusion:
@@ -529,7 +567,7 @@ def forward(P, cfg, frame_feats, segment_feats, frame_masks, segment_masks, span
         target = pooled.mean(dim=1)[:, None].expand(-1, cfg.num_moment_queries, -1)
     else:
         target = None
-    hs, mem = detr_transformer(fus, fus_mask, pos, target, P, cfg)
+    hs, mem = detr_transformer(fus, fus_mask, pos, target, P, cfg, drop)
     r["hs"], r["memory"] = hs, mem
 
     # retrieval loss (model_Uni.py:236-275)

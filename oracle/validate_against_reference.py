@@ -82,6 +82,61 @@ def compare_forward(cfg: MadeConfig, B: int, T_v: int, T_a: int, tag: str) -> di
     return d
 
 
+class _RecordingDrop(O.Drop):
+    """Oracle-side dropout that also records (site, p, logical shape) of every call, in call order."""
+
+    def __init__(self, seed):
+        super().__init__(seed)
+        self.calls = []
+
+    def __call__(self, x, site, p):
+        if p > 0.0:
+            self.calls.append((site, p, tuple(x.shape)))
+        return super().__call__(x, site, p)
+
+
+def compare_backward(cfg: MadeConfig, B: int, T_v: int, T_a: int, tag: str, train: bool, double: bool = True) -> dict:
+    """Gradients of (retrieval_loss + localization_loss) w.r.t. every parameter: reference autograd vs oracle autograd.
+    train=False: reference in eval() (dropout off).  train=True: reference in train(); its dropout calls
+    (torch.nn.functional.dropout and the fused attention's dropout_p) are replaced, for this comparison only, by the
+    build's stateless masks in the order the oracle consumed them -- this pins the PLACEMENT of every dropout.
+    double=True runs both sides in float64: in float32 a ReLU input within rounding noise of 0 (|x| ~ 1e-6 occurs) can
+    take different sides in the two implementations, which changes a gradient row by a whole token's contribution."""
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, B, T_v, T_a, seed=1)
+    ref = ref_import.build_reference_model(cfg, sd)
+    P = O.to_torch_params(sd)
+    dt = torch.float64 if double else torch.float32
+    if double:
+        ref = ref.double()
+        P = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    pnames = [n for n, p_ in ref.named_parameters() if p_.requires_grad and n in P]
+    for n in pnames:
+        P[n].requires_grad_(True)
+    drop = _RecordingDrop(1234) if train else None
+    r = O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"],
+                  inp["spans_target"], v_duration=inp["v_duration"], music_ids=None, is_train=train, drop=drop)
+    (r["retrieval_loss"] + r["localization_loss"]).backward()
+
+    lm, ref_grads = ref_import.reference_grads(ref, inp, train, schedule=drop.calls if train else None, seed=1234, dtype=dt)
+    d = {"retrieval_loss": _maxabs(lm["retrieval_loss"], r["retrieval_loss"]),
+         "localization_loss": _maxabs(lm["localization_loss"], r["localization_loss"])}
+    worst_rel = 0.0
+    for n in pnames:
+        g_ref, g_o = ref_grads.get(n), P[n].grad
+        if g_ref is None:
+            assert g_o is None or float(g_o.abs().max()) == 0.0, n
+            continue
+        rel = _maxabs(g_ref, g_o) / max(float(g_ref.abs().max()), 1e-4)   # floor: k-bias grads are exactly 0 in theory
+        worst_rel = max(worst_rel, rel)
+    d["grad_worst_rel_to_max"] = worst_rel
+    d["n_params_compared"] = float(len(pnames))
+    if train:
+        d["n_dropout_calls"] = float(len(drop.calls))
+    print(f"[{tag}] grads: worst rel-to-max = {worst_rel:.3e}; losses {d['retrieval_loss']:.2e} {d['localization_loss']:.2e}")
+    return d
+
+
 def compare_lsap(n_cases: int = 400) -> dict:
     from scipy.optimize import linear_sum_assignment
     rng = np.random.default_rng(7)
@@ -142,9 +197,17 @@ def main():
     report["native_fb10_shortcut_B4"] = compare_forward(c, 4, 50, 96, "native fb10/short-cut/act")
     c = cfg_headline()
     report["cfg2_B4"] = compare_forward(c, 4, 30, 512, "cfg2 shape B=4 Tv=30 Ta=512 D=512")
+    report["grad_eval_native_B3"] = compare_backward(cfg_native(), 3, 20, 40, "native eval-mode grads", train=False)
+    report["grad_train_native_B3"] = compare_backward(cfg_native(), 3, 20, 40, "native train-mode grads (dropout)", train=True)
+    c = cfg_native(); c.num_moment_queries = 3
+    report["grad_train_native_Q3_B4"] = compare_backward(c, 4, 20, 40, "native Q=3 train-mode grads", train=True)   # B != Q: layouts unambiguous
     report["lsap_vs_scipy"] = compare_lsap()
     report["retrieval_N48x40_S96"] = compare_retrieval(cfg_native(), 48, 40, 96)
-    worst = max(v for k, sec in report.items() if isinstance(sec, dict) for v in sec.values() if isinstance(v, float))
+    worst = max(v for k, sec in report.items() if isinstance(sec, dict) and not k.startswith("grad_")
+                for v in sec.values() if isinstance(v, float))
+    worst_grad = max(sec["grad_worst_rel_to_max"] for k, sec in report.items() if k.startswith("grad_"))
+    report["worst_grad_rel"] = worst_grad
+    assert worst_grad < 1e-5, worst_grad
     report["worst_maxabs"] = worst
     out = os.path.join(ROOT, "tests", "golden", "VALIDATION.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)

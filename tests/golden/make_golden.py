@@ -149,7 +149,42 @@ def retrieval_fixture():
     print("retrieval.npz")
 
 
+def train_fixture(cfg: MadeConfig, B: int, T_v: int, T_a: int, name: str, cfg_overrides: dict, seed: int = 1234):
+    """Losses and parameter gradients of the reference in train() mode (with the build's dropout masks, see
+    oracle/ref_import.reference_grads) and in eval() mode, computed in float64.  Per parameter: L2 norm, sum and a
+    strided sample of 512 entries."""
+    from oracle import made_oracle as O
+    from oracle.validate_against_reference import _RecordingDrop
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, B, T_v, T_a, seed=1)
+    ref = ref_import.build_reference_model(cfg, sd).double()
+    P = {k: (v.double() if v.is_floating_point() else v) for k, v in O.to_torch_params(sd).items()}
+    drop = _RecordingDrop(seed)
+    drop.p_detr = cfg.detr_dropout
+    with torch.no_grad():                                       # only to learn the order / shapes of the dropout calls
+        O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"],
+                  inp["spans_target"], v_duration=inp["v_duration"], drop=drop)
+    fix = dict(meta_B=B, meta_T_v=T_v, meta_T_a=T_a, meta_weight_seed=0, meta_data_seed=1, meta_dropout_seed=seed,
+               meta_cfg_overrides=np.array(repr(sorted(cfg_overrides.items()))))
+    for mode, train in (("train", True), ("eval", False)):
+        lm, grads = ref_import.reference_grads(ref, inp, train, schedule=drop.calls if train else None, seed=seed,
+                                               dtype=torch.float64)
+        fix[f"{mode}.retrieval_loss"] = np.float64(lm["retrieval_loss"].detach())
+        fix[f"{mode}.localization_loss"] = np.float64(lm["localization_loss"].detach())
+        for k, v in lm["localization_loss_dict"].items():
+            fix[f"{mode}.loss_{k}"] = np.float64(v.detach())
+        for n, g in grads.items():
+            flat = g.reshape(-1).numpy()
+            step = max(1, flat.size // 512)
+            fix[f"{mode}.gnorm.{n}"] = np.float64(np.sqrt((flat ** 2).sum()))
+            fix[f"{mode}.gsum.{n}"] = np.float64(flat.sum())
+            fix[f"{mode}.gsample.{n}"] = flat[::step][:512].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fix)
+    print("wrote", name, len(fix), "entries")
+
+
 def main():
+    train_fixture(cfg_native(), 3, 20, 40, "train_native_B3", {})
     forward_fixture(cfg_plumbing(), 2, 30, 200, "forward_cfg1_B2", {})
     c = cfg_native(); c.num_moment_queries = 3
     forward_fixture(c, 4, 50, 96, "forward_native_Q3_B4", {"num_moment_queries": 3})

@@ -118,3 +118,53 @@ def test_state_dict_layout_counts():
     assert len(sd) == 199
     n = sum(int(np.prod(v.shape)) for v in sd.values())
     assert abs(n - 10.68e6) < 0.02e6
+
+
+# ------------------------------------------------------------------ training path: losses + gradients
+def _oracle_grads(golden_dir, mode: str, double: bool):
+    import torch
+    from mgsv_amd.config import cfg_native
+    fix = _load(golden_dir, "train_native_B3")
+    cfg = cfg_native()
+    sd = synth.make_state_dict(cfg, seed=int(fix["meta_weight_seed"]))
+    inp = synth.make_inputs(cfg, int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"]), seed=int(fix["meta_data_seed"]))
+    P = O.to_torch_params(sd)
+    if double:
+        P = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    names = [k[len(mode) + 7:] for k in fix.files if k.startswith(mode + ".gnorm.")]
+    for n in names:
+        P[n].requires_grad_(True)
+    drop = O.Drop(int(fix["meta_dropout_seed"]), p_detr=cfg.detr_dropout) if mode == "train" else None
+    r = O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"],
+                  inp["spans_target"], v_duration=inp["v_duration"], drop=drop)
+    (r["retrieval_loss"] + r["localization_loss"]).backward()
+    return fix, names, P, r
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_oracle_gradients_match_reference_fixture(golden_dir, mode):
+    """float64 oracle autograd == float64 reference autograd (train mode: same stateless dropout masks)."""
+    fix, names, P, r = _oracle_grads(golden_dir, mode, double=True)
+    assert abs(float(r["retrieval_loss"]) - float(fix[f"{mode}.retrieval_loss"])) < 1e-6
+    assert abs(float(r["localization_loss"]) - float(fix[f"{mode}.localization_loss"])) < 1e-6
+    assert len(names) > 150
+    for n in names:
+        g = P[n].grad.reshape(-1).numpy()
+        step = max(1, g.size // 512)
+        ref = fix[f"{mode}.gsample.{n}"].astype(np.float64)
+        scale = max(float(np.abs(ref).max()), 1e-4)
+        assert np.abs(g[::step][:512] - ref).max() / scale < 1e-5, n
+        assert abs(np.sqrt((g ** 2).sum()) - float(fix[f"{mode}.gnorm.{n}"])) <= 1e-5 * max(float(fix[f"{mode}.gnorm.{n}"]), 1e-4), n
+
+
+def test_dropout_mask_statistics_and_determinism():
+    from mgsv_amd import dropout as dr
+    for p in (0.1, 0.3, 0.8):
+        k = dr.keep_mask(77, dr.site_id("enc.0.attn"), p, 1 << 18)
+        assert abs(k.mean() - (1 - p)) < 4e-3
+        assert (k == dr.keep_mask(77, dr.site_id("enc.0.attn"), p, 1 << 18)).all()
+        assert (k[1000:2000] == dr.keep_mask(77, dr.site_id("enc.0.attn"), p, 1000, offset=1000)).all()
+        k2 = dr.keep_mask(77, dr.site_id("enc.1.attn"), p, 1 << 18)
+        assert abs((k == k2).mean() - (p * p + (1 - p) ** 2)) < 6e-3          # independent sites
+    big = dr.rng_mix(5, 9, np.array([(1 << 32) + 7, 7], dtype=np.uint64))    # the high index word matters
+    assert big[0] != big[1]
