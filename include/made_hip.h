@@ -37,6 +37,41 @@ enum MadeAct {
     MADE_ACT_SIGMOID = 4     /* span head: reference model/model_Uni.py:135 */
 };
 
+/* act'(.) factors of the backward Linears (made_linear `gate`): out = (A W^T) * act'(G) * gate_scale */
+enum MadeGate {
+    MADE_GATE_NONE = 0,
+    MADE_GATE_RELU_OUT = 1,      /* G = saved output of ReLU (after dropout): 1 where G != 0 */
+    MADE_GATE_GELU_Z = 2,        /* G = saved pre-activation of the erf GELU */
+    MADE_GATE_QUICKGELU_Z = 3,   /* G = saved pre-activation of x*sigmoid(1.702x) */
+    MADE_GATE_SIGMOID_OUT = 4    /* G = saved sigmoid output: G (1 - G) */
+};
+
+/* Stateless dropout: keep(seed, site, idx) <=> (made_rng_mix(seed, site, idx) >> 8) >= floor(p * 2^24); kept values are
+ * scaled by 1/(1-p).  Forward and backward kernels regenerate the same mask from (seed, site, logical element index), so
+ * no mask is ever stored (mgsv_amd/dropout.py documents the index conventions and restates the mix in numpy).
+ * Replaces torch's Philox draws at reference model/model_Base.py:69-75, modules/transformer.py:177,
+ * music_detr/transformer.py:153-162,229-241 (value semantics identical, stream different by construction). */
+typedef struct MadeDropout {
+    uint64_t seed;
+    uint32_t site;
+    float    p;              /* 0 = no dropout */
+} MadeDropout;
+
+#if defined(__HIPCC__)
+#define MADE_HOST_DEVICE __host__ __device__      /* the kernels call the same definition */
+#else
+#define MADE_HOST_DEVICE
+#endif
+MADE_HOST_DEVICE static inline uint32_t made_rng_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+MADE_HOST_DEVICE static inline uint32_t made_rng_mix(uint64_t seed, uint32_t site, uint64_t idx) {
+    uint32_t k = (uint32_t)seed ^ (site * 0x9E3779B9u) ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ ((uint32_t)(idx >> 32) * 0xC2B2AE35u);
+    return made_rng_fmix32((uint32_t)idx ^ made_rng_fmix32(k));
+}
+
+
 enum MadeStatus {
     MADE_OK = 0,
     MADE_ERR_INVALID_ARG = -1,
@@ -104,6 +139,11 @@ typedef struct MadeLinearArgs {
     int32_t      nseg; int32_t split_k;                     /* split_k > 1: see below */
     float*       split_ws;                                  /* [split_k, M, N] f32 workspace or NULL */
     MadeLinearSeg seg[4];
+    /* training-path epilogue (plain segments only; element order: z = A'W^T + bias [-> Zout], act, gate, dropout, +R, row mask) */
+    const void*  G;  int32_t g_dtype; int32_t gate;         /* MadeGate: multiply by act'(G[row*ldg + col]) * gate_scale */
+    int64_t      ldg; float gate_scale; int32_t z_dtype;
+    void*        Zout; int64_t ldz;                         /* optional: the pre-activation z is also stored (saved for backward) */
+    MadeDropout  drop; int64_t drop_ld;                     /* dropout after act/gate, element index row*drop_ld + col */
 } MadeLinearArgs;
 
 int made_linear(const MadeLinearArgs* args, void* stream);
@@ -147,6 +187,11 @@ typedef struct MadeAttnArgs {
     float scale; int32_t _pad;
     const float* q_skip_mask;  /* [B, Lq] or NULL: queries that are 0 here are padding whose output nobody reads; 32-query
                                   groups (and whole workgroups) made only of them are skipped and their O rows left untouched */
+    /* training path */
+    float*      lse;           /* [B, H, Lq] f32 or NULL: log-sum-exp of the scaled, masked scores (+inf for a row with no valid
+                                  key), saved for made_attention_bwd */
+    MadeDropout drop;          /* dropout on the attention weights (after the softmax, as nn.MultiheadAttention does),
+                                  element index ((b*H + h)*Lq + i)*Lk + j */
 } MadeAttnArgs;
 
 int made_attention(const MadeAttnArgs* args, void* stream);
@@ -281,6 +326,57 @@ int made_set_criterion(const float* pred_logits, const float* pred_spans, const 
                        int64_t n_layers, int64_t B, int64_t Q, int64_t G, int64_t Dc, int32_t fg_label,
                        float temperature, const float* weights /* [5] */,
                        float* losses, float* total, void* stream);
+
+
+/* ==========================================================================================
+ * Training path (backward kernels).  The reference trains through torch autograd
+ * (reference train-MaDe.py:337-381: forward, loss.backward(), three clip_grad_norm_, Adam); the
+ * entries below are the hand-written counterparts of the autograd nodes on the hot path.
+ * ========================================================================================== */
+
+/* made_attention_bwd: gradients of made_attention (flash style: the probabilities are recomputed from Q, K and the saved
+ * log-sum-exp; nothing of size Lq x Lk touches HBM).  With Pd = dropout(P):
+ *   delta_i = dO_i . O_i      dV = Pd^T dO      dP = dropout'(dO V^T)      dS = P * (dP - delta)
+ *   dQ = scale * dS K         dK = scale * dS^T Q
+ * Replaces autograd through nn.MultiheadAttention (reference model/model_Base.py:87, music_detr/transformer.py:199,287,
+ * 293-296).  All tensors use the addressing of made_attention (element (b,i,h,d) at base + b*bs + i*ld + h*hd + d); dQ, dK,
+ * dV may be column blocks of one [rows, 3*H*hd] buffer.  `delta` is a [B,H,Lq] f32 workspace the call fills.  Rows of dQ
+ * whose q_skip_mask is 0 and rows of dK/dV whose key_mask is 0 are written as zeros. */
+typedef struct MadeAttnBwdArgs {
+    const void* Q; const void* K; const void* V; const void* O; const void* dO;
+    void* dQ; void* dK; void* dV;
+    const float* lse; float* delta;
+    int32_t dtype; int32_t hd;
+    int64_t B, H, Lq, Lk;
+    int64_t q_bs, ldq, k_bs, ldk, v_bs, ldv, o_bs, ldo, do_bs, lddo, dq_bs, lddq, dk_bs, lddk, dv_bs, lddv;
+    const float* key_mask; const float* q_skip_mask;
+    float scale; int32_t _pad;
+    MadeDropout drop;
+} MadeAttnBwdArgs;
+
+int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream);
+
+/* made_gemm_tn: C[N,K] (+)= alpha * sum_m A[m,n] * B[m,k]   (reduction index m is the slow dimension of both operands).
+ * The weight gradient of every nn.Linear on the path: dW = dY^T X with A = dY [M,N], B = X [M,K], and
+ * colsum[n] += alpha * sum_m A[m,n] is the bias gradient.  Also the P^T dO / dS^T Q products of the wide-head attention
+ * backward (batched).  Batch index z = z1 * batch2 + z2 with independent element strides per level (a C stride of 0 sums
+ * the batch into one C).  split_m > 1 splits the reduction over workgroups; partial tiles are combined with f32 atomic
+ * adds, so it requires accumulate = 1 and an f32 C that the caller has initialised (gradients are zeroed once per step).
+ * Rows whose row_mask is 0 are read as zero in BOTH operands (padded tokens may hold stale data). */
+typedef struct MadeGemmTNArgs {
+    const void* A; const void* B; void* C;
+    int32_t ab_dtype; int32_t c_dtype;             /* MadeDtype; C is f32 or the operand dtype */
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int64_t batch1, batch2;
+    int64_t a_zs1, a_zs2, b_zs1, b_zs2, c_zs1, c_zs2;
+    const float* row_mask; int64_t mask_zs1, mask_zs2;
+    float   alpha; int32_t accumulate;
+    int64_t split_m;
+    float*  colsum; int64_t colsum_zs1, colsum_zs2; /* optional, always accumulated */
+} MadeGemmTNArgs;
+
+int made_gemm_tn(const MadeGemmTNArgs* args, void* stream);
 
 #ifdef __cplusplus
 }

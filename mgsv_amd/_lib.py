@@ -13,8 +13,13 @@ LIB_PATH = os.path.join(_HERE, "libmade_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+GATE_NONE, GATE_RELU_OUT, GATE_GELU_Z, GATE_QUICKGELU_Z, GATE_SIGMOID_OUT = 0, 1, 2, 3, 4
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+
+
+class MadeDropout(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("site", C.c_uint32), ("p", f32)]
 
 
 class MadeLinearSeg(C.Structure):
@@ -38,7 +43,9 @@ class MadeLinearArgs(C.Structure):
                 ("tile_skip_mask", vp),
                 ("nseg", i32), ("split_k", i32),
                 ("split_ws", vp),
-                ("seg", MadeLinearSeg * 4)]
+                ("seg", MadeLinearSeg * 4),
+                ("G", vp), ("g_dtype", i32), ("gate", i32), ("ldg", i64), ("gate_scale", f32), ("z_dtype", i32),
+                ("Zout", vp), ("ldz", i64), ("drop", MadeDropout), ("drop_ld", i64)]
 
 
 class MadeFinishArgs(C.Structure):
@@ -59,7 +66,17 @@ class MadeAttnArgs(C.Structure):
                 ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("ldo", i64),
                 ("key_mask", vp), ("q_mask", vp),
                 ("scale", f32), ("_pad", i32),
-                ("q_skip_mask", vp)]
+                ("q_skip_mask", vp),
+                ("lse", vp), ("drop", MadeDropout)]
+
+
+class MadeAttnBwdArgs(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("dO", vp), ("dQ", vp), ("dK", vp), ("dV", vp),
+                ("lse", vp), ("delta", vp), ("dtype", i32), ("hd", i32),
+                ("B", i64), ("H", i64), ("Lq", i64), ("Lk", i64),
+                ("q_bs", i64), ("ldq", i64), ("k_bs", i64), ("ldk", i64), ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("ldo", i64),
+                ("do_bs", i64), ("lddo", i64), ("dq_bs", i64), ("lddq", i64), ("dk_bs", i64), ("lddk", i64), ("dv_bs", i64), ("lddv", i64),
+                ("key_mask", vp), ("q_skip_mask", vp), ("scale", f32), ("_pad", i32), ("drop", MadeDropout)]
 
 
 class MadeWideAttnArgs(C.Structure):
@@ -70,6 +87,16 @@ class MadeWideAttnArgs(C.Structure):
                 ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("o_s1", i64), ("o_s2", i64),
                 ("scale", f32), ("_pad", i32),
                 ("n_split", i64), ("part_o", vp), ("part_ml", vp)]
+
+
+class MadeGemmTNArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("ab_dtype", i32), ("c_dtype", i32),
+                ("M", i64), ("N", i64), ("K", i64), ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("batch1", i64), ("batch2", i64),
+                ("a_zs1", i64), ("a_zs2", i64), ("b_zs1", i64), ("b_zs2", i64), ("c_zs1", i64), ("c_zs2", i64),
+                ("row_mask", vp), ("mask_zs1", i64), ("mask_zs2", i64),
+                ("alpha", f32), ("accumulate", i32), ("split_m", i64),
+                ("colsum", vp), ("colsum_zs1", i64), ("colsum_zs2", i64)]
 
 
 # name -> (restype, argtypes); every symbol include/made_hip.h declares
@@ -91,6 +118,8 @@ SIGNATURES = {
     "made_xpool_tail": (C.c_int, [vp, i32, i64, vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, f32, vp]),
     "made_clip_loss": (C.c_int, [vp, i64, i64, vp, f32, i32, vp, vp]),
     "made_hungarian_match": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp]),
+    "made_attention_bwd": (C.c_int, [C.POINTER(MadeAttnBwdArgs), vp]),
+    "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
     "made_set_criterion": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp, vp, vp]),
 }
 

@@ -251,6 +251,21 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
                 for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
         }
 
+        // ---- training: dropout on the attention weights (the row sum l keeps the undropped probabilities)
+        if (a.drop.p > 0.f) {
+            const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+            const float sc = 1.f / (1.f - a.drop.p);
+            int64_t qq = q0 + r; qq = qq < a.Lq ? qq : a.Lq - 1;
+            const uint64_t rowbase = (uint64_t)((b * a.H + h) * a.Lq + qq) * (uint64_t)a.Lk + (uint64_t)(t * BKEY);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t hsh = made_rng_mix(a.drop.seed, a.drop.site, rowbase + (uint64_t)(kt * 32 + acc_row(e, hh)));
+                    s[kt][e] = (hsh >> 8) >= thr ? s[kt][e] * sc : 0.f;
+                }
+        }
+
         // ---- O^T += V^T P^T
         if constexpr (IS_BF16) {
             const int g = lane >> 4, i = lane & 15;
@@ -293,6 +308,11 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     float inv = 1.f / l_tot;
     const int64_t q = q0 + r;
     if (q >= a.Lq) return;
+    if (a.lse && hh == 0) {
+        // natural-log units of the scaled scores; the bf16 path keeps its running max on the RAW scores
+        const float m_nat = IS_BF16 ? m_run * a.scale : m_run;
+        a.lse[(b * a.H + h) * a.Lq + q] = l_tot > 0.f ? m_nat + logf(l_tot) : INFINITY;
+    }
     bool zero_row = a.q_mask != nullptr && a.q_mask[b * a.Lq + q] == 0.f;
     TC* op = (TC*)a.O + b * a.o_bs + q * a.ldo + h * HD;
 #pragma unroll

@@ -1,0 +1,512 @@
+// made_attention_bwd: flash-style backward of made_attention on MFMA, gfx950.
+//
+// Three kernels, none of which writes anything of size Lq x Lk:
+//   delta   : delta[b,h,i] = dO_i . O_i                                  (one wave per query row)
+//   dq      : one workgroup = 128 queries of one (batch, head), loop over key tiles of 64.  Same SWAPPED layout as the
+//             forward (S^T = K Q^T: the query sits on the lane), so lse / delta are per-lane scalars and dS^T is directly
+//             the B operand of dQ^T += K^T dS^T (K^T fragments through the transposing LDS read).
+//   dkv     : one workgroup = 128 keys of one (batch, head) (32 per wave, K and V fragments stay in registers), loop over
+//             query tiles of 64 staged in LDS.  NON-swapped layout (S = Q K^T: the key sits on the lane), so Pd and dS are
+//             directly the B operands of dV^T += dO^T Pd and dK^T += Q^T dS (dO^T / Q^T through the transposing read).
+// Probabilities are recomputed as exp(scale * s + mask - lse) from the log-sum-exp the forward saved; the dropout mask is
+// regenerated from (seed, site, element index).  bf16: v_mfma_f32_32x32x16_bf16, f32: v_mfma_f32_32x32x2_f32.
+#include "common.h"
+
+namespace {
+
+constexpr int NTH = 256;
+constexpr int BKEY = 64;       // keys per tile (dq kernel)
+constexpr int BQT = 64;        // queries per tile (dkv kernel)
+
+template <typename TC> struct Frag;
+template <> struct Frag<float>  { typedef f32x4  type; };
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+
+__device__ __forceinline__ bool drop_keep(const MadeDropout& d, uint32_t thr, uint64_t idx) {
+    return (made_rng_mix(d.seed, d.site, idx) >> 8) >= thr;
+}
+
+// ---------------------------------------------------------------------------------------------- delta
+__global__ __launch_bounds__(NTH) void attn_delta_kernel(const MadeAttnBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, h, i)
+    if (row >= a.B * a.H * a.Lq) return;
+    const int64_t i = row % a.Lq, h = (row / a.Lq) % a.H, b = row / (a.Lq * a.H);
+    float acc = 0.f;
+    for (int d = lane; d < a.hd; d += 64) {
+        const float o = load_as_f32(a.O, a.dtype, b * a.o_bs + i * a.ldo + h * a.hd + d);
+        const float g = load_as_f32(a.dO, a.dtype, b * a.do_bs + i * a.lddo + h * a.hd + d);
+        acc += o * g;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.delta[row] = acc;
+}
+
+// transposing fragment: A operand X^T (row index on the lane, reduction rows kb.. of an LDS tile stored [row][col], pitch P)
+// slots j = 0..7 of lane half hh <-> tile row kb16 + 8 (j >> 2) + 4 hh + (j & 3); col block = c0 .. c0 + 31
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int P, int kb16, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned char* p = tile + (kb16 + 4 * (g >> 1) + (i >> 2)) * P + (c0 + (g & 1) * 16 + 4 * (i & 3)) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 8 * P));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ---------------------------------------------------------------------------------------------- dQ
+template <typename TC, int HD>
+__global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(const MadeAttnBwdArgs a) {
+    typedef typename Frag<TC>::type frag_t;
+    constexpr int SZ = (int)sizeof(TC);
+    constexpr int PER16 = 16 / SZ;
+    constexpr int P = HD * SZ + 16;              // LDS row pitch (16-byte row reads conflict-free)
+    constexpr int CPR = HD * SZ / 16;
+    constexpr int NCH = BKEY * CPR / NTH;
+    static_assert(BKEY * CPR % NTH == 0, "staging split");
+    constexpr int NQF = HD * SZ / 32;
+    constexpr int NDT = HD / 32;
+    constexpr bool IS_BF16 = SZ == 2;
+    constexpr int BQ = 128;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BKEY * P + BKEY * 4 + 32];
+    unsigned char* lds_k = lds;
+    unsigned char* lds_v = lds + BKEY * P;
+    float* lds_bias = (float*)(lds + 2 * BKEY * P);
+    int* lds_flag = (int*)(lds + 2 * BKEY * P + BKEY * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qtiles = (int)((a.Lq + BQ - 1) / BQ);
+    int wg;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
+        wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+    }
+    const int qt = wg % qtiles;
+    const int64_t h = (wg / qtiles) % a.H, b = wg / (qtiles * a.H);
+    const int64_t q0 = (int64_t)qt * BQ + wave * 32;
+    const int64_t q = q0 + r;
+    const int64_t qc = q < a.Lq ? q : a.Lq - 1;
+    bool my_valid = q < a.Lq && (a.q_skip_mask == nullptr || a.q_skip_mask[b * a.Lq + qc] != 0.f);
+    const bool wave_active = __any(my_valid);
+    if (!__syncthreads_or(wave_active ? 1 : 0)) {
+        // every query of this workgroup is padding: its dQ rows are zeros
+        if (q < a.Lq) {
+            TC* dst = (TC*)a.dQ + b * a.dq_bs + q * a.lddq + h * HD;
+            for (int d = hh; d < HD; d += 2) dst[d] = (TC)0.f;
+        }
+        return;
+    }
+
+    const TC* Kg = (const TC*)a.K + b * a.k_bs + h * HD;
+    const TC* Vg = (const TC*)a.V + b * a.v_bs + h * HD;
+    const float* maskg = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
+
+    frag_t qf[NQF], dof[NQF];
+    {
+        const TC* qp = (const TC*)a.Q + b * a.q_bs + qc * a.ldq + h * HD;
+        const TC* gp = (const TC*)a.dO + b * a.do_bs + qc * a.lddo + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) {
+            qf[ks] = *(const frag_t*)(qp + ks * 2 * PER16 + hh * PER16);
+            dof[ks] = keep_or_zero(*(const frag_t*)(gp + ks * 2 * PER16 + hh * PER16), my_valid);
+        }
+    }
+    const float lse_q = my_valid ? a.lse[(b * a.H + h) * a.Lq + qc] : INFINITY;     // +inf: every probability is 0
+    const float delta_q = my_valid ? a.delta[(b * a.H + h) * a.Lq + qc] : 0.f;
+
+    frag_t rk[NCH], rv[NCH];
+    float rbias = 0.f;
+    auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
+        float mk[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTH;
+            const int64_t key = key0 + c / CPR;
+            const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
+            rk[i] = *(const frag_t*)(Kg + kcl * a.ldk + (c % CPR) * PER16);
+            rv[i] = *(const frag_t*)(Vg + kcl * a.ldv + (c % CPR) * PER16);
+            mk[i] = maskg ? maskg[kcl] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTH;
+            const bool keep = (key0 + c / CPR) < a.Lk && mk[i] != 0.f;
+            rk[i] = keep_or_zero(rk[i], keep);
+            rv[i] = keep_or_zero(rv[i], keep);
+        }
+        if (tid < BKEY) {
+            const int64_t key = key0 + tid;
+            const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
+            const float mkb = maskg ? maskg[kcl] : 1.f;
+            rbias = (key < a.Lk && mkb != 0.f) ? 0.f : -INFINITY;
+        }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTH;
+            *(frag_t*)(lds_k + (c / CPR) * P + (c % CPR) * 16) = rk[i];
+            *(frag_t*)(lds_v + (c / CPR) * P + (c % CPR) * 16) = rv[i];
+        }
+        if (tid < BKEY) lds_bias[tid] = rbias;
+    };
+
+    f32x16 dq[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+
+    int64_t lk_eff = a.Lk;
+    if (maskg) {
+        int last = -1;
+        for (int j = tid; j < (int)a.Lk; j += NTH)
+            if (maskg[j] != 0.f) last = j;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
+        if (lane == 0) lds_flag[1 + wave] = last;
+        __syncthreads();
+        lk_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
+    }
+    const int64_t ntiles = (lk_eff + BKEY - 1) / BKEY;
+    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
+    const uint64_t rowbase = (uint64_t)((b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
+
+    if (ntiles > 0) load_tile(0);
+    for (int64_t t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile((t + 1) * BKEY);
+        if (!wave_active) continue;
+
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[kt][e] = 0.f; dp[kt][e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                frag_t kf = *(const frag_t*)(lds_k + (kt * 32 + r) * P + ks * 32 + hh * 16);
+                frag_t vf = *(const frag_t*)(lds_v + (kt * 32 + r) * P + ks * 32 + hh * 16);
+                if constexpr (IS_BF16) {
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                    dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[ks][e], s[kt], 0, 0, 0);
+                        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], dof[ks][e], dp[kt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // dS^T = P^T * (dP^T - delta) * scale, in place of s
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kl = kt * 32 + acc_row(e, hh);
+                const float p = expf(s[kt][e] * a.scale + lds_bias[kl] - lse_q);
+                float g = dp[kt][e];
+                if (a.drop.p > 0.f) g = drop_keep(a.drop, thr, rowbase + (uint64_t)(t * BKEY + kl)) ? g * dsc : 0.f;
+                s[kt][e] = p * (g - delta_q) * a.scale;
+            }
+        // dQ^T += K^T dS^T
+        if constexpr (IS_BF16) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[kt][8 * s2 + j];
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d)
+                        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(lds_k, P, kt * 32 + 16 * s2, d * 32, lane), pf, dq[d], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * 32 + acc_row(e, hh);
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        const float kv = *(const float*)(lds_k + key * P + (d * 32 + r) * 4);
+                        dq[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, s[kt][e], dq[d], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    if (q >= a.Lq) return;
+    TC* op = (TC*)a.dQ + b * a.dq_bs + q * a.lddq + h * HD;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            TC* dst = op + d * 32 + 8 * g + 4 * hh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = from_f32<TC>(my_valid ? dq[d][4 * g + j] : 0.f);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- dK, dV
+template <typename TC, int HD>
+__global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs a) {
+    typedef typename Frag<TC>::type frag_t;
+    constexpr int SZ = (int)sizeof(TC);
+    constexpr int PER16 = 16 / SZ;
+    constexpr int P = HD * SZ + 16;
+    constexpr int CPR = HD * SZ / 16;
+    constexpr int NCH = BQT * CPR / NTH;
+    static_assert(BQT * CPR % NTH == 0, "staging split");
+    constexpr int NQF = HD * SZ / 32;
+    constexpr int NDT = HD / 32;
+    constexpr bool IS_BF16 = SZ == 2;
+    constexpr int BK = 128;                       // keys per workgroup
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BQT * P + 2 * BQT * 4 + 32];
+    unsigned char* lds_q = lds;
+    unsigned char* lds_do = lds + BQT * P;
+    float* lds_lse = (float*)(lds + 2 * BQT * P);
+    float* lds_delta = lds_lse + BQT;
+    int* lds_flag = (int*)(lds_delta + BQT);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ktiles = (int)((a.Lk + BK - 1) / BK);
+    const int kt_blk = blockIdx.x % ktiles;
+    const int64_t h = (blockIdx.x / ktiles) % a.H, b = blockIdx.x / (ktiles * a.H);
+    const int64_t key = (int64_t)kt_blk * BK + wave * 32 + r;
+    const int64_t keyc = key < a.Lk ? key : a.Lk - 1;
+    const float* maskg = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
+    const bool key_valid = key < a.Lk && (maskg == nullptr || maskg[keyc] != 0.f);
+    const float bias_key = key_valid ? 0.f : -INFINITY;
+
+    // K / V fragments of this lane's key (B operands): K[key][ks*2*PER16 + hh*PER16 ..]; invalid keys read as zero rows
+    frag_t kf[NQF], vf[NQF];
+    {
+        const TC* kp = (const TC*)a.K + b * a.k_bs + keyc * a.ldk + h * HD;
+        const TC* vp = (const TC*)a.V + b * a.v_bs + keyc * a.ldv + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) {
+            kf[ks] = keep_or_zero(*(const frag_t*)(kp + ks * 2 * PER16 + hh * PER16), key_valid);
+            vf[ks] = keep_or_zero(*(const frag_t*)(vp + ks * 2 * PER16 + hh * PER16), key_valid);
+        }
+    }
+
+    const TC* Qg = (const TC*)a.Q + b * a.q_bs + h * HD;
+    const TC* Gg = (const TC*)a.dO + b * a.do_bs + h * HD;
+    const float* skipg = a.q_skip_mask ? a.q_skip_mask + b * a.Lq : nullptr;
+    const float* lseg = a.lse + (b * a.H + h) * a.Lq;
+    const float* delg = a.delta + (b * a.H + h) * a.Lq;
+
+    frag_t rq[NCH], rg[NCH];
+    float rl = INFINITY, rd = 0.f;
+    auto load_tile = [&](int64_t qbase) __attribute__((always_inline)) {
+        float sk[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTH;
+            const int64_t qq = qbase + c / CPR;
+            const int64_t qcl = qq < a.Lq ? qq : a.Lq - 1;
+            rq[i] = *(const frag_t*)(Qg + qcl * a.ldq + (c % CPR) * PER16);
+            rg[i] = *(const frag_t*)(Gg + qcl * a.lddo + (c % CPR) * PER16);
+            sk[i] = skipg ? skipg[qcl] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTH;
+            const bool keep = (qbase + c / CPR) < a.Lq && sk[i] != 0.f;
+            rq[i] = keep_or_zero(rq[i], keep);
+            rg[i] = keep_or_zero(rg[i], keep);
+        }
+        if (tid < BQT) {
+            const int64_t qq = qbase + tid;
+            const int64_t qcl = qq < a.Lq ? qq : a.Lq - 1;
+            const float skv = skipg ? skipg[qcl] : 1.f;
+            const bool ok = qq < a.Lq && skv != 0.f;
+            const float l = lseg[qcl], dl = delg[qcl];
+            rl = ok ? l : INFINITY;                    // +inf: the whole probability row is 0
+            rd = ok ? dl : 0.f;
+        }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTH;
+            *(frag_t*)(lds_q + (c / CPR) * P + (c % CPR) * 16) = rq[i];
+            *(frag_t*)(lds_do + (c / CPR) * P + (c % CPR) * 16) = rg[i];
+        }
+        if (tid < BQT) { lds_lse[tid] = rl; lds_delta[tid] = rd; }
+    };
+
+    f32x16 dk[NDT], dv[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+
+    // queries after the last valid one contribute nothing (padding is a suffix)
+    int64_t lq_eff = a.Lq;
+    if (skipg) {
+        int last = -1;
+        for (int j = tid; j < (int)a.Lq; j += NTH)
+            if (skipg[j] != 0.f) last = j;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
+        if (lane == 0) lds_flag[1 + wave] = last;
+        __syncthreads();
+        lq_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
+    }
+    const int64_t ntiles = (lq_eff + BQT - 1) / BQT;
+    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
+    const uint64_t bhbase = (uint64_t)(b * a.H + h) * (uint64_t)a.Lq;
+    const bool wave_active = __any(key_valid);
+
+    if (ntiles > 0) load_tile(0);
+    for (int64_t t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile((t + 1) * BQT);
+        if (!wave_active) continue;
+
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[qi][e] = 0.f; dp[qi][e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) {
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+                frag_t qa = *(const frag_t*)(lds_q + (qi * 32 + r) * P + ks * 32 + hh * 16);
+                frag_t ga = *(const frag_t*)(lds_do + (qi * 32 + r) * P + ks * 32 + hh * 16);
+                if constexpr (IS_BF16) {
+                    s[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s[qi], 0, 0, 0);
+                    dp[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp[qi], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[ks][e], s[qi], 0, 0, 0);
+                        dp[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[e], vf[ks][e], dp[qi], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // s <- Pd (dropped probabilities), dp <- dS
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ql = qi * 32 + acc_row(e, hh);
+                const float p = expf(s[qi][e] * a.scale + bias_key - lds_lse[ql]);
+                float pd = p, g = dp[qi][e];
+                if (a.drop.p > 0.f) {
+                    const bool keep = drop_keep(a.drop, thr, (bhbase + (uint64_t)(t * BQT + ql)) * (uint64_t)a.Lk + (uint64_t)keyc);
+                    pd = keep ? p * dsc : 0.f;
+                    g = keep ? g * dsc : 0.f;
+                }
+                s[qi][e] = pd;
+                dp[qi][e] = p * (g - lds_delta[ql]) * a.scale;
+            }
+        // dV^T += dO^T Pd,  dK^T += Q^T dS
+        if constexpr (IS_BF16) {
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf, sf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)s[qi][8 * s2 + j]; sf[j] = (bf16_t)dp[qi][8 * s2 + j]; }
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(lds_do, P, qi * 32 + 16 * s2, d * 32, lane), pf, dv[d], 0, 0, 0);
+                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(lds_q, P, qi * 32 + 16 * s2, d * 32, lane), sf, dk[d], 0, 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ql = qi * 32 + acc_row(e, hh);
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        const float gv = *(const float*)(lds_do + ql * P + (d * 32 + r) * 4);
+                        const float qv = *(const float*)(lds_q + ql * P + (d * 32 + r) * 4);
+                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, s[qi][e], dv[d], 0, 0, 0);
+                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, dp[qi][e], dk[d], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    if (key >= a.Lk) return;
+    TC* kp = (TC*)a.dK + b * a.dk_bs + key * a.lddk + h * HD;
+    TC* vp = (TC*)a.dV + b * a.dv_bs + key * a.lddv + h * HD;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dd = d * 32 + 8 * g + 4 * hh + j;
+                kp[dd] = from_f32<TC>(key_valid ? dk[d][4 * g + j] : 0.f);
+                vp[dd] = from_f32<TC>(key_valid ? dv[d][4 * g + j] : 0.f);
+            }
+}
+
+template <typename TC>
+int launch_bwd(const MadeAttnBwdArgs& a, hipStream_t st) {
+    const int64_t rows = a.B * a.H * a.Lq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTH), 0, st, a);
+    dim3 gq((unsigned)(((a.Lq + 127) / 128) * a.H * a.B)), gk((unsigned)(((a.Lk + 127) / 128) * a.H * a.B)), block(NTH);
+    switch (a.hd) {
+        case 32:
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 32>), gq, block, 0, st, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 32>), gk, block, 0, st, a);
+            break;
+        case 64:
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 64>), gq, block, 0, st, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 64>), gk, block, 0, st, a);
+            break;
+        case 128:
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 128>), gq, block, 0, st, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 128>), gk, block, 0, st, a);
+            break;
+        default:
+            made_set_error("made_attention_bwd: head dim %d not in {32,64,128}", a.hd);
+            return MADE_ERR_UNSUPPORTED;
+    }
+    return made_check_launch("made_attention_bwd");
+}
+
+}  // namespace
+
+extern "C" int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream) {
+    MADE_REQUIRE(args != nullptr, "made_attention_bwd: null args");
+    const MadeAttnBwdArgs& a = *args;
+    MADE_REQUIRE(a.Q && a.K && a.V && a.O && a.dO && a.dQ && a.dK && a.dV && a.lse && a.delta, "made_attention_bwd: null tensor");
+    MADE_REQUIRE(a.B >= 0 && a.H > 0 && a.Lq >= 0 && a.Lk > 0, "made_attention_bwd: bad dims");
+    MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention_bwd: bad dtype %d", a.dtype);
+    MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_attention_bwd: dropout p out of [0,1)");
+    const int per16 = a.dtype == MADE_F32 ? 4 : 8;
+    MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.lddo % per16 == 0 &&
+                     a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.v_bs % per16 == 0 && a.do_bs % per16 == 0,
+                     "made_attention_bwd: strides must keep 16-byte alignment");
+    MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && ((uintptr_t)a.dO % 16) == 0,
+                     "made_attention_bwd: base pointers must be 16-byte aligned");
+    MADE_UNSUPPORTED(((a.Lq + 127) / 128) * a.H * a.B < (1LL << 31) && ((a.Lk + 127) / 128) * a.H * a.B < (1LL << 31),
+                     "made_attention_bwd: too many workgroups");
+    if (a.B == 0 || a.Lq == 0) return MADE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return a.dtype == MADE_BF16 ? launch_bwd<bf16_t>(a, st) : launch_bwd<float>(a, st);
+}

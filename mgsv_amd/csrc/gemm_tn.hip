@@ -1,0 +1,246 @@
+// made_gemm_tn: C[N,K] (+)= alpha * sum_m A[m,n] * B[m,k]  -- the weight-gradient product of the training path
+// (dW = dY^T X: both operands are stored with the REDUCTION index m as the slow dimension, i.e. as the forward pass
+// left them in HBM), gfx950.
+//
+// One workgroup = 4 waves = one 128 x 128 tile of C; wave (wn, wk) owns a 64 x 64 quadrant = 2 x 2 MFMA 32x32 tiles.
+// A and B slabs of BM reduction rows are staged global -> registers -> LDS row-major exactly as they lie in HBM
+// (coalesced 16-byte chunks; the next slab's loads are in flight during the current slab's MFMAs); the MFMA operand
+// fragments (row index on the lane, reduction index along k) come out of LDS through ds_read_b64_tr_b16, the hardware
+// transposing read (bf16), or plain 4-byte reads with the lane on the row index (f32).  No transposed copy of an
+// activation is ever written.  The reduction can be split over workgroups (split_m) and over a batch whose C stride is
+// 0; partial tiles are then combined with f32 atomic adds (accumulate = 1), which is also how gradients of a weight used
+// at several places add up.  Optionally the column sums of A (the bias gradient) are accumulated by the k-tile-0 blocks.
+//   bf16 : v_mfma_f32_32x32x16_bf16,  f32 : v_mfma_f32_32x32x2_f32 (exact f32; parity mode)
+#include "common.h"
+
+namespace {
+
+constexpr int TBN = 128, TBK = 128, TNT = 256;
+
+template <typename TC> struct TnCfg;
+// row pitch: 4 consecutive rows must land on disjoint quarters of the 64 LDS banks for the transposing reads
+template <> struct TnCfg<bf16_t> { static constexpr int BM = 64, ROW = 128 * 2 + 64, CPR = 16; typedef bf16x8 frag_t; };
+// f32: the two reduction rows a wave reads per MFMA must sit 32 banks apart
+template <> struct TnCfg<float>  { static constexpr int BM = 32, ROW = 128 * 4 + 128, CPR = 32; typedef f32x4 frag_t; };
+
+template <typename TC>
+__global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
+    typedef TnCfg<TC> Cfg;
+    typedef typename Cfg::frag_t frag_t;
+    constexpr int BM = Cfg::BM, ROW = Cfg::ROW, CPR = Cfg::CPR;
+    constexpr int PER16 = 16 / (int)sizeof(TC);
+    constexpr int NCH = BM * CPR / TNT;             // 16-byte chunks per thread per operand (= 4)
+    constexpr bool IS_BF16 = sizeof(TC) == 2;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * ROW];
+    unsigned char* lds_a = lds;
+    unsigned char* lds_b = lds + BM * ROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int tiles_k = (int)((a.K + TBK - 1) / TBK);
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x % tiles_k;
+    const int64_t n0 = (int64_t)tile_n * TBN, k0 = (int64_t)tile_k * TBK;
+    const int64_t z = blockIdx.z, z1 = z / a.batch2, z2 = z % a.batch2;
+
+    const TC* Ag = (const TC*)a.A + z1 * a.a_zs1 + z2 * a.a_zs2;
+    const TC* Bg = (const TC*)a.B + z1 * a.b_zs1 + z2 * a.b_zs2;
+    const float* maskg = a.row_mask ? a.row_mask + z1 * a.mask_zs1 + z2 * a.mask_zs2 : nullptr;
+
+    // this block's share of the reduction: slabs [s_begin, s_end)
+    const int64_t nslab = (a.M + BM - 1) / BM;
+    const int64_t per = (nslab + a.split_m - 1) / a.split_m;
+    const int64_t s_begin = (int64_t)blockIdx.y * per;
+    const int64_t s_end = s_begin + per < nslab ? s_begin + per : nslab;
+    if (s_begin >= s_end) return;
+
+    frag_t ra[NCH], rb[NCH];
+    auto load_slab = [&](int64_t slab) __attribute__((always_inline)) {
+        // branch-free: clamped addresses, masking on the registers (rows past M, columns past N / K, masked rows)
+        float mk[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * TNT;
+            const int row = c / CPR, cc = c % CPR;
+            int64_t m = slab * BM + row;
+            const int64_t mc = m < a.M ? m : a.M - 1;
+            int64_t na = n0 + cc * PER16, kb = k0 + cc * PER16;
+            const int64_t nac = na + PER16 <= a.N ? na : 0, kbc = kb + PER16 <= a.K ? kb : 0;
+            ra[i] = *(const frag_t*)(Ag + mc * a.lda + nac);
+            rb[i] = *(const frag_t*)(Bg + mc * a.ldb + kbc);
+            mk[i] = maskg ? maskg[mc] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * TNT;
+            const int row = c / CPR, cc = c % CPR;
+            const bool rowok = (slab * BM + row) < a.M && mk[i] != 0.f;
+            ra[i] = keep_or_zero(ra[i], rowok && (n0 + cc * PER16 + PER16 <= a.N));
+            rb[i] = keep_or_zero(rb[i], rowok && (k0 + cc * PER16 + PER16 <= a.K));
+        }
+    };
+    auto store_slab = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * TNT;
+            *(frag_t*)(lds_a + (c / CPR) * ROW + (c % CPR) * 16) = ra[i];
+            *(frag_t*)(lds_b + (c / CPR) * ROW + (c % CPR) * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float csum = 0.f;
+    const bool do_colsum = a.colsum != nullptr && tile_k == 0 && tid < TBN;
+
+    load_slab(s_begin);
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        __syncthreads();
+        store_slab();
+        __syncthreads();
+        if (s + 1 < s_end) load_slab(s + 1);
+
+        if (do_colsum) {
+#pragma unroll 8
+            for (int m = 0; m < BM; ++m) csum += to_f32(*(const TC*)(lds_a + m * ROW + tid * (int)sizeof(TC)));
+        }
+        if constexpr (IS_BF16) {
+            const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+            for (int ks = 0; ks < BM / 16; ++ks) {
+                // reduction rows of this k-step: slots j = 0..7 of lane half hh <-> row 16 ks + 8 (j >> 2) + 4 hh + (j & 3)
+                const int kb = 16 * ks + 4 * (g >> 1) + (i16 >> 2);
+                const int cofs = ((g & 1) * 16 + 4 * (i16 & 3)) * 2;
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned char* pa = lds_a + kb * ROW + (wn * 64 + t * 32) * 2 + cofs;
+                    const unsigned char* pb = lds_b + kb * ROW + (wk * 64 + t * 32) * 2 + cofs;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pa);
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa + 8 * ROW));
+                    af[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pb);
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pb + 8 * ROW));
+                    bfr[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 4
+            for (int ks = 0; ks < BM / 2; ++ks) {
+                const int m = 2 * ks + hh;
+                float af[2], bfr[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    af[t] = *(const float*)(lds_a + m * ROW + (wn * 64 + t * 32 + r) * 4);
+                    bfr[t] = *(const float*)(lds_b + m * ROW + (wk * 64 + t * 32 + r) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: C[n][k], n on the accumulator rows, k on the lanes (128-byte runs per half-wave)
+    const int64_t cz = z1 * a.c_zs1 + z2 * a.c_zs2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t k = k0 + wk * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t n = n0 + wn * 64 + i * 32 + acc_row(e, hh);
+                if (n < a.N && k < a.K) {
+                    const float v = acc[i][j][e] * a.alpha;
+                    if (a.c_dtype == MADE_F32) {
+                        float* p = (float*)a.C + cz + n * a.ldc + k;
+                        if (a.accumulate) unsafeAtomicAdd(p, v); else *p = v;
+                    } else {
+                        ((bf16_t*)a.C)[cz + n * a.ldc + k] = (bf16_t)v;
+                    }
+                }
+            }
+        }
+    if (do_colsum && n0 + tid < a.N)
+        unsafeAtomicAdd(a.colsum + z1 * a.colsum_zs1 + z2 * a.colsum_zs2 + n0 + tid, csum * a.alpha);
+}
+
+// shapes the tiled kernel cannot address with 16-byte chunks (tiny heads: N = 2 classes / span coordinates):
+// one thread per C element, the reduction split over blockIdx.y
+__global__ __launch_bounds__(256) void gemm_tn_small_kernel(const MadeGemmTNArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t z = blockIdx.z, z1 = z / a.batch2, z2 = z % a.batch2;
+    const bool active = e < a.N * a.K;
+    const int64_t n = active ? e / a.K : 0, k = active ? e % a.K : 0;
+    const int64_t per = (a.M + gridDim.y - 1) / gridDim.y;
+    const int64_t m0 = (int64_t)blockIdx.y * per, m1 = m0 + per < a.M ? m0 + per : a.M;
+    const float* maskg = a.row_mask ? a.row_mask + z1 * a.mask_zs1 + z2 * a.mask_zs2 : nullptr;
+    const int64_t ao = z1 * a.a_zs1 + z2 * a.a_zs2, bo = z1 * a.b_zs1 + z2 * a.b_zs2;
+    float acc = 0.f, cs = 0.f;
+    for (int64_t m = m0; m < m1; ++m) {
+        if (maskg && maskg[m] == 0.f) continue;
+        const float av = load_as_f32(a.A, a.ab_dtype, ao + m * a.lda + n);
+        acc += av * load_as_f32(a.B, a.ab_dtype, bo + m * a.ldb + k);
+        cs += av;
+    }
+    if (!active) return;
+    const int64_t co = z1 * a.c_zs1 + z2 * a.c_zs2 + n * a.ldc + k;
+    if (a.c_dtype == MADE_F32) {
+        if (a.accumulate) unsafeAtomicAdd((float*)a.C + co, acc * a.alpha); else ((float*)a.C)[co] = acc * a.alpha;
+    } else {
+        ((bf16_t*)a.C)[co] = (bf16_t)(acc * a.alpha);
+    }
+    if (a.colsum && k == 0) unsafeAtomicAdd(a.colsum + z1 * a.colsum_zs1 + z2 * a.colsum_zs2 + n, cs * a.alpha);
+}
+
+}  // namespace
+
+extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
+    MADE_REQUIRE(args != nullptr, "made_gemm_tn: null args");
+    MadeGemmTNArgs a = *args;
+    MADE_REQUIRE(a.A && a.B && a.C, "made_gemm_tn: null tensor");
+    MADE_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "made_gemm_tn: bad dims");
+    MADE_REQUIRE(a.ab_dtype == MADE_F32 || a.ab_dtype == MADE_BF16, "made_gemm_tn: bad operand dtype %d", a.ab_dtype);
+    MADE_REQUIRE(a.c_dtype == MADE_F32 || a.c_dtype == a.ab_dtype, "made_gemm_tn: C must be f32 or the operand dtype");
+    if (a.batch1 <= 0) a.batch1 = 1;
+    if (a.batch2 <= 0) a.batch2 = 1;
+    if (a.split_m <= 0) a.split_m = 1;
+    const int64_t nz = a.batch1 * a.batch2;
+    MADE_REQUIRE(a.split_m == 1 || a.accumulate, "made_gemm_tn: split_m > 1 needs accumulate = 1 (partials are added atomically)");
+    MADE_REQUIRE(!a.accumulate || a.c_dtype == MADE_F32, "made_gemm_tn: accumulation needs an f32 C");
+    MADE_UNSUPPORTED(nz < 65536 && a.split_m < 65536, "made_gemm_tn: batch / split too large for the grid");
+    if (a.M == 0) return MADE_OK;                                   /* nothing to add (C is not cleared: callers zero gradients) */
+    hipStream_t st = (hipStream_t)stream;
+    const int per16 = a.ab_dtype == MADE_F32 ? 4 : 8;
+    const bool aligned = a.lda % per16 == 0 && a.ldb % per16 == 0 && a.N % per16 == 0 && a.K % per16 == 0 &&
+                         a.a_zs1 % per16 == 0 && a.a_zs2 % per16 == 0 && a.b_zs1 % per16 == 0 && a.b_zs2 % per16 == 0 &&
+                         ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0;
+    if (!aligned || a.N * a.K <= 4096) {
+        MADE_UNSUPPORTED(a.N * a.K <= (1 << 20), "made_gemm_tn: unaligned operands are only supported for small outputs");
+        int sy = (int)a.split_m;
+        if (!a.accumulate) sy = 1;
+        dim3 grid((unsigned)((a.N * a.K + 255) / 256), (unsigned)sy, (unsigned)nz);
+        hipLaunchKernelGGL(gemm_tn_small_kernel, grid, dim3(256), 0, st, a);
+        return made_check_launch("made_gemm_tn(small)");
+    }
+    const int64_t tiles = ((a.N + TBN - 1) / TBN) * ((a.K + TBK - 1) / TBK);
+    MADE_UNSUPPORTED(tiles < (1LL << 31), "made_gemm_tn: too many tiles");
+    dim3 grid((unsigned)tiles, (unsigned)a.split_m, (unsigned)nz);
+    if (a.ab_dtype == MADE_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(TNT), 0, st, a);
+    else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(TNT), 0, st, a);
+    return made_check_launch("made_gemm_tn");
+}

@@ -101,6 +101,79 @@ __device__ __forceinline__ void store8(void* out, int odt, int64_t off, const fl
     }
 }
 
+// 8 consecutive f32 from `p` in a runtime dtype (vector load when `vec`)
+__device__ __forceinline__ void load8(const void* p, int dt, int64_t off, float* v, int nvalid, bool vec) {
+    if (vec && nvalid == 8) {
+        if (dt == MADE_F32) {
+            f32x4 r0 = *(const f32x4*)((const float*)p + off), r1 = *(const f32x4*)((const float*)p + off + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = r0[j]; v[4 + j] = r1[j]; }
+        } else {
+            bf16x8 rb = *(const bf16x8*)((const bf16_t*)p + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)rb[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = j < nvalid ? load_as_f32(p, dt, off + j) : 0.f;
+    }
+}
+
+__device__ __forceinline__ float act_grad(float g, int gate) {
+    switch (gate) {
+        case MADE_GATE_RELU_OUT: return g != 0.f ? 1.f : 0.f;                    // g = saved output (after ReLU and dropout)
+        case MADE_GATE_GELU_Z: {                                                // g = saved pre-activation
+            const float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752440f));
+            return cdf + g * 0.39894228040143267794f * expf(-0.5f * g * g);
+        }
+        case MADE_GATE_QUICKGELU_Z: {
+            const float sg = 1.f / (1.f + expf(-1.702f * g));
+            return sg * (1.f + 1.702f * g * (1.f - sg));
+        }
+        case MADE_GATE_SIGMOID_OUT: return g * (1.f - g);                        // g = saved sigmoid output
+        default: return 1.f;
+    }
+}
+
+// The element-wise tail of made_linear on 8 consecutive outputs of row m starting at column n:
+//   z = acc + bias  [-> Zout]   v = act(z)   v *= act'(G) * gate_scale   v = dropout(v)   v += R   row mask
+__device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n, int nvalid, float* v, const float* bv,
+                                          int rmod, bool r_vec) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += bv[j];
+    if (a.Zout) {
+        const bool zv = (a.ldz % 8 == 0) && (((uintptr_t)a.Zout & 15) == 0);
+        store8(a.Zout, a.z_dtype, (int64_t)m * a.ldz + n, v, nvalid, zv);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], a.act);
+    if (a.gate != MADE_GATE_NONE) {
+        float g[8];
+        load8(a.G, a.g_dtype, (int64_t)m * a.ldg + n, g, nvalid, (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= act_grad(g[j], a.gate) * a.gate_scale;
+    }
+    if (a.drop.p > 0.f) {
+        const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+        const float sc = 1.f / (1.f - a.drop.p);
+        const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = (made_rng_mix(a.drop.seed, a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+    }
+    if (a.R) {
+        const int rr = rmod > 0 ? m % rmod : m;
+        float rv[8];
+        load8(a.R, a.r_dtype, (int64_t)rr * a.ldr + n, rv, nvalid, r_vec);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rv[j];
+    }
+    if (a.out_row_mask && a.out_row_mask[m] == 0.f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+}
+
 template <typename TA, typename TC>
 __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArgs a) {
     typedef typename Frag<TC>::type frag_t;
@@ -326,29 +399,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
                 const float* cp = Ct + row * CT_LD + cc * 8;
                 f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], a.act);
-                if (a.R) {
-                    const int rr = rmod > 0 ? m % rmod : m;
-                    const int64_t ro = (int64_t)rr * a.ldr + n;
-                    if (r_vec && nvalid == 8) {
-                        if (a.r_dtype == MADE_F32) {
-                            f32x4 r0 = *(const f32x4*)((const float*)a.R + ro), r1 = *(const f32x4*)((const float*)a.R + ro + 4);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
-                        } else {
-                            bf16x8 rb = *(const bf16x8*)((const bf16_t*)a.R + ro);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)rb[j];
-                        }
-                    } else {
-                        for (int j = 0; j < nvalid; ++j) v[j] += load_as_f32(a.R, a.r_dtype, ro + j);
-                    }
-                }
-                if (a.out_row_mask && a.out_row_mask[m] == 0.f) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = 0.f;
-                }
+                epilogue8(a, m, n, nvalid, v, bv, rmod, r_vec);
                 int64_t orow;
                 if (rpb > 0) {
                     const int b = m / rpb, t = m - b * rpb;
@@ -553,29 +604,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_glds_kernel(const MadeLine
                 const float* cp = Ct + row * G_CT_LD + cc * 8;
                 f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], a.act);
-                if (a.R) {
-                    const int rr = rmod > 0 ? m % rmod : m;
-                    const int64_t ro = (int64_t)rr * a.ldr + n;
-                    if (r_vec && nvalid == 8) {
-                        if (a.r_dtype == MADE_F32) {
-                            f32x4 r0 = *(const f32x4*)((const float*)a.R + ro), r1 = *(const f32x4*)((const float*)a.R + ro + 4);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
-                        } else {
-                            bf16x8 rb = *(const bf16x8*)((const bf16_t*)a.R + ro);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)rb[j];
-                        }
-                    } else {
-                        for (int j = 0; j < nvalid; ++j) v[j] += load_as_f32(a.R, a.r_dtype, ro + j);
-                    }
-                }
-                if (a.out_row_mask && a.out_row_mask[m] == 0.f) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = 0.f;
-                }
+                epilogue8(a, m, n, nvalid, v, bv, rmod, r_vec);
                 int64_t orow;
                 if (rpb > 0) {
                     const int b = m / rpb, t = m - b * rpb;
@@ -621,6 +650,13 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
         } else {
             MADE_REQUIRE(a.seg[0].col_begin == 0, "made_linear: first segment must start at column 0");
         }
+    }
+    if (a.gate != MADE_GATE_NONE) MADE_REQUIRE(a.G != nullptr, "made_linear: gate without G");
+    if (a.gate != MADE_GATE_NONE || a.Zout || a.drop.p > 0.f) {
+        MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_linear: dropout p=%f out of [0,1)", (double)a.drop.p);
+        MADE_UNSUPPORTED(a.split_k <= 1, "made_linear: gate / Zout / dropout are not available with split-K");
+        for (int s = 0; s < a.nseg; ++s)
+            MADE_UNSUPPORTED(!a.seg[s].transposed, "made_linear: gate / Zout / dropout are not available on transposed segments");
     }
     if (a.M == 0) return MADE_OK;
     const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);

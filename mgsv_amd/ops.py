@@ -127,8 +127,11 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
            a2_replace: bool = False, a_row_mask: Optional[Tensor] = None, act: int = ACT_NONE, R: Optional[Tensor] = None,
            r_row_mod: int = 0, out_row_mask: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
            tile_skip_mask: Optional[Tensor] = None, batch: int = 1, a_z_stride: int = 0, w_z_stride: int = 0, M: Optional[int] = None,
-           N: Optional[int] = None, K: Optional[int] = None) -> Tensor:
-    """out = act(A' W^T + bias) (+R).  A [M,K] (row stride free, unit inner stride), W [N,K]."""
+           N: Optional[int] = None, K: Optional[int] = None, gate: int = 0, G: Optional[Tensor] = None, gate_scale: float = 1.0,
+           Zout: Optional[Tensor] = None, drop=None, drop_ld: Optional[int] = None) -> Tensor:
+    """out = act(A' W^T + bias) (+R).  A [M,K] (row stride free, unit inner stride), W [N,K].
+    Training extras: Zout receives the pre-activation; gate/G multiply by act'(G) * gate_scale; drop = (seed, site, p)
+    applies the stateless dropout of include/made_hip.h after act/gate (element index row * drop_ld + col)."""
     assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
     M = A.shape[0] if M is None else M
     K = A.shape[1] if K is None else K
@@ -150,6 +153,15 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
         a.R, a.r_dtype, a.ldr, a.r_row_mod = _p(R), dt_of(R), R.stride(0), r_row_mod
     a.out_row_mask = _p(_f32(out_row_mask, "out_row_mask"))
     a.tile_skip_mask = _p(_f32(tile_skip_mask, "tile_skip_mask"))
+    if gate:
+        assert G is not None and G.dim() == 2 and G.stride(1) == 1
+        a.G, a.g_dtype, a.gate, a.ldg, a.gate_scale = _p(G), dt_of(G), gate, G.stride(0), float(gate_scale)
+    if Zout is not None:
+        assert Zout.dim() == 2 and Zout.stride(1) == 1
+        a.Zout, a.z_dtype, a.ldz = _p(Zout), dt_of(Zout), Zout.stride(0)
+    if drop is not None and drop[2] > 0.0:
+        a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
+        a.drop_ld = N if drop_ld is None else drop_ld
     if segs is None:
         if out is None:
             out = torch.empty((M, N) if batch == 1 else (batch, M, N), device=A.device,
@@ -219,9 +231,10 @@ def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, spli
 
 def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,
               q_mask: Optional[Tensor] = None, scale: Optional[float] = None, Lk: Optional[int] = None,
-              q_skip_mask: Optional[Tensor] = None) -> Tensor:
+              q_skip_mask: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop=None) -> Tensor:
     """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K / V [B,Lk,H*hd], O [B,Lq,H*hd]
-    (any batch/row strides, unit inner stride).  Lk defaults to K.shape[1]."""
+    (any batch/row strides, unit inner stride).  Lk defaults to K.shape[1].
+    Training: lse [B,H,Lq] f32 receives the log-sum-exp, drop = (seed, site, p) drops attention weights."""
     assert Q.dim() == 3 and K.dim() == 3 and V.dim() == 3 and O.dim() == 3
     assert Q.stride(2) == 1 and K.stride(2) == 1 and V.stride(2) == 1 and O.stride(2) == 1
     assert Q.dtype == K.dtype == V.dtype == O.dtype
@@ -239,6 +252,11 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
     a.q_mask = _p(_f32(q_mask, "q_mask"))
     a.q_skip_mask = _p(_f32(q_skip_mask, "q_skip_mask"))
     a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
+    if lse is not None:
+        assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * H * Lq
+        a.lse = _p(lse)
+    if drop is not None and drop[2] > 0.0:
+        a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
     esz = 4 if a.dtype == F32 else 2
     flops = 4.0 * B * H * Lq * a.Lk * hd
     nbytes = esz * B * D * (2 * Lq + 2 * a.Lk)

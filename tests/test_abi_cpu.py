@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "made_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(made_[a-z0-9_]+)\s*\(", text)))
+    names = set(re.findall(r"\b(made_[a-z0-9_]+)\s*\(", text))
+    inline = set(re.findall(r"static inline \w+ (made_[a-z0-9_]+)\s*\(", text))     # header-only helpers (dropout RNG)
+    return sorted(names - inline)
 
 
 def test_library_exports_every_declared_symbol():
@@ -36,7 +38,8 @@ def test_struct_layout_matches_header():
     src = textwrap.dedent('''
         #include <stdio.h>
         #include "made_hip.h"
-        int main(void){ printf("%zu %zu %zu", sizeof(MadeLinearSeg), sizeof(MadeLinearArgs), sizeof(MadeAttnArgs)); return 0; }
+        int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu", sizeof(MadeLinearSeg), sizeof(MadeLinearArgs), sizeof(MadeAttnArgs),
+                               sizeof(MadeWideAttnArgs), sizeof(MadeFinishArgs), sizeof(MadeDropout), sizeof(MadeGemmTNArgs)); return 0; }
     ''')
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "s.c")
@@ -44,7 +47,39 @@ def test_struct_layout_matches_header():
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [C.sizeof(_lib.MadeLinearSeg), C.sizeof(_lib.MadeLinearArgs), C.sizeof(_lib.MadeAttnArgs)]
+    assert sizes == [C.sizeof(x) for x in (_lib.MadeLinearSeg, _lib.MadeLinearArgs, _lib.MadeAttnArgs, _lib.MadeWideAttnArgs,
+                                           _lib.MadeFinishArgs, _lib.MadeDropout, _lib.MadeGemmTNArgs)]
+
+
+def test_dropout_rng_header_matches_numpy_restatement():
+    """made_rng_mix in include/made_hip.h (compiled here with gcc) == mgsv_amd.dropout.rng_mix."""
+    import subprocess, tempfile, textwrap
+    import numpy as np
+    from mgsv_amd import dropout as dr
+    src = textwrap.dedent('''
+        #include <stdio.h>
+        #include "made_hip.h"
+        int main(void){
+            unsigned long long seeds[2] = {1234ULL, 0xDEADBEEF12345678ULL};
+            for (int s = 0; s < 2; ++s) for (unsigned site = 5; site < 4000000000u; site += 1999999999u)
+                for (unsigned long long i = 0; i < 6; ++i) {
+                    unsigned long long idx = i * 0x40000001ULL + i;
+                    printf("%u\\n", made_rng_mix(seeds[s], site, idx));
+                }
+            return 0; }
+    ''')
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "r.c")
+        open(p, "w").write(src)
+        exe = os.path.join(d, "r")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
+        got = [int(x) for x in subprocess.check_output([exe]).split()]
+    want = []
+    for seed in (1234, 0xDEADBEEF12345678):
+        for site in range(5, 4000000000, 1999999999):
+            idx = np.array([i * 0x40000001 + i for i in range(6)], dtype=np.uint64)
+            want += [int(x) for x in dr.rng_mix(seed, site, idx)]
+    assert got == want
 
 
 def test_argument_validation_without_gpu():
