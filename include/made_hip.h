@@ -378,6 +378,78 @@ typedef struct MadeGemmTNArgs {
 
 int made_gemm_tn(const MadeGemmTNArgs* args, void* stream);
 
+/* Row kernels of the backward pass (all parameter gradients are ACCUMULATED into f32 buffers the caller zeroes once per step).
+ *
+ * made_layernorm_bwd: dx = LN'(x; gamma)(dy) [+ add]; optionally also dx_drop = dropout(dx) (the gradient entering a
+ *   residual branch whose output was dropped: `x + dropout(branch)`); dgamma += sum dy*xhat, dbeta += sum dy.  Rows whose
+ *   row_skip is 0 produce zeros and contribute nothing.  Autograd of nn.LayerNorm at reference model/model_Base.py:77-78,
+ *   music_detr/transformer.py:157-158,235-237, modules/transformer.py:141-143. */
+int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
+                       const float* gamma, const void* dy, int32_t dy_dtype, int64_t lddy,
+                       const void* add, int32_t add_dtype, int64_t ld_add,
+                       void* dx, int32_t dx_dtype, int64_t lddx,
+                       void* dx_drop, int64_t lddxd, const MadeDropout* drop, int64_t drop_ld,
+                       float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, const float* row_skip, void* stream);
+
+/* made_pool_bwd: backward of vec = normalize(masked_mean(local)) (reference model/model_Base.py:579-580,615-616) merged with
+ *   the other gradients of `local`: out[b,t,:] = mask[b,t] * (in1[b,t,:] + in2[b,t,:] + dmean[b,:] / count_b),
+ *   dmean = (dvec - vhat (vhat.dvec)) / max(|mean|, eps).  in1 / in2 may be NULL. */
+int made_pool_bwd(const float* mean, const float* dvec, const float* mask,
+                  const void* in1, int32_t in1_dtype, int64_t in1_bs, int64_t in1_ld,
+                  const void* in2, int32_t in2_dtype, int64_t in2_bs, int64_t in2_ld,
+                  void* out, int32_t out_dtype, int64_t out_bs, int64_t out_ld,
+                  int64_t B, int64_t T, int64_t D, float eps, void* stream);
+
+/* made_l2norm_bwd: y = x / max(|x|, eps)  ->  dx = (dy - yhat (yhat.dy)) / max(|x|, eps); dx f32 (stored or accumulated)
+ *   and/or dx_alt in another dtype.  F.normalize at reference model/model_Uni.py:142-146, cosine at modules/loss.py:52-56. */
+int made_l2norm_bwd(const void* x, int32_t x_dtype, int64_t ldx, const float* dy, int64_t lddy,
+                    float* dx, int64_t lddx, int32_t accumulate, void* dx_alt, int32_t alt_dtype, int64_t lddxa,
+                    int64_t rows, int64_t D, float eps, void* stream);
+
+/* made_clip_loss_bwd: gradient of weight * CLIPLoss(sims, logit_scale) (reference modules/loss.py:5-24) times upstream[0]
+ *   (NULL = 1): dsims [n,n] and its transpose dsims_t (may be NULL), d_logit_scale[0] += .  lse_ws: [2n] f32 workspace. */
+int made_clip_loss_bwd(const float* sims, int64_t ld, int64_t n, const float* logit_scale, float weight,
+                       const float* upstream, float* lse_ws, float* dsims, float* dsims_t, int32_t accumulate,
+                       float* d_logit_scale, void* stream);
+
+/* made_xpool_tail_bwd: backward of made_xpool_tail (LayerNorm3 + cosine with the video, reference modules/transformer.py:178,
+ *   modules/metrics.py:10-24): dy [Nm*Nv, D], optionally dy_drop = dropout(dy) (element index row*D + col), dgamma/dbeta
+ *   accumulated, dvideo[n,:] += (atomic). */
+int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, const float* gamma, const float* beta,
+                        const float* video, int64_t ld_video, const float* dsims, int64_t ld_dsims,
+                        void* dy, int32_t dy_dtype, int64_t lddy, void* dy_drop, const MadeDropout* drop,
+                        float* dgamma, float* dbeta, float* dvideo, int64_t ld_dvideo,
+                        int64_t Nm, int64_t Nv, int64_t D, float eps, void* stream);
+
+/* made_softmax_bwd: softmax backward of the wide-head attention with materialised scores (few query rows per batch):
+ *   P = softmax(scale*S + mask), Pd = dropout(P), dP = dropout'(dPd + extra[row]), dS = scale * P * (dP - sum_k P_k dP_k).
+ *   Writes Pd and dS [rows, ldo] (columns L..ldo-1 zero) and dS^T [rows/rows_per_batch, L, ldt] in out_dtype; the products
+ *   dV = Pd^T dO, dK = dS^T Q and dQ = dS K are then made_gemm_tn calls.  mask row = row / rows_per_mask. */
+int made_softmax_bwd(const float* S, int64_t ld_s, const float* dP, int64_t ld_dp, const float* mask, int64_t rows_per_mask,
+                     const float* extra, float scale, const MadeDropout* drop,
+                     void* Pd, void* dS, void* dSt, int32_t out_dtype, int64_t ldo, int64_t ldt,
+                     int64_t rows, int64_t rows_per_batch, int64_t L, void* stream);
+
+/* x[row, h*hd + j] += s[row, h] * bias[h*hd + j]: the value-projection bias of the memory-space cross-attention when the
+ * attention weights of a row no longer sum to 1 (dropout); s = that sum.  And its backward. */
+int made_head_bias(void* x, int32_t x_dtype, int64_t ldx, const float* s, const float* bias, int64_t rows, int64_t H, int64_t hd,
+                   void* stream);
+int made_head_bias_bwd(const void* dy, int32_t dtype, int64_t ld, const float* s, const float* bias, float* dbias, float* ds,
+                       int64_t rows, int64_t H, int64_t hd, void* stream);
+
+/* out = a + b + c over n contiguous elements (b, c may be NULL; any mix of f32 / bf16): merges gradient streams. */
+int made_add3(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, const void* b, int32_t b_dtype,
+              const void* c, int32_t c_dtype, int64_t n, void* stream);
+
+/* made_set_criterion_bwd: gradients of made_set_criterion's total (times upstream[0]) w.r.t. pred_logits, pred_spans
+ *   [n_layers,B,Q,2], proj_queries [n_layers,B,Q,Dc] (stored) and vid_sum [B,Dc] (accumulated). */
+int made_set_criterion_bwd(const float* pred_logits, const float* pred_spans, const float* targets,
+                           const int64_t* pred_idx, const int64_t* tgt_idx, const int32_t* count,
+                           const float* proj_queries, const float* vid_sum, const float* empty_weight,
+                           int64_t n_layers, int64_t B, int64_t Q, int64_t G, int64_t Dc, int32_t fg_label,
+                           float temperature, const float* weights, const float* upstream,
+                           float* d_logits, float* d_spans, float* d_proj_queries, float* d_vid_sum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

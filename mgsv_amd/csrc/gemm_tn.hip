@@ -66,7 +66,7 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
             int64_t m = slab * BM + row;
             const int64_t mc = m < a.M ? m : a.M - 1;
             int64_t na = n0 + cc * PER16, kb = k0 + cc * PER16;
-            const int64_t nac = na + PER16 <= a.N ? na : 0, kbc = kb + PER16 <= a.K ? kb : 0;
+            const int64_t nac = na < a.N ? na : 0, kbc = kb < a.K ? kb : 0;     // a chunk may run past N / K inside the row pitch
             ra[i] = *(const frag_t*)(Ag + mc * a.lda + nac);
             rb[i] = *(const frag_t*)(Bg + mc * a.ldb + kbc);
             mk[i] = maskg ? maskg[mc] : 1.f;
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
             const int c = tid + i * TNT;
             const int row = c / CPR, cc = c % CPR;
             const bool rowok = (slab * BM + row) < a.M && mk[i] != 0.f;
-            ra[i] = keep_or_zero(ra[i], rowok && (n0 + cc * PER16 + PER16 <= a.N));
-            rb[i] = keep_or_zero(rb[i], rowok && (k0 + cc * PER16 + PER16 <= a.K));
+            ra[i] = keep_or_zero(ra[i], rowok && (n0 + cc * PER16 < a.N));     // columns >= N only feed C rows that are not stored
+            rb[i] = keep_or_zero(rb[i], rowok && (k0 + cc * PER16 < a.K));
         }
     };
     auto store_slab = [&]() __attribute__((always_inline)) {
@@ -226,7 +226,8 @@ extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
     if (a.M == 0) return MADE_OK;                                   /* nothing to add (C is not cleared: callers zero gradients) */
     hipStream_t st = (hipStream_t)stream;
     const int per16 = a.ab_dtype == MADE_F32 ? 4 : 8;
-    const bool aligned = a.lda % per16 == 0 && a.ldb % per16 == 0 && a.N % per16 == 0 && a.K % per16 == 0 &&
+    const int64_t n_up = (a.N + per16 - 1) / per16 * per16, k_up = (a.K + per16 - 1) / per16 * per16;
+    const bool aligned = a.lda % per16 == 0 && a.ldb % per16 == 0 && n_up <= a.lda && k_up <= a.ldb &&
                          a.a_zs1 % per16 == 0 && a.a_zs2 % per16 == 0 && a.b_zs1 % per16 == 0 && a.b_zs2 % per16 == 0 &&
                          ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0;
     if (!aligned || a.N * a.K <= 4096) {

@@ -265,6 +265,114 @@ __global__ void criterion_total_kernel(const float* losses, const float* weights
     total[0] = t;
 }
 
+// ---- set criterion backward --------------------------------------------------------------------------
+// Gradients of total = sum_l sum_k weights[k] * losses[l][k] w.r.t. logits, spans, proj_queries and vid_sum, scaled by
+// upstream[0] (the gradient arriving at localization_loss).  One workgroup per decoder layer; vid_sum gradients of all
+// layers are added atomically.  Ties of min/max inside the GIoU have measure zero and take the first operand's branch.
+__global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float* logits, const float* spans, const float* targets,
+                                                                     const int64_t* pred_idx, const int64_t* tgt_idx, const int32_t* count,
+                                                                     const float* proj_q, const float* vid_sum, const float* empty_w,
+                                                                     int B, int Q, int G, int Dc, int fg, float temperature,
+                                                                     const float* weights, const float* upstream,
+                                                                     float* dlogits, float* dspans, float* dproj_q, float* dvid_sum) {
+    __shared__ unsigned char matched[CRIT_MAX_BQ];
+    __shared__ float lgt[CRIT_MAX_BQ];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int width = Q < G ? Q : G;
+    const int bg = 1 - fg;
+    const int l = blockIdx.x;
+    const float up = upstream ? upstream[0] : 1.f;
+    const float* lg = logits + (int64_t)l * B * Q * 2;
+    const float* sp = spans + (int64_t)l * B * Q * 2;
+    float* dlg = dlogits + (int64_t)l * B * Q * 2;
+    float* dsp = dspans + (int64_t)l * B * Q * 2;
+    for (int i = tid; i < B * Q; i += CRIT_THREADS) { matched[i] = 0; dsp[2 * i] = 0.f; dsp[2 * i + 1] = 0.f; }
+    __syncthreads();
+    float npairs = 0.f;
+    for (int i = tid; i < B * width; i += CRIT_THREADS) {
+        int b = i / width, slot = i % width;
+        if (slot < count[l * B + b]) npairs += 1.f;
+    }
+    npairs = block_sum(npairs, red);
+    for (int i = tid; i < B * width; i += CRIT_THREADS) {
+        int b = i / width, slot = i % width;
+        int s = l * B + b;
+        if (slot < count[s]) {
+            int q = (int)pred_idx[(int64_t)s * width + slot];
+            int g = kth_kept(targets + (int64_t)b * G * 2, G, (int)tgt_idx[(int64_t)s * width + slot]);
+            float pc = sp[(b * Q + q) * 2], pw = sp[(b * Q + q) * 2 + 1];
+            float tc = targets[((int64_t)b * G + g) * 2], tw = targets[((int64_t)b * G + g) * 2 + 1];
+            // L1: mean over 2 * npairs entries
+            const float wl1 = up * weights[0] / (2.f * npairs);
+            float dc = wl1 * (pc > tc ? 1.f : (pc < tc ? -1.f : 0.f));
+            float dw = wl1 * (pw > tw ? 1.f : (pw < tw ? -1.f : 0.f));
+            // GIoU: loss = mean(1 - giou)
+            float ps, pe, ts, te;
+            cw_to_se(pc, pw, ps, pe);
+            cw_to_se(tc, tw, ts, te);
+            const float mn_e = fminf(pe, te), mx_s = fmaxf(ps, ts);
+            const float inter = fmaxf(mn_e - mx_s, 0.f);
+            const float uni = (pe - ps) + (te - ts) - inter;
+            const float enc = fmaxf(fmaxf(pe, te) - fminf(ps, ts), 0.f);
+            const float pos_i = (mn_e - mx_s) > 0.f ? 1.f : 0.f;
+            const float di_pe = pos_i * (pe <= te ? 1.f : 0.f), di_ps = -pos_i * (ps >= ts ? 1.f : 0.f);
+            const float du_pe = 1.f - di_pe, du_ps = -1.f - di_ps;
+            const float pos_e = enc > 0.f ? 1.f : 0.f;
+            const float de_pe = pos_e * (pe >= te ? 1.f : 0.f), de_ps = -pos_e * (ps <= ts ? 1.f : 0.f);
+            // giou = inter/uni - (enc - uni)/enc = inter/uni - 1 + uni/enc
+            const float dg_pe = (di_pe * uni - inter * du_pe) / (uni * uni) + (du_pe * enc - uni * de_pe) / (enc * enc);
+            const float dg_ps = (di_ps * uni - inter * du_ps) / (uni * uni) + (du_ps * enc - uni * de_ps) / (enc * enc);
+            const float wg = -up * weights[1] / npairs;
+            dc += wg * (dg_pe + dg_ps);
+            dw += wg * 0.5f * (dg_pe - dg_ps);
+            dsp[(b * Q + q) * 2] = dc;
+            dsp[(b * Q + q) * 2 + 1] = dw;
+            matched[b * Q + q] = 1;
+        }
+    }
+    __syncthreads();
+    // weighted NLL, plain mean over B*Q
+    for (int i = tid; i < B * Q; i += CRIT_THREADS) {
+        int cls = matched[i] ? fg : bg;
+        float l0 = lg[i * 2], l1 = lg[i * 2 + 1];
+        float mx = fmaxf(l0, l1);
+        float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        const float w = up * weights[2] * empty_w[cls] / (float)(B * Q);
+        dlg[i * 2] = w * (p0 - (cls == 0 ? 1.f : 0.f));
+        dlg[i * 2 + 1] = w * (p1 - (cls == 1 ? 1.f : 0.f));
+    }
+    if (proj_q && vid_sum && dproj_q && dvid_sum) {
+        for (int i = wave; i < B * Q; i += CRIT_THREADS / 64) {
+            int b = i / Q;
+            const float* pq = proj_q + ((int64_t)l * B * Q + i) * Dc;
+            const float* vs = vid_sum + (int64_t)b * Dc;
+            float d = 0.f;
+            for (int k = lane; k < Dc; k += 64) d += pq[k] * vs[k];
+            d = wave_sum(d);
+            if (lane == 0) lgt[i] = d / temperature;
+        }
+        __syncthreads();
+        const float wc = up * weights[4] / ((float)B * temperature);
+        for (int i = wave; i < B * Q; i += CRIT_THREADS / 64) {
+            int b = i / Q;
+            float mx = -INFINITY, npos = 0.f;
+            for (int q = 0; q < Q; ++q) { mx = fmaxf(mx, lgt[b * Q + q]); npos += matched[b * Q + q] ? 1.f : 0.f; }
+            float se = 0.f;
+            for (int q = 0; q < Q; ++q) se += expf(lgt[b * Q + q] - mx);
+            const float dl = wc * (expf(lgt[i] - mx) / se - (matched[i] ? 1.f / npos : 0.f));
+            const float* pq = proj_q + ((int64_t)l * B * Q + i) * Dc;
+            const float* vs = vid_sum + (int64_t)b * Dc;
+            float* dpq = dproj_q + ((int64_t)l * B * Q + i) * Dc;
+            for (int k = lane; k < Dc; k += 64) {
+                dpq[k] = dl * vs[k];
+                unsafeAtomicAdd(dvid_sum + (int64_t)b * Dc + k, dl * pq[k]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int made_hungarian_match(const float* pred_logits, const float* pred_spans, const float* targets,
@@ -301,4 +409,20 @@ extern "C" int made_set_criterion(const float* pred_logits, const float* pred_sp
     if (rc != MADE_OK || total == nullptr) return rc;
     hipLaunchKernelGGL(criterion_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, weights, (int)n_layers, total);
     return made_check_launch("made_set_criterion(total)");
+}
+
+extern "C" int made_set_criterion_bwd(const float* pred_logits, const float* pred_spans, const float* targets,
+                                      const int64_t* pred_idx, const int64_t* tgt_idx, const int32_t* count,
+                                      const float* proj_queries, const float* vid_sum, const float* empty_weight,
+                                      int64_t n_layers, int64_t B, int64_t Q, int64_t G, int64_t Dc, int32_t fg_label,
+                                      float temperature, const float* weights, const float* upstream,
+                                      float* d_logits, float* d_spans, float* d_proj_queries, float* d_vid_sum, void* stream) {
+    MADE_REQUIRE(pred_logits && pred_spans && targets && pred_idx && tgt_idx && count && empty_weight && weights && d_logits && d_spans,
+                 "made_set_criterion_bwd: null pointer");
+    MADE_REQUIRE(n_layers >= 1 && B >= 1 && Q >= 1 && G >= 1, "made_set_criterion_bwd: bad dims");
+    MADE_UNSUPPORTED(n_layers <= 65535 && B * Q <= CRIT_MAX_BQ, "made_set_criterion_bwd: B*Q=%lld exceeds %d", (long long)(B * Q), CRIT_MAX_BQ);
+    hipLaunchKernelGGL(criterion_bwd_kernel, dim3((unsigned)n_layers), dim3(CRIT_THREADS), 0, (hipStream_t)stream, pred_logits, pred_spans,
+                       targets, pred_idx, tgt_idx, count, proj_queries, vid_sum, empty_weight, (int)B, (int)Q, (int)G, (int)Dc,
+                       (int)fg_label, temperature, weights, upstream, d_logits, d_spans, d_proj_queries, d_vid_sum);
+    return made_check_launch("made_set_criterion_bwd");
 }

@@ -1,0 +1,675 @@
+// Row kernels of the training path (HBM-bound): backward of LayerNorm, of the masked mean + L2 normalisation that
+// produces the clip-level vectors, of the row L2 normalisations, of the symmetric cross entropy, of the X-Pool tail
+// (LayerNorm3 + cosine) and of the softmax inside the wide-head attention.  One wave per row, 16-byte accesses, wave
+// shuffles for the row reductions; parameter gradients are accumulated in registers over the rows a wave owns and added
+// to the f32 gradient buffers with one atomic per column per workgroup.
+#include "common.h"
+
+namespace {
+
+constexpr int RT = 256;                    // 4 waves per workgroup
+constexpr int MAXV = 8;
+
+__device__ __forceinline__ f32x4 ld4(const void* p, int dtype, int64_t idx) {
+    f32x4 v;
+    if (dtype == MADE_F32) {
+        v = *(const f32x4*)((const float*)p + idx);
+    } else {
+        bf16x4 t = *(const bf16x4*)((const bf16_t*)p + idx);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    return v;
+}
+__device__ __forceinline__ void st4(void* p, int dtype, int64_t idx, f32x4 v) {
+    if (dtype == MADE_F32) {
+        *(f32x4*)((float*)p + idx) = v;
+    } else {
+        bf16x4 t;
+        t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+        *(bf16x4*)((bf16_t*)p + idx) = t;
+    }
+}
+__device__ __forceinline__ bool keep_at(const MadeDropout& d, uint32_t thr, uint64_t idx) {
+    return (made_rng_mix(d.seed, d.site, idx) >> 8) >= thr;
+}
+
+// combine per-wave column partials through LDS and add them to a global f32 vector
+template <int NV>
+__device__ __forceinline__ void flush_cols(float* __restrict__ dst, const f32x4* acc, int D, int lane, int wave, float* sm /* [4][NV*256] */) {
+    if (dst == nullptr) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[wave * (NV * 256) + (i * WAVE + lane) * 4 + j] = acc[i][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += RT) {
+        const float s = (sm[c] + sm[NV * 256 + c]) + (sm[2 * NV * 256 + c] + sm[3 * NV * 256 + c]);
+        unsafeAtomicAdd(dst + c, s);
+    }
+    __syncthreads();
+}
+
+// ---- LayerNorm backward ---------------------------------------------------------------------------
+//   xhat = (x - mean) * rstd,  g = dy * gamma
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ add];   dgamma += sum_rows dy * xhat;   dbeta += sum_rows dy
+struct LnBwdArgs {
+    const void* x; int xdt; int64_t ldx, rpb, xbs;
+    const float* gamma;
+    const void* dy; int dydt; int64_t lddy;
+    const void* add; int adt; int64_t ldadd;
+    void* dx; int dxdt; int64_t lddx;
+    void* dxd; int64_t lddxd; MadeDropout drop; int64_t drop_ld;
+    float* dgamma; float* dbeta;
+    int64_t rows; int D; float eps; const float* row_skip;
+};
+
+template <int NV>
+__global__ __launch_bounds__(RT) void layernorm_bwd_kernel(const LnBwdArgs a) {
+    __shared__ float sm[4 * NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
+    const int D = a.D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+        const bool skip = a.row_skip && a.row_skip[row] == 0.f;
+        const int64_t xoff = a.rpb > 0 ? (row / a.rpb) * a.xbs + (row % a.rpb) * a.ldx : row * a.ldx;
+        f32x4 xv[NV], gy[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            const int cc = c < D ? c : 0;
+            xv[i] = ld4(a.x, a.xdt, xoff + cc);
+            gy[i] = ld4(a.dy, a.dydt, row * a.lddy + cc);
+            if (c >= D || skip) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[i][j] = 0.f; gy[i][j] = 0.f; }
+            }
+            sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+        }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = xv[i][j] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + a.eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c < D) {
+                const f32x4 gm = *(const f32x4*)(a.gamma + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[i][j] - mean) * rstd;
+                    const float g = gy[i][j] * gm[j];
+                    dg[i][j] += gy[i][j] * xh;
+                    db[i][j] += gy[i][j];
+                    xv[i][j] = xh;                 // keep xhat
+                    gy[i][j] = g;                  // keep g
+                    s1 += g; s2 += g * xh;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = skip ? 0.f : rstd * (gy[i][j] - s1 - xv[i][j] * s2);
+                if (a.add && !skip) {
+                    const f32x4 ad = ld4(a.add, a.adt, row * a.ldadd + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += ad[j];
+                }
+                st4(a.dx, a.dxdt, row * a.lddx + c, o);
+                if (a.dxd) {
+                    if (a.drop.p > 0.f) {
+                        const uint64_t base = (uint64_t)row * (uint64_t)a.drop_ld + (uint64_t)c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = keep_at(a.drop, thr, base + j) ? o[j] * dsc : 0.f;
+                    }
+                    st4(a.dxd, a.dxdt, row * a.lddxd + c, o);
+                }
+            }
+        }
+    }
+    flush_cols<NV>(a.dgamma, dg, D, lane, wave, sm);
+    flush_cols<NV>(a.dbeta, db, D, lane, wave, sm);
+}
+
+// ---- clip-level vector backward: vec = normalize(masked mean(local)) --------------------------------
+//   dmean = (dvec - vhat (vhat . dvec)) / max(|mean|, eps);  out[b,t,:] = mask[b,t] * (in1 + in2 + dmean / count_b)
+struct PoolBwdArgs {
+    const float* mean; const float* dvec; const float* mask;
+    const void* in1; int in1dt; int64_t in1_bs, in1_ld;
+    const void* in2; int in2dt; int64_t in2_bs, in2_ld;
+    void* out; int odt; int64_t out_bs, out_ld;
+    int64_t B, T; int D; float eps;
+};
+
+template <int NV>
+__global__ __launch_bounds__(RT) void pool_bwd_kernel(const PoolBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.B * a.T) return;
+    const int64_t b = row / a.T, t = row % a.T;
+    const int D = a.D;
+    const bool valid = a.mask[row] != 0.f;
+    float cnt = 0.f;
+    for (int64_t j = lane; j < a.T; j += 64) cnt += a.mask[b * a.T + j];
+    cnt = wave_sum(cnt);
+    f32x4 mv[NV], gv[NV];
+    float nn = 0.f, dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * WAVE + lane) * 4;
+        const int cc = c < D ? c : 0;
+        mv[i] = *(const f32x4*)(a.mean + b * D + cc);
+        gv[i] = *(const f32x4*)(a.dvec + b * D + cc);
+        if (c >= D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mv[i][j] = 0.f; gv[i][j] = 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { nn += mv[i][j] * mv[i][j]; dot += mv[i][j] * gv[i][j]; }
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(nn)), a.eps);
+    dot = wave_sum(dot) / (nrm * nrm);                       // (vhat . dvec) / nrm
+    const float inv = 1.f / (nrm * cnt);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (gv[i][j] - mv[i][j] * dot) * inv;
+            if (a.in1) {
+                const f32x4 x = ld4(a.in1, a.in1dt, b * a.in1_bs + t * a.in1_ld + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += x[j];
+            }
+            if (a.in2) {
+                const f32x4 x = ld4(a.in2, a.in2dt, b * a.in2_bs + t * a.in2_ld + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += x[j];
+            }
+            if (!valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = 0.f;
+            }
+            st4(a.out, a.odt, b * a.out_bs + t * a.out_ld + c, o);
+        }
+    }
+}
+
+// ---- y = x / max(|x|, eps)  ->  dx = (dy - yhat (yhat . dy)) / max(|x|, eps) -------------------------------
+struct L2BwdArgs {
+    const void* x; int xdt; int64_t ldx;
+    const float* dy; int64_t lddy;
+    float* dx; int64_t lddx; int accumulate;
+    void* dxa; int adt; int64_t lddxa;
+    int64_t rows; int D; float eps;
+};
+
+template <int NV>
+__global__ __launch_bounds__(RT) void l2norm_bwd_kernel(const L2BwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int D = a.D;
+    f32x4 xv[NV], gv[NV];
+    float nn = 0.f, dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * WAVE + lane) * 4;
+        const int cc = c < D ? c : 0;
+        xv[i] = ld4(a.x, a.xdt, row * a.ldx + cc);
+        gv[i] = *(const f32x4*)(a.dy + row * a.lddy + cc);
+        if (c >= D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[i][j] = 0.f; gv[i][j] = 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { nn += xv[i][j] * xv[i][j]; dot += xv[i][j] * gv[i][j]; }
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(nn)), a.eps);
+    dot = wave_sum(dot) / (nrm * nrm);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (gv[i][j] - xv[i][j] * dot) / nrm;
+            if (a.dxa) st4(a.dxa, a.adt, row * a.lddxa + c, o);
+            if (a.dx) {
+                float* p = a.dx + row * a.lddx + c;
+                if (a.accumulate) {
+                    const f32x4 old = *(const f32x4*)p;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += old[j];
+                }
+                *(f32x4*)p = o;
+            }
+        }
+    }
+}
+
+// ---- symmetric cross entropy backward ---------------------------------------------------------------------
+// z = sims * exp(logit_scale); L = w/2 (mean_i (lse_row_i - z_ii) + mean_j (lse_col_j - z_jj))
+//   dz_ij = w/(2n) (exp(z_ij - lse_row_i) + exp(z_ij - lse_col_j) - 2 [i == j]);  dsims = dz * e^ls;  dls = sum dz z
+__global__ __launch_bounds__(RT) void clip_lse_kernel(const float* sims, int64_t ld, int n, const float* logit_scale, float* lse) {
+    const int lane = threadIdx.x & 63;
+    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);         // 0..n-1 rows, n..2n-1 columns
+    if (line >= 2 * n) return;
+    const float gsc = expf(logit_scale[0]);
+    const bool col = line >= n;
+    const int i = col ? line - n : line;
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, (col ? sims[(int64_t)j * ld + i] : sims[(int64_t)i * ld + j]) * gsc);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < n; j += 64) se += expf((col ? sims[(int64_t)j * ld + i] : sims[(int64_t)i * ld + j]) * gsc - mx);
+    se = wave_sum(se);
+    if (lane == 0) lse[line] = mx + logf(se);
+}
+
+__global__ __launch_bounds__(RT) void clip_bwd_kernel(const float* sims, int64_t ld, int n, const float* logit_scale, float weight,
+                                                      const float* upstream, const float* lse, float* dsims, float* dsims_t,
+                                                      int accumulate, float* dls) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float gsc = expf(logit_scale[0]);
+    const float w = weight * (upstream ? upstream[0] : 1.f) / (2.f * (float)n);
+    float acc = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        const float z = sims[(int64_t)i * ld + j] * gsc;
+        const float dz = w * (expf(z - lse[i]) + expf(z - lse[n + j]) - (i == j ? 2.f : 0.f));
+        acc += dz * z;
+        const float g = dz * gsc;
+        if (accumulate) {
+            dsims[(int64_t)i * n + j] += g;
+            if (dsims_t) dsims_t[(int64_t)j * n + i] += g;
+        } else {
+            dsims[(int64_t)i * n + j] = g;
+            if (dsims_t) dsims_t[(int64_t)j * n + i] = g;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && dls) unsafeAtomicAdd(dls, acc);
+}
+
+// ---- X-Pool tail backward: sims[n,m] = cos(video_n, LayerNorm3(y[m,n])) -------------------------------------------
+struct XtailBwdArgs {
+    const void* y; int ydt; int64_t ldy;
+    const float* gamma; const float* beta; const float* video; int64_t ldv;
+    const float* dsims; int64_t ldds;
+    void* dy; int dydt; int64_t lddy;
+    void* dyd; MadeDropout drop;
+    float* dgamma; float* dbeta; float* dvideo; int64_t lddv;
+    int64_t rows, Nv; int D; float eps;
+};
+
+template <int NV>
+__global__ __launch_bounds__(RT) void xpool_tail_bwd_kernel(const XtailBwdArgs a) {
+    __shared__ float sm[4 * NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D;
+    f32x4 dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t m = row / a.Nv, n = row % a.Nv;
+        f32x4 xh[NV], pv[NV], vd[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            const int cc = c < D ? c : 0;
+            xh[i] = ld4(a.y, a.ydt, row * a.ldy + cc);
+            vd[i] = *(const f32x4*)(a.video + n * a.ldv + cc);
+            if (c >= D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; vd[i][j] = 0.f; }
+            }
+            sum += (xh[i][0] + xh[i][1]) + (xh[i][2] + xh[i][3]);
+        }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = xh[i][j] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + a.eps);
+        float pp = 0.f, vv = 0.f, pdv = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c < D) {
+                const f32x4 gm = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (xh[i][j] - mean) * rstd;
+                    pv[i][j] = xh[i][j] * gm[j] + bt[j];
+                    pp += pv[i][j] * pv[i][j]; vv += vd[i][j] * vd[i][j]; pdv += pv[i][j] * vd[i][j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[i][j] = 0.f;
+            }
+        }
+        const float np = sqrtf(wave_sum(pp)), nvn = sqrtf(wave_sum(vv));
+        const float sim = wave_sum(pdv) / (np * nvn);
+        const float ds = a.dsims[n * a.ldds + m];
+        // dp = ds * (vhat - sim * phat) / |p| ;  dvideo_n += ds * (phat - sim * vhat) / |v|
+        float s1 = 0.f, s2 = 0.f;
+        f32x4 g[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c < D) {
+                const f32x4 gm = *(const f32x4*)(a.gamma + c);
+                f32x4 dvd;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float ph = pv[i][j] / np, vh = vd[i][j] / nvn;
+                    const float dp = ds * (vh - sim * ph) / np;
+                    dvd[j] = ds * (ph - sim * vh) / nvn;
+                    dg[i][j] += dp * xh[i][j];
+                    db[i][j] += dp;
+                    g[i][j] = dp * gm[j];
+                    s1 += g[i][j]; s2 += g[i][j] * xh[i][j];
+                }
+                if (a.dvideo) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(a.dvideo + n * a.lddv + c + j, dvd[j]);
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+                st4(a.dy, a.dydt, row * a.lddy + c, o);
+                if (a.dyd) {
+                    if (a.drop.p > 0.f) {
+                        const uint64_t base = (uint64_t)row * (uint64_t)D + (uint64_t)c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = keep_at(a.drop, thr, base + j) ? o[j] * dsc : 0.f;
+                    }
+                    st4(a.dyd, a.dydt, row * a.lddy + c, o);
+                }
+            }
+        }
+    }
+    flush_cols<NV>(a.dgamma, dg, D, lane, wave, sm);
+    flush_cols<NV>(a.dbeta, db, D, lane, wave, sm);
+}
+
+// ---- softmax backward of the wide-head attention (scores materialised: [rows, L] with few rows per batch) ---------
+//   P = softmax(scale * S + mask);  Pd = dropout(P);  dP = dropout'(dPd + extra);  dS = scale * P * (dP - sum_k P_k dP_k)
+// Outputs in the compute dtype: Pd [rows, ldo], dS [rows, ldo] and dS^T [batch, L, ldt] (rows of one batch along ldt).
+// Columns L .. ldo-1 of Pd / dS are written as zeros (the TN products read whole 16-byte chunks).
+struct SmBwdArgs {
+    const float* S; int64_t lds_; const float* dP; int64_t lddp;
+    const float* mask; int64_t rows_per_mask;            // mask row = row / rows_per_mask
+    const float* extra; float scale; MadeDropout drop;
+    void* Pd; void* dS; void* dSt; int odt; int64_t ldo, ldt;
+    int64_t rows, rpb, L;
+};
+
+__global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* s = a.S + row * a.lds_;
+    const float* g = a.dP + row * a.lddp;
+    const float* mk = a.mask ? a.mask + (row / a.rows_per_mask) * a.L : nullptr;
+    const float ex = a.extra ? a.extra[row] : 0.f;
+    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
+    const uint64_t base = (uint64_t)row * (uint64_t)a.L;
+    float mx = -INFINITY;
+    for (int64_t k = lane; k < a.L; k += 64) {
+        const bool ok = mk == nullptr || mk[k] != 0.f;
+        mx = fmaxf(mx, ok ? s[k] * a.scale : -INFINITY);
+    }
+    mx = wave_max(mx);
+    float se = 0.f, dot = 0.f;
+    for (int64_t k = lane; k < a.L; k += 64) {
+        const bool ok = mk == nullptr || mk[k] != 0.f;
+        const float p = ok ? expf(s[k] * a.scale - mx) : 0.f;
+        float dp = g[k] + ex;
+        if (a.drop.p > 0.f) dp = keep_at(a.drop, thr, base + (uint64_t)k) ? dp * dsc : 0.f;
+        se += p; dot += p * dp;
+    }
+    se = wave_sum(se); dot = wave_sum(dot);
+    const float inv = 1.f / se;
+    dot *= inv;
+    const int64_t z = row / a.rpb, i = row % a.rpb;
+    for (int64_t k = lane; k < a.ldo; k += 64) {
+        float pd = 0.f, ds = 0.f;
+        if (k < a.L) {
+            const bool ok = mk == nullptr || mk[k] != 0.f;
+            const float p = ok ? expf(s[k] * a.scale - mx) * inv : 0.f;
+            float dp = g[k] + ex;
+            pd = p;
+            if (a.drop.p > 0.f) {
+                const bool kp = keep_at(a.drop, thr, base + (uint64_t)k);
+                dp = kp ? dp * dsc : 0.f;
+                pd = kp ? p * dsc : 0.f;
+            }
+            ds = a.scale * p * (dp - dot);
+        }
+        store_from_f32(a.Pd, a.odt, row * a.ldo + k, pd);
+        store_from_f32(a.dS, a.odt, row * a.ldo + k, ds);
+        if (a.dSt && k < a.L) store_from_f32(a.dSt, a.odt, (z * a.L + k) * a.ldt + i, ds);
+    }
+}
+
+// ---- out[row, h*hd + j] (+)= s[row, h] * bias[h*hd + j]  (the value bias of the memory-space cross-attention under dropout)
+__global__ void head_bias_kernel(void* x, int xdt, int64_t ldx, const float* s, const float* bias, int64_t rows, int H, int hd) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * H * hd) return;
+    const int64_t row = idx / (H * hd);
+    const int c = (int)(idx % (H * hd));
+    const float v = load_as_f32(x, xdt, row * ldx + c) + s[row * H + c / hd] * bias[c];
+    store_from_f32(x, xdt, row * ldx + c, v);
+}
+// backward: dbias[c] += sum_rows s[row,h] * dy[row,c];  ds[row,h] = sum_j dy[row, h*hd+j] * bias[h*hd+j]
+__global__ __launch_bounds__(RT) void head_bias_bwd_kernel(const void* dy, int dt, int64_t ld, const float* s, const float* bias,
+                                                           float* dbias, float* ds, int64_t rows, int H, int hd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);         // (row, h)
+    if (rh >= rows * H) return;
+    const int64_t row = rh / H;
+    const int h = (int)(rh % H);
+    float acc = 0.f;
+    for (int j = lane; j < hd; j += 64) {
+        const float g = load_as_f32(dy, dt, row * ld + h * hd + j);
+        acc += g * bias[h * hd + j];
+        unsafeAtomicAdd(dbias + h * hd + j, g * s[rh]);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) ds[rh] = acc;
+}
+
+// ---- out = a + b (+ c), any mix of f32 / bf16, contiguous [n] ------------------------------------------------------
+__global__ void add3_kernel(void* out, int odt, const void* a, int adt, const void* b, int bdt, const void* c, int cdt, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = load_as_f32(a, adt, i);
+    if (b) v += load_as_f32(b, bdt, i);
+    if (c) v += load_as_f32(c, cdt, i);
+    store_from_f32(out, odt, i, v);
+}
+
+inline unsigned blocks4(int64_t rows) { return (unsigned)((rows + 3) / 4); }
+inline int nv_of(int64_t D) { return D <= 512 ? 2 : (D <= 1024 ? 4 : 8); }
+
+#define DISPATCH_NVB(D, CALL)                                       \
+    switch (nv_of(D)) {                                             \
+        case 2: { constexpr int NV = 2; CALL; } break;              \
+        case 4: { constexpr int NV = 4; CALL; } break;              \
+        default: { constexpr int NV = 8; CALL; } break;             \
+    }
+
+}  // namespace
+
+extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
+                                  const float* gamma, const void* dy, int32_t dy_dtype, int64_t lddy,
+                                  const void* add, int32_t add_dtype, int64_t ld_add,
+                                  void* dx, int32_t dx_dtype, int64_t lddx,
+                                  void* dx_drop, int64_t lddxd, const MadeDropout* drop, int64_t drop_ld,
+                                  float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, const float* row_skip,
+                                  void* stream) {
+    MADE_REQUIRE(x && gamma && dy && dx, "made_layernorm_bwd: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "made_layernorm_bwd: D=%lld must be a multiple of 4 and <= %d", (long long)D, 64 * 4 * MAXV);
+    MADE_UNSUPPORTED(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ld_add % 4 == 0 && lddxd % 4 == 0 && x_batch_stride % 4 == 0,
+                     "made_layernorm_bwd: row strides must be multiples of 4");
+    if (rows <= 0) return MADE_OK;
+    LnBwdArgs a;
+    a.x = x; a.xdt = x_dtype; a.ldx = ldx; a.rpb = x_rows_per_batch; a.xbs = x_batch_stride;
+    a.gamma = gamma; a.dy = dy; a.dydt = dy_dtype; a.lddy = lddy;
+    a.add = add; a.adt = add_dtype; a.ldadd = ld_add;
+    a.dx = dx; a.dxdt = dx_dtype; a.lddx = lddx;
+    a.dxd = dx_drop; a.lddxd = lddxd;
+    a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f;
+    if (drop) a.drop = *drop;
+    a.drop_ld = drop_ld > 0 ? drop_ld : D;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.rows = rows; a.D = (int)D; a.eps = eps; a.row_skip = row_skip;
+    int64_t nb = (rows + 3) / 4;
+    if (nb > 1024) nb = 1024;                                   // each workgroup flushes 2*D atomics
+    DISPATCH_NVB(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a));
+    return made_check_launch("made_layernorm_bwd");
+}
+
+extern "C" int made_pool_bwd(const float* mean, const float* dvec, const float* mask,
+                             const void* in1, int32_t in1_dtype, int64_t in1_bs, int64_t in1_ld,
+                             const void* in2, int32_t in2_dtype, int64_t in2_bs, int64_t in2_ld,
+                             void* out, int32_t out_dtype, int64_t out_bs, int64_t out_ld,
+                             int64_t B, int64_t T, int64_t D, float eps, void* stream) {
+    MADE_REQUIRE(mean && dvec && mask && out, "made_pool_bwd: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV && in1_ld % 4 == 0 && in2_ld % 4 == 0 && out_ld % 4 == 0 &&
+                     in1_bs % 4 == 0 && in2_bs % 4 == 0 && out_bs % 4 == 0, "made_pool_bwd: bad D/strides");
+    if (B * T <= 0) return MADE_OK;
+    PoolBwdArgs a{mean, dvec, mask, in1, in1_dtype, in1_bs, in1_ld, in2, in2_dtype, in2_bs, in2_ld, out, out_dtype, out_bs, out_ld, B, T, (int)D, eps};
+    DISPATCH_NVB(D, hipLaunchKernelGGL((pool_bwd_kernel<NV>), dim3(blocks4(B * T)), dim3(RT), 0, (hipStream_t)stream, a));
+    return made_check_launch("made_pool_bwd");
+}
+
+extern "C" int made_l2norm_bwd(const void* x, int32_t x_dtype, int64_t ldx, const float* dy, int64_t lddy,
+                               float* dx, int64_t lddx, int32_t accumulate, void* dx_alt, int32_t alt_dtype, int64_t lddxa,
+                               int64_t rows, int64_t D, float eps, void* stream) {
+    MADE_REQUIRE(x && dy && (dx || dx_alt), "made_l2norm_bwd: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddxa % 4 == 0,
+                     "made_l2norm_bwd: bad D/strides");
+    if (rows <= 0) return MADE_OK;
+    L2BwdArgs a{x, x_dtype, ldx, dy, lddy, dx, lddx, accumulate, dx_alt, alt_dtype, lddxa, rows, (int)D, eps};
+    DISPATCH_NVB(D, hipLaunchKernelGGL((l2norm_bwd_kernel<NV>), dim3(blocks4(rows)), dim3(RT), 0, (hipStream_t)stream, a));
+    return made_check_launch("made_l2norm_bwd");
+}
+
+extern "C" int made_clip_loss_bwd(const float* sims, int64_t ld, int64_t n, const float* logit_scale, float weight,
+                                  const float* upstream, float* lse_ws, float* dsims, float* dsims_t, int32_t accumulate,
+                                  float* d_logit_scale, void* stream) {
+    MADE_REQUIRE(sims && logit_scale && lse_ws && dsims, "made_clip_loss_bwd: null pointer");
+    MADE_REQUIRE(n > 0 && n <= (1 << 20) && ld >= n, "made_clip_loss_bwd: n=%lld out of range", (long long)n);
+    hipLaunchKernelGGL(clip_lse_kernel, dim3(blocks4(2 * n)), dim3(RT), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale, lse_ws);
+    hipLaunchKernelGGL(clip_bwd_kernel, dim3(blocks4(n)), dim3(RT), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale, weight,
+                       upstream, lse_ws, dsims, dsims_t, accumulate, d_logit_scale);
+    return made_check_launch("made_clip_loss_bwd");
+}
+
+extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, const float* gamma, const float* beta,
+                                   const float* video, int64_t ld_video, const float* dsims, int64_t ld_dsims,
+                                   void* dy, int32_t dy_dtype, int64_t lddy, void* dy_drop, const MadeDropout* drop,
+                                   float* dgamma, float* dbeta, float* dvideo, int64_t ld_dvideo,
+                                   int64_t Nm, int64_t Nv, int64_t D, float eps, void* stream) {
+    MADE_REQUIRE(y && gamma && beta && video && dsims && dy, "made_xpool_tail_bwd: null pointer");
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV && ldy % 4 == 0 && ld_video % 4 == 0 && lddy % 4 == 0,
+                     "made_xpool_tail_bwd: bad D/strides");
+    const int64_t rows = Nm * Nv;
+    if (rows <= 0) return MADE_OK;
+    XtailBwdArgs a;
+    a.y = y; a.ydt = y_dtype; a.ldy = ldy; a.gamma = gamma; a.beta = beta; a.video = video; a.ldv = ld_video;
+    a.dsims = dsims; a.ldds = ld_dsims; a.dy = dy; a.dydt = dy_dtype; a.lddy = lddy; a.dyd = dy_drop;
+    a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f;
+    if (drop) a.drop = *drop;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.dvideo = dvideo; a.lddv = ld_dvideo;
+    a.rows = rows; a.Nv = Nv; a.D = (int)D; a.eps = eps;
+    int64_t nb = (rows + 3) / 4;
+    if (nb > 1024) nb = 1024;
+    DISPATCH_NVB(D, hipLaunchKernelGGL((xpool_tail_bwd_kernel<NV>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a));
+    return made_check_launch("made_xpool_tail_bwd");
+}
+
+extern "C" int made_softmax_bwd(const float* S, int64_t ld_s, const float* dP, int64_t ld_dp, const float* mask,
+                                int64_t rows_per_mask, const float* extra, float scale, const MadeDropout* drop,
+                                void* Pd, void* dS, void* dSt, int32_t out_dtype, int64_t ldo, int64_t ldt,
+                                int64_t rows, int64_t rows_per_batch, int64_t L, void* stream) {
+    MADE_REQUIRE(S && dP && Pd && dS, "made_softmax_bwd: null pointer");
+    MADE_REQUIRE(rows >= 0 && L > 0 && ldo >= L && rows_per_batch > 0 && rows_per_mask > 0, "made_softmax_bwd: bad dims");
+    MADE_REQUIRE(dSt == nullptr || ldt >= rows_per_batch, "made_softmax_bwd: ldt too small");
+    if (rows == 0) return MADE_OK;
+    SmBwdArgs a;
+    a.S = S; a.lds_ = ld_s; a.dP = dP; a.lddp = ld_dp; a.mask = mask; a.rows_per_mask = rows_per_mask; a.extra = extra;
+    a.scale = scale; a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f;
+    if (drop) a.drop = *drop;
+    a.Pd = Pd; a.dS = dS; a.dSt = dSt; a.odt = out_dtype; a.ldo = ldo; a.ldt = ldt; a.rows = rows; a.rpb = rows_per_batch; a.L = L;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(blocks4(rows)), dim3(RT), 0, (hipStream_t)stream, a);
+    return made_check_launch("made_softmax_bwd");
+}
+
+extern "C" int made_head_bias(void* x, int32_t x_dtype, int64_t ldx, const float* s, const float* bias,
+                              int64_t rows, int64_t H, int64_t hd, void* stream) {
+    MADE_REQUIRE(x && s && bias && H > 0 && hd > 0, "made_head_bias: bad arguments");
+    const int64_t n = rows * H * hd;
+    if (n <= 0) return MADE_OK;
+    hipLaunchKernelGGL(head_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, ldx, s, bias, rows, (int)H, (int)hd);
+    return made_check_launch("made_head_bias");
+}
+
+extern "C" int made_head_bias_bwd(const void* dy, int32_t dtype, int64_t ld, const float* s, const float* bias,
+                                  float* dbias, float* ds, int64_t rows, int64_t H, int64_t hd, void* stream) {
+    MADE_REQUIRE(dy && s && bias && dbias && ds && H > 0 && hd > 0, "made_head_bias_bwd: bad arguments");
+    if (rows <= 0) return MADE_OK;
+    hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(blocks4(rows * H)), dim3(RT), 0, (hipStream_t)stream, dy, dtype, ld, s, bias, dbias, ds, rows, (int)H, (int)hd);
+    return made_check_launch("made_head_bias_bwd");
+}
+
+extern "C" int made_add3(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, const void* b, int32_t b_dtype,
+                         const void* c, int32_t c_dtype, int64_t n, void* stream) {
+    MADE_REQUIRE(out && a, "made_add3: null pointer");
+    if (n <= 0) return MADE_OK;
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, out_dtype, a, a_dtype, b, b_dtype, c, c_dtype, n);
+    return made_check_launch("made_add3");
+}

@@ -89,3 +89,111 @@ def attention_bwd(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, dO: Tensor, dQ: Te
     flops = 10.0 * B * H * Lq * a.Lk * hd * 1.4          # 7 products of 2*Lq*Lk*hd
     _timed("made_attention_bwd", flops, float(Q.element_size() * B * D * (4 * Lq + 4 * a.Lk)),
            lambda: check(lib().made_attention_bwd(C.byref(a), _stream()), "made_attention_bwd"), f"B={B} H={H} hd={hd} Lq={Lq} Lk={a.Lk}")
+
+
+def _drop_ptr(drop):
+    if drop is None or drop[2] <= 0.0:
+        return None
+    return C.byref(dropout_desc(*drop))
+
+
+def _dt(t: Optional[Tensor]) -> int:
+    return dt_of(t) if t is not None else F32
+
+
+def layernorm_bwd(x: Tensor, gamma: Tensor, dy: Tensor, dx: Tensor, *, dgamma: Optional[Tensor], dbeta: Optional[Tensor],
+                  add: Optional[Tensor] = None, dx_drop: Optional[Tensor] = None, drop=None, drop_ld: int = 0,
+                  row_skip: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+    """dx = LN'(dy) (+ add); dx_drop = dropout(dx); dgamma / dbeta accumulated.  x may be a [B,T,D] view (batch stride)."""
+    if x.dim() == 3:
+        rpb, xbs, ldx = x.shape[1], x.stride(0), x.stride(1)
+        rows, D = x.shape[0] * x.shape[1], x.shape[2]
+    else:
+        rpb, xbs, ldx = 0, 0, x.stride(0)
+        rows, D = x.shape
+    assert dy.dim() == 2 and dx.dim() == 2 and dy.shape[0] == rows and dx.shape[0] == rows
+    check(lib().made_layernorm_bwd(_p(x), dt_of(x), ldx, rpb, xbs, _p(_f32(gamma, "gamma")), _p(dy), dt_of(dy), dy.stride(0),
+                                   _p(add), _dt(add), add.stride(0) if add is not None else 0,
+                                   _p(dx), dt_of(dx), dx.stride(0),
+                                   _p(dx_drop), dx_drop.stride(0) if dx_drop is not None else 0, _drop_ptr(drop), drop_ld,
+                                   _p(_f32(dgamma, "dgamma")), _p(_f32(dbeta, "dbeta")), rows, D, eps,
+                                   _p(_f32(row_skip, "row_skip")), _stream()), "made_layernorm_bwd")
+    return dx
+
+
+def pool_bwd(mean: Tensor, dvec: Tensor, mask: Tensor, out: Tensor, in1: Optional[Tensor] = None, in2: Optional[Tensor] = None,
+             eps: float = 1e-12) -> Tensor:
+    """out[b,t,:] = mask * (in1 + in2 + d masked-mean / normalise); in1 / in2 / out are [B,T,D] views."""
+    B, T, D = out.shape
+    def bs(t): return (t.stride(0), t.stride(1)) if t is not None else (0, 0)
+    check(lib().made_pool_bwd(_p(_f32(mean, "mean")), _p(_f32(dvec, "dvec")), _p(_f32(mask, "mask")),
+                              _p(in1), _dt(in1), *bs(in1), _p(in2), _dt(in2), *bs(in2),
+                              _p(out), dt_of(out), *bs(out), B, T, D, eps, _stream()), "made_pool_bwd")
+    return out
+
+
+def l2norm_bwd(x: Tensor, dy: Tensor, dx: Optional[Tensor] = None, *, accumulate: bool = False, dx_alt: Optional[Tensor] = None,
+               eps: float = 1e-12) -> None:
+    rows, D = x.shape
+    check(lib().made_l2norm_bwd(_p(x), dt_of(x), x.stride(0), _p(_f32(dy, "dy")), dy.stride(0),
+                                _p(dx), dx.stride(0) if dx is not None else 0, int(accumulate),
+                                _p(dx_alt), _dt(dx_alt), dx_alt.stride(0) if dx_alt is not None else 0,
+                                rows, D, eps, _stream()), "made_l2norm_bwd")
+
+
+def clip_loss_bwd(sims: Tensor, logit_scale: Tensor, weight: float, upstream: Optional[Tensor], lse_ws: Tensor, dsims: Tensor,
+                  dsims_t: Optional[Tensor], d_logit_scale: Optional[Tensor], accumulate: bool = False) -> None:
+    n = sims.shape[0]
+    assert lse_ws.numel() >= 2 * n and dsims.is_contiguous()
+    check(lib().made_clip_loss_bwd(_p(_f32(sims, "sims")), sims.stride(0), n, _p(logit_scale), float(weight), _p(upstream),
+                                   _p(lse_ws), _p(dsims), _p(dsims_t), int(accumulate), _p(d_logit_scale), _stream()),
+          "made_clip_loss_bwd")
+
+
+def xpool_tail_bwd(y: Tensor, gamma: Tensor, beta: Tensor, video: Tensor, dsims: Tensor, dy: Tensor, Nm: int, Nv: int, *,
+                   dy_drop: Optional[Tensor] = None, drop=None, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
+                   dvideo: Optional[Tensor] = None, eps: float = 1e-5) -> None:
+    D = y.shape[1]
+    check(lib().made_xpool_tail_bwd(_p(y), dt_of(y), y.stride(0), _p(gamma), _p(beta), _p(_f32(video, "video")), video.stride(0),
+                                    _p(_f32(dsims, "dsims")), dsims.stride(0), _p(dy), dt_of(dy), dy.stride(0), _p(dy_drop),
+                                    _drop_ptr(drop), _p(dgamma), _p(dbeta), _p(dvideo), dvideo.stride(0) if dvideo is not None else 0,
+                                    Nm, Nv, D, eps, _stream()), "made_xpool_tail_bwd")
+
+
+def softmax_bwd(S: Tensor, dP: Tensor, mask: Optional[Tensor], rows_per_mask: int, scale: float, Pd: Tensor, dS: Tensor,
+                dSt: Optional[Tensor], rows_per_batch: int, L: int, *, extra: Optional[Tensor] = None, drop=None,
+                ldt: int = 0) -> None:
+    rows = S.shape[0]
+    check(lib().made_softmax_bwd(_p(_f32(S, "S")), S.stride(0), _p(dP), dP.stride(0), _p(mask), rows_per_mask,
+                                 _p(extra), float(scale), _drop_ptr(drop), _p(Pd), _p(dS), _p(dSt), dt_of(Pd), Pd.stride(0),
+                                 ldt, rows, rows_per_batch, L, _stream()), "made_softmax_bwd")
+
+
+def head_bias(x: Tensor, s: Tensor, bias: Tensor, H: int) -> None:
+    rows, D = x.shape
+    check(lib().made_head_bias(_p(x), dt_of(x), x.stride(0), _p(_f32(s, "s")), _p(bias), rows, H, D // H, _stream()), "made_head_bias")
+
+
+def head_bias_bwd(dy: Tensor, s: Tensor, bias: Tensor, dbias: Tensor, ds: Tensor, H: int) -> None:
+    rows, D = dy.shape
+    check(lib().made_head_bias_bwd(_p(dy), dt_of(dy), dy.stride(0), _p(_f32(s, "s")), _p(bias), _p(dbias), _p(ds), rows, H, D // H,
+                                   _stream()), "made_head_bias_bwd")
+
+
+def add3(out: Tensor, a: Tensor, b: Optional[Tensor] = None, c: Optional[Tensor] = None) -> Tensor:
+    for t in (out, a, b, c):
+        assert t is None or t.is_contiguous()
+    check(lib().made_add3(_p(out), dt_of(out), _p(a), dt_of(a), _p(b), _dt(b), _p(c), _dt(c), out.numel(), _stream()), "made_add3")
+    return out
+
+
+def set_criterion_bwd(logits: Tensor, spans: Tensor, targets: Tensor, pi: Tensor, ti: Tensor, cnt: Tensor, pq: Optional[Tensor],
+                      vid_sum: Optional[Tensor], empty_weight: Tensor, fg: int, weights: Tensor, upstream: Optional[Tensor],
+                      d_logits: Tensor, d_spans: Tensor, d_pq: Optional[Tensor], d_vid_sum: Optional[Tensor],
+                      temperature: float = 0.07) -> None:
+    nd, B, Q, _ = logits.shape
+    G = targets.shape[1]
+    Dc = pq.shape[-1] if pq is not None else 0
+    check(lib().made_set_criterion_bwd(_p(logits), _p(spans), _p(targets), _p(pi), _p(ti), _p(cnt), _p(pq), _p(vid_sum),
+                                       _p(empty_weight), nd, B, Q, G, Dc, fg, temperature, _p(weights), _p(upstream),
+                                       _p(d_logits), _p(d_spans), _p(d_pq), _p(d_vid_sum), _stream()), "made_set_criterion_bwd")

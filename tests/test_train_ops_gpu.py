@@ -175,3 +175,186 @@ def test_attention_forward_dropout_lse_and_backward(T, dtype, tol, B, H, hd, Lq,
         assert torch.isfinite(got).all(), name
         err = float((got - ref).abs().max())
         assert err <= tol * max(float(ref.abs().max()), 0.05 * gscale) * 2, (name, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("rows,D", [(1000, 512), (333, 256), (64, 1024)])
+def test_layernorm_bwd(T, dtype, tol, rows, D):
+    ops, tr = T
+    x, dy, add = _rand(rows, D, dtype=dtype, seed=1), _rand(rows, D, dtype=dtype, seed=2), _rand(rows, D, dtype=dtype, seed=3)
+    gamma = _rand(D, dtype=torch.float32, seed=4) * 0.3 + 1.0
+    skip = (torch.rand(rows, device="cuda") > 0.2).float()
+    xr = x.float().clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = torch.zeros(D, device="cuda", requires_grad=True)
+    y = torch.nn.functional.layer_norm(xr, (D,), gr, br)
+    (y * dy.float() * skip[:, None]).sum().backward()
+    seed, site, p = 5, 6, 0.25
+    dx = torch.empty(rows, D, device="cuda", dtype=dtype)
+    dxd = torch.empty(rows, D, device="cuda", dtype=dtype)
+    dg, db = torch.ones(D, device="cuda"), torch.ones(D, device="cuda")
+    tr.layernorm_bwd(x, gamma, dy, dx, dgamma=dg, dbeta=db, add=add, dx_drop=dxd, drop=(seed, site, p), row_skip=skip)
+    ref = xr.grad + add.float() * skip[:, None]
+    sc = float(ref.abs().max())
+    assert float((dx.float() - ref).abs().max()) <= tol * sc
+    keep = _keep(seed, site, p, (rows, D)).float()
+    assert float((dxd.float() - ref * keep / (1 - p)).abs().max()) <= tol * sc / (1 - p)
+    assert float((dg - 1 - gr.grad).abs().max()) <= tol * float(gr.grad.abs().max()) * 2
+    assert float((db - 1 - br.grad).abs().max()) <= tol * float(br.grad.abs().max()) * 2
+
+
+def test_pool_and_l2norm_bwd(T):
+    ops, tr = T
+    B, Tn, D = 5, 37, 256
+    local = _rand(B, Tn, D, dtype=torch.float32, seed=1).requires_grad_(True)
+    lens = torch.tensor([37, 20, 5, 1, 30], device="cuda")
+    mask = (torch.arange(Tn, device="cuda")[None] < lens[:, None]).float()
+    mean = (local * mask[:, :, None]).sum(1) / mask.sum(1, keepdim=True)
+    vec = torch.nn.functional.normalize(mean, dim=-1)
+    dvec = _rand(B, D, dtype=torch.float32, seed=2)
+    in1 = _rand(B, Tn, D, dtype=torch.float32, seed=3)
+    in2 = _rand(B, Tn + 3, D, dtype=torch.bfloat16, seed=4)[:, 3:]
+    (vec * dvec).sum().backward()
+    out = torch.empty(B, Tn, D, device="cuda")
+    tr.pool_bwd(mean.detach().contiguous(), dvec, mask, out, in1=in1, in2=in2)
+    ref = (local.grad + in1 + in2.float()) * mask[:, :, None]
+    assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # row L2 normalisation
+    x = _rand(50, D, dtype=torch.float32, seed=5).requires_grad_(True)
+    dy = _rand(50, D, dtype=torch.float32, seed=6)
+    (torch.nn.functional.normalize(x, dim=-1) * dy).sum().backward()
+    dx = torch.ones(50, D, device="cuda")
+    alt = torch.empty(50, D, device="cuda", dtype=torch.bfloat16)
+    tr.l2norm_bwd(x.detach(), dy, dx, accumulate=True, dx_alt=alt)
+    assert float((dx - 1 - x.grad).abs().max()) <= 1e-5 * float(x.grad.abs().max())
+    assert float((alt.float() - x.grad).abs().max()) <= 1e-2 * float(x.grad.abs().max())
+
+
+def test_clip_loss_bwd(T):
+    ops, tr = T
+    n = 70
+    sims = (_rand(n, n, dtype=torch.float32, seed=1) * 0.3).requires_grad_(True)
+    ls = torch.tensor([3.5], device="cuda", requires_grad=True)
+    z = sims * ls.exp()
+    loss = 0.5 * (-torch.diagonal(torch.log_softmax(z, 1)).mean() - torch.diagonal(torch.log_softmax(z, 0)).mean())
+    up = torch.tensor([0.7], device="cuda")
+    (loss * 1.3 * up).backward()
+    ws = torch.empty(2 * n, device="cuda")
+    d, dt_ = torch.empty(n, n, device="cuda"), torch.empty(n, n, device="cuda")
+    dls = torch.zeros(1, device="cuda")
+    tr.clip_loss_bwd(sims.detach(), ls.detach(), 1.3, up, ws, d, dt_, dls)
+    assert float((d - sims.grad).abs().max()) <= 2e-5 * float(sims.grad.abs().max())
+    assert float((dt_ - sims.grad.t()).abs().max()) <= 2e-5 * float(sims.grad.abs().max())
+    assert abs(float(dls) - float(ls.grad)) <= 1e-4 * abs(float(ls.grad))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 2e-2)])
+def test_xpool_tail_bwd(T, dtype, tol):
+    ops, tr = T
+    Nm, Nv, D = 6, 9, 256
+    y = _rand(Nm * Nv, D, dtype=dtype, seed=1)
+    gamma = _rand(D, dtype=torch.float32, seed=2) * 0.2 + 1
+    beta = _rand(D, dtype=torch.float32, seed=3) * 0.1
+    video = _rand(Nv, D, dtype=torch.float32, seed=4)
+    dsims = _rand(Nv, Nm, dtype=torch.float32, seed=5)
+    yr, gr, br, vr = [t.float().clone().requires_grad_(True) for t in (y, gamma, beta, video)]
+    p_ = torch.nn.functional.layer_norm(yr, (D,), gr, br).view(Nm, Nv, D)
+    sims = torch.einsum("nd,mnd->nm", vr / vr.norm(dim=-1, keepdim=True), p_ / p_.norm(dim=-1, keepdim=True))
+    (sims * dsims).sum().backward()
+    dy = torch.empty(Nm * Nv, D, device="cuda", dtype=dtype)
+    dyd = torch.empty_like(dy)
+    dg, db, dv = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(Nv, D, device="cuda")
+    tr.xpool_tail_bwd(y, gamma, beta, video, dsims, dy, Nm, Nv, dy_drop=dyd, drop=(3, 4, 0.3), dgamma=dg, dbeta=db, dvideo=dv)
+    sc = float(yr.grad.abs().max())
+    assert float((dy.float() - yr.grad).abs().max()) <= tol * sc
+    keep = _keep(3, 4, 0.3, (Nm * Nv, D)).float()
+    assert float((dyd.float() - yr.grad * keep / 0.7).abs().max()) <= tol * sc / 0.7
+    assert float((dg - gr.grad).abs().max()) <= 1e-4 * float(gr.grad.abs().max())
+    assert float((db - br.grad).abs().max()) <= 1e-4 * float(br.grad.abs().max())
+    assert float((dv - vr.grad).abs().max()) <= 1e-4 * float(vr.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_softmax_bwd_rows(T, dtype, tol):
+    ops, tr = T
+    Z, rpb, L = 5, 8, 77
+    ldo = 80
+    S = _rand(Z * rpb, L, dtype=torch.float32, seed=1)
+    dPd = _rand(Z * rpb, L, dtype=torch.float32, seed=2)
+    extra = _rand(Z * rpb, dtype=torch.float32, seed=3)
+    lens = torch.tensor([77, 40, 9, 60, 1], device="cuda")
+    mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).float()
+    scale, p, seed, site = 0.37, 0.2, 8, 9
+    keep = _keep(seed, site, p, (Z * rpb, L)).float()
+    Sr = S.clone().requires_grad_(True)
+    logits = (Sr * scale).masked_fill((mask == 0).repeat_interleave(rpb, 0), float("-inf"))
+    Pd_ref = torch.softmax(logits, -1) * keep / (1 - p)
+    (Pd_ref * (dPd + extra[:, None])).sum().backward()
+    Pd = torch.empty(Z * rpb, ldo, device="cuda", dtype=dtype)
+    dS = torch.empty_like(Pd)
+    dSt = torch.zeros(Z, L, rpb, device="cuda", dtype=dtype)
+    tr.softmax_bwd(S, dPd, mask, rpb, scale, Pd, dS, dSt, rpb, L, extra=extra, drop=(seed, site, p), ldt=rpb)
+    assert float((Pd[:, :L].float() - Pd_ref).abs().max()) <= tol
+    assert float(Pd[:, L:].abs().max()) == 0 and float(dS[:, L:].abs().max()) == 0
+    sc = float(Sr.grad.abs().max())
+    assert float((dS[:, :L].float() - Sr.grad).abs().max()) <= tol * sc
+    assert float((dSt.float() - Sr.grad.view(Z, rpb, L).transpose(1, 2)).abs().max()) <= tol * sc
+
+
+def test_head_bias_and_add3(T):
+    ops, tr = T
+    rows, H, hd = 10, 8, 32
+    x = _rand(rows, H * hd, dtype=torch.float32, seed=1)
+    s = _rand(rows, H, dtype=torch.float32, seed=2)
+    bias = _rand(H * hd, dtype=torch.float32, seed=3)
+    ref = x + (s[:, :, None] * bias.view(H, hd)[None]).reshape(rows, -1)
+    y = x.clone()
+    tr.head_bias(y, s, bias, H)
+    assert float((y - ref).abs().max()) <= 1e-6
+    dy = _rand(rows, H * hd, dtype=torch.float32, seed=4)
+    dbias, ds = torch.zeros(H * hd, device="cuda"), torch.empty(rows, H, device="cuda")
+    tr.head_bias_bwd(dy, s, bias, dbias, ds, H)
+    assert float((dbias - (dy.view(rows, H, hd) * s[:, :, None]).sum(0).reshape(-1)).abs().max()) <= 1e-5
+    assert float((ds - (dy.view(rows, H, hd) * bias.view(1, H, hd)).sum(-1)).abs().max()) <= 1e-5
+    a, b, c = _rand(1000, dtype=torch.float32, seed=5), _rand(1000, dtype=torch.bfloat16, seed=6), _rand(1000, dtype=torch.float32, seed=7)
+    out = torch.empty(1000, device="cuda", dtype=torch.bfloat16)
+    tr.add3(out, a, b, c)
+    assert float((out.float() - (a + b.float() + c)).abs().max()) <= 3e-2
+
+
+@pytest.mark.parametrize("Q,G", [(1, 1), (3, 2), (5, 4)])
+def test_set_criterion_bwd(T, Q, G):
+    """against autograd through the oracle's criterion (same matcher indices)."""
+    ops, tr = T
+    from oracle import made_oracle as O
+    from mgsv_amd.config import cfg_native
+    cfg = cfg_native(); cfg.num_moment_queries = Q
+    nd, B, Dc = 3, 6, 64
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(nd, B, Q, 2, generator=g)
+    spans = torch.rand(nd, B, Q, 2, generator=g) * 0.5 + 0.2
+    tg = torch.rand(B, G, 2, generator=g) * 0.4 + 0.2
+    if G > 1:
+        tg[1, 1, 1] = 0.0                                              # a zero-width target is dropped
+    pq = torch.nn.functional.normalize(torch.randn(nd, B, Q, Dc, generator=g), dim=-1)
+    pv = torch.nn.functional.normalize(torch.randn(B, 7, Dc, generator=g), dim=-1)
+    P = {"criterion.empty_weight": torch.tensor([1.0, 0.1]) if cfg.foreground_label == 0 else torch.tensor([0.1, 1.0])}
+    lr, sr, pqr, pvr = [t.clone().requires_grad_(True) for t in (logits, spans, pq, pv)]
+    wd = O.criterion_weight_dict(cfg)
+    total = 0
+    for l in range(nd):
+        ld = O.set_criterion({"pred_logits": lr[l], "pred_spans": sr[l], "proj_queries": pqr[l], "proj_vid_mem": pvr}, tg, P, cfg)
+        total = total + sum(v * wd[k] for k, v in ld.items() if k in wd)
+    up = 0.9
+    (total * up).backward()
+    dev = "cuda"
+    lg, sp, tgd, pqd = logits.to(dev), spans.to(dev), tg.to(dev), pq.to(dev).contiguous()
+    vid_sum = pv.sum(1).to(dev).contiguous()
+    pi, ti, cnt, status, cost = ops.hungarian_match(lg.view(nd * B, Q, 2), sp.view(nd * B, Q, 2), tgd, cfg.foreground_label)
+    w = torch.tensor([4.0, 1.0, 0.8, 0.0, 0.2], device=dev)
+    dl, ds = torch.empty_like(lg), torch.empty_like(sp)
+    dpq, dvs = torch.empty_like(pqd), torch.zeros_like(vid_sum)
+    tr.set_criterion_bwd(lg, sp, tgd, pi, ti, cnt, pqd, vid_sum, P["criterion.empty_weight"].to(dev), cfg.foreground_label, w,
+                         torch.tensor([up], device=dev), dl, ds, dpq, dvs)
+    for name, got, ref in (("dlogits", dl, lr.grad), ("dspans", ds, sr.grad), ("dpq", dpq, pqr.grad), ("dvid_sum", dvs, pvr.grad[:, 0])):
+        assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-3), name
