@@ -66,6 +66,8 @@ MADE_HOST_DEVICE static inline uint32_t made_rng_fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
+/* keep threshold of probability p (a float32): floor(p * 2^24), evaluated exactly */
+MADE_HOST_DEVICE static inline uint32_t made_drop_threshold(float p) { return (uint32_t)((double)p * 16777216.0); }
 MADE_HOST_DEVICE static inline uint32_t made_rng_mix(uint64_t seed, uint32_t site, uint64_t idx) {
     uint32_t k = (uint32_t)seed ^ (site * 0x9E3779B9u) ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ ((uint32_t)(idx >> 32) * 0xC2B2AE35u);
     return made_rng_fmix32((uint32_t)idx ^ made_rng_fmix32(k));
@@ -221,6 +223,9 @@ typedef struct MadeWideAttnArgs {
     int64_t n_split;           /* > 1: keys are split over grid.z (few queries, long memory: fills the chip) and */
     float*  part_o;            /*      the slices are merged by a second launch; [B, n_split, NQ, D] f32 */
     float*  part_ml;           /*      [B, n_split, NQ, 2] f32 (running max, sum) */
+    /* training path (n_split must be 1) */
+    MadeDropout drop;          /* dropout on the attention weights, element index ((b*NQ1 + i1)*NQ2 + i2)*L + key */
+    float*  sum_out;           /* [B, NQ1*NQ2] f32 or NULL: sum of the dropped weights of each row (1 without dropout) */
 } MadeWideAttnArgs;
 
 int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
@@ -401,8 +406,8 @@ int made_pool_bwd(const float* mean, const float* dvec, const float* mask,
                   int64_t B, int64_t T, int64_t D, float eps, void* stream);
 
 /* made_l2norm_bwd: y = x / max(|x|, eps)  ->  dx = (dy - yhat (yhat.dy)) / max(|x|, eps); dx f32 (stored or accumulated)
- *   and/or dx_alt in another dtype.  F.normalize at reference model/model_Uni.py:142-146, cosine at modules/loss.py:52-56. */
-int made_l2norm_bwd(const void* x, int32_t x_dtype, int64_t ldx, const float* dy, int64_t lddy,
+ *   and/or dx_alt in another dtype (always the plain gradient).  dy row of x row r is r / dy_rows_per (0 or 1: one each).  F.normalize at reference model/model_Uni.py:142-146, cosine at modules/loss.py:52-56. */
+int made_l2norm_bwd(const void* x, int32_t x_dtype, int64_t ldx, const float* dy, int64_t lddy, int64_t dy_rows_per,
                     float* dx, int64_t lddx, int32_t accumulate, void* dx_alt, int32_t alt_dtype, int64_t lddxa,
                     int64_t rows, int64_t D, float eps, void* stream);
 
@@ -428,6 +433,7 @@ int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, const float
 int made_softmax_bwd(const float* S, int64_t ld_s, const float* dP, int64_t ld_dp, const float* mask, int64_t rows_per_mask,
                      const float* extra, float scale, const MadeDropout* drop,
                      void* Pd, void* dS, void* dSt, int32_t out_dtype, int64_t ldo, int64_t ldt,
+                     int64_t out_batch_stride, int64_t t_batch_stride,   /* 0: dense (rows_per_batch*ldo, L*ldt) */
                      int64_t rows, int64_t rows_per_batch, int64_t L, void* stream);
 
 /* x[row, h*hd + j] += s[row, h] * bias[h*hd + j]: the value-projection bias of the memory-space cross-attention when the
@@ -437,18 +443,24 @@ int made_head_bias(void* x, int32_t x_dtype, int64_t ldx, const float* s, const 
 int made_head_bias_bwd(const void* dy, int32_t dtype, int64_t ld, const float* s, const float* bias, float* dbias, float* ds,
                        int64_t rows, int64_t H, int64_t hd, void* stream);
 
-/* out = a + b + c over n contiguous elements (b, c may be NULL; any mix of f32 / bf16): merges gradient streams. */
+/* out = a + b + c over n contiguous elements (b, c may be NULL; any mix of f32 / bf16): merges gradient streams.
+ * b_mod > 0: b is broadcast, b[i % b_mod] (the decoder's query embedding added to every sample). */
 int made_add3(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, const void* b, int32_t b_dtype,
-              const void* c, int32_t c_dtype, int64_t n, void* stream);
+              const void* c, int32_t c_dtype, int64_t n, int64_t b_mod, void* stream);
+/* out[c] += sum over rows of x[row, c]  (f32, accumulated): gradient of a row vector that was broadcast over the rows. */
+int made_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream);
 
 /* made_set_criterion_bwd: gradients of made_set_criterion's total (times upstream[0]) w.r.t. pred_logits, pred_spans
- *   [n_layers,B,Q,2], proj_queries [n_layers,B,Q,Dc] (stored) and vid_sum [B,Dc] (accumulated). */
+ *   [n_layers,B,Q,2], proj_queries [n_layers,B,Q,Dc] (stored) and vid_sum [B,Dc] (accumulated).  d_logits / d_spans rows have
+ *   pitch ld_out >= 2 (only columns 0,1 are written: a zero-padded pitch of 8 lets the row feed made_linear as an A operand);
+ *   through_sigmoid != 0: d_spans is the gradient w.r.t. the pre-sigmoid value (pred_spans = sigmoid(z), model_Uni.py:135). */
 int made_set_criterion_bwd(const float* pred_logits, const float* pred_spans, const float* targets,
                            const int64_t* pred_idx, const int64_t* tgt_idx, const int32_t* count,
                            const float* proj_queries, const float* vid_sum, const float* empty_weight,
                            int64_t n_layers, int64_t B, int64_t Q, int64_t G, int64_t Dc, int32_t fg_label,
                            float temperature, const float* weights, const float* upstream,
-                           float* d_logits, float* d_spans, float* d_proj_queries, float* d_vid_sum, void* stream);
+                           float* d_logits, float* d_spans, int64_t ld_out, int32_t through_sigmoid,
+                           float* d_proj_queries, float* d_vid_sum, void* stream);
 
 #ifdef __cplusplus
 }

@@ -86,7 +86,7 @@ class MadeWideAttnArgs(C.Structure):
                 ("q_bs", i64), ("q_s1", i64), ("q_s2", i64), ("k_bs", i64), ("ldk", i64), ("kadd_bs", i64), ("ldkadd", i64),
                 ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("o_s1", i64), ("o_s2", i64),
                 ("scale", f32), ("_pad", i32),
-                ("n_split", i64), ("part_o", vp), ("part_ml", vp)]
+                ("n_split", i64), ("part_o", vp), ("part_ml", vp), ("drop", MadeDropout), ("sum_out", vp)]
 
 
 class MadeGemmTNArgs(C.Structure):
@@ -122,17 +122,18 @@ SIGNATURES = {
     "made_layernorm_bwd": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i64,
                                      C.POINTER(MadeDropout), i64, vp, vp, i64, i64, f32, vp, vp]),
     "made_pool_bwd": (C.c_int, [vp, vp, vp, vp, i32, i64, i64, vp, i32, i64, i64, vp, i32, i64, i64, i64, i64, i64, f32, vp]),
-    "made_l2norm_bwd": (C.c_int, [vp, i32, i64, vp, i64, vp, i64, i32, vp, i32, i64, i64, i64, f32, vp]),
+    "made_l2norm_bwd": (C.c_int, [vp, i32, i64, vp, i64, i64, vp, i64, i32, vp, i32, i64, i64, i64, f32, vp]),
     "made_clip_loss_bwd": (C.c_int, [vp, i64, i64, vp, f32, vp, vp, vp, vp, i32, vp, vp]),
     "made_xpool_tail_bwd": (C.c_int, [vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, i32, i64, vp, C.POINTER(MadeDropout),
                                       vp, vp, vp, i64, i64, i64, i64, f32, vp]),
     "made_softmax_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, f32, C.POINTER(MadeDropout), vp, vp, vp, i32, i64, i64,
-                                   i64, i64, i64, vp]),
+                                   i64, i64, i64, i64, i64, vp]),
     "made_head_bias": (C.c_int, [vp, i32, i64, vp, vp, i64, i64, i64, vp]),
     "made_head_bias_bwd": (C.c_int, [vp, i32, i64, vp, vp, vp, vp, i64, i64, i64, vp]),
-    "made_add3": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, vp]),
+    "made_add3": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, i64, vp]),
+    "made_colsum": (C.c_int, [vp, i32, i64, i64, i64, vp, vp]),
     "made_set_criterion_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp,
-                                         vp, vp, vp, vp, vp]),
+                                         vp, vp, i64, i32, vp, vp, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
     "made_set_criterion": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp, vp, vp]),
 }

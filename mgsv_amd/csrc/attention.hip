@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
 
         // ---- training: dropout on the attention weights (the row sum l keeps the undropped probabilities)
         if (a.drop.p > 0.f) {
-            const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+            const uint32_t thr = made_drop_threshold(a.drop.p);
             const float sc = 1.f / (1.f - a.drop.p);
             int64_t qq = q0 + r; qq = qq < a.Lq ? qq : a.Lq - 1;
             const uint64_t rowbase = (uint64_t)((b * a.H + h) * a.Lq + qq) * (uint64_t)a.Lk + (uint64_t)(t * BKEY);

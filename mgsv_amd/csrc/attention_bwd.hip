@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(const MadeAttnBwdArgs 
         lk_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
     }
     const int64_t ntiles = (lk_eff + BKEY - 1) / BKEY;
-    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const uint32_t thr = made_drop_threshold(a.drop.p);
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t rowbase = (uint64_t)((b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
 
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs
         lq_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
     }
     const int64_t ntiles = (lq_eff + BQT - 1) / BQT;
-    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const uint32_t thr = made_drop_threshold(a.drop.p);
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t bhbase = (uint64_t)(b * a.H + h) * (uint64_t)a.Lq;
     const bool wave_active = __any(key_valid);

@@ -140,6 +140,10 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    float sd_run = 0.f;                             // training: running sum of the DROPPED probabilities (they no longer sum to l)
+    const uint32_t drop_thr = made_drop_threshold(a.drop.p);
+    const float drop_sc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
+    const uint64_t drop_base = (uint64_t)(b * nq_total + (my_q < nq_total ? my_q : nq_total - 1)) * (uint64_t)a.L;
 
     // keys of this workgroup: all of them, or the blockIdx.z-th slice when the keys are split over workgroups
     // keys after the last valid one contribute exactly 0: stop there (padding is a suffix in the dataset's masks)
@@ -222,6 +226,16 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (a.drop.p > 0.f) {                       // dropout on the attention weights; l keeps the undropped sum
+            float dsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool kp = (made_rng_mix(a.drop.seed, a.drop.site, drop_base + (uint64_t)(t * WKEY + acc_row(e, hh))) >> 8) >= drop_thr;
+                s[e] = kp ? s[e] * drop_sc : 0.f;
+                dsum += s[e];
+            }
+            sd_run = sd_run * alpha + dsum;
+        }
 #pragma unroll
         for (int d = 0; d < NDT; ++d)
 #pragma unroll
@@ -267,7 +281,9 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
+    const float sd_tot = sd_run + __shfl_xor(sd_run, 32);
     if (my_q >= nq_total) return;
+    if (a.sum_out && wave == 0 && hh == 0) a.sum_out[b * nq_total + my_q] = a.drop.p > 0.f ? sd_tot * inv : 1.f;
     if (nsplit > 1) {
         // un-normalised partial result of this key slice; made_attention_wide_combine merges the slices
         const int64_t prow = (b * nsplit + blockIdx.z) * nq_total + my_q;
@@ -390,6 +406,8 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
                      "made_attention_wide: strides must keep 16-byte alignment");
     MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && ((uintptr_t)a.O % 16) == 0 &&
                      ((uintptr_t)a.Kadd % 16) == 0, "made_attention_wide: base pointers must be 16-byte aligned");
+    MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_attention_wide: dropout p out of [0,1)");
+    MADE_UNSUPPORTED(!(a.n_split > 1 && (a.drop.p > 0.f || a.sum_out)), "made_attention_wide: dropout / sum_out need n_split == 1");
     if (a.n_split > 1) {
         MADE_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr, "made_attention_wide: n_split > 1 needs part_o / part_ml");
         MADE_UNSUPPORTED(a.n_split <= 64, "made_attention_wide: n_split <= 64");

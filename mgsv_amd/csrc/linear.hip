@@ -154,7 +154,7 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
         for (int j = 0; j < 8; ++j) v[j] *= act_grad(g[j], a.gate) * a.gate_scale;
     }
     if (a.drop.p > 0.f) {
-        const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+        const uint32_t thr = made_drop_threshold(a.drop.p);
         const float sc = 1.f / (1.f - a.drop.p);
         const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
 #pragma unroll

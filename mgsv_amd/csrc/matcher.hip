@@ -274,7 +274,8 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
                                                                      const float* proj_q, const float* vid_sum, const float* empty_w,
                                                                      int B, int Q, int G, int Dc, int fg, float temperature,
                                                                      const float* weights, const float* upstream,
-                                                                     float* dlogits, float* dspans, float* dproj_q, float* dvid_sum) {
+                                                                     float* dlogits, float* dspans, int ldo, int through_sigmoid,
+                                                                     float* dproj_q, float* dvid_sum) {
     __shared__ unsigned char matched[CRIT_MAX_BQ];
     __shared__ float lgt[CRIT_MAX_BQ];
     __shared__ float red[4];
@@ -285,9 +286,9 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
     const float up = upstream ? upstream[0] : 1.f;
     const float* lg = logits + (int64_t)l * B * Q * 2;
     const float* sp = spans + (int64_t)l * B * Q * 2;
-    float* dlg = dlogits + (int64_t)l * B * Q * 2;
-    float* dsp = dspans + (int64_t)l * B * Q * 2;
-    for (int i = tid; i < B * Q; i += CRIT_THREADS) { matched[i] = 0; dsp[2 * i] = 0.f; dsp[2 * i + 1] = 0.f; }
+    float* dlg = dlogits + (int64_t)l * B * Q * ldo;
+    float* dsp = dspans + (int64_t)l * B * Q * ldo;
+    for (int i = tid; i < B * Q; i += CRIT_THREADS) { matched[i] = 0; dsp[ldo * i] = 0.f; dsp[ldo * i + 1] = 0.f; }
     __syncthreads();
     float npairs = 0.f;
     for (int i = tid; i < B * width; i += CRIT_THREADS) {
@@ -326,8 +327,9 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
             const float wg = -up * weights[1] / npairs;
             dc += wg * (dg_pe + dg_ps);
             dw += wg * 0.5f * (dg_pe - dg_ps);
-            dsp[(b * Q + q) * 2] = dc;
-            dsp[(b * Q + q) * 2 + 1] = dw;
+            if (through_sigmoid) { dc *= pc * (1.f - pc); dw *= pw * (1.f - pw); }   // pred_spans = sigmoid(z): gradient w.r.t. z
+            dsp[(b * Q + q) * ldo] = dc;
+            dsp[(b * Q + q) * ldo + 1] = dw;
             matched[b * Q + q] = 1;
         }
     }
@@ -340,8 +342,8 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
         float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
         float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
         const float w = up * weights[2] * empty_w[cls] / (float)(B * Q);
-        dlg[i * 2] = w * (p0 - (cls == 0 ? 1.f : 0.f));
-        dlg[i * 2 + 1] = w * (p1 - (cls == 1 ? 1.f : 0.f));
+        dlg[i * ldo] = w * (p0 - (cls == 0 ? 1.f : 0.f));
+        dlg[i * ldo + 1] = w * (p1 - (cls == 1 ? 1.f : 0.f));
     }
     if (proj_q && vid_sum && dproj_q && dvid_sum) {
         for (int i = wave; i < B * Q; i += CRIT_THREADS / 64) {
@@ -416,13 +418,15 @@ extern "C" int made_set_criterion_bwd(const float* pred_logits, const float* pre
                                       const float* proj_queries, const float* vid_sum, const float* empty_weight,
                                       int64_t n_layers, int64_t B, int64_t Q, int64_t G, int64_t Dc, int32_t fg_label,
                                       float temperature, const float* weights, const float* upstream,
-                                      float* d_logits, float* d_spans, float* d_proj_queries, float* d_vid_sum, void* stream) {
+                                      float* d_logits, float* d_spans, int64_t ld_out, int32_t through_sigmoid,
+                                      float* d_proj_queries, float* d_vid_sum, void* stream) {
     MADE_REQUIRE(pred_logits && pred_spans && targets && pred_idx && tgt_idx && count && empty_weight && weights && d_logits && d_spans,
                  "made_set_criterion_bwd: null pointer");
     MADE_REQUIRE(n_layers >= 1 && B >= 1 && Q >= 1 && G >= 1, "made_set_criterion_bwd: bad dims");
     MADE_UNSUPPORTED(n_layers <= 65535 && B * Q <= CRIT_MAX_BQ, "made_set_criterion_bwd: B*Q=%lld exceeds %d", (long long)(B * Q), CRIT_MAX_BQ);
     hipLaunchKernelGGL(criterion_bwd_kernel, dim3((unsigned)n_layers), dim3(CRIT_THREADS), 0, (hipStream_t)stream, pred_logits, pred_spans,
                        targets, pred_idx, tgt_idx, count, proj_queries, vid_sum, empty_weight, (int)B, (int)Q, (int)G, (int)Dc,
-                       (int)fg_label, temperature, weights, upstream, d_logits, d_spans, d_proj_queries, d_vid_sum);
+                       (int)fg_label, temperature, weights, upstream, d_logits, d_spans, (int)(ld_out > 0 ? ld_out : 2), (int)through_sigmoid,
+                       d_proj_queries, d_vid_sum);
     return made_check_launch("made_set_criterion_bwd");
 }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(RT) void layernorm_bwd_kernel(const LnBwdArgs a) {
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
-    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const uint32_t thr = made_drop_threshold(a.drop.p);
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const int D = a.D;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(RT) void pool_bwd_kernel(const PoolBwdArgs a) {
 // ---- y = x / max(|x|, eps)  ->  dx = (dy - yhat (yhat . dy)) / max(|x|, eps) -------------------------------
 struct L2BwdArgs {
     const void* x; int xdt; int64_t ldx;
-    const float* dy; int64_t lddy;
+    const float* dy; int64_t lddy; int64_t dy_rows_per;
     float* dx; int64_t lddx; int accumulate;
     void* dxa; int adt; int64_t lddxa;
     int64_t rows; int D; float eps;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(RT) void l2norm_bwd_kernel(const L2BwdArgs a) {
         const int c = (i * WAVE + lane) * 4;
         const int cc = c < D ? c : 0;
         xv[i] = ld4(a.x, a.xdt, row * a.ldx + cc);
-        gv[i] = *(const f32x4*)(a.dy + row * a.lddy + cc);
+        gv[i] = *(const f32x4*)(a.dy + (row / a.dy_rows_per) * a.lddy + cc);
         if (c >= D) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { xv[i][j] = 0.f; gv[i][j] = 0.f; }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(RT) void xpool_tail_bwd_kernel(const XtailBwdArgs a
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
-    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const uint32_t thr = made_drop_threshold(a.drop.p);
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
         const int64_t m = row / a.Nv, n = row % a.Nv;
@@ -442,7 +442,7 @@ struct SmBwdArgs {
     const float* S; int64_t lds_; const float* dP; int64_t lddp;
     const float* mask; int64_t rows_per_mask;            // mask row = row / rows_per_mask
     const float* extra; float scale; MadeDropout drop;
-    void* Pd; void* dS; void* dSt; int odt; int64_t ldo, ldt;
+    void* Pd; void* dS; void* dSt; int odt; int64_t ldo, ldt, obs, tbs;
     int64_t rows, rpb, L;
 };
 
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
     const float* g = a.dP + row * a.lddp;
     const float* mk = a.mask ? a.mask + (row / a.rows_per_mask) * a.L : nullptr;
     const float ex = a.extra ? a.extra[row] : 0.f;
-    const uint32_t thr = (uint32_t)(a.drop.p * 16777216.f);
+    const uint32_t thr = made_drop_threshold(a.drop.p);
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t base = (uint64_t)row * (uint64_t)a.L;
     float mx = -INFINITY;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
     for (int64_t k = lane; k < a.L; k += 64) {
         const bool ok = mk == nullptr || mk[k] != 0.f;
         const float p = ok ? expf(s[k] * a.scale - mx) : 0.f;
-        float dp = g[k] + ex;
+        float dp = ok ? g[k] + ex : 0.f;              // masked keys may hold stale (non-finite) products: never touch them
         if (a.drop.p > 0.f) dp = keep_at(a.drop, thr, base + (uint64_t)k) ? dp * dsc : 0.f;
         se += p; dot += p * dp;
     }
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
         if (k < a.L) {
             const bool ok = mk == nullptr || mk[k] != 0.f;
             const float p = ok ? expf(s[k] * a.scale - mx) * inv : 0.f;
-            float dp = g[k] + ex;
+            float dp = ok ? g[k] + ex : 0.f;
             pd = p;
             if (a.drop.p > 0.f) {
                 const bool kp = keep_at(a.drop, thr, base + (uint64_t)k);
@@ -489,9 +489,9 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
             }
             ds = a.scale * p * (dp - dot);
         }
-        store_from_f32(a.Pd, a.odt, row * a.ldo + k, pd);
-        store_from_f32(a.dS, a.odt, row * a.ldo + k, ds);
-        if (a.dSt && k < a.L) store_from_f32(a.dSt, a.odt, (z * a.L + k) * a.ldt + i, ds);
+        store_from_f32(a.Pd, a.odt, z * a.obs + i * a.ldo + k, pd);
+        store_from_f32(a.dS, a.odt, z * a.obs + i * a.ldo + k, ds);
+        if (a.dSt && k < a.L) store_from_f32(a.dSt, a.odt, z * a.tbs + k * a.ldt + i, ds);
     }
 }
 
@@ -523,13 +523,25 @@ __global__ __launch_bounds__(RT) void head_bias_bwd_kernel(const void* dy, int d
 }
 
 // ---- out = a + b (+ c), any mix of f32 / bf16, contiguous [n] ------------------------------------------------------
-__global__ void add3_kernel(void* out, int odt, const void* a, int adt, const void* b, int bdt, const void* c, int cdt, int64_t n) {
+__global__ void add3_kernel(void* out, int odt, const void* a, int adt, const void* b, int bdt, const void* c, int cdt, int64_t n,
+                            int64_t b_mod) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float v = load_as_f32(a, adt, i);
-    if (b) v += load_as_f32(b, bdt, i);
+    if (b) v += load_as_f32(b, bdt, b_mod > 0 ? i % b_mod : i);
     if (c) v += load_as_f32(c, cdt, i);
     store_from_f32(out, odt, i, v);
+}
+
+// ---- out[c] += sum_rows x[row, c]  (f32 accumulate; gradient of a vector broadcast over rows) -------------------------
+__global__ __launch_bounds__(RT) void colsum_kernel(const void* x, int dt, int64_t ld, int64_t rows, int64_t cols, float* out) {
+    const int64_t c = (int64_t)blockIdx.x * RT + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc += load_as_f32(x, dt, r * ld + c);
+    unsafeAtomicAdd(out + c, acc);
 }
 
 inline unsigned blocks4(int64_t rows) { return (unsigned)((rows + 3) / 4); }
@@ -586,14 +598,14 @@ extern "C" int made_pool_bwd(const float* mean, const float* dvec, const float* 
     return made_check_launch("made_pool_bwd");
 }
 
-extern "C" int made_l2norm_bwd(const void* x, int32_t x_dtype, int64_t ldx, const float* dy, int64_t lddy,
+extern "C" int made_l2norm_bwd(const void* x, int32_t x_dtype, int64_t ldx, const float* dy, int64_t lddy, int64_t dy_rows_per,
                                float* dx, int64_t lddx, int32_t accumulate, void* dx_alt, int32_t alt_dtype, int64_t lddxa,
                                int64_t rows, int64_t D, float eps, void* stream) {
     MADE_REQUIRE(x && dy && (dx || dx_alt), "made_l2norm_bwd: null pointer");
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddxa % 4 == 0,
                      "made_l2norm_bwd: bad D/strides");
     if (rows <= 0) return MADE_OK;
-    L2BwdArgs a{x, x_dtype, ldx, dy, lddy, dx, lddx, accumulate, dx_alt, alt_dtype, lddxa, rows, (int)D, eps};
+    L2BwdArgs a{x, x_dtype, ldx, dy, lddy, dy_rows_per > 0 ? dy_rows_per : 1, dx, lddx, accumulate, dx_alt, alt_dtype, lddxa, rows, (int)D, eps};
     DISPATCH_NVB(D, hipLaunchKernelGGL((l2norm_bwd_kernel<NV>), dim3(blocks4(rows)), dim3(RT), 0, (hipStream_t)stream, a));
     return made_check_launch("made_l2norm_bwd");
 }
@@ -635,6 +647,7 @@ extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, 
 extern "C" int made_softmax_bwd(const float* S, int64_t ld_s, const float* dP, int64_t ld_dp, const float* mask,
                                 int64_t rows_per_mask, const float* extra, float scale, const MadeDropout* drop,
                                 void* Pd, void* dS, void* dSt, int32_t out_dtype, int64_t ldo, int64_t ldt,
+                                int64_t out_batch_stride, int64_t t_batch_stride,
                                 int64_t rows, int64_t rows_per_batch, int64_t L, void* stream) {
     MADE_REQUIRE(S && dP && Pd && dS, "made_softmax_bwd: null pointer");
     MADE_REQUIRE(rows >= 0 && L > 0 && ldo >= L && rows_per_batch > 0 && rows_per_mask > 0, "made_softmax_bwd: bad dims");
@@ -645,6 +658,8 @@ extern "C" int made_softmax_bwd(const float* S, int64_t ld_s, const float* dP, i
     a.scale = scale; a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f;
     if (drop) a.drop = *drop;
     a.Pd = Pd; a.dS = dS; a.dSt = dSt; a.odt = out_dtype; a.ldo = ldo; a.ldt = ldt; a.rows = rows; a.rpb = rows_per_batch; a.L = L;
+    a.obs = out_batch_stride > 0 ? out_batch_stride : rows_per_batch * ldo;
+    a.tbs = t_batch_stride > 0 ? t_batch_stride : L * ldt;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(blocks4(rows)), dim3(RT), 0, (hipStream_t)stream, a);
     return made_check_launch("made_softmax_bwd");
 }
@@ -667,9 +682,18 @@ extern "C" int made_head_bias_bwd(const void* dy, int32_t dtype, int64_t ld, con
 }
 
 extern "C" int made_add3(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, const void* b, int32_t b_dtype,
-                         const void* c, int32_t c_dtype, int64_t n, void* stream) {
+                         const void* c, int32_t c_dtype, int64_t n, int64_t b_mod, void* stream) {
     MADE_REQUIRE(out && a, "made_add3: null pointer");
     if (n <= 0) return MADE_OK;
-    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, out_dtype, a, a_dtype, b, b_dtype, c, c_dtype, n);
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, out_dtype, a, a_dtype, b, b_dtype, c, c_dtype, n, b_mod);
     return made_check_launch("made_add3");
+}
+
+extern "C" int made_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream) {
+    MADE_REQUIRE(x && out && cols > 0, "made_colsum: bad arguments");
+    if (rows <= 0) return MADE_OK;
+    int64_t ny = (rows + 63) / 64;
+    if (ny > 64) ny = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + RT - 1) / RT), (unsigned)ny), dim3(RT), 0, (hipStream_t)stream, x, dtype, ld, rows, cols, out);
+    return made_check_launch("made_colsum");
 }

@@ -33,7 +33,8 @@ def site_id(name: str) -> int:
 
 
 def threshold(p: float) -> int:
-    return int(np.floor(float(p) * (1 << 24)))
+    """floor(float32(p) * 2^24), exactly (made_drop_threshold in include/made_hip.h)."""
+    return int(np.floor(float(np.float32(p)) * (1 << 24)))
 
 
 def _fmix32(h: np.ndarray) -> np.ndarray:

@@ -267,7 +267,8 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
 
 def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, Kadd: Optional[Tensor] = None,
                    key_mask: Optional[Tensor] = None, shared_q: bool = False, n_split: int = 1,
-                   part_o: Optional[Tensor] = None, part_ml: Optional[Tensor] = None) -> Tensor:
+                   part_o: Optional[Tensor] = None, part_ml: Optional[Tensor] = None, drop=None,
+                   sum_out: Optional[Tensor] = None) -> Tensor:
     """Single-head attention with head dim = D.  Q [B|1, NQ1, NQ2, D], K/Kadd/V [B, L, D], O [B, NQ1, NQ2, D]
     (strided views fine, unit inner stride).  shared_q: the same queries for every batch entry (Q.shape[0] == 1)."""
     assert Q.dim() == 4 and O.dim() == 4 and K.dim() == 3 and V.dim() == 3
@@ -294,6 +295,11 @@ def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, 
             part_ml = torch.empty(B * n_split * nq * 2, device=Q.device, dtype=torch.float32)
         assert part_o.numel() >= B * n_split * nq * D and part_ml.numel() >= B * n_split * nq * 2
         a.n_split, a.part_o, a.part_ml = n_split, _p(_f32(part_o, "part_o")), _p(_f32(part_ml, "part_ml"))
+    if drop is not None and drop[2] > 0.0:
+        a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
+    if sum_out is not None:
+        assert sum_out.dtype == torch.float32 and sum_out.is_contiguous() and sum_out.numel() >= B * nq
+        a.sum_out = _p(sum_out)
     esz = 4 if a.dtype == F32 else 2
     _timed("attention_wide_" + ("f32" if a.dtype == F32 else "bf16"), 4.0 * B * nq * L * D,
            esz * B * (2 * L * D + 2 * nq * D),

@@ -133,9 +133,9 @@ def pool_bwd(mean: Tensor, dvec: Tensor, mask: Tensor, out: Tensor, in1: Optiona
 
 
 def l2norm_bwd(x: Tensor, dy: Tensor, dx: Optional[Tensor] = None, *, accumulate: bool = False, dx_alt: Optional[Tensor] = None,
-               eps: float = 1e-12) -> None:
+               eps: float = 1e-12, dy_rows_per: int = 1) -> None:
     rows, D = x.shape
-    check(lib().made_l2norm_bwd(_p(x), dt_of(x), x.stride(0), _p(_f32(dy, "dy")), dy.stride(0),
+    check(lib().made_l2norm_bwd(_p(x), dt_of(x), x.stride(0), _p(_f32(dy, "dy")), dy.stride(0), dy_rows_per,
                                 _p(dx), dx.stride(0) if dx is not None else 0, int(accumulate),
                                 _p(dx_alt), _dt(dx_alt), dx_alt.stride(0) if dx_alt is not None else 0,
                                 rows, D, eps, _stream()), "made_l2norm_bwd")
@@ -162,11 +162,13 @@ def xpool_tail_bwd(y: Tensor, gamma: Tensor, beta: Tensor, video: Tensor, dsims:
 
 def softmax_bwd(S: Tensor, dP: Tensor, mask: Optional[Tensor], rows_per_mask: int, scale: float, Pd: Tensor, dS: Tensor,
                 dSt: Optional[Tensor], rows_per_batch: int, L: int, *, extra: Optional[Tensor] = None, drop=None,
-                ldt: int = 0) -> None:
+                ldo: Optional[int] = None, ldt: int = 0, out_batch_stride: int = 0, t_batch_stride: int = 0) -> None:
+    """S, dP [rows, >= L] f32; Pd / dS: element (z, i, k) at z*out_batch_stride + i*ldo + k; dSt: z*t_batch_stride + k*ldt + i."""
     rows = S.shape[0]
     check(lib().made_softmax_bwd(_p(_f32(S, "S")), S.stride(0), _p(dP), dP.stride(0), _p(mask), rows_per_mask,
-                                 _p(extra), float(scale), _drop_ptr(drop), _p(Pd), _p(dS), _p(dSt), dt_of(Pd), Pd.stride(0),
-                                 ldt, rows, rows_per_batch, L, _stream()), "made_softmax_bwd")
+                                 _p(extra), float(scale), _drop_ptr(drop), _p(Pd), _p(dS), _p(dSt), dt_of(Pd),
+                                 Pd.stride(-2) if ldo is None else ldo, ldt, out_batch_stride, t_batch_stride,
+                                 rows, rows_per_batch, L, _stream()), "made_softmax_bwd")
 
 
 def head_bias(x: Tensor, s: Tensor, bias: Tensor, H: int) -> None:
@@ -180,20 +182,27 @@ def head_bias_bwd(dy: Tensor, s: Tensor, bias: Tensor, dbias: Tensor, ds: Tensor
                                    _stream()), "made_head_bias_bwd")
 
 
-def add3(out: Tensor, a: Tensor, b: Optional[Tensor] = None, c: Optional[Tensor] = None) -> Tensor:
+def add3(out: Tensor, a: Tensor, b: Optional[Tensor] = None, c: Optional[Tensor] = None, b_mod: int = 0) -> Tensor:
     for t in (out, a, b, c):
         assert t is None or t.is_contiguous()
-    check(lib().made_add3(_p(out), dt_of(out), _p(a), dt_of(a), _p(b), _dt(b), _p(c), _dt(c), out.numel(), _stream()), "made_add3")
+    check(lib().made_add3(_p(out), dt_of(out), _p(a), dt_of(a), _p(b), _dt(b), _p(c), _dt(c), out.numel(), b_mod, _stream()), "made_add3")
     return out
+
+
+def colsum(x: Tensor, out: Tensor) -> None:
+    """out[c] += sum_rows x[row, c]."""
+    rows, cols = x.shape
+    check(lib().made_colsum(_p(x), dt_of(x), x.stride(0), rows, cols, _p(_f32(out, "out")), _stream()), "made_colsum")
 
 
 def set_criterion_bwd(logits: Tensor, spans: Tensor, targets: Tensor, pi: Tensor, ti: Tensor, cnt: Tensor, pq: Optional[Tensor],
                       vid_sum: Optional[Tensor], empty_weight: Tensor, fg: int, weights: Tensor, upstream: Optional[Tensor],
                       d_logits: Tensor, d_spans: Tensor, d_pq: Optional[Tensor], d_vid_sum: Optional[Tensor],
-                      temperature: float = 0.07) -> None:
+                      temperature: float = 0.07, ld_out: int = 2, through_sigmoid: bool = False) -> None:
     nd, B, Q, _ = logits.shape
     G = targets.shape[1]
     Dc = pq.shape[-1] if pq is not None else 0
     check(lib().made_set_criterion_bwd(_p(logits), _p(spans), _p(targets), _p(pi), _p(ti), _p(cnt), _p(pq), _p(vid_sum),
                                        _p(empty_weight), nd, B, Q, G, Dc, fg, temperature, _p(weights), _p(upstream),
-                                       _p(d_logits), _p(d_spans), _p(d_pq), _p(d_vid_sum), _stream()), "made_set_criterion_bwd")
+                                       _p(d_logits), _p(d_spans), ld_out, int(through_sigmoid), _p(d_pq), _p(d_vid_sum), _stream()),
+          "made_set_criterion_bwd")

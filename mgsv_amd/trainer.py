@@ -1,0 +1,753 @@
+"""Training executor of the MaDe hot path on MI355X: forward in train() mode + hand-written backward.
+
+Mirrors one iteration of the reference's training loop up to the gradients (reference train-MaDe.py:337-371:
+`model(..., is_train=True)`, `loss = retrieval_loss*w_r + localization_loss*w_l`, `loss.backward()`): every autograd node
+on the path is a kernel of libmade_hip.so (include/made_hip.h, "Training path").  PyTorch provides device memory and the
+stream; nothing falls back to ATen/autograd.
+
+Layout
+  * master parameters and their gradients live in two flat f32 buffers (`flat_param`, `flat_grad`), addressed through
+    per-parameter views named like the reference's state_dict -- one memset clears all gradients, one RCCL all-reduce
+    averages them over data-parallel ranks, one fused optimizer launch can walk them;
+  * `repack()` derives the kernel-facing copies (compute dtype W for the forward / dX products' B operand W^T);
+  * activations needed by the backward are kept per layer in the compute dtype (about 10 [B*L, D] tensors per layer);
+    dropout masks are never stored: they are a pure function of (seed, site, element index) (mgsv_amd/dropout.py);
+  * weight gradients are A^T B products over the token axis (made_gemm_tn) accumulated with f32 atomics.
+
+Differences from the eval executor (engine.py): the decoder cross-attention still runs in memory space, but with the
+per-head products written out (q' = W_k,h^T q_h and v_h = W_v,h pooled_h as batched GEMMs) instead of pre-folded weights,
+so the gradients of in_proj / out_proj come out of ordinary Linear backward steps.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, dropout as dr, ops, ops_train as tr
+from .config import MadeConfig
+from .engine import MadeEngine
+from .ops import Seg, round_up
+
+Tensor = torch.Tensor
+XA = "video_guided_to_music_pooling_cross_transformer"
+
+
+class MadeTrainer(MadeEngine):
+    def __init__(self, cfg: MadeConfig, state_dict: Dict[str, object], device="cuda:0", dtype: str = "f32"):
+        super().__init__(cfg, state_dict, device, dtype)
+        self._check_train_supported()
+        self._init_master(state_dict)
+        self.repack()
+        self._tws: Dict[tuple, Dict[str, Tensor]] = {}
+        self.seed = 0
+        self.training_dropout = True
+
+    # ------------------------------------------------------------------ support matrix
+    def _check_train_supported(self):
+        c = self.cfg
+        bad = []
+        if "concat" not in c.mml_fusion:
+            bad.append(f"mml_fusion={c.mml_fusion}")
+        if c.num_moment_queries != 1:
+            bad.append("num_moment_queries > 1")
+        if c.with_act_after_proj:
+            bad.append("with_act_after_proj")
+        if c.moment_query_type not in ("video", "music"):
+            bad.append(f"moment_query_type={c.moment_query_type}")
+        if bad:
+            raise NotImplementedError("MadeTrainer (HIP training path) does not cover yet: " + "; ".join(bad))
+
+    # ------------------------------------------------------------------ parameters
+    def _table(self) -> Tuple[List[Tuple[str, object]], List[Tuple[str, object]]]:
+        """(kernel key, reference name(s)) for matrices and for vectors, mirroring MadeEngine.load_state_dict."""
+        c = self.cfg
+        mats: List[Tuple[str, object]] = []
+        vecs: List[Tuple[str, object]] = []
+
+        def lin(key, name):
+            mats.append((key + ".w", name + ".weight")); vecs.append((key + ".b", name + ".bias"))
+
+        def ln(key, name):
+            vecs.append((key + ".g", name + ".weight")); vecs.append((key + ".b", name + ".bias"))
+
+        lin("vit_proj", "vit_proj"); lin("ast_proj", "ast_proj")
+        for mod, depth in (("video_transformer", c.video_transformer_depth), ("audio_transformer", c.audio_transformer_depth)):
+            for l in range(depth):
+                p = f"{mod}.layers.{l}"
+                ln(p + ".ln1", p + ".0")
+                mats.append((p + ".in.w", p + ".1.in_proj_weight")); vecs.append((p + ".in.b", p + ".1.in_proj_bias"))
+                lin(p + ".out", p + ".1.out_proj"); ln(p + ".ln2", p + ".2")
+                lin(p + ".ff1", p + ".3.0"); lin(p + ".ff2", p + ".3.3")
+            lin(mod + ".final", mod + ".final_linear")
+        ln("xa.ln1", XA + ".layer_norm1"); ln("xa.ln2", XA + ".layer_norm2"); ln("xa.ln3", XA + ".layer_norm3")
+        lin("xa.q", XA + ".cross_attn.q_proj")
+        mats.append(("xa.kv.w", (XA + ".cross_attn.k_proj.weight", XA + ".cross_attn.v_proj.weight")))
+        vecs.append(("xa.kv.b", (XA + ".cross_attn.k_proj.bias", XA + ".cross_attn.v_proj.bias")))
+        lin("xa.out", XA + ".cross_attn.out_proj"); lin("xa.lin", XA + ".linear_proj")
+        vecs.append(("logit_scale", "logit_scale"))
+        for l in range(c.detr_enc_layers):
+            p = f"detr_transformer.encoder.layers.{l}"
+            mats.append((p + ".in.w", p + ".self_attn.in_proj_weight")); vecs.append((p + ".in.b", p + ".self_attn.in_proj_bias"))
+            lin(p + ".out", p + ".self_attn.out_proj"); lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
+            ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2")
+        for l in range(c.detr_dec_layers):
+            p = f"detr_transformer.decoder.layers.{l}"
+            mats.append((p + ".sa.in.w", p + ".self_attn.in_proj_weight")); vecs.append((p + ".sa.in.b", p + ".self_attn.in_proj_bias"))
+            lin(p + ".sa.out", p + ".self_attn.out_proj")
+            mats.append((p + ".ca.in.w", p + ".multihead_attn.in_proj_weight")); vecs.append((p + ".ca.in.b", p + ".multihead_attn.in_proj_bias"))
+            lin(p + ".ca.out", p + ".multihead_attn.out_proj")
+            lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
+            ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2"); ln(p + ".ln3", p + ".norm3")
+        ln("dec.norm", "detr_transformer.decoder.norm")
+        mats.append(("query_embed", "decoder_query_embed.weight"))
+        lin("class_embed", "class_embed")
+        for i in range(3):
+            lin(f"span_embed.{i}", f"span_embed.layers.{i}")
+        if c.contrastive_align_loss:
+            lin("proj_q", "contrastive_align_projection_query"); lin("proj_v", "contrastive_align_projection_vid")
+        return mats, vecs
+
+    def _init_master(self, sd: Dict[str, object]):
+        """Flat f32 master / gradient buffers; k_proj|v_proj of the X-Pool block are laid out back to back so the packed
+        [2D, D] projection is one view."""
+        dev = self.device
+        names = [k for k in sd if not k.endswith(".pe") and k != "criterion.empty_weight"]
+        pair_after = {XA + ".cross_attn.k_proj.weight": XA + ".cross_attn.v_proj.weight",
+                      XA + ".cross_attn.k_proj.bias": XA + ".cross_attn.v_proj.bias"}
+        order: List[str] = []
+        for k in names:
+            if k in pair_after.values():
+                continue
+            order.append(k)
+            if k in pair_after:
+                order.append(pair_after[k])
+        shapes = {k: tuple(np.asarray(sd[k].detach().cpu() if isinstance(sd[k], torch.Tensor) else sd[k]).shape) for k in order}
+        offs, off = {}, 0
+        for k in order:
+            offs[k] = off
+            n = int(np.prod(shapes[k])) if len(shapes[k]) else 1
+            off += n if k in pair_after else round_up(n, 64)
+            if k in pair_after:
+                assert n % 64 == 0
+        self.flat_param = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.master: Dict[str, Tensor] = {}
+        self.grad: Dict[str, Tensor] = {}
+        for k in order:
+            n = int(np.prod(shapes[k])) if len(shapes[k]) else 1
+            self.master[k] = self.flat_param[offs[k]:offs[k] + n].view(shapes[k])
+            self.grad[k] = self.flat_grad[offs[k]:offs[k] + n].view(shapes[k])
+            v = sd[k]
+            t = v.detach() if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+            self.master[k].copy_(t.to(dev, torch.float32))
+        self.param_names = order
+        self._offs = offs
+
+    def _view(self, store: Dict[str, Tensor], ref) -> Tensor:
+        if isinstance(ref, tuple):                       # adjacent pair -> one view over both
+            a, b = store[ref[0]], store[ref[1]]
+            flat = self.flat_param if store is self.master else self.flat_grad
+            o = self._offs[ref[0]]
+            rows = a.shape[0] + b.shape[0]
+            return flat[o:o + a.numel() + b.numel()].view((rows,) + tuple(a.shape[1:]))
+        return store[ref]
+
+    def repack(self):
+        """Kernel-facing parameter copies from the f32 masters: W (compute dtype), W^T (for dX = dY W), vectors aliased."""
+        P, tc = self.P, self.tc
+        mats, vecs = self._table()
+        self.G: Dict[str, Tensor] = {}
+        for key, ref in vecs:
+            v = self._view(self.master, ref)
+            P[key] = v.view(-1) if v.dim() != 1 else v
+            g = self._view(self.grad, ref)
+            self.G[key] = g.view(-1) if g.dim() != 1 else g
+        for key, ref in mats:
+            m = self._view(self.master, ref)
+            P[key] = m if tc == torch.float32 else m.to(tc)
+            self.G[key] = self._view(self.grad, ref)
+            if key in ("query_embed", "vit_proj.w", "ast_proj.w"):
+                continue
+            base = key[:-2] if key.endswith(".w") else key
+            if m.shape[0] < 8:                           # tiny heads (N = 2): zero-pad the reduction dim of W^T to 8
+                wt = torch.zeros(m.shape[1], 8, device=self.device, dtype=tc)
+                wt[:, :m.shape[0]] = m.t().to(tc)
+                P[base + ".wt"] = wt
+            else:
+                P[base + ".wt"] = m.t().contiguous().to(tc)
+
+    def state_dict_numpy(self) -> Dict[str, np.ndarray]:
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.master.items()}
+
+    def grads_numpy(self) -> Dict[str, np.ndarray]:
+        torch.cuda.synchronize()
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.grad.items()}
+
+    # ------------------------------------------------------------------ dropout sites
+    def _drop(self, site: str, p: float):
+        if not self.training_dropout or p <= 0.0:
+            return None
+        return (self.seed, dr.site_id(site), float(p))
+
+    # ------------------------------------------------------------------ training workspace
+    def _train_buffers(self, B: int, Tv: int, Ta: int) -> Dict[str, Tensor]:
+        key = (B, Tv, Ta)
+        ws = self._tws.get(key)
+        if ws is not None:
+            return ws
+        c, dev, tc = self.cfg, self.device, self.tc
+        D, L, Q, H = c.D, Tv + Ta, c.num_moment_queries, c.detr_nheads
+        Ft, Fd, nd, ne = c.temporal_ffn_dim, c.detr_dim_feedforward, c.detr_dec_layers, c.detr_enc_layers
+        Hh = c.SA_temporal_heads
+        f32 = torch.float32
+
+        def E(*shape, dtype=None):
+            return torch.empty(shape, device=dev, dtype=dtype or tc)
+
+        def Z(*shape, dtype=None):
+            return torch.zeros(shape, device=dev, dtype=dtype or tc)
+
+        ws = {}
+        for tag, T, Kin, depth in (("v", Tv, c.vit_dim, c.video_transformer_depth), ("a", Ta, c.ast_dim, c.audio_transformer_depth)):
+            r = B * T
+            ws.update({f"{tag}.xin": E(r, Kin), f"{tag}.xlast": E(r, D), f"{tag}.mean": E(B, D, dtype=f32),
+                       f"{tag}.dl": E(r, D), f"{tag}.g1": E(r, D), f"{tag}.g2": E(r, D), f"{tag}.g3": E(r, D),
+                       f"{tag}.gqkv": E(r, 3 * D), f"{tag}.gffn": E(r, Ft), f"{tag}.delta": E(B * Hh * T, dtype=f32)})
+            for l in range(depth):
+                ws.update({f"{tag}.{l}.x0": E(r, D), f"{tag}.{l}.x1": E(r, D), f"{tag}.{l}.qkv": E(r, 3 * D), f"{tag}.{l}.att": E(r, D),
+                           f"{tag}.{l}.lse": E(B * Hh * T, dtype=f32), f"{tag}.{l}.x2": E(r, D), f"{tag}.{l}.x3": E(r, D),
+                           f"{tag}.{l}.z1": E(r, Ft), f"{tag}.{l}.h": E(r, Ft)})
+        rows = B * L
+        Lp = round_up(L, 8)
+        Sp = round_up(Ta, 8)
+        HQ = H * Q
+        ws.update(
+            # X-Pool (in-batch: every video against every track)
+            xv1=E(B, D), xq=E(B, D), xs1=E(B * Ta, D), xk=E(B * Ta, D), xu=E(B * Ta, D), xo=E(B * B, D), xa2=E(B * B, D),
+            xa3=E(B * B, D), xy=E(B * B, D), xg1=E(B * B, D), xg2=E(B * B, D), xg3=E(B * B, D),
+            xS=E(B * B, Sp, dtype=f32), xdP=E(B * B, Sp, dtype=f32), xP=E(B * B, Sp), xdS=E(B * B, Sp), xdSt=E(B, Ta, B),
+            xdkv=E(B * Ta, 2 * D), xds1=E(B * Ta, D), xdseg=E(B * Ta, D), xdq32=E(B, D, dtype=f32), xdq=E(B, D), xdv1=E(B, D),
+            vn=E(B, D, dtype=f32), mn=E(B, D, dtype=f32), dvn=E(B, D, dtype=f32), dmn=E(B, D, dtype=f32),
+            dsims_s=E(B, B, dtype=f32), dsims_d=E(B, B, dtype=f32), dsims_dt=E(B, B, dtype=f32), clip_ws=E(2 * B, dtype=f32),
+            sims_both=E(B, B, dtype=f32),
+            dvideo=E(B, D, dtype=f32), dmusic=E(B, D, dtype=f32),
+            # DETR encoder
+            e_delta=E(B * H * L, dtype=f32), eg1=E(rows, D), eg2=E(rows, D), eg3=E(rows, D), egqkv=E(rows, 3 * D), egffn=E(rows, Fd),
+            dfus=E(rows, D),
+            # decoder (rows = B*Q)
+            d_tq0=E(B * Q, D), GQ=Z(B, 2, nd, HQ, D), PdS=Z(B, 2, nd, HQ, Lp), dS_S=E(B * HQ, Lp, dtype=f32), dS_dP=E(B * HQ, Lp, dtype=f32),
+            dSt=E(B, L, HQ), d_ds=E(B * Q, H, dtype=f32), d_delta=E(B * H * Q, dtype=f32),
+            dg1=E(B * Q, D), dg2=E(B * Q, D), dg3=E(B * Q, D), dg4=E(B * Q, D), dgqkv=E(B * Q, 3 * D), dgffn=E(B * Q, Fd),
+            dgq=E(B, HQ, D), dtgt=E(B * Q, D), dhs=E(nd * B * Q, D),
+            # heads
+            h1=E(nd * B * Q, D), h2=E(nd * B * Q, D), hg1=E(nd * B * Q, D), hg2=E(nd * B * Q, D),
+            dlog=Z(nd * B * Q, 8, dtype=f32), dsp=Z(nd * B * Q, 8, dtype=f32), dlog_c=Z(nd * B * Q, 8), dsp_c=Z(nd * B * Q, 8),
+        )
+        for l in range(ne):
+            ws.update({f"e.{l}.src": E(rows, D), f"e.{l}.srcpos": E(rows, D), f"e.{l}.qkv": E(rows, 3 * D), f"e.{l}.att": E(rows, D),
+                       f"e.{l}.lse": E(B * H * L, dtype=f32), f"e.{l}.x": E(rows, D), f"e.{l}.s1": E(rows, D), f"e.{l}.h": E(rows, Fd),
+                       f"e.{l}.x2": E(rows, D)})
+        ws.update(mem=E(rows, D), mempos=E(rows, D))
+        for l in range(nd):
+            ws.update({f"d.{l}.tgt": E(B * Q, D), f"d.{l}.tq": E(B * Q, D), f"d.{l}.qkv": E(B * Q, 3 * D), f"d.{l}.att": E(B * Q, D),
+                       f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.t_a": E(B * Q, D), f"d.{l}.t1": E(B * Q, D), f"d.{l}.t1q": E(B * Q, D),
+                       f"d.{l}.qc": E(B * Q, D), f"d.{l}.pooled": E(B * Q, H * D), f"d.{l}.s": E(B * Q, H, dtype=f32),
+                       f"d.{l}.attc": E(B * Q, D), f"d.{l}.t_b": E(B * Q, D), f"d.{l}.t2": E(B * Q, D), f"d.{l}.h": E(B * Q, Fd),
+                       f"d.{l}.t_c": E(B * Q, D), f"d.{l}.t3": E(B * Q, D)})
+        if c.contrastive_align_loss:
+            Dc = c.contrastive_hdim
+            ws.update(dpq=E(nd * B * Q, Dc, dtype=f32), dvid_sum=E(B, Dc, dtype=f32), dpq_raw=E(nd * B * Q, Dc), dpv_raw=E(B * Tv, Dc),
+                      dframe_x=E(B * Tv, D))
+        self._tws[key] = ws
+        return ws
+
+    # ================================================================== forward (train mode)
+    @torch.no_grad()
+    def forward_train(self, frame_feats: Tensor, segment_feats: Tensor, frame_masks: Tensor, segment_masks: Tensor,
+                      spans_target: Tensor, seed: int = 0) -> Dict[str, Tensor]:
+        """reference model/model_Uni.py:177-322 under model.train(): same outputs as MadeEngine.forward plus everything
+        the backward needs, kept in the training workspace."""
+        c, P = self.cfg, self.P
+        self.seed = int(seed)
+        B, Tv, _ = frame_feats.shape
+        Ta = segment_feats.shape[1]
+        D, L, Q, nd, H = c.D, Tv + Ta, c.num_moment_queries, c.detr_dec_layers, c.detr_nheads
+        ws, tw = self._buffers(B, Tv, Ta), self._train_buffers(B, Tv, Ta)
+        fm, sm = frame_masks.contiguous(), segment_masks.contiguous()
+        pd = float(c.detr_dropout)
+        self._shape = (B, Tv, Ta)
+        self._inputs = (frame_feats.contiguous(), segment_feats.contiguous(), fm, sm, spans_target.contiguous())
+
+        fus, fus_mask = ws["fus"], ws["fus_mask"]
+        fus_mask[:, :Tv].copy_(fm)
+        fus_mask[:, Tv:].copy_(sm)
+        pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
+        self._encode_train(self._inputs[0], fm, "video", ws, tw, 0)
+        self._encode_train(self._inputs[1], sm, "audio", ws, tw, Tv)
+        frame, seg = fus[:, :Tv], fus[:, Tv:]
+        video, music = ws["video"], ws["music"]
+        out: Dict[str, Tensor] = dict(video_feats=video, music_feats=music, frame_feats=frame, segment_feats=seg)
+
+        # ---- X-Pool (in-batch) + similarities + retrieval loss
+        xmask = sm if c.fusion_mask == 1 else None
+        self._xpool_train(video, seg, xmask, ws, tw, B, Ta)
+        ops.l2norm_rows(video, out_f32=tw["vn"]); ops.l2norm_rows(music, out_f32=tw["mn"])
+        ops.linear(tw["vn"], tw["mn"], None, out=ws["sims_dual"])
+        self._retrieval_loss(ws, video, music)
+        out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"], retrieval_loss=ws["ret_loss"])
+
+        # ---- DETR encoder
+        rows = B * L
+        fskip = fus_mask.view(-1)
+        pos2 = pos.view(rows, D)
+        src, srcpos = tw["e.0.src"], tw["e.0.srcpos"]
+        ops.layernorm_add(fus.view(rows, D), None, None, pos2, None, srcpos, row_skip=fskip)
+        src = fus.view(rows, D)
+        for l in range(c.detr_enc_layers):
+            p, e = f"detr_transformer.encoder.layers.{l}", f"e.{l}"
+            if l > 0:
+                src, srcpos = tw[e + ".src"], tw[e + ".srcpos"]
+            qkv = tw[e + ".qkv"]
+            ops.linear(src, P[p + ".in.w"], P[p + ".in.b"], A2=srcpos, a2_replace=True, tile_skip_mask=fskip,
+                       segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
+            q3 = qkv.view(B, L, 3 * D)
+            att = tw[e + ".att"]
+            ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, L, D), H, key_mask=fus_mask,
+                          q_skip_mask=fus_mask, lse=tw[e + ".lse"], drop=self._drop(f"enc.{l}" + ".attn", pd))
+            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=tw[e + ".x"], tile_skip_mask=fskip,
+                           drop=self._drop(f"enc.{l}" + ".drop1", pd))
+            s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[e + ".s1"], row_skip=fskip)
+            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[e + ".h"], tile_skip_mask=fskip,
+                           drop=self._drop(f"enc.{l}" + ".ffn_act", pd))
+            x2 = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=tw[e + ".x2"], tile_skip_mask=fskip,
+                            drop=self._drop(f"enc.{l}" + ".drop2", pd))
+            last = l == c.detr_enc_layers - 1
+            nsrc, nsp = (tw["mem"], tw["mempos"]) if last else (tw[f"e.{l + 1}.src"], tw[f"e.{l + 1}.srcpos"])
+            ops.layernorm_add(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], pos2, nsrc, nsp, row_skip=fskip)
+        memory, mempos = tw["mem"], tw["mempos"]
+        out["memory"] = memory.view(B, L, D)
+
+        # ---- DETR decoder (memory-space cross-attention, per-head products written out)
+        mem3, mempos3 = memory.view(B, L, D), mempos.view(B, L, D)
+        qp = P["query_embed"]
+        hd = D // H
+        ca_scale = 1.0 / math.sqrt(hd)
+        src_vec = video if c.moment_query_type == "video" else music
+        tgt = tw["d.0.tgt"]
+        tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
+        hs = ws["hs"]
+        GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
+        for l in range(nd):
+            p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
+            tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
+            qkv = tw[d + ".qkv"]
+            ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
+                       segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
+            q3 = qkv.view(B, Q, 3 * D)
+            ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), H, lse=tw[d + ".lse"],
+                          drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+            ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
+            t1 = tw[d + ".t1"]
+            ops.layernorm_add(ta, P[p + ".ln1.g"], P[p + ".ln1.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t1, tw[d + ".t1q"])
+            Win, bin_ = P[p + ".ca.in.w"], P[p + ".ca.in.b"]
+            Wt = P[p + ".ca.in.wt"]                           # [D, 3D] = in_proj^T
+            qc = ops.linear(tw[d + ".t1q"], Win[:D], bin_[:D], out=tw[d + ".qc"])
+            qprime = GQ[:, 1, l]                              # [B, H*Q, D] view; q'_h = W_k,h^T qc_h  (b_k shifts all keys alike)
+            ops.linear(qc[:, :hd], Wt[:, D:D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
+                       segs=[Seg(out=qprime, ldo=D, rows_per_batch=Q, out_batch_stride=qprime.stride(0), out_z_stride=Q * D)])
+            pooled = tw[d + ".pooled"]                        # [B*Q, H*D] == [B, H, Q, D] for Q == 1
+            ops.attention_wide(qprime.view(B, H, Q, D), mempos3, mem3, pooled.view(B, H, Q, D), scale=ca_scale, key_mask=fus_mask,
+                               drop=self._drop(f"dec.{l}" + ".ca_attn", pd), sum_out=tw[d + ".s"])
+            attc = tw[d + ".attc"]
+            ops.linear(pooled[:, :D], Win[2 * D:2 * D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
+                       segs=[Seg(out=attc, ldo=D, out_z_stride=hd)])
+            tr.head_bias(attc, tw[d + ".s"], bin_[2 * D:], H)
+            tb = ops.linear(attc, P[p + ".ca.out.w"], P[p + ".ca.out.b"], R=t1, out=tw[d + ".t_b"], drop=self._drop(f"dec.{l}" + ".drop2", pd))
+            t2 = ops.layernorm(tb, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[d + ".t2"])
+            h = ops.linear(t2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[d + ".h"], drop=self._drop(f"dec.{l}" + ".ffn_act", pd))
+            tcx = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=t2, out=tw[d + ".t_c"], drop=self._drop(f"dec.{l}" + ".drop3", pd))
+            t3 = tw[d + ".t3"]
+            if l + 1 < nd:
+                ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D), tw[f"d.{l + 1}.tgt"], tw[f"d.{l + 1}.tq"])
+                ops.layernorm(tw[f"d.{l + 1}.tgt"], P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
+                t3.copy_(tw[f"d.{l + 1}.tgt"])
+            else:
+                ops.layernorm(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], out=t3)
+                ops.layernorm(t3, P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
+        out["hs"] = hs.view(nd, B, Q, D)
+
+        # ---- heads
+        hs2 = hs.view(nd * B * Q, D)
+        logits, spans = ws["logits"], ws["spans"]
+        ops.linear(hs2, P["class_embed.w"], P["class_embed.b"], out=logits.view(-1, 2))
+        h1 = ops.linear(hs2, P["span_embed.0.w"], P["span_embed.0.b"], act=ops.ACT_RELU, out=tw["h1"])
+        h2 = ops.linear(h1, P["span_embed.1.w"], P["span_embed.1.b"], act=ops.ACT_RELU, out=tw["h2"])
+        ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, out=spans.view(-1, 2))
+        out.update(pred_logits=logits[-1], pred_spans=spans[-1], logits_all=logits, spans_all=spans)
+        pq = vid_sum = None
+        if c.contrastive_align_loss:
+            ops.linear(hs2, P["proj_q.w"], P["proj_q.b"], out=ws["pq_raw"])
+            pq = ws["pq"]
+            ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
+            self._frame_rows_linear(frame, P["proj_v.w"], P["proj_v.b"], ws["pv_raw"], B, Tv)
+            pv = ws["pv"]
+            ops.l2norm_rows(ws["pv_raw"], out_f32=pv.view(B * Tv, pq.shape[-1]))
+            vid_sum = ops.masked_mean(pv, None, out=ws["vid_sum"])
+            out.update(proj_queries=pq[-1], proj_vid_mem=pv, proj_queries_all=pq)
+        tg = self._inputs[4]
+        pi, ti, cnt, status, cost = ops.hungarian_match(logits.view(nd * B, Q, 2), spans.view(nd * B, Q, 2), tg, c.foreground_label)
+        losses, total = ops.set_criterion(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"], c.foreground_label, P["crit_weights"])
+        self._match = (pi, ti, cnt)
+        out.update(matcher_pred_idx=pi.view(nd, B, -1), matcher_tgt_idx=ti.view(nd, B, -1), matcher_count=cnt.view(nd, B),
+                   matcher_status=status, criterion_losses=losses, localization_loss=total)
+        return out
+
+    def _encode_train(self, feats: Tensor, mask: Tensor, which: str, ws, tw, row_off: int) -> None:
+        """reference model/model_Base.py:544-617 in train mode (dropout 0.8 inside the temporal block)."""
+        c, P = self.cfg, self.P
+        B, T, Kin = feats.shape
+        D, Hh = c.D, c.SA_temporal_heads
+        proj, mod, pe, depth, tag = (("vit_proj", "video_transformer", "pe_video", c.video_transformer_depth, "v") if which == "video"
+                                     else ("ast_proj", "audio_transformer", "pe_audio", c.audio_transformer_depth, "a"))
+        if P[pe].shape[0] < T:
+            raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < T={T}")
+        rows = B * T
+        mflat = mask.reshape(-1)
+        pt = dr.P_TEMPORAL
+        name = "video" if which == "video" else "audio"
+        if self.tc == torch.bfloat16:
+            xin = ops.cast_mask_rows(feats.view(rows, Kin), mflat, tw[tag + ".xin"])
+            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], R=P[pe][:T], r_row_mod=T, out=tw[f"{tag}.0.x0"], tile_skip_mask=mflat)
+        else:
+            x = ops.linear(feats.view(rows, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, R=P[pe][:T], r_row_mod=T,
+                           out=tw[f"{tag}.0.x0"], tile_skip_mask=mflat)
+        for l in range(depth):
+            p, t = f"{mod}.layers.{l}", f"{tag}.{l}"
+            x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[t + ".x1"], row_skip=mflat)
+            qkv = ops.linear(x1, P[p + ".in.w"], P[p + ".in.b"], out=tw[t + ".qkv"], tile_skip_mask=mflat)
+            q3 = qkv.view(B, T, 3 * D)
+            att = tw[t + ".att"]
+            ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), Hh, key_mask=mask, q_skip_mask=mask,
+                          lse=tw[t + ".lse"], drop=self._drop(f"{name}.{l}.attn", pt))
+            x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=tw[t + ".x2"], tile_skip_mask=mflat)
+            x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[t + ".x3"], row_skip=mflat)
+            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=tw[t + ".h"], Zout=tw[t + ".z1"], tile_skip_mask=mflat,
+                           drop=self._drop(f"{name}.{l}.ffn_act", pt))
+            nxt = tw[f"{tag}.{l + 1}.x0"] if l + 1 < depth else tw[tag + ".xlast"]
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=nxt, tile_skip_mask=mflat, drop=self._drop(f"{name}.{l}.ffn_out", pt))
+        local = ws["fus"][:, row_off:row_off + T]
+        ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat, tile_skip_mask=mflat,
+                   segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
+        vec = ws["video"] if which == "video" else ws["music"]
+        ops.masked_mean(local, mask, out=tw[tag + ".mean"])
+        ops.l2norm_rows(tw[tag + ".mean"], out_f32=vec)
+
+    def _xpool_train(self, video: Tensor, seg: Tensor, seg_mask: Optional[Tensor], ws, tw, B: int, S: int) -> None:
+        """reference modules/transformer.py:156-180 (+ :87-123) over the batch's B x B pairs, dropout 0.3 on linear_out."""
+        P, D = self.P, self.cfg.D
+        skip = seg_mask.reshape(-1) if seg_mask is not None else None
+        v1 = ops.layernorm(video, P["xa.ln1.g"], P["xa.ln1.b"], out=tw["xv1"])
+        q = ops.linear(v1, P["xa.q.w"], P["xa.q.b"], out=tw["xq"])
+        s1 = ops.layernorm(seg, P["xa.ln1.g"], P["xa.ln1.b"], out=tw["xs1"], row_skip=skip)
+        ops.linear(s1, P["xa.kv.w"], P["xa.kv.b"], tile_skip_mask=skip, segs=[Seg(out=tw["xk"], col_begin=0), Seg(out=tw["xu"], col_begin=D)])
+        ops.attention_wide(q.view(1, B, 1, D), tw["xk"].view(B, S, D), tw["xu"].view(B, S, D), tw["xo"].view(B, B, 1, D),
+                           scale=1.0 / math.sqrt(D), key_mask=seg_mask, shared_q=True)
+        a2 = ops.linear(tw["xo"], P["xa.out.w"], P["xa.out.b"], out=tw["xa2"])
+        a3 = ops.layernorm(a2, P["xa.ln2.g"], P["xa.ln2.b"], out=tw["xa3"])
+        y = ops.linear(a3, P["xa.lin.w"], P["xa.lin.b"], R=a3, out=tw["xy"], drop=self._drop("xa.linear_out", dr.P_XPOOL))
+        ops.xpool_tail(y, P["xa.ln3.g"], P["xa.ln3.b"], video, ws["sims_single"], B, B)
+
+    # ================================================================== backward
+    def _lin_bwd(self, dz: Tensor, x: Tensor, key: str, *, dx_out: Optional[Tensor] = None, row_mask: Optional[Tensor] = None,
+                 skip: Optional[Tensor] = None, gw: Optional[Tensor] = None, gb: Optional[Tensor] = None, wt: Optional[Tensor] = None,
+                 **kw) -> Optional[Tensor]:
+        """Linear backward: dW += dz^T x, db += colsum(dz), dx = dz W (with the epilogue options of ops.linear)."""
+        tr.gemm_tn(dz, x, self.G[key + ".w"] if gw is None else gw, accumulate=True, colsum=self.G[key + ".b"] if gb is None else gb,
+                   row_mask=row_mask)
+        if dx_out is None:
+            return None
+        return ops.linear(dz, self.P[key + ".wt"] if wt is None else wt, None, out=dx_out, tile_skip_mask=skip, **kw)
+
+    @torch.no_grad()
+    def backward(self, g_ret: Optional[Tensor] = None, g_loc: Optional[Tensor] = None, zero_grad: bool = True) -> None:
+        """Gradients of g_ret * retrieval_loss + g_loc * localization_loss (device scalars, default 1) into `flat_grad`."""
+        c, P, G = self.cfg, self.P, self.G
+        B, Tv, Ta = self._shape
+        ws, tw = self._buffers(B, Tv, Ta), self._train_buffers(B, Tv, Ta)
+        feats_v, feats_a, fm, sm, tg = self._inputs
+        D, L, Q, nd, ne, H = c.D, Tv + Ta, c.num_moment_queries, c.detr_dec_layers, c.detr_enc_layers, c.detr_nheads
+        hd, HQ = D // H, H * Q
+        pd = float(c.detr_dropout)
+        inv_keep = 1.0 / (1.0 - pd) if (self.training_dropout and pd > 0) else 1.0
+        fus, fus_mask = ws["fus"], ws["fus_mask"]
+        fskip = fus_mask.view(-1)
+        rows = B * L
+        if zero_grad:
+            self.flat_grad.zero_()
+        dvideo, dmusic = tw["dvideo"], tw["dmusic"]
+        dvideo.zero_(); dmusic.zero_()
+        video, music = ws["video"], ws["music"]
+        frame = fus[:, :Tv]
+
+        # ---------------- criterion + heads
+        logits, spans = ws["logits"], ws["spans"]
+        pi, ti, cnt = self._match
+        pq = ws["pq"] if c.contrastive_align_loss else None
+        vid_sum = ws["vid_sum"] if c.contrastive_align_loss else None
+        if c.contrastive_align_loss:
+            tw["dvid_sum"].zero_()
+        tr.set_criterion_bwd(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"], c.foreground_label, P["crit_weights"], g_loc,
+                             tw["dlog"], tw["dsp"], tw["dpq"] if pq is not None else None, tw["dvid_sum"] if pq is not None else None,
+                             ld_out=8, through_sigmoid=True)
+        hs2 = ws["hs"].view(nd * B * Q, D)
+        dhs = tw["dhs"]
+        dlog, dsp = tw["dlog"], tw["dsp"]
+        if self.tc != torch.float32:                          # same dtype as the activations for the A^T B products
+            dlog, dsp = tr.add3(tw["dlog_c"], dlog), tr.add3(tw["dsp_c"], dsp)
+        tr.gemm_tn(dlog[:, :2], hs2, G["class_embed.w"], accumulate=True, colsum=G["class_embed.b"])
+        ops.linear(dlog, P["class_embed.wt"], None, out=dhs)
+        tr.gemm_tn(dsp[:, :2], tw["h2"], G["span_embed.2.w"], accumulate=True, colsum=G["span_embed.2.b"])
+        dz2 = ops.linear(dsp, P["span_embed.2.wt"], None, out=tw["hg1"], gate=_lib.GATE_RELU_OUT, G=tw["h2"])
+        dz1 = self._lin_bwd(dz2, tw["h1"], "span_embed.1", dx_out=tw["hg2"], gate=_lib.GATE_RELU_OUT, G=tw["h1"])
+        self._lin_bwd(dz1, hs2, "span_embed.0", dx_out=dhs, R=dhs)
+        if c.contrastive_align_loss:
+            Dc = pq.shape[-1]
+            tr.l2norm_bwd(ws["pq_raw"], tw["dpq"], dx_alt=tw["dpq_raw"])
+            self._lin_bwd(tw["dpq_raw"], hs2, "proj_q", dx_out=dhs, R=dhs)
+            # proj_vid_mem: every frame (padded ones too) receives d vid_sum (reference loss_detr.py:118)
+            tr.l2norm_bwd(ws["pv_raw"], tw["dvid_sum"], dx_alt=tw["dpv_raw"], dy_rows_per=Tv)
+            tr.gemm_tn(tw["dpv_raw"][:Tv], frame[0], G["proj_v.w"], accumulate=True, colsum=G["proj_v.b"], batch=(B, 1),
+                       a_zs=(Tv * Dc, 0), b_zs=(frame.stride(0), 0), colsum_zs=(0, 0))
+            ops.linear(tw["dpv_raw"], P["proj_v.wt"], None, out=tw["dframe_x"])
+
+        # ---------------- decoder, last layer first
+        qp = P["query_embed"]
+        mem3, mempos3 = tw["mem"].view(B, L, D), tw["mempos"].view(B, L, D)
+        Lp = tw["PdS"].shape[-1]
+        GQ, PdS = tw["GQ"], tw["PdS"]
+        ca_scale = 1.0 / math.sqrt(hd)
+        dtgt = None
+        for l in range(nd - 1, -1, -1):
+            p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
+            g1, g2, g3, g4 = tw["dg1"], tw["dg2"], tw["dg3"], tw["dg4"]
+            Win, Wt = P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
+            gWin, gbin = G[p + ".ca.in.w"], G[p + ".ca.in.b"]
+            # hs_l = dec.norm(t3); t3 also feeds the next layer
+            tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
+            # t3 = LN3(t2 + drop3(ffn))
+            tr.layernorm_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], g1, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"],
+                             dx_drop=g3, drop=self._drop(f"dec.{l}" + ".drop3", pd))
+            dz = self._lin_bwd(g3, tw[d + ".h"], p + ".ff2", dx_out=tw["dgffn"], gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
+            dt2 = self._lin_bwd(dz, tw[d + ".t2"], p + ".ff1", dx_out=g1, R=g2)
+            # t2 = LN2(t1 + drop2(cross-attention))
+            tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"],
+                             dx_drop=g3, drop=self._drop(f"dec.{l}" + ".drop2", pd))
+            dattc = self._lin_bwd(g3, tw[d + ".attc"], p + ".ca.out", dx_out=g4)
+            tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], gbin[2 * D:], tw["d_ds"], H)
+            pooled = tw[d + ".pooled"]
+            # v_h = W_v,h pooled_h : dW_v,h += dattc_h^T pooled_h ; dpooled_h = dattc_h W_v,h
+            tr.gemm_tn(dattc[:, :hd], pooled[:, :D], gWin[2 * D:2 * D + hd], accumulate=True, batch=(H, 1),
+                       a_zs=(hd, 0), b_zs=(D, 0), c_zs=(hd * D, 0))
+            dpooled = GQ[:, 0, l]                             # [B, H*Q, D] slice of the concatenated buffer
+            ops.linear(dattc[:, :hd], Wt[:, 2 * D:2 * D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
+                       segs=[Seg(out=dpooled, ldo=D, rows_per_batch=Q, out_batch_stride=dpooled.stride(0), out_z_stride=Q * D)])
+            # scores and dPd of the memory-space attention (few rows per sample: materialised)
+            qprime = GQ[:, 1, l]
+            S, dP = tw["dS_S"], tw["dS_dP"]
+            ops.linear(qprime[0], mempos3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=qprime.stride(0), w_z_stride=L * D,
+                       segs=[Seg(out=S, ldo=Lp, out_z_stride=HQ * Lp)])
+            ops.linear(dpooled[0], mem3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=dpooled.stride(0), w_z_stride=L * D,
+                       segs=[Seg(out=dP, ldo=Lp, out_z_stride=HQ * Lp)])
+            tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=tw["d_ds"].view(-1),
+                           drop=self._drop(f"dec.{l}" + ".ca_attn", pd), ldo=Lp, ldt=HQ, out_batch_stride=PdS.stride(0))
+            # dq'[b] = dS[b] (mem + pos)[b]
+            dq = tw["dgq"]
+            tr.gemm_tn(tw["dSt"][0], mempos3[0], dq[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
+                       row_mask=fus_mask, mask_zs=(L, 0))
+            # q'_h = W_k,h^T qc_h : dW_k,h += qc_h^T dq'_h ; dqc_h = dq'_h W_k,h^T
+            qc = tw[d + ".qc"]
+            dq2 = dq.view(B * Q, H * D)
+            tr.gemm_tn(qc[:, :hd], dq2[:, :D], gWin[D:D + hd], accumulate=True, batch=(H, 1), a_zs=(hd, 0), b_zs=(D, 0), c_zs=(hd * D, 0))
+            dqc = g3
+            ops.linear(dq2[:, :D], Win[D:D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
+                       segs=[Seg(out=dqc, ldo=D, out_z_stride=hd)])
+            # qc = W_q (t1 + qp) + b_q
+            tr.gemm_tn(dqc, tw[d + ".t1q"], gWin[:D], accumulate=True, colsum=gbin[:D])
+            dt1q = ops.linear(dqc, Wt[:, :D], None, out=g4)
+            tr.colsum(dt1q, G["query_embed"].view(-1))
+            tr.add3(g1, g2, dt1q)                             # dt1 = residual path + query path
+            # t1 = LN1(tgt + drop1(self-attention))
+            tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
+                             dx_drop=g3, drop=self._drop(f"dec.{l}" + ".drop1", pd))
+            datt = self._lin_bwd(g3, tw[d + ".att"], p + ".sa.out", dx_out=g4)
+            qkv, gqkv = tw[d + ".qkv"], tw["dgqkv"]
+            q3, g3v = qkv.view(B, Q, 3 * D), gqkv.view(B, Q, 3 * D)
+            tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), datt.view(B, Q, D),
+                             g3v[:, :, :D], g3v[:, :, D:2 * D], g3v[:, :, 2 * D:], tw[d + ".lse"], tw["d_delta"], H,
+                             drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+            gW, gb = G[p + ".sa.in.w"], G[p + ".sa.in.b"]
+            tr.gemm_tn(gqkv[:, :2 * D], tw[d + ".tq"], gW[:2 * D], accumulate=True, colsum=gb[:2 * D])
+            tr.gemm_tn(gqkv[:, 2 * D:], tw[d + ".tgt"], gW[2 * D:], accumulate=True, colsum=gb[2 * D:])
+            dtgt = ops.linear(gqkv, P[p + ".sa.in.wt"], None, R=g2, out=tw["dtgt"])
+            if Q > 1 or True:                                 # the query embedding also enters through q,k of the self-attention
+                dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
+                tr.colsum(dqk, G["query_embed"].view(-1))
+        (dvideo if c.moment_query_type == "video" else dmusic).copy_(dtgt.view(B, D).float()) if Q == 1 else None
+        # gradient of the memory: values path (Pd^T dpooled) + keys path (dS^T q'), all layers in one product per sample
+        dmem = tw["eg1"]
+        tr.gemm_tn(PdS.view(B, 2 * nd * HQ, Lp)[0, :, :L], GQ.view(B, 2 * nd * HQ, D)[0], dmem.view(B, L, D)[0], batch=(B, 1),
+                   a_zs=(PdS.stride(0), 0), b_zs=(GQ.stride(0), 0), c_zs=(L * D, 0))
+
+        # ---------------- DETR encoder
+        dsrc = dmem
+        for l in range(ne - 1, -1, -1):
+            p, e = f"detr_transformer.encoder.layers.{l}", f"e.{l}"
+            g2, g3, gq, gf = tw["eg2"], tw["eg3"], tw["egqkv"], tw["egffn"]
+            src = fus.view(rows, D) if l == 0 else tw[e + ".src"]
+            srcpos = tw[e + ".srcpos"]
+            # src_{l+1} = LN2(s1 + drop2(ffn))
+            tr.layernorm_bwd(tw[e + ".x2"], P[p + ".ln2.g"], dsrc, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"], dx_drop=g3,
+                             drop=self._drop(f"enc.{l}" + ".drop2", pd), row_skip=fskip)
+            dz = self._lin_bwd(g3, tw[e + ".h"], p + ".ff2", dx_out=gf, row_mask=fskip, skip=fskip, gate=_lib.GATE_RELU_OUT, G=tw[e + ".h"],
+                               gate_scale=inv_keep)
+            ds1 = self._lin_bwd(dz, tw[e + ".s1"], p + ".ff1", dx_out=g3, row_mask=fskip, skip=fskip, R=g2)
+            # s1 = LN1(src + drop1(attention))
+            dx = tw["eg1"] if dsrc is not tw["eg1"] else tw["dfus"]
+            tr.layernorm_bwd(tw[e + ".x"], P[p + ".ln1.g"], ds1, dx, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], dx_drop=g2,
+                             drop=self._drop(f"enc.{l}" + ".drop1", pd), row_skip=fskip)
+            datt = self._lin_bwd(g2, tw[e + ".att"], p + ".out", dx_out=g3, row_mask=fskip, skip=fskip)
+            qkv = tw[e + ".qkv"]
+            q3, gq3 = qkv.view(B, L, 3 * D), gq.view(B, L, 3 * D)
+            tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[e + ".att"].view(B, L, D), datt.view(B, L, D),
+                             gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[e + ".lse"], tw["e_delta"], H,
+                             key_mask=fus_mask, q_skip_mask=fus_mask, drop=self._drop(f"enc.{l}" + ".attn", pd))
+            gW, gb = G[p + ".in.w"], G[p + ".in.b"]
+            tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], row_mask=fskip)
+            tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], row_mask=fskip)
+            nxt = tw["dfus"] if dx is tw["eg1"] else tw["eg1"]
+            dsrc = ops.linear(gq, P[p + ".in.wt"], None, R=dx, out=nxt, tile_skip_mask=fskip)
+        dfus = dsrc.view(B, L, D)
+
+        # ---------------- X-Pool + similarities + retrieval loss
+        self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
+
+        # ---------------- temporal encoders
+        self._encode_bwd("video", ws, tw, dfus[:, :Tv], tw["dframe_x"].view(B, Tv, D) if c.contrastive_align_loss else None, dvideo, fm, feats_v)
+        self._encode_bwd("audio", ws, tw, dfus[:, Tv:], tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a)
+
+    def _retrieval_bwd(self, ws, tw, g_ret: Optional[Tensor], B: int, S: int, sm: Tensor) -> None:
+        c, P, G, D = self.cfg, self.P, self.G, self.cfg.D
+        video, music = ws["video"], ws["music"]
+        dvideo, dmusic = tw["dvideo"], tw["dmusic"]
+        ls, gls = P["logit_scale"], G["logit_scale"]
+        wgt = float(c.dual_single_loss_weight)
+        ds_s, ds_d, ds_dt, cws = tw["dsims_s"], tw["dsims_d"], tw["dsims_dt"], tw["clip_ws"]
+        single = dual = False
+        if c.vmr_loss == "dual":
+            tr.clip_loss_bwd(ws["sims_dual"], ls, wgt, g_ret, cws, ds_d, ds_dt, gls); dual = True
+        elif c.vmr_loss == "single":
+            tr.clip_loss_bwd(ws["sims_single"], ls, wgt, g_ret, cws, ds_s, None, gls); single = True
+        elif c.vmr_loss == "dual_single_loss_fuse":
+            tr.clip_loss_bwd(ws["sims_dual"], ls, 1.0, g_ret, cws, ds_d, ds_dt, gls)
+            tr.clip_loss_bwd(ws["sims_single"], ls, 1.0, g_ret, cws, ds_s, None, gls)
+            single = dual = True
+        else:                                                # dual_single_sim_fuse: one loss on the summed similarities
+            both = tr.add3(tw["sims_both"], ws["sims_dual"], ws["sims_single"])
+            tr.clip_loss_bwd(both, ls, wgt, g_ret, cws, ds_d, ds_dt, gls)
+            ds_s.copy_(ds_d)
+            single = dual = True
+        seg_mask = sm if c.fusion_mask == 1 else None
+        skip = seg_mask.reshape(-1) if seg_mask is not None else None
+        if single:
+            g1, g2, g3 = tw["xg1"], tw["xg2"], tw["xg3"]
+            tr.xpool_tail_bwd(tw["xy"], P["xa.ln3.g"], P["xa.ln3.b"], video, ds_s, g1, B, B, dy_drop=g2, drop=self._drop("xa.linear_out", dr.P_XPOOL),
+                              dgamma=G["xa.ln3.g"], dbeta=G["xa.ln3.b"], dvideo=dvideo)
+            da3 = self._lin_bwd(g2, tw["xa3"], "xa.lin", dx_out=g3, R=g1)
+            tr.layernorm_bwd(tw["xa2"], P["xa.ln2.g"], da3, g1, dgamma=G["xa.ln2.g"], dbeta=G["xa.ln2.b"])
+            do = self._lin_bwd(g1, tw["xo"], "xa.out", dx_out=g2)
+            Sp = tw["xS"].shape[1]
+            xk, xu, q = tw["xk"], tw["xu"], tw["xq"]
+            ops.linear(q, xk[:S], None, M=B, N=S, K=D, batch=B, a_z_stride=0, w_z_stride=S * D, segs=[Seg(out=tw["xS"], ldo=Sp, out_z_stride=B * Sp)])
+            ops.linear(do[:B], xu[:S], None, M=B, N=S, K=D, batch=B, a_z_stride=B * D, w_z_stride=S * D, segs=[Seg(out=tw["xdP"], ldo=Sp, out_z_stride=B * Sp)])
+            tr.softmax_bwd(tw["xS"], tw["xdP"], seg_mask, B, 1.0 / math.sqrt(D), tw["xP"], tw["xdS"], tw["xdSt"], B, S, ldo=Sp, ldt=B)
+            dkv = tw["xdkv"]
+            # dU[m] = P[m]^T dO[m];  dK[m] = dS[m]^T q;  dq = sum_m dS[m] K[m]
+            tr.gemm_tn(tw["xP"][:B, :S], do[:B], dkv[:S, D:], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(B * D, 0), c_zs=(S * 2 * D, 0))
+            tr.gemm_tn(tw["xdS"][:B, :S], q, dkv[:S, :D], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(0, 0), c_zs=(S * 2 * D, 0))
+            tw["xdq32"].zero_()
+            tr.gemm_tn(tw["xdSt"][0], xk[:S], tw["xdq32"], batch=(B, 1), a_zs=(S * B, 0), b_zs=(S * D, 0), c_zs=(0, 0), accumulate=True,
+                       row_mask=seg_mask, mask_zs=(S, 0))
+            ds1 = self._lin_bwd(dkv, tw["xs1"], "xa.kv", dx_out=tw["xds1"], row_mask=skip, skip=skip)
+            seg = ws["fus"][:, self._shape[1]:]
+            tr.layernorm_bwd(seg, P["xa.ln1.g"], ds1, tw["xdseg"], dgamma=G["xa.ln1.g"], dbeta=G["xa.ln1.b"], row_skip=skip)
+            dq = tr.add3(tw["xdq"], tw["xdq32"])
+            dv1 = self._lin_bwd(dq, tw["xv1"], "xa.q", dx_out=tw["xdv1"])
+            tr.layernorm_bwd(video, P["xa.ln1.g"], dv1, dvideo, dgamma=G["xa.ln1.g"], dbeta=G["xa.ln1.b"], add=dvideo)
+        else:
+            tw["xdseg"].zero_()
+        if dual:
+            tr.gemm_tn(ds_dt, tw["mn"], tw["dvn"])            # d vhat = dsims mhat
+            tr.gemm_tn(ds_d, tw["vn"], tw["dmn"])             # d mhat = dsims^T vhat
+            tr.l2norm_bwd(video, tw["dvn"], dvideo, accumulate=True)
+            tr.l2norm_bwd(music, tw["dmn"], dmusic, accumulate=True)
+
+    def _encode_bwd(self, which: str, ws, tw, d_local: Tensor, d_extra: Optional[Tensor], dvec: Tensor, mask: Tensor, feats: Tensor) -> None:
+        c, P, G = self.cfg, self.P, self.G
+        B, T, Kin = feats.shape
+        D, Hh = c.D, c.SA_temporal_heads
+        proj, mod, depth, tag = (("vit_proj", "video_transformer", c.video_transformer_depth, "v") if which == "video"
+                                 else ("ast_proj", "audio_transformer", c.audio_transformer_depth, "a"))
+        name = "video" if which == "video" else "audio"
+        rows = B * T
+        mflat = mask.reshape(-1)
+        pt = dr.P_TEMPORAL
+        dl = tw[tag + ".dl"]
+        tr.pool_bwd(tw[tag + ".mean"], dvec, mask, dl.view(B, T, D), in1=d_local, in2=d_extra)
+        g1, g2, g3, gq, gf = tw[tag + ".g1"], tw[tag + ".g2"], tw[tag + ".g3"], tw[tag + ".gqkv"], tw[tag + ".gffn"]
+        # local = mask(final(x4)); x4 = x3 + drop(ffn2): the product dl W_f is needed raw (residual) and dropped (branch)
+        x_last = tw[tag + ".xlast"]
+        dx = None
+        for l in range(depth - 1, -1, -1):
+            p, t = f"{mod}.layers.{l}", f"{tag}.{l}"
+            x4 = x_last if l == depth - 1 else tw[f"{tag}.{l + 1}.x0"]
+            if l == depth - 1:
+                df = self._lin_bwd(dl, x4, mod + ".final", dx_out=g1, row_mask=mflat, skip=mflat, Zout=g2,
+                                   drop=self._drop(f"{name}.{l}.ffn_out", pt))
+                dx4 = g2
+            else:                                            # deeper stacks: x0_{l+1} = x4_l, its gradient arrives from LN1 of layer l+1
+                dx4 = dx
+                df = tr.add3(g1, dx4) if not self.training_dropout else self._dropped_copy(g1, dx4, f"{name}.{l}.ffn_out", pt, D)
+            dz1 = self._lin_bwd(df, tw[t + ".h"], p + ".ff2", dx_out=gf, row_mask=mflat, skip=mflat, gate=_lib.GATE_GELU_Z, G=tw[t + ".z1"],
+                                drop=self._drop(f"{name}.{l}.ffn_act", pt))
+            dx3 = self._lin_bwd(dz1, tw[t + ".x3"], p + ".ff1", dx_out=g3, row_mask=mflat, skip=mflat, R=dx4)
+            tr.layernorm_bwd(tw[t + ".x2"], P[p + ".ln2.g"], dx3, g1, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"], row_skip=mflat)
+            datt = self._lin_bwd(g1, tw[t + ".att"], p + ".out", dx_out=g2, row_mask=mflat, skip=mflat)
+            qkv = tw[t + ".qkv"]
+            q3, gq3 = qkv.view(B, T, 3 * D), gq.view(B, T, 3 * D)
+            tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[t + ".att"].view(B, T, D), datt.view(B, T, D),
+                             gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[t + ".lse"], tw[tag + ".delta"], Hh,
+                             key_mask=mask, q_skip_mask=mask, drop=self._drop(f"{name}.{l}.attn", pt))
+            dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3, row_mask=mflat, skip=mflat, R=g1)
+            dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
+        xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
+        tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], row_mask=mflat)
+
+    def _dropped_copy(self, out: Tensor, x: Tensor, site: str, p: float, ld: int) -> Tensor:
+        raise NotImplementedError("temporal transformer depth > 1 is not covered by the training path yet")
+
+    # ================================================================== convenience
+    def loss_and_grads(self, inp: dict, seed: int = 0, w_ret: float = 1.0, w_loc: float = 1.0) -> dict:
+        """numpy in, numpy out (synchronises): losses and all parameter gradients of w_ret*retrieval + w_loc*localization."""
+        dev = self.device
+        t = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
+        o = self.forward_train(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=seed)
+        gr = torch.tensor([w_ret], device=dev) if w_ret != 1.0 else None
+        gl = torch.tensor([w_loc], device=dev) if w_loc != 1.0 else None
+        self.backward(gr, gl)
+        torch.cuda.synchronize()
+        return dict(retrieval_loss=float(o["retrieval_loss"].cpu()), localization_loss=float(o["localization_loss"].cpu()),
+                    grads=self.grads_numpy(), loss_dict={k: float(v.cpu()) for k, v in self.loss_dict(o).items()})

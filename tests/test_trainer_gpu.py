@@ -1,0 +1,111 @@
+"""GPU: the training path (forward in train mode + hand-written backward) against the oracle's autograd.
+
+The oracle (oracle/made_oracle.py) is pinned to the reference's autograd in float64 (tests/golden/VALIDATION.json,
+tests/golden/train_native_B3.npz); here every parameter gradient of the HIP path is compared with it on the same seeded
+inputs and the same stateless dropout masks.  f32 path: relative L2 error per tensor <= 2e-3 (a ReLU input within rounding
+noise of 0 may take the other side, which moves a whole row; measured errors are ~1e-5) and losses to 1e-4.  bf16 path:
+cosine similarity of every gradient tensor >= 0.99 and losses within 2e-2 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, Tv, Ta, overrides=None):
+    from mgsv_amd import synth
+    from mgsv_amd.config import cfg_native
+    cfg = cfg_native()
+    for k, v in (overrides or {}).items():
+        setattr(cfg, k, v)
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, B, Tv, Ta, seed=1)
+    return cfg, sd, inp
+
+
+def _oracle(cfg, sd, inp, seed, dropout, names, double=True):
+    from oracle import made_oracle as O
+    P = O.to_torch_params(sd)
+    if double:
+        P = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    for n in names:
+        P[n].requires_grad_(True)
+    drop = O.Drop(seed, p_detr=cfg.detr_dropout) if dropout else None
+    r = O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"], inp["spans_target"],
+                  v_duration=inp["v_duration"], drop=drop)
+    (r["retrieval_loss"] + r["localization_loss"]).backward()
+    return r, {n: (P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])) for n in names}
+
+
+def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
+    assert abs(res["retrieval_loss"] - float(r["retrieval_loss"])) <= loss_tol * max(1.0, abs(float(r["retrieval_loss"])))
+    assert abs(res["localization_loss"] - float(r["localization_loss"])) <= loss_tol * max(1.0, abs(float(r["localization_loss"])))
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    worst = []
+    for n, g in grads.items():
+        ref = g.double().numpy().reshape(-1)
+        got = res["grads"][n].astype(np.float64).reshape(-1)
+        assert np.isfinite(got).all(), n
+        nr = np.linalg.norm(ref)
+        if nr < 1e-6 * gmax * np.sqrt(ref.size):            # theoretically zero gradients (e.g. the key bias): absolute check
+            assert np.abs(got).max() <= 1e-4 * gmax, (n, np.abs(got).max())
+            continue
+        if cos_min is not None:
+            cos = float(got @ ref / (np.linalg.norm(got) * nr + 1e-30))
+            worst.append((1 - cos, n))
+            assert cos >= cos_min, (n, cos)
+        else:
+            rel = float(np.linalg.norm(got - ref) / nr)
+            worst.append((rel, n))
+            assert rel <= rel_tol, (n, rel)
+    return sorted(worst)[-3:]
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+@pytest.mark.parametrize("overrides", [{}, {"vmr_loss": "dual_single_sim_fuse", "moment_query_type": "music"}])
+def test_f32_gradients_match_oracle_autograd(dropout, overrides):
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, inp = _setup(3, 20, 40, overrides)
+    trn = MadeTrainer(cfg, sd, dtype="f32")
+    trn.training_dropout = dropout
+    res = trn.loss_and_grads(inp, seed=1234)
+    r, grads = _oracle(cfg, sd, inp, 1234, dropout, trn.param_names)
+    print(_compare(res, r, grads, rel_tol=2e-3, loss_tol=1e-4))
+
+
+def test_f32_gradients_match_reference_fixture(golden_dir):
+    """straight against the reference's own autograd (float64 fixture made by tests/golden/make_golden.py)."""
+    from mgsv_amd.trainer import MadeTrainer
+    fix = np.load(os.path.join(golden_dir, "train_native_B3.npz"))
+    cfg, sd, inp = _setup(int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"]))
+    trn = MadeTrainer(cfg, sd, dtype="f32")
+    for mode, dropout in (("train", True), ("eval", False)):
+        trn.training_dropout = dropout
+        res = trn.loss_and_grads(inp, seed=int(fix["meta_dropout_seed"]))
+        assert abs(res["retrieval_loss"] - float(fix[f"{mode}.retrieval_loss"])) <= 1e-4
+        assert abs(res["localization_loss"] - float(fix[f"{mode}.localization_loss"])) <= 2e-4
+        names = [k[len(mode) + 7:] for k in fix.files if k.startswith(mode + ".gnorm.")]
+        gmax = max(float(fix[f"{mode}.gnorm.{n}"]) / np.sqrt(res["grads"][n].size) for n in names)
+        for n in names:
+            g = res["grads"][n].reshape(-1).astype(np.float64)
+            step = max(1, g.size // 512)
+            ref = fix[f"{mode}.gsample.{n}"].astype(np.float64)
+            nr = float(fix[f"{mode}.gnorm.{n}"])
+            if nr < 1e-6 * gmax * np.sqrt(g.size):
+                continue
+            assert abs(np.linalg.norm(g) - nr) <= 2e-3 * nr, (mode, n)
+            s = g[::step][:512]
+            assert np.linalg.norm(s - ref) <= 5e-3 * max(np.linalg.norm(ref), 1e-3 * nr), (mode, n)
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_bf16_gradients_close_to_oracle(dropout):
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, inp = _setup(4, 20, 40)
+    trn = MadeTrainer(cfg, sd, dtype="bf16")
+    trn.training_dropout = dropout
+    res = trn.loss_and_grads(inp, seed=77)
+    r, grads = _oracle(cfg, sd, inp, 77, dropout, trn.param_names, double=False)
+    print(_compare(res, r, grads, rel_tol=None, loss_tol=2e-2, cos_min=0.99))
