@@ -244,15 +244,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
         const TA* A2 = has_a2 ? (const TA*)a.A2 : nullptr;
         const TC* W = (const TC*)a.W + z * a.w_z_stride;
         const int a2mod = (int)a.a2_row_mod;
+        const int kce = kc * PER16 < K ? kc * PER16 : 0;      // rows shorter than one slab (K < 64 / 32): stay inside the row
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = m0 + srow0 + 32 * i, gn = n0 + srow0 + 32 * i;
             const int gmc = gm < M ? gm : M - 1, gnc = gn < N ? gn : N - 1;       // clamped: every lane always loads
             ka[i] = gm < M && (a.a_row_mask == nullptr || a.a_row_mask[gmc] != 0.f);
             kw[i] = gn < N;
-            pa[i] = A + (int64_t)gmc * lda + kc * PER16;
-            pa2[i] = A2 ? A2 + (int64_t)(a2mod > 0 ? gmc % a2mod : gmc) * a.lda2 + kc * PER16 : nullptr;
-            pw[i] = W + (int64_t)gnc * a.ldw + kc * PER16;
+            pa[i] = A + (int64_t)gmc * lda + kce;
+            pa2[i] = A2 ? A2 + (int64_t)(a2mod > 0 ? gmc % a2mod : gmc) * a.lda2 + kce : nullptr;
+            pw[i] = W + (int64_t)gnc * a.ldw + kce;
         }
     }
     frag_t ra[4], rw[4];
