@@ -42,10 +42,11 @@ def parse():
     p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--launch", choices=["graph", "eager"], default="graph")
-    p.add_argument("--workload", choices=["forward", "retrieval"], default="forward")
+    p.add_argument("--workload", choices=["forward", "retrieval", "train"], default="forward")
     p.add_argument("--nv", type=int, default=53000)
     p.add_argument("--nm", type=int, default=4000)
     p.add_argument("--seg", type=int, default=96)
+    p.add_argument("--ta", type=int, default=0, help="train workload: number of music segments (default: configs[1]'s 512)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=2)
     return p.parse_args()
@@ -125,6 +126,76 @@ def retrieval_main(args, rank, world, local, dist):
                        "pairs_per_s": round(pairs / sec, 1), "algorithmic_gb": round(alg_bytes / 1e9, 3)}}))
 
 
+def train_main(args, rank, world, local, dist):
+    """BASELINE.json configs[2] (N = 1) / configs[4] (N > 1, per-rank B = 64): one full training iteration per step --
+    train-mode forward (dropout on), matcher + criterion, hand-written backward, data-parallel gradient all-reduce (RCCL, one
+    flat f32 buffer), three-group clipping + Adam, re-derivation of the bf16 weights (reference train-MaDe.py:337-381)."""
+    from mgsv_amd.trainer import MadeTrainer
+    cfg = cfg_headline()
+    if args.ta:
+        cfg.max_snippet_num = args.ta
+        cfg.audio_attention_seqlen = max(cfg.audio_attention_seqlen, args.ta)
+    B, Tv, Ta = args.batch, cfg.max_v_frames, cfg.max_snippet_num
+    dev = torch.device("cuda", local)
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, B, Tv, Ta, seed=1 + rank)
+    trn = MadeTrainer(cfg, sd, device=dev, dtype=args.dtype)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
+    it = [0]
+
+    def step():
+        it[0] += 1
+        return trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
+                              seed=it[0], lrs=(1e-4, 1e-4, 1e-4), max_grad_norm=1.0, dist=dist)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    assert bool(torch.isfinite(out["localization_loss"]).all()) and bool(torch.isfinite(out["retrieval_loss"]).all())
+    assert bool(torch.isfinite(trn.flat_param).all())
+    per_kernel, roof = {}, None
+    if rank == 0:
+        with ops.KernelTimer() as kt:
+            for _ in range(2):
+                step()
+        summ = kt.summary()
+        for k, v in summ.items():
+            per_kernel[k] = dict(launches_per_step=v["launches"] // 2, ms_per_step=round(v["ms"] / 2, 4),
+                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))
+        mm = [k for k in summ if k.startswith("linear_") or k == "made_gemm_tn"]
+        fl = sum(summ[k]["flops"] for k in mm)
+        ms_ = sum(summ[k]["ms"] for k in mm)
+        peak = PEAK_TFLOPS[args.dtype]
+        roof = dict(bound="mfma", kernel="made_linear + made_gemm_tn (all GEMMs of the step)", achieved=round(fl / (ms_ * 1e-3) / 1e12, 2),
+                    peak=peak, unit="TFLOP/s", frac=round(fl / (ms_ * 1e-3) / 1e12 / peak, 4), traffic=None)
+    if rank == 0:
+        sec = elapsed / args.steps
+        print(json.dumps({
+            "metric": "video-music pairs/s, full training step (fwd + bwd + matcher + clip/Adam), B=64 per GPU",
+            "value": round(world * B / sec, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 4}]: B={B}/GPU, T_v={Tv}, T_a={Ta}, D={cfg.D}, train mode (dropout on), "
+                                   "f32 master weights + Adam, f32 gradient accumulation",
+                       "global_batch": world * B, "parallelism": f"dp{world}: one all-reduce of the flat f32 gradient buffer per step",
+                       "launch": "eager"},
+            "roofline": roof, "cpu_baseline": None, "kernels": per_kernel}))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -138,8 +209,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # backend "nccl" is RCCL on ROCm
 
-    if args.workload == "retrieval":
-        retrieval_main(args, rank, world, local, dist)
+    if args.workload in ("retrieval", "train"):
+        (retrieval_main if args.workload == "retrieval" else train_main)(args, rank, world, local, dist)
         if dist is not None:
             dist.destroy_process_group()
         return

@@ -462,6 +462,29 @@ int made_set_criterion_bwd(const float* pred_logits, const float* pred_spans, co
                            float* d_logits, float* d_spans, int64_t ld_out, int32_t through_sigmoid,
                            float* d_proj_queries, float* d_vid_sum, void* stream);
 
+/* made_adam_step: the optimizer tail of one training iteration on the flat f32 master buffer (reference train-MaDe.py:
+ * 262-266,375-381): for each group the L2 norm of its (grad_scale-scaled) gradient is clipped to max_norm exactly as
+ * nn.utils.clip_grad_norm_ does (coef = max_norm / (norm + 1e-6), capped at 1; max_norm <= 0: no clipping), then
+ * torch.optim.Adam's update (amsgrad off, weight_decay 0) with the group's lr (host-side schedule) and the given step
+ * count (>= 1, for the bias corrections).  Elements outside every group are left untouched (the reference keeps
+ * decoder_query_embed out of the optimizer).  grad_scale folds the 1/world_size of a summed data-parallel all-reduce.
+ * norm_ws: [MADE_ADAM_MAX_GROUPS] f32 device workspace (returns the squared group norms). */
+#define MADE_ADAM_MAX_GROUPS 4
+typedef struct MadeAdamGroup { int64_t begin, end; float lr; float max_norm; } MadeAdamGroup;
+int made_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, int64_t step,
+                   float grad_scale, float* norm_ws, void* stream);
+
+/* made_repack: rebuild the kernel-facing copies of every matrix parameter from the f32 masters in one launch:
+ * w (rows x cols, `dtype`; NULL = the kernels read the master itself) and wt = W^T (cols x wt_ld, wt_ld >= rows; NULL = not
+ * needed).  `descs_device` is a device array sorted by tile_begin (prefix sum of ceil(rows/32)*ceil(cols/32)). */
+typedef struct MadeRepackDesc {
+    const float* src; void* w; void* wt;
+    int64_t rows, cols, wt_ld, tile_begin;
+    int32_t dtype; int32_t _pad;
+} MadeRepackDesc;
+int made_repack(const MadeRepackDesc* descs_device, int32_t n_desc, int64_t total_tiles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

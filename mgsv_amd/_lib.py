@@ -99,6 +99,15 @@ class MadeGemmTNArgs(C.Structure):
                 ("colsum", vp), ("colsum_zs1", i64), ("colsum_zs2", i64)]
 
 
+class MadeAdamGroup(C.Structure):
+    _fields_ = [("begin", i64), ("end", i64), ("lr", f32), ("max_norm", f32)]
+
+
+class MadeRepackDesc(C.Structure):
+    _fields_ = [("src", vp), ("w", vp), ("wt", vp), ("rows", i64), ("cols", i64), ("wt_ld", i64), ("tile_begin", i64),
+                ("dtype", i32), ("_pad", i32)]
+
+
 # name -> (restype, argtypes); every symbol include/made_hip.h declares
 SIGNATURES = {
     "made_abi_version": (C.c_int, []),
@@ -134,6 +143,8 @@ SIGNATURES = {
     "made_colsum": (C.c_int, [vp, i32, i64, i64, i64, vp, vp]),
     "made_set_criterion_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp,
                                          vp, vp, i64, i32, vp, vp, vp]),
+    "made_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, i64, f32, vp, vp]),
+    "made_repack": (C.c_int, [vp, i32, i64, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
     "made_set_criterion": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp, vp, vp]),
 }

@@ -1,0 +1,156 @@
+// Train-step tail of the MaDe path on gfx950: per-group gradient-norm clipping + Adam on the flat f32 master buffer, and the
+// re-derivation of the kernel-facing parameter copies (compute-dtype W and W^T) in one launch each.
+// Replaces, per step, the reference's three nn.utils.clip_grad_norm_ calls, optim.Adam.step() over ~200 tensors and the
+// implicit per-tensor work of autograd (reference train-MaDe.py:262-266,375-381): three launches instead of several hundred.
+#include "common.h"
+
+namespace {
+
+constexpr int OT = 256;
+
+struct AdamArgs {
+    float* param; const float* grad; float* m; float* v; int64_t n;
+    MadeAdamGroup g[MADE_ADAM_MAX_GROUPS]; int n_groups;
+    float beta1, beta2, eps, bc1, bc2_sqrt, grad_scale;
+    float* norm_sq;
+};
+
+__device__ __forceinline__ int group_of(const AdamArgs& a, int64_t i) {
+    int gi = -1;
+#pragma unroll
+    for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k)
+        if (k < a.n_groups && i >= a.g[k].begin && i < a.g[k].end) gi = k;
+    return gi;
+}
+
+// squared L2 norm of every group's (scaled) gradient; one atomic per group per workgroup
+__global__ __launch_bounds__(OT) void grad_norm_kernel(const AdamArgs a) {
+    __shared__ float red[MADE_ADAM_MAX_GROUPS][OT / 64];
+    float acc[MADE_ADAM_MAX_GROUPS];
+#pragma unroll
+    for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) acc[k] = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * OT + threadIdx.x) * 4; i < a.n; i += (int64_t)gridDim.x * OT * 4) {
+        const f32x4 g4 = *(const f32x4*)(a.grad + i);           // n is a multiple of 4 (parameters start on 64-element boundaries)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gi = group_of(a, i + j);
+            const float g = g4[j] * a.grad_scale;
+#pragma unroll
+            for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) acc[k] += (gi == k) ? g * g : 0.f;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) red[k][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < MADE_ADAM_MAX_GROUPS && threadIdx.x < a.n_groups) {
+        float s = 0.f;
+        for (int w = 0; w < OT / 64; ++w) s += red[threadIdx.x][w];
+        unsafeAtomicAdd(a.norm_sq + threadIdx.x, s);
+    }
+}
+
+// g' = clip_coef(group) * grad_scale * g;  m, v, p updated as torch.optim.Adam does (amsgrad off, weight_decay 0)
+__global__ __launch_bounds__(OT) void adam_update_kernel(const AdamArgs a) {
+    float coef[MADE_ADAM_MAX_GROUPS];
+#pragma unroll
+    for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) {
+        coef[k] = 1.f;
+        if (k < a.n_groups && a.g[k].max_norm > 0.f) {
+            const float c = a.g[k].max_norm / (sqrtf(a.norm_sq[k]) + 1e-6f);       // nn.utils.clip_grad_norm_
+            coef[k] = c < 1.f ? c : 1.f;
+        }
+    }
+    for (int64_t i = ((int64_t)blockIdx.x * OT + threadIdx.x) * 4; i < a.n; i += (int64_t)gridDim.x * OT * 4) {
+        const int g0 = group_of(a, i), g3 = group_of(a, i + 3);
+        if (g0 < 0 && g3 < 0) continue;
+        f32x4 g4 = *(const f32x4*)(a.grad + i), m4 = *(const f32x4*)(a.m + i), v4 = *(const f32x4*)(a.v + i), p4 = *(const f32x4*)(a.param + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gi = group_of(a, i + j);
+            if (gi < 0) continue;
+            float cf = 1.f, lr = 0.f;
+#pragma unroll
+            for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k)
+                if (gi == k) { cf = coef[k]; lr = a.g[k].lr; }
+            const float g = g4[j] * a.grad_scale * cf;
+            m4[j] = a.beta1 * m4[j] + (1.f - a.beta1) * g;
+            v4[j] = a.beta2 * v4[j] + (1.f - a.beta2) * g * g;
+            const float denom = sqrtf(v4[j]) / a.bc2_sqrt + a.eps;
+            p4[j] -= (lr / a.bc1) * (m4[j] / denom);
+        }
+        *(f32x4*)(a.m + i) = m4; *(f32x4*)(a.v + i) = v4; *(f32x4*)(a.param + i) = p4;
+    }
+}
+
+// one 32 x 32 tile of one matrix per workgroup: W (cast) and W^T (cast, through LDS so both sides stay coalesced)
+__global__ __launch_bounds__(OT) void repack_kernel(const MadeRepackDesc* descs, int n_desc) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n_desc - 1;
+    const int64_t t = blockIdx.x;
+    while (lo < hi) {                                    // last descriptor whose tile_begin <= t
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile_begin <= t) lo = mid; else hi = mid - 1;
+    }
+    const MadeRepackDesc d = descs[lo];
+    const int64_t local = t - d.tile_begin;
+    const int64_t tc_n = (d.cols + 31) / 32;
+    const int64_t r0 = (local / tc_n) * 32, c0 = (local % tc_n) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int rr = ty; rr < 32; rr += 8) {
+        const int64_t r = r0 + rr, c = c0 + tx;
+        float v = 0.f;
+        if (r < d.rows && c < d.cols) {
+            v = d.src[r * d.cols + c];
+            if (d.w) store_from_f32(d.w, d.dtype, r * d.cols + c, v);
+        }
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    if (d.wt) {
+        for (int cc = ty; cc < 32; cc += 8) {
+            const int64_t c = c0 + cc, r = r0 + tx;
+            if (r < d.rows && c < d.cols) store_from_f32(d.wt, d.dtype, c * d.wt_ld + r, tile[tx][cc]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int made_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, int64_t step,
+                              float grad_scale, float* norm_ws, void* stream) {
+    MADE_REQUIRE(param && grad && exp_avg && exp_avg_sq && groups && norm_ws, "made_adam_step: null pointer");
+    MADE_REQUIRE(n_groups >= 1 && n_groups <= MADE_ADAM_MAX_GROUPS, "made_adam_step: n_groups=%d out of range", n_groups);
+    MADE_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, "made_adam_step: n must be a positive multiple of 4 and step >= 1");
+    AdamArgs a;
+    a.param = param; a.grad = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.n_groups = n_groups;
+    for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) {
+        if (k < n_groups) a.g[k] = groups[k];
+        else { a.g[k].begin = a.g[k].end = 0; a.g[k].lr = 0.f; a.g[k].max_norm = 0.f; }
+    }
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.norm_sq = norm_ws;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(norm_ws, 0, sizeof(float) * MADE_ADAM_MAX_GROUPS, st) != hipSuccess) {
+        made_set_error("made_adam_step: hipMemsetAsync failed");
+        return MADE_ERR_HIP;
+    }
+    int64_t nb = (n / 4 + OT - 1) / OT;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(grad_norm_kernel, dim3((unsigned)nb), dim3(OT), 0, st, a);
+    hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nb), dim3(OT), 0, st, a);
+    return made_check_launch("made_adam_step");
+}
+
+extern "C" int made_repack(const MadeRepackDesc* descs_device, int32_t n_desc, int64_t total_tiles, void* stream) {
+    MADE_REQUIRE(descs_device != nullptr && n_desc >= 1 && total_tiles >= 1, "made_repack: bad arguments");
+    MADE_UNSUPPORTED(total_tiles < (1LL << 31), "made_repack: too many tiles");
+    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)total_tiles), dim3(OT), 0, (hipStream_t)stream, descs_device, (int)n_desc);
+    return made_check_launch("made_repack");
+}

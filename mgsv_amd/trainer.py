@@ -117,6 +117,16 @@ class MadeTrainer(MadeEngine):
         names = [k for k in sd if not k.endswith(".pe") and k != "criterion.empty_weight"]
         pair_after = {XA + ".cross_attn.k_proj.weight": XA + ".cross_attn.v_proj.weight",
                       XA + ".cross_attn.k_proj.bias": XA + ".cross_attn.v_proj.bias"}
+        # optimizer groups of the reference (model/model_Uni.py:73-114, train-MaDe.py:262-266) laid out as contiguous ranges
+        def group_of(k: str) -> int:
+            if k.startswith(("vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.")):
+                return 0                                      # temporal
+            if k.startswith(XA + ".") or k == "logit_scale":
+                return 1                                      # matching
+            if k.startswith(("detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_")):
+                return 2                                      # detection
+            return 3                                          # not optimised (decoder_query_embed, unused variants)
+        names = sorted(names, key=group_of)                   # stable: keeps the state_dict order inside a group
         order: List[str] = []
         for k in names:
             if k in pair_after.values():
@@ -145,6 +155,17 @@ class MadeTrainer(MadeEngine):
             self.master[k].copy_(t.to(dev, torch.float32))
         self.param_names = order
         self._offs = offs
+        self.group_ranges = []
+        for gi in range(3):
+            ks = [k for k in order if group_of(k) == gi]
+            b = offs[ks[0]]
+            last = ks[-1]
+            e = offs[last] + round_up(int(np.prod(shapes[last])) if len(shapes[last]) else 1, 64)
+            self.group_ranges.append((b, e))
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.opt_step = 0
+        self._norm_ws = torch.zeros(4, device=dev, dtype=torch.float32)
 
     def _view(self, store: Dict[str, Tensor], ref) -> Tensor:
         if isinstance(ref, tuple):                       # adjacent pair -> one view over both
@@ -156,28 +177,78 @@ class MadeTrainer(MadeEngine):
         return store[ref]
 
     def repack(self):
-        """Kernel-facing parameter copies from the f32 masters: W (compute dtype), W^T (for dX = dY W), vectors aliased."""
-        P, tc = self.P, self.tc
-        mats, vecs = self._table()
-        self.G: Dict[str, Tensor] = {}
-        for key, ref in vecs:
-            v = self._view(self.master, ref)
-            P[key] = v.view(-1) if v.dim() != 1 else v
-            g = self._view(self.grad, ref)
-            self.G[key] = g.view(-1) if g.dim() != 1 else g
-        for key, ref in mats:
-            m = self._view(self.master, ref)
-            P[key] = m if tc == torch.float32 else m.to(tc)
-            self.G[key] = self._view(self.grad, ref)
-            if key in ("query_embed", "vit_proj.w", "ast_proj.w"):
-                continue
-            base = key[:-2] if key.endswith(".w") else key
-            if m.shape[0] < 8:                           # tiny heads (N = 2): zero-pad the reduction dim of W^T to 8
-                wt = torch.zeros(m.shape[1], 8, device=self.device, dtype=tc)
-                wt[:, :m.shape[0]] = m.t().to(tc)
-                P[base + ".wt"] = wt
-            else:
-                P[base + ".wt"] = m.t().contiguous().to(tc)
+        """Kernel-facing parameter copies from the f32 masters: W (compute dtype), W^T (for dX = dY W) -- one launch
+        (made_repack) into buffers allocated once, so the pointers the kernels (and a captured hipGraph) see never change.
+        Vectors (biases, LayerNorm parameters) and, in f32 mode, the matrices themselves alias the masters."""
+        import ctypes as C
+        if getattr(self, "_pack_desc", None) is None:
+            P, tc, dev = self.P, self.tc, self.device
+            mats, vecs = self._table()
+            self.G: Dict[str, Tensor] = {}
+            for key, ref in vecs:
+                v = self._view(self.master, ref)
+                P[key] = v.view(-1) if v.dim() != 1 else v
+                g = self._view(self.grad, ref)
+                self.G[key] = g.view(-1) if g.dim() != 1 else g
+            descs = []
+            tiles = 0
+            for key, ref in mats:
+                m = self._view(self.master, ref)
+                self.G[key] = self._view(self.grad, ref)
+                rows, cols = m.shape
+                w = None
+                if tc == torch.float32:
+                    P[key] = m
+                else:
+                    w = torch.empty(rows, cols, device=dev, dtype=tc)
+                    P[key] = w
+                wt = None
+                if key not in ("query_embed", "vit_proj.w", "ast_proj.w"):
+                    base = key[:-2] if key.endswith(".w") else key
+                    wt = torch.zeros(cols, max(rows, 8), device=dev, dtype=tc)     # tiny heads (N = 2): reduction dim zero-padded to 8
+                    P[base + ".wt"] = wt
+                if w is None and wt is None:
+                    continue
+                d = _lib.MadeRepackDesc()
+                d.src, d.w, d.wt = m.data_ptr(), (w.data_ptr() if w is not None else None), (wt.data_ptr() if wt is not None else None)
+                d.rows, d.cols, d.wt_ld, d.tile_begin = rows, cols, (wt.shape[1] if wt is not None else 0), tiles
+                d.dtype = ops.dt_of(wt if wt is not None else w)
+                tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+                descs.append(d)
+            arr = (_lib.MadeRepackDesc * len(descs))(*descs)
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self._pack_desc = torch.from_numpy(raw).to(dev)
+            self._pack_n, self._pack_tiles = len(descs), tiles
+        _lib.check(_lib.lib().made_repack(self._pack_desc.data_ptr(), self._pack_n, self._pack_tiles,
+                                          torch.cuda.current_stream().cuda_stream), "made_repack")
+
+    def optimizer_step(self, lr_temporal: float, lr_matching: float, lr_detection: float, max_grad_norm: float = 1.0,
+                       betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+        """Three-group gradient clipping + Adam (reference train-MaDe.py:262-266,375-381) on the flat buffers, then repack()."""
+        import ctypes as C
+        self.opt_step += 1
+        groups = (_lib.MadeAdamGroup * 3)()
+        for i, lr in enumerate((lr_temporal, lr_matching, lr_detection)):
+            groups[i].begin, groups[i].end = self.group_ranges[i]
+            groups[i].lr, groups[i].max_norm = float(lr), float(max_grad_norm)
+        _lib.check(_lib.lib().made_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                             self.exp_avg_sq.data_ptr(), self.flat_param.numel(), groups, 3, float(betas[0]), float(betas[1]),
+                                             float(eps), self.opt_step, float(grad_scale), self._norm_ws.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "made_adam_step")
+        self.repack()
+
+    def train_step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed: int, lrs=(1e-4, 1e-4, 1e-4),
+                   max_grad_norm: float = 1.0, w_ret: Optional[Tensor] = None, w_loc: Optional[Tensor] = None, dist=None) -> Dict[str, Tensor]:
+        """One iteration of the reference's loop body (train-MaDe.py:337-381): forward, backward, (data-parallel gradient
+        average: one RCCL all-reduce of the flat buffer), clip + Adam, repack."""
+        out = self.forward_train(frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed=seed)
+        self.backward(w_ret, w_loc)
+        scale = 1.0
+        if dist is not None and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grad)
+            scale = 1.0 / dist.get_world_size()
+        self.optimizer_step(*lrs, max_grad_norm=max_grad_norm, grad_scale=scale)
+        return out
 
     def state_dict_numpy(self) -> Dict[str, np.ndarray]:
         return {k: v.detach().cpu().numpy().copy() for k, v in self.master.items()}

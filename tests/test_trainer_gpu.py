@@ -109,3 +109,66 @@ def test_bf16_gradients_close_to_oracle(dropout):
     res = trn.loss_and_grads(inp, seed=77)
     r, grads = _oracle(cfg, sd, inp, 77, dropout, trn.param_names, double=False)
     print(_compare(res, r, grads, rel_tol=None, loss_tol=2e-2, cos_min=0.97 if dropout else 0.99))   # p = 0.8 dropout amplifies bf16 rounding 5x
+
+
+def test_optimizer_step_matches_torch_adam_with_group_clipping():
+    """made_adam_step == three nn.utils.clip_grad_norm_ + torch.optim.Adam (reference train-MaDe.py:262-266,375-381)."""
+    from mgsv_amd.trainer import MadeTrainer, XA
+    cfg, sd, inp = _setup(3, 20, 40)
+    trn = MadeTrainer(cfg, sd, dtype="bf16")
+    names = trn.param_names
+
+    def group(k):
+        if k.startswith(("vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.")):
+            return 0
+        if k.startswith(XA + ".") or k == "logit_scale":
+            return 1
+        if k.startswith(("detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_")):
+            return 2
+        return 3
+    params = {k: torch.nn.Parameter(trn.master[k].detach().clone()) for k in names}
+    groups = [[params[k] for k in names if group(k) == g] for g in range(3)]
+    lrs = (1e-3, 2e-3, 5e-4)
+    opt = torch.optim.Adam([{"params": groups[g], "lr": lrs[g]} for g in range(3)])
+    for it in range(3):
+        trn.loss_and_grads(inp, seed=10 + it)
+        for k in names:
+            params[k].grad = trn.grad[k].detach().clone() * 0.5           # grad_scale = 0.5 (a 2-rank average)
+        for g in range(3):
+            torch.nn.utils.clip_grad_norm_(groups[g], 0.7)
+        opt.step()
+        trn.optimizer_step(*lrs, max_grad_norm=0.7, grad_scale=0.5)
+        torch.cuda.synchronize()
+        for k in names:
+            ref, got = params[k].detach(), trn.master[k]
+            if group(k) == 3:
+                assert torch.equal(got, torch.from_numpy(np.asarray(sd[k])).to(got.device).view_as(got)), k    # untouched
+                continue
+            assert float((got - ref).abs().max()) <= 2e-6 + 1e-5 * float(ref.abs().max()), (it, k)
+        # keep both sides on identical parameters so rounding does not accumulate through the next forward
+        for k in names:
+            trn.master[k].copy_(params[k].detach())
+        trn.repack()
+    # repack: compute-dtype copies and transposes follow the masters
+    P = trn.P
+    w = trn.master["detr_transformer.encoder.layers.0.linear1.weight"]
+    assert torch.equal(P["detr_transformer.encoder.layers.0.ff1.w"], w.to(torch.bfloat16))
+    assert torch.equal(P["detr_transformer.encoder.layers.0.ff1.wt"], w.t().contiguous().to(torch.bfloat16))
+    assert torch.equal(P["class_embed.wt"][:, :2], trn.master["class_embed.weight"].t().to(torch.bfloat16))
+    kv = torch.cat([trn.master[XA + ".cross_attn.k_proj.weight"], trn.master[XA + ".cross_attn.v_proj.weight"]], 0)
+    assert torch.equal(P["xa.kv.w"], kv.to(torch.bfloat16))
+
+
+def test_training_reduces_the_loss():
+    """a few optimiser steps on one batch (dropout on): the total loss goes down."""
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, inp = _setup(8, 20, 40)
+    trn = MadeTrainer(cfg, sd, dtype="bf16")
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    losses = []
+    for it in range(12):
+        o = trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=it,
+                           lrs=(3e-4, 3e-4, 3e-4))
+        losses.append(float(o["retrieval_loss"]) + float(o["localization_loss"]))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-3:]) < 0.9 * np.mean(losses[:3]), losses
