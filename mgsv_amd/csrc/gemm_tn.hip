@@ -230,7 +230,7 @@ extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
     const bool aligned = a.lda % per16 == 0 && a.ldb % per16 == 0 && n_up <= a.lda && k_up <= a.ldb &&
                          a.a_zs1 % per16 == 0 && a.a_zs2 % per16 == 0 && a.b_zs1 % per16 == 0 && a.b_zs2 % per16 == 0 &&
                          ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0;
-    if (!aligned || a.N * a.K <= 4096) {
+    if (!aligned) {
         MADE_UNSUPPORTED(a.N * a.K <= (1 << 20), "made_gemm_tn: unaligned operands are only supported for small outputs");
         int sy = (int)a.split_m;
         if (!a.accumulate) sy = 1;

@@ -303,7 +303,7 @@ class MadeTrainer(MadeEngine):
             xdkv=E(B * Ta, 2 * D), xds1=E(B * Ta, D), xdseg=E(B * Ta, D), xdq32=E(B, D, dtype=f32), xdq=E(B, D), xdv1=E(B, D),
             vn=E(B, D, dtype=f32), mn=E(B, D, dtype=f32), dvn=E(B, D, dtype=f32), dmn=E(B, D, dtype=f32),
             dsims_s=E(B, B, dtype=f32), dsims_d=E(B, B, dtype=f32), dsims_dt=E(B, B, dtype=f32), clip_ws=E(2 * B, dtype=f32),
-            sims_both=E(B, B, dtype=f32),
+            sims_both=E(B, B, dtype=f32), sd_ws=E(16 * B * B, dtype=f32),
             dvideo=E(B, D, dtype=f32), dmusic=E(B, D, dtype=f32),
             # DETR encoder
             e_delta=E(B * H * L, dtype=f32), eg1=E(rows, D), eg2=E(rows, D), eg3=E(rows, D), egqkv=E(rows, 3 * D), egffn=E(rows, Fd),
@@ -366,7 +366,11 @@ class MadeTrainer(MadeEngine):
         xmask = sm if c.fusion_mask == 1 else None
         self._xpool_train(video, seg, xmask, ws, tw, B, Ta)
         ops.l2norm_rows(video, out_f32=tw["vn"]); ops.l2norm_rows(music, out_f32=tw["mn"])
-        ops.linear(tw["vn"], tw["mn"], None, out=ws["sims_dual"])
+        if B % 4 == 0 and B <= 256:                          # one output tile: split K over workgroups (exact-f32 MFMA either way)
+            split = max(2, min(16, D // 32))
+            ops.linear_splitk(tw["vn"], tw["mn"], None, tw["sd_ws"][:split * B * B], split, out=ws["sims_dual"])
+        else:
+            ops.linear(tw["vn"], tw["mn"], None, out=ws["sims_dual"])
         self._retrieval_loss(ws, video, music)
         out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"], retrieval_loss=ws["ret_loss"])
 
