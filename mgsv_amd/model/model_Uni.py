@@ -9,10 +9,13 @@ path).  Underneath, every op runs as a hand-written HIP k
 libmade_hip.so (mgsv_amd/engine.py); there is no ATen fallback -- on a box without the library or a
 GPU the model raises.
 
-Scope of this round: inference (`torch.no_grad()` / `model.eval()`): the full forward including the
-retrieval loss, Hungarian matcher and set criterion values.  Backward kernels are not written yet, so
-calling forward with autograd enabled in train mode raises NotImplementedError instead of silently
-returning losses that cannot be differentiated.
+Inference (`model.eval()` / `torch.no_grad()`): mgsv_amd/engine.py.  Training (`model.train()` with autograd on):
+mgsv_amd/trainer.py -- the two losses come back attached to the autograd tape through one custom Function whose backward
+runs the hand-written backward pass and points every parameter's `.grad` at its slice of the trainer's flat gradient
+buffer, so the reference's loop body works unchanged (train-MaDe.py:337-381: `loss.backward()`, the three
+`clip_grad_norm_` calls, `optimizer.step()`, `optimizer.zero_grad()`).  Parameters alias the trainer's flat f32 master
+buffer, so in-place optimizer updates are seen by the next forward (the bf16 copies are re-derived when a parameter's
+version counter moved).  Configurations the HIP training path does not cover raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -24,6 +27,40 @@ import torch.nn as nn
 from .. import synth
 from ..config import MadeConfig
 from ..engine import MadeEngine
+
+
+class _TrainStep(torch.autograd.Function):
+    """(retrieval_loss, localization_loss) = forward_train(batch); backward = MadeTrainer.backward.
+    The parameters are inputs only so that autograd schedules the node; their gradients are written straight into
+    `param.grad` (views of the trainer's flat buffer, accumulated if a gradient is already there)."""
+
+    @staticmethod
+    def forward(ctx, owner, batch, seed, *params):
+        trn = owner._trainer
+        out = trn.forward_train(*batch, seed=seed)
+        ctx.owner = owner
+        owner._last_train_out = out
+        return out["retrieval_loss"].clone().view(()), out["localization_loss"].clone().view(())
+
+    @staticmethod
+    def backward(ctx, g_ret, g_loc):
+        owner = ctx.owner
+        trn = owner._trainer
+        dev = trn.device
+        zero = torch.zeros(1, device=dev)
+        gr = g_ret.reshape(1).to(dev, torch.float32) if g_ret is not None else zero
+        gl = g_loc.reshape(1).to(dev, torch.float32) if g_loc is not None else zero
+        trn.backward(gr, gl)
+        with torch.no_grad():
+            for name, p in owner.named_parameters():
+                g = trn.grad.get(name)
+                if g is None:
+                    continue
+                if p.grad is None:
+                    p.grad = g
+                elif p.grad.data_ptr() != g.data_ptr():
+                    p.grad.add_(g)
+        return (None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))
 
 _FROZEN_PREFIXES = ("vit_model.", "ast_model.")
 
@@ -107,6 +144,9 @@ class Uni_model(nn.Module):
         self.criterion.register_buffer("empty_weight", torch.from_numpy(sd["criterion.empty_weight"].copy()))
         self._engine: Optional[MadeEngine] = None
         self._engine_stamp = None
+        self._trainer = None
+        self._trainer_stamp = None
+        self._train_seed = int(getattr(args, "seed", 0)) << 20
 
     # ---- parameter groups (reference model/model_Uni.py:73-114, model_Base.py:379-404)
     def _params(self, prefixes) -> List[nn.Parameter]:
@@ -140,12 +180,68 @@ class Uni_model(nn.Module):
         self._engine_stamp = stamp
         return self._engine
 
+    def _trainer_ready(self):
+        """MadeTrainer whose flat f32 master buffer the module's parameters alias."""
+        from ..trainer import MadeTrainer
+        if self._trainer is None:
+            self._trainer = MadeTrainer(self.cfg, self.state_dict(), device=self.device, dtype=self.compute_dtype)
+            with torch.no_grad():
+                for name, p in self.named_parameters():
+                    if name in self._trainer.master:
+                        p.data = self._trainer.master[name]
+            self._trainer_stamp = self._stamp()
+        elif self._stamp() != self._trainer_stamp:                 # an optimizer (or load_state_dict) touched the masters
+            with torch.no_grad():
+                for name, p in self.named_parameters():
+                    m = self._trainer.master.get(name)
+                    if m is not None and p.data_ptr() != m.data_ptr():
+                        m.copy_(p.data)
+                        p.data = m
+            self._trainer.repack()
+            self._trainer_stamp = self._stamp()
+        return self._trainer
+
+    def _maps(self, o, eng, frame_masks, segment_masks, video_ids, music_ids):
+        nd, cfg = self.cfg.detr_dec_layers, self.cfg
+        output_map: Dict[str, object] = {"pred_logits": o["pred_logits"], "pred_spans": o["pred_spans"]}
+        if cfg.contrastive_align_loss:
+            output_map.update(proj_queries=o["proj_queries"], proj_vid_mem=o["proj_vid_mem"])
+        if cfg.aux_loss:
+            aux = []
+            for i in range(nd - 1):
+                d = {"pred_logits": o["logits_all"][i], "pred_spans": o["spans_all"][i]}
+                if cfg.contrastive_align_loss:
+                    d.update(proj_queries=o["proj_queries_all"][i], proj_vid_mem=o["proj_vid_mem"])
+                aux.append(d)
+            output_map["aux_outputs"] = aux
+        feat_map = {"video_feats": o["video_feats"], "music_feats": o["music_feats"],
+                    "frame_feats": o["frame_feats"].float(), "segment_feats": o["segment_feats"].float()}
+        mask_map = {"frame_masks": frame_masks, "segment_masks": segment_masks}
+        id_map = {"video_ids": video_ids, "music_ids": music_ids}
+        self.last_matcher = {k: o[k] for k in ("matcher_pred_idx", "matcher_tgt_idx", "matcher_count", "matcher_status")}
+        return output_map, feat_map, mask_map, id_map
+
     # ---- forward (reference model/model_Uni.py:177-322)
     def forward(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, v_duration=None,
                 video_ids=None, music_ids=None, is_train=False):
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("training (backward kernels) is not implemented on the HIP path yet; "
-                                      "use model.eval() / torch.no_grad() for inference")
+        if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse") or "XA" not in self.cfg.vmr_fusion:
+            raise ValueError(f"Error: vmr_loss={self.cfg.vmr_loss} and vmr_fusion={self.cfg.vmr_fusion} is not supported in VMR_model")
+        if self.training:
+            trn = self._trainer_ready()
+            dev, f32 = trn.device, torch.float32
+            batch = (frame_feats.to(dev, f32), segment_feats.to(dev, f32), frame_masks.to(dev, f32), segment_masks.to(dev, f32),
+                     spans_target.to(dev, f32))
+            self._train_seed += 1
+            if torch.is_grad_enabled():
+                params = [p for _, p in self.named_parameters()]
+                ret, loc = _TrainStep.apply(self, batch, self._train_seed, *params)
+                o = self._last_train_out
+            else:
+                o = trn.forward_train(*batch, seed=self._train_seed)
+                ret, loc = o["retrieval_loss"][0], o["localization_loss"][0]
+            output_map, feat_map, mask_map, id_map = self._maps(o, trn, frame_masks, segment_masks, video_ids, music_ids)
+            loss_map = {"retrieval_loss": ret, "localization_loss": loc, "localization_loss_dict": trn.loss_dict(o)}
+            return output_map, loss_map, feat_map, mask_map, id_map
         if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse") or "XA" not in self.cfg.vmr_fusion:
             raise ValueError(f"Error: vmr_loss={self.cfg.vmr_loss} and vmr_fusion={self.cfg.vmr_fusion} is not supported in VMR_model")
         eng = self._engine_ready()

@@ -62,3 +62,49 @@ def test_dropin_forward_and_state_dict(golden_dir):
     model.train()
     with pytest.raises(NotImplementedError):
         model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+
+
+def test_training_loop_body_of_the_reference_driver_runs_unchanged():
+    """reference train-MaDe.py:337-381 verbatim in spirit: forward(is_train=True), weighted loss, loss.backward(), three
+    clip_grad_norm_ calls, Adam step, zero_grad -- on the drop-in module.  Gradients equal the trainer's (which are pinned to the
+    reference's autograd in tests/test_trainer_gpu.py), the loss goes down, and eval() afterwards sees the updated weights."""
+    import numpy as np
+    import torch
+    from mgsv_amd import synth
+    from mgsv_amd.config import cfg_native
+    from mgsv_amd.model import Uni_model
+    cfg = cfg_native()
+    args = cfg.to_args(local_rank=0)
+    args.compute_dtype = "bf16"
+    model = Uni_model(args, device=torch.device("cuda:0"))
+    keys_before = list(model.state_dict().keys())
+    inp = synth.make_inputs(cfg, 8, 20, 40, seed=3)
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    opt = torch.optim.Adam([{"params": model.get_temporal_parameter(), "lr": 3e-4},
+                            {"params": model.get_matching_parameter(), "lr": 3e-4},
+                            {"params": model.get_detection_parameter(), "lr": 3e-4}])
+    model.train()
+    losses = []
+    for it in range(10):
+        om, lm, fm, mm, im = model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
+                                   v_duration=t["v_duration"], video_ids=inp["video_ids"], music_ids=inp["music_ids"], is_train=True)
+        loss = lm["retrieval_loss"] * 1.0 + lm["localization_loss"] * 1.0
+        loss.backward()
+        if it == 0:
+            trn = model._trainer
+            for n, p in model.named_parameters():
+                assert p.grad is not None and torch.equal(p.grad, trn.grad[n]), n
+            assert float(model.vit_proj.weight.grad.abs().max()) > 0
+        torch.nn.utils.clip_grad_norm_(model.get_temporal_parameter(), 1.0)
+        torch.nn.utils.clip_grad_norm_(model.get_matching_parameter(), 1.0)
+        torch.nn.utils.clip_grad_norm_(model.get_detection_parameter(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+        assert "loss_label" in lm["localization_loss_dict"] and om["pred_spans"].shape == (8, 1, 2)
+    assert np.isfinite(losses).all() and np.mean(losses[-3:]) < 0.9 * np.mean(losses[:3]), losses
+    assert list(model.state_dict().keys()) == keys_before
+    model.eval()
+    with torch.no_grad():
+        om, lm, *_ = model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+    assert float(lm["retrieval_loss"] + lm["localization_loss"]) < losses[0]
