@@ -468,8 +468,11 @@ int made_set_criterion_bwd(const float* pred_logits, const float* pred_spans, co
  * torch.optim.Adam's update (amsgrad off, weight_decay 0) with the group's lr (host-side schedule) and the given step
  * count (>= 1, for the bias corrections).  Elements outside every group are left untouched (the reference keeps
  * decoder_query_embed out of the optimizer).  grad_scale folds the 1/world_size of a summed data-parallel all-reduce.
- * norm_ws: [MADE_ADAM_MAX_GROUPS] f32 device workspace (returns the squared group norms). */
+ * norm_ws: [MADE_ADAM_MAX_GROUPS * (1 + MADE_ADAM_NORM_BLOCKS)] f32 device workspace; its first MADE_ADAM_MAX_GROUPS entries
+ * return the squared group norms.  The norms are reduced in a fixed order (no atomics), so data-parallel ranks that hold the
+ * same all-reduced gradients apply bit-identical updates. */
 #define MADE_ADAM_MAX_GROUPS 4
+#define MADE_ADAM_NORM_BLOCKS 1024
 typedef struct MadeAdamGroup { int64_t begin, end; float lr; float max_norm; } MadeAdamGroup;
 int made_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, int64_t step,

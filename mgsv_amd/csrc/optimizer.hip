@@ -23,7 +23,7 @@ __device__ __forceinline__ int group_of(const AdamArgs& a, int64_t i) {
     return gi;
 }
 
-// squared L2 norm of every group's (scaled) gradient; one atomic per group per workgroup
+// squared L2 norm of every group's (scaled) gradient: per-workgroup partial sums
 __global__ __launch_bounds__(OT) void grad_norm_kernel(const AdamArgs a) {
     __shared__ float red[MADE_ADAM_MAX_GROUPS][OT / 64];
     float acc[MADE_ADAM_MAX_GROUPS];
@@ -46,10 +46,28 @@ __global__ __launch_bounds__(OT) void grad_norm_kernel(const AdamArgs a) {
         if (lane == 0) red[k][wave] = s;
     }
     __syncthreads();
-    if (threadIdx.x < MADE_ADAM_MAX_GROUPS && threadIdx.x < a.n_groups) {
+    // per-workgroup partials, combined in a fixed order by norm_finish_kernel: every rank of a data-parallel job computes
+    // bit-identical norms from the all-reduced gradients (atomics would let the ranks drift apart)
+    if (threadIdx.x < MADE_ADAM_MAX_GROUPS) {
         float s = 0.f;
         for (int w = 0; w < OT / 64; ++w) s += red[threadIdx.x][w];
-        unsafeAtomicAdd(a.norm_sq + threadIdx.x, s);
+        a.norm_sq[MADE_ADAM_MAX_GROUPS + (int64_t)blockIdx.x * MADE_ADAM_MAX_GROUPS + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(OT) void norm_finish_kernel(float* norm_ws, int nblocks) {
+    __shared__ float red[OT];
+    for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < nblocks; b += OT) s += norm_ws[MADE_ADAM_MAX_GROUPS + (int64_t)b * MADE_ADAM_MAX_GROUPS + k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = OT / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) norm_ws[k] = red[0];
+        __syncthreads();
     }
 }
 
@@ -137,13 +155,10 @@ extern "C" int made_adam_step(float* param, const float* grad, float* exp_avg, f
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     a.norm_sq = norm_ws;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(norm_ws, 0, sizeof(float) * MADE_ADAM_MAX_GROUPS, st) != hipSuccess) {
-        made_set_error("made_adam_step: hipMemsetAsync failed");
-        return MADE_ERR_HIP;
-    }
     int64_t nb = (n / 4 + OT - 1) / OT;
-    if (nb > 2048) nb = 2048;
+    if (nb > MADE_ADAM_NORM_BLOCKS) nb = MADE_ADAM_NORM_BLOCKS;
     hipLaunchKernelGGL(grad_norm_kernel, dim3((unsigned)nb), dim3(OT), 0, st, a);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(OT), 0, st, norm_ws, (int)nb);
     hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nb), dim3(OT), 0, st, a);
     return made_check_launch("made_adam_step");
 }

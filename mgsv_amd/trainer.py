@@ -165,7 +165,7 @@ class MadeTrainer(MadeEngine):
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.opt_step = 0
-        self._norm_ws = torch.zeros(4, device=dev, dtype=torch.float32)
+        self._norm_ws = torch.zeros(4 * (1 + 1024), device=dev, dtype=torch.float32)
 
     def _view(self, store: Dict[str, Tensor], ref) -> Tensor:
         if isinstance(ref, tuple):                       # adjacent pair -> one view over both
