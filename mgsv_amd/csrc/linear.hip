@@ -454,8 +454,13 @@ constexpr int G_LDS = (64 * G_CT_LD * 4 > G_STAGE) ? 64 * G_CT_LD * 4 : G_STAGE;
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-__global__ __launch_bounds__(NTHREADS, 4) void linear_glds_kernel(const MadeLinearArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[G_LDS];
+// NST = 1: one 32 KB stage, two barriers per slab, latency hidden by 4 workgroups per CU (grids that fill the chip).
+// NST = 3: three stages, slabs kt+1 and kt+2 in flight while slab kt is multiplied, one barrier per slab and counted
+//          vmcnt waits -- for grids of at most one workgroup per CU (the decoder's 64-row Linears), where nothing else
+//          hides the ~2 us a slab takes to arrive.
+template <int NST>
+__global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel(const MadeLinearArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST == 1 ? G_LDS : NST * G_STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -542,22 +547,23 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_glds_kernel(const MadeLine
     }
 
     const int nk = K / 64;
-    for (int kt = 0; kt < nk; ++kt) {
+    auto issue = [&](int kt, unsigned char* st) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = 4 * wave + i;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(lds + BM * KB + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(st + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(st + BM * KB + piece * 1024), 16, 0, 0);
         }
-        __syncthreads();                                   // waits for the LDS-DMA (vmcnt(0)) of every wave
+    };
+    auto multiply = [&](const unsigned char* st) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 fa[2], fw[2];
             const int c = 2 * ks + hh;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fa[t] = *(const bf16x8*)(lds + offa[t] + ((c ^ sa[t]) << 4));
-                fw[t] = *(const bf16x8*)(lds + offw[t] + ((c ^ sw[t]) << 4));
+                fa[t] = *(const bf16x8*)(st + offa[t] + ((c ^ sa[t]) << 4));
+                fw[t] = *(const bf16x8*)(st + offw[t] + ((c ^ sw[t]) << 4));
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -565,7 +571,27 @@ __global__ __launch_bounds__(NTHREADS, 4) void linear_glds_kernel(const MadeLine
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fw[nt], acc[mt][nt], 0, 0, 0);
         }
-        __syncthreads();                                   // all fragment reads done before the stage is overwritten
+    };
+    if constexpr (NST == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            issue(kt, lds);
+            __syncthreads();                               // waits for the LDS-DMA (vmcnt(0)) of every wave
+            multiply(lds);
+            __syncthreads();                               // all fragment reads done before the stage is overwritten
+        }
+    } else {
+        // slab kt lives in stage kt % NST; 8 LDS-DMA loads per wave per slab, so "slab kt landed" == at most 8 newer loads
+        // outstanding.  The barrier also proves every wave finished reading stage (kt - 1) % NST, which slab kt + 2 reuses.
+        issue(0, lds);
+        if (nk > 1) issue(1, lds + G_STAGE);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (kt + 2 < nk) issue(kt + 2, lds + ((kt + 2) % NST) * G_STAGE);
+            multiply(lds + (kt % NST) * G_STAGE);
+        }
+        __syncthreads();                                   // the epilogue reuses the staging LDS
     }
 
     // ---- epilogue, two 64-row halves through LDS ------------------------------------------------------
@@ -674,7 +700,10 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
                     (a.A2 == nullptr || a.a2_replace) && ((uintptr_t)a.A % 16 == 0) && (a.lda % 8 == 0);
         for (int s = 0; s < a.nseg; ++s) fast = fast && !a.seg[s].transposed;
         if (a.A2 && a.a2_replace) fast = fast && (a.a2_row_mod == 0) && (a.lda2 % 8 == 0);
-        if (fast) hipLaunchKernelGGL(linear_glds_kernel, grid, block, 0, st, a);
+        if (fast) {
+            if (tiles * a.batch <= 256) hipLaunchKernelGGL(linear_glds_kernel<3>, grid, block, 0, st, a);   // at most one workgroup per CU
+            else hipLaunchKernelGGL(linear_glds_kernel<1>, grid, block, 0, st, a);
+        }
         else if (a.a_dtype == MADE_F32) hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((linear_kernel<bf16_t, bf16_t>), grid, block, 0, st, a);
     } else {

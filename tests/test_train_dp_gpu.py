@@ -31,8 +31,15 @@ def _worker(rank, world, port, out_dir):
     inp = synth.make_inputs(cfg, 4, 20, 40, seed=1 + rank)
     t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
     for it in range(2):
-        trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=100 + it,
-                       lrs=(1e-3, 1e-3, 1e-3), dist=dist)
+        if it == 0:                                          # the body of train_step, with a look at the reduced gradient
+            trn.forward_train(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=100)
+            trn.backward()
+            dist.all_reduce(trn.flat_grad)
+            np.save(os.path.join(out_dir, f"gsum_{rank}.npy"), trn.flat_grad.cpu().numpy())
+            trn.optimizer_step(1e-3, 1e-3, 1e-3, grad_scale=0.5)
+        else:
+            trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=100 + it,
+                           lrs=(1e-3, 1e-3, 1e-3), dist=dist)
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"params_{rank}.npy"), trn.flat_param.cpu().numpy())
     dist.barrier()
@@ -55,13 +62,21 @@ def test_two_rank_data_parallel_step(tmp_path):
     for r in range(2):
         inp = synth.make_inputs(cfg, 4, 20, 40, seed=1 + r)
         batches.append({k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)})
+    g_dp = np.load(tmp_path / "gsum_0.npy")
+    assert np.array_equal(g_dp, np.load(tmp_path / "gsum_1.npy"))
     for it in range(2):
         acc = torch.zeros_like(trn.flat_grad)
         for t in batches:
             trn.forward_train(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=100 + it)
             trn.backward()
             acc += trn.flat_grad
+        if it == 0:                                          # the reduced gradient itself: f32 atomics reorder sums, nothing more
+            ref_g = acc.cpu().numpy()
+            assert np.abs(ref_g - g_dp).max() <= 2e-5 * np.abs(ref_g).max(), np.abs(ref_g - g_dp).max()
         trn.flat_grad.copy_(acc)
         trn.optimizer_step(1e-3, 1e-3, 1e-3, grad_scale=0.5)
+    # parameters after two Adam steps: Adam normalises every element's update to ~lr, so an element whose gradient is
+    # rounding noise may move by up to lr per step in either direction; everything else agrees far tighter
     ref = trn.flat_param.cpu().numpy()
-    assert np.abs(ref - p0).max() <= 2e-5 * max(1.0, np.abs(ref).max()), np.abs(ref - p0).max()   # atomics reorder f32 sums
+    diff = np.abs(ref - p0)
+    assert diff.max() <= 2.5e-3 and np.mean(diff > 1e-5) < 1e-2, (diff.max(), np.mean(diff > 1e-5))
