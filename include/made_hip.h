@@ -68,9 +68,12 @@ MADE_HOST_DEVICE static inline uint32_t made_rng_fmix32(uint32_t h) {
 }
 /* keep threshold of probability p (a float32): floor(p * 2^24), evaluated exactly */
 MADE_HOST_DEVICE static inline uint32_t made_drop_threshold(float p) { return (uint32_t)((double)p * 16777216.0); }
+/* mix(seed, site, idx) = fmix32(lo32(idx) ^ key(seed, site, hi32(idx))): kernels hoist the key out of their inner loops */
+MADE_HOST_DEVICE static inline uint32_t made_rng_key(uint64_t seed, uint32_t site, uint32_t idx_hi) {
+    return made_rng_fmix32((uint32_t)seed ^ (site * 0x9E3779B9u) ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ (idx_hi * 0xC2B2AE35u));
+}
 MADE_HOST_DEVICE static inline uint32_t made_rng_mix(uint64_t seed, uint32_t site, uint64_t idx) {
-    uint32_t k = (uint32_t)seed ^ (site * 0x9E3779B9u) ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ ((uint32_t)(idx >> 32) * 0xC2B2AE35u);
-    return made_rng_fmix32((uint32_t)idx ^ made_rng_fmix32(k));
+    return made_rng_fmix32((uint32_t)idx ^ made_rng_key(seed, site, (uint32_t)(idx >> 32)));
 }
 
 

@@ -256,14 +256,26 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
             const uint32_t thr = made_drop_threshold(a.drop.p);
             const float sc = 1.f / (1.f - a.drop.p);
             int64_t qq = q0 + r; qq = qq < a.Lq ? qq : a.Lq - 1;
-            const uint64_t rowbase = (uint64_t)((b * a.H + h) * a.Lq + qq) * (uint64_t)a.Lk + (uint64_t)(t * BKEY);
+            const uint64_t base = (uint64_t)((b * a.H + h) * a.Lq + qq) * (uint64_t)a.Lk + (uint64_t)(t * BKEY);
+            const uint32_t lo = (uint32_t)base;
+            if (__all(lo <= 0xFFFFFFFFu - BKEY)) {           // the tile's indices share their high word: hoist the key
+                const uint32_t kk = made_rng_key(a.drop.seed, a.drop.site, (uint32_t)(base >> 32));
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t hsh = made_rng_mix(a.drop.seed, a.drop.site, rowbase + (uint64_t)(kt * 32 + acc_row(e, hh)));
-                    s[kt][e] = (hsh >> 8) >= thr ? s[kt][e] * sc : 0.f;
-                }
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t hsh = made_rng_fmix32((lo + (uint32_t)(kt * 32 + acc_row(e, hh))) ^ kk);
+                        s[kt][e] = (hsh >> 8) >= thr ? s[kt][e] * sc : 0.f;
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t hsh = made_rng_mix(a.drop.seed, a.drop.site, base + (uint64_t)(kt * 32 + acc_row(e, hh)));
+                        s[kt][e] = (hsh >> 8) >= thr ? s[kt][e] * sc : 0.f;
+                    }
+            }
         }
 
         // ---- O^T += V^T P^T

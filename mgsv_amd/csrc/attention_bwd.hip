@@ -116,6 +116,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(const MadeAttnBwdArgs 
 
     frag_t rk[NCH], rv[NCH];
     float rbias = 0.f;
+    int rflag = 0;
     auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
         float mk[NCH];
 #pragma unroll
@@ -138,7 +139,9 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(const MadeAttnBwdArgs 
             const int64_t key = key0 + tid;
             const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
             const float mkb = maskg ? maskg[kcl] : 1.f;
-            rbias = (key < a.Lk && mkb != 0.f) ? 0.f : -INFINITY;
+            const bool valid = key < a.Lk && mkb != 0.f;
+            rbias = valid ? 0.f : -INFINITY;
+            rflag = __any(!valid) ? 1 : 0;                   // tid < 64 is exactly wave 0
         }
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(const MadeAttnBwdArgs 
             *(frag_t*)(lds_v + (c / CPR) * P + (c % CPR) * 16) = rv[i];
         }
         if (tid < BKEY) lds_bias[tid] = rbias;
+        if (tid == 0) lds_flag[0] = rflag;
     };
 
     f32x16 dq[NDT];
@@ -205,16 +209,47 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(const MadeAttnBwdArgs 
             }
         }
         // dS^T = P^T * (dP^T - delta) * scale, in place of s
+        const uint64_t tbase = rowbase + (uint64_t)(t * BKEY);
+        const uint32_t tlo = (uint32_t)tbase;
+        const bool fast_idx = __all(tlo <= 0xFFFFFFFFu - BKEY);
+        const uint32_t kk = made_rng_key(a.drop.seed, a.drop.site, (uint32_t)(tbase >> 32));
+        if constexpr (IS_BF16) {
+            // VALU diet (the elementwise part, not the MFMAs, bounds this kernel): exp2 with the scale and -lse folded into
+            // one FMA, the key-mask bias only on tiles that contain an invalid key, delta pre-multiplied by the scale
+            const float c2 = a.scale * 1.4426950408889634f;
+            const float nl = -lse_q * 1.4426950408889634f;
+            const float dsq = delta_q * a.scale;
+            if (lds_flag[0] != 0) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int kl = kt * 32 + acc_row(e, hh);
-                const float p = expf(s[kt][e] * a.scale + lds_bias[kl] - lse_q);
-                float g = dp[kt][e];
-                if (a.drop.p > 0.f) g = drop_keep(a.drop, thr, rowbase + (uint64_t)(t * BKEY + kl)) ? g * dsc : 0.f;
-                s[kt][e] = p * (g - delta_q) * a.scale;
+                    for (int e = 0; e < 16; ++e) s[kt][e] += lds_bias[kt * 32 + acc_row(e, hh)];   // -inf * anything stays -inf below
             }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = kt * 32 + acc_row(e, hh);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nl));
+                    float g = dp[kt][e];
+                    if (a.drop.p > 0.f) {
+                        const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)kl) ^ kk) : made_rng_mix(a.drop.seed, a.drop.site, tbase + (uint64_t)kl);
+                        g = (hsh >> 8) >= thr ? g * dsc : 0.f;
+                    }
+                    s[kt][e] = p * __builtin_fmaf(g, a.scale, -dsq);
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = kt * 32 + acc_row(e, hh);
+                    const float p = expf(s[kt][e] * a.scale + lds_bias[kl] - lse_q);
+                    float g = dp[kt][e];
+                    if (a.drop.p > 0.f) g = drop_keep(a.drop, thr, tbase + (uint64_t)kl) ? g * dsc : 0.f;
+                    s[kt][e] = p * (g - delta_q) * a.scale;
+                }
+        }
         // dQ^T += K^T dS^T
         if constexpr (IS_BF16) {
 #pragma unroll
@@ -334,6 +369,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs
             const float l = lseg[qcl], dl = delg[qcl];
             rl = ok ? l : INFINITY;                    // +inf: the whole probability row is 0
             rd = ok ? dl : 0.f;
+            if constexpr (IS_BF16) { rl = -rl * 1.4426950408889634f; rd = rd * a.scale; }   // pre-folded for the exp2 / FMA form
         }
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
@@ -402,21 +438,47 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs
             }
         }
         // s <- Pd (dropped probabilities), dp <- dS
+        const uint64_t tfirst = (bhbase + (uint64_t)(t * BQT)) * (uint64_t)a.Lk;
+        const uint64_t tlast = tfirst + (uint64_t)BQT * (uint64_t)a.Lk;
+        const bool fast_idx = (tfirst >> 32) == (tlast >> 32);            // wave-uniform: the tile's indices share their high word
+        const uint32_t kk = made_rng_key(a.drop.seed, a.drop.site, (uint32_t)(tfirst >> 32));
+        const uint32_t tlo = (uint32_t)tfirst + (uint32_t)keyc;
+        if constexpr (IS_BF16) {
+            const float c2 = a.scale * 1.4426950408889634f;
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
+            for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ql = qi * 32 + acc_row(e, hh);
-                const float p = expf(s[qi][e] * a.scale + bias_key - lds_lse[ql]);
-                float pd = p, g = dp[qi][e];
-                if (a.drop.p > 0.f) {
-                    const bool keep = drop_keep(a.drop, thr, (bhbase + (uint64_t)(t * BQT + ql)) * (uint64_t)a.Lk + (uint64_t)keyc);
-                    pd = keep ? p * dsc : 0.f;
-                    g = keep ? g * dsc : 0.f;
+                for (int e = 0; e < 16; ++e) {
+                    const int ql = qi * 32 + acc_row(e, hh);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][e], c2, lds_lse[ql]) + bias_key);
+                    float pd = p, g = dp[qi][e];
+                    if (a.drop.p > 0.f) {
+                        const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)ql * (uint32_t)a.Lk) ^ kk)
+                                                      : made_rng_mix(a.drop.seed, a.drop.site, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
+                        const bool keep = (hsh >> 8) >= thr;
+                        pd = keep ? p * dsc : 0.f;
+                        g = keep ? g * dsc : 0.f;
+                    }
+                    s[qi][e] = pd;
+                    dp[qi][e] = p * __builtin_fmaf(g, a.scale, -lds_delta[ql]);
                 }
-                s[qi][e] = pd;
-                dp[qi][e] = p * (g - lds_delta[ql]) * a.scale;
-            }
+        } else {
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ql = qi * 32 + acc_row(e, hh);
+                    const float p = expf(s[qi][e] * a.scale + bias_key - lds_lse[ql]);
+                    float pd = p, g = dp[qi][e];
+                    if (a.drop.p > 0.f) {
+                        const bool keep = drop_keep(a.drop, thr, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
+                        pd = keep ? p * dsc : 0.f;
+                        g = keep ? g * dsc : 0.f;
+                    }
+                    s[qi][e] = pd;
+                    dp[qi][e] = p * (g - lds_delta[ql]) * a.scale;
+                }
+        }
         // dV^T += dO^T Pd,  dK^T += Q^T dS
         if constexpr (IS_BF16) {
 #pragma unroll

@@ -137,23 +137,24 @@ __device__ __forceinline__ float act_grad(float g, int gate) {
 
 // The element-wise tail of made_linear on 8 consecutive outputs of row m starting at column n:
 //   z = acc + bias  [-> Zout]   v = act(z)   v *= act'(G) * gate_scale   v = dropout(v)   v += R   row mask
+template <bool TRAIN>
 __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n, int nvalid, float* v, const float* bv,
                                           int rmod, bool r_vec) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += bv[j];
-    if (a.Zout) {
+    if (TRAIN && a.Zout) {
         const bool zv = (a.ldz % 8 == 0) && (((uintptr_t)a.Zout & 15) == 0);
         store8(a.Zout, a.z_dtype, (int64_t)m * a.ldz + n, v, nvalid, zv);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], a.act);
-    if (a.gate != MADE_GATE_NONE) {
+    if (TRAIN && a.gate != MADE_GATE_NONE) {
         float g[8];
         load8(a.G, a.g_dtype, (int64_t)m * a.ldg + n, g, nvalid, (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0));
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= act_grad(g[j], a.gate) * a.gate_scale;
     }
-    if (a.drop.p > 0.f) {
+    if (TRAIN && a.drop.p > 0.f) {
         const uint32_t thr = made_drop_threshold(a.drop.p);
         const float sc = 1.f / (1.f - a.drop.p);
         const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
                 const float* cp = Ct + row * CT_LD + cc * 8;
                 f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                epilogue8(a, m, n, nvalid, v, bv, rmod, r_vec);
+                epilogue8<true>(a, m, n, nvalid, v, bv, rmod, r_vec);
                 int64_t orow;
                 if (rpb > 0) {
                     const int b = m / rpb, t = m - b * rpb;
@@ -458,7 +459,8 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 // NST = 3: three stages, slabs kt+1 and kt+2 in flight while slab kt is multiplied, one barrier per slab and counted
 //          vmcnt waits -- for grids of at most one workgroup per CU (the decoder's 64-row Linears), where nothing else
 //          hides the ~2 us a slab takes to arrive.
-template <int NST>
+// TRAIN: the epilogue carries the training-path options (Zout / gate / dropout); the eval instantiation stays lean.
+template <int NST, bool TRAIN>
 __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel(const MadeLinearArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST == 1 ? G_LDS : NST * G_STAGE];
     const int tid = threadIdx.x;
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
                 const float* cp = Ct + row * G_CT_LD + cc * 8;
                 f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                epilogue8(a, m, n, nvalid, v, bv, rmod, r_vec);
+                epilogue8<TRAIN>(a, m, n, nvalid, v, bv, rmod, r_vec);
                 int64_t orow;
                 if (rpb > 0) {
                     const int b = m / rpb, t = m - b * rpb;
@@ -701,8 +703,12 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
         for (int s = 0; s < a.nseg; ++s) fast = fast && !a.seg[s].transposed;
         if (a.A2 && a.a2_replace) fast = fast && (a.a2_row_mod == 0) && (a.lda2 % 8 == 0);
         if (fast) {
-            if (tiles * a.batch <= 256) hipLaunchKernelGGL(linear_glds_kernel<3>, grid, block, 0, st, a);   // at most one workgroup per CU
-            else hipLaunchKernelGGL(linear_glds_kernel<1>, grid, block, 0, st, a);
+            const bool train = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
+            const bool small = tiles * a.batch <= 256;       // at most one workgroup per CU
+            if (small && train) hipLaunchKernelGGL((linear_glds_kernel<3, true>), grid, block, 0, st, a);
+            else if (small) hipLaunchKernelGGL((linear_glds_kernel<3, false>), grid, block, 0, st, a);
+            else if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_glds_kernel<1, false>), grid, block, 0, st, a);
         }
         else if (a.a_dtype == MADE_F32) hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((linear_kernel<bf16_t, bf16_t>), grid, block, 0, st, a);
