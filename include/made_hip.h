@@ -382,9 +382,13 @@ typedef struct MadeGemmTNArgs {
     float   alpha; int32_t accumulate;
     int64_t split_m;
     float*  colsum; int64_t colsum_zs1, colsum_zs2; /* optional, always accumulated */
+    const float* row_group_valid;                   /* optional [ceil(M/32)] (made_row_groups of row_mask; unbatched calls): slabs
+                                                       whose rows are all masked are skipped without being loaded */
 } MadeGemmTNArgs;
 
 int made_gemm_tn(const MadeGemmTNArgs* args, void* stream);
+/* out[g] = 1 if any of mask[32g .. 32g+31] is nonzero else 0 (computed once per batch, shared by every weight-gradient product) */
+int made_row_groups(const float* mask, int64_t M, float* out, void* stream);
 
 /* Row kernels of the backward pass (all parameter gradients are ACCUMULATED into f32 buffers the caller zeroes once per step).
  *

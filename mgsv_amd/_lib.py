@@ -96,7 +96,7 @@ class MadeGemmTNArgs(C.Structure):
                 ("a_zs1", i64), ("a_zs2", i64), ("b_zs1", i64), ("b_zs2", i64), ("c_zs1", i64), ("c_zs2", i64),
                 ("row_mask", vp), ("mask_zs1", i64), ("mask_zs2", i64),
                 ("alpha", f32), ("accumulate", i32), ("split_m", i64),
-                ("colsum", vp), ("colsum_zs1", i64), ("colsum_zs2", i64)]
+                ("colsum", vp), ("colsum_zs1", i64), ("colsum_zs2", i64), ("row_group_valid", vp)]
 
 
 class MadeAdamGroup(C.Structure):
@@ -145,6 +145,7 @@ SIGNATURES = {
                                          vp, vp, i64, i32, vp, vp, vp]),
     "made_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, i64, f32, vp, vp]),
     "made_repack": (C.c_int, [vp, i32, i64, vp]),
+    "made_row_groups": (C.c_int, [vp, i64, vp, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
     "made_set_criterion": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp, vp, vp]),
 }

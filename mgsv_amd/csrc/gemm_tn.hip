@@ -48,12 +48,33 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
     const TC* Bg = (const TC*)a.B + z1 * a.b_zs1 + z2 * a.b_zs2;
     const float* maskg = a.row_mask ? a.row_mask + z1 * a.mask_zs1 + z2 * a.mask_zs2 : nullptr;
 
-    // this block's share of the reduction: slabs [s_begin, s_end)
+    // this block's share of the reduction: slabs blockIdx.y, blockIdx.y + split_m, ... (interleaved, so that runs of padded
+    // rows -- whose slabs are skipped -- spread evenly over the blocks); local slab i <-> global slab blockIdx.y + i * split_m
     const int64_t nslab = (a.M + BM - 1) / BM;
-    const int64_t per = (nslab + a.split_m - 1) / a.split_m;
-    const int64_t s_begin = (int64_t)blockIdx.y * per;
-    const int64_t s_end = s_begin + per < nslab ? s_begin + per : nslab;
+    const int64_t sstep = a.split_m;
+    const int64_t s_begin = 0;
+    const int64_t s_end = nslab > (int64_t)blockIdx.y ? (nslab - blockIdx.y + sstep - 1) / sstep : 0;
     if (s_begin >= s_end) return;
+    auto gslab = [&](int64_t i) __attribute__((always_inline)) { return (int64_t)blockIdx.y + i * sstep; };
+
+    // slabs made only of masked rows contribute nothing: with row_group_valid (one flag per 32 rows, made_row_groups) the
+    // block learns which of its slabs to skip from ONE load + ballot (bit i = slab s_begin + i has a valid row)
+    uint64_t slab_bits = ~0ull;
+    if (a.row_group_valid && (s_end - s_begin) <= 64 && a.batch1 * a.batch2 == 1) {
+        const int64_t sl = lane < s_end ? gslab(lane) : nslab;
+        bool any = false;
+        if (lane < s_end) {
+            constexpr int GP = BM / 32;                     // 32-row groups per slab
+            const int64_t ngroups = (a.M + 31) / 32;
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const int64_t gi = sl * GP + g;
+                any = any || (gi < ngroups && a.row_group_valid[gi] != 0.f);
+            }
+        }
+        slab_bits = __ballot(any);
+    }
+    auto slab_live = [&](int64_t i) __attribute__((always_inline)) { return i >= 64 || ((slab_bits >> i) & 1ull) != 0; };
 
     frag_t ra[NCH], rb[NCH];
     auto load_slab = [&](int64_t slab) __attribute__((always_inline)) {
@@ -99,12 +120,16 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
     float csum = 0.f;
     const bool do_colsum = a.colsum != nullptr && tile_k == 0 && tid < TBN;
 
-    load_slab(s_begin);
+    if (slab_live(s_begin)) load_slab(gslab(s_begin));
     for (int64_t s = s_begin; s < s_end; ++s) {
-        __syncthreads();
-        store_slab();
-        __syncthreads();
-        if (s + 1 < s_end) load_slab(s + 1);
+        const bool live = slab_live(s);                     // block-uniform
+        if (live) {
+            __syncthreads();
+            store_slab();
+            __syncthreads();
+        }
+        if (s + 1 < s_end && slab_live(s + 1)) load_slab(gslab(s + 1));
+        if (!live) continue;
 
         if (do_colsum) {
 #pragma unroll 8
@@ -223,6 +248,7 @@ extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
     MADE_REQUIRE(a.split_m == 1 || a.accumulate, "made_gemm_tn: split_m > 1 needs accumulate = 1 (partials are added atomically)");
     MADE_REQUIRE(!a.accumulate || a.c_dtype == MADE_F32, "made_gemm_tn: accumulation needs an f32 C");
     MADE_UNSUPPORTED(nz < 65536 && a.split_m < 65536, "made_gemm_tn: batch / split too large for the grid");
+    MADE_REQUIRE(a.row_group_valid == nullptr || a.row_mask != nullptr, "made_gemm_tn: row_group_valid without row_mask");
     if (a.M == 0) return MADE_OK;                                   /* nothing to add (C is not cleared: callers zero gradients) */
     hipStream_t st = (hipStream_t)stream;
     const int per16 = a.ab_dtype == MADE_F32 ? 4 : 8;
@@ -244,4 +270,24 @@ extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
     if (a.ab_dtype == MADE_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(TNT), 0, st, a);
     else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(TNT), 0, st, a);
     return made_check_launch("made_gemm_tn");
+}
+
+namespace {
+__global__ __launch_bounds__(256) void row_groups_kernel(const float* mask, int64_t M, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;      // one half-wave per 32-row group
+    const int64_t ngroups = (M + 31) / 32;
+    const int64_t row = g * 32 + (lane & 31);
+    const bool v = g < ngroups && row < M && mask[row] != 0.f;
+    const uint64_t bal = __ballot(v);
+    const uint32_t half = (lane >> 5) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+    if ((lane & 31) == 0 && g < ngroups) out[g] = half != 0 ? 1.f : 0.f;
+}
+}  // namespace
+
+extern "C" int made_row_groups(const float* mask, int64_t M, float* out, void* stream) {
+    MADE_REQUIRE(mask && out && M > 0, "made_row_groups: bad arguments");
+    const int64_t ngroups = (M + 31) / 32;
+    hipLaunchKernelGGL(row_groups_kernel, dim3((unsigned)((ngroups * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, M, out);
+    return made_check_launch("made_row_groups");
 }

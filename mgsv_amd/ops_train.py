@@ -19,7 +19,7 @@ Pair = Tuple[int, int]
 
 
 def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulate: bool = False, split_m: Optional[int] = None,
-            row_mask: Optional[Tensor] = None, colsum: Optional[Tensor] = None, batch: Pair = (1, 1),
+            row_mask: Optional[Tensor] = None, row_groups: Optional[Tensor] = None, colsum: Optional[Tensor] = None, batch: Pair = (1, 1),
             a_zs: Pair = (0, 0), b_zs: Pair = (0, 0), c_zs: Pair = (0, 0), mask_zs: Pair = (0, 0),
             colsum_zs: Pair = (0, 0)) -> Tensor:
     """Cout[N,K] (+)= alpha * A[M,N]^T B[M,K]  (made_gemm_tn).  A, B, Cout are the 2-D views of batch element 0; the
@@ -46,6 +46,7 @@ def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulat
     a.b_zs1, a.b_zs2 = b_zs
     a.c_zs1, a.c_zs2 = c_zs
     a.row_mask = _p(_f32(row_mask, "row_mask"))
+    a.row_group_valid = _p(_f32(row_groups, "row_groups")) if (row_mask is not None and nz == 1) else None
     a.mask_zs1, a.mask_zs2 = mask_zs
     a.alpha, a.accumulate, a.split_m = float(alpha), int(bool(accumulate)), int(split_m)
     a.colsum = _p(_f32(colsum, "colsum"))
@@ -55,6 +56,16 @@ def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulat
     _timed("made_gemm_tn", flops, nbytes, lambda: check(lib().made_gemm_tn(C.byref(a), _stream()), "made_gemm_tn"),
            f"M={M} N={N} K={K} z={nz}")
     return Cout
+
+
+def row_groups(mask: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """flags per 32 rows of a flat [M] mask (made_row_groups): lets made_gemm_tn skip slabs of padded tokens."""
+    m = mask.reshape(-1)
+    M = m.numel()
+    if out is None:
+        out = torch.empty((M + 31) // 32, device=m.device, dtype=torch.float32)
+    check(lib().made_row_groups(_p(_f32(m, "mask")), M, _p(out), _stream()), "made_row_groups")
+    return out
 
 
 def dropout_desc(seed: int, site: int, p: float) -> MadeDropout:

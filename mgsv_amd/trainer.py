@@ -355,6 +355,8 @@ class MadeTrainer(MadeEngine):
         fus, fus_mask = ws["fus"], ws["fus_mask"]
         fus_mask[:, :Tv].copy_(fm)
         fus_mask[:, Tv:].copy_(sm)
+        # flags per 32 token rows: the weight-gradient products skip slabs made of padding without loading them
+        self._groups = {fus_mask.data_ptr(): tr.row_groups(fus_mask), fm.data_ptr(): tr.row_groups(fm), sm.data_ptr(): tr.row_groups(sm)}
         pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
         self._encode_train(self._inputs[0], fm, "video", ws, tw, 0)
         self._encode_train(self._inputs[1], sm, "audio", ws, tw, Tv)
@@ -542,10 +544,13 @@ class MadeTrainer(MadeEngine):
                  **kw) -> Optional[Tensor]:
         """Linear backward: dW += dz^T x, db += colsum(dz), dx = dz W (with the epilogue options of ops.linear)."""
         tr.gemm_tn(dz, x, self.G[key + ".w"] if gw is None else gw, accumulate=True, colsum=self.G[key + ".b"] if gb is None else gb,
-                   row_mask=row_mask)
+                   row_mask=row_mask, row_groups=self._rg(row_mask))
         if dx_out is None:
             return None
         return ops.linear(dz, self.P[key + ".wt"] if wt is None else wt, None, out=dx_out, tile_skip_mask=skip, **kw)
+
+    def _rg(self, row_mask: Optional[Tensor]) -> Optional[Tensor]:
+        return self._groups.get(row_mask.data_ptr()) if row_mask is not None else None
 
     @torch.no_grad()
     def backward(self, g_ret: Optional[Tensor] = None, g_loc: Optional[Tensor] = None, zero_grad: bool = True) -> None:
@@ -701,8 +706,8 @@ class MadeTrainer(MadeEngine):
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[e + ".lse"], tw["e_delta"], H,
                              key_mask=fus_mask, q_skip_mask=fus_mask, drop=self._drop(f"enc.{l}" + ".attn", pd))
             gW, gb = G[p + ".in.w"], G[p + ".in.b"]
-            tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], row_mask=fskip)
-            tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], row_mask=fskip)
+            tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], row_mask=fskip, row_groups=self._rg(fskip))
+            tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], row_mask=fskip, row_groups=self._rg(fskip))
             nxt = tw["dfus"] if dx is tw["eg1"] else tw["eg1"]
             dsrc = ops.linear(gq, P[p + ".in.wt"], None, R=dx, out=nxt, tile_skip_mask=fskip)
         dfus = dsrc.view(B, L, D)
@@ -809,7 +814,7 @@ class MadeTrainer(MadeEngine):
             dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3, row_mask=mflat, skip=mflat, R=g1)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
         xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
-        tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], row_mask=mflat)
+        tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], row_mask=mflat, row_groups=self._rg(mflat))
 
     def _dropped_copy(self, out: Tensor, x: Tensor, site: str, p: float, ld: int) -> Tensor:
         raise NotImplementedError("temporal transformer depth > 1 is not covered by the training path yet")

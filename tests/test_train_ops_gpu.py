@@ -45,6 +45,30 @@ def test_gemm_tn_matches_torch(T, dtype, tol, M, N, K):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-3)])
+def test_gemm_tn_skips_padded_slabs(T, dtype, tol):
+    """prefix-valid sequences (long runs of padding): with the 32-row validity flags whole slabs are skipped, result unchanged
+    even when the padded rows hold NaN."""
+    ops, tr = T
+    Bn, L, N, K = 12, 300, 256, 384
+    lens = torch.tensor([300, 10, 150, 0, 299, 33, 64, 65, 1, 200, 128, 31], device="cuda")
+    mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).float().reshape(-1)
+    M = Bn * L
+    A, B = _rand(M, N, dtype=dtype, seed=1), _rand(M, K, dtype=dtype, seed=2)
+    ref = (A.float() * mask[:, None]).t() @ B.float()
+    A[mask == 0] = float("nan"); B[mask == 0] = float("nan")
+    groups = tr.row_groups(mask)
+    assert groups.numel() == (M + 31) // 32
+    gref = torch.nn.functional.pad(mask, (0, (-M) % 32)).view(-1, 32).amax(1)
+    assert torch.equal(groups, gref)
+    for split in (1, 7, None):
+        C = torch.zeros(N, K, device="cuda")
+        cs = torch.zeros(N, device="cuda")
+        tr.gemm_tn(A, B, C, accumulate=True, row_mask=mask, row_groups=groups, split_m=split, colsum=cs)
+        assert torch.isfinite(C).all()
+        assert float((C - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-3)])
 def test_gemm_tn_batched_and_summed(T, dtype, tol):
     ops, tr = T
     Z1, Z2, M, N, K = 3, 4, 70, 128, 256
