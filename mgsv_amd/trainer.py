@@ -357,23 +357,31 @@ class MadeTrainer(MadeEngine):
         fus_mask[:, Tv:].copy_(sm)
         # flags per 32 token rows: the weight-gradient products skip slabs made of padding without loading them
         self._groups = {fus_mask.data_ptr(): tr.row_groups(fus_mask), fm.data_ptr(): tr.row_groups(fm), sm.data_ptr(): tr.row_groups(sm)}
-        pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
-        self._encode_train(self._inputs[0], fm, "video", ws, tw, 0)
+        # the video branch (B*T_v rows: launches far smaller than the chip) runs on a second HIP stream beside the audio branch;
+        # so does the X-Pool / similarity / retrieval-loss branch beside the DETR stack (joined at the end of the step)
+        cur, side = torch.cuda.current_stream(), self._side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
+            self._encode_train(self._inputs[0], fm, "video", ws, tw, 0)
         self._encode_train(self._inputs[1], sm, "audio", ws, tw, Tv)
+        cur.wait_stream(side)
         frame, seg = fus[:, :Tv], fus[:, Tv:]
         video, music = ws["video"], ws["music"]
         out: Dict[str, Tensor] = dict(video_feats=video, music_feats=music, frame_feats=frame, segment_feats=seg)
 
         # ---- X-Pool (in-batch) + similarities + retrieval loss
-        xmask = sm if c.fusion_mask == 1 else None
-        self._xpool_train(video, seg, xmask, ws, tw, B, Ta)
-        ops.l2norm_rows(video, out_f32=tw["vn"]); ops.l2norm_rows(music, out_f32=tw["mn"])
-        if B % 4 == 0 and B <= 256:                          # one output tile: split K over workgroups (exact-f32 MFMA either way)
-            split = max(2, min(16, D // 32))
-            ops.linear_splitk(tw["vn"], tw["mn"], None, tw["sd_ws"][:split * B * B], split, out=ws["sims_dual"])
-        else:
-            ops.linear(tw["vn"], tw["mn"], None, out=ws["sims_dual"])
-        self._retrieval_loss(ws, video, music)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            xmask = sm if c.fusion_mask == 1 else None
+            self._xpool_train(video, seg, xmask, ws, tw, B, Ta)
+            ops.l2norm_rows(video, out_f32=tw["vn"]); ops.l2norm_rows(music, out_f32=tw["mn"])
+            if B % 4 == 0 and B <= 256:                      # one output tile: split K over workgroups (exact-f32 MFMA either way)
+                split = max(2, min(16, D // 32))
+                ops.linear_splitk(tw["vn"], tw["mn"], None, tw["sd_ws"][:split * B * B], split, out=ws["sims_dual"])
+            else:
+                ops.linear(tw["vn"], tw["mn"], None, out=ws["sims_dual"])
+            self._retrieval_loss(ws, video, music)
         out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"], retrieval_loss=ws["ret_loss"])
 
         # ---- DETR encoder
@@ -481,6 +489,7 @@ class MadeTrainer(MadeEngine):
         self._match = (pi, ti, cnt)
         out.update(matcher_pred_idx=pi.view(nd, B, -1), matcher_tgt_idx=ti.view(nd, B, -1), matcher_count=cnt.view(nd, B),
                    matcher_status=status, criterion_losses=losses, localization_loss=total)
+        cur.wait_stream(side)
         return out
 
     def _encode_train(self, feats: Tensor, mask: Tensor, which: str, ws, tw, row_off: int) -> None:
@@ -572,6 +581,12 @@ class MadeTrainer(MadeEngine):
         dvideo.zero_(); dmusic.zero_()
         video, music = ws["video"], ws["music"]
         frame = fus[:, :Tv]
+        # the X-Pool / similarity branch is independent of the DETR stack until the temporal encoders: its (latency-bound)
+        # backward runs on the second stream beside the decoder's
+        cur, side = torch.cuda.current_stream(), self._side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
 
         # ---------------- criterion + heads
         logits, spans = ws["logits"], ws["spans"]
@@ -676,7 +691,7 @@ class MadeTrainer(MadeEngine):
             if Q > 1 or True:                                 # the query embedding also enters through q,k of the self-attention
                 dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
                 tr.colsum(dqk, G["query_embed"].view(-1))
-        (dvideo if c.moment_query_type == "video" else dmusic).copy_(dtgt.view(B, D).float()) if Q == 1 else None
+        dtgt0 = dtgt                                          # gradient of the decoder's content query = the clip-level vector
         # gradient of the memory: values path (Pd^T dpooled) + keys path (dS^T q'), all layers in one product per sample
         dmem = tw["eg1"]
         tr.gemm_tn(PdS.view(B, 2 * nd * HQ, Lp)[0, :, :L], GQ.view(B, 2 * nd * HQ, D)[0], dmem.view(B, L, D)[0], batch=(B, 1),
@@ -712,12 +727,17 @@ class MadeTrainer(MadeEngine):
             dsrc = ops.linear(gq, P[p + ".in.wt"], None, R=dx, out=nxt, tile_skip_mask=fskip)
         dfus = dsrc.view(B, L, D)
 
-        # ---------------- X-Pool + similarities + retrieval loss
-        self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
+        # ---------------- join the X-Pool / similarity branch, merge the gradients of the clip-level vectors
+        cur.wait_stream(side)
+        dq_vec = dvideo if c.moment_query_type == "video" else dmusic
+        tr.add3(dq_vec, dq_vec, dtgt0.view(B, D))
 
-        # ---------------- temporal encoders
-        self._encode_bwd("video", ws, tw, dfus[:, :Tv], tw["dframe_x"].view(B, Tv, D) if c.contrastive_align_loss else None, dvideo, fm, feats_v)
+        # ---------------- temporal encoders (video on the second stream)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._encode_bwd("video", ws, tw, dfus[:, :Tv], tw["dframe_x"].view(B, Tv, D) if c.contrastive_align_loss else None, dvideo, fm, feats_v)
         self._encode_bwd("audio", ws, tw, dfus[:, Tv:], tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a)
+        cur.wait_stream(side)
 
     def _retrieval_bwd(self, ws, tw, g_ret: Optional[Tensor], B: int, S: int, sm: Tensor) -> None:
         c, P, G, D = self.cfg, self.P, self.G, self.cfg.D
