@@ -149,6 +149,11 @@ typedef struct MadeLinearArgs {
     int64_t      ldg; float gate_scale; int32_t z_dtype;
     void*        Zout; int64_t ldz;                         /* optional: the pre-activation z is also stored (saved for backward) */
     MadeDropout  drop; int64_t drop_ld;                     /* dropout after act/gate, element index row*drop_ld + col */
+    /* row gather (padded tokens cost nothing): the kernel works on logical rows r < *n_rows (device scalar) that live at
+       physical rows row_index[r] of A / A2 / R / G / out / masks (made_row_index of the token mask); every per-row quantity
+       (residual, dropout index, rows_per_batch addressing) keeps using the PHYSICAL row, so valid rows are bit-identical to
+       the ungathered call and padded rows are simply never read or written.  M stays the physical row count. */
+    const int32_t* row_index; const int32_t* n_rows;
 } MadeLinearArgs;
 
 int made_linear(const MadeLinearArgs* args, void* stream);
@@ -384,11 +389,17 @@ typedef struct MadeGemmTNArgs {
     float*  colsum; int64_t colsum_zs1, colsum_zs2; /* optional, always accumulated */
     const float* row_group_valid;                   /* optional [ceil(M/32)] (made_row_groups of row_mask; unbatched calls): slabs
                                                        whose rows are all masked are skipped without being loaded */
+    const int32_t* row_index; const int32_t* n_rows; /* optional row gather (unbatched calls): the reduction runs over the
+                                                       *n_rows rows row_index[0..] only (made_row_index); row_mask is not needed */
 } MadeGemmTNArgs;
 
 int made_gemm_tn(const MadeGemmTNArgs* args, void* stream);
 /* out[g] = 1 if any of mask[32g .. 32g+31] is nonzero else 0 (computed once per batch, shared by every weight-gradient product) */
 int made_row_groups(const float* mask, int64_t M, float* out, void* stream);
+/* made_row_index: compaction of a [M] token mask: row_index[r] = index of the r-th nonzero entry (r < n), entries r >= n repeat
+ * the last valid row (0 when there is none), n_rows[0] = n.  One workgroup, M <= 2^22.  Feeds the row gather of made_linear /
+ * made_gemm_tn: the GEMMs of a padded batch then cost what its valid tokens cost. */
+int made_row_index(const float* mask, int64_t M, int32_t* row_index, int32_t* n_rows, void* stream);
 
 /* Row kernels of the backward pass (all parameter gradients are ACCUMULATED into f32 buffers the caller zeroes once per step).
  *

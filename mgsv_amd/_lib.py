@@ -45,7 +45,7 @@ class MadeLinearArgs(C.Structure):
                 ("split_ws", vp),
                 ("seg", MadeLinearSeg * 4),
                 ("G", vp), ("g_dtype", i32), ("gate", i32), ("ldg", i64), ("gate_scale", f32), ("z_dtype", i32),
-                ("Zout", vp), ("ldz", i64), ("drop", MadeDropout), ("drop_ld", i64)]
+                ("Zout", vp), ("ldz", i64), ("drop", MadeDropout), ("drop_ld", i64), ("row_index", vp), ("n_rows", vp)]
 
 
 class MadeFinishArgs(C.Structure):
@@ -96,7 +96,8 @@ class MadeGemmTNArgs(C.Structure):
                 ("a_zs1", i64), ("a_zs2", i64), ("b_zs1", i64), ("b_zs2", i64), ("c_zs1", i64), ("c_zs2", i64),
                 ("row_mask", vp), ("mask_zs1", i64), ("mask_zs2", i64),
                 ("alpha", f32), ("accumulate", i32), ("split_m", i64),
-                ("colsum", vp), ("colsum_zs1", i64), ("colsum_zs2", i64), ("row_group_valid", vp)]
+                ("colsum", vp), ("colsum_zs1", i64), ("colsum_zs2", i64), ("row_group_valid", vp),
+                ("row_index", vp), ("n_rows", vp)]
 
 
 class MadeAdamGroup(C.Structure):
@@ -146,6 +147,7 @@ SIGNATURES = {
     "made_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, i64, f32, vp, vp]),
     "made_repack": (C.c_int, [vp, i32, i64, vp]),
     "made_row_groups": (C.c_int, [vp, i64, vp, vp]),
+    "made_row_index": (C.c_int, [vp, i64, vp, vp, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
     "made_set_criterion": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp, vp, vp]),
 }

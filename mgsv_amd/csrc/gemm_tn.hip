@@ -50,7 +50,9 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
 
     // this block's share of the reduction: slabs blockIdx.y, blockIdx.y + split_m, ... (interleaved, so that runs of padded
     // rows -- whose slabs are skipped -- spread evenly over the blocks); local slab i <-> global slab blockIdx.y + i * split_m
-    const int64_t nslab = (a.M + BM - 1) / BM;
+    int64_t Mv = a.M;                                       // row gather: the reduction runs over the valid rows only
+    if (a.n_rows) { const int64_t nv = *a.n_rows; Mv = nv < a.M ? nv : a.M; }
+    const int64_t nslab = (Mv + BM - 1) / BM;
     const int64_t sstep = a.split_m;
     const int64_t s_begin = 0;
     const int64_t s_end = nslab > (int64_t)blockIdx.y ? (nslab - blockIdx.y + sstep - 1) / sstep : 0;
@@ -77,15 +79,24 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
     auto slab_live = [&](int64_t i) __attribute__((always_inline)) { return i >= 64 || ((slab_bits >> i) & 1ull) != 0; };
 
     frag_t ra[NCH], rb[NCH];
+    int64_t prow[NCH];                                      // physical rows of the slab that is loaded next (fetched one slab ahead)
+    auto load_rows = [&](int64_t slab) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * TNT;
+            const int64_t m = slab * BM + c / CPR;
+            const int64_t ml = m < Mv ? m : Mv - 1;
+            prow[i] = a.row_index ? (int64_t)a.row_index[ml] : ml;
+        }
+    };
     auto load_slab = [&](int64_t slab) __attribute__((always_inline)) {
         // branch-free: clamped addresses, masking on the registers (rows past M, columns past N / K, masked rows)
         float mk[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * TNT;
-            const int row = c / CPR, cc = c % CPR;
-            int64_t m = slab * BM + row;
-            const int64_t mc = m < a.M ? m : a.M - 1;
+            const int cc = c % CPR;
+            const int64_t mc = prow[i];
             int64_t na = n0 + cc * PER16, kb = k0 + cc * PER16;
             const int64_t nac = na < a.N ? na : 0, kbc = kb < a.K ? kb : 0;     // a chunk may run past N / K inside the row pitch
             ra[i] = *(const frag_t*)(Ag + mc * a.lda + nac);
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * TNT;
             const int row = c / CPR, cc = c % CPR;
-            const bool rowok = (slab * BM + row) < a.M && mk[i] != 0.f;
+            const bool rowok = (slab * BM + row) < Mv && mk[i] != 0.f;
             ra[i] = keep_or_zero(ra[i], rowok && (n0 + cc * PER16 < a.N));     // columns >= N only feed C rows that are not stored
             rb[i] = keep_or_zero(rb[i], rowok && (k0 + cc * PER16 < a.K));
         }
@@ -120,7 +131,9 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
     float csum = 0.f;
     const bool do_colsum = a.colsum != nullptr && tile_k == 0 && tid < TBN;
 
+    load_rows(gslab(s_begin));
     if (slab_live(s_begin)) load_slab(gslab(s_begin));
+    if (s_begin + 1 < s_end) load_rows(gslab(s_begin + 1));
     for (int64_t s = s_begin; s < s_end; ++s) {
         const bool live = slab_live(s);                     // block-uniform
         if (live) {
@@ -128,7 +141,10 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
             store_slab();
             __syncthreads();
         }
-        if (s + 1 < s_end && slab_live(s + 1)) load_slab(gslab(s + 1));
+        if (s + 1 < s_end) {
+            if (slab_live(s + 1)) load_slab(gslab(s + 1));
+            if (s + 2 < s_end) load_rows(gslab(s + 2));
+        }
         if (!live) continue;
 
         if (do_colsum) {
@@ -211,12 +227,15 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const MadeGemmTNArgs
     const int64_t z = blockIdx.z, z1 = z / a.batch2, z2 = z % a.batch2;
     const bool active = e < a.N * a.K;
     const int64_t n = active ? e / a.K : 0, k = active ? e % a.K : 0;
-    const int64_t per = (a.M + gridDim.y - 1) / gridDim.y;
-    const int64_t m0 = (int64_t)blockIdx.y * per, m1 = m0 + per < a.M ? m0 + per : a.M;
+    int64_t Mv = a.M;
+    if (a.n_rows) { const int64_t nv = *a.n_rows; Mv = nv < a.M ? nv : a.M; }
+    const int64_t per = (Mv + gridDim.y - 1) / gridDim.y;
+    const int64_t m0 = (int64_t)blockIdx.y * per, m1 = m0 + per < Mv ? m0 + per : Mv;
     const float* maskg = a.row_mask ? a.row_mask + z1 * a.mask_zs1 + z2 * a.mask_zs2 : nullptr;
     const int64_t ao = z1 * a.a_zs1 + z2 * a.a_zs2, bo = z1 * a.b_zs1 + z2 * a.b_zs2;
     float acc = 0.f, cs = 0.f;
-    for (int64_t m = m0; m < m1; ++m) {
+    for (int64_t ml = m0; ml < m1; ++ml) {
+        const int64_t m = a.row_index ? (int64_t)a.row_index[ml] : ml;
         if (maskg && maskg[m] == 0.f) continue;
         const float av = load_as_f32(a.A, a.ab_dtype, ao + m * a.lda + n);
         acc += av * load_as_f32(a.B, a.ab_dtype, bo + m * a.ldb + k);
@@ -249,6 +268,9 @@ extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
     MADE_REQUIRE(!a.accumulate || a.c_dtype == MADE_F32, "made_gemm_tn: accumulation needs an f32 C");
     MADE_UNSUPPORTED(nz < 65536 && a.split_m < 65536, "made_gemm_tn: batch / split too large for the grid");
     MADE_REQUIRE(a.row_group_valid == nullptr || a.row_mask != nullptr, "made_gemm_tn: row_group_valid without row_mask");
+    MADE_REQUIRE((a.row_index == nullptr) == (a.n_rows == nullptr), "made_gemm_tn: row_index and n_rows come together");
+    MADE_UNSUPPORTED(a.row_index == nullptr || nz == 1, "made_gemm_tn: row gather is for unbatched calls");
+    if (a.row_index) a.row_group_valid = nullptr;
     if (a.M == 0) return MADE_OK;                                   /* nothing to add (C is not cleared: callers zero gradients) */
     hipStream_t st = (hipStream_t)stream;
     const int per16 = a.ab_dtype == MADE_F32 ? 4 : 8;
@@ -290,4 +312,46 @@ extern "C" int made_row_groups(const float* mask, int64_t M, float* out, void* s
     const int64_t ngroups = (M + 31) / 32;
     hipLaunchKernelGGL(row_groups_kernel, dim3((unsigned)((ngroups * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, M, out);
     return made_check_launch("made_row_groups");
+}
+
+namespace {
+// stream compaction of a token mask in one workgroup of 16 waves: each wave owns a contiguous range, counts it with
+// ballots (coalesced loads, no serial dependence), the 16 totals are scanned, then the indices are scattered
+__global__ __launch_bounds__(1024) void row_index_kernel(const float* mask, int64_t M, int32_t* row_index, int32_t* n_rows) {
+    __shared__ int wsum[16];
+    __shared__ int wlast[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per = ((M + 15) / 16 + 63) / 64 * 64;          // elements per wave, multiple of 64
+    const int64_t b = (int64_t)wave * per, e = b + per < M ? b + per : M;
+    int cnt = 0, last = -1;
+    for (int64_t i = b + lane; i - lane < e; i += 64) {
+        const bool v = i < e && mask[i] != 0.f;
+        const uint64_t bal = __ballot(v);
+        cnt += __popcll(bal);
+        if (bal) last = (int)(i - lane) + 63 - __clzll(bal);
+    }
+    if (lane == 0) { wsum[wave] = cnt; wlast[wave] = last; }
+    __syncthreads();
+    int base = 0, total = 0, lastv = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) base += wsum[w];
+        total += wsum[w];
+        if (wlast[w] >= 0) lastv = wlast[w];
+    }
+    for (int64_t i = b + lane; i - lane < e; i += 64) {
+        const bool v = i < e && mask[i] != 0.f;
+        const uint64_t bal = __ballot(v);
+        if (v) row_index[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
+        base += __popcll(bal);
+    }
+    if (threadIdx.x == 0) n_rows[0] = total;
+    for (int64_t i = total + threadIdx.x; i < M; i += 1024) row_index[i] = lastv;
+}
+}  // namespace
+
+extern "C" int made_row_index(const float* mask, int64_t M, int32_t* row_index, int32_t* n_rows, void* stream) {
+    MADE_REQUIRE(mask && row_index && n_rows && M > 0, "made_row_index: bad arguments");
+    MADE_UNSUPPORTED(M <= (1 << 22), "made_row_index: M=%lld too large for the single-workgroup scan", (long long)M);
+    hipLaunchKernelGGL(row_index_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, M, row_index, n_rows);
+    return made_check_launch("made_row_index");
 }

@@ -197,6 +197,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int splitk = a.split_k > 1 ? a.split_k : 1;
     const int64_t z = splitk > 1 ? 0 : blockIdx.z;         // grid.z = K split index when split_k > 1, else problem index
+    // row gather: logical row r (r < *n_rows) lives at physical row row_index[r]; tiles past the valid rows have nothing to do
+    int Mv = M;
+    if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
+    if (m0 >= Mv) return;
 
     // segment of this column tile
     int si = 0;
@@ -249,8 +253,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = m0 + srow0 + 32 * i, gn = n0 + srow0 + 32 * i;
-            const int gmc = gm < M ? gm : M - 1, gnc = gn < N ? gn : N - 1;       // clamped: every lane always loads
-            ka[i] = gm < M && (a.a_row_mask == nullptr || a.a_row_mask[gmc] != 0.f);
+            const int gml = gm < Mv ? gm : Mv - 1, gnc = gn < N ? gn : N - 1;     // clamped: every lane always loads
+            const int gmc = a.row_index ? a.row_index[gml] : gml;                 // physical row
+            ka[i] = gm < Mv && (a.a_row_mask == nullptr || a.a_row_mask[gmc] != 0.f);
             kw[i] = gn < N;
             pa[i] = A + (int64_t)gmc * lda + kce;
             pa2[i] = A2 ? A2 + (int64_t)(a2mod > 0 ? gmc % a2mod : gmc) * a.lda2 + kce : nullptr;
@@ -396,8 +401,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
 #pragma unroll 2
             for (int i = 0; i < 8; ++i) {
                 const int row = (tid >> 4) + 16 * i;
-                const int m = m0 + row;
-                if (m >= M) break;
+                const int ml = m0 + row;
+                if (ml >= Mv) break;
+                const int m = a.row_index ? a.row_index[ml] : ml;                   // physical row from here on
                 const float* cp = Ct + row * CT_LD + cc * 8;
                 f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -472,9 +478,13 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
     const int n_tiles = (N + BN - 1) / BN;
     // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2); give each XCD a contiguous run of
     // tiles so the n-tiles of one 128-row activation panel hit the same L2 (bijective for any tile count)
+    int Mv = M;                                            // row gather (see linear_kernel): only the first ceil(Mv/128) row tiles exist
+    if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
+    const int nwg = ((Mv + BM - 1) / BM) * n_tiles;        // live tiles; workgroups are dispatched round-robin over the XCDs in
+    if ((int)blockIdx.x >= nwg) return;                    // blockIdx order, so the first nwg of them spread evenly
     int tile_id;
     {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
+        const int xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
         tile_id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
     }
     const int tile_m = tile_id / n_tiles, tile_n = tile_id % n_tiles;
@@ -523,7 +533,8 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * (4 * wave + i) + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(row);
-        int gm = m0 + row; gm = gm < M ? gm : M - 1;          // rows past the edge are fetched from a valid row and never stored
+        int gm = m0 + row; gm = gm < Mv ? gm : Mv - 1;        // rows past the edge are fetched from a valid row and never stored
+        if (a.row_index) gm = a.row_index[gm];
         int gn = n0 + row; gn = gn < N ? gn : N - 1;
         pa[i] = Abase + (int64_t)gm * lda + chunk * 8;
         pw[i] = Wbase + (int64_t)gn * a.ldw + chunk * 8;
@@ -628,8 +639,9 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
 #pragma unroll 2
             for (int i = 0; i < 4; ++i) {
                 const int row = (tid >> 4) + 16 * i;
-                const int m = m0 + half * 64 + row;
-                if (m >= M) break;
+                const int ml = m0 + half * 64 + row;
+                if (ml >= Mv) break;
+                const int m = a.row_index ? a.row_index[ml] : ml;
                 const float* cp = Ct + row * G_CT_LD + cc * 8;
                 f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -679,6 +691,12 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
         } else {
             MADE_REQUIRE(a.seg[0].col_begin == 0, "made_linear: first segment must start at column 0");
         }
+    }
+    MADE_REQUIRE((a.row_index == nullptr) == (a.n_rows == nullptr), "made_linear: row_index and n_rows come together");
+    if (a.row_index) {
+        MADE_UNSUPPORTED(a.split_k <= 1 && a.batch == 1, "made_linear: row gather is not available with split-K or batches");
+        for (int s = 0; s < a.nseg; ++s)
+            MADE_UNSUPPORTED(!a.seg[s].transposed, "made_linear: row gather is not available on transposed segments");
     }
     if (a.gate != MADE_GATE_NONE) MADE_REQUIRE(a.G != nullptr, "made_linear: gate without G");
     if (a.gate != MADE_GATE_NONE || a.Zout || a.drop.p > 0.f) {

@@ -218,6 +218,9 @@ class MadeEngine:
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D),
             sims_single=E(B, B, dtype=torch.float32), sims_dual=E(B, B, dtype=torch.float32),
             ret_loss=E(1, dtype=torch.float32),
+            # row gather (valid-token lists) of the video / audio / fused sequences
+            rows_v=(E(B * Tv, dtype=torch.int32), E(1, dtype=torch.int32)), rows_a=(E(B * Ta, dtype=torch.int32), E(1, dtype=torch.int32)),
+            rows_f=(E(B * L, dtype=torch.int32), E(1, dtype=torch.int32)),
         )
         if c.contrastive_align_loss:
             Dc = c.contrastive_hdim
@@ -234,14 +237,14 @@ class MadeEngine:
 
     # ------------------------------------------------------------------ building blocks
     def _mha_block(self, x: Tensor, B: int, T: int, w_in: Tensor, b_in: Tensor, key_mask: Optional[Tensor],
-                   ws: Dict[str, Tensor], H: int, pos: Optional[Tensor] = None, skip: Optional[Tensor] = None) -> Tensor:
+                   ws: Dict[str, Tensor], H: int, pos: Optional[Tensor] = None, skip: Optional[Tensor] = None, rows=None) -> Tensor:
         """packed in-proj -> flash attention; x [B*T, D]; q,k from (x + pos), v from x; returns att [B*T, D]."""
         D = self.cfg.D
         qkv = ws["qkv"][:B * T]
         if pos is None:
-            ops.linear(x, w_in, b_in, out=qkv, tile_skip_mask=skip)
+            ops.linear(x, w_in, b_in, out=qkv, rows=rows)
         else:                                       # q and k are projected from x + pos (given precomputed), v from x
-            ops.linear(x, w_in, b_in, A2=pos, a2_replace=True, tile_skip_mask=skip,
+            ops.linear(x, w_in, b_in, A2=pos, a2_replace=True, rows=rows,
                        segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
         q3 = qkv.view(B, T, 3 * D)
         att = ws["att"][:B * T]
@@ -249,7 +252,7 @@ class MadeEngine:
                       q_skip_mask=key_mask if skip is not None else None)
         return att
 
-    def _encode(self, feats: Tensor, mask: Tensor, which: str, wsall: Dict[str, Tensor], row_off: int) -> None:
+    def _encode(self, feats: Tensor, mask: Tensor, which: str, wsall: Dict[str, Tensor], row_off: int, rows=None) -> None:
         """reference model/model_Base.py:544-617 -> writes fus[:, row_off:row_off+T] and mean/normalised vector."""
         c, P = self.cfg, self.P
         ws = wsall if which == "audio" else {**wsall, **{k[2:]: v for k, v in wsall.items() if k.startswith("v_")}}
@@ -260,26 +263,25 @@ class MadeEngine:
         if P[pe].shape[0] < T:
             raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < T={T} "
                              "(reference model/model_Base.py:533 raises here too)")
-        rows = B * T
+        nrow = B * T
         mflat = mask.reshape(-1)
         act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE
+        # padded tokens (mask 0) are never read by a valid token: the GEMMs gather the valid rows only (`rows`), the row kernels
+        # and the attention skip them; valid rows are bit-identical to the dense computation
         if self.tc == torch.bfloat16:       # mask + f32->bf16 once, then the direct-to-LDS GEMM
-            xin = ops.cast_mask_rows(feats.view(rows, Kin), mflat, ws["xin"][:rows * Kin].view(rows, Kin))
-            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows],
-                           tile_skip_mask=mflat)
+            xin = ops.cast_mask_rows(feats.view(nrow, Kin), mflat, ws["xin"][:nrow * Kin].view(nrow, Kin))
+            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, R=P[pe][:T], r_row_mod=T, out=ws["x0"][:nrow], rows=rows)
         else:
-            x = ops.linear(feats.view(rows, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act,
-                           R=P[pe][:T], r_row_mod=T, out=ws["x0"][:rows], tile_skip_mask=mflat)
+            x = ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act,
+                           R=P[pe][:T], r_row_mod=T, out=ws["x0"][:nrow], rows=rows)
         for l in range(depth):
             p = f"{mod}.layers.{l}"
-            # padded tokens (mask 0) are never read by a valid token, so whole tiles / rows / query groups of them are skipped
-            x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x1"][:rows], row_skip=mflat)
-            att = self._mha_block(x1, B, T, P[p + ".in.w"], P[p + ".in.b"], mask, ws, c.SA_temporal_heads, skip=mflat)
-            x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=ws["x2"][:rows], tile_skip_mask=mflat)
-            x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3"][:rows], row_skip=mflat)
-            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=ws["ffn"][:rows, :c.temporal_ffn_dim],
-                           tile_skip_mask=mflat)
-            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=ws["x0"][:rows], tile_skip_mask=mflat)
+            x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x1"][:nrow], row_skip=mflat)
+            att = self._mha_block(x1, B, T, P[p + ".in.w"], P[p + ".in.b"], mask, ws, c.SA_temporal_heads, skip=mflat, rows=rows)
+            x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=ws["x2"][:nrow], rows=rows)
+            x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3"][:nrow], row_skip=mflat)
+            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=ws["ffn"][:nrow, :c.temporal_ffn_dim], rows=rows)
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=ws["x0"][:nrow], rows=rows)
         if "concat" in c.mml_fusion:
             fus = ws["fus"]
             local = fus[:, row_off:row_off + T]                          # [B, T, D] view
@@ -390,8 +392,9 @@ class MadeEngine:
             else:
                 fus_mask.copy_(sm)
             pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
-            self._encode(frame_feats.contiguous(), fm, "video", ws, 0)
-        self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv)
+            rows_f = ops.row_index(fus_mask, out=ws["rows_f"])
+            self._encode(frame_feats.contiguous(), fm, "video", ws, 0, rows=ops.row_index(fm, out=ws["rows_v"]))
+        self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv, rows=ops.row_index(sm, out=ws["rows_a"]))
         cur.wait_stream(side)
         if concat:
             frame, seg = fus[:, :Tv], fus[:, Tv:]
@@ -425,12 +428,11 @@ class MadeEngine:
         ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)      # layer 0: src + pos (no norm)
         for l in range(c.detr_enc_layers):
             p = f"detr_transformer.encoder.layers.{l}"
-            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip)
-            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows], tile_skip_mask=fskip)
+            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip, rows=rows_f)
+            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows], rows=rows_f)
             s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x2"][:rows], row_skip=fskip)
-            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward],
-                           tile_skip_mask=fskip)
-            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=ws["x1"][:rows], tile_skip_mask=fskip)
+            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward], rows=rows_f)
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=ws["x1"][:rows], rows=rows_f)
             # the norm that produces the next src also emits src + pos (next layer's q/k input, decoder's keys)
             src = ws["x3" if l % 2 == 0 else "x0"][:rows]
             ops.layernorm_add(x, P[p + ".ln2.g"], P[p + ".ln2.b"], pos2, src, srcpos, row_skip=fskip)

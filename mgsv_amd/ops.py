@@ -80,7 +80,9 @@ class KernelTimer:
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             frac = 1.0
-            if isinstance(desc, tuple):                 # (text, skip mask, rows per tile): count only tiles that were executed
+            if isinstance(desc, tuple) and desc[0] == "rows":   # row gather: (tag, n_rows tensor, M): only the valid rows are computed
+                frac = min(1.0, (math.ceil(int(desc[1].item()) / 128) * 128) / max(desc[2], 1))
+            elif isinstance(desc, tuple):               # (text, skip mask, rows per tile): count only tiles that were executed
                 _, mask, tile = desc
                 key = (mask.data_ptr(), mask.numel(), tile)
                 if key not in frac_cache:
@@ -128,7 +130,7 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
            r_row_mod: int = 0, out_row_mask: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
            tile_skip_mask: Optional[Tensor] = None, batch: int = 1, a_z_stride: int = 0, w_z_stride: int = 0, M: Optional[int] = None,
            N: Optional[int] = None, K: Optional[int] = None, gate: int = 0, G: Optional[Tensor] = None, gate_scale: float = 1.0,
-           Zout: Optional[Tensor] = None, drop=None, drop_ld: Optional[int] = None) -> Tensor:
+           Zout: Optional[Tensor] = None, drop=None, drop_ld: Optional[int] = None, rows=None) -> Tensor:
     """out = act(A' W^T + bias) (+R).  A [M,K] (row stride free, unit inner stride), W [N,K].
     Training extras: Zout receives the pre-activation; gate/G multiply by act'(G) * gate_scale; drop = (seed, site, p)
     applies the stateless dropout of include/made_hip.h after act/gate (element index row * drop_ld + col)."""
@@ -162,6 +164,8 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     if drop is not None and drop[2] > 0.0:
         a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
         a.drop_ld = N if drop_ld is None else drop_ld
+    if rows is not None:                                      # row gather: (row_index int32 [M], n_rows int32 [1]) from row_index()
+        a.row_index, a.n_rows = _p(rows[0]), _p(rows[1])
     if segs is None:
         if out is None:
             out = torch.empty((M, N) if batch == 1 else (batch, M, N), device=A.device,
@@ -181,8 +185,22 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     nbytes = batch * (M * K * (4 if a.a_dtype == F32 else 2) + N * K * esz + M * N * esz)
     desc = f"M={M} N={N} K={K} z={batch} nseg={len(segs)} a2={int(A2 is not None)} R={int(R is not None)} act={act} tr={int(any(s_.transposed for s_ in segs))}"
     _timed(kind, flops, nbytes, lambda: check(lib().made_linear(C.byref(a), _stream()), "made_linear"),
-           (desc, tile_skip_mask, 128) if tile_skip_mask is not None else desc)
+           ("rows", rows[1], M) if rows is not None else ((desc, tile_skip_mask, 128) if tile_skip_mask is not None else desc))
     return segs[0].out
+
+
+def row_index(mask: Tensor, out=None):
+    """(row_index int32 [M], n_rows int32 [1]) of a token mask (made_row_index): the `rows=` argument of linear / gemm_tn."""
+    m = mask.reshape(-1)
+    M = m.numel()
+    if out is not None:
+        idx, n = out
+        assert idx.dtype == torch.int32 and idx.numel() >= M and n.dtype == torch.int32
+    else:
+        idx = torch.empty(M, device=m.device, dtype=torch.int32)
+        n = torch.empty(1, device=m.device, dtype=torch.int32)
+    check(lib().made_row_index(_p(_f32(m, "mask")), M, _p(idx), _p(n), _stream()), "made_row_index")
+    return idx, n
 
 
 def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, split_k: int, *, A2: Optional[Tensor] = None,

@@ -19,7 +19,8 @@ Pair = Tuple[int, int]
 
 
 def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulate: bool = False, split_m: Optional[int] = None,
-            row_mask: Optional[Tensor] = None, row_groups: Optional[Tensor] = None, colsum: Optional[Tensor] = None, batch: Pair = (1, 1),
+            row_mask: Optional[Tensor] = None, row_groups: Optional[Tensor] = None, rows=None, colsum: Optional[Tensor] = None,
+            batch: Pair = (1, 1),
             a_zs: Pair = (0, 0), b_zs: Pair = (0, 0), c_zs: Pair = (0, 0), mask_zs: Pair = (0, 0),
             colsum_zs: Pair = (0, 0)) -> Tensor:
     """Cout[N,K] (+)= alpha * A[M,N]^T B[M,K]  (made_gemm_tn).  A, B, Cout are the 2-D views of batch element 0; the
@@ -47,6 +48,8 @@ def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulat
     a.c_zs1, a.c_zs2 = c_zs
     a.row_mask = _p(_f32(row_mask, "row_mask"))
     a.row_group_valid = _p(_f32(row_groups, "row_groups")) if (row_mask is not None and nz == 1) else None
+    if rows is not None and nz == 1:                          # (row_index int32 [M], n_rows int32 [1]) from ops.row_index
+        a.row_index, a.n_rows = _p(rows[0]), _p(rows[1])
     a.mask_zs1, a.mask_zs2 = mask_zs
     a.alpha, a.accumulate, a.split_m = float(alpha), int(bool(accumulate)), int(split_m)
     a.colsum = _p(_f32(colsum, "colsum"))
@@ -54,7 +57,7 @@ def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulat
     flops = 2.0 * M * N * K * nz
     nbytes = float((M * N + M * K) * A.element_size() * nz + N * K * Cout.element_size())
     _timed("made_gemm_tn", flops, nbytes, lambda: check(lib().made_gemm_tn(C.byref(a), _stream()), "made_gemm_tn"),
-           f"M={M} N={N} K={K} z={nz}")
+           ("rows", rows[1], M) if (rows is not None and nz == 1) else f"M={M} N={N} K={K} z={nz}")
     return Cout
 
 

@@ -322,6 +322,8 @@ class MadeTrainer(MadeEngine):
                        f"e.{l}.lse": E(B * H * L, dtype=f32), f"e.{l}.x": E(rows, D), f"e.{l}.s1": E(rows, D), f"e.{l}.h": E(rows, Fd),
                        f"e.{l}.x2": E(rows, D)})
         ws.update(mem=E(rows, D), mempos=E(rows, D))
+        i32 = torch.int32
+        ws.update(rows_v=(E(B * Tv, dtype=i32), E(1, dtype=i32)), rows_a=(E(B * Ta, dtype=i32), E(1, dtype=i32)), rows_f=(E(rows, dtype=i32), E(1, dtype=i32)))
         for l in range(nd):
             ws.update({f"d.{l}.tgt": E(B * Q, D), f"d.{l}.tq": E(B * Q, D), f"d.{l}.qkv": E(B * Q, 3 * D), f"d.{l}.att": E(B * Q, D),
                        f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.t_a": E(B * Q, D), f"d.{l}.t1": E(B * Q, D), f"d.{l}.t1q": E(B * Q, D),
@@ -355,8 +357,11 @@ class MadeTrainer(MadeEngine):
         fus, fus_mask = ws["fus"], ws["fus_mask"]
         fus_mask[:, :Tv].copy_(fm)
         fus_mask[:, Tv:].copy_(sm)
-        # flags per 32 token rows: the weight-gradient products skip slabs made of padding without loading them
-        self._groups = {fus_mask.data_ptr(): tr.row_groups(fus_mask), fm.data_ptr(): tr.row_groups(fm), sm.data_ptr(): tr.row_groups(sm)}
+        # valid-token lists: every large GEMM (forward, dX and dW) gathers the valid rows only, so padding costs nothing
+        self._groups = {}
+        self._rows = {fus_mask.data_ptr(): ops.row_index(fus_mask, out=tw["rows_f"]), fm.data_ptr(): ops.row_index(fm, out=tw["rows_v"]),
+                      sm.data_ptr(): ops.row_index(sm, out=tw["rows_a"])}
+        rows_f = self._rows[fus_mask.data_ptr()]
         # the video branch (B*T_v rows: launches far smaller than the chip) runs on a second HIP stream beside the audio branch;
         # so does the X-Pool / similarity / retrieval-loss branch beside the DETR stack (joined at the end of the step)
         cur, side = torch.cuda.current_stream(), self._side_stream()
@@ -396,18 +401,18 @@ class MadeTrainer(MadeEngine):
             if l > 0:
                 src, srcpos = tw[e + ".src"], tw[e + ".srcpos"]
             qkv = tw[e + ".qkv"]
-            ops.linear(src, P[p + ".in.w"], P[p + ".in.b"], A2=srcpos, a2_replace=True, tile_skip_mask=fskip,
+            ops.linear(src, P[p + ".in.w"], P[p + ".in.b"], A2=srcpos, a2_replace=True, rows=rows_f,
                        segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
             q3 = qkv.view(B, L, 3 * D)
             att = tw[e + ".att"]
             ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, L, D), H, key_mask=fus_mask,
                           q_skip_mask=fus_mask, lse=tw[e + ".lse"], drop=self._drop(f"enc.{l}" + ".attn", pd))
-            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=tw[e + ".x"], tile_skip_mask=fskip,
+            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=tw[e + ".x"], rows=rows_f,
                            drop=self._drop(f"enc.{l}" + ".drop1", pd))
             s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[e + ".s1"], row_skip=fskip)
-            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[e + ".h"], tile_skip_mask=fskip,
+            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[e + ".h"], rows=rows_f,
                            drop=self._drop(f"enc.{l}" + ".ffn_act", pd))
-            x2 = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=tw[e + ".x2"], tile_skip_mask=fskip,
+            x2 = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=tw[e + ".x2"], rows=rows_f,
                             drop=self._drop(f"enc.{l}" + ".drop2", pd))
             last = l == c.detr_enc_layers - 1
             nsrc, nsp = (tw["mem"], tw["mempos"]) if last else (tw[f"e.{l + 1}.src"], tw[f"e.{l + 1}.srcpos"])
@@ -501,30 +506,31 @@ class MadeTrainer(MadeEngine):
                                      else ("ast_proj", "audio_transformer", "pe_audio", c.audio_transformer_depth, "a"))
         if P[pe].shape[0] < T:
             raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < T={T}")
-        rows = B * T
+        nrow = B * T
         mflat = mask.reshape(-1)
+        rws = self._rw(mflat)
         pt = dr.P_TEMPORAL
         name = "video" if which == "video" else "audio"
         if self.tc == torch.bfloat16:
-            xin = ops.cast_mask_rows(feats.view(rows, Kin), mflat, tw[tag + ".xin"])
-            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], R=P[pe][:T], r_row_mod=T, out=tw[f"{tag}.0.x0"], tile_skip_mask=mflat)
+            xin = ops.cast_mask_rows(feats.view(nrow, Kin), mflat, tw[tag + ".xin"])
+            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], R=P[pe][:T], r_row_mod=T, out=tw[f"{tag}.0.x0"], rows=rws)
         else:
-            x = ops.linear(feats.view(rows, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, R=P[pe][:T], r_row_mod=T,
-                           out=tw[f"{tag}.0.x0"], tile_skip_mask=mflat)
+            x = ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, R=P[pe][:T], r_row_mod=T,
+                           out=tw[f"{tag}.0.x0"], rows=rws)
         for l in range(depth):
             p, t = f"{mod}.layers.{l}", f"{tag}.{l}"
             x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[t + ".x1"], row_skip=mflat)
-            qkv = ops.linear(x1, P[p + ".in.w"], P[p + ".in.b"], out=tw[t + ".qkv"], tile_skip_mask=mflat)
+            qkv = ops.linear(x1, P[p + ".in.w"], P[p + ".in.b"], out=tw[t + ".qkv"], rows=rws)
             q3 = qkv.view(B, T, 3 * D)
             att = tw[t + ".att"]
             ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), Hh, key_mask=mask, q_skip_mask=mask,
                           lse=tw[t + ".lse"], drop=self._drop(f"{name}.{l}.attn", pt))
-            x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=tw[t + ".x2"], tile_skip_mask=mflat)
+            x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=tw[t + ".x2"], rows=rws)
             x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[t + ".x3"], row_skip=mflat)
-            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=tw[t + ".h"], Zout=tw[t + ".z1"], tile_skip_mask=mflat,
+            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=tw[t + ".h"], Zout=tw[t + ".z1"], rows=rws,
                            drop=self._drop(f"{name}.{l}.ffn_act", pt))
             nxt = tw[f"{tag}.{l + 1}.x0"] if l + 1 < depth else tw[tag + ".xlast"]
-            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=nxt, tile_skip_mask=mflat, drop=self._drop(f"{name}.{l}.ffn_out", pt))
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=nxt, rows=rws, drop=self._drop(f"{name}.{l}.ffn_out", pt))
         local = ws["fus"][:, row_off:row_off + T]
         ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat, tile_skip_mask=mflat,
                    segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
@@ -539,7 +545,8 @@ class MadeTrainer(MadeEngine):
         v1 = ops.layernorm(video, P["xa.ln1.g"], P["xa.ln1.b"], out=tw["xv1"])
         q = ops.linear(v1, P["xa.q.w"], P["xa.q.b"], out=tw["xq"])
         s1 = ops.layernorm(seg, P["xa.ln1.g"], P["xa.ln1.b"], out=tw["xs1"], row_skip=skip)
-        ops.linear(s1, P["xa.kv.w"], P["xa.kv.b"], tile_skip_mask=skip, segs=[Seg(out=tw["xk"], col_begin=0), Seg(out=tw["xu"], col_begin=D)])
+        ops.linear(s1, P["xa.kv.w"], P["xa.kv.b"], rows=self._rw(skip), tile_skip_mask=skip if self._rw(skip) is None else None,
+                   segs=[Seg(out=tw["xk"], col_begin=0), Seg(out=tw["xu"], col_begin=D)])
         ops.attention_wide(q.view(1, B, 1, D), tw["xk"].view(B, S, D), tw["xu"].view(B, S, D), tw["xo"].view(B, B, 1, D),
                            scale=1.0 / math.sqrt(D), key_mask=seg_mask, shared_q=True)
         a2 = ops.linear(tw["xo"], P["xa.out.w"], P["xa.out.b"], out=tw["xa2"])
@@ -552,14 +559,20 @@ class MadeTrainer(MadeEngine):
                  skip: Optional[Tensor] = None, gw: Optional[Tensor] = None, gb: Optional[Tensor] = None, wt: Optional[Tensor] = None,
                  **kw) -> Optional[Tensor]:
         """Linear backward: dW += dz^T x, db += colsum(dz), dx = dz W (with the epilogue options of ops.linear)."""
+        rows = self._rw(row_mask)                             # the mask's valid-row list: gather instead of masking
         tr.gemm_tn(dz, x, self.G[key + ".w"] if gw is None else gw, accumulate=True, colsum=self.G[key + ".b"] if gb is None else gb,
-                   row_mask=row_mask, row_groups=self._rg(row_mask))
+                   row_mask=row_mask if rows is None else None, row_groups=self._rg(row_mask), rows=rows)
         if dx_out is None:
             return None
-        return ops.linear(dz, self.P[key + ".wt"] if wt is None else wt, None, out=dx_out, tile_skip_mask=skip, **kw)
+        return ops.linear(dz, self.P[key + ".wt"] if wt is None else wt, None, out=dx_out, tile_skip_mask=skip if rows is None else None,
+                          rows=rows, **kw)
 
     def _rg(self, row_mask: Optional[Tensor]) -> Optional[Tensor]:
         return self._groups.get(row_mask.data_ptr()) if row_mask is not None else None
+
+    def _rw(self, mask: Optional[Tensor]):
+        """(row_index, n_rows) of a token mask computed in forward_train, or None."""
+        return self._rows.get(mask.data_ptr()) if mask is not None else None
 
     @torch.no_grad()
     def backward(self, g_ret: Optional[Tensor] = None, g_loc: Optional[Tensor] = None, zero_grad: bool = True) -> None:
@@ -721,10 +734,10 @@ class MadeTrainer(MadeEngine):
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[e + ".lse"], tw["e_delta"], H,
                              key_mask=fus_mask, q_skip_mask=fus_mask, drop=self._drop(f"enc.{l}" + ".attn", pd))
             gW, gb = G[p + ".in.w"], G[p + ".in.b"]
-            tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], row_mask=fskip, row_groups=self._rg(fskip))
-            tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], row_mask=fskip, row_groups=self._rg(fskip))
+            tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], rows=self._rw(fskip))
+            tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], rows=self._rw(fskip))
             nxt = tw["dfus"] if dx is tw["eg1"] else tw["eg1"]
-            dsrc = ops.linear(gq, P[p + ".in.wt"], None, R=dx, out=nxt, tile_skip_mask=fskip)
+            dsrc = ops.linear(gq, P[p + ".in.wt"], None, R=dx, out=nxt, rows=self._rw(fskip))
         dfus = dsrc.view(B, L, D)
 
         # ---------------- join the X-Pool / similarity branch, merge the gradients of the clip-level vectors
@@ -834,7 +847,7 @@ class MadeTrainer(MadeEngine):
             dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3, row_mask=mflat, skip=mflat, R=g1)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
         xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
-        tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], row_mask=mflat, row_groups=self._rg(mflat))
+        tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], rows=self._rw(mflat))
 
     def _dropped_copy(self, out: Tensor, x: Tensor, site: str, p: float, ld: int) -> Tensor:
         raise NotImplementedError("temporal transformer depth > 1 is not covered by the training path yet")

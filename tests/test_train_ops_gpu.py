@@ -382,3 +382,39 @@ def test_set_criterion_bwd(T, Q, G):
                          torch.tensor([up], device=dev), dl, ds, dpq, dvs)
     for name, got, ref in (("dlogits", dl, lr.grad), ("dspans", ds, sr.grad), ("dpq", dpq, pqr.grad), ("dvid_sum", dvs, pvr.grad[:, 0])):
         assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-3), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_gather_linear_and_gemm_tn_bit_identical_on_valid_rows(T, dtype):
+    """rows=(row_index, n_rows): the GEMMs touch the valid tokens only; their results equal the ungathered call bit for bit,
+    padded rows are neither read (they hold NaN here) nor written (sentinel survives)."""
+    ops, tr = T
+    Bn, L, K, N = 9, 150, 256, 384
+    lens = torch.tensor([150, 3, 77, 0, 149, 128, 1, 64, 100], device="cuda")
+    mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).float().reshape(-1)
+    M = Bn * L
+    rows = ops.row_index(mask)
+    idx_ref = torch.nonzero(mask).flatten().int()
+    assert int(rows[1]) == idx_ref.numel() and torch.equal(rows[0][:idx_ref.numel()], idx_ref)
+    assert bool((rows[0][idx_ref.numel():] == idx_ref[-1]).all())
+    A, W = _rand(M, K, dtype=dtype, seed=1), _rand(N, K, dtype=dtype, seed=2) * 0.1
+    bias = _rand(N, dtype=torch.float32, seed=3)
+    R = _rand(M, N, dtype=dtype, seed=4)
+    full = ops.linear(A, W, bias, act=ops.ACT_GELU, R=R, drop=(5, 6, 0.3))
+    A2 = A.clone(); A2[mask == 0] = float("nan")
+    R2 = R.clone(); R2[mask == 0] = float("nan")
+    out = torch.full((M, N), 7.0, device="cuda", dtype=dtype)
+    ops.linear(A2, W, bias, act=ops.ACT_GELU, R=R2, drop=(5, 6, 0.3), out=out, rows=rows)
+    v = mask.bool()
+    assert torch.equal(out[v], full[v])
+    assert bool((out[~v] == 7.0).all())
+    # weight gradient over the valid rows only
+    dY, X = _rand(M, N, dtype=dtype, seed=7), _rand(M, K, dtype=dtype, seed=8)
+    ref = (dY.float() * mask[:, None]).t() @ X.float()
+    dY[mask == 0] = float("nan"); X[mask == 0] = float("nan")
+    for split in (1, 5, None):
+        Cg = torch.zeros(N, K, device="cuda"); cs = torch.zeros(N, device="cuda")
+        tr.gemm_tn(dY, X, Cg, accumulate=True, colsum=cs, rows=rows, split_m=split)
+        assert torch.isfinite(Cg).all() and torch.isfinite(cs).all()
+        tol = 2e-5 if dtype == torch.float32 else 2e-3
+        assert float((Cg - ref).abs().max()) <= tol * float(ref.abs().max())
