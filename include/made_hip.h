@@ -405,7 +405,7 @@ int made_row_index(const float* mask, int64_t M, int32_t* row_index, int32_t* n_
  *
  * made_layernorm_bwd: dx = LN'(x; gamma)(dy) [+ add]; optionally also dx_drop = dropout(dx) (the gradient entering a
  *   residual branch whose output was dropped: `x + dropout(branch)`); dgamma += sum dy*xhat, dbeta += sum dy.  Rows whose
- *   row_skip is 0 produce zeros and contribute nothing.  Autograd of nn.LayerNorm at reference model/model_Base.py:77-78,
+ *   row_skip is 0 are neither read nor written and contribute nothing (their consumers gather / mask the valid rows).  Autograd of nn.LayerNorm at reference model/model_Base.py:77-78,
  *   music_detr/transformer.py:157-158,235-237, modules/transformer.py:141-143. */
 int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
                        const float* gamma, const void* dy, int32_t dy_dtype, int64_t lddy,

@@ -448,9 +448,15 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
+                for (int e4 = 0; e4 < 4; ++e4) {
+                // the 4 accumulator rows of a register quad are consecutive queries: one 16-byte LDS read each for -lse and delta
+                const f32x4 nl4 = *(const f32x4*)(lds_lse + qi * 32 + 8 * e4 + 4 * hh);
+                const f32x4 dl4 = *(const f32x4*)(lds_delta + qi * 32 + 8 * e4 + 4 * hh);
+#pragma unroll
+                for (int ej = 0; ej < 4; ++ej) {
+                    const int e = 4 * e4 + ej;
                     const int ql = qi * 32 + acc_row(e, hh);
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][e], c2, lds_lse[ql]) + bias_key);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][e], c2, nl4[ej]) + bias_key);
                     float pd = p, g = dp[qi][e];
                     if (a.drop.p > 0.f) {
                         const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)ql * (uint32_t)a.Lk) ^ kk)
@@ -460,7 +466,8 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs
                         g = keep ? g * dsc : 0.f;
                     }
                     s[qi][e] = pd;
-                    dp[qi][e] = p * __builtin_fmaf(g, a.scale, -lds_delta[ql]);
+                    dp[qi][e] = p * __builtin_fmaf(g, a.scale, -dl4[ej]);
+                }
                 }
         } else {
 #pragma unroll

@@ -625,6 +625,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
     const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        if (m0 + half * 64 >= Mv) break;                   // block-uniform: the decoder's 64-row problems have no second half
         if (wm == half) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)

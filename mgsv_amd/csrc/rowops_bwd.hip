@@ -76,7 +76,8 @@ __global__ __launch_bounds__(RT) void layernorm_bwd_kernel(const LnBwdArgs a) {
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const int D = a.D;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
-        const bool skip = a.row_skip && a.row_skip[row] == 0.f;
+        if (a.row_skip && a.row_skip[row] == 0.f) continue;   // padded token: nothing read, nothing written (wave-uniform)
+        const bool skip = false;
         const int64_t xoff = a.rpb > 0 ? (row / a.rpb) * a.xbs + (row % a.rpb) * a.ldx : row * a.ldx;
         f32x4 xv[NV], gy[NV];
         float sum = 0.f;
@@ -692,8 +693,8 @@ extern "C" int made_add3(void* out, int32_t out_dtype, const void* a, int32_t a_
 extern "C" int made_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream) {
     MADE_REQUIRE(x && out && cols > 0, "made_colsum: bad arguments");
     if (rows <= 0) return MADE_OK;
-    int64_t ny = (rows + 63) / 64;
-    if (ny > 64) ny = 64;
+    int64_t ny = (rows + 7) / 8;                           // few rows per thread: the loads of a column run in parallel
+    if (ny > 512) ny = 512;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + RT - 1) / RT), (unsigned)ny), dim3(RT), 0, (hipStream_t)stream, x, dtype, ld, rows, cols, out);
     return made_check_launch("made_colsum");
 }

@@ -330,6 +330,8 @@ class MadeTrainer(MadeEngine):
                        f"d.{l}.qc": E(B * Q, D), f"d.{l}.pooled": E(B * Q, H * D), f"d.{l}.s": E(B * Q, H, dtype=f32),
                        f"d.{l}.attc": E(B * Q, D), f"d.{l}.t_b": E(B * Q, D), f"d.{l}.t2": E(B * Q, D), f"d.{l}.h": E(B * Q, Fd),
                        f"d.{l}.t_c": E(B * Q, D), f"d.{l}.t3": E(B * Q, D)})
+        for l in range(nd - 1):                              # t3 of layer l IS the content query of layer l + 1
+            ws[f"d.{l}.t3"] = ws[f"d.{l + 1}.tgt"]
         if c.contrastive_align_loss:
             Dc = c.contrastive_hdim
             ws.update(dpq=E(nd * B * Q, Dc, dtype=f32), dvid_sum=E(B, Dc, dtype=f32), dpq_raw=E(nd * B * Q, Dc), dpv_raw=E(B * Tv, Dc),
@@ -464,7 +466,6 @@ class MadeTrainer(MadeEngine):
             if l + 1 < nd:
                 ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D), tw[f"d.{l + 1}.tgt"], tw[f"d.{l + 1}.tq"])
                 ops.layernorm(tw[f"d.{l + 1}.tgt"], P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
-                t3.copy_(tw[f"d.{l + 1}.tgt"])
             else:
                 ops.layernorm(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], out=t3)
                 ops.layernorm(t3, P["dec.norm.g"], P["dec.norm.b"], out=hs[l])

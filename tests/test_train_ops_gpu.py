@@ -217,12 +217,15 @@ def test_layernorm_bwd(T, dtype, tol, rows, D):
     dx = torch.empty(rows, D, device="cuda", dtype=dtype)
     dxd = torch.empty(rows, D, device="cuda", dtype=dtype)
     dg, db = torch.ones(D, device="cuda"), torch.ones(D, device="cuda")
+    dx.fill_(3.0); dxd.fill_(3.0)
     tr.layernorm_bwd(x, gamma, dy, dx, dgamma=dg, dbeta=db, add=add, dx_drop=dxd, drop=(seed, site, p), row_skip=skip)
-    ref = xr.grad + add.float() * skip[:, None]
-    sc = float(ref.abs().max())
-    assert float((dx.float() - ref).abs().max()) <= tol * sc
+    ref = xr.grad + add.float()
+    v = skip.bool()
+    sc = float(ref[v].abs().max())
+    assert float((dx.float() - ref)[v].abs().max()) <= tol * sc
     keep = _keep(seed, site, p, (rows, D)).float()
-    assert float((dxd.float() - ref * keep / (1 - p)).abs().max()) <= tol * sc / (1 - p)
+    assert float((dxd.float() - ref * keep / (1 - p))[v].abs().max()) <= tol * sc / (1 - p)
+    assert bool((dx[~v] == 3.0).all()) and bool((dxd[~v] == 3.0).all())       # skipped rows are left untouched
     assert float((dg - 1 - gr.grad).abs().max()) <= tol * float(gr.grad.abs().max()) * 2
     assert float((db - 1 - br.grad).abs().max()) <= tol * float(br.grad.abs().max()) * 2
 
