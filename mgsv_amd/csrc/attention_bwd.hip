@@ -54,7 +54,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int P, int 
 
 // ---------------------------------------------------------------------------------------------- dQ
 template <typename TC, int HD>
-__global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(const MadeAttnBwdArgs a) {
+__global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void attn_bwd_dq_kernel(const MadeAttnBwdArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
     constexpr int PER16 = 16 / SZ;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(const MadeAttnBwdArgs 
 
 // ---------------------------------------------------------------------------------------------- dK, dV
 template <typename TC, int HD>
-__global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs a) {
+__global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
     constexpr int PER16 = 16 / SZ;
@@ -414,96 +414,87 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs
         if (t + 1 < ntiles) load_tile((t + 1) * BQT);
         if (!wave_active) continue;
 
-        f32x16 s[2], dp[2];
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { s[qi][e] = 0.f; dp[qi][e] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < NQF; ++ks) {
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                frag_t qa = *(const frag_t*)(lds_q + (qi * 32 + r) * P + ks * 32 + hh * 16);
-                frag_t ga = *(const frag_t*)(lds_do + (qi * 32 + r) * P + ks * 32 + hh * 16);
-                if constexpr (IS_BF16) {
-                    s[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s[qi], 0, 0, 0);
-                    dp[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp[qi], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[ks][e], s[qi], 0, 0, 0);
-                        dp[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[e], vf[ks][e], dp[qi], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        // s <- Pd (dropped probabilities), dp <- dS
         const uint64_t tfirst = (bhbase + (uint64_t)(t * BQT)) * (uint64_t)a.Lk;
         const uint64_t tlast = tfirst + (uint64_t)BQT * (uint64_t)a.Lk;
         const bool fast_idx = (tfirst >> 32) == (tlast >> 32);            // wave-uniform: the tile's indices share their high word
         const uint32_t kk = made_rng_key(a.drop.seed, a.drop.site, (uint32_t)(tfirst >> 32));
         const uint32_t tlo = (uint32_t)tfirst + (uint32_t)keyc;
-        if constexpr (IS_BF16) {
-            const float c2 = a.scale * 1.4426950408889634f;
+        // the two 32-query halves of the tile one after the other (not unrolled): one score / dP tile pair live at a time keeps
+        // the kernel at 3 waves per SIMD
+#pragma nounroll
+        for (int qi = 0; qi < 2; ++qi) {
+            f32x16 s, dp;
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < NQF; ++ks) {
+                frag_t qa = *(const frag_t*)(lds_q + (qi * 32 + r) * P + ks * 32 + hh * 16);
+                frag_t ga = *(const frag_t*)(lds_do + (qi * 32 + r) * P + ks * 32 + hh * 16);
+                if constexpr (IS_BF16) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[ks][e], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[e], vf[ks][e], dp, 0, 0, 0);
+                    }
+                }
+            }
+            // s <- Pd (dropped probabilities), dp <- dS
+            if constexpr (IS_BF16) {
+                const float c2 = a.scale * 1.4426950408889634f;
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
-                // the 4 accumulator rows of a register quad are consecutive queries: one 16-byte LDS read each for -lse and delta
-                const f32x4 nl4 = *(const f32x4*)(lds_lse + qi * 32 + 8 * e4 + 4 * hh);
-                const f32x4 dl4 = *(const f32x4*)(lds_delta + qi * 32 + 8 * e4 + 4 * hh);
+                    // the 4 accumulator rows of a register quad are consecutive queries: one 16-byte LDS read each for -lse and delta
+                    const f32x4 nl4 = *(const f32x4*)(lds_lse + qi * 32 + 8 * e4 + 4 * hh);
+                    const f32x4 dl4 = *(const f32x4*)(lds_delta + qi * 32 + 8 * e4 + 4 * hh);
 #pragma unroll
-                for (int ej = 0; ej < 4; ++ej) {
-                    const int e = 4 * e4 + ej;
-                    const int ql = qi * 32 + acc_row(e, hh);
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][e], c2, nl4[ej]) + bias_key);
-                    float pd = p, g = dp[qi][e];
-                    if (a.drop.p > 0.f) {
-                        const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)ql * (uint32_t)a.Lk) ^ kk)
-                                                      : made_rng_mix(a.drop.seed, a.drop.site, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
-                        const bool keep = (hsh >> 8) >= thr;
-                        pd = keep ? p * dsc : 0.f;
-                        g = keep ? g * dsc : 0.f;
+                    for (int ej = 0; ej < 4; ++ej) {
+                        const int e = 4 * e4 + ej;
+                        const int ql = qi * 32 + acc_row(e, hh);
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c2, nl4[ej]) + bias_key);
+                        float pd = p, g = dp[e];
+                        if (a.drop.p > 0.f) {
+                            const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)ql * (uint32_t)a.Lk) ^ kk)
+                                                          : made_rng_mix(a.drop.seed, a.drop.site, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
+                            const bool keep = (hsh >> 8) >= thr;
+                            pd = keep ? p * dsc : 0.f;
+                            g = keep ? g * dsc : 0.f;
+                        }
+                        s[e] = pd;
+                        dp[e] = p * __builtin_fmaf(g, a.scale, -dl4[ej]);
                     }
-                    s[qi][e] = pd;
-                    dp[qi][e] = p * __builtin_fmaf(g, a.scale, -dl4[ej]);
                 }
-                }
-        } else {
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
+            } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int ql = qi * 32 + acc_row(e, hh);
-                    const float p = expf(s[qi][e] * a.scale + bias_key - lds_lse[ql]);
-                    float pd = p, g = dp[qi][e];
+                    const float p = expf(s[e] * a.scale + bias_key - lds_lse[ql]);
+                    float pd = p, g = dp[e];
                     if (a.drop.p > 0.f) {
                         const bool keep = drop_keep(a.drop, thr, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
                         pd = keep ? p * dsc : 0.f;
                         g = keep ? g * dsc : 0.f;
                     }
-                    s[qi][e] = pd;
-                    dp[qi][e] = p * (g - lds_delta[ql]) * a.scale;
+                    s[e] = pd;
+                    dp[e] = p * (g - lds_delta[ql]) * a.scale;
                 }
-        }
-        // dV^T += dO^T Pd,  dK^T += Q^T dS
-        if constexpr (IS_BF16) {
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
+            }
+            // dV^T += dO^T Pd,  dK^T += Q^T dS
+            if constexpr (IS_BF16) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     bf16x8 pf, sf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)s[qi][8 * s2 + j]; sf[j] = (bf16_t)dp[qi][8 * s2 + j]; }
+                    for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)s[8 * s2 + j]; sf[j] = (bf16_t)dp[8 * s2 + j]; }
 #pragma unroll
                     for (int d = 0; d < NDT; ++d) {
                         dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(lds_do, P, qi * 32 + 16 * s2, d * 32, lane), pf, dv[d], 0, 0, 0);
                         dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(lds_q, P, qi * 32 + 16 * s2, d * 32, lane), sf, dk[d], 0, 0, 0);
                     }
                 }
-        } else {
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
+            } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int ql = qi * 32 + acc_row(e, hh);
@@ -511,10 +502,11 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs
                     for (int d = 0; d < NDT; ++d) {
                         const float gv = *(const float*)(lds_do + ql * P + (d * 32 + r) * 4);
                         const float qv = *(const float*)(lds_q + ql * P + (d * 32 + r) * 4);
-                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, s[qi][e], dv[d], 0, 0, 0);
-                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, dp[qi][e], dk[d], 0, 0, 0);
+                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, s[e], dv[d], 0, 0, 0);
+                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, dp[e], dk[d], 0, 0, 0);
                     }
                 }
+            }
         }
     }
 
