@@ -661,6 +661,138 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
     }
 }
 
+// =================================================================================================
+// Skinny problems (the decoder's B*Q = 64 rows, the heads): a launch of a handful of workgroups is bound by the latency
+// of its K loop, not by bandwidth or MFMA rate.  64 x 64 tiles (twice the workgroups of the 128-wide tiling) and an
+// 8-stage LDS ring of 16 KB stages: for K <= 512 every slab of the problem is in flight before the first MFMA, so the
+// loop costs one memory round trip plus the stream time instead of one round trip per two slabs.
+constexpr int S_BM = 64, S_BN = 64, S_NST = 8;
+constexpr int S_STAGE = (S_BM + S_BN) * KB;           // 16 KB
+constexpr int S_CT_LD = S_BN + 4;
+
+template <bool TRAIN>
+__global__ __launch_bounds__(NTHREADS, 1) void linear_skinny_kernel(const MadeLinearArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[S_NST * S_STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+    const int n_tiles = (N + S_BN - 1) / S_BN;
+    const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+    const int m0 = tile_m * S_BM, n0 = tile_n * S_BN;
+    const int64_t z = blockIdx.z;
+    int Mv = M;
+    if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
+    if (m0 >= Mv) return;
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+        if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
+    const MadeLinearSeg seg = a.seg[si];
+
+    // wave w issues 1 KB pieces 2w, 2w+1 of A and of W per slab; piece j = rows 8j..8j+7; lane l -> row 8j + l/8, slot l%8
+    // holding global chunk (l%8) ^ swz(row)
+    const bool repl = seg.use_a2 && a.A2 && a.a2_replace;
+    const bf16_t* Abase = (repl ? (const bf16_t*)a.A2 : (const bf16_t*)a.A) + z * a.a_z_stride;
+    const int64_t lda = repl ? a.lda2 : a.lda;
+    const bf16_t* Wbase = (const bf16_t*)a.W + z * a.w_z_stride;
+    const bf16_t* pa[2];
+    const bf16_t* pw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gm = m0 + row; gm = gm < Mv ? gm : Mv - 1;
+        if (a.row_index) gm = a.row_index[gm];
+        int gn = n0 + row; gn = gn < N ? gn : N - 1;
+        pa[i] = Abase + (int64_t)gm * lda + chunk * 8;
+        pw[i] = Wbase + (int64_t)gn * a.ldw + chunk * 8;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        unsigned char* st = lds + (kt % S_NST) * S_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = 2 * wave + i;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(st + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(st + S_BM * KB + piece * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int ra = wm * 32 + r, rw = wn * 32 + r;
+    const int offa = ra * KB, sa = swz(ra), offw = S_BM * KB + rw * KB, sw = swz(rw);
+
+    const int nk = K / 64;
+    const int pre = nk < S_NST - 1 ? nk : S_NST - 1;
+    for (int kt = 0; kt < pre; ++kt) issue(kt);
+    for (int kt = 0; kt < nk; ++kt) {
+        // slab kt has landed once at most 4 * (slabs issued after it) loads of this wave are outstanding
+        int ahead = (kt + S_NST - 1 < nk ? kt + S_NST - 1 : nk) - (kt + 1);
+        switch (ahead) {
+            case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        asm volatile("s_barrier" ::: "memory");            // also: every wave is done reading stage (kt - 1) % S_NST
+        if (kt + S_NST - 1 < nk) issue(kt + S_NST - 1);
+        const unsigned char* st = lds + (kt % S_NST) * S_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + hh;
+            const bf16x8 fa = *(const bf16x8*)(st + offa + ((c ^ sa) << 4));
+            const bf16x8 fw = *(const bf16x8*)(st + offw + ((c ^ sw) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fw, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    float* Ct = (float*)lds;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Ct[(wm * 32 + acc_row(e, hh)) * S_CT_LD + wn * 32 + r] = acc[e];
+    __syncthreads();
+    unsigned char* outp = (unsigned char*)seg.out;
+    const int64_t out_z = z * seg.out_z_stride;
+    const int rpb = (int)seg.rows_per_batch, rmod = (int)a.r_row_mod;
+    const int colb = (int)seg.col_begin;
+    const int cc = tid & 7;
+    const int n = n0 + cc * 8;
+    int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+    if (nvalid <= 0) return;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (a.bias && j < nvalid) ? a.bias[n + j] : 0.f;
+    const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
+                         (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
+    const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int ml = m0 + row;
+        if (ml >= Mv) break;
+        const int m = a.row_index ? a.row_index[ml] : ml;
+        const float* cp = Ct + row * S_CT_LD + cc * 8;
+        f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        epilogue8<TRAIN>(a, m, n, nvalid, v, bv, rmod, r_vec);
+        int64_t orow;
+        if (rpb > 0) {
+            const int b = m / rpb, t = m - b * rpb;
+            orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo;
+        } else {
+            orow = (int64_t)m * seg.ldo;
+        }
+        store8(outp, seg.out_dtype, out_z + orow + (n - colb), v, nvalid, out_vec);
+    }
+}
+
 }  // namespace
 
 extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
@@ -723,6 +855,13 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
         if (a.A2 && a.a2_replace) fast = fast && (a.a2_row_mod == 0) && (a.lda2 % 8 == 0);
         if (fast) {
             const bool train = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
+            const int64_t tiles64 = ((a.M + S_BM - 1) / S_BM) * ((a.N + S_BN - 1) / S_BN);
+            if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) {   // latency-bound: 64 x 64 tiles, all slabs in flight
+                dim3 g64((unsigned)tiles64, 1, (unsigned)a.batch);
+                if (train) hipLaunchKernelGGL((linear_skinny_kernel<true>), g64, block, 0, st, a);
+                else hipLaunchKernelGGL((linear_skinny_kernel<false>), g64, block, 0, st, a);
+                return made_check_launch("made_linear");
+            }
             const bool small = tiles * a.batch <= 256;       // at most one workgroup per CU
             if (small && train) hipLaunchKernelGGL((linear_glds_kernel<3, true>), grid, block, 0, st, a);
             else if (small) hipLaunchKernelGGL((linear_glds_kernel<3, false>), grid, block, 0, st, a);
