@@ -230,8 +230,8 @@ typedef struct MadeWideAttnArgs {
     float scale; int32_t _pad;
     int64_t n_split;           /* > 1: keys are split over grid.z (few queries, long memory: fills the chip) and */
     float*  part_o;            /*      the slices are merged by a second launch; [B, n_split, NQ, D] f32 */
-    float*  part_ml;           /*      [B, n_split, NQ, 2] f32 (running max, sum) */
-    /* training path (n_split must be 1) */
+    float*  part_ml;           /*      [B, n_split, NQ, 4] f32 (running max, sum, sum of the dropped weights, unused) */
+    /* training path */
     MadeDropout drop;          /* dropout on the attention weights, element index ((b*NQ1 + i1)*NQ2 + i2)*L + key */
     float*  sum_out;           /* [B, NQ1*NQ2] f32 or NULL: sum of the dropped weights of each row (1 without dropout) */
 } MadeWideAttnArgs;

@@ -27,19 +27,36 @@ __device__ __forceinline__ bool drop_keep(const MadeDropout& d, uint32_t thr, ui
 }
 
 // ---------------------------------------------------------------------------------------------- delta
+// delta[b,h,i] = dO_i,h . O_i,h : one wave per token row (all heads at once, 16-byte loads), head sums by lane-group shuffles;
+// rows whose q_skip_mask is 0 are skipped (their delta is never read)
 __global__ __launch_bounds__(NTH) void attn_delta_kernel(const MadeAttnBwdArgs a) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, h, i)
-    if (row >= a.B * a.H * a.Lq) return;
-    const int64_t i = row % a.Lq, h = (row / a.Lq) % a.H, b = row / (a.Lq * a.H);
-    float acc = 0.f;
-    for (int d = lane; d < a.hd; d += 64) {
-        const float o = load_as_f32(a.O, a.dtype, b * a.o_bs + i * a.ldo + h * a.hd + d);
-        const float g = load_as_f32(a.dO, a.dtype, b * a.do_bs + i * a.lddo + h * a.hd + d);
-        acc += o * g;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, i)
+    if (row >= a.B * a.Lq) return;
+    const int64_t i = row % a.Lq, b = row / a.Lq;
+    if (a.q_skip_mask && a.q_skip_mask[row] == 0.f) return;
+    const int D = (int)(a.H * a.hd);
+    const int per = a.dtype == MADE_F32 ? 4 : 8;                           // elements per 16-byte chunk
+    const int lanes_per_head = a.hd / per;                                 // 4, 8, 16 (bf16) / 8, 16, 32 (f32): powers of two
+    for (int c0 = 0; c0 < D; c0 += 64 * per) {
+        const int c = c0 + lane * per;
+        float acc = 0.f;
+        if (c < D) {
+            if (a.dtype == MADE_F32) {
+                const f32x4 o = *(const f32x4*)((const float*)a.O + b * a.o_bs + i * a.ldo + c);
+                const f32x4 g = *(const f32x4*)((const float*)a.dO + b * a.do_bs + i * a.lddo + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += o[j] * g[j];
+            } else {
+                const bf16x8 o = *(const bf16x8*)((const bf16_t*)a.O + b * a.o_bs + i * a.ldo + c);
+                const bf16x8 g = *(const bf16x8*)((const bf16_t*)a.dO + b * a.do_bs + i * a.lddo + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += (float)o[j] * (float)g[j];
+            }
+        }
+        for (int o2 = lanes_per_head >> 1; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2);
+        if (c < D && (lane % lanes_per_head) == 0) a.delta[(b * a.H + c / a.hd) * a.Lq + i] = acc;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) a.delta[row] = acc;
 }
 
 // transposing fragment: A operand X^T (row index on the lane, reduction rows kb.. of an LDS tile stored [row][col], pitch P)
@@ -527,7 +544,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
 
 template <typename TC>
 int launch_bwd(const MadeAttnBwdArgs& a, hipStream_t st) {
-    const int64_t rows = a.B * a.H * a.Lq;
+    const int64_t rows = a.B * a.Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTH), 0, st, a);
     dim3 gq((unsigned)(((a.Lq + 127) / 128) * a.H * a.B)), gk((unsigned)(((a.Lk + 127) / 128) * a.H * a.B)), block(NTH);
     switch (a.hd) {
@@ -560,8 +577,9 @@ extern "C" int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream) {
     MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention_bwd: bad dtype %d", a.dtype);
     MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_attention_bwd: dropout p out of [0,1)");
     const int per16 = a.dtype == MADE_F32 ? 4 : 8;
-    MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.lddo % per16 == 0 &&
-                     a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.v_bs % per16 == 0 && a.do_bs % per16 == 0,
+    MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.lddo % per16 == 0 && a.ldo % per16 == 0 &&
+                     a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.v_bs % per16 == 0 && a.do_bs % per16 == 0 && a.o_bs % per16 == 0 &&
+                     ((uintptr_t)a.O % 16) == 0,
                      "made_attention_bwd: strides must keep 16-byte alignment");
     MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && ((uintptr_t)a.dO % 16) == 0,
                      "made_attention_bwd: base pointers must be 16-byte aligned");

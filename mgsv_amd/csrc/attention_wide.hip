@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     const float inv = 1.f / l_tot;
     const float sd_tot = sd_run + __shfl_xor(sd_run, 32);
     if (my_q >= nq_total) return;
-    if (a.sum_out && wave == 0 && hh == 0) a.sum_out[b * nq_total + my_q] = a.drop.p > 0.f ? sd_tot * inv : 1.f;
+    if (a.sum_out && nsplit == 1 && wave == 0 && hh == 0) a.sum_out[b * nq_total + my_q] = a.drop.p > 0.f ? sd_tot * inv : 1.f;
     if (nsplit > 1) {
         // un-normalised partial result of this key slice; made_attention_wide_combine merges the slices
         const int64_t prow = (b * nsplit + blockIdx.z) * nq_total + my_q;
@@ -295,7 +295,9 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                 f32x4 pk; pk[0] = o[d][4 * g4]; pk[1] = o[d][4 * g4 + 1]; pk[2] = o[d][4 * g4 + 2]; pk[3] = o[d][4 * g4 + 3];
                 *(f32x4*)(po + d * 32 + 8 * g4 + 4 * hh) = pk;
             }
-        if (wave == 0 && hh == 0) { a.part_ml[prow * 2] = m_run; a.part_ml[prow * 2 + 1] = l_tot; }
+        if (wave == 0 && hh == 0) {
+            a.part_ml[prow * 4] = m_run; a.part_ml[prow * 4 + 1] = l_tot; a.part_ml[prow * 4 + 2] = a.drop.p > 0.f ? sd_tot : l_tot;
+        }
         return;
     }
     const int64_t obase = b * a.o_bs + (my_q / a.NQ2) * a.o_s1 + (my_q % a.NQ2) * a.o_s2 + wave * DS;
@@ -324,16 +326,17 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_combine_kernel(const 
     const int64_t b = row / nq_total, q = row % nq_total;
     const int D = (int)a.D;
     float M = -INFINITY;
-    for (int64_t s = 0; s < a.n_split; ++s) M = fmaxf(M, a.part_ml[((b * a.n_split + s) * nq_total + q) * 2]);
+    for (int64_t s = 0; s < a.n_split; ++s) M = fmaxf(M, a.part_ml[((b * a.n_split + s) * nq_total + q) * 4]);
     const float Muse = (M == -INFINITY) ? 0.f : M;
-    float Lsum = 0.f;
+    float Lsum = 0.f, Dsum = 0.f;
     f32x4 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
     for (int64_t s = 0; s < a.n_split; ++s) {
         const int64_t prow = (b * a.n_split + s) * nq_total + q;
-        const float w = expf(a.part_ml[prow * 2] - Muse);
-        Lsum += a.part_ml[prow * 2 + 1] * w;
+        const float w = expf(a.part_ml[prow * 4] - Muse);
+        Lsum += a.part_ml[prow * 4 + 1] * w;
+        Dsum += a.part_ml[prow * 4 + 2] * w;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int c = (i * 64 + lane) * 4;
@@ -345,6 +348,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_combine_kernel(const 
         }
     }
     const float inv = 1.f / Lsum;
+    if (a.sum_out && lane == 0) a.sum_out[b * nq_total + q] = Dsum * inv;     // sum of the dropped weights (1 without dropout)
     const int64_t obase = b * a.o_bs + (q / a.NQ2) * a.o_s1 + (q % a.NQ2) * a.o_s2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -407,7 +411,6 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
     MADE_UNSUPPORTED(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && ((uintptr_t)a.O % 16) == 0 &&
                      ((uintptr_t)a.Kadd % 16) == 0, "made_attention_wide: base pointers must be 16-byte aligned");
     MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_attention_wide: dropout p out of [0,1)");
-    MADE_UNSUPPORTED(!(a.n_split > 1 && (a.drop.p > 0.f || a.sum_out)), "made_attention_wide: dropout / sum_out need n_split == 1");
     if (a.n_split > 1) {
         MADE_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr, "made_attention_wide: n_split > 1 needs part_o / part_ml");
         MADE_UNSUPPORTED(a.n_split <= 64, "made_attention_wide: n_split <= 64");

@@ -208,7 +208,7 @@ class MadeEngine:
             qkv=E(rows, 3 * D), att=E(rows, D), ffn=E(rows, max(F_t, F_d)),
             dq_all=E(B * Q, c.detr_nheads * D), dpool=E(B * Q, c.detr_nheads * D),
             dws=E(32 * B * Q * max(D, 256) * 4 * max(1, nd // 4), dtype=torch.float32),   # split-K partials of the skinny GEMMs
-            part_o=E(B * 8 * c.detr_nheads * Q * D, dtype=torch.float32), part_ml=E(B * 8 * c.detr_nheads * Q * 2, dtype=torch.float32),
+            part_o=E(B * 8 * c.detr_nheads * Q * D, dtype=torch.float32), part_ml=E(B * 8 * c.detr_nheads * Q * 4, dtype=torch.float32),
             vmean=E(B, D, dtype=torch.float32), mmean=E(B, D, dtype=torch.float32),
             video=E(B, D, dtype=torch.float32), music=E(B, D, dtype=torch.float32),
             tgt=E(B * Q, D), t1=E(B * Q, D), t2=E(B * Q, D), tx=E(B * Q, D),

@@ -310,8 +310,8 @@ def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, 
     if n_split > 1:
         if part_o is None:
             part_o = torch.empty(B * n_split * nq * D, device=Q.device, dtype=torch.float32)
-            part_ml = torch.empty(B * n_split * nq * 2, device=Q.device, dtype=torch.float32)
-        assert part_o.numel() >= B * n_split * nq * D and part_ml.numel() >= B * n_split * nq * 2
+            part_ml = torch.empty(B * n_split * nq * 4, device=Q.device, dtype=torch.float32)
+        assert part_o.numel() >= B * n_split * nq * D and part_ml.numel() >= B * n_split * nq * 4
         a.n_split, a.part_o, a.part_ml = n_split, _p(_f32(part_o, "part_o")), _p(_f32(part_ml, "part_ml"))
     if drop is not None and drop[2] > 0.0:
         a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])

@@ -324,14 +324,18 @@ class MadeTrainer(MadeEngine):
         ws.update(mem=E(rows, D), mempos=E(rows, D))
         i32 = torch.int32
         ws.update(rows_v=(E(B * Tv, dtype=i32), E(1, dtype=i32)), rows_a=(E(B * Ta, dtype=i32), E(1, dtype=i32)), rows_f=(E(rows, dtype=i32), E(1, dtype=i32)))
+        # decoder: saved activations and per-layer output gradients as [nd, ...] stacks (uniform layer stride), so the weight
+        # gradients of all 6 layers are a handful of layer-batched products after the loop instead of 60 tiny launches inside it
+        BQ = B * Q
+        stacks = dict(tgt=E(nd + 1, BQ, D), tq=E(nd + 1, BQ, D), qkv=E(nd, BQ, 3 * D), att=E(nd, BQ, D), t_a=E(nd, BQ, D), t1=E(nd, BQ, D),
+                      t1q=E(nd, BQ, D), qc=E(nd, BQ, D), pooled=E(nd, BQ, H * D), attc=E(nd, BQ, D), t_b=E(nd, BQ, D), t2=E(nd, BQ, D),
+                      h=E(nd, BQ, Fd), t_c=E(nd, BQ, D),
+                      g_ffn=E(nd, BQ, D), g_z=E(nd, BQ, Fd), g_ca=E(nd, BQ, D), g_attc=E(nd, BQ, D), g_q=E(nd, B, HQ, D), g_qc=E(nd, BQ, D),
+                      g_sa=E(nd, BQ, D), g_qkv=E(nd, BQ, 3 * D))
+        ws["dstack"] = stacks
         for l in range(nd):
-            ws.update({f"d.{l}.tgt": E(B * Q, D), f"d.{l}.tq": E(B * Q, D), f"d.{l}.qkv": E(B * Q, 3 * D), f"d.{l}.att": E(B * Q, D),
-                       f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.t_a": E(B * Q, D), f"d.{l}.t1": E(B * Q, D), f"d.{l}.t1q": E(B * Q, D),
-                       f"d.{l}.qc": E(B * Q, D), f"d.{l}.pooled": E(B * Q, H * D), f"d.{l}.s": E(B * Q, H, dtype=f32),
-                       f"d.{l}.attc": E(B * Q, D), f"d.{l}.t_b": E(B * Q, D), f"d.{l}.t2": E(B * Q, D), f"d.{l}.h": E(B * Q, Fd),
-                       f"d.{l}.t_c": E(B * Q, D), f"d.{l}.t3": E(B * Q, D)})
-        for l in range(nd - 1):                              # t3 of layer l IS the content query of layer l + 1
-            ws[f"d.{l}.t3"] = ws[f"d.{l + 1}.tgt"]
+            ws.update({f"d.{l}.{k}": v[l] for k, v in stacks.items() if not k.startswith("g_")})
+            ws.update({f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.s": E(B * Q, H, dtype=f32), f"d.{l}.t3": stacks["tgt"][l + 1]})
         if c.contrastive_align_loss:
             Dc = c.contrastive_hdim
             ws.update(dpq=E(nd * B * Q, Dc, dtype=f32), dvid_sum=E(B, Dc, dtype=f32), dpq_raw=E(nd * B * Q, Dc), dpv_raw=E(B * Tv, Dc),
@@ -433,6 +437,7 @@ class MadeTrainer(MadeEngine):
         tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
         hs = ws["hs"]
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
+        n_split = max(1, min(8, 256 // max(B, 1)))           # few queries, long memory: keys split over workgroups
         for l in range(nd):
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
             tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
@@ -453,7 +458,8 @@ class MadeTrainer(MadeEngine):
                        segs=[Seg(out=qprime, ldo=D, rows_per_batch=Q, out_batch_stride=qprime.stride(0), out_z_stride=Q * D)])
             pooled = tw[d + ".pooled"]                        # [B*Q, H*D] == [B, H, Q, D] for Q == 1
             ops.attention_wide(qprime.view(B, H, Q, D), mempos3, mem3, pooled.view(B, H, Q, D), scale=ca_scale, key_mask=fus_mask,
-                               drop=self._drop(f"dec.{l}" + ".ca_attn", pd), sum_out=tw[d + ".s"])
+                               drop=self._drop(f"dec.{l}" + ".ca_attn", pd), sum_out=tw[d + ".s"],
+                               n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
             attc = tw[d + ".attc"]
             ops.linear(pooled[:, :D], Win[2 * D:2 * D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
                        segs=[Seg(out=attc, ldo=D, out_z_stride=hd)])
@@ -462,13 +468,12 @@ class MadeTrainer(MadeEngine):
             t2 = ops.layernorm(tb, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[d + ".t2"])
             h = ops.linear(t2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[d + ".h"], drop=self._drop(f"dec.{l}" + ".ffn_act", pd))
             tcx = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=t2, out=tw[d + ".t_c"], drop=self._drop(f"dec.{l}" + ".drop3", pd))
-            t3 = tw[d + ".t3"]
+            t3 = tw[d + ".t3"]                                # = the content query of layer l + 1 (slot l + 1 of the tgt stack)
             if l + 1 < nd:
-                ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D), tw[f"d.{l + 1}.tgt"], tw[f"d.{l + 1}.tq"])
-                ops.layernorm(tw[f"d.{l + 1}.tgt"], P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
+                ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D), t3, tw[f"d.{l + 1}.tq"])
             else:
                 ops.layernorm(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], out=t3)
-                ops.layernorm(t3, P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
+            ops.layernorm(t3, P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
         out["hs"] = hs.view(nd, B, Q, D)
 
         # ---- heads
@@ -633,34 +638,33 @@ class MadeTrainer(MadeEngine):
                        a_zs=(Tv * Dc, 0), b_zs=(frame.stride(0), 0), colsum_zs=(0, 0))
             ops.linear(tw["dpv_raw"], P["proj_v.wt"], None, out=tw["dframe_x"])
 
-        # ---------------- decoder, last layer first
+        # ---------------- decoder, last layer first.  Inside the loop only the data-gradient chain runs; every output gradient a
+        # weight gradient needs is kept per layer (the g_* stacks) and the weight-gradient products of all layers are batched after it.
         qp = P["query_embed"]
         mem3, mempos3 = tw["mem"].view(B, L, D), tw["mempos"].view(B, L, D)
         Lp = tw["PdS"].shape[-1]
         GQ, PdS = tw["GQ"], tw["PdS"]
         ca_scale = 1.0 / math.sqrt(hd)
+        st = tw["dstack"]
         dtgt = None
         for l in range(nd - 1, -1, -1):
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
-            g1, g2, g3, g4 = tw["dg1"], tw["dg2"], tw["dg3"], tw["dg4"]
+            g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
             Win, Wt = P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
-            gWin, gbin = G[p + ".ca.in.w"], G[p + ".ca.in.b"]
+            g_ffn, g_z, g_ca, g_attc, g_q, g_qc, g_sa, gqkv = (st[k][l] for k in ("g_ffn", "g_z", "g_ca", "g_attc", "g_q", "g_qc", "g_sa", "g_qkv"))
             # hs_l = dec.norm(t3); t3 also feeds the next layer
             tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
             # t3 = LN3(t2 + drop3(ffn))
             tr.layernorm_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], g1, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"],
-                             dx_drop=g3, drop=self._drop(f"dec.{l}" + ".drop3", pd))
-            dz = self._lin_bwd(g3, tw[d + ".h"], p + ".ff2", dx_out=tw["dgffn"], gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
-            dt2 = self._lin_bwd(dz, tw[d + ".t2"], p + ".ff1", dx_out=g1, R=g2)
+                             dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
+            ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
+            dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1, R=g2)
             # t2 = LN2(t1 + drop2(cross-attention))
             tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"],
-                             dx_drop=g3, drop=self._drop(f"dec.{l}" + ".drop2", pd))
-            dattc = self._lin_bwd(g3, tw[d + ".attc"], p + ".ca.out", dx_out=g4)
-            tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], gbin[2 * D:], tw["d_ds"], H)
-            pooled = tw[d + ".pooled"]
-            # v_h = W_v,h pooled_h : dW_v,h += dattc_h^T pooled_h ; dpooled_h = dattc_h W_v,h
-            tr.gemm_tn(dattc[:, :hd], pooled[:, :D], gWin[2 * D:2 * D + hd], accumulate=True, batch=(H, 1),
-                       a_zs=(hd, 0), b_zs=(D, 0), c_zs=(hd * D, 0))
+                             dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
+            dattc = ops.linear(g_ca, P[p + ".ca.out.wt"], None, out=g_attc)
+            tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], G[p + ".ca.in.b"][2 * D:], tw["d_ds"], H)
+            # v_h = W_v,h pooled_h : dpooled_h = dattc_h W_v,h
             dpooled = GQ[:, 0, l]                             # [B, H*Q, D] slice of the concatenated buffer
             ops.linear(dattc[:, :hd], Wt[:, 2 * D:2 * D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
                        segs=[Seg(out=dpooled, ldo=D, rows_per_batch=Q, out_batch_stride=dpooled.stride(0), out_z_stride=Q * D)])
@@ -674,38 +678,69 @@ class MadeTrainer(MadeEngine):
             tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=tw["d_ds"].view(-1),
                            drop=self._drop(f"dec.{l}" + ".ca_attn", pd), ldo=Lp, ldt=HQ, out_batch_stride=PdS.stride(0))
             # dq'[b] = dS[b] (mem + pos)[b]
-            dq = tw["dgq"]
-            tr.gemm_tn(tw["dSt"][0], mempos3[0], dq[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
+            tr.gemm_tn(tw["dSt"][0], mempos3[0], g_q[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
                        row_mask=fus_mask, mask_zs=(L, 0))
-            # q'_h = W_k,h^T qc_h : dW_k,h += qc_h^T dq'_h ; dqc_h = dq'_h W_k,h^T
-            qc = tw[d + ".qc"]
-            dq2 = dq.view(B * Q, H * D)
-            tr.gemm_tn(qc[:, :hd], dq2[:, :D], gWin[D:D + hd], accumulate=True, batch=(H, 1), a_zs=(hd, 0), b_zs=(D, 0), c_zs=(hd * D, 0))
-            dqc = g3
+            # q'_h = W_k,h^T qc_h : dqc_h = dq'_h W_k,h^T
+            dq2 = g_q.view(B * Q, H * D)
             ops.linear(dq2[:, :D], Win[D:D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
-                       segs=[Seg(out=dqc, ldo=D, out_z_stride=hd)])
+                       segs=[Seg(out=g_qc, ldo=D, out_z_stride=hd)])
             # qc = W_q (t1 + qp) + b_q
-            tr.gemm_tn(dqc, tw[d + ".t1q"], gWin[:D], accumulate=True, colsum=gbin[:D])
-            dt1q = ops.linear(dqc, Wt[:, :D], None, out=g4)
+            dt1q = ops.linear(g_qc, Wt[:, :D], None, out=g4)
             tr.colsum(dt1q, G["query_embed"].view(-1))
             tr.add3(g1, g2, dt1q)                             # dt1 = residual path + query path
             # t1 = LN1(tgt + drop1(self-attention))
             tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
-                             dx_drop=g3, drop=self._drop(f"dec.{l}" + ".drop1", pd))
-            datt = self._lin_bwd(g3, tw[d + ".att"], p + ".sa.out", dx_out=g4)
-            qkv, gqkv = tw[d + ".qkv"], tw["dgqkv"]
+                             dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
+            datt = ops.linear(g_sa, P[p + ".sa.out.wt"], None, out=g4)
+            qkv = tw[d + ".qkv"]
             q3, g3v = qkv.view(B, Q, 3 * D), gqkv.view(B, Q, 3 * D)
             tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), datt.view(B, Q, D),
                              g3v[:, :, :D], g3v[:, :, D:2 * D], g3v[:, :, 2 * D:], tw[d + ".lse"], tw["d_delta"], H,
                              drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
-            gW, gb = G[p + ".sa.in.w"], G[p + ".sa.in.b"]
-            tr.gemm_tn(gqkv[:, :2 * D], tw[d + ".tq"], gW[:2 * D], accumulate=True, colsum=gb[:2 * D])
-            tr.gemm_tn(gqkv[:, 2 * D:], tw[d + ".tgt"], gW[2 * D:], accumulate=True, colsum=gb[2 * D:])
             dtgt = ops.linear(gqkv, P[p + ".sa.in.wt"], None, R=g2, out=tw["dtgt"])
-            if Q > 1 or True:                                 # the query embedding also enters through q,k of the self-attention
-                dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
-                tr.colsum(dqk, G["query_embed"].view(-1))
+            # the query embedding also enters through q,k of the self-attention
+            dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
+            tr.colsum(dqk, G["query_embed"].view(-1))
         dtgt0 = dtgt                                          # gradient of the decoder's content query = the clip-level vector
+
+        # ---- weight gradients of all decoder layers: one layer-batched product per parameter (the layers' parameters, and
+        # the [nd, ...] stacks, are equally spaced)
+        p0, p1 = "detr_transformer.decoder.layers.0", "detr_transformer.decoder.layers.1"
+        BQ = B * Q
+
+        def lstride(key):
+            return (G[p1 + key].data_ptr() - G[p0 + key].data_ptr()) // 4 if nd > 1 else 0
+
+        def batched(a_stack, b_stack, wkey, bkey, a_cols=None, b_cols=None, w_rows=None):
+            A, Bm = a_stack[0], b_stack[0]
+            if a_cols is not None:
+                A = A[:, a_cols[0]:a_cols[1]]
+            if b_cols is not None:
+                Bm = Bm[:, b_cols[0]:b_cols[1]]
+            gw, gb = G[p0 + wkey], (G[p0 + bkey] if bkey is not None else None)
+            if w_rows is not None:
+                gw = gw[w_rows[0]:w_rows[1]]
+                gb = gb[w_rows[0]:w_rows[1]] if gb is not None else None
+            tr.gemm_tn(A, Bm, gw, accumulate=True, colsum=gb, batch=(nd, 1), a_zs=(a_stack.stride(0), 0), b_zs=(b_stack.stride(0), 0),
+                       c_zs=(lstride(wkey), 0), colsum_zs=(lstride(bkey) if bkey is not None else 0, 0))
+
+        batched(st["g_ffn"], st["h"], ".ff2.w", ".ff2.b")
+        batched(st["g_z"], st["t2"], ".ff1.w", ".ff1.b")
+        batched(st["g_ca"], st["attc"], ".ca.out.w", ".ca.out.b")
+        batched(st["g_qc"], st["t1q"], ".ca.in.w", ".ca.in.b", w_rows=(0, D))
+        batched(st["g_sa"], st["att"], ".sa.out.w", ".sa.out.b")
+        batched(st["g_qkv"], st["tq"], ".sa.in.w", ".sa.in.b", a_cols=(0, 2 * D), w_rows=(0, 2 * D))
+        batched(st["g_qkv"], st["tgt"], ".sa.in.w", ".sa.in.b", a_cols=(2 * D, 3 * D), w_rows=(2 * D, 3 * D))
+        # per-head products of the memory-space cross-attention, batched over (layer, head)
+        gWin0 = G[p0 + ".ca.in.w"]
+        ls = lstride(".ca.in.w")
+        # v_h = W_v,h pooled_h : dW_v,h += dattc_h^T pooled_h
+        tr.gemm_tn(st["g_attc"][0][:, :hd], st["pooled"][0][:, :D], gWin0[2 * D:2 * D + hd], accumulate=True, batch=(nd, H),
+                   a_zs=(st["g_attc"].stride(0), hd), b_zs=(st["pooled"].stride(0), D), c_zs=(ls, hd * D))
+        # q'_h = W_k,h^T qc_h : dW_k,h += qc_h^T dq'_h
+        gq2 = st["g_q"].view(nd, BQ, H * D)
+        tr.gemm_tn(st["qc"][0][:, :hd], gq2[0][:, :D], gWin0[D:D + hd], accumulate=True, batch=(nd, H),
+                   a_zs=(st["qc"].stride(0), hd), b_zs=(gq2.stride(0), D), c_zs=(ls, hd * D))
         # gradient of the memory: values path (Pd^T dpooled) + keys path (dS^T q'), all layers in one product per sample
         dmem = tw["eg1"]
         tr.gemm_tn(PdS.view(B, 2 * nd * HQ, Lp)[0, :, :L], GQ.view(B, 2 * nd * HQ, D)[0], dmem.view(B, L, D)[0], batch=(B, 1),
