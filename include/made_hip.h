@@ -506,6 +506,26 @@ typedef struct MadeRepackDesc {
 } MadeRepackDesc;
 int made_repack(const MadeRepackDesc* descs_device, int32_t n_desc, int64_t total_tiles, void* stream);
 
+/* ==========================================================================================
+ * Evaluation metrics that follow the similarity matrix: computed where the matrix lives.
+ * ========================================================================================== */
+
+/* made_recall_ranks: de-duplicated rank of every video's ground-truth music (reference utils/util_test.py:44-70, Recall_metrics
+ * with dedup=True).  group_id [Nm] int32 maps every music column to the index of its music id (columns with the same id form a
+ * group; built once on the host from the id strings), gt_group [Nv] int32 is the group of each video's ground truth.
+ * rank_out[i] = number of other groups whose best similarity in row i exceeds the ground-truth group's best one (0 = retrieved
+ * first) -- what walking the descending sort while skipping already-seen ids counts.  Exact ties between different ids are
+ * counted as ranked after the ground truth (the reference's order among equal values is that of an unstable sort).
+ * top1_out [Nv] (may be NULL): column of the row maximum (lowest index among equal maxima).  n_groups <= 32768. */
+int made_recall_ranks(const float* sims, int64_t ld, const int32_t* group_id, const int32_t* gt_group, int64_t Nv, int64_t Nm,
+                      int64_t n_groups, int32_t* rank_out, int32_t* top1_out, void* stream);
+
+/* made_span_iou: per sample, the highest-scoring query's span (centre, width) -> (start, end) seconds and its IoU with the
+ * ground-truth moment (reference test-MaDe.py:304-313 ranked_preds[0]; music_detr/span_utils.py:119-170 detr_iou /
+ * individual_IoU_tensor, discounted = False).  pred_out [N,3] (may be NULL) = (start, end, foreground probability) unclamped. */
+int made_span_iou(const float* pred_logits, const float* pred_spans, const float* gt_moment, const float* m_duration,
+                  int64_t N, int64_t Q, int32_t fg_label, float max_m_duration, float* iou_out, float* pred_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,8 @@ SIGNATURES = {
     "made_repack": (C.c_int, [vp, i32, i64, vp]),
     "made_row_groups": (C.c_int, [vp, i64, vp, vp]),
     "made_row_index": (C.c_int, [vp, i64, vp, vp, vp]),
+    "made_recall_ranks": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp]),
+    "made_span_iou": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
     "made_set_criterion": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp, vp, vp]),
 }

@@ -628,3 +628,47 @@ def retrieval_sim_matrix(P, cfg, video_embeds, segment_embeds, segment_masks, mu
         pooled = xpool(vc, s, sm if cfg.fusion_mask == 1 else None, P)
         rows.append(sim_music_pooling(vc, pooled) + cos_sim(vc, m))
     return torch.cat(rows, dim=0)
+
+
+# ------------------------------------------------------------ evaluation metrics (utils/util_test.py)
+def recall_ranks_dedup(sim: np.ndarray, music_ids: Sequence) -> np.ndarray:
+    """reference: utils/util_test.py:44-70 (Recall_metrics, dedup=True): walk each row in descending similarity, count the
+    distinct music ids met before the ground-truth id."""
+    sim = np.asarray(sim)
+    order = np.argsort(sim, axis=1)[:, ::-1]
+    ind = []
+    for i, gt in enumerate(music_ids):
+        seen = set()
+        for j in order[i]:
+            m = music_ids[j]
+            if m not in seen:
+                seen.add(m)
+                if m == gt:
+                    ind.append(len(seen) - 1)
+                    break
+    return np.asarray(ind)
+
+
+def recall_ranks_plain(sim: np.ndarray) -> np.ndarray:
+    """reference: utils/util_test.py:71-80 (dedup=False): position of the diagonal element in the sorted row."""
+    sim = np.asarray(sim)
+    srt = np.sort(sim, axis=1)[:, ::-1]
+    return np.argmax((srt - np.diag(sim)[:, None]) == 0, axis=1)
+
+
+def top_span_iou(pred_logits: Tensor, pred_spans: Tensor, gt_moment: Tensor, m_duration: Tensor, fg: int, max_m_duration: float) -> Tensor:
+    """reference: test-MaDe.py:304-313 (ranked_preds[0]) + music_detr/span_utils.py:119-170 (detr_iou, individual_IoU_tensor)."""
+    out = []
+    prob = torch.softmax(pred_logits.float(), dim=-1)[:, :, fg]
+    for i in range(pred_spans.shape[0]):
+        se = span_cw_to_se(pred_spans[i].float()) * max_m_duration
+        q = max(range(se.shape[0]), key=lambda k: (float(prob[i, k]), -k))
+        ps, pe = se[q, 0].clamp(min=0), se[q, 1].clamp(max=max_m_duration)
+        gs, ge = gt_moment[i].reshape(-1)[0].float(), gt_moment[i].reshape(-1)[1].float()
+        if gs >= ge:
+            out.append(torch.tensor(0.0)); continue
+        ps, pe = ps.clamp(min=0), torch.minimum(pe, m_duration[i].float())
+        inter = (torch.minimum(ge, pe) - torch.maximum(gs, ps)).clamp(min=0)
+        union = (pe - ps) + (ge - gs) - inter
+        out.append(inter / union if union > 0 else torch.tensor(0.0))
+    return torch.stack(out)

@@ -183,7 +183,51 @@ def train_fixture(cfg: MadeConfig, B: int, T_v: int, T_a: int, name: str, cfg_ov
     print("wrote", name, len(fix), "entries")
 
 
+def metrics_fixture():
+    """Evaluation metrics of the reference's drivers on seeded inputs (utils/util_test.py, music_detr/span_utils.py)."""
+    import argparse
+    ref_import.import_reference()
+    from utils.util_test import Recall_metrics, IoU_metrics, Composite_metrics
+    from music_detr.span_utils import detr_iou, span_cw_to_se
+    rng = np.random.default_rng(11)
+    N = 60
+    ids = [f"m{int(x)}" for x in rng.integers(0, 23, size=N)]          # many videos share a music id
+    sim = rng.standard_normal((N, N)).astype(np.float32)
+    for i in range(N):                                                   # make the ground truth competitive
+        sim[i, i] += 1.5
+    met, ind, res = Recall_metrics(sim, dedup=True, all_music_ids_list=ids)
+    Q = 3
+    logits = rng.standard_normal((N, Q, 2)).astype(np.float32)
+    spans = np.stack([rng.uniform(0.1, 0.9, (N, Q)), rng.uniform(0.02, 0.6, (N, Q))], -1).astype(np.float32)
+    gt = np.sort(rng.uniform(0, 200, (N, 1, 2)), axis=-1).astype(np.float32)
+    gt[5, 0, 1] = gt[5, 0, 0]                                            # degenerate moment -> IoU 0
+    dur = rng.uniform(150, 240, N).astype(np.float32)
+    args = argparse.Namespace(max_m_duration=240)
+    mr = []
+    prob = torch.softmax(torch.from_numpy(logits), -1)[:, :, 0]
+    for i in range(N):
+        se = span_cw_to_se(torch.from_numpy(spans[i])) * 240
+        rp = torch.cat((se, prob[i].unsqueeze(-1)), dim=-1)
+        rp = sorted(rp, key=lambda x: x[2], reverse=True)
+        mr.append(dict(gt_moment=torch.from_numpy(gt[i]), m_duration=torch.tensor(dur[i]), ranked_preds=rp))
+    iou = [float(x) for x in detr_iou(args, mr)]
+    loc = IoU_metrics(iou)
+    com = Composite_metrics(ind, iou, mr, ids, ids)
+    fix = dict(sim=sim, ids=np.array(ids), ind=np.asarray(ind), logits=logits, spans=spans, gt=gt, dur=dur, iou=np.asarray(iou, dtype=np.float32),
+               top1=np.array([r["topk_music_ids"][0] for r in res]))
+    for k, v in met.items():
+        if k != "cols":
+            fix["ret." + k] = np.float64(v)
+    for k, v in loc.items():
+        fix["loc." + k] = np.float64(v)
+    for k, v in com.items():
+        fix["com." + k] = np.float64(v)
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **fix)
+    print("wrote metrics", len(fix), "entries; R1 =", met["R1"], "mIoU =", loc["mIoU"])
+
+
 def main():
+    metrics_fixture()
     train_fixture(cfg_native(), 3, 20, 40, "train_native_B3", {})
     forward_fixture(cfg_plumbing(), 2, 30, 200, "forward_cfg1_B2", {})
     c = cfg_native(); c.num_moment_queries = 3

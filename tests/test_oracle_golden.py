@@ -168,3 +168,17 @@ def test_dropout_mask_statistics_and_determinism():
         assert abs((k == k2).mean() - (p * p + (1 - p) ** 2)) < 6e-3          # independent sites
     big = dr.rng_mix(5, 9, np.array([(1 << 32) + 7, 7], dtype=np.uint64))    # the high index word matters
     assert big[0] != big[1]
+
+
+def test_eval_metrics_oracle_matches_reference_fixture(golden_dir):
+    """oracle restatement of Recall_metrics(dedup=True) / detr_iou against values the reference's own functions produced."""
+    import torch
+    fix = _load(golden_dir, "metrics")
+    ids = [str(x) for x in fix["ids"]]
+    ind = O.recall_ranks_dedup(fix["sim"], ids)
+    assert ind.tolist() == fix["ind"].tolist()
+    iou = O.top_span_iou(torch.from_numpy(fix["logits"]), torch.from_numpy(fix["spans"]), torch.from_numpy(fix["gt"]),
+                         torch.from_numpy(fix["dur"]), 0, 240.0)
+    assert float((iou - torch.from_numpy(fix["iou"])).abs().max()) <= 1e-6
+    plain = O.recall_ranks_plain(fix["sim"])
+    assert plain.tolist() == [(fix["sim"][i] > fix["sim"][i, i]).sum() for i in range(len(ids))]
