@@ -49,7 +49,7 @@ class MadeTrainer(MadeEngine):
     def _check_train_supported(self):
         c = self.cfg
         bad = []
-        if "concat" not in c.mml_fusion:
+        if "concat" not in c.mml_fusion and "CA" not in c.mml_fusion:
             bad.append(f"mml_fusion={c.mml_fusion}")
         if c.num_moment_queries != 1:
             bad.append("num_moment_queries > 1")
@@ -88,6 +88,12 @@ class MadeTrainer(MadeEngine):
         vecs.append(("xa.kv.b", (XA + ".cross_attn.k_proj.bias", XA + ".cross_attn.v_proj.bias")))
         lin("xa.out", XA + ".cross_attn.out_proj"); lin("xa.lin", XA + ".linear_proj")
         vecs.append(("logit_scale", "logit_scale"))
+        if "CA" in c.mml_fusion:                                      # reference model/model_Base.py:99-213 (bias-free q / kv)
+            ca = "video_music_fusion_cross_transformer"
+            mats.append(("ca.q.w", ca + ".layers.0.0.to_q.weight")); mats.append(("ca.kv.w", ca + ".layers.0.0.to_kv.weight"))
+            lin("ca.out", ca + ".layers.0.0.to_out.0"); lin("ca.ff1", ca + ".layers.0.1.net.0"); lin("ca.ff2", ca + ".layers.0.1.net.3")
+            ln("ca.lnq", ca + ".attention_query_layer_norms.0"); ln("ca.lnc", ca + ".attention_context_layer_norms.0")
+            ln("ca.lnf", ca + ".ff_layer_norms.0"); lin("ca.final", ca + ".final_linear")
         for l in range(c.detr_enc_layers):
             p = f"detr_transformer.encoder.layers.{l}"
             mats.append((p + ".in.w", p + ".self_attn.in_proj_weight")); vecs.append((p + ".in.b", p + ".self_attn.in_proj_bias"))
@@ -270,7 +276,8 @@ class MadeTrainer(MadeEngine):
         if ws is not None:
             return ws
         c, dev, tc = self.cfg, self.device, self.tc
-        D, L, Q, H = c.D, Tv + Ta, c.num_moment_queries, c.detr_nheads
+        concat = "concat" in c.mml_fusion
+        D, L, Q, H = c.D, (Tv + Ta if concat else Ta), c.num_moment_queries, c.detr_nheads
         Ft, Fd, nd, ne = c.temporal_ffn_dim, c.detr_dim_feedforward, c.detr_dec_layers, c.detr_enc_layers
         Hh = c.SA_temporal_heads
         f32 = torch.float32
@@ -322,6 +329,12 @@ class MadeTrainer(MadeEngine):
                        f"e.{l}.lse": E(B * H * L, dtype=f32), f"e.{l}.x": E(rows, D), f"e.{l}.s1": E(rows, D), f"e.{l}.h": E(rows, Fd),
                        f"e.{l}.x2": E(rows, D)})
         ws.update(mem=E(rows, D), mempos=E(rows, D))
+        if not concat:                                          # CA fusion block (query = segments, context = frames)
+            inner, ra, rv = c.ca_heads * c.ca_dim_head, B * Ta, B * Tv
+            ws.update(c_nx=E(ra, D), c_nc=E(rv, D), c_q=E(ra, inner), c_kv=E(rv, 2 * inner), c_att=E(ra, inner), c_lse=E(B * c.ca_heads * Ta, dtype=f32),
+                      c_ax=E(ra, D), c_nf=E(ra, D), c_z1=E(ra, c.ca_ffn_dim), c_h=E(ra, c.ca_ffn_dim), c_y=E(ra, D),
+                      c_g1=E(ra, D), c_g2=E(ra, D), c_g3=E(ra, D), c_gf=E(ra, c.ca_ffn_dim), c_gq=E(ra, inner), c_gkv=E(rv, 2 * inner),
+                      c_gatt=E(ra, inner), c_delta=E(B * c.ca_heads * Ta, dtype=f32), c_dseg=E(ra, D), c_dframe=E(rv, D), c_gnc=E(rv, D))
         i32 = torch.int32
         ws.update(rows_v=(E(B * Tv, dtype=i32), E(1, dtype=i32)), rows_a=(E(B * Ta, dtype=i32), E(1, dtype=i32)), rows_f=(E(rows, dtype=i32), E(1, dtype=i32)))
         # decoder: saved activations and per-layer output gradients as [nd, ...] stacks (uniform layer stride), so the weight
@@ -353,7 +366,8 @@ class MadeTrainer(MadeEngine):
         self.seed = int(seed)
         B, Tv, _ = frame_feats.shape
         Ta = segment_feats.shape[1]
-        D, L, Q, nd, H = c.D, Tv + Ta, c.num_moment_queries, c.detr_dec_layers, c.detr_nheads
+        concat = "concat" in c.mml_fusion
+        D, L, Q, nd, H = c.D, (Tv + Ta if concat else Ta), c.num_moment_queries, c.detr_dec_layers, c.detr_nheads
         ws, tw = self._buffers(B, Tv, Ta), self._train_buffers(B, Tv, Ta)
         fm, sm = frame_masks.contiguous(), segment_masks.contiguous()
         pd = float(c.detr_dropout)
@@ -361,8 +375,11 @@ class MadeTrainer(MadeEngine):
         self._inputs = (frame_feats.contiguous(), segment_feats.contiguous(), fm, sm, spans_target.contiguous())
 
         fus, fus_mask = ws["fus"], ws["fus_mask"]
-        fus_mask[:, :Tv].copy_(fm)
-        fus_mask[:, Tv:].copy_(sm)
+        if concat:
+            fus_mask[:, :Tv].copy_(fm)
+            fus_mask[:, Tv:].copy_(sm)
+        else:
+            fus_mask.copy_(sm)
         # valid-token lists: every large GEMM (forward, dX and dW) gathers the valid rows only, so padding costs nothing
         self._groups = {}
         self._rows = {fus_mask.data_ptr(): ops.row_index(fus_mask, out=tw["rows_f"]), fm.data_ptr(): ops.row_index(fm, out=tw["rows_v"]),
@@ -377,7 +394,12 @@ class MadeTrainer(MadeEngine):
             self._encode_train(self._inputs[0], fm, "video", ws, tw, 0)
         self._encode_train(self._inputs[1], sm, "audio", ws, tw, Tv)
         cur.wait_stream(side)
-        frame, seg = fus[:, :Tv], fus[:, Tv:]
+        if concat:
+            frame, seg = fus[:, :Tv], fus[:, Tv:]
+        else:
+            frame, seg = ws["frame_buf"], ws["seg_buf"]
+            self._ca_fusion_train(ws, tw, frame, seg, fm, sm, B, Tv, Ta)
+        self._views = (frame, seg)
         video, music = ws["video"], ws["music"]
         out: Dict[str, Tensor] = dict(video_feats=video, music_feats=music, frame_feats=frame, segment_feats=seg)
 
@@ -399,9 +421,12 @@ class MadeTrainer(MadeEngine):
         rows = B * L
         fskip = fus_mask.view(-1)
         pos2 = pos.view(rows, D)
-        src, srcpos = tw["e.0.src"], tw["e.0.srcpos"]
-        ops.layernorm_add(fus.view(rows, D), None, None, pos2, None, srcpos, row_skip=fskip)
         src = fus.view(rows, D)
+        if c.detr_enc_layers == 0:                            # no encoder: memory = the fused sequence itself
+            ops.layernorm_add(src, None, None, pos2, tw["mem"], tw["mempos"], row_skip=fskip)
+        else:
+            srcpos = tw["e.0.srcpos"]
+            ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)
         for l in range(c.detr_enc_layers):
             p, e = f"detr_transformer.encoder.layers.{l}", f"e.{l}"
             if l > 0:
@@ -537,7 +562,10 @@ class MadeTrainer(MadeEngine):
                            drop=self._drop(f"{name}.{l}.ffn_act", pt))
             nxt = tw[f"{tag}.{l + 1}.x0"] if l + 1 < depth else tw[tag + ".xlast"]
             x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=nxt, rows=rws, drop=self._drop(f"{name}.{l}.ffn_out", pt))
-        local = ws["fus"][:, row_off:row_off + T]
+        if "concat" in c.mml_fusion:
+            local = ws["fus"][:, row_off:row_off + T]
+        else:
+            local = ws["frame_buf"] if which == "video" else ws["seg_buf"]
         ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat, tile_skip_mask=mflat,
                    segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
         vec = ws["video"] if which == "video" else ws["music"]
@@ -560,13 +588,63 @@ class MadeTrainer(MadeEngine):
         y = ops.linear(a3, P["xa.lin.w"], P["xa.lin.b"], R=a3, out=tw["xy"], drop=self._drop("xa.linear_out", dr.P_XPOOL))
         ops.xpool_tail(y, P["xa.ln3.g"], P["xa.ln3.b"], video, ws["sims_single"], B, B)
 
+    def _ca_fusion_train(self, ws, tw, frame: Tensor, seg: Tensor, fm: Tensor, sm: Tensor, B: int, Tv: int, Ta: int) -> None:
+        """reference model/model_Base.py:194-213 (+ :130-167, :22-45) in train mode, then the masked_fill of model_Uni.py:211:
+        pre-LN cross-attention (query = segments, context = frames, 8 heads x 128, bias-free q / kv, key mask before the softmax,
+        query mask after it), residual, pre-LN GELU FFN with residual, final Linear -> ws["fus"]; dropout 0.8 at three sites."""
+        c, P = self.cfg, self.P
+        D, Hc = c.D, c.ca_heads
+        inner = Hc * c.ca_dim_head
+        pt = dr.P_TEMPORAL
+        sflat, fflat = sm.reshape(-1), fm.reshape(-1)
+        ra, rv = self._rw(sflat), self._rw(fflat)
+        x = seg.reshape(B * Ta, D)
+        nx = ops.layernorm(x, P["ca.lnq.g"], P["ca.lnq.b"], out=tw["c_nx"], row_skip=sflat)
+        nc = ops.layernorm(frame.reshape(B * Tv, D), P["ca.lnc.g"], P["ca.lnc.b"], out=tw["c_nc"], row_skip=fflat)
+        q = ops.linear(nx, P["ca.q.w"], None, out=tw["c_q"], rows=ra)
+        kv = ops.linear(nc, P["ca.kv.w"], None, out=tw["c_kv"], rows=rv)
+        kv3 = kv.view(B, Tv, 2 * inner)
+        ops.attention(q.view(B, Ta, inner), kv3[:, :, :inner], kv3[:, :, inner:], tw["c_att"].view(B, Ta, inner), Hc, key_mask=fm, q_mask=sm,
+                      q_skip_mask=sm, scale=c.ca_dim_head ** -0.5, lse=tw["c_lse"])
+        ax = ops.linear(tw["c_att"], P["ca.out.w"], P["ca.out.b"], R=x, out=tw["c_ax"], rows=ra, drop=self._drop("ca.attn_out", pt))
+        nf = ops.layernorm(ax, P["ca.lnf.g"], P["ca.lnf.b"], out=tw["c_nf"], row_skip=sflat)
+        h = ops.linear(nf, P["ca.ff1.w"], P["ca.ff1.b"], act=ops.ACT_GELU, out=tw["c_h"], Zout=tw["c_z1"], rows=ra, drop=self._drop("ca.ffn_act", pt))
+        y = ops.linear(h, P["ca.ff2.w"], P["ca.ff2.b"], R=ax, out=tw["c_y"], rows=ra, drop=self._drop("ca.ffn_out", pt))
+        ops.linear(y, P["ca.final.w"], P["ca.final.b"], out_row_mask=sflat, tile_skip_mask=sflat, out=ws["fus"].view(B * Ta, D))
+
+    def _ca_fusion_bwd(self, ws, tw, dfus: Tensor, frame: Tensor, seg: Tensor, fm: Tensor, sm: Tensor, B: int, Tv: int, Ta: int) -> None:
+        """gradients of the CA fusion block: -> tw["c_dseg"] (w.r.t. the segment features) and tw["c_dframe"] (frame features)."""
+        c, P, G = self.cfg, self.P, self.G
+        D, Hc = c.D, c.ca_heads
+        inner = Hc * c.ca_dim_head
+        pt = dr.P_TEMPORAL
+        sflat, fflat = sm.reshape(-1), fm.reshape(-1)
+        g1, g2, g3, gf = tw["c_g1"], tw["c_g2"], tw["c_g3"], tw["c_gf"]
+        # fus = mask(final(y)); y = ax + drop(ffn2(h)): d y raw (residual) and dropped (branch)
+        dff = self._lin_bwd(dfus, tw["c_y"], "ca.final", dx_out=g1, row_mask=sflat, Zout=g2, drop=self._drop("ca.ffn_out", pt))
+        dz1 = self._lin_bwd(dff, tw["c_h"], "ca.ff2", dx_out=gf, row_mask=sflat, gate=_lib.GATE_GELU_Z, G=tw["c_z1"], drop=self._drop("ca.ffn_act", pt))
+        dnf = self._lin_bwd(dz1, tw["c_nf"], "ca.ff1", dx_out=g3, row_mask=sflat)
+        # ax = x + drop(to_out(att)): LN_f backward + the residual d y
+        tr.layernorm_bwd(tw["c_ax"], P["ca.lnf.g"], dnf, g1, dgamma=G["ca.lnf.g"], dbeta=G["ca.lnf.b"], add=g2, dx_drop=g3,
+                         drop=self._drop("ca.attn_out", pt), row_skip=sflat)
+        datt = self._lin_bwd(g3, tw["c_att"], "ca.out", dx_out=tw["c_gatt"], row_mask=sflat)
+        q, kv = tw["c_q"], tw["c_kv"]
+        kv3, gkv3 = kv.view(B, Tv, 2 * inner), tw["c_gkv"].view(B, Tv, 2 * inner)
+        tr.attention_bwd(q.view(B, Ta, inner), kv3[:, :, :inner], kv3[:, :, inner:], tw["c_att"].view(B, Ta, inner), datt.view(B, Ta, inner),
+                         tw["c_gq"].view(B, Ta, inner), gkv3[:, :, :inner], gkv3[:, :, inner:], tw["c_lse"], tw["c_delta"], Hc,
+                         key_mask=fm, q_skip_mask=sm, scale=c.ca_dim_head ** -0.5)
+        dnx = self._lin_bwd(tw["c_gq"], tw["c_nx"], "ca.q", dx_out=g2, row_mask=sflat)
+        tr.layernorm_bwd(seg, P["ca.lnq.g"], dnx, tw["c_dseg"], dgamma=G["ca.lnq.g"], dbeta=G["ca.lnq.b"], add=g1, row_skip=sflat)
+        dnc = self._lin_bwd(tw["c_gkv"], tw["c_nc"], "ca.kv", dx_out=tw["c_gnc"], row_mask=fflat)
+        tr.layernorm_bwd(frame, P["ca.lnc.g"], dnc, tw["c_dframe"], dgamma=G["ca.lnc.g"], dbeta=G["ca.lnc.b"], row_skip=fflat)
+
     # ================================================================== backward
     def _lin_bwd(self, dz: Tensor, x: Tensor, key: str, *, dx_out: Optional[Tensor] = None, row_mask: Optional[Tensor] = None,
                  skip: Optional[Tensor] = None, gw: Optional[Tensor] = None, gb: Optional[Tensor] = None, wt: Optional[Tensor] = None,
                  **kw) -> Optional[Tensor]:
         """Linear backward: dW += dz^T x, db += colsum(dz), dx = dz W (with the epilogue options of ops.linear)."""
         rows = self._rw(row_mask)                             # the mask's valid-row list: gather instead of masking
-        tr.gemm_tn(dz, x, self.G[key + ".w"] if gw is None else gw, accumulate=True, colsum=self.G[key + ".b"] if gb is None else gb,
+        tr.gemm_tn(dz, x, self.G[key + ".w"] if gw is None else gw, accumulate=True, colsum=self.G.get(key + ".b") if gb is None else gb,
                    row_mask=row_mask if rows is None else None, row_groups=self._rg(row_mask), rows=rows)
         if dx_out is None:
             return None
@@ -587,7 +665,8 @@ class MadeTrainer(MadeEngine):
         B, Tv, Ta = self._shape
         ws, tw = self._buffers(B, Tv, Ta), self._train_buffers(B, Tv, Ta)
         feats_v, feats_a, fm, sm, tg = self._inputs
-        D, L, Q, nd, ne, H = c.D, Tv + Ta, c.num_moment_queries, c.detr_dec_layers, c.detr_enc_layers, c.detr_nheads
+        concat = "concat" in c.mml_fusion
+        D, L, Q, nd, ne, H = c.D, (Tv + Ta if concat else Ta), c.num_moment_queries, c.detr_dec_layers, c.detr_enc_layers, c.detr_nheads
         hd, HQ = D // H, H * Q
         pd = float(c.detr_dropout)
         inv_keep = 1.0 / (1.0 - pd) if (self.training_dropout and pd > 0) else 1.0
@@ -599,7 +678,7 @@ class MadeTrainer(MadeEngine):
         dvideo, dmusic = tw["dvideo"], tw["dmusic"]
         dvideo.zero_(); dmusic.zero_()
         video, music = ws["video"], ws["music"]
-        frame = fus[:, :Tv]
+        frame, seg_view = self._views
         # the X-Pool / similarity branch is independent of the DETR stack until the temporal encoders: its (latency-bound)
         # backward runs on the second stream beside the decoder's
         cur, side = torch.cuda.current_stream(), self._side_stream()
@@ -775,6 +854,11 @@ class MadeTrainer(MadeEngine):
             nxt = tw["dfus"] if dx is tw["eg1"] else tw["eg1"]
             dsrc = ops.linear(gq, P[p + ".in.wt"], None, R=dx, out=nxt, rows=self._rw(fskip))
         dfus = dsrc.view(B, L, D)
+        if concat:
+            dl_v, dl_a = dfus[:, :Tv], dfus[:, Tv:]
+        else:                                                 # through the CA fusion block back to the two encoders' outputs
+            self._ca_fusion_bwd(ws, tw, dsrc, frame, seg_view, fm, sm, B, Tv, Ta)
+            dl_v, dl_a = tw["c_dframe"].view(B, Tv, D), tw["c_dseg"].view(B, Ta, D)
 
         # ---------------- join the X-Pool / similarity branch, merge the gradients of the clip-level vectors
         cur.wait_stream(side)
@@ -784,8 +868,8 @@ class MadeTrainer(MadeEngine):
         # ---------------- temporal encoders (video on the second stream)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._encode_bwd("video", ws, tw, dfus[:, :Tv], tw["dframe_x"].view(B, Tv, D) if c.contrastive_align_loss else None, dvideo, fm, feats_v)
-        self._encode_bwd("audio", ws, tw, dfus[:, Tv:], tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a)
+            self._encode_bwd("video", ws, tw, dl_v, tw["dframe_x"].view(B, Tv, D) if c.contrastive_align_loss else None, dvideo, fm, feats_v)
+        self._encode_bwd("audio", ws, tw, dl_a, tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a)
         cur.wait_stream(side)
 
     def _retrieval_bwd(self, ws, tw, g_ret: Optional[Tensor], B: int, S: int, sm: Tensor) -> None:
@@ -831,7 +915,7 @@ class MadeTrainer(MadeEngine):
             tr.gemm_tn(tw["xdSt"][0], xk[:S], tw["xdq32"], batch=(B, 1), a_zs=(S * B, 0), b_zs=(S * D, 0), c_zs=(0, 0), accumulate=True,
                        row_mask=seg_mask, mask_zs=(S, 0))
             ds1 = self._lin_bwd(dkv, tw["xs1"], "xa.kv", dx_out=tw["xds1"], row_mask=skip, skip=skip)
-            seg = ws["fus"][:, self._shape[1]:]
+            seg = self._views[1]
             tr.layernorm_bwd(seg, P["xa.ln1.g"], ds1, tw["xdseg"], dgamma=G["xa.ln1.g"], dbeta=G["xa.ln1.b"], row_skip=skip)
             dq = tr.add3(tw["xdq"], tw["xdq32"])
             dv1 = self._lin_bwd(dq, tw["xv1"], "xa.q", dx_out=tw["xdv1"])

@@ -292,9 +292,11 @@ def detr_transformer(src: Tensor, mask: Tensor, pos: Tensor, target: Optional[Te
 
 
 # ------------------------------------------------------------------- a17: CA fusion
-def ca_fusion(query: Tensor, context: Tensor, q_mask: Tensor, kv_mask: Tensor, P, cfg) -> Tensor:
+def ca_fusion(query: Tensor, context: Tensor, q_mask: Tensor, kv_mask: Tensor, P, cfg, drop: Optional[Drop] = None) -> Tensor:
     """reference: model/model_Base.py:194-213 + :130-167 + :22-45 (depth 1), SURVEY a17.
-    kv-mask before the softmax, q-mask after it; bias-free q/kv projections."""
+    kv-mask before the softmax, q-mask after it; bias-free q/kv projections.  Train mode: dropout (p = 0.8, model_Uni.py:41)
+    after the attention's output Linear (:113), after the GELU and after the second FFN Linear (:28-30)."""
+    pc = drop.p_temporal if drop is not None else 0.0
     ca = "video_music_fusion_cross_transformer"
     H, dh = cfg.ca_heads, cfg.ca_dim_head
     B, Lq, D = query.shape
@@ -309,9 +311,10 @@ def ca_fusion(query: Tensor, context: Tensor, q_mask: Tensor, kv_mask: Tensor, P
     dots = dots.masked_fill((kv_mask == 0)[:, None, None, :], float("-inf"))
     attn = torch.softmax(dots, dim=-1).masked_fill((q_mask == 0)[:, None, :, None], 0)
     o = (attn @ v).transpose(1, 2).reshape(B, Lq, H * dh)
-    x = linear(o, P, ca + ".layers.0.0.to_out.0") + query
+    x = _drop(drop, linear(o, P, ca + ".layers.0.0.to_out.0"), "ca.attn_out", pc) + query
     nx = layer_norm(x, P, ca + ".ff_layer_norms.0")
-    x = linear(gelu_erf(linear(nx, P, ca + ".layers.0.1.net.0")), P, ca + ".layers.0.1.net.3") + x
+    h = _drop(drop, gelu_erf(linear(nx, P, ca + ".layers.0.1.net.0")), "ca.ffn_act", pc)
+    x = _drop(drop, linear(h, P, ca + ".layers.0.1.net.3"), "ca.ffn_out", pc) + x
     return linear(x, P, ca + ".final_linear")
 
 
@@ -555,7 +558,7 @@ def forward(P, cfg, frame_feats, segment_feats, frame_masks, segment_masks, span
         fus = torch.cat([frame, seg], dim=1)
         fus_mask = torch.cat([fm, sm], dim=1)
     else:                                                           # "CA" (model_Uni.py:209-212)
-        fus = ca_fusion(seg, frame, sm, fm, P, cfg) * (sm != 0).unsqueeze(-1)
+        fus = ca_fusion(seg, frame, sm, fm, P, cfg, drop) * (sm != 0).unsqueeze(-1)
         fus_mask = sm
     pos = sine_position_embedding(fus_mask, D)
     r["detr_pos"] = pos

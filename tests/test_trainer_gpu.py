@@ -64,7 +64,8 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
 
 
 @pytest.mark.parametrize("dropout", [False, True])
-@pytest.mark.parametrize("overrides", [{}, {"vmr_loss": "dual_single_sim_fuse", "moment_query_type": "music"}])
+@pytest.mark.parametrize("overrides", [{}, {"vmr_loss": "dual_single_sim_fuse", "moment_query_type": "music"}, {"mml_fusion": "CA"},
+                                       {"mml_fusion": "CA", "detr_enc_layers": 0, "vmr_loss": "single"}])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     cfg, sd, inp = _setup(3, 20, 40, overrides)
