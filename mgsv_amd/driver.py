@@ -116,11 +116,20 @@ class MGSV_EC_Dataset(torch.utils.data.Dataset):
         self.csv = pd.read_csv(csv_path)
         if getattr(args, "max_samples", 0):
             self.csv = self.csv.iloc[:args.max_samples]
+        # packed stores written by tools/pack_features.py take precedence over the per-id .pt files (mgsv_amd/feature_store.py)
+        from .feature_store import PackedFeatures
+        self.packed = {}
+        for kind, root in (("vit", args.frame_frozen_feature_path), ("ast", args.music_frozen_feature_path)):
+            path = os.path.join(root, f"{kind}.made")
+            if os.path.isfile(path):
+                self.packed[kind] = PackedFeatures(path)
 
     def __len__(self):
         return len(self.csv)
 
     def _features(self, root: str, kind: str, ident: str, T: int, dim: int, length_hint: float):
+        if kind in self.packed:
+            return self.packed[kind].get(ident)
         fp = os.path.join(root, f"{kind}_feature", f"{ident}.pt")
         mp = os.path.join(root, f"{kind}_mask", f"{ident}.pt")
         if os.path.isfile(fp) and os.path.isfile(mp):
