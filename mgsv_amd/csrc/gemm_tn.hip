@@ -129,7 +129,10 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float csum = 0.f;
-    const bool do_colsum = a.colsum != nullptr && tile_k == 0 && tid < TBN;
+    // bias gradient: the k-tiles of one n-tile share the work (rows tile_k, tile_k + tiles_k, ... of every slab), so no block
+    // carries the column sums alone and finishes late
+    const bool do_colsum = a.colsum != nullptr && tid < TBN;
+    const int cs_step = tiles_k < BM ? tiles_k : BM;
 
     load_rows(gslab(s_begin));
     if (slab_live(s_begin)) load_slab(gslab(s_begin));
@@ -147,9 +150,9 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
         }
         if (!live) continue;
 
-        if (do_colsum) {
-#pragma unroll 8
-            for (int m = 0; m < BM; ++m) csum += to_f32(*(const TC*)(lds_a + m * ROW + tid * (int)sizeof(TC)));
+        if (do_colsum && tile_k < cs_step) {
+#pragma unroll 4
+            for (int m = tile_k; m < BM; m += cs_step) csum += to_f32(*(const TC*)(lds_a + m * ROW + tid * (int)sizeof(TC)));
         }
         if constexpr (IS_BF16) {
             const int g = lane >> 4, i16 = lane & 15;
@@ -253,6 +256,8 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const MadeGemmTNArgs
 
 }  // namespace
 
+int made_gemm_tn_fast(const MadeGemmTNArgs& a, hipStream_t st);      // gemm_tn_glds.hip
+
 extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
     MADE_REQUIRE(args != nullptr, "made_gemm_tn: null args");
     MadeGemmTNArgs a = *args;
@@ -288,6 +293,10 @@ extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
     }
     const int64_t tiles = ((a.N + TBN - 1) / TBN) * ((a.K + TBK - 1) / TBK);
     MADE_UNSUPPORTED(tiles < (1LL << 31), "made_gemm_tn: too many tiles");
+    {
+        const int rc = made_gemm_tn_fast(a, st);                     // direct-to-LDS 3-stage kernel when the shapes allow
+        if (rc != 1) return rc;
+    }
     dim3 grid((unsigned)tiles, (unsigned)a.split_m, (unsigned)nz);
     if (a.ab_dtype == MADE_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(TNT), 0, st, a);
     else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(TNT), 0, st, a);

@@ -36,7 +36,15 @@ def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulat
         if accumulate:
             slab = 64 if A.dtype == torch.bfloat16 else 32
             tiles = ((N + 127) // 128) * ((K + 127) // 128) * nz
-            split_m = max(1, min(512 // max(tiles, 1), (M + slab - 1) // slab, 256))
+            fast = A.dtype == torch.bfloat16 and N % 128 == 0 and K % 128 == 0 and nz == 1 and (row_mask is None or rows is not None)
+            if fast:                                          # direct-to-LDS kernel: one workgroup per CU, all tiles of a split on one
+                split_m = max(8, (256 // max(tiles, 1)) // 8 * 8)   # XCD -> a multiple of 8 splits keeps the 8 XCDs evenly loaded
+                nslab = (M + slab - 1) // slab
+                while (nslab + split_m - 1) // split_m > 96:      # a workgroup keeps at most 96 slabs' row indices in LDS
+                    split_m += 8
+                split_m = min(split_m, max(1, nslab))
+            else:
+                split_m = max(1, min(512 // max(tiles, 1), (M + slab - 1) // slab, 256))
     a = MadeGemmTNArgs()
     a.A, a.B, a.C = _p(A), _p(B), _p(Cout)
     a.ab_dtype, a.c_dtype = dt_of(A), dt_of(Cout)

@@ -421,3 +421,27 @@ def test_row_gather_linear_and_gemm_tn_bit_identical_on_valid_rows(T, dtype):
         assert torch.isfinite(Cg).all() and torch.isfinite(cs).all()
         tol = 2e-5 if dtype == torch.float32 else 2e-3
         assert float((Cg - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 128), (4133, 512, 512), (333, 128, 384), (20000, 1024, 512)])
+def test_gemm_tn_direct_to_lds_path(T, M, N, K):
+    """bf16, N and K multiples of 128, no row mask (or a row list): the 3-stage direct-to-LDS kernel, incl. a ragged last slab."""
+    ops, tr = T
+    A, B = _rand(M, N, dtype=torch.bfloat16, seed=1), _rand(M, K, dtype=torch.bfloat16, seed=2)
+    ref = A.float().t() @ B.float()
+    sc = float(ref.abs().max())
+    for split in (1, 3, None):
+        C = torch.zeros(N, K, device="cuda"); cs = torch.zeros(N, device="cuda")
+        tr.gemm_tn(A, B, C, accumulate=True, colsum=cs, split_m=split)
+        assert float((C - ref).abs().max()) <= 2e-3 * sc, split
+        assert float((cs - A.float().sum(0)).abs().max()) <= 2e-3 * float(A.float().sum(0).abs().max()) + 0.05
+    Cs = torch.empty(N, K, device="cuda", dtype=torch.bfloat16)
+    tr.gemm_tn(A, B, Cs)
+    assert float((Cs.float() - ref).abs().max()) <= 1e-2 * sc
+    mask = (torch.rand(M, device="cuda") > 0.4).float()
+    rows = ops.row_index(mask)
+    refm = (A.float() * mask[:, None]).t() @ B.float()
+    A2 = A.clone(); A2[mask == 0] = float("nan")
+    C = torch.zeros(N, K, device="cuda")
+    tr.gemm_tn(A2, B, C, accumulate=True, rows=rows)
+    assert torch.isfinite(C).all() and float((C - refm).abs().max()) <= 2e-3 * float(refm.abs().max())

@@ -22,3 +22,7 @@ for split in (None, 8, 16, 32, 64):
     bench(34688, 512, 512, split)
 bench(34688, 1536, 512); bench(34688, 1024, 512); bench(34688, 512, 1024); bench(34688, 1024, 512, 16); bench(34688, 1536, 512, 8)
 bench(32768, 512, 768); bench(1920, 512, 512)
+print("-- no mask (direct-to-LDS kernel)")
+for sp in (None, 8, 16, 32):
+    bench(34688, 512, 512, sp, mask=False)
+bench(34688, 1536, 512, mask=False); bench(34688, 1024, 512, mask=False); bench(34688, 512, 1024, mask=False); bench(18700, 512, 512, mask=False); bench(18700, 1024, 512, mask=False)
