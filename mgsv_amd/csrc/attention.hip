@@ -51,14 +51,14 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     const int r = lane & 31, hh = lane >> 5;
     // 1-D grid, XCD-aware order: workgroups b, b+8, ... share an XCD; give each XCD a contiguous run of (batch, head,
     // q-tile) triples so the q-tiles of one (batch, head) re-read its K / V from that XCD's L2 instead of HBM
+    // 1-D grid, XCD-aware and balanced: workgroup i runs on XCD i % 8.  (batch, head) pair p goes to XCD p % 8 with all its
+    // q-tiles (they re-read its K / V from that XCD's L2); with H a multiple of 8 every XCD gets the same heads of EVERY sample,
+    // so ragged sequence lengths load the 8 XCDs equally (contiguous runs of samples per XCD left whole XCDs idle)
     const int qtiles = (int)((a.Lq + BQ - 1) / BQ);
-    int wg;
-    {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
-        wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
-    }
-    const int qt = wg % qtiles;
-    const int64_t h = (wg / qtiles) % a.H, b = wg / (qtiles * a.H);
+    const int64_t pair = (int64_t)(blockIdx.x & 7) + 8 * (int64_t)((blockIdx.x >> 3) / qtiles);
+    if (pair >= a.B * a.H) return;
+    const int qt = (int)((blockIdx.x >> 3) % qtiles);
+    const int64_t h = pair % a.H, b = pair / a.H;
     const int64_t q0 = (int64_t)qt * BQ + wave * 32;
     bool wave_active = q0 < a.Lq;
     if (a.q_skip_mask) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
 
 template <typename TC>
 int launch_attention(const MadeAttnArgs& a, hipStream_t st) {
-    dim3 grid((unsigned)(((a.Lq + BQ - 1) / BQ) * a.H * a.B)), block(NTHREADS);
+    dim3 grid((unsigned)(((a.Lq + BQ - 1) / BQ) * 8 * ((a.H * a.B + 7) / 8))), block(NTHREADS);
     switch (a.hd) {
         case 32: hipLaunchKernelGGL((attention_kernel<TC, 32>), grid, block, 0, st, a); break;
         case 64: hipLaunchKernelGGL((attention_kernel<TC, 64>), grid, block, 0, st, a); break;

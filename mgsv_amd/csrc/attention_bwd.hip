@@ -92,14 +92,12 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
+    // XCD-aware, balanced placement as in the forward kernel: (batch, head) pair p -> XCD p % 8 with all its q-tiles
     const int qtiles = (int)((a.Lq + BQ - 1) / BQ);
-    int wg;
-    {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
-        wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
-    }
-    const int qt = wg % qtiles;
-    const int64_t h = (wg / qtiles) % a.H, b = wg / (qtiles * a.H);
+    const int64_t pair = (int64_t)(blockIdx.x & 7) + 8 * (int64_t)((blockIdx.x >> 3) / qtiles);
+    if (pair >= a.B * a.H) return;
+    const int qt = (int)((blockIdx.x >> 3) % qtiles);
+    const int64_t h = pair % a.H, b = pair / a.H;
     const int64_t q0 = (int64_t)qt * BQ + wave * 32;
     const int64_t q = q0 + r;
     const int64_t qc = q < a.Lq ? q : a.Lq - 1;
@@ -332,8 +330,10 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int ktiles = (int)((a.Lk + BK - 1) / BK);
-    const int kt_blk = blockIdx.x % ktiles;
-    const int64_t h = (blockIdx.x / ktiles) % a.H, b = blockIdx.x / (ktiles * a.H);
+    const int64_t pair = (int64_t)(blockIdx.x & 7) + 8 * (int64_t)((blockIdx.x >> 3) / ktiles);      // pair p -> XCD p % 8 (see dq)
+    if (pair >= a.B * a.H) return;
+    const int kt_blk = (int)((blockIdx.x >> 3) % ktiles);
+    const int64_t h = pair % a.H, b = pair / a.H;
     const int64_t key = (int64_t)kt_blk * BK + wave * 32 + r;
     const int64_t keyc = key < a.Lk ? key : a.Lk - 1;
     const float* maskg = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
@@ -546,7 +546,8 @@ template <typename TC>
 int launch_bwd(const MadeAttnBwdArgs& a, hipStream_t st) {
     const int64_t rows = a.B * a.Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTH), 0, st, a);
-    dim3 gq((unsigned)(((a.Lq + 127) / 128) * a.H * a.B)), gk((unsigned)(((a.Lk + 127) / 128) * a.H * a.B)), block(NTH);
+    const int64_t pairs8 = 8 * ((a.H * a.B + 7) / 8);
+    dim3 gq((unsigned)(((a.Lq + 127) / 128) * pairs8)), gk((unsigned)(((a.Lk + 127) / 128) * pairs8)), block(NTH);
     switch (a.hd) {
         case 32:
             hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 32>), gq, block, 0, st, a);
