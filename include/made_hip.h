@@ -202,6 +202,9 @@ typedef struct MadeAttnArgs {
                                   key), saved for made_attention_bwd */
     MadeDropout drop;          /* dropout on the attention weights (after the softmax, as nn.MultiheadAttention does),
                                   element index ((b*H + h)*Lq + i)*Lk + j */
+    const int32_t* batch_order; /* [B] or NULL: a permutation of the batch (made_batch_order: longest sequence first).  Only the
+                                  ORDER in which workgroups are issued changes -- a padded batch then finishes with its short
+                                  samples instead of waiting on a long one that started last; results are unchanged */
 } MadeAttnArgs;
 
 int made_attention(const MadeAttnArgs* args, void* stream);
@@ -365,6 +368,7 @@ typedef struct MadeAttnBwdArgs {
     const float* key_mask; const float* q_skip_mask;
     float scale; int32_t _pad;
     MadeDropout drop;
+    const int32_t* batch_order; /* [B] or NULL: issue order of the batch, as in MadeAttnArgs */
 } MadeAttnBwdArgs;
 
 int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream);
@@ -400,6 +404,10 @@ int made_row_groups(const float* mask, int64_t M, float* out, void* stream);
  * the last valid row (0 when there is none), n_rows[0] = n.  One workgroup, M <= 2^22.  Feeds the row gather of made_linear /
  * made_gemm_tn: the GEMMs of a padded batch then cost what its valid tokens cost. */
 int made_row_index(const float* mask, int64_t M, int32_t* row_index, int32_t* n_rows, void* stream);
+/* made_batch_order: order[r] = index of the sample with the r-th largest number of nonzero mask entries (mask [B, T]; ties in
+ * ascending sample index, so the result is a deterministic permutation).  The `batch_order` of made_attention / _bwd.
+ * One workgroup, B <= 8192. */
+int made_batch_order(const float* mask, int64_t B, int64_t T, int32_t* order, void* stream);
 
 /* Row kernels of the backward pass (all parameter gradients are ACCUMULATED into f32 buffers the caller zeroes once per step).
  *

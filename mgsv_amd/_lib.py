@@ -67,7 +67,7 @@ class MadeAttnArgs(C.Structure):
                 ("key_mask", vp), ("q_mask", vp),
                 ("scale", f32), ("_pad", i32),
                 ("q_skip_mask", vp),
-                ("lse", vp), ("drop", MadeDropout)]
+                ("lse", vp), ("drop", MadeDropout), ("batch_order", vp)]
 
 
 class MadeAttnBwdArgs(C.Structure):
@@ -76,7 +76,8 @@ class MadeAttnBwdArgs(C.Structure):
                 ("B", i64), ("H", i64), ("Lq", i64), ("Lk", i64),
                 ("q_bs", i64), ("ldq", i64), ("k_bs", i64), ("ldk", i64), ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("ldo", i64),
                 ("do_bs", i64), ("lddo", i64), ("dq_bs", i64), ("lddq", i64), ("dk_bs", i64), ("lddk", i64), ("dv_bs", i64), ("lddv", i64),
-                ("key_mask", vp), ("q_skip_mask", vp), ("scale", f32), ("_pad", i32), ("drop", MadeDropout)]
+                ("key_mask", vp), ("q_skip_mask", vp), ("scale", f32), ("_pad", i32), ("drop", MadeDropout),
+                ("batch_order", vp)]
 
 
 class MadeWideAttnArgs(C.Structure):
@@ -148,6 +149,7 @@ SIGNATURES = {
     "made_repack": (C.c_int, [vp, i32, i64, vp]),
     "made_row_groups": (C.c_int, [vp, i64, vp, vp]),
     "made_row_index": (C.c_int, [vp, i64, vp, vp, vp]),
+    "made_batch_order": (C.c_int, [vp, i64, i64, vp, vp]),
     "made_recall_ranks": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp]),
     "made_span_iou": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
     const int64_t pair = (int64_t)(blockIdx.x & 7) + 8 * (int64_t)((blockIdx.x >> 3) / qtiles);
     if (pair >= a.B * a.H) return;
     const int qt = (int)((blockIdx.x >> 3) % qtiles);
-    const int64_t h = pair % a.H, b = pair / a.H;
+    const int64_t h = pair % a.H;
+    const int64_t b = a.batch_order ? (int64_t)a.batch_order[pair / a.H] : pair / a.H;   // issue order: longest sample first
     const int64_t q0 = (int64_t)qt * BQ + wave * 32;
     bool wave_active = q0 < a.Lq;
     if (a.q_skip_mask) {

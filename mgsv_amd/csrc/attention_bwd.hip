@@ -97,7 +97,8 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
     const int64_t pair = (int64_t)(blockIdx.x & 7) + 8 * (int64_t)((blockIdx.x >> 3) / qtiles);
     if (pair >= a.B * a.H) return;
     const int qt = (int)((blockIdx.x >> 3) % qtiles);
-    const int64_t h = pair % a.H, b = pair / a.H;
+    const int64_t h = pair % a.H;
+    const int64_t b = a.batch_order ? (int64_t)a.batch_order[pair / a.H] : pair / a.H;   // issue order: longest sample first
     const int64_t q0 = (int64_t)qt * BQ + wave * 32;
     const int64_t q = q0 + r;
     const int64_t qc = q < a.Lq ? q : a.Lq - 1;
@@ -333,7 +334,8 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
     const int64_t pair = (int64_t)(blockIdx.x & 7) + 8 * (int64_t)((blockIdx.x >> 3) / ktiles);      // pair p -> XCD p % 8 (see dq)
     if (pair >= a.B * a.H) return;
     const int kt_blk = (int)((blockIdx.x >> 3) % ktiles);
-    const int64_t h = pair % a.H, b = pair / a.H;
+    const int64_t h = pair % a.H;
+    const int64_t b = a.batch_order ? (int64_t)a.batch_order[pair / a.H] : pair / a.H;   // issue order: longest sample first
     const int64_t key = (int64_t)kt_blk * BK + wave * 32 + r;
     const int64_t keyc = key < a.Lk ? key : a.Lk - 1;
     const float* maskg = a.key_mask ? a.key_mask + b * a.Lk : nullptr;

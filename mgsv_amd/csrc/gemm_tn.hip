@@ -356,7 +356,36 @@ __global__ __launch_bounds__(1024) void row_index_kernel(const float* mask, int6
     if (threadIdx.x == 0) n_rows[0] = total;
     for (int64_t i = total + threadIdx.x; i < M; i += 1024) row_index[i] = lastv;
 }
+
+// valid length of every sample (one wave per sample, ballots), then rank by (length descending, index ascending)
+__global__ __launch_bounds__(1024) void batch_order_kernel(const float* mask, int B, int64_t T, int32_t* order) {
+    __shared__ int len[8192];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 16) {
+        const float* m = mask + (int64_t)b * T;
+        int cnt = 0;
+        for (int64_t i = lane; i - lane < T; i += 64) cnt += __popcll(__ballot(i < T && m[i] != 0.f));
+        if (lane == 0) len[b] = cnt;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        const int mine = len[b];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) {
+            const int l = len[j];
+            rank += (l > mine || (l == mine && j < b)) ? 1 : 0;
+        }
+        order[rank] = b;
+    }
+}
 }  // namespace
+
+extern "C" int made_batch_order(const float* mask, int64_t B, int64_t T, int32_t* order, void* stream) {
+    MADE_REQUIRE(mask && order && B > 0 && T > 0, "made_batch_order: bad arguments");
+    MADE_UNSUPPORTED(B <= 8192, "made_batch_order: B=%lld exceeds the single-workgroup table (8192)", (long long)B);
+    hipLaunchKernelGGL(batch_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, (int)B, T, order);
+    return made_check_launch("made_batch_order");
+}
 
 extern "C" int made_row_index(const float* mask, int64_t M, int32_t* row_index, int32_t* n_rows, void* stream) {
     MADE_REQUIRE(mask && row_index && n_rows && M > 0, "made_row_index: bad arguments");

@@ -283,12 +283,18 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
     const int width = Q < G ? Q : G;
     const int bg = 1 - fg;
     const int l = blockIdx.x;
+    // grid.y slices the samples of the contrastive term (its rows cost a pass over Dc each); slice 0 also writes the span / label
+    // gradients.  Every slice rebuilds the (cheap) matched flags of the whole layer.
+    const int slice = blockIdx.y, nslice = gridDim.y;
     const float up = upstream ? upstream[0] : 1.f;
     const float* lg = logits + (int64_t)l * B * Q * 2;
     const float* sp = spans + (int64_t)l * B * Q * 2;
     float* dlg = dlogits + (int64_t)l * B * Q * ldo;
     float* dsp = dspans + (int64_t)l * B * Q * ldo;
-    for (int i = tid; i < B * Q; i += CRIT_THREADS) { matched[i] = 0; dsp[ldo * i] = 0.f; dsp[ldo * i + 1] = 0.f; }
+    for (int i = tid; i < B * Q; i += CRIT_THREADS) {
+        matched[i] = 0;
+        if (slice == 0) { dsp[ldo * i] = 0.f; dsp[ldo * i + 1] = 0.f; }
+    }
     __syncthreads();
     float npairs = 0.f;
     for (int i = tid; i < B * width; i += CRIT_THREADS) {
@@ -301,6 +307,8 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
         int s = l * B + b;
         if (slot < count[s]) {
             int q = (int)pred_idx[(int64_t)s * width + slot];
+            matched[b * Q + q] = 1;
+            if (slice != 0) continue;
             int g = kth_kept(targets + (int64_t)b * G * 2, G, (int)tgt_idx[(int64_t)s * width + slot]);
             float pc = sp[(b * Q + q) * 2], pw = sp[(b * Q + q) * 2 + 1];
             float tc = targets[((int64_t)b * G + g) * 2], tw = targets[((int64_t)b * G + g) * 2 + 1];
@@ -330,12 +338,11 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
             if (through_sigmoid) { dc *= pc * (1.f - pc); dw *= pw * (1.f - pw); }   // pred_spans = sigmoid(z): gradient w.r.t. z
             dsp[(b * Q + q) * ldo] = dc;
             dsp[(b * Q + q) * ldo + 1] = dw;
-            matched[b * Q + q] = 1;
         }
     }
     __syncthreads();
     // weighted NLL, plain mean over B*Q
-    for (int i = tid; i < B * Q; i += CRIT_THREADS) {
+    for (int i = tid; i < B * Q && slice == 0; i += CRIT_THREADS) {
         int cls = matched[i] ? fg : bg;
         float l0 = lg[i * 2], l1 = lg[i * 2 + 1];
         float mx = fmaxf(l0, l1);
@@ -346,8 +353,9 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
         dlg[i * ldo + 1] = w * (p1 - (cls == 1 ? 1.f : 0.f));
     }
     if (proj_q && vid_sum && dproj_q && dvid_sum) {
-        for (int i = wave; i < B * Q; i += CRIT_THREADS / 64) {
-            int b = i / Q;
+        const int nrow = ((B - slice + nslice - 1) / nslice) * Q;      // rows of the samples b = slice, slice + nslice, ...
+        for (int j = wave; j < nrow; j += CRIT_THREADS / 64) {
+            const int b = slice + (j / Q) * nslice, i = b * Q + j % Q;
             const float* pq = proj_q + ((int64_t)l * B * Q + i) * Dc;
             const float* vs = vid_sum + (int64_t)b * Dc;
             float d = 0.f;
@@ -357,8 +365,8 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_bwd_kernel(const float
         }
         __syncthreads();
         const float wc = up * weights[4] / ((float)B * temperature);
-        for (int i = wave; i < B * Q; i += CRIT_THREADS / 64) {
-            int b = i / Q;
+        for (int j = wave; j < nrow; j += CRIT_THREADS / 64) {
+            const int b = slice + (j / Q) * nslice, i = b * Q + j % Q;
             float mx = -INFINITY, npos = 0.f;
             for (int q = 0; q < Q; ++q) { mx = fmaxf(mx, lgt[b * Q + q]); npos += matched[b * Q + q] ? 1.f : 0.f; }
             float se = 0.f;
@@ -424,7 +432,8 @@ extern "C" int made_set_criterion_bwd(const float* pred_logits, const float* pre
                  "made_set_criterion_bwd: null pointer");
     MADE_REQUIRE(n_layers >= 1 && B >= 1 && Q >= 1 && G >= 1, "made_set_criterion_bwd: bad dims");
     MADE_UNSUPPORTED(n_layers <= 65535 && B * Q <= CRIT_MAX_BQ, "made_set_criterion_bwd: B*Q=%lld exceeds %d", (long long)(B * Q), CRIT_MAX_BQ);
-    hipLaunchKernelGGL(criterion_bwd_kernel, dim3((unsigned)n_layers), dim3(CRIT_THREADS), 0, (hipStream_t)stream, pred_logits, pred_spans,
+    const unsigned nslice = (proj_queries && vid_sum && d_proj_queries && d_vid_sum) ? (unsigned)(B < 16 ? B : 16) : 1u;
+    hipLaunchKernelGGL(criterion_bwd_kernel, dim3((unsigned)n_layers, nslice), dim3(CRIT_THREADS), 0, (hipStream_t)stream, pred_logits, pred_spans,
                        targets, pred_idx, tgt_idx, count, proj_queries, vid_sum, empty_weight, (int)B, (int)Q, (int)G, (int)Dc,
                        (int)fg_label, temperature, weights, upstream, d_logits, d_spans, (int)(ld_out > 0 ? ld_out : 2), (int)through_sigmoid,
                        d_proj_queries, d_vid_sum);

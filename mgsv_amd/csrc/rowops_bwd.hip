@@ -33,17 +33,22 @@ __device__ __forceinline__ bool keep_at(const MadeDropout& d, uint32_t thr, uint
     return (made_rng_mix(d.seed, d.site, idx) >> 8) >= thr;
 }
 
-// combine per-wave column partials through LDS and add them to a global f32 vector
-template <int NV>
-__device__ __forceinline__ void flush_cols(float* __restrict__ dst, const f32x4* acc, int D, int lane, int wave, float* sm /* [4][NV*256] */) {
+// combine per-wave column partials through LDS and add them to a global f32 vector.  Every workgroup ends with one atomic per
+// column on the SAME D addresses, and same-address atomics serialise in L2: the kernels that flush are launched with few, large
+// (16-wave) workgroups when there are many rows
+template <int NV, int NW = 4>
+__device__ __forceinline__ void flush_cols(float* __restrict__ dst, const f32x4* acc, int D, int lane, int wave, float* sm /* [NW][NV*256] */) {
     if (dst == nullptr) return;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) sm[wave * (NV * 256) + (i * WAVE + lane) * 4 + j] = acc[i][j];
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += RT) {
-        const float s = (sm[c] + sm[NV * 256 + c]) + (sm[2 * NV * 256 + c] + sm[3 * NV * 256 + c]);
+    for (int c = threadIdx.x; c < D; c += NW * 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4)
+            s += (sm[w * (NV * 256) + c] + sm[(w + 1) * (NV * 256) + c]) + (sm[(w + 2) * (NV * 256) + c] + sm[(w + 3) * (NV * 256) + c]);
         unsafeAtomicAdd(dst + c, s);
     }
     __syncthreads();
@@ -63,9 +68,9 @@ struct LnBwdArgs {
     int64_t rows; int D; float eps; const float* row_skip;
 };
 
-template <int NV>
-__global__ __launch_bounds__(RT) void layernorm_bwd_kernel(const LnBwdArgs a) {
-    __shared__ float sm[4 * NV * 256];
+template <int NV, int NW>
+__global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs a) {
+    __shared__ float sm[NW * NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[NV], db[NV];
 #pragma unroll
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(RT) void layernorm_bwd_kernel(const LnBwdArgs a) {
     const uint32_t thr = made_drop_threshold(a.drop.p);
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const int D = a.D;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < a.rows; row += (int64_t)gridDim.x * NW) {
         if (a.row_skip && a.row_skip[row] == 0.f) continue;   // padded token: nothing read, nothing written (wave-uniform)
         const bool skip = false;
         const int64_t xoff = a.rpb > 0 ? (row / a.rpb) * a.xbs + (row % a.rpb) * a.ldx : row * a.ldx;
@@ -148,8 +153,8 @@ __global__ __launch_bounds__(RT) void layernorm_bwd_kernel(const LnBwdArgs a) {
             }
         }
     }
-    flush_cols<NV>(a.dgamma, dg, D, lane, wave, sm);
-    flush_cols<NV>(a.dbeta, db, D, lane, wave, sm);
+    flush_cols<NV, NW>(a.dgamma, dg, D, lane, wave, sm);
+    flush_cols<NV, NW>(a.dbeta, db, D, lane, wave, sm);
 }
 
 // ---- clip-level vector backward: vec = normalize(masked mean(local)) --------------------------------
@@ -326,9 +331,9 @@ struct XtailBwdArgs {
     int64_t rows, Nv; int D; float eps;
 };
 
-template <int NV>
-__global__ __launch_bounds__(RT) void xpool_tail_bwd_kernel(const XtailBwdArgs a) {
-    __shared__ float sm[4 * NV * 256];
+template <int NV, int NW>
+__global__ __launch_bounds__(NW * 64) void xpool_tail_bwd_kernel(const XtailBwdArgs a) {
+    __shared__ float sm[NW * NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = a.D;
     f32x4 dg[NV], db[NV];
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(RT) void xpool_tail_bwd_kernel(const XtailBwdArgs a
         for (int j = 0; j < 4; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
     const uint32_t thr = made_drop_threshold(a.drop.p);
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < a.rows; row += (int64_t)gridDim.x * NW) {
         const int64_t m = row / a.Nv, n = row % a.Nv;
         f32x4 xh[NV], pv[NV], vd[NV];
         float sum = 0.f;
@@ -431,8 +436,8 @@ __global__ __launch_bounds__(RT) void xpool_tail_bwd_kernel(const XtailBwdArgs a
             }
         }
     }
-    flush_cols<NV>(a.dgamma, dg, D, lane, wave, sm);
-    flush_cols<NV>(a.dbeta, db, D, lane, wave, sm);
+    flush_cols<NV, NW>(a.dgamma, dg, D, lane, wave, sm);
+    flush_cols<NV, NW>(a.dbeta, db, D, lane, wave, sm);
 }
 
 // ---- softmax backward of the wide-head attention (scores materialised: [rows, L] with few rows per batch) ---------
@@ -579,9 +584,15 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
     if (drop) a.drop = *drop;
     a.drop_ld = drop_ld > 0 ? drop_ld : D;
     a.dgamma = dgamma; a.dbeta = dbeta; a.rows = rows; a.D = (int)D; a.eps = eps; a.row_skip = row_skip;
-    int64_t nb = (rows + 3) / 4;
-    if (nb > 1024) nb = 1024;                                   // each workgroup flushes 2*D atomics
-    DISPATCH_NVB(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a));
+    if (rows > 256 && D <= 1024) {                              // each workgroup flushes 2*D same-address atomics: few, large workgroups
+        int64_t nb = (rows + 15) / 16;
+        if (nb > 512) nb = 512;
+        DISPATCH_NVB(D, hipLaunchKernelGGL((layernorm_bwd_kernel<(NV > 4 ? 4 : NV), 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a));
+    } else {
+        int64_t nb = (rows + 3) / 4;
+        if (nb > 1024) nb = 1024;
+        DISPATCH_NVB(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 4>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a));
+    }
     return made_check_launch("made_layernorm_bwd");
 }
 
@@ -639,9 +650,15 @@ extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, 
     if (drop) a.drop = *drop;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dvideo = dvideo; a.lddv = ld_dvideo;
     a.rows = rows; a.Nv = Nv; a.D = (int)D; a.eps = eps;
-    int64_t nb = (rows + 3) / 4;
-    if (nb > 1024) nb = 1024;
-    DISPATCH_NVB(D, hipLaunchKernelGGL((xpool_tail_bwd_kernel<NV>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a));
+    if (rows > 256 && D <= 1024) {
+        int64_t nb = (rows + 15) / 16;
+        if (nb > 512) nb = 512;
+        DISPATCH_NVB(D, hipLaunchKernelGGL((xpool_tail_bwd_kernel<(NV > 4 ? 4 : NV), 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a));
+    } else {
+        int64_t nb = (rows + 3) / 4;
+        if (nb > 1024) nb = 1024;
+        DISPATCH_NVB(D, hipLaunchKernelGGL((xpool_tail_bwd_kernel<NV, 4>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a));
+    }
     return made_check_launch("made_xpool_tail_bwd");
 }
 

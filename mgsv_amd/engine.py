@@ -221,6 +221,7 @@ class MadeEngine:
             # row gather (valid-token lists) of the video / audio / fused sequences
             rows_v=(E(B * Tv, dtype=torch.int32), E(1, dtype=torch.int32)), rows_a=(E(B * Ta, dtype=torch.int32), E(1, dtype=torch.int32)),
             rows_f=(E(B * L, dtype=torch.int32), E(1, dtype=torch.int32)),
+            order_v=E(B, dtype=torch.int32), order_a=E(B, dtype=torch.int32), order_f=E(B, dtype=torch.int32),
         )
         if c.contrastive_align_loss:
             Dc = c.contrastive_hdim
@@ -237,7 +238,8 @@ class MadeEngine:
 
     # ------------------------------------------------------------------ building blocks
     def _mha_block(self, x: Tensor, B: int, T: int, w_in: Tensor, b_in: Tensor, key_mask: Optional[Tensor],
-                   ws: Dict[str, Tensor], H: int, pos: Optional[Tensor] = None, skip: Optional[Tensor] = None, rows=None) -> Tensor:
+                   ws: Dict[str, Tensor], H: int, pos: Optional[Tensor] = None, skip: Optional[Tensor] = None, rows=None,
+                   order: Optional[Tensor] = None) -> Tensor:
         """packed in-proj -> flash attention; x [B*T, D]; q,k from (x + pos), v from x; returns att [B*T, D]."""
         D = self.cfg.D
         qkv = ws["qkv"][:B * T]
@@ -249,10 +251,10 @@ class MadeEngine:
         q3 = qkv.view(B, T, 3 * D)
         att = ws["att"][:B * T]
         ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), H, key_mask=key_mask,
-                      q_skip_mask=key_mask if skip is not None else None)
+                      q_skip_mask=key_mask if skip is not None else None, order=order)
         return att
 
-    def _encode(self, feats: Tensor, mask: Tensor, which: str, wsall: Dict[str, Tensor], row_off: int, rows=None) -> None:
+    def _encode(self, feats: Tensor, mask: Tensor, which: str, wsall: Dict[str, Tensor], row_off: int, rows=None, order=None) -> None:
         """reference model/model_Base.py:544-617 -> writes fus[:, row_off:row_off+T] and mean/normalised vector."""
         c, P = self.cfg, self.P
         ws = wsall if which == "audio" else {**wsall, **{k[2:]: v for k, v in wsall.items() if k.startswith("v_")}}
@@ -277,7 +279,7 @@ class MadeEngine:
         for l in range(depth):
             p = f"{mod}.layers.{l}"
             x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x1"][:nrow], row_skip=mflat)
-            att = self._mha_block(x1, B, T, P[p + ".in.w"], P[p + ".in.b"], mask, ws, c.SA_temporal_heads, skip=mflat, rows=rows)
+            att = self._mha_block(x1, B, T, P[p + ".in.w"], P[p + ".in.b"], mask, ws, c.SA_temporal_heads, skip=mflat, rows=rows, order=order)
             x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=ws["x2"][:nrow], rows=rows)
             x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3"][:nrow], row_skip=mflat)
             h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=ws["ffn"][:nrow, :c.temporal_ffn_dim], rows=rows)
@@ -393,8 +395,11 @@ class MadeEngine:
                 fus_mask.copy_(sm)
             pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
             rows_f = ops.row_index(fus_mask, out=ws["rows_f"])
-            self._encode(frame_feats.contiguous(), fm, "video", ws, 0, rows=ops.row_index(fm, out=ws["rows_v"]))
-        self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv, rows=ops.row_index(sm, out=ws["rows_a"]))
+            order_f = ops.batch_order(fus_mask, out=ws["order_f"])       # attention workgroups: longest sample first
+            self._encode(frame_feats.contiguous(), fm, "video", ws, 0, rows=ops.row_index(fm, out=ws["rows_v"]),
+                         order=ops.batch_order(fm, out=ws["order_v"]))
+        self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv, rows=ops.row_index(sm, out=ws["rows_a"]),
+                     order=ops.batch_order(sm, out=ws["order_a"]))
         cur.wait_stream(side)
         if concat:
             frame, seg = fus[:, :Tv], fus[:, Tv:]
@@ -428,7 +433,7 @@ class MadeEngine:
         ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)      # layer 0: src + pos (no norm)
         for l in range(c.detr_enc_layers):
             p = f"detr_transformer.encoder.layers.{l}"
-            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip, rows=rows_f)
+            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip, rows=rows_f, order=order_f)
             x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows], rows=rows_f)
             s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x2"][:rows], row_skip=fskip)
             h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward], rows=rows_f)

@@ -203,6 +203,17 @@ def row_index(mask: Tensor, out=None):
     return idx, n
 
 
+def batch_order(mask: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """int32 [B]: samples of a [B, T] token mask by descending valid length (made_batch_order): `order=` of attention / _bwd."""
+    assert mask.dim() == 2
+    B, T = mask.shape
+    if out is None:
+        out = torch.empty(B, device=mask.device, dtype=torch.int32)
+    assert out.dtype == torch.int32 and out.numel() == B
+    check(lib().made_batch_order(_p(_f32(mask.contiguous(), "mask")), B, T, _p(out), _stream()), "made_batch_order")
+    return out
+
+
 def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, split_k: int, *, A2: Optional[Tensor] = None,
                   a2_row_mod: int = 0, act: int = ACT_NONE, R: Optional[Tensor] = None, r_row_mod: int = 0,
                   out: Optional[Tensor] = None, ln1=None, ln1_out: Optional[Tensor] = None, ln2=None,
@@ -249,7 +260,8 @@ def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, spli
 
 def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,
               q_mask: Optional[Tensor] = None, scale: Optional[float] = None, Lk: Optional[int] = None,
-              q_skip_mask: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop=None) -> Tensor:
+              q_skip_mask: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop=None,
+              order: Optional[Tensor] = None) -> Tensor:
     """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K / V [B,Lk,H*hd], O [B,Lq,H*hd]
     (any batch/row strides, unit inner stride).  Lk defaults to K.shape[1].
     Training: lse [B,H,Lq] f32 receives the log-sum-exp, drop = (seed, site, p) drops attention weights."""
@@ -270,6 +282,9 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
     a.q_mask = _p(_f32(q_mask, "q_mask"))
     a.q_skip_mask = _p(_f32(q_skip_mask, "q_skip_mask"))
     a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
+    if order is not None:                       # issue order of the batch (batch_order): longest sample first
+        assert order.dtype == torch.int32 and order.numel() == B and order.is_contiguous()
+        a.batch_order = _p(order)
     if lse is not None:
         assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * H * Lq
         a.lse = _p(lse)

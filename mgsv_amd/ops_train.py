@@ -87,7 +87,7 @@ def dropout_desc(seed: int, site: int, p: float) -> MadeDropout:
 
 def attention_bwd(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, dO: Tensor, dQ: Tensor, dK: Tensor, dV: Tensor, lse: Tensor,
                   delta: Tensor, H: int, *, key_mask: Optional[Tensor] = None, q_skip_mask: Optional[Tensor] = None,
-                  scale: Optional[float] = None, drop=None) -> None:
+                  scale: Optional[float] = None, drop=None, order: Optional[Tensor] = None) -> None:
     """Gradients of ops.attention (made_attention_bwd).  All [B, L, H*hd] views with unit inner stride."""
     import math
     for t in (Q, K, V, O, dO, dQ, dK, dV):
@@ -105,6 +105,9 @@ def attention_bwd(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, dO: Tensor, dQ: Te
     a.dq_bs, a.lddq, a.dk_bs, a.lddk, a.dv_bs, a.lddv = dQ.stride(0), dQ.stride(1), dK.stride(0), dK.stride(1), dV.stride(0), dV.stride(1)
     a.key_mask = _p(_f32(key_mask, "key_mask"))
     a.q_skip_mask = _p(_f32(q_skip_mask, "q_skip_mask"))
+    if order is not None:
+        assert order.dtype == torch.int32 and order.numel() == a.B and order.is_contiguous()
+        a.batch_order = _p(order)
     a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
     if drop is not None and drop[2] > 0.0:
         a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])

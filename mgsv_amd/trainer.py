@@ -336,7 +336,8 @@ class MadeTrainer(MadeEngine):
                       c_g1=E(ra, D), c_g2=E(ra, D), c_g3=E(ra, D), c_gf=E(ra, c.ca_ffn_dim), c_gq=E(ra, inner), c_gkv=E(rv, 2 * inner),
                       c_gatt=E(ra, inner), c_delta=E(B * c.ca_heads * Ta, dtype=f32), c_dseg=E(ra, D), c_dframe=E(rv, D), c_gnc=E(rv, D))
         i32 = torch.int32
-        ws.update(rows_v=(E(B * Tv, dtype=i32), E(1, dtype=i32)), rows_a=(E(B * Ta, dtype=i32), E(1, dtype=i32)), rows_f=(E(rows, dtype=i32), E(1, dtype=i32)))
+        ws.update(rows_v=(E(B * Tv, dtype=i32), E(1, dtype=i32)), rows_a=(E(B * Ta, dtype=i32), E(1, dtype=i32)), rows_f=(E(rows, dtype=i32), E(1, dtype=i32)),
+                  order_v=E(B, dtype=i32), order_a=E(B, dtype=i32), order_f=E(B, dtype=i32))
         # decoder: saved activations and per-layer output gradients as [nd, ...] stacks (uniform layer stride), so the weight
         # gradients of all 6 layers are a handful of layer-batched products after the loop instead of 60 tiny launches inside it
         BQ = B * Q
@@ -385,6 +386,10 @@ class MadeTrainer(MadeEngine):
         self._rows = {fus_mask.data_ptr(): ops.row_index(fus_mask, out=tw["rows_f"]), fm.data_ptr(): ops.row_index(fm, out=tw["rows_v"]),
                       sm.data_ptr(): ops.row_index(sm, out=tw["rows_a"])}
         rows_f = self._rows[fus_mask.data_ptr()]
+        # issue order of the attention workgroups: longest sample first (a padded batch otherwise waits on whichever long sample
+        # happens to start last)
+        self._order = {fus_mask.data_ptr(): ops.batch_order(fus_mask, out=tw["order_f"]), fm.data_ptr(): ops.batch_order(fm, out=tw["order_v"]),
+                       sm.data_ptr(): ops.batch_order(sm, out=tw["order_a"])}
         # the video branch (B*T_v rows: launches far smaller than the chip) runs on a second HIP stream beside the audio branch;
         # so does the X-Pool / similarity / retrieval-loss branch beside the DETR stack (joined at the end of the step)
         cur, side = torch.cuda.current_stream(), self._side_stream()
@@ -437,7 +442,8 @@ class MadeTrainer(MadeEngine):
             q3 = qkv.view(B, L, 3 * D)
             att = tw[e + ".att"]
             ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, L, D), H, key_mask=fus_mask,
-                          q_skip_mask=fus_mask, lse=tw[e + ".lse"], drop=self._drop(f"enc.{l}" + ".attn", pd))
+                          q_skip_mask=fus_mask, lse=tw[e + ".lse"], drop=self._drop(f"enc.{l}" + ".attn", pd),
+                          order=self._order[fus_mask.data_ptr()])
             x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=tw[e + ".x"], rows=rows_f,
                            drop=self._drop(f"enc.{l}" + ".drop1", pd))
             s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[e + ".s1"], row_skip=fskip)
@@ -555,7 +561,7 @@ class MadeTrainer(MadeEngine):
             q3 = qkv.view(B, T, 3 * D)
             att = tw[t + ".att"]
             ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), Hh, key_mask=mask, q_skip_mask=mask,
-                          lse=tw[t + ".lse"], drop=self._drop(f"{name}.{l}.attn", pt))
+                          lse=tw[t + ".lse"], drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask.data_ptr()])
             x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=tw[t + ".x2"], rows=rws)
             x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[t + ".x3"], row_skip=mflat)
             h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=tw[t + ".h"], Zout=tw[t + ".z1"], rows=rws,
@@ -605,7 +611,7 @@ class MadeTrainer(MadeEngine):
         kv = ops.linear(nc, P["ca.kv.w"], None, out=tw["c_kv"], rows=rv)
         kv3 = kv.view(B, Tv, 2 * inner)
         ops.attention(q.view(B, Ta, inner), kv3[:, :, :inner], kv3[:, :, inner:], tw["c_att"].view(B, Ta, inner), Hc, key_mask=fm, q_mask=sm,
-                      q_skip_mask=sm, scale=c.ca_dim_head ** -0.5, lse=tw["c_lse"])
+                      q_skip_mask=sm, scale=c.ca_dim_head ** -0.5, lse=tw["c_lse"], order=self._order[sm.data_ptr()])
         ax = ops.linear(tw["c_att"], P["ca.out.w"], P["ca.out.b"], R=x, out=tw["c_ax"], rows=ra, drop=self._drop("ca.attn_out", pt))
         nf = ops.layernorm(ax, P["ca.lnf.g"], P["ca.lnf.b"], out=tw["c_nf"], row_skip=sflat)
         h = ops.linear(nf, P["ca.ff1.w"], P["ca.ff1.b"], act=ops.ACT_GELU, out=tw["c_h"], Zout=tw["c_z1"], rows=ra, drop=self._drop("ca.ffn_act", pt))
@@ -632,7 +638,7 @@ class MadeTrainer(MadeEngine):
         kv3, gkv3 = kv.view(B, Tv, 2 * inner), tw["c_gkv"].view(B, Tv, 2 * inner)
         tr.attention_bwd(q.view(B, Ta, inner), kv3[:, :, :inner], kv3[:, :, inner:], tw["c_att"].view(B, Ta, inner), datt.view(B, Ta, inner),
                          tw["c_gq"].view(B, Ta, inner), gkv3[:, :, :inner], gkv3[:, :, inner:], tw["c_lse"], tw["c_delta"], Hc,
-                         key_mask=fm, q_skip_mask=sm, scale=c.ca_dim_head ** -0.5)
+                         key_mask=fm, q_skip_mask=sm, scale=c.ca_dim_head ** -0.5, order=self._order[sm.data_ptr()])
         dnx = self._lin_bwd(tw["c_gq"], tw["c_nx"], "ca.q", dx_out=g2, row_mask=sflat)
         tr.layernorm_bwd(seg, P["ca.lnq.g"], dnx, tw["c_dseg"], dgamma=G["ca.lnq.g"], dbeta=G["ca.lnq.b"], add=g1, row_skip=sflat)
         dnc = self._lin_bwd(tw["c_gkv"], tw["c_nc"], "ca.kv", dx_out=tw["c_gnc"], row_mask=fflat)
@@ -847,7 +853,8 @@ class MadeTrainer(MadeEngine):
             q3, gq3 = qkv.view(B, L, 3 * D), gq.view(B, L, 3 * D)
             tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[e + ".att"].view(B, L, D), datt.view(B, L, D),
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[e + ".lse"], tw["e_delta"], H,
-                             key_mask=fus_mask, q_skip_mask=fus_mask, drop=self._drop(f"enc.{l}" + ".attn", pd))
+                             key_mask=fus_mask, q_skip_mask=fus_mask, drop=self._drop(f"enc.{l}" + ".attn", pd),
+                             order=self._order[fus_mask.data_ptr()])
             gW, gb = G[p + ".in.w"], G[p + ".in.b"]
             tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], rows=self._rw(fskip))
             tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], rows=self._rw(fskip))
@@ -963,7 +970,7 @@ class MadeTrainer(MadeEngine):
             q3, gq3 = qkv.view(B, T, 3 * D), gq.view(B, T, 3 * D)
             tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[t + ".att"].view(B, T, D), datt.view(B, T, D),
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[t + ".lse"], tw[tag + ".delta"], Hh,
-                             key_mask=mask, q_skip_mask=mask, drop=self._drop(f"{name}.{l}.attn", pt))
+                             key_mask=mask, q_skip_mask=mask, drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask.data_ptr()])
             dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3, row_mask=mflat, skip=mflat, R=g1)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
         xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)

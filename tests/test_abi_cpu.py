@@ -38,8 +38,9 @@ def test_struct_layout_matches_header():
     src = textwrap.dedent('''
         #include <stdio.h>
         #include "made_hip.h"
-        int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu", sizeof(MadeLinearSeg), sizeof(MadeLinearArgs), sizeof(MadeAttnArgs),
-                               sizeof(MadeWideAttnArgs), sizeof(MadeFinishArgs), sizeof(MadeDropout), sizeof(MadeGemmTNArgs)); return 0; }
+        int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", sizeof(MadeLinearSeg), sizeof(MadeLinearArgs), sizeof(MadeAttnArgs),
+                               sizeof(MadeWideAttnArgs), sizeof(MadeFinishArgs), sizeof(MadeDropout), sizeof(MadeGemmTNArgs),
+                               sizeof(MadeAttnBwdArgs), sizeof(MadeAdamGroup), sizeof(MadeRepackDesc)); return 0; }
     ''')
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "s.c")
@@ -48,7 +49,8 @@ def test_struct_layout_matches_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [C.sizeof(x) for x in (_lib.MadeLinearSeg, _lib.MadeLinearArgs, _lib.MadeAttnArgs, _lib.MadeWideAttnArgs,
-                                           _lib.MadeFinishArgs, _lib.MadeDropout, _lib.MadeGemmTNArgs)]
+                                           _lib.MadeFinishArgs, _lib.MadeDropout, _lib.MadeGemmTNArgs, _lib.MadeAttnBwdArgs,
+                                           _lib.MadeAdamGroup, _lib.MadeRepackDesc)]
 
 
 def test_dropout_rng_header_matches_numpy_restatement():

@@ -243,6 +243,29 @@ def test_attention_qmask_nomask_and_all_masked(dev, mode):
     assert torch.isnan(Od[1].float()).all() and not torch.isnan(Od[0].float()).any()
 
 
+def test_batch_order_and_ordered_attention_bit_identical(dev):
+    """made_batch_order ranks samples by valid length (descending, ties by index); passing it to made_attention changes only
+    the order in which workgroups are issued, so the outputs are bit-identical."""
+    B, H, hd, L = 13, 8, 64, 150
+    D = H * hd
+    lens = torch.tensor([150, 3, 77, 77, 1, 149, 20, 150, 64, 65, 128, 129, 77])
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    mask[6, ::2] = 0                                   # non-prefix mask: what counts is the number of valid entries
+    order = ops.batch_order(mask.to(dev))
+    cnt = mask.sum(1).long()
+    expect = sorted(range(B), key=lambda b: (-int(cnt[b]), b))
+    assert order.cpu().tolist() == expect
+    qkv = torch.cat([rnd(B, L, D, seed=s_) for s_ in (1, 2, 3)], -1).to(dev).to(torch.bfloat16)
+    Qd, Kd, Vd = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    O1 = torch.zeros(B, L, D, device=dev, dtype=torch.bfloat16)
+    O2 = torch.zeros_like(O1)
+    md = mask.to(dev)
+    ops.attention(Qd, Kd, Vd, O1, H, key_mask=md, q_skip_mask=md)
+    ops.attention(Qd, Kd, Vd, O2, H, key_mask=md, q_skip_mask=md, order=order)
+    torch.cuda.synchronize()
+    assert torch.equal(O1, O2)
+
+
 def test_attention_online_softmax_rescale(dev):
     """cdna guide rule 26: force the running-max rescale with a late spike in the scores."""
     B, H, hd, Lq, Lk = 1, 1, 64, 32, 256
