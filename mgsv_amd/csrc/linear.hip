@@ -455,9 +455,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
 // chunk of the row it fetches) and undone on the fragment reads, so ds_read_b128 stays conflict-free.
 // One 32 KB stage, two barriers per slab; latency is hidden by running 4 workgroups per CU (about 100
 // VGPRs, 34 KB LDS).  The epilogue streams the tile out in two 64-row halves through the same LDS.
-constexpr int G_STAGE = 2 * BM * KB;                 // 32 KB: A rows then W rows, 128 B each
+
 constexpr int G_CT_LD = BN + 4;
-constexpr int G_LDS = (64 * G_CT_LD * 4 > G_STAGE) ? 64 * G_CT_LD * 4 : G_STAGE;
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
@@ -466,13 +465,22 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 //          vmcnt waits -- for grids of at most one workgroup per CU (the decoder's 64-row Linears), where nothing else
 //          hides the ~2 us a slab takes to arrive.
 // TRAIN: the epilogue carries the training-path options (Zout / gate / dropout); the eval instantiation stays lean.
-template <int NST, bool TRAIN>
-__global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel(const MadeLinearArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NST == 1 ? G_LDS : NST * G_STAGE];
+// BMT = 128: 128 x 128 tiles, waves 2 x 2 (64 x 64 each).
+// BMT = 64 : 64 x 128 tiles, waves 1 x 4 (64 x 32 each), 24 KB of LDS: for grids that would leave the CUs with only one or
+//            two 128-row workgroups each (a padded batch gathered down to its valid rows) -- with NST = 1 the only thing that
+//            hides a slab's latency is the OTHER workgroups of the CU, so twice as many, half as tall, run faster.
+template <int NST, bool TRAIN, int BMT>
+__global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 5 : 4) : 1) void linear_glds_kernel(const MadeLinearArgs a) {
+    constexpr int STAGE = (BMT + BN) * KB;
+    constexpr int NT = BMT == 128 ? 2 : 1;                 // 32-column accumulator tiles per wave
+    constexpr int AP = BMT / 32;                           // 1 KB A pieces per wave per slab
+    constexpr int EROWS = BMT == 128 ? 64 : 32;            // rows per epilogue pass
+    constexpr int CT_BYTES = EROWS * G_CT_LD * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST == 1 ? (CT_BYTES > STAGE ? CT_BYTES : STAGE) : NST * STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BMT == 128 ? wave >> 1 : 0, wn = BMT == 128 ? wave & 1 : wave;
 
     const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
     const int n_tiles = (N + BN - 1) / BN;
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
     // tiles so the n-tiles of one 128-row activation panel hit the same L2 (bijective for any tile count)
     int Mv = M;                                            // row gather (see linear_kernel): only the first ceil(Mv/128) row tiles exist
     if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
-    const int nwg = ((Mv + BM - 1) / BM) * n_tiles;        // live tiles; workgroups are dispatched round-robin over the XCDs in
+    const int nwg = ((Mv + BMT - 1) / BMT) * n_tiles;        // live tiles; workgroups are dispatched round-robin over the XCDs in
     if ((int)blockIdx.x >= nwg) return;                    // blockIdx order, so the first nwg of them spread evenly
     int tile_id;
     {
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
         tile_id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
     }
     const int tile_m = tile_id / n_tiles, tile_n = tile_id % n_tiles;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BMT, n0 = tile_n * BN;
     const int64_t z = blockIdx.z;
 
     int si = 0;
@@ -502,11 +510,11 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
     // rows itself (2 per lane), so the answer is wave-uniform and identical in the 4 waves: no barrier on this path.
     if (a.tile_skip_mask) {
         const int g0 = m0 + lane, g1 = m0 + 64 + lane;
-        const float v0 = g0 < M ? a.tile_skip_mask[g0] : 0.f, v1 = g1 < M ? a.tile_skip_mask[g1] : 0.f;
+        const float v0 = g0 < M ? a.tile_skip_mask[g0] : 0.f, v1 = (BMT == 128 && g1 < M) ? a.tile_skip_mask[g1] : 0.f;
         if (!__any(v0 != 0.f || v1 != 0.f)) {
             if (a.out_row_mask && !seg.transposed && (a.split_k <= 1)) {       // consumers expect zeros in masked rows
                 const int rpb0 = (int)seg.rows_per_batch;
-                for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {
+                for (int idx = tid; idx < BMT * (BN / 8); idx += NTHREADS) {
                     const int row = idx / (BN / 8), c8 = idx % (BN / 8);
                     const int m = m0 + row, n = n0 + c8 * 8;
                     if (m >= M || n >= N) continue;
@@ -527,61 +535,69 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
     const bf16_t* Abase = ((seg.use_a2 && a.A2 && a.a2_replace) ? (const bf16_t*)a.A2 : (const bf16_t*)a.A) + z * a.a_z_stride;
     const int64_t lda = (seg.use_a2 && a.A2 && a.a2_replace) ? a.lda2 : a.lda;
     const bf16_t* Wbase = (const bf16_t*)a.W + z * a.w_z_stride;
-    const bf16_t* pa[4];
+    const bf16_t* pa[AP];
     const bf16_t* pw[4];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int row = 8 * (AP * wave + i) + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gm = m0 + row; gm = gm < Mv ? gm : Mv - 1;        // rows past the edge are fetched from a valid row and never stored
+        if (a.row_index) gm = a.row_index[gm];
+        pa[i] = Abase + (int64_t)gm * lda + chunk * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * (4 * wave + i) + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(row);
-        int gm = m0 + row; gm = gm < Mv ? gm : Mv - 1;        // rows past the edge are fetched from a valid row and never stored
-        if (a.row_index) gm = a.row_index[gm];
         int gn = n0 + row; gn = gn < N ? gn : N - 1;
-        pa[i] = Abase + (int64_t)gm * lda + chunk * 8;
         pw[i] = Wbase + (int64_t)gn * a.ldw + chunk * 8;
     }
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // fragment read offsets: row rr, 16-byte chunk c = 2*ks + hh -> rr*128 + ((c ^ swz(rr)) * 16)
-    int offa[2], offw[2], sa[2], sw[2];
+    int offa[2], offw[NT], sa[2], sw[NT];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int ra = wm * 64 + t * 32 + r, rw = wn * 64 + t * 32 + r;
+        const int ra = wm * 64 + t * 32 + r;
         offa[t] = ra * KB; sa[t] = swz(ra);
-        offw[t] = BM * KB + rw * KB; sw[t] = swz(rw);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int rw = wn * (NT * 32) + t * 32 + r;
+        offw[t] = BMT * KB + rw * KB; sw[t] = swz(rw);
     }
 
     const int nk = K / 64;
     auto issue = [&](int kt, unsigned char* st) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = 4 * wave + i;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(st + piece * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(st + BM * KB + piece * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < AP; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(st + (AP * wave + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(st + BMT * KB + (4 * wave + i) * 1024), 16, 0, 0);
     };
     auto multiply = [&](const unsigned char* st) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[2], fw[2];
+            bf16x8 fa[2], fw[NT];
             const int c = 2 * ks + hh;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                fa[t] = *(const bf16x8*)(st + offa[t] + ((c ^ sa[t]) << 4));
-                fw[t] = *(const bf16x8*)(st + offw[t] + ((c ^ sw[t]) << 4));
-            }
+            for (int t = 0; t < 2; ++t) fa[t] = *(const bf16x8*)(st + offa[t] + ((c ^ sa[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) fw[t] = *(const bf16x8*)(st + offw[t] + ((c ^ sw[t]) << 4));
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fw[nt], acc[mt][nt], 0, 0, 0);
         }
     };
@@ -593,21 +609,22 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
             __syncthreads();                               // all fragment reads done before the stage is overwritten
         }
     } else {
+        static_assert(BMT == 128, "the multi-stage ring counts 8 loads per wave per slab");
         // slab kt lives in stage kt % NST; 8 LDS-DMA loads per wave per slab, so "slab kt landed" == at most 8 newer loads
         // outstanding.  The barrier also proves every wave finished reading stage (kt - 1) % NST, which slab kt + 2 reuses.
         issue(0, lds);
-        if (nk > 1) issue(1, lds + G_STAGE);
+        if (nk > 1) issue(1, lds + STAGE);
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
-            if (kt + 2 < nk) issue(kt + 2, lds + ((kt + 2) % NST) * G_STAGE);
-            multiply(lds + (kt % NST) * G_STAGE);
+            if (kt + 2 < nk) issue(kt + 2, lds + ((kt + 2) % NST) * STAGE);
+            multiply(lds + (kt % NST) * STAGE);
         }
         __syncthreads();                                   // the epilogue reuses the staging LDS
     }
 
-    // ---- epilogue, two 64-row halves through LDS ------------------------------------------------------
+    // ---- epilogue, two passes of EROWS rows through LDS ------------------------------------------------------
     float* Ct = (float*)lds;
     unsigned char* outp = (unsigned char*)seg.out;
     const int64_t out_z = z * seg.out_z_stride;
@@ -625,22 +642,28 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? 4 : 1) void linear_glds_kernel
     const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (m0 + half * 64 >= Mv) break;                   // block-uniform: the decoder's 64-row problems have no second half
-        if (wm == half) {
+        if (m0 + half * EROWS >= Mv) break;                // block-uniform: the decoder's 64-row problems have no second half
+        if constexpr (BMT == 128) {
+            if (wm == half) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        Ct[(mt * 32 + acc_row(e, hh)) * G_CT_LD + wn * 64 + nt * 32 + r] = acc[mt][nt][e];
+                        for (int e = 0; e < 16; ++e)
+                            Ct[(mt * 32 + acc_row(e, hh)) * G_CT_LD + wn * 64 + nt * 32 + r] = acc[mt][nt][e];
+            }
+        } else {                                           // every wave holds rows 0..63 of its 32 columns: pass h = accumulator tile h
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                Ct[acc_row(e, hh) * G_CT_LD + wn * 32 + r] = half == 0 ? acc[0][0][e] : acc[1][0][e];
         }
         __syncthreads();
         if (nvalid > 0) {
 #pragma unroll 2
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < EROWS / 16; ++i) {
                 const int row = (tid >> 4) + 16 * i;
-                const int ml = m0 + half * 64 + row;
+                const int ml = m0 + half * EROWS + row;
                 if (ml >= Mv) break;
                 const int m = a.row_index ? a.row_index[ml] : ml;
                 const float* cp = Ct + row * G_CT_LD + cc * 8;
@@ -795,6 +818,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void linear_skinny_kernel(const MadeLi
 
 }  // namespace
 
+// tuning knob for the micro-benchmarks: MADE_LINEAR_TILE=64|128 forces the tile height of the direct-to-LDS kernel
+static int tile_pref() {
+    static const int v = [] { const char* e = getenv("MADE_LINEAR_TILE"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
     MADE_REQUIRE(args != nullptr, "made_linear: null args");
     const MadeLinearArgs& a = *args;
@@ -863,10 +892,17 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
                 return made_check_launch("made_linear");
             }
             const bool small = tiles * a.batch <= 256;       // at most one workgroup per CU
-            if (small && train) hipLaunchKernelGGL((linear_glds_kernel<3, true>), grid, block, 0, st, a);
-            else if (small) hipLaunchKernelGGL((linear_glds_kernel<3, false>), grid, block, 0, st, a);
-            else if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((linear_glds_kernel<1, false>), grid, block, 0, st, a);
+            // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
+            const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
+            if (small && train) hipLaunchKernelGGL((linear_glds_kernel<3, true, 128>), grid, block, 0, st, a);
+            else if (small) hipLaunchKernelGGL((linear_glds_kernel<3, false, 128>), grid, block, 0, st, a);
+            else if (tile_pref() == 64 || (tile_pref() == 0 && live <= 1280)) {   // fewer than ~4 tall workgroups per CU: 64-row tiles
+                dim3 g((unsigned)(((a.M + 63) / 64) * ((a.N + BN - 1) / BN)), 1, (unsigned)a.batch);
+                if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 64>), g, block, 0, st, a);
+                else hipLaunchKernelGGL((linear_glds_kernel<1, false, 64>), g, block, 0, st, a);
+            }
+            else if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128>), grid, block, 0, st, a);
         }
         else if (a.a_dtype == MADE_F32) hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((linear_kernel<bf16_t, bf16_t>), grid, block, 0, st, a);

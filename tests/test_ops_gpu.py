@@ -52,7 +52,8 @@ def act_ref(x, act):
 
 # ------------------------------------------------------------------------------------ made_linear
 @pytest.mark.parametrize("mode", ["f32", "f32_to_bf16", "bf16"])
-@pytest.mark.parametrize("M,N,K", [(200, 192, 96), (128, 128, 64), (33, 2, 256), (300, 130, 40), (1920, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 96), (128, 128, 64), (33, 2, 256), (300, 130, 40), (1920, 512, 512),
+                                   (9000, 640, 192), (33000, 640, 64)])     # bf16: 64-row-tile and 128-row-tile direct-to-LDS kernels
 @pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU, ops.ACT_QUICKGELU, ops.ACT_SIGMOID])
 def test_linear_basic(dev, mode, M, N, K, act):
     if act not in (ops.ACT_NONE, ops.ACT_RELU) and (M, N, K) != (200, 192, 96):

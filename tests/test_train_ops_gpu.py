@@ -387,13 +387,17 @@ def test_set_criterion_bwd(T, Q, G):
         assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-3), name
 
 
+@pytest.mark.parametrize("Bn,N", [(9, 384), (60, 640), (200, 1280)])     # skinny / 64-row-tile / 128-row-tile kernels in bf16
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_row_gather_linear_and_gemm_tn_bit_identical_on_valid_rows(T, dtype):
+def test_row_gather_linear_and_gemm_tn_bit_identical_on_valid_rows(T, dtype, Bn, N):
     """rows=(row_index, n_rows): the GEMMs touch the valid tokens only; their results equal the ungathered call bit for bit,
     padded rows are neither read (they hold NaN here) nor written (sentinel survives)."""
     ops, tr = T
-    Bn, L, K, N = 9, 150, 256, 384
+    L, K = 150, 256
     lens = torch.tensor([150, 3, 77, 0, 149, 128, 1, 64, 100], device="cuda")
+    if Bn > 9:
+        g = torch.Generator().manual_seed(Bn)
+        lens = torch.cat([lens, torch.randint(0, L + 1, (Bn - 9,), generator=g).cuda()])
     mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).float().reshape(-1)
     M = Bn * L
     rows = ops.row_index(mask)
