@@ -816,6 +816,124 @@ __global__ __launch_bounds__(NTHREADS, 1) void linear_skinny_kernel(const MadeLi
     }
 }
 
+// =================================================================================================
+// Tiny-M problems, second form: no LDS staging at all.  A 64-row x 32-column output tile per workgroup; its four waves split
+// K four ways and load their MFMA fragments straight from global memory (a 32x32x16 fragment is 16 contiguous bytes of one
+// row per lane), four K steps of fragments in flight while the previous four are multiplied; the four partial tiles meet in
+// LDS and the epilogue runs on all 256 threads (one row x 8 columns each).  Against the 64 x 64 ring kernel above: twice the
+// workgroups, a quarter of the serial K steps per wave, no barrier inside the K loop -- a K = 512 Linear on 64 rows is one
+// memory round trip long.
+constexpr int T_BN = 32, T_BM = 64, T_CH = 4;
+constexpr int T_CT_LD = T_BN + 4;
+
+template <bool TRAIN>
+__global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ct[4 * T_BM * T_CT_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+    const int n_tiles = (N + T_BN - 1) / T_BN;
+    const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+    const int m0 = tile_m * T_BM, n0 = tile_n * T_BN;
+    const int64_t z = blockIdx.z;
+    int Mv = M;
+    if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
+    if (m0 >= Mv) return;
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+        if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
+    const MadeLinearSeg seg = a.seg[si];
+
+    const bool repl = seg.use_a2 && a.A2 && a.a2_replace;
+    const bf16_t* Abase = (repl ? (const bf16_t*)a.A2 : (const bf16_t*)a.A) + z * a.a_z_stride;
+    const int64_t lda = repl ? a.lda2 : a.lda;
+    const int steps = K / 64;                              // 16-deep K steps per wave (K is a multiple of 64 on this path)
+    const int kw = wave * steps * 16 + hh * 8;             // this lane's first K index
+    const bf16_t* pa[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int gm = m0 + t * 32 + r; gm = gm < Mv ? gm : Mv - 1;   // rows past the edge are fetched from a valid row and never stored
+        if (a.row_index) gm = a.row_index[gm];
+        pa[t] = Abase + (int64_t)gm * lda + kw;
+    }
+    int gn = n0 + r; gn = gn < N ? gn : N - 1;
+    const bf16_t* pw = (const bf16_t*)a.W + z * a.w_z_stride + (int64_t)gn * a.ldw + kw;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    bf16x8 fa[2][T_CH][2], fw[2][T_CH];
+    auto load = [&](int buf, int s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < T_CH; ++i) {
+            const int s = s0 + i < steps ? s0 + i : steps - 1;       // past the end: a harmless re-read, never multiplied
+            fw[buf][i] = *(const bf16x8*)(pw + s * 16);
+            fa[buf][i][0] = *(const bf16x8*)(pa[0] + s * 16);
+            fa[buf][i][1] = *(const bf16x8*)(pa[1] + s * 16);
+        }
+    };
+    auto mul = [&](int buf, int s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < T_CH; ++i) {
+            if (s0 + i < steps) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][0], fw[buf][i], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][1], fw[buf][i], acc[1], 0, 0, 0);
+            }
+        }
+    };
+    load(0, 0);
+    for (int s0 = 0; s0 < steps; s0 += 2 * T_CH) {
+        if (s0 + T_CH < steps) load(1, s0 + T_CH);
+        mul(0, s0);
+        if (s0 + 2 * T_CH < steps) load(0, s0 + 2 * T_CH);
+        if (s0 + T_CH < steps) mul(1, s0 + T_CH);
+    }
+
+    float* mine = Ct + wave * (T_BM * T_CT_LD);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[(t * 32 + acc_row(e, hh)) * T_CT_LD + r] = acc[t][e];
+    __syncthreads();
+
+    unsigned char* outp = (unsigned char*)seg.out;
+    const int64_t out_z = z * seg.out_z_stride;
+    const int rpb = (int)seg.rows_per_batch, rmod = (int)a.r_row_mod;
+    const int colb = (int)seg.col_begin;
+    const int cc = tid & 3, row = tid >> 2;
+    const int n = n0 + cc * 8;
+    int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+    const int ml = m0 + row;
+    if (nvalid <= 0 || ml >= Mv) return;
+    float v[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = 0.f; bv[j] = (a.bias && j < nvalid) ? a.bias[n + j] : 0.f; }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float* cp = Ct + w * (T_BM * T_CT_LD) + row * T_CT_LD + cc * 8;
+        const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+        v[0] += c0[0]; v[1] += c0[1]; v[2] += c0[2]; v[3] += c0[3];
+        v[4] += c1[0]; v[5] += c1[1]; v[6] += c1[2]; v[7] += c1[3];
+    }
+    const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
+                         (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
+    const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+    const int m = a.row_index ? a.row_index[ml] : ml;
+    epilogue8<TRAIN>(a, m, n, nvalid, v, bv, rmod, r_vec);
+    int64_t orow;
+    if (rpb > 0) {
+        const int b = m / rpb, t = m - b * rpb;
+        orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo;
+    } else {
+        orow = (int64_t)m * seg.ldo;
+    }
+    store8(outp, seg.out_dtype, out_z + orow + (n - colb), v, nvalid, out_vec);
+}
+
 }  // namespace
 
 // tuning knob for the micro-benchmarks: MADE_LINEAR_TILE=64|128 forces the tile height of the direct-to-LDS kernel
@@ -885,6 +1003,14 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
         if (fast) {
             const bool train = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
             const int64_t tiles64 = ((a.M + S_BM - 1) / S_BM) * ((a.N + S_BN - 1) / S_BN);
+            const int64_t tiles32 = ((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN);
+            if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) {
+                // latency-bound and short in K: fragments straight from global memory, K split over the four waves
+                dim3 g32((unsigned)tiles32, 1, (unsigned)a.batch);
+                if (train) hipLaunchKernelGGL((linear_tiny_kernel<true>), g32, block, 0, st, a);
+                else hipLaunchKernelGGL((linear_tiny_kernel<false>), g32, block, 0, st, a);
+                return made_check_launch("made_linear");
+            }
             if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) {   // latency-bound: 64 x 64 tiles, all slabs in flight
                 dim3 g64((unsigned)tiles64, 1, (unsigned)a.batch);
                 if (train) hipLaunchKernelGGL((linear_skinny_kernel<true>), g64, block, 0, st, a);

@@ -50,7 +50,8 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
         assert np.isfinite(got).all(), n
         nr = np.linalg.norm(ref)
         if nr < 1e-6 * gmax * np.sqrt(ref.size):            # theoretically zero gradients (e.g. the key bias): absolute check
-            assert np.abs(got).max() <= 1e-4 * gmax, (n, np.abs(got).max())
+            zero_tol = 1e-4 if cos_min is None else 5e-4      # bf16 mode: a sum of rounded terms that cancel exactly in f32
+            assert np.abs(got).max() <= zero_tol * gmax, (n, np.abs(got).max())
             continue
         if cos_min is not None:
             cos = float(got @ ref / (np.linalg.norm(got) * nr + 1e-30))

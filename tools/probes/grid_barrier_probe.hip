@@ -22,6 +22,30 @@ __device__ __forceinline__ bool grid_barrier(unsigned* cnt, unsigned target, uns
     return ok;
 }
 
+// barrier among the workgroups that share blockIdx % 8 (one XCD under round-robin dispatch): own counter, own cache line
+template <int SLEEP>
+__global__ __launch_bounds__(1024) void probe_xcd(unsigned* cnt, unsigned* err, float* data, int nbar, int fence) {
+    const int xcd = blockIdx.x & 7, nloc = gridDim.x >> 3, j = blockIdx.x >> 3;
+    unsigned* c = cnt + xcd * 64;
+    for (int i = 0; i < nbar; ++i) {
+        if (threadIdx.x == 0) __hip_atomic_store(&data[((i & 1) * 8 + xcd) * 64 + j], (float)(i + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (fence) __threadfence();
+            atomicAdd(c, 1u);
+            unsigned spins = 0;
+            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(i + 1) * nloc) {
+                __builtin_amdgcn_s_sleep(SLEEP);
+                if (++spins > (1u << 22)) { atomicExch(err, 1u); return; }
+            }
+            if (fence) __threadfence();
+            const float v = __hip_atomic_load(&data[((i & 1) * 8 + xcd) * 64 + (j + 1) % nloc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != (float)(i + (j + 1) % nloc)) atomicExch(err, 2u);
+        }
+        __syncthreads();
+    }
+}
+
 template <int SLEEP>
 __global__ __launch_bounds__(1024) void probe(unsigned* cnt, unsigned* err, float* data, int nbar, int work) {
     float acc = 0.f;
@@ -43,12 +67,13 @@ int main(int argc, char** argv) {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     printf("CUs %d\n", p.multiProcessorCount);
     unsigned *cnt, *err; float* data;
-    hipMalloc(&cnt, 4); hipMalloc(&err, 4); hipMalloc(&data, 2 * nblk * 4);
+    hipMalloc(&cnt, 4096); hipMalloc(&err, 4); hipMalloc(&data, 2 * 8 * 64 * 4 + 2 * nblk * 4);
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
     for (int rep = 0; rep < 2; ++rep) {
-        hipMemset(cnt, 0, 4); hipMemset(err, 0, 4);
+        hipMemset(cnt, 0, 4096); hipMemset(err, 0, 4);
         hipEventRecord(s);
-        if (slp == 1) hipLaunchKernelGGL(probe<1>, dim3(nblk), dim3(nthr), 0, 0, cnt, err, data, nbar, 0);
+        if (slp >= 100) hipLaunchKernelGGL(probe_xcd<1>, dim3(nblk), dim3(nthr), 0, 0, cnt, err, data, nbar, slp - 100);
+        else if (slp == 1) hipLaunchKernelGGL(probe<1>, dim3(nblk), dim3(nthr), 0, 0, cnt, err, data, nbar, 0);
         else if (slp == 8) hipLaunchKernelGGL(probe<8>, dim3(nblk), dim3(nthr), 0, 0, cnt, err, data, nbar, 0);
         else hipLaunchKernelGGL(probe<32>, dim3(nblk), dim3(nthr), 0, 0, cnt, err, data, nbar, 0);
         hipEventRecord(e); hipEventSynchronize(e);
