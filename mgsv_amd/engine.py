@@ -50,12 +50,16 @@ class MadeEngine:
             unsupported.append("temporal transformer depth 0 (agg_module != transf)")
         if "concat" not in c.mml_fusion and "CA" not in c.mml_fusion:
             unsupported.append(f"mml_fusion={c.mml_fusion}")
-        if c.vmr_fusion != "XA-music":
+        if "XA" not in c.vmr_fusion or not ("music" in c.vmr_fusion or "video" in c.vmr_fusion):
             unsupported.append(f"vmr_fusion={c.vmr_fusion}")
-        if c.mml_localization != "detr":
+        if "music" not in c.vmr_fusion and c.vmr_loss not in ("dual", "single"):
+            unsupported.append(f"vmr_loss={c.vmr_loss} without the music-pooling tower (the reference fails there too)")
+        if not ("detr" in c.mml_localization or "regression" in c.mml_localization):
             unsupported.append(f"mml_localization={c.mml_localization}")
-        if c.predict_center != 0 or c.audio_short_cut != 0 or c.moment_loss != 0:
-            unsupported.append("predict_center/audio_short_cut/moment_loss")
+        if c.moment_loss != 0:
+            unsupported.append("moment_loss")
+        if c.audio_short_cut and not c.contrastive_align_loss:
+            unsupported.append("audio_short_cut without contrastive_align_loss")
         if c.moment_query_type not in ("video", "music", "zero", "random"):
             unsupported.append(f"moment_query_type={c.moment_query_type}")
         if c.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse"):
@@ -110,13 +114,18 @@ class MadeEngine:
                 lin(p + ".ff1", p + ".3.0")
                 lin(p + ".ff2", p + ".3.3")
             lin(mod + ".final", mod + ".final_linear")
-        xa = "video_guided_to_music_pooling_cross_transformer"
-        ln("xa.ln1", xa + ".layer_norm1"); ln("xa.ln2", xa + ".layer_norm2"); ln("xa.ln3", xa + ".layer_norm3")
-        lin("xa.q", xa + ".cross_attn.q_proj")
-        mat("xa.kv.w", torch.cat([T(xa + ".cross_attn.k_proj.weight"), T(xa + ".cross_attn.v_proj.weight")], 0))
-        vec("xa.kv.b", torch.cat([T(xa + ".cross_attn.k_proj.bias"), T(xa + ".cross_attn.v_proj.bias")], 0))
-        lin("xa.out", xa + ".cross_attn.out_proj")
-        lin("xa.lin", xa + ".linear_proj")
+        towers = []
+        if "music" in c.vmr_fusion:
+            towers.append(("xa", "video_guided_to_music_pooling_cross_transformer"))
+        if "video" in c.vmr_fusion:                                      # reference model/model_Uni.py:26-27
+            towers.append(("xav", "music_guided_to_video_pooling_cross_transformer"))
+        for key, xa in towers:
+            ln(key + ".ln1", xa + ".layer_norm1"); ln(key + ".ln2", xa + ".layer_norm2"); ln(key + ".ln3", xa + ".layer_norm3")
+            lin(key + ".q", xa + ".cross_attn.q_proj")
+            mat(key + ".kv.w", torch.cat([T(xa + ".cross_attn.k_proj.weight"), T(xa + ".cross_attn.v_proj.weight")], 0))
+            vec(key + ".kv.b", torch.cat([T(xa + ".cross_attn.k_proj.bias"), T(xa + ".cross_attn.v_proj.bias")], 0))
+            lin(key + ".out", xa + ".cross_attn.out_proj")
+            lin(key + ".lin", xa + ".linear_proj")
         vec("logit_scale", T("logit_scale").view(1))
         if "CA" in c.mml_fusion:                                          # reference model/model_Base.py:99-213
             ca = "video_music_fusion_cross_transformer"
@@ -159,13 +168,17 @@ class MadeEngine:
             ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2"); ln(p + ".ln3", p + ".norm3")
         ln("dec.norm", "detr_transformer.decoder.norm")
         mat("query_embed", T("decoder_query_embed.weight"))
-        lin("class_embed", "class_embed")
-        for i in range(3):
-            lin(f"span_embed.{i}", f"span_embed.layers.{i}")
-        if c.contrastive_align_loss:
-            lin("proj_q", "contrastive_align_projection_query")
-            lin("proj_v", "contrastive_align_projection_vid")
-        vec("empty_weight", T("criterion.empty_weight"))
+        if "regression" in c.mml_localization:                           # reference model/model_Uni.py:66-69
+            for i in range(3):
+                lin(f"reg_mlp.{i}", f"reg_mlp.layers.{i}")
+        else:
+            lin("class_embed", "class_embed")
+            for i in range(3):
+                lin(f"span_embed.{i}", f"span_embed.layers.{i}")
+            if c.contrastive_align_loss:
+                lin("proj_q", "contrastive_align_projection_query")
+                lin("proj_v", "contrastive_align_projection_vid")
+            vec("empty_weight", T("criterion.empty_weight"))
         # constants
         i = torch.arange(D, dtype=torch.float32)
         vec("dim_t", (10000.0 ** (2 * torch.div(i, 2, rounding_mode="floor") / D)).to(dev))
@@ -216,7 +229,7 @@ class MadeEngine:
             dffn=E(B * Q, F_d), hs=E(nd, B * Q, D),
             logits=E(nd, B, Q, 2, dtype=torch.float32), spans=E(nd, B, Q, 2, dtype=torch.float32),
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D),
-            sims_single=E(B, B, dtype=torch.float32), sims_dual=E(B, B, dtype=torch.float32),
+            sims_single=E(B, B, dtype=torch.float32), sims_dual=E(B, B, dtype=torch.float32), sims_vp_t=E(B, B, dtype=torch.float32),
             ret_loss=E(1, dtype=torch.float32),
             # row gather (valid-token lists) of the video / audio / fused sequences
             rows_v=(E(B * Tv, dtype=torch.int32), E(1, dtype=torch.int32)), rows_a=(E(B * Ta, dtype=torch.int32), E(1, dtype=torch.int32)),
@@ -297,9 +310,11 @@ class MadeEngine:
 
     # ------------------------------------------------------------------ X-Pool scoring
     def xpool_sims(self, video: Tensor, seg: Tensor, seg_mask: Tensor, sims_out: Optional[Tensor] = None,
-                   pooled_out: Optional[Tensor] = None, chunk_m: Optional[int] = None) -> Tensor:
+                   pooled_out: Optional[Tensor] = None, chunk_m: Optional[int] = None, tower: str = "xa") -> Tensor:
         """sims[n, m] = <v_n/|v_n|, XA(v, seg, mask)[m, n]/|.|>: reference modules/transformer.py:156-180 +
         modules/metrics.py:10-24.  video [Nv, D] f32; seg [Nm, S, D] (compute dtype, strided ok); mask [Nm, S].
+        tower = "xav": the music-guided video pooling block (reference model_Uni.py:203, metrics.py:26-41) -- same
+        arithmetic with the roles swapped: pass (music, frames, frame mask) and read the result as sims[m, v].
         Music tracks are processed in chunks so the per-pair intermediates stay bounded."""
         P, tc, dev = self.P, self.tc, self.device
         Nv, D = video.shape
@@ -310,8 +325,8 @@ class MadeEngine:
             budget = 6 << 30                                             # bytes of per-pair intermediates per chunk
             per_m = Nv * 3 * D * tc.itemsize + 4 * S * D * tc.itemsize
             chunk_m = max(1, min(Nm, budget // max(per_m, 1)))
-        v1 = ops.layernorm(video, P["xa.ln1.g"], P["xa.ln1.b"], out_dtype=tc)
-        q = ops.linear(v1, P["xa.q.w"], P["xa.q.b"])
+        v1 = ops.layernorm(video, P[tower + ".ln1.g"], P[tower + ".ln1.b"], out_dtype=tc)
+        q = ops.linear(v1, P[tower + ".q.w"], P[tower + ".q.b"])
         hoist = Nv > S          # out_proj commutes with the softmax-weighted sum (rows sum to 1): apply it to U instead
         cm = min(chunk_m, Nm)
         s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
@@ -325,12 +340,12 @@ class MadeEngine:
         for m0 in range(0, Nm, cm):
             n = min(cm, Nm - m0)
             skip = seg_mask[m0:m0 + n].reshape(-1) if seg_mask is not None else None    # masked segments are never attended to
-            ops.layernorm(seg[m0:m0 + n], P["xa.ln1.g"], P["xa.ln1.b"], out=s1[:n * S], row_skip=skip)   # [n,S,D] view -> compact rows
-            ops.linear(s1[:n * S], P["xa.kv.w"], P["xa.kv.b"], tile_skip_mask=skip,
+            ops.layernorm(seg[m0:m0 + n], P[tower + ".ln1.g"], P[tower + ".ln1.b"], out=s1[:n * S], row_skip=skip)   # [n,S,D] view -> compact rows
+            ops.linear(s1[:n * S], P[tower + ".kv.w"], P[tower + ".kv.b"], tile_skip_mask=skip,
                        segs=[Seg(out=kbuf, col_begin=0), Seg(out=ubuf, col_begin=D)])
             u = ubuf
             if hoist:
-                u = ops.linear(ubuf[:n * S], P["xa.out.w"], P["xa.out.b"], out=ubuf2[:n * S], tile_skip_mask=skip)
+                u = ops.linear(ubuf[:n * S], P[tower + ".out.w"], P[tower + ".out.b"], out=ubuf2[:n * S], tile_skip_mask=skip)
             # all videos attend to each track's segments: softmax over segments, scores never leave the chip
             ops.attention_wide(q.view(1, Nv, 1, D), kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D),
                                o[:n * Nv].view(n, Nv, 1, D), scale=scale,
@@ -339,10 +354,10 @@ class MadeEngine:
             if hoist:
                 a2 = o[:rows]
             else:
-                a2 = ops.linear(o[:rows], P["xa.out.w"], P["xa.out.b"], out=o2[:rows])
-            a3 = ops.layernorm(a2, P["xa.ln2.g"], P["xa.ln2.b"], out=o3[:rows])
-            y = ops.linear(a3, P["xa.lin.w"], P["xa.lin.b"], R=a3, out=o2[:rows] if hoist else o[:rows])
-            ops.xpool_tail(y, P["xa.ln3.g"], P["xa.ln3.b"], video, sims_out[:, m0:m0 + n], n, Nv,
+                a2 = ops.linear(o[:rows], P[tower + ".out.w"], P[tower + ".out.b"], out=o2[:rows])
+            a3 = ops.layernorm(a2, P[tower + ".ln2.g"], P[tower + ".ln2.b"], out=o3[:rows])
+            y = ops.linear(a3, P[tower + ".lin.w"], P[tower + ".lin.b"], R=a3, out=o2[:rows] if hoist else o[:rows])
+            ops.xpool_tail(y, P[tower + ".ln3.g"], P[tower + ".ln3.b"], video, sims_out[:, m0:m0 + n], n, Nv,
                            pooled_out=pooled_out[m0 * Nv:(m0 + n) * Nv] if pooled_out is not None else None)
         return sims_out
 
@@ -370,8 +385,12 @@ class MadeEngine:
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
     def forward(self, frame_feats: Tensor, segment_feats: Tensor, frame_masks: Tensor, segment_masks: Tensor,
-                spans_target: Tensor, with_losses: bool = True, want_pooled: bool = False) -> Dict[str, Tensor]:
+                spans_target: Tensor, with_losses: bool = True, want_pooled: bool = False,
+                v_duration: Optional[Tensor] = None) -> Dict[str, Tensor]:
         c, P = self.cfg, self.P
+        regression = "regression" in c.mml_localization
+        if c.predict_center == 1 and v_duration is None:
+            raise ValueError("predict_center=1 needs v_duration (reference model/model_Uni.py:280-282)")
         B, Tv, _ = frame_feats.shape
         Ta = segment_feats.shape[1]
         concat = "concat" in c.mml_fusion
@@ -413,8 +432,18 @@ class MadeEngine:
         # beside the (latency-bound) decoder and join at the end of the step
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if want_pooled else None
-            self.xpool_sims(video, seg, sm if c.fusion_mask == 1 else None, sims_out=ws["sims_single"], pooled_out=pooled)
+            pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if (want_pooled and "music" in c.vmr_fusion) else None
+            if "music" in c.vmr_fusion:
+                self.xpool_sims(video, seg, sm if c.fusion_mask == 1 else None, sims_out=ws["sims_single"], pooled_out=pooled)
+            if "video" in c.vmr_fusion:
+                # music-guided video pooling (reference model_Uni.py:203, metrics.py:26-41): the same block with the roles
+                # swapped gives sims[m, v]; the reference adds its transpose to the music-pooling similarities (:247-251)
+                vp = self.xpool_sims(music, frame, fm if c.fusion_mask == 1 else None, sims_out=ws["sims_vp_t"], tower="xav")
+                out["sims_video_pooling"] = vp.t()
+                if "music" in c.vmr_fusion:
+                    ws["sims_single"].add_(vp.t())
+                else:
+                    ws["sims_single"].copy_(vp.t())
             self.dual_sims(video, music, out=ws["sims_dual"])
             if with_losses:
                 self._retrieval_loss(ws, video, music)
@@ -430,19 +459,26 @@ class MadeEngine:
         pos2 = pos.view(rows, D)
         srcpos = ws["srcpos"]
         fskip = fus_mask.view(-1)             # padded tokens of the fused sequence: skipped everywhere below
+        enc_rows, order_e = rows_f, order_f
+        if regression:
+            # the regression head sums the memory over ALL positions, padded ones included (reference model_Uni.py:229), so
+            # here the encoder computes them too
+            fskip = enc_rows = None
         ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)      # layer 0: src + pos (no norm)
         for l in range(c.detr_enc_layers):
             p = f"detr_transformer.encoder.layers.{l}"
-            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip, rows=rows_f, order=order_f)
-            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows], rows=rows_f)
+            att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip, rows=enc_rows, order=order_e)
+            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows], rows=enc_rows)
             s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x2"][:rows], row_skip=fskip)
-            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward], rows=rows_f)
-            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=ws["x1"][:rows], rows=rows_f)
+            h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward], rows=enc_rows)
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=ws["x1"][:rows], rows=enc_rows)
             # the norm that produces the next src also emits src + pos (next layer's q/k input, decoder's keys)
             src = ws["x3" if l % 2 == 0 else "x0"][:rows]
             ops.layernorm_add(x, P[p + ".ln2.g"], P[p + ".ln2.b"], pos2, src, srcpos, row_skip=fskip)
         memory = src
         out["memory"] = memory.view(B, L, D)
+        if regression:
+            return self._regression_head(out, ws, memory.view(B, L, D), fus_mask, spans_target, v_duration, with_losses, cur, side)
 
         # ---- DETR decoder (K10).  Cross-attention runs in memory space (made_attention_wide): no projection of
         # the L memory rows at all; self-attention collapses to one folded Linear when there is a single query.
@@ -504,7 +540,13 @@ class MadeEngine:
         else:
             h1 = ops.linear(hs2, P["span_embed.0.w"], P["span_embed.0.b"], act=ops.ACT_RELU, out=ws["h1"])
             h2 = ops.linear(h1, P["span_embed.1.w"], P["span_embed.1.b"], act=ops.ACT_RELU, out=ws["h2"])
-        ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, out=spans.view(-1, 2))
+        if c.predict_center == 1:
+            # the head predicts the centre only; the width is the video's share of the longest track (reference
+            # model/model_Uni.py:135-136,280-282)
+            ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, segs=[Seg(out=spans.view(-1, 2), ldo=2)])
+            spans[..., 1] = (v_duration.to(self.device, torch.float32) / c.max_m_duration).view(1, B, 1)
+        else:
+            ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, out=spans.view(-1, 2))
         out.update(pred_logits=logits[-1], pred_spans=spans[-1], logits_all=logits, spans_all=spans)
         pq = vid_sum = None
         if c.contrastive_align_loss:
@@ -512,6 +554,11 @@ class MadeEngine:
             pq = ws["pq"]
             ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
             Dc = pq.shape[-1]
+            if c.audio_short_cut:                                        # reference model/model_Uni.py:144-145: normalize(pq + music)
+                from . import ops_train
+                mq = music if Q == 1 else music[:, None, :].expand(B, Q, D).contiguous()
+                ops_train.add3(ws["pq_raw"], pq, mq, b_mod=B * Q * D)
+                ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
             self._frame_rows_linear(frame, P["proj_v.w"], P["proj_v.b"], ws["pv_raw"], B, Tv)
             pv = ws["pv"]
             ops.l2norm_rows(ws["pv_raw"], out_f32=pv.view(B * Tv, Dc))
@@ -528,6 +575,30 @@ class MadeEngine:
                                           c.foreground_label, P["crit_weights"])
         out.update(matcher_pred_idx=pi.view(nd, B, -1), matcher_tgt_idx=ti.view(nd, B, -1), matcher_count=cnt.view(nd, B),
                    matcher_status=status, criterion_losses=losses, localization_loss=total)
+        cur.wait_stream(side)
+        return out
+
+    def _regression_head(self, out, ws, mem3: Tensor, fus_mask: Tensor, spans_target: Tensor, v_duration, with_losses: bool, cur, side):
+        """reference model/model_Uni.py:228-232,290-300: memory summed over all L positions / number of valid ones -> 3-layer
+        ReLU MLP -> sigmoid; loss = 20 * L1.  The decoder's output is not used on this path, so it is not run."""
+        c, P = self.cfg, self.P
+        B = mem3.shape[0]
+        fusion = ops.masked_mean(mem3, None) / fus_mask.sum(dim=1, keepdim=True)           # [B, D] f32
+        h1 = ops.linear(fusion, P["reg_mlp.0.w"], P["reg_mlp.0.b"], act=ops.ACT_RELU)
+        h2 = ops.linear(h1, P["reg_mlp.1.w"], P["reg_mlp.1.b"], act=ops.ACT_RELU)
+        if c.predict_center == 1:
+            spans = torch.empty(B, 2, device=self.device, dtype=torch.float32)
+            ops.linear(h2, P["reg_mlp.2.w"], P["reg_mlp.2.b"], act=ops.ACT_SIGMOID, segs=[Seg(out=spans, ldo=2)])
+            spans[:, 1] = v_duration.to(self.device, torch.float32) / c.max_m_duration
+        else:
+            spans = ops.linear(h2, P["reg_mlp.2.w"], P["reg_mlp.2.b"], act=ops.ACT_SIGMOID, out_dtype=torch.float32)
+        out["pred_spans"] = spans.view(B, 1, 2)
+        if with_losses:
+            tg = spans_target.to(torch.float32)
+            assert tg.shape == out["pred_spans"].shape, f"spans_target.shape {tuple(tg.shape)} must equal to src_spans.shape {tuple(out['pred_spans'].shape)}"
+            l1 = (out["pred_spans"] - tg).abs().mean()
+            out["regression_loss_span"] = l1
+            out["localization_loss"] = (l1 * 20).view(1)
         cur.wait_stream(side)
         return out
 
@@ -601,10 +672,14 @@ class MadeEngine:
         dev = self.device
         t = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
         o = self.forward(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
-                         with_losses=with_losses, want_pooled=want_pooled)
+                         with_losses=with_losses, want_pooled=want_pooled, v_duration=t.get("v_duration"))
         torch.cuda.synchronize()
         r = {k: v.float().cpu().numpy() for k, v in o.items() if isinstance(v, torch.Tensor) and v.dtype in (torch.float32, torch.bfloat16)}
-        if with_losses:
+        if with_losses and "regression" in self.cfg.mml_localization:
+            r["loss_dict"] = {"loss_span": float(o["regression_loss_span"].cpu()), "loss_giou": 0, "loss_label": 0, "class_error": 0}
+            r["retrieval_loss"] = float(o["retrieval_loss"].cpu())
+            r["localization_loss"] = float(o["localization_loss"].cpu())
+        elif with_losses:
             if int(o["matcher_status"].cpu()) != 0:
                 raise ValueError("matrix contains invalid numeric entries")   # what SciPy raises in the reference
             nd = self.cfg.detr_dec_layers

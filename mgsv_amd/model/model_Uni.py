@@ -139,9 +139,11 @@ class Uni_model(nn.Module):
                 continue
             target, rel = (xpool, name[len(xa) + 1:]) if name.startswith(xa + ".") else (self, name)
             _attach(target, rel, t, is_buf)
-        self.add_module(xa, xpool)
-        self.criterion = _Criterion(self.cfg)
-        self.criterion.register_buffer("empty_weight", torch.from_numpy(sd["criterion.empty_weight"].copy()))
+        if "music" in self.cfg.vmr_fusion:
+            self.add_module(xa, xpool)
+        if "detr" in self.cfg.mml_localization:                    # the regression variant builds no criterion (model_Uni.py:66-69)
+            self.criterion = _Criterion(self.cfg)
+            self.criterion.register_buffer("empty_weight", torch.from_numpy(sd["criterion.empty_weight"].copy()))
         self._engine: Optional[MadeEngine] = None
         self._engine_stamp = None
         self._trainer = None
@@ -156,10 +158,15 @@ class Uni_model(nn.Module):
         return self._params(["vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer."])
 
     def get_matching_parameter(self):
-        return self._params(["video_guided_to_music_pooling_cross_transformer."]) + [self.logit_scale]
+        return self._params(["video_guided_to_music_pooling_cross_transformer.", "music_guided_to_video_pooling_cross_transformer."]) + [self.logit_scale]
 
     def get_detection_parameter(self):
-        return self._params(["detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_"])
+        # reference model/model_Uni.py:92-114: the CA fusion block, then the DETR stack + heads -- or, for the regression
+        # variant, the regression MLP only (the DETR transformer is then in no optimizer group)
+        if "regression" in self.cfg.mml_localization:
+            return self._params(["video_music_fusion_cross_transformer.", "reg_mlp."])
+        return self._params(["video_music_fusion_cross_transformer.", "detr_transformer.", "span_embed.", "class_embed.",
+                             "contrastive_align_projection_"])
 
     # ---- state handling
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -248,8 +255,17 @@ class Uni_model(nn.Module):
         dev = eng.device
         f32 = torch.float32
         o = eng.forward(frame_feats.to(dev, f32), segment_feats.to(dev, f32), frame_masks.to(dev, f32),
-                        segment_masks.to(dev, f32), spans_target.to(dev, f32))
+                        segment_masks.to(dev, f32), spans_target.to(dev, f32),
+                        v_duration=v_duration.to(dev, f32) if torch.is_tensor(v_duration) else v_duration)
         nd, cfg = self.cfg.detr_dec_layers, self.cfg
+        feat_map = {"video_feats": o["video_feats"], "music_feats": o["music_feats"],
+                    "frame_feats": o["frame_feats"].float(), "segment_feats": o["segment_feats"].float()}
+        mask_map = {"frame_masks": frame_masks, "segment_masks": segment_masks}
+        id_map = {"video_ids": video_ids, "music_ids": music_ids}
+        if "regression" in cfg.mml_localization:                   # reference model/model_Uni.py:228-232,290-300
+            loss_map = {"retrieval_loss": o["retrieval_loss"][0], "localization_loss": o["localization_loss"][0],
+                        "localization_loss_dict": {"loss_span": o["regression_loss_span"], "loss_giou": 0, "loss_label": 0, "class_error": 0}}
+            return {"pred_spans": o["pred_spans"]}, loss_map, feat_map, mask_map, id_map
         output_map: Dict[str, object] = {"pred_logits": o["pred_logits"], "pred_spans": o["pred_spans"]}
         if cfg.contrastive_align_loss:
             output_map.update(proj_queries=o["proj_queries"], proj_vid_mem=o["proj_vid_mem"])

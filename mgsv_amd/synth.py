@@ -106,6 +106,11 @@ def param_shapes(cfg: MadeConfig) -> "OrderedDict[str, tuple]":
     # heads (model_Uni.py:46-64)
     s["decoder_query_embed.weight"] = (cfg.num_moment_queries, D)
     span_dim = 1 if cfg.predict_center == 1 else 2
+    if "regression" in cfg.mml_localization:               # model_Uni.py:66-69: MLP(D, 256, span_dim, 3), no criterion
+        lin("reg_mlp.layers.0", 256, D)
+        lin("reg_mlp.layers.1", 256, 256)
+        lin("reg_mlp.layers.2", span_dim, 256)
+        return s
     lin("span_embed.layers.0", D, D)
     lin("span_embed.layers.1", D, D)
     lin("span_embed.layers.2", span_dim, D)

@@ -57,6 +57,12 @@ class MadeTrainer(MadeEngine):
             bad.append("with_act_after_proj")
         if c.moment_query_type not in ("video", "music"):
             bad.append(f"moment_query_type={c.moment_query_type}")
+        if c.vmr_fusion != "XA-music":
+            bad.append(f"vmr_fusion={c.vmr_fusion}")
+        if "detr" not in c.mml_localization:
+            bad.append(f"mml_localization={c.mml_localization}")
+        if c.predict_center or c.audio_short_cut:
+            bad.append("predict_center / audio_short_cut")
         if bad:
             raise NotImplementedError("MadeTrainer (HIP training path) does not cover yet: " + "; ".join(bad))
 
@@ -129,8 +135,9 @@ class MadeTrainer(MadeEngine):
                 return 0                                      # temporal
             if k.startswith(XA + ".") or k == "logit_scale":
                 return 1                                      # matching
-            if k.startswith(("detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_")):
-                return 2                                      # detection
+            if k.startswith(("detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_",
+                             "video_music_fusion_cross_transformer.")):
+                return 2                                      # detection (the CA fusion block belongs here: model_Uni.py:95-97)
             return 3                                          # not optimised (decoder_query_embed, unused variants)
         names = sorted(names, key=group_of)                   # stable: keeps the state_dict order inside a group
         order: List[str] = []

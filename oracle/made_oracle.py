@@ -586,7 +586,8 @@ def forward(P, cfg, frame_feats, segment_feats, frame_masks, segment_masks, span
             if pooled is not None:
                 single = single + r["sims_single"]
             if pooled_v is not None:
-                single = single + sim_video_pooling(pooled_v, music)
+                r["sims_video_pooling"] = sim_video_pooling(pooled_v, music)
+                single = single + r["sims_video_pooling"]
             r["retrieval_loss"] = clip_loss(single, ls) * cfg.dual_single_loss_weight
         elif cfg.vmr_loss == "dual_single_loss_fuse" and "XA" in cfg.vmr_fusion:
             if is_train and cfg.ignore_same_music == 0 and music_ids is not None:
@@ -604,7 +605,21 @@ def forward(P, cfg, frame_feats, segment_feats, frame_masks, segment_masks, span
 
     wp = None
     if cfg.predict_center == 1:
-        wp = (_t(v_duration).float() / cfg.max_m_duration)[:, None, None].expand(-1, cfg.num_moment_queries, -1)
+        wp = (_t(v_duration).to(dt) / cfg.max_m_duration)[:, None, None].expand(-1, cfg.num_moment_queries, -1)
+    if "regression" in cfg.mml_localization:
+        # model_Uni.py:228-232,290-300: mean of the encoder memory over ALL L positions' values / number of valid ones
+        # (padded positions are not masked out of the sum), 3-layer MLP, sigmoid; L1 * 20
+        fusion = mem.sum(dim=1) / fus_mask.sum(dim=1, keepdim=True)
+        coord = torch.sigmoid(mlp3(fusion, P, "reg_mlp"))[:, None, :]
+        if cfg.predict_center == 1:
+            coord = torch.cat([coord, wp], dim=-1)
+        r["pred_spans"] = coord
+        if with_losses:
+            assert coord.shape == tg.shape, (coord.shape, tg.shape)
+            l1 = (coord - tg).abs().mean()
+            r["loss_dict"] = {"loss_span": l1, "loss_giou": 0, "loss_label": 0, "class_error": 0}
+            r["localization_loss"] = l1 * 20
+        return r
     out = calc_output(hs, frame, music, P, cfg, wp)
     r.update({k: v for k, v in out.items()})
     if with_losses:

@@ -56,15 +56,22 @@ def compare_forward(cfg: MadeConfig, B: int, T_v: int, T_a: int, tag: str) -> di
     d["retrieval_loss"] = _maxabs(lm["retrieval_loss"], r["retrieval_loss"])
     d["localization_loss"] = _maxabs(lm["localization_loss"], r["localization_loss"])
     for k, v in lm["localization_loss_dict"].items():
-        d["loss." + k] = _maxabs(v, r["loss_dict"][k])
+        d["loss." + k] = _maxabs(torch.as_tensor(v, dtype=torch.float32), torch.as_tensor(r["loss_dict"][k], dtype=torch.float32))
     assert set(lm["localization_loss_dict"]) == set(r["loss_dict"]), "loss key sets differ"
-    # weight dict
-    assert dict(ref.criterion.weight_dict) == O.criterion_weight_dict(cfg)
-    # matcher indices on the last layer
-    ref_idx = ref.criterion.matcher({"pred_logits": om["pred_logits"], "pred_spans": om["pred_spans"]}, tin["spans_target"])
-    for (ri, rj), (oi, oj) in zip(ref_idx, r["matcher_indices"]):
-        assert ri.tolist() == oi.tolist() and rj.tolist() == oj.tolist(), "matcher indices differ"
-    d["matcher_indices"] = 0.0
+    if "detr" in cfg.mml_localization:
+        # weight dict
+        assert dict(ref.criterion.weight_dict) == O.criterion_weight_dict(cfg)
+        # matcher indices on the last layer
+        ref_idx = ref.criterion.matcher({"pred_logits": om["pred_logits"], "pred_spans": om["pred_spans"]}, tin["spans_target"])
+        for (ri, rj), (oi, oj) in zip(ref_idx, r["matcher_indices"]):
+            assert ri.tolist() == oi.tolist() and rj.tolist() == oj.tolist(), "matcher indices differ"
+        d["matcher_indices"] = 0.0
+    if "video" in cfg.vmr_fusion:
+        with torch.no_grad():
+            xv = ref.music_guided_to_video_pooling_cross_transformer(
+                fm["music_feats"], fm["frame_feats"], mm["frame_masks"] if cfg.fusion_mask == 1 else None)
+        from modules.metrics import sim_matrix_video_pooling
+        d["sims_video_pooling"] = _maxabs(sim_matrix_video_pooling(xv, fm["music_feats"]), r["sims_video_pooling"])
     # X-Pool block called directly, as the drivers do (test-MaDe.py:392-395)
     if "music" in cfg.vmr_fusion:
         with torch.no_grad():
@@ -195,6 +202,16 @@ def main():
     report["native_CA_B4"] = compare_forward(c, 4, 50, 96, "native CA fusion")
     c = cfg_native(); c.fb_label = "10"; c.audio_short_cut = 1; c.with_act_after_proj = 1
     report["native_fb10_shortcut_B4"] = compare_forward(c, 4, 50, 96, "native fb10/short-cut/act")
+    c = cfg_native(); c.vmr_fusion = "XA-music-video"; c.vmr_loss = "single"
+    report["native_XA_music_video_B4"] = compare_forward(c, 4, 50, 96, "native XA-music-video / single")
+    c = cfg_native(); c.vmr_fusion = "XA-video"; c.vmr_loss = "single"
+    report["native_XA_video_B4"] = compare_forward(c, 4, 50, 96, "native XA-video / single")
+    c = cfg_native(); c.predict_center = 1
+    report["native_predict_center_B4"] = compare_forward(c, 4, 50, 96, "native predict_center")
+    c = cfg_native(); c.mml_localization = "regression"
+    report["native_regression_B4"] = compare_forward(c, 4, 50, 96, "native regression head")
+    c = cfg_native(); c.mml_localization = "regression"; c.predict_center = 1; c.mml_fusion = "CA"
+    report["native_regression_center_CA_B4"] = compare_forward(c, 4, 50, 96, "native regression head, predict_center, CA")
     c = cfg_headline()
     report["cfg2_B4"] = compare_forward(c, 4, 30, 512, "cfg2 shape B=4 Tv=30 Ta=512 D=512")
     report["grad_eval_native_B3"] = compare_backward(cfg_native(), 3, 20, 40, "native eval-mode grads", train=False)

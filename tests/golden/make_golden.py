@@ -65,6 +65,42 @@ def forward_fixture(cfg: MadeConfig, B: int, T_v: int, T_a: int, name: str, cfg_
     print(name, {k: getattr(v, "shape", None) for k, v in fix.items() if not k.startswith("meta")})
 
 
+VARIANTS = {      # name -> cfg overrides (on cfg_native): the option variants of SURVEY section 8(f) item 4
+    "xa_music_video_single": {"vmr_fusion": "XA-music-video", "vmr_loss": "single"},
+    "xa_video_single": {"vmr_fusion": "XA-video", "vmr_loss": "single"},
+    "predict_center": {"predict_center": 1},
+    "audio_short_cut_fb10": {"audio_short_cut": 1, "fb_label": "10"},
+    "regression": {"mml_localization": "regression"},
+    "regression_center_CA": {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
+}
+
+
+def variants_fixture(B: int = 4, T_v: int = 50, T_a: int = 96):
+    """One small fixture for all option variants: what the reference's forward returns for each."""
+    fix = dict(meta_B=B, meta_T_v=T_v, meta_T_a=T_a, meta_weight_seed=0, meta_data_seed=1)
+    for name, ov in VARIANTS.items():
+        cfg = cfg_native()
+        for k, v in ov.items():
+            setattr(cfg, k, v)
+        sd = synth.make_state_dict(cfg, seed=0)
+        inp = synth.make_inputs(cfg, B, T_v, T_a, seed=1)
+        ref = ref_import.build_reference_model(cfg, sd)
+        t = {k: torch.from_numpy(v) for k, v in inp.items() if isinstance(v, np.ndarray)}
+        with torch.no_grad():
+            om, lm, fm, mm, im = ref(t["frame_feats"].clone(), t["segment_feats"].clone(), t["frame_masks"].clone(),
+                                     t["segment_masks"].clone(), t["spans_target"].clone(), v_duration=t["v_duration"],
+                                     video_ids=inp["video_ids"], music_ids=inp["music_ids"], is_train=False)
+        for k in ("pred_logits", "pred_spans", "proj_queries"):
+            if k in om:
+                fix[f"{name}.{k}"] = om[k].numpy()
+        fix[f"{name}.retrieval_loss"] = np.float32(lm["retrieval_loss"])
+        fix[f"{name}.localization_loss"] = np.float32(lm["localization_loss"])
+        for k, v in lm["localization_loss_dict"].items():
+            fix[f"{name}.loss_{k}"] = np.float32(v)
+    np.savez_compressed(os.path.join(HERE, "variants.npz"), **fix)
+    print("variants:", len(fix), "entries for", list(VARIANTS))
+
+
 def matcher_fixture():
     """Known-answer test held by the reference (music_detr/test_matcher.py:15-29, expected
     output in its comment at :28) plus seeded random Q x G cases with ties, zero-width
@@ -227,6 +263,7 @@ def metrics_fixture():
 
 
 def main():
+    variants_fixture()
     metrics_fixture()
     train_fixture(cfg_native(), 3, 20, 40, "train_native_B3", {})
     forward_fixture(cfg_plumbing(), 2, 30, 200, "forward_cfg1_B2", {})

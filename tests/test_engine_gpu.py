@@ -155,8 +155,26 @@ def test_retrieval_matches_reference_golden_and_oracle(golden_dir):
     np.testing.assert_allclose(sim.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("name", ["xa_music_video_single", "xa_video_single", "predict_center", "audio_short_cut_fb10", "regression",
+                                  "regression_center_CA"])
+def test_option_variants_match_reference_fixture_and_oracle(golden_dir, name):
+    """the second X-Pool tower, predict_center, audio_short_cut and the regression head, f32 engine
+    against the reference's own outputs (tests/golden/variants.npz) and, for the similarities, the oracle."""
+    from test_oracle_golden import variant_case, check_variant
+    fix = np.load(os.path.join(golden_dir, "variants.npz"))
+    cfg, sd, inp = variant_case(fix, name)
+    out = MadeEngine(cfg, sd, dtype="f32").forward_numpy(inp)
+    check_variant(fix, name, out)
+    ref = _oracle(cfg, sd, inp)
+    for k in ("video_feats", "music_feats", "sims_dual", "sims_video_pooling"):
+        if k in ref and k in out:
+            np.testing.assert_allclose(out[k], ref[k].numpy(), atol=1e-4, rtol=0, err_msg=k)
+    if "regression" in name:       # the regression head reads the encoder memory at EVERY position, padded ones included
+        np.testing.assert_allclose(out["memory"], ref["memory"].numpy(), atol=1e-4, rtol=0)
+
+
 def test_engine_rejects_unsupported_configs_loudly():
-    cfg = cfg_native(); cfg.vmr_fusion = "XA-music-video"
+    cfg = cfg_native(); cfg.vmr_fusion = "XA-video"; cfg.vmr_loss = "dual_single_loss_fuse"     # the reference fails there too
     with pytest.raises(NotImplementedError):
         MadeEngine(cfg, synth.make_state_dict(cfg, seed=0), dtype="f32")
     cfg = cfg_headline(); cfg.audio_attention_seqlen = 300

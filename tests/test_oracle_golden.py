@@ -182,3 +182,49 @@ def test_eval_metrics_oracle_matches_reference_fixture(golden_dir):
     assert float((iou - torch.from_numpy(fix["iou"])).abs().max()) <= 1e-6
     plain = O.recall_ranks_plain(fix["sim"])
     assert plain.tolist() == [(fix["sim"][i] > fix["sim"][i, i]).sum() for i in range(len(ids))]
+
+
+VARIANTS = {      # the same table as tests/golden/make_golden.py
+    "xa_music_video_single": {"vmr_fusion": "XA-music-video", "vmr_loss": "single"},
+    "xa_video_single": {"vmr_fusion": "XA-video", "vmr_loss": "single"},
+    "predict_center": {"predict_center": 1},
+    "audio_short_cut_fb10": {"audio_short_cut": 1, "fb_label": "10"},
+    "regression": {"mml_localization": "regression"},
+    "regression_center_CA": {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
+}
+
+
+def variant_case(fix, name):
+    cfg = cfg_native()
+    for k, v in VARIANTS[name].items():
+        setattr(cfg, k, v)
+    B, Tv, Ta = int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"])
+    sd = synth.make_state_dict(cfg, seed=int(fix["meta_weight_seed"]))
+    inp = synth.make_inputs(cfg, B, Tv, Ta, seed=int(fix["meta_data_seed"]))
+    return cfg, sd, inp
+
+
+def check_variant(fix, name, got, tol=1e-4):
+    """got: dict with pred_spans, (pred_logits, proj_queries), retrieval_loss, localization_loss, loss_dict."""
+    for k in ("pred_logits", "pred_spans", "proj_queries"):
+        if f"{name}.{k}" in fix.files:
+            np.testing.assert_allclose(np.asarray(got[k]), fix[f"{name}.{k}"], atol=tol, rtol=0, err_msg=f"{name}.{k}")
+    np.testing.assert_allclose(float(got["retrieval_loss"]), float(fix[f"{name}.retrieval_loss"]), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(float(got["localization_loss"]), float(fix[f"{name}.localization_loss"]), rtol=2e-4, atol=5e-4)
+    keys = [k[len(name) + 6:] for k in fix.files if k.startswith(name + ".loss_")]
+    assert set(keys) == set(got["loss_dict"]), (sorted(keys), sorted(got["loss_dict"]))
+    for k in keys:
+        np.testing.assert_allclose(float(got["loss_dict"][k]), float(fix[f"{name}.loss_{k}"]), rtol=2e-4, atol=2e-4, err_msg=f"{name}.{k}")
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_option_variants_match_reference_fixture(golden_dir, name):
+    """Oracle against what the reference's forward returned for each option variant (tests/golden/variants.npz)."""
+    fix = _load(golden_dir, "variants")
+    cfg, sd, inp = variant_case(fix, name)
+    with torch.no_grad():
+        r = O.forward(O.to_torch_params(sd), cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"],
+                      inp["spans_target"], v_duration=inp["v_duration"], music_ids=inp["music_ids"])
+    got = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in r.items() if k in ("pred_logits", "pred_spans", "proj_queries")}
+    got.update(retrieval_loss=r["retrieval_loss"], localization_loss=r["localization_loss"], loss_dict=r["loss_dict"])
+    check_variant(fix, name, got, tol=2e-5)
