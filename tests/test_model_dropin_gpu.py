@@ -108,3 +108,30 @@ def test_training_loop_body_of_the_reference_driver_runs_unchanged():
     with torch.no_grad():
         om, lm, *_ = model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
     assert float(lm["retrieval_loss"] + lm["localization_loss"]) < losses[0]
+
+
+@pytest.mark.parametrize("name", ["xa_music_video_single", "regression_center_CA"])
+def test_dropin_option_variants(golden_dir, name):
+    """The drop-in module on two option variants (second X-Pool tower; regression head + predict_center + CA fusion): key layout,
+    optimizer groups and outputs as the reference's (tests/golden/variants.npz)."""
+    from test_oracle_golden import variant_case, check_variant
+    fix = np.load(os.path.join(golden_dir, "variants.npz"))
+    cfg, sd_np, inp = variant_case(fix, name)
+    model = Uni_model(cfg.to_args(local_rank=0), device=torch.device("cuda:0"), logger=logging.getLogger("t"))
+    assert set(model.state_dict().keys()) == set(sd_np.keys())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    model.eval()
+    t = {k: torch.from_numpy(v) for k, v in inp.items() if isinstance(v, np.ndarray)}
+    with torch.no_grad():
+        om, lm, fm, mm, im = model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
+                                   v_duration=t["v_duration"], video_ids=inp["video_ids"], music_ids=inp["music_ids"], is_train=False)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in om.items() if torch.is_tensor(v)}
+    got.update(retrieval_loss=lm["retrieval_loss"], localization_loss=lm["localization_loss"], loss_dict=lm["localization_loss_dict"])
+    check_variant(fix, name, got)
+    grouped = {id(p) for g in (model.get_temporal_parameter(), model.get_matching_parameter(), model.get_detection_parameter()) for p in g}
+    left = {n.split(".")[0] for n, p in model.named_parameters() if id(p) not in grouped}
+    if "regression" in name:       # reference model_Uni.py:112-113: only reg_mlp (and the CA block) train; the DETR stack is in no group
+        assert set(om) == {"pred_spans"} and left == {"decoder_query_embed", "detr_transformer"}
+    else:
+        assert left == {"decoder_query_embed"}
