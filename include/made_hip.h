@@ -294,6 +294,30 @@ int made_masked_softmax(const float* logits, int64_t ld_logits, const float* mas
                         void* probs, int32_t out_dtype, int64_t ldp,
                         int64_t M_outer, int64_t R, int64_t S, int64_t S_pad, float scale, void* stream);
 
+/* made_xpool_fused: all-pairs X-Pool scoring in one kernel (bf16, D = 256): for every (video n, track m)
+ *   softmax_s(<Q[n], K[m,s]> * scale + mask) . U[m,s,:] -> LayerNorm2 -> x + (Wl x + bl) -> LayerNorm3 -> cosine with vn[n]
+ *   -> sims[n*ld_sims + m].
+ * Replaces, for retrieval (reference test-MaDe.py:392-403), the chain modules/transformer.py:110-123 (attention; out_proj is
+ * hoisted onto the values by the caller: U = out_proj(v_proj(LN1(seg))), valid because the softmax rows sum to 1),
+ * :172-178 (LayerNorm2, linear_proj with residual, LayerNorm3) and modules/metrics.py:19-24 (cosine) -- no [Nm*Nv, D]
+ * tensor is ever written.  Q = q_proj(LN1(video)) [Nv, D]; K = k_proj(LN1(seg)), U [Nm, S, D] (rows at m*{k,u}_bs + s*ld);
+ * key_mask [Nm, S] f32 or NULL; vn = video / |video| [Nv, D] f32.  A track with no valid segment gives NaN, like the
+ * reference's softmax over -inf. */
+typedef struct MadeXpoolFusedArgs {
+    const void* Q; int64_t ldq;
+    const void* K; const void* U; int64_t k_bs, ldk, u_bs, ldu;
+    const float* key_mask;
+    const float* ln2_g; const float* ln2_b;
+    const void* Wl; int64_t ldw; const float* bl;
+    const float* ln3_g; const float* ln3_b;
+    const float* vn; int64_t ldvn;
+    float* sims; int64_t ld_sims;
+    int64_t Nv, Nm, S, D;
+    float scale, eps;
+} MadeXpoolFusedArgs;
+
+int made_xpool_fused(const MadeXpoolFusedArgs* args, void* stream);
+
 /* X-Pool tail: y [Nm*Nv, D] (the pre-LayerNorm3 sum, reference modules/transformer.py:177) ->
  * LayerNorm3 -> (optional) pooled[m,n,:] -> cosine with video n -> sims[n*ld_sims + m].
  * Fuses reference modules/transformer.py:178 with modules/metrics.py:19-24 so the pooled tensor

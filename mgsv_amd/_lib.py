@@ -80,6 +80,13 @@ class MadeAttnBwdArgs(C.Structure):
                 ("batch_order", vp)]
 
 
+class MadeXpoolFusedArgs(C.Structure):
+    _fields_ = [("Q", vp), ("ldq", i64), ("K", vp), ("U", vp), ("k_bs", i64), ("ldk", i64), ("u_bs", i64), ("ldu", i64),
+                ("key_mask", vp), ("ln2_g", vp), ("ln2_b", vp), ("Wl", vp), ("ldw", i64), ("bl", vp), ("ln3_g", vp), ("ln3_b", vp),
+                ("vn", vp), ("ldvn", i64), ("sims", vp), ("ld_sims", i64),
+                ("Nv", i64), ("Nm", i64), ("S", i64), ("D", i64), ("scale", f32), ("eps", f32)]
+
+
 class MadeWideAttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("Kadd", vp), ("V", vp), ("O", vp), ("key_mask", vp),
                 ("dtype", i32), ("o_dtype", i32),
@@ -149,6 +156,7 @@ SIGNATURES = {
     "made_repack": (C.c_int, [vp, i32, i64, vp]),
     "made_row_groups": (C.c_int, [vp, i64, vp, vp]),
     "made_row_index": (C.c_int, [vp, i64, vp, vp, vp]),
+    "made_xpool_fused": (C.c_int, [C.POINTER(MadeXpoolFusedArgs), vp]),
     "made_batch_order": (C.c_int, [vp, i64, i64, vp, vp]),
     "made_recall_ranks": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp]),
     "made_span_iou": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, vp]),

@@ -328,6 +328,27 @@ class MadeEngine:
         v1 = ops.layernorm(video, P[tower + ".ln1.g"], P[tower + ".ln1.b"], out_dtype=tc)
         q = ops.linear(v1, P[tower + ".q.w"], P[tower + ".q.b"])
         hoist = Nv > S          # out_proj commutes with the softmax-weighted sum (rows sum to 1): apply it to U instead
+        if tc == torch.bfloat16 and D == 256 and pooled_out is None and Nv >= 256:
+            # retrieval scale: the per-pair chain (attention -> LayerNorm2 -> Linear + residual -> LayerNorm3 -> cosine) in one
+            # kernel, nothing per pair ever written to HBM (made_xpool_fused); the per-track K / U projections stay GEMMs
+            vn = ops.l2norm_rows(video)
+            cm = min(Nm, max(1, (2 << 30) // (3 * S * D * tc.itemsize)), 65535)
+            s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
+            kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
+            ubuf = torch.empty(cm * S, D, device=dev, dtype=tc)
+            ubuf2 = torch.empty(cm * S, D, device=dev, dtype=tc)
+            for m0 in range(0, Nm, cm):
+                n = min(cm, Nm - m0)
+                skip = seg_mask[m0:m0 + n].reshape(-1) if seg_mask is not None else None
+                ops.layernorm(seg[m0:m0 + n], P[tower + ".ln1.g"], P[tower + ".ln1.b"], out=s1[:n * S], row_skip=skip)
+                ops.linear(s1[:n * S], P[tower + ".kv.w"], P[tower + ".kv.b"], tile_skip_mask=skip,
+                           segs=[Seg(out=kbuf, col_begin=0), Seg(out=ubuf, col_begin=D)])
+                ops.linear(ubuf[:n * S], P[tower + ".out.w"], P[tower + ".out.b"], out=ubuf2[:n * S], tile_skip_mask=skip)
+                ops.xpool_fused(q, kbuf[:n * S].view(n, S, D), ubuf2[:n * S].view(n, S, D),
+                                seg_mask[m0:m0 + n] if seg_mask is not None else None,
+                                (P[tower + ".ln2.g"], P[tower + ".ln2.b"]), P[tower + ".lin.w"], P[tower + ".lin.b"],
+                                (P[tower + ".ln3.g"], P[tower + ".ln3.b"]), vn, sims_out[:, m0:m0 + n], scale=1.0 / math.sqrt(D))
+            return sims_out
         cm = min(chunk_m, Nm)
         s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
         kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)

@@ -445,6 +445,31 @@ def xpool_tail(y: Tensor, gamma: Tensor, beta: Tensor, video: Tensor, sims: Tens
     return sims
 
 
+def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2, Wl: Tensor, bl: Tensor, ln3, vn: Tensor,
+                sims: Tensor, scale: float, eps: float = 1e-5) -> Tensor:
+    """All-pairs X-Pool scoring in one launch (made_xpool_fused; bf16, D = 256): Q [Nv,D], K / U [Nm,S,D] (unit inner stride),
+    key_mask [Nm,S] or None, ln2 / ln3 = (gamma, beta) f32, Wl [D,D] bf16, bl f32, vn [Nv,D] f32 (L2-normalised videos)
+    -> sims[n, m] written into `sims` ([Nv, >= Nm] f32 view)."""
+    from ._lib import MadeXpoolFusedArgs
+    Nv, D = Q.shape
+    Nm, S, _ = K.shape
+    assert Q.dtype == K.dtype == U.dtype == Wl.dtype == torch.bfloat16 and Q.stride(1) == 1 and K.stride(2) == 1 and U.stride(2) == 1
+    assert U.shape == K.shape and Wl.shape == (D, D) and Wl.stride(1) == 1 and vn.shape == (Nv, D) and vn.dtype == torch.float32
+    assert sims.dtype == torch.float32 and sims.stride(1) == 1 and sims.shape[0] == Nv and sims.shape[1] >= Nm
+    a = MadeXpoolFusedArgs()
+    a.Q, a.ldq = _p(Q), Q.stride(0)
+    a.K, a.U, a.k_bs, a.ldk, a.u_bs, a.ldu = _p(K), _p(U), K.stride(0), K.stride(1), U.stride(0), U.stride(1)
+    a.key_mask = _p(_f32(key_mask.contiguous(), "key_mask")) if key_mask is not None else None
+    a.ln2_g, a.ln2_b, a.ln3_g, a.ln3_b = _p(_f32(ln2[0], "ln2")), _p(_f32(ln2[1], "ln2")), _p(_f32(ln3[0], "ln3")), _p(_f32(ln3[1], "ln3"))
+    a.Wl, a.ldw, a.bl = _p(Wl), Wl.stride(0), _p(_f32(bl, "bl"))
+    a.vn, a.ldvn = _p(vn), vn.stride(0)
+    a.sims, a.ld_sims = _p(sims), sims.stride(0)
+    a.Nv, a.Nm, a.S, a.D, a.scale, a.eps = Nv, Nm, S, D, scale, eps
+    flops = 2.0 * Nv * Nm * (2 * S * D + D * D)
+    _timed("xpool_fused", flops, 0.0, lambda: check(lib().made_xpool_fused(C.byref(a), _stream()), "made_xpool_fused"))
+    return sims
+
+
 def clip_loss(sims: Tensor, logit_scale: Tensor, loss_out: Tensor, weight: float = 1.0, accumulate: bool = False) -> Tensor:
     assert sims.dim() == 2 and sims.shape[0] == sims.shape[1] and sims.stride(1) == 1 and sims.dtype == torch.float32
     check(lib().made_clip_loss(_p(sims), sims.stride(0), sims.shape[0], _p(logit_scale), weight, 1 if accumulate else 0,

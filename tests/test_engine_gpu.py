@@ -182,3 +182,32 @@ def test_engine_rejects_unsupported_configs_loudly():
     inp = synth.make_inputs(cfg, 2, 30, 512, seed=1)
     with pytest.raises(ValueError):      # the reference raises at model_Base.py:533 when T_a > 300
         eng.forward_numpy(inp)
+
+
+@pytest.mark.parametrize("N_v,N_m,S", [(300, 37, 96), (257, 5, 40), (640, 12, 130)])
+def test_retrieval_bf16_fused_xpool_kernel(N_v, N_m, S):
+    """made_xpool_fused (bf16, D = 256, retrieval scale): the one-kernel per-pair chain against the f32 oracle within the bf16
+    tolerance of the similarity matrix, and against the unfused bf16 path (same tolerance class, different rounding points)."""
+    cfg = cfg_native()
+    sd = synth.make_state_dict(cfg, seed=0)
+    eng = MadeEngine(cfg, sd, dtype="bf16")
+    dev = eng.device
+    ri = synth.make_retrieval_inputs(N_v, N_m, S, cfg.D, seed=7, min_len=3)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in ri.items()}
+    sim = eng.retrieval_sim_matrix(t["video_embeds"], t["segment_embeds"], t["segment_masks"], t["music_embeds"])
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.retrieval_sim_matrix(O.to_torch_params(sd), cfg, ri["video_embeds"], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
+    err = float((sim.cpu() - ref).abs().max())
+    assert err <= 3e-2, err
+    # the unfused path (taken below 256 videos): same quantity, rows computed in two slices
+    parts = [eng.retrieval_sim_matrix(t["video_embeds"][a:a + 200], t["segment_embeds"], t["segment_masks"], t["music_embeds"])
+             for a in range(0, N_v, 200)]
+    unfused = torch.cat(parts, 0)
+    torch.cuda.synchronize()
+    assert float((unfused.cpu() - ref).abs().max()) <= 3e-2
+    assert float((sim - unfused).abs().max()) <= 3e-2
+    # ranking agreement with the oracle on the top-1 track of each video, where the margin is not a rounding tie
+    top_ref = ref.topk(2, dim=1)
+    clear = (top_ref.values[:, 0] - top_ref.values[:, 1]) > 6e-2
+    assert bool((sim.cpu().argmax(1)[clear] == top_ref.indices[:, 0][clear]).all())
