@@ -302,7 +302,7 @@ int made_masked_softmax(const float* logits, int64_t ld_logits, const float* mas
  * :172-178 (LayerNorm2, linear_proj with residual, LayerNorm3) and modules/metrics.py:19-24 (cosine) -- no [Nm*Nv, D]
  * tensor is ever written.  Q = q_proj(LN1(video)) [Nv, D]; K = k_proj(LN1(seg)), U [Nm, S, D] (rows at m*{k,u}_bs + s*ld);
  * key_mask [Nm, S] f32 or NULL; vn = video / |video| [Nv, D] f32.  A track with no valid segment gives NaN, like the
- * reference's softmax over -inf. */
+ * reference's softmax over -inf.  LayerNorm variances are taken in one pass (E[x^2] - E[x]^2, f32): a bf16-path kernel. */
 typedef struct MadeXpoolFusedArgs {
     const void* Q; int64_t ldq;
     const void* K; const void* U; int64_t k_bs, ldk, u_bs, ldu;
@@ -314,6 +314,9 @@ typedef struct MadeXpoolFusedArgs {
     float* sims; int64_t ld_sims;
     int64_t Nv, Nm, S, D;
     float scale, eps;
+    float* ws;                 /* workspace, Nv*(D+2) + 4 floats: per-video terms of LayerNorm3 + cosine that do not depend on the track */
+    int32_t prepare_ws; int32_t _pad;   /* 1: fill ws from vn / ln3 first (a small launch); 0: ws is still valid from a previous call
+                                           with the same vn and ln3 (the caller loops over chunks of tracks) */
 } MadeXpoolFusedArgs;
 
 int made_xpool_fused(const MadeXpoolFusedArgs* args, void* stream);

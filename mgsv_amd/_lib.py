@@ -84,7 +84,7 @@ class MadeXpoolFusedArgs(C.Structure):
     _fields_ = [("Q", vp), ("ldq", i64), ("K", vp), ("U", vp), ("k_bs", i64), ("ldk", i64), ("u_bs", i64), ("ldu", i64),
                 ("key_mask", vp), ("ln2_g", vp), ("ln2_b", vp), ("Wl", vp), ("ldw", i64), ("bl", vp), ("ln3_g", vp), ("ln3_b", vp),
                 ("vn", vp), ("ldvn", i64), ("sims", vp), ("ld_sims", i64),
-                ("Nv", i64), ("Nm", i64), ("S", i64), ("D", i64), ("scale", f32), ("eps", f32)]
+                ("Nv", i64), ("Nm", i64), ("S", i64), ("D", i64), ("scale", f32), ("eps", f32), ("ws", vp), ("prepare_ws", i32), ("_pad", i32)]
 
 
 class MadeWideAttnArgs(C.Structure):

@@ -337,6 +337,7 @@ class MadeEngine:
             kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
             ubuf = torch.empty(cm * S, D, device=dev, dtype=tc)
             ubuf2 = torch.empty(cm * S, D, device=dev, dtype=tc)
+            xws = torch.empty(Nv * (D + 2) + 4, device=dev, dtype=torch.float32)
             for m0 in range(0, Nm, cm):
                 n = min(cm, Nm - m0)
                 skip = seg_mask[m0:m0 + n].reshape(-1) if seg_mask is not None else None
@@ -347,7 +348,8 @@ class MadeEngine:
                 ops.xpool_fused(q, kbuf[:n * S].view(n, S, D), ubuf2[:n * S].view(n, S, D),
                                 seg_mask[m0:m0 + n] if seg_mask is not None else None,
                                 (P[tower + ".ln2.g"], P[tower + ".ln2.b"]), P[tower + ".lin.w"], P[tower + ".lin.b"],
-                                (P[tower + ".ln3.g"], P[tower + ".ln3.b"]), vn, sims_out[:, m0:m0 + n], scale=1.0 / math.sqrt(D))
+                                (P[tower + ".ln3.g"], P[tower + ".ln3.b"]), vn, sims_out[:, m0:m0 + n], scale=1.0 / math.sqrt(D),
+                                ws=xws, prepare_ws=(m0 == 0))
             return sims_out
         cm = min(chunk_m, Nm)
         s1 = torch.empty(cm * S, D, device=dev, dtype=tc)

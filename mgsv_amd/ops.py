@@ -446,7 +446,7 @@ def xpool_tail(y: Tensor, gamma: Tensor, beta: Tensor, video: Tensor, sims: Tens
 
 
 def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2, Wl: Tensor, bl: Tensor, ln3, vn: Tensor,
-                sims: Tensor, scale: float, eps: float = 1e-5) -> Tensor:
+                sims: Tensor, scale: float, eps: float = 1e-5, ws: Optional[Tensor] = None, prepare_ws: bool = True) -> Tensor:
     """All-pairs X-Pool scoring in one launch (made_xpool_fused; bf16, D = 256): Q [Nv,D], K / U [Nm,S,D] (unit inner stride),
     key_mask [Nm,S] or None, ln2 / ln3 = (gamma, beta) f32, Wl [D,D] bf16, bl f32, vn [Nv,D] f32 (L2-normalised videos)
     -> sims[n, m] written into `sims` ([Nv, >= Nm] f32 view)."""
@@ -465,6 +465,11 @@ def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2
     a.vn, a.ldvn = _p(vn), vn.stride(0)
     a.sims, a.ld_sims = _p(sims), sims.stride(0)
     a.Nv, a.Nm, a.S, a.D, a.scale, a.eps = Nv, Nm, S, D, scale, eps
+    if ws is None:
+        ws = torch.empty(Nv * (D + 2) + 4, device=Q.device, dtype=torch.float32)
+        prepare_ws = True
+    assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.numel() >= Nv * (D + 2) + 4
+    a.ws, a.prepare_ws = _p(ws), 1 if prepare_ws else 0
     flops = 2.0 * Nv * Nm * (2 * S * D + D * D)
     _timed("xpool_fused", flops, 0.0, lambda: check(lib().made_xpool_fused(C.byref(a), _stream()), "made_xpool_fused"))
     return sims
