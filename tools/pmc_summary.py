@@ -5,7 +5,7 @@ import collections, csv, json, sys
 
 
 def kind(name):
-    if "linear_glds_kernel" in name or "linear_skinny_kernel" in name:
+    if "linear_glds_kernel" in name or "linear_skinny_kernel" in name or "linear_tiny_kernel" in name:
         return "linear_bf16"                       # what bench.py times as made_linear bf16 (the split-K launches use linear_kernel<bf16,bf16>)
     if "linear_kernelIDF16bDF16b" in name:
         return "linear_splitk_bf16"
@@ -14,7 +14,7 @@ def kind(name):
     if "linear_kernelIff" in name or "linear_kernel<float, float>" in name:
         return "linear_f32"
     for k in ("attention_wide_kernel", "attention_kernel", "attn_bwd_dkv", "attn_bwd_dq", "gemm_tn_kernel", "layernorm_bwd", "layernorm_add",
-              "layernorm_kernel", "splitk_finish", "masked_mean", "xpool_tail"):
+              "layernorm_kernel", "splitk_finish", "masked_mean", "xpool_tail", "xpool_fused"):
         if k in name:
             return k
     return None
