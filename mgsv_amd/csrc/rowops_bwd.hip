@@ -54,6 +54,50 @@ __device__ __forceinline__ void flush_cols(float* __restrict__ dst, const f32x4*
     __syncthreads();
 }
 
+// ---- element-wise gate: out = dropout(x * act'(G) * scale) ------------------------------------------
+// (the same options a made_linear epilogue carries, for the places of a backward chain where there is no GEMM to carry them)
+__device__ __forceinline__ float gate_grad(float g, int gate) {
+    switch (gate) {
+        case MADE_GATE_RELU_OUT: return g != 0.f ? 1.f : 0.f;
+        case MADE_GATE_GELU_Z: {
+            const float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752440f));
+            return cdf + g * 0.39894228040143267794f * expf(-0.5f * g * g);
+        }
+        case MADE_GATE_QUICKGELU_Z: {
+            const float sg = 1.f / (1.f + expf(-1.702f * g));
+            return sg * (1.f + 1.702f * g * (1.f - sg));
+        }
+        case MADE_GATE_SIGMOID_OUT: return g * (1.f - g);
+        default: return 1.f;
+    }
+}
+
+__global__ __launch_bounds__(RT) void gate_rows_kernel(const void* x, int xdt, int64_t ldx, const void* G, int gdt, int64_t ldg, int gate,
+                                                       float scale, MadeDropout drop, int64_t drop_ld, void* out, int odt, int64_t ldo,
+                                                       const float* row_skip, int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (RT / 64) + (threadIdx.x >> 6);
+    if (row >= rows || (row_skip && row_skip[row] == 0.f)) return;
+    const uint32_t thr = made_drop_threshold(drop.p);
+    const float dsc = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        f32x4 v = ld4(x, xdt, row * ldx + c);
+        if (G) {
+            const f32x4 g = ld4(G, gdt, row * ldg + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= gate_grad(g[j], gate);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= scale;
+        if (drop.p > 0.f) {
+            const uint64_t base = (uint64_t)row * (uint64_t)drop_ld + (uint64_t)c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = keep_at(drop, thr, base + j) ? v[j] * dsc : 0.f;
+        }
+        st4(out, odt, row * ldo + c, v);
+    }
+}
+
 // ---- LayerNorm backward ---------------------------------------------------------------------------
 //   xhat = (x - mean) * rstd,  g = dy * gamma
 //   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ add];   dgamma += sum_rows dy * xhat;   dbeta += sum_rows dy
@@ -594,6 +638,21 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
         DISPATCH_NVB(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 4>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a));
     }
     return made_check_launch("made_layernorm_bwd");
+}
+
+extern "C" int made_gate_rows(const void* x, int32_t x_dtype, int64_t ldx, const void* G, int32_t g_dtype, int64_t ldg, int32_t gate,
+                              float scale, const MadeDropout* drop, int64_t drop_ld, void* out, int32_t out_dtype, int64_t ldo,
+                              const float* row_skip, int64_t rows, int64_t cols, void* stream) {
+    MADE_REQUIRE(x && out, "made_gate_rows: null pointer");
+    MADE_REQUIRE(gate == MADE_GATE_NONE || G != nullptr, "made_gate_rows: gate without G");
+    MADE_UNSUPPORTED(cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (G == nullptr || ldg % 4 == 0), "made_gate_rows: bad cols/strides");
+    if (rows <= 0) return MADE_OK;
+    MadeDropout d; d.seed = 0; d.site = 0; d.p = 0.f;
+    if (drop) d = *drop;
+    MADE_REQUIRE(d.p >= 0.f && d.p < 1.f, "made_gate_rows: dropout p out of [0,1)");
+    hipLaunchKernelGGL(gate_rows_kernel, dim3(blocks4(rows)), dim3(RT), 0, (hipStream_t)stream, x, x_dtype, ldx, G, g_dtype, ldg, gate, scale,
+                       d, drop_ld > 0 ? drop_ld : cols, out, out_dtype, ldo, row_skip, rows, (int)cols);
+    return made_check_launch("made_gate_rows");
 }
 
 extern "C" int made_pool_bwd(const float* mean, const float* dvec, const float* mask,

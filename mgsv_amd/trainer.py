@@ -53,9 +53,7 @@ class MadeTrainer(MadeEngine):
             bad.append(f"mml_fusion={c.mml_fusion}")
         if c.num_moment_queries != 1:
             bad.append("num_moment_queries > 1")
-        if c.with_act_after_proj:
-            bad.append("with_act_after_proj")
-        if c.moment_query_type not in ("video", "music"):
+        if c.moment_query_type not in ("video", "music", "zero", "random"):
             bad.append(f"moment_query_type={c.moment_query_type}")
         if c.vmr_fusion != "XA-music":
             bad.append(f"vmr_fusion={c.vmr_fusion}")
@@ -298,6 +296,8 @@ class MadeTrainer(MadeEngine):
         ws = {}
         for tag, T, Kin, depth in (("v", Tv, c.vit_dim, c.video_transformer_depth), ("a", Ta, c.ast_dim, c.audio_transformer_depth)):
             r = B * T
+            if c.with_act_after_proj:
+                ws[f"{tag}.zproj"] = E(r, D)
             ws.update({f"{tag}.xin": E(r, Kin), f"{tag}.xlast": E(r, D), f"{tag}.mean": E(B, D, dtype=f32),
                        f"{tag}.dl": E(r, D), f"{tag}.g1": E(r, D), f"{tag}.g2": E(r, D), f"{tag}.g3": E(r, D),
                        f"{tag}.gqkv": E(r, 3 * D), f"{tag}.gffn": E(r, Ft), f"{tag}.delta": E(B * Hh * T, dtype=f32)})
@@ -469,9 +469,12 @@ class MadeTrainer(MadeEngine):
         qp = P["query_embed"]
         hd = D // H
         ca_scale = 1.0 / math.sqrt(hd)
-        src_vec = video if c.moment_query_type == "video" else music
         tgt = tw["d.0.tgt"]
-        tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        if c.moment_query_type in ("video", "music"):
+            src_vec = video if c.moment_query_type == "video" else music
+            tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        else:                                                # "zero" / "random": reference music_detr/transformer.py:73-74
+            tgt.zero_()
         tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
         hs = ws["hs"]
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
@@ -555,11 +558,13 @@ class MadeTrainer(MadeEngine):
         rws = self._rw(mflat)
         pt = dr.P_TEMPORAL
         name = "video" if which == "video" else "audio"
+        act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE       # reference model_Base.py:559-561
+        zp = tw[tag + ".zproj"] if c.with_act_after_proj else None             # pre-activation, for the backward gate
         if self.tc == torch.bfloat16:
             xin = ops.cast_mask_rows(feats.view(nrow, Kin), mflat, tw[tag + ".xin"])
-            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], R=P[pe][:T], r_row_mod=T, out=tw[f"{tag}.0.x0"], rows=rws)
+            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, Zout=zp, R=P[pe][:T], r_row_mod=T, out=tw[f"{tag}.0.x0"], rows=rws)
         else:
-            x = ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, R=P[pe][:T], r_row_mod=T,
+            x = ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act, Zout=zp, R=P[pe][:T], r_row_mod=T,
                            out=tw[f"{tag}.0.x0"], rows=rws)
         for l in range(depth):
             p, t = f"{mod}.layers.{l}", f"{tag}.{l}"
@@ -876,8 +881,9 @@ class MadeTrainer(MadeEngine):
 
         # ---------------- join the X-Pool / similarity branch, merge the gradients of the clip-level vectors
         cur.wait_stream(side)
-        dq_vec = dvideo if c.moment_query_type == "video" else dmusic
-        tr.add3(dq_vec, dq_vec, dtgt0.view(B, D))
+        if c.moment_query_type in ("video", "music"):       # (a zero content query has no gradient to hand on)
+            dq_vec = dvideo if c.moment_query_type == "video" else dmusic
+            tr.add3(dq_vec, dq_vec, dtgt0.view(B, D))
 
         # ---------------- temporal encoders (video on the second stream)
         side.wait_stream(cur)
@@ -967,7 +973,7 @@ class MadeTrainer(MadeEngine):
                 dx4 = g2
             else:                                            # deeper stacks: x0_{l+1} = x4_l, its gradient arrives from LN1 of layer l+1
                 dx4 = dx
-                df = tr.add3(g1, dx4) if not self.training_dropout else self._dropped_copy(g1, dx4, f"{name}.{l}.ffn_out", pt, D)
+                df = tr.gate_rows(dx4, g1, drop=self._drop(f"{name}.{l}.ffn_out", pt), drop_ld=D, row_skip=mflat)
             dz1 = self._lin_bwd(df, tw[t + ".h"], p + ".ff2", dx_out=gf, row_mask=mflat, skip=mflat, gate=_lib.GATE_GELU_Z, G=tw[t + ".z1"],
                                 drop=self._drop(f"{name}.{l}.ffn_act", pt))
             dx3 = self._lin_bwd(dz1, tw[t + ".x3"], p + ".ff1", dx_out=g3, row_mask=mflat, skip=mflat, R=dx4)
@@ -981,10 +987,9 @@ class MadeTrainer(MadeEngine):
             dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3, row_mask=mflat, skip=mflat, R=g1)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
         xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
+        if c.with_act_after_proj:                            # x0 = quickgelu(z) + pe: gradient w.r.t. z (the input itself needs none)
+            dx = tr.gate_rows(dx, g1, G=tw[tag + ".zproj"], gate=_lib.GATE_QUICKGELU_Z, row_skip=mflat)
         tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], rows=self._rw(mflat))
-
-    def _dropped_copy(self, out: Tensor, x: Tensor, site: str, p: float, ld: int) -> Tensor:
-        raise NotImplementedError("temporal transformer depth > 1 is not covered by the training path yet")
 
     # ================================================================== convenience
     def loss_and_grads(self, inp: dict, seed: int = 0, w_ret: float = 1.0, w_loc: float = 1.0) -> dict:

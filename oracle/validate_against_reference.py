@@ -220,6 +220,8 @@ def main():
     report["grad_train_native_Q3_B4"] = compare_backward(c, 4, 20, 40, "native Q=3 train-mode grads", train=True)   # B != Q: layouts unambiguous
     c = cfg_native(); c.mml_fusion = "CA"
     report["grad_train_native_CA_B3"] = compare_backward(c, 3, 20, 40, "native CA-fusion train-mode grads", train=True)
+    c = cfg_native(); c.video_transformer_depth = c.audio_transformer_depth = 2; c.with_act_after_proj = 1; c.moment_query_type = "zero"
+    report["grad_train_native_depth2_act_zeroquery_B3"] = compare_backward(c, 3, 20, 40, "native depth-2 / act / zero-query train-mode grads", train=True)
     report["lsap_vs_scipy"] = compare_lsap()
     report["retrieval_N48x40_S96"] = compare_retrieval(cfg_native(), 48, 40, 96)
     worst = max(v for k, sec in report.items() if isinstance(sec, dict) and not k.startswith("grad_")

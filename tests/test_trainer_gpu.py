@@ -66,6 +66,8 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
 
 @pytest.mark.parametrize("dropout", [False, True])
 @pytest.mark.parametrize("overrides", [{}, {"vmr_loss": "dual_single_sim_fuse", "moment_query_type": "music"}, {"mml_fusion": "CA"},
+                                       {"with_act_after_proj": 1, "moment_query_type": "zero"},
+                                       {"video_transformer_depth": 2, "audio_transformer_depth": 2, "with_act_after_proj": 1},
                                        {"mml_fusion": "CA", "detr_enc_layers": 0, "vmr_loss": "single"}])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
