@@ -29,47 +29,72 @@ constexpr int W_ROW = XD * 2 + 16;
 constexpr int KV_BYTES = XKEY * K_ROW + XKEY * V_ROW;
 constexpr int W_BYTES = 128 * W_ROW;
 constexpr int STAGE_BYTES = W_BYTES > KV_BYTES ? W_BYTES : KV_BYTES;
-constexpr int XLDS = STAGE_BYTES + 5 * XD * 4 + XKEY * 4 + 16;
+static_assert(XT == XD, "the prologue stages one vector element per thread");
+constexpr int XS_MAX = 1024;            // segments per track this kernel accepts (its mask row lives in LDS)
+constexpr int XLDS = STAGE_BYTES + 5 * XD * 4 + XKEY * 4 + XS_MAX * 4;
 
 __global__ __launch_bounds__(XT, 1) void xpool_fused_kernel(const MadeXpoolFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* vec = (float*)(lds + STAGE_BYTES);          // [5][256]: ln2 gamma, ln2 beta, linear bias, ln3 gamma^2, ln3 gamma*beta
     float* lds_bias = vec + 5 * XD;                    // [32]
-    int* red = (int*)(lds_bias + XKEY);                // [4]
+    float* lds_mask = lds_bias + XKEY;                 // [S]: the track's mask row (all ones without a mask)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int64_t m = blockIdx.y;
     const int64_t my_n = (int64_t)blockIdx.x * XQ + wave * 32 + r;
     const int64_t nc = my_n < a.Nv ? my_n : a.Nv - 1;
 
-    for (int i = tid; i < XD; i += XT) {
-        vec[i] = a.ln2_g[i]; vec[XD + i] = a.ln2_b[i]; vec[2 * XD + i] = a.bl[i];
-        const float g3 = a.ln3_g[i], b3 = a.ln3_b[i];
-        vec[3 * XD + i] = g3 * g3; vec[4 * XD + i] = g3 * b3;
-    }
+    const bf16_t* Kg = (const bf16_t*)a.K + m * a.k_bs;
+    const bf16_t* Ug = (const bf16_t*)a.U + m * a.u_bs;
+    const float* maskg = a.key_mask ? a.key_mask + m * a.S : nullptr;
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[n][ks*16 + hh*8 ..]
+    // ---- everything the workgroup needs first is requested in ONE round trip: the small vectors, the track's mask row, the
+    // per-video scalars, the Q fragments and the first K / U tile (one workgroup per CU: nobody else hides these latencies)
+    const float v0 = a.ln2_g[tid], v1 = a.ln2_b[tid], v2 = a.bl[tid], g3 = a.ln3_g[tid], b3 = a.ln3_b[tid];
+    float mrow[XS_MAX / XT];
+#pragma unroll
+    for (int i = 0; i < XS_MAX / XT; ++i) {
+        const int j = tid + i * XT;
+        float mv = 1.f;
+        if (maskg) mv = maskg[j < (int)a.S ? j : 0];   // (uniform branch; the load itself is unconditional, index clamped)
+        mrow[i] = j < (int)a.S ? mv : 0.f;
+    }
+    const float* pvp = a.ws + a.Nv * XD + nc * 2;      // sum g v, sum b v of this lane's video
+    const float* csp = a.ws + a.Nv * (XD + 2);         // sum g^2, sum g b, sum b^2
+    const float p0 = pvp[0], pb = pvp[1], c0 = csp[0], e0 = csp[1], f0 = csp[2];
+    // Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[n][ks*16 + hh*8 ..]
     bf16x8 qf[XD / 16];
     {
         const bf16_t* qp = (const bf16_t*)a.Q + nc * a.ldq + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < XD / 16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
     }
-    const bf16_t* Kg = (const bf16_t*)a.K + m * a.k_bs;
-    const bf16_t* Ug = (const bf16_t*)a.U + m * a.u_bs;
-    const float* maskg = a.key_mask ? a.key_mask + m * a.S : nullptr;
-
-    // segments after the last valid one contribute exactly 0: stop there
-    int64_t s_eff = a.S;
-    if (maskg) {
+    bf16x8 rk[4], rv[4];
+    bf16x8 rw[16];
+    auto load_kv = [&](int64_t t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                  // branch-free: always load (row clamped), mask on the registers
+            const int ch = tid + i * XT, row = ch >> 5, cc = ch & 31;
+            const int64_t key = t * XKEY + row;
+            const int64_t kcl = key < a.S ? key : a.S - 1;
+            rk[i] = *(const bf16x8*)(Kg + kcl * a.ldk + cc * 8);
+            rv[i] = *(const bf16x8*)(Ug + kcl * a.ldu + cc * 8);
+        }
+    };
+    load_kv(0);
+    vec[tid] = v0; vec[XD + tid] = v1; vec[2 * XD + tid] = v2; vec[3 * XD + tid] = g3 * g3; vec[4 * XD + tid] = g3 * b3;
+#pragma unroll
+    for (int i = 0; i < XS_MAX / XT; ++i) lds_mask[tid + i * XT] = mrow[i];
+    __syncthreads();
+    // segments after the last valid one contribute exactly 0: stop there (every wave scans the row itself: no second barrier)
+    int64_t s_eff;
+    {
         int last = -1;
-        for (int j = tid; j < (int)a.S; j += XT)
-            if (maskg[j] != 0.f) last = j;
+        for (int j = lane; j < (int)a.S; j += 64)
+            if (lds_mask[j] != 0.f) last = j;
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
-        if (lane == 0) red[wave] = last;
-        __syncthreads();
-        s_eff = max(max(red[0], red[1]), max(red[2], red[3])) + 1;
+        s_eff = last + 1;
     }
     const int64_t ntiles = (s_eff + XKEY - 1) / XKEY;
 
@@ -84,22 +109,7 @@ __global__ __launch_bounds__(XT, 1) void xpool_fused_kernel(const MadeXpoolFused
     unsigned char* lds_v = lds + XKEY * K_ROW;
     const int g = lane >> 4, i16 = lane & 15;
 
-    // K / U tile t+1 (and, under the last tile, the first half of the Linear's weight) travel global -> registers while tile t
-    // is multiplied: one workgroup per CU leaves nobody else to hide that latency
-    bf16x8 rk[4], rv[4];
-    float mk[4];
-    bf16x8 rw[16];
-    auto load_kv = [&](int64_t t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                  // branch-free: always load (row clamped), mask on the registers
-            const int ch = tid + i * XT, row = ch >> 5, cc = ch & 31;
-            const int64_t key = t * XKEY + row;
-            const int64_t kcl = key < a.S ? key : a.S - 1;
-            rk[i] = *(const bf16x8*)(Kg + kcl * a.ldk + cc * 8);
-            rv[i] = *(const bf16x8*)(Ug + kcl * a.ldu + cc * 8);
-            mk[i] = maskg ? maskg[kcl] : 1.f;
-        }
-    };
+    // K / U tile t+1 travels global -> registers while tile t is multiplied, the Linear's weight halves likewise
     auto load_w = [&](int h) __attribute__((always_inline)) {
         const bf16_t* Wg = (const bf16_t*)a.Wl + (int64_t)(128 * h) * a.ldw;
 #pragma unroll
@@ -120,21 +130,19 @@ __global__ __launch_bounds__(XT, 1) void xpool_fused_kernel(const MadeXpoolFused
             *(bf16x4*)(dst + ((cc & 1) ? 24 : 16)) = w1;
         }
     };
-    if (ntiles > 0) load_kv(0);
     for (int64_t t = 0; t < ntiles; ++t) {
         __syncthreads();                               // previous tile consumed (and the vectors / s_eff published)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ch = tid + i * XT, row = ch >> 5, cc = ch & 31;
-            const bool keep = (t * XKEY + row) < a.S && mk[i] != 0.f;
+            const int64_t key = t * XKEY + row;
+            const bool keep = key < a.S && lds_mask[key < a.S ? key : 0] != 0.f;
             *(bf16x8*)(lds_k + row * K_ROW + cc * 16) = keep_or_zero(rk[i], keep);
             *(bf16x8*)(lds_v + row * V_ROW + cc * 16) = keep_or_zero(rv[i], keep);
         }
         if (tid < XKEY) {
             const int64_t key = t * XKEY + tid;
-            const int64_t kcl = key < a.S ? key : a.S - 1;
-            const float mkb = maskg ? maskg[kcl] : 1.f;
-            lds_bias[tid] = (key < a.S && mkb != 0.f) ? 0.f : -INFINITY;
+            lds_bias[tid] = (key < a.S && lds_mask[key < a.S ? key : 0] != 0.f) ? 0.f : -INFINITY;
         }
         __syncthreads();
         if (t + 1 < ntiles) load_kv(t + 1);
@@ -299,9 +307,6 @@ __global__ __launch_bounds__(XT, 1) void xpool_fused_kernel(const MadeXpoolFused
     float s1 = S1[0] + S1[1], s2 = S2[0] + S2[1], p1 = P1[0] + P1[1], c2 = C2[0] + C2[1], c1 = C1[0] + C1[1], e1 = E1[0] + E1[1];
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); p1 += __shfl_xor(p1, 32);
     c2 += __shfl_xor(c2, 32); c1 += __shfl_xor(c1, 32); e1 += __shfl_xor(e1, 32);
-    const float* pv = a.ws + a.Nv * XD + nc * 2;       // sum g v, sum b v of this video
-    const float* cs = a.ws + a.Nv * (XD + 2);          // sum g^2, sum g b, sum b^2
-    const float p0 = pv[0], pb = pv[1], c0 = cs[0], e0 = cs[1], f0 = cs[2];
     const float mu = s1 * (1.f / XD);
     const float var = fmaxf(s2 * (1.f / XD) - mu * mu, 0.f);
     const float rs = 1.0f / sqrtf(var + a.eps);
@@ -345,6 +350,7 @@ extern "C" int made_xpool_fused(const MadeXpoolFusedArgs* args, void* stream) {
                  "made_xpool_fused: null pointer");
     MADE_REQUIRE(a.Nv >= 0 && a.Nm >= 0 && a.S > 0, "made_xpool_fused: bad dims");
     MADE_UNSUPPORTED(a.D == XD, "made_xpool_fused: D=%lld (built for %d)", (long long)a.D, XD);
+    MADE_UNSUPPORTED(a.S <= XS_MAX, "made_xpool_fused: S=%lld segments per track (at most %d)", (long long)a.S, XS_MAX);
     MADE_UNSUPPORTED(a.Nm <= 65535, "made_xpool_fused: more than 65535 tracks per call (chunk them)");
     MADE_UNSUPPORTED(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldu % 8 == 0 && a.k_bs % 8 == 0 && a.u_bs % 8 == 0 && a.ldw % 8 == 0 &&
                      a.ldvn % 4 == 0 && ((uintptr_t)a.ws % 16) == 0 && ((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.U % 16) == 0 &&
