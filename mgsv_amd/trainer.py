@@ -51,8 +51,6 @@ class MadeTrainer(MadeEngine):
         bad = []
         if "concat" not in c.mml_fusion and "CA" not in c.mml_fusion:
             bad.append(f"mml_fusion={c.mml_fusion}")
-        if c.num_moment_queries != 1:
-            bad.append("num_moment_queries > 1")
         if c.moment_query_type not in ("video", "music", "zero", "random"):
             bad.append(f"moment_query_type={c.moment_query_type}")
         if c.vmr_fusion != "XA-music":
@@ -323,6 +321,7 @@ class MadeTrainer(MadeEngine):
             e_delta=E(B * H * L, dtype=f32), eg1=E(rows, D), eg2=E(rows, D), eg3=E(rows, D), egqkv=E(rows, 3 * D), egffn=E(rows, Fd),
             dfus=E(rows, D),
             # decoder (rows = B*Q)
+            s_raw=E(B * HQ, dtype=f32), dds_raw=E(B * HQ, dtype=f32), gq_raw=E(B, HQ, D),
             d_tq0=E(B * Q, D), GQ=Z(B, 2, nd, HQ, D), PdS=Z(B, 2, nd, HQ, Lp), dS_S=E(B * HQ, Lp, dtype=f32), dS_dP=E(B * HQ, Lp, dtype=f32),
             dSt=E(B, L, HQ), d_ds=E(B * Q, H, dtype=f32), d_delta=E(B * H * Q, dtype=f32),
             dg1=E(B * Q, D), dg2=E(B * Q, D), dg3=E(B * Q, D), dg4=E(B * Q, D), dgqkv=E(B * Q, 3 * D), dgffn=E(B * Q, Fd),
@@ -497,10 +496,13 @@ class MadeTrainer(MadeEngine):
             qprime = GQ[:, 1, l]                              # [B, H*Q, D] view; q'_h = W_k,h^T qc_h  (b_k shifts all keys alike)
             ops.linear(qc[:, :hd], Wt[:, D:D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
                        segs=[Seg(out=qprime, ldo=D, rows_per_batch=Q, out_batch_stride=qprime.stride(0), out_z_stride=Q * D)])
-            pooled = tw[d + ".pooled"]                        # [B*Q, H*D] == [B, H, Q, D] for Q == 1
-            ops.attention_wide(qprime.view(B, H, Q, D), mempos3, mem3, pooled.view(B, H, Q, D), scale=ca_scale, key_mask=fus_mask,
-                               drop=self._drop(f"dec.{l}" + ".ca_attn", pd), sum_out=tw[d + ".s"],
+            pooled = tw[d + ".pooled"]                        # [B*Q, H*D]: row (b, q), head-major columns
+            s_out = tw[d + ".s"] if Q == 1 else tw["s_raw"]   # the kernel numbers its rows (b, h, q); the Linears below (b, q, h)
+            ops.attention_wide(qprime.view(B, H, Q, D), mempos3, mem3, pooled.view(B, Q, H, D).permute(0, 2, 1, 3), scale=ca_scale,
+                               key_mask=fus_mask, drop=self._drop(f"dec.{l}" + ".ca_attn", pd), sum_out=s_out,
                                n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
+            if Q > 1:
+                tw[d + ".s"].view(B, Q, H).copy_(s_out.view(B, H, Q).permute(0, 2, 1))
             attc = tw[d + ".attc"]
             ops.linear(pooled[:, :D], Win[2 * D:2 * D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
                        segs=[Seg(out=attc, ldo=D, out_z_stride=hd)])
@@ -511,7 +513,7 @@ class MadeTrainer(MadeEngine):
             tcx = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=t2, out=tw[d + ".t_c"], drop=self._drop(f"dec.{l}" + ".drop3", pd))
             t3 = tw[d + ".t3"]                                # = the content query of layer l + 1 (slot l + 1 of the tgt stack)
             if l + 1 < nd:
-                ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D), t3, tw[f"d.{l + 1}.tq"])
+                ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t3, tw[f"d.{l + 1}.tq"])
             else:
                 ops.layernorm(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], out=t3)
             ops.layernorm(t3, P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
@@ -761,6 +763,10 @@ class MadeTrainer(MadeEngine):
                              dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
             dattc = ops.linear(g_ca, P[p + ".ca.out.wt"], None, out=g_attc)
             tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], G[p + ".ca.in.b"][2 * D:], tw["d_ds"], H)
+            d_ds = tw["d_ds"]                                 # rows (b, q), columns h; the softmax backward numbers its rows (b, h, q)
+            if Q > 1:
+                tw["dds_raw"].view(B, H, Q).copy_(d_ds.view(B, Q, H).permute(0, 2, 1))
+                d_ds = tw["dds_raw"]
             # v_h = W_v,h pooled_h : dpooled_h = dattc_h W_v,h
             dpooled = GQ[:, 0, l]                             # [B, H*Q, D] slice of the concatenated buffer
             ops.linear(dattc[:, :hd], Wt[:, 2 * D:2 * D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
@@ -772,18 +778,21 @@ class MadeTrainer(MadeEngine):
                        segs=[Seg(out=S, ldo=Lp, out_z_stride=HQ * Lp)])
             ops.linear(dpooled[0], mem3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=dpooled.stride(0), w_z_stride=L * D,
                        segs=[Seg(out=dP, ldo=Lp, out_z_stride=HQ * Lp)])
-            tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=tw["d_ds"].view(-1),
+            tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=d_ds.view(-1),
                            drop=self._drop(f"dec.{l}" + ".ca_attn", pd), ldo=Lp, ldt=HQ, out_batch_stride=PdS.stride(0))
             # dq'[b] = dS[b] (mem + pos)[b]
-            tr.gemm_tn(tw["dSt"][0], mempos3[0], g_q[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
+            gq_out = g_q if Q == 1 else tw["gq_raw"]         # [B, (h, q), D] out of the product; [B, (q, h), D] for the Linears
+            tr.gemm_tn(tw["dSt"][0], mempos3[0], gq_out[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
                        row_mask=fus_mask, mask_zs=(L, 0))
+            if Q > 1:
+                g_q.view(B, Q, H, D).copy_(gq_out.view(B, H, Q, D).permute(0, 2, 1, 3))
             # q'_h = W_k,h^T qc_h : dqc_h = dq'_h W_k,h^T
             dq2 = g_q.view(B * Q, H * D)
             ops.linear(dq2[:, :D], Win[D:D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
                        segs=[Seg(out=g_qc, ldo=D, out_z_stride=hd)])
             # qc = W_q (t1 + qp) + b_q
             dt1q = ops.linear(g_qc, Wt[:, :D], None, out=g4)
-            tr.colsum(dt1q, G["query_embed"].view(-1))
+            tr.colsum(dt1q.view(B, Q * D), G["query_embed"].view(-1))
             tr.add3(g1, g2, dt1q)                             # dt1 = residual path + query path
             # t1 = LN1(tgt + drop1(self-attention))
             tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
@@ -797,7 +806,7 @@ class MadeTrainer(MadeEngine):
             dtgt = ops.linear(gqkv, P[p + ".sa.in.wt"], None, R=g2, out=tw["dtgt"])
             # the query embedding also enters through q,k of the self-attention
             dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
-            tr.colsum(dqk, G["query_embed"].view(-1))
+            tr.colsum(dqk.view(B, Q * D), G["query_embed"].view(-1))
         dtgt0 = dtgt                                          # gradient of the decoder's content query = the clip-level vector
 
         # ---- weight gradients of all decoder layers: one layer-batched product per parameter (the layers' parameters, and
@@ -883,7 +892,7 @@ class MadeTrainer(MadeEngine):
         cur.wait_stream(side)
         if c.moment_query_type in ("video", "music"):       # (a zero content query has no gradient to hand on)
             dq_vec = dvideo if c.moment_query_type == "video" else dmusic
-            tr.add3(dq_vec, dq_vec, dtgt0.view(B, D))
+            tr.add3(dq_vec, dq_vec, dtgt0.view(B, D) if Q == 1 else dtgt0.view(B, Q, D).float().sum(dim=1))    # the vector was repeated Q times
 
         # ---------------- temporal encoders (video on the second stream)
         side.wait_stream(cur)
