@@ -265,6 +265,12 @@ __global__ __launch_bounds__(XT, 1) void xpool_fused_kernel(const MadeXpoolFused
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) v4n[g4] = *(const f32x4*)(vp + (dt + 1) * 32 + 8 * g4 + 4 * hh);
             }
+            f32x4 g2v[4], gbv[4];                      // the epilogue's LayerNorm3 vectors: read under the MFMAs, not after them
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                g2v[g4] = *(const f32x4*)(vec + 3 * XD + dt * 32 + 8 * g4 + 4 * hh);
+                gbv[g4] = *(const f32x4*)(vec + 4 * XD + dt * 32 + 8 * g4 + 4 * hh);
+            }
             f32x16 acc;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {           // accumulator starts from the Linear's bias
@@ -282,8 +288,7 @@ __global__ __launch_bounds__(XT, 1) void xpool_fused_kernel(const MadeXpoolFused
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int dd = dt * 32 + 8 * g4 + 4 * hh;
-                const f32x4 g2 = *(const f32x4*)(vec + 3 * XD + dd), gb = *(const f32x4*)(vec + 4 * XD + dd);
+                const f32x4 g2 = g2v[g4], gb = gbv[g4];
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const int e = 4 * g4 + j;
