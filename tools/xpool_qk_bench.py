@@ -1,0 +1,43 @@
+"""The micro-benchmark BASELINE.json's north_star names: the X-Pool cross-attention core (QK^T over the segments, softmax, P.V)
+at B = 64 videos x 64 tracks, T_a = 512 segments, d = 512, bf16 (reference modules/transformer.py:110-119).  HBM-bound by
+construction (4.3 GFLOP against >= 67 MB of K / U): reports time, GB/s against the 8 TB/s HBM peak and TFLOP/s
+against the 2.5 PFLOP/s bf16 MFMA peak, for several key splits; then the same contraction at retrieval scale, where MFMA binds."""
+import math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mgsv_amd import ops
+
+dev, dt = torch.device("cuda"), torch.bfloat16
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def run(Nv, Nm, S, D, splits):
+    q = torch.randn(Nv, D, device=dev).to(dt)
+    k, u = torch.randn(Nm, S, D, device=dev).to(dt), torch.randn(Nm, S, D, device=dev).to(dt)
+    lens = torch.randint(12, S + 1, (Nm,), device=dev)
+    o = torch.empty(Nm * Nv, D, device=dev, dtype=dt)
+    flops = 4.0 * Nv * Nm * S * D
+    for name, mask in (("full-length tracks", None), ("ragged tracks (12..S segments)", (torch.arange(S, device=dev)[None] < lens[:, None]).float())):
+        frac = 1.0 if mask is None else float(mask.mean())
+        byts = 2.0 * Nm * S * D * 2 * frac + Nv * D * 2 + Nm * Nv * D * 2
+        for ns in splits:
+            t = timeit(lambda: ops.attention_wide(q.view(1, Nv, 1, D), k, u, o.view(Nm, Nv, 1, D), scale=1 / math.sqrt(D), key_mask=mask,
+                                                  shared_q=True, n_split=ns))
+            print(f"  Nv={Nv} Nm={Nm} S={S} D={D} {name:32s} n_split={ns}: {t:8.1f} us  {byts / t / 1e3:7.1f} GB/s ({byts / t / 1e3 / 8000 * 100:4.1f}% of HBM peak)  "
+                  f"{flops * frac / t / 1e6:7.1f} TFLOP/s ({flops * frac / t / 1e6 / 2500 * 100:4.1f}% of bf16 MFMA peak)", flush=True)
+
+
+print("in-batch X-Pool attention core, the shape north_star names:")
+run(64, 64, 512, 512, (1, 2, 4, 8))
+print("the scripts' native shape:")
+run(64, 64, 96, 256, (1, 2, 4))
+print("retrieval scale (unfused attention core only; the product path is made_xpool_fused, tools/xpool_only.py):")
+run(4096, 128, 96, 256, (1,))
