@@ -44,6 +44,8 @@ def _cases():
         "native_musicquery_nocontrast_B3": (c5, 3, 50, 96),
         "cfg2_shape_B4": (cfg_headline(), 4, 30, 512),
         "ragged_B3_Tv7_Ta13": (cfg_native(), 3, 7, 13),
+        "single_sample_B1_Tv3_Ta5": (cfg_native(), 1, 3, 5),
+        "odd_B7_Tv33_Ta131": (cfg_native(), 7, 33, 131),
     }
 
 

@@ -1,11 +1,13 @@
-import os, sys, torch
+"""Runs made_attention_wide alone at the in-batch X-Pool shape (for rocprofv3 --pmc passes)."""
+import math, os, sys
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mgsv_amd import ops
-dev = torch.device("cuda"); dt = torch.bfloat16
-B, H, D, L = 64, 8, 512, 542
-q = torch.randn(B, 1, H * D, device=dev).to(dt); mem = torch.randn(B, L, D, device=dev).to(dt); mp = torch.randn(B, L, D, device=dev).to(dt)
-o = torch.empty(B, 1, H * D, device=dev, dtype=dt)
-q4 = q.view(B, 1, H, D).permute(0, 2, 1, 3); o4 = o.view(B, 1, H, D).permute(0, 2, 1, 3)
-for _ in range(5):
-    ops.attention_wide(q4, mp, mem, o4, scale=0.125, key_mask=None, n_split=1)
+Nv, Nm, S, D = 64, 64, 512, 512
+ns = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+dev, dt = "cuda", torch.bfloat16
+q = torch.randn(Nv, D, device=dev).to(dt); k = torch.randn(Nm, S, D, device=dev).to(dt); u = torch.randn(Nm, S, D, device=dev).to(dt)
+o = torch.empty(Nm * Nv, D, device=dev, dtype=dt)
+for _ in range(6):
+    ops.attention_wide(q.view(1, Nv, 1, D), k, u, o.view(Nm, Nv, 1, D), scale=1 / math.sqrt(D), key_mask=None, shared_q=True, n_split=ns)
 torch.cuda.synchronize()
