@@ -30,13 +30,17 @@ template <> struct Frag<float>  { typedef f32x4  type; };
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 
 
-template <typename TC, int D, bool DB>
+// NSL = D slices per query tile: 4 -> one tile of 32 queries per workgroup, its four waves split D four ways; 2 -> two query
+// tiles per workgroup (waves 0-1 and 2-3), each split two ways: the K / V tiles staged through LDS then serve 64 queries, which
+// halves the staging per flop where a batch entry has 64 or more query rows (X-Pool: all videos against one track).
+template <typename TC, int D, bool DB, int NSL>
 __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWideAttnArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
     constexpr bool IS_BF16 = SZ == 2;
     constexpr int PER16 = 16 / SZ;
-    constexpr int DS = D / 4;                       // this wave's slice of D
+    constexpr int DS = D / NSL;                     // this wave's slice of D
+    constexpr int WQB = WQ * (4 / NSL);             // queries per workgroup
     constexpr int K_ROW = D * SZ + 16;              // padded: conflict-free 16-byte row reads
     constexpr int V_ROW = D * SZ + (IS_BF16 ? 64 : 16);   // bf16: 4 consecutive rows land on disjoint bank quarters (tr reads)
     constexpr int CPR = D * SZ / 16;                // 16-byte chunks per row
@@ -54,9 +58,14 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int64_t b = blockIdx.y;
+    const int sl = wave % NSL, qt = wave / NSL;     // D slice and query tile of this wave
+    // few query tiles per batch entry (in-batch X-Pool: 2): the batch index runs fastest, so the query tiles of one entry are
+    // gridDim.x apart in dispatch order = on the same XCD when the batch is a multiple of 8, and share its K / V in that L2;
+    // many query tiles (retrieval scale): the tiles of an entry are consecutive workgroups and share it in time instead
+    const bool batch_fast = gridDim.x == (unsigned)a.B && (a.NQ1 * a.NQ2 + WQB - 1) / WQB != (int64_t)a.B;
+    const int64_t b = batch_fast ? blockIdx.x : blockIdx.y;
     const int64_t nq_total = a.NQ1 * a.NQ2;
-    const int64_t nq0 = (int64_t)blockIdx.x * WQ;
+    const int64_t nq0 = (int64_t)(batch_fast ? blockIdx.y : blockIdx.x) * WQB + qt * WQ;
 
     const TC* Kg = (const TC*)a.K + b * a.k_bs;
     const TC* Ag = a.Kadd ? (const TC*)a.Kadd + b * a.kadd_bs : nullptr;
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     int64_t my_q = nq0 + r;
     {
         int64_t q = my_q < nq_total ? my_q : nq_total - 1;
-        const TC* qp = (const TC*)a.Q + b * a.q_bs + (q / a.NQ2) * a.q_s1 + (q % a.NQ2) * a.q_s2 + wave * DS;
+        const TC* qp = (const TC*)a.Q + b * a.q_bs + (q / a.NQ2) * a.q_s1 + (q % a.NQ2) * a.q_s2 + sl * DS;
 #pragma unroll
         for (int ks = 0; ks < NQF; ++ks) qf[ks] = *(const frag_t*)(qp + ks * 2 * PER16 + hh * PER16);
     }
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NQF; ++ks) {
-            frag_t kf = *(const frag_t*)(lds_k + r * K_ROW + wave * DS * SZ + ks * 32 + hh * 16);
+            frag_t kf = *(const frag_t*)(lds_k + r * K_ROW + sl * DS * SZ + ks * 32 + hh * 16);
             if constexpr (IS_BF16) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             } else {
@@ -208,7 +217,9 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int idx = acc_row(e, hh) * 32 + r;
-            float v = (lds_s[idx] + lds_s[1024 + idx]) + (lds_s[2048 + idx] + lds_s[3072 + idx]);
+            float v;
+            if constexpr (NSL == 4) v = (lds_s[idx] + lds_s[1024 + idx]) + (lds_s[2048 + idx] + lds_s[3072 + idx]);
+            else v = lds_s[qt * 2048 + idx] + lds_s[qt * 2048 + 1024 + idx];
             v = v * a.scale + lds_bias[acc_row(e, hh)];
             s[e] = v;
             mx = fmaxf(mx, v);
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                 const int kb = 16 * s2 + 4 * (g >> 1);
 #pragma unroll
                 for (int d = 0; d < NDT; ++d) {
-                    const int dcol = wave * DS + d * 32 + (g & 1) * 16 + 4 * (i & 3);
+                    const int dcol = sl * DS + d * 32 + (g & 1) * 16 + 4 * (i & 3);
                     const unsigned char* vp = lds_v + (kb + (i >> 2)) * V_ROW + dcol * 2;
                     // (the _v4i16 flavour + per-element casts miscompiles on ROCm 7.2: keep whole-vector bf16 types)
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)vp);
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                 const int key = acc_row(e, hh);
 #pragma unroll
                 for (int d = 0; d < NDT; ++d) {
-                    float vv = *(const float*)(lds_v + key * V_ROW + (wave * DS + d * 32 + r) * 4);
+                    float vv = *(const float*)(lds_v + key * V_ROW + (sl * DS + d * 32 + r) * 4);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[e], o[d], 0, 0, 0);
                 }
             }
@@ -283,11 +294,11 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     const float inv = 1.f / l_tot;
     const float sd_tot = sd_run + __shfl_xor(sd_run, 32);
     if (my_q >= nq_total) return;
-    if (a.sum_out && nsplit == 1 && wave == 0 && hh == 0) a.sum_out[b * nq_total + my_q] = a.drop.p > 0.f ? sd_tot * inv : 1.f;
+    if (a.sum_out && nsplit == 1 && sl == 0 && hh == 0) a.sum_out[b * nq_total + my_q] = a.drop.p > 0.f ? sd_tot * inv : 1.f;
     if (nsplit > 1) {
         // un-normalised partial result of this key slice; made_attention_wide_combine merges the slices
         const int64_t prow = (b * nsplit + blockIdx.z) * nq_total + my_q;
-        float* po = a.part_o + prow * D + wave * DS;
+        float* po = a.part_o + prow * D + sl * DS;
 #pragma unroll
         for (int d = 0; d < NDT; ++d)
 #pragma unroll
@@ -295,12 +306,12 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                 f32x4 pk; pk[0] = o[d][4 * g4]; pk[1] = o[d][4 * g4 + 1]; pk[2] = o[d][4 * g4 + 2]; pk[3] = o[d][4 * g4 + 3];
                 *(f32x4*)(po + d * 32 + 8 * g4 + 4 * hh) = pk;
             }
-        if (wave == 0 && hh == 0) {
+        if (sl == 0 && hh == 0) {
             a.part_ml[prow * 4] = m_run; a.part_ml[prow * 4 + 1] = l_tot; a.part_ml[prow * 4 + 2] = a.drop.p > 0.f ? sd_tot : l_tot;
         }
         return;
     }
-    const int64_t obase = b * a.o_bs + (my_q / a.NQ2) * a.o_s1 + (my_q % a.NQ2) * a.o_s2 + wave * DS;
+    const int64_t obase = b * a.o_bs + (my_q / a.NQ2) * a.o_s1 + (my_q % a.NQ2) * a.o_s2 + sl * DS;
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_combine_kernel(const 
     }
 }
 
-template <typename TC, int D, bool DB>
+template <typename TC, int D, bool DB, int NSL>
 int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     constexpr int SZ = (int)sizeof(TC);
     constexpr int K_ROW = D * SZ + 16, V_ROW = D * SZ + (SZ == 2 ? 64 : 16);
@@ -374,7 +385,7 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     const size_t lds_bytes = (size_t)NSTAGE * (WKEY * K_ROW + WKEY * V_ROW) + 4 * 1024 * 4 + NSTAGE * 32 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D, DB, NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {
             made_set_error("made_attention_wide: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
             return MADE_ERR_HIP;
@@ -383,8 +394,11 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     }
     const int64_t nq = a.NQ1 * a.NQ2;
     const int64_t nsplit = a.n_split > 1 ? a.n_split : 1;
-    dim3 grid((unsigned)((nq + WQ - 1) / WQ), (unsigned)a.B, (unsigned)nsplit), block(NTHREADS);
-    hipLaunchKernelGGL((attention_wide_kernel<TC, D, DB>), grid, block, lds_bytes, st, a);
+    constexpr int WQB = WQ * (4 / NSL);
+    const int64_t qtiles = (nq + WQB - 1) / WQB;
+    const bool batch_fast = qtiles > 1 && qtiles <= 8 && qtiles != a.B;       // see the kernel: which index runs fastest
+    dim3 grid((unsigned)(batch_fast ? a.B : qtiles), (unsigned)(batch_fast ? qtiles : a.B), (unsigned)nsplit), block(NTHREADS);
+    hipLaunchKernelGGL((attention_wide_kernel<TC, D, DB, NSL>), grid, block, lds_bytes, st, a);
     int rc = made_check_launch("made_attention_wide");
     if (rc != MADE_OK || nsplit == 1) return rc;
     const int64_t rows = a.B * nq;
@@ -418,9 +432,15 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
     if (a.B == 0 || a.NQ1 == 0) return MADE_OK;
     hipStream_t st = (hipStream_t)stream;
     if (a.dtype == MADE_BF16) {
-        const bool few = a.NQ1 * a.NQ2 <= 64;           // few query tiles per batch entry: latency-bound, use the two-stage variant
-        if (a.D == 512) return few ? launch_wide<bf16_t, 512, true>(a, st) : launch_wide<bf16_t, 512, false>(a, st);
-        return few ? launch_wide<bf16_t, 256, true>(a, st) : launch_wide<bf16_t, 256, false>(a, st);
+        const int64_t nq = a.NQ1 * a.NQ2;
+        const bool few = nq <= 64;                      // few query tiles per batch entry: latency-bound, use the two-stage variant
+        const bool pair = nq > 32 && nq <= 64;          // exactly two query tiles per entry (in-batch X-Pool at B = 64): one workgroup
+        if (a.D == 512) {
+            if (pair) return launch_wide<bf16_t, 512, true, 2>(a, st);
+            return few ? launch_wide<bf16_t, 512, true, 4>(a, st) : launch_wide<bf16_t, 512, false, 4>(a, st);
+        }
+        if (pair) return launch_wide<bf16_t, 256, true, 2>(a, st);
+        return few ? launch_wide<bf16_t, 256, true, 4>(a, st) : launch_wide<bf16_t, 256, false, 4>(a, st);
     }
-    return a.D == 512 ? launch_wide<float, 512, false>(a, st) : launch_wide<float, 256, false>(a, st);
+    return a.D == 512 ? launch_wide<float, 512, false, 4>(a, st) : launch_wide<float, 256, false, 4>(a, st);
 }

@@ -58,10 +58,14 @@ def test_dropin_forward_and_state_dict(golden_dir):
     pooled = xa(fm["video_feats"].cpu(), fm["segment_feats"].cpu(), mm["segment_masks"])
     xa.to(torch.device("cuda:0"))
     np.testing.assert_allclose(pooled.numpy()[:, :, ::5], fix["music_feats_pooled_sub"], atol=1e-4, rtol=0)
-    # training mode with autograd is refused loudly (no silent non-differentiable losses)
+    # training mode (three moment queries): the losses come back on the autograd tape and backward fills every gradient
     model.train()
-    with pytest.raises(NotImplementedError):
-        model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+    om2, lm2, *_ = model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], is_train=True)
+    loss = lm2["retrieval_loss"] + lm2["localization_loss"]
+    assert loss.requires_grad and bool(torch.isfinite(loss))
+    loss.backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for n, p in model.named_parameters() if n != "decoder_query_embed.weight" or True)
+    assert float(model.decoder_query_embed.weight.grad.abs().sum()) > 0 and om2["pred_spans"].shape == (int(fix["meta_B"]), 3, 2)
 
 
 def test_training_loop_body_of_the_reference_driver_runs_unchanged():
