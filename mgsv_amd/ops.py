@@ -239,8 +239,18 @@ def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, spli
     esz = 4 if a.w_dtype == F32 else 2
     _timed("linear_splitk_" + ("f32" if a.w_dtype == F32 else "bf16"), 2.0 * M * N * K, M * K * esz + N * K * esz + M * N * 4 * a.split_k,
            lambda: check(lib().made_linear(C.byref(a), _stream()), "made_linear(split_k)"), f"M={M} N={N} K={K} split={a.split_k}")
+    splitk_finish(ws, a.split_k, M, N, bias, act=act, R=R, r_row_mod=r_row_mod, out=out, ln1=ln1, ln1_out=ln1_out, ln2=ln2, ln2_out=ln2_out,
+                  eps=eps)
+
+
+def splitk_finish(ws: Tensor, split_k: int, M: int, N: int, bias: Optional[Tensor], *, act: int = ACT_NONE, R: Optional[Tensor] = None,
+                  r_row_mod: int = 0, out: Optional[Tensor] = None, ln1=None, ln1_out: Optional[Tensor] = None, ln2=None,
+                  ln2_out: Optional[Tensor] = None, eps: float = 1e-5) -> None:
+    """made_splitk_finish: sum the `split_k` f32 partials in ws ([split_k, M, N]), + bias, act, + residual -> out; then optionally
+    LayerNorm (ln1 = (gamma, beta)) -> ln1_out and a second LayerNorm on top (ln2) -> ln2_out."""
+    assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.numel() >= split_k * M * N
     f = MadeFinishArgs()
-    f.ws, f.split_k, f.M, f.N = _p(ws), a.split_k, M, N
+    f.ws, f.split_k, f.M, f.N = _p(ws), split_k, M, N
     f.bias, f.act = _p(_f32(bias, "bias")), act
     if R is not None:
         assert R.dim() == 2 and R.stride(1) == 1
