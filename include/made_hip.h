@@ -332,8 +332,11 @@ int made_xpool_tail(const void* y, int32_t y_dtype, int64_t ldy, const float* ga
 /* Symmetric cross-entropy of reference modules/loss.py:5-24 (== InfoNCELoss with audio_id=None,
  * :116-122): loss_out[0] (+)= weight * 0.5*(CE_rows + CE_cols) of sims*exp(*logit_scale).
  * accumulate != 0 adds to loss_out[0] instead of overwriting.  n <= 4096. */
+/* row_exclude [n, n] f32 or NULL (made_clip_loss and made_clip_loss_bwd): entries equal to 1 are left out of the row-direction
+ * (video -> music) softmax -- the negatives that share the row's own music track when the drivers run with
+ * --ignore_same_music 0 (reference modules/loss.py:90-114); the column direction always uses every entry. */
 int made_clip_loss(const float* sims, int64_t ld, int64_t n, const float* logit_scale, float weight,
-                   int32_t accumulate, float* loss_out, void* stream);
+                   int32_t accumulate, float* loss_out, const float* row_exclude, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hungarian matcher and set criterion (reference music_detr/matcher.py:36-92, loss_detr.py).   */
@@ -468,7 +471,7 @@ int made_l2norm_bwd(const void* x, int32_t x_dtype, int64_t ldx, const float* dy
  *   (NULL = 1): dsims [n,n] and its transpose dsims_t (may be NULL), d_logit_scale[0] += .  lse_ws: [2n] f32 workspace. */
 int made_clip_loss_bwd(const float* sims, int64_t ld, int64_t n, const float* logit_scale, float weight,
                        const float* upstream, float* lse_ws, float* dsims, float* dsims_t, int32_t accumulate,
-                       float* d_logit_scale, void* stream);
+                       float* d_logit_scale, const float* row_exclude, void* stream);
 
 /* made_xpool_tail_bwd: backward of made_xpool_tail (LayerNorm3 + cosine with the video, reference modules/transformer.py:178,
  *   modules/metrics.py:10-24): dy [Nm*Nv, D], optionally dy_drop = dropout(dy) (element index row*D + col), dgamma/dbeta

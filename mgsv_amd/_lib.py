@@ -134,14 +134,14 @@ SIGNATURES = {
     "made_sine_pe": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, vp]),
     "made_masked_softmax": (C.c_int, [vp, i64, vp, i64, vp, i32, i64, i64, i64, i64, i64, f32, vp]),
     "made_xpool_tail": (C.c_int, [vp, i32, i64, vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, f32, vp]),
-    "made_clip_loss": (C.c_int, [vp, i64, i64, vp, f32, i32, vp, vp]),
+    "made_clip_loss": (C.c_int, [vp, i64, i64, vp, f32, i32, vp, vp, vp]),
     "made_hungarian_match": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp]),
     "made_attention_bwd": (C.c_int, [C.POINTER(MadeAttnBwdArgs), vp]),
     "made_layernorm_bwd": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i64,
                                      C.POINTER(MadeDropout), i64, vp, vp, i64, i64, f32, vp, vp]),
     "made_pool_bwd": (C.c_int, [vp, vp, vp, vp, i32, i64, i64, vp, i32, i64, i64, vp, i32, i64, i64, i64, i64, i64, f32, vp]),
     "made_l2norm_bwd": (C.c_int, [vp, i32, i64, vp, i64, i64, vp, i64, i32, vp, i32, i64, i64, i64, f32, vp]),
-    "made_clip_loss_bwd": (C.c_int, [vp, i64, i64, vp, f32, vp, vp, vp, vp, i32, vp, vp]),
+    "made_clip_loss_bwd": (C.c_int, [vp, i64, i64, vp, f32, vp, vp, vp, vp, i32, vp, vp, vp]),
     "made_xpool_tail_bwd": (C.c_int, [vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, i32, i64, vp, C.POINTER(MadeDropout),
                                       vp, vp, vp, i64, i64, i64, i64, f32, vp]),
     "made_softmax_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, f32, C.POINTER(MadeDropout), vp, vp, vp, i32, i64, i64,

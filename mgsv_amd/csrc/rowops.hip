@@ -262,23 +262,28 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void xpool_tail_kerne
 
 // ---- symmetric cross entropy ----------------------------------------------------------------------
 // One workgroup of 1024 threads; rows then columns, each wave strides over lines.
+// row_exclude [n, n] (optional): entries that are 1 are left out of the ROW-direction softmax (video -> music): the negatives that
+// share the row's own music track (reference modules/loss.py:90-114); the column direction always uses every entry.
 __global__ __launch_bounds__(1024) void clip_loss_kernel(const float* sims, int64_t ld, int n, const float* logit_scale,
-                                                         float weight, int accumulate, float* loss_out) {
+                                                         float weight, int accumulate, float* loss_out, const float* row_exclude) {
     __shared__ float partial[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const float gsc = expf(logit_scale[0]);
     float acc = 0.f;                       // sum over lines of (lse - z_ii), both directions
     for (int dir = 0; dir < 2; ++dir) {
         for (int i = wave; i < n; i += nwaves) {
+            const float* ex = (dir == 0 && row_exclude) ? row_exclude + (int64_t)i * n : nullptr;
             float mx = -INFINITY;
             for (int j = lane; j < n; j += WAVE) {
                 float z = (dir == 0 ? sims[(int64_t)i * ld + j] : sims[(int64_t)j * ld + i]) * gsc;
+                if (ex && ex[j] != 0.f) z = -INFINITY;
                 mx = fmaxf(mx, z);
             }
             mx = wave_max(mx);
             float se = 0.f;
             for (int j = lane; j < n; j += WAVE) {
                 float z = (dir == 0 ? sims[(int64_t)i * ld + j] : sims[(int64_t)j * ld + i]) * gsc;
+                if (ex && ex[j] != 0.f) z = -INFINITY;
                 se += expf(z - mx);
             }
             se = wave_sum(se);
@@ -562,11 +567,11 @@ extern "C" int made_xpool_tail(const void* y, int32_t y_dtype, int64_t ldy, cons
 }
 
 extern "C" int made_clip_loss(const float* sims, int64_t ld, int64_t n, const float* logit_scale, float weight,
-                              int32_t accumulate, float* loss_out, void* stream) {
+                              int32_t accumulate, float* loss_out, const float* row_exclude, void* stream) {
     MADE_REQUIRE(sims && logit_scale && loss_out, "made_clip_loss: null pointer");
     MADE_REQUIRE(n > 0 && n <= 4096 && ld >= n, "made_clip_loss: n=%lld out of range", (long long)n);
     hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale,
-                       weight, accumulate, loss_out);
+                       weight, accumulate, loss_out, row_exclude);
     return made_check_launch("made_clip_loss");
 }
 

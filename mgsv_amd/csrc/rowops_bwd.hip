@@ -322,25 +322,33 @@ __global__ __launch_bounds__(RT) void l2norm_bwd_kernel(const L2BwdArgs a) {
 // ---- symmetric cross entropy backward ---------------------------------------------------------------------
 // z = sims * exp(logit_scale); L = w/2 (mean_i (lse_row_i - z_ii) + mean_j (lse_col_j - z_jj))
 //   dz_ij = w/(2n) (exp(z_ij - lse_row_i) + exp(z_ij - lse_col_j) - 2 [i == j]);  dsims = dz * e^ls;  dls = sum dz z
-__global__ __launch_bounds__(RT) void clip_lse_kernel(const float* sims, int64_t ld, int n, const float* logit_scale, float* lse) {
+__global__ __launch_bounds__(RT) void clip_lse_kernel(const float* sims, int64_t ld, int n, const float* logit_scale, float* lse,
+                                                      const float* row_exclude) {
     const int lane = threadIdx.x & 63;
     const int line = blockIdx.x * 4 + (threadIdx.x >> 6);         // 0..n-1 rows, n..2n-1 columns
     if (line >= 2 * n) return;
     const float gsc = expf(logit_scale[0]);
     const bool col = line >= n;
     const int i = col ? line - n : line;
+    const float* ex = (!col && row_exclude) ? row_exclude + (int64_t)i * n : nullptr;     // same-track negatives leave the row softmax
     float mx = -INFINITY;
-    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, (col ? sims[(int64_t)j * ld + i] : sims[(int64_t)i * ld + j]) * gsc);
+    for (int j = lane; j < n; j += 64) {
+        const float z = (col ? sims[(int64_t)j * ld + i] : sims[(int64_t)i * ld + j]) * gsc;
+        mx = fmaxf(mx, (ex && ex[j] != 0.f) ? -INFINITY : z);
+    }
     mx = wave_max(mx);
     float se = 0.f;
-    for (int j = lane; j < n; j += 64) se += expf((col ? sims[(int64_t)j * ld + i] : sims[(int64_t)i * ld + j]) * gsc - mx);
+    for (int j = lane; j < n; j += 64) {
+        const float z = (col ? sims[(int64_t)j * ld + i] : sims[(int64_t)i * ld + j]) * gsc;
+        se += (ex && ex[j] != 0.f) ? 0.f : expf(z - mx);
+    }
     se = wave_sum(se);
     if (lane == 0) lse[line] = mx + logf(se);
 }
 
 __global__ __launch_bounds__(RT) void clip_bwd_kernel(const float* sims, int64_t ld, int n, const float* logit_scale, float weight,
                                                       const float* upstream, const float* lse, float* dsims, float* dsims_t,
-                                                      int accumulate, float* dls) {
+                                                      int accumulate, float* dls, const float* row_exclude) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -349,7 +357,8 @@ __global__ __launch_bounds__(RT) void clip_bwd_kernel(const float* sims, int64_t
     float acc = 0.f;
     for (int j = lane; j < n; j += 64) {
         const float z = sims[(int64_t)i * ld + j] * gsc;
-        const float dz = w * (expf(z - lse[i]) + expf(z - lse[n + j]) - (i == j ? 2.f : 0.f));
+        const float prow = (row_exclude && row_exclude[(int64_t)i * n + j] != 0.f) ? 0.f : expf(z - lse[i]);
+        const float dz = w * (prow + expf(z - lse[n + j]) - (i == j ? 2.f : 0.f));
         acc += dz * z;
         const float g = dz * gsc;
         if (accumulate) {
@@ -683,12 +692,12 @@ extern "C" int made_l2norm_bwd(const void* x, int32_t x_dtype, int64_t ldx, cons
 
 extern "C" int made_clip_loss_bwd(const float* sims, int64_t ld, int64_t n, const float* logit_scale, float weight,
                                   const float* upstream, float* lse_ws, float* dsims, float* dsims_t, int32_t accumulate,
-                                  float* d_logit_scale, void* stream) {
+                                  float* d_logit_scale, const float* row_exclude, void* stream) {
     MADE_REQUIRE(sims && logit_scale && lse_ws && dsims, "made_clip_loss_bwd: null pointer");
     MADE_REQUIRE(n > 0 && n <= (1 << 20) && ld >= n, "made_clip_loss_bwd: n=%lld out of range", (long long)n);
-    hipLaunchKernelGGL(clip_lse_kernel, dim3(blocks4(2 * n)), dim3(RT), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale, lse_ws);
+    hipLaunchKernelGGL(clip_lse_kernel, dim3(blocks4(2 * n)), dim3(RT), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale, lse_ws, row_exclude);
     hipLaunchKernelGGL(clip_bwd_kernel, dim3(blocks4(n)), dim3(RT), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale, weight,
-                       upstream, lse_ws, dsims, dsims_t, accumulate, d_logit_scale);
+                       upstream, lse_ws, dsims, dsims_t, accumulate, d_logit_scale, row_exclude);
     return made_check_launch("made_clip_loss_bwd");
 }
 

@@ -647,7 +647,7 @@ class MadeEngine:
         y = ops.linear(h, P["ca.ff2.w"], P["ca.ff2.b"], R=ax, out=ws["ca_y"])
         ops.linear(y, P["ca.final.w"], P["ca.final.b"], out_row_mask=sm.reshape(-1), out=ws["fus"].view(B * Ta, D))
 
-    def _retrieval_loss(self, ws: Dict[str, Tensor], video: Tensor, music: Tensor) -> None:
+    def _retrieval_loss(self, ws: Dict[str, Tensor], video: Tensor, music: Tensor, row_exclude: Optional[Tensor] = None) -> None:
         """reference model/model_Uni.py:236-275 -> ws["ret_loss"]"""
         c, P = self.cfg, self.P
         rl = ws["ret_loss"]
@@ -658,7 +658,9 @@ class MadeEngine:
         elif c.vmr_loss == "single":
             ops.clip_loss(ws["sims_single"], ls, rl, weight=wgt)
         elif c.vmr_loss == "dual_single_loss_fuse":
-            ops.clip_loss(ws["sims_dual"], ls, rl, weight=1.0)
+            # row_exclude: training with --ignore_same_music 0 drops the same-track negatives of the dual loss's video -> music
+            # direction (reference modules/loss.py:90-114; model_Uni.py:255)
+            ops.clip_loss(ws["sims_dual"], ls, rl, weight=1.0, row_exclude=row_exclude)
             ops.clip_loss(ws["sims_single"], ls, rl, weight=1.0, accumulate=True)
         else:                                                            # dual_single_sim_fuse
             both = self.dual_sims(video, music, add=ws["sims_single"])

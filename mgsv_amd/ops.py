@@ -485,10 +485,14 @@ def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2
     return sims
 
 
-def clip_loss(sims: Tensor, logit_scale: Tensor, loss_out: Tensor, weight: float = 1.0, accumulate: bool = False) -> Tensor:
+def clip_loss(sims: Tensor, logit_scale: Tensor, loss_out: Tensor, weight: float = 1.0, accumulate: bool = False,
+              row_exclude: Optional[Tensor] = None) -> Tensor:
+    """Symmetric cross entropy of a square similarity matrix; row_exclude [n, n] f32 (1 = same-track negative left out of the
+    video -> music softmax, reference modules/loss.py:90-114)."""
     assert sims.dim() == 2 and sims.shape[0] == sims.shape[1] and sims.stride(1) == 1 and sims.dtype == torch.float32
+    assert row_exclude is None or (row_exclude.shape == sims.shape and row_exclude.is_contiguous())
     check(lib().made_clip_loss(_p(sims), sims.stride(0), sims.shape[0], _p(logit_scale), weight, 1 if accumulate else 0,
-                               _p(loss_out), _stream()), "made_clip_loss")
+                               _p(loss_out), _p(_f32(row_exclude, "row_exclude")), _stream()), "made_clip_loss")
     return loss_out
 
 

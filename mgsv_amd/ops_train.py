@@ -167,11 +167,14 @@ def l2norm_bwd(x: Tensor, dy: Tensor, dx: Optional[Tensor] = None, *, accumulate
 
 
 def clip_loss_bwd(sims: Tensor, logit_scale: Tensor, weight: float, upstream: Optional[Tensor], lse_ws: Tensor, dsims: Tensor,
-                  dsims_t: Optional[Tensor], d_logit_scale: Optional[Tensor], accumulate: bool = False) -> None:
+                  dsims_t: Optional[Tensor], d_logit_scale: Optional[Tensor], accumulate: bool = False,
+                  row_exclude: Optional[Tensor] = None) -> None:
     n = sims.shape[0]
     assert lse_ws.numel() >= 2 * n and dsims.is_contiguous()
+    assert row_exclude is None or (row_exclude.shape == sims.shape and row_exclude.is_contiguous())
     check(lib().made_clip_loss_bwd(_p(_f32(sims, "sims")), sims.stride(0), n, _p(logit_scale), float(weight), _p(upstream),
-                                   _p(lse_ws), _p(dsims), _p(dsims_t), int(accumulate), _p(d_logit_scale), _stream()),
+                                   _p(lse_ws), _p(dsims), _p(dsims_t), int(accumulate), _p(d_logit_scale),
+                                   _p(_f32(row_exclude, "row_exclude")), _stream()),
           "made_clip_loss_bwd")
 
 

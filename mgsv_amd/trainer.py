@@ -247,10 +247,11 @@ class MadeTrainer(MadeEngine):
         self.repack()
 
     def train_step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed: int, lrs=(1e-4, 1e-4, 1e-4),
-                   max_grad_norm: float = 1.0, w_ret: Optional[Tensor] = None, w_loc: Optional[Tensor] = None, dist=None) -> Dict[str, Tensor]:
+                   max_grad_norm: float = 1.0, w_ret: Optional[Tensor] = None, w_loc: Optional[Tensor] = None, dist=None,
+                   music_ids=None) -> Dict[str, Tensor]:
         """One iteration of the reference's loop body (train-MaDe.py:337-381): forward, backward, (data-parallel gradient
         average: one RCCL all-reduce of the flat buffer), clip + Adam, repack."""
-        out = self.forward_train(frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed=seed)
+        out = self.forward_train(frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed=seed, music_ids=music_ids)
         self.backward(w_ret, w_loc)
         scale = 1.0
         if dist is not None and dist.get_world_size() > 1:
@@ -365,8 +366,22 @@ class MadeTrainer(MadeEngine):
 
     # ================================================================== forward (train mode)
     @torch.no_grad()
+    def same_music_exclusion(self, music_ids) -> Optional[Tensor]:
+        """[B, B] f32, 1 where another sample shares this row's music track: the negatives modules/loss.py:90-114 leaves out of
+        the video -> music direction of the dual loss.  OPT-IN (pass music_ids to forward_train / train_step): the reference's
+        own forward hands that loss audio_id=None (model_Uni.py:255), so the drop-in module and the drivers never use it."""
+        c = self.cfg
+        if music_ids is None or c.vmr_loss != "dual_single_loss_fuse":
+            return None
+        ids = list(music_ids)
+        code = {}
+        idx = torch.tensor([code.setdefault(str(i), len(code)) for i in ids])
+        ex = (idx[:, None] == idx[None, :]).float()
+        ex.fill_diagonal_(0.0)
+        return ex.to(self.device)
+
     def forward_train(self, frame_feats: Tensor, segment_feats: Tensor, frame_masks: Tensor, segment_masks: Tensor,
-                      spans_target: Tensor, seed: int = 0) -> Dict[str, Tensor]:
+                      spans_target: Tensor, seed: int = 0, music_ids=None) -> Dict[str, Tensor]:
         """reference model/model_Uni.py:177-322 under model.train(): same outputs as MadeEngine.forward plus everything
         the backward needs, kept in the training workspace."""
         c, P = self.cfg, self.P
@@ -425,7 +440,8 @@ class MadeTrainer(MadeEngine):
                 ops.linear_splitk(tw["vn"], tw["mn"], None, tw["sd_ws"][:split * B * B], split, out=ws["sims_dual"])
             else:
                 ops.linear(tw["vn"], tw["mn"], None, out=ws["sims_dual"])
-            self._retrieval_loss(ws, video, music)
+            self._row_exclude = self.same_music_exclusion(music_ids)
+            self._retrieval_loss(ws, video, music, row_exclude=self._row_exclude)
         out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"], retrieval_loss=ws["ret_loss"])
 
         # ---- DETR encoder
@@ -914,7 +930,7 @@ class MadeTrainer(MadeEngine):
         elif c.vmr_loss == "single":
             tr.clip_loss_bwd(ws["sims_single"], ls, wgt, g_ret, cws, ds_s, None, gls); single = True
         elif c.vmr_loss == "dual_single_loss_fuse":
-            tr.clip_loss_bwd(ws["sims_dual"], ls, 1.0, g_ret, cws, ds_d, ds_dt, gls)
+            tr.clip_loss_bwd(ws["sims_dual"], ls, 1.0, g_ret, cws, ds_d, ds_dt, gls, row_exclude=getattr(self, "_row_exclude", None))
             tr.clip_loss_bwd(ws["sims_single"], ls, 1.0, g_ret, cws, ds_s, None, gls)
             single = dual = True
         else:                                                # dual_single_sim_fuse: one loss on the summed similarities
@@ -1005,7 +1021,8 @@ class MadeTrainer(MadeEngine):
         """numpy in, numpy out (synchronises): losses and all parameter gradients of w_ret*retrieval + w_loc*localization."""
         dev = self.device
         t = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
-        o = self.forward_train(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=seed)
+        o = self.forward_train(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=seed,
+                               music_ids=inp.get("music_ids"))
         gr = torch.tensor([w_ret], device=dev) if w_ret != 1.0 else None
         gl = torch.tensor([w_loc], device=dev) if w_loc != 1.0 else None
         self.backward(gr, gl)

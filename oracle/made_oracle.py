@@ -590,10 +590,9 @@ def forward(P, cfg, frame_feats, segment_feats, frame_masks, segment_masks, span
                 single = single + r["sims_video_pooling"]
             r["retrieval_loss"] = clip_loss(single, ls) * cfg.dual_single_loss_weight
         elif cfg.vmr_loss == "dual_single_loss_fuse" and "XA" in cfg.vmr_fusion:
-            if is_train and cfg.ignore_same_music == 0 and music_ids is not None:
-                dual = info_nce_same_music(r["sims_dual"], ls, music_ids)
-            else:
-                dual = clip_loss(r["sims_dual"], ls)
+            # the reference calls InfoNCELoss(..., audio_id=None, ...) here (model_Uni.py:255), so its same-music branch
+            # (modules/loss.py:90-114, restated as info_nce_same_music above) is never taken whatever --ignore_same_music says
+            dual = clip_loss(r["sims_dual"], ls)
             r["retrieval_loss"] = dual + clip_loss(r["sims_single"], ls)
         elif cfg.vmr_loss == "dual_single_sim_fuse" and "XA" in cfg.vmr_fusion:
             r["retrieval_loss"] = clip_loss(r["sims_dual"] + r["sims_single"], ls) * cfg.dual_single_loss_weight

@@ -1,5 +1,7 @@
 """GPU: the backward kernels of the training path against plain PyTorch fp32 references of the same op
 (tolerances are stated per test; bf16 inputs are compared after the same rounding of the inputs)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -449,3 +451,31 @@ def test_gemm_tn_direct_to_lds_path(T, M, N, K):
     C = torch.zeros(N, K, device="cuda")
     tr.gemm_tn(A2, B, C, accumulate=True, rows=rows)
     assert torch.isfinite(C).all() and float((C - refm).abs().max()) <= 2e-3 * float(refm.abs().max())
+
+
+def test_clip_loss_same_music_exclusion_forward_and_backward(T):
+    """row_exclude of made_clip_loss / made_clip_loss_bwd = the same-music-aware InfoNCE of reference modules/loss.py:90-114
+    (oracle restatement info_nce_same_music): loss and d(loss)/d(sims), d/d(logit_scale) against its autograd."""
+    ops, tr = T
+    from oracle import made_oracle as O
+    n = 12
+    ids = [str(i % 5) for i in range(n)]                      # tracks shared by two or three videos
+    sims = (_rand(n, n, dtype=torch.float32, seed=3) * 0.3).contiguous()
+    ls = torch.tensor([math.log(1 / 0.07)], device="cuda")
+    idx = torch.tensor([int(i) for i in ids])
+    ex = (idx[:, None] == idx[None, :]).float()
+    ex.fill_diagonal_(0.0)
+    ex = ex.cuda()
+    loss = torch.zeros(1, device="cuda")
+    ops.clip_loss(sims, ls, loss, weight=1.0, row_exclude=ex)
+    s_ref = sims.cpu().double().requires_grad_(True)
+    l_ref = ls.cpu().double()[0].requires_grad_(True)
+    ref = O.info_nce_same_music(s_ref, l_ref, ids)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    ds, dst, gls = torch.zeros(n, n, device="cuda"), torch.zeros(n, n, device="cuda"), torch.zeros(1, device="cuda")
+    tr.clip_loss_bwd(sims, ls, 1.0, None, torch.empty(2 * n, device="cuda"), ds, dst, gls, row_exclude=ex)
+    np.testing.assert_allclose(ds.cpu().numpy(), s_ref.grad.float().numpy(), atol=2e-6, rtol=1e-4)
+    np.testing.assert_allclose(dst.cpu().numpy(), s_ref.grad.float().numpy().T, atol=2e-6, rtol=1e-4)
+    np.testing.assert_allclose(float(gls), float(l_ref.grad), rtol=1e-4, atol=1e-5)
+    assert float(ds[0, 5].abs()) > 0 and bool((ex[0, 5] == 1))       # an excluded pair still gets the column-direction gradient
