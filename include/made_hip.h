@@ -321,6 +321,12 @@ typedef struct MadeXpoolFusedArgs {
 
 int made_xpool_fused(const MadeXpoolFusedArgs* args, void* stream);
 
+/* made_row_affine: out[r, :] = act(x[r, :] * scale[r % period] + shift[r % period]), act = none | ReLU.  Eval-mode
+ * BatchNorm1d of the EmbeddingNet aggregator (reference model/model_Base.py:224-229): its input is [B, T, F], so the
+ * "channels" are the T token positions and the running statistics reduce to one (scale, shift) per position. */
+int made_row_affine(const void* x, int32_t x_dtype, int64_t ldx, const float* scale, const float* shift, int64_t period,
+                    int32_t act, void* out, int32_t out_dtype, int64_t ldo, int64_t rows, int64_t cols, void* stream);
+
 /* X-Pool tail: y [Nm*Nv, D] (the pre-LayerNorm3 sum, reference modules/transformer.py:177) ->
  * LayerNorm3 -> (optional) pooled[m,n,:] -> cosine with video n -> sims[n*ld_sims + m].
  * Fuses reference modules/transformer.py:178 with modules/metrics.py:19-24 so the pooled tensor

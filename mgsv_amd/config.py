@@ -28,6 +28,10 @@ class MadeConfig:
     video_attention_seqlen: int = 250   # PE table length, video (flag)
     audio_attention_seqlen: int = 300   # PE table length, audio (hard-coded model_Base.py:293)
     with_act_after_proj: int = 0
+    agg_module: str = "transf"          # "transf" | "mlp" (EmbeddingNet, model_Base.py:216-249,357-377)
+    transformer_is_share: int = 0       # one temporal block for both towers (model_Base.py:300-302,322-331)
+    with_cls_token: int = 0             # learned token prepended, clip vector = its output (model_Base.py:527-530,572-574)
+    with_last_token: int = 0            # only read when agg_module contains "cal": unreachable through the parsers
     # sequence bounds
     max_v_frames: int = 50
     max_snippet_num: int = 96       # int(max_m_duration / stride)
@@ -110,10 +114,6 @@ class MadeConfig:
             name="made",
             audio_encoder_type="AST",
             video_encoder_type="ViT",
-            transformer_is_share=0,
-            agg_module="transf",
-            with_cls_token=0,
-            with_last_token=0,
             music_frozen_feature_path="ast_feature2p5",
             frame_frozen_feature_path="vit_feature1",
         )

@@ -260,6 +260,21 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void xpool_tail_kerne
     if (lane == 0) sims[n * lds_ + m] = pv / (sqrtf(pp) * sqrtf(vv));
 }
 
+// ---- per-row affine + activation: out[r, :] = act(x[r, :] * scale[r % period] + shift[r % period]) -------------------
+// (eval-mode BatchNorm1d over the token axis of a [B, T, F] tensor, reference model/model_Base.py:224-229)
+__global__ __launch_bounds__(ROW_THREADS) void row_affine_kernel(const void* x, int xdt, int64_t ldx, const float* scale, const float* shift,
+                                                                int period, int act, void* out, int odt, int64_t ldo, int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (ROW_THREADS / WAVE) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float sc = scale[row % period], sh = shift[row % period];
+    for (int c = lane; c < cols; c += WAVE) {
+        float v = load_as_f32(x, xdt, row * ldx + c) * sc + sh;
+        if (act == MADE_ACT_RELU) v = fmaxf(v, 0.f);
+        store_from_f32(out, odt, row * ldo + c, v);
+    }
+}
+
 // ---- symmetric cross entropy ----------------------------------------------------------------------
 // One workgroup of 1024 threads; rows then columns, each wave strides over lines.
 // row_exclude [n, n] (optional): entries that are 1 are left out of the ROW-direction softmax (video -> music): the negatives that
@@ -573,6 +588,16 @@ extern "C" int made_clip_loss(const float* sims, int64_t ld, int64_t n, const fl
     hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sims, ld, (int)n, logit_scale,
                        weight, accumulate, loss_out, row_exclude);
     return made_check_launch("made_clip_loss");
+}
+
+extern "C" int made_row_affine(const void* x, int32_t x_dtype, int64_t ldx, const float* scale, const float* shift, int64_t period,
+                               int32_t act, void* out, int32_t out_dtype, int64_t ldo, int64_t rows, int64_t cols, void* stream) {
+    MADE_REQUIRE(x && scale && shift && out && period > 0 && cols > 0, "made_row_affine: bad arguments");
+    MADE_UNSUPPORTED(act == MADE_ACT_NONE || act == MADE_ACT_RELU, "made_row_affine: act %d (none or ReLU)", act);
+    if (rows <= 0) return MADE_OK;
+    hipLaunchKernelGGL(row_affine_kernel, dim3(row_blocks(rows)), dim3(ROW_THREADS), 0, (hipStream_t)stream, x, x_dtype, ldx, scale, shift,
+                       (int)period, act, out, out_dtype, ldo, rows, (int)cols);
+    return made_check_launch("made_row_affine");
 }
 
 extern "C" int made_splitk_finish(const MadeFinishArgs* args, void* stream) {

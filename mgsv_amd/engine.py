@@ -46,8 +46,11 @@ class MadeEngine:
     def _check_supported(self):
         c = self.cfg
         unsupported = []
-        if c.video_transformer_depth < 1 or c.audio_transformer_depth < 1:
-            unsupported.append("temporal transformer depth 0 (agg_module != transf)")
+        if c.agg_module == "mlp":
+            if c.video_transformer_depth != 0 or c.audio_transformer_depth != 0:
+                unsupported.append("agg_module=mlp with a temporal transformer depth > 0 (the reference asserts 0, model_Base.py:308)")
+        elif "transf" not in c.agg_module or c.video_transformer_depth < 1 or c.audio_transformer_depth < 1:
+            unsupported.append(f"agg_module={c.agg_module} / temporal transformer depth 0")
         if "concat" not in c.mml_fusion and "CA" not in c.mml_fusion:
             unsupported.append(f"mml_fusion={c.mml_fusion}")
         if "XA" not in c.vmr_fusion or not ("music" in c.vmr_fusion or "video" in c.vmr_fusion):
@@ -102,18 +105,31 @@ class MadeEngine:
 
         lin("vit_proj", "vit_proj")
         lin("ast_proj", "ast_proj")
-        vec("pe_video", T("video_position_embedding.pe")[0])
-        vec("pe_audio", T("audio_position_embedding.pe")[0])
-        for mod, depth in (("video_transformer", c.video_transformer_depth), ("audio_transformer", c.audio_transformer_depth)):
-            for l in range(depth):
-                p = f"{mod}.layers.{l}"
-                ln(p + ".ln1", p + ".0")
-                mat(p + ".in.w", T(p + ".1.in_proj_weight")); vec(p + ".in.b", T(p + ".1.in_proj_bias"))
-                lin(p + ".out", p + ".1.out_proj")
-                ln(p + ".ln2", p + ".2")
-                lin(p + ".ff1", p + ".3.0")
-                lin(p + ".ff2", p + ".3.3")
-            lin(mod + ".final", mod + ".final_linear")
+        if c.agg_module == "mlp":                                        # reference model/model_Base.py:216-249,357-377
+            for key, mod in (("video_mlp", "Video_encoder_projection"), ("audio_mlp", "Music_encoder_projection")):
+                lin(key + ".0", mod + ".net.0"); lin(key + ".3", mod + ".net.3"); lin(key + ".6", mod + ".net.6")
+                for bn in ("1", "4"):                                     # eval-mode BatchNorm1d over the token axis -> (scale, shift) per position
+                    sc = T(f"{mod}.net.{bn}.weight") / torch.sqrt(T(f"{mod}.net.{bn}.running_var") + 1e-5)
+                    vec(f"{key}.{bn}.scale", sc)
+                    vec(f"{key}.{bn}.shift", T(f"{mod}.net.{bn}.bias") - T(f"{mod}.net.{bn}.running_mean") * sc)
+        else:
+            vec("pe_video", T("video_position_embedding.pe")[0])
+            vec("pe_audio", T("audio_position_embedding.pe")[0])
+            share = bool(c.transformer_is_share) and c.video_transformer_depth == c.audio_transformer_depth
+            if c.with_cls_token:                                          # reference model/model_Base.py:314-321
+                vec("cls_video", T("video_cls_token").view(-1))
+                vec("cls_audio", T("audio_cls_token").view(-1))
+            for mod, depth in (("video_transformer", c.video_transformer_depth), ("audio_transformer", c.audio_transformer_depth)):
+                src = "share_transformer" if share else mod               # one block for both towers (model_Base.py:322-331)
+                for l in range(depth):
+                    p, q = f"{mod}.layers.{l}", f"{src}.layers.{l}"
+                    ln(p + ".ln1", q + ".0")
+                    mat(p + ".in.w", T(q + ".1.in_proj_weight")); vec(p + ".in.b", T(q + ".1.in_proj_bias"))
+                    lin(p + ".out", q + ".1.out_proj")
+                    ln(p + ".ln2", q + ".2")
+                    lin(p + ".ff1", q + ".3.0")
+                    lin(p + ".ff2", q + ".3.3")
+                lin(mod + ".final", src + ".final_linear")
         towers = []
         if "music" in c.vmr_fusion:
             towers.append(("xa", "video_guided_to_music_pooling_cross_transformer"))
@@ -201,7 +217,7 @@ class MadeEngine:
         concat = "concat" in c.mml_fusion
         D, L, Q = c.D, (Tv + Ta if concat else Ta), c.num_moment_queries
         F_t, F_d, nd = c.temporal_ffn_dim, c.detr_dim_feedforward, c.detr_dec_layers
-        Lmax = max(L, Ta, Tv)
+        Lmax = max(L, Ta + 1, Tv + 1) if c.with_cls_token else max(L, Ta, Tv)
         Lpad = round_up(Lmax, 64)
         rows = B * Lmax
 
@@ -211,7 +227,7 @@ class MadeEngine:
         def Z(*shape, dtype=None):
             return torch.zeros(shape, device=dev, dtype=dtype or tc)
 
-        vr = B * Tv
+        vr = B * (Tv + 1 if c.with_cls_token else Tv)
         ws = dict(
             # private scratch of the video branch (it runs on its own stream beside the audio branch)
             v_x0=E(vr, D), v_x1=E(vr, D), v_x2=E(vr, D), v_x3=E(vr, D), v_xin=E(vr * c.vit_dim), v_qkv=E(vr, 3 * D),
@@ -275,12 +291,21 @@ class MadeEngine:
         D = c.D
         proj, mod, pe, depth = (("vit_proj", "video_transformer", "pe_video", c.video_transformer_depth) if which == "video"
                                 else ("ast_proj", "audio_transformer", "pe_audio", c.audio_transformer_depth))
-        if P[pe].shape[0] < T:
-            raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < T={T} "
-                             "(reference model/model_Base.py:533 raises here too)")
         nrow = B * T
         mflat = mask.reshape(-1)
         act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE
+        if "concat" in c.mml_fusion:
+            local = ws["fus"][:, row_off:row_off + T]                   # [B, T, D] view
+        else:
+            local = ws["frame_buf"] if which == "video" else ws["seg_buf"]
+        mean, vec = (ws["vmean"], ws["video"]) if which == "video" else (ws["mmean"], ws["music"])
+        if c.agg_module == "mlp":
+            return self._encode_mlp(feats, mask, which, ws, local, mean, vec)
+        if c.with_cls_token:
+            return self._encode_cls(feats, mask, which, ws, local, vec)
+        if P[pe].shape[0] < T:
+            raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < T={T} "
+                             "(reference model/model_Base.py:533 raises here too)")
         # padded tokens (mask 0) are never read by a valid token: the GEMMs gather the valid rows only (`rows`), the row kernels
         # and the attention skip them; valid rows are bit-identical to the dense computation
         if self.tc == torch.bfloat16:       # mask + f32->bf16 once, then the direct-to-LDS GEMM
@@ -289,6 +314,17 @@ class MadeEngine:
         else:
             x = ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act,
                            R=P[pe][:T], r_row_mod=T, out=ws["x0"][:nrow], rows=rows)
+        x = self._temporal_layers(x, B, T, mask, mod, depth, ws, rows, order)
+        ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat, tile_skip_mask=mflat,
+                   segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
+        ops.masked_mean(local, mask, out=mean)
+        ops.l2norm_rows(mean, out_f32=vec)
+
+    def _temporal_layers(self, x: Tensor, B: int, T: int, mask: Tensor, mod: str, depth: int, ws, rows, order) -> Tensor:
+        """reference model/model_Base.py:82-91 without the final Linear; x [B*T, D] in ws["x0"]."""
+        c, P = self.cfg, self.P
+        nrow = B * T
+        mflat = mask.reshape(-1)
         for l in range(depth):
             p = f"{mod}.layers.{l}"
             x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=ws["x1"][:nrow], row_skip=mflat)
@@ -297,16 +333,64 @@ class MadeEngine:
             x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x3"][:nrow], row_skip=mflat)
             h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=ws["ffn"][:nrow, :c.temporal_ffn_dim], rows=rows)
             x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=ws["x0"][:nrow], rows=rows)
-        if "concat" in c.mml_fusion:
-            fus = ws["fus"]
-            local = fus[:, row_off:row_off + T]                          # [B, T, D] view
+        return x
+
+    def _encode_mlp(self, feats: Tensor, mask: Tensor, which: str, ws, local: Tensor, mean: Tensor, vec: Tensor) -> None:
+        """agg_module = "mlp" (reference model/model_Base.py:567-570,606-609 with EmbeddingNet :216-249, eval mode): projection,
+        Linear - BatchNorm1d - ReLU - Linear - BatchNorm1d - ReLU - Linear on every token, masked mean.  The BatchNorms' channel
+        axis is the token position, so T must equal the length they were built for."""
+        c, P = self.cfg, self.P
+        B, T, Kin = feats.shape
+        key, proj, Tbn = (("video_mlp", "vit_proj", c.max_v_frames) if which == "video" else ("audio_mlp", "ast_proj", c.max_snippet_num))
+        if T != Tbn:
+            raise ValueError(f"agg_module=mlp: {which} sequence length {T} != {Tbn} positions of its BatchNorm1d (the reference fails there too)")
+        nrow = B * T
+        mflat = mask.reshape(-1)
+        act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE
+        if self.tc == torch.bfloat16:
+            xin = ops.cast_mask_rows(feats.view(nrow, Kin), mflat, ws["xin"][:nrow * Kin].view(nrow, Kin))
+            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, out=ws["x0"][:nrow])
         else:
-            local = ws["frame_buf"] if which == "video" else ws["seg_buf"]
-        ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat, tile_skip_mask=mflat,
+            x = ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act, out=ws["x0"][:nrow])
+        h = ops.linear(x, P[key + ".0.w"], P[key + ".0.b"], out=ws["ffn"][:nrow, :1024])
+        ops.row_affine(h, P[key + ".1.scale"], P[key + ".1.shift"], act=ops.ACT_RELU)
+        y = ops.linear(h, P[key + ".3.w"], P[key + ".3.b"], out=ws["x1"][:nrow])
+        ops.row_affine(y, P[key + ".4.scale"], P[key + ".4.shift"], act=ops.ACT_RELU)
+        ops.linear(y, P[key + ".6.w"], P[key + ".6.b"], out_row_mask=mflat,
                    segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
-        mean, vec = (ws["vmean"], ws["video"]) if which == "video" else (ws["mmean"], ws["music"])
         ops.masked_mean(local, mask, out=mean)
         ops.l2norm_rows(mean, out_f32=vec)
+
+    def _encode_cls(self, feats: Tensor, mask: Tensor, which: str, ws, local: Tensor, vec: Tensor) -> None:
+        """with_cls_token (reference model/model_Base.py:527-530,572-574): a learned token is prepended (its mask entry is 1), the
+        block runs on T + 1 positions, the clip vector is the token's output and the local features are the other T rows."""
+        c, P = self.cfg, self.P
+        B, T, Kin = feats.shape
+        D = c.D
+        proj, mod, pe, depth, cls = (("vit_proj", "video_transformer", "pe_video", c.video_transformer_depth, "cls_video") if which == "video"
+                                     else ("ast_proj", "audio_transformer", "pe_audio", c.audio_transformer_depth, "cls_audio"))
+        T1 = T + 1
+        if P[pe].shape[0] < T1:
+            raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < T+1={T1} (reference model/model_Base.py:533)")
+        mask1 = torch.cat([torch.ones_like(mask[:, :1]), mask], dim=1).contiguous()
+        rows1 = ops.row_index(mask1)
+        order1 = ops.batch_order(mask1)
+        act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE
+        x = ws["x0"][:B * T1]
+        x3d = x.view(B, T1, D)
+        x3d[:, 0] = (P[cls] + P[pe][0]).to(self.tc)                      # the token, with position 0's encoding
+        seg = Seg(out=x3d[:, 1:], ldo=D, rows_per_batch=T, out_batch_stride=T1 * D)
+        if self.tc == torch.bfloat16:
+            xin = ops.cast_mask_rows(feats.view(B * T, Kin), mask.reshape(-1), ws["xin"][:B * T * Kin].view(B * T, Kin))
+            ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, R=P[pe][1:T1], r_row_mod=T, segs=[seg])
+        else:
+            ops.linear(feats.view(B * T, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mask.reshape(-1), act=act,
+                       R=P[pe][1:T1], r_row_mod=T, segs=[seg])
+        x = self._temporal_layers(x, B, T1, mask1, mod, depth, ws, rows1, order1)
+        y = ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mask1.reshape(-1), out=ws["x1"][:B * T1])
+        y3 = y.view(B, T1, D)
+        ops.l2norm_rows(y3[:, 0], out_f32=vec)
+        local.copy_(y3[:, 1:])
 
     # ------------------------------------------------------------------ X-Pool scoring
     def xpool_sims(self, video: Tensor, seg: Tensor, seg_mask: Tensor, sims_out: Optional[Tensor] = None,

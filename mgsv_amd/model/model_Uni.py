@@ -134,7 +134,7 @@ class Uni_model(nn.Module):
         xpool = _XPoolModule(self)
         for name, arr in sd.items():
             t = torch.from_numpy(arr.copy())
-            is_buf = name.endswith(".pe") or name == "criterion.empty_weight"
+            is_buf = name.endswith((".pe", ".running_mean", ".running_var", ".num_batches_tracked")) or name == "criterion.empty_weight"
             if name.startswith("criterion."):
                 continue
             target, rel = (xpool, name[len(xa) + 1:]) if name.startswith(xa + ".") else (self, name)
@@ -155,7 +155,9 @@ class Uni_model(nn.Module):
         return [p for n, p in self.named_parameters() if n.startswith(tuple(prefixes))]
 
     def get_temporal_parameter(self):
-        return self._params(["vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer."])
+        # reference model/model_Base.py:379-404 (projection + SA parameters)
+        return self._params(["vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.", "share_transformer.", "video_cls_token",
+                             "audio_cls_token", "Video_encoder_projection.", "Music_encoder_projection."])
 
     def get_matching_parameter(self):
         return self._params(["video_guided_to_music_pooling_cross_transformer.", "music_guided_to_video_pooling_cross_transformer."]) + [self.logit_scale]

@@ -393,6 +393,15 @@ def cast_mask_rows(x: Tensor, mask: Optional[Tensor], out: Tensor) -> Tensor:
     return out
 
 
+def row_affine(x: Tensor, scale: Tensor, shift: Tensor, act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
+    """out[r] = act(x[r] * scale[r % P] + shift[r % P]) with P = scale.numel() (made_row_affine); x [rows, cols], in place by default."""
+    assert x.dim() == 2 and x.stride(1) == 1 and scale.numel() == shift.numel()
+    out = x if out is None else out
+    check(lib().made_row_affine(_p(x), dt_of(x), x.stride(0), _p(_f32(scale, "scale")), _p(_f32(shift, "shift")), scale.numel(), act,
+                                _p(out), dt_of(out), out.stride(0), x.shape[0], x.shape[1], _stream()), "made_row_affine")
+    return out
+
+
 def masked_mean(x: Tensor, mask: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
     """x [B,T,D] (unit inner stride), mask [B,T] or None (plain sum) -> [B,D] f32."""
     assert x.dim() == 3 and x.stride(2) == 1

@@ -41,20 +41,37 @@ def param_shapes(cfg: MadeConfig) -> "OrderedDict[str, tuple]":
     # feature projections (model_Base.py:282,289)
     lin("ast_proj", D, cfg.ast_dim)
     lin("vit_proj", D, cfg.vit_dim)
-    # fixed sin/cos tables are persistent buffers (model_Base.py:58)
-    s["video_position_embedding.pe"] = (1, cfg.video_attention_seqlen, D)
-    s["audio_position_embedding.pe"] = (1, cfg.audio_attention_seqlen, D)
-    # temporal blocks (model_Base.py:64-80)
-    for mod, depth in (("video_transformer", cfg.video_transformer_depth),
-                       ("audio_transformer", cfg.audio_transformer_depth)):
-        for l in range(depth):
-            p = f"{mod}.layers.{l}"
-            ln(p + ".0")
-            mha(p + ".1")
-            ln(p + ".2")
-            lin(p + ".3.0", F, D)
-            lin(p + ".3.3", D, F)
-        lin(mod + ".final_linear", D, D)
+    if cfg.agg_module == "mlp":
+        # EmbeddingNet (model_Base.py:216-249,357-377): Linear(D,1024) - BatchNorm1d(T) - ReLU - Linear(1024,D) - BatchNorm1d(T) -
+        # ReLU - Linear(D,D); BatchNorm1d sees [B, T, F] so its channels are the T token positions
+        for mod, T in (("Video_encoder_projection", cfg.max_v_frames), ("Music_encoder_projection", cfg.max_snippet_num)):
+            lin(mod + ".net.0", 1024, D)
+            for bn in (".net.1", ".net.4"):
+                s[mod + bn + ".weight"] = (T,); s[mod + bn + ".bias"] = (T,)
+                s[mod + bn + ".running_mean"] = (T,); s[mod + bn + ".running_var"] = (T,)
+                s[mod + bn + ".num_batches_tracked"] = ()
+            lin(mod + ".net.3", D, 1024)
+            lin(mod + ".net.6", D, D)
+    else:
+        if cfg.with_cls_token:                              # model_Base.py:314-321
+            s["video_cls_token"] = (1, 1, D)
+            s["audio_cls_token"] = (1, 1, D)
+        # fixed sin/cos tables are persistent buffers (model_Base.py:58)
+        s["video_position_embedding.pe"] = (1, cfg.video_attention_seqlen, D)
+        s["audio_position_embedding.pe"] = (1, cfg.audio_attention_seqlen, D)
+        # temporal blocks (model_Base.py:64-80); one shared block when transformer_is_share (model_Base.py:300-302,322-331)
+        share = bool(cfg.transformer_is_share) and cfg.video_transformer_depth == cfg.audio_transformer_depth and cfg.video_transformer_depth > 0
+        mods = ((("share_transformer", cfg.video_transformer_depth),) if share else
+                (("video_transformer", cfg.video_transformer_depth), ("audio_transformer", cfg.audio_transformer_depth)))
+        for mod, depth in mods:
+            for l in range(depth):
+                p = f"{mod}.layers.{l}"
+                ln(p + ".0")
+                mha(p + ".1")
+                ln(p + ".2")
+                lin(p + ".3.0", F, D)
+                lin(p + ".3.3", D, F)
+            lin(mod + ".final_linear", D, D)
     # DETR transformer (music_detr/transformer.py)
     Fd = cfg.detr_dim_feedforward
     for l in range(cfg.detr_enc_layers):
@@ -157,6 +174,14 @@ def make_state_dict(cfg: MadeConfig, seed: int = 0) -> "OrderedDict[str, np.ndar
             sd[name] = w
         elif name == "decoder_query_embed.weight":
             sd[name] = rng.standard_normal(shape, dtype=np.float32)
+        elif name.endswith(".num_batches_tracked"):
+            sd[name] = np.array(0, dtype=np.int64)
+        elif name.endswith(".running_var"):
+            sd[name] = (0.5 + np.abs(rng.standard_normal(shape, dtype=np.float32))).astype(np.float32)
+        elif name.endswith(".running_mean"):
+            sd[name] = (0.3 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        elif name.endswith("_cls_token"):
+            sd[name] = (0.02 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
         elif len(shape) == 2:                  # Linear weight / in_proj_weight
             sd[name] = (rng.standard_normal(shape, dtype=np.float32) / np.float32(math.sqrt(shape[1])))
         else:                                  # 1-D: bias or LayerNorm

@@ -118,14 +118,14 @@ def mha(xq: Tensor, xk: Tensor, xv: Tensor, P, name: str, H: int,
 
 
 # ------------------------------------------------------------ K1-K4: feature encoders
-def temporal_block(x: Tensor, mask: Tensor, P, mod: str, depth: int, H: int, drop: Optional[Drop] = None) -> Tensor:
+def temporal_block(x: Tensor, mask: Tensor, P, mod: str, depth: int, H: int, drop: Optional[Drop] = None, tag: Optional[str] = None) -> Tensor:
     """reference: model/model_Base.py:82-91 (Transformer_enhancement.forward), SURVEY A4.
     Residuals are taken onto the *normalised* tensors; erf-GELU FFN; final Linear.
     Train mode: dropout (p = 0.8, model_Uni.py:41) on the attention weights, after the GELU and after the second
     Linear (model_Base.py:69-75)."""
     pad = ~(mask.bool())
     pt = drop.p_temporal if drop is not None else 0.0
-    tag = "video" if mod.startswith("video") else "audio"
+    tag = tag or ("video" if mod.startswith("video") else "audio")        # dropout site names follow the tower, not the module
     for l in range(depth):
         p = f"{mod}.layers.{l}"
         x = layer_norm(x, P, p + ".0")
@@ -136,26 +136,53 @@ def temporal_block(x: Tensor, mask: Tensor, P, mod: str, depth: int, H: int, dro
     return linear(x, P, mod + ".final_linear")
 
 
+def embedding_net(x: Tensor, P, mod: str) -> Tensor:
+    """reference: model/model_Base.py:216-249 in eval mode (hidden_size = 1024, use_bn): Linear - BatchNorm1d - ReLU - Linear -
+    BatchNorm1d - ReLU - Linear.  BatchNorm1d gets [B, T, F], so its channel axis is the token position t: with the running
+    statistics it is the per-position affine (y - mean[t]) / sqrt(var[t] + 1e-5) * weight[t] + bias[t]."""
+    def bn(y, name):
+        sc = P[name + ".weight"] / torch.sqrt(P[name + ".running_var"] + 1e-5)
+        return (y - P[name + ".running_mean"][None, :, None]) * sc[None, :, None] + P[name + ".bias"][None, :, None]
+    h = torch.relu(bn(linear(x, P, mod + ".net.0"), mod + ".net.1"))
+    h = torch.relu(bn(linear(h, P, mod + ".net.3"), mod + ".net.4"))
+    return linear(h, P, mod + ".net.6")
+
+
 def encode_features(feats: Tensor, mask: Tensor, P, cfg, which: str, drop: Optional[Drop] = None) -> Tuple[Tensor, Tensor]:
     """reference: model/model_Base.py:544-581 (video) / :583-617 (audio) with
-    temporal_transformer :520-542.  Returns (local_feats [B,T,D], global_feats [B,D])."""
+    temporal_transformer :520-542.  Returns (local_feats [B,T,D], global_feats [B,D]).
+    Variants: one shared temporal block (transformer_is_share), a learned CLS token whose output is the clip vector
+    (with_cls_token), the EmbeddingNet aggregator instead of the temporal block (agg_module = "mlp", eval mode)."""
     proj, mod, pe, depth = (("vit_proj", "video_transformer", "video_position_embedding.pe",
                              cfg.video_transformer_depth) if which == "video" else
                             ("ast_proj", "audio_transformer", "audio_position_embedding.pe",
                              cfg.audio_transformer_depth))
+    if cfg.transformer_is_share and cfg.video_transformer_depth == cfg.audio_transformer_depth and depth > 0:
+        mod = "share_transformer"
     valid = (mask != 0).unsqueeze(-1)
     x = feats * valid                                            # masked_fill(mask==0, 0)
     x = linear(x, P, proj)
     if cfg.with_act_after_proj:
         x = quick_gelu(x)
-    if depth > 0:
+    if cfg.agg_module == "mlp":
+        assert drop is None, "EmbeddingNet in train mode (batch statistics) is not restated"
+        x = embedding_net(x, P, "Video_encoder_projection" if which == "video" else "Music_encoder_projection")
+        x = x * valid
+    elif depth > 0:
+        if cfg.with_cls_token:                                   # model_Base.py:527-530: token first, its mask entry is 1
+            tok = P[("video" if which == "video" else "audio") + "_cls_token"].to(x.dtype)
+            x = torch.cat([tok.expand(x.shape[0], -1, -1), x], dim=1)
+            mask = torch.cat([torch.ones_like(mask[:, :1]), mask], dim=1)
+            valid = (mask != 0).unsqueeze(-1)
         T = x.shape[1]
         table = P[pe]
         if table.shape[1] < T:
             raise ValueError(f"{pe} holds {table.shape[1]} positions < T={T} (model_Base.py:533)")
         x = x + table[:, :T]
-        x = temporal_block(x, mask, P, mod, depth, cfg.SA_temporal_heads, drop)
+        x = temporal_block(x, mask, P, mod, depth, cfg.SA_temporal_heads, drop, tag=which)
         x = x * valid
+        if cfg.with_cls_token:                                   # model_Base.py:572-574: the token's output, not the mean
+            return x[:, 1:], l2_normalize(x[:, 0])
     g = x.sum(1) / mask.sum(1, keepdim=True)
     return x, l2_normalize(g)
 

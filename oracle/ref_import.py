@@ -82,7 +82,7 @@ def build_reference_model(cfg, state_dict_np, T_a_max=None):
     # audio PE table is hard-coded to 300 positions (model_Base.py:293); rebuild when longer
     from model.model_Base import PositionalEncoding
     need = cfg.audio_attention_seqlen
-    if model.audio_position_embedding.pe.shape[1] != need:
+    if hasattr(model, "audio_position_embedding") and model.audio_position_embedding.pe.shape[1] != need:
         model.audio_position_embedding = PositionalEncoding(seq_len=need, dim_model=cfg.D)
     sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in state_dict_np.items()}
     ref_keys = set(model.state_dict().keys())

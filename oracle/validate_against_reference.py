@@ -212,6 +212,12 @@ def main():
     report["native_regression_B4"] = compare_forward(c, 4, 50, 96, "native regression head")
     c = cfg_native(); c.mml_localization = "regression"; c.predict_center = 1; c.mml_fusion = "CA"
     report["native_regression_center_CA_B4"] = compare_forward(c, 4, 50, 96, "native regression head, predict_center, CA")
+    c = cfg_native(); c.transformer_is_share = 1
+    report["native_shared_block_B4"] = compare_forward(c, 4, 50, 96, "native shared temporal block")
+    c = cfg_native(); c.with_cls_token = 1
+    report["native_cls_token_B4"] = compare_forward(c, 4, 50, 96, "native CLS-token pooling")
+    c = cfg_native(); c.agg_module = "mlp"; c.video_transformer_depth = c.audio_transformer_depth = 0
+    report["native_agg_mlp_B4"] = compare_forward(c, 4, 50, 96, "native EmbeddingNet aggregator (eval-mode BatchNorm)")
     c = cfg_headline()
     report["cfg2_B4"] = compare_forward(c, 4, 30, 512, "cfg2 shape B=4 Tv=30 Ta=512 D=512")
     report["grad_eval_native_B3"] = compare_backward(cfg_native(), 3, 20, 40, "native eval-mode grads", train=False)

@@ -72,6 +72,9 @@ VARIANTS = {      # name -> cfg overrides (on cfg_native): the option variants o
     "audio_short_cut_fb10": {"audio_short_cut": 1, "fb_label": "10"},
     "regression": {"mml_localization": "regression"},
     "regression_center_CA": {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
+    "shared_temporal_block": {"transformer_is_share": 1},
+    "cls_token": {"with_cls_token": 1},
+    "agg_mlp": {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_depth": 0},
 }
 
 
@@ -93,6 +96,8 @@ def variants_fixture(B: int = 4, T_v: int = 50, T_a: int = 96):
         for k in ("pred_logits", "pred_spans", "proj_queries"):
             if k in om:
                 fix[f"{name}.{k}"] = om[k].numpy()
+        fix[f"{name}.video_feats"] = fm["video_feats"].numpy()
+        fix[f"{name}.music_feats"] = fm["music_feats"].numpy()
         fix[f"{name}.retrieval_loss"] = np.float32(lm["retrieval_loss"])
         fix[f"{name}.localization_loss"] = np.float32(lm["localization_loss"])
         for k, v in lm["localization_loss_dict"].items():

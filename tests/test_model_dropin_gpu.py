@@ -114,7 +114,7 @@ def test_training_loop_body_of_the_reference_driver_runs_unchanged():
     assert float(lm["retrieval_loss"] + lm["localization_loss"]) < losses[0]
 
 
-@pytest.mark.parametrize("name", ["xa_music_video_single", "regression_center_CA"])
+@pytest.mark.parametrize("name", ["xa_music_video_single", "regression_center_CA", "agg_mlp", "cls_token", "shared_temporal_block"])
 def test_dropin_option_variants(golden_dir, name):
     """The drop-in module on two option variants (second X-Pool tower; regression head + predict_center + CA fusion): key layout,
     optimizer groups and outputs as the reference's (tests/golden/variants.npz)."""
