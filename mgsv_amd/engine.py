@@ -667,6 +667,12 @@ class MadeEngine:
                 mq = music if Q == 1 else music[:, None, :].expand(B, Q, D).contiguous()
                 ops_train.add3(ws["pq_raw"], pq, mq, b_mod=B * Q * D)
                 ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
+                if c.aux_loss and nd > 1:
+                    # the auxiliary layers get the short-cut a SECOND time when their output dicts are built (reference
+                    # model/model_Uni.py:166-169 adds the music vector to the already short-cut proj_queries[:-1])
+                    n_aux = (nd - 1) * B * Q
+                    ops_train.add3(ws["pq_raw"][:n_aux], pq.view(nd * B * Q, -1)[:n_aux], mq, b_mod=B * Q * D)
+                    ops.l2norm_rows(ws["pq_raw"][:n_aux], out_f32=pq.view(nd * B * Q, -1)[:n_aux])
             self._frame_rows_linear(frame, P["proj_v.w"], P["proj_v.b"], ws["pv_raw"], B, Tv)
             pv = ws["pv"]
             ops.l2norm_rows(ws["pv_raw"], out_f32=pv.view(B * Tv, Dc))

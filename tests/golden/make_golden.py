@@ -70,6 +70,7 @@ VARIANTS = {      # name -> cfg overrides (on cfg_native): the option variants o
     "xa_video_single": {"vmr_fusion": "XA-video", "vmr_loss": "single"},
     "predict_center": {"predict_center": 1},
     "audio_short_cut_fb10": {"audio_short_cut": 1, "fb_label": "10"},
+    "audio_short_cut_Q3": {"audio_short_cut": 1, "num_moment_queries": 3},
     "regression": {"mml_localization": "regression"},
     "regression_center_CA": {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
     "shared_temporal_block": {"transformer_is_share": 1},
