@@ -63,8 +63,10 @@ class MadeEngine:
             unsupported.append("moment_loss")
         if c.audio_short_cut and not c.contrastive_align_loss:
             unsupported.append("audio_short_cut without contrastive_align_loss")
-        if c.moment_query_type not in ("video", "music", "zero", "random"):
+        if c.moment_query_type not in ("video", "music", "zero", "random", "xpool"):
             unsupported.append(f"moment_query_type={c.moment_query_type}")
+        if c.moment_query_type == "xpool" and "music" not in c.vmr_fusion:
+            unsupported.append("moment_query_type=xpool without the music-pooling tower (the reference fails there too)")
         if c.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse"):
             unsupported.append(f"vmr_loss={c.vmr_loss}")
         if c.detr_dec_layers < 1:
@@ -540,7 +542,8 @@ class MadeEngine:
         # beside the (latency-bound) decoder and join at the end of the step
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if (want_pooled and "music" in c.vmr_fusion) else None
+            need_pooled = want_pooled or c.moment_query_type == "xpool"
+            pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if (need_pooled and "music" in c.vmr_fusion) else None
             if "music" in c.vmr_fusion:
                 self.xpool_sims(video, seg, sm if c.fusion_mask == 1 else None, sims_out=ws["sims_single"], pooled_out=pooled)
             if "video" in c.vmr_fusion:
@@ -594,6 +597,10 @@ class MadeEngine:
         tgt = ws["tgt"]
         if c.moment_query_type in ("video", "music"):
             src_vec = video if c.moment_query_type == "video" else music
+            tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        elif c.moment_query_type == "xpool":                             # reference model_Uni.py:222-223: the track's pooled vectors,
+            cur.wait_stream(side)                                        # averaged over the videos of the batch (X-Pool branch first)
+            src_vec = ops.masked_mean(pooled.view(B, B, D), torch.ones(B, B, device=self.device))
             tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
         else:                                                            # "zero" / "random": reference transformer.py:73-74
             tgt.zero_()

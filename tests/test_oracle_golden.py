@@ -190,6 +190,7 @@ VARIANTS = {      # the same table as tests/golden/make_golden.py (SURVEY sectio
     "predict_center": {"predict_center": 1},
     "audio_short_cut_fb10": {"audio_short_cut": 1, "fb_label": "10"},
     "audio_short_cut_Q3": {"audio_short_cut": 1, "num_moment_queries": 3},
+    "xpool_query": {"moment_query_type": "xpool"},
     "regression": {"mml_localization": "regression"},
     "regression_center_CA": {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
     "shared_temporal_block": {"transformer_is_share": 1},
