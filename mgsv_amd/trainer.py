@@ -254,11 +254,20 @@ class MadeTrainer(MadeEngine):
         """One iteration of the reference's loop body (train-MaDe.py:337-381): forward, backward, (data-parallel gradient
         average: one RCCL all-reduce of the flat buffer), clip + Adam, repack."""
         out = self.forward_train(frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed=seed, music_ids=music_ids)
-        self.backward(w_ret, w_loc)
         scale = 1.0
         if dist is not None and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_grad)
+            # two buckets of the flat f32 gradient buffer (RCCL all-reduce, sum; the 1/W goes into the optimizer's grad_scale): the
+            # matching + detection ranges (~85 % of the bytes) are final before the temporal encoders' backward starts and travel
+            # under it; the temporal range follows at the end
+            cut = self.group_ranges[0][1]
+            works = []
+            self.backward(w_ret, w_loc, grad_sync=lambda: works.append(dist.all_reduce(self.flat_grad[cut:], async_op=True)))
+            works.append(dist.all_reduce(self.flat_grad[:cut], async_op=True))
+            for w in works:
+                w.wait()
             scale = 1.0 / dist.get_world_size()
+        else:
+            self.backward(w_ret, w_loc)
         self.optimizer_step(*lrs, max_grad_norm=max_grad_norm, grad_scale=scale)
         return out
 
@@ -697,8 +706,10 @@ class MadeTrainer(MadeEngine):
         return self._rows.get(mask.data_ptr()) if mask is not None else None
 
     @torch.no_grad()
-    def backward(self, g_ret: Optional[Tensor] = None, g_loc: Optional[Tensor] = None, zero_grad: bool = True) -> None:
-        """Gradients of g_ret * retrieval_loss + g_loc * localization_loss (device scalars, default 1) into `flat_grad`."""
+    def backward(self, g_ret: Optional[Tensor] = None, g_loc: Optional[Tensor] = None, zero_grad: bool = True, grad_sync=None) -> None:
+        """Gradients of g_ret * retrieval_loss + g_loc * localization_loss (device scalars, default 1) into `flat_grad`.
+        grad_sync(): called once, at the point where every gradient except the temporal group's (the first range of the flat
+        buffer) is final -- data-parallel training starts that part's all-reduce there, under the encoders' backward."""
         c, P, G = self.cfg, self.P, self.G
         B, Tv, Ta = self._shape
         ws, tw = self._buffers(B, Tv, Ta), self._train_buffers(B, Tv, Ta)
@@ -912,6 +923,8 @@ class MadeTrainer(MadeEngine):
             dq_vec = dvideo if c.moment_query_type == "video" else dmusic
             tr.add3(dq_vec, dq_vec, dtgt0.view(B, D) if Q == 1 else dtgt0.view(B, Q, D).float().sum(dim=1))    # the vector was repeated Q times
 
+        if grad_sync is not None:
+            grad_sync()
         # ---------------- temporal encoders (video on the second stream)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
