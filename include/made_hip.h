@@ -505,12 +505,14 @@ int made_head_bias(void* x, int32_t x_dtype, int64_t ldx, const float* s, const 
 int made_head_bias_bwd(const void* dy, int32_t dtype, int64_t ld, const float* s, const float* bias, float* dbias, float* ds,
                        int64_t rows, int64_t H, int64_t hd, void* stream);
 
-/* made_gate_rows: out[r, c] = dropout(x[r, c] * act'(G[r, c]) * scale)  (element index of the dropout r*drop_ld + c; rows whose
- * row_skip is 0 are left untouched).  The element-wise options of a made_linear epilogue for the places of the backward chain
+/* made_gate_rows: out[r, c] = dropout(x[r, c] * act'(G[r, c]) * scale)  (element index of the dropout r*drop_ld + c/drop_col_div,
+ * drop_col_div <= 0 meaning 1: with drop_col_div = head width and drop_ld = H the mask is one draw per (row, head) -- the
+ * attention-weight dropout of a self-attention over a single key, whose only weight is 1; rows whose row_skip is 0 are left
+ * untouched).  The element-wise options of a made_linear epilogue for the places of the backward chain
  * where no GEMM can carry them: the activation after the input projection (reference model/model_Base.py:559-561, whose
  * input needs no gradient) and a residual stream that enters a dropped branch (temporal blocks deeper than one layer). */
 int made_gate_rows(const void* x, int32_t x_dtype, int64_t ldx, const void* G, int32_t g_dtype, int64_t ldg, int32_t gate,
-                   float scale, const MadeDropout* drop, int64_t drop_ld, void* out, int32_t out_dtype, int64_t ldo,
+                   float scale, const MadeDropout* drop, int64_t drop_ld, int64_t drop_col_div, void* out, int32_t out_dtype, int64_t ldo,
                    const float* row_skip, int64_t rows, int64_t cols, void* stream);
 /* out = a + b + c over n contiguous elements (b, c may be NULL; any mix of f32 / bf16): merges gradient streams.
  * b_mod > 0: b is broadcast, b[i % b_mod] (the decoder's query embedding added to every sample). */

@@ -73,8 +73,8 @@ __device__ __forceinline__ float gate_grad(float g, int gate) {
 }
 
 __global__ __launch_bounds__(RT) void gate_rows_kernel(const void* x, int xdt, int64_t ldx, const void* G, int gdt, int64_t ldg, int gate,
-                                                       float scale, MadeDropout drop, int64_t drop_ld, void* out, int odt, int64_t ldo,
-                                                       const float* row_skip, int64_t rows, int cols) {
+                                                       float scale, MadeDropout drop, int64_t drop_ld, int drop_col_div, void* out, int odt,
+                                                       int64_t ldo, const float* row_skip, int64_t rows, int cols) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (RT / 64) + (threadIdx.x >> 6);
     if (row >= rows || (row_skip && row_skip[row] == 0.f)) return;
@@ -90,9 +90,9 @@ __global__ __launch_bounds__(RT) void gate_rows_kernel(const void* x, int xdt, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= scale;
         if (drop.p > 0.f) {
-            const uint64_t base = (uint64_t)row * (uint64_t)drop_ld + (uint64_t)c;
+            const uint64_t base = (uint64_t)row * (uint64_t)drop_ld;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = keep_at(drop, thr, base + j) ? v[j] * dsc : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = keep_at(drop, thr, base + (uint64_t)((c + j) / drop_col_div)) ? v[j] * dsc : 0.f;
         }
         st4(out, odt, row * ldo + c, v);
     }
@@ -650,8 +650,8 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
 }
 
 extern "C" int made_gate_rows(const void* x, int32_t x_dtype, int64_t ldx, const void* G, int32_t g_dtype, int64_t ldg, int32_t gate,
-                              float scale, const MadeDropout* drop, int64_t drop_ld, void* out, int32_t out_dtype, int64_t ldo,
-                              const float* row_skip, int64_t rows, int64_t cols, void* stream) {
+                              float scale, const MadeDropout* drop, int64_t drop_ld, int64_t drop_col_div, void* out, int32_t out_dtype,
+                              int64_t ldo, const float* row_skip, int64_t rows, int64_t cols, void* stream) {
     MADE_REQUIRE(x && out, "made_gate_rows: null pointer");
     MADE_REQUIRE(gate == MADE_GATE_NONE || G != nullptr, "made_gate_rows: gate without G");
     MADE_UNSUPPORTED(cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (G == nullptr || ldg % 4 == 0), "made_gate_rows: bad cols/strides");
@@ -660,7 +660,7 @@ extern "C" int made_gate_rows(const void* x, int32_t x_dtype, int64_t ldx, const
     if (drop) d = *drop;
     MADE_REQUIRE(d.p >= 0.f && d.p < 1.f, "made_gate_rows: dropout p out of [0,1)");
     hipLaunchKernelGGL(gate_rows_kernel, dim3(blocks4(rows)), dim3(RT), 0, (hipStream_t)stream, x, x_dtype, ldx, G, g_dtype, ldg, gate, scale,
-                       d, drop_ld > 0 ? drop_ld : cols, out, out_dtype, ldo, row_skip, rows, (int)cols);
+                       d, drop_ld > 0 ? drop_ld : cols, (int)(drop_col_div > 0 ? drop_col_div : 1), out, out_dtype, ldo, row_skip, rows, (int)cols);
     return made_check_launch("made_gate_rows");
 }
 

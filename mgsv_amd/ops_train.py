@@ -218,12 +218,13 @@ def add3(out: Tensor, a: Tensor, b: Optional[Tensor] = None, c: Optional[Tensor]
 
 
 def gate_rows(x: Tensor, out: Tensor, *, G: Optional[Tensor] = None, gate: int = 0, scale: float = 1.0, drop=None, drop_ld: int = 0,
-              row_skip: Optional[Tensor] = None) -> Tensor:
-    """out = dropout(x * act'(G) * scale), row-wise (made_gate_rows); x / G / out [rows, cols] with unit inner stride."""
+              drop_col_div: int = 1, row_skip: Optional[Tensor] = None) -> Tensor:
+    """out = dropout(x * act'(G) * scale), row-wise (made_gate_rows); x / G / out [rows, cols] with unit inner stride; dropout
+    element index row*drop_ld + col // drop_col_div."""
     rows, cols = x.shape
     assert x.stride(1) == 1 and out.stride(1) == 1 and out.shape == x.shape and (G is None or (G.shape == x.shape and G.stride(1) == 1))
     check(lib().made_gate_rows(_p(x), dt_of(x), x.stride(0), _p(G), _dt(G), G.stride(0) if G is not None else 0, gate, scale,
-                               _drop_ptr(drop), drop_ld, _p(out), dt_of(out), out.stride(0), _p(_f32(row_skip, "row_skip")), rows, cols,
+                               _drop_ptr(drop), drop_ld, drop_col_div, _p(out), dt_of(out), out.stride(0), _p(_f32(row_skip, "row_skip")), rows, cols,
                                _stream()), "made_gate_rows")
     return out
 

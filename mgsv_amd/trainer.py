@@ -509,11 +509,18 @@ class MadeTrainer(MadeEngine):
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
             tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
             qkv = tw[d + ".qkv"]
-            ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
-                       segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
-            q3 = qkv.view(B, Q, 3 * D)
-            ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), H, lse=tw[d + ".lse"],
-                          drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+            if Q == 1:
+                # one query, one key: the softmax weight is 1, so the block is the value path; its attention-weight dropout is one
+                # draw per (sample, head) (element index (b*H + h)*1*1), and q / k get no gradient
+                Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
+                ops.linear(tgt, Wsa[2 * D:], bsa[2 * D:], segs=[Seg(out=qkv[:, 2 * D:], ldo=qkv.stride(0))])
+                tr.gate_rows(qkv[:, 2 * D:], tw[d + ".att"], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+            else:
+                ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
+                           segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
+                q3 = qkv.view(B, Q, 3 * D)
+                ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), H, lse=tw[d + ".lse"],
+                              drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
             ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
             t1 = tw[d + ".t1"]
             ops.layernorm_add(ta, P[p + ".ln1.g"], P[p + ".ln1.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t1, tw[d + ".t1q"])
@@ -827,15 +834,19 @@ class MadeTrainer(MadeEngine):
             tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
                              dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
             datt = ops.linear(g_sa, P[p + ".sa.out.wt"], None, out=g4)
-            qkv = tw[d + ".qkv"]
-            q3, g3v = qkv.view(B, Q, 3 * D), gqkv.view(B, Q, 3 * D)
-            tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), datt.view(B, Q, D),
-                             g3v[:, :, :D], g3v[:, :, D:2 * D], g3v[:, :, 2 * D:], tw[d + ".lse"], tw["d_delta"], H,
-                             drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
-            dtgt = ops.linear(gqkv, P[p + ".sa.in.wt"], None, R=g2, out=tw["dtgt"])
-            # the query embedding also enters through q,k of the self-attention
-            dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
-            tr.colsum(dqk.view(B, Q * D), G["query_embed"].view(-1))
+            if Q == 1:                                        # value path only (see the forward): dv = datt under the same per-head mask
+                tr.gate_rows(datt, gqkv[:, 2 * D:], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+                dtgt = ops.linear(gqkv[:, 2 * D:], P[p + ".sa.in.wt"][:, 2 * D:], None, R=g2, out=tw["dtgt"])
+            else:
+                qkv = tw[d + ".qkv"]
+                q3, g3v = qkv.view(B, Q, 3 * D), gqkv.view(B, Q, 3 * D)
+                tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), datt.view(B, Q, D),
+                                 g3v[:, :, :D], g3v[:, :, D:2 * D], g3v[:, :, 2 * D:], tw[d + ".lse"], tw["d_delta"], H,
+                                 drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+                dtgt = ops.linear(gqkv, P[p + ".sa.in.wt"], None, R=g2, out=tw["dtgt"])
+                # the query embedding also enters through q,k of the self-attention
+                dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
+                tr.colsum(dqk.view(B, Q * D), G["query_embed"].view(-1))
         dtgt0 = dtgt                                          # gradient of the decoder's content query = the clip-level vector
 
         # ---- weight gradients of all decoder layers: one layer-batched product per parameter (the layers' parameters, and
@@ -864,7 +875,8 @@ class MadeTrainer(MadeEngine):
         batched(st["g_ca"], st["attc"], ".ca.out.w", ".ca.out.b")
         batched(st["g_qc"], st["t1q"], ".ca.in.w", ".ca.in.b", w_rows=(0, D))
         batched(st["g_sa"], st["att"], ".sa.out.w", ".sa.out.b")
-        batched(st["g_qkv"], st["tq"], ".sa.in.w", ".sa.in.b", a_cols=(0, 2 * D), w_rows=(0, 2 * D))
+        if Q > 1:                                             # (a single query's q / k projections get no gradient)
+            batched(st["g_qkv"], st["tq"], ".sa.in.w", ".sa.in.b", a_cols=(0, 2 * D), w_rows=(0, 2 * D))
         batched(st["g_qkv"], st["tgt"], ".sa.in.w", ".sa.in.b", a_cols=(2 * D, 3 * D), w_rows=(2 * D, 3 * D))
         # per-head products of the memory-space cross-attention, batched over (layer, head)
         gWin0 = G[p0 + ".ca.in.w"]
