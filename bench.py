@@ -73,6 +73,48 @@ def cpu_baseline(cfg, sd, inp, steps: int):
                 sample=f"{steps} eval forwards of the same B={B} batch (oracle/made_oracle.py, torch CPU f32, {n} threads), {dt:.2f} s each")
 
 
+def cpu_baseline_retrieval(cfg, sd, S: int, n_v: int = 2048, n_m: int = 256):
+    """The oracle's all-pairs retrieval scoring (reference test-MaDe.py:386-403, video chunks of 512) on a bounded sample."""
+    from oracle import made_oracle as O
+    P = O.to_torch_params(sd)
+    ri = synth.make_retrieval_inputs(n_v, n_m, S, cfg.D, seed=3)
+    n = torch.get_num_threads()
+    with torch.no_grad():
+        O.retrieval_sim_matrix(P, cfg, ri["video_embeds"][:512], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])   # warm-up
+        t0 = time.perf_counter()
+        O.retrieval_sim_matrix(P, cfg, ri["video_embeds"], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
+        dt = time.perf_counter() - t0
+    byts = 4.0 * (n_m * S * cfg.D + n_m * S + n_v * cfg.D + n_m * cfg.D + n_v * n_m)
+    return dict(value=round(byts / dt / 1e9, 4), unit="GB/s", cores=n, kind="port", pairs_per_s=round(n_v * n_m / dt, 1),
+                sample=f"one pass over {n_v} videos x {n_m} tracks, S={S}, D={cfg.D} (oracle/made_oracle.py, torch CPU f32, {n} threads), {dt:.2f} s")
+
+
+def cpu_baseline_train(cfg, sd, inp, B: int = 16):
+    """The oracle's train-mode forward (dropout on) + autograd backward on a bounded sample: the first B samples of the batch."""
+    from oracle import made_oracle as O
+    P = O.to_torch_params(sd)
+    names = [k for k, v in P.items() if v.is_floating_point() and not k.endswith(".pe") and k != "criterion.empty_weight"]
+    for k in names:
+        P[k].requires_grad_(True)
+    sub = {k: (v[:B] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    n = torch.get_num_threads()
+
+    def one(seed):
+        r = O.forward(P, cfg, sub["frame_feats"], sub["segment_feats"], sub["frame_masks"], sub["segment_masks"], sub["spans_target"],
+                      v_duration=sub["v_duration"], drop=O.Drop(seed, p_detr=cfg.detr_dropout))
+        (r["retrieval_loss"] + r["localization_loss"]).backward()
+        for k in names:
+            P[k].grad = None
+
+    one(1)
+    t0 = time.perf_counter()
+    one(2)
+    dt = time.perf_counter() - t0
+    return dict(value=round(B / dt, 3), unit="pairs/s", cores=n, kind="port",
+                sample=f"one train-mode forward + backward of the first {B} samples (oracle/made_oracle.py autograd, torch CPU f32, {n} threads; "
+                       f"no optimizer step), {dt:.2f} s")
+
+
 def retrieval_main(args, rank, world, local, dist):
     """BASELINE.json configs[3]: all-pairs video x music similarity, videos row-sharded over the ranks, music side
     all-gathered once per pass (RCCL).  A step = one full pass (exchange + scoring).  Strong scaling: the problem is fixed."""
@@ -139,7 +181,8 @@ def retrieval_main(args, rank, world, local, dist):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[3]: N_v={N_v}, N_m={N_m}, S={S}, D={D}; videos row-sharded, music all-gathered",
                        "pairs_per_s": round(pairs / sec, 1), "algorithmic_gb": round(alg_bytes / 1e9, 3)},
-            "roofline": roof, "cpu_baseline": None}))
+            "roofline": roof,
+            "cpu_baseline": (cpu_baseline_retrieval(cfg, synth.make_state_dict(cfg, seed=0), S) if (world == 1 and not args.no_cpu_baseline) else None)}))
 
 
 def train_main(args, rank, world, local, dist):
@@ -207,9 +250,11 @@ def train_main(args, rank, world, local, dist):
             "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 4}]: B={B}/GPU, T_v={Tv}, T_a={Ta}, D={cfg.D}, train mode (dropout on), "
                                    "f32 master weights + Adam, f32 gradient accumulation",
-                       "global_batch": world * B, "parallelism": f"dp{world}: one all-reduce of the flat f32 gradient buffer per step",
+                       "global_batch": world * B, "parallelism": f"dp{world}: the flat f32 gradient buffer all-reduced in two buckets, the large one under the encoders' backward",
                        "launch": "eager"},
-            "roofline": roof, "cpu_baseline": None, "kernels": per_kernel}))
+            "roofline": roof,
+            "cpu_baseline": (cpu_baseline_train(cfg, sd, inp) if (world == 1 and not args.no_cpu_baseline) else None),
+            "kernels": per_kernel}))
 
 
 def main():
