@@ -96,6 +96,16 @@ class MadeConfig:
             if hasattr(args, f.name):
                 kw[f.name] = getattr(args, f.name)
         cfg = cls(**kw)
+        # flags that select code this build does not have must fail loudly, not be ignored
+        bad = []
+        if getattr(args, "detr_pre_norm", False):
+            bad.append("detr_pre_norm (pre-norm DETR layers, music_detr/transformer.py:180-189,246-271)")
+        if getattr(args, "span_loss_type", "l1") != "l1":
+            bad.append(f"span_loss_type={args.span_loss_type} (only the l1 span head / matcher cost is built)")
+        if getattr(args, "position_embedding", "sine") not in ("sine", "v2"):
+            bad.append(f"position_embedding={args.position_embedding}")
+        if bad:
+            raise NotImplementedError("MaDe HIP path does not cover: " + "; ".join(bad))
         if hasattr(args, "max_m_duration") and hasattr(args, "stride") and not hasattr(args, "max_snippet_num"):
             cfg.max_snippet_num = int(args.max_m_duration / args.stride)
         return cfg

@@ -44,3 +44,19 @@ def test_derived_fields_and_checks():
     a = driver.parse_option(["--name", "x", "--audio_short_cut", "0"])
     assert driver.lr_factor(a, 0, 10, 100) == 0.0 and abs(driver.lr_factor(a, 5, 10, 100) - 0.5) < 1e-12
     assert abs(driver.lr_factor(a, 55, 10, 100) - 0.5) < 1e-12 and driver.lr_factor(a, 100, 10, 100) < 1e-12
+
+
+def test_flags_that_select_unbuilt_code_fail_loudly():
+    """A legal reference flag the HIP path has no code for must raise when the configuration is built, never be dropped silently."""
+    import pytest
+    from mgsv_amd.config import MadeConfig, cfg_native
+    for k, v in (("detr_pre_norm", True), ("span_loss_type", "ce"), ("position_embedding", "learned")):
+        args = cfg_native().to_args(local_rank=0)
+        setattr(args, k, v)
+        with pytest.raises(NotImplementedError):
+            MadeConfig.from_args(args)
+    # encoder-variant flags are carried into the configuration (they used to be ignored)
+    args = cfg_native().to_args(local_rank=0)
+    args.with_cls_token, args.transformer_is_share, args.agg_module = 1, 1, "transf"
+    c = MadeConfig.from_args(args)
+    assert c.with_cls_token == 1 and c.transformer_is_share == 1 and c.agg_module == "transf"
