@@ -158,6 +158,20 @@ typedef struct MadeLinearArgs {
 
 int made_linear(const MadeLinearArgs* args, void* stream);
 
+/* Which kernel made_linear dispatches these arguments to (no launch; for profilers and bench.py's per-kernel roofline, so a
+ * HIP-event average can be set beside rocprofv3's per-symbol average). */
+enum MadeLinearVariant {
+    MADE_LINEAR_GENERAL_F32 = 0,    /* linear_kernel<float, float>: exact-f32 MFMA, every option */
+    MADE_LINEAR_GENERAL_F32IN = 1,  /* linear_kernel<float, bf16>: f32 activations converted in the prologue */
+    MADE_LINEAR_GENERAL_BF16 = 2,   /* linear_kernel<bf16, bf16>: split-K, additive A2, transposed segments */
+    MADE_LINEAR_TINY = 3,           /* linear_tiny_kernel: 64 x 32 tiles, fragments straight from global memory (K <= 1024) */
+    MADE_LINEAR_SKINNY = 4,         /* linear_skinny_kernel: 64 x 64 tiles, 8-stage LDS-DMA ring */
+    MADE_LINEAR_GLDS3 = 5,          /* linear_glds_kernel<3, ., 128>: at most one workgroup per CU, three LDS stages */
+    MADE_LINEAR_GLDS64 = 6,         /* linear_glds_kernel<1, ., 64>: 64 x 128 tiles */
+    MADE_LINEAR_GLDS128 = 7         /* linear_glds_kernel<1, ., 128>: 128 x 128 tiles */
+};
+int made_linear_variant(const MadeLinearArgs* args);
+
 /* y = act(sum_s ws[s] + bias) + R[row % r_row_mod]  -> out (any dtype, may be NULL);
  * then optionally z1 = LayerNorm(y; ln1) -> ln1_out, and z2 = LayerNorm(z1; ln2) -> ln2_out (the decoder's
  * per-layer norm followed by the shared output norm, reference music_detr/transformer.py:306,136).

@@ -156,6 +156,7 @@ SIGNATURES = {
     "made_repack": (C.c_int, [vp, i32, i64, vp]),
     "made_row_groups": (C.c_int, [vp, i64, vp, vp]),
     "made_row_index": (C.c_int, [vp, i64, vp, vp, vp]),
+    "made_linear_variant": (C.c_int, [C.POINTER(MadeLinearArgs)]),
     "made_row_affine": (C.c_int, [vp, i32, i64, vp, vp, i64, i32, vp, i32, i64, i64, i64, vp]),
     "made_gate_rows": (C.c_int, [vp, i32, i64, vp, i32, i64, i32, f32, vp, i64, i64, vp, i32, i64, vp, i64, i64, vp]),
     "made_xpool_fused": (C.c_int, [C.POINTER(MadeXpoolFusedArgs), vp]),

@@ -942,6 +942,26 @@ static int tile_pref() {
     return v;
 }
 
+// which kernel made_linear runs for these arguments (one place: the launcher and made_linear_variant both ask here)
+static int pick_variant(const MadeLinearArgs& a) {
+    if (a.w_dtype != MADE_BF16) return MADE_LINEAR_GENERAL_F32;
+    bool fast = a.a_dtype == MADE_BF16 && a.K % 64 == 0 && a.a_row_mask == nullptr && a.split_k <= 1 &&
+                (a.A2 == nullptr || a.a2_replace) && ((uintptr_t)a.A % 16 == 0) && (a.lda % 8 == 0);
+    for (int s = 0; s < a.nseg; ++s) fast = fast && !a.seg[s].transposed;
+    if (a.A2 && a.a2_replace) fast = fast && (a.a2_row_mod == 0) && (a.lda2 % 8 == 0);
+    if (!fast) return a.a_dtype == MADE_F32 ? MADE_LINEAR_GENERAL_F32IN : MADE_LINEAR_GENERAL_BF16;
+    const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int64_t tiles64 = ((a.M + S_BM - 1) / S_BM) * ((a.N + S_BN - 1) / S_BN);
+    const int64_t tiles32 = ((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN);
+    if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) return MADE_LINEAR_TINY;
+    if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) return MADE_LINEAR_SKINNY;
+    if (tiles * a.batch <= 256) return MADE_LINEAR_GLDS3;                  // at most one workgroup per CU
+    // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
+    const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
+    if (tile_pref() == 64 || (tile_pref() == 0 && live <= 1280)) return MADE_LINEAR_GLDS64;
+    return MADE_LINEAR_GLDS128;
+}
+
 extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
     MADE_REQUIRE(args != nullptr, "made_linear: null args");
     const MadeLinearArgs& a = *args;
@@ -995,45 +1015,42 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
     }
     dim3 grid((unsigned)tiles, 1, (unsigned)(a.split_k > 1 ? a.split_k : a.batch)), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
-    if (a.w_dtype == MADE_BF16) {
-        bool fast = a.a_dtype == MADE_BF16 && a.K % 64 == 0 && a.a_row_mask == nullptr && a.split_k <= 1 &&
-                    (a.A2 == nullptr || a.a2_replace) && ((uintptr_t)a.A % 16 == 0) && (a.lda % 8 == 0);
-        for (int s = 0; s < a.nseg; ++s) fast = fast && !a.seg[s].transposed;
-        if (a.A2 && a.a2_replace) fast = fast && (a.a2_row_mod == 0) && (a.lda2 % 8 == 0);
-        if (fast) {
-            const bool train = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
-            const int64_t tiles64 = ((a.M + S_BM - 1) / S_BM) * ((a.N + S_BN - 1) / S_BN);
-            const int64_t tiles32 = ((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN);
-            if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) {
-                // latency-bound and short in K: fragments straight from global memory, K split over the four waves
-                dim3 g32((unsigned)tiles32, 1, (unsigned)a.batch);
-                if (train) hipLaunchKernelGGL((linear_tiny_kernel<true>), g32, block, 0, st, a);
-                else hipLaunchKernelGGL((linear_tiny_kernel<false>), g32, block, 0, st, a);
-                return made_check_launch("made_linear");
-            }
-            if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) {   // latency-bound: 64 x 64 tiles, all slabs in flight
-                dim3 g64((unsigned)tiles64, 1, (unsigned)a.batch);
-                if (train) hipLaunchKernelGGL((linear_skinny_kernel<true>), g64, block, 0, st, a);
-                else hipLaunchKernelGGL((linear_skinny_kernel<false>), g64, block, 0, st, a);
-                return made_check_launch("made_linear");
-            }
-            const bool small = tiles * a.batch <= 256;       // at most one workgroup per CU
-            // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
-            const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
-            if (small && train) hipLaunchKernelGGL((linear_glds_kernel<3, true, 128>), grid, block, 0, st, a);
-            else if (small) hipLaunchKernelGGL((linear_glds_kernel<3, false, 128>), grid, block, 0, st, a);
-            else if (tile_pref() == 64 || (tile_pref() == 0 && live <= 1280)) {   // fewer than ~4 tall workgroups per CU: 64-row tiles
-                dim3 g((unsigned)(((a.M + 63) / 64) * ((a.N + BN - 1) / BN)), 1, (unsigned)a.batch);
-                if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 64>), g, block, 0, st, a);
-                else hipLaunchKernelGGL((linear_glds_kernel<1, false, 64>), g, block, 0, st, a);
-            }
-            else if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128>), grid, block, 0, st, a);
+    const bool train = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
+    switch (pick_variant(a)) {
+        case MADE_LINEAR_TINY: {
+            // latency-bound and short in K: fragments straight from global memory, K split over the four waves
+            dim3 g32((unsigned)(((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN)), 1, (unsigned)a.batch);
+            if (train) hipLaunchKernelGGL((linear_tiny_kernel<true>), g32, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_tiny_kernel<false>), g32, block, 0, st, a);
+            break;
         }
-        else if (a.a_dtype == MADE_F32) hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((linear_kernel<bf16_t, bf16_t>), grid, block, 0, st, a);
-    } else {
-        hipLaunchKernelGGL((linear_kernel<float, float>), grid, block, 0, st, a);
+        case MADE_LINEAR_SKINNY: {                         // latency-bound, long K: 64 x 64 tiles, all slabs in flight
+            dim3 g64((unsigned)(((a.M + S_BM - 1) / S_BM) * ((a.N + S_BN - 1) / S_BN)), 1, (unsigned)a.batch);
+            if (train) hipLaunchKernelGGL((linear_skinny_kernel<true>), g64, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_skinny_kernel<false>), g64, block, 0, st, a);
+            break;
+        }
+        case MADE_LINEAR_GLDS3:
+            if (train) hipLaunchKernelGGL((linear_glds_kernel<3, true, 128>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_glds_kernel<3, false, 128>), grid, block, 0, st, a);
+            break;
+        case MADE_LINEAR_GLDS64: {                         // fewer than ~4 tall workgroups per CU: 64-row tiles
+            dim3 g((unsigned)(((a.M + 63) / 64) * ((a.N + BN - 1) / BN)), 1, (unsigned)a.batch);
+            if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 64>), g, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_glds_kernel<1, false, 64>), g, block, 0, st, a);
+            break;
+        }
+        case MADE_LINEAR_GLDS128:
+            if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128>), grid, block, 0, st, a);
+            break;
+        case MADE_LINEAR_GENERAL_F32IN: hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a); break;
+        case MADE_LINEAR_GENERAL_BF16: hipLaunchKernelGGL((linear_kernel<bf16_t, bf16_t>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((linear_kernel<float, float>), grid, block, 0, st, a); break;
     }
     return made_check_launch("made_linear");
+}
+
+extern "C" int made_linear_variant(const MadeLinearArgs* args) {
+    return args ? pick_variant(*args) : -1;
 }

@@ -124,6 +124,11 @@ class Seg:
     use_a2: bool = False
 
 
+# made_linear_variant codes (include/made_hip.h: MadeLinearVariant) -> KernelTimer kinds = rocprofv3 kernel symbols
+LINEAR_VARIANTS = {0: "linear_f32", 1: "linear_f32in_bf16", 2: "linear_kernel<bf16,bf16>", 3: "linear_tiny_kernel", 4: "linear_skinny_kernel",
+                   5: "linear_glds_kernel<3,.,128>", 6: "linear_glds_kernel<1,.,64>", 7: "linear_glds_kernel<1,.,128>"}
+
+
 def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,
            segs: Optional[Sequence[Seg]] = None, A2: Optional[Tensor] = None, a2_row_mod: int = 0,
            a2_replace: bool = False, a_row_mask: Optional[Tensor] = None, act: int = ACT_NONE, R: Optional[Tensor] = None,
@@ -181,6 +186,8 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
         sg.use_a2 = 1 if s.use_a2 else 0
     esz = 4 if a.w_dtype == F32 else 2
     kind = "linear_" + ("f32" if a.w_dtype == F32 else ("bf16" if a.a_dtype == BF16 else "f32in_bf16"))
+    if _timer is not None and kind == "linear_bf16":          # timed runs label the launch with the kernel it dispatches to
+        kind = LINEAR_VARIANTS[lib().made_linear_variant(C.byref(a))]
     flops = 2.0 * M * N * K * batch
     nbytes = batch * (M * K * (4 if a.a_dtype == F32 else 2) + N * K * esz + M * N * esz)
     desc = f"M={M} N={N} K={K} z={batch} nseg={len(segs)} a2={int(A2 is not None)} R={int(R is not None)} act={act} tr={int(any(s_.transposed for s_ in segs))}"
@@ -237,7 +244,7 @@ def linear_splitk(A: Tensor, W: Tensor, bias: Optional[Tensor], ws: Tensor, spli
     sg = a.seg[0]
     sg.col_begin, sg.out, sg.out_dtype, sg.ldo, sg.use_a2 = 0, _p(ws), F32, N, 1 if use_a2 else 0
     esz = 4 if a.w_dtype == F32 else 2
-    _timed("linear_splitk_" + ("f32" if a.w_dtype == F32 else "bf16"), 2.0 * M * N * K, M * K * esz + N * K * esz + M * N * 4 * a.split_k,
+    _timed("linear_splitk_f32" if a.w_dtype == F32 else "linear_kernel<bf16,bf16>", 2.0 * M * N * K, M * K * esz + N * K * esz + M * N * 4 * a.split_k,
            lambda: check(lib().made_linear(C.byref(a), _stream()), "made_linear(split_k)"), f"M={M} N={N} K={K} split={a.split_k}")
     splitk_finish(ws, a.split_k, M, N, bias, act=act, R=R, r_row_mod=r_row_mod, out=out, ln1=ln1, ln1_out=ln1_out, ln2=ln2, ln2_out=ln2_out,
                   eps=eps)

@@ -5,10 +5,17 @@ import collections, csv, json, sys
 
 
 def kind(name):
-    if "linear_glds_kernel" in name or "linear_skinny_kernel" in name or "linear_tiny_kernel" in name:
-        return "linear_bf16"                       # what bench.py times as made_linear bf16 (the split-K launches use linear_kernel<bf16,bf16>)
+    # the kinds bench.py's timed launches carry (mgsv_amd/ops.py: LINEAR_VARIANTS)
+    if "linear_glds_kernelILi1" in name or "linear_glds_kernel<1" in name:
+        return "linear_glds_kernel<1,.,64>" if ("ELi64E" in name or ", 64>" in name) else "linear_glds_kernel<1,.,128>"
+    if "linear_glds_kernel" in name:
+        return "linear_glds_kernel<3,.,128>"
+    if "linear_skinny_kernel" in name:
+        return "linear_skinny_kernel"
+    if "linear_tiny_kernel" in name:
+        return "linear_tiny_kernel"
     if "linear_kernelIDF16bDF16b" in name:
-        return "linear_splitk_bf16"
+        return "linear_kernel<bf16,bf16>"
     if "linear_kernelIfDF16b" in name:
         return "linear_f32in_bf16"
     if "linear_kernelIff" in name or "linear_kernel<float, float>" in name:
