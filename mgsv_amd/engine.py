@@ -59,8 +59,6 @@ class MadeEngine:
             unsupported.append(f"vmr_loss={c.vmr_loss} without the music-pooling tower (the reference fails there too)")
         if not ("detr" in c.mml_localization or "regression" in c.mml_localization):
             unsupported.append(f"mml_localization={c.mml_localization}")
-        if c.moment_loss != 0:
-            unsupported.append("moment_loss")
         if c.audio_short_cut and not c.contrastive_align_loss:
             unsupported.append("audio_short_cut without contrastive_align_loss")
         if c.moment_query_type not in ("video", "music", "zero", "random", "xpool"):
@@ -193,6 +191,8 @@ class MadeEngine:
             lin("class_embed", "class_embed")
             for i in range(3):
                 lin(f"span_embed.{i}", f"span_embed.layers.{i}")
+                if c.moment_loss:
+                    lin(f"moment_embed.{i}", f"moment_embed.layers.{i}")
             if c.contrastive_align_loss:
                 lin("proj_q", "contrastive_align_projection_query")
                 lin("proj_v", "contrastive_align_projection_vid")
@@ -686,6 +686,18 @@ class MadeEngine:
             vid_sum = ops.masked_mean(pv, None, out=ws["vid_sum"])
             out.update(proj_queries=pq[-1], proj_vid_mem=pv, proj_queries_all=pq)
 
+        if c.moment_loss:                                                # reference model_Uni.py:152-159 (outputs only: no loss reads them)
+            last = hs[nd - 1]
+            m1 = ops.linear(last, P["moment_embed.0.w"], P["moment_embed.0.b"], act=ops.ACT_RELU)
+            m2 = ops.linear(m1, P["moment_embed.1.w"], P["moment_embed.1.b"], act=ops.ACT_RELU)
+            m3 = ops.linear(m2, P["moment_embed.2.w"], P["moment_embed.2.b"], out_dtype=torch.float32)
+            mf = ops.l2norm_rows(m3)
+            if c.audio_short_cut:
+                from . import ops_train
+                mq = music if Q == 1 else music[:, None, :].expand(B, Q, D).contiguous()
+                ops_train.add3(m3, mf, mq, b_mod=B * Q * D)
+                mf = ops.l2norm_rows(m3)
+            out["moment_feats"] = mf.view(B, Q, D)
         if not with_losses:
             cur.wait_stream(side)
             return out

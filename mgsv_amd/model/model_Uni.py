@@ -167,7 +167,7 @@ class Uni_model(nn.Module):
         # variant, the regression MLP only (the DETR transformer is then in no optimizer group)
         if "regression" in self.cfg.mml_localization:
             return self._params(["video_music_fusion_cross_transformer.", "reg_mlp."])
-        return self._params(["video_music_fusion_cross_transformer.", "detr_transformer.", "span_embed.", "class_embed.",
+        return self._params(["video_music_fusion_cross_transformer.", "detr_transformer.", "span_embed.", "class_embed.", "moment_embed.",
                              "contrastive_align_projection_"])
 
     # ---- state handling
@@ -271,6 +271,8 @@ class Uni_model(nn.Module):
         output_map: Dict[str, object] = {"pred_logits": o["pred_logits"], "pred_spans": o["pred_spans"]}
         if cfg.contrastive_align_loss:
             output_map.update(proj_queries=o["proj_queries"], proj_vid_mem=o["proj_vid_mem"])
+        if cfg.moment_loss:                                        # reference model/model_Uni.py:152-159
+            output_map.update(moment_feats=o["moment_feats"], video_feats=o["video_feats"])
         if cfg.aux_loss:
             aux = []
             for i in range(nd - 1):

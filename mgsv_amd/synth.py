@@ -132,6 +132,9 @@ def param_shapes(cfg: MadeConfig) -> "OrderedDict[str, tuple]":
     lin("span_embed.layers.1", D, D)
     lin("span_embed.layers.2", span_dim, D)
     lin("class_embed", 2, D)
+    if cfg.moment_loss:                                   # model_Uni.py:55-56: MLP(D, D, D, 3)
+        for i in range(3):
+            lin(f"moment_embed.layers.{i}", D, D)
     if cfg.contrastive_align_loss:
         lin("contrastive_align_projection_query", cfg.contrastive_hdim, D)
         lin("contrastive_align_projection_vid", cfg.contrastive_hdim, D)

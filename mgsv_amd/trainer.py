@@ -59,8 +59,8 @@ class MadeTrainer(MadeEngine):
             bad.append("agg_module=mlp / with_cls_token / transformer_is_share")
         if "detr" not in c.mml_localization:
             bad.append(f"mml_localization={c.mml_localization}")
-        if c.predict_center or c.audio_short_cut:
-            bad.append("predict_center / audio_short_cut")
+        if c.predict_center or c.audio_short_cut or c.moment_loss:
+            bad.append("predict_center / audio_short_cut / moment_loss")
         if bad:
             raise NotImplementedError("MadeTrainer (HIP training path) does not cover yet: " + "; ".join(bad))
 

@@ -541,6 +541,11 @@ def calc_output(hs: Tensor, frame_feats: Tensor, music_feats: Tensor, P, cfg,
             pq = l2_normalize(pq + music_feats[:, None])
         pv = l2_normalize(linear(frame_feats, P, "contrastive_align_projection_vid"))
         out["proj_queries"], out["proj_vid_mem"] = pq[-1], pv
+    if cfg.moment_loss:                                   # model_Uni.py:152-159: an extra normalised embedding of the last layer's queries
+        mf = l2_normalize(mlp3(hs[-1], P, "moment_embed"))
+        if cfg.audio_short_cut:
+            mf = l2_normalize(mf + music_feats[:, None])
+        out["moment_feats"] = mf
     if cfg.aux_loss:
         aux = [{"pred_logits": a, "pred_spans": b} for a, b in zip(cls[:-1], coord[:-1])]
         if cfg.contrastive_align_loss:

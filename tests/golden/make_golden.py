@@ -72,6 +72,7 @@ VARIANTS = {      # name -> cfg overrides (on cfg_native): the option variants o
     "audio_short_cut_fb10": {"audio_short_cut": 1, "fb_label": "10"},
     "audio_short_cut_Q3": {"audio_short_cut": 1, "num_moment_queries": 3},
     "xpool_query": {"moment_query_type": "xpool"},
+    "moment_embedding": {"moment_loss": 1, "audio_short_cut": 1},
     "regression": {"mml_localization": "regression"},
     "regression_center_CA": {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
     "shared_temporal_block": {"transformer_is_share": 1},
@@ -95,7 +96,7 @@ def variants_fixture(B: int = 4, T_v: int = 50, T_a: int = 96):
             om, lm, fm, mm, im = ref(t["frame_feats"].clone(), t["segment_feats"].clone(), t["frame_masks"].clone(),
                                      t["segment_masks"].clone(), t["spans_target"].clone(), v_duration=t["v_duration"],
                                      video_ids=inp["video_ids"], music_ids=inp["music_ids"], is_train=False)
-        for k in ("pred_logits", "pred_spans", "proj_queries"):
+        for k in ("pred_logits", "pred_spans", "proj_queries", "moment_feats"):
             if k in om:
                 fix[f"{name}.{k}"] = om[k].numpy()
         fix[f"{name}.video_feats"] = fm["video_feats"].numpy()

@@ -191,6 +191,7 @@ VARIANTS = {      # the same table as tests/golden/make_golden.py (SURVEY sectio
     "audio_short_cut_fb10": {"audio_short_cut": 1, "fb_label": "10"},
     "audio_short_cut_Q3": {"audio_short_cut": 1, "num_moment_queries": 3},
     "xpool_query": {"moment_query_type": "xpool"},
+    "moment_embedding": {"moment_loss": 1, "audio_short_cut": 1},
     "regression": {"mml_localization": "regression"},
     "regression_center_CA": {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
     "shared_temporal_block": {"transformer_is_share": 1},
@@ -211,7 +212,7 @@ def variant_case(fix, name):
 
 def check_variant(fix, name, got, tol=1e-4):
     """got: dict with pred_spans, (pred_logits, proj_queries), retrieval_loss, localization_loss, loss_dict."""
-    for k in ("pred_logits", "pred_spans", "proj_queries", "video_feats", "music_feats"):
+    for k in ("pred_logits", "pred_spans", "proj_queries", "moment_feats", "video_feats", "music_feats"):
         if f"{name}.{k}" in fix.files and k in got:
             np.testing.assert_allclose(np.asarray(got[k]), fix[f"{name}.{k}"], atol=tol, rtol=0, err_msg=f"{name}.{k}")
     np.testing.assert_allclose(float(got["retrieval_loss"]), float(fix[f"{name}.retrieval_loss"]), rtol=2e-4, atol=2e-4)
@@ -231,6 +232,6 @@ def test_option_variants_match_reference_fixture(golden_dir, name):
         r = O.forward(O.to_torch_params(sd), cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"],
                       inp["spans_target"], v_duration=inp["v_duration"], music_ids=inp["music_ids"])
     got = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in r.items()
-           if k in ("pred_logits", "pred_spans", "proj_queries", "video_feats", "music_feats")}
+           if k in ("pred_logits", "pred_spans", "proj_queries", "moment_feats", "video_feats", "music_feats")}
     got.update(retrieval_loss=r["retrieval_loss"], localization_loss=r["localization_loss"], loss_dict=r["loss_dict"])
     check_variant(fix, name, got, tol=2e-5)
