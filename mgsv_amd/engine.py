@@ -65,7 +65,7 @@ class MadeEngine:
             unsupported.append(f"moment_query_type={c.moment_query_type}")
         if c.moment_query_type == "xpool" and "music" not in c.vmr_fusion:
             unsupported.append("moment_query_type=xpool without the music-pooling tower (the reference fails there too)")
-        if c.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse"):
+        if c.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse", "dual_single_feature_fuse"):
             unsupported.append(f"vmr_loss={c.vmr_loss}")
         if c.detr_dec_layers < 1:
             unsupported.append("detr_dec_layers=0")
@@ -542,7 +542,7 @@ class MadeEngine:
         # beside the (latency-bound) decoder and join at the end of the step
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            need_pooled = want_pooled or c.moment_query_type == "xpool"
+            need_pooled = want_pooled or c.moment_query_type == "xpool" or c.vmr_loss == "dual_single_feature_fuse"
             pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if (need_pooled and "music" in c.vmr_fusion) else None
             if "music" in c.vmr_fusion:
                 self.xpool_sims(video, seg, sm if c.fusion_mask == 1 else None, sims_out=ws["sims_single"], pooled_out=pooled)
@@ -557,7 +557,7 @@ class MadeEngine:
                     ws["sims_single"].copy_(vp.t())
             self.dual_sims(video, music, out=ws["sims_dual"])
             if with_losses:
-                self._retrieval_loss(ws, video, music)
+                self._retrieval_loss(ws, video, music, pooled=pooled)
         out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"])
         if pooled is not None:
             out["music_feats_pooled"] = pooled.view(B, B, D)
@@ -756,7 +756,8 @@ class MadeEngine:
         y = ops.linear(h, P["ca.ff2.w"], P["ca.ff2.b"], R=ax, out=ws["ca_y"])
         ops.linear(y, P["ca.final.w"], P["ca.final.b"], out_row_mask=sm.reshape(-1), out=ws["fus"].view(B * Ta, D))
 
-    def _retrieval_loss(self, ws: Dict[str, Tensor], video: Tensor, music: Tensor, row_exclude: Optional[Tensor] = None) -> None:
+    def _retrieval_loss(self, ws: Dict[str, Tensor], video: Tensor, music: Tensor, row_exclude: Optional[Tensor] = None,
+                        pooled: Optional[Tensor] = None) -> None:
         """reference model/model_Uni.py:236-275 -> ws["ret_loss"]"""
         c, P = self.cfg, self.P
         rl = ws["ret_loss"]
@@ -771,6 +772,21 @@ class MadeEngine:
             # direction (reference modules/loss.py:90-114; model_Uni.py:255)
             ops.clip_loss(ws["sims_dual"], ls, rl, weight=1.0, row_exclude=row_exclude)
             ops.clip_loss(ws["sims_single"], ls, rl, weight=1.0, accumulate=True)
+        elif c.vmr_loss == "dual_single_feature_fuse":
+            # reference model_Uni.py:268-273: the pooled track vectors averaged with the track's own vector, then the music-pooling
+            # similarity (metrics.py:10-24) -- cos(v_n, (pooled[m, n] + music[m]) / 2); the 1/2 cancels in the cosine
+            from . import ops_train
+            B, D = video.shape
+            fused = torch.empty(B * B, D, device=self.device, dtype=torch.float32)
+            ops_train.add3(fused, pooled, music[:, None, :].expand(B, B, D).contiguous())        # rows (m, n): + music[m]
+            fn = ops.l2norm_rows(fused)
+            vn = ops.l2norm_rows(video)
+            sims = torch.empty(B, B, device=self.device, dtype=torch.float32)
+            # sims[n, m] = <fn[m, n, :], vn[n, :]>: one row-vector product per video, batched over the videos
+            ops.linear(fn.view(B, B * D)[:, :D], vn, None, M=B, N=1, K=D, batch=B, a_z_stride=D, w_z_stride=D,     # rows m of video 0, stride B*D
+                       segs=[Seg(out=sims, ldo=1, out_z_stride=B)])
+            ws["sims_fused"] = sims
+            ops.clip_loss(sims, ls, rl, weight=wgt)
         else:                                                            # dual_single_sim_fuse
             both = self.dual_sims(video, music, add=ws["sims_single"])
             ops.clip_loss(both, ls, rl, weight=wgt)

@@ -233,7 +233,7 @@ class Uni_model(nn.Module):
     # ---- forward (reference model/model_Uni.py:177-322)
     def forward(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, v_duration=None,
                 video_ids=None, music_ids=None, is_train=False):
-        if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse") or "XA" not in self.cfg.vmr_fusion:
+        if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse", "dual_single_feature_fuse") or "XA" not in self.cfg.vmr_fusion:
             raise ValueError(f"Error: vmr_loss={self.cfg.vmr_loss} and vmr_fusion={self.cfg.vmr_fusion} is not supported in VMR_model")
         if self.training:
             trn = self._trainer_ready()
@@ -251,7 +251,7 @@ class Uni_model(nn.Module):
             output_map, feat_map, mask_map, id_map = self._maps(o, trn, frame_masks, segment_masks, video_ids, music_ids)
             loss_map = {"retrieval_loss": ret, "localization_loss": loc, "localization_loss_dict": trn.loss_dict(o)}
             return output_map, loss_map, feat_map, mask_map, id_map
-        if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse") or "XA" not in self.cfg.vmr_fusion:
+        if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse", "dual_single_feature_fuse") or "XA" not in self.cfg.vmr_fusion:
             raise ValueError(f"Error: vmr_loss={self.cfg.vmr_loss} and vmr_fusion={self.cfg.vmr_fusion} is not supported in VMR_model")
         eng = self._engine_ready()
         dev = eng.device

@@ -55,6 +55,8 @@ class MadeTrainer(MadeEngine):
             bad.append(f"moment_query_type={c.moment_query_type}")
         if c.vmr_fusion != "XA-music":
             bad.append(f"vmr_fusion={c.vmr_fusion}")
+        if c.vmr_loss == "dual_single_feature_fuse":
+            bad.append("vmr_loss=dual_single_feature_fuse")
         if c.agg_module != "transf" or c.with_cls_token or c.transformer_is_share:
             bad.append("agg_module=mlp / with_cls_token / transformer_is_share")
         if "detr" not in c.mml_localization:

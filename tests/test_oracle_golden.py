@@ -192,6 +192,7 @@ VARIANTS = {      # the same table as tests/golden/make_golden.py (SURVEY sectio
     "audio_short_cut_Q3": {"audio_short_cut": 1, "num_moment_queries": 3},
     "xpool_query": {"moment_query_type": "xpool"},
     "moment_embedding": {"moment_loss": 1, "audio_short_cut": 1},
+    "feature_fuse": {"vmr_loss": "dual_single_feature_fuse"},
     "regression": {"mml_localization": "regression"},
     "regression_center_CA": {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
     "shared_temporal_block": {"transformer_is_share": 1},
