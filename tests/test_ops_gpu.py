@@ -321,6 +321,58 @@ def test_attention_wide(dev, mode, B, NQ1, NQ2, L, D, shared, kadd, alias):
                                        err_msg=f"n_split={n_split}")
 
 
+@pytest.mark.parametrize("B,NQ1,NQ2,L,D,shared,alias", [
+    (3, 8, 1, 544, 512, False, True),        # decoder-like: one query tile
+    (5, 64, 1, 512, 512, True, False),       # in-batch X-Pool block at B = 64: two query tiles
+    (4, 40, 1, 200, 256, True, False),       # D = 256: two query tiles, ragged last tile
+    (2, 8, 2, 96, 256, False, False),        # D = 256: three key tiles
+    (2, 33, 1, 2048, 512, True, False),      # a long key row
+])
+def test_attention_wide_few_queries(dev, B, NQ1, NQ2, L, D, shared, alias):
+    """The bf16 / no-Kadd / <= 64 query rows shapes (in-batch X-Pool block, decoder-like rows): same contract as
+    test_attention_wide, plus a late score spike (forces the running-max rescale) and garbage after the last valid key."""
+    tdt = torch.bfloat16
+    q = rnd(1 if shared else B, NQ1, NQ2, D, seed=1)
+    k = rnd(B, L, D, seed=2)
+    v = k if alias else rnd(B, L, D, seed=4)
+    lens = torch.tensor([max(1, L - 37 * i) for i in range(B)])
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    if B > 1:
+        mask[1, ::3] = 0
+        mask[1, 1] = 1
+    if not alias:
+        k[0, L - 3] = q[0, 2, 0] * 3.0       # a late spike for one query of sample 0
+    scale = 0.125
+    sc = torch.einsum("bxyd,bld->bxyl", bf(q).expand(B, -1, -1, -1), bf(k)) * scale
+    sc = sc.masked_fill((mask == 0)[:, None, None, :], float("-inf"))
+    ref = torch.einsum("bxyl,bld->bxyd", torch.softmax(sc, -1), bf(v))
+    Qd = torch.empty(q.shape[0], NQ2, NQ1, D, device=dev, dtype=tdt).permute(0, 2, 1, 3)
+    Qd.copy_(q.to(dev).to(tdt))
+    kd = k.clone()
+    vd = v.clone()
+    for b in range(B):                       # rows after the last valid key may hold anything
+        last = int(mask[b].nonzero().max())
+        kd[b, last + 1:] = float("nan")
+        if not alias:
+            vd[b, last + 1:] = float("nan")
+    Kd = kd.to(dev).to(tdt)
+    Vd = Kd if alias else vd.to(dev).to(tdt)
+    for odt in (tdt, torch.float32):
+        for n_split in (1, 2, 5):
+            Od = torch.full((B, NQ2, NQ1, D), float("nan"), device=dev, dtype=odt).permute(0, 2, 1, 3)
+            ops.attention_wide(Qd, Kd, Vd, Od, scale=scale, key_mask=mask.to(dev), shared_q=shared, n_split=n_split)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(Od.float().cpu().numpy(), ref.numpy(), atol=BF16_TOL, rtol=0, err_msg=f"n_split={n_split}")
+    # without a mask every key counts
+    if L <= 200:
+        Od = torch.empty(B, NQ2, NQ1, D, device=dev, dtype=torch.float32).permute(0, 2, 1, 3)
+        ops.attention_wide(Qd, k.to(dev).to(tdt), (k if alias else v).to(dev).to(tdt), Od, scale=scale, shared_q=shared)
+        torch.cuda.synchronize()
+        sc = torch.einsum("bxyd,bld->bxyl", bf(q).expand(B, -1, -1, -1), bf(k)) * scale
+        ref2 = torch.einsum("bxyl,bld->bxyd", torch.softmax(sc, -1), bf(v))
+        np.testing.assert_allclose(Od.cpu().numpy(), ref2.numpy(), atol=BF16_TOL, rtol=0)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_padding_skips_leave_valid_rows_bit_identical(dev, mode):
     """tile_skip_mask (GEMM), row_skip (LayerNorm) and q_skip_mask (attention): rows that are padding are not computed,
