@@ -146,8 +146,19 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
         const bool zv = (a.ldz % 8 == 0) && (((uintptr_t)a.Zout & 15) == 0);
         store8(a.Zout, a.z_dtype, (int64_t)m * a.ldz + n, v, nvalid, zv);
     }
+    // one (wave-uniform) switch per 8 outputs, not one per output: the epilogue of a one-wave-per-SIMD kernel has nothing to hide
+    // a chain of taken branches behind
+    switch (a.act) {
+        case MADE_ACT_NONE: break;
+        case MADE_ACT_RELU:
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], a.act);
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            break;
+        default:
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], a.act);
+            break;
+    }
     if (TRAIN && a.gate != MADE_GATE_NONE) {
         float g[8];
         load8(a.G, a.g_dtype, (int64_t)m * a.ldg + n, g, nvalid, (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0));
@@ -958,8 +969,17 @@ static int pick_variant(const MadeLinearArgs& a) {
     if (tiles * a.batch <= 256) return MADE_LINEAR_GLDS3;                  // at most one workgroup per CU
     // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
     const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
-    if (tile_pref() == 64 || (tile_pref() == 0 && live <= 1280)) return MADE_LINEAR_GLDS64;
-    return MADE_LINEAR_GLDS128;
+    if (tile_pref() == 64) return MADE_LINEAR_GLDS64;
+    if (tile_pref() == 128) return MADE_LINEAR_GLDS128;
+    if (live > 1280) return MADE_LINEAR_GLDS128;
+    // Between one and five tall workgroups per CU.  Measured (tools/linear_tiles_bench.py, K = 512): 128-row tiles win by 6-8 % when they
+    // fill whole rounds of the 256 x 4 resident workgroups (32768 x 512: 33.6 vs 36.0 us; x 1024: 58 vs 63) and lose by 10 %
+    // when a last partial round idles most of the chip (34688 x 512: 42 vs 38) -- only knowable when the row count is (no gather)
+    if (!a.row_index) {
+        const int64_t slots = 256 * 4, rounds = (live + slots - 1) / slots;
+        if (live * 10 >= rounds * slots * 9) return MADE_LINEAR_GLDS128;
+    }
+    return MADE_LINEAR_GLDS64;
 }
 
 extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {

@@ -75,6 +75,42 @@ def test_linear_basic(dev, mode, M, N, K, act):
         np.testing.assert_allclose(outb.float().cpu().numpy(), ref.numpy(), atol=BF16_TOL, rtol=2e-2)
 
 
+@pytest.mark.parametrize("M,N,gather", [(20000, 512, False), (33000, 1024, False), (40960, 512, True), (16385, 1024, False)])
+def test_linear_encoder_sized(dev, M, N, gather):
+    """Encoder-sized bf16 Linears (tens of thousands of rows, K = 512: the direct-to-LDS kernels at both tile heights): bias +
+    ReLU + residual + output row mask, two output segments, row gather, ragged last tile."""
+    K = 512
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3) * 0.1
+    R = rnd(M, N, seed=5)
+    omask = (torch.arange(M) % 7 != 0).float()
+    Ad, Wd = A.to(dev).bfloat16(), W.to(dev).bfloat16()
+    rows, valid = None, torch.ones(M, dtype=torch.bool)
+    if gather:
+        T = 512
+        lens = torch.tensor([(37 * i) % T + 1 for i in range(M // T)])
+        mask = (torch.arange(T)[None] < lens[:, None]).float()
+        rows = ops.row_index(mask.to(dev))
+        valid = mask.reshape(-1) != 0
+    ref = (torch.relu(bf(A) @ bf(W).t() + b) + bf(R)) * omask[:, None]
+    for odt in (torch.float32, torch.bfloat16):
+        out = torch.full((M, N), float("nan"), device=dev, dtype=odt)
+        ops.linear(Ad, Wd, b.to(dev), act=ops.ACT_RELU, R=R.to(dev).bfloat16(), out_row_mask=omask.to(dev), out=out, rows=rows)
+        torch.cuda.synchronize()
+        got = out.float().cpu()
+        np.testing.assert_allclose(got[valid].numpy(), ref[valid].numpy(), atol=2e-3 if odt == torch.float32 else BF16_TOL, rtol=2e-2)
+        if gather:
+            assert torch.isnan(got[~valid]).all()              # rows outside the list are not touched
+    # two segments (the fused Q|K projection writes two buffers); no bias
+    if N == 1024:
+        o1 = torch.empty(M, 512, device=dev, dtype=torch.bfloat16)
+        o2 = torch.empty(M, 512, device=dev, dtype=torch.float32)
+        ops.linear(Ad, Wd, None, segs=[Seg(out=o1, col_begin=0), Seg(out=o2, col_begin=512)])
+        torch.cuda.synchronize()
+        full = bf(A) @ bf(W).t()
+        np.testing.assert_allclose(o1.float().cpu().numpy(), full[:, :512].numpy(), atol=BF16_TOL, rtol=2e-2)
+        np.testing.assert_allclose(o2.cpu().numpy(), full[:, 512:].numpy(), atol=2e-3, rtol=0)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_linear_prologue_epilogue(dev, mode):
     """row mask on A, +A2 with row modulo, residual table with row modulo, output row mask."""
