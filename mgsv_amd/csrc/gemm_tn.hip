@@ -325,19 +325,36 @@ extern "C" int made_row_groups(const float* mask, int64_t M, float* out, void* s
 
 namespace {
 // stream compaction of a token mask in one workgroup of 16 waves: each wave owns a contiguous range, counts it with
-// ballots (coalesced loads, no serial dependence), the 16 totals are scanned, then the indices are scattered
+// ballots, the 16 totals are scanned, then the indices are scattered.  The range is walked in batches of 32 x 64 elements whose
+// 32 (coalesced) loads are all issued before the first ballot: a dependent load per 64 elements made this a 17 us kernel at the
+// head of every step's critical path.  With a single batch per wave (M <= 32768) the ballots of the counting pass are kept
+// for the scatter pass.
 __global__ __launch_bounds__(1024) void row_index_kernel(const float* mask, int64_t M, int32_t* row_index, int32_t* n_rows) {
     __shared__ int wsum[16];
     __shared__ int wlast[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t per = ((M + 15) / 16 + 63) / 64 * 64;          // elements per wave, multiple of 64
     const int64_t b = (int64_t)wave * per, e = b + per < M ? b + per : M;
+    const bool one = per <= 2048;
+    uint64_t bal[32];
+    auto ballots = [&](int64_t i0) __attribute__((always_inline)) {
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int64_t i = i0 + j * 64 + lane;
+            v[j] = i < e ? mask[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) bal[j] = __ballot(v[j] != 0.f);
+    };
     int cnt = 0, last = -1;
-    for (int64_t i = b + lane; i - lane < e; i += 64) {
-        const bool v = i < e && mask[i] != 0.f;
-        const uint64_t bal = __ballot(v);
-        cnt += __popcll(bal);
-        if (bal) last = (int)(i - lane) + 63 - __clzll(bal);
+    for (int64_t i0 = b; i0 < e; i0 += 2048) {
+        ballots(i0);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            cnt += __popcll(bal[j]);
+            if (bal[j]) last = (int)(i0 + j * 64) + 63 - __clzll(bal[j]);
+        }
     }
     if (lane == 0) { wsum[wave] = cnt; wlast[wave] = last; }
     __syncthreads();
@@ -347,24 +364,36 @@ __global__ __launch_bounds__(1024) void row_index_kernel(const float* mask, int6
         total += wsum[w];
         if (wlast[w] >= 0) lastv = wlast[w];
     }
-    for (int64_t i = b + lane; i - lane < e; i += 64) {
-        const bool v = i < e && mask[i] != 0.f;
-        const uint64_t bal = __ballot(v);
-        if (v) row_index[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
-        base += __popcll(bal);
+    for (int64_t i0 = b; i0 < e; i0 += 2048) {
+        if (!one) ballots(i0);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if ((bal[j] >> lane) & 1ull) row_index[base + __popcll(bal[j] & ((1ull << lane) - 1ull))] = (int32_t)(i0 + j * 64 + lane);
+            base += __popcll(bal[j]);
+        }
     }
     if (threadIdx.x == 0) n_rows[0] = total;
     for (int64_t i = total + threadIdx.x; i < M; i += 1024) row_index[i] = lastv;
 }
 
-// valid length of every sample (one wave per sample, ballots), then rank by (length descending, index ascending)
+// valid length of every sample (one wave per sample, ballots over batches of 8 x 64 entries loaded together), then rank by
+// (length descending, index ascending)
 __global__ __launch_bounds__(1024) void batch_order_kernel(const float* mask, int B, int64_t T, int32_t* order) {
     __shared__ int len[8192];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int b = wave; b < B; b += 16) {
         const float* m = mask + (int64_t)b * T;
         int cnt = 0;
-        for (int64_t i = lane; i - lane < T; i += 64) cnt += __popcll(__ballot(i < T && m[i] != 0.f));
+        for (int64_t i0 = 0; i0 < T; i0 += 512) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t i = i0 + j * 64 + lane;
+                v[j] = i < T ? m[i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnt += __popcll(__ballot(v[j] != 0.f));
+        }
         if (lane == 0) len[b] = cnt;
     }
     __syncthreads();

@@ -179,6 +179,29 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(const float* lo
         const float* lg = logits + (int64_t)l * B * Q * 2;
         const float* sp = spans + (int64_t)l * B * Q * 2;
         for (int i = tid; i < B * Q; i += CRIT_THREADS) matched[i] = 0;
+        // contrastive-align logits first: they depend on nothing the matching produces, so their loads travel together with
+        // the first loads of the matched-pair pass instead of adding a round trip at the end.  Four lanes per (b, q) pair,
+        // 16-byte loads where the rows allow them.
+        if (proj_q && vid_sum) {
+            const bool vec = (Dc % 4 == 0) && (((uintptr_t)proj_q | (uintptr_t)vid_sum) % 16 == 0);
+            for (int i = tid >> 2; i < B * Q; i += CRIT_THREADS / 4) {
+                const int b = i / Q, part = tid & 3;
+                const float* pq = proj_q + ((int64_t)l * B * Q + i) * Dc;
+                const float* vs = vid_sum + (int64_t)b * Dc;
+                float d = 0.f;
+                if (vec) {
+                    for (int k = part * 4; k < Dc; k += 16) {
+                        const f32x4 x = *(const f32x4*)(pq + k), y = *(const f32x4*)(vs + k);
+                        d += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+                    }
+                } else {
+                    for (int k = part; k < Dc; k += 4) d += pq[k] * vs[k];
+                }
+                d += __shfl_xor(d, 1);
+                d += __shfl_xor(d, 2);
+                if (part == 0) lgt[i] = d / temperature;
+            }
+        }
         __syncthreads();
         // matched pairs: one thread per (b, slot)
         float span_sum = 0.f, giou_sum = 0.f, correct = 0.f, npairs = 0.f;
@@ -219,16 +242,6 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(const float* lo
         // contrastive align (reference loss_detr.py:112-128)
         float contr = 0.f;
         if (proj_q && vid_sum) {
-            for (int i = wave; i < B * Q; i += CRIT_THREADS / 64) {
-                int b = i / Q;
-                const float* pq = proj_q + ((int64_t)l * B * Q + i) * Dc;
-                const float* vs = vid_sum + (int64_t)b * Dc;
-                float d = 0.f;
-                for (int k = lane; k < Dc; k += 64) d += pq[k] * vs[k];
-                d = wave_sum(d);
-                if (lane == 0) lgt[i] = d / temperature;
-            }
-            __syncthreads();
             float csum = 0.f;
             for (int b = tid; b < B; b += CRIT_THREADS) {
                 float mx = -INFINITY, pos = 0.f, npos = 0.f;

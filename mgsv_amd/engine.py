@@ -515,6 +515,10 @@ class MadeEngine:
         side = self._side_stream()
         fus, fus_mask = ws["fus"], ws["fus_mask"]
         side.wait_stream(cur)
+        # The audio branch (the launches that fill the chip) is enqueued first, the video branch (17 launches of at most a few
+        # hundred workgroups) second on the side stream: eager launching is 1-3 % faster this way, graph replay unchanged.
+        self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv, rows=ops.row_index(sm, out=ws["rows_a"]),
+                     order=ops.batch_order(sm, out=ws["order_a"]))
         with torch.cuda.stream(side):
             # the DETR mask and its sine position embedding depend on the masks only: off the critical path
             if concat:
@@ -527,8 +531,6 @@ class MadeEngine:
             order_f = ops.batch_order(fus_mask, out=ws["order_f"])       # attention workgroups: longest sample first
             self._encode(frame_feats.contiguous(), fm, "video", ws, 0, rows=ops.row_index(fm, out=ws["rows_v"]),
                          order=ops.batch_order(fm, out=ws["order_v"]))
-        self._encode(segment_feats.contiguous(), sm, "audio", ws, Tv, rows=ops.row_index(sm, out=ws["rows_a"]),
-                     order=ops.batch_order(sm, out=ws["order_a"]))
         cur.wait_stream(side)
         if concat:
             frame, seg = fus[:, :Tv], fus[:, Tv:]
