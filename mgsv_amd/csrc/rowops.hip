@@ -104,6 +104,51 @@ __global__ __launch_bounds__(ROW_THREADS) void masked_mean_kernel(const void* x,
     }
 }
 
+// The same for rows that allow 4-column vector loads: grid (D/256 column slabs, B), 16 waves, wave w takes tokens w, w + 16, ...
+// (four of its tokens in flight), a lane 4 consecutive columns.  The scalar kernel above moves 2 bytes per load instruction:
+// 41 us for the audio branch's 64 x 512 x 512 bf16 tokens, on the critical path of every step.
+__global__ __launch_bounds__(1024) void masked_mean_vec_kernel(const void* x, int xdt, int64_t x_bs, int64_t ldx,
+                                                               const float* mask, float* out, int64_t T, int D) {
+    __shared__ f32x4 part[16][64];
+    __shared__ float cnt[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + lane * 4;
+    const int64_t b = blockIdx.y;
+    const int colc = col < D ? col : D - 4;
+    f32x4 acc; acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+    float n = 0.f;
+    for (int64_t t0 = wave; t0 < T; t0 += 64) {
+        f32x4 v[4];
+        float mk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t t = t0 + 16 * j;
+            const int64_t tc = t < T ? t : T - 1;
+            mk[j] = t < T ? (mask ? mask[b * T + tc] : 1.f) : 0.f;
+            v[j] = load4(x, xdt, b * x_bs + tc * ldx + colc);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            n += mk[j];
+            if (mk[j] != 0.f) { acc[0] += v[j][0]; acc[1] += v[j][1]; acc[2] += v[j][2]; acc[3] += v[j][3]; }
+        }
+    }
+    part[wave][lane] = acc;
+    if (lane == 0) cnt[wave] = n;
+    __syncthreads();
+    if (wave == 0 && col < D) {
+        f32x4 s = part[0][lane];
+        float c = cnt[0];
+        for (int w = 1; w < 16; ++w) {
+            const f32x4 p = part[w][lane];
+            s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];
+            c += cnt[w];
+        }
+        if (mask) { s[0] /= c; s[1] /= c; s[2] /= c; s[3] /= c; }
+        *(f32x4*)(out + b * D + col) = s;
+    }
+}
+
 // ---- L2 normalise rows -------------------------------------------------------------------------
 template <int NV, bool FULL>
 __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void l2norm_kernel(const void* x, int xdt, int64_t ldx, float* y32,
@@ -532,8 +577,13 @@ extern "C" int made_masked_mean(const void* x, int32_t x_dtype, int64_t x_bs, in
     MADE_REQUIRE(x && out, "made_masked_mean: null pointer");
     MADE_REQUIRE(B >= 0 && T > 0 && D > 0 && B <= 65535, "made_masked_mean: bad dims");
     if (B == 0) return MADE_OK;
-    hipLaunchKernelGGL(masked_mean_kernel, dim3((unsigned)((D + 63) / 64), (unsigned)B), dim3(ROW_THREADS), 0,
-                       (hipStream_t)stream, x, x_dtype, x_bs, ldx, mask, out, T, (int)D);
+    const int esz = x_dtype == MADE_F32 ? 4 : 2;
+    if (D % 4 == 0 && ldx % 4 == 0 && x_bs % 4 == 0 && ((uintptr_t)x % (4 * esz)) == 0 && ((uintptr_t)out % 16) == 0)
+        hipLaunchKernelGGL(masked_mean_vec_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)B), dim3(1024), 0,
+                           (hipStream_t)stream, x, x_dtype, x_bs, ldx, mask, out, T, (int)D);
+    else
+        hipLaunchKernelGGL(masked_mean_kernel, dim3((unsigned)((D + 63) / 64), (unsigned)B), dim3(ROW_THREADS), 0,
+                           (hipStream_t)stream, x, x_dtype, x_bs, ldx, mask, out, T, (int)D);
     return made_check_launch("made_masked_mean");
 }
 

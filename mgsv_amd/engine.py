@@ -543,7 +543,16 @@ class MadeEngine:
         # ---- X-Pool similarities + retrieval loss (K5-K7): independent of the DETR branch, so they run on the side stream
         # beside the (latency-bound) decoder and join at the end of the step
         side.wait_stream(cur)
+        dec_early = None
         with torch.cuda.stream(side):
+            if not regression and c.moment_query_type != "xpool":
+                # The query side of decoder layer 0 (initial queries -> self-attention block -> the folded cross-attention
+                # query) reads nothing the DETR encoder produces: it runs here, beside the encoder, instead of at the head of
+                # the decoder's chain of dependent launches.
+                self._decoder_queries(ws, video, music, None, B)
+                self._decoder_query_side(ws, 0, B)
+                dec_early = torch.cuda.Event()
+                dec_early.record(side)
             need_pooled = want_pooled or c.moment_query_type == "xpool" or c.vmr_loss == "dual_single_feature_fuse"
             pooled = torch.empty(B * B, D, device=self.device, dtype=torch.float32) if (need_pooled and "music" in c.vmr_fusion) else None
             if "music" in c.vmr_fusion:
@@ -597,48 +606,27 @@ class MadeEngine:
         # the L memory rows at all; self-attention collapses to one folded Linear when there is a single query.
         mem3, mempos3 = memory.view(B, L, D), srcpos.view(B, L, D)
         tgt = ws["tgt"]
-        if c.moment_query_type in ("video", "music"):
-            src_vec = video if c.moment_query_type == "video" else music
-            tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
-        elif c.moment_query_type == "xpool":                             # reference model_Uni.py:222-223: the track's pooled vectors,
-            cur.wait_stream(side)                                        # averaged over the videos of the batch (X-Pool branch first)
-            src_vec = ops.masked_mean(pooled.view(B, B, D), torch.ones(B, B, device=self.device))
-            tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
-        else:                                                            # "zero" / "random": reference transformer.py:73-74
-            tgt.zero_()
+        if dec_early is not None:
+            cur.wait_event(dec_early)                                    # layer 0's query side was computed beside the encoder
+        else:
+            if c.moment_query_type == "xpool":                           # reference model_Uni.py:222-223: the track's pooled vectors,
+                cur.wait_stream(side)                                    # averaged over the videos of the batch (X-Pool branch first)
+            self._decoder_queries(ws, video, music, pooled, B)
         qp = P["query_embed"]
         hs = ws["hs"]
         ca_scale = 1.0 / math.sqrt(D // H)
         dq_all, dpool = ws["dq_all"], ws["dpool"]
         dq4 = dq_all.view(B, Q, H, D).permute(0, 2, 1, 3)               # [B, H, Q, D] view: row (b,q), head-major columns
         dp4 = dpool.view(B, Q, H, D).permute(0, 2, 1, 3)
-        dws = ws["dws"]
-        slab = 64 if self.tc == torch.bfloat16 else 32
-
-        def skinny(A, wkey, **kw):
-            """Linear on the B*Q decoder rows: K split over workgroups so the launch fills the chip."""
-            W = P[wkey + ".w"]
-            N, K = W.shape
-            tiles = ((A.shape[0] + 127) // 128) * ((N + 127) // 128)
-            split = max(2, min(192 // max(tiles, 1), (K + slab - 1) // slab, 32, dws.numel() // (A.shape[0] * N)))
-            ops.linear_splitk(A, W, P[wkey + ".b"], dws, split, **kw)
+        skinny = lambda A, wkey, **kw: self._skinny(ws, A, wkey, **kw)
 
         n_split = max(1, min(8, 256 // max(B, 1)))
         for l in range(nd):
             p = f"detr_transformer.decoder.layers.{l}"
-            ln1, ln2, ln3 = [(P[p + f".ln{i}.g"], P[p + f".ln{i}.b"]) for i in (1, 2, 3)]
+            ln2, ln3 = [(P[p + f".ln{i}.g"], P[p + f".ln{i}.b"]) for i in (2, 3)]
             t1, t2 = ws["t1"], ws["t2"]
-            if Q == 1:
-                skinny(tgt, p + ".sa.fold", R=tgt, ln1=ln1, ln1_out=t1)
-            else:
-                dqkv = ws["dqkv"]
-                ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=qp, a2_row_mod=Q,
-                           segs=[Seg(out=dqkv, col_begin=0, use_a2=True),
-                                 Seg(out=dqkv[:, 2 * D:], col_begin=2 * D, ldo=dqkv.stride(0))])
-                d3 = dqkv.view(B, Q, 3 * D)
-                ops.attention(d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:], ws["datt"].view(B, Q, D), H)
-                skinny(ws["datt"], p + ".sa.out", R=tgt, ln1=ln1, ln1_out=t1)
-            skinny(t1, p + ".ca.qk", A2=qp, a2_row_mod=Q, out=dq_all)
+            if l > 0 or dec_early is None:
+                self._decoder_query_side(ws, l, B)
             ops.attention_wide(dq4, mempos3, mem3, dp4, scale=ca_scale, key_mask=fus_mask,
                                n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
             skinny(dpool, p + ".ca.vo", R=t1, ln1=ln2, ln1_out=t2)
@@ -712,6 +700,50 @@ class MadeEngine:
                    matcher_status=status, criterion_losses=losses, localization_loss=total)
         cur.wait_stream(side)
         return out
+
+    def _skinny(self, ws, A: Tensor, wkey: str, **kw):
+        """Linear on the B*Q decoder rows: K split over workgroups so the launch fills the chip."""
+        P, dws = self.P, ws["dws"]
+        W = P[wkey + ".w"]
+        N, K = W.shape
+        slab = 64 if self.tc == torch.bfloat16 else 32
+        tiles = ((A.shape[0] + 127) // 128) * ((N + 127) // 128)
+        split = max(2, min(192 // max(tiles, 1), (K + slab - 1) // slab, 32, dws.numel() // (A.shape[0] * N)))
+        ops.linear_splitk(A, W, P[wkey + ".b"], dws, split, **kw)
+
+    def _decoder_queries(self, ws, video: Tensor, music: Tensor, pooled: Optional[Tensor], B: int):
+        """Initial decoder queries (reference transformer.py:73-74, model_Uni.py:216-223) -> ws["tgt"]."""
+        c = self.cfg
+        Q, D = c.num_moment_queries, c.D
+        tgt = ws["tgt"]
+        if c.moment_query_type in ("video", "music"):
+            src_vec = video if c.moment_query_type == "video" else music
+            tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        elif c.moment_query_type == "xpool":                             # the track's pooled vectors, averaged over the batch's videos
+            src_vec = ops.masked_mean(pooled.view(B, B, D), torch.ones(B, B, device=self.device))
+            tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+        else:                                                            # "zero" / "random"
+            tgt.zero_()
+
+    def _decoder_query_side(self, ws, l: int, B: int):
+        """Decoder layer l up to the cross-attention: self-attention block over the queries (one folded Linear when Q = 1) ->
+        ws["t1"], then the cross-attention query folded with W_k per head -> ws["dq_all"].  Reads ws["tgt"] only."""
+        c, P = self.cfg, self.P
+        Q, D, H = c.num_moment_queries, c.D, c.detr_nheads
+        p = f"detr_transformer.decoder.layers.{l}"
+        ln1 = (P[p + ".ln1.g"], P[p + ".ln1.b"])
+        tgt, t1, qp = ws["tgt"], ws["t1"], P["query_embed"]
+        if Q == 1:
+            self._skinny(ws, tgt, p + ".sa.fold", R=tgt, ln1=ln1, ln1_out=t1)
+        else:
+            dqkv = ws["dqkv"]
+            ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=qp, a2_row_mod=Q,
+                       segs=[Seg(out=dqkv, col_begin=0, use_a2=True),
+                             Seg(out=dqkv[:, 2 * D:], col_begin=2 * D, ldo=dqkv.stride(0))])
+            d3 = dqkv.view(B, Q, 3 * D)
+            ops.attention(d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:], ws["datt"].view(B, Q, D), H)
+            self._skinny(ws, ws["datt"], p + ".sa.out", R=tgt, ln1=ln1, ln1_out=t1)
+        self._skinny(ws, t1, p + ".ca.qk", A2=qp, a2_row_mod=Q, out=ws["dq_all"])
 
     def _regression_head(self, out, ws, mem3: Tensor, fus_mask: Tensor, spans_target: Tensor, v_duration, with_losses: bool, cur, side):
         """reference model/model_Uni.py:228-232,290-300: memory summed over all L positions / number of valid ones -> 3-layer
