@@ -634,10 +634,27 @@ class MadeEngine:
             skinny(ws["dffn"], p + ".ff2", R=t2, ln1=ln3, ln1_out=tgt, ln2=(P["dec.norm.g"], P["dec.norm.b"]), ln2_out=hs[l])
         out["hs"] = hs.view(nd, B, Q, D)
 
-        # ---- heads (K11) on all decoder layers at once
+        # ---- heads (K11) on all decoder layers at once.  (Running the class head and the query projection on the side stream
+        # beside the span head was tried: +150 us per step under graph replay, so the three chains stay on one stream.)
         hs2 = hs.view(nd * B * Q, D)
         logits, spans = ws["logits"], ws["spans"]
+        pq = vid_sum = None
         ops.linear(hs2, P["class_embed.w"], P["class_embed.b"], out=logits.view(-1, 2))
+        if c.contrastive_align_loss:
+            ops.linear(hs2, P["proj_q.w"], P["proj_q.b"], out=ws["pq_raw"])
+            pq = ws["pq"]
+            ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
+            if c.audio_short_cut:                                    # reference model/model_Uni.py:144-145: normalize(pq + music)
+                from . import ops_train
+                mq = music if Q == 1 else music[:, None, :].expand(B, Q, D).contiguous()
+                ops_train.add3(ws["pq_raw"], pq, mq, b_mod=B * Q * D)
+                ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
+                if c.aux_loss and nd > 1:
+                    # the auxiliary layers get the short-cut a SECOND time when their output dicts are built (reference
+                    # model/model_Uni.py:166-169 adds the music vector to the already short-cut proj_queries[:-1])
+                    n_aux = (nd - 1) * B * Q
+                    ops_train.add3(ws["pq_raw"][:n_aux], pq.view(nd * B * Q, -1)[:n_aux], mq, b_mod=B * Q * D)
+                    ops.l2norm_rows(ws["pq_raw"][:n_aux], out_f32=pq.view(nd * B * Q, -1)[:n_aux])
         if hs2.shape[0] <= 1024:
             skinny(hs2, "span_embed.0", act=ops.ACT_RELU, out=ws["h1"])
             skinny(ws["h1"], "span_embed.1", act=ops.ACT_RELU, out=ws["h2"])
@@ -653,26 +670,10 @@ class MadeEngine:
         else:
             ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, out=spans.view(-1, 2))
         out.update(pred_logits=logits[-1], pred_spans=spans[-1], logits_all=logits, spans_all=spans)
-        pq = vid_sum = None
         if c.contrastive_align_loss:
-            ops.linear(hs2, P["proj_q.w"], P["proj_q.b"], out=ws["pq_raw"])
-            pq = ws["pq"]
-            ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
-            Dc = pq.shape[-1]
-            if c.audio_short_cut:                                        # reference model/model_Uni.py:144-145: normalize(pq + music)
-                from . import ops_train
-                mq = music if Q == 1 else music[:, None, :].expand(B, Q, D).contiguous()
-                ops_train.add3(ws["pq_raw"], pq, mq, b_mod=B * Q * D)
-                ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
-                if c.aux_loss and nd > 1:
-                    # the auxiliary layers get the short-cut a SECOND time when their output dicts are built (reference
-                    # model/model_Uni.py:166-169 adds the music vector to the already short-cut proj_queries[:-1])
-                    n_aux = (nd - 1) * B * Q
-                    ops_train.add3(ws["pq_raw"][:n_aux], pq.view(nd * B * Q, -1)[:n_aux], mq, b_mod=B * Q * D)
-                    ops.l2norm_rows(ws["pq_raw"][:n_aux], out_f32=pq.view(nd * B * Q, -1)[:n_aux])
             self._frame_rows_linear(frame, P["proj_v.w"], P["proj_v.b"], ws["pv_raw"], B, Tv)
             pv = ws["pv"]
-            ops.l2norm_rows(ws["pv_raw"], out_f32=pv.view(B * Tv, Dc))
+            ops.l2norm_rows(ws["pv_raw"], out_f32=pv.view(B * Tv, -1))
             vid_sum = ops.masked_mean(pv, None, out=ws["vid_sum"])
             out.update(proj_queries=pq[-1], proj_vid_mem=pv, proj_queries_all=pq)
 
