@@ -325,33 +325,35 @@ extern "C" int made_row_groups(const float* mask, int64_t M, float* out, void* s
 
 namespace {
 // stream compaction of a token mask in one workgroup of 16 waves: each wave owns a contiguous range, counts it with
-// ballots, the 16 totals are scanned, then the indices are scattered.  The range is walked in batches of 32 x 64 elements whose
-// 32 (coalesced) loads are all issued before the first ballot: a dependent load per 64 elements made this a 17 us kernel at the
-// head of every step's critical path.  With a single batch per wave (M <= 32768) the ballots of the counting pass are kept
-// for the scatter pass.
+// ballots, the 16 totals are scanned, then the indices are scattered.  The range is walked in batches of 16 x 64 elements whose
+// 16 (coalesced) loads are all issued before the first ballot: a dependent load per 64 elements made this a 17 us kernel at the
+// head of every step's critical path.
 __global__ __launch_bounds__(1024) void row_index_kernel(const float* mask, int64_t M, int32_t* row_index, int32_t* n_rows) {
+    constexpr int NB = 16;
     __shared__ int wsum[16];
     __shared__ int wlast[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t per = ((M + 15) / 16 + 63) / 64 * 64;          // elements per wave, multiple of 64
     const int64_t b = (int64_t)wave * per, e = b + per < M ? b + per : M;
-    const bool one = per <= 2048;
-    uint64_t bal[32];
+    uint64_t bal[NB];
     auto ballots = [&](int64_t i0) __attribute__((always_inline)) {
-        float v[32];
+        float v[NB];
+        const float* p = mask + i0 + lane;
+        if (i0 + NB * 64 <= e) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int64_t i = i0 + j * 64 + lane;
-            v[j] = i < e ? mask[i] : 0.f;
+            for (int j = 0; j < NB; ++j) v[j] = p[j * 64];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[j] = i0 + j * 64 + lane < e ? p[j * 64] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) bal[j] = __ballot(v[j] != 0.f);
+        for (int j = 0; j < NB; ++j) bal[j] = __ballot(v[j] != 0.f);
     };
     int cnt = 0, last = -1;
-    for (int64_t i0 = b; i0 < e; i0 += 2048) {
+    for (int64_t i0 = b; i0 < e; i0 += NB * 64) {
         ballots(i0);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < NB; ++j) {
             cnt += __popcll(bal[j]);
             if (bal[j]) last = (int)(i0 + j * 64) + 63 - __clzll(bal[j]);
         }
@@ -364,10 +366,10 @@ __global__ __launch_bounds__(1024) void row_index_kernel(const float* mask, int6
         total += wsum[w];
         if (wlast[w] >= 0) lastv = wlast[w];
     }
-    for (int64_t i0 = b; i0 < e; i0 += 2048) {
-        if (!one) ballots(i0);
+    for (int64_t i0 = b; i0 < e; i0 += NB * 64) {
+        ballots(i0);                                   // the second look at the range comes out of L2
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < NB; ++j) {
             if ((bal[j] >> lane) & 1ull) row_index[base + __popcll(bal[j] & ((1ull << lane) - 1ull))] = (int32_t)(i0 + j * 64 + lane);
             base += __popcll(bal[j]);
         }
@@ -381,20 +383,28 @@ __global__ __launch_bounds__(1024) void row_index_kernel(const float* mask, int6
 __global__ __launch_bounds__(1024) void batch_order_kernel(const float* mask, int B, int64_t T, int32_t* order) {
     __shared__ int len[8192];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = wave; b < B; b += 16) {
-        const float* m = mask + (int64_t)b * T;
-        int cnt = 0;
+    for (int b0 = wave; b0 < B; b0 += 64) {            // four samples of this wave at a time: their loads travel together
+        int cnt[4] = {0, 0, 0, 0};
         for (int64_t i0 = 0; i0 < T; i0 += 512) {
-            float v[8];
+            float v[4][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int64_t i = i0 + j * 64 + lane;
-                v[j] = i < T ? m[i] : 0.f;
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int b = b0 + 16 * s4;
+                const float* m = mask + (int64_t)(b < B ? b : B - 1) * T;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t i = i0 + j * 64 + lane;
+                    v[s4][j] = i < T ? m[i] : 0.f;
+                }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) cnt += __popcll(__ballot(v[j] != 0.f));
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cnt[s4] += __popcll(__ballot(v[s4][j] != 0.f));
         }
-        if (lane == 0) len[b] = cnt;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+            if (lane == 0 && b0 + 16 * s4 < B) len[b0 + 16 * s4] = cnt[s4];
     }
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += 1024) {
