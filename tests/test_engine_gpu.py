@@ -213,3 +213,45 @@ def test_retrieval_bf16_fused_xpool_kernel(N_v, N_m, S):
     top_ref = ref.topk(2, dim=1)
     clear = (top_ref.values[:, 0] - top_ref.values[:, 1]) > 6e-2
     assert bool((sim.cpu().argmax(1)[clear] == top_ref.indices[:, 0][clear]).all())
+
+
+def test_two_batches_in_flight_match_one_at_a_time():
+    """bench.py --in-flight 2: two engines (own workspace, stream, captured graph) run different batches concurrently.  Every
+    output of either lane must be bit-identical to the same engine running its batch alone: nothing in the library or the
+    workspaces may be shared between lanes."""
+    cfg = cfg_headline()
+    B, Tv, Ta = 16, 30, 512
+    sd = synth.make_state_dict(cfg, seed=0)
+    dev = torch.device("cuda")
+    lanes = []
+    for l in range(2):
+        inp = synth.make_inputs(cfg, B, Tv, Ta, seed=11 + 7 * l)
+        t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
+        lanes.append((MadeEngine(cfg, sd, device=dev, dtype="bf16"), t))
+
+    def step(l):
+        eng, t = lanes[l]
+        return eng.forward(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+
+    keys = ["pred_logits", "pred_spans", "sims_single", "sims_dual", "retrieval_loss", "localization_loss", "criterion_losses",
+            "matcher_pred_idx", "video_feats", "music_feats"]
+    alone = []
+    for l in range(2):
+        o = step(l)
+        torch.cuda.synchronize()
+        alone.append({k: o[k].clone() for k in keys})
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    graphs, outs = [], [None, None]
+    for l in range(2):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs[l] = step(l)
+        graphs.append(g)
+    for it in range(6):                                  # interleaved replays, both graphs in flight at once
+        for l in range(2):
+            with torch.cuda.stream(streams[l]):
+                graphs[l].replay()
+    torch.cuda.synchronize()
+    for l in range(2):
+        for k in keys:
+            assert torch.equal(outs[l][k], alone[l][k]), f"lane {l}: {k} differs when two batches are in flight"
