@@ -14,6 +14,7 @@ What is different on purpose:
 from __future__ import annotations
 
 import argparse
+import contextlib
 import datetime
 import logging
 import math
@@ -66,7 +67,8 @@ TEST_ONLY = [("test_best", int, 0, None)]
 TEST_DROPS = {"matching_lr", "detection_lr"}                  # the test parser has no optimizer learning rates
 # additions of this build (not in the reference)
 EXTRA = [("synthetic_features", int, 0, None), ("max_samples", int, 0, None), ("compute_dtype", str, "bf16", ["bf16", "f32"]),
-         ("fused_step", int, 1, None)]
+         ("fused_step", int, 1, None),
+         ("eval_in_flight", int, 2, None)]                    # evaluation: independent batches in flight (engine workspace + stream each)
 
 
 def build_parser(for_test: bool = False) -> argparse.ArgumentParser:
@@ -291,17 +293,31 @@ def eval_epoch(epoch, args, model, loader, device, dist, logger):
     model.eval()
     t0 = time.time()
     vids, mids, V, M, S, SM, IOU = [], [], [], [], [], [], []
-    loss_sum, n = 0.0, 0
-    for data_map, meta_map, spans_target in loader:
-        ff, sf, fm, sm, tg, vdur = _to_device(data_map, meta_map, spans_target, device)
-        om, lm, feat, mask, ids = model(ff, sf, fm, sm, tg, v_duration=vdur, video_ids=meta_map["video_id"], music_ids=meta_map["music_id"], is_train=False)
-        loss_sum += float(lm["retrieval_loss"] * args.ret_loss_weight + lm["localization_loss"] * args.loc_loss_weight) * ff.shape[0]
-        n += ff.shape[0]
-        V.append(feat["video_feats"].clone()); M.append(feat["music_feats"].clone()); S.append(feat["segment_feats"].clone()); SM.append(sm)
-        vids.extend(meta_map["video_id"]); mids.extend(meta_map["music_id"])
-        iou, _ = detr_iou_device(om["pred_logits"], om["pred_spans"], meta_map["gt_moment"].to(device), meta_map["m_duration"].to(device),
-                                 model.criterion.foreground_label, float(args.max_m_duration))
-        IOU.append(iou)
+    # Batches are independent: keep `eval_in_flight` of them in flight, each on its own HIP stream with its own engine workspace
+    # (one batch's decoder, a chain of dependent launches, then runs beside the next batch's encoders), and read nothing back
+    # until the loop is over: the loss is accumulated on the device.
+    n_lanes = max(1, int(getattr(args, "eval_in_flight", 2))) if device.type == "cuda" else 1
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_lanes)] if n_lanes > 1 else [None]
+    loss_acc = [torch.zeros((), device=device) for _ in range(n_lanes)]
+    n = 0
+    for it, (data_map, meta_map, spans_target) in enumerate(loader):
+        lane = it % n_lanes
+        if streams[lane] is not None:
+            streams[lane].wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(streams[lane]) if streams[lane] is not None else contextlib.nullcontext():
+            ff, sf, fm, sm, tg, vdur = _to_device(data_map, meta_map, spans_target, device)
+            om, lm, feat, mask, ids = model(ff, sf, fm, sm, tg, v_duration=vdur, video_ids=meta_map["video_id"], music_ids=meta_map["music_id"],
+                                            is_train=False, lane=lane)
+            loss_acc[lane] += (lm["retrieval_loss"] * args.ret_loss_weight + lm["localization_loss"] * args.loc_loss_weight) * ff.shape[0]
+            n += ff.shape[0]
+            V.append(feat["video_feats"].clone()); M.append(feat["music_feats"].clone()); S.append(feat["segment_feats"].clone()); SM.append(sm)
+            vids.extend(meta_map["video_id"]); mids.extend(meta_map["music_id"])
+            iou, _ = detr_iou_device(om["pred_logits"], om["pred_spans"], meta_map["gt_moment"].to(device), meta_map["m_duration"].to(device),
+                                     model.criterion.foreground_label, float(args.max_m_duration))
+            IOU.append(iou)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    loss_sum = float(sum(loss_acc))
     video, music, seg, segm, iou = torch.cat(V), torch.cat(M), torch.cat(S), torch.cat(SM), torch.cat(IOU)
     if "XA" not in args.vmr_fusion or args.vmr_loss == "dual":
         sim = model._engine_ready().dual_sims(video, music)

@@ -146,6 +146,8 @@ class Uni_model(nn.Module):
             self.criterion.register_buffer("empty_weight", torch.from_numpy(sd["criterion.empty_weight"].copy()))
         self._engine: Optional[MadeEngine] = None
         self._engine_stamp = None
+        self._lane_engines: Dict[int, MadeEngine] = {}              # extra engines (own workspace) for batches in flight
+        self._lane_stamps: Dict[int, object] = {}
         self._trainer = None
         self._trainer_stamp = None
         self._train_seed = int(getattr(args, "seed", 0)) << 20
@@ -180,8 +182,18 @@ class Uni_model(nn.Module):
     def _stamp(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def _engine_ready(self) -> MadeEngine:
+    def _engine_ready(self, lane: int = 0) -> MadeEngine:
+        """The forward executor with this module's current weights.  lane > 0: a further engine with its own workspace, so that an
+        evaluation loop can keep several independent batches in flight on different streams (mgsv_amd/driver.py: eval_epoch)."""
         stamp = self._stamp()
+        if lane > 0:
+            eng = self._lane_engines.get(lane)
+            if eng is None:
+                eng = self._lane_engines[lane] = MadeEngine(self.cfg, self.state_dict(), device=self.device, dtype=self.compute_dtype)
+            elif self._lane_stamps.get(lane) != stamp:
+                eng.load_state_dict(self.state_dict())
+            self._lane_stamps[lane] = stamp
+            return eng
         if self._engine is None:
             self._engine = MadeEngine(self.cfg, self.state_dict(), device=self.device, dtype=self.compute_dtype)
         elif stamp != self._engine_stamp:
@@ -232,7 +244,7 @@ class Uni_model(nn.Module):
 
     # ---- forward (reference model/model_Uni.py:177-322)
     def forward(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, v_duration=None,
-                video_ids=None, music_ids=None, is_train=False):
+                video_ids=None, music_ids=None, is_train=False, lane: int = 0):
         if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse", "dual_single_feature_fuse") or "XA" not in self.cfg.vmr_fusion:
             raise ValueError(f"Error: vmr_loss={self.cfg.vmr_loss} and vmr_fusion={self.cfg.vmr_fusion} is not supported in VMR_model")
         if self.training:
@@ -253,7 +265,7 @@ class Uni_model(nn.Module):
             return output_map, loss_map, feat_map, mask_map, id_map
         if self.cfg.vmr_loss not in ("dual", "single", "dual_single_loss_fuse", "dual_single_sim_fuse", "dual_single_feature_fuse") or "XA" not in self.cfg.vmr_fusion:
             raise ValueError(f"Error: vmr_loss={self.cfg.vmr_loss} and vmr_fusion={self.cfg.vmr_fusion} is not supported in VMR_model")
-        eng = self._engine_ready()
+        eng = self._engine_ready(lane)
         dev = eng.device
         f32 = torch.float32
         o = eng.forward(frame_feats.to(dev, f32), segment_feats.to(dev, f32), frame_masks.to(dev, f32),

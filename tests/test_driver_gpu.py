@@ -37,6 +37,9 @@ def test_train_and_test_entry_points(tmp_path):
     out = driver.main_test(["--name", "t", "--test_csv", va, "--output_dir", str(tmp_path / "logs")] + COMMON)
     assert set(out["ret"]) >= {"R1", "R5", "R10", "R100", "MedianR", "MeanR", "MRR"} and 0 <= out["ret"]["R1"] <= 100
     assert set(out["loc"]) == {"mIoU", "IoU@0.3", "IoU@0.5", "IoU@0.7"} and len(out["com"]) == 12
+    # two batches in flight (the default) and one at a time score the split identically
+    one = driver.main_test(["--name", "t", "--test_csv", va, "--output_dir", str(tmp_path / "logs"), "--eval_in_flight", "1"] + COMMON)
+    assert one["ret"] == out["ret"] and one["loc"] == out["loc"] and one["com"] == out["com"]
     # the unfused path of the reference's loop body (torch Adam + clip_grad_norm_) also runs
     res2 = driver.main_train(["--name", "t2", "--do_train", "--epochs", "1", "--batch_size_train", "16", "--train_csv", tr, "--val_csv", va,
                               "--output_dir", str(tmp_path / "logs"), "--fused_step", "0"] + COMMON)
