@@ -185,7 +185,7 @@ __global__ __launch_bounds__(ROW_THREADS, NV <= 4 ? 4 : 2) void l2norm_kernel(co
 // ---- mask-aware sine position embedding --------------------------------------------------------
 // grid (ceil(L/PE_ROWS), B).  Every workgroup re-reduces its batch row's mask (L floats) to get the
 // running count before its rows and the total, then writes PE_ROWS x D outputs.
-constexpr int PE_ROWS = 4;
+constexpr int PE_ROWS = 16;
 __global__ __launch_bounds__(ROW_THREADS) void sine_pe_kernel(const float* mask, const float* dim_t, void* out, int odt,
                                                               int L, int D) {
     __shared__ float red_before[4], red_total[4];
@@ -212,10 +212,32 @@ __global__ __launch_bounds__(ROW_THREADS) void sine_pe_kernel(const float* mask,
         if (t >= L) break;
         c += mrow[t];                                   // inclusive cumsum (counts are exact in f32)
         const float xe = __fmul_rn(__fdiv_rn(c, denom), two_pi);
-        for (int i = threadIdx.x; i < D; i += ROW_THREADS) {
-            float ang = __fdiv_rn(xe, dim_t[i]);
-            float v = (i & 1) ? cosf(ang) : sinf(ang);
-            store_from_f32(out, odt, (b * L + t) * (int64_t)D + i, v);
+        if ((D & 3) == 0) {
+            // four columns per thread = two (sin, cos) pairs; a pair shares its frequency (dim_t[2k] == dim_t[2k+1] in the
+            // reference's table), so one range reduction serves both; one 8- or 16-byte store
+            for (int i = threadIdx.x * 4; i < D; i += ROW_THREADS * 4) {
+                const f32x4 dt = *(const f32x4*)(dim_t + i);
+                f32x4 v;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const float a0 = __fdiv_rn(xe, dt[2 * pr]);
+                    if (dt[2 * pr] == dt[2 * pr + 1]) {
+                        float sn, cs;
+                        sincosf(a0, &sn, &cs);
+                        v[2 * pr] = sn; v[2 * pr + 1] = cs;
+                    } else {
+                        v[2 * pr] = sinf(a0);
+                        v[2 * pr + 1] = cosf(__fdiv_rn(xe, dt[2 * pr + 1]));
+                    }
+                }
+                store4(out, odt, (b * L + t) * (int64_t)D + i, v);
+            }
+        } else {
+            for (int i = threadIdx.x; i < D; i += ROW_THREADS) {
+                float ang = __fdiv_rn(xe, dim_t[i]);
+                float v = (i & 1) ? cosf(ang) : sinf(ang);
+                store_from_f32(out, odt, (b * L + t) * (int64_t)D + i, v);
+            }
         }
     }
 }
