@@ -4,6 +4,7 @@
 // shuffles for the row reductions; parameter gradients are accumulated in registers over the rows a wave owns and added
 // to the f32 gradient buffers with one atomic per column per workgroup.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -124,19 +125,26 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs 
     const uint32_t thr = made_drop_threshold(a.drop.p);
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const int D = a.D;
-    for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < a.rows; row += (int64_t)gridDim.x * NW) {
-        if (a.row_skip && a.row_skip[row] == 0.f) continue;   // padded token: nothing read, nothing written (wave-uniform)
-        const bool skip = false;
+    // A wave's rows are base + k * stride.  It looks 64 of them ahead (one row_skip load per lane, one ballot), then walks the valid
+    // ones two at a time with the loads of both in flight: padded tokens cost nothing, and a row's latency is hidden by its pair.
+    const int64_t stride = (int64_t)gridDim.x * NW;
+    auto load_row = [&](int64_t row, f32x4 (&xv)[NV], f32x4 (&gy)[NV]) __attribute__((always_inline)) {
         const int64_t xoff = a.rpb > 0 ? (row / a.rpb) * a.xbs + (row % a.rpb) * a.ldx : row * a.ldx;
-        f32x4 xv[NV], gy[NV];
-        float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * WAVE + lane) * 4;
             const int cc = c < D ? c : 0;
             xv[i] = ld4(a.x, a.xdt, xoff + cc);
             gy[i] = ld4(a.dy, a.dydt, row * a.lddy + cc);
-            if (c >= D || skip) {
+        }
+    };
+    auto process = [&](int64_t row, f32x4 (&xv)[NV], f32x4 (&gy)[NV]) __attribute__((always_inline)) {
+        const bool skip = false;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c >= D) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { xv[i][j] = 0.f; gy[i][j] = 0.f; }
             }
@@ -195,6 +203,24 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs 
                     st4(a.dxd, a.dxdt, row * a.lddxd + c, o);
                 }
             }
+        }
+    };
+    for (int64_t base = (int64_t)blockIdx.x * NW + wave; base < a.rows; base += 64 * stride) {
+        const int64_t cand = base + (int64_t)lane * stride;
+        const bool ok = cand < a.rows && (!a.row_skip || a.row_skip[cand] != 0.f);
+        uint64_t todo = __ballot(ok);
+        while (todo) {
+            const int j0 = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const bool two = todo != 0;
+            const int j1 = two ? __builtin_ctzll(todo) : j0;
+            if (two) todo &= todo - 1;
+            const int64_t r0 = base + (int64_t)j0 * stride, r1 = base + (int64_t)j1 * stride;
+            f32x4 xa[NV], ga[NV], xb[NV], gb[NV];
+            load_row(r0, xa, ga);
+            load_row(r1, xb, gb);
+            process(r0, xa, ga);
+            if (two) process(r1, xb, gb);
         }
     }
     flush_cols<NV, NW>(a.dgamma, dg, D, lane, wave, sm);
@@ -639,7 +665,8 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
     a.dgamma = dgamma; a.dbeta = dbeta; a.rows = rows; a.D = (int)D; a.eps = eps; a.row_skip = row_skip;
     if (rows > 256 && D <= 1024) {                              // each workgroup flushes 2*D same-address atomics: few, large workgroups
         int64_t nb = (rows + 15) / 16;
-        if (nb > 512) nb = 512;
+        static const int nb_cap = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
+        if (nb > nb_cap) nb = nb_cap;
         DISPATCH_NVB(D, hipLaunchKernelGGL((layernorm_bwd_kernel<(NV > 4 ? 4 : NV), 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a));
     } else {
         int64_t nb = (rows + 3) / 4;
@@ -720,7 +747,8 @@ extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, 
     a.rows = rows; a.Nv = Nv; a.D = (int)D; a.eps = eps;
     if (rows > 256 && D <= 1024) {
         int64_t nb = (rows + 15) / 16;
-        if (nb > 512) nb = 512;
+        static const int nb_cap = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
+        if (nb > nb_cap) nb = nb_cap;
         DISPATCH_NVB(D, hipLaunchKernelGGL((xpool_tail_bwd_kernel<(NV > 4 ? 4 : NV), 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a));
     } else {
         int64_t nb = (rows + 3) / 4;
