@@ -37,7 +37,7 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, batch, seed, *params):
         trn = owner._trainer
-        out = trn.forward_train(*batch, seed=seed)
+        out = trn.forward_train(*batch, seed=seed, v_duration=getattr(owner, "_train_vdur", None))
         ctx.owner = owner
         owner._last_train_out = out
         return out["retrieval_loss"].clone().view(()), out["localization_loss"].clone().view(())
@@ -253,12 +253,13 @@ class Uni_model(nn.Module):
             batch = (frame_feats.to(dev, f32), segment_feats.to(dev, f32), frame_masks.to(dev, f32), segment_masks.to(dev, f32),
                      spans_target.to(dev, f32))
             self._train_seed += 1
+            self._train_vdur = v_duration.to(dev, f32) if torch.is_tensor(v_duration) else v_duration
             if torch.is_grad_enabled():
                 params = [p for _, p in self.named_parameters()]
                 ret, loc = _TrainStep.apply(self, batch, self._train_seed, *params)
                 o = self._last_train_out
             else:
-                o = trn.forward_train(*batch, seed=self._train_seed)
+                o = trn.forward_train(*batch, seed=self._train_seed, v_duration=self._train_vdur)
                 ret, loc = o["retrieval_loss"][0], o["localization_loss"][0]
             output_map, feat_map, mask_map, id_map = self._maps(o, trn, frame_masks, segment_masks, video_ids, music_ids)
             loss_map = {"retrieval_loss": ret, "localization_loss": loc, "localization_loss_dict": trn.loss_dict(o)}

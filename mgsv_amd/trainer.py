@@ -61,8 +61,8 @@ class MadeTrainer(MadeEngine):
             bad.append("agg_module=mlp / with_cls_token / transformer_is_share")
         if "detr" not in c.mml_localization:
             bad.append(f"mml_localization={c.mml_localization}")
-        if c.predict_center or c.audio_short_cut or c.moment_loss:
-            bad.append("predict_center / audio_short_cut / moment_loss")
+        if c.audio_short_cut:
+            bad.append("audio_short_cut")
         if bad:
             raise NotImplementedError("MadeTrainer (HIP training path) does not cover yet: " + "; ".join(bad))
 
@@ -120,6 +120,9 @@ class MadeTrainer(MadeEngine):
             lin(f"span_embed.{i}", f"span_embed.layers.{i}")
         if c.contrastive_align_loss:
             lin("proj_q", "contrastive_align_projection_query"); lin("proj_v", "contrastive_align_projection_vid")
+        if c.moment_loss:
+            for i in range(3):
+                lin(f"moment_embed.{i}", f"moment_embed.layers.{i}")
         return mats, vecs
 
     def _init_master(self, sd: Dict[str, object]):
@@ -135,7 +138,7 @@ class MadeTrainer(MadeEngine):
                 return 0                                      # temporal
             if k.startswith(XA + ".") or k == "logit_scale":
                 return 1                                      # matching
-            if k.startswith(("detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_",
+            if k.startswith(("detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_", "moment_embed.",
                              "video_music_fusion_cross_transformer.")):
                 return 2                                      # detection (the CA fusion block belongs here: model_Uni.py:95-97)
             return 3                                          # not optimised (decoder_query_embed, unused variants)
@@ -252,10 +255,11 @@ class MadeTrainer(MadeEngine):
 
     def train_step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed: int, lrs=(1e-4, 1e-4, 1e-4),
                    max_grad_norm: float = 1.0, w_ret: Optional[Tensor] = None, w_loc: Optional[Tensor] = None, dist=None,
-                   music_ids=None) -> Dict[str, Tensor]:
+                   music_ids=None, v_duration: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """One iteration of the reference's loop body (train-MaDe.py:337-381): forward, backward, (data-parallel gradient
         average: one RCCL all-reduce of the flat buffer), clip + Adam, repack."""
-        out = self.forward_train(frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed=seed, music_ids=music_ids)
+        out = self.forward_train(frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed=seed, music_ids=music_ids,
+                                 v_duration=v_duration)
         scale = 1.0
         if dist is not None and dist.get_world_size() > 1:
             # two buckets of the flat f32 gradient buffer (RCCL all-reduce, sum; the 1/W goes into the optimizer's grad_scale): the
@@ -394,10 +398,12 @@ class MadeTrainer(MadeEngine):
         return ex.to(self.device)
 
     def forward_train(self, frame_feats: Tensor, segment_feats: Tensor, frame_masks: Tensor, segment_masks: Tensor,
-                      spans_target: Tensor, seed: int = 0, music_ids=None) -> Dict[str, Tensor]:
+                      spans_target: Tensor, seed: int = 0, music_ids=None, v_duration: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """reference model/model_Uni.py:177-322 under model.train(): same outputs as MadeEngine.forward plus everything
         the backward needs, kept in the training workspace."""
         c, P = self.cfg, self.P
+        if c.predict_center == 1 and v_duration is None:
+            raise ValueError("predict_center=1 needs v_duration (reference model/model_Uni.py:280-282)")
         self.seed = int(seed)
         B, Tv, _ = frame_feats.shape
         Ta = segment_feats.shape[1]
@@ -561,8 +567,20 @@ class MadeTrainer(MadeEngine):
         ops.linear(hs2, P["class_embed.w"], P["class_embed.b"], out=logits.view(-1, 2))
         h1 = ops.linear(hs2, P["span_embed.0.w"], P["span_embed.0.b"], act=ops.ACT_RELU, out=tw["h1"])
         h2 = ops.linear(h1, P["span_embed.1.w"], P["span_embed.1.b"], act=ops.ACT_RELU, out=tw["h2"])
-        ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, out=spans.view(-1, 2))
+        if c.predict_center == 1:
+            # the head predicts the centre only; the width is the video's share of the longest track, a constant of the batch
+            # (reference model/model_Uni.py:135-136,280-282): no gradient reaches it
+            ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, segs=[Seg(out=spans.view(-1, 2), ldo=2)])
+            spans[..., 1] = (v_duration.to(self.device, torch.float32) / c.max_m_duration).view(1, B, 1)
+        else:
+            ops.linear(h2, P["span_embed.2.w"], P["span_embed.2.b"], act=ops.ACT_SIGMOID, out=spans.view(-1, 2))
         out.update(pred_logits=logits[-1], pred_spans=spans[-1], logits_all=logits, spans_all=spans)
+        if c.moment_loss:                                    # reference model_Uni.py:152-159: outputs only, no loss reads them, so
+            last = hs[nd - 1]                                # moment_embed gets no gradient (nor does the reference's)
+            m1 = ops.linear(last, P["moment_embed.0.w"], P["moment_embed.0.b"], act=ops.ACT_RELU)
+            m2 = ops.linear(m1, P["moment_embed.1.w"], P["moment_embed.1.b"], act=ops.ACT_RELU)
+            m3 = ops.linear(m2, P["moment_embed.2.w"], P["moment_embed.2.b"], out_dtype=torch.float32)
+            out["moment_feats"] = ops.l2norm_rows(m3).view(B, Q, D)
         pq = vid_sum = None
         if c.contrastive_align_loss:
             ops.linear(hs2, P["proj_q.w"], P["proj_q.b"], out=ws["pq_raw"])
@@ -761,7 +779,8 @@ class MadeTrainer(MadeEngine):
             dlog, dsp = tr.add3(tw["dlog_c"], dlog), tr.add3(tw["dsp_c"], dsp)
         tr.gemm_tn(dlog[:, :2], hs2, G["class_embed.w"], accumulate=True, colsum=G["class_embed.b"])
         ops.linear(dlog, P["class_embed.wt"], None, out=dhs)
-        tr.gemm_tn(dsp[:, :2], tw["h2"], G["span_embed.2.w"], accumulate=True, colsum=G["span_embed.2.b"])
+        n_span = 1 if c.predict_center == 1 else 2             # predict_center: the width column is a constant, its gradient is dropped
+        tr.gemm_tn(dsp[:, :n_span], tw["h2"], G["span_embed.2.w"], accumulate=True, colsum=G["span_embed.2.b"])
         dz2 = ops.linear(dsp, P["span_embed.2.wt"], None, out=tw["hg1"], gate=_lib.GATE_RELU_OUT, G=tw["h2"])
         dz1 = self._lin_bwd(dz2, tw["h1"], "span_embed.1", dx_out=tw["hg2"], gate=_lib.GATE_RELU_OUT, G=tw["h1"])
         self._lin_bwd(dz1, hs2, "span_embed.0", dx_out=dhs, R=dhs)
@@ -1051,7 +1070,7 @@ class MadeTrainer(MadeEngine):
         dev = self.device
         t = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
         o = self.forward_train(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=seed,
-                               music_ids=inp.get("music_ids"))
+                               music_ids=inp.get("music_ids"), v_duration=t.get("v_duration"))
         gr = torch.tensor([w_ret], device=dev) if w_ret != 1.0 else None
         gl = torch.tensor([w_loc], device=dev) if w_loc != 1.0 else None
         self.backward(gr, gl)
