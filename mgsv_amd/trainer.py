@@ -61,8 +61,8 @@ class MadeTrainer(MadeEngine):
             bad.append("agg_module=mlp / with_cls_token / transformer_is_share")
         if "detr" not in c.mml_localization:
             bad.append(f"mml_localization={c.mml_localization}")
-        if c.audio_short_cut:
-            bad.append("audio_short_cut")
+        if c.audio_short_cut and c.contrastive_align_loss and c.contrastive_hdim != c.D:
+            bad.append("audio_short_cut with contrastive_dim != D (the reference's own add would not broadcast)")
         if bad:
             raise NotImplementedError("MadeTrainer (HIP training path) does not cover yet: " + "; ".join(bad))
 
@@ -376,6 +376,9 @@ class MadeTrainer(MadeEngine):
             ws.update({f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.s": E(B * Q, H, dtype=f32), f"d.{l}.t3": stacks["tgt"][l + 1]})
         if c.contrastive_align_loss:
             Dc = c.contrastive_hdim
+            if c.audio_short_cut:                             # normalize(normalize(p) + music), a second time for the auxiliary layers
+                ws.update(pq_n0=E(nd * B * Q, Dc, dtype=f32), pq_s1=E(nd * B * Q, Dc, dtype=f32), pq_s2=E(nd * B * Q, Dc, dtype=f32),
+                          dpq_s=E(nd * B * Q, Dc, dtype=f32), dpq_s2=E(nd * B * Q, Dc, dtype=f32))
             ws.update(dpq=E(nd * B * Q, Dc, dtype=f32), dvid_sum=E(B, Dc, dtype=f32), dpq_raw=E(nd * B * Q, Dc), dpv_raw=E(B * Tv, Dc),
                       dframe_x=E(B * Tv, D))
         self._tws[key] = ws
@@ -580,12 +583,30 @@ class MadeTrainer(MadeEngine):
             m1 = ops.linear(last, P["moment_embed.0.w"], P["moment_embed.0.b"], act=ops.ACT_RELU)
             m2 = ops.linear(m1, P["moment_embed.1.w"], P["moment_embed.1.b"], act=ops.ACT_RELU)
             m3 = ops.linear(m2, P["moment_embed.2.w"], P["moment_embed.2.b"], out_dtype=torch.float32)
-            out["moment_feats"] = ops.l2norm_rows(m3).view(B, Q, D)
+            mf = ops.l2norm_rows(m3)
+            if c.audio_short_cut:
+                mq = music if Q == 1 else music[:, None, :].expand(B, Q, D).contiguous()
+                tr.add3(m3, mf, mq, b_mod=B * Q * D)
+                mf = ops.l2norm_rows(m3)
+            out["moment_feats"] = mf.view(B, Q, D)
         pq = vid_sum = None
         if c.contrastive_align_loss:
             ops.linear(hs2, P["proj_q.w"], P["proj_q.b"], out=ws["pq_raw"])
             pq = ws["pq"]
-            ops.l2norm_rows(ws["pq_raw"], out_f32=pq.view(nd * B * Q, -1))
+            pq2 = pq.view(nd * B * Q, -1)
+            if c.audio_short_cut:
+                # reference model/model_Uni.py:142-145,166-169: normalize(normalize(proj) + music); the auxiliary layers get the
+                # short-cut a second time when their output dicts are built.  Every stage is kept for the backward.
+                mq = music if Q == 1 else music[:, None, :].expand(B, Q, D).contiguous()
+                ops.l2norm_rows(ws["pq_raw"], out_f32=tw["pq_n0"])
+                tr.add3(tw["pq_s1"], tw["pq_n0"], mq, b_mod=B * Q * D)
+                ops.l2norm_rows(tw["pq_s1"], out_f32=pq2)
+                if c.aux_loss and nd > 1:
+                    n_aux = (nd - 1) * B * Q
+                    tr.add3(tw["pq_s2"][:n_aux], pq2[:n_aux], mq, b_mod=B * Q * D)
+                    ops.l2norm_rows(tw["pq_s2"][:n_aux], out_f32=pq2[:n_aux])
+            else:
+                ops.l2norm_rows(ws["pq_raw"], out_f32=pq2)
             self._frame_rows_linear(frame, P["proj_v.w"], P["proj_v.b"], ws["pv_raw"], B, Tv)
             pv = ws["pv"]
             ops.l2norm_rows(ws["pv_raw"], out_f32=pv.view(B * Tv, pq.shape[-1]))
@@ -786,7 +807,18 @@ class MadeTrainer(MadeEngine):
         self._lin_bwd(dz1, hs2, "span_embed.0", dx_out=dhs, R=dhs)
         if c.contrastive_align_loss:
             Dc = pq.shape[-1]
-            tr.l2norm_bwd(ws["pq_raw"], tw["dpq"], dx_alt=tw["dpq_raw"])
+            dn = tw["dpq"]
+            if c.audio_short_cut:                             # back through normalize(. + music), aux layers twice; music collects the sums
+                if c.aux_loss and nd > 1:
+                    n_aux = (nd - 1) * B * Q
+                    ds2 = tw["dpq_s2"][:n_aux]
+                    tr.l2norm_bwd(tw["pq_s2"][:n_aux], dn[:n_aux], dx=ds2)
+                    dmusic.add_(ds2.view(nd - 1, B, Q, D).sum((0, 2)))
+                    dn[:n_aux].copy_(ds2)
+                tr.l2norm_bwd(tw["pq_s1"], dn, dx=tw["dpq_s"])
+                dmusic.add_(tw["dpq_s"].view(nd, B, Q, D).sum((0, 2)))
+                dn = tw["dpq_s"]
+            tr.l2norm_bwd(ws["pq_raw"], dn, dx_alt=tw["dpq_raw"])
             self._lin_bwd(tw["dpq_raw"], hs2, "proj_q", dx_out=dhs, R=dhs)
             # proj_vid_mem: every frame (padded ones too) receives d vid_sum (reference loss_detr.py:118)
             tr.l2norm_bwd(ws["pv_raw"], tw["dvid_sum"], dx_alt=tw["dpv_raw"], dy_rows_per=Tv)

@@ -228,6 +228,10 @@ def main():
     report["grad_train_native_CA_B3"] = compare_backward(c, 3, 20, 40, "native CA-fusion train-mode grads", train=True)
     c = cfg_native(); c.video_transformer_depth = c.audio_transformer_depth = 2; c.with_act_after_proj = 1; c.moment_query_type = "zero"
     report["grad_train_native_depth2_act_zeroquery_B3"] = compare_backward(c, 3, 20, 40, "native depth-2 / act / zero-query train-mode grads", train=True)
+    c = cfg_native(); c.audio_short_cut = 1; c.num_moment_queries = 3; c.moment_loss = 1
+    report["grad_train_native_shortcut_Q3_moment_B4"] = compare_backward(c, 4, 20, 40, "native audio short-cut / Q=3 / moment_loss train-mode grads", train=True)
+    c = cfg_native(); c.predict_center = 1
+    report["grad_train_native_predict_center_B3"] = compare_backward(c, 3, 20, 40, "native predict_center train-mode grads", train=True)
     report["lsap_vs_scipy"] = compare_lsap()
     report["retrieval_N48x40_S96"] = compare_retrieval(cfg_native(), 48, 40, 96)
     worst = max(v for k, sec in report.items() if isinstance(sec, dict) and not k.startswith("grad_")

@@ -44,3 +44,8 @@ def test_train_and_test_entry_points(tmp_path):
     res2 = driver.main_train(["--name", "t2", "--do_train", "--epochs", "1", "--batch_size_train", "16", "--train_csv", tr, "--val_csv", va,
                               "--output_dir", str(tmp_path / "logs"), "--fused_step", "0"] + COMMON)
     assert np.isfinite(res2[1]["train_loss"])
+    # the CLI's default --audio_short_cut 1 trains too (the reference's scripts pass 0)
+    sc = [("1" if i > 0 and COMMON[i - 1] == "--audio_short_cut" else a) for i, a in enumerate(COMMON)]
+    res3 = driver.main_train(["--name", "t3", "--do_train", "--do_eval", "--epochs", "1", "--batch_size_train", "16", "--train_csv", tr, "--val_csv", va,
+                              "--output_dir", str(tmp_path / "logs")] + sc)
+    assert np.isfinite(res3[1]["train_loss"])

@@ -71,7 +71,8 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
                                        {"num_moment_queries": 2}, {"num_moment_queries": 4, "mml_fusion": "CA", "moment_query_type": "music"},
                                        {"video_transformer_depth": 2, "audio_transformer_depth": 2, "with_act_after_proj": 1},
                                        {"mml_fusion": "CA", "detr_enc_layers": 0, "vmr_loss": "single"},
-                                       {"predict_center": 1}, {"moment_loss": 1}])
+                                       {"predict_center": 1}, {"moment_loss": 1}, {"audio_short_cut": 1},
+                                       {"audio_short_cut": 1, "num_moment_queries": 3, "moment_loss": 1}])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     overrides = dict(overrides)
