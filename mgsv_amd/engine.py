@@ -839,6 +839,8 @@ class MadeEngine:
         """criterion_losses [dec,5] -> the reference's 30-entry dict (main = last layer, `_i` = layer i)."""
         names = ["loss_span", "loss_giou", "loss_label", "class_error", "loss_contrastive_align"]
         nd = self.cfg.detr_dec_layers
+        if "criterion_losses" not in out:                     # regression variant (reference model/model_Uni.py:296-300)
+            return {"loss_span": out["regression_loss_span"], "loss_giou": 0, "loss_label": 0, "class_error": 0}
         L = out["criterion_losses"]
         d = {}
         for l in range(nd):

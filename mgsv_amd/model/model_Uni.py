@@ -224,6 +224,11 @@ class Uni_model(nn.Module):
 
     def _maps(self, o, eng, frame_masks, segment_masks, video_ids, music_ids):
         nd, cfg = self.cfg.detr_dec_layers, self.cfg
+        if "regression" in cfg.mml_localization:                   # reference model/model_Uni.py:290-300: spans only, no matcher
+            feat_map = {"video_feats": o["video_feats"], "music_feats": o["music_feats"],
+                        "frame_feats": o["frame_feats"].float(), "segment_feats": o["segment_feats"].float()}
+            return ({"pred_spans": o["pred_spans"]}, feat_map, {"frame_masks": frame_masks, "segment_masks": segment_masks},
+                    {"video_ids": video_ids, "music_ids": music_ids})
         output_map: Dict[str, object] = {"pred_logits": o["pred_logits"], "pred_spans": o["pred_spans"]}
         if cfg.contrastive_align_loss:
             output_map.update(proj_queries=o["proj_queries"], proj_vid_mem=o["proj_vid_mem"])

@@ -59,7 +59,7 @@ class MadeTrainer(MadeEngine):
             bad.append("vmr_loss=dual_single_feature_fuse")
         if c.agg_module != "transf" or c.with_cls_token or c.transformer_is_share:
             bad.append("agg_module=mlp / with_cls_token / transformer_is_share")
-        if "detr" not in c.mml_localization:
+        if "detr" not in c.mml_localization and "regression" not in c.mml_localization:
             bad.append(f"mml_localization={c.mml_localization}")
         if c.audio_short_cut and c.contrastive_align_loss and c.contrastive_hdim != c.D:
             bad.append("audio_short_cut with contrastive_dim != D (the reference's own add would not broadcast)")
@@ -115,6 +115,10 @@ class MadeTrainer(MadeEngine):
             ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2"); ln(p + ".ln3", p + ".norm3")
         ln("dec.norm", "detr_transformer.decoder.norm")
         mats.append(("query_embed", "decoder_query_embed.weight"))
+        if "regression" in c.mml_localization:                # reference model/model_Uni.py:66-69: no DETR heads in this variant
+            for i in range(3):
+                lin(f"reg_mlp.{i}", f"reg_mlp.layers.{i}")
+            return mats, vecs
         lin("class_embed", "class_embed")
         for i in range(3):
             lin(f"span_embed.{i}", f"span_embed.layers.{i}")
@@ -138,6 +142,10 @@ class MadeTrainer(MadeEngine):
                 return 0                                      # temporal
             if k.startswith(XA + ".") or k == "logit_scale":
                 return 1                                      # matching
+            if "regression" in self.cfg.mml_localization:     # model_Uni.py:92-100: the regression variant optimises the CA fusion block and
+                if k.startswith(("video_music_fusion_cross_transformer.", "reg_mlp.")):       # the regression MLP only; the DETR
+                    return 2                                  # transformer gets gradients but is in no optimizer group
+                return 3
             if k.startswith(("detr_transformer.", "span_embed.", "class_embed.", "contrastive_align_projection_", "moment_embed.",
                              "video_music_fusion_cross_transformer.")):
                 return 2                                      # detection (the CA fusion block belongs here: model_Uni.py:95-97)
@@ -469,6 +477,12 @@ class MadeTrainer(MadeEngine):
         # ---- DETR encoder
         rows = B * L
         fskip = fus_mask.view(-1)
+        qskip = fus_mask
+        regression = "regression" in c.mml_localization
+        if regression:
+            # the regression head sums the memory over ALL positions, padded ones included (reference model_Uni.py:229): the encoder
+            # computes them too (keys stay masked)
+            fskip = qskip = rows_f = None
         pos2 = pos.view(rows, D)
         src = fus.view(rows, D)
         if c.detr_enc_layers == 0:                            # no encoder: memory = the fused sequence itself
@@ -486,7 +500,7 @@ class MadeTrainer(MadeEngine):
             q3 = qkv.view(B, L, 3 * D)
             att = tw[e + ".att"]
             ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, L, D), H, key_mask=fus_mask,
-                          q_skip_mask=fus_mask, lse=tw[e + ".lse"], drop=self._drop(f"enc.{l}" + ".attn", pd),
+                          q_skip_mask=qskip, lse=tw[e + ".lse"], drop=self._drop(f"enc.{l}" + ".attn", pd),
                           order=self._order[fus_mask.data_ptr()])
             x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=tw[e + ".x"], rows=rows_f,
                            drop=self._drop(f"enc.{l}" + ".drop1", pd))
@@ -500,6 +514,9 @@ class MadeTrainer(MadeEngine):
             ops.layernorm_add(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], pos2, nsrc, nsp, row_skip=fskip)
         memory, mempos = tw["mem"], tw["mempos"]
         out["memory"] = memory.view(B, L, D)
+
+        if regression:
+            return self._regression_train(out, ws, tw, memory.view(B, L, D), fus_mask, v_duration, cur, side)
 
         # ---- DETR decoder (memory-space cross-attention, per-head products written out)
         mem3, mempos3 = memory.view(B, L, D), mempos.view(B, L, D)
@@ -769,6 +786,10 @@ class MadeTrainer(MadeEngine):
         inv_keep = 1.0 / (1.0 - pd) if (self.training_dropout and pd > 0) else 1.0
         fus, fus_mask = ws["fus"], ws["fus_mask"]
         fskip = fus_mask.view(-1)
+        qskip = fus_mask
+        regression = "regression" in c.mml_localization
+        if regression:
+            fskip = qskip = None
         rows = B * L
         if zero_grad:
             self.flat_grad.zero_()
@@ -783,168 +804,172 @@ class MadeTrainer(MadeEngine):
         with torch.cuda.stream(side):
             self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
 
-        # ---------------- criterion + heads
-        logits, spans = ws["logits"], ws["spans"]
-        pi, ti, cnt = self._match
-        pq = ws["pq"] if c.contrastive_align_loss else None
-        vid_sum = ws["vid_sum"] if c.contrastive_align_loss else None
-        if c.contrastive_align_loss:
-            tw["dvid_sum"].zero_()
-        tr.set_criterion_bwd(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"], c.foreground_label, P["crit_weights"], g_loc,
-                             tw["dlog"], tw["dsp"], tw["dpq"] if pq is not None else None, tw["dvid_sum"] if pq is not None else None,
-                             ld_out=8, through_sigmoid=True)
-        hs2 = ws["hs"].view(nd * B * Q, D)
-        dhs = tw["dhs"]
-        dlog, dsp = tw["dlog"], tw["dsp"]
-        if self.tc != torch.float32:                          # same dtype as the activations for the A^T B products
-            dlog, dsp = tr.add3(tw["dlog_c"], dlog), tr.add3(tw["dsp_c"], dsp)
-        tr.gemm_tn(dlog[:, :2], hs2, G["class_embed.w"], accumulate=True, colsum=G["class_embed.b"])
-        ops.linear(dlog, P["class_embed.wt"], None, out=dhs)
-        n_span = 1 if c.predict_center == 1 else 2             # predict_center: the width column is a constant, its gradient is dropped
-        tr.gemm_tn(dsp[:, :n_span], tw["h2"], G["span_embed.2.w"], accumulate=True, colsum=G["span_embed.2.b"])
-        dz2 = ops.linear(dsp, P["span_embed.2.wt"], None, out=tw["hg1"], gate=_lib.GATE_RELU_OUT, G=tw["h2"])
-        dz1 = self._lin_bwd(dz2, tw["h1"], "span_embed.1", dx_out=tw["hg2"], gate=_lib.GATE_RELU_OUT, G=tw["h1"])
-        self._lin_bwd(dz1, hs2, "span_embed.0", dx_out=dhs, R=dhs)
-        if c.contrastive_align_loss:
-            Dc = pq.shape[-1]
-            dn = tw["dpq"]
-            if c.audio_short_cut:                             # back through normalize(. + music), aux layers twice; music collects the sums
-                if c.aux_loss and nd > 1:
-                    n_aux = (nd - 1) * B * Q
-                    ds2 = tw["dpq_s2"][:n_aux]
-                    tr.l2norm_bwd(tw["pq_s2"][:n_aux], dn[:n_aux], dx=ds2)
-                    dmusic.add_(ds2.view(nd - 1, B, Q, D).sum((0, 2)))
-                    dn[:n_aux].copy_(ds2)
-                tr.l2norm_bwd(tw["pq_s1"], dn, dx=tw["dpq_s"])
-                dmusic.add_(tw["dpq_s"].view(nd, B, Q, D).sum((0, 2)))
-                dn = tw["dpq_s"]
-            tr.l2norm_bwd(ws["pq_raw"], dn, dx_alt=tw["dpq_raw"])
-            self._lin_bwd(tw["dpq_raw"], hs2, "proj_q", dx_out=dhs, R=dhs)
-            # proj_vid_mem: every frame (padded ones too) receives d vid_sum (reference loss_detr.py:118)
-            tr.l2norm_bwd(ws["pv_raw"], tw["dvid_sum"], dx_alt=tw["dpv_raw"], dy_rows_per=Tv)
-            tr.gemm_tn(tw["dpv_raw"][:Tv], frame[0], G["proj_v.w"], accumulate=True, colsum=G["proj_v.b"], batch=(B, 1),
-                       a_zs=(Tv * Dc, 0), b_zs=(frame.stride(0), 0), colsum_zs=(0, 0))
-            ops.linear(tw["dpv_raw"], P["proj_v.wt"], None, out=tw["dframe_x"])
+        if regression:
+            dmem, dtgt0 = self._regression_bwd(ws, tw, g_loc, B, L), None
+        else:
+            # ---------------- criterion + heads
+            logits, spans = ws["logits"], ws["spans"]
+            pi, ti, cnt = self._match
+            pq = ws["pq"] if c.contrastive_align_loss else None
+            vid_sum = ws["vid_sum"] if c.contrastive_align_loss else None
+            if c.contrastive_align_loss:
+                tw["dvid_sum"].zero_()
+            tr.set_criterion_bwd(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"], c.foreground_label, P["crit_weights"], g_loc,
+                                 tw["dlog"], tw["dsp"], tw["dpq"] if pq is not None else None, tw["dvid_sum"] if pq is not None else None,
+                                 ld_out=8, through_sigmoid=True)
+            hs2 = ws["hs"].view(nd * B * Q, D)
+            dhs = tw["dhs"]
+            dlog, dsp = tw["dlog"], tw["dsp"]
+            if self.tc != torch.float32:                          # same dtype as the activations for the A^T B products
+                dlog, dsp = tr.add3(tw["dlog_c"], dlog), tr.add3(tw["dsp_c"], dsp)
+            tr.gemm_tn(dlog[:, :2], hs2, G["class_embed.w"], accumulate=True, colsum=G["class_embed.b"])
+            ops.linear(dlog, P["class_embed.wt"], None, out=dhs)
+            n_span = 1 if c.predict_center == 1 else 2             # predict_center: the width column is a constant, its gradient is dropped
+            tr.gemm_tn(dsp[:, :n_span], tw["h2"], G["span_embed.2.w"], accumulate=True, colsum=G["span_embed.2.b"])
+            dz2 = ops.linear(dsp, P["span_embed.2.wt"], None, out=tw["hg1"], gate=_lib.GATE_RELU_OUT, G=tw["h2"])
+            dz1 = self._lin_bwd(dz2, tw["h1"], "span_embed.1", dx_out=tw["hg2"], gate=_lib.GATE_RELU_OUT, G=tw["h1"])
+            self._lin_bwd(dz1, hs2, "span_embed.0", dx_out=dhs, R=dhs)
+            if c.contrastive_align_loss:
+                Dc = pq.shape[-1]
+                dn = tw["dpq"]
+                if c.audio_short_cut:                             # back through normalize(. + music), aux layers twice; music collects the sums
+                    if c.aux_loss and nd > 1:
+                        n_aux = (nd - 1) * B * Q
+                        ds2 = tw["dpq_s2"][:n_aux]
+                        tr.l2norm_bwd(tw["pq_s2"][:n_aux], dn[:n_aux], dx=ds2)
+                        dmusic.add_(ds2.view(nd - 1, B, Q, D).sum((0, 2)))
+                        dn[:n_aux].copy_(ds2)
+                    tr.l2norm_bwd(tw["pq_s1"], dn, dx=tw["dpq_s"])
+                    dmusic.add_(tw["dpq_s"].view(nd, B, Q, D).sum((0, 2)))
+                    dn = tw["dpq_s"]
+                tr.l2norm_bwd(ws["pq_raw"], dn, dx_alt=tw["dpq_raw"])
+                self._lin_bwd(tw["dpq_raw"], hs2, "proj_q", dx_out=dhs, R=dhs)
+                # proj_vid_mem: every frame (padded ones too) receives d vid_sum (reference loss_detr.py:118)
+                tr.l2norm_bwd(ws["pv_raw"], tw["dvid_sum"], dx_alt=tw["dpv_raw"], dy_rows_per=Tv)
+                tr.gemm_tn(tw["dpv_raw"][:Tv], frame[0], G["proj_v.w"], accumulate=True, colsum=G["proj_v.b"], batch=(B, 1),
+                           a_zs=(Tv * Dc, 0), b_zs=(frame.stride(0), 0), colsum_zs=(0, 0))
+                ops.linear(tw["dpv_raw"], P["proj_v.wt"], None, out=tw["dframe_x"])
 
-        # ---------------- decoder, last layer first.  Inside the loop only the data-gradient chain runs; every output gradient a
-        # weight gradient needs is kept per layer (the g_* stacks) and the weight-gradient products of all layers are batched after it.
-        qp = P["query_embed"]
-        mem3, mempos3 = tw["mem"].view(B, L, D), tw["mempos"].view(B, L, D)
-        Lp = tw["PdS"].shape[-1]
-        GQ, PdS = tw["GQ"], tw["PdS"]
-        ca_scale = 1.0 / math.sqrt(hd)
-        st = tw["dstack"]
-        dtgt = None
-        for l in range(nd - 1, -1, -1):
-            p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
-            g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
-            Win, Wt = P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
-            g_ffn, g_z, g_ca, g_attc, g_q, g_qc, g_sa, gqkv = (st[k][l] for k in ("g_ffn", "g_z", "g_ca", "g_attc", "g_q", "g_qc", "g_sa", "g_qkv"))
-            # hs_l = dec.norm(t3); t3 also feeds the next layer
-            tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
-            # t3 = LN3(t2 + drop3(ffn))
-            tr.layernorm_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], g1, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"],
-                             dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
-            ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
-            dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1, R=g2)
-            # t2 = LN2(t1 + drop2(cross-attention))
-            tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"],
-                             dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
-            dattc = ops.linear(g_ca, P[p + ".ca.out.wt"], None, out=g_attc)
-            tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], G[p + ".ca.in.b"][2 * D:], tw["d_ds"], H)
-            d_ds = tw["d_ds"]                                 # rows (b, q), columns h; the softmax backward numbers its rows (b, h, q)
-            if Q > 1:
-                tw["dds_raw"].view(B, H, Q).copy_(d_ds.view(B, Q, H).permute(0, 2, 1))
-                d_ds = tw["dds_raw"]
-            # v_h = W_v,h pooled_h : dpooled_h = dattc_h W_v,h
-            dpooled = GQ[:, 0, l]                             # [B, H*Q, D] slice of the concatenated buffer
-            ops.linear(dattc[:, :hd], Wt[:, 2 * D:2 * D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
-                       segs=[Seg(out=dpooled, ldo=D, rows_per_batch=Q, out_batch_stride=dpooled.stride(0), out_z_stride=Q * D)])
-            # scores and dPd of the memory-space attention (few rows per sample: materialised)
-            qprime = GQ[:, 1, l]
-            S, dP = tw["dS_S"], tw["dS_dP"]
-            ops.linear(qprime[0], mempos3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=qprime.stride(0), w_z_stride=L * D,
-                       segs=[Seg(out=S, ldo=Lp, out_z_stride=HQ * Lp)])
-            ops.linear(dpooled[0], mem3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=dpooled.stride(0), w_z_stride=L * D,
-                       segs=[Seg(out=dP, ldo=Lp, out_z_stride=HQ * Lp)])
-            tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=d_ds.view(-1),
-                           drop=self._drop(f"dec.{l}" + ".ca_attn", pd), ldo=Lp, ldt=HQ, out_batch_stride=PdS.stride(0))
-            # dq'[b] = dS[b] (mem + pos)[b]
-            gq_out = g_q if Q == 1 else tw["gq_raw"]         # [B, (h, q), D] out of the product; [B, (q, h), D] for the Linears
-            tr.gemm_tn(tw["dSt"][0], mempos3[0], gq_out[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
-                       row_mask=fus_mask, mask_zs=(L, 0))
-            if Q > 1:
-                g_q.view(B, Q, H, D).copy_(gq_out.view(B, H, Q, D).permute(0, 2, 1, 3))
-            # q'_h = W_k,h^T qc_h : dqc_h = dq'_h W_k,h^T
-            dq2 = g_q.view(B * Q, H * D)
-            ops.linear(dq2[:, :D], Win[D:D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
-                       segs=[Seg(out=g_qc, ldo=D, out_z_stride=hd)])
-            # qc = W_q (t1 + qp) + b_q
-            dt1q = ops.linear(g_qc, Wt[:, :D], None, out=g4)
-            tr.colsum(dt1q.view(B, Q * D), G["query_embed"].view(-1))
-            tr.add3(g1, g2, dt1q)                             # dt1 = residual path + query path
-            # t1 = LN1(tgt + drop1(self-attention))
-            tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
-                             dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
-            datt = ops.linear(g_sa, P[p + ".sa.out.wt"], None, out=g4)
-            if Q == 1:                                        # value path only (see the forward): dv = datt under the same per-head mask
-                tr.gate_rows(datt, gqkv[:, 2 * D:], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
-                dtgt = ops.linear(gqkv[:, 2 * D:], P[p + ".sa.in.wt"][:, 2 * D:], None, R=g2, out=tw["dtgt"])
-            else:
-                qkv = tw[d + ".qkv"]
-                q3, g3v = qkv.view(B, Q, 3 * D), gqkv.view(B, Q, 3 * D)
-                tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), datt.view(B, Q, D),
-                                 g3v[:, :, :D], g3v[:, :, D:2 * D], g3v[:, :, 2 * D:], tw[d + ".lse"], tw["d_delta"], H,
-                                 drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
-                dtgt = ops.linear(gqkv, P[p + ".sa.in.wt"], None, R=g2, out=tw["dtgt"])
-                # the query embedding also enters through q,k of the self-attention
-                dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
-                tr.colsum(dqk.view(B, Q * D), G["query_embed"].view(-1))
-        dtgt0 = dtgt                                          # gradient of the decoder's content query = the clip-level vector
+            # ---------------- decoder, last layer first.  Inside the loop only the data-gradient chain runs; every output gradient a
+            # weight gradient needs is kept per layer (the g_* stacks) and the weight-gradient products of all layers are batched after it.
+            qp = P["query_embed"]
+            mem3, mempos3 = tw["mem"].view(B, L, D), tw["mempos"].view(B, L, D)
+            Lp = tw["PdS"].shape[-1]
+            GQ, PdS = tw["GQ"], tw["PdS"]
+            ca_scale = 1.0 / math.sqrt(hd)
+            st = tw["dstack"]
+            dtgt = None
+            for l in range(nd - 1, -1, -1):
+                p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
+                g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
+                Win, Wt = P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
+                g_ffn, g_z, g_ca, g_attc, g_q, g_qc, g_sa, gqkv = (st[k][l] for k in ("g_ffn", "g_z", "g_ca", "g_attc", "g_q", "g_qc", "g_sa", "g_qkv"))
+                # hs_l = dec.norm(t3); t3 also feeds the next layer
+                tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
+                # t3 = LN3(t2 + drop3(ffn))
+                tr.layernorm_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], g1, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"],
+                                 dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
+                ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
+                dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1, R=g2)
+                # t2 = LN2(t1 + drop2(cross-attention))
+                tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"],
+                                 dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
+                dattc = ops.linear(g_ca, P[p + ".ca.out.wt"], None, out=g_attc)
+                tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], G[p + ".ca.in.b"][2 * D:], tw["d_ds"], H)
+                d_ds = tw["d_ds"]                                 # rows (b, q), columns h; the softmax backward numbers its rows (b, h, q)
+                if Q > 1:
+                    tw["dds_raw"].view(B, H, Q).copy_(d_ds.view(B, Q, H).permute(0, 2, 1))
+                    d_ds = tw["dds_raw"]
+                # v_h = W_v,h pooled_h : dpooled_h = dattc_h W_v,h
+                dpooled = GQ[:, 0, l]                             # [B, H*Q, D] slice of the concatenated buffer
+                ops.linear(dattc[:, :hd], Wt[:, 2 * D:2 * D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
+                           segs=[Seg(out=dpooled, ldo=D, rows_per_batch=Q, out_batch_stride=dpooled.stride(0), out_z_stride=Q * D)])
+                # scores and dPd of the memory-space attention (few rows per sample: materialised)
+                qprime = GQ[:, 1, l]
+                S, dP = tw["dS_S"], tw["dS_dP"]
+                ops.linear(qprime[0], mempos3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=qprime.stride(0), w_z_stride=L * D,
+                           segs=[Seg(out=S, ldo=Lp, out_z_stride=HQ * Lp)])
+                ops.linear(dpooled[0], mem3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=dpooled.stride(0), w_z_stride=L * D,
+                           segs=[Seg(out=dP, ldo=Lp, out_z_stride=HQ * Lp)])
+                tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=d_ds.view(-1),
+                               drop=self._drop(f"dec.{l}" + ".ca_attn", pd), ldo=Lp, ldt=HQ, out_batch_stride=PdS.stride(0))
+                # dq'[b] = dS[b] (mem + pos)[b]
+                gq_out = g_q if Q == 1 else tw["gq_raw"]         # [B, (h, q), D] out of the product; [B, (q, h), D] for the Linears
+                tr.gemm_tn(tw["dSt"][0], mempos3[0], gq_out[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
+                           row_mask=fus_mask, mask_zs=(L, 0))
+                if Q > 1:
+                    g_q.view(B, Q, H, D).copy_(gq_out.view(B, H, Q, D).permute(0, 2, 1, 3))
+                # q'_h = W_k,h^T qc_h : dqc_h = dq'_h W_k,h^T
+                dq2 = g_q.view(B * Q, H * D)
+                ops.linear(dq2[:, :D], Win[D:D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
+                           segs=[Seg(out=g_qc, ldo=D, out_z_stride=hd)])
+                # qc = W_q (t1 + qp) + b_q
+                dt1q = ops.linear(g_qc, Wt[:, :D], None, out=g4)
+                tr.colsum(dt1q.view(B, Q * D), G["query_embed"].view(-1))
+                tr.add3(g1, g2, dt1q)                             # dt1 = residual path + query path
+                # t1 = LN1(tgt + drop1(self-attention))
+                tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
+                                 dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
+                datt = ops.linear(g_sa, P[p + ".sa.out.wt"], None, out=g4)
+                if Q == 1:                                        # value path only (see the forward): dv = datt under the same per-head mask
+                    tr.gate_rows(datt, gqkv[:, 2 * D:], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+                    dtgt = ops.linear(gqkv[:, 2 * D:], P[p + ".sa.in.wt"][:, 2 * D:], None, R=g2, out=tw["dtgt"])
+                else:
+                    qkv = tw[d + ".qkv"]
+                    q3, g3v = qkv.view(B, Q, 3 * D), gqkv.view(B, Q, 3 * D)
+                    tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), datt.view(B, Q, D),
+                                     g3v[:, :, :D], g3v[:, :, D:2 * D], g3v[:, :, 2 * D:], tw[d + ".lse"], tw["d_delta"], H,
+                                     drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+                    dtgt = ops.linear(gqkv, P[p + ".sa.in.wt"], None, R=g2, out=tw["dtgt"])
+                    # the query embedding also enters through q,k of the self-attention
+                    dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
+                    tr.colsum(dqk.view(B, Q * D), G["query_embed"].view(-1))
+            dtgt0 = dtgt                                          # gradient of the decoder's content query = the clip-level vector
 
-        # ---- weight gradients of all decoder layers: one layer-batched product per parameter (the layers' parameters, and
-        # the [nd, ...] stacks, are equally spaced)
-        p0, p1 = "detr_transformer.decoder.layers.0", "detr_transformer.decoder.layers.1"
-        BQ = B * Q
+            # ---- weight gradients of all decoder layers: one layer-batched product per parameter (the layers' parameters, and
+            # the [nd, ...] stacks, are equally spaced)
+            p0, p1 = "detr_transformer.decoder.layers.0", "detr_transformer.decoder.layers.1"
+            BQ = B * Q
 
-        def lstride(key):
-            return (G[p1 + key].data_ptr() - G[p0 + key].data_ptr()) // 4 if nd > 1 else 0
+            def lstride(key):
+                return (G[p1 + key].data_ptr() - G[p0 + key].data_ptr()) // 4 if nd > 1 else 0
 
-        def batched(a_stack, b_stack, wkey, bkey, a_cols=None, b_cols=None, w_rows=None):
-            A, Bm = a_stack[0], b_stack[0]
-            if a_cols is not None:
-                A = A[:, a_cols[0]:a_cols[1]]
-            if b_cols is not None:
-                Bm = Bm[:, b_cols[0]:b_cols[1]]
-            gw, gb = G[p0 + wkey], (G[p0 + bkey] if bkey is not None else None)
-            if w_rows is not None:
-                gw = gw[w_rows[0]:w_rows[1]]
-                gb = gb[w_rows[0]:w_rows[1]] if gb is not None else None
-            tr.gemm_tn(A, Bm, gw, accumulate=True, colsum=gb, batch=(nd, 1), a_zs=(a_stack.stride(0), 0), b_zs=(b_stack.stride(0), 0),
-                       c_zs=(lstride(wkey), 0), colsum_zs=(lstride(bkey) if bkey is not None else 0, 0))
+            def batched(a_stack, b_stack, wkey, bkey, a_cols=None, b_cols=None, w_rows=None):
+                A, Bm = a_stack[0], b_stack[0]
+                if a_cols is not None:
+                    A = A[:, a_cols[0]:a_cols[1]]
+                if b_cols is not None:
+                    Bm = Bm[:, b_cols[0]:b_cols[1]]
+                gw, gb = G[p0 + wkey], (G[p0 + bkey] if bkey is not None else None)
+                if w_rows is not None:
+                    gw = gw[w_rows[0]:w_rows[1]]
+                    gb = gb[w_rows[0]:w_rows[1]] if gb is not None else None
+                tr.gemm_tn(A, Bm, gw, accumulate=True, colsum=gb, batch=(nd, 1), a_zs=(a_stack.stride(0), 0), b_zs=(b_stack.stride(0), 0),
+                           c_zs=(lstride(wkey), 0), colsum_zs=(lstride(bkey) if bkey is not None else 0, 0))
 
-        batched(st["g_ffn"], st["h"], ".ff2.w", ".ff2.b")
-        batched(st["g_z"], st["t2"], ".ff1.w", ".ff1.b")
-        batched(st["g_ca"], st["attc"], ".ca.out.w", ".ca.out.b")
-        batched(st["g_qc"], st["t1q"], ".ca.in.w", ".ca.in.b", w_rows=(0, D))
-        batched(st["g_sa"], st["att"], ".sa.out.w", ".sa.out.b")
-        if Q > 1:                                             # (a single query's q / k projections get no gradient)
-            batched(st["g_qkv"], st["tq"], ".sa.in.w", ".sa.in.b", a_cols=(0, 2 * D), w_rows=(0, 2 * D))
-        batched(st["g_qkv"], st["tgt"], ".sa.in.w", ".sa.in.b", a_cols=(2 * D, 3 * D), w_rows=(2 * D, 3 * D))
-        # per-head products of the memory-space cross-attention, batched over (layer, head)
-        gWin0 = G[p0 + ".ca.in.w"]
-        ls = lstride(".ca.in.w")
-        # v_h = W_v,h pooled_h : dW_v,h += dattc_h^T pooled_h
-        tr.gemm_tn(st["g_attc"][0][:, :hd], st["pooled"][0][:, :D], gWin0[2 * D:2 * D + hd], accumulate=True, batch=(nd, H),
-                   a_zs=(st["g_attc"].stride(0), hd), b_zs=(st["pooled"].stride(0), D), c_zs=(ls, hd * D))
-        # q'_h = W_k,h^T qc_h : dW_k,h += qc_h^T dq'_h
-        gq2 = st["g_q"].view(nd, BQ, H * D)
-        tr.gemm_tn(st["qc"][0][:, :hd], gq2[0][:, :D], gWin0[D:D + hd], accumulate=True, batch=(nd, H),
-                   a_zs=(st["qc"].stride(0), hd), b_zs=(gq2.stride(0), D), c_zs=(ls, hd * D))
-        # gradient of the memory: values path (Pd^T dpooled) + keys path (dS^T q'), all layers in one product per sample
-        dmem = tw["eg1"]
-        tr.gemm_tn(PdS.view(B, 2 * nd * HQ, Lp)[0, :, :L], GQ.view(B, 2 * nd * HQ, D)[0], dmem.view(B, L, D)[0], batch=(B, 1),
-                   a_zs=(PdS.stride(0), 0), b_zs=(GQ.stride(0), 0), c_zs=(L * D, 0))
+            batched(st["g_ffn"], st["h"], ".ff2.w", ".ff2.b")
+            batched(st["g_z"], st["t2"], ".ff1.w", ".ff1.b")
+            batched(st["g_ca"], st["attc"], ".ca.out.w", ".ca.out.b")
+            batched(st["g_qc"], st["t1q"], ".ca.in.w", ".ca.in.b", w_rows=(0, D))
+            batched(st["g_sa"], st["att"], ".sa.out.w", ".sa.out.b")
+            if Q > 1:                                             # (a single query's q / k projections get no gradient)
+                batched(st["g_qkv"], st["tq"], ".sa.in.w", ".sa.in.b", a_cols=(0, 2 * D), w_rows=(0, 2 * D))
+            batched(st["g_qkv"], st["tgt"], ".sa.in.w", ".sa.in.b", a_cols=(2 * D, 3 * D), w_rows=(2 * D, 3 * D))
+            # per-head products of the memory-space cross-attention, batched over (layer, head)
+            gWin0 = G[p0 + ".ca.in.w"]
+            ls = lstride(".ca.in.w")
+            # v_h = W_v,h pooled_h : dW_v,h += dattc_h^T pooled_h
+            tr.gemm_tn(st["g_attc"][0][:, :hd], st["pooled"][0][:, :D], gWin0[2 * D:2 * D + hd], accumulate=True, batch=(nd, H),
+                       a_zs=(st["g_attc"].stride(0), hd), b_zs=(st["pooled"].stride(0), D), c_zs=(ls, hd * D))
+            # q'_h = W_k,h^T qc_h : dW_k,h += qc_h^T dq'_h
+            gq2 = st["g_q"].view(nd, BQ, H * D)
+            tr.gemm_tn(st["qc"][0][:, :hd], gq2[0][:, :D], gWin0[D:D + hd], accumulate=True, batch=(nd, H),
+                       a_zs=(st["qc"].stride(0), hd), b_zs=(gq2.stride(0), D), c_zs=(ls, hd * D))
+            # gradient of the memory: values path (Pd^T dpooled) + keys path (dS^T q'), all layers in one product per sample
+            dmem = tw["eg1"]
+            tr.gemm_tn(PdS.view(B, 2 * nd * HQ, Lp)[0, :, :L], GQ.view(B, 2 * nd * HQ, D)[0], dmem.view(B, L, D)[0], batch=(B, 1),
+                       a_zs=(PdS.stride(0), 0), b_zs=(GQ.stride(0), 0), c_zs=(L * D, 0))
+
 
         # ---------------- DETR encoder
         dsrc = dmem
@@ -968,7 +993,7 @@ class MadeTrainer(MadeEngine):
             q3, gq3 = qkv.view(B, L, 3 * D), gq.view(B, L, 3 * D)
             tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[e + ".att"].view(B, L, D), datt.view(B, L, D),
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[e + ".lse"], tw["e_delta"], H,
-                             key_mask=fus_mask, q_skip_mask=fus_mask, drop=self._drop(f"enc.{l}" + ".attn", pd),
+                             key_mask=fus_mask, q_skip_mask=qskip, drop=self._drop(f"enc.{l}" + ".attn", pd),
                              order=self._order[fus_mask.data_ptr()])
             gW, gb = G[p + ".in.w"], G[p + ".in.b"]
             tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], rows=self._rw(fskip))
@@ -984,7 +1009,7 @@ class MadeTrainer(MadeEngine):
 
         # ---------------- join the X-Pool / similarity branch, merge the gradients of the clip-level vectors
         cur.wait_stream(side)
-        if c.moment_query_type in ("video", "music"):       # (a zero content query has no gradient to hand on)
+        if c.moment_query_type in ("video", "music") and not regression:       # (a zero content query has no gradient to hand on)
             dq_vec = dvideo if c.moment_query_type == "video" else dmusic
             tr.add3(dq_vec, dq_vec, dtgt0.view(B, D) if Q == 1 else dtgt0.view(B, Q, D).float().sum(dim=1))    # the vector was repeated Q times
 
@@ -993,9 +1018,52 @@ class MadeTrainer(MadeEngine):
         # ---------------- temporal encoders (video on the second stream)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._encode_bwd("video", ws, tw, dl_v, tw["dframe_x"].view(B, Tv, D) if c.contrastive_align_loss else None, dvideo, fm, feats_v)
+            self._encode_bwd("video", ws, tw, dl_v, tw["dframe_x"].view(B, Tv, D) if (c.contrastive_align_loss and not regression) else None, dvideo, fm, feats_v)
         self._encode_bwd("audio", ws, tw, dl_a, tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a)
         cur.wait_stream(side)
+
+    def _regression_train(self, out, ws, tw, mem3: Tensor, fus_mask: Tensor, v_duration, cur, side) -> Dict[str, Tensor]:
+        """reference model/model_Uni.py:228-232,290-300 in train mode: memory summed over all L positions / number of valid ones ->
+        3-layer ReLU MLP -> sigmoid; loss = 20 * L1 (mean over every element of the [B, 1, 2] spans).  No decoder on this path."""
+        c, P = self.cfg, self.P
+        B = mem3.shape[0]
+        cnt = fus_mask.sum(dim=1, keepdim=True)
+        fx = (ops.masked_mean(mem3, None) / cnt).to(self.tc)
+        h1 = ops.linear(fx, P["reg_mlp.0.w"], P["reg_mlp.0.b"], act=ops.ACT_RELU)
+        h2 = ops.linear(h1, P["reg_mlp.1.w"], P["reg_mlp.1.b"], act=ops.ACT_RELU)
+        spans = torch.empty(B, 2, device=self.device, dtype=torch.float32)
+        if c.predict_center == 1:
+            ops.linear(h2, P["reg_mlp.2.w"], P["reg_mlp.2.b"], act=ops.ACT_SIGMOID, segs=[Seg(out=spans, ldo=2)])
+            spans[:, 1] = v_duration.to(self.device, torch.float32) / c.max_m_duration
+        else:
+            ops.linear(h2, P["reg_mlp.2.w"], P["reg_mlp.2.b"], act=ops.ACT_SIGMOID, out=spans)
+        tg = self._inputs[4].to(torch.float32)
+        assert tg.shape == (B, 1, 2), f"spans_target.shape {tuple(tg.shape)} must equal to src_spans.shape {(B, 1, 2)}"
+        l1 = (spans.view(B, 1, 2) - tg).abs().mean()
+        self._reg = (fx, h1, h2, spans, cnt, tg)
+        out.update(pred_spans=spans.view(B, 1, 2), regression_loss_span=l1, localization_loss=(l1 * 20).view(1))
+        cur.wait_stream(side)
+        return out
+
+    def _regression_bwd(self, ws, tw, g_loc: Optional[Tensor], B: int, L: int) -> Tensor:
+        """Gradient of g_loc * 20 * mean|spans - target| back through the regression MLP to the encoder memory: every one of the L
+        positions of a sample receives d fusion / (number of valid positions).  Returns the memory gradient buffer."""
+        c, P, G, D = self.cfg, self.P, self.G, self.cfg.D
+        fx, h1, h2, spans, cnt, tg = self._reg
+        n = 1 if c.predict_center == 1 else 2                  # predict_center: the width column is a constant of the batch
+        scale = 20.0 / (B * 2)
+        g = torch.sign(spans - tg.view(B, 2)) * scale
+        if g_loc is not None:
+            g = g * g_loc.to(torch.float32).view(())
+        dz = torch.zeros(B, 8, device=self.device, dtype=self.tc)  # through the sigmoid; reduction dim padded like reg_mlp.2.wt
+        dz[:, :n] = (g * spans * (1.0 - spans))[:, :n].to(self.tc)
+        tr.gemm_tn(dz[:, :n], h2, G["reg_mlp.2.w"], accumulate=True, colsum=G["reg_mlp.2.b"])
+        dh2 = ops.linear(dz, P["reg_mlp.2.wt"], None, out=torch.empty_like(h2), gate=_lib.GATE_RELU_OUT, G=h2)
+        dh1 = self._lin_bwd(dh2, h1, "reg_mlp.1", dx_out=torch.empty_like(h1), gate=_lib.GATE_RELU_OUT, G=h1)
+        dfx = self._lin_bwd(dh1, fx, "reg_mlp.0", dx_out=torch.empty(B, D, device=self.device, dtype=self.tc))
+        dmem = tw["eg1"]
+        dmem.view(B, L, D).copy_((dfx.float() / cnt)[:, None, :].expand(B, L, D))
+        return dmem
 
     def _retrieval_bwd(self, ws, tw, g_ret: Optional[Tensor], B: int, S: int, sm: Tensor) -> None:
         c, P, G, D = self.cfg, self.P, self.G, self.cfg.D
@@ -1108,4 +1176,4 @@ class MadeTrainer(MadeEngine):
         self.backward(gr, gl)
         torch.cuda.synchronize()
         return dict(retrieval_loss=float(o["retrieval_loss"].cpu()), localization_loss=float(o["localization_loss"].cpu()),
-                    grads=self.grads_numpy(), loss_dict={k: float(v.cpu()) for k, v in self.loss_dict(o).items()})
+                    grads=self.grads_numpy(), loss_dict={k: float(v.cpu()) if torch.is_tensor(v) else float(v) for k, v in self.loss_dict(o).items()})

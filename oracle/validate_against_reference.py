@@ -232,6 +232,8 @@ def main():
     report["grad_train_native_shortcut_Q3_moment_B4"] = compare_backward(c, 4, 20, 40, "native audio short-cut / Q=3 / moment_loss train-mode grads", train=True)
     c = cfg_native(); c.predict_center = 1
     report["grad_train_native_predict_center_B3"] = compare_backward(c, 3, 20, 40, "native predict_center train-mode grads", train=True)
+    c = cfg_native(); c.mml_localization = "regression"; c.predict_center = 1; c.mml_fusion = "CA"
+    report["grad_train_native_regression_center_CA_B3"] = compare_backward(c, 3, 20, 40, "native regression / predict_center / CA train-mode grads", train=True)
     report["lsap_vs_scipy"] = compare_lsap()
     report["retrieval_N48x40_S96"] = compare_retrieval(cfg_native(), 48, 40, 96)
     worst = max(v for k, sec in report.items() if isinstance(sec, dict) and not k.startswith("grad_")

@@ -139,3 +139,41 @@ def test_dropin_option_variants(golden_dir, name):
         assert set(om) == {"pred_spans"} and left == {"decoder_query_embed", "detr_transformer"}
     else:
         assert left == {"decoder_query_embed"}
+
+
+@pytest.mark.parametrize("overrides", [{"mml_localization": "regression"}, {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
+                                       {"audio_short_cut": 1, "predict_center": 1, "moment_loss": 1}])
+def test_training_loop_body_on_option_variants(overrides):
+    """The reference's loop body on the drop-in module for variants the scripts do not use: the regression localisation head (its
+    own optimizer group: reg_mlp + the CA block), predict_center, the audio short-cut (the CLI's default), moment_loss."""
+    import numpy as np
+    import torch
+    from mgsv_amd import synth
+    from mgsv_amd.config import cfg_native
+    from mgsv_amd.model import Uni_model
+    cfg = cfg_native()
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    args = cfg.to_args(local_rank=0)
+    args.compute_dtype = "bf16"
+    model = Uni_model(args, device=torch.device("cuda:0"))
+    inp = synth.make_inputs(cfg, 8, 20, 40, seed=3)
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    opt = torch.optim.Adam([{"params": model.get_temporal_parameter(), "lr": 3e-4},
+                            {"params": model.get_matching_parameter(), "lr": 3e-4},
+                            {"params": model.get_detection_parameter(), "lr": 3e-4}])
+    model.train()
+    losses = []
+    for it in range(8):
+        om, lm, fm, mm, im = model(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
+                                   v_duration=t["v_duration"], video_ids=inp["video_ids"], music_ids=inp["music_ids"], is_train=True)
+        loss = lm["retrieval_loss"] + lm["localization_loss"]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.get_temporal_parameter(), 1.0)
+        torch.nn.utils.clip_grad_norm_(model.get_matching_parameter(), 1.0)
+        torch.nn.utils.clip_grad_norm_(model.get_detection_parameter(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+        assert om["pred_spans"].shape == (8, 1, 2) and "loss_span" in lm["localization_loss_dict"]
+    assert np.isfinite(losses).all() and np.mean(losses[-2:]) < np.mean(losses[:2]), losses

@@ -72,7 +72,9 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
                                        {"video_transformer_depth": 2, "audio_transformer_depth": 2, "with_act_after_proj": 1},
                                        {"mml_fusion": "CA", "detr_enc_layers": 0, "vmr_loss": "single"},
                                        {"predict_center": 1}, {"moment_loss": 1}, {"audio_short_cut": 1},
-                                       {"audio_short_cut": 1, "num_moment_queries": 3, "moment_loss": 1}])
+                                       {"audio_short_cut": 1, "num_moment_queries": 3, "moment_loss": 1},
+                                       {"mml_localization": "regression"},
+                                       {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"}])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     overrides = dict(overrides)
