@@ -238,6 +238,25 @@ def _to_device(data_map, meta_map, spans_target, device):
             data_map["segment_mask"].to(device, f32), spans_target.to(device, f32), meta_map["v_duration"].to(device, f32))
 
 
+def _batch_iou(args, model, output_map, meta_map, device):
+    """IoU of every sample's top prediction with its ground-truth moment, on the device.  DETR head: reference test-MaDe.py:304-313
+    (made_span_iou); regression head: test-MaDe.py:331-340 + music_detr/span_utils.py:119-139,147-170 -- the one regressed span,
+    centre / width -> start / end in seconds, start clamped at 0, end at min(max_m_duration, the track's duration)."""
+    from .utils.util_test import detr_iou_device
+    if "regression" in args.mml_localization:
+        sp = output_map["pred_spans"][:, 0].float()
+        gt = meta_map["gt_moment"].to(device, torch.float32).reshape(sp.shape[0], -1)[:, :2]
+        dur = meta_map["m_duration"].to(device, torch.float32)
+        st = ((sp[:, 0] - 0.5 * sp[:, 1]) * float(args.max_m_duration)).clamp(min=0)
+        ed = torch.minimum(((sp[:, 0] + 0.5 * sp[:, 1]) * float(args.max_m_duration)).clamp(max=float(args.max_m_duration)), dur)
+        inter = (torch.minimum(gt[:, 1], ed) - torch.maximum(gt[:, 0], st)).clamp(min=0)
+        union = (ed - st) + (gt[:, 1] - gt[:, 0]) - inter
+        return torch.where((gt[:, 0] < gt[:, 1]) & (union > 0), inter / union.clamp(min=1e-30), torch.zeros_like(inter))
+    iou, _ = detr_iou_device(output_map["pred_logits"], output_map["pred_spans"], meta_map["gt_moment"].to(device), meta_map["m_duration"].to(device),
+                             model.criterion.foreground_label, float(args.max_m_duration))
+    return iou
+
+
 def train_one_epoch(epoch, args, model, loader, optimizer, device, dist, logger, total_step, warmup_steps):
     """reference train-MaDe.py:300-425."""
     from .utils.util_test import IoU_metrics, detr_iou_device
@@ -254,9 +273,9 @@ def train_one_epoch(epoch, args, model, loader, optimizer, device, dist, logger,
             wl = torch.tensor([args.loc_loss_weight], device=device)
             model._train_seed += 1
             o = trn.train_step(ff, sf, fm, sm, tg, seed=model._train_seed, lrs=(args.matching_lr * fac, args.matching_lr * fac, args.detection_lr * fac),
-                               max_grad_norm=args.max_grad_norm, w_ret=wr, w_loc=wl, dist=dist if args.world_size > 1 else None)
+                               max_grad_norm=args.max_grad_norm, w_ret=wr, w_loc=wl, dist=dist if args.world_size > 1 else None, v_duration=vdur)
             ret, loc = o["retrieval_loss"][0] * args.ret_loss_weight, o["localization_loss"][0] * args.loc_loss_weight
-            logits, spans = o["pred_logits"], o["pred_spans"]
+            om = o
         else:
             for g, base in zip(optimizer.param_groups, (args.matching_lr, args.matching_lr, args.detection_lr)):
                 g["lr"] = base * fac
@@ -271,9 +290,7 @@ def train_one_epoch(epoch, args, model, loader, optimizer, device, dist, logger,
             torch.nn.utils.clip_grad_norm_(model.get_matching_parameter(), args.max_grad_norm)
             torch.nn.utils.clip_grad_norm_(model.get_detection_parameter(), args.max_grad_norm)
             optimizer.step(); optimizer.zero_grad()
-            logits, spans = om["pred_logits"], om["pred_spans"]
-        iou, _ = detr_iou_device(logits, spans, meta_map["gt_moment"].to(device), meta_map["m_duration"].to(device),
-                                 model.criterion.foreground_label, float(args.max_m_duration))
+        iou = _batch_iou(args, model, om, meta_map, device)
         ious.extend(iou.cpu().tolist())
         args.total_step += 1
         b = ff.shape[0]
@@ -312,8 +329,7 @@ def eval_epoch(epoch, args, model, loader, device, dist, logger):
             n += ff.shape[0]
             V.append(feat["video_feats"].clone()); M.append(feat["music_feats"].clone()); S.append(feat["segment_feats"].clone()); SM.append(sm)
             vids.extend(meta_map["video_id"]); mids.extend(meta_map["music_id"])
-            iou, _ = detr_iou_device(om["pred_logits"], om["pred_spans"], meta_map["gt_moment"].to(device), meta_map["m_duration"].to(device),
-                                     model.criterion.foreground_label, float(args.max_m_duration))
+            iou = _batch_iou(args, model, om, meta_map, device)
             IOU.append(iou)
     if device.type == "cuda":
         torch.cuda.synchronize(device)

@@ -49,3 +49,7 @@ def test_train_and_test_entry_points(tmp_path):
     res3 = driver.main_train(["--name", "t3", "--do_train", "--do_eval", "--epochs", "1", "--batch_size_train", "16", "--train_csv", tr, "--val_csv", va,
                               "--output_dir", str(tmp_path / "logs")] + sc)
     assert np.isfinite(res3[1]["train_loss"])
+    # the regression localisation variant: train + evaluate (IoU from the single regressed span)
+    res4 = driver.main_train(["--name", "t4", "--do_train", "--do_eval", "--epochs", "1", "--batch_size_train", "16", "--train_csv", tr, "--val_csv", va,
+                              "--output_dir", str(tmp_path / "logs"), "--mml_localization", "regression"] + COMMON)
+    assert np.isfinite(res4[1]["train_loss"]) and 0 <= res4[1]["mIoU"] <= 1
