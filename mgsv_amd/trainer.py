@@ -57,8 +57,8 @@ class MadeTrainer(MadeEngine):
             bad.append(f"vmr_fusion={c.vmr_fusion}")
         if c.vmr_loss == "dual_single_feature_fuse":
             bad.append("vmr_loss=dual_single_feature_fuse")
-        if c.agg_module != "transf" or c.with_cls_token or c.transformer_is_share:
-            bad.append("agg_module=mlp / with_cls_token / transformer_is_share")
+        if c.agg_module != "transf" or c.with_cls_token:
+            bad.append("agg_module=mlp / with_cls_token")
         if "detr" not in c.mml_localization and "regression" not in c.mml_localization:
             bad.append(f"mml_localization={c.mml_localization}")
         if c.audio_short_cut and c.contrastive_align_loss and c.contrastive_hdim != c.D:
@@ -80,14 +80,19 @@ class MadeTrainer(MadeEngine):
             vecs.append((key + ".g", name + ".weight")); vecs.append((key + ".b", name + ".bias"))
 
         lin("vit_proj", "vit_proj"); lin("ast_proj", "ast_proj")
+        # one block for both towers when transformer_is_share (reference model/model_Base.py:300-302,322-331): both towers' keys view the
+        # same masters and the same gradient ranges; every gradient kernel accumulates atomically, so the two towers' backward passes
+        # (on two streams) simply add up there
+        share = bool(c.transformer_is_share) and c.video_transformer_depth == c.audio_transformer_depth and c.video_transformer_depth > 0
         for mod, depth in (("video_transformer", c.video_transformer_depth), ("audio_transformer", c.audio_transformer_depth)):
+            src = "share_transformer" if share else mod
             for l in range(depth):
-                p = f"{mod}.layers.{l}"
-                ln(p + ".ln1", p + ".0")
-                mats.append((p + ".in.w", p + ".1.in_proj_weight")); vecs.append((p + ".in.b", p + ".1.in_proj_bias"))
-                lin(p + ".out", p + ".1.out_proj"); ln(p + ".ln2", p + ".2")
-                lin(p + ".ff1", p + ".3.0"); lin(p + ".ff2", p + ".3.3")
-            lin(mod + ".final", mod + ".final_linear")
+                p, q = f"{mod}.layers.{l}", f"{src}.layers.{l}"
+                ln(p + ".ln1", q + ".0")
+                mats.append((p + ".in.w", q + ".1.in_proj_weight")); vecs.append((p + ".in.b", q + ".1.in_proj_bias"))
+                lin(p + ".out", q + ".1.out_proj"); ln(p + ".ln2", q + ".2")
+                lin(p + ".ff1", q + ".3.0"); lin(p + ".ff2", q + ".3.3")
+            lin(mod + ".final", src + ".final_linear")
         ln("xa.ln1", XA + ".layer_norm1"); ln("xa.ln2", XA + ".layer_norm2"); ln("xa.ln3", XA + ".layer_norm3")
         lin("xa.q", XA + ".cross_attn.q_proj")
         mats.append(("xa.kv.w", (XA + ".cross_attn.k_proj.weight", XA + ".cross_attn.v_proj.weight")))
@@ -138,7 +143,7 @@ class MadeTrainer(MadeEngine):
                       XA + ".cross_attn.k_proj.bias": XA + ".cross_attn.v_proj.bias"}
         # optimizer groups of the reference (model/model_Uni.py:73-114, train-MaDe.py:262-266) laid out as contiguous ranges
         def group_of(k: str) -> int:
-            if k.startswith(("vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.")):
+            if k.startswith(("vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.", "share_transformer.")):
                 return 0                                      # temporal
             if k.startswith(XA + ".") or k == "logit_scale":
                 return 1                                      # matching

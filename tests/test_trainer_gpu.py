@@ -74,7 +74,8 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
                                        {"predict_center": 1}, {"moment_loss": 1}, {"audio_short_cut": 1},
                                        {"audio_short_cut": 1, "num_moment_queries": 3, "moment_loss": 1},
                                        {"mml_localization": "regression"},
-                                       {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"}])
+                                       {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
+                                       {"transformer_is_share": 1, "_shape": (4, 18, 36)}])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     overrides = dict(overrides)
