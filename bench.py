@@ -419,7 +419,7 @@ def main():
             "config": {"workload": f"BASELINE.json configs[1]: B={B}, T_v={Tv}, T_a={Ta}, D={cfg.D}, enc={cfg.detr_enc_layers}, "
                                    f"dec={cfg.detr_dec_layers}, Q={cfg.num_moment_queries}, concat fusion, fwd-only",
                        "global_batch": world * B, "launch": launch, "batches_in_flight": n_lanes,
-                       "single_batch_ms": round(lat_ms, 4),
+                       "single_batch_ms": round(lat_ms, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
                        "parallelism": f"dp{world} (independent batches, no collective)",
                        "accumulate": "f32", "activations": args.dtype},
             "roofline": roof, "cpu_baseline": cpu, "kernels": per_kernel,
