@@ -459,7 +459,8 @@ class MadeEngine:
             ops.attention_wide(q.view(1, Nv, 1, D), kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D),
                                o[:n * Nv].view(n, Nv, 1, D), scale=scale,
                                key_mask=seg_mask[m0:m0 + n] if seg_mask is not None else None, shared_q=True,
-                               n_split=(max(1, min(4, 256 // max(n * ((Nv + 63) // 64), 1))) if S >= 256 else 1))   # in-batch, long tracks: fill the chip
+                               n_split=1)       # (splitting the keys over workgroups + a merge launch is no faster here and costs the other stream CUs:
+                               # 1.2 % of the eval throughput with two batches in flight)
             rows = n * Nv
             if hoist:
                 a2 = o[:rows]
