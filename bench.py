@@ -5,12 +5,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one eval-mode `Uni_model.forward` (reference model/model_Uni.py:177-322: both temporal
-encoders, X-Pool similarities, DETR encoder/decoder, heads, retrieval loss, Hungarian matcher and set
-criterion) over one batch of B=64 synthetic video-music pairs at BASELINE.json configs[1]
-(T_v=30, T_a=512, D=512), inputs resident in HBM.  N>1: every rank runs its own batch (pairs are
-independent; no data-path collective), value = all pairs / max-over-ranks time ("weak").
-Prints ONE JSON line on rank 0.
+BASELINE.json's metric has two halves, so the ONE JSON line rank 0 prints carries both:
+
+  * `value` = video-music pairs/s of the FULL TRAINING STEP (fwd + bwd + matcher + clip/Adam, reference
+    train-MaDe.py:337-381) at B=64 per GPU, BASELINE configs[2] (T_v=30, T_a=512, D=512, bf16 compute, f32 masters);
+    a "step" is one iteration over one batch of synthetic features resident in HBM.  `roofline` describes the kernel
+    that takes the most time in that step (HIP events on the launch stream), `cpu_baseline` the oracle's forward +
+    backward on the host cores.  N > 1: data parallel, one RCCL all-reduce of the flat gradient buffer per step ("weak").
+  * `retrieval` = the all-pairs video x music similarity of reference test-MaDe.py:386-403 at BASELINE configs[3]
+    (53 000 x 4 000, S=96, D=256) in GB/s of algorithmic bytes, videos row-sharded over the ranks, music side
+    all-gathered (RCCL), with its own roofline (executed flops of the valid segments) and CPU baseline.
+  * `eval_fwd` = the eval-mode forward (BASELINE configs[1]) with one and two batches in flight in bf16, and in the f32
+    parity mode (the mode whose outputs meet north_star's <= 1e-4 gate).
+
+`--workload train|forward|retrieval` runs one leg alone (tools/, profiling); the default `all` runs the three.
 """
 from __future__ import annotations
 
@@ -32,6 +40,7 @@ from mgsv_amd.engine import MadeEngine  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh)
 
 
 def parse():
@@ -42,21 +51,74 @@ def parse():
     p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--launch", choices=["graph", "eager"], default="graph")
-    p.add_argument("--workload", choices=["forward", "retrieval", "train"], default="forward")
+    p.add_argument("--workload", choices=["all", "forward", "retrieval", "train"], default="all")
     p.add_argument("--nv", type=int, default=53000)
     p.add_argument("--nm", type=int, default=4000)
     p.add_argument("--seg", type=int, default=96)
     p.add_argument("--ta", type=int, default=0, help="train workload: number of music segments (default: configs[1]'s 512)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--cpu-steps", type=int, default=1)
     p.add_argument("--in-flight", type=int, default=2,
                    help="forward workload: independent batches in flight (one engine, workspace, stream and graph each); steps "
                         "are issued round-robin over them")
     return p.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------- helpers
+def _roofline(summ: dict, kind: str, dtype: str, per: int) -> dict:
+    """Roofline entry of one timed kernel kind: achieved = algorithmic (executed: valid rows / valid keys only) flops / summed
+    launch time; the binding roof is the slower of the MFMA and the HBM floor for the kernel's algorithmic flops and bytes."""
+    d = summ[kind]
+    sec = d["ms"] * 1e-3
+    peak = PEAK_TFLOPS[dtype]
+    t_mfma = d["flops"] / (peak * 1e12)
+    t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
+    traffic = None
+    if os.path.isfile(PMC_FILE):
+        try:
+            traffic = json.load(open(PMC_FILE)).get(kind, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    common = dict(kernel=kind, launches_per_step=d["launches"] // per, avg_launch_us=round(d["ms"] / d["launches"] * 1e3, 2),
+                  algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
+                  algorithmic_mb_per_launch=round(d["bytes"] / d["launches"] / 1e6, 3), traffic=traffic,
+                  mfma_tflops=round(d["flops"] / sec / 1e12, 2), hbm_gbs=round(d["bytes"] / sec / 1e9, 1),
+                  executed_fraction_of_nominal=round(d["flops"] / max(d["flops_nominal"], 1.0), 3))
+    if t_hbm > t_mfma:
+        a = d["bytes"] / sec / 1e9
+        return dict(bound="hbm", achieved=round(a, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4), **common)
+    a = d["flops"] / sec / 1e12
+    return dict(bound="mfma", achieved=round(a, 2), peak=peak, unit="TFLOP/s", frac=round(a / peak, 4), **common)
+
+
+def _per_kernel(summ: dict, per: int) -> dict:
+    return {k: dict(launches_per_step=v["launches"] // per, ms_per_step=round(v["ms"] / per, 4),
+                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
+            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def _dominant(summ: dict) -> str:
+    """The kernel kind with the largest summed launch time (what rocprofv3 --stats ranks first among the timed kinds)."""
+    return max(summ, key=lambda k: summ[k]["ms"])
+
+
+def _max_over_ranks(elapsed: float, dist, dev) -> float:
+    if dist is None:
+        return elapsed
+    te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    return float(te.item())
+
+
+def _barrier(dist):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------- CPU baselines (oracle)
 def cpu_baseline(cfg, sd, inp, steps: int):
-    """The oracle (CPU restatement validated against the reference) on this box's host cores."""
+    """The oracle (CPU restatement validated against the reference) on this box's host cores: eval forward."""
     from oracle import made_oracle as O
     P = O.to_torch_params(sd)
     n = torch.get_num_threads()
@@ -72,8 +134,8 @@ def cpu_baseline(cfg, sd, inp, steps: int):
         one()
     dt = (time.perf_counter() - t0) / steps
     B = inp["frame_feats"].shape[0]
-    return dict(value=B / dt, unit="pairs/s", cores=n, kind="port",
-                sample=f"{steps} eval forwards of the same B={B} batch (oracle/made_oracle.py, torch CPU f32, {n} threads), {dt:.2f} s each")
+    return dict(value=round(B / dt, 3), unit="pairs/s", cores=n, kind="port",
+                sample=f"{steps} eval forward(s) of the same B={B} batch (oracle/made_oracle.py, torch CPU f32, {n} threads), {dt:.2f} s each")
 
 
 def cpu_baseline_retrieval(cfg, sd, S: int, n_v: int = 2048, n_m: int = 256):
@@ -118,7 +180,8 @@ def cpu_baseline_train(cfg, sd, inp, B: int = 16):
                        f"no optimizer step), {dt:.2f} s")
 
 
-def retrieval_main(args, rank, world, local, dist):
+# ------------------------------------------------------------------------------------------------- legs
+def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
     """BASELINE.json configs[3]: all-pairs video x music similarity, videos row-sharded over the ranks, music side
     all-gathered once per pass (RCCL).  A step = one full pass (exchange + scoring).  Strong scaling: the problem is fixed."""
     from mgsv_amd.config import cfg_native
@@ -141,54 +204,41 @@ def retrieval_main(args, rank, world, local, dist):
     def step():
         return sr.sim_rows(v, seg, mask, mu)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         rows = step()
-    barrier()
+    _barrier(dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         rows = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    _barrier(dist)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert rows.shape == (vhi - vlo, N_m) and bool(torch.isfinite(rows).all())
     alg_bytes = 4.0 * (N_m * S * D + N_m * S + N_v * D + N_m * D + N_v * N_m)      # inputs once + sim matrix once
     pairs = float(N_v) * N_m
-    roof = None
+    roof, per_kernel = None, {}
     if rank == 0:
-        # dominant kernel, timed live with HIP events on its launch stream: the per-pair chain (made_xpool_fused when the engine
-        # takes that path: bf16, D = 256); algorithmic flops per pair = 4 S D (scores + pooling) + 2 D^2 (Linear), SURVEY 8(d)
+        # dominant kernel, timed live with HIP events on its launch stream; executed flops: 4 * valid segments * D (scores +
+        # pooling) + 2 D^2 (Linear) per pair, the padded segments of a track are skipped by the kernel and not counted here
         with ops.KernelTimer() as kt:
             step()
         summ = kt.summary()
-        k = "xpool_fused" if "xpool_fused" in summ else max(summ, key=lambda n: summ[n]["ms"])
-        ms_k = summ[k]["ms"]
-        fl = pairs / world * (4.0 * S * D + 2.0 * D * D) if k == "xpool_fused" else summ[k]["flops"]
-        peak = PEAK_TFLOPS[args.dtype]
-        roof = dict(bound="mfma", kernel=k, achieved=round(fl / (ms_k * 1e-3) / 1e12, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(fl / (ms_k * 1e-3) / 1e12 / peak, 4), traffic=None, launches_per_step=summ[k]["launches"],
-                    avg_launch_us=round(ms_k * 1e3 / max(summ[k]["launches"], 1), 1),
-                    algorithmic_gflop_per_launch=round(fl / max(summ[k]["launches"], 1) / 1e9, 1))
-    if rank == 0:
-        sec = elapsed / args.steps
-        print(json.dumps({
-            "metric": "retrieval sim-matrix GB/s (all-pairs video x music, X-Pool + dual tower)", "value": round(alg_bytes / sec / 1e9, 3),
-            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[3]: N_v={N_v}, N_m={N_m}, S={S}, D={D}; videos row-sharded, music all-gathered",
-                       "pairs_per_s": round(pairs / sec, 1), "algorithmic_gb": round(alg_bytes / 1e9, 3)},
-            "roofline": roof,
-            "cpu_baseline": (cpu_baseline_retrieval(cfg, synth.make_state_dict(cfg, seed=0), S) if (world == 1 and not args.no_cpu_baseline) else None)}))
+        roof = _roofline(summ, _dominant(summ), args.dtype, 1)
+        per_kernel = _per_kernel(summ, 1)
+    sec = elapsed / steps
+    out = {"metric": "retrieval sim-matrix GB/s (all-pairs video x music, X-Pool + dual tower)", "value": round(alg_bytes / sec / 1e9, 3),
+           "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(sec * 1e3, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"BASELINE.json configs[3]: N_v={N_v}, N_m={N_m}, S={S}, D={D}, segment lengths U{{12..{S}}}; videos row-sharded, music all-gathered",
+                      "pairs_per_s": round(pairs / sec, 1), "algorithmic_gb": round(alg_bytes / 1e9, 3),
+                      "sim_matrix_only_gbs": round(4.0 * N_v * N_m / sec / 1e9, 3)},
+           "roofline": roof, "kernels": per_kernel,
+           "cpu_baseline": (cpu_baseline_retrieval(cfg, synth.make_state_dict(cfg, seed=0), S) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None)}
+    del eng, sr, rows, v, seg, mu
+    torch.cuda.empty_cache()
+    return out
 
 
-def train_main(args, rank, world, local, dist):
+def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
     """BASELINE.json configs[2] (N = 1) / configs[4] (N > 1, per-rank B = 64): one full training iteration per step --
     train-mode forward (dropout on), matcher + criterion, hand-written backward, data-parallel gradient all-reduce (RCCL, one
     flat f32 buffer), three-group clipping + Adam, re-derivation of the bf16 weights (reference train-MaDe.py:337-381)."""
@@ -210,23 +260,14 @@ def train_main(args, rank, world, local, dist):
         return trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
                               seed=it[0], lrs=(1e-4, 1e-4, 1e-4), max_grad_norm=1.0, dist=dist)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         out = step()
-    barrier()
+    _barrier(dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    _barrier(dist)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert bool(torch.isfinite(out["localization_loss"]).all()) and bool(torch.isfinite(out["retrieval_loss"]).all())
     assert bool(torch.isfinite(trn.flat_param).all())
     per_kernel, roof = {}, None
@@ -235,74 +276,49 @@ def train_main(args, rank, world, local, dist):
             for _ in range(2):
                 step()
         summ = kt.summary()
-        for k, v in summ.items():
-            per_kernel[k] = dict(launches_per_step=v["launches"] // 2, ms_per_step=round(v["ms"] / 2, 4),
-                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))
+        per_kernel = _per_kernel(summ, 2)
+        dom = _dominant(summ)
+        roof = _roofline(summ, dom, args.dtype, 2)
         mm = [k for k in summ if k.startswith("linear_") or k == "made_gemm_tn"]
-        fl = sum(summ[k]["flops"] for k in mm)
-        ms_ = sum(summ[k]["ms"] for k in mm)
-        peak = PEAK_TFLOPS[args.dtype]
-        roof = dict(bound="mfma", kernel="made_linear + made_gemm_tn (all GEMMs of the step)", achieved=round(fl / (ms_ * 1e-3) / 1e12, 2),
-                    peak=peak, unit="TFLOP/s", frac=round(fl / (ms_ * 1e-3) / 1e12 / peak, 4), traffic=None)
-    if rank == 0:
-        sec = elapsed / args.steps
-        print(json.dumps({
-            "metric": "video-music pairs/s, full training step (fwd + bwd + matcher + clip/Adam), B=64 per GPU",
-            "value": round(world * B / sec, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 4}]: B={B}/GPU, T_v={Tv}, T_a={Ta}, D={cfg.D}, train mode (dropout on), "
-                                   "f32 master weights + Adam, f32 gradient accumulation",
-                       "global_batch": world * B, "parallelism": f"dp{world}: the flat f32 gradient buffer all-reduced in two buckets, the large one under the encoders' backward",
-                       "launch": "eager"},
-            "roofline": roof,
-            "cpu_baseline": (cpu_baseline_train(cfg, sd, inp) if (world == 1 and not args.no_cpu_baseline) else None),
-            "kernels": per_kernel}))
+        fl, ms_ = sum(summ[k]["flops"] for k in mm), sum(summ[k]["ms"] for k in mm)
+        roof["all_gemms_of_the_step"] = dict(tflops=round(fl / (ms_ * 1e-3) / 1e12, 2), frac=round(fl / (ms_ * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                                             ms_per_step=round(ms_ / 2, 3), launches_per_step=sum(summ[k]["launches"] for k in mm) // 2)
+    sec = elapsed / steps
+    res = {"metric": "video-music pairs/s, full training step (fwd + bwd + matcher + clip/Adam), B=64 per GPU",
+           "value": round(world * B / sec, 1), "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+           "data": "synthetic",
+           "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 4}]: B={B}/GPU, T_v={Tv}, T_a={Ta}, D={cfg.D}, train mode (dropout on), "
+                                  "f32 master weights + Adam, f32 gradient accumulation",
+                      "global_batch": world * B, "parallelism": f"dp{world}: the flat f32 gradient buffer all-reduced in two buckets, the large one under the encoders' backward",
+                      "launch": "eager", "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)},
+           "roofline": roof,
+           "cpu_baseline": (cpu_baseline_train(cfg, sd, inp) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None),
+           "kernels": per_kernel}
+    del trn, t, out
+    torch.cuda.empty_cache()
+    return res
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1 or "RANK" in os.environ:           # launched by torch.distributed.run: one process per GPU, RCCL
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # backend "nccl" is RCCL on ROCm
-
-    if args.workload in ("retrieval", "train"):
-        (retrieval_main if args.workload == "retrieval" else train_main)(args, rank, world, local, dist)
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
+def eval_leg(args, rank, world, local, dist, dtype: str, n_lanes: int, steps: int, warmup: int, with_roofline: bool, with_cpu: bool) -> dict:
+    """BASELINE.json configs[1]: eval-mode `Uni_model.forward` (reference model/model_Uni.py:177-322) over B=64 batches resident in HBM.
+    Steps are independent batches; `n_lanes` of them are kept in flight (one engine, workspace, stream and captured graph each), issued
+    round-robin: one batch's decoder -- a chain of dependent launches that leaves most of the chip idle -- then runs beside another
+    batch's encoders.  N > 1: every rank runs its own batches (no data-path collective)."""
     cfg = cfg_headline()
     B, Tv, Ta = args.batch, cfg.max_v_frames, cfg.max_snippet_num
     sd = synth.make_state_dict(cfg, seed=0)
     inp = synth.make_inputs(cfg, B, Tv, Ta, seed=1 + rank)
     dev = torch.device("cuda", local)
-    # Steps are independent batches.  --in-flight N keeps N of them in flight: N engines (own workspace), each on its own HIP
-    # stream with its own captured graph, steps issued round-robin.  One batch's decoder -- a chain of ~70 dependent launches
-    # that leaves most of the chip idle -- then runs beside another batch's encoders.  Lane 0 is what the roofline leg times.
-    n_lanes = max(1, args.in_flight)
-    engines = [MadeEngine(cfg, sd, device=dev, dtype=args.dtype) for _ in range(n_lanes)]
-    eng = engines[0]
+    n_lanes = max(1, n_lanes)
+    engines = [MadeEngine(cfg, sd, device=dev, dtype=dtype) for _ in range(n_lanes)]
     lane_inp = [inp] + [synth.make_inputs(cfg, B, Tv, Ta, seed=1 + rank + 1000 * l) for l in range(1, n_lanes)]
     lane_t = [{k: torch.from_numpy(v).to(dev) for k, v in li.items() if isinstance(v, np.ndarray)} for li in lane_inp]
-    t = lane_t[0]
     lane_stream = [torch.cuda.Stream() for _ in range(n_lanes)] if n_lanes > 1 else [torch.cuda.current_stream()]
 
     def step(l=0):
         tl = lane_t[l]
         return engines[l].forward(tl["frame_feats"], tl["segment_feats"], tl["frame_masks"], tl["segment_masks"], tl["spans_target"])
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     outs = [step(l) for l in range(n_lanes)]         # allocates the workspaces
     torch.cuda.synchronize()
@@ -325,7 +341,6 @@ def main():
         except Exception as ex:                      # report, do not hide: fall back to eager launches
             print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); using eager launches", file=sys.stderr)
             launch, graphs = "eager", None
-    out = outs[0]
     issued = [0]
 
     def run():
@@ -337,93 +352,84 @@ def main():
         with torch.cuda.stream(lane_stream[l]):
             graphs[l].replay() if graphs else step(l)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         run()
-    barrier()
+    _barrier(dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    ms = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
+    _barrier(dist)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, dist, dev)
+    ms = elapsed / steps * 1e3
+    value = world * B * steps / elapsed
 
-    # one batch alone (nothing else in flight): what a single forward takes end to end
-    lat_ms = ms
-    if n_lanes > 1:
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            graphs[0].replay() if graphs else step(0)
-        torch.cuda.synchronize()
-        lat_ms = (time.perf_counter() - t1) / 10 * 1e3
-
-    # sanity: the step really produced finite losses and a valid matching
     torch.cuda.synchronize()
-    for o in outs:
+    for o in outs:                                   # sanity: the step really produced finite losses and a valid matching
         assert int(o["matcher_status"].cpu()) == 0
         assert bool(torch.isfinite(o["localization_loss"]).all()) and bool(torch.isfinite(o["retrieval_loss"]).all())
 
-    # ---- roofline leg: HIP events around every launch of the dominant kernel, same stream, same step
-    roof = None
-    per_kernel = {}
-    if rank == 0:
+    roof, per_kernel = None, {}
+    if rank == 0 and with_roofline:
         with ops.KernelTimer() as kt:
             for _ in range(3):
                 step()
         summ = kt.summary()
-        # dominant kernel = the made_linear kernel symbol that does most of the step's arithmetic (timed launches are labelled
-        # with the kernel they dispatch to, made_linear_variant, so this average sits beside rocprofv3's per-symbol average;
-        # ranking by summed event time would favour the many tiny launches, whose event pairs cost as much as the kernels)
+        roof = _roofline(summ, _dominant(summ), dtype, 3)
         lin = [k for k in summ if k.startswith("linear_")]
-        dom = max(lin, key=lambda k: summ[k]["flops"]) if lin else max(summ, key=lambda k: summ[k]["ms"])
-        d = summ[dom]
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.dtype]
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.isfile(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        all_lin = dict(launches_per_step=sum(summ[k]["launches"] for k in lin) // 3,
-                       tflops=round(sum(summ[k]["flops"] for k in lin) / (sum(summ[k]["ms"] for k in lin) * 1e-3) / 1e12, 2)) if lin else None
-        roof = dict(bound="mfma", kernel=f"{dom} (made_linear)", achieved=round(achieved, 2), peak=peak,
-                    unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
-                    launches_per_step=d["launches"] // 3, avg_launch_us=round(d["ms"] / d["launches"] * 1e3, 2),
-                    algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
-                    algorithmic_mb_per_launch=round(d["bytes"] / d["launches"] / 1e6, 3),
-                    all_made_linear_kernels=all_lin,
-                    note="flops/bytes count the gathered (valid-token) rows only: padded tokens are not computed "
-                         f"({100 * (1 - d['flops'] / max(d['flops_nominal'], 1)):.0f}% of this kernel's nominal work)")
-        for k, v in summ.items():
-            per_kernel[k] = dict(launches_per_step=v["launches"] // 3, ms_per_step=round(v["ms"] / 3, 4),
-                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                 gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
+        if lin:
+            fl, ms_ = sum(summ[k]["flops"] for k in lin), sum(summ[k]["ms"] for k in lin)
+            roof["all_made_linear_kernels"] = dict(launches_per_step=sum(summ[k]["launches"] for k in lin) // 3, ms_per_step=round(ms_ / 3, 3),
+                                                   tflops=round(fl / (ms_ * 1e-3) / 1e12, 2))
+        per_kernel = _per_kernel(summ, 3)
+    res = {"metric": "video-music pairs/s, eval forward (cross-modal transformer + DETR + matcher), B=64",
+           "value": round(value, 1), "unit": "pairs/s", "ms_per_step": round(ms, 4), "dtype": dtype,
+           "config": {"workload": f"BASELINE.json configs[1]: B={B}, T_v={Tv}, T_a={Ta}, D={cfg.D}, enc={cfg.detr_enc_layers}, "
+                                  f"dec={cfg.detr_dec_layers}, Q={cfg.num_moment_queries}, concat fusion, fwd-only",
+                      "global_batch": world * B, "launch": launch, "batches_in_flight": n_lanes,
+                      "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}}
+    if with_roofline:
+        res.update(roofline=roof, kernels=per_kernel)
+    if with_cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, sd, inp, args.cpu_steps)
+    del engines, graphs, outs, lane_t
+    torch.cuda.empty_cache()
+    return res
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, sd, inp, args.cpu_steps)
 
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1 or "RANK" in os.environ:           # launched by torch.distributed.run: one process per GPU, RCCL
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # backend "nccl" is RCCL on ROCm
+
+    if args.workload == "train":
+        line = train_leg(args, rank, world, local, dist, args.steps, args.warmup)
+    elif args.workload == "retrieval":
+        line = retrieval_leg(args, rank, world, local, dist, args.steps, args.warmup)
+    elif args.workload == "forward":
+        line = eval_leg(args, rank, world, local, dist, args.dtype, args.in_flight, args.steps, args.warmup, True, True)
+        line.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak", vs_baseline=None, data="synthetic")
+    else:
+        # the headline line: the training step is `value`; retrieval and the eval forward ride along as sub-objects
+        line = train_leg(args, rank, world, local, dist, args.steps, args.warmup)
+        r_steps = max(2, min(5, args.steps))
+        line["retrieval"] = retrieval_leg(args, rank, world, local, dist, r_steps, 1)
+        ev = {}
+        ev["bf16_two_in_flight"] = eval_leg(args, rank, world, local, dist, "bf16", 2, max(args.steps, 40), args.warmup, True, True)
+        ev["bf16_one_in_flight"] = eval_leg(args, rank, world, local, dist, "bf16", 1, max(args.steps, 20), args.warmup, False, False)
+        ev["f32_parity_mode_one_in_flight"] = eval_leg(args, rank, world, local, dist, "f32", 1, 10, 2, False, False)
+        ev["note"] = ("f32_parity_mode is the mode whose logits / spans meet north_star's <= 1e-4 gate against the oracle and the reference goldens "
+                      "(tests/test_engine_gpu.py); the bf16 modes are checked at 5e-2 (logits) / 2e-2 (spans)")
+        line["eval_fwd"] = ev
+        line["metric"] = "video-music pairs/s fwd+bwd at B=64 (full training step); sub-objects: retrieval sim-matrix GB/s, eval forward pairs/s"
     if rank == 0:
-        line = {
-            "metric": "video-music pairs/s, eval forward (cross-modal transformer + DETR + matcher), B=64",
-            "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: B={B}, T_v={Tv}, T_a={Ta}, D={cfg.D}, enc={cfg.detr_enc_layers}, "
-                                   f"dec={cfg.detr_dec_layers}, Q={cfg.num_moment_queries}, concat fusion, fwd-only",
-                       "global_batch": world * B, "launch": launch, "batches_in_flight": n_lanes,
-                       "single_batch_ms": round(lat_ms, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
-                       "parallelism": f"dp{world} (independent batches, no collective)",
-                       "accumulate": "f32", "activations": args.dtype},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": per_kernel,
-        }
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

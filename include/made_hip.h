@@ -168,7 +168,8 @@ enum MadeLinearVariant {
     MADE_LINEAR_SKINNY = 4,         /* linear_skinny_kernel: 64 x 64 tiles, 8-stage LDS-DMA ring */
     MADE_LINEAR_GLDS3 = 5,          /* linear_glds_kernel<3, ., 128>: at most one workgroup per CU, three LDS stages */
     MADE_LINEAR_GLDS64 = 6,         /* linear_glds_kernel<1, ., 64>: 64 x 128 tiles */
-    MADE_LINEAR_GLDS128 = 7         /* linear_glds_kernel<1, ., 128>: 128 x 128 tiles */
+    MADE_LINEAR_GLDS128 = 7,        /* linear_glds_kernel<1, ., 128>: 128 x 128 tiles */
+    MADE_LINEAR_RING128 = 8         /* linear_ring_kernel<128, 128>: two-stage LDS-DMA ring, one barrier per slab, two workgroups per CU */
 };
 int made_linear_variant(const MadeLinearArgs* args);
 

@@ -81,6 +81,39 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     }
 }
 
+// erf for the bf16 fast paths (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7: far inside a bf16 output's half-ulp of 2e-3 and the
+// f32 output tolerance; ~14 instructions against erff's ~50).  The f32 parity kernels keep erff.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = fmaf(-p * t, e, 1.f);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float apply_act_fast(float x, int act) {
+    switch (act) {
+        case MADE_ACT_RELU: return fmaxf(x, 0.f);
+        case MADE_ACT_GELU: return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752440f));
+        case MADE_ACT_QUICKGELU: return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+        case MADE_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_grad(float g, int gate);
+__device__ __forceinline__ float act_grad_fast(float g, int gate) {
+    switch (gate) {
+        case MADE_GATE_GELU_Z: {
+            const float cdf = 0.5f * (1.f + fast_erf(g * 0.70710678118654752440f));
+            return fmaf(g * 0.39894228040143267794f, __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * g * g), cdf);
+        }
+        default: return act_grad(g, gate);
+    }
+}
+
 // 8 consecutive f32 -> output dtype, vector store when `vec_ok`
 __device__ __forceinline__ void store8(void* out, int odt, int64_t off, const float* v, int nvalid, bool vec_ok) {
     if (vec_ok && nvalid == 8) {
@@ -696,6 +729,317 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 5 : 4) : 1) void 
 }
 
 // =================================================================================================
+// Ring path: the encoder-sized launches (tens of thousands of rows, K = 512 .. 1024).
+// Measured (tools/probes/gemm_ring_probe.hip, profiles/r02_a_gemm_ring_probe.txt): with one LDS stage and two barriers per slab a
+// workgroup's LDS-DMA and its MFMAs never overlap; what bounds these launches is the rate at which a CU takes operand bytes in
+// (about 40-55 GB/s per CU through global_load_lds), so the loop must keep a slab in flight ALL the time and the tile must be
+// large enough that a byte is used often.  Here: two 32 KB (128 x 128) / 64 KB (256 x 256) stages, slab kt + 1 in flight while slab
+// kt is multiplied, one raw s_barrier per slab (a __syncthreads would add vmcnt(0) to every barrier), the wait for a slab placed
+// at its first reader.  128 x 128: four waves (2 x 2), two workgroups per CU, so one workgroup's epilogue runs beside the
+// other's K loop.  256 x 256: eight waves (2 x 4, 128 x 64 each), one workgroup per CU, half the operand bytes per flop.
+// Operands are swapped (acc = W-fragment x A-fragment): a lane then holds FOUR CONSECUTIVE COLUMNS of one output row, so the
+// accumulators go to the f32 LDS tile as 16-byte stores (16 per wave tile instead of 64 four-byte ones); the LDS tile is XOR
+// swizzled by row so both those stores and the row-contiguous read-back are bank-conflict free.
+template <int RBM, int RBN, int WM, int WN, bool TRAIN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void linear_ring_kernel(const MadeLinearArgs a) {
+    constexpr int NST = 2, NW = WM * WN, NTH = NW * 64;
+    constexpr int TM = RBM / WM, TN = RBN / WN, MT = TM / 32, NTL = TN / 32;
+    constexpr int STAGE = (RBM + RBN) * KB;
+    constexpr int PA = RBM / 8 / NW, PWN = RBN / 8 / NW;   // 1 KB pieces (8 rows x 128 B) per wave per slab
+    constexpr int PROWS = NST * STAGE / (RBN * 4);          // rows of the f32 epilogue tile that fit in the ring's LDS
+    constexpr int NPASS = RBM / PROWS;
+    static_assert(RBM % PROWS == 0 && PROWS % 32 == 0, "epilogue passes cover whole MFMA tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char rlds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+    const int n_tiles = (N + RBN - 1) / RBN;
+    int Mv = M;                                            // row gather (see linear_kernel)
+    if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
+    const int nwg = ((Mv + RBM - 1) / RBM) * n_tiles;
+    if ((int)blockIdx.x >= nwg) return;
+    int tile_id;                                           // XCD-aware order: the n-tiles of one activation panel share an L2
+    {
+        const int xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
+        tile_id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+    }
+    const int tile_m = tile_id / n_tiles, tile_n = tile_id % n_tiles;
+    const int m0 = tile_m * RBM, n0 = tile_n * RBN;
+    const int64_t z = blockIdx.z;
+
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+        if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
+    const MadeLinearSeg seg = a.seg[si];
+
+    // ---- padded tiles (see linear_glds_kernel): every wave checks all rows itself, so the answer is uniform without a barrier
+    if (a.tile_skip_mask) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < RBM / 64; ++i) {
+            const int g = m0 + 64 * i + lane;
+            any = any || (g < M && a.tile_skip_mask[g] != 0.f);
+        }
+        if (!__any(any)) {
+            if (a.out_row_mask && !seg.transposed && (a.split_k <= 1)) {       // consumers expect zeros in masked rows
+                const int rpb0 = (int)seg.rows_per_batch;
+                for (int idx = tid; idx < RBM * (RBN / 8); idx += NTH) {
+                    const int row = idx / (RBN / 8), c8 = idx % (RBN / 8);
+                    const int m = m0 + row, n = n0 + c8 * 8;
+                    if (m >= M || n >= N) continue;
+                    int64_t orow;
+                    if (rpb0 > 0) { const int b = m / rpb0, t = m - b * rpb0; orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo; }
+                    else orow = (int64_t)m * seg.ldo;
+                    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    int nv = N - n; nv = nv > 8 ? 8 : nv;
+                    store8(seg.out, seg.out_dtype, blockIdx.z * seg.out_z_stride + orow + (n - (int)seg.col_begin), zero8, nv, false);
+                }
+            }
+            return;
+        }
+    }
+
+    // ---- per-lane LDS-DMA sources: piece j = rows 8j..8j+7 of the slab; lane l -> row 8j + l/8, LDS slot l%8 <- global chunk (l%8) ^ swz(row)
+    const bool repl = seg.use_a2 && a.A2 && a.a2_replace;
+    const bf16_t* Abase = (repl ? (const bf16_t*)a.A2 : (const bf16_t*)a.A) + z * a.a_z_stride;
+    const int64_t lda = repl ? a.lda2 : a.lda;
+    const bf16_t* Wbase = (const bf16_t*)a.W + z * a.w_z_stride;
+    const bf16_t* pa[PA];
+    const bf16_t* pw[PWN];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = 8 * (PA * wave + i) + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gm = m0 + row; gm = gm < Mv ? gm : Mv - 1;        // rows past the edge are fetched from a valid row and never stored
+        if (a.row_index) gm = a.row_index[gm];
+        pa[i] = Abase + (int64_t)gm * lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PWN; ++i) {
+        const int row = 8 * (PWN * wave + i) + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gn = n0 + row; gn = gn < N ? gn : N - 1;
+        pw[i] = Wbase + (int64_t)gn * a.ldw + chunk * 8;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int offa[MT], offw[NTL], sa[MT], sw[NTL];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { const int ra = wm * TM + t * 32 + r; offa[t] = ra * KB; sa[t] = swz(ra); }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) { const int rw = wn * TN + t * 32 + r; offw[t] = RBM * KB + rw * KB; sw[t] = swz(rw); }
+
+    const int nk = K / 64;
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        unsigned char* st = rlds + (kt & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(st + (PA * wave + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PWN; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(st + RBM * KB + (PWN * wave + i) * 1024), 16, 0, 0);
+    };
+    auto multiply = [&](int kt) __attribute__((always_inline)) {
+        const unsigned char* st = rlds + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[MT], fw[NTL];
+            const int c = 2 * ks + hh;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) fa[t] = *(const bf16x8*)(st + offa[t] + ((c ^ sa[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) fw[t] = *(const bf16x8*)(st + offw[t] + ((c ^ sw[t]) << 4));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    // ---- the rows this thread finishes in the epilogue (one row per 16 tile rows, 8 columns each): their physical row numbers
+    // are loaded now, under the flight of slab 0, so that the residual / gate / mask loads that depend on them can be sent
+    // before the LAST slab is multiplied and land while the accumulators move through LDS.  With two workgroups per CU nothing
+    // else would hide those two dependent round trips per row (they cost the first version of this kernel 11 us of a 26 us launch).
+    constexpr int TPR = RBN / 8;                           // threads per output row
+    constexpr int RSTEP = NTH / TPR;                       // tile rows between two rows of one thread
+    constexpr int RPT = PROWS / RSTEP;                     // rows per thread
+    static_assert(NPASS == 1, "the prefetching epilogue covers the tile in one pass");
+    const int cc = tid % TPR, rr = tid / TPR;
+    const int n = n0 + cc * 8;
+    int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+    issue(0);
+    // (loads under a per-element condition are serialised by hipcc, one round trip each: every group of loads below sits under ONE
+    // uniform branch, addresses are clamped instead of guarded)
+    int mrow[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) { const int ml = m0 + rr + RSTEP * i; mrow[i] = ml < Mv ? ml : Mv - 1; }
+    if (a.row_index) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) mrow[i] = a.row_index[mrow[i]];
+    }
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int nj = n + j < N ? n + j : N - 1; bv[j] = a.bias[nj]; }
+    }
+    const int rmod = (int)a.r_row_mod;
+    const bool r_pref = a.R && a.r_dtype == MADE_BF16 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0) && nvalid == 8;
+    const bool g_pref = TRAIN && a.gate != MADE_GATE_NONE && a.g_dtype == MADE_BF16 && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0) && nvalid == 8;
+    bf16x8 rpre[RPT], gpre[TRAIN ? RPT : 1];
+    float om[RPT];
+
+    // slab kt lives in stage kt & 1.  Per iteration: wait for slab kt (the only one in flight), barrier (everyone's pieces have landed AND
+    // everyone is done reading the other stage), send slab kt + 1 into that other stage, multiply slab kt under its flight.
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        issue(kt + 1);
+        multiply(kt);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    // in flight under the last slab's MFMAs and the LDS staging
+    int rrow[RPT];                                         // row of the residual: the physical row, or its position in the table
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) rrow[i] = mrow[i];
+    if (rmod > 0) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) rrow[i] = mrow[i] % rmod;
+    }
+    if (r_pref) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) rpre[i] = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)rrow[i] * a.ldr + n);
+    }
+    if constexpr (TRAIN) {
+        if (g_pref) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) gpre[i] = *(const bf16x8*)((const bf16_t*)a.G + (int64_t)mrow[i] * a.ldg + n);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) om[i] = 1.f;
+    if (a.out_row_mask) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) om[i] = a.out_row_mask[mrow[i]];
+    }
+    multiply(nk - 1);
+    asm volatile("s_barrier" ::: "memory");                 // the epilogue reuses the ring's LDS
+
+    // ---- epilogue: accumulators -> swizzled f32 LDS tile (16-byte stores) -> row-contiguous vector I/O (bias, act, residual, ...)
+    float* Ct = (float*)rlds;
+    unsigned char* outp = (unsigned char*)seg.out;
+    const int64_t out_z = z * seg.out_z_stride;
+    const int rpb = (int)seg.rows_per_batch;
+    const int colb = (int)seg.col_begin;
+    const int odt = seg.out_dtype;
+    const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
+                         (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
+    const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rl = wm * TM + mt * 32 + r;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = (wn * TN + nt * 32) / 4 + 2 * g + hh;       // 16-byte chunk (4 columns) of the row
+                f32x4 v;
+                v[0] = acc[mt][nt][4 * g]; v[1] = acc[mt][nt][4 * g + 1]; v[2] = acc[mt][nt][4 * g + 2]; v[3] = acc[mt][nt][4 * g + 3];
+                *(f32x4*)(Ct + rl * RBN + ((c ^ (rl & 15)) << 2)) = v;
+            }
+    }
+    __syncthreads();
+    if (nvalid <= 0) return;
+    const int act = a.act;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = rr + RSTEP * i;
+        if (m0 + row >= Mv) break;
+        const int m = mrow[i];
+        const float* rp = Ct + row * RBN;
+        const int sx = row & 15;
+        const f32x4 c0 = *(const f32x4*)(rp + (((2 * cc) ^ sx) << 2)), c1 = *(const f32x4*)(rp + (((2 * cc + 1) ^ sx) << 2));
+        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        // z = acc + bias [-> Zout]   v = act(z)   v *= act'(G) * gate_scale   v = dropout(v)   v += R   row mask   (epilogue8's order)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bv[j];
+        if constexpr (TRAIN) {
+            if (a.Zout) store8(a.Zout, a.z_dtype, (int64_t)m * a.ldz + n, v, nvalid, (a.ldz % 8 == 0) && (((uintptr_t)a.Zout & 15) == 0));
+        }
+        switch (act) {
+            case MADE_ACT_NONE: break;
+            case MADE_ACT_RELU:
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                break;
+            default:
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = apply_act_fast(v[j], act);
+                break;
+        }
+        if constexpr (TRAIN) {
+            if (a.gate != MADE_GATE_NONE) {
+                float g[8];
+                if (g_pref) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = (float)gpre[i][j];
+                } else {
+                    load8(a.G, a.g_dtype, (int64_t)m * a.ldg + n, g, nvalid, (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= act_grad_fast(g[j], a.gate) * a.gate_scale;
+            }
+            if (a.drop.p > 0.f) {
+                const uint32_t thr = made_drop_threshold(a.drop.p);
+                const float sc = 1.f / (1.f - a.drop.p);
+                const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = (made_rng_mix(a.drop.seed, a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+            }
+        }
+        if (a.R) {
+            if (r_pref) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)rpre[i][j];
+            } else {
+                float rv[8];
+                load8(a.R, a.r_dtype, (int64_t)rrow[i] * a.ldr + n, rv, nvalid, r_vec);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rv[j];
+            }
+        }
+        if (om[i] == 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        int64_t orow;
+        if (rpb > 0) {
+            const int b = m / rpb, t = m - b * rpb;
+            orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo;
+        } else {
+            orow = (int64_t)m * seg.ldo;
+        }
+        store8(outp, odt, out_z + orow + (n - colb), v, nvalid, out_vec);
+    }
+}
+
+// =================================================================================================
 // Skinny problems (the decoder's B*Q = 64 rows, the heads): a launch of a handful of workgroups is bound by the latency
 // of its K loop, not by bandwidth or MFMA rate.  64 x 64 tiles (twice the workgroups of the 128-wide tiling) and an
 // 8-stage LDS ring of 16 KB stages: for K <= 512 every slab of the problem is in flight before the first MFMA, so the
@@ -947,10 +1291,11 @@ __global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearA
 
 }  // namespace
 
-// tuning knob for the micro-benchmarks: MADE_LINEAR_TILE=64|128 forces the tile height of the direct-to-LDS kernel
-static int tile_pref() {
-    static const int v = [] { const char* e = getenv("MADE_LINEAR_TILE"); return e ? atoi(e) : 0; }();
-    return v;
+// tuning knob for the micro-benchmarks and tests: MADE_LINEAR_TILE=64|128 forces the single-stage direct-to-LDS kernels of round 1,
+// 2128 | 2256 the ring kernel's tile (default: 128 x 128 ring), 1000 round 1's choice between its two kernels
+static int tile_pref() {                                   // read on every call: the tests switch kernels inside one process
+    const char* e = getenv("MADE_LINEAR_TILE");
+    return e ? atoi(e) : 0;
 }
 
 // which kernel made_linear runs for these arguments (one place: the launcher and made_linear_variant both ask here)
@@ -967,6 +1312,11 @@ static int pick_variant(const MadeLinearArgs& a) {
     if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) return MADE_LINEAR_TINY;
     if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) return MADE_LINEAR_SKINNY;
     if (tiles * a.batch <= 256) return MADE_LINEAR_GLDS3;                  // at most one workgroup per CU
+    // Ring kernel (round 2): measured per shape against round 1's kernels under graph replay (tools/ring_bench.py,
+    // profiles/r02_a_ring_bench.txt): it wins by 8-17 % on the gathered launches that are 512 columns wide (out-proj, the second FFN
+    // Linear, the encoders' final / input projections) and loses by 5-15 % on the wider ones, where round 1's 4-5 small
+    // workgroups per CU hide prologue, epilogue and the write burst better than two large ones.
+    if (tile_pref() == 2128 || (tile_pref() == 0 && a.row_index && a.N <= 512)) return MADE_LINEAR_RING128;
     // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
     const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
     if (tile_pref() == 64) return MADE_LINEAR_GLDS64;
@@ -1064,6 +1414,17 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
             if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128>), grid, block, 0, st, a);
             break;
+        case MADE_LINEAR_RING128: {                        // 128 x 128 tiles, two-stage LDS-DMA ring, two workgroups per CU
+            constexpr int LDSB = 2 * (128 + 128) * KB;
+            static const bool once = [] {
+                return hipFuncSetAttribute((const void*)linear_ring_kernel<128, 128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
+                       hipFuncSetAttribute((const void*)linear_ring_kernel<128, 128, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+            }();
+            (void)once;
+            if (train) hipLaunchKernelGGL((linear_ring_kernel<128, 128, 2, 2, true>), grid, block, LDSB, st, a);
+            else hipLaunchKernelGGL((linear_ring_kernel<128, 128, 2, 2, false>), grid, block, LDSB, st, a);
+            break;
+        }
         case MADE_LINEAR_GENERAL_F32IN: hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a); break;
         case MADE_LINEAR_GENERAL_BF16: hipLaunchKernelGGL((linear_kernel<bf16_t, bf16_t>), grid, block, 0, st, a); break;
         default: hipLaunchKernelGGL((linear_kernel<float, float>), grid, block, 0, st, a); break;

@@ -82,6 +82,16 @@ class KernelTimer:
             frac = 1.0
             if isinstance(desc, tuple) and desc[0] == "rows":   # row gather: (tag, n_rows tensor, M): only the valid rows are computed
                 frac = min(1.0, (math.ceil(int(desc[1].item()) / 128) * 128) / max(desc[2], 1))
+            elif isinstance(desc, tuple) and desc[0] == "attn":  # (tag, key mask [B,Lk] | None, query skip mask [B,Lq] | None): ragged batch
+                key = ("attn", desc[1].data_ptr() if desc[1] is not None else 0, desc[2].data_ptr() if desc[2] is not None else 0)
+                if key not in frac_cache:
+                    fk = (desc[1] != 0).float().mean(dim=1) if desc[1] is not None else 1.0
+                    fq = (desc[2] != 0).float().mean(dim=1) if desc[2] is not None else 1.0
+                    f = fk * fq
+                    frac_cache[key] = float(f.mean().item()) if isinstance(f, torch.Tensor) else 1.0
+                frac = frac_cache[key]
+            elif isinstance(desc, tuple) and desc[0] == "frac":  # (tag, executed fraction) computed by the caller
+                frac = float(desc[1])
             elif isinstance(desc, tuple):               # (text, skip mask, rows per tile): count only tiles that were executed
                 _, mask, tile = desc
                 key = (mask.data_ptr(), mask.numel(), tile)
@@ -126,7 +136,8 @@ class Seg:
 
 # made_linear_variant codes (include/made_hip.h: MadeLinearVariant) -> KernelTimer kinds = rocprofv3 kernel symbols
 LINEAR_VARIANTS = {0: "linear_f32", 1: "linear_f32in_bf16", 2: "linear_kernel<bf16,bf16>", 3: "linear_tiny_kernel", 4: "linear_skinny_kernel",
-                   5: "linear_glds_kernel<3,.,128>", 6: "linear_glds_kernel<1,.,64>", 7: "linear_glds_kernel<1,.,128>"}
+                   5: "linear_glds_kernel<3,.,128>", 6: "linear_glds_kernel<1,.,64>", 7: "linear_glds_kernel<1,.,128>",
+                   8: "linear_ring_kernel<128,128>"}
 
 
 def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,
@@ -311,7 +322,8 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
     flops = 4.0 * B * H * Lq * a.Lk * hd
     nbytes = esz * B * D * (2 * Lq + 2 * a.Lk)
     _timed("attention_" + ("f32" if a.dtype == F32 else "bf16"), flops, nbytes,
-           lambda: check(lib().made_attention(C.byref(a), _stream()), "made_attention"), f"B={B} H={H} hd={hd} Lq={Lq} Lk={a.Lk}")
+           lambda: check(lib().made_attention(C.byref(a), _stream()), "made_attention"),
+           ("attn", key_mask, q_skip_mask) if (key_mask is not None and key_mask.dim() == 2) else f"B={B} H={H} hd={hd} Lq={Lq} Lk={a.Lk}")
     return O
 
 
@@ -497,7 +509,12 @@ def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2
     assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.numel() >= Nv * (D + 2) + 4
     a.ws, a.prepare_ws = _p(ws), 1 if prepare_ws else 0
     flops = 2.0 * Nv * Nm * (2 * S * D + D * D)
-    _timed("xpool_fused", flops, 0.0, lambda: check(lib().made_xpool_fused(C.byref(a), _stream()), "made_xpool_fused"))
+    desc = ""
+    if _timer is not None and key_mask is not None:             # executed work: the valid segments of each track only
+        valid = float((key_mask != 0).sum().item())
+        desc = ("frac", (2.0 * Nv * (2 * valid * D + Nm * D * D)) / flops)
+    _timed("xpool_fused", flops, float(2 * (K.numel() + U.numel()) + 4 * Nv * Nm + 2 * Q.numel()),
+           lambda: check(lib().made_xpool_fused(C.byref(a), _stream()), "made_xpool_fused"), desc)
     return sims
 
 

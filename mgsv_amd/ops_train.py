@@ -111,9 +111,10 @@ def attention_bwd(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, dO: Tensor, dQ: Te
     a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
     if drop is not None and drop[2] > 0.0:
         a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
-    flops = 10.0 * B * H * Lq * a.Lk * hd * 1.4          # 7 products of 2*Lq*Lk*hd
+    flops = 10.0 * B * H * Lq * a.Lk * hd                # five products of 2*Lq*Lk*hd (S, dP, dV, dK, dQ): cdna_hip_programming.md, attention backward
     _timed("made_attention_bwd", flops, float(Q.element_size() * B * D * (4 * Lq + 4 * a.Lk)),
-           lambda: check(lib().made_attention_bwd(C.byref(a), _stream()), "made_attention_bwd"), f"B={B} H={H} hd={hd} Lq={Lq} Lk={a.Lk}")
+           lambda: check(lib().made_attention_bwd(C.byref(a), _stream()), "made_attention_bwd"),
+           ("attn", key_mask, q_skip_mask) if (key_mask is not None and key_mask.dim() == 2) else f"B={B} H={H} hd={hd} Lq={Lq} Lk={a.Lk}")
 
 
 def _drop_ptr(drop):
