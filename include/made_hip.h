@@ -173,6 +173,28 @@ enum MadeLinearVariant {
 };
 int made_linear_variant(const MadeLinearArgs* args);
 
+/* One stage of the moment-DETR decoder's chain of B*Q-row Linears with the PREVIOUS stage's LayerNorm in its prologue
+ * (reference music_detr/transformer.py:273-307, forward_post; :136 for the shared output norm):
+ *     x   = LayerNorm(Zin; ln_g, ln_b)          Zin raw f32 rows [M, K]; ln_g == NULL: x = Zin
+ *     x2  = LayerNorm(x; ln2_g, ln2_b)          optional -> x2_out (bf16): the decoder output of the previous layer
+ *     A   = bf16(x) (+ add[row % add_row_mod])  add: bf16 rows of K elements (query_pos) or NULL; x itself -> x_out (bf16) or NULL
+ *     out = act(A W^T + bias) + R               R: bf16 [M, N] or NULL; res_from_x: + bf16(x) instead (needs N == K, no add)
+ * bf16 MFMA, f32 accumulate; K (the LayerNorm width) is 256 or 512; out is f32 (raw rows for the next stage's norm) or bf16.
+ * One launch of ceil(N / 32) x ceil(M / 64) workgroups, no split-K workspace, no finish launch. */
+typedef struct MadeDecStageArgs {
+    const float* Zin; int64_t ldz;
+    const float* ln_g; const float* ln_b;
+    const float* ln2_g; const float* ln2_b; void* x2_out; int64_t ldx2;
+    const void*  add; int64_t add_row_mod;
+    void*        x_out; int64_t ldx;
+    const void*  W; int64_t ldw; const float* bias;
+    const void*  R; int64_t ldr;
+    void*        out; int64_t ldo;
+    int32_t      out_dtype; int32_t act; int32_t res_from_x; float eps;
+    int64_t      M, N, K;
+} MadeDecStageArgs;
+int made_dec_stage(const MadeDecStageArgs* args, void* stream);
+
 /* y = act(sum_s ws[s] + bias) + R[row % r_row_mod]  -> out (any dtype, may be NULL);
  * then optionally z1 = LayerNorm(y; ln1) -> ln1_out, and z2 = LayerNorm(z1; ln2) -> ln2_out (the decoder's
  * per-layer norm followed by the shared output norm, reference music_detr/transformer.py:306,136).

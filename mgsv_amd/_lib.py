@@ -58,6 +58,15 @@ class MadeFinishArgs(C.Structure):
                 ("eps", f32), ("_pad3", i32)]
 
 
+class MadeDecStageArgs(C.Structure):
+    _fields_ = [("Zin", vp), ("ldz", i64), ("ln_g", vp), ("ln_b", vp),
+                ("ln2_g", vp), ("ln2_b", vp), ("x2_out", vp), ("ldx2", i64),
+                ("add", vp), ("add_row_mod", i64), ("x_out", vp), ("ldx", i64),
+                ("W", vp), ("ldw", i64), ("bias", vp), ("R", vp), ("ldr", i64), ("out", vp), ("ldo", i64),
+                ("out_dtype", i32), ("act", i32), ("res_from_x", i32), ("eps", f32),
+                ("M", i64), ("N", i64), ("K", i64)]
+
+
 class MadeAttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp),
                 ("dtype", i32), ("hd", i32),
@@ -124,6 +133,7 @@ SIGNATURES = {
     "made_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "made_linear": (C.c_int, [C.POINTER(MadeLinearArgs), vp]),
     "made_splitk_finish": (C.c_int, [C.POINTER(MadeFinishArgs), vp]),
+    "made_dec_stage": (C.c_int, [C.POINTER(MadeDecStageArgs), vp]),
     "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
     "made_attention_wide": (C.c_int, [C.POINTER(MadeWideAttnArgs), vp]),
     "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp, vp]),

@@ -82,13 +82,29 @@ template <typename F> __device__ __forceinline__ F keep_or_zero(F x, bool keep) 
     return __builtin_bit_cast(F, b);
 }
 
+// Wave-wide reductions on the DPP path (VALU only).  The butterfly of six __shfl_xor compiles to six ds_bpermute_b32, which go
+// through the LDS crossbar: ~100 cycles each and one LDS unit per CU -- 96 of them per wave cost made_dec_stage 4 us of 10.
+// Here: four DPP steps reduce each row of 16 lanes (every lane of the row ends with the row's value), two row broadcasts chain the
+// four rows, lane 63 holds the total and is read back as a scalar.  Every lane returns the same bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f32<0xB1, 0xF>(v, v);                               // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E, 0xF>(v, v);                               // quad_perm [2,3,0,1]
+    v += dpp_f32<0x124, 0xF>(v, v);                              // row_ror:4
+    v += dpp_f32<0x128, 0xF>(v, v);                              // row_ror:8
+    v += dpp_f32<0x142, 0xA>(0.f, v);                            // row_bcast:15 -> rows 1, 3
+    v += dpp_f32<0x143, 0xC>(0.f, v);                            // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_f32<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x124, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x128, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));                     // rows 0, 2 keep their own value (old = v)
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }

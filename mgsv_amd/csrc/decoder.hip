@@ -1,0 +1,302 @@
+// made_dec_stage: one stage of the moment-DETR decoder's chain of 64-row Linears (reference music_detr/transformer.py:273-307 with
+// Q = 1: B*Q rows, every Linear depends on the one before it).
+//
+// Round 1 ran each such Linear as a split-K GEMM + a finish launch (bias / residual / LayerNorm), 12 launches per layer.  A
+// LayerNorm needs whole rows, which a column-split GEMM does not have -- but the NEXT Linear's workgroups each read whole
+// rows of their input anyway (K = D).  So the LayerNorm moves into the prologue of its consumer: a stage is
+//     x  = LayerNorm(Zin)            raw f32 rows of the previous stage (or x = Zin when there is no norm)
+//     x2 = LayerNorm2(x)             optional (the decoder's shared output norm -> hs[l - 1])
+//     A  = x (+ add)                 bf16, e.g. + query_pos
+//     out = act(A W^T + bias) (+ R | + x)   f32 raw rows for the next norm, or bf16
+// computed by N / 32 workgroups of 64 rows x 32 columns; every workgroup normalises the rows itself (64 x 512 f32 = 128 KB from
+// L2, under the flight of its own weight fragments), the rows r with r % gridDim.x == blockIdx.x are also written out as x / x2
+// (the residual of a later stage, the decoder output).  No split-K, no finish launch, no partial sums in HBM: 8 launches per
+// layer.  The four waves split K four ways (as linear_tiny_kernel does): weight fragments come straight from global memory
+// (16 contiguous bytes of one row per lane), A fragments from the normalised LDS tile, partial tiles meet in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int DS_BM = 64, DS_BN = 32, DS_THREADS = 512, DS_RPW = 8, DS_CT_LD = DS_BN + 4;   // 8 waves, 8 rows each in the prologue
+
+__device__ __forceinline__ float ds_act(float x, int act) {   // (ReLU is all the decoder uses; erf / exp code would double the kernel)
+    return act == MADE_ACT_RELU ? fmaxf(x, 0.f) : x;
+}
+
+template <int NV>                                               // K = 64 * NV (NV = 4: D = 256, NV = 8: D = 512)
+__global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStageArgs a) {
+    constexpr int K = 64 * NV;
+    constexpr int LDA = K * 2 + 16;                             // bytes per row of the LDS A tile (padded: conflict-free 16-byte reads)
+    constexpr int STEPS = NV;                                   // 16-deep MFMA k-steps per wave (K / 4 / 16)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int M = (int)a.M, N = (int)a.N;
+    const int n0 = blockIdx.x * DS_BN, m0 = blockIdx.y * DS_BM;
+
+    // What such a one-shot kernel pays for is dependent memory round trips (about 1 us each, and vmcnt counts STORES too: a load
+    // issued after a store waits for the store to retire) and spills.  Hence: every global load is requested before the first
+    // wait, every global store of the prologue comes after its last load, and 8 waves (256 registers each) share the 64 rows.
+    // ---- 1. the GEMM waves' weight fragments (a quarter of K each), in flight before anything else
+    const int gw = wave & 3;
+    const int kw = gw * (K / 4) + hh * 8;
+    int gn = n0 + r; gn = gn < N ? gn : N - 1;
+    const bf16_t* pw = (const bf16_t*)a.W + (int64_t)gn * a.ldw + kw;
+    bf16x8 fw[STEPS];
+    if (wave < 4) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) fw[s] = *(const bf16x8*)(pw + s * 16);
+    }
+
+    // ---- 2. LayerNorm prologue: wave w normalises rows 8w .. 8w + 7, all 64 lanes on one row at a time (lane l: columns
+    // NV*l .. NV*l + NV - 1): the norm parameters of a lane's columns are loaded once and shared by its rows, the rows' reductions
+    // are independent chains the scheduler interleaves.
+    constexpr int RPW = DS_RPW;
+    const int c0 = NV * lane;
+    const bool has_ln = a.ln_g != nullptr, has_ln2 = a.ln2_g != nullptr && a.x2_out != nullptr;
+    float v[RPW][NV];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        int gm = m0 + wave * RPW + i; gm = gm < M ? gm : M - 1;
+        const float* zp = a.Zin + (int64_t)gm * a.ldz + c0;
+#pragma unroll
+        for (int j = 0; j < NV; j += 4) {
+            const f32x4 t = *(const f32x4*)(zp + j);
+            v[i][j] = t[0]; v[i][j + 1] = t[1]; v[i][j + 2] = t[2]; v[i][j + 3] = t[3];
+        }
+    }
+    float g1[NV], b1[NV], g2[NV], b2[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { g1[j] = 1.f; b1[j] = 0.f; g2[j] = 1.f; b2[j] = 0.f; }
+    if (has_ln) {
+#pragma unroll
+        for (int j = 0; j < NV; j += 4) {
+            const f32x4 g = *(const f32x4*)(a.ln_g + c0 + j), b = *(const f32x4*)(a.ln_b + c0 + j);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { g1[j + u] = g[u]; b1[j + u] = b[u]; }
+        }
+    }
+    if (has_ln2) {
+#pragma unroll
+        for (int j = 0; j < NV; j += 4) {
+            const f32x4 g = *(const f32x4*)(a.ln2_g + c0 + j), b = *(const f32x4*)(a.ln2_b + c0 + j);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { g2[j + u] = g[u]; b2[j + u] = b[u]; }
+        }
+    }
+    const int add_mod = (int)a.add_row_mod;
+    const bool add_same = a.add != nullptr && add_mod == 1;     // one vector for every row (Q = 1)
+    float ad[RPW][NV];
+    if (a.add) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            if (add_same && i > 0) {
+#pragma unroll
+                for (int u = 0; u < NV; ++u) ad[i][u] = ad[0][u];
+                continue;
+            }
+            int gm = m0 + wave * RPW + i; gm = gm < M ? gm : M - 1;
+            const bf16_t* ap = (const bf16_t*)a.add + (int64_t)(add_same ? 0 : gm % add_mod) * K + c0;
+            if constexpr (NV == 8) {
+                const bf16x8 t = *(const bf16x8*)ap;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ad[i][u] = (float)t[u];
+            } else {
+                const bf16x4 t = *(const bf16x4*)ap;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ad[i][u] = (float)t[u];
+            }
+        }
+    }
+    float y2[RPW][NV];                                           // the second norm's output, stored after the last load
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int rl = wave * RPW + i;                          // row inside the tile (wave-uniform)
+        if (has_ln) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) s += v[i][j];
+            const float mean = wave_sum(s) * (1.f / K);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { v[i][j] -= mean; q += v[i][j] * v[i][j]; }
+            const float rstd = rsqrtf(wave_sum(q) * (1.f / K) + a.eps);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[i][j] = v[i][j] * rstd * g1[j] + b1[j];
+        }
+        if (has_ln2) {                                          // the decoder's output norm on top of this layer's norm
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) s += v[i][j];
+            const float mean = wave_sum(s) * (1.f / K);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { const float d = v[i][j] - mean; q += d * d; }
+            const float rstd = rsqrtf(wave_sum(q) * (1.f / K) + a.eps);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) y2[i][j] = (v[i][j] - mean) * rstd * g2[j] + b2[j];
+        }
+        // the GEMM input: x as stored (bf16) + add, rounded once
+        if constexpr (NV == 8) {
+            bf16x8 t;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = a.add ? (bf16_t)((float)(bf16_t)v[i][u] + ad[i][u]) : (bf16_t)v[i][u];
+            *(bf16x8*)(dlds + rl * LDA + c0 * 2) = t;
+        } else {
+            bf16x4 t;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = a.add ? (bf16_t)((float)(bf16_t)v[i][u] + ad[i][u]) : (bf16_t)v[i][u];
+            *(bf16x4*)(dlds + rl * LDA + c0 * 2) = t;
+        }
+    }
+    // the epilogue's inputs (thread t < 256 finishes row t / 4, 8 columns)
+    const int cc = tid & 3, row = (tid >> 2) & 63;
+    const int n = n0 + cc * 8;
+    int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+    const int ml = m0 + row;
+    const int mlc = ml < M ? ml : M - 1;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int nj = n + j < N ? n + j : N - 1; bv[j] = a.bias[nj]; }
+    }
+    const bool r_vec = a.R && nvalid == 8 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+    bf16x8 rpre;
+    if (r_vec) rpre = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)mlc * a.ldr + n);
+
+    // the prologue's global stores (x, x2), after the last load of this wave
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int gm = m0 + wave * RPW + i;
+        const bool writer = (gm < M) && (gm % (int)gridDim.x == (int)blockIdx.x);
+        if (!writer) continue;
+        if (a.x_out) {
+            bf16_t* xp = (bf16_t*)a.x_out + (int64_t)gm * a.ldx + c0;
+            if constexpr (NV == 8) { bf16x8 t; for (int u = 0; u < 8; ++u) t[u] = (bf16_t)v[i][u]; *(bf16x8*)xp = t; }
+            else { bf16x4 t; for (int u = 0; u < 4; ++u) t[u] = (bf16_t)v[i][u]; *(bf16x4*)xp = t; }
+        }
+        if (has_ln2) {
+            bf16_t* yp = (bf16_t*)a.x2_out + (int64_t)gm * a.ldx2 + c0;
+            if constexpr (NV == 8) { bf16x8 t; for (int u = 0; u < 8; ++u) t[u] = (bf16_t)y2[i][u]; *(bf16x8*)yp = t; }
+            else { bf16x4 t; for (int u = 0; u < 4; ++u) t[u] = (bf16_t)y2[i][u]; *(bf16x4*)yp = t; }
+        }
+    }
+    __syncthreads();
+    const bool gemm_wave = wave < 4;                            // waves 4-7 only keep the barriers company from here on
+
+    // ---- 3. 64 x 32 partial tile of this wave's K quarter
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    if (gemm_wave) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const bf16x8 fa0 = *(const bf16x8*)(dlds + r * LDA + (kw + s * 16) * 2);
+            const bf16x8 fa1 = *(const bf16x8*)(dlds + (r + 32) * LDA + (kw + s * 16) * 2);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fw[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fw[s], acc[1], 0, 0, 0);
+        }
+    }
+
+    // ---- 4. the four partial tiles meet in LDS; bias, activation, residual, store
+    float xres[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xres[j] = 0.f;
+    if (gemm_wave && a.res_from_x && n + 8 <= K) {              // residual = the normalised input itself (N == K): still in the A tile
+        const bf16x8 t = *(const bf16x8*)(dlds + row * LDA + n * 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xres[j] = (float)t[j];
+    }
+    __syncthreads();                                            // everyone is done with the A tile: the partials take its place
+    float* Ct = (float*)dlds;
+    if (gemm_wave) {
+        float* mine = Ct + wave * (DS_BM * DS_CT_LD);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mine[(t * 32 + acc_row(e, hh)) * DS_CT_LD + r] = acc[t][e];
+    }
+    __syncthreads();
+    if (!gemm_wave || nvalid <= 0 || ml >= M) return;
+    float v8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v8[j] = 0.f;
+    float rv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rv[j] = xres[j];
+    const bool vec = nvalid == 8;
+    if (a.R) {
+        if (r_vec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rv[j] = (float)rpre[j];
+        } else {
+            for (int j = 0; j < nvalid; ++j) rv[j] = (float)((const bf16_t*)a.R)[(int64_t)ml * a.ldr + n + j];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float* cp = Ct + w * (DS_BM * DS_CT_LD) + row * DS_CT_LD + cc * 8;
+        const f32x4 q0 = *(const f32x4*)cp, q1 = *(const f32x4*)(cp + 4);
+        v8[0] += q0[0]; v8[1] += q0[1]; v8[2] += q0[2]; v8[3] += q0[3];
+        v8[4] += q1[0]; v8[5] += q1[1]; v8[6] += q1[2]; v8[7] += q1[3];
+    }
+    const int act = a.act;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v8[j] = ds_act(v8[j] + bv[j], act) + rv[j];
+    if (a.out_dtype == MADE_F32) {
+        float* op = (float*)a.out + (int64_t)ml * a.ldo + n;
+        if (vec && (a.ldo % 4 == 0) && (((uintptr_t)a.out & 15) == 0)) {
+            f32x4 o0, o1;
+            o0[0] = v8[0]; o0[1] = v8[1]; o0[2] = v8[2]; o0[3] = v8[3]; o1[0] = v8[4]; o1[1] = v8[5]; o1[2] = v8[6]; o1[3] = v8[7];
+            *(f32x4*)op = o0; *(f32x4*)(op + 4) = o1;
+        } else {
+            for (int j = 0; j < nvalid; ++j) op[j] = v8[j];
+        }
+    } else {
+        bf16_t* op = (bf16_t*)a.out + (int64_t)ml * a.ldo + n;
+        if (vec && (a.ldo % 8 == 0) && (((uintptr_t)a.out & 15) == 0)) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v8[j];
+            *(bf16x8*)op = o;
+        } else {
+            for (int j = 0; j < nvalid; ++j) op[j] = (bf16_t)v8[j];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int made_dec_stage(const MadeDecStageArgs* args, void* stream) {
+    MADE_REQUIRE(args != nullptr, "made_dec_stage: null args");
+    const MadeDecStageArgs& a = *args;
+    MADE_REQUIRE(a.Zin && a.W && a.out, "made_dec_stage: null Zin, W or out");
+    MADE_REQUIRE(a.M > 0 && a.N > 0, "made_dec_stage: bad dims M=%lld N=%lld", (long long)a.M, (long long)a.N);
+    MADE_UNSUPPORTED(a.K == 256 || a.K == 512, "made_dec_stage: K=%lld (the row width of the LayerNorm) must be 256 or 512", (long long)a.K);
+    MADE_UNSUPPORTED(a.ldz % 4 == 0 && ((uintptr_t)a.Zin % 16) == 0, "made_dec_stage: Zin rows must be 16-byte aligned");
+    MADE_UNSUPPORTED(a.ldw % 8 == 0 && ((uintptr_t)a.W % 16) == 0, "made_dec_stage: W rows must be 16-byte aligned");
+    MADE_REQUIRE((a.ln_g == nullptr) == (a.ln_b == nullptr) && (a.ln2_g == nullptr) == (a.ln2_b == nullptr), "made_dec_stage: gamma and beta come together");
+    MADE_REQUIRE(a.out_dtype == MADE_F32 || a.out_dtype == MADE_BF16, "made_dec_stage: bad out_dtype %d", a.out_dtype);
+    MADE_UNSUPPORTED(a.act == MADE_ACT_NONE || a.act == MADE_ACT_RELU, "made_dec_stage: act=%d (ReLU or none)", a.act);
+    if (a.x_out) MADE_UNSUPPORTED(a.ldx % 8 == 0 && ((uintptr_t)a.x_out % 16) == 0, "made_dec_stage: x_out rows must be 16-byte aligned");
+    if (a.x2_out) MADE_UNSUPPORTED(a.ldx2 % 8 == 0 && ((uintptr_t)a.x2_out % 16) == 0, "made_dec_stage: x2_out rows must be 16-byte aligned");
+    if (a.add) MADE_REQUIRE(a.add_row_mod >= 1 && ((uintptr_t)a.add % 16) == 0, "made_dec_stage: add needs add_row_mod >= 1 and 16-byte alignment");
+    if (a.res_from_x) MADE_REQUIRE(a.N == a.K && a.add == nullptr && a.R == nullptr, "made_dec_stage: res_from_x needs N == K, no add, no R");
+    const dim3 grid((unsigned)((a.N + DS_BN - 1) / DS_BN), (unsigned)((a.M + DS_BM - 1) / DS_BM)), block(DS_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.K == 512) {
+        constexpr int LDSB = DS_BM * (512 * 2 + 16);
+        static const bool once = hipFuncSetAttribute((const void*)dec_stage_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+        (void)once;
+        hipLaunchKernelGGL((dec_stage_kernel<8>), grid, block, LDSB, st, a);
+    } else {
+        constexpr int LDSB = 4 * DS_BM * DS_CT_LD * 4;          // the partial tiles are larger than the 256-wide A tile
+        hipLaunchKernelGGL((dec_stage_kernel<4>), grid, block, LDSB, st, a);
+    }
+    return made_check_launch("made_dec_stage");
+}

@@ -114,6 +114,17 @@ __device__ __forceinline__ float act_grad_fast(float g, int gate) {
     }
 }
 
+// bias of 8 consecutive columns.  Loads under a per-element condition are serialised by hipcc (one round trip each: 8 of them cost
+// the 64-row kernels 3-4 us of a 10 us launch); ONE uniform branch, clamped addresses, columns past N are never stored.
+__device__ __forceinline__ void load_bias8(const float* __restrict__ bias, int n, int N, float* bv) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+    if (bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int nj = n + j < N ? n + j : N - 1; bv[j] = bias[nj]; }
+    }
+}
+
 // 8 consecutive f32 -> output dtype, vector store when `vec_ok`
 __device__ __forceinline__ void store8(void* out, int odt, int64_t off, const float* v, int nvalid, bool vec_ok) {
     if (vec_ok && nvalid == 8) {
@@ -170,9 +181,12 @@ __device__ __forceinline__ float act_grad(float g, int gate) {
 
 // The element-wise tail of made_linear on 8 consecutive outputs of row m starting at column n:
 //   z = acc + bias  [-> Zout]   v = act(z)   v *= act'(G) * gate_scale   v = dropout(v)   v += R   row mask
+// rpre / gpre / om: residual, gate tensor and output row mask of these 8 outputs when the caller loaded them ahead of its K loop
+// (the 64-row kernels are one dependent memory round trip after another; whatever the epilogue needs is requested up front)
 template <bool TRAIN>
 __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n, int nvalid, float* v, const float* bv,
-                                          int rmod, bool r_vec) {
+                                          int rmod, bool r_vec, const bf16x8* rpre = nullptr, const bf16x8* gpre = nullptr,
+                                          const float* om = nullptr) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += bv[j];
     if (TRAIN && a.Zout) {
@@ -194,7 +208,12 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
     }
     if (TRAIN && a.gate != MADE_GATE_NONE) {
         float g[8];
-        load8(a.G, a.g_dtype, (int64_t)m * a.ldg + n, g, nvalid, (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0));
+        if (gpre) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = (float)(*gpre)[j];
+        } else {
+            load8(a.G, a.g_dtype, (int64_t)m * a.ldg + n, g, nvalid, (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0));
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= act_grad(g[j], a.gate) * a.gate_scale;
     }
@@ -207,13 +226,18 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
             v[j] = (made_rng_mix(a.drop.seed, a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
     }
     if (a.R) {
-        const int rr = rmod > 0 ? m % rmod : m;
         float rv[8];
-        load8(a.R, a.r_dtype, (int64_t)rr * a.ldr + n, rv, nvalid, r_vec);
+        if (rpre) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rv[j] = (float)(*rpre)[j];
+        } else {
+            const int rr = rmod > 0 ? m % rmod : m;
+            load8(a.R, a.r_dtype, (int64_t)rr * a.ldr + n, rv, nvalid, r_vec);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += rv[j];
     }
-    if (a.out_row_mask && a.out_row_mask[m] == 0.f) {
+    if (om ? (*om == 0.f) : (a.out_row_mask && a.out_row_mask[m] == 0.f)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
@@ -437,8 +461,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
         int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
         if (nvalid > 0) {
             float bv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bv[j] = (a.bias && j < nvalid) ? a.bias[n + j] : 0.f;
+            load_bias8(a.bias, n, N, bv);
             const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
                                  (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
             const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
@@ -679,8 +702,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 5 : 4) : 1) void 
     const int n = n0 + cc * 8;
     int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
     float bv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = (a.bias && j < nvalid) ? a.bias[n + j] : 0.f;
+    load_bias8(a.bias, n, N, bv);
     const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
                          (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
     const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
@@ -891,12 +913,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void linear_ring_kernel(const Made
         for (int i = 0; i < RPT; ++i) mrow[i] = a.row_index[mrow[i]];
     }
     float bv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
-    if (a.bias) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const int nj = n + j < N ? n + j : N - 1; bv[j] = a.bias[nj]; }
-    }
+    load_bias8(a.bias, n, N, bv);
     const int rmod = (int)a.r_row_mod;
     const bool r_pref = a.R && a.r_dtype == MADE_BF16 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0) && nvalid == 8;
     const bool g_pref = TRAIN && a.gate != MADE_GATE_NONE && a.g_dtype == MADE_BF16 && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0) && nvalid == 8;
@@ -1145,8 +1162,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void linear_skinny_kernel(const MadeLi
     int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
     if (nvalid <= 0) return;
     float bv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = (a.bias && j < nvalid) ? a.bias[n + j] : 0.f;
+    load_bias8(a.bias, n, N, bv);
     const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
                          (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
     const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
@@ -1216,6 +1232,25 @@ __global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearA
     int gn = n0 + r; gn = gn < N ? gn : N - 1;
     const bf16_t* pw = (const bf16_t*)a.W + z * a.w_z_stride + (int64_t)gn * a.ldw + kw;
 
+    // the epilogue's inputs (this thread finishes row tid / 4, 8 columns): physical row, bias, residual, gate, row mask -- all
+    // requested now, so they travel with the operand fragments instead of costing a round trip each after the K loop
+    const int e_cc = tid & 3, e_row = tid >> 2;
+    const int e_n = n0 + e_cc * 8;
+    int e_nvalid = N - e_n; e_nvalid = e_nvalid > 8 ? 8 : e_nvalid;
+    const int e_ml = m0 + e_row;
+    int e_m = e_ml < Mv ? e_ml : Mv - 1;
+    if (a.row_index) e_m = a.row_index[e_m];
+    float e_bv[8];
+    load_bias8(a.bias, e_n, N, e_bv);
+    const int e_rmod = (int)a.r_row_mod;
+    const bool e_rpref = a.R && a.r_dtype == MADE_BF16 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0) && e_nvalid == 8;
+    const bool e_gpref = TRAIN && a.gate != MADE_GATE_NONE && a.g_dtype == MADE_BF16 && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0) && e_nvalid == 8;
+    bf16x8 e_r, e_g;
+    if (e_rpref) e_r = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)(e_rmod > 0 ? e_m % e_rmod : e_m) * a.ldr + e_n);
+    if constexpr (TRAIN) { if (e_gpref) e_g = *(const bf16x8*)((const bf16_t*)a.G + (int64_t)e_m * a.ldg + e_n); }
+    float e_om = 1.f;
+    if (a.out_row_mask) e_om = a.out_row_mask[e_m];
+
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -1259,14 +1294,11 @@ __global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearA
     const int64_t out_z = z * seg.out_z_stride;
     const int rpb = (int)seg.rows_per_batch, rmod = (int)a.r_row_mod;
     const int colb = (int)seg.col_begin;
-    const int cc = tid & 3, row = tid >> 2;
-    const int n = n0 + cc * 8;
-    int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
-    const int ml = m0 + row;
+    const int cc = e_cc, row = e_row, n = e_n, nvalid = e_nvalid, ml = e_ml;
     if (nvalid <= 0 || ml >= Mv) return;
-    float v[8], bv[8];
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { v[j] = 0.f; bv[j] = (a.bias && j < nvalid) ? a.bias[n + j] : 0.f; }
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         const float* cp = Ct + w * (T_BM * T_CT_LD) + row * T_CT_LD + cc * 8;
@@ -1277,8 +1309,8 @@ __global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearA
     const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
                          (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
     const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
-    const int m = a.row_index ? a.row_index[ml] : ml;
-    epilogue8<TRAIN>(a, m, n, nvalid, v, bv, rmod, r_vec);
+    const int m = e_m;
+    epilogue8<TRAIN>(a, m, n, nvalid, v, e_bv, rmod, r_vec, e_rpref ? &e_r : nullptr, e_gpref ? &e_g : nullptr, &e_om);
     int64_t orow;
     if (rpb > 0) {
         const int b = m / rpb, t = m - b * rpb;

@@ -179,6 +179,7 @@ class MadeEngine:
             mat(p + ".ca.qk.w", torch.einsum("hjn,hjk->hnk", wk_h, wq_h).reshape(H * D, D).float().to(dev))
             vec(p + ".ca.qk.b", torch.einsum("hjn,hj->hn", wk_h, b[:D].view(H, hd)).reshape(H * D).float().to(dev))
             mat(p + ".ca.vo.w", torch.einsum("mhj,hjn->mhn", wo.view(D, H, hd), wv_h).reshape(D, H * D).float().to(dev))
+            mat(p + ".ca.v.w", w[2 * D:].float().to(dev)); mat(p + ".ca.o.w", wo.float().to(dev))    # the same two Linears, not folded (fused chain)
             vec(p + ".ca.vo.b", (wo @ b[2 * D:] + bo).float().to(dev))
             lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
             ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2"); ln(p + ".ln3", p + ".norm3")
@@ -244,6 +245,7 @@ class MadeEngine:
             video=E(B, D, dtype=torch.float32), music=E(B, D, dtype=torch.float32),
             tgt=E(B * Q, D), t1=E(B * Q, D), t2=E(B * Q, D), tx=E(B * Q, D),
             dqkv=E(B * Q, 3 * D), datt=E(B * Q, D),
+            dz=E(3, B * Q, D, dtype=torch.float32), dv=E(B * Q, D), dzero=Z(B * Q, D, dtype=torch.float32),   # fused decoder chain: raw (pre-norm) rows
             dffn=E(B * Q, F_d), hs=E(nd, B * Q, D),
             logits=E(nd, B, Q, 2, dtype=torch.float32), spans=E(nd, B, Q, 2, dtype=torch.float32),
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D),
@@ -550,8 +552,11 @@ class MadeEngine:
                 # The query side of decoder layer 0 (initial queries -> self-attention block -> the folded cross-attention
                 # query) reads nothing the DETR encoder produces: it runs here, beside the encoder, instead of at the head of
                 # the decoder's chain of dependent launches.
-                self._decoder_queries(ws, video, music, None, B)
-                self._decoder_query_side(ws, 0, B)
+                if self._fused_decoder():
+                    self._dec_fused_query_side(ws, 0, self._dec_first_rows(ws, video, music))
+                else:
+                    self._decoder_queries(ws, video, music, None, B)
+                    self._decoder_query_side(ws, 0, B)
                 dec_early = torch.cuda.Event()
                 dec_early.record(side)
             need_pooled = want_pooled or c.moment_query_type == "xpool" or c.vmr_loss == "dual_single_feature_fuse"
@@ -612,7 +617,8 @@ class MadeEngine:
         else:
             if c.moment_query_type == "xpool":                           # reference model_Uni.py:222-223: the track's pooled vectors,
                 cur.wait_stream(side)                                    # averaged over the videos of the batch (X-Pool branch first)
-            self._decoder_queries(ws, video, music, pooled, B)
+            if not self._fused_decoder():
+                self._decoder_queries(ws, video, music, pooled, B)
         qp = P["query_embed"]
         hs = ws["hs"]
         ca_scale = 1.0 / math.sqrt(D // H)
@@ -622,10 +628,28 @@ class MadeEngine:
         skinny = lambda A, wkey, **kw: self._skinny(ws, A, wkey, **kw)
 
         n_split = max(1, min(8, 256 // max(B, 1)))
+        fused = self._fused_decoder()
         for l in range(nd):
             p = f"detr_transformer.decoder.layers.{l}"
             ln2, ln3 = [(P[p + f".ln{i}.g"], P[p + f".ln{i}.b"]) for i in (2, 3)]
             t1, t2 = ws["t1"], ws["t2"]
+            if fused:
+                # Fused chain (made_dec_stage): every LayerNorm runs in the prologue of the Linear that consumes it, so a layer is
+                # 8 launches instead of 12 and no split-K partial sums go through HBM.  z[0..2]: the raw rows before norm 1 / 2 / 3.
+                z, hd = ws["dz"], D // H
+                if l > 0 or dec_early is None:
+                    self._dec_fused_query_side(ws, l, self._dec_first_rows(ws, video, music) if l == 0 else None)
+                ops.attention_wide(dq4, mempos3, mem3, dp4, scale=ca_scale, key_mask=fus_mask,
+                                   n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
+                dv = ws["dv"]
+                ops.linear(dpool[:, :D], P[p + ".ca.v.w"][:hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
+                           segs=[Seg(out=dv, ldo=D, out_z_stride=hd)])                       # v_h = W_v,h pooled_h (b_v rides in ca.vo.b)
+                ops.linear(dv, P[p + ".ca.o.w"], P[p + ".ca.vo.b"], R=t1, out=z[1])
+                ops.dec_stage(z[1], P[p + ".ff1.w"], P[p + ".ff1.b"], ws["dffn"], ln=ln2, x_out=t2, act=ops.ACT_RELU)
+                ops.linear(ws["dffn"], P[p + ".ff2.w"], P[p + ".ff2.b"], R=t2, out=z[2])
+                if l == nd - 1:                                  # the last layer's norms have no consumer stage: one row kernel
+                    ops.splitk_finish(z[2].view(-1), 1, B * Q, D, None, ln1=ln3, ln1_out=tgt, ln2=(P["dec.norm.g"], P["dec.norm.b"]), ln2_out=hs[l])
+                continue
             if l > 0 or dec_early is None:
                 self._decoder_query_side(ws, l, B)
             ops.attention_wide(dq4, mempos3, mem3, dp4, scale=ca_scale, key_mask=fus_mask,
@@ -712,6 +736,34 @@ class MadeEngine:
         tiles = ((A.shape[0] + 127) // 128) * ((N + 127) // 128)
         split = max(2, min(192 // max(tiles, 1), (K + slab - 1) // slab, 32, dws.numel() // (A.shape[0] * N)))
         ops.linear_splitk(A, W, P[wkey + ".b"], dws, split, **kw)
+
+    def _fused_decoder(self) -> bool:
+        """The fused decoder chain (made_dec_stage) covers the scripts' configuration: bf16, one moment query, queries from the clip
+        vectors (or zeros).  Everything else (f32 parity mode, Q > 1, the pooled-track query) keeps the split-K chain."""
+        c = self.cfg
+        return (self.tc == torch.bfloat16 and c.num_moment_queries == 1 and c.moment_query_type in ("video", "music", "zero", "random")
+                and not getattr(self, "force_unfused_decoder", False))
+
+    def _dec_first_rows(self, ws, video: Tensor, music: Tensor) -> Tensor:
+        """Raw rows feeding decoder layer 0 (reference transformer.py:73-74, model_Uni.py:216-221): the clip vectors, read in place."""
+        t = self.cfg.moment_query_type
+        return video if t == "video" else (music if t == "music" else ws["dzero"])
+
+    def _dec_fused_query_side(self, ws, l: int, first_rows: Optional[Tensor]):
+        """Fused chain, layer l up to the cross-attention.  Stage 1: the previous layer's norm 3 (+ the decoder output norm -> hs[l - 1]) in
+        the prologue, the folded self-attention Linear + residual -> raw rows z[0].  Stage 2: norm 1 in the prologue (-> t1), + query_pos,
+        the cross-attention query folded with W_k per head -> ws["dq_all"]."""
+        P = self.P
+        p = f"detr_transformer.decoder.layers.{l}"
+        z = ws["dz"]
+        if l == 0:
+            ops.dec_stage(first_rows, P[p + ".sa.fold.w"], P[p + ".sa.fold.b"], z[0], res_from_x=True)
+        else:
+            q = f"detr_transformer.decoder.layers.{l - 1}"
+            ops.dec_stage(z[2], P[p + ".sa.fold.w"], P[p + ".sa.fold.b"], z[0], ln=(P[q + ".ln3.g"], P[q + ".ln3.b"]),
+                          ln2=(P["dec.norm.g"], P["dec.norm.b"]), x2_out=ws["hs"][l - 1], res_from_x=True)
+        ops.dec_stage(z[0], P[p + ".ca.qk.w"], P[p + ".ca.qk.b"], ws["dq_all"], ln=(P[p + ".ln1.g"], P[p + ".ln1.b"]),
+                      add=P["query_embed"], x_out=ws["t1"])
 
     def _decoder_queries(self, ws, video: Tensor, music: Tensor, pooled: Optional[Tensor], B: int):
         """Initial decoder queries (reference transformer.py:73-74, model_Uni.py:216-223) -> ws["tgt"]."""

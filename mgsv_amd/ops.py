@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, BF16, F32,  # noqa: F401
-                   MadeAttnArgs, MadeFinishArgs, MadeLinearArgs, MadeLinearSeg, MadeWideAttnArgs, check, lib)
+                   MadeAttnArgs, MadeDecStageArgs, MadeFinishArgs, MadeLinearArgs, MadeLinearSeg, MadeWideAttnArgs, check, lib)
 
 Tensor = torch.Tensor
 
@@ -284,6 +284,42 @@ def splitk_finish(ws: Tensor, split_k: int, M: int, N: int, bias: Optional[Tenso
         f.ln2_out, f.ln2_dtype, f.ln2_ld = _p(ln2_out), dt_of(ln2_out), ln2_out.stride(0)
     f.eps = eps
     check(lib().made_splitk_finish(C.byref(f), _stream()), "made_splitk_finish")
+
+
+def dec_stage(Zin: Tensor, W: Tensor, bias: Optional[Tensor], out: Tensor, *, ln=None, ln2=None, x2_out: Optional[Tensor] = None,
+              add: Optional[Tensor] = None, x_out: Optional[Tensor] = None, R: Optional[Tensor] = None, res_from_x: bool = False,
+              act: int = ACT_NONE, eps: float = 1e-5) -> Tensor:
+    """One decoder stage with the previous stage's LayerNorm in its prologue (made_dec_stage): x = LayerNorm(Zin; ln) (ln = (gamma,
+    beta) or None: x = Zin), x2_out = LayerNorm(x; ln2), x_out = bf16(x), out = act((x + add) W^T + bias) + R (or + x).
+    Zin [M, K] f32; W [N, K] bf16; add [rows, K] bf16 (row modulo); R [M, N] bf16; out [M, N] f32 or bf16."""
+    assert Zin.dim() == 2 and W.dim() == 2 and out.dim() == 2 and Zin.dtype == torch.float32 and W.dtype == torch.bfloat16
+    assert Zin.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1
+    M, K = Zin.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and tuple(out.shape) == (M, N)
+    a = MadeDecStageArgs()
+    a.Zin, a.ldz = _p(Zin), Zin.stride(0)
+    if ln is not None:
+        a.ln_g, a.ln_b = _p(_f32(ln[0], "ln.g")), _p(_f32(ln[1], "ln.b"))
+    if ln2 is not None:
+        assert x2_out is not None and x2_out.dtype == torch.bfloat16 and x2_out.stride(1) == 1
+        a.ln2_g, a.ln2_b, a.x2_out, a.ldx2 = _p(_f32(ln2[0], "ln2.g")), _p(_f32(ln2[1], "ln2.b")), _p(x2_out), x2_out.stride(0)
+    if add is not None:
+        assert add.dim() == 2 and add.dtype == torch.bfloat16 and add.is_contiguous() and add.shape[1] == K
+        a.add, a.add_row_mod = _p(add), add.shape[0]
+    if x_out is not None:
+        assert x_out.dtype == torch.bfloat16 and x_out.stride(1) == 1 and tuple(x_out.shape) == (M, K)
+        a.x_out, a.ldx = _p(x_out), x_out.stride(0)
+    a.W, a.ldw, a.bias = _p(W), W.stride(0), _p(_f32(bias, "bias"))
+    if R is not None:
+        assert R.dtype == torch.bfloat16 and R.stride(1) == 1 and tuple(R.shape) == (M, N)
+        a.R, a.ldr = _p(R), R.stride(0)
+    a.out, a.ldo, a.out_dtype = _p(out), out.stride(0), dt_of(out)
+    a.act, a.res_from_x, a.eps = act, 1 if res_from_x else 0, eps
+    a.M, a.N, a.K = M, N, K
+    _timed("dec_stage_kernel", 2.0 * M * N * K, float(M * K * 4 * ((N + 31) // 32) + N * K * 2 + M * N * out.element_size()),
+           lambda: check(lib().made_dec_stage(C.byref(a), _stream()), "made_dec_stage"), f"M={M} N={N} K={K}")
+    return out
 
 
 def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,

@@ -114,7 +114,55 @@ def test_f32_forward_matches_reference_golden(golden_dir, name):
     np.testing.assert_allclose(out["localization_loss"], float(fix["localization_loss"]), rtol=2e-4, atol=5e-4)
 
 
-@pytest.mark.parametrize("name", ["native_B8", "cfg2_shape_B4"])
+def test_fused_decoder_chain_matches_split_k_chain():
+    """bf16, Q = 1: the fused decoder chain (made_dec_stage: LayerNorms in the consumers' prologues, unfolded value path) against
+    round 1's split-K + finish chain on the same weights and batch: the decoder states of all layers agree to bf16 rounding."""
+    for cfg, B, Tv, Ta in ((cfg_headline(), 8, 30, 512), (cfg_native(), 5, 50, 96)):
+        sd = synth.make_state_dict(cfg, seed=0)
+        inp = synth.make_inputs(cfg, B, Tv, Ta, seed=3)
+        fused = MadeEngine(cfg, sd, dtype="bf16")
+        plain = MadeEngine(cfg, sd, dtype="bf16")
+        plain.force_unfused_decoder = True
+        assert fused._fused_decoder() and not plain._fused_decoder()
+        a, b = fused.forward_numpy(inp), plain.forward_numpy(inp)
+        for k, tol in (("hs", 3e-2), ("pred_logits", 3e-2), ("pred_spans", 1e-2)):       # + 2 bf16 ulps of the value (hs reaches |8|)
+            err = (np.abs(a[k] - b[k]) - 2.0 ** -7 * np.abs(b[k])).max()
+            assert err <= tol, (k, float(err))
+        np.testing.assert_allclose(a["localization_loss"], b["localization_loss"], rtol=2e-2)
+
+
+def test_bf16_graph_replay_full_batch_properties():
+    """The configuration bench.py times (B = 64, T_v = 30, T_a = 512, D = 512, bf16, hipGraph): outputs finite, the matcher accepts
+    the costs, and a graph replay is bit-identical to the eager step (no launch depends on host state or on timing)."""
+    cfg = cfg_headline()
+    B, Tv, Ta = 64, 30, 512
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, B, Tv, Ta, seed=1)
+    dev = torch.device("cuda")
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
+    eng = MadeEngine(cfg, sd, device=dev, dtype="bf16")
+    step = lambda: eng.forward(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+    keys = ["pred_logits", "pred_spans", "sims_single", "sims_dual", "retrieval_loss", "localization_loss", "criterion_losses", "hs",
+            "matcher_pred_idx", "video_feats", "music_feats", "memory"]
+    valid = torch.cat([t["frame_masks"], t["segment_masks"]], dim=1) != 0          # padded tokens of `memory` are never computed or written
+    pick = lambda k, x: x[valid] if k == "memory" else x
+    o = step(); torch.cuda.synchronize()
+    eager = {k: pick(k, o[k]).clone() for k in keys}
+    assert int(o["matcher_status"].cpu()) == 0
+    for k in keys:
+        assert bool(torch.isfinite(eager[k].float()).all()), k
+    assert float(eager["pred_spans"].min()) >= 0.0 and float(eager["pred_spans"].max()) <= 1.0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        og = step()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(pick(k, og[k]), eager[k]), f"{k}: graph replay differs from the eager step"
+
+
+@pytest.mark.parametrize("name", ["native_B8", "cfg2_shape_B4", "native_nomask_zeroquery_B4", "native_musicquery_nocontrast_B3", "single_sample_B1_Tv3_Ta5"])
 def test_bf16_forward_within_stated_tolerance(name):
     cfg, B, Tv, Ta = _cases()[name]
     sd = synth.make_state_dict(cfg, seed=0)

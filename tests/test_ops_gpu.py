@@ -114,6 +114,47 @@ def test_linear_encoder_sized(dev, M, N, gather, tile, monkeypatch):
         np.testing.assert_allclose(o2.cpu().numpy(), full[:, 512:].numpy(), atol=2e-3, rtol=0)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 512, 512), (64, 4096, 512), (7, 1024, 512), (130, 256, 256), (64, 96, 256)])
+@pytest.mark.parametrize("variant", ["plain", "ln_add_xout", "ln_ln2_resx", "ln_R_relu_bf16"])
+def test_dec_stage(dev, M, N, K, variant):
+    """made_dec_stage (one stage of the fused decoder chain): LayerNorm prologue, second norm output, + add, x written out, Linear,
+    activation, residual from R or from x, f32 / bf16 output -- against the same math in f32 on bf16-rounded operands."""
+    if variant == "ln_ln2_resx" and N != K:
+        pytest.skip("res_from_x needs N == K")
+    z, W, b = rnd(M, K, seed=1) * 2 + 0.3, rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3) * 0.1
+    g1, b1, g2, b2 = 1 + 0.1 * rnd(K, seed=4), 0.1 * rnd(K, seed=5), 1 + 0.1 * rnd(K, seed=6), 0.1 * rnd(K, seed=7)
+    add, R = rnd(1, K, seed=8), rnd(M, N, seed=9)
+    ln = lambda t, g, bb: torch.nn.functional.layer_norm(t, (K,), g, bb, 1e-5)
+    kw, x = {}, z
+    if variant != "plain":
+        kw["ln"] = (g1.to(dev), b1.to(dev)); x = ln(z, g1, b1)
+    A = bf(x)
+    x_out = x2_out = None
+    if variant == "ln_add_xout":
+        x_out = torch.full((M, K), float("nan"), device=dev, dtype=torch.bfloat16)
+        kw.update(add=add.to(dev).bfloat16(), x_out=x_out); A = bf(bf(x) + bf(add))
+    if variant == "ln_ln2_resx":
+        x2_out = torch.full((M, K), float("nan"), device=dev, dtype=torch.bfloat16)
+        kw.update(ln2=(g2.to(dev), b2.to(dev)), x2_out=x2_out, res_from_x=True)
+    odt = torch.bfloat16 if variant == "ln_R_relu_bf16" else torch.float32
+    ref = A @ bf(W).t() + b
+    if variant == "ln_R_relu_bf16":
+        kw.update(R=R.to(dev).bfloat16(), act=ops.ACT_RELU); ref = torch.relu(ref) + bf(R)
+    if variant == "ln_ln2_resx":
+        ref = ref + bf(x)
+    out = torch.full((M, N), float("nan"), device=dev, dtype=odt)
+    ops.dec_stage(z.to(dev), W.to(dev).bfloat16(), b.to(dev), out, **kw)
+    torch.cuda.synchronize()
+    # (res_from_x adds the bf16-rounded x: where the kernel's f32 LayerNorm lands on the other side of a rounding tie the residual moves
+    # by one bf16 ulp of x, hence the relative term)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=4e-3 if odt == torch.float32 else 3e-2,
+                               rtol=2e-2 if odt != torch.float32 else (8e-3 if variant == "ln_ln2_resx" else 0))
+    if x_out is not None:
+        np.testing.assert_allclose(x_out.float().cpu().numpy(), x.numpy(), atol=BF16_TOL, rtol=1e-2)
+    if x2_out is not None:
+        np.testing.assert_allclose(x2_out.float().cpu().numpy(), ln(x, g2, b2).numpy(), atol=BF16_TOL, rtol=1e-2)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_linear_prologue_epilogue(dev, mode):
     """row mask on A, +A2 with row modulo, residual table with row modulo, output row mask."""
