@@ -616,6 +616,27 @@ int made_recall_ranks(const float* sims, int64_t ld, const int32_t* group_id, co
 int made_span_iou(const float* pred_logits, const float* pred_spans, const float* gt_moment, const float* m_duration,
                   int64_t N, int64_t Q, int32_t fg_label, float max_m_duration, float* iou_out, float* pred_out, void* stream);
 
+/* ---- the free functions the reference's drivers import (train-MaDe.py:16,20,22); Python mirrors with the
+ * reference's names: mgsv_amd/modules/metrics.py, mgsv_amd/modules/loss.py, mgsv_amd/music_detr/span_utils.py ---- */
+
+/* out[a * sa + p * sp] = cos(anchor[a, :], pooled[p, a, :]); anchor f32 [A, D] (row stride lda), pooled [P, A, D] contiguous (f32 or
+ * bf16).  reference modules/metrics.py:10-24 sim_matrix_music_pooling (anchor = videos, sa = ld, sp = 1) and :26-41
+ * sim_matrix_video_pooling (anchor = tracks, sa = 1, sp = ld). */
+int made_pooled_cosine(const float* anchor, int64_t lda, const void* pooled, int32_t pooled_dtype, float* out, int64_t sa, int64_t sp,
+                       int64_t A, int64_t P, int64_t D, void* stream);
+/* out[i] = x[i] * exp(*logit_scale): the scaled logits of reference modules/loss.py:12-13 (CLIPLoss), :86-88 (InfoNCELoss). */
+int made_scale_exp(const float* x, const float* logit_scale, float* out, int64_t n, void* stream);
+/* mode 0: (centre, width) -> (start, end) (reference music_detr/span_utils.py:15-24 span_cw_to_se); 1: the inverse (:4-13). [N, 2] f32. */
+int made_span_convert(const float* in, float* out, int64_t N, int32_t mode, void* stream);
+/* all pairs of spans1 [N, 2] x spans2 [M, 2] (start, end): IoU and union (reference span_utils.py:39-66 temporal_iou), generalised
+ * IoU (:86-115), intersection over the second span (:69-83); any output may be NULL.  [N, M] f32 each. */
+int made_span_pairwise(const float* spans1, const float* spans2, float* iou, float* uni, float* giou, float* inter_over_2,
+                       int64_t N, int64_t M, void* stream);
+/* IoU of one predicted (start, end) in seconds per sample with its ground-truth moment (reference span_utils.py:119-170:
+ * individual_IoU_tensor; clamp_to_max = 1 adds detr_iou's clamp of the prediction to [0, max_m_duration]). */
+int made_span_iou_se(const float* pred_se, const float* gt_moment, const float* m_duration, int64_t N, float max_m_duration,
+                     int32_t clamp_to_max, int32_t discounted, float* iou_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1348,7 +1348,10 @@ static int pick_variant(const MadeLinearArgs& a) {
     // profiles/r02_a_ring_bench.txt): it wins by 8-17 % on the gathered launches that are 512 columns wide (out-proj, the second FFN
     // Linear, the encoders' final / input projections) and loses by 5-15 % on the wider ones, where round 1's 4-5 small
     // workgroups per CU hide prologue, epilogue and the write burst better than two large ones.
-    if (tile_pref() == 2128 || (tile_pref() == 0 && a.row_index && a.N <= 512)) return MADE_LINEAR_RING128;
+    // (eval epilogues only: with two workgroups per CU the training epilogue's dropout hash / GELU' are not hidden: 90-124 us against
+    // round 1's 48-70 us on the same launches, profiles/r02_b_train_trace_summary.txt)
+    const bool train_epi = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
+    if (tile_pref() == 2128 || (tile_pref() == 0 && a.row_index && a.N <= 512 && !train_epi)) return MADE_LINEAR_RING128;
     // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
     const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
     if (tile_pref() == 64) return MADE_LINEAR_GLDS64;

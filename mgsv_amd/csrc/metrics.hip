@@ -92,6 +92,78 @@ __global__ void span_iou_kernel(const float* logits, const float* spans, const f
     iou_out[i] = iou;
 }
 
+// ---- the free functions the reference's drivers import ------------------------------------------------
+// out[a * sa + p * sp] = cos(anchor[a], pooled[p, a]) -- reference modules/metrics.py:10-24 (music pooling: anchor = videos,
+// pooled [bs_m, bs_v, D], out [bs_v, bs_m]) and :26-41 (video pooling: anchor = tracks, pooled [bs_v, bs_m, D]).  One wave per pair.
+template <typename TP>
+__global__ void pooled_cosine_kernel(const float* anchor, int64_t lda, const TP* pooled, float* out, int64_t sa, int64_t sp,
+                                     int64_t A, int64_t P, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= A * P) return;
+    const int64_t p = pair / A, ai = pair % A;
+    const float* ar = anchor + ai * lda;
+    const TP* pr = pooled + pair * D;
+    float dot = 0.f, na = 0.f, np_ = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float x = ar[c], y = (float)pr[c];
+        dot += x * y; na += x * x; np_ += y * y;
+    }
+    dot = wave_sum(dot); na = wave_sum(na); np_ = wave_sum(np_);
+    if (lane == 0) out[ai * sa + p * sp] = (dot / sqrtf(na)) / sqrtf(np_);       // x / |x| . y / |y| as the reference forms it
+}
+
+// out = x * exp(*logit_scale): the logits CLIPLoss / InfoNCELoss return beside the loss (reference modules/loss.py:12-13,86-88)
+__global__ void scale_exp_kernel(const float* x, const float* logit_scale, float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] * expf(*logit_scale);
+}
+
+// mode 0: (centre, width) -> (start, end); mode 1: (start, end) -> (centre, width)   (reference music_detr/span_utils.py:4-24)
+__global__ void span_convert_kernel(const float* in, float* out, int64_t N, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float a = in[2 * i], b = in[2 * i + 1];
+    if (mode == 0) { out[2 * i] = a - 0.5f * b; out[2 * i + 1] = a + 0.5f * b; }
+    else { out[2 * i] = (a + b) * 0.5f; out[2 * i + 1] = b - a; }
+}
+
+// all pairs of two span lists: IoU, union, generalised IoU, intersection over the second span (reference span_utils.py:39-115)
+__global__ void span_pairwise_kernel(const float* s1, const float* s2, float* iou, float* uni, float* giou, float* iop, int64_t N, int64_t M) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * M) return;
+    const int64_t i = idx / M, j = idx % M;
+    const float a0 = s1[2 * i], a1 = s1[2 * i + 1], b0 = s2[2 * j], b1 = s2[2 * j + 1];
+    const float inter = fmaxf(fminf(a1, b1) - fmaxf(a0, b0), 0.f);
+    const float u = (a1 - a0) + (b1 - b0) - inter;
+    const float io = inter / u;
+    if (iou) iou[idx] = io;
+    if (uni) uni[idx] = u;
+    if (giou) { const float enc = fmaxf(fmaxf(a1, b1) - fminf(a0, b0), 0.f); giou[idx] = io - (enc - u) / enc; }
+    if (iop) iop[idx] = inter / (b1 - b0);
+}
+
+// IoU of one predicted (start, end) [seconds] per sample with its ground truth (reference span_utils.py:119-170: detr_iou clamps the
+// prediction to [0, max_m_duration], individual_IoU_tensor to [0, m_duration]; discounted: x (1 - |d start| / dur)(1 - |d end| / dur))
+__global__ void span_iou_se_kernel(const float* pred, const float* gt, const float* dur, int64_t N, float max_dur, int clamp_max, int discounted, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float ps = pred[2 * i], pe = pred[2 * i + 1];
+    if (clamp_max) { ps = fmaxf(ps, 0.f); pe = fminf(pe, max_dur); }
+    const float gs = gt[2 * i], ge = gt[2 * i + 1], d = dur[i];
+    float v = 0.f;
+    if (gs < ge) {
+        ps = fmaxf(ps, 0.f); pe = fminf(pe, d);
+        const float inter = fmaxf(fminf(ge, pe) - fmaxf(gs, ps), 0.f);
+        const float u = (pe - ps) + (ge - gs) - inter;
+        if (u > 0.f) {
+            v = inter / u;
+            if (discounted) v = v * (1.f - fabsf(gs - ps) / d) * (1.f - fabsf(ge - pe) / d);
+        }
+    }
+    out[i] = v;
+}
+
 }  // namespace
 
 extern "C" int made_recall_ranks(const float* sims, int64_t ld, const int32_t* group_id, const int32_t* gt_group, int64_t Nv, int64_t Nm,
@@ -119,4 +191,47 @@ extern "C" int made_span_iou(const float* pred_logits, const float* pred_spans, 
     hipLaunchKernelGGL(span_iou_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred_logits, pred_spans, gt_moment,
                        m_duration, N, (int)Q, (int)fg_label, max_m_duration, iou_out, pred_out);
     return made_check_launch("made_span_iou");
+}
+
+extern "C" int made_pooled_cosine(const float* anchor, int64_t lda, const void* pooled, int32_t pooled_dtype, float* out, int64_t sa,
+                                  int64_t sp, int64_t A, int64_t P, int64_t D, void* stream) {
+    MADE_REQUIRE(anchor && pooled && out, "made_pooled_cosine: null pointer");
+    MADE_REQUIRE(A >= 0 && P >= 0 && D > 0 && lda >= D, "made_pooled_cosine: bad dims");
+    if (A * P == 0) return MADE_OK;
+    const dim3 grid((unsigned)((A * P + 3) / 4)), block(256);
+    if (pooled_dtype == MADE_F32) hipLaunchKernelGGL(pooled_cosine_kernel<float>, grid, block, 0, (hipStream_t)stream, anchor, lda, (const float*)pooled, out, sa, sp, A, P, (int)D);
+    else hipLaunchKernelGGL(pooled_cosine_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, anchor, lda, (const bf16_t*)pooled, out, sa, sp, A, P, (int)D);
+    return made_check_launch("made_pooled_cosine");
+}
+
+extern "C" int made_scale_exp(const float* x, const float* logit_scale, float* out, int64_t n, void* stream) {
+    MADE_REQUIRE(x && logit_scale && out && n >= 0, "made_scale_exp: bad arguments");
+    if (n == 0) return MADE_OK;
+    hipLaunchKernelGGL(scale_exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, logit_scale, out, n);
+    return made_check_launch("made_scale_exp");
+}
+
+extern "C" int made_span_convert(const float* in, float* out, int64_t N, int32_t mode, void* stream) {
+    MADE_REQUIRE(in && out && N >= 0 && (mode == 0 || mode == 1), "made_span_convert: bad arguments");
+    if (N == 0) return MADE_OK;
+    hipLaunchKernelGGL(span_convert_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, (int)mode);
+    return made_check_launch("made_span_convert");
+}
+
+extern "C" int made_span_pairwise(const float* spans1, const float* spans2, float* iou, float* uni, float* giou, float* inter_over_2,
+                                  int64_t N, int64_t M, void* stream) {
+    MADE_REQUIRE(spans1 && spans2 && N >= 0 && M >= 0, "made_span_pairwise: bad arguments");
+    if (N * M == 0) return MADE_OK;
+    hipLaunchKernelGGL(span_pairwise_kernel, dim3((unsigned)((N * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, spans1, spans2, iou, uni, giou,
+                       inter_over_2, N, M);
+    return made_check_launch("made_span_pairwise");
+}
+
+extern "C" int made_span_iou_se(const float* pred_se, const float* gt_moment, const float* m_duration, int64_t N, float max_m_duration,
+                                int32_t clamp_to_max, int32_t discounted, float* iou_out, void* stream) {
+    MADE_REQUIRE(pred_se && gt_moment && m_duration && iou_out && N >= 0, "made_span_iou_se: bad arguments");
+    if (N == 0) return MADE_OK;
+    hipLaunchKernelGGL(span_iou_se_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred_se, gt_moment, m_duration, N,
+                       max_m_duration, (int)clamp_to_max, (int)discounted, iou_out);
+    return made_check_launch("made_span_iou_se");
 }

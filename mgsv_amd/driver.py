@@ -154,7 +154,9 @@ class MGSV_EC_Dataset(torch.utils.data.Dataset):
         v_dur = float(r["video_end"]) - float(r["video_start"])
         meta = {"video_id": video_id, "music_id": music_id, "v_duration": torch.tensor(v_dur), "m_duration": torch.tensor(m_duration),
                 "gt_moment": gt}
-        g = gt.clone()
+        # the reference clamps the end of the moment IN PLACE on the tensor it has already stored as meta_map["gt_moment"]
+        # (dataloader_MGSV_EC_feature.py:18-27,46-75), so the IoU ground truth is clamped too
+        g = gt
         g[:, 1] = torch.clamp(g[:, 1], max=a.max_m_duration)
         spans_target = torch.stack([(g[:, 0] + g[:, 1]) / 2.0 / a.max_m_duration, (g[:, 1] - g[:, 0]) / a.max_m_duration], dim=-1)
         ff, fm = self._features(a.frame_frozen_feature_path, "vit", video_id, a.max_v_frames, 512, v_dur)
@@ -177,7 +179,10 @@ def lr_factor(args, step: int, warmup_steps: int, total: int) -> float:
     if s == "constant":
         return 1.0
     if s == "exponential":
-        return args.decay_rate ** (step // max(args.lr_update_rate, 1))
+        # the reference steps its ExponentialLR when total_step % lr_update_rate == 0, checked BEFORE the increment (train-MaDe.py:
+        # 379-381): the first decay lands right after step 0, so step s has seen ceil(s / rate) decays
+        r = max(args.lr_update_rate, 1)
+        return args.decay_rate ** ((step + r - 1) // r)
     if step < warmup_steps:
         return float(step) / float(max(1.0, warmup_steps))
     if s == "warmupconstant":
@@ -221,14 +226,38 @@ def init_runtime(args):
     return device, dist, logger
 
 
-def build_model(args, device, logger):
+def save_model(epoch, args, logger, model, optimizer=None, loss=None, best_model=False, best_name="best"):
+    """reference utils/util_train.py:21-36: `pytorch_model.bin.<epoch | best_name>` under args.path_log with the keys epoch / loss /
+    model_state_dict / optimizer_state_dict."""
+    if args.save_model == 0:
+        return None
+    os.makedirs(args.path_log, exist_ok=True)
+    path = os.path.join(args.path_log, f"pytorch_model.bin.{best_name}" if best_model else f"pytorch_model.bin.{epoch}")
+    torch.save({"epoch": epoch, "loss": loss if loss is not None else "None",
+                "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "optimizer_state_dict": optimizer.state_dict() if optimizer is not None else "None"}, path)
+    logger.info("Model saved to %s", path)
+    return path
+
+
+def load_model(args, logger, model, path=None):
+    """reference utils/util_train.py:38-60 (stage 0): strict load of `model_state_dict` (or of a bare state dict); the frozen
+    `vit_model.` / `ast_model.` tensors a reference checkpoint also carries are never used on the feature path and are dropped by
+    Uni_model.load_state_dict.  Returns (model, resume_epoch, resume_loss)."""
+    path = path or args.resume_path or args.load_uni_model_path
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ckpt["model_state_dict"] if "model_state_dict" in ckpt else ckpt, strict=True)
+    if getattr(args, "rank", 0) == 0:
+        logger.info("Model loaded from %s", path)
+    return model, (ckpt["epoch"] if "epoch" in ckpt else 0), (ckpt["loss"] if "loss" in ckpt else 0)
+
+
+def build_model(args, device, logger, load: bool = True):
     from .model import Uni_model
     model = Uni_model(args, device, logger, compute_dtype=args.compute_dtype)
-    path = args.load_uni_model_path or args.resume_path
-    if path:
-        ckpt = torch.load(path, map_location="cpu")
-        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=False)
-        logger.info(f"loaded {path}")
+    path = args.resume_path or args.load_uni_model_path
+    if load and path and os.path.isfile(path):
+        load_model(args, logger, model, path)
     return model
 
 
@@ -376,18 +405,26 @@ def main_train(argv=None):
                                           {"params": model.get_detection_parameter(), "lr": args.detection_lr}])
         logger.info(f"train_length = {train_len}, val_length = {val_len}, total_step = {total_step}, warmup_steps = {warmup_steps}")
         args.total_step = 0
-        best = {"R1": -1.0, "epoch": 0}
+        # reference train-MaDe.py:686-727: four "best" checkpoints, each rewritten when its criterion is matched or beaten
+        best = {"R1": dict(v=0.0, epoch=0, name="best_r1", strict=False), "mIoU": dict(v=0.0, epoch=0, name="best_iou", strict=False),
+                "R1_iou0.5": dict(v=0.0, epoch=0, name="best_r1iou05", strict=True), "R1_iou0.7": dict(v=0.0, epoch=0, name="best_r1iou07", strict=False)}
         for epoch in range(args.start_epoch + 1, args.epochs + 1):
             if sampler is not None:
                 sampler.set_epoch(epoch)
             tl, tm = train_one_epoch(epoch, args, model, train_loader, optimizer, device, dist, logger, total_step, warmup_steps)
             logger.info(f"Epoch {epoch}/{args.epochs} Finished, Train Loss: {tl:.4f}, train mIoU {tm['mIoU']:.4f}")
             vl, ret, loc, com = eval_epoch(epoch, args, model, val_loader, device, dist, logger)
-            results[epoch] = dict(train_loss=tl, val_loss=vl, R1=ret["R1"], mIoU=loc["mIoU"])
-            if args.rank == 0 and args.save_model and ret["R1"] > best["R1"]:
-                best = {"R1": ret["R1"], "epoch": epoch}
-                os.makedirs(args.path_log, exist_ok=True)
-                torch.save({"epoch": epoch, "model_state_dict": model.state_dict()}, os.path.join(args.path_log, "best_R1.pth"))
+            results[epoch] = dict(train_loss=tl, val_loss=vl, R1=ret["R1"], mIoU=loc["mIoU"], R5=ret["R5"], R1_iou05=com["R1_iou0.5"],
+                                  R1_iou07=com["R1_iou0.7"])
+            if args.rank == 0:
+                now = {"R1": ret["R1"], "mIoU": loc["mIoU"], "R1_iou0.5": com["R1_iou0.5"], "R1_iou0.7": com["R1_iou0.7"]}
+                for key, b in best.items():
+                    if (now[key] > b["v"]) if b["strict"] else (now[key] >= b["v"]):
+                        b["v"], b["epoch"] = now[key], epoch
+                        save_model(epoch, args, logger, model, optimizer=optimizer, loss=vl, best_model=True, best_name=b["name"])
+                logger.info("Best R1: %.4f in epoch %d, Best mIoU: %.4f in epoch %d, Best R1IoU0.5: %.4f in epoch %d, Best R1IoU0.7: %.4f in epoch %d",
+                            best["R1"]["v"], best["R1"]["epoch"], best["mIoU"]["v"], best["mIoU"]["epoch"], best["R1_iou0.5"]["v"],
+                            best["R1_iou0.5"]["epoch"], best["R1_iou0.7"]["v"], best["R1_iou0.7"]["epoch"])
     elif args.do_eval:
         vl, ret, loc, com = eval_epoch(0, args, model, val_loader, device, dist, logger)
         results[0] = dict(val_loss=vl, R1=ret["R1"], mIoU=loc["mIoU"])
@@ -397,12 +434,45 @@ def main_train(argv=None):
 
 
 def main_test(argv=None):
+    """reference test-MaDe.py:472-520: --load_uni_model_path names one checkpoint file (`pytorch_model.*`), or a directory whose best
+    checkpoints (--test_best 1) or per-epoch checkpoints (`pytorch_model.bin.<epoch>`, start_epoch + 1 .. epochs) are evaluated in
+    turn.  Returns {checkpoint name: metrics}; a single file also under the keys loss / ret / loc / com."""
     args = parse_option(argv, for_test=True)
     device, dist, logger = init_runtime(args)
-    model = build_model(args, device, logger)
+    model = build_model(args, device, logger, load=False)
     loader, n, _ = make_loader(args.test_csv, args, args.batch_size_val, False, 1, 0)
     logger.info(f"test_length = {n}")
-    vl, ret, loc, com = eval_epoch(0, args, model, loader, device, dist, logger)
+    out = {}
+
+    def run(path, tag):
+        _, epoch, _ = load_model(args, logger, model, path)
+        vl, ret, loc, com = eval_epoch(epoch, args, model, loader, device, dist, logger)
+        out[tag] = dict(loss=vl, ret=ret, loc=loc, com=com, epoch=epoch)
+        return out[tag]
+
+    path = args.load_uni_model_path
+    if path == "":
+        # the reference does nothing without a checkpoint; scoring fresh weights is only useful as a plumbing check -- say so loudly
+        logger.warning("test: no --load_uni_model_path given -- evaluating FRESHLY INITIALISED weights (plumbing check only)")
+        vl, ret, loc, com = eval_epoch(0, args, model, loader, device, dist, logger)
+        out.update(loss=vl, ret=ret, loc=loc, com=com)
+    elif os.path.basename(path).split(".")[0] == "pytorch_model" and not os.path.isdir(path):
+        out.update(run(path, os.path.basename(path)))
+    elif args.test_best == 1:
+        for name in ("pytorch_model.bin.best_r1iou07", "pytorch_model.bin.best_r1iou05", "pytorch_model.bin.best_r1", "pytorch_model.bin.best_iou"):
+            f = os.path.join(path, name)
+            if not os.path.exists(f):
+                logger.info(f"Model {f} not exists")
+                continue
+            run(f, name)
+    else:
+        for epoch in range(args.start_epoch + 1, args.epochs + 1):
+            f = os.path.join(path, f"pytorch_model.bin.{epoch}")
+            if not os.path.exists(f):
+                logger.info(f"Model {f} not exists")
+                continue
+            r = run(f, f"pytorch_model.bin.{epoch}")
+            assert r["epoch"] == epoch, f"resume_epoch {r['epoch']} != epoch {epoch}"
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
-    return dict(loss=vl, ret=ret, loc=loc, com=com)
+    return out

@@ -128,8 +128,11 @@ class Uni_model(nn.Module):
         self.num_moment_queries = self.cfg.num_moment_queries
         self.aux_loss = self.cfg.aux_loss
         self.compute_dtype = compute_dtype or getattr(args, "compute_dtype", "f32")
-        # parameters and persistent buffers with the reference's names and shapes
-        sd = synth.make_state_dict(self.cfg, seed=0)
+        # parameters and persistent buffers with the reference's names and shapes, initialised module by module as the reference
+        # does (mgsv_amd/model/init.py) from args.seed -- every rank of a data-parallel run draws the same weights from the same
+        # seed, so no broadcast is needed.  (mgsv_amd.synth's N(0, 1/fan_in) weights are for tests and bench.py only.)
+        from .init import reference_init
+        sd = reference_init(self.cfg, seed=int(getattr(args, "seed", 0) or 0))
         xa = "video_guided_to_music_pooling_cross_transformer"
         xpool = _XPoolModule(self)
         for name, arr in sd.items():
@@ -180,7 +183,10 @@ class Uni_model(nn.Module):
         return res
 
     def _stamp(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # (the fused optimizer step updates the masters in place through raw pointers: neither data_ptr nor _version moves, so the
+        # trainer counts its own updates)
+        gen = self._trainer.generation if self._trainer is not None else 0
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (gen,)
 
     def _engine_ready(self, lane: int = 0) -> MadeEngine:
         """The forward executor with this module's current weights.  lane > 0: a further engine with its own workspace, so that an

@@ -42,6 +42,7 @@ class MadeTrainer(MadeEngine):
         self._init_master(state_dict)
         self.repack()
         self._tws: Dict[tuple, Dict[str, Tensor]] = {}
+        self.generation = 0                                  # bumped by every in-place update of the masters (optimizer_step)
         self.seed = 0
         self.training_dropout = True
 
@@ -256,6 +257,7 @@ class MadeTrainer(MadeEngine):
         """Three-group gradient clipping + Adam (reference train-MaDe.py:262-266,375-381) on the flat buffers, then repack()."""
         import ctypes as C
         self.opt_step += 1
+        self.generation += 1
         groups = (_lib.MadeAdamGroup * 3)()
         for i, lr in enumerate((lr_temporal, lr_matching, lr_detection)):
             groups[i].begin, groups[i].end = self.group_ranges[i]

@@ -3,6 +3,7 @@
 import json
 import os
 
+import numpy as np
 import pytest
 
 from mgsv_amd import driver
@@ -60,3 +61,20 @@ def test_flags_that_select_unbuilt_code_fail_loudly():
     args.with_cls_token, args.transformer_is_share, args.agg_module = 1, 1, "transf"
     c = MadeConfig.from_args(args)
     assert c.with_cls_token == 1 and c.transformer_is_share == 1 and c.agg_module == "transf"
+
+
+def test_fresh_weights_follow_the_reference_initialisers():
+    """args.seed seeds the initialisation; identity X-Pool projections, zero attention biases, LayerNorm 1 / 0, xavier DETR matrices
+    (reference modules/transformer.py:148-154, music_detr/transformer.py:46-49)."""
+    from mgsv_amd.config import cfg_native
+    from mgsv_amd.model.init import reference_init
+    c = cfg_native()
+    a, b, a2 = reference_init(c, 1), reference_init(c, 2), reference_init(c, 1)
+    assert all(np.array_equal(a[k], a2[k]) for k in a) and not np.array_equal(a["vit_proj.weight"], b["vit_proj.weight"])
+    xa = "video_guided_to_music_pooling_cross_transformer."
+    assert np.array_equal(a[xa + "cross_attn.k_proj.weight"], np.eye(c.D, dtype=np.float32)) and not a[xa + "linear_proj.bias"].any()
+    assert np.all(a["detr_transformer.decoder.norm.weight"] == 1) and not a["detr_transformer.encoder.layers.0.self_attn.in_proj_bias"].any()
+    w = a["detr_transformer.encoder.layers.0.linear1.weight"]
+    bound = np.sqrt(6.0 / (w.shape[0] + w.shape[1]))
+    assert np.abs(w).max() <= bound + 1e-6 and np.abs(w).max() > 0.95 * bound
+    assert abs(float(a["logit_scale"]) - np.log(1 / c.temperature_init_value)) < 1e-6

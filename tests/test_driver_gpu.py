@@ -53,3 +53,46 @@ def test_train_and_test_entry_points(tmp_path):
     res4 = driver.main_train(["--name", "t4", "--do_train", "--do_eval", "--epochs", "1", "--batch_size_train", "16", "--train_csv", tr, "--val_csv", va,
                               "--output_dir", str(tmp_path / "logs"), "--mml_localization", "regression"] + COMMON)
     assert np.isfinite(res4[1]["train_loss"]) and 0 <= res4[1]["mIoU"] <= 1
+
+
+def test_fused_training_updates_the_eval_weights_and_checkpoints_round_trip(tmp_path):
+    """(1) With the fused optimizer step (the default) the masters change in place through raw pointers; the evaluation after every epoch
+    must see the new weights (round 1 scored epoch-1 weights forever).  (2) The four best-* checkpoints carry the reference's file names
+    and keys, load strictly, and reproduce the validation metrics of the epoch that wrote them (reference utils/util_train.py:21-60,
+    train-MaDe.py:709-727, test-MaDe.py:486-514)."""
+    import glob
+
+    import torch
+
+    from mgsv_amd import driver
+    tr, va = str(tmp_path / "train.csv"), str(tmp_path / "val.csv")
+    _csv(tr, 48, 3); _csv(va, 32, 4)
+    common = [a if a != "0" or COMMON[i - 1] != "--save_model" else "1" for i, a in enumerate(COMMON)]
+    res = driver.main_train(["--name", "ck", "--do_train", "--do_eval", "--epochs", "3", "--batch_size_train", "16", "--train_csv", tr, "--val_csv", va,
+                             "--output_dir", str(tmp_path / "logs"), "--matching_lr", "1e-3", "--detection_lr", "1e-3", "--warmup_rate", "0.0",
+                             "--scheduler", "constant", "--seed", "7"] + common)
+    losses = [res[e]["val_loss"] for e in (1, 2, 3)]
+    assert len({round(v, 6) for v in losses}) == 3, f"validation loss did not move between epochs: {losses}"
+    logdir = glob.glob(str(tmp_path / "logs" / "*" / "*+ck"))
+    assert len(logdir) == 1
+    files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(logdir[0], "pytorch_model.bin.*")))
+    assert files == ["pytorch_model.bin.best_iou", "pytorch_model.bin.best_r1", "pytorch_model.bin.best_r1iou05", "pytorch_model.bin.best_r1iou07"] or \
+        set(files) >= {"pytorch_model.bin.best_iou", "pytorch_model.bin.best_r1", "pytorch_model.bin.best_r1iou07"}
+    ck = torch.load(os.path.join(logdir[0], "pytorch_model.bin.best_r1"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "loss", "model_state_dict", "optimizer_state_dict"}
+    ep = ck["epoch"]
+    out = driver.main_test(["--name", "ck", "--test_csv", va, "--output_dir", str(tmp_path / "logs2"), "--load_uni_model_path", logdir[0], "--test_best", "1",
+                            "--seed", "99"] + COMMON)
+    got = out["pytorch_model.bin.best_r1"]
+    assert got["epoch"] == ep
+    np.testing.assert_allclose(got["loss"], res[ep]["val_loss"], rtol=1e-5)
+    assert got["ret"]["R1"] == res[ep]["R1"] and abs(got["loc"]["mIoU"] - res[ep]["mIoU"]) < 1e-6
+    # a single checkpoint file
+    one = driver.main_test(["--name", "ck", "--test_csv", va, "--output_dir", str(tmp_path / "logs2"), "--load_uni_model_path",
+                            os.path.join(logdir[0], "pytorch_model.bin.best_r1")] + COMMON)
+    assert one["ret"] == got["ret"] and one["loc"] == got["loc"]
+    # strict loading: a checkpoint with a missing key is refused
+    bad = dict(ck); bad["model_state_dict"] = {k: v for k, v in ck["model_state_dict"].items() if k != "class_embed.weight"}
+    torch.save(bad, str(tmp_path / "pytorch_model.bin.bad"))
+    with pytest.raises(RuntimeError):
+        driver.main_test(["--name", "ck", "--test_csv", va, "--output_dir", str(tmp_path / "logs2"), "--load_uni_model_path", str(tmp_path / "pytorch_model.bin.bad")] + COMMON)
