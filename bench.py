@@ -199,10 +199,13 @@ def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> di
     mask = (torch.arange(S, device=dev)[None] < lens[:, None]).float()
     seg = (seg * mask[:, :, None]).to(eng.tc)
     mu = torch.nn.functional.normalize(torch.randn(mhi - mlo, D, device=dev, generator=g), dim=-1)
-    sr = ShardedRetrieval(lambda a, b, c, d: eng.retrieval_sim_matrix(a, b, c, d))
+    # the music side travels as one packed buffer (bf16 segments + masks + pooled vectors) in ONE all-gather; the split's partition is
+    # known on every rank, so nothing is read back to the host
+    sr = ShardedRetrieval(lambda a, b, c, d: eng.retrieval_sim_matrix(a, b, c, d), pack_dtype=eng.tc)
+    mcounts = [shard_rows(N_m, world, r)[1] - shard_rows(N_m, world, r)[0] for r in range(world)]
 
     def step():
-        return sr.sim_rows(v, seg, mask, mu)
+        return sr.sim_rows(v, seg, mask, mu, counts=mcounts)
 
     for _ in range(max(warmup, 1)):
         rows = step()

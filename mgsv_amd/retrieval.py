@@ -20,13 +20,15 @@ import torch.distributed as dist
 Tensor = torch.Tensor
 
 
-def _all_gather_ragged(t: Tensor, group=None) -> Tuple[Tensor, List[int]]:
-    """All-gather along dim 0 when ranks hold different row counts: pad to the largest shard, gather, trim."""
+def _all_gather_ragged(t: Tensor, group=None, counts: Optional[List[int]] = None) -> Tuple[Tensor, List[int]]:
+    """All-gather along dim 0 when ranks hold different row counts: pad to the largest shard, gather, trim.  `counts` (rows per rank,
+    e.g. from shard_rows) saves the count exchange and its host synchronisation."""
     world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+        cl = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(cl, n, group=group)
+        counts = [int(c.item()) for c in cl]
     mx = max(counts)
     if t.shape[0] < mx:
         pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
@@ -46,28 +48,82 @@ def shard_rows(n: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 class ShardedRetrieval:
-    def __init__(self, score_fn: Callable[[Tensor, Tensor, Tensor, Tensor], Tensor], group=None):
+    """`pack_dtype`: dtype the per-segment embeddings travel in (bf16 when the scoring kernel consumes bf16: half the bytes of the one
+    large tensor).  The music side travels as ONE packed buffer per track -- [S*D segment embeddings | S mask floats | D pooled
+    vector] -- in ONE all-gather; with `counts` (tracks per rank, known from the split's partition: shard_rows) nothing is read back
+    to the host.  Unequal shards are scored block by block straight out of the gathered buffer (no compaction copy)."""
+
+    def __init__(self, score_fn: Callable[[Tensor, Tensor, Tensor, Tensor], Tensor], group=None, pack_dtype: Optional[torch.dtype] = None):
         self.score_fn = score_fn
         self.group = group
+        self.pack_dtype = pack_dtype
 
-    def gather_music_side(self, seg_local: Tensor, mask_local: Tensor, music_local: Tensor):
-        """One exchange step: every rank ends up with all tracks, in rank order."""
-        if not (dist.is_available() and dist.is_initialized()):
-            return seg_local, mask_local, music_local
-        seg_all, _ = _all_gather_ragged(seg_local, self.group)
-        mask_all, _ = _all_gather_ragged(mask_local, self.group)
-        music_all, _ = _all_gather_ragged(music_local, self.group)
-        return seg_all, mask_all, music_all
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
-    def sim_rows(self, video_local: Tensor, seg_local: Tensor, mask_local: Tensor, music_local: Tensor) -> Tensor:
+    @staticmethod
+    def _layout(S: int, D: int, esz: int):
+        a = S * D * esz                       # segment embeddings
+        b = a + S * 4                         # + mask (f32)
+        c = b + D * 4                         # + pooled music vector (f32)
+        return a, b, (c + 15) // 16 * 16      # 16-byte aligned records (S*D*esz is a multiple of 4 for every esz we send)
+
+    def gather_music_side(self, seg_local: Tensor, mask_local: Tensor, music_local: Tensor, counts: Optional[List[int]] = None):
+        """One exchange step.  Returns a list of per-source-rank blocks [(seg [c, S, D], mask [c, S], music [c, D]), ...] in rank order:
+        views into the gathered buffer (one block covering everything when all shards have the same size)."""
+        if not self._active():
+            return [(seg_local, mask_local, music_local)]
+        world = dist.get_world_size(self.group)
+        n, S, D = seg_local.shape
+        sdt = self.pack_dtype or seg_local.dtype
+        esz = torch.empty((), dtype=sdt).element_size()
+        a, b, rec = self._layout(S, D, esz)
+        if counts is None:
+            cnt = torch.tensor([n], device=seg_local.device, dtype=torch.int64)
+            cl = [torch.zeros_like(cnt) for _ in range(world)]
+            dist.all_gather(cl, cnt, group=self.group)
+            counts = [int(x.item()) for x in cl]             # (pass `counts` to avoid this synchronisation)
+        assert len(counts) == world and counts[dist.get_rank(self.group)] == n
+        mx = max(counts)
+        send = torch.zeros(mx, rec, device=seg_local.device, dtype=torch.uint8)
+        send[:n, :a].view(sdt).view(n, S, D).copy_(seg_local)              # (converts to the travel dtype)
+        send[:n, a:b].view(torch.float32).view(n, S).copy_(mask_local)
+        send[:n, b:b + D * 4].view(torch.float32).view(n, D).copy_(music_local)
+        recv = torch.empty(world * mx, rec, device=seg_local.device, dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+
+        def views(lo, cnt_):
+            blk = recv[lo:lo + cnt_]
+            seg = blk[:, :a].view(sdt).view(cnt_, S, D)                    # row stride = rec bytes: strided, unit inner stride
+            mask = blk[:, a:b].view(torch.float32).view(cnt_, S)
+            music = blk[:, b:b + D * 4].view(torch.float32).view(cnt_, D)
+            return seg, mask, music
+
+        if all(c == mx for c in counts):
+            return [views(0, world * mx)]
+        return [views(r * mx, c) for r, c in enumerate(counts) if c > 0]
+
+    def sim_rows(self, video_local: Tensor, seg_local: Tensor, mask_local: Tensor, music_local: Tensor,
+                 counts: Optional[List[int]] = None) -> Tensor:
         """This rank's complete rows of the similarity matrix: [n_v_local, N_m]."""
-        seg_all, mask_all, music_all = self.gather_music_side(seg_local, mask_local, music_local)
-        return self.score_fn(video_local, seg_all, mask_all, music_all)
+        blocks = self.gather_music_side(seg_local, mask_local, music_local, counts)
+        if len(blocks) == 1:
+            return self.score_fn(video_local, *blocks[0])
+        n_m = sum(b[0].shape[0] for b in blocks)
+        out = None
+        off = 0
+        for seg, mask, music in blocks:
+            part = self.score_fn(video_local, seg, mask, music)
+            if out is None:
+                out = torch.empty(video_local.shape[0], n_m, device=part.device, dtype=part.dtype)
+            out[:, off:off + seg.shape[0]] = part
+            off += seg.shape[0]
+        return out
 
     def sim_matrix(self, video_local: Tensor, seg_local: Tensor, mask_local: Tensor, music_local: Tensor,
-                   gather_rows: bool = True) -> Tensor:
-        rows = self.sim_rows(video_local, seg_local, mask_local, music_local)
-        if not gather_rows or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+                   gather_rows: bool = True, counts: Optional[List[int]] = None, video_counts: Optional[List[int]] = None) -> Tensor:
+        rows = self.sim_rows(video_local, seg_local, mask_local, music_local, counts)
+        if not gather_rows or not self._active():
             return rows
-        full, _ = _all_gather_ragged(rows, self.group)
+        full, _ = _all_gather_ragged(rows, self.group, video_counts)
         return full

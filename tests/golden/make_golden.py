@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from mgsv_amd.config import MadeConfig, cfg_plumbing, cfg_native  # noqa: E402
+from mgsv_amd.config import cfg_headline, MadeConfig, cfg_plumbing, cfg_native  # noqa: E402
 from mgsv_amd import synth  # noqa: E402
 from oracle import ref_import  # noqa: E402
 
@@ -271,7 +271,18 @@ def metrics_fixture():
     print("wrote metrics", len(fix), "entries; R1 =", met["R1"], "mIoU =", loc["mIoU"])
 
 
+def bench_shape_fixtures():
+    """Gradients of the reference at the shapes bench.py times: BASELINE configs[2] (D = 512, T_a = 512) and the per-GPU shape of
+    configs[4] (T_a = 1024: the audio position table is rebuilt for 1024 positions on both sides), B = 2."""
+    train_fixture(cfg_headline(), 2, 30, 512, "train_cfg2_B2", {"_cfg": "headline"})
+    c = cfg_headline(); c.max_snippet_num = 1024; c.audio_attention_seqlen = 1024
+    train_fixture(c, 2, 30, 1024, "train_cfg4_Ta1024_B2", {"_cfg": "headline", "max_snippet_num": 1024, "audio_attention_seqlen": 1024})
+
+
 def main():
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "bench_shapes":
+        return bench_shape_fixtures()
     variants_fixture()
     metrics_fixture()
     train_fixture(cfg_native(), 3, 20, 40, "train_native_B3", {})

@@ -37,8 +37,18 @@ def _worker(rank, world, port, N_v, N_m, S, out_dir):
     sr = ShardedRetrieval(score)
     rows = sr.sim_rows(ri["video_embeds"][vlo:vhi], ri["segment_embeds"][mlo:mhi], ri["segment_masks"][mlo:mhi],
                        ri["music_embeds"][mlo:mhi])
+    # the same with the partition known up front: one packed all-gather, no count exchange, nothing read back to the host
+    mcounts = [shard_rows(N_m, world, r)[1] - shard_rows(N_m, world, r)[0] for r in range(world)]
+    vcounts = [shard_rows(N_v, world, r)[1] - shard_rows(N_v, world, r)[0] for r in range(world)]
     full = sr.sim_matrix(ri["video_embeds"][vlo:vhi], ri["segment_embeds"][mlo:mhi], ri["segment_masks"][mlo:mhi],
-                         ri["music_embeds"][mlo:mhi], gather_rows=True)
+                         ri["music_embeds"][mlo:mhi], gather_rows=True, counts=mcounts, video_counts=vcounts)
+    # equal shards (one block straight out of the gathered buffer) with the segments travelling in bf16
+    n_eq = (N_m // world) * world
+    elo, ehi = shard_rows(n_eq, world, rank)
+    sr16 = ShardedRetrieval(lambda v, s, m, mu: score(v, s.float(), m, mu), pack_dtype=torch.bfloat16)
+    rows16 = sr16.sim_rows(ri["video_embeds"][vlo:vhi], ri["segment_embeds"][elo:ehi], ri["segment_masks"][elo:ehi], ri["music_embeds"][elo:ehi],
+                           counts=[n_eq // world] * world)
+    np.save(os.path.join(out_dir, f"rows16_{rank}.npy"), rows16.numpy())
     np.save(os.path.join(out_dir, f"rows{rank}.npy"), rows.numpy())
     np.save(os.path.join(out_dir, f"full{rank}.npy"), full.numpy())
     dist.barrier()
@@ -61,6 +71,11 @@ def test_sharded_retrieval_world2_matches_single_rank(tmp_path):
         assert rows.shape == (hi - lo, N_m)
         np.testing.assert_allclose(rows, ref[lo:hi], atol=1e-6, rtol=0)
         np.testing.assert_allclose(np.load(tmp_path / f"full{rank}.npy"), ref, atol=1e-6, rtol=0)
+        n_eq = (N_m // world) * world
+        seg16 = torch.from_numpy(ri["segment_embeds"][:n_eq]).bfloat16().float().numpy()
+        with torch.no_grad():
+            ref16 = O.retrieval_sim_matrix(P, cfg, ri["video_embeds"][lo:hi], seg16, ri["segment_masks"][:n_eq], ri["music_embeds"][:n_eq]).numpy()
+        np.testing.assert_allclose(np.load(tmp_path / f"rows16_{rank}.npy"), ref16, atol=1e-6, rtol=0)
 
 
 def test_shard_rows_partition():
