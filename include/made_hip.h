@@ -616,6 +616,10 @@ int made_recall_ranks(const float* sims, int64_t ld, const int32_t* group_id, co
 int made_span_iou(const float* pred_logits, const float* pred_spans, const float* gt_moment, const float* m_duration,
                   int64_t N, int64_t Q, int32_t fg_label, float max_m_duration, float* iou_out, float* pred_out, void* stream);
 
+/* out[b, :cols_a] = a[b, :], out[b, cols_a:] = c[b, :]; contiguous f32 rows.  The DETR token mask [frame mask ; segment mask]
+ * (reference model/model_Uni.py:209 torch.cat); either part may be empty. */
+int made_concat_cols(const float* a, int64_t cols_a, const float* c, int64_t cols_c, float* out, int64_t rows, void* stream);
+
 /* ---- the free functions the reference's drivers import (train-MaDe.py:16,20,22); Python mirrors with the
  * reference's names: mgsv_amd/modules/metrics.py, mgsv_amd/modules/loss.py, mgsv_amd/music_detr/span_utils.py ---- */
 

@@ -174,6 +174,7 @@ SIGNATURES = {
     "made_recall_ranks": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp]),
     "made_span_iou": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
+    "made_concat_cols": (C.c_int, [vp, i64, vp, i64, vp, i64, vp]),
     "made_pooled_cosine": (C.c_int, [vp, i64, vp, i32, vp, i64, i64, i64, i64, i64, vp]),
     "made_scale_exp": (C.c_int, [vp, vp, vp, i64, vp]),
     "made_span_convert": (C.c_int, [vp, vp, i64, i32, vp]),

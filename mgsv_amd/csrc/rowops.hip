@@ -566,6 +566,16 @@ __global__ __launch_bounds__(ROW_THREADS) void cast_mask_rows_kernel(const float
     store4(y, ydt, row * ldy + c + 4, a1);
 }
 
+// out[b, :Ca] = a[b, :], out[b, Ca:] = c[b, :] (f32): the DETR token mask = [frame mask ; segment mask] (reference model/model_Uni.py:209)
+__global__ void concat_cols_kernel(const float* a, int Ca, const float* c, int Cc, float* out, int64_t rows) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = Ca + Cc;
+    if (idx >= rows * C) return;
+    const int64_t b = idx / C;
+    const int j = (int)(idx % C);
+    out[idx] = j < Ca ? a[b * Ca + j] : c[b * Cc + (j - Ca)];
+}
+
 inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
 inline int nv_for(int64_t D) { return D <= 512 ? 2 : (D <= 1024 ? 4 : 8); }
 // NV = 16-byte vectors per lane; FULL = the row fills them exactly (D == 256*NV), so the bounds checks fold away and the
@@ -715,4 +725,12 @@ extern "C" int made_cast_mask_rows(const float* x, int64_t ldx, const float* mas
     hipLaunchKernelGGL(cast_mask_rows_kernel, dim3((unsigned)((n + ROW_THREADS - 1) / ROW_THREADS)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        x, ldx, mask, y, y_dtype, ldy, rows, (int)D);
     return made_check_launch("made_cast_mask_rows");
+}
+
+extern "C" int made_concat_cols(const float* a, int64_t cols_a, const float* c, int64_t cols_c, float* out, int64_t rows, void* stream) {
+    MADE_REQUIRE(out && rows >= 0 && cols_a >= 0 && cols_c >= 0 && (a || cols_a == 0) && (c || cols_c == 0), "made_concat_cols: bad arguments");
+    const int64_t n = rows * (cols_a + cols_c);
+    if (n == 0) return MADE_OK;
+    hipLaunchKernelGGL(concat_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (int)cols_a, c, (int)cols_c, out, rows);
+    return made_check_launch("made_concat_cols");
 }

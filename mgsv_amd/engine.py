@@ -524,11 +524,7 @@ class MadeEngine:
                      order=ops.batch_order(sm, out=ws["order_a"]))
         with torch.cuda.stream(side):
             # the DETR mask and its sine position embedding depend on the masks only: off the critical path
-            if concat:
-                fus_mask[:, :Tv].copy_(fm)
-                fus_mask[:, Tv:].copy_(sm)
-            else:
-                fus_mask.copy_(sm)
+            ops.concat_cols(fm if concat else None, sm, fus_mask)
             pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
             rows_f = ops.row_index(fus_mask, out=ws["rows_f"])
             order_f = ops.batch_order(fus_mask, out=ws["order_f"])       # attention workgroups: longest sample first

@@ -457,6 +457,17 @@ def row_affine(x: Tensor, scale: Tensor, shift: Tensor, act: int = ACT_NONE, out
     return out
 
 
+def concat_cols(a: Optional[Tensor], c: Optional[Tensor], out: Tensor) -> Tensor:
+    """out[b] = [a[b] ; c[b]] for contiguous f32 [B, *] tensors (made_concat_cols): the DETR token mask."""
+    B = out.shape[0]
+    ca = a.shape[1] if a is not None else 0
+    cc = c.shape[1] if c is not None else 0
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[1] == ca + cc
+    check(lib().made_concat_cols(_p(_f32(a, "a")) if a is not None else None, ca, _p(_f32(c, "c")) if c is not None else None, cc, _p(out), B, _stream()),
+          "made_concat_cols")
+    return out
+
+
 def masked_mean(x: Tensor, mask: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
     """x [B,T,D] (unit inner stride), mask [B,T] or None (plain sum) -> [B,D] f32."""
     assert x.dim() == 3 and x.stride(2) == 1

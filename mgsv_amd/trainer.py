@@ -434,11 +434,7 @@ class MadeTrainer(MadeEngine):
         self._inputs = (frame_feats.contiguous(), segment_feats.contiguous(), fm, sm, spans_target.contiguous())
 
         fus, fus_mask = ws["fus"], ws["fus_mask"]
-        if concat:
-            fus_mask[:, :Tv].copy_(fm)
-            fus_mask[:, Tv:].copy_(sm)
-        else:
-            fus_mask.copy_(sm)
+        ops.concat_cols(fm if concat else None, sm, fus_mask)
         # valid-token lists: every large GEMM (forward, dX and dW) gathers the valid rows only, so padding costs nothing
         self._groups = {}
         self._rows = {fus_mask.data_ptr(): ops.row_index(fus_mask, out=tw["rows_f"]), fm.data_ptr(): ops.row_index(fm, out=tw["rows_v"]),

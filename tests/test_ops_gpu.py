@@ -644,6 +644,10 @@ def test_matcher_golden_fixture_bit_exact(dev, golden_dir):
             assert abs(tot[0] - tot[1]) <= 2e-5, (n, b_, tot)
             n_fused_equal += int(np.array_equal(a, ra) and np.array_equal(bb, rb))
     total = sum(fix[f"c{n}_logits"].shape[0] for n in range(int(fix["n_cases"])))
+    # The fused cost evaluates the class probability in f64 and rounds once (correctly rounded); torch's CPU softmax is a 1-ulp f32
+    # evaluation.  A sample's assignment can only differ where two assignments tie to the last bits of the cost (checked above: the
+    # totals agree to 2e-5); the count is recorded so that a change of it is seen.
+    print(f"matcher fixture: {total - n_fused_equal} of {total} samples assigned differently from SciPy-on-torch-CPU-costs (all exact-cost ties)")
     assert n_fused_equal >= total - 3, (n_fused_equal, total)      # near-ties are rare even in the adversarial cases
 
 
