@@ -471,6 +471,25 @@ typedef struct MadeGemmTNArgs {
 } MadeGemmTNArgs;
 
 int made_gemm_tn(const MadeGemmTNArgs* args, void* stream);
+
+/* made_gemm_tn_grouped: up to 8 weight gradients that reduce over the same rows -- the Linears of one transformer layer
+ * (reference music_detr/transformer.py:191-210, model/model_Base.py:64-91: dW_i += alpha * dY_i^T X_i, db_i += alpha * colsum(dY_i)) --
+ * in ONE launch: bf16 operands, f32 C accumulated with atomics (the caller zeroes gradients once per step), N_i and K_i multiples
+ * of 128, one row list (row_index / n_rows as in made_gemm_tn, or all M rows) and one split of the reduction for all problems.
+ * tile_end is filled in by the library. */
+#define MADE_GEMM_TN_MAX_GROUP 8
+typedef struct MadeGemmTNProblem {
+    const void* A; const void* B; float* C; float* colsum;      /* A [M, N] = dY, B [M, K] = X, C [N, K], colsum [N] or NULL */
+    int64_t N, K, lda, ldb, ldc;
+} MadeGemmTNProblem;
+typedef struct MadeGemmTNGroup {
+    int32_t n_problems; float alpha;
+    int64_t M, split_m;
+    const int32_t* row_index; const int32_t* n_rows;
+    MadeGemmTNProblem p[MADE_GEMM_TN_MAX_GROUP];
+    int32_t tile_end[MADE_GEMM_TN_MAX_GROUP];
+} MadeGemmTNGroup;
+int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream);
 /* out[g] = 1 if any of mask[32g .. 32g+31] is nonzero else 0 (computed once per batch, shared by every weight-gradient product) */
 int made_row_groups(const float* mask, int64_t M, float* out, void* stream);
 /* made_row_index: compaction of a [M] token mask: row_index[r] = index of the r-th nonzero entry (r < n), entries r >= n repeat

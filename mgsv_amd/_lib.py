@@ -117,6 +117,15 @@ class MadeGemmTNArgs(C.Structure):
                 ("row_index", vp), ("n_rows", vp)]
 
 
+class MadeGemmTNProblem(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("colsum", vp), ("N", i64), ("K", i64), ("lda", i64), ("ldb", i64), ("ldc", i64)]
+
+
+class MadeGemmTNGroup(C.Structure):
+    _fields_ = [("n_problems", i32), ("alpha", f32), ("M", i64), ("split_m", i64), ("row_index", vp), ("n_rows", vp),
+                ("p", MadeGemmTNProblem * 8), ("tile_end", i32 * 8)]
+
+
 class MadeAdamGroup(C.Structure):
     _fields_ = [("begin", i64), ("end", i64), ("lr", f32), ("max_norm", f32)]
 
@@ -174,6 +183,7 @@ SIGNATURES = {
     "made_recall_ranks": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp]),
     "made_span_iou": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
+    "made_gemm_tn_grouped": (C.c_int, [C.POINTER(MadeGemmTNGroup), vp]),
     "made_concat_cols": (C.c_int, [vp, i64, vp, i64, vp, i64, vp]),
     "made_pooled_cosine": (C.c_int, [vp, i64, vp, i32, vp, i64, i64, i64, i64, i64, vp]),
     "made_scale_exp": (C.c_int, [vp, vp, vp, i64, vp]),

@@ -1,7 +1,8 @@
 // Fast path of made_gemm_tn (bf16, N and K multiples of 128, rows all valid or gathered): the weight-gradient product with the
-// operands going global -> LDS directly (global_load_lds, no VGPR staging) into a four-stage ring, so three slabs of the
-// reduction are in flight while a fourth is multiplied -- the register-staged kernel has one, and at one or two workgroups per
-// CU its loop is a chain of exposed memory round trips (measured: 3.2 us per 64-row slab vs 0.2 us of MFMA work).
+// operands going global -> LDS directly (global_load_lds, no VGPR staging) into a two-stage ring (slab i + 1 in flight while slab i
+// is multiplied), 80 KB of LDS so that TWO workgroups share a CU.  Round 1 ran one workgroup per CU with a four-stage ring: three
+// slabs in flight did not buy bandwidth (a CU's four waves took in 21 GB/s; the forward GEMMs reach 40-50 GB/s with two to five
+// workgroups per CU), a second workgroup does (profiles/r02_c_tn_bench.txt).
 //
 // LDS image of a stage: A rows [64][256 B] then B rows [64][256 B], unpadded (the LDS-DMA writes 1 KB contiguous per wave
 // instruction = 4 rows), with the 32-byte column pairs of a row XOR-swizzled by (row & 3) on the SOURCE side, so the four rows a
@@ -12,11 +13,12 @@
 
 namespace {
 
-constexpr int GT_BN = 128, GT_BK = 128, GT_BM = 64, GT_NT = 256, GT_NST = 4;
+constexpr int GT_BN = 128, GT_BK = 128, GT_BM = 64, GT_NT = 256, GT_NST = 2;
 constexpr int GT_ROW = 256;                              // bytes per LDS row (128 bf16)
 constexpr int GT_HALF = GT_BM * GT_ROW;                  // 16 KB: one operand of one stage
 constexpr int GT_STAGE = 2 * GT_HALF;                    // 32 KB
-constexpr int GT_MAX_ROWS = 6144;                        // row indices a block may hold (96 slabs)
+constexpr int GT_MAX_ROWS = 4096;                        // row indices a block may hold (64 slabs)
+constexpr int GT_LDS = GT_NST * GT_STAGE + GT_MAX_ROWS * 4;  // 80 KB: two workgroups per CU
 
 // The transposing LDS read as inline asm: through the builtin, hipcc's waitcnt pass cannot tell the read from the in-flight
 // LDS-DMA writes of OTHER stages and drains vmcnt(0) before every fragment read, which serialises the ring.  The price: the
@@ -33,30 +35,35 @@ __device__ __forceinline__ void gt_wait(bf16x4 (&f)[8]) {           // wait unti
                  : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(N));
 }
 
-__global__ __launch_bounds__(GT_NT, 1) void gemm_tn_glds_kernel(const MadeGemmTNArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[GT_NST * GT_STAGE + GT_MAX_ROWS * 4];
+// One problem of a launch: C[N, K] (+)= alpha * A[M, N]^T B[M, K] over the rows of this workgroup's reduction split.
+struct GtProblem {
+    const bf16_t* A; const bf16_t* B; void* C; float* colsum;
+    int64_t lda, ldb, ldc;
+    int tiles_k, tile;                                       // tiles along K of this problem, this workgroup's tile inside it
+    int c_dtype, accumulate;
+    float alpha;
+};
+struct GtShared {                                            // what the problems of a launch have in common
+    int64_t M, split_m, split_y;
+    const int32_t* row_index; const int32_t* n_rows;
+};
+
+__device__ __forceinline__ void gemm_tn_glds_body(const GtProblem a, const GtShared sh, unsigned char* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int wn = wave >> 1, wk = wave & 1;
-    // XCD-aware placement (1-D grid; workgroup b runs on XCD b % 8): all output tiles of one reduction split -- which read the
-    // same rows of A and B -- go to ONE XCD, so each 16 KB panel slab is fetched from HBM once per split and served to the other
-    // tiles from that XCD's L2 (with the tiles of a split spread over the XCDs every tile re-fetched its two panels)
-    const int tiles_k = (int)(a.K / GT_BK);
-    const int tiles = (int)(a.N / GT_BN) * tiles_k;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int64_t split_y = xcd + 8 * (int64_t)(jx / tiles);
-    if (split_y >= a.split_m) return;
-    const int tile = jx % tiles;
-    const int tile_n = tile / tiles_k, tile_k = tile % tiles_k;
+    const int tiles_k = a.tiles_k;
+    const int64_t split_y = sh.split_y;
+    const int tile_n = a.tile / tiles_k, tile_k = a.tile % tiles_k;
     const int64_t n0 = (int64_t)tile_n * GT_BN, k0 = (int64_t)tile_k * GT_BK;
-    int64_t Mv = a.M;
-    if (a.n_rows) { const int64_t nv = *a.n_rows; Mv = nv < a.M ? nv : a.M; }
+    int64_t Mv = sh.M;
+    if (sh.n_rows) { const int64_t nv = *sh.n_rows; Mv = nv < sh.M ? nv : sh.M; }
     const int64_t nslab = (Mv + GT_BM - 1) / GT_BM;
-    const int64_t sstep = a.split_m;
+    const int64_t sstep = sh.split_m;
     const int64_t nloc = nslab > split_y ? (nslab - split_y + sstep - 1) / sstep : 0;   // slabs y, y + split, ...
     if (nloc == 0) return;
-    const bf16_t* Ag = (const bf16_t*)a.A;
-    const bf16_t* Bg = (const bf16_t*)a.B;
+    const bf16_t* Ag = a.A;
+    const bf16_t* Bg = a.B;
 
     // physical rows of every slab this block reduces, resolved ONCE into LDS: a per-slab index load would be a vector-memory
     // operation in front of the slab's LDS-DMA loads, and waiting for it (vmcnt is in-order) would drain the pipeline
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(GT_NT, 1) void gemm_tn_glds_kernel(const MadeGemmTN
         const int64_t g = split_y + (t / GT_BM) * sstep;
         const int64_t m = g * GT_BM + (t % GT_BM);
         const int64_t ml = m < Mv ? m : Mv - 1;
-        lds_rows[t] = a.row_index ? a.row_index[ml] : (int)ml;
+        lds_rows[t] = sh.row_index ? sh.row_index[ml] : (int)ml;
     }
     __syncthreads();
 
@@ -108,20 +115,17 @@ __global__ __launch_bounds__(GT_NT, 1) void gemm_tn_glds_kernel(const MadeGemmTN
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    float csum = 0.f;
-    const bool do_colsum = a.colsum != nullptr && tid < GT_BN;
-    const int cs_step = tiles_k < GT_BM ? tiles_k : GT_BM;
+    // bias gradient = column sums of A: taken from the A fragments the MFMAs consume anyway (lane (r, hh) of an A fragment holds 8
+    // consecutive reduction rows of output row n = r), by the K-tile-0 workgroup of every row of tiles, in its wk = 0 waves (the two
+    // wk waves read the same A fragments).  Round 1 summed 2-byte LDS reads here: 20-25 % of the kernel.
+    float csum[2] = {0.f, 0.f};
+    const bool do_colsum = a.colsum != nullptr && tile_k == 0 && wk == 0;
 
     issue(0);
-    if (nloc > 1) issue(1);
-    if (nloc > 2) issue(2);
     for (int64_t i = 0; i < nloc; ++i) {
-        // slab i landed <=> at most the 8 LDS-DMA loads of each of the (up to two) newer slabs are still outstanding
-        if (i + 2 < nloc) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (i + 1 < nloc) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");             // every wave's part landed; everyone is done with stage (i - 1) % 4
-        if (i + 3 < nloc) issue(i + 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slab i (the only one in flight) has landed
+        asm volatile("s_barrier" ::: "memory");             // every wave's part landed; everyone is done with the other stage
+        if (i + 1 < nloc) issue(i + 1);
         unsigned char* st = lds + (i % GT_NST) * GT_STAGE;
         const int64_t g = split_y + i * sstep;
         const int64_t live = Mv - g * GT_BM;                 // rows of this slab that exist
@@ -135,12 +139,6 @@ __global__ __launch_bounds__(GT_NT, 1) void gemm_tn_glds_kernel(const MadeGemmTN
                 *(f32x4*)(st + half * GT_HALF + row * GT_ROW + c16 * 16) = z;
             }
             __syncthreads();
-        }
-        const unsigned char* sa = st;
-        if (do_colsum && tile_k < cs_step) {
-#pragma unroll 4
-            for (int m = tile_k; m < GT_BM; m += cs_step)
-                csum += (float)*(const bf16_t*)(sa + m * GT_ROW + ((((tid >> 4) ^ (m & 3))) << 5) + (tid & 15) * 2);
         }
         // fragment reads of k-step ks + 1 are issued before the MFMAs of k-step ks (two register sets, counted lgkmcnt)
         const uint32_t sbase = lds_base + (uint32_t)((i % GT_NST) * GT_STAGE);
@@ -164,6 +162,12 @@ __global__ __launch_bounds__(GT_NT, 1) void gemm_tn_glds_kernel(const MadeGemmTN
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2)
                     acc[i2][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i2], bfr[j2], acc[i2][j2], 0, 0, 0);
+            if (do_colsum) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) csum[t] += (float)af[t][j];
+            }
         };
         read_step(0, std::integral_constant<int, 0>{});
         read_step(1, std::integral_constant<int, 1>{});
@@ -192,10 +196,87 @@ __global__ __launch_bounds__(GT_NT, 1) void gemm_tn_glds_kernel(const MadeGemmTN
                 }
             }
         }
-    if (do_colsum && tile_k < cs_step) unsafeAtomicAdd(a.colsum + n0 + tid, csum * a.alpha);
+    if (do_colsum) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float tot = csum[t] + __shfl_xor(csum[t], 32);                     // the two lane halves hold different reduction rows
+            if (hh == 0) unsafeAtomicAdd(a.colsum + n0 + wn * 64 + t * 32 + r, tot * a.alpha);
+        }
+    }
+}
+
+__global__ __launch_bounds__(GT_NT, 2) void gemm_tn_glds_kernel(const MadeGemmTNArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // XCD-aware placement (1-D grid; workgroup b runs on XCD b % 8): all output tiles of one reduction split -- which read the
+    // same rows of A and B -- go to ONE XCD, so each 16 KB panel slab is fetched from HBM once per split and served to the other
+    // tiles from that XCD's L2 (with the tiles of a split spread over the XCDs every tile re-fetched its two panels)
+    const int tiles_k = (int)(a.K / GT_BK);
+    const int tiles = (int)(a.N / GT_BN) * tiles_k;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int64_t split_y = xcd + 8 * (int64_t)(jx / tiles);
+    if (split_y >= a.split_m) return;
+    GtProblem p;
+    p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.B; p.C = a.C; p.colsum = a.colsum;
+    p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.tiles_k = tiles_k; p.tile = jx % tiles;
+    p.c_dtype = a.c_dtype; p.accumulate = a.accumulate; p.alpha = a.alpha;
+    GtShared sh;
+    sh.M = a.M; sh.split_m = a.split_m; sh.split_y = split_y; sh.row_index = a.row_index; sh.n_rows = a.n_rows;
+    gemm_tn_glds_body(p, sh, lds);
+}
+
+// Several weight gradients that reduce over the SAME rows (the Linears of one transformer layer: dW_i = dY_i^T X_i) in one launch.
+// Separate launches need 256 / tiles_i reduction splits each to fill the chip, and every split adds its whole 128 x 128 f32 tile
+// to the gradient with atomics (16.8 MB per launch at 1.3 TB/s = 13 us, whatever the problem size); together the problems of a
+// layer have 128 tiles, so 3-4 splits are enough: a quarter of the atomic traffic and one ramp-up / drain instead of five.
+__global__ __launch_bounds__(GT_NT, 2) void gemm_tn_glds_grouped_kernel(const MadeGemmTNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tiles = g.tile_end[g.n_problems - 1];
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int64_t split_y = xcd + 8 * (int64_t)(jx / tiles);
+    if (split_y >= g.split_m) return;
+    int tile = jx % tiles, pi = 0;
+#pragma unroll
+    for (int i = 0; i < MADE_GEMM_TN_MAX_GROUP - 1; ++i)
+        if (i + 1 < g.n_problems && tile >= g.tile_end[i]) pi = i + 1;
+    if (pi > 0) tile -= g.tile_end[pi - 1];
+    GtProblem p;
+    p.A = (const bf16_t*)g.p[pi].A; p.B = (const bf16_t*)g.p[pi].B; p.C = g.p[pi].C; p.colsum = g.p[pi].colsum;
+    p.lda = g.p[pi].lda; p.ldb = g.p[pi].ldb; p.ldc = g.p[pi].ldc; p.tiles_k = (int)(g.p[pi].K / GT_BK); p.tile = tile;
+    p.c_dtype = MADE_F32; p.accumulate = 1; p.alpha = g.alpha;
+    GtShared sh;
+    sh.M = g.M; sh.split_m = g.split_m; sh.split_y = split_y; sh.row_index = g.row_index; sh.n_rows = g.n_rows;
+    gemm_tn_glds_body(p, sh, lds);
 }
 
 }  // namespace
+
+extern "C" int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream) {
+    MADE_REQUIRE(group != nullptr, "made_gemm_tn_grouped: null args");
+    MadeGemmTNGroup g = *group;
+    MADE_REQUIRE(g.n_problems >= 1 && g.n_problems <= MADE_GEMM_TN_MAX_GROUP, "made_gemm_tn_grouped: n_problems=%d out of [1, %d]", g.n_problems, MADE_GEMM_TN_MAX_GROUP);
+    MADE_REQUIRE(g.M >= 0 && g.split_m >= 1, "made_gemm_tn_grouped: bad M / split_m");
+    MADE_REQUIRE((g.row_index == nullptr) == (g.n_rows == nullptr), "made_gemm_tn_grouped: row_index and n_rows come together");
+    if (g.M == 0) return MADE_OK;
+    int tiles = 0;
+    for (int i = 0; i < g.n_problems; ++i) {
+        const auto& p = g.p[i];
+        MADE_REQUIRE(p.A && p.B && p.C, "made_gemm_tn_grouped: problem %d has a null tensor", i);
+        MADE_UNSUPPORTED(p.N > 0 && p.K > 0 && p.N % GT_BN == 0 && p.K % GT_BK == 0, "made_gemm_tn_grouped: problem %d: N=%lld, K=%lld must be multiples of 128",
+                         i, (long long)p.N, (long long)p.K);
+        MADE_UNSUPPORTED(p.lda % 8 == 0 && p.ldb % 8 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
+                         "made_gemm_tn_grouped: problem %d: operand rows must be 16-byte aligned", i);
+        tiles += (int)((p.N / GT_BN) * (p.K / GT_BK));
+        g.tile_end[i] = tiles;
+    }
+    MADE_UNSUPPORTED(((g.M + GT_BM - 1) / GT_BM + g.split_m - 1) / g.split_m * GT_BM <= GT_MAX_ROWS,
+                     "made_gemm_tn_grouped: split_m=%lld leaves more than %d rows per workgroup", (long long)g.split_m, GT_MAX_ROWS);
+    dim3 grid((unsigned)(8 * (int64_t)tiles * ((g.split_m + 7) / 8)), 1, 1);
+    static const bool once = hipFuncSetAttribute((const void*)gemm_tn_glds_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS) == hipSuccess;
+    (void)once;
+    hipLaunchKernelGGL(gemm_tn_glds_grouped_kernel, grid, dim3(GT_NT), GT_LDS, (hipStream_t)stream, g);
+    return made_check_launch("made_gemm_tn_grouped");
+}
+
 
 // called by made_gemm_tn after validation; returns MADE_ERR_UNSUPPORTED-like sentinel 1 when the fast path does not apply
 int made_gemm_tn_fast(const MadeGemmTNArgs& a, hipStream_t st) {
@@ -206,6 +287,8 @@ int made_gemm_tn_fast(const MadeGemmTNArgs& a, hipStream_t st) {
     if (!ok) return 1;
     const int64_t tiles = (a.N / GT_BN) * (a.K / GT_BK);
     dim3 grid((unsigned)(8 * tiles * ((a.split_m + 7) / 8)), 1, 1);
-    hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(GT_NT), 0, st, a);
+    static const bool once = hipFuncSetAttribute((const void*)gemm_tn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS) == hipSuccess;
+    (void)once;
+    hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(GT_NT), GT_LDS, st, a);
     return made_check_launch("made_gemm_tn(glds)");
 }

@@ -330,7 +330,7 @@ class MadeTrainer(MadeEngine):
             if c.with_act_after_proj:
                 ws[f"{tag}.zproj"] = E(r, D)
             ws.update({f"{tag}.xin": E(r, Kin), f"{tag}.xlast": E(r, D), f"{tag}.mean": E(B, D, dtype=f32),
-                       f"{tag}.dl": E(r, D), f"{tag}.g1": E(r, D), f"{tag}.g2": E(r, D), f"{tag}.g3": E(r, D),
+                       f"{tag}.dl": E(r, D), f"{tag}.g1": E(r, D), f"{tag}.g1b": E(r, D), f"{tag}.g2": E(r, D), f"{tag}.g3": E(r, D), f"{tag}.g3b": E(r, D),
                        f"{tag}.gqkv": E(r, 3 * D), f"{tag}.gffn": E(r, Ft), f"{tag}.delta": E(B * Hh * T, dtype=f32)})
             for l in range(depth):
                 ws.update({f"{tag}.{l}.x0": E(r, D), f"{tag}.{l}.x1": E(r, D), f"{tag}.{l}.qkv": E(r, 3 * D), f"{tag}.{l}.att": E(r, D),
@@ -351,7 +351,8 @@ class MadeTrainer(MadeEngine):
             sims_both=E(B, B, dtype=f32), sd_ws=E(16 * B * B, dtype=f32),
             dvideo=E(B, D, dtype=f32), dmusic=E(B, D, dtype=f32),
             # DETR encoder
-            e_delta=E(B * H * L, dtype=f32), eg1=E(rows, D), eg2=E(rows, D), eg3=E(rows, D), egqkv=E(rows, 3 * D), egffn=E(rows, Fd),
+            e_delta=E(B * H * L, dtype=f32), eg1=E(rows, D), eg2=E(rows, D), eg2b=E(rows, D), eg3=E(rows, D), eg3b=E(rows, D), eg3c=E(rows, D),
+            egqkv=E(rows, 3 * D), egffn=E(rows, Fd),
             dfus=E(rows, D),
             # decoder (rows = B*Q)
             s_raw=E(B * HQ, dtype=f32), dds_raw=E(B * HQ, dtype=f32), gq_raw=E(B, HQ, D),
@@ -754,13 +755,30 @@ class MadeTrainer(MadeEngine):
         tr.layernorm_bwd(frame, P["ca.lnc.g"], dnc, tw["c_dframe"], dgamma=G["ca.lnc.g"], dbeta=G["ca.lnc.b"], row_skip=fflat)
 
     # ================================================================== backward
+    def _groupable(self, dz: Tensor, x: Tensor, gw: Tensor) -> bool:
+        return (self.tc == torch.bfloat16 and dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gw.shape[0] % 128 == 0
+                and gw.shape[1] % 128 == 0 and dz.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dz.shape[0] >= 256
+                and not getattr(self, "no_grouped_dw", False))
+
+    def _flush_dw(self, pending: list, row_mask: Optional[Tensor]) -> None:
+        """The weight gradients a layer's backward has queued (they reduce over the same rows) in one launch (made_gemm_tn_grouped)."""
+        rows = self._rw(row_mask)
+        for i in range(0, len(pending), 8):
+            tr.gemm_tn_grouped(pending[i:i + 8], rows=rows)
+        pending.clear()
+
     def _lin_bwd(self, dz: Tensor, x: Tensor, key: str, *, dx_out: Optional[Tensor] = None, row_mask: Optional[Tensor] = None,
                  skip: Optional[Tensor] = None, gw: Optional[Tensor] = None, gb: Optional[Tensor] = None, wt: Optional[Tensor] = None,
-                 **kw) -> Optional[Tensor]:
+                 defer: Optional[list] = None, **kw) -> Optional[Tensor]:
         """Linear backward: dW += dz^T x, db += colsum(dz), dx = dz W (with the epilogue options of ops.linear)."""
         rows = self._rw(row_mask)                             # the mask's valid-row list: gather instead of masking
-        tr.gemm_tn(dz, x, self.G[key + ".w"] if gw is None else gw, accumulate=True, colsum=self.G.get(key + ".b") if gb is None else gb,
-                   row_mask=row_mask if rows is None else None, row_groups=self._rg(row_mask), rows=rows)
+        gw_ = self.G[key + ".w"] if gw is None else gw
+        gb_ = self.G.get(key + ".b") if gb is None else gb
+        if defer is not None and self._groupable(dz, x, gw_):
+            defer.append((dz, x, gw_, gb_))                   # launched with the layer's other weight gradients (_flush_dw): the caller
+        else:                                                 # keeps dz and x untouched until then
+            tr.gemm_tn(dz, x, gw_, accumulate=True, colsum=gb_,
+                       row_mask=row_mask if rows is None else None, row_groups=self._rg(row_mask), rows=rows)
         if dx_out is None:
             return None
         return ops.linear(dz, self.P[key + ".wt"] if wt is None else wt, None, out=dx_out, tile_skip_mask=skip if rows is None else None,
@@ -978,20 +996,22 @@ class MadeTrainer(MadeEngine):
         dsrc = dmem
         for l in range(ne - 1, -1, -1):
             p, e = f"detr_transformer.encoder.layers.{l}", f"e.{l}"
-            g2, g3, gq, gf = tw["eg2"], tw["eg3"], tw["egqkv"], tw["egffn"]
+            # (every gradient that feeds a weight-gradient product keeps a buffer of its own until the layer's grouped launch)
+            g2, g2b, g3, g3b, g3c, gq, gf = tw["eg2"], tw["eg2b"], tw["eg3"], tw["eg3b"], tw["eg3c"], tw["egqkv"], tw["egffn"]
+            pend: list = []
             src = fus.view(rows, D) if l == 0 else tw[e + ".src"]
             srcpos = tw[e + ".srcpos"]
             # src_{l+1} = LN2(s1 + drop2(ffn))
             tr.layernorm_bwd(tw[e + ".x2"], P[p + ".ln2.g"], dsrc, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"], dx_drop=g3,
                              drop=self._drop(f"enc.{l}" + ".drop2", pd), row_skip=fskip)
             dz = self._lin_bwd(g3, tw[e + ".h"], p + ".ff2", dx_out=gf, row_mask=fskip, skip=fskip, gate=_lib.GATE_RELU_OUT, G=tw[e + ".h"],
-                               gate_scale=inv_keep)
-            ds1 = self._lin_bwd(dz, tw[e + ".s1"], p + ".ff1", dx_out=g3, row_mask=fskip, skip=fskip, R=g2)
+                               gate_scale=inv_keep, defer=pend)
+            ds1 = self._lin_bwd(dz, tw[e + ".s1"], p + ".ff1", dx_out=g3b, row_mask=fskip, skip=fskip, R=g2, defer=pend)
             # s1 = LN1(src + drop1(attention))
             dx = tw["eg1"] if dsrc is not tw["eg1"] else tw["dfus"]
-            tr.layernorm_bwd(tw[e + ".x"], P[p + ".ln1.g"], ds1, dx, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], dx_drop=g2,
+            tr.layernorm_bwd(tw[e + ".x"], P[p + ".ln1.g"], ds1, dx, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], dx_drop=g2b,
                              drop=self._drop(f"enc.{l}" + ".drop1", pd), row_skip=fskip)
-            datt = self._lin_bwd(g2, tw[e + ".att"], p + ".out", dx_out=g3, row_mask=fskip, skip=fskip)
+            datt = self._lin_bwd(g2b, tw[e + ".att"], p + ".out", dx_out=g3c, row_mask=fskip, skip=fskip, defer=pend)
             qkv = tw[e + ".qkv"]
             q3, gq3 = qkv.view(B, L, 3 * D), gq.view(B, L, 3 * D)
             tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[e + ".att"].view(B, L, D), datt.view(B, L, D),
@@ -999,10 +1019,15 @@ class MadeTrainer(MadeEngine):
                              key_mask=fus_mask, q_skip_mask=qskip, drop=self._drop(f"enc.{l}" + ".attn", pd),
                              order=self._order[fus_mask.data_ptr()])
             gW, gb = G[p + ".in.w"], G[p + ".in.b"]
-            tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], rows=self._rw(fskip))
-            tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], rows=self._rw(fskip))
+            if self._groupable(gq, srcpos, gW[:2 * D]) and self._rw(fskip) is not None:
+                pend.append((gq[:, :2 * D], srcpos, gW[:2 * D], gb[:2 * D]))
+                pend.append((gq[:, 2 * D:], src, gW[2 * D:], gb[2 * D:]))
+            else:
+                tr.gemm_tn(gq[:, :2 * D], srcpos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], rows=self._rw(fskip))
+                tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], rows=self._rw(fskip))
             nxt = tw["dfus"] if dx is tw["eg1"] else tw["eg1"]
             dsrc = ops.linear(gq, P[p + ".in.wt"], None, R=dx, out=nxt, rows=self._rw(fskip))
+            self._flush_dw(pend, fskip)
         dfus = dsrc.view(B, L, D)
         if concat:
             dl_v, dl_a = dfus[:, :Tv], dfus[:, Tv:]
@@ -1136,7 +1161,9 @@ class MadeTrainer(MadeEngine):
         pt = dr.P_TEMPORAL
         dl = tw[tag + ".dl"]
         tr.pool_bwd(tw[tag + ".mean"], dvec, mask, dl.view(B, T, D), in1=d_local, in2=d_extra)
-        g1, g2, g3, gq, gf = tw[tag + ".g1"], tw[tag + ".g2"], tw[tag + ".g3"], tw[tag + ".gqkv"], tw[tag + ".gffn"]
+        g1, g1b, g2, g3, g3b, gq, gf = (tw[tag + ".g1"], tw[tag + ".g1b"], tw[tag + ".g2"], tw[tag + ".g3"], tw[tag + ".g3b"], tw[tag + ".gqkv"],
+                                        tw[tag + ".gffn"])
+        pend: list = []                                      # this layer's weight gradients: one grouped launch (see the DETR encoder)
         # local = mask(final(x4)); x4 = x3 + drop(ffn2): the product dl W_f is needed raw (residual) and dropped (branch)
         x_last = tw[tag + ".xlast"]
         dx = None
@@ -1145,23 +1172,24 @@ class MadeTrainer(MadeEngine):
             x4 = x_last if l == depth - 1 else tw[f"{tag}.{l + 1}.x0"]
             if l == depth - 1:
                 df = self._lin_bwd(dl, x4, mod + ".final", dx_out=g1, row_mask=mflat, skip=mflat, Zout=g2,
-                                   drop=self._drop(f"{name}.{l}.ffn_out", pt))
+                                   drop=self._drop(f"{name}.{l}.ffn_out", pt), defer=pend)
                 dx4 = g2
             else:                                            # deeper stacks: x0_{l+1} = x4_l, its gradient arrives from LN1 of layer l+1
                 dx4 = dx
                 df = tr.gate_rows(dx4, g1, drop=self._drop(f"{name}.{l}.ffn_out", pt), drop_ld=D, row_skip=mflat)
             dz1 = self._lin_bwd(df, tw[t + ".h"], p + ".ff2", dx_out=gf, row_mask=mflat, skip=mflat, gate=_lib.GATE_GELU_Z, G=tw[t + ".z1"],
-                                drop=self._drop(f"{name}.{l}.ffn_act", pt))
-            dx3 = self._lin_bwd(dz1, tw[t + ".x3"], p + ".ff1", dx_out=g3, row_mask=mflat, skip=mflat, R=dx4)
-            tr.layernorm_bwd(tw[t + ".x2"], P[p + ".ln2.g"], dx3, g1, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"], row_skip=mflat)
-            datt = self._lin_bwd(g1, tw[t + ".att"], p + ".out", dx_out=g2, row_mask=mflat, skip=mflat)
+                                drop=self._drop(f"{name}.{l}.ffn_act", pt), defer=pend)
+            dx3 = self._lin_bwd(dz1, tw[t + ".x3"], p + ".ff1", dx_out=g3, row_mask=mflat, skip=mflat, R=dx4, defer=pend)
+            tr.layernorm_bwd(tw[t + ".x2"], P[p + ".ln2.g"], dx3, g1b, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"], row_skip=mflat)
+            datt = self._lin_bwd(g1b, tw[t + ".att"], p + ".out", dx_out=g2, row_mask=mflat, skip=mflat, defer=pend)
             qkv = tw[t + ".qkv"]
             q3, gq3 = qkv.view(B, T, 3 * D), gq.view(B, T, 3 * D)
             tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[t + ".att"].view(B, T, D), datt.view(B, T, D),
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[t + ".lse"], tw[tag + ".delta"], Hh,
                              key_mask=mask, q_skip_mask=mask, drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask.data_ptr()])
-            dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3, row_mask=mflat, skip=mflat, R=g1)
+            dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3b, row_mask=mflat, skip=mflat, R=g1b, defer=pend)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
+            self._flush_dw(pend, mflat)
         xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
         if c.with_act_after_proj:                            # x0 = quickgelu(z) + pe: gradient w.r.t. z (the input itself needs none)
             dx = tr.gate_rows(dx, g1, G=tw[tag + ".zproj"], gate=_lib.GATE_QUICKGELU_Z, row_skip=mflat)

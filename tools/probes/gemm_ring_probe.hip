@@ -324,10 +324,13 @@ int main(int argc, char** argv) {
     run_cfg<BM, BN, WM, WN, NST, BKB, MINW, 3>("   (direct epilogue)", shapes, nbuf, dA, dW, dbias, dC, dref, iters); \
     run_cfg<BM, BN, WM, WN, NST, BKB, MINW, 0>("   (K loop only)", shapes, nbuf, dA, dW, dbias, dC, dref, iters);
     RUN(128, 128, 2, 2, 2, 128, 2)
-    RUN(128, 128, 2, 2, 3, 64, 3)
-    RUN(128, 128, 2, 2, 2, 64, 4)
+    RUN(128, 128, 2, 4, 2, 128, 4)
+    RUN(128, 128, 4, 2, 2, 128, 4)
+    RUN(128, 128, 4, 4, 2, 128, 8)
     RUN(64, 128, 1, 4, 2, 128, 4)
+    RUN(64, 128, 2, 4, 2, 128, 6)
+    RUN(128, 256, 2, 4, 2, 128, 2)
     RUN(256, 128, 4, 2, 2, 128, 2)
-    RUN(256, 256, 2, 4, 2, 128, 2)
+    RUN(256, 128, 4, 4, 2, 128, 4)
     return 0;
 }
