@@ -40,7 +40,7 @@ from mgsv_amd.engine import MadeEngine  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round2.sh), per leg
 
 
 def parse():
@@ -65,7 +65,7 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------- helpers
-def _roofline(summ: dict, kind: str, dtype: str, per: int) -> dict:
+def _roofline(summ: dict, kind: str, dtype: str, per: int, leg: str) -> dict:
     """Roofline entry of one timed kernel kind: achieved = algorithmic (executed: valid rows / valid keys only) flops / summed
     launch time; the binding roof is the slower of the MFMA and the HBM floor for the kernel's algorithmic flops and bytes."""
     d = summ[kind]
@@ -76,7 +76,7 @@ def _roofline(summ: dict, kind: str, dtype: str, per: int) -> dict:
     traffic = None
     if os.path.isfile(PMC_FILE):
         try:
-            traffic = json.load(open(PMC_FILE)).get(kind, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(PMC_FILE)).get(leg, {}).get(kind, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     common = dict(kernel=kind, launches_per_step=d["launches"] // per, avg_launch_us=round(d["ms"] / d["launches"] * 1e3, 2),
@@ -225,7 +225,7 @@ def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> di
         with ops.KernelTimer() as kt:
             step()
         summ = kt.summary()
-        roof = _roofline(summ, _dominant(summ), args.dtype, 1)
+        roof = _roofline(summ, _dominant(summ), args.dtype, 1, "retrieval")
         per_kernel = _per_kernel(summ, 1)
     sec = elapsed / steps
     out = {"metric": "retrieval sim-matrix GB/s (all-pairs video x music, X-Pool + dual tower)", "value": round(alg_bytes / sec / 1e9, 3),
@@ -281,7 +281,7 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
         summ = kt.summary()
         per_kernel = _per_kernel(summ, 2)
         dom = _dominant(summ)
-        roof = _roofline(summ, dom, args.dtype, 2)
+        roof = _roofline(summ, dom, args.dtype, 2, "train")
         mm = [k for k in summ if k.startswith("linear_") or k == "made_gemm_tn"]
         fl, ms_ = sum(summ[k]["flops"] for k in mm), sum(summ[k]["ms"] for k in mm)
         roof["all_gemms_of_the_step"] = dict(tflops=round(fl / (ms_ * 1e-3) / 1e12, 2), frac=round(fl / (ms_ * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
@@ -377,7 +377,7 @@ def eval_leg(args, rank, world, local, dist, dtype: str, n_lanes: int, steps: in
             for _ in range(3):
                 step()
         summ = kt.summary()
-        roof = _roofline(summ, _dominant(summ), dtype, 3)
+        roof = _roofline(summ, _dominant(summ), dtype, 3, "eval")
         lin = [k for k in summ if k.startswith("linear_")]
         if lin:
             fl, ms_ = sum(summ[k]["flops"] for k in lin), sum(summ[k]["ms"] for k in lin)

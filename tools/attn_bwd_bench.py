@@ -1,11 +1,11 @@
-"""Microbenchmark: attention forward / backward at the DETR-encoder shape (B=64, H=8, hd=64, L=542): dense batch, ragged batch
+"""Microbenchmark: attention forward / backward at the DETR-encoder shape (B=64, H=8, hd=64, L=576): dense batch, ragged batch
 (valid lengths as bench.py draws them), ragged with the longest-first issue order, with and without dropout (GPU box)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mgsv_amd import ops, ops_train as tr
 
-B, H, hd, L = 64, 8, 64, 542
+B, H, hd, L = 64, 8, 64, 576
 D = H * hd
 qkv = torch.randn(B, L, 3 * D, device="cuda").bfloat16()
 q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
@@ -13,9 +13,9 @@ O = torch.empty(B, L, D, device="cuda", dtype=torch.bfloat16); dO = torch.randn_
 lse = torch.empty(B, H, L, device="cuda"); delta = torch.empty_like(lse)
 dqkv = torch.empty_like(qkv)
 g = torch.Generator().manual_seed(0)
-lv, la = torch.randint(5, 31, (B,), generator=g), torch.randint(12, 513, (B,), generator=g)
+lv, la = torch.randint(5, 65, (B,), generator=g), torch.randint(12, 513, (B,), generator=g)
 pos = torch.arange(L)[None]
-ragged = ((pos < lv[:, None]) | ((pos >= 30) & (pos < 30 + la[:, None]))).float().cuda()
+ragged = ((pos < lv[:, None]) | ((pos >= 64) & (pos < 64 + la[:, None]))).float().cuda()
 dense = torch.ones(B, L, device="cuda")
 
 
