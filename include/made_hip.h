@@ -351,9 +351,12 @@ typedef struct MadeXpoolFusedArgs {
     float* sims; int64_t ld_sims;
     int64_t Nv, Nm, S, D;
     float scale, eps;
-    float* ws;                 /* workspace, Nv*(D+2) + 4 floats: per-video terms of LayerNorm3 + cosine that do not depend on the track */
-    int32_t prepare_ws; int32_t _pad;   /* 1: fill ws from vn / ln3 first (a small launch); 0: ws is still valid from a previous call
-                                           with the same vn and ln3 (the caller loops over chunks of tracks) */
+    float* ws;                 /* workspace, Nv*(D+2) + 4 + 2*D + D*D/2 + 4*Nm floats, 16-byte aligned: per-video terms of LayerNorm3 +
+                                  cosine that do not depend on the track, the Linear folded with LayerNorm2 (bf16 weight, two
+                                  vectors), four ints per track (valid range of its segments) */
+    int32_t prepare_ws; int32_t _pad;   /* 1: fill the per-video and per-model parts of ws first (small launches); 0: they are still
+                                           valid from a previous call with the same vn, ln2, Wl, bl and ln3 (the caller loops over
+                                           chunks of tracks); the per-track part is rebuilt by every call */
 } MadeXpoolFusedArgs;
 
 int made_xpool_fused(const MadeXpoolFusedArgs* args, void* stream);

@@ -425,7 +425,7 @@ class MadeEngine:
             kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
             ubuf = torch.empty(cm * S, D, device=dev, dtype=tc)
             ubuf2 = torch.empty(cm * S, D, device=dev, dtype=tc)
-            xws = torch.empty(Nv * (D + 2) + 4, device=dev, dtype=torch.float32)
+            xws = torch.empty(ops.xpool_fused_ws_floats(Nv, cm, D), device=dev, dtype=torch.float32)
             for m0 in range(0, Nm, cm):
                 n = min(cm, Nm - m0)
                 skip = seg_mask[m0:m0 + n].reshape(-1) if seg_mask is not None else None

@@ -530,6 +530,12 @@ def xpool_tail(y: Tensor, gamma: Tensor, beta: Tensor, video: Tensor, sims: Tens
     return sims
 
 
+def xpool_fused_ws_floats(Nv: int, Nm: int, D: int = 256) -> int:
+    """Workspace of made_xpool_fused in floats (include/made_hip.h): per-video LayerNorm3 / cosine terms, the folded Linear
+    (W'' in bf16, two vectors) and four ints per track."""
+    return Nv * (D + 2) + 4 + 2 * D + D * D // 2 + 4 * Nm
+
+
 def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2, Wl: Tensor, bl: Tensor, ln3, vn: Tensor,
                 sims: Tensor, scale: float, eps: float = 1e-5, ws: Optional[Tensor] = None, prepare_ws: bool = True) -> Tensor:
     """All-pairs X-Pool scoring in one launch (made_xpool_fused; bf16, D = 256): Q [Nv,D], K / U [Nm,S,D] (unit inner stride),
@@ -551,9 +557,9 @@ def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2
     a.sims, a.ld_sims = _p(sims), sims.stride(0)
     a.Nv, a.Nm, a.S, a.D, a.scale, a.eps = Nv, Nm, S, D, scale, eps
     if ws is None:
-        ws = torch.empty(Nv * (D + 2) + 4, device=Q.device, dtype=torch.float32)
+        ws = torch.empty(xpool_fused_ws_floats(Nv, Nm, D), device=Q.device, dtype=torch.float32)
         prepare_ws = True
-    assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.numel() >= Nv * (D + 2) + 4
+    assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.numel() >= xpool_fused_ws_floats(Nv, Nm, D)
     a.ws, a.prepare_ws = _p(ws), 1 if prepare_ws else 0
     flops = 2.0 * Nv * Nm * (2 * S * D + D * D)
     desc = ""

@@ -581,6 +581,55 @@ def test_masked_softmax(dev, pdt):
     assert (probs[:, :, S:] == 0).all()
 
 
+@pytest.mark.parametrize("Nv,Nm,S,holes", [(300, 21, 96, False), (64, 9, 40, True), (513, 70, 130, True), (129, 3, 17, False)])
+def test_xpool_fused_against_f32_math(dev, Nv, Nm, S, holes):
+    """made_xpool_fused (reference modules/transformer.py:110-123,172-178 + modules/metrics.py:19-24 for every (video, track) pair)
+    against the same chain in f32 torch math on the same bf16 operands: prefix and non-prefix masks, NaN in the rows of masked
+    segments (they may hold anything), a track without any valid segment (NaN like the reference's softmax over -inf), video
+    counts that do not fill a workgroup, several chunks of tracks."""
+    D = 256
+    g = torch.Generator(device=dev).manual_seed(Nv * 7 + Nm)
+    rn = lambda *s_: torch.randn(*s_, device=dev, generator=g)
+    Q, K, U = rn(Nv, D).bfloat16(), rn(Nm, S, D).bfloat16(), rn(Nm, S, D).bfloat16()
+    lens = torch.randint(1, S + 1, (Nm,), device=dev, generator=g)
+    mask = (torch.arange(S, device=dev)[None] < lens[:, None]).float()
+    if holes:
+        mask = mask * (torch.rand(Nm, S, device=dev, generator=g) > 0.3).float()
+        mask[:, 0] = 1.0
+        mask[1, :] = 0.0                                   # no valid segment at all
+        mask[2, :5] = 0.0                                  # first valid segment is not segment 0
+        mask[2, 5] = 1.0
+    Wl = (rn(D, D) / math.sqrt(D)).bfloat16()
+    ln2, ln3, bl = (1 + 0.1 * rn(D), 0.1 * rn(D)), (1 + 0.1 * rn(D), 0.1 * rn(D)), 0.1 * rn(D)
+    vn = torch.nn.functional.normalize(rn(Nv, D), dim=-1)
+    scale = 1 / math.sqrt(D)
+    Kd, Ud = K.clone(), U.clone()
+    Kd[mask == 0] = float("nan"); Ud[mask == 0] = float("nan")
+    sims = torch.full((Nv, Nm + 3), -7.0, device=dev)
+    ops.xpool_fused(Q, Kd, Ud, mask, ln2, Wl, bl, ln3, vn, sims[:, :Nm], scale=scale)
+    torch.cuda.synchronize()
+    assert bool((sims[:, Nm:] == -7.0).all())
+    Kf, Uf = K.float() * mask[..., None], U.float() * mask[..., None]
+    logits = torch.einsum("nd,msd->nms", Q.float(), Kf) * scale + torch.where(mask == 0, float("-inf"), 0.0)[None]
+    o = torch.einsum("nms,msd->nmd", torch.softmax(logits, -1), Uf)
+    a3 = torch.nn.functional.layer_norm(o, (D,), ln2[0], ln2[1], 1e-5)
+    y = a3 + a3 @ Wl.float().t() + bl
+    z = torch.nn.functional.layer_norm(y, (D,), ln3[0], ln3[1], 1e-5)
+    ref = (z * vn[:, None]).sum(-1) / z.norm(dim=-1)
+    got = sims[:, :Nm]
+    dead = mask.sum(1) == 0
+    assert bool(torch.isnan(got[:, dead]).all()) and bool(torch.isfinite(got[:, ~dead]).all())
+    err = float((got[:, ~dead] - ref[:, ~dead]).abs().max())
+    assert err <= 1.5e-2, err
+    # a second call on a slice of the tracks with the per-video workspace reused
+    ws = torch.empty(ops.xpool_fused_ws_floats(Nv, Nm, D), device=dev)
+    s2 = torch.empty(Nv, Nm, device=dev)
+    h = Nm // 2
+    ops.xpool_fused(Q, Kd[:h], Ud[:h], mask[:h], ln2, Wl, bl, ln3, vn, s2[:, :h], scale=scale, ws=ws, prepare_ws=True)
+    ops.xpool_fused(Q, Kd[h:], Ud[h:], mask[h:], ln2, Wl, bl, ln3, vn, s2[:, h:], scale=scale, ws=ws, prepare_ws=False)
+    assert torch.equal(torch.nan_to_num(s2, nan=5.0), torch.nan_to_num(got, nan=5.0))
+
+
 def test_xpool_tail_and_clip_loss(dev):
     Nm, Nv, D = 9, 13, 256
     y = rnd(Nm * Nv, D, seed=1)
