@@ -27,7 +27,7 @@ template <> struct Frag<float>  { typedef f32x4  type; };
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 
 template <typename TC, int HD>
-__global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs a) {
+__global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel(const MadeAttnArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
     constexpr int PER16 = 16 / SZ;
@@ -85,13 +85,15 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
         for (int ks = 0; ks < NQF; ++ks) qf[ks] = *(const frag_t*)(qp + ks * 2 * PER16 + hh * PER16);
     }
 
-    // ---- staging registers
+    // ---- staging registers.  load_tile only ISSUES the loads of the next tile (K / V rows, their mask values); everything that
+    // consumes a loaded value -- zeroing the rows of masked keys, the tile's bias row -- happens in store_tile, one iteration later,
+    // after the current tile has been multiplied: a use right behind the loads would make the wave wait for them before its MFMAs.
     frag_t rk[NCH], rv[NCH];
-    float rbias = 0.f;
-    int rflag = 0;
+    float rmk[NCH], rmkb = 1.f;
+    int64_t rkey0 = 0;
     auto load_tile_impl = [&](int64_t key0, auto has_mask) __attribute__((always_inline)) {
         // branch-free: every lane always loads (row index clamped into the tensor), masking happens on the registers
-        float mk[NCH];
+        rkey0 = key0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;
@@ -100,37 +102,27 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
             const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
             rk[i] = *(const frag_t*)(Kg + kcl * a.ldk + kc * PER16);
             rv[i] = *(const frag_t*)(Vg + kcl * a.ldv + kc * PER16);
-            if constexpr (decltype(has_mask)::value) mk[i] = maskg[kcl]; else mk[i] = 1.f;
+            if constexpr (decltype(has_mask)::value) rmk[i] = maskg[kcl]; else rmk[i] = 1.f;
         }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            int c = tid + i * NTHREADS;
-            const bool keep = (key0 + c / K_CPR) < a.Lk && mk[i] != 0.f;   // masked keys read as zero rows: 0*garbage must stay 0
-            rk[i] = keep_or_zero(rk[i], keep);
-            rv[i] = keep_or_zero(rv[i], keep);
+        if constexpr (decltype(has_mask)::value) {       // (every wave loads, wave 0 stores: a load under `if (tid < 64)` would be
+            const int64_t key = key0 + lane;               // joined with the other waves' untouched register, and the join waits)
+            rmkb = maskg[key < a.Lk ? key : a.Lk - 1];
         }
-        if (tid < BKEY) {
-            int64_t key = key0 + tid;
-            const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
-            float mkb = 1.f;
-            if constexpr (decltype(has_mask)::value) mkb = maskg[kcl];
-            const bool valid = key < a.Lk && mkb != 0.f;
-            rbias = valid ? 0.f : -INFINITY;
-            rflag = __any(!valid) ? 1 : 0;                 // tid < 64 is exactly wave 0
-        }
-    };
-    auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
-        if (maskg) load_tile_impl(key0, std::true_type{}); else load_tile_impl(key0, std::false_type{});
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;
-            *(frag_t*)(lds_k + (c / K_CPR) * K_ROW + (c % K_CPR) * 16) = rk[i];
-            *(frag_t*)(lds_v + (c / K_CPR) * V_ROW + (c % K_CPR) * 16) = rv[i];
+            const bool keep = (rkey0 + c / K_CPR) < a.Lk && rmk[i] != 0.f;   // masked keys read as zero rows: 0*garbage must stay 0
+            *(frag_t*)(lds_k + (c / K_CPR) * K_ROW + (c % K_CPR) * 16) = keep_or_zero(rk[i], keep);
+            *(frag_t*)(lds_v + (c / K_CPR) * V_ROW + (c % K_CPR) * 16) = keep_or_zero(rv[i], keep);
         }
-        if (tid < BKEY) lds_bias[tid] = rbias;
-        if (tid == 0) lds_flag[0] = rflag;
+        if (tid < BKEY) {                                  // tid < 64 is exactly wave 0
+            const bool valid = (rkey0 + tid) < a.Lk && rmkb != 0.f;
+            lds_bias[tid] = valid ? 0.f : -INFINITY;
+            const int flag = __any(!valid) ? 1 : 0;
+            if (tid == 0) lds_flag[0] = flag;
+        }
     };
 
     f32x16 o[NDT];
@@ -153,12 +145,15 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
         lk_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
     }
     const int64_t ntiles = (lk_eff + BKEY - 1) / BKEY;
-    if (ntiles > 0) load_tile(0);
+    // (the whole tile loop exists twice, with and without a mask: selecting per load would join two register-loading paths in
+    // front of the MFMAs, and the join waits for the loads)
+    auto tile_loop = [&](auto has_mask) __attribute__((always_inline)) {
+    if (ntiles > 0) load_tile_impl(0, has_mask);
     for (int64_t t = 0; t < ntiles; ++t) {
         __syncthreads();
         store_tile();
         __syncthreads();
-        if (t + 1 < ntiles) load_tile((t + 1) * BKEY);
+        if (t + 1 < ntiles) load_tile_impl((t + 1) * BKEY, has_mask);
         if (!wave_active) continue;
 
         // ---- S^T tile [64 keys x 32 queries] = two 32x32 accumulators
@@ -315,6 +310,8 @@ __global__ __launch_bounds__(NTHREADS) void attention_kernel(const MadeAttnArgs 
                 }
         }
     }
+    };
+    if (maskg) tile_loop(std::true_type{}); else tile_loop(std::false_type{});
 
     if (!wave_active) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32);

@@ -11,6 +11,7 @@
 // Probabilities are recomputed as exp(scale * s + mask - lse) from the log-sum-exp the forward saved; the dropout mask is
 // regenerated from (seed, site, element index).  bf16: v_mfma_f32_32x32x16_bf16, f32: v_mfma_f32_32x32x2_f32.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int P, int 
 
 // ---------------------------------------------------------------------------------------------- dQ
 template <typename TC, int HD>
-__global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void attn_bwd_dq_kernel(const MadeAttnBwdArgs a) {
+__global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void attn_bwd_dq_kernel(const MadeAttnBwdArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
     constexpr int PER16 = 16 / SZ;
@@ -84,11 +85,12 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
     constexpr bool IS_BF16 = SZ == 2;
     constexpr int BQ = 128;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BKEY * P + BKEY * 4 + 32];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BKEY * P + 32];
+    extern __shared__ __attribute__((aligned(16))) float lds_row[];      // the sample's key bias row (0 / -inf), whole tiles
     unsigned char* lds_k = lds;
     unsigned char* lds_v = lds + BKEY * P;
-    float* lds_bias = (float*)(lds + 2 * BKEY * P);
-    int* lds_flag = (int*)(lds + 2 * BKEY * P + BKEY * 4);
+    float* kbias = lds_row;
+    int* lds_flag = (int*)(lds + 2 * BKEY * P);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -130,11 +132,12 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
     const float lse_q = my_valid ? a.lse[(b * a.H + h) * a.Lq + qc] : INFINITY;     // +inf: every probability is 0
     const float delta_q = my_valid ? a.delta[(b * a.H + h) * a.Lq + qc] : 0.f;
 
+    // load_tile only ISSUES the next tile's loads (a use right behind them would make the wave wait before multiplying the current
+    // tile); masked keys are zeroed in store_tile, one iteration later, from the bias row staged in LDS at the start
     frag_t rk[NCH], rv[NCH];
-    float rbias = 0.f;
-    int rflag = 0;
+    int64_t rkey0 = 0;
     auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
-        float mk[NCH];
+        rkey0 = key0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * NTH;
@@ -142,33 +145,16 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
             const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
             rk[i] = *(const frag_t*)(Kg + kcl * a.ldk + (c % CPR) * PER16);
             rv[i] = *(const frag_t*)(Vg + kcl * a.ldv + (c % CPR) * PER16);
-            mk[i] = maskg ? maskg[kcl] : 1.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + i * NTH;
-            const bool keep = (key0 + c / CPR) < a.Lk && mk[i] != 0.f;
-            rk[i] = keep_or_zero(rk[i], keep);
-            rv[i] = keep_or_zero(rv[i], keep);
-        }
-        if (tid < BKEY) {
-            const int64_t key = key0 + tid;
-            const int64_t kcl = key < a.Lk ? key : a.Lk - 1;
-            const float mkb = maskg ? maskg[kcl] : 1.f;
-            const bool valid = key < a.Lk && mkb != 0.f;
-            rbias = valid ? 0.f : -INFINITY;
-            rflag = __any(!valid) ? 1 : 0;                   // tid < 64 is exactly wave 0
         }
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * NTH;
-            *(frag_t*)(lds_k + (c / CPR) * P + (c % CPR) * 16) = rk[i];
-            *(frag_t*)(lds_v + (c / CPR) * P + (c % CPR) * 16) = rv[i];
+            const bool keep = kbias[rkey0 + c / CPR] == 0.f;
+            *(frag_t*)(lds_k + (c / CPR) * P + (c % CPR) * 16) = keep_or_zero(rk[i], keep);
+            *(frag_t*)(lds_v + (c / CPR) * P + (c % CPR) * 16) = keep_or_zero(rv[i], keep);
         }
-        if (tid < BKEY) lds_bias[tid] = rbias;
-        if (tid == 0) lds_flag[0] = rflag;
     };
 
     f32x16 dq[NDT];
@@ -177,16 +163,23 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
 
+    // the sample's key bias row -> LDS (whole tiles; keys beyond Lk are masked), and the last valid key
     int64_t lk_eff = a.Lk;
-    if (maskg) {
+    {
+        const int lkp = (int)((a.Lk + BKEY - 1) / BKEY) * BKEY;
         int last = -1;
-        for (int j = tid; j < (int)a.Lk; j += NTH)
-            if (maskg[j] != 0.f) last = j;
+        for (int j = tid; j < lkp; j += NTH) {
+            const bool valid = j < (int)a.Lk && (maskg == nullptr || maskg[j] != 0.f);
+            kbias[j] = valid ? 0.f : -INFINITY;
+            if (valid) last = j;
+        }
+        if (maskg) {
 #pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
-        if (lane == 0) lds_flag[1 + wave] = last;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
+            if (lane == 0) lds_flag[1 + wave] = last;
+        }
         __syncthreads();
-        lk_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
+        if (maskg) lk_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
     }
     const int64_t ntiles = (lk_eff + BKEY - 1) / BKEY;
     const uint32_t thr = made_drop_threshold(a.drop.p);
@@ -200,6 +193,8 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
         __syncthreads();
         if (t + 1 < ntiles) load_tile((t + 1) * BKEY);
         if (!wave_active) continue;
+        const float* tb = kbias + t * BKEY;                 // this tile's bias row
+        const bool tile_has_masked = __any(tb[lane] != 0.f);
 
         f32x16 s[2], dp[2];
 #pragma unroll
@@ -235,11 +230,11 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
             const float c2 = a.scale * 1.4426950408889634f;
             const float nl = -lse_q * 1.4426950408889634f;
             const float dsq = delta_q * a.scale;
-            if (lds_flag[0] != 0) {
+            if (tile_has_masked) {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) s[kt][e] += lds_bias[kt * 32 + acc_row(e, hh)];   // -inf * anything stays -inf below
+                    for (int e = 0; e < 16; ++e) s[kt][e] += tb[kt * 32 + acc_row(e, hh)];   // -inf * anything stays -inf below
             }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -260,7 +255,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kl = kt * 32 + acc_row(e, hh);
-                    const float p = expf(s[kt][e] * a.scale + lds_bias[kl] - lse_q);
+                    const float p = expf(s[kt][e] * a.scale + tb[kl] - lse_q);
                     float g = dp[kt][e];
                     if (a.drop.p > 0.f) g = drop_keep(a.drop, thr, tbase + (uint64_t)kl) ? g * dsc : 0.f;
                     s[kt][e] = p * (g - delta_q) * a.scale;
@@ -294,6 +289,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
         }
     }
 
+
     if (q >= a.Lq) return;
     TC* op = (TC*)a.dQ + b * a.dq_bs + q * a.lddq + h * HD;
 #pragma unroll
@@ -308,7 +304,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
 
 // ---------------------------------------------------------------------------------------------- dK, dV
 template <typename TC, int HD>
-__global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs a) {
+__global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
     constexpr int PER16 = 16 / SZ;
@@ -321,12 +317,15 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
     constexpr bool IS_BF16 = SZ == 2;
     constexpr int BK = 128;                       // keys per workgroup
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BQT * P + 2 * BQT * 4 + 32];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BQT * P + 32];
+    extern __shared__ __attribute__((aligned(16))) float lds_row[];      // per query of this (batch, head), whole tiles: see below
     unsigned char* lds_q = lds;
     unsigned char* lds_do = lds + BQT * P;
-    float* lds_lse = (float*)(lds + 2 * BQT * P);
-    float* lds_delta = lds_lse + BQT;
-    int* lds_flag = (int*)(lds_delta + BQT);
+    int* lds_flag = (int*)(lds + 2 * BQT * P);
+    const int lqp = (int)((a.Lq + BQT - 1) / BQT) * BQT;
+    float* lse_all = lds_row;                       // log-sum-exp (pre-folded for the exp2 form in bf16; +-inf for padded queries: p = 0)
+    float* delta_all = lds_row + lqp;               // delta (pre-multiplied by the scale in bf16; 0 for padded queries)
+    float* live_all = lds_row + 2 * lqp;            // 1 / 0: the query is computed
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -360,10 +359,11 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
     const float* lseg = a.lse + (b * a.H + h) * a.Lq;
     const float* delg = a.delta + (b * a.H + h) * a.Lq;
 
+    // (as in the dq kernel: the next tile's loads are only issued here; padded queries are zeroed in store_tile from the rows in LDS)
     frag_t rq[NCH], rg[NCH];
-    float rl = INFINITY, rd = 0.f;
+    int64_t rqbase = 0;
     auto load_tile = [&](int64_t qbase) __attribute__((always_inline)) {
-        float sk[NCH];
+        rqbase = qbase;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * NTH;
@@ -371,34 +371,16 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
             const int64_t qcl = qq < a.Lq ? qq : a.Lq - 1;
             rq[i] = *(const frag_t*)(Qg + qcl * a.ldq + (c % CPR) * PER16);
             rg[i] = *(const frag_t*)(Gg + qcl * a.lddo + (c % CPR) * PER16);
-            sk[i] = skipg ? skipg[qcl] : 1.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + i * NTH;
-            const bool keep = (qbase + c / CPR) < a.Lq && sk[i] != 0.f;
-            rq[i] = keep_or_zero(rq[i], keep);
-            rg[i] = keep_or_zero(rg[i], keep);
-        }
-        if (tid < BQT) {
-            const int64_t qq = qbase + tid;
-            const int64_t qcl = qq < a.Lq ? qq : a.Lq - 1;
-            const float skv = skipg ? skipg[qcl] : 1.f;
-            const bool ok = qq < a.Lq && skv != 0.f;
-            const float l = lseg[qcl], dl = delg[qcl];
-            rl = ok ? l : INFINITY;                    // +inf: the whole probability row is 0
-            rd = ok ? dl : 0.f;
-            if constexpr (IS_BF16) { rl = -rl * 1.4426950408889634f; rd = rd * a.scale; }   // pre-folded for the exp2 / FMA form
         }
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * NTH;
-            *(frag_t*)(lds_q + (c / CPR) * P + (c % CPR) * 16) = rq[i];
-            *(frag_t*)(lds_do + (c / CPR) * P + (c % CPR) * 16) = rg[i];
+            const bool keep = live_all[rqbase + c / CPR] != 0.f;
+            *(frag_t*)(lds_q + (c / CPR) * P + (c % CPR) * 16) = keep_or_zero(rq[i], keep);
+            *(frag_t*)(lds_do + (c / CPR) * P + (c % CPR) * 16) = keep_or_zero(rg[i], keep);
         }
-        if (tid < BQT) { lds_lse[tid] = rl; lds_delta[tid] = rd; }
     };
 
     f32x16 dk[NDT], dv[NDT];
@@ -407,17 +389,26 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
 
-    // queries after the last valid one contribute nothing (padding is a suffix)
+    // the per-query scalars of this (batch, head) -> LDS once; queries after the last computed one contribute nothing
     int64_t lq_eff = a.Lq;
-    if (skipg) {
+    {
         int last = -1;
-        for (int j = tid; j < (int)a.Lq; j += NTH)
-            if (skipg[j] != 0.f) last = j;
+        for (int j = tid; j < lqp; j += NTH) {
+            const int jc = j < (int)a.Lq ? j : (int)a.Lq - 1;
+            const bool ok = j < (int)a.Lq && (skipg == nullptr || skipg[jc] != 0.f);
+            float l = ok ? lseg[jc] : INFINITY;            // +inf: the whole probability row is 0
+            float dl = ok ? delg[jc] : 0.f;
+            if constexpr (IS_BF16) { l = -l * 1.4426950408889634f; dl = dl * a.scale; }   // pre-folded for the exp2 / FMA form
+            lse_all[j] = l; delta_all[j] = dl; live_all[j] = ok ? 1.f : 0.f;
+            if (ok) last = j;
+        }
+        if (skipg) {
 #pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
-        if (lane == 0) lds_flag[1 + wave] = last;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
+            if (lane == 0) lds_flag[1 + wave] = last;
+        }
         __syncthreads();
-        lq_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
+        if (skipg) lq_eff = max(max(lds_flag[1], lds_flag[2]), max(lds_flag[3], lds_flag[4])) + 1;
     }
     const int64_t ntiles = (lq_eff + BQT - 1) / BQT;
     const uint32_t thr = made_drop_threshold(a.drop.p);
@@ -432,6 +423,8 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
         __syncthreads();
         if (t + 1 < ntiles) load_tile((t + 1) * BQT);
         if (!wave_active) continue;
+        const float* lds_lse = lse_all + t * BQT;
+        const float* lds_delta = delta_all + t * BQT;
 
         const uint64_t tfirst = (bhbase + (uint64_t)(t * BQT)) * (uint64_t)a.Lk;
         const uint64_t tlast = tfirst + (uint64_t)BQT * (uint64_t)a.Lk;
@@ -529,6 +522,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
         }
     }
 
+
     if (key >= a.Lk) return;
     TC* kp = (TC*)a.dK + b * a.dk_bs + key * a.lddk + h * HD;
     TC* vp = (TC*)a.dV + b * a.dv_bs + key * a.lddv + h * HD;
@@ -544,29 +538,50 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 3 : 1) void at
             }
 }
 
+constexpr int BWD_ROW_LDS_MAX = 96 * 1024;        // per-sample rows staged in LDS by the dq (4 B per key) and dkv (12 B per query) kernels
+
+template <typename TC, int HD>
+int launch_bwd_hd(const MadeAttnBwdArgs& a, dim3 gq, dim3 gk, size_t lds_q, size_t lds_k, hipStream_t st) {
+    // the kernels' static tiles (2 x 64 rows) + the per-sample rows must fit the CU's 160 KB
+    constexpr int kStatic = 2 * 64 * (HD * (int)sizeof(TC) + 16) + 32;
+    constexpr int kMaxDyn = (160 * 1024 - kStatic - 256 < BWD_ROW_LDS_MAX) ? (160 * 1024 - kStatic - 256) / 256 * 256 : BWD_ROW_LDS_MAX;
+    if (lds_q > (size_t)kMaxDyn || lds_k > (size_t)kMaxDyn) {
+        made_set_error("made_attention_bwd: Lq=%lld / Lk=%lld too long for the per-sample rows kept in LDS at head dim %d (at most %d queries, %d keys)",
+                       (long long)a.Lq, (long long)a.Lk, HD, kMaxDyn / 12, kMaxDyn / 4);
+        return MADE_ERR_UNSUPPORTED;
+    }
+    static bool attr_done = false;                // (per instantiation)
+    if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<TC, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
+        hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<TC, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            made_set_error("made_attention_bwd: cannot reserve %d bytes of LDS", kMaxDyn);
+            return MADE_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, HD>), gq, dim3(NTH), lds_q, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, HD>), gk, dim3(NTH), lds_k, st, a);
+    return MADE_OK;
+}
+
 template <typename TC>
 int launch_bwd(const MadeAttnBwdArgs& a, hipStream_t st) {
     const int64_t rows = a.B * a.Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTH), 0, st, a);
     const int64_t pairs8 = 8 * ((a.H * a.B + 7) / 8);
-    dim3 gq((unsigned)(((a.Lq + 127) / 128) * pairs8)), gk((unsigned)(((a.Lk + 127) / 128) * pairs8)), block(NTH);
+    dim3 gq((unsigned)(((a.Lq + 127) / 128) * pairs8)), gk((unsigned)(((a.Lk + 127) / 128) * pairs8));
+    const size_t lds_q = (size_t)((a.Lk + BKEY - 1) / BKEY) * BKEY * 4, lds_k = (size_t)((a.Lq + BQT - 1) / BQT) * BQT * 12;
+    int rc;
     switch (a.hd) {
-        case 32:
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 32>), gq, block, 0, st, a);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 32>), gk, block, 0, st, a);
-            break;
-        case 64:
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 64>), gq, block, 0, st, a);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 64>), gk, block, 0, st, a);
-            break;
-        case 128:
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 128>), gq, block, 0, st, a);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 128>), gk, block, 0, st, a);
-            break;
+        case 32: rc = launch_bwd_hd<TC, 32>(a, gq, gk, lds_q, lds_k, st); break;
+        case 64: rc = launch_bwd_hd<TC, 64>(a, gq, gk, lds_q, lds_k, st); break;
+        case 128: rc = launch_bwd_hd<TC, 128>(a, gq, gk, lds_q, lds_k, st); break;
         default:
             made_set_error("made_attention_bwd: head dim %d not in {32,64,128}", a.hd);
             return MADE_ERR_UNSUPPORTED;
     }
+    if (rc != MADE_OK) return rc;
     return made_check_launch("made_attention_bwd");
 }
 

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* lds_s = (float*)(lds + NSTAGE * KV_STAGE);                 // [4][32*32] partial score tiles
     float* lds_bias_all = lds_s + 4 * 1024;                           // [NSTAGE][32]
+    uint32_t* lds_mbits = (uint32_t*)(lds_bias_all + NSTAGE * 32);    // one bit per key of this batch entry: 1 = attended to
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -82,12 +83,13 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
         for (int ks = 0; ks < NQF; ++ks) qf[ks] = *(const frag_t*)(qp + ks * 2 * PER16 + hh * PER16);
     }
 
+    // load_tile only ISSUES the next tile's loads; what consumes them (zeroing the rows of masked keys) runs in store_tile, after
+    // the current tile's MFMAs: a use right behind the loads would make the wave wait for them first.  Which keys are masked comes
+    // from a bit row staged in LDS at the start, so the loop loads nothing but K / V rows.
     frag_t rk[NCH], rv[NCH];
-    float rbias = 0.f;
-    auto load_tile_impl = [&](int64_t key0, auto has_mask) __attribute__((always_inline)) {
-        // branch-free: every lane always loads (row index clamped into the tensor), masking happens on the registers
-        bool keep[NCH];
-        float mk[NCH];
+    int64_t rkey0 = 0;
+    auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
+        rkey0 = key0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;
@@ -96,51 +98,31 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
             const int64_t kcl = key < a.L ? key : a.L - 1;
             rk[i] = *(const frag_t*)(Kg + kcl * a.ldk + cc * PER16);
             rv[i] = *(const frag_t*)(Vg + kcl * a.ldv + cc * PER16);
-            if constexpr (decltype(has_mask)::value) mk[i] = maskg[kcl]; else mk[i] = 1.f;
         }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            int c = tid + i * NTHREADS;
-            keep[i] = (key0 + c / CPR) < a.L && mk[i] != 0.f;
-        }
-        if (Ag) {
-#pragma unroll
+        if (Ag) {                                            // (K + Kadd formed here, at the price of waiting for both: not on the model's path,
+#pragma unroll                                               // which hands in the precomputed sum)
             for (int i = 0; i < NCH; ++i) {
                 int c = tid + i * NTHREADS;
-                int row = c / CPR, cc = c % CPR;
-                int64_t key = key0 + row;
+                int64_t key = key0 + c / CPR;
                 const int64_t kcl = key < a.L ? key : a.L - 1;
-                frag_t av = *(const frag_t*)(Ag + kcl * a.ldkadd + cc * PER16);
+                const frag_t av = *(const frag_t*)(Ag + kcl * a.ldkadd + (c % CPR) * PER16);
 #pragma unroll
                 for (int j = 0; j < PER16; ++j) rk[i][j] = from_f32<TC>(to_f32(rk[i][j]) + to_f32(av[j]));
             }
         }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {                      // masked / out-of-range keys read as zero rows
-            rk[i] = keep_or_zero(rk[i], keep[i]);
-            rv[i] = keep_or_zero(rv[i], keep[i]);
-        }
-        if (tid < WKEY) {
-            int64_t key = key0 + tid;
-            const int64_t kcl = key < a.L ? key : a.L - 1;
-            float mkb = 1.f;
-            if constexpr (decltype(has_mask)::value) mkb = maskg[kcl];
-            rbias = (key < a.L && mkb != 0.f) ? 0.f : -INFINITY;
-        }
-    };
-    auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
-        if (maskg) load_tile_impl(key0, std::true_type{}); else load_tile_impl(key0, std::false_type{});
     };
     auto store_tile = [&](int stage) __attribute__((always_inline)) {
         unsigned char* sk = lds + stage * KV_STAGE;
         unsigned char* sv = sk + WKEY * K_ROW;
+        const uint32_t bits = lds_mbits[rkey0 / WKEY];       // (WKEY = 32 keys = one word; tiles start at multiples of 32)
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + i * NTHREADS;
-            *(frag_t*)(sk + (c / CPR) * K_ROW + (c % CPR) * 16) = rk[i];
-            *(frag_t*)(sv + (c / CPR) * V_ROW + (c % CPR) * 16) = rv[i];
+            const bool keep = (bits >> (c / CPR)) & 1u;      // masked / out-of-range keys read as zero rows
+            *(frag_t*)(sk + (c / CPR) * K_ROW + (c % CPR) * 16) = keep_or_zero(rk[i], keep);
+            *(frag_t*)(sv + (c / CPR) * V_ROW + (c % CPR) * 16) = keep_or_zero(rv[i], keep);
         }
-        if (tid < WKEY) lds_bias_all[stage * WKEY + tid] = rbias;
+        if (tid < WKEY) lds_bias_all[stage * WKEY + tid] = ((bits >> tid) & 1u) ? 0.f : -INFINITY;
     };
 
     f32x16 o[NDT];
@@ -157,16 +139,24 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     // keys of this workgroup: all of them, or the blockIdx.z-th slice when the keys are split over workgroups
     // keys after the last valid one contribute exactly 0: stop there (padding is a suffix in the dataset's masks)
     int64_t l_eff = a.L;
-    if (maskg) {
+    {
+        const int lpad = (int)((a.L + 63) / 64) * 64;
         int last = -1;
-        for (int j = tid; j < (int)a.L; j += NTHREADS)
-            if (maskg[j] != 0.f) last = j;
+        for (int j = tid; j < lpad; j += NTHREADS) {
+            const bool valid = j < (int)a.L && (maskg == nullptr || maskg[j] != 0.f);
+            const unsigned long long bal = __ballot(valid);
+            if (lane == 0) { lds_mbits[j / 32] = (uint32_t)bal; lds_mbits[j / 32 + 1] = (uint32_t)(bal >> 32); }
+            if (valid) last = j;
+        }
+        if (tid == 0) lds_mbits[lpad / 32] = 0u;
+        if (maskg) {
 #pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
-        int* red = (int*)lds_s;
-        if (lane == 0) red[wave] = last;
-        __syncthreads();
-        l_eff = max(max(red[0], red[1]), max(red[2], red[3])) + 1;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
+            int* red = (int*)lds_s;
+            if (lane == 0) red[wave] = last;
+            __syncthreads();
+            l_eff = max(max(red[0], red[1]), max(red[2], red[3])) + 1;
+        }
         __syncthreads();
     }
     const int64_t nsplit = a.n_split > 1 ? a.n_split : 1;
@@ -382,12 +372,18 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     constexpr int SZ = (int)sizeof(TC);
     constexpr int K_ROW = D * SZ + 16, V_ROW = D * SZ + (SZ == 2 ? 64 : 16);
     constexpr int NSTAGE = DB ? 2 : 1;
-    const size_t lds_bytes = (size_t)NSTAGE * (WKEY * K_ROW + WKEY * V_ROW) + 4 * 1024 * 4 + NSTAGE * 32 * 4;
+    constexpr size_t kBase = (size_t)NSTAGE * (WKEY * K_ROW + WKEY * V_ROW) + 4 * 1024 * 4 + NSTAGE * 32 * 4;
+    constexpr size_t kCap = kBase + 8192 < 160 * 1024 ? kBase + 8192 : 160 * 1024;      // + the mask bit row (one bit per key)
+    const size_t lds_bytes = kBase + (size_t)((a.L + 63) / 64 * 2 + 2) * 4;
+    if (lds_bytes > kCap) {
+        made_set_error("made_attention_wide: L=%lld keys: the mask bit row does not fit in LDS beside the K / V stages", (long long)a.L);
+        return MADE_ERR_UNSUPPORTED;
+    }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D, DB, NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D, DB, NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCap);
         if (e != hipSuccess) {
-            made_set_error("made_attention_wide: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+            made_set_error("made_attention_wide: cannot reserve %zu bytes of LDS: %s", kCap, hipGetErrorString(e));
             return MADE_ERR_HIP;
         }
         attr_done = true;
