@@ -15,6 +15,8 @@
 
 namespace {
 
+__device__ const float kOne = 1.f;     // the "row mask" read when there is none (stride 0)
+
 constexpr int TBN = 128, TBK = 128, TNT = 256;
 
 template <typename TC> struct TnCfg;
@@ -89,9 +91,15 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
             prow[i] = a.row_index ? (int64_t)a.row_index[ml] : ml;
         }
     };
+    // load_slab only ISSUES the loads of the next slab (clamped addresses, the row mask read unconditionally: stride 0 over a
+    // constant 1.0 when there is none); rows past M, columns past N / K and masked rows are zeroed in store_slab, one slab later,
+    // after the current slab's MFMAs -- a use right behind the loads would make the wave wait for them before multiplying
+    float rmk[NCH];
+    int64_t rslab = 0;
+    const float* mrow = maskg ? maskg : &kOne;
+    const int64_t mstride = maskg ? 1 : 0;
     auto load_slab = [&](int64_t slab) __attribute__((always_inline)) {
-        // branch-free: clamped addresses, masking on the registers (rows past M, columns past N / K, masked rows)
-        float mk[NCH];
+        rslab = slab;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * TNT;
@@ -101,23 +109,18 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
             const int64_t nac = na < a.N ? na : 0, kbc = kb < a.K ? kb : 0;     // a chunk may run past N / K inside the row pitch
             ra[i] = *(const frag_t*)(Ag + mc * a.lda + nac);
             rb[i] = *(const frag_t*)(Bg + mc * a.ldb + kbc);
-            mk[i] = maskg ? maskg[mc] : 1.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + i * TNT;
-            const int row = c / CPR, cc = c % CPR;
-            const bool rowok = (slab * BM + row) < Mv && mk[i] != 0.f;
-            ra[i] = keep_or_zero(ra[i], rowok && (n0 + cc * PER16 < a.N));     // columns >= N only feed C rows that are not stored
-            rb[i] = keep_or_zero(rb[i], rowok && (k0 + cc * PER16 < a.K));
+            rmk[i] = mrow[mc * mstride];
         }
     };
     auto store_slab = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * TNT;
-            *(frag_t*)(lds_a + (c / CPR) * ROW + (c % CPR) * 16) = ra[i];
-            *(frag_t*)(lds_b + (c / CPR) * ROW + (c % CPR) * 16) = rb[i];
+            const int row = c / CPR, cc = c % CPR;
+            const bool rowok = (rslab * BM + row) < Mv && rmk[i] != 0.f;
+            // (columns >= N only feed C rows that are not stored)
+            *(frag_t*)(lds_a + row * ROW + cc * 16) = keep_or_zero(ra[i], rowok && (n0 + cc * PER16 < a.N));
+            *(frag_t*)(lds_b + row * ROW + cc * 16) = keep_or_zero(rb[i], rowok && (k0 + cc * PER16 < a.K));
         }
     };
 
