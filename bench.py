@@ -263,6 +263,11 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
         return trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
                               seed=it[0], lrs=(1e-4, 1e-4, 1e-4), max_grad_norm=1.0, dist=dist)
 
+    # a freshly booted box runs its first second of work at low clocks: bring the GPU to its working state before the W warmup steps
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.75:
+        step()
+    torch.cuda.synchronize()
     for _ in range(max(warmup, 1)):
         out = step()
     _barrier(dist)
