@@ -41,8 +41,13 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     constexpr int PER16 = 16 / SZ;
     constexpr int DS = D / NSL;                     // this wave's slice of D
     constexpr int WQB = WQ * (4 / NSL);             // queries per workgroup
-    constexpr int K_ROW = D * SZ + 16;              // padded: conflict-free 16-byte row reads
-    constexpr int V_ROW = D * SZ + (IS_BF16 ? 64 : 16);   // bf16: 4 consecutive rows land on disjoint bank quarters (tr reads)
+    // DMA: the two-stage bf16 variants (few, latency-bound workgroups: decoder cross-attention, in-batch X-Pool) stage K / V tiles
+    // global -> LDS directly (global_load_lds), so a whole tile is in flight under the current one without holding registers;
+    // rows are unpadded and XOR-swizzled on the source side (16-byte chunks by row for the K row reads, 64-byte groups by row for
+    // the transposing V reads); masked / out-of-range rows are fetched from the entry's first valid key instead of being zeroed.
+    constexpr bool DMA = IS_BF16 && DB;
+    constexpr int K_ROW = DMA ? D * SZ : D * SZ + 16;              // padded: conflict-free 16-byte row reads
+    constexpr int V_ROW = DMA ? D * SZ : D * SZ + (IS_BF16 ? 64 : 16);   // bf16: 4 consecutive rows land on disjoint bank quarters (tr reads)
     constexpr int CPR = D * SZ / 16;                // 16-byte chunks per row
     constexpr int NCH = WKEY * CPR / NTHREADS;      // chunks per thread per tensor
     static_assert(WKEY * CPR % NTHREADS == 0, "staging split");
@@ -139,23 +144,26 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     // keys of this workgroup: all of them, or the blockIdx.z-th slice when the keys are split over workgroups
     // keys after the last valid one contribute exactly 0: stop there (padding is a suffix in the dataset's masks)
     int64_t l_eff = a.L;
+    int first_valid = 0;
     {
         const int lpad = (int)((a.L + 63) / 64) * 64;
-        int last = -1;
+        int last = -1, first = 0x7fffffff;
         for (int j = tid; j < lpad; j += NTHREADS) {
             const bool valid = j < (int)a.L && (maskg == nullptr || maskg[j] != 0.f);
             const unsigned long long bal = __ballot(valid);
             if (lane == 0) { lds_mbits[j / 32] = (uint32_t)bal; lds_mbits[j / 32 + 1] = (uint32_t)(bal >> 32); }
-            if (valid) last = j;
+            if (valid) { last = j; first = min(first, j); }
         }
         if (tid == 0) lds_mbits[lpad / 32] = 0u;
         if (maskg) {
 #pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) last = max(last, __shfl_xor(last, o2));
+            for (int o2 = 32; o2 > 0; o2 >>= 1) { last = max(last, __shfl_xor(last, o2)); first = min(first, __shfl_xor(first, o2)); }
             int* red = (int*)lds_s;
-            if (lane == 0) red[wave] = last;
+            if (lane == 0) { red[wave] = last; red[4 + wave] = first; }
             __syncthreads();
             l_eff = max(max(red[0], red[1]), max(red[2], red[3])) + 1;
+            first_valid = min(min(red[4], red[5]), min(red[6], red[7]));
+            if (first_valid == 0x7fffffff) first_valid = 0;
         }
         __syncthreads();
     }
@@ -164,7 +172,34 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     const int64_t tiles_per = (tiles_all + nsplit - 1) / nsplit;
     const int64_t tile0 = (int64_t)blockIdx.z * tiles_per;
     const int64_t ntiles = tile0 >= tiles_all ? 0 : (tile0 + tiles_per <= tiles_all ? tiles_per : tiles_all - tile0);
-    if (NSTAGE == 2 && ntiles > 0) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    // (DMA) tile `key0` -> stage: this wave moves pieces wave, wave + 4, ... of both tiles (1 KB each: D = 512 one row, D = 256 two)
+    auto issue_tile = [&](int64_t key0, int stage) __attribute__((always_inline)) {
+        constexpr int ROWS_PER_PIECE = DMA ? 1024 / (D * SZ) : 1;
+        constexpr int NPIECE = WKEY / ROWS_PER_PIECE;
+        constexpr int CPRW = D * SZ / 16;                          // chunks per row
+        const uint32_t bits = lds_mbits[key0 / WKEY];
+        unsigned char* st = lds + stage * KV_STAGE;
+        const unsigned char* Kb = (const unsigned char*)Kg;
+        const unsigned char* Vb = (const unsigned char*)Vg;
+        const uint32_t ldk_b = (uint32_t)a.ldk * SZ, ldv_b = (uint32_t)a.ldv * SZ;
+#pragma unroll
+        for (int i = 0; i < NPIECE / 4; ++i) {
+            const int jp = wave + 4 * i;
+            const int row = ROWS_PER_PIECE == 1 ? jp : 2 * jp + (lane >> 5);
+            const uint32_t cl = ROWS_PER_PIECE == 1 ? (uint32_t)lane : (uint32_t)(lane & 31);
+            const uint32_t srow = ((bits >> row) & 1u) ? (uint32_t)(key0 + row) : (uint32_t)first_valid;
+            const uint32_t ck = cl ^ (uint32_t)(row & 31) & (uint32_t)(CPRW - 1);
+            const uint32_t cu = ((((cl >> 2) ^ (uint32_t)(row & 7)) << 2) | (cl & 3));
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kb + (size_t)(srow * ldk_b + ck * 16u)), (lds_ptr_t)(st + jp * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Vb + (size_t)(srow * ldv_b + cu * 16u)), (lds_ptr_t)(st + WKEY * K_ROW + jp * 1024), 16, 0, 0);
+        }
+    };
+    if constexpr (DMA) {
+        __builtin_amdgcn_s_waitcnt(0x0070);                         // (the Q fragment loads: see csrc/xpool_fused.hip on why a builtin)
+        if (ntiles > 0) issue_tile(tile0 * WKEY, 0);
+    } else if (NSTAGE == 2 && ntiles > 0) {
         load_tile(tile0 * WKEY);
         store_tile(0);
         __syncthreads();
@@ -172,7 +207,11 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     for (int64_t tt = 0; tt < ntiles; ++tt) {
         const int64_t t = tile0 + tt;
         const int cur = NSTAGE == 2 ? (int)(tt & 1) : 0;
-        if (NSTAGE == 2) {
+        uint32_t tbits = 0xffffffffu;
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile t landed; the other stage is free
+            tbits = lds_mbits[t];
+        } else if (NSTAGE == 2) {
             if (tt + 1 < ntiles) load_tile((t + 1) * WKEY);   // in flight during this tile's MFMAs; stored at the end of the tile
         } else {
             load_tile(t * WKEY);
@@ -190,13 +229,19 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NQF; ++ks) {
-            frag_t kf = *(const frag_t*)(lds_k + r * K_ROW + sl * DS * SZ + ks * 32 + hh * 16);
+            frag_t kf;
+            if constexpr (DMA) kf = *(const frag_t*)(lds_k + r * K_ROW + ((((sl * DS * SZ) / 16 + ks * 2 + hh) ^ r) << 4));   // (chunk ^ row)
+            else kf = *(const frag_t*)(lds_k + r * K_ROW + sl * DS * SZ + ks * 32 + hh * 16);
             if constexpr (IS_BF16) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[ks][e], s, 0, 0, 0);
             }
+        }
+        if constexpr (DMA) {
+            // the next tile's pieces are issued behind this tile's score MFMAs (a piece costs its wave 60-180 cycles of issue)
+            if (tt + 1 < ntiles) issue_tile((t + 1) * WKEY, cur ^ 1);
         }
         // ---- sum the four partial tiles through LDS; every wave ends with the full tile
 #pragma unroll
@@ -210,7 +255,8 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
             float v;
             if constexpr (NSL == 4) v = (lds_s[idx] + lds_s[1024 + idx]) + (lds_s[2048 + idx] + lds_s[3072 + idx]);
             else v = lds_s[qt * 2048 + idx] + lds_s[qt * 2048 + 1024 + idx];
-            v = v * a.scale + lds_bias[acc_row(e, hh)];
+            if constexpr (DMA) v = ((tbits >> acc_row(e, hh)) & 1u) ? v * a.scale : -INFINITY;
+            else v = v * a.scale + lds_bias[acc_row(e, hh)];
             s[e] = v;
             mx = fmaxf(mx, v);
         }
@@ -252,6 +298,27 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[8 * s2 + j];
                 // block rows = keys kb + (0..3) [+8 for the second read], block cols = 16 d's of this lane group
                 const int kb = 16 * s2 + 4 * (g >> 1);
+                if constexpr (DMA) {
+                    // transposing reads as inline assembly with a hand-placed wait: as builtins behind an LDS-DMA the compiler guards them
+                    // with s_waitcnt vmcnt(0), i.e. with a wait for the tile in flight (csrc/xpool_fused.hip)
+                    const int row = kb + (i >> 2);
+                    const uint32_t vb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_v + row * V_ROW + (g & 1) * 32 + (i & 3) * 8;
+                    bf16x4 lo[NDT], hi[NDT];
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        const uint32_t va = vb + ((((sl * DS) / 32 + d) ^ (row & 7)) << 6);
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[d]) : "v"(va));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[d]) : "v"(va), "n"(8 * V_ROW));
+                    }
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) asm volatile("" : "+v"(lo[d]), "+v"(hi[d]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        asm volatile("" : "+v"(lo[d]), "+v"(hi[d]));
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(lo[d], hi[d], 0, 1, 2, 3, 4, 5, 6, 7), pf, o[d], 0, 0, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int d = 0; d < NDT; ++d) {
                     const int dcol = sl * DS + d * 32 + (g & 1) * 16 + 4 * (i & 3);
@@ -261,6 +328,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp + 8 * V_ROW));
                     bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+                }
                 }
             }
         } else {
@@ -274,7 +342,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                 }
             }
         }
-        if (NSTAGE == 2) {
+        if (NSTAGE == 2 && !DMA) {
             if (tt + 1 < ntiles) store_tile(cur ^ 1);          // the other stage: nobody reads it during this tile
             __syncthreads();
         }
@@ -370,7 +438,8 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_combine_kernel(const 
 template <typename TC, int D, bool DB, int NSL>
 int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     constexpr int SZ = (int)sizeof(TC);
-    constexpr int K_ROW = D * SZ + 16, V_ROW = D * SZ + (SZ == 2 ? 64 : 16);
+    constexpr bool DMA = SZ == 2 && DB;                // (as in the kernel)
+    constexpr int K_ROW = DMA ? D * SZ : D * SZ + 16, V_ROW = DMA ? D * SZ : D * SZ + (SZ == 2 ? 64 : 16);
     constexpr int NSTAGE = DB ? 2 : 1;
     constexpr size_t kBase = (size_t)NSTAGE * (WKEY * K_ROW + WKEY * V_ROW) + 4 * 1024 * 4 + NSTAGE * 32 * 4;
     constexpr size_t kCap = kBase + 8192 < 160 * 1024 ? kBase + 8192 : 160 * 1024;      // + the mask bit row (one bit per key)
@@ -429,8 +498,9 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a.dtype == MADE_BF16) {
         const int64_t nq = a.NQ1 * a.NQ2;
-        const bool few = nq <= 64;                      // few query tiles per batch entry: latency-bound, use the two-stage variant
-        const bool pair = nq > 32 && nq <= 64;          // exactly two query tiles per entry (in-batch X-Pool at B = 64): one workgroup
+        // few query tiles per batch entry: latency-bound, use the two-stage (LDS-DMA) variant -- which cannot add Kadd on the way
+        const bool few = nq <= 64 && a.Kadd == nullptr;
+        const bool pair = nq > 32 && nq <= 64 && a.Kadd == nullptr;   // exactly two query tiles per entry (in-batch X-Pool at B = 64): one workgroup
         if (a.D == 512) {
             if (pair) return launch_wide<bf16_t, 512, true, 2>(a, st);
             return few ? launch_wide<bf16_t, 512, true, 4>(a, st) : launch_wide<bf16_t, 512, false, 4>(a, st);
