@@ -54,7 +54,7 @@ class MadeTrainer(MadeEngine):
             bad.append(f"mml_fusion={c.mml_fusion}")
         if c.moment_query_type not in ("video", "music", "zero", "random"):
             bad.append(f"moment_query_type={c.moment_query_type}")
-        if c.vmr_fusion != "XA-music":
+        if c.vmr_fusion not in ("XA-music", "XA-video", "XA-video-music", "XA-music-video"):
             bad.append(f"vmr_fusion={c.vmr_fusion}")
         if c.vmr_loss == "dual_single_feature_fuse":
             bad.append("vmr_loss=dual_single_feature_fuse")
@@ -68,6 +68,14 @@ class MadeTrainer(MadeEngine):
             raise NotImplementedError("MadeTrainer (HIP training path) does not cover yet: " + "; ".join(bad))
 
     # ------------------------------------------------------------------ parameters
+    def _towers(self) -> List[Tuple[str, str]]:
+        t = []
+        if "music" in self.cfg.vmr_fusion:
+            t.append(("xa", XA))
+        if "video" in self.cfg.vmr_fusion:
+            t.append(("xav", "music_guided_to_video_pooling_cross_transformer"))
+        return t
+
     def _table(self) -> Tuple[List[Tuple[str, object]], List[Tuple[str, object]]]:
         """(kernel key, reference name(s)) for matrices and for vectors, mirroring MadeEngine.load_state_dict."""
         c = self.cfg
@@ -94,11 +102,14 @@ class MadeTrainer(MadeEngine):
                 lin(p + ".out", q + ".1.out_proj"); ln(p + ".ln2", q + ".2")
                 lin(p + ".ff1", q + ".3.0"); lin(p + ".ff2", q + ".3.3")
             lin(mod + ".final", src + ".final_linear")
-        ln("xa.ln1", XA + ".layer_norm1"); ln("xa.ln2", XA + ".layer_norm2"); ln("xa.ln3", XA + ".layer_norm3")
-        lin("xa.q", XA + ".cross_attn.q_proj")
-        mats.append(("xa.kv.w", (XA + ".cross_attn.k_proj.weight", XA + ".cross_attn.v_proj.weight")))
-        vecs.append(("xa.kv.b", (XA + ".cross_attn.k_proj.bias", XA + ".cross_attn.v_proj.bias")))
-        lin("xa.out", XA + ".cross_attn.out_proj"); lin("xa.lin", XA + ".linear_proj")
+        # the X-Pool towers the configuration builds (reference model/model_Uni.py:24-27): video-guided music pooling ("xa"),
+        # music-guided video pooling ("xav": the same block with the roles swapped)
+        for key, xa in self._towers():
+            ln(key + ".ln1", xa + ".layer_norm1"); ln(key + ".ln2", xa + ".layer_norm2"); ln(key + ".ln3", xa + ".layer_norm3")
+            lin(key + ".q", xa + ".cross_attn.q_proj")
+            mats.append((key + ".kv.w", (xa + ".cross_attn.k_proj.weight", xa + ".cross_attn.v_proj.weight")))
+            vecs.append((key + ".kv.b", (xa + ".cross_attn.k_proj.bias", xa + ".cross_attn.v_proj.bias")))
+            lin(key + ".out", xa + ".cross_attn.out_proj"); lin(key + ".lin", xa + ".linear_proj")
         vecs.append(("logit_scale", "logit_scale"))
         if "CA" in c.mml_fusion:                                      # reference model/model_Base.py:99-213 (bias-free q / kv)
             ca = "video_music_fusion_cross_transformer"
@@ -140,14 +151,17 @@ class MadeTrainer(MadeEngine):
         [2D, D] projection is one view."""
         dev = self.device
         names = [k for k in sd if not k.endswith(".pe") and k != "criterion.empty_weight"]
-        pair_after = {XA + ".cross_attn.k_proj.weight": XA + ".cross_attn.v_proj.weight",
-                      XA + ".cross_attn.k_proj.bias": XA + ".cross_attn.v_proj.bias"}
+        XAV = "music_guided_to_video_pooling_cross_transformer"
+        pair_after = {}
+        for xa in (XA, XAV):
+            pair_after[xa + ".cross_attn.k_proj.weight"] = xa + ".cross_attn.v_proj.weight"
+            pair_after[xa + ".cross_attn.k_proj.bias"] = xa + ".cross_attn.v_proj.bias"
         # optimizer groups of the reference (model/model_Uni.py:73-114, train-MaDe.py:262-266) laid out as contiguous ranges
         def group_of(k: str) -> int:
             if k.startswith(("vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.", "share_transformer.")):
                 return 0                                      # temporal
-            if k.startswith(XA + ".") or k == "logit_scale":
-                return 1                                      # matching
+            if k.startswith((XA + ".", XAV + ".")) or k == "logit_scale":
+                return 1                                      # matching (both X-Pool towers: model_Uni.py:77-86)
             if "regression" in self.cfg.mml_localization:     # model_Uni.py:92-100: the regression variant optimises the CA fusion block and
                 if k.startswith(("video_music_fusion_cross_transformer.", "reg_mlp.")):       # the regression MLP only; the DETR
                     return 2                                  # transformer gets gradients but is in no optimizer group
@@ -347,6 +361,7 @@ class MadeTrainer(MadeEngine):
             xS=E(B * B, Sp, dtype=f32), xdP=E(B * B, Sp, dtype=f32), xP=E(B * B, Sp), xdS=E(B * B, Sp), xdSt=E(B, Ta, B),
             xdkv=E(B * Ta, 2 * D), xds1=E(B * Ta, D), xdseg=E(B * Ta, D), xdq32=E(B, D, dtype=f32), xdq=E(B, D), xdv1=E(B, D),
             vn=E(B, D, dtype=f32), mn=E(B, D, dtype=f32), dvn=E(B, D, dtype=f32), dmn=E(B, D, dtype=f32),
+            sims_vp_t=E(B, B, dtype=f32), dsims_st=E(B, B, dtype=f32),
             dsims_s=E(B, B, dtype=f32), dsims_d=E(B, B, dtype=f32), dsims_dt=E(B, B, dtype=f32), clip_ws=E(2 * B, dtype=f32),
             sims_both=E(B, B, dtype=f32), sd_ws=E(16 * B * B, dtype=f32),
             dvideo=E(B, D, dtype=f32), dmusic=E(B, D, dtype=f32),
@@ -364,6 +379,14 @@ class MadeTrainer(MadeEngine):
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D), hg1=E(nd * B * Q, D), hg2=E(nd * B * Q, D),
             dlog=Z(nd * B * Q, 8, dtype=f32), dsp=Z(nd * B * Q, 8, dtype=f32), dlog_c=Z(nd * B * Q, 8), dsp_c=Z(nd * B * Q, 8),
         )
+        if "video" in c.vmr_fusion:                             # second X-Pool tower: music vectors attend to the frames ("y" = "x" with S = T_v)
+            Svp = round_up(Tv, 8)
+            ws.update(
+                yv1=E(B, D), yq=E(B, D), ys1=E(B * Tv, D), yk=E(B * Tv, D), yu=E(B * Tv, D), yo=E(B * B, D), ya2=E(B * B, D),
+                ya3=E(B * B, D), yy=E(B * B, D), yg1=E(B * B, D), yg2=E(B * B, D), yg3=E(B * B, D),
+                yS=E(B * B, Svp, dtype=f32), ydP=E(B * B, Svp, dtype=f32), yP=E(B * B, Svp), ydS=E(B * B, Svp), ydSt=E(B, Tv, B),
+                ydkv=E(B * Tv, 2 * D), yds1=E(B * Tv, D), ydseg=E(B * Tv, D), ydq32=E(B, D, dtype=f32), ydq=E(B, D), ydv1=E(B, D),
+                dframe_sum=E(B * Tv, D))
         for l in range(ne):
             ws.update({f"e.{l}.src": E(rows, D), f"e.{l}.srcpos": E(rows, D), f"e.{l}.qkv": E(rows, 3 * D), f"e.{l}.att": E(rows, D),
                        f"e.{l}.lse": E(B * H * L, dtype=f32), f"e.{l}.x": E(rows, D), f"e.{l}.s1": E(rows, D), f"e.{l}.h": E(rows, Fd),
@@ -467,7 +490,17 @@ class MadeTrainer(MadeEngine):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             xmask = sm if c.fusion_mask == 1 else None
-            self._xpool_train(video, seg, xmask, ws, tw, B, Ta)
+            if "music" in c.vmr_fusion:
+                self._xpool_train(video, seg, xmask, ws, tw, B, Ta)
+            if "video" in c.vmr_fusion and c.vmr_loss == "single":
+                # music-guided video pooling gives sims[m, v]; the reference adds its transpose to the music-pooling similarities in
+                # the `single` loss and uses it nowhere else (model_Uni.py:203,247-251)
+                self._xpool_train(music, frame, fm if c.fusion_mask == 1 else None, ws, tw, B, Tv, key="xav", pre="y", sims_out=tw["sims_vp_t"])
+                if "music" in c.vmr_fusion:
+                    ws["sims_single"].add_(tw["sims_vp_t"].t())
+                else:
+                    ws["sims_single"].copy_(tw["sims_vp_t"].t())
+                out["sims_video_pooling"] = tw["sims_vp_t"].t()
             ops.l2norm_rows(video, out_f32=tw["vn"]); ops.l2norm_rows(music, out_f32=tw["mn"])
             if B % 4 == 0 and B <= 256:                      # one output tile: split K over workgroups (exact-f32 MFMA either way)
                 split = max(2, min(16, D // 32))
@@ -688,21 +721,24 @@ class MadeTrainer(MadeEngine):
         ops.masked_mean(local, mask, out=tw[tag + ".mean"])
         ops.l2norm_rows(tw[tag + ".mean"], out_f32=vec)
 
-    def _xpool_train(self, video: Tensor, seg: Tensor, seg_mask: Optional[Tensor], ws, tw, B: int, S: int) -> None:
-        """reference modules/transformer.py:156-180 (+ :87-123) over the batch's B x B pairs, dropout 0.3 on linear_out."""
+    def _xpool_train(self, video: Tensor, seg: Tensor, seg_mask: Optional[Tensor], ws, tw, B: int, S: int, key: str = "xa", pre: str = "x",
+                     sims_out: Optional[Tensor] = None) -> None:
+        """reference modules/transformer.py:156-180 (+ :87-123) over the batch's B x B pairs, dropout 0.3 on linear_out.  `video` = the
+        B query vectors, `seg` [B, S, D] the sequences they pool; tower "xav" (buffers "y*") is the same block with the roles swapped."""
         P, D = self.P, self.cfg.D
         skip = seg_mask.reshape(-1) if seg_mask is not None else None
-        v1 = ops.layernorm(video, P["xa.ln1.g"], P["xa.ln1.b"], out=tw["xv1"])
-        q = ops.linear(v1, P["xa.q.w"], P["xa.q.b"], out=tw["xq"])
-        s1 = ops.layernorm(seg, P["xa.ln1.g"], P["xa.ln1.b"], out=tw["xs1"], row_skip=skip)
-        ops.linear(s1, P["xa.kv.w"], P["xa.kv.b"], rows=self._rw(skip), tile_skip_mask=skip if self._rw(skip) is None else None,
-                   segs=[Seg(out=tw["xk"], col_begin=0), Seg(out=tw["xu"], col_begin=D)])
-        ops.attention_wide(q.view(1, B, 1, D), tw["xk"].view(B, S, D), tw["xu"].view(B, S, D), tw["xo"].view(B, B, 1, D),
+        v1 = ops.layernorm(video, P[key + ".ln1.g"], P[key + ".ln1.b"], out=tw[pre + "v1"])
+        q = ops.linear(v1, P[key + ".q.w"], P[key + ".q.b"], out=tw[pre + "q"])
+        s1 = ops.layernorm(seg, P[key + ".ln1.g"], P[key + ".ln1.b"], out=tw[pre + "s1"], row_skip=skip)
+        ops.linear(s1, P[key + ".kv.w"], P[key + ".kv.b"], rows=self._rw(skip), tile_skip_mask=skip if self._rw(skip) is None else None,
+                   segs=[Seg(out=tw[pre + "k"], col_begin=0), Seg(out=tw[pre + "u"], col_begin=D)])
+        ops.attention_wide(q.view(1, B, 1, D), tw[pre + "k"].view(B, S, D), tw[pre + "u"].view(B, S, D), tw[pre + "o"].view(B, B, 1, D),
                            scale=1.0 / math.sqrt(D), key_mask=seg_mask, shared_q=True)
-        a2 = ops.linear(tw["xo"], P["xa.out.w"], P["xa.out.b"], out=tw["xa2"])
-        a3 = ops.layernorm(a2, P["xa.ln2.g"], P["xa.ln2.b"], out=tw["xa3"])
-        y = ops.linear(a3, P["xa.lin.w"], P["xa.lin.b"], R=a3, out=tw["xy"], drop=self._drop("xa.linear_out", dr.P_XPOOL))
-        ops.xpool_tail(y, P["xa.ln3.g"], P["xa.ln3.b"], video, ws["sims_single"], B, B)
+        a2 = ops.linear(tw[pre + "o"], P[key + ".out.w"], P[key + ".out.b"], out=tw[pre + "a2"])
+        a3 = ops.layernorm(a2, P[key + ".ln2.g"], P[key + ".ln2.b"], out=tw[pre + "a3"])
+        # (the oracle / reference masks name the site after the block class, not the tower)
+        y = ops.linear(a3, P[key + ".lin.w"], P[key + ".lin.b"], R=a3, out=tw[pre + "y"], drop=self._drop("xa.linear_out", dr.P_XPOOL))
+        ops.xpool_tail(y, P[key + ".ln3.g"], P[key + ".ln3.b"], video, ws["sims_single"] if sims_out is None else sims_out, B, B)
 
     def _ca_fusion_train(self, ws, tw, frame: Tensor, seg: Tensor, fm: Tensor, sm: Tensor, B: int, Tv: int, Ta: int) -> None:
         """reference model/model_Base.py:194-213 (+ :130-167, :22-45) in train mode, then the masked_fill of model_Uni.py:211:
@@ -1046,7 +1082,11 @@ class MadeTrainer(MadeEngine):
         # ---------------- temporal encoders (video on the second stream)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._encode_bwd("video", ws, tw, dl_v, tw["dframe_x"].view(B, Tv, D) if (c.contrastive_align_loss and not regression) else None, dvideo, fm, feats_v)
+            # extra gradients of the frame features: the contrastive-align projection and the second X-Pool tower's pooled sequences
+            dxv = tw["dframe_x"] if (c.contrastive_align_loss and not regression) else None
+            if "video" in c.vmr_fusion:
+                dxv = tw["ydseg"] if dxv is None else tr.add3(tw["dframe_sum"], dxv, tw["ydseg"])
+            self._encode_bwd("video", ws, tw, dl_v, dxv.view(B, Tv, D) if dxv is not None else None, dvideo, fm, feats_v)
         self._encode_bwd("audio", ws, tw, dl_a, tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a)
         cur.wait_stream(side)
 
@@ -1100,54 +1140,67 @@ class MadeTrainer(MadeEngine):
         ls, gls = P["logit_scale"], G["logit_scale"]
         wgt = float(c.dual_single_loss_weight)
         ds_s, ds_d, ds_dt, cws = tw["dsims_s"], tw["dsims_d"], tw["dsims_dt"], tw["clip_ws"]
+        ds_st = tw["dsims_st"] if "video" in c.vmr_fusion else None      # d sims_single^T: the second tower scores [track, video]
         single = dual = False
         if c.vmr_loss == "dual":
             tr.clip_loss_bwd(ws["sims_dual"], ls, wgt, g_ret, cws, ds_d, ds_dt, gls); dual = True
         elif c.vmr_loss == "single":
-            tr.clip_loss_bwd(ws["sims_single"], ls, wgt, g_ret, cws, ds_s, None, gls); single = True
+            tr.clip_loss_bwd(ws["sims_single"], ls, wgt, g_ret, cws, ds_s, ds_st, gls); single = True
         elif c.vmr_loss == "dual_single_loss_fuse":
             tr.clip_loss_bwd(ws["sims_dual"], ls, 1.0, g_ret, cws, ds_d, ds_dt, gls, row_exclude=getattr(self, "_row_exclude", None))
-            tr.clip_loss_bwd(ws["sims_single"], ls, 1.0, g_ret, cws, ds_s, None, gls)
+            tr.clip_loss_bwd(ws["sims_single"], ls, 1.0, g_ret, cws, ds_s, ds_st, gls)
             single = dual = True
         else:                                                # dual_single_sim_fuse: one loss on the summed similarities
             both = tr.add3(tw["sims_both"], ws["sims_dual"], ws["sims_single"])
             tr.clip_loss_bwd(both, ls, wgt, g_ret, cws, ds_d, ds_dt, gls)
             ds_s.copy_(ds_d)
+            if ds_st is not None:
+                ds_st.copy_(ds_dt)
             single = dual = True
-        seg_mask = sm if c.fusion_mask == 1 else None
-        skip = seg_mask.reshape(-1) if seg_mask is not None else None
-        if single:
-            g1, g2, g3 = tw["xg1"], tw["xg2"], tw["xg3"]
-            tr.xpool_tail_bwd(tw["xy"], P["xa.ln3.g"], P["xa.ln3.b"], video, ds_s, g1, B, B, dy_drop=g2, drop=self._drop("xa.linear_out", dr.P_XPOOL),
-                              dgamma=G["xa.ln3.g"], dbeta=G["xa.ln3.b"], dvideo=dvideo)
-            da3 = self._lin_bwd(g2, tw["xa3"], "xa.lin", dx_out=g3, R=g1)
-            tr.layernorm_bwd(tw["xa2"], P["xa.ln2.g"], da3, g1, dgamma=G["xa.ln2.g"], dbeta=G["xa.ln2.b"])
-            do = self._lin_bwd(g1, tw["xo"], "xa.out", dx_out=g2)
-            Sp = tw["xS"].shape[1]
-            xk, xu, q = tw["xk"], tw["xu"], tw["xq"]
-            ops.linear(q, xk[:S], None, M=B, N=S, K=D, batch=B, a_z_stride=0, w_z_stride=S * D, segs=[Seg(out=tw["xS"], ldo=Sp, out_z_stride=B * Sp)])
-            ops.linear(do[:B], xu[:S], None, M=B, N=S, K=D, batch=B, a_z_stride=B * D, w_z_stride=S * D, segs=[Seg(out=tw["xdP"], ldo=Sp, out_z_stride=B * Sp)])
-            tr.softmax_bwd(tw["xS"], tw["xdP"], seg_mask, B, 1.0 / math.sqrt(D), tw["xP"], tw["xdS"], tw["xdSt"], B, S, ldo=Sp, ldt=B)
-            dkv = tw["xdkv"]
-            # dU[m] = P[m]^T dO[m];  dK[m] = dS[m]^T q;  dq = sum_m dS[m] K[m]
-            tr.gemm_tn(tw["xP"][:B, :S], do[:B], dkv[:S, D:], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(B * D, 0), c_zs=(S * 2 * D, 0))
-            tr.gemm_tn(tw["xdS"][:B, :S], q, dkv[:S, :D], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(0, 0), c_zs=(S * 2 * D, 0))
-            tw["xdq32"].zero_()
-            tr.gemm_tn(tw["xdSt"][0], xk[:S], tw["xdq32"], batch=(B, 1), a_zs=(S * B, 0), b_zs=(S * D, 0), c_zs=(0, 0), accumulate=True,
-                       row_mask=seg_mask, mask_zs=(S, 0))
-            ds1 = self._lin_bwd(dkv, tw["xs1"], "xa.kv", dx_out=tw["xds1"], row_mask=skip, skip=skip)
-            seg = self._views[1]
-            tr.layernorm_bwd(seg, P["xa.ln1.g"], ds1, tw["xdseg"], dgamma=G["xa.ln1.g"], dbeta=G["xa.ln1.b"], row_skip=skip)
-            dq = tr.add3(tw["xdq"], tw["xdq32"])
-            dv1 = self._lin_bwd(dq, tw["xv1"], "xa.q", dx_out=tw["xdv1"])
-            tr.layernorm_bwd(video, P["xa.ln1.g"], dv1, dvideo, dgamma=G["xa.ln1.g"], dbeta=G["xa.ln1.b"], add=dvideo)
+        frame, seg = self._views
+        if single and "music" in c.vmr_fusion:
+            self._xpool_bwd(tw, "xa", "x", ds_s, video, dvideo, seg, sm if c.fusion_mask == 1 else None, B, S)
         else:
             tw["xdseg"].zero_()
+        if "video" in c.vmr_fusion:
+            if single and c.vmr_loss == "single":            # queries = the music vectors, pooled sequences = the frames
+                self._xpool_bwd(tw, "xav", "y", ds_st, music, dmusic, frame, self._inputs[2] if c.fusion_mask == 1 else None, B, frame.shape[1])
+            else:
+                tw["ydseg"].zero_()
         if dual:
             tr.gemm_tn(ds_dt, tw["mn"], tw["dvn"])            # d vhat = dsims mhat
             tr.gemm_tn(ds_d, tw["vn"], tw["dmn"])             # d mhat = dsims^T vhat
             tr.l2norm_bwd(video, tw["dvn"], dvideo, accumulate=True)
             tr.l2norm_bwd(music, tw["dmn"], dmusic, accumulate=True)
+
+    def _xpool_bwd(self, tw, key: str, pre: str, ds: Tensor, qvec: Tensor, dqvec: Tensor, seg: Tensor, seg_mask: Optional[Tensor], B: int, S: int) -> None:
+        """backward of one X-Pool tower (_xpool_train): ds = d loss / d sims [query, sequence]; accumulates the gradient of the query
+        vectors into dqvec and writes the gradient of the pooled sequences to tw[pre + "dseg"]."""
+        P, G, D = self.P, self.G, self.cfg.D
+        skip = seg_mask.reshape(-1) if seg_mask is not None else None
+        g1, g2, g3 = tw[pre + "g1"], tw[pre + "g2"], tw[pre + "g3"]
+        tr.xpool_tail_bwd(tw[pre + "y"], P[key + ".ln3.g"], P[key + ".ln3.b"], qvec, ds, g1, B, B, dy_drop=g2, drop=self._drop("xa.linear_out", dr.P_XPOOL),
+                          dgamma=G[key + ".ln3.g"], dbeta=G[key + ".ln3.b"], dvideo=dqvec)
+        da3 = self._lin_bwd(g2, tw[pre + "a3"], key + ".lin", dx_out=g3, R=g1)
+        tr.layernorm_bwd(tw[pre + "a2"], P[key + ".ln2.g"], da3, g1, dgamma=G[key + ".ln2.g"], dbeta=G[key + ".ln2.b"])
+        do = self._lin_bwd(g1, tw[pre + "o"], key + ".out", dx_out=g2)
+        Sp = tw[pre + "S"].shape[1]
+        xk, xu, q = tw[pre + "k"], tw[pre + "u"], tw[pre + "q"]
+        ops.linear(q, xk[:S], None, M=B, N=S, K=D, batch=B, a_z_stride=0, w_z_stride=S * D, segs=[Seg(out=tw[pre + "S"], ldo=Sp, out_z_stride=B * Sp)])
+        ops.linear(do[:B], xu[:S], None, M=B, N=S, K=D, batch=B, a_z_stride=B * D, w_z_stride=S * D, segs=[Seg(out=tw[pre + "dP"], ldo=Sp, out_z_stride=B * Sp)])
+        tr.softmax_bwd(tw[pre + "S"], tw[pre + "dP"], seg_mask, B, 1.0 / math.sqrt(D), tw[pre + "P"], tw[pre + "dS"], tw[pre + "dSt"], B, S, ldo=Sp, ldt=B)
+        dkv = tw[pre + "dkv"]
+        # dU[m] = P[m]^T dO[m];  dK[m] = dS[m]^T q;  dq = sum_m dS[m] K[m]
+        tr.gemm_tn(tw[pre + "P"][:B, :S], do[:B], dkv[:S, D:], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(B * D, 0), c_zs=(S * 2 * D, 0))
+        tr.gemm_tn(tw[pre + "dS"][:B, :S], q, dkv[:S, :D], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(0, 0), c_zs=(S * 2 * D, 0))
+        tw[pre + "dq32"].zero_()
+        tr.gemm_tn(tw[pre + "dSt"][0], xk[:S], tw[pre + "dq32"], batch=(B, 1), a_zs=(S * B, 0), b_zs=(S * D, 0), c_zs=(0, 0), accumulate=True,
+                   row_mask=seg_mask, mask_zs=(S, 0))
+        ds1 = self._lin_bwd(dkv, tw[pre + "s1"], key + ".kv", dx_out=tw[pre + "ds1"], row_mask=skip, skip=skip)
+        tr.layernorm_bwd(seg, P[key + ".ln1.g"], ds1, tw[pre + "dseg"], dgamma=G[key + ".ln1.g"], dbeta=G[key + ".ln1.b"], row_skip=skip)
+        dq = tr.add3(tw[pre + "dq"], tw[pre + "dq32"])
+        dv1 = self._lin_bwd(dq, tw[pre + "v1"], key + ".q", dx_out=tw[pre + "dv1"])
+        tr.layernorm_bwd(qvec, P[key + ".ln1.g"], dv1, dqvec, dgamma=G[key + ".ln1.g"], dbeta=G[key + ".ln1.b"], add=dqvec)
 
     def _encode_bwd(self, which: str, ws, tw, d_local: Tensor, d_extra: Optional[Tensor], dvec: Tensor, mask: Tensor, feats: Tensor) -> None:
         c, P, G = self.cfg, self.P, self.G

@@ -584,7 +584,7 @@ def forward(P, cfg, frame_feats, segment_feats, frame_masks, segment_masks, span
     pooled_v = None
     if "XA" in cfg.vmr_fusion and "video" in cfg.vmr_fusion:
         pooled_v = xpool(music, frame, fm if cfg.fusion_mask == 1 else None, P,
-                         xa="music_guided_to_video_pooling_cross_transformer")
+                         xa="music_guided_to_video_pooling_cross_transformer", drop=drop)
 
     if "concat" in cfg.mml_fusion:
         fus = torch.cat([frame, seg], dim=1)

@@ -1,6 +1,5 @@
 R=$GRAFT_REPO_ROOT; cd $R
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-P='import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])'
-python bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "$P"
-python bench.py --workload forward --steps 40 --warmup 5 --no-cpu-baseline --in-flight 1 2>/dev/null | python -c "$P"
-python bench.py --workload forward --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "$P"
+timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -k "xpool_fused" 2>&1 | tail -2
+timeout 300 python tools/xpool_only.py 53000 512 2>&1 | tail -1
+timeout 300 python tools/xpool_only.py 53000 512 2>&1 | tail -1
+python tools/xpool_stamps.py 96 | sed -n 2,3p; python tools/xpool_stamps.py 96 | sed -n 16,17p
