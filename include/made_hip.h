@@ -542,11 +542,14 @@ int made_clip_loss_bwd(const float* sims, int64_t ld, int64_t n, const float* lo
 
 /* made_xpool_tail_bwd: backward of made_xpool_tail (LayerNorm3 + cosine with the video, reference modules/transformer.py:178,
  *   modules/metrics.py:10-24): dy [Nm*Nv, D], optionally dy_drop = dropout(dy) (element index row*D + col), dgamma/dbeta
- *   accumulated, dvideo[n,:] += (atomic). */
+ *   accumulated, dvideo[n,:] += (atomic).  dpool [Nm, D] f32 or NULL: an additional gradient of the pooled rows themselves,
+ *   dpool[m, :] * dpool_scale for every n (moment_query_type = "xpool": the decoder's content query is the mean over the
+ *   videos of a track's pooled vectors, reference model/model_Uni.py:222-223). */
 int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, const float* gamma, const float* beta,
                         const float* video, int64_t ld_video, const float* dsims, int64_t ld_dsims,
                         void* dy, int32_t dy_dtype, int64_t lddy, void* dy_drop, const MadeDropout* drop,
                         float* dgamma, float* dbeta, float* dvideo, int64_t ld_dvideo,
+                        const float* dpool, int64_t ld_dpool, float dpool_scale,
                         int64_t Nm, int64_t Nv, int64_t D, float eps, void* stream);
 
 /* made_softmax_bwd: softmax backward of the wide-head attention with materialised scores (few query rows per batch):

@@ -162,7 +162,7 @@ SIGNATURES = {
     "made_l2norm_bwd": (C.c_int, [vp, i32, i64, vp, i64, i64, vp, i64, i32, vp, i32, i64, i64, i64, f32, vp]),
     "made_clip_loss_bwd": (C.c_int, [vp, i64, i64, vp, f32, vp, vp, vp, vp, i32, vp, vp, vp]),
     "made_xpool_tail_bwd": (C.c_int, [vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, i32, i64, vp, C.POINTER(MadeDropout),
-                                      vp, vp, vp, i64, i64, i64, i64, f32, vp]),
+                                      vp, vp, vp, i64, vp, i64, f32, i64, i64, i64, f32, vp]),
     "made_softmax_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, f32, C.POINTER(MadeDropout), vp, vp, vp, i32, i64, i64,
                                    i64, i64, i64, i64, i64, vp]),
     "made_head_bias": (C.c_int, [vp, i32, i64, vp, vp, i64, i64, i64, vp]),

@@ -407,6 +407,7 @@ struct XtailBwdArgs {
     void* dy; int dydt; int64_t lddy;
     void* dyd; MadeDropout drop;
     float* dgamma; float* dbeta; float* dvideo; int64_t lddv;
+    const float* dpool; int64_t lddp; float dpool_scale;      // extra gradient of the pooled rows: dpool[m, :] * scale for every n
     int64_t rows, Nv; int D; float eps;
 };
 
@@ -477,11 +478,12 @@ __global__ __launch_bounds__(NW * 64) void xpool_tail_bwd_kernel(const XtailBwdA
             const int c = (i * WAVE + lane) * 4;
             if (c < D) {
                 const f32x4 gm = *(const f32x4*)(a.gamma + c);
-                f32x4 dvd;
+                f32x4 dvd, dpx = {0.f, 0.f, 0.f, 0.f};
+                if (a.dpool) dpx = *(const f32x4*)(a.dpool + m * a.lddp + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float ph = pv[i][j] / np, vh = vd[i][j] / nvn;
-                    const float dp = ds * (vh - sim * ph) / np;
+                    const float dp = ds * (vh - sim * ph) / np + dpx[j] * a.dpool_scale;
                     dvd[j] = ds * (ph - sim * vh) / nvn;
                     dg[i][j] += dp * xh[i][j];
                     db[i][j] += dp;
@@ -732,8 +734,10 @@ extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, 
                                    const float* video, int64_t ld_video, const float* dsims, int64_t ld_dsims,
                                    void* dy, int32_t dy_dtype, int64_t lddy, void* dy_drop, const MadeDropout* drop,
                                    float* dgamma, float* dbeta, float* dvideo, int64_t ld_dvideo,
+                                   const float* dpool, int64_t ld_dpool, float dpool_scale,
                                    int64_t Nm, int64_t Nv, int64_t D, float eps, void* stream) {
     MADE_REQUIRE(y && gamma && beta && video && dsims && dy, "made_xpool_tail_bwd: null pointer");
+    MADE_UNSUPPORTED(dpool == nullptr || (ld_dpool % 4 == 0 && ((uintptr_t)dpool % 16) == 0), "made_xpool_tail_bwd: dpool must keep 16-byte alignment");
     MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV && ldy % 4 == 0 && ld_video % 4 == 0 && lddy % 4 == 0,
                      "made_xpool_tail_bwd: bad D/strides");
     const int64_t rows = Nm * Nv;
@@ -744,6 +748,7 @@ extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, 
     a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f;
     if (drop) a.drop = *drop;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dvideo = dvideo; a.lddv = ld_dvideo;
+    a.dpool = dpool; a.lddp = ld_dpool; a.dpool_scale = dpool_scale;
     a.rows = rows; a.Nv = Nv; a.D = (int)D; a.eps = eps;
     if (rows > 256 && D <= 1024) {
         int64_t nb = (rows + 15) / 16;

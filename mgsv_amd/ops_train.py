@@ -214,11 +214,13 @@ def clip_loss_bwd(sims: Tensor, logit_scale: Tensor, weight: float, upstream: Op
 
 def xpool_tail_bwd(y: Tensor, gamma: Tensor, beta: Tensor, video: Tensor, dsims: Tensor, dy: Tensor, Nm: int, Nv: int, *,
                    dy_drop: Optional[Tensor] = None, drop=None, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
-                   dvideo: Optional[Tensor] = None, eps: float = 1e-5) -> None:
+                   dvideo: Optional[Tensor] = None, dpool: Optional[Tensor] = None, dpool_scale: float = 1.0, eps: float = 1e-5) -> None:
+    """dpool [Nm, D] f32: an extra gradient of the pooled rows, dpool[m] * dpool_scale for every video n (include/made_hip.h)."""
     D = y.shape[1]
     check(lib().made_xpool_tail_bwd(_p(y), dt_of(y), y.stride(0), _p(gamma), _p(beta), _p(_f32(video, "video")), video.stride(0),
                                     _p(_f32(dsims, "dsims")), dsims.stride(0), _p(dy), dt_of(dy), dy.stride(0), _p(dy_drop),
                                     _drop_ptr(drop), _p(dgamma), _p(dbeta), _p(dvideo), dvideo.stride(0) if dvideo is not None else 0,
+                                    _p(_f32(dpool, "dpool")), dpool.stride(0) if dpool is not None else 0, float(dpool_scale),
                                     Nm, Nv, D, eps, _stream()), "made_xpool_tail_bwd")
 
 

@@ -52,8 +52,10 @@ class MadeTrainer(MadeEngine):
         bad = []
         if "concat" not in c.mml_fusion and "CA" not in c.mml_fusion:
             bad.append(f"mml_fusion={c.mml_fusion}")
-        if c.moment_query_type not in ("video", "music", "zero", "random"):
+        if c.moment_query_type not in ("video", "music", "zero", "random", "xpool"):
             bad.append(f"moment_query_type={c.moment_query_type}")
+        if c.moment_query_type == "xpool" and "music" not in c.vmr_fusion:
+            bad.append("moment_query_type=xpool without the music-pooling tower (the reference fails there too)")
         if c.vmr_fusion not in ("XA-music", "XA-video", "XA-video-music", "XA-music-video"):
             bad.append(f"vmr_fusion={c.vmr_fusion}")
         if c.vmr_loss == "dual_single_feature_fuse":
@@ -362,6 +364,8 @@ class MadeTrainer(MadeEngine):
             xdkv=E(B * Ta, 2 * D), xds1=E(B * Ta, D), xdseg=E(B * Ta, D), xdq32=E(B, D, dtype=f32), xdq=E(B, D), xdv1=E(B, D),
             vn=E(B, D, dtype=f32), mn=E(B, D, dtype=f32), dvn=E(B, D, dtype=f32), dmn=E(B, D, dtype=f32),
             sims_vp_t=E(B, B, dtype=f32), dsims_st=E(B, B, dtype=f32),
+            xpooled=E(B * B, D, dtype=f32), xpool_q=E(B, D, dtype=f32), dxpool_q=E(B, D, dtype=f32),
+            ones_bb=torch.ones(B, B, device=self.device, dtype=f32),
             dsims_s=E(B, B, dtype=f32), dsims_d=E(B, B, dtype=f32), dsims_dt=E(B, B, dtype=f32), clip_ws=E(2 * B, dtype=f32),
             sims_both=E(B, B, dtype=f32), sd_ws=E(16 * B * B, dtype=f32),
             dvideo=E(B, D, dtype=f32), dmusic=E(B, D, dtype=f32),
@@ -561,8 +565,10 @@ class MadeTrainer(MadeEngine):
         hd = D // H
         ca_scale = 1.0 / math.sqrt(hd)
         tgt = tw["d.0.tgt"]
-        if c.moment_query_type in ("video", "music"):
-            src_vec = video if c.moment_query_type == "video" else music
+        if c.moment_query_type in ("video", "music", "xpool"):
+            if c.moment_query_type == "xpool":
+                cur.wait_stream(side)                        # the X-Pool branch (second stream) produces the query
+            src_vec = video if c.moment_query_type == "video" else (music if c.moment_query_type == "music" else tw["xpool_q"])
             tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
         else:                                                # "zero" / "random": reference music_detr/transformer.py:73-74
             tgt.zero_()
@@ -738,7 +744,11 @@ class MadeTrainer(MadeEngine):
         a3 = ops.layernorm(a2, P[key + ".ln2.g"], P[key + ".ln2.b"], out=tw[pre + "a3"])
         # (the oracle / reference masks name the site after the block class, not the tower)
         y = ops.linear(a3, P[key + ".lin.w"], P[key + ".lin.b"], R=a3, out=tw[pre + "y"], drop=self._drop("xa.linear_out", dr.P_XPOOL))
-        ops.xpool_tail(y, P[key + ".ln3.g"], P[key + ".ln3.b"], video, ws["sims_single"] if sims_out is None else sims_out, B, B)
+        want_pooled = key == "xa" and self.cfg.moment_query_type == "xpool"
+        ops.xpool_tail(y, P[key + ".ln3.g"], P[key + ".ln3.b"], video, ws["sims_single"] if sims_out is None else sims_out, B, B,
+                       pooled_out=tw["xpooled"] if want_pooled else None)
+        if want_pooled:                                      # reference model_Uni.py:222-223: a track's pooled vectors, averaged over the videos
+            ops.masked_mean(tw["xpooled"].view(B, B, D), tw["ones_bb"], out=tw["xpool_q"])       # (a NULL mask would give the sum)
 
     def _ca_fusion_train(self, ws, tw, frame: Tensor, seg: Tensor, fm: Tensor, sm: Tensor, B: int, Tv: int, Ta: int) -> None:
         """reference model/model_Base.py:194-213 (+ :130-167, :22-45) in train mode, then the masked_fill of model_Uni.py:211:
@@ -857,9 +867,11 @@ class MadeTrainer(MadeEngine):
         # the X-Pool / similarity branch is independent of the DETR stack until the temporal encoders: its (latency-bound)
         # backward runs on the second stream beside the decoder's
         cur, side = torch.cuda.current_stream(), self._side_stream()
+        xq = c.moment_query_type == "xpool" and not regression
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
+        if not xq:                                           # (with an xpool query it follows the decoder's backward: see below)
+            with torch.cuda.stream(side):
+                self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
 
         if regression:
             dmem, dtgt0 = self._regression_bwd(ws, tw, g_loc, B, L), None
@@ -1073,6 +1085,12 @@ class MadeTrainer(MadeEngine):
 
         # ---------------- join the X-Pool / similarity branch, merge the gradients of the clip-level vectors
         cur.wait_stream(side)
+        if xq:
+            # the decoder's content query was the mean over the videos of each track's pooled vectors: its gradient enters the
+            # X-Pool tail as dpool[m] / N_v for every video n
+            dq = tw["dxpool_q"]
+            tr.add3(dq, dtgt0.view(B, D) if Q == 1 else dtgt0.view(B, Q, D).float().sum(dim=1).contiguous())
+            self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm, dpool=dq)
         if c.moment_query_type in ("video", "music") and not regression:       # (a zero content query has no gradient to hand on)
             dq_vec = dvideo if c.moment_query_type == "video" else dmusic
             tr.add3(dq_vec, dq_vec, dtgt0.view(B, D) if Q == 1 else dtgt0.view(B, Q, D).float().sum(dim=1))    # the vector was repeated Q times
@@ -1133,7 +1151,7 @@ class MadeTrainer(MadeEngine):
         dmem.view(B, L, D).copy_((dfx.float() / cnt)[:, None, :].expand(B, L, D))
         return dmem
 
-    def _retrieval_bwd(self, ws, tw, g_ret: Optional[Tensor], B: int, S: int, sm: Tensor) -> None:
+    def _retrieval_bwd(self, ws, tw, g_ret: Optional[Tensor], B: int, S: int, sm: Tensor, dpool: Optional[Tensor] = None) -> None:
         c, P, G, D = self.cfg, self.P, self.G, self.cfg.D
         video, music = ws["video"], ws["music"]
         dvideo, dmusic = tw["dvideo"], tw["dmusic"]
@@ -1158,8 +1176,10 @@ class MadeTrainer(MadeEngine):
                 ds_st.copy_(ds_dt)
             single = dual = True
         frame, seg = self._views
-        if single and "music" in c.vmr_fusion:
-            self._xpool_bwd(tw, "xa", "x", ds_s, video, dvideo, seg, sm if c.fusion_mask == 1 else None, B, S)
+        if (single or dpool is not None) and "music" in c.vmr_fusion:
+            if not single:
+                ds_s.zero_()                                 # the tower feeds only the decoder's query
+            self._xpool_bwd(tw, "xa", "x", ds_s, video, dvideo, seg, sm if c.fusion_mask == 1 else None, B, S, dpool=dpool)
         else:
             tw["xdseg"].zero_()
         if "video" in c.vmr_fusion:
@@ -1173,14 +1193,15 @@ class MadeTrainer(MadeEngine):
             tr.l2norm_bwd(video, tw["dvn"], dvideo, accumulate=True)
             tr.l2norm_bwd(music, tw["dmn"], dmusic, accumulate=True)
 
-    def _xpool_bwd(self, tw, key: str, pre: str, ds: Tensor, qvec: Tensor, dqvec: Tensor, seg: Tensor, seg_mask: Optional[Tensor], B: int, S: int) -> None:
+    def _xpool_bwd(self, tw, key: str, pre: str, ds: Tensor, qvec: Tensor, dqvec: Tensor, seg: Tensor, seg_mask: Optional[Tensor], B: int, S: int,
+                   dpool: Optional[Tensor] = None) -> None:
         """backward of one X-Pool tower (_xpool_train): ds = d loss / d sims [query, sequence]; accumulates the gradient of the query
         vectors into dqvec and writes the gradient of the pooled sequences to tw[pre + "dseg"]."""
         P, G, D = self.P, self.G, self.cfg.D
         skip = seg_mask.reshape(-1) if seg_mask is not None else None
         g1, g2, g3 = tw[pre + "g1"], tw[pre + "g2"], tw[pre + "g3"]
         tr.xpool_tail_bwd(tw[pre + "y"], P[key + ".ln3.g"], P[key + ".ln3.b"], qvec, ds, g1, B, B, dy_drop=g2, drop=self._drop("xa.linear_out", dr.P_XPOOL),
-                          dgamma=G[key + ".ln3.g"], dbeta=G[key + ".ln3.b"], dvideo=dqvec)
+                          dgamma=G[key + ".ln3.g"], dbeta=G[key + ".ln3.b"], dvideo=dqvec, dpool=dpool, dpool_scale=1.0 / B)
         da3 = self._lin_bwd(g2, tw[pre + "a3"], key + ".lin", dx_out=g3, R=g1)
         tr.layernorm_bwd(tw[pre + "a2"], P[key + ".ln2.g"], da3, g1, dgamma=G[key + ".ln2.g"], dbeta=G[key + ".ln2.b"])
         do = self._lin_bwd(g1, tw[pre + "o"], key + ".out", dx_out=g2)
