@@ -869,7 +869,7 @@ class MadeEngine:
             # sims[n, m] = <fn[m, n, :], vn[n, :]>: one row-vector product per video, batched over the videos
             ops.linear(fn.view(B, B * D)[:, :D], vn, None, M=B, N=1, K=D, batch=B, a_z_stride=D, w_z_stride=D,     # rows m of video 0, stride B*D
                        segs=[Seg(out=sims, ldo=1, out_z_stride=B)])
-            ws["sims_fused"] = sims
+            ws["sims_fused"], ws["ff_fused"], ws["ff_fn"], ws["ff_vn"] = sims, fused, fn, vn      # (the training path's backward reads them)
             ops.clip_loss(sims, ls, rl, weight=wgt)
         else:                                                            # dual_single_sim_fuse
             both = self.dual_sims(video, music, add=ws["sims_single"])

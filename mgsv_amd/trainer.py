@@ -58,8 +58,8 @@ class MadeTrainer(MadeEngine):
             bad.append("moment_query_type=xpool without the music-pooling tower (the reference fails there too)")
         if c.vmr_fusion not in ("XA-music", "XA-video", "XA-video-music", "XA-music-video"):
             bad.append(f"vmr_fusion={c.vmr_fusion}")
-        if c.vmr_loss == "dual_single_feature_fuse":
-            bad.append("vmr_loss=dual_single_feature_fuse")
+        if c.vmr_loss == "dual_single_feature_fuse" and "music" not in c.vmr_fusion:
+            bad.append("vmr_loss=dual_single_feature_fuse without the music-pooling tower (the reference fails there too)")
         if c.agg_module != "transf" or c.with_cls_token:
             bad.append("agg_module=mlp / with_cls_token")
         if "detr" not in c.mml_localization and "regression" not in c.mml_localization:
@@ -512,7 +512,8 @@ class MadeTrainer(MadeEngine):
             else:
                 ops.linear(tw["vn"], tw["mn"], None, out=ws["sims_dual"])
             self._row_exclude = self.same_music_exclusion(music_ids)
-            self._retrieval_loss(ws, video, music, row_exclude=self._row_exclude)
+            self._retrieval_loss(ws, video, music, row_exclude=self._row_exclude,
+                                 pooled=tw["xpooled"] if c.vmr_loss == "dual_single_feature_fuse" else None)
         out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"], retrieval_loss=ws["ret_loss"])
 
         # ---- DETR encoder
@@ -744,10 +745,10 @@ class MadeTrainer(MadeEngine):
         a3 = ops.layernorm(a2, P[key + ".ln2.g"], P[key + ".ln2.b"], out=tw[pre + "a3"])
         # (the oracle / reference masks name the site after the block class, not the tower)
         y = ops.linear(a3, P[key + ".lin.w"], P[key + ".lin.b"], R=a3, out=tw[pre + "y"], drop=self._drop("xa.linear_out", dr.P_XPOOL))
-        want_pooled = key == "xa" and self.cfg.moment_query_type == "xpool"
+        want_pooled = key == "xa" and (self.cfg.moment_query_type == "xpool" or self.cfg.vmr_loss == "dual_single_feature_fuse")
         ops.xpool_tail(y, P[key + ".ln3.g"], P[key + ".ln3.b"], video, ws["sims_single"] if sims_out is None else sims_out, B, B,
                        pooled_out=tw["xpooled"] if want_pooled else None)
-        if want_pooled:                                      # reference model_Uni.py:222-223: a track's pooled vectors, averaged over the videos
+        if want_pooled and self.cfg.moment_query_type == "xpool":   # reference model_Uni.py:222-223: a track's pooled vectors, averaged over the videos
             ops.masked_mean(tw["xpooled"].view(B, B, D), tw["ones_bb"], out=tw["xpool_q"])       # (a NULL mask would give the sum)
 
     def _ca_fusion_train(self, ws, tw, frame: Tensor, seg: Tensor, fm: Tensor, sm: Tensor, B: int, Tv: int, Ta: int) -> None:
@@ -1160,6 +1161,7 @@ class MadeTrainer(MadeEngine):
         ds_s, ds_d, ds_dt, cws = tw["dsims_s"], tw["dsims_d"], tw["dsims_dt"], tw["clip_ws"]
         ds_st = tw["dsims_st"] if "video" in c.vmr_fusion else None      # d sims_single^T: the second tower scores [track, video]
         single = dual = False
+        fuse_dz = None
         if c.vmr_loss == "dual":
             tr.clip_loss_bwd(ws["sims_dual"], ls, wgt, g_ret, cws, ds_d, ds_dt, gls); dual = True
         elif c.vmr_loss == "single":
@@ -1168,6 +1170,18 @@ class MadeTrainer(MadeEngine):
             tr.clip_loss_bwd(ws["sims_dual"], ls, 1.0, g_ret, cws, ds_d, ds_dt, gls, row_exclude=getattr(self, "_row_exclude", None))
             tr.clip_loss_bwd(ws["sims_single"], ls, 1.0, g_ret, cws, ds_s, ds_st, gls)
             single = dual = True
+        elif c.vmr_loss == "dual_single_feature_fuse":
+            # sims[n, m] = <f^[m, n], v^[n]> with f = pooled[m, n] + music[m] (reference model_Uni.py:268-273).  Rare variant: the glue
+            # between the kernels (outer products of the similarity gradient) is plain torch
+            fused, fn, vn = ws["ff_fused"], ws["ff_fn"], ws["ff_vn"]
+            tr.clip_loss_bwd(ws["sims_fused"], ls, wgt, g_ret, cws, ds_s, None, gls)
+            dfn = (ds_s.t().reshape(B * B, 1) * vn.repeat(B, 1)).contiguous()              # rows (m, n): ds[n, m] v^[n]
+            dvn = torch.einsum("nm,mnd->nd", ds_s, fn.view(B, B, D)).contiguous()
+            dfused = torch.empty(B * B, D, device=self.device, dtype=torch.float32)
+            tr.l2norm_bwd(fused, dfn, dfused)
+            tr.l2norm_bwd(video, dvn, dvideo, accumulate=True)
+            dmusic.add_(dfused.view(B, B, D).sum(dim=1))
+            fuse_dz = dfused                                 # = the gradient of the pooled rows (LayerNorm3's output)
         else:                                                # dual_single_sim_fuse: one loss on the summed similarities
             both = tr.add3(tw["sims_both"], ws["sims_dual"], ws["sims_single"])
             tr.clip_loss_bwd(both, ls, wgt, g_ret, cws, ds_d, ds_dt, gls)
@@ -1176,10 +1190,10 @@ class MadeTrainer(MadeEngine):
                 ds_st.copy_(ds_dt)
             single = dual = True
         frame, seg = self._views
-        if (single or dpool is not None) and "music" in c.vmr_fusion:
+        if (single or dpool is not None or fuse_dz is not None) and "music" in c.vmr_fusion:
             if not single:
-                ds_s.zero_()                                 # the tower feeds only the decoder's query
-            self._xpool_bwd(tw, "xa", "x", ds_s, video, dvideo, seg, sm if c.fusion_mask == 1 else None, B, S, dpool=dpool)
+                ds_s.zero_()                                 # the tower feeds only the decoder's query / the fused similarity
+            self._xpool_bwd(tw, "xa", "x", ds_s, video, dvideo, seg, sm if c.fusion_mask == 1 else None, B, S, dpool=dpool, dz=fuse_dz)
         else:
             tw["xdseg"].zero_()
         if "video" in c.vmr_fusion:
@@ -1194,14 +1208,22 @@ class MadeTrainer(MadeEngine):
             tr.l2norm_bwd(music, tw["dmn"], dmusic, accumulate=True)
 
     def _xpool_bwd(self, tw, key: str, pre: str, ds: Tensor, qvec: Tensor, dqvec: Tensor, seg: Tensor, seg_mask: Optional[Tensor], B: int, S: int,
-                   dpool: Optional[Tensor] = None) -> None:
+                   dpool: Optional[Tensor] = None, dz: Optional[Tensor] = None) -> None:
         """backward of one X-Pool tower (_xpool_train): ds = d loss / d sims [query, sequence]; accumulates the gradient of the query
         vectors into dqvec and writes the gradient of the pooled sequences to tw[pre + "dseg"]."""
         P, G, D = self.P, self.G, self.cfg.D
         skip = seg_mask.reshape(-1) if seg_mask is not None else None
         g1, g2, g3 = tw[pre + "g1"], tw[pre + "g2"], tw[pre + "g3"]
-        tr.xpool_tail_bwd(tw[pre + "y"], P[key + ".ln3.g"], P[key + ".ln3.b"], qvec, ds, g1, B, B, dy_drop=g2, drop=self._drop("xa.linear_out", dr.P_XPOOL),
-                          dgamma=G[key + ".ln3.g"], dbeta=G[key + ".ln3.b"], dvideo=dqvec, dpool=dpool, dpool_scale=1.0 / B)
+        if dz is not None:
+            # the pooled rows were consumed outside the fused tail (dual_single_feature_fuse): plain LayerNorm3 backward of their gradient,
+            # plus the decoder query's share when it is an xpool query
+            if dpool is not None:
+                dz = dz + (dpool / B)[:, None, :].expand(B, B, dpool.shape[-1]).reshape(B * B, -1)
+            tr.layernorm_bwd(tw[pre + "y"], P[key + ".ln3.g"], dz.contiguous(), g1, dgamma=G[key + ".ln3.g"], dbeta=G[key + ".ln3.b"], dx_drop=g2,
+                             drop=self._drop("xa.linear_out", dr.P_XPOOL), drop_ld=D)
+        else:
+            tr.xpool_tail_bwd(tw[pre + "y"], P[key + ".ln3.g"], P[key + ".ln3.b"], qvec, ds, g1, B, B, dy_drop=g2, drop=self._drop("xa.linear_out", dr.P_XPOOL),
+                              dgamma=G[key + ".ln3.g"], dbeta=G[key + ".ln3.b"], dvideo=dqvec, dpool=dpool, dpool_scale=1.0 / B)
         da3 = self._lin_bwd(g2, tw[pre + "a3"], key + ".lin", dx_out=g3, R=g1)
         tr.layernorm_bwd(tw[pre + "a2"], P[key + ".ln2.g"], da3, g1, dgamma=G[key + ".ln2.g"], dbeta=G[key + ".ln2.b"])
         do = self._lin_bwd(g1, tw[pre + "o"], key + ".out", dx_out=g2)

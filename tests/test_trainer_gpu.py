@@ -78,7 +78,8 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
                                        {"transformer_is_share": 1, "_shape": (4, 18, 36)},
                                        {"vmr_fusion": "XA-video-music", "vmr_loss": "single"}, {"vmr_fusion": "XA-video", "vmr_loss": "single"},
                                        {"vmr_fusion": "XA-music-video", "vmr_loss": "dual_single_loss_fuse", "mml_fusion": "CA"},
-                                       {"moment_query_type": "xpool"}, {"moment_query_type": "xpool", "vmr_loss": "dual", "num_moment_queries": 2}])
+                                       {"moment_query_type": "xpool"}, {"moment_query_type": "xpool", "vmr_loss": "dual", "num_moment_queries": 2},
+                                       {"vmr_loss": "dual_single_feature_fuse"}, {"vmr_loss": "dual_single_feature_fuse", "moment_query_type": "xpool", "mml_fusion": "CA"}])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     overrides = dict(overrides)
