@@ -60,8 +60,10 @@ class MadeTrainer(MadeEngine):
             bad.append(f"vmr_fusion={c.vmr_fusion}")
         if c.vmr_loss == "dual_single_feature_fuse" and "music" not in c.vmr_fusion:
             bad.append("vmr_loss=dual_single_feature_fuse without the music-pooling tower (the reference fails there too)")
-        if c.agg_module != "transf" or c.with_cls_token:
-            bad.append("agg_module=mlp / with_cls_token")
+        if c.agg_module != "transf":
+            bad.append("agg_module=mlp")
+        if c.with_cls_token and (c.video_transformer_depth < 1 or c.audio_transformer_depth < 1):
+            bad.append("with_cls_token without a temporal block")
         if "detr" not in c.mml_localization and "regression" not in c.mml_localization:
             bad.append(f"mml_localization={c.mml_localization}")
         if c.audio_short_cut and c.contrastive_align_loss and c.contrastive_hdim != c.D:
@@ -91,6 +93,8 @@ class MadeTrainer(MadeEngine):
             vecs.append((key + ".g", name + ".weight")); vecs.append((key + ".b", name + ".bias"))
 
         lin("vit_proj", "vit_proj"); lin("ast_proj", "ast_proj")
+        if c.with_cls_token:                                  # reference model/model_Base.py:314-321: [1, 1, D] learned tokens
+            vecs.append(("cls_video", "video_cls_token")); vecs.append(("cls_audio", "audio_cls_token"))
         # one block for both towers when transformer_is_share (reference model/model_Base.py:300-302,322-331): both towers' keys view the
         # same masters and the same gradient ranges; every gradient kernel accumulates atomically, so the two towers' backward passes
         # (on two streams) simply add up there
@@ -342,15 +346,21 @@ class MadeTrainer(MadeEngine):
 
         ws = {}
         for tag, T, Kin, depth in (("v", Tv, c.vit_dim, c.video_transformer_depth), ("a", Ta, c.ast_dim, c.audio_transformer_depth)):
-            r = B * T
+            T1 = T + 1 if c.with_cls_token else T               # with_cls_token: the block runs on T + 1 positions
+            r, r0 = B * T1, B * T
             if c.with_act_after_proj:
-                ws[f"{tag}.zproj"] = E(r, D)
-            ws.update({f"{tag}.xin": E(r, Kin), f"{tag}.xlast": E(r, D), f"{tag}.mean": E(B, D, dtype=f32),
-                       f"{tag}.dl": E(r, D), f"{tag}.g1": E(r, D), f"{tag}.g1b": E(r, D), f"{tag}.g2": E(r, D), f"{tag}.g3": E(r, D), f"{tag}.g3b": E(r, D),
-                       f"{tag}.gqkv": E(r, 3 * D), f"{tag}.gffn": E(r, Ft), f"{tag}.delta": E(B * Hh * T, dtype=f32)})
+                ws[f"{tag}.zproj"] = E(r0, D)
+            ws.update({f"{tag}.xin": E(r0, Kin), f"{tag}.xlast": E(r, D), f"{tag}.mean": E(B, D, dtype=f32),
+                       f"{tag}.dl": Z(r, D), f"{tag}.g1": E(r, D), f"{tag}.g1b": E(r, D), f"{tag}.g2": E(r, D), f"{tag}.g3": E(r, D), f"{tag}.g3b": E(r, D),
+                       f"{tag}.gqkv": E(r, 3 * D), f"{tag}.gffn": E(r, Ft), f"{tag}.delta": E(B * Hh * T1, dtype=f32)})
+            if c.with_cls_token:
+                ws.update({f"{tag}.mask1": E(B, T1, dtype=f32), f"{tag}.rows1": (torch.empty(r, device=dev, dtype=torch.int32), torch.zeros(1, device=dev, dtype=torch.int32)),
+                           f"{tag}.order1": torch.empty(B, device=dev, dtype=torch.int32), f"{tag}.y1": E(r, D), f"{tag}.dtok": Z(B, D, dtype=f32),
+                           f"{tag}.dproj": E(r0, D)})
+                ws[f"{tag}.mean"].fill_(1.0)                      # neutral operands of pool_bwd (dtok = 0): mask * (in1 + in2)
             for l in range(depth):
                 ws.update({f"{tag}.{l}.x0": E(r, D), f"{tag}.{l}.x1": E(r, D), f"{tag}.{l}.qkv": E(r, 3 * D), f"{tag}.{l}.att": E(r, D),
-                           f"{tag}.{l}.lse": E(B * Hh * T, dtype=f32), f"{tag}.{l}.x2": E(r, D), f"{tag}.{l}.x3": E(r, D),
+                           f"{tag}.{l}.lse": E(B * Hh * T1, dtype=f32), f"{tag}.{l}.x2": E(r, D), f"{tag}.{l}.x3": E(r, D),
                            f"{tag}.{l}.z1": E(r, Ft), f"{tag}.{l}.h": E(r, Ft)})
         rows = B * L
         Lp = round_up(L, 8)
@@ -689,42 +699,64 @@ class MadeTrainer(MadeEngine):
         D, Hh = c.D, c.SA_temporal_heads
         proj, mod, pe, depth, tag = (("vit_proj", "video_transformer", "pe_video", c.video_transformer_depth, "v") if which == "video"
                                      else ("ast_proj", "audio_transformer", "pe_audio", c.audio_transformer_depth, "a"))
-        if P[pe].shape[0] < T:
-            raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < T={T}")
+        cls = bool(c.with_cls_token)
+        T1 = T + 1 if cls else T
+        if P[pe].shape[0] < T1:
+            raise ValueError(f"{which} position table holds {P[pe].shape[0]} positions < {T1}")
         nrow = B * T
         mflat = mask.reshape(-1)
-        rws = self._rw(mflat)
         pt = dr.P_TEMPORAL
         name = "video" if which == "video" else "audio"
         act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE       # reference model_Base.py:559-561
         zp = tw[tag + ".zproj"] if c.with_act_after_proj else None             # pre-activation, for the backward gate
+        x = tw[f"{tag}.0.x0"]
+        if cls:
+            # reference model_Base.py:527-530: the learned token goes first with mask entry 1; the block then runs on T + 1 positions
+            mask1 = tw[tag + ".mask1"]
+            mask1[:, 0] = 1.0; mask1[:, 1:] = mask
+            self._rows[mask1.data_ptr()] = ops.row_index(mask1, out=tw[tag + ".rows1"])
+            self._order[mask1.data_ptr()] = ops.batch_order(mask1, out=tw[tag + ".order1"])
+            x3 = x.view(B, T1, D)
+            x3[:, 0] = (P["cls_" + name].float() + P[pe][0].float()).to(self.tc)
+            lin_out = dict(segs=[Seg(out=x3[:, 1:], ldo=D, rows_per_batch=T, out_batch_stride=T1 * D)])
+            pe_rows = P[pe][1:T1]
+        else:
+            mask1 = mask
+            lin_out = dict(out=x, rows=self._rw(mflat))
+            pe_rows = P[pe][:T]
+        mflat1 = mask1.reshape(-1)
+        rws = self._rw(mflat1)
         if self.tc == torch.bfloat16:
             xin = ops.cast_mask_rows(feats.view(nrow, Kin), mflat, tw[tag + ".xin"])
-            x = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, Zout=zp, R=P[pe][:T], r_row_mod=T, out=tw[f"{tag}.0.x0"], rows=rws)
+            ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, Zout=zp, R=pe_rows, r_row_mod=T, **lin_out)
         else:
-            x = ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act, Zout=zp, R=P[pe][:T], r_row_mod=T,
-                           out=tw[f"{tag}.0.x0"], rows=rws)
+            ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act, Zout=zp, R=pe_rows, r_row_mod=T, **lin_out)
         for l in range(depth):
             p, t = f"{mod}.layers.{l}", f"{tag}.{l}"
-            x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[t + ".x1"], row_skip=mflat)
+            x1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[t + ".x1"], row_skip=mflat1)
             qkv = ops.linear(x1, P[p + ".in.w"], P[p + ".in.b"], out=tw[t + ".qkv"], rows=rws)
-            q3 = qkv.view(B, T, 3 * D)
+            q3 = qkv.view(B, T1, 3 * D)
             att = tw[t + ".att"]
-            ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T, D), Hh, key_mask=mask, q_skip_mask=mask,
-                          lse=tw[t + ".lse"], drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask.data_ptr()])
+            ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T1, D), Hh, key_mask=mask1, q_skip_mask=mask1,
+                          lse=tw[t + ".lse"], drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask1.data_ptr()])
             x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=tw[t + ".x2"], rows=rws)
-            x3 = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[t + ".x3"], row_skip=mflat)
-            h = ops.linear(x3, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=tw[t + ".h"], Zout=tw[t + ".z1"], rows=rws,
+            x3_ = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[t + ".x3"], row_skip=mflat1)
+            h = ops.linear(x3_, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=tw[t + ".h"], Zout=tw[t + ".z1"], rows=rws,
                            drop=self._drop(f"{name}.{l}.ffn_act", pt))
             nxt = tw[f"{tag}.{l + 1}.x0"] if l + 1 < depth else tw[tag + ".xlast"]
-            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3, out=nxt, rows=rws, drop=self._drop(f"{name}.{l}.ffn_out", pt))
+            x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x3_, out=nxt, rows=rws, drop=self._drop(f"{name}.{l}.ffn_out", pt))
         if "concat" in c.mml_fusion:
             local = ws["fus"][:, row_off:row_off + T]
         else:
             local = ws["frame_buf"] if which == "video" else ws["seg_buf"]
+        vec = ws["video"] if which == "video" else ws["music"]
+        if cls:                                              # reference model_Base.py:572-574: clip vector = the token's output
+            y3 = ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat1, out=tw[tag + ".y1"]).view(B, T1, D)
+            ops.l2norm_rows(y3[:, 0], out_f32=vec)
+            local.copy_(y3[:, 1:])
+            return
         ops.linear(x, P[mod + ".final.w"], P[mod + ".final.b"], out_row_mask=mflat, tile_skip_mask=mflat,
                    segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
-        vec = ws["video"] if which == "video" else ws["music"]
         ops.masked_mean(local, mask, out=tw[tag + ".mean"])
         ops.l2norm_rows(tw[tag + ".mean"], out_f32=vec)
 
@@ -1252,11 +1284,21 @@ class MadeTrainer(MadeEngine):
         proj, mod, depth, tag = (("vit_proj", "video_transformer", c.video_transformer_depth, "v") if which == "video"
                                  else ("ast_proj", "audio_transformer", c.audio_transformer_depth, "a"))
         name = "video" if which == "video" else "audio"
+        cls = bool(c.with_cls_token)
+        T1 = T + 1 if cls else T
         rows = B * T
+        mask0, mflat0 = mask, mask.reshape(-1)
+        if cls:
+            mask = tw[tag + ".mask1"]
         mflat = mask.reshape(-1)
         pt = dr.P_TEMPORAL
         dl = tw[tag + ".dl"]
-        tr.pool_bwd(tw[tag + ".mean"], dvec, mask, dl.view(B, T, D), in1=d_local, in2=d_extra)
+        if cls:                                              # vec = l2norm(y[:, 0]); local = y[:, 1:]
+            dl3, y3 = dl.view(B, T1, D), tw[tag + ".y1"].view(B, T1, D)
+            tr.l2norm_bwd(y3[:, 0], dvec, None, dx_alt=dl3[:, 0])
+            tr.pool_bwd(tw[tag + ".mean"], tw[tag + ".dtok"], mask0, dl3[:, 1:], in1=d_local, in2=d_extra)    # mask * (d_local + d_extra)
+        else:
+            tr.pool_bwd(tw[tag + ".mean"], dvec, mask, dl.view(B, T, D), in1=d_local, in2=d_extra)
         g1, g1b, g2, g3, g3b, gq, gf = (tw[tag + ".g1"], tw[tag + ".g1b"], tw[tag + ".g2"], tw[tag + ".g3"], tw[tag + ".g3b"], tw[tag + ".gqkv"],
                                         tw[tag + ".gffn"])
         pend: list = []                                      # this layer's weight gradients: one grouped launch (see the DETR encoder)
@@ -1279,17 +1321,22 @@ class MadeTrainer(MadeEngine):
             tr.layernorm_bwd(tw[t + ".x2"], P[p + ".ln2.g"], dx3, g1b, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"], row_skip=mflat)
             datt = self._lin_bwd(g1b, tw[t + ".att"], p + ".out", dx_out=g2, row_mask=mflat, skip=mflat, defer=pend)
             qkv = tw[t + ".qkv"]
-            q3, gq3 = qkv.view(B, T, 3 * D), gq.view(B, T, 3 * D)
-            tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[t + ".att"].view(B, T, D), datt.view(B, T, D),
+            q3, gq3 = qkv.view(B, T1, 3 * D), gq.view(B, T1, 3 * D)
+            tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[t + ".att"].view(B, T1, D), datt.view(B, T1, D),
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[t + ".lse"], tw[tag + ".delta"], Hh,
                              key_mask=mask, q_skip_mask=mask, drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask.data_ptr()])
             dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3b, row_mask=mflat, skip=mflat, R=g1b, defer=pend)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
             self._flush_dw(pend, mflat)
         xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
+        if cls:                                              # x0 = [token + pe_0 ; proj(x) + pe_1..T]
+            dx3d = dx.view(B, T1, D)
+            G["cls_" + name].view(-1).add_(dx3d[:, 0].float().sum(0))
+            dx = tw[tag + ".dproj"]
+            dx.view(B, T, D).copy_(dx3d[:, 1:])
         if c.with_act_after_proj:                            # x0 = quickgelu(z) + pe: gradient w.r.t. z (the input itself needs none)
-            dx = tr.gate_rows(dx, g1, G=tw[tag + ".zproj"], gate=_lib.GATE_QUICKGELU_Z, row_skip=mflat)
-        tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], rows=self._rw(mflat))
+            dx = tr.gate_rows(dx, g1[:rows], G=tw[tag + ".zproj"], gate=_lib.GATE_QUICKGELU_Z, row_skip=mflat0)
+        tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], rows=self._rw(mflat0))
 
     # ================================================================== convenience
     def loss_and_grads(self, inp: dict, seed: int = 0, w_ret: float = 1.0, w_loc: float = 1.0) -> dict:

@@ -234,6 +234,17 @@ def main():
     report["grad_train_native_predict_center_B3"] = compare_backward(c, 3, 20, 40, "native predict_center train-mode grads", train=True)
     c = cfg_native(); c.mml_localization = "regression"; c.predict_center = 1; c.mml_fusion = "CA"
     report["grad_train_native_regression_center_CA_B3"] = compare_backward(c, 3, 20, 40, "native regression / predict_center / CA train-mode grads", train=True)
+    for vf in ("XA-video-music", "XA-video", "XA-music-video"):        # the music-guided video-pooling tower (used by the `single` loss)
+        c = cfg_native(); c.vmr_fusion = vf; c.vmr_loss = "single"
+        report[f"grad_train_native_{vf.replace('-', '_')}_single_B3"] = compare_backward(c, 3, 20, 40, f"native {vf} / single train-mode grads", train=True)
+    c = cfg_native(); c.moment_query_type = "xpool"
+    report["grad_train_native_xpool_query_B3"] = compare_backward(c, 3, 20, 40, "native xpool moment query train-mode grads", train=True)
+    c = cfg_native(); c.vmr_loss = "dual_single_feature_fuse"
+    report["grad_train_native_feature_fuse_B3"] = compare_backward(c, 3, 20, 40, "native dual_single_feature_fuse train-mode grads", train=True)
+    c = cfg_native(); c.with_cls_token = 1
+    report["grad_train_native_cls_token_B3"] = compare_backward(c, 3, 20, 40, "native CLS-token train-mode grads", train=True)
+    c = cfg_native(); c.with_cls_token = 1; c.with_act_after_proj = 1; c.video_transformer_depth = c.audio_transformer_depth = 2
+    report["grad_eval_native_cls_token_act_depth2_B3"] = compare_backward(c, 3, 20, 40, "native CLS-token / act / depth-2 eval-mode grads", train=False)
     report["lsap_vs_scipy"] = compare_lsap()
     report["retrieval_N48x40_S96"] = compare_retrieval(cfg_native(), 48, 40, 96)
     worst = max(v for k, sec in report.items() if isinstance(sec, dict) and not k.startswith("grad_")
