@@ -585,6 +585,21 @@ int made_add3(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, cons
 /* out[c] += sum over rows of x[row, c]  (f32, accumulated): gradient of a row vector that was broadcast over the rows. */
 int made_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream);
 
+/* made_posbn_relu_fwd / _bwd: y = relu(BatchNorm1d_over_positions(x)) of the EmbeddingNet aggregator (agg_module = "mlp", reference
+ *   model/model_Base.py:216-249: nn.BatchNorm1d(num_features = T) applied to [B, T, F], so position t is the channel and its
+ *   statistics run over the B * F values there).  x / y: rows b * T + t of pitch ldx / ldy, F columns.  batch_stats != 0
+ *   (model.train()): biased batch statistics normalise, running_mean / running_var (may both be NULL) move by `momentum` towards
+ *   the batch mean / unbiased variance; batch_stats == 0 (model.eval()): the running statistics normalise.  save_mean /
+ *   save_rstd [T] keep what was used, for the backward.  _bwd: dx (stored), dweight[t] += , dbias[t] += (may be NULL). */
+int made_posbn_relu_fwd(const void* x, int32_t x_dtype, int64_t ldx, const float* weight, const float* bias,
+                        float* running_mean, float* running_var, float momentum, float eps, int32_t batch_stats,
+                        float* save_mean, float* save_rstd, void* y, int32_t y_dtype, int64_t ldy,
+                        int64_t B, int64_t T, int64_t F, void* stream);
+int made_posbn_relu_bwd(const void* x, int32_t x_dtype, int64_t ldx, const void* y, int32_t y_dtype, int64_t ldy,
+                        const void* dy, int32_t dy_dtype, int64_t lddy, const float* weight, const float* save_mean,
+                        const float* save_rstd, int32_t batch_stats, void* dx, int32_t dx_dtype, int64_t lddx,
+                        float* dweight, float* dbias, int64_t B, int64_t T, int64_t F, void* stream);
+
 /* made_set_criterion_bwd: gradients of made_set_criterion's total (times upstream[0]) w.r.t. pred_logits, pred_spans
  *   [n_layers,B,Q,2], proj_queries [n_layers,B,Q,Dc] (stored) and vid_sum [B,Dc] (accumulated).  d_logits / d_spans rows have
  *   pitch ld_out >= 2 (only columns 0,1 are written: a zero-padded pitch of 8 lets the row feed made_linear as an A operand);

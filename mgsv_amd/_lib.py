@@ -169,6 +169,8 @@ SIGNATURES = {
     "made_head_bias_bwd": (C.c_int, [vp, i32, i64, vp, vp, vp, vp, i64, i64, i64, vp]),
     "made_add3": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, i64, vp]),
     "made_colsum": (C.c_int, [vp, i32, i64, i64, i64, vp, vp]),
+    "made_posbn_relu_fwd": (C.c_int, [vp, i32, i64, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, i32, i64, i64, i64, i64, vp]),
+    "made_posbn_relu_bwd": (C.c_int, [vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, vp, i32, i64, vp, vp, i64, i64, i64, vp]),
     "made_set_criterion_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp,
                                          vp, vp, i64, i32, vp, vp, vp]),
     "made_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, i64, f32, vp, vp]),

@@ -271,6 +271,31 @@ def colsum(x: Tensor, out: Tensor) -> None:
     check(lib().made_colsum(_p(x), dt_of(x), x.stride(0), rows, cols, _p(_f32(out, "out")), _stream()), "made_colsum")
 
 
+def posbn_relu(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], momentum: float,
+               batch_stats: bool, save_mean: Tensor, save_rstd: Tensor, out: Tensor, eps: float = 1e-5) -> Tensor:
+    """out = relu(BatchNorm1d over positions(x)); x / out [B, T, F] (contiguous rows).  made_posbn_relu_fwd."""
+    B, T, F = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
+    check(lib().made_posbn_relu_fwd(_p(x), dt_of(x), F, _p(_f32(weight, "weight")), _p(_f32(bias, "bias")), _p(_f32(running_mean, "running_mean")),
+                                    _p(_f32(running_var, "running_var")), float(momentum), float(eps), int(bool(batch_stats)),
+                                    _p(_f32(save_mean, "save_mean")), _p(_f32(save_rstd, "save_rstd")), _p(out), dt_of(out), F, B, T, F, _stream()),
+          "made_posbn_relu_fwd")
+    return out
+
+
+def posbn_relu_bwd(x: Tensor, y: Tensor, dy: Tensor, weight: Tensor, save_mean: Tensor, save_rstd: Tensor, batch_stats: bool, dx: Tensor,
+                   dweight: Optional[Tensor], dbias: Optional[Tensor]) -> Tensor:
+    """dx of posbn_relu (stored), dweight / dbias accumulated.  made_posbn_relu_bwd."""
+    B, T, F = x.shape
+    for t in (x, y, dy, dx):
+        assert t.is_contiguous() and tuple(t.shape) == (B, T, F)
+    check(lib().made_posbn_relu_bwd(_p(x), dt_of(x), F, _p(y), dt_of(y), F, _p(dy), dt_of(dy), F, _p(_f32(weight, "weight")),
+                                    _p(_f32(save_mean, "save_mean")), _p(_f32(save_rstd, "save_rstd")), int(bool(batch_stats)),
+                                    _p(dx), dt_of(dx), F, _p(_f32(dweight, "dweight")), _p(_f32(dbias, "dbias")), B, T, F, _stream()),
+          "made_posbn_relu_bwd")
+    return dx
+
+
 def set_criterion_bwd(logits: Tensor, spans: Tensor, targets: Tensor, pi: Tensor, ti: Tensor, cnt: Tensor, pq: Optional[Tensor],
                       vid_sum: Optional[Tensor], empty_weight: Tensor, fg: int, weights: Tensor, upstream: Optional[Tensor],
                       d_logits: Tensor, d_spans: Tensor, d_pq: Optional[Tensor], d_vid_sum: Optional[Tensor],

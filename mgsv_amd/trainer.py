@@ -60,9 +60,7 @@ class MadeTrainer(MadeEngine):
             bad.append(f"vmr_fusion={c.vmr_fusion}")
         if c.vmr_loss == "dual_single_feature_fuse" and "music" not in c.vmr_fusion:
             bad.append("vmr_loss=dual_single_feature_fuse without the music-pooling tower (the reference fails there too)")
-        if c.agg_module != "transf":
-            bad.append("agg_module=mlp")
-        if c.with_cls_token and (c.video_transformer_depth < 1 or c.audio_transformer_depth < 1):
+        if c.agg_module != "mlp" and c.with_cls_token and (c.video_transformer_depth < 1 or c.audio_transformer_depth < 1):
             bad.append("with_cls_token without a temporal block")
         if "detr" not in c.mml_localization and "regression" not in c.mml_localization:
             bad.append(f"mml_localization={c.mml_localization}")
@@ -80,6 +78,10 @@ class MadeTrainer(MadeEngine):
             t.append(("xav", "music_guided_to_video_pooling_cross_transformer"))
         return t
 
+    def _mlp_towers(self):
+        c = self.cfg
+        return (("video_mlp", "Video_encoder_projection", c.max_v_frames), ("audio_mlp", "Music_encoder_projection", c.max_snippet_num))
+
     def _table(self) -> Tuple[List[Tuple[str, object]], List[Tuple[str, object]]]:
         """(kernel key, reference name(s)) for matrices and for vectors, mirroring MadeEngine.load_state_dict."""
         c = self.cfg
@@ -93,13 +95,18 @@ class MadeTrainer(MadeEngine):
             vecs.append((key + ".g", name + ".weight")); vecs.append((key + ".b", name + ".bias"))
 
         lin("vit_proj", "vit_proj"); lin("ast_proj", "ast_proj")
-        if c.with_cls_token:                                  # reference model/model_Base.py:314-321: [1, 1, D] learned tokens
+        if c.with_cls_token and c.agg_module != "mlp":        # reference model/model_Base.py:314-321: [1, 1, D] learned tokens
             vecs.append(("cls_video", "video_cls_token")); vecs.append(("cls_audio", "audio_cls_token"))
         # one block for both towers when transformer_is_share (reference model/model_Base.py:300-302,322-331): both towers' keys view the
         # same masters and the same gradient ranges; every gradient kernel accumulates atomically, so the two towers' backward passes
         # (on two streams) simply add up there
         share = bool(c.transformer_is_share) and c.video_transformer_depth == c.audio_transformer_depth and c.video_transformer_depth > 0
-        for mod, depth in (("video_transformer", c.video_transformer_depth), ("audio_transformer", c.audio_transformer_depth)):
+        if c.agg_module == "mlp":                              # EmbeddingNet aggregators (reference model/model_Base.py:216-249,357-377)
+            for key, mod, _ in self._mlp_towers():
+                lin(key + ".0", mod + ".net.0"); lin(key + ".3", mod + ".net.3"); lin(key + ".6", mod + ".net.6")
+                for bn in ("1", "4"):
+                    vecs.append((f"{key}.{bn}.g", f"{mod}.net.{bn}.weight")); vecs.append((f"{key}.{bn}.beta", f"{mod}.net.{bn}.bias"))
+        for mod, depth in (() if c.agg_module == "mlp" else (("video_transformer", c.video_transformer_depth), ("audio_transformer", c.audio_transformer_depth))):
             src = "share_transformer" if share else mod
             for l in range(depth):
                 p, q = f"{mod}.layers.{l}", f"{src}.layers.{l}"
@@ -156,7 +163,13 @@ class MadeTrainer(MadeEngine):
         """Flat f32 master / gradient buffers; k_proj|v_proj of the X-Pool block are laid out back to back so the packed
         [2D, D] projection is one view."""
         dev = self.device
-        names = [k for k in sd if not k.endswith(".pe") and k != "criterion.empty_weight"]
+        BUF = (".running_mean", ".running_var", ".num_batches_tracked")      # BatchNorm buffers (agg_module = "mlp"): state, not parameters
+        names = [k for k in sd if not k.endswith(".pe") and k != "criterion.empty_weight" and not k.endswith(BUF)]
+        self.buffers: Dict[str, Tensor] = {}
+        for k in sd:
+            if k.endswith(BUF):
+                t = sd[k].detach() if isinstance(sd[k], torch.Tensor) else torch.from_numpy(np.asarray(sd[k]))
+                self.buffers[k] = t.to(dev, torch.int64 if k.endswith(".num_batches_tracked") else torch.float32).clone()
         XAV = "music_guided_to_video_pooling_cross_transformer"
         pair_after = {}
         for xa in (XA, XAV):
@@ -164,8 +177,9 @@ class MadeTrainer(MadeEngine):
             pair_after[xa + ".cross_attn.k_proj.bias"] = xa + ".cross_attn.v_proj.bias"
         # optimizer groups of the reference (model/model_Uni.py:73-114, train-MaDe.py:262-266) laid out as contiguous ranges
         def group_of(k: str) -> int:
-            if k.startswith(("vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.", "share_transformer.")):
-                return 0                                      # temporal
+            if k.startswith(("vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.", "share_transformer.",
+                             "video_cls_token", "audio_cls_token", "Video_encoder_projection.", "Music_encoder_projection.")):
+                return 0                                      # temporal (model_Base.py:378-401: projections + SA block / CLS tokens / EmbeddingNets)
             if k.startswith((XA + ".", XAV + ".")) or k == "logit_scale":
                 return 1                                      # matching (both X-Pool towers: model_Uni.py:77-86)
             if "regression" in self.cfg.mml_localization:     # model_Uni.py:92-100: the regression variant optimises the CA fusion block and
@@ -271,6 +285,15 @@ class MadeTrainer(MadeEngine):
             self._pack_n, self._pack_tiles = len(descs), tiles
         _lib.check(_lib.lib().made_repack(self._pack_desc.data_ptr(), self._pack_n, self._pack_tiles,
                                           torch.cuda.current_stream().cuda_stream), "made_repack")
+        if self.cfg.agg_module == "mlp":                      # the eval path's per-position affine (MadeEngine._encode_mlp) from the current
+            P = self.P                                        # BatchNorm parameters and running buffers
+            for key, mod, _ in self._mlp_towers():
+                for bn in ("1", "4"):
+                    sc, sh = P[f"{key}.{bn}.scale"], P[f"{key}.{bn}.shift"]
+                    torch.add(self.buffers[f"{mod}.net.{bn}.running_var"], 1e-5, out=sc)
+                    sc.rsqrt_().mul_(P[f"{key}.{bn}.g"])
+                    torch.mul(self.buffers[f"{mod}.net.{bn}.running_mean"], sc, out=sh)
+                    sh.neg_().add_(P[f"{key}.{bn}.beta"])
 
     def optimizer_step(self, lr_temporal: float, lr_matching: float, lr_detection: float, max_grad_norm: float = 1.0,
                        betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> None:
@@ -313,7 +336,9 @@ class MadeTrainer(MadeEngine):
         return out
 
     def state_dict_numpy(self) -> Dict[str, np.ndarray]:
-        return {k: v.detach().cpu().numpy().copy() for k, v in self.master.items()}
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in self.master.items()}
+        sd.update({k: v.detach().cpu().numpy().copy() for k, v in self.buffers.items()})
+        return sd
 
     def grads_numpy(self) -> Dict[str, np.ndarray]:
         torch.cuda.synchronize()
@@ -345,7 +370,14 @@ class MadeTrainer(MadeEngine):
             return torch.zeros(shape, device=dev, dtype=dtype or tc)
 
         ws = {}
-        for tag, T, Kin, depth in (("v", Tv, c.vit_dim, c.video_transformer_depth), ("a", Ta, c.ast_dim, c.audio_transformer_depth)):
+        for tag, T, Kin in ((("v", Tv, c.vit_dim), ("a", Ta, c.ast_dim)) if c.agg_module == "mlp" else ()):
+            r, Fh = B * T, 1024                                 # EmbeddingNet: Linear(D, 1024) - BN - ReLU - Linear(1024, D) - BN - ReLU - Linear(D, D)
+            if c.with_act_after_proj:
+                ws[f"{tag}.zproj"] = E(r, D)
+            ws.update({f"{tag}.xin": E(r, Kin), f"{tag}.x0": E(r, D), f"{tag}.h0": E(r, Fh), f"{tag}.h1": E(r, Fh), f"{tag}.y0": E(r, D),
+                       f"{tag}.y1": E(r, D), f"{tag}.mean": E(B, D, dtype=f32), f"{tag}.bn": E(4, T, dtype=f32), f"{tag}.dl": E(r, D),
+                       f"{tag}.gd1": E(r, D), f"{tag}.gd2": E(r, D), f"{tag}.gh1": E(r, Fh), f"{tag}.gh2": E(r, Fh)})
+        for tag, T, Kin, depth in (() if c.agg_module == "mlp" else (("v", Tv, c.vit_dim, c.video_transformer_depth), ("a", Ta, c.ast_dim, c.audio_transformer_depth))):
             T1 = T + 1 if c.with_cls_token else T               # with_cls_token: the block runs on T + 1 positions
             r, r0 = B * T1, B * T
             if c.with_act_after_proj:
@@ -695,6 +727,8 @@ class MadeTrainer(MadeEngine):
     def _encode_train(self, feats: Tensor, mask: Tensor, which: str, ws, tw, row_off: int) -> None:
         """reference model/model_Base.py:544-617 in train mode (dropout 0.8 inside the temporal block)."""
         c, P = self.cfg, self.P
+        if c.agg_module == "mlp":
+            return self._encode_train_mlp(feats, mask, which, ws, tw, row_off)
         B, T, Kin = feats.shape
         D, Hh = c.D, c.SA_temporal_heads
         proj, mod, pe, depth, tag = (("vit_proj", "video_transformer", "pe_video", c.video_transformer_depth, "v") if which == "video"
@@ -1277,8 +1311,78 @@ class MadeTrainer(MadeEngine):
         dv1 = self._lin_bwd(dq, tw[pre + "v1"], key + ".q", dx_out=tw[pre + "dv1"])
         tr.layernorm_bwd(qvec, P[key + ".ln1.g"], dv1, dqvec, dgamma=G[key + ".ln1.g"], dbeta=G[key + ".ln1.b"], add=dqvec)
 
+    def _encode_train_mlp(self, feats: Tensor, mask: Tensor, which: str, ws, tw, row_off: int) -> None:
+        """agg_module = "mlp" (reference model/model_Base.py:567-570,606-609 with EmbeddingNet :216-249).  In train mode both
+        BatchNorm1d layers normalise every position with the statistics of the batch's B * F values there (padded samples
+        included: every row is computed, none gathered away) and move their running buffers; with `training_dropout` off
+        (= the reference's model.eval()) they use the running statistics."""
+        c, P = self.cfg, self.P
+        B, T, Kin = feats.shape
+        D = c.D
+        tag, proj = ("v", "vit_proj") if which == "video" else ("a", "ast_proj")
+        key, mod, Tbn = self._mlp_towers()[0 if which == "video" else 1]
+        if T != Tbn:
+            raise ValueError(f"agg_module=mlp: {which} sequence length {T} != {Tbn} positions of its BatchNorm1d (the reference fails there too)")
+        nrow = B * T
+        mflat = mask.reshape(-1)
+        act = ops.ACT_QUICKGELU if c.with_act_after_proj else ops.ACT_NONE
+        zp = tw[tag + ".zproj"] if c.with_act_after_proj else None
+        if self.tc == torch.bfloat16:
+            xin = ops.cast_mask_rows(feats.view(nrow, Kin), mflat, tw[tag + ".xin"])
+            x0 = ops.linear(xin, P[proj + ".w"], P[proj + ".b"], act=act, Zout=zp, out=tw[tag + ".x0"])
+        else:
+            x0 = ops.linear(feats.view(nrow, Kin), P[proj + ".w"], P[proj + ".b"], a_row_mask=mflat, act=act, Zout=zp, out=tw[tag + ".x0"])
+        stats = bool(self.training_dropout)
+        bn, buf = tw[tag + ".bn"], self.buffers
+        h0 = ops.linear(x0, P[key + ".0.w"], P[key + ".0.b"], out=tw[tag + ".h0"])
+        h1 = tr.posbn_relu(h0.view(B, T, -1), P[key + ".1.g"], P[key + ".1.beta"], buf[mod + ".net.1.running_mean"], buf[mod + ".net.1.running_var"],
+                           0.1, stats, bn[0], bn[1], out=tw[tag + ".h1"].view(B, T, -1))
+        y0 = ops.linear(h1.view(nrow, -1), P[key + ".3.w"], P[key + ".3.b"], out=tw[tag + ".y0"])
+        y1 = tr.posbn_relu(y0.view(B, T, D), P[key + ".4.g"], P[key + ".4.beta"], buf[mod + ".net.4.running_mean"], buf[mod + ".net.4.running_var"],
+                           0.99, stats, bn[2], bn[3], out=tw[tag + ".y1"].view(B, T, D))      # momentum 0.99: model_Base.py:228
+        if stats:
+            buf[mod + ".net.1.num_batches_tracked"] += 1; buf[mod + ".net.4.num_batches_tracked"] += 1
+        if "concat" in c.mml_fusion:
+            local = ws["fus"][:, row_off:row_off + T]
+        else:
+            local = ws["frame_buf"] if which == "video" else ws["seg_buf"]
+        ops.linear(y1.view(nrow, D), P[key + ".6.w"], P[key + ".6.b"], out_row_mask=mflat,
+                   segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
+        vec = ws["video"] if which == "video" else ws["music"]
+        ops.masked_mean(local, mask, out=tw[tag + ".mean"])
+        ops.l2norm_rows(tw[tag + ".mean"], out_f32=vec)
+
+    def _encode_bwd_mlp(self, which: str, ws, tw, d_local: Tensor, d_extra: Optional[Tensor], dvec: Tensor, mask: Tensor, feats: Tensor) -> None:
+        c, P, G = self.cfg, self.P, self.G
+        B, T, Kin = feats.shape
+        D = c.D
+        tag, proj = ("v", "vit_proj") if which == "video" else ("a", "ast_proj")
+        key, mod, _ = self._mlp_towers()[0 if which == "video" else 1]
+        nrow = B * T
+        mflat = mask.reshape(-1)
+        stats = bool(self.training_dropout)
+        bn = tw[tag + ".bn"]
+        dl, gd1, gd2, gh1, gh2 = tw[tag + ".dl"], tw[tag + ".gd1"], tw[tag + ".gd2"], tw[tag + ".gh1"], tw[tag + ".gh2"]
+        tr.pool_bwd(tw[tag + ".mean"], dvec, mask, dl.view(B, T, D), in1=d_local, in2=d_extra)        # zero at padded tokens
+        dy1 = self._lin_bwd(dl, tw[tag + ".y1"], key + ".6", dx_out=gd1)
+        dy0 = tr.posbn_relu_bwd(tw[tag + ".y0"].view(B, T, D), tw[tag + ".y1"].view(B, T, D), dy1.view(B, T, D), P[key + ".4.g"], bn[2], bn[3], stats,
+                                gd2.view(B, T, D), G[key + ".4.g"], G[key + ".4.beta"])
+        dh1 = self._lin_bwd(dy0.view(nrow, D), tw[tag + ".h1"], key + ".3", dx_out=gh1)
+        dh0 = tr.posbn_relu_bwd(tw[tag + ".h0"].view(B, T, -1), tw[tag + ".h1"].view(B, T, -1), dh1.view(B, T, -1), P[key + ".1.g"], bn[0], bn[1], stats,
+                                gh2.view(B, T, -1), G[key + ".1.g"], G[key + ".1.beta"])
+        dx = self._lin_bwd(dh0.view(nrow, -1), tw[tag + ".x0"], key + ".0", dx_out=gd1)
+        if c.with_act_after_proj:
+            dx = tr.gate_rows(dx, gd2, G=tw[tag + ".zproj"], gate=_lib.GATE_QUICKGELU_Z)
+        # with batch statistics the padded tokens (projection of a zero row = the bias) shape the normalisation: they send a
+        # gradient to the projection's bias, none to its weight
+        xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(nrow, Kin)
+        tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, rows=self._rw(mflat))
+        tr.colsum(dx, G[proj + ".b"])
+
     def _encode_bwd(self, which: str, ws, tw, d_local: Tensor, d_extra: Optional[Tensor], dvec: Tensor, mask: Tensor, feats: Tensor) -> None:
         c, P, G = self.cfg, self.P, self.G
+        if c.agg_module == "mlp":
+            return self._encode_bwd_mlp(which, ws, tw, d_local, d_extra, dvec, mask, feats)
         B, T, Kin = feats.shape
         D, Hh = c.D, c.SA_temporal_heads
         proj, mod, depth, tag = (("vit_proj", "video_transformer", c.video_transformer_depth, "v") if which == "video"

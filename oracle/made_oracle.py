@@ -136,23 +136,39 @@ def temporal_block(x: Tensor, mask: Tensor, P, mod: str, depth: int, H: int, dro
     return linear(x, P, mod + ".final_linear")
 
 
-def embedding_net(x: Tensor, P, mod: str) -> Tensor:
-    """reference: model/model_Base.py:216-249 in eval mode (hidden_size = 1024, use_bn): Linear - BatchNorm1d - ReLU - Linear -
-    BatchNorm1d - ReLU - Linear.  BatchNorm1d gets [B, T, F], so its channel axis is the token position t: with the running
-    statistics it is the per-position affine (y - mean[t]) / sqrt(var[t] + 1e-5) * weight[t] + bias[t]."""
-    def bn(y, name):
-        sc = P[name + ".weight"] / torch.sqrt(P[name + ".running_var"] + 1e-5)
-        return (y - P[name + ".running_mean"][None, :, None]) * sc[None, :, None] + P[name + ".bias"][None, :, None]
-    h = torch.relu(bn(linear(x, P, mod + ".net.0"), mod + ".net.1"))
-    h = torch.relu(bn(linear(h, P, mod + ".net.3"), mod + ".net.4"))
+def embedding_net(x: Tensor, P, mod: str, train: bool = False, updates: Optional[dict] = None) -> Tensor:
+    """reference: model/model_Base.py:216-249 (hidden_size = 1024, use_bn): Linear - BatchNorm1d - ReLU - Linear - BatchNorm1d -
+    ReLU - Linear.  BatchNorm1d gets [B, T, F], so its channel axis is the token position t.  Eval mode: the per-position affine
+    (y - mean[t]) / sqrt(var[t] + 1e-5) * weight[t] + bias[t] of the running statistics.  Train mode: the statistics of position
+    t are those of the batch's B * F values there (biased variance; padded samples count like any other), and the running
+    buffers move by `momentum` (0.1 for net.1, 0.99 for net.4: model_Base.py:224,228) towards the mean / UNBIASED variance --
+    the new buffer values are stored in `updates` (torch.nn.BatchNorm1d semantics)."""
+    def bn(y, name, momentum):
+        w, b = P[name + ".weight"][None, :, None], P[name + ".bias"][None, :, None]
+        if not train:
+            sc = 1.0 / torch.sqrt(P[name + ".running_var"] + 1e-5)
+            return (y - P[name + ".running_mean"][None, :, None]) * sc[None, :, None] * w + b
+        n = y.shape[0] * y.shape[2]
+        mean = y.mean(dim=(0, 2))
+        var = ((y - mean[None, :, None]) ** 2).mean(dim=(0, 2))
+        if updates is not None:
+            with torch.no_grad():
+                updates[name + ".running_mean"] = (1 - momentum) * P[name + ".running_mean"] + momentum * mean
+                updates[name + ".running_var"] = (1 - momentum) * P[name + ".running_var"] + momentum * var * (n / max(n - 1, 1))
+                updates[name + ".num_batches_tracked"] = P[name + ".num_batches_tracked"] + 1
+        return (y - mean[None, :, None]) / torch.sqrt(var[None, :, None] + 1e-5) * w + b
+    h = torch.relu(bn(linear(x, P, mod + ".net.0"), mod + ".net.1", 0.1))
+    h = torch.relu(bn(linear(h, P, mod + ".net.3"), mod + ".net.4", 0.99))
     return linear(h, P, mod + ".net.6")
 
 
-def encode_features(feats: Tensor, mask: Tensor, P, cfg, which: str, drop: Optional[Drop] = None) -> Tuple[Tensor, Tensor]:
+def encode_features(feats: Tensor, mask: Tensor, P, cfg, which: str, drop: Optional[Drop] = None, train: Optional[bool] = None,
+                    updates: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
     """reference: model/model_Base.py:544-581 (video) / :583-617 (audio) with
     temporal_transformer :520-542.  Returns (local_feats [B,T,D], global_feats [B,D]).
     Variants: one shared temporal block (transformer_is_share), a learned CLS token whose output is the clip vector
-    (with_cls_token), the EmbeddingNet aggregator instead of the temporal block (agg_module = "mlp", eval mode)."""
+    (with_cls_token), the EmbeddingNet aggregator instead of the temporal block (agg_module = "mlp"; train = batch statistics,
+    default: whenever a dropout source is given, i.e. the reference's model.train())."""
     proj, mod, pe, depth = (("vit_proj", "video_transformer", "video_position_embedding.pe",
                              cfg.video_transformer_depth) if which == "video" else
                             ("ast_proj", "audio_transformer", "audio_position_embedding.pe",
@@ -165,8 +181,8 @@ def encode_features(feats: Tensor, mask: Tensor, P, cfg, which: str, drop: Optio
     if cfg.with_act_after_proj:
         x = quick_gelu(x)
     if cfg.agg_module == "mlp":
-        assert drop is None, "EmbeddingNet in train mode (batch statistics) is not restated"
-        x = embedding_net(x, P, "Video_encoder_projection" if which == "video" else "Music_encoder_projection")
+        x = embedding_net(x, P, "Video_encoder_projection" if which == "video" else "Music_encoder_projection",
+                          train=(drop is not None) if train is None else train, updates=updates)
         x = x * valid
     elif depth > 0:
         if cfg.with_cls_token:                                   # model_Base.py:527-530: token first, its mask entry is 1
@@ -573,9 +589,10 @@ def forward(P, cfg, frame_feats, segment_feats, frame_masks, segment_masks, span
     tg = _t(spans_target).to(dt)
     D = cfg.D
     r: dict = {}
-    frame, video = encode_features(ff, fm, P, cfg, "video", drop)
-    seg, music = encode_features(sf, sm, P, cfg, "audio", drop)
-    r.update(frame_feats=frame, video_feats=video, segment_feats=seg, music_feats=music)
+    upd: dict = {}                                  # train-mode BatchNorm buffer updates (agg_module = "mlp")
+    frame, video = encode_features(ff, fm, P, cfg, "video", drop, updates=upd)
+    seg, music = encode_features(sf, sm, P, cfg, "audio", drop, updates=upd)
+    r.update(frame_feats=frame, video_feats=video, segment_feats=seg, music_feats=music, buffer_updates=upd)
 
     pooled = None
     if "XA" in cfg.vmr_fusion and "music" in cfg.vmr_fusion:

@@ -137,6 +137,10 @@ def compare_backward(cfg: MadeConfig, B: int, T_v: int, T_a: int, tag: str, trai
         rel = _maxabs(g_ref, g_o) / max(float(g_ref.abs().max()), 1e-4)   # floor: k-bias grads are exactly 0 in theory
         worst_rel = max(worst_rel, rel)
     d["grad_worst_rel_to_max"] = worst_rel
+    if r["buffer_updates"]:                                            # train-mode BatchNorm: the running buffers after one step
+        rsd = ref.state_dict()
+        d["buffers_worst_abs"] = max(_maxabs(rsd[k], v) for k, v in r["buffer_updates"].items())
+        d["n_buffers_compared"] = float(len(r["buffer_updates"]))
     d["n_params_compared"] = float(len(pnames))
     if train:
         d["n_dropout_calls"] = float(len(drop.calls))
@@ -245,6 +249,10 @@ def main():
     report["grad_train_native_cls_token_B3"] = compare_backward(c, 3, 20, 40, "native CLS-token train-mode grads", train=True)
     c = cfg_native(); c.with_cls_token = 1; c.with_act_after_proj = 1; c.video_transformer_depth = c.audio_transformer_depth = 2
     report["grad_eval_native_cls_token_act_depth2_B3"] = compare_backward(c, 3, 20, 40, "native CLS-token / act / depth-2 eval-mode grads", train=False)
+    c = cfg_native(); c.agg_module = "mlp"; c.video_transformer_depth = c.audio_transformer_depth = 0; c.max_v_frames = 20; c.max_snippet_num = 40
+    report["grad_train_native_agg_mlp_B3"] = compare_backward(c, 3, 20, 40, "native EmbeddingNet aggregator train-mode grads (batch statistics)", train=True)
+    assert report["grad_train_native_agg_mlp_B3"]["buffers_worst_abs"] < 1e-9
+    report["grad_eval_native_agg_mlp_B3"] = compare_backward(c, 3, 20, 40, "native EmbeddingNet aggregator eval-mode grads", train=False)
     report["lsap_vs_scipy"] = compare_lsap()
     report["retrieval_N48x40_S96"] = compare_retrieval(cfg_native(), 48, 40, 96)
     worst = max(v for k, sec in report.items() if isinstance(sec, dict) and not k.startswith("grad_")

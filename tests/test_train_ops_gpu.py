@@ -479,3 +479,41 @@ def test_clip_loss_same_music_exclusion_forward_and_backward(T):
     np.testing.assert_allclose(dst.cpu().numpy(), s_ref.grad.float().numpy().T, atol=2e-6, rtol=1e-4)
     np.testing.assert_allclose(float(gls), float(l_ref.grad), rtol=1e-4, atol=1e-5)
     assert float(ds[0, 5].abs()) > 0 and bool((ex[0, 5] == 1))       # an excluded pair still gets the column-direction gradient
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,Tn,F", [(5, 20, 1024), (3, 7, 256), (128, 50, 256), (1, 3, 8)])
+@pytest.mark.parametrize("batch_stats", [True, False])
+def test_posbn_relu_forward_backward_match_torch_batchnorm(T, dtype, tol, B, Tn, F, batch_stats):
+    """nn.BatchNorm1d(num_features = positions) on [B, positions, F] followed by ReLU (EmbeddingNet, reference model_Base.py:216-249):
+    batch statistics + running-buffer update in train mode, the running statistics in eval mode; dx / dweight / dbias of both."""
+    ops, tr = T
+    x, dy = _rand(B, Tn, F, dtype=dtype, seed=1) * 1.5 + 0.3, _rand(B, Tn, F, dtype=dtype, seed=2)
+    momentum = 0.99
+    bn = torch.nn.BatchNorm1d(Tn, momentum=momentum).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(_rand(Tn, dtype=torch.float32, seed=3) * 0.3 + 1.0); bn.bias.copy_(_rand(Tn, dtype=torch.float32, seed=4) * 0.2)
+        bn.running_mean.copy_(_rand(Tn, dtype=torch.float32, seed=5) * 0.1 + 0.3); bn.running_var.copy_(torch.rand(Tn, device="cuda") + 1.5)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train(batch_stats)
+    xr = x.float().clone().requires_grad_(True)
+    yr = torch.relu(bn(xr))
+    (yr * dy.float()).sum().backward()
+    y = torch.empty_like(x)
+    sm, sr = torch.empty(Tn, device="cuda"), torch.empty(Tn, device="cuda")
+    w, b = bn.weight.detach().clone(), bn.bias.detach().clone()
+    tr.posbn_relu(x, w, b, rm, rv, momentum, batch_stats, sm, sr, out=y)
+    sc = float(yr.abs().max())
+    assert float((y.float() - yr).abs().max()) <= tol * sc
+    if B * F > 1 or not batch_stats:
+        assert float((rm - bn.running_mean).abs().max()) <= 1e-5 and float((rv - bn.running_var).abs().max()) <= 1e-4 * float(bn.running_var.max())
+    dx = torch.empty_like(x)
+    dw, db = torch.ones(Tn, device="cuda"), torch.ones(Tn, device="cuda")
+    tr.posbn_relu_bwd(x, y, dy, w, sm, sr, batch_stats, dx, dw, db)
+    if dtype == torch.float32:      # (bf16: a value the rounding of y moves across the ReLU's zero flips a whole gradient entry -- compared in f32 only)
+        assert float((dx.float() - xr.grad).abs().max()) <= 5 * tol * float(xr.grad.abs().max())
+        assert float((dw - 1 - bn.weight.grad).abs().max()) <= 5 * tol * max(float(bn.weight.grad.abs().max()), 1.0)
+        assert float((db - 1 - bn.bias.grad).abs().max()) <= 5 * tol * max(float(bn.bias.grad.abs().max()), 1.0)
+    else:
+        cos = torch.nn.functional.cosine_similarity(dx.float().reshape(-1), xr.grad.reshape(-1), dim=0)
+        assert float(cos) >= 0.995

@@ -64,6 +64,9 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
     return sorted(worst)[-3:]
 
 
+_MLP = {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_depth": 0, "max_v_frames": 20, "max_snippet_num": 40}
+
+
 @pytest.mark.parametrize("dropout", [False, True])
 @pytest.mark.parametrize("overrides", [{}, {"vmr_loss": "dual_single_sim_fuse", "moment_query_type": "music"}, {"mml_fusion": "CA"},
                                        {"with_act_after_proj": 1, "moment_query_type": "zero"},
@@ -81,7 +84,8 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
                                        {"moment_query_type": "xpool"}, {"moment_query_type": "xpool", "vmr_loss": "dual", "num_moment_queries": 2},
                                        {"vmr_loss": "dual_single_feature_fuse"}, {"vmr_loss": "dual_single_feature_fuse", "moment_query_type": "xpool", "mml_fusion": "CA"},
                                        {"with_cls_token": 1}, {"with_cls_token": 1, "with_act_after_proj": 1, "video_transformer_depth": 2, "audio_transformer_depth": 2},
-                                       {"with_cls_token": 1, "mml_fusion": "CA", "transformer_is_share": 1}])
+                                       {"with_cls_token": 1, "mml_fusion": "CA", "transformer_is_share": 1},
+                                       dict(_MLP), dict(_MLP, with_act_after_proj=1, mml_fusion="CA")])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     overrides = dict(overrides)
@@ -192,3 +196,31 @@ def test_training_reduces_the_loss():
         losses.append(float(o["retrieval_loss"]) + float(o["localization_loss"]))
     assert np.isfinite(losses).all()
     assert np.mean(losses[-3:]) < 0.9 * np.mean(losses[:3]), losses
+
+
+def test_mlp_aggregator_running_buffers_and_eval_after_a_step():
+    """agg_module = "mlp" in train mode: the BatchNorm running buffers move as torch.nn.BatchNorm1d moves them (oracle
+    `buffer_updates`, pinned against the reference in VALIDATION.json), and the eval path then normalises with the moved buffers."""
+    from mgsv_amd.trainer import MadeTrainer
+    from oracle import made_oracle as O
+    cfg, sd, inp = _setup(3, 20, 40, _MLP)
+    trn = MadeTrainer(cfg, sd, dtype="f32")
+    trn.loss_and_grads(inp, seed=5)
+    P = O.to_torch_params(sd)
+    r = O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"], inp["spans_target"],
+                  v_duration=inp["v_duration"], drop=O.Drop(5, p_detr=cfg.detr_dropout))
+    assert len(r["buffer_updates"]) == 12
+    now = trn.state_dict_numpy()
+    for k, v in r["buffer_updates"].items():
+        ref = v.detach().numpy()
+        assert np.abs(now[k] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+    # eval forward of the trainer (kernel-facing affine refreshed by repack) against the oracle on the updated state
+    trn.repack()
+    P2 = O.to_torch_params({k: now[k] if k in now else v for k, v in sd.items()})
+    e = O.forward(P2, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"], inp["spans_target"],
+                  v_duration=inp["v_duration"])
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    out = trn.forward(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], v_duration=t["v_duration"])
+    torch.cuda.synchronize()
+    assert float((out["video_feats"].cpu() - e["video_feats"]).abs().max()) <= 2e-5
+    assert float((out["music_feats"].cpu() - e["music_feats"]).abs().max()) <= 2e-5
