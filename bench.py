@@ -258,16 +258,38 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
     t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items() if isinstance(v, np.ndarray)}
     it = [0]
 
-    def step():
-        it[0] += 1
-        return trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"],
-                              seed=it[0], lrs=(1e-4, 1e-4, 1e-4), max_grad_norm=1.0, dist=dist)
+    batch = (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
 
+    def eager_step():
+        it[0] += 1
+        return trn.train_step(*batch, seed=it[0], lrs=(1e-4, 1e-4, 1e-4), max_grad_norm=1.0, dist=dist)
+
+    step = eager_step
     # a freshly booted box runs its first second of work at low clocks: bring the GPU to its working state before the W warmup steps
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.75:
         step()
     torch.cuda.synchronize()
+    # The iteration also exists as hipGraph(s) (MadeTrainer.capture_train_step -- seed / Adam step / learning rates in
+    # device memory, the all-reduces between the graphs).  It is measured beside the eager step and NOT used for `value`: on this
+    # ROCm a replay costs the host as much as issuing the ~600 launches itself and the device time is the same.
+    graph_ms = None
+    if args.launch == "graph" and world == 1:
+        try:
+            graph = trn.capture_train_step(*batch, max_grad_norm=1.0)
+            for _ in range(3):
+                it[0] += 1
+                graph.step(*batch, seed=it[0], lrs=(1e-4, 1e-4, 1e-4))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                it[0] += 1
+                graph.step(*batch, seed=it[0], lrs=(1e-4, 1e-4, 1e-4))
+            torch.cuda.synchronize()
+            graph_ms = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+            del graph
+        except Exception as ex:                      # report, do not hide
+            print(f"[bench] hipGraph capture of the training step failed ({type(ex).__name__}: {ex})", file=sys.stderr)
     for _ in range(max(warmup, 1)):
         out = step()
     _barrier(dist)
@@ -280,9 +302,9 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
     assert bool(torch.isfinite(trn.flat_param).all())
     per_kernel, roof = {}, None
     if rank == 0:
-        with ops.KernelTimer() as kt:
+        with ops.KernelTimer() as kt:                # per-kernel HIP events need the eager launches (a replay is one launch)
             for _ in range(2):
-                step()
+                eager_step()
         summ = kt.summary()
         per_kernel = _per_kernel(summ, 2)
         dom = _dominant(summ)
@@ -299,7 +321,7 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
            "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 4}]: B={B}/GPU, T_v={Tv}, T_a={Ta}, D={cfg.D}, train mode (dropout on), "
                                   "f32 master weights + Adam, f32 gradient accumulation",
                       "global_batch": world * B, "parallelism": f"dp{world}: the flat f32 gradient buffer all-reduced in two buckets, the large one under the encoders' backward",
-                      "launch": "eager", "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)},
+                      "launch": "eager", "captured_graph_ms_per_step": graph_ms, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)},
            "roofline": roof,
            "cpu_baseline": (cpu_baseline_train(cfg, sd, inp) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None),
            "kernels": per_kernel}

@@ -55,6 +55,8 @@ typedef struct MadeDropout {
     uint64_t seed;
     uint32_t site;
     float    p;              /* 0 = no dropout */
+    const uint64_t* seed_device;   /* non-NULL: the kernels read the seed from this device word instead of `seed`, so a captured
+                                      hipGraph of the training step draws fresh masks on every replay (the host updates one word) */
 } MadeDropout;
 
 #if defined(__HIPCC__)
@@ -75,6 +77,10 @@ MADE_HOST_DEVICE static inline uint32_t made_rng_key(uint64_t seed, uint32_t sit
 MADE_HOST_DEVICE static inline uint32_t made_rng_mix(uint64_t seed, uint32_t site, uint64_t idx) {
     return made_rng_fmix32((uint32_t)idx ^ made_rng_key(seed, site, (uint32_t)(idx >> 32)));
 }
+#if defined(__HIPCC__)
+/* the seed a kernel uses: one scalar load per kernel when it lives in device memory */
+__device__ static inline uint64_t made_drop_seed(const MadeDropout& d) { return d.seed_device ? *d.seed_device : d.seed; }
+#endif
 
 
 enum MadeStatus {
@@ -627,6 +633,14 @@ typedef struct MadeAdamGroup { int64_t begin, end; float lr; float max_norm; } M
 int made_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, int64_t step,
                    float grad_scale, float* norm_ws, void* stream);
+
+/* made_adam_step_device: the same tail with its per-step scalars in DEVICE memory, so that the whole training iteration can sit in
+ * one captured hipGraph: `state->step` is incremented by the launch and then used for the bias corrections;
+ * `state->lr[g]` replaces groups[g].lr (the host-side LambdaLR schedule writes the three floats before it replays the graph). */
+typedef struct MadeAdamDeviceState { int64_t step; float lr[MADE_ADAM_MAX_GROUPS]; float bc1, bc2_sqrt; } MadeAdamDeviceState;
+int made_adam_step_device(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps,
+                          MadeAdamDeviceState* state_device, float grad_scale, float* norm_ws, void* stream);
 
 /* made_repack: rebuild the kernel-facing copies of every matrix parameter from the f32 masters in one launch:
  * w (rows x cols, `dtype`; NULL = the kernels read the master itself) and wt = W^T (cols x wt_ld, wt_ld >= rows; NULL = not

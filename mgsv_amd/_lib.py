@@ -19,7 +19,7 @@ vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 
 
 class MadeDropout(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("site", C.c_uint32), ("p", f32)]
+    _fields_ = [("seed", C.c_uint64), ("site", C.c_uint32), ("p", f32), ("seed_device", vp)]
 
 
 class MadeLinearSeg(C.Structure):
@@ -130,6 +130,10 @@ class MadeAdamGroup(C.Structure):
     _fields_ = [("begin", i64), ("end", i64), ("lr", f32), ("max_norm", f32)]
 
 
+class MadeAdamDeviceState(C.Structure):
+    _fields_ = [("step", i64), ("lr", f32 * 4), ("bc1", f32), ("bc2_sqrt", f32)]
+
+
 class MadeRepackDesc(C.Structure):
     _fields_ = [("src", vp), ("w", vp), ("wt", vp), ("rows", i64), ("cols", i64), ("wt_ld", i64), ("tile_begin", i64),
                 ("dtype", i32), ("_pad", i32)]
@@ -174,6 +178,7 @@ SIGNATURES = {
     "made_set_criterion_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp,
                                          vp, vp, i64, i32, vp, vp, vp]),
     "made_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, i64, f32, vp, vp]),
+    "made_adam_step_device": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, vp, f32, vp, vp]),
     "made_repack": (C.c_int, [vp, i32, i64, vp]),
     "made_row_groups": (C.c_int, [vp, i64, vp, vp]),
     "made_row_index": (C.c_int, [vp, i64, vp, vp, vp]),

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
     constexpr int NQF = HD * SZ / 32;            // Q fragments (k-steps of the score product)
     constexpr int NDT = HD / 32;                 // 32-row tiles of O^T
     constexpr bool IS_BF16 = SZ == 2;
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[BKEY * K_ROW + BKEY * V_ROW + BKEY * 4 + 32];
     unsigned char* lds_k = lds;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
             const uint64_t base = (uint64_t)((b * a.H + h) * a.Lq + qq) * (uint64_t)a.Lk + (uint64_t)(t * BKEY);
             const uint32_t lo = (uint32_t)base;
             if (__all(lo <= 0xFFFFFFFFu - BKEY)) {           // the tile's indices share their high word: hoist the key
-                const uint32_t kk = made_rng_key(a.drop.seed, a.drop.site, (uint32_t)(base >> 32));
+                const uint32_t kk = made_rng_key(drop_seed, a.drop.site, (uint32_t)(base >> 32));
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const uint32_t hsh = made_rng_mix(a.drop.seed, a.drop.site, base + (uint64_t)(kt * 32 + acc_row(e, hh)));
+                        const uint32_t hsh = made_rng_mix(drop_seed, a.drop.site, base + (uint64_t)(kt * 32 + acc_row(e, hh)));
                         s[kt][e] = (hsh >> 8) >= thr ? s[kt][e] * sc : 0.f;
                     }
             }

@@ -23,8 +23,8 @@ template <typename TC> struct Frag;
 template <> struct Frag<float>  { typedef f32x4  type; };
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 
-__device__ __forceinline__ bool drop_keep(const MadeDropout& d, uint32_t thr, uint64_t idx) {
-    return (made_rng_mix(d.seed, d.site, idx) >> 8) >= thr;
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t site, uint32_t thr, uint64_t idx) {
+    return (made_rng_mix(seed, site, idx) >> 8) >= thr;
 }
 
 // ---------------------------------------------------------------------------------------------- delta
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     }
     const int64_t ntiles = (lk_eff + BKEY - 1) / BKEY;
     const uint32_t thr = made_drop_threshold(a.drop.p);
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t rowbase = (uint64_t)((b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
 
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
         const uint64_t tbase = rowbase + (uint64_t)(t * BKEY);
         const uint32_t tlo = (uint32_t)tbase;
         const bool fast_idx = __all(tlo <= 0xFFFFFFFFu - BKEY);
-        const uint32_t kk = made_rng_key(a.drop.seed, a.drop.site, (uint32_t)(tbase >> 32));
+        const uint32_t kk = made_rng_key(drop_seed, a.drop.site, (uint32_t)(tbase >> 32));
         if constexpr (IS_BF16) {
             // VALU diet (the elementwise part, not the MFMAs, bounds this kernel): exp2 with the scale and -lse folded into
             // one FMA, the key-mask bias only on tiles that contain an invalid key, delta pre-multiplied by the scale
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nl));
                     float g = dp[kt][e];
                     if (a.drop.p > 0.f) {
-                        const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)kl) ^ kk) : made_rng_mix(a.drop.seed, a.drop.site, tbase + (uint64_t)kl);
+                        const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)kl) ^ kk) : made_rng_mix(drop_seed, a.drop.site, tbase + (uint64_t)kl);
                         g = (hsh >> 8) >= thr ? g * dsc : 0.f;
                     }
                     s[kt][e] = p * __builtin_fmaf(g, a.scale, -dsq);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                     const int kl = kt * 32 + acc_row(e, hh);
                     const float p = expf(s[kt][e] * a.scale + tb[kl] - lse_q);
                     float g = dp[kt][e];
-                    if (a.drop.p > 0.f) g = drop_keep(a.drop, thr, tbase + (uint64_t)kl) ? g * dsc : 0.f;
+                    if (a.drop.p > 0.f) g = drop_keep(drop_seed, a.drop.site, thr, tbase + (uint64_t)kl) ? g * dsc : 0.f;
                     s[kt][e] = p * (g - delta_q) * a.scale;
                 }
         }
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     }
     const int64_t ntiles = (lq_eff + BQT - 1) / BQT;
     const uint32_t thr = made_drop_threshold(a.drop.p);
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t bhbase = (uint64_t)(b * a.H + h) * (uint64_t)a.Lq;
     const bool wave_active = __any(key_valid);
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
         const uint64_t tfirst = (bhbase + (uint64_t)(t * BQT)) * (uint64_t)a.Lk;
         const uint64_t tlast = tfirst + (uint64_t)BQT * (uint64_t)a.Lk;
         const bool fast_idx = (tfirst >> 32) == (tlast >> 32);            // wave-uniform: the tile's indices share their high word
-        const uint32_t kk = made_rng_key(a.drop.seed, a.drop.site, (uint32_t)(tfirst >> 32));
+        const uint32_t kk = made_rng_key(drop_seed, a.drop.site, (uint32_t)(tfirst >> 32));
         const uint32_t tlo = (uint32_t)tfirst + (uint32_t)keyc;
         // the two 32-query halves of the tile one after the other (not unrolled): one score / dP tile pair live at a time keeps
         // the kernel at 3 waves per SIMD
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                         float pd = p, g = dp[e];
                         if (a.drop.p > 0.f) {
                             const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)ql * (uint32_t)a.Lk) ^ kk)
-                                                          : made_rng_mix(a.drop.seed, a.drop.site, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
+                                                          : made_rng_mix(drop_seed, a.drop.site, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
                             const bool keep = (hsh >> 8) >= thr;
                             pd = keep ? p * dsc : 0.f;
                             g = keep ? g * dsc : 0.f;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                     const float p = expf(s[e] * a.scale + bias_key - lds_lse[ql]);
                     float pd = p, g = dp[e];
                     if (a.drop.p > 0.f) {
-                        const bool keep = drop_keep(a.drop, thr, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
+                        const bool keep = drop_keep(drop_seed, a.drop.site, thr, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
                         pd = keep ? p * dsc : 0.f;
                         g = keep ? g * dsc : 0.f;
                     }

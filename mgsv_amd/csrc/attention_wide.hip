@@ -138,6 +138,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     float m_run = -INFINITY, l_run = 0.f;
     float sd_run = 0.f;                             // training: running sum of the DROPPED probabilities (they no longer sum to l)
     const uint32_t drop_thr = made_drop_threshold(a.drop.p);
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float drop_sc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t drop_base = (uint64_t)(b * nq_total + (my_q < nq_total ? my_q : nq_total - 1)) * (uint64_t)a.L;
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
             const int row = ROWS_PER_PIECE == 1 ? jp : 2 * jp + (lane >> 5);
             const uint32_t cl = ROWS_PER_PIECE == 1 ? (uint32_t)lane : (uint32_t)(lane & 31);
             const uint32_t srow = ((bits >> row) & 1u) ? (uint32_t)(key0 + row) : (uint32_t)first_valid;
-            const uint32_t ck = cl ^ (uint32_t)(row & 31) & (uint32_t)(CPRW - 1);
+            const uint32_t ck = cl ^ ((uint32_t)(row & 31) & (uint32_t)(CPRW - 1));
             const uint32_t cu = ((((cl >> 2) ^ (uint32_t)(row & 7)) << 2) | (cl & 3));
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kb + (size_t)(srow * ldk_b + ck * 16u)), (lds_ptr_t)(st + jp * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(Vb + (size_t)(srow * ldv_b + cu * 16u)), (lds_ptr_t)(st + WKEY * K_ROW + jp * 1024), 16, 0, 0);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
             float dsum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const bool kp = (made_rng_mix(a.drop.seed, a.drop.site, drop_base + (uint64_t)(t * WKEY + acc_row(e, hh))) >> 8) >= drop_thr;
+                const bool kp = (made_rng_mix(drop_seed, a.drop.site, drop_base + (uint64_t)(t * WKEY + acc_row(e, hh))) >> 8) >= drop_thr;
                 s[e] = kp ? s[e] * drop_sc : 0.f;
                 dsum += s[e];
             }

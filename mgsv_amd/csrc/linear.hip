@@ -223,7 +223,7 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
         const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            v[j] = (made_rng_mix(a.drop.seed, a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+            v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
     }
     if (a.R) {
         float rv[8];
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void linear_ring_kernel(const Made
                 const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    v[j] = (made_rng_mix(a.drop.seed, a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+                    v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
             }
         }
         if (a.R) {

@@ -13,6 +13,7 @@ struct AdamArgs {
     MadeAdamGroup g[MADE_ADAM_MAX_GROUPS]; int n_groups;
     float beta1, beta2, eps, bc1, bc2_sqrt, grad_scale;
     float* norm_sq;
+    const MadeAdamDeviceState* st;          // non-NULL: step count / learning rates / bias corrections live in device memory
 };
 
 __device__ __forceinline__ int group_of(const AdamArgs& a, int64_t i) {
@@ -55,8 +56,13 @@ __global__ __launch_bounds__(OT) void grad_norm_kernel(const AdamArgs a) {
     }
 }
 
-__global__ __launch_bounds__(OT) void norm_finish_kernel(float* norm_ws, int nblocks) {
+__global__ __launch_bounds__(OT) void norm_finish_kernel(float* norm_ws, int nblocks, MadeAdamDeviceState* st, float beta1, float beta2) {
     __shared__ float red[OT];
+    if (st && threadIdx.x == 0) {           // this single-workgroup launch also advances the device-side step count
+        const int64_t step = ++st->step;
+        st->bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+        st->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    }
     for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) {
         float s = 0.f;
         for (int b = threadIdx.x; b < nblocks; b += OT) s += norm_ws[MADE_ADAM_MAX_GROUPS + (int64_t)b * MADE_ADAM_MAX_GROUPS + k];
@@ -82,6 +88,10 @@ __global__ __launch_bounds__(OT) void adam_update_kernel(const AdamArgs a) {
             coef[k] = c < 1.f ? c : 1.f;
         }
     }
+    float lrs[MADE_ADAM_MAX_GROUPS];
+#pragma unroll
+    for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) lrs[k] = a.st ? a.st->lr[k] : a.g[k].lr;
+    const float bc1 = a.st ? a.st->bc1 : a.bc1, bc2_sqrt = a.st ? a.st->bc2_sqrt : a.bc2_sqrt;
     for (int64_t i = ((int64_t)blockIdx.x * OT + threadIdx.x) * 4; i < a.n; i += (int64_t)gridDim.x * OT * 4) {
         const int g0 = group_of(a, i), g3 = group_of(a, i + 3);
         if (g0 < 0 && g3 < 0) continue;
@@ -93,12 +103,12 @@ __global__ __launch_bounds__(OT) void adam_update_kernel(const AdamArgs a) {
             float cf = 1.f, lr = 0.f;
 #pragma unroll
             for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k)
-                if (gi == k) { cf = coef[k]; lr = a.g[k].lr; }
+                if (gi == k) { cf = coef[k]; lr = lrs[k]; }
             const float g = g4[j] * a.grad_scale * cf;
             m4[j] = a.beta1 * m4[j] + (1.f - a.beta1) * g;
             v4[j] = a.beta2 * v4[j] + (1.f - a.beta2) * g * g;
-            const float denom = sqrtf(v4[j]) / a.bc2_sqrt + a.eps;
-            p4[j] -= (lr / a.bc1) * (m4[j] / denom);
+            const float denom = sqrtf(v4[j]) / bc2_sqrt + a.eps;
+            p4[j] -= (lr / bc1) * (m4[j] / denom);
         }
         *(f32x4*)(a.m + i) = m4; *(f32x4*)(a.v + i) = v4; *(f32x4*)(a.param + i) = p4;
     }
@@ -138,12 +148,9 @@ __global__ __launch_bounds__(OT) void repack_kernel(const MadeRepackDesc* descs,
 
 }  // namespace
 
-extern "C" int made_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                              const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, int64_t step,
-                              float grad_scale, float* norm_ws, void* stream) {
-    MADE_REQUIRE(param && grad && exp_avg && exp_avg_sq && groups && norm_ws, "made_adam_step: null pointer");
-    MADE_REQUIRE(n_groups >= 1 && n_groups <= MADE_ADAM_MAX_GROUPS, "made_adam_step: n_groups=%d out of range", n_groups);
-    MADE_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, "made_adam_step: n must be a positive multiple of 4 and step >= 1");
+static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const MadeAdamGroup* groups,
+                       int32_t n_groups, float beta1, float beta2, float eps, int64_t step, MadeAdamDeviceState* state_device,
+                       float grad_scale, float* norm_ws, void* stream, const char* what) {
     AdamArgs a;
     a.param = param; a.grad = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.n_groups = n_groups;
     for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) {
@@ -151,16 +158,37 @@ extern "C" int made_adam_step(float* param, const float* grad, float* exp_avg, f
         else { a.g[k].begin = a.g[k].end = 0; a.g[k].lr = 0.f; a.g[k].max_norm = 0.f; }
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
-    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.bc1 = state_device ? 1.f : (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = state_device ? 1.f : (float)sqrt(1.0 - pow((double)beta2, (double)step));
     a.norm_sq = norm_ws;
+    a.st = state_device;
     hipStream_t st = (hipStream_t)stream;
     int64_t nb = (n / 4 + OT - 1) / OT;
     if (nb > MADE_ADAM_NORM_BLOCKS) nb = MADE_ADAM_NORM_BLOCKS;
     hipLaunchKernelGGL(grad_norm_kernel, dim3((unsigned)nb), dim3(OT), 0, st, a);
-    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(OT), 0, st, norm_ws, (int)nb);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(OT), 0, st, norm_ws, (int)nb, state_device, beta1, beta2);
     hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nb), dim3(OT), 0, st, a);
-    return made_check_launch("made_adam_step");
+    return made_check_launch(what);
+}
+
+extern "C" int made_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, int64_t step,
+                              float grad_scale, float* norm_ws, void* stream) {
+    MADE_REQUIRE(param && grad && exp_avg && exp_avg_sq && groups && norm_ws, "made_adam_step: null pointer");
+    MADE_REQUIRE(n_groups >= 1 && n_groups <= MADE_ADAM_MAX_GROUPS, "made_adam_step: n_groups=%d out of range", n_groups);
+    MADE_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, "made_adam_step: n must be a positive multiple of 4 and step >= 1");
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, groups, n_groups, beta1, beta2, eps, step, nullptr, grad_scale, norm_ws, stream,
+                       "made_adam_step");
+}
+
+extern "C" int made_adam_step_device(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                     const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps,
+                                     MadeAdamDeviceState* state_device, float grad_scale, float* norm_ws, void* stream) {
+    MADE_REQUIRE(param && grad && exp_avg && exp_avg_sq && groups && norm_ws && state_device, "made_adam_step_device: null pointer");
+    MADE_REQUIRE(n_groups >= 1 && n_groups <= MADE_ADAM_MAX_GROUPS, "made_adam_step_device: n_groups=%d out of range", n_groups);
+    MADE_REQUIRE(n > 0 && n % 4 == 0, "made_adam_step_device: n must be a positive multiple of 4");
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, groups, n_groups, beta1, beta2, eps, 0, state_device, grad_scale, norm_ws, stream,
+                       "made_adam_step_device");
 }
 
 extern "C" int made_repack(const MadeRepackDesc* descs_device, int32_t n_desc, int64_t total_tiles, void* stream) {

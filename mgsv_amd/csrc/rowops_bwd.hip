@@ -30,8 +30,8 @@ __device__ __forceinline__ void st4(void* p, int dtype, int64_t idx, f32x4 v) {
         *(bf16x4*)((bf16_t*)p + idx) = t;
     }
 }
-__device__ __forceinline__ bool keep_at(const MadeDropout& d, uint32_t thr, uint64_t idx) {
-    return (made_rng_mix(d.seed, d.site, idx) >> 8) >= thr;
+__device__ __forceinline__ bool keep_at(uint64_t seed, uint32_t site, uint32_t thr, uint64_t idx) {
+    return (made_rng_mix(seed, site, idx) >> 8) >= thr;
 }
 
 // combine per-wave column partials through LDS and add them to a global f32 vector.  Every workgroup ends with one atomic per
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(RT) void gate_rows_kernel(const void* x, int xdt, i
     const int64_t row = (int64_t)blockIdx.x * (RT / 64) + (threadIdx.x >> 6);
     if (row >= rows || (row_skip && row_skip[row] == 0.f)) return;
     const uint32_t thr = made_drop_threshold(drop.p);
+    const uint64_t drop_seed = drop.p > 0.f ? made_drop_seed(drop) : 0;
     const float dsc = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     for (int c = lane * 4; c < cols; c += 256) {
         f32x4 v = ld4(x, xdt, row * ldx + c);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(RT) void gate_rows_kernel(const void* x, int xdt, i
         if (drop.p > 0.f) {
             const uint64_t base = (uint64_t)row * (uint64_t)drop_ld;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = keep_at(drop, thr, base + (uint64_t)((c + j) / drop_col_div)) ? v[j] * dsc : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = keep_at(drop_seed, drop.site, thr, base + (uint64_t)((c + j) / drop_col_div)) ? v[j] * dsc : 0.f;
         }
         st4(out, odt, row * ldo + c, v);
     }
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
     const uint32_t thr = made_drop_threshold(a.drop.p);
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const int D = a.D;
     // A wave's rows are base + k * stride.  It looks 64 of them ahead (one row_skip load per lane, one ballot), then walks the valid
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs 
                     if (a.drop.p > 0.f) {
                         const uint64_t base = (uint64_t)row * (uint64_t)a.drop_ld + (uint64_t)c;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = keep_at(a.drop, thr, base + j) ? o[j] * dsc : 0.f;
+                        for (int j = 0; j < 4; ++j) o[j] = keep_at(drop_seed, a.drop.site, thr, base + j) ? o[j] * dsc : 0.f;
                     }
                     st4(a.dxd, a.dxdt, row * a.lddxd + c, o);
                 }
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(NW * 64) void xpool_tail_bwd_kernel(const XtailBwdA
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
     const uint32_t thr = made_drop_threshold(a.drop.p);
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < a.rows; row += (int64_t)gridDim.x * NW) {
         const int64_t m = row / a.Nv, n = row % a.Nv;
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void xpool_tail_bwd_kernel(const XtailBwdA
                     if (a.drop.p > 0.f) {
                         const uint64_t base = (uint64_t)row * (uint64_t)D + (uint64_t)c;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = keep_at(a.drop, thr, base + j) ? o[j] * dsc : 0.f;
+                        for (int j = 0; j < 4; ++j) o[j] = keep_at(drop_seed, a.drop.site, thr, base + j) ? o[j] * dsc : 0.f;
                     }
                     st4(a.dyd, a.dydt, row * a.lddy + c, o);
                 }
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
     const float* mk = a.mask ? a.mask + (row / a.rows_per_mask) * a.L : nullptr;
     const float ex = a.extra ? a.extra[row] : 0.f;
     const uint32_t thr = made_drop_threshold(a.drop.p);
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t base = (uint64_t)row * (uint64_t)a.L;
     float mx = -INFINITY;
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
         const bool ok = mk == nullptr || mk[k] != 0.f;
         const float p = ok ? expf(s[k] * a.scale - mx) : 0.f;
         float dp = ok ? g[k] + ex : 0.f;              // masked keys may hold stale (non-finite) products: never touch them
-        if (a.drop.p > 0.f) dp = keep_at(a.drop, thr, base + (uint64_t)k) ? dp * dsc : 0.f;
+        if (a.drop.p > 0.f) dp = keep_at(drop_seed, a.drop.site, thr, base + (uint64_t)k) ? dp * dsc : 0.f;
         se += p; dot += p * dp;
     }
     se = wave_sum(se); dot = wave_sum(dot);
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
             float dp = ok ? g[k] + ex : 0.f;
             pd = p;
             if (a.drop.p > 0.f) {
-                const bool kp = keep_at(a.drop, thr, base + (uint64_t)k);
+                const bool kp = keep_at(drop_seed, a.drop.site, thr, base + (uint64_t)k);
                 dp = kp ? dp * dsc : 0.f;
                 pd = kp ? p * dsc : 0.f;
             }
@@ -661,7 +665,7 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
     a.add = add; a.adt = add_dtype; a.ldadd = ld_add;
     a.dx = dx; a.dxdt = dx_dtype; a.lddx = lddx;
     a.dxd = dx_drop; a.lddxd = lddxd;
-    a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f;
+    a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f; a.drop.seed_device = nullptr;
     if (drop) a.drop = *drop;
     a.drop_ld = drop_ld > 0 ? drop_ld : D;
     a.dgamma = dgamma; a.dbeta = dbeta; a.rows = rows; a.D = (int)D; a.eps = eps; a.row_skip = row_skip;
@@ -685,7 +689,7 @@ extern "C" int made_gate_rows(const void* x, int32_t x_dtype, int64_t ldx, const
     MADE_REQUIRE(gate == MADE_GATE_NONE || G != nullptr, "made_gate_rows: gate without G");
     MADE_UNSUPPORTED(cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (G == nullptr || ldg % 4 == 0), "made_gate_rows: bad cols/strides");
     if (rows <= 0) return MADE_OK;
-    MadeDropout d; d.seed = 0; d.site = 0; d.p = 0.f;
+    MadeDropout d; d.seed = 0; d.site = 0; d.p = 0.f; d.seed_device = nullptr;
     if (drop) d = *drop;
     MADE_REQUIRE(d.p >= 0.f && d.p < 1.f, "made_gate_rows: dropout p out of [0,1)");
     hipLaunchKernelGGL(gate_rows_kernel, dim3(blocks4(rows)), dim3(RT), 0, (hipStream_t)stream, x, x_dtype, ldx, G, g_dtype, ldg, gate, scale,
@@ -745,7 +749,7 @@ extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, 
     XtailBwdArgs a;
     a.y = y; a.ydt = y_dtype; a.ldy = ldy; a.gamma = gamma; a.beta = beta; a.video = video; a.ldv = ld_video;
     a.dsims = dsims; a.ldds = ld_dsims; a.dy = dy; a.dydt = dy_dtype; a.lddy = lddy; a.dyd = dy_drop;
-    a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f;
+    a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f; a.drop.seed_device = nullptr;
     if (drop) a.drop = *drop;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dvideo = dvideo; a.lddv = ld_dvideo;
     a.dpool = dpool; a.lddp = ld_dpool; a.dpool_scale = dpool_scale;
@@ -774,7 +778,7 @@ extern "C" int made_softmax_bwd(const float* S, int64_t ld_s, const float* dP, i
     if (rows == 0) return MADE_OK;
     SmBwdArgs a;
     a.S = S; a.lds_ = ld_s; a.dP = dP; a.lddp = ld_dp; a.mask = mask; a.rows_per_mask = rows_per_mask; a.extra = extra;
-    a.scale = scale; a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f;
+    a.scale = scale; a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f; a.drop.seed_device = nullptr;
     if (drop) a.drop = *drop;
     a.Pd = Pd; a.dS = dS; a.dSt = dSt; a.odt = out_dtype; a.ldo = ldo; a.ldt = ldt; a.rows = rows; a.rpb = rows_per_batch; a.L = L;
     a.obs = out_batch_stride > 0 ? out_batch_stride : rows_per_batch * ldo;

@@ -50,6 +50,18 @@ def _f32(t: Optional[Tensor], name: str) -> Optional[Tensor]:
     return t
 
 
+def set_drop(d, drop) -> None:
+    """fill a MadeDropout from (seed, site, p); `seed` is an int, or a 1-element int64 device tensor the kernels read at run
+    time (MadeDropout.seed_device: a captured graph of the training step then draws new masks on every replay)."""
+    seed, site, p = drop
+    if isinstance(seed, Tensor):
+        assert seed.dtype == torch.int64 and seed.numel() == 1 and seed.is_cuda
+        d.seed, d.seed_device = 0, seed.data_ptr()
+    else:
+        d.seed, d.seed_device = int(seed) & 0xFFFFFFFFFFFFFFFF, None
+    d.site, d.p = int(site) & 0xFFFFFFFF, float(p)
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -178,7 +190,7 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
         assert Zout.dim() == 2 and Zout.stride(1) == 1
         a.Zout, a.z_dtype, a.ldz = _p(Zout), dt_of(Zout), Zout.stride(0)
     if drop is not None and drop[2] > 0.0:
-        a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
+        set_drop(a.drop, drop)
         a.drop_ld = N if drop_ld is None else drop_ld
     if rows is not None:                                      # row gather: (row_index int32 [M], n_rows int32 [1]) from row_index()
         a.row_index, a.n_rows = _p(rows[0]), _p(rows[1])
@@ -353,7 +365,7 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
         assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * H * Lq
         a.lse = _p(lse)
     if drop is not None and drop[2] > 0.0:
-        a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
+        set_drop(a.drop, drop)
     esz = 4 if a.dtype == F32 else 2
     flops = 4.0 * B * H * Lq * a.Lk * hd
     nbytes = esz * B * D * (2 * Lq + 2 * a.Lk)
@@ -394,7 +406,7 @@ def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, 
         assert part_o.numel() >= B * n_split * nq * D and part_ml.numel() >= B * n_split * nq * 4
         a.n_split, a.part_o, a.part_ml = n_split, _p(_f32(part_o, "part_o")), _p(_f32(part_ml, "part_ml"))
     if drop is not None and drop[2] > 0.0:
-        a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
+        set_drop(a.drop, drop)
     if sum_out is not None:
         assert sum_out.dtype == torch.float32 and sum_out.is_contiguous() and sum_out.numel() >= B * nq
         a.sum_out = _p(sum_out)

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import BF16, F32, MadeAttnBwdArgs, MadeDropout, MadeGemmTNArgs, MadeGemmTNGroup, check, lib
-from .ops import _f32, _p, _stream, _timed, dt_of
+from .ops import _f32, _p, _stream, _timed, dt_of, set_drop
 
 Tensor = torch.Tensor
 Pair = Tuple[int, int]
@@ -114,7 +114,7 @@ def row_groups(mask: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 def dropout_desc(seed: int, site: int, p: float) -> MadeDropout:
     d = MadeDropout()
-    d.seed, d.site, d.p = int(seed) & 0xFFFFFFFFFFFFFFFF, int(site) & 0xFFFFFFFF, float(p)
+    set_drop(d, (seed, site, p))
     return d
 
 
@@ -143,7 +143,7 @@ def attention_bwd(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, dO: Tensor, dQ: Te
         a.batch_order = _p(order)
     a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
     if drop is not None and drop[2] > 0.0:
-        a.drop.seed, a.drop.site, a.drop.p = int(drop[0]), int(drop[1]), float(drop[2])
+        set_drop(a.drop, drop)
     flops = 10.0 * B * H * Lq * a.Lk * hd                # five products of 2*Lq*Lk*hd (S, dP, dV, dK, dQ): cdna_hip_programming.md, attention backward
     _timed("made_attention_bwd", flops, float(Q.element_size() * B * D * (4 * Lq + 4 * a.Lk)),
            lambda: check(lib().made_attention_bwd(C.byref(a), _stream()), "made_attention_bwd"),

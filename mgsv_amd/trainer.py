@@ -296,8 +296,10 @@ class MadeTrainer(MadeEngine):
                     sh.neg_().add_(P[f"{key}.{bn}.beta"])
 
     def optimizer_step(self, lr_temporal: float, lr_matching: float, lr_detection: float, max_grad_norm: float = 1.0,
-                       betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> None:
-        """Three-group gradient clipping + Adam (reference train-MaDe.py:262-266,375-381) on the flat buffers, then repack()."""
+                       betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, device_state: Optional[Tensor] = None) -> None:
+        """Three-group gradient clipping + Adam (reference train-MaDe.py:262-266,375-381) on the flat buffers, then repack().
+        device_state (a MadeAdamDeviceState in device memory, see TrainStepGraph): the step count and the learning rates are read
+        there by the kernels -- the launch sequence no longer depends on host values and can be captured."""
         import ctypes as C
         self.opt_step += 1
         self.generation += 1
@@ -305,6 +307,14 @@ class MadeTrainer(MadeEngine):
         for i, lr in enumerate((lr_temporal, lr_matching, lr_detection)):
             groups[i].begin, groups[i].end = self.group_ranges[i]
             groups[i].lr, groups[i].max_norm = float(lr), float(max_grad_norm)
+        if device_state is not None:
+            _lib.check(_lib.lib().made_adam_step_device(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                        self.exp_avg_sq.data_ptr(), self.flat_param.numel(), groups, 3, float(betas[0]),
+                                                        float(betas[1]), float(eps), device_state.data_ptr(), float(grad_scale),
+                                                        self._norm_ws.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "made_adam_step_device")
+            self.repack()
+            return
         _lib.check(_lib.lib().made_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                              self.exp_avg_sq.data_ptr(), self.flat_param.numel(), groups, 3, float(betas[0]), float(betas[1]),
                                              float(eps), self.opt_step, float(grad_scale), self._norm_ws.data_ptr(),
@@ -335,6 +345,13 @@ class MadeTrainer(MadeEngine):
         self.optimizer_step(*lrs, max_grad_norm=max_grad_norm, grad_scale=scale)
         return out
 
+    def capture_train_step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, *, max_grad_norm: float = 1.0,
+                           music_ids=None, v_duration: Optional[Tensor] = None, dist=None) -> "TrainStepGraph":
+        """The whole iteration (forward, backward, clip + Adam, repack) as hipGraph(s) over fixed buffers -- SURVEY 8(f)2.  The
+        given batch only shapes the buffers and warms the kernels up: the trainer's state is the same before and after."""
+        return TrainStepGraph(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, max_grad_norm=max_grad_norm,
+                              music_ids=music_ids, v_duration=v_duration, dist=dist)
+
     def state_dict_numpy(self) -> Dict[str, np.ndarray]:
         sd = {k: v.detach().cpu().numpy().copy() for k, v in self.master.items()}
         sd.update({k: v.detach().cpu().numpy().copy() for k, v in self.buffers.items()})
@@ -348,7 +365,8 @@ class MadeTrainer(MadeEngine):
     def _drop(self, site: str, p: float):
         if not self.training_dropout or p <= 0.0:
             return None
-        return (self.seed, dr.site_id(site), float(p))
+        seed_dev = getattr(self, "_seed_dev", None)           # set while a TrainStepGraph is captured: the kernels read the seed there
+        return (seed_dev if seed_dev is not None else self.seed, dr.site_id(site), float(p))
 
     # ------------------------------------------------------------------ training workspace
     def _train_buffers(self, B: int, Tv: int, Ta: int) -> Dict[str, Tensor]:
@@ -553,7 +571,8 @@ class MadeTrainer(MadeEngine):
                 ops.linear_splitk(tw["vn"], tw["mn"], None, tw["sd_ws"][:split * B * B], split, out=ws["sims_dual"])
             else:
                 ops.linear(tw["vn"], tw["mn"], None, out=ws["sims_dual"])
-            self._row_exclude = self.same_music_exclusion(music_ids)
+            static_ex = getattr(self, "_static_exclusion", None)  # TrainStepGraph: a fixed buffer the host refills before each replay
+            self._row_exclude = static_ex if static_ex is not None else self.same_music_exclusion(music_ids)
             self._retrieval_loss(ws, video, music, row_exclude=self._row_exclude,
                                  pooled=tw["xpooled"] if c.vmr_loss == "dual_single_feature_fuse" else None)
         out.update(sims_single=ws["sims_single"], sims_dual=ws["sims_dual"], retrieval_loss=ws["ret_loss"])
@@ -1455,3 +1474,137 @@ class MadeTrainer(MadeEngine):
         torch.cuda.synchronize()
         return dict(retrieval_loss=float(o["retrieval_loss"].cpu()), localization_loss=float(o["localization_loss"].cpu()),
                     grads=self.grads_numpy(), loss_dict={k: float(v.cpu()) if torch.is_tensor(v) else float(v) for k, v in self.loss_dict(o).items()})
+
+
+class TrainStepGraph:
+    """One training iteration of the reference's loop body (train-MaDe.py:337-381) captured once and replayed: about 600 kernel
+    launches cost the host one graph launch.  Everything that changes from step to step lives in device memory the host
+    refreshes before a replay: the batch (fixed input buffers), the dropout seed (MadeDropout.seed_device), the Adam step count
+    and the three learning rates of the LambdaLR schedule (MadeAdamDeviceState), the same-music exclusion matrix.
+    Data-parallel jobs replay three graphs with the two bucketed RCCL all-reduces of the flat gradient buffer between them,
+    the large bucket under the encoders' backward exactly as the eager path has it."""
+
+    def __init__(self, trainer: MadeTrainer, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, *,
+                 max_grad_norm: float = 1.0, music_ids=None, v_duration: Optional[Tensor] = None, dist=None):
+        t = self.trainer = trainer
+        dev = t.device
+        self.dist = dist if (dist is not None and dist.get_world_size() > 1) else None
+        self.inputs = {k: v.to(dev).contiguous().clone() for k, v in (("frame_feats", frame_feats), ("segment_feats", segment_feats),
+                                                                    ("frame_masks", frame_masks), ("segment_masks", segment_masks),
+                                                                    ("spans_target", spans_target))}
+        self.v_duration = v_duration.to(dev).contiguous().clone() if v_duration is not None else None
+        self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        # MadeAdamDeviceState {int64 step; float lr[4]; float bc1, bc2_sqrt}: 32 bytes
+        self.adam_state = torch.zeros(4, device=dev, dtype=torch.int64)
+        self._lr_view = self.adam_state.view(torch.float32)[2:5]
+        self._lrs: Optional[tuple] = None                   # what the device words hold (refilled only when the schedule moves)
+        ex = t.same_music_exclusion(music_ids)
+        self.exclusion = ex.clone() if ex is not None else None
+        scale = 1.0 / self.dist.get_world_size() if self.dist is not None else 1.0
+        i = self.inputs
+
+        def fwd_bwd():
+            out = t.forward_train(i["frame_feats"], i["segment_feats"], i["frame_masks"], i["segment_masks"], i["spans_target"], seed=0,
+                                  v_duration=self.v_duration)
+            t.backward(None, None)
+            return out
+
+        def opt():
+            t.optimizer_step(0.0, 0.0, 0.0, max_grad_norm=max_grad_norm, grad_scale=scale, device_state=self.adam_state)
+
+        # warm-up run (loads the kernels, allocates the workspaces, creates the side streams) on a copy of the state
+        keep = [x.clone() for x in (t.flat_param, t.exp_avg, t.exp_avg_sq)]
+        keep_buf = {k: v.clone() for k, v in t.buffers.items()}
+        keep_step, keep_gen = t.opt_step, t.generation
+        t._seed_dev, t._static_exclusion = self.seed_dev, self.exclusion
+        try:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                fwd_bwd(); opt()
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            for dst, src in zip((t.flat_param, t.exp_avg, t.exp_avg_sq), keep):
+                dst.copy_(src)
+            for k, v in keep_buf.items():
+                t.buffers[k].copy_(v)
+            t.opt_step, t.generation = keep_step, keep_gen
+            t.repack()
+            self.adam_state[0] = keep_step
+            torch.cuda.synchronize()
+            self.graphs = []
+            if self.dist is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out = fwd_bwd(); opt()
+                self.graphs.append(g)
+            else:
+                # three graphs cut where the eager path starts its collectives: [forward .. backward of everything but the temporal
+                # encoders] | all-reduce of the matching + detection ranges starts | [encoders' backward] | all-reduce of the
+                # temporal range | [optimizer].  The capture is switched from the first graph to the second inside backward's
+                # grad_sync hook (both streams are joined there).
+                ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                ctx = [torch.cuda.graph(ga)]
+                ctx[0].__enter__()
+
+                def cut():
+                    ctx[0].__exit__(None, None, None)
+                    ctx[0] = torch.cuda.graph(gb, pool=ga.pool())
+                    ctx[0].__enter__()
+                try:
+                    self.out = t.forward_train(i["frame_feats"], i["segment_feats"], i["frame_masks"], i["segment_masks"], i["spans_target"],
+                                               seed=0, v_duration=self.v_duration)
+                    t.backward(None, None, grad_sync=cut)
+                finally:
+                    ctx[0].__exit__(None, None, None)
+                with torch.cuda.graph(gc_, pool=ga.pool()):
+                    opt()
+                self.graphs += [ga, gb, gc_]
+            t.opt_step, t.generation = keep_step, keep_gen        # capturing runs the Python side of optimizer_step, not the kernels
+            self._dev_step = keep_step
+        finally:
+            t._seed_dev, t._static_exclusion = None, None
+
+    def step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed: int, lrs=(1e-4, 1e-4, 1e-4),
+             music_ids=None, v_duration: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """Same contract as MadeTrainer.train_step; the returned tensors are the graph's fixed output buffers."""
+        t, i = self.trainer, self.inputs
+        for k, v in (("frame_feats", frame_feats), ("segment_feats", segment_feats), ("frame_masks", frame_masks),
+                     ("segment_masks", segment_masks), ("spans_target", spans_target)):
+            if v.data_ptr() != i[k].data_ptr():
+                if tuple(v.shape) != tuple(i[k].shape):
+                    raise ValueError(f"TrainStepGraph: {k} has shape {tuple(v.shape)}, captured for {tuple(i[k].shape)}")
+                i[k].copy_(v, non_blocking=True)
+        if (v_duration is None) != (self.v_duration is None):
+            raise ValueError("TrainStepGraph: v_duration must be given exactly when it was at capture")
+        if v_duration is not None:
+            self.v_duration.copy_(v_duration, non_blocking=True)
+        if self.exclusion is not None:
+            ex = t.same_music_exclusion(music_ids)
+            if ex is None:
+                raise ValueError("TrainStepGraph: captured with music_ids; pass them on every step")
+            self.exclusion.copy_(ex, non_blocking=True)
+        # the per-step scalars travel as kernel arguments of tiny fill launches (stream-ordered; a pinned staging word would be
+        # overwritten by the host while earlier replays are still queued)
+        self.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        lrs = tuple(float(x) for x in lrs)
+        if lrs != self._lrs:
+            for k in range(3):
+                self._lr_view[k:k + 1].fill_(lrs[k])
+            self._lrs = lrs
+        if t.opt_step != self._dev_step:                      # eager optimizer steps in between: realign the device-side count
+            self.adam_state[0:1].fill_(t.opt_step)
+        t.seed = int(seed)
+        self.graphs[0].replay()
+        if self.dist is not None:
+            cut = t.group_ranges[0][1]
+            w1 = self.dist.all_reduce(t.flat_grad[cut:], async_op=True)      # travels under the encoders' backward
+            self.graphs[1].replay()
+            w2 = self.dist.all_reduce(t.flat_grad[:cut], async_op=True)
+            w1.wait(); w2.wait()
+            self.graphs[2].replay()
+        t.opt_step += 1
+        t.generation += 1
+        self._dev_step = t.opt_step
+        return self.out

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, graph=False):
     import torch.distributed as dist
     from mgsv_amd import synth
     from mgsv_amd.config import cfg_native
@@ -30,8 +30,14 @@ def _worker(rank, world, port, out_dir):
     trn = MadeTrainer(cfg, synth.make_state_dict(cfg, seed=0), device="cuda:0", dtype="f32")
     inp = synth.make_inputs(cfg, 4, 20, 40, seed=1 + rank)
     t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    g = trn.capture_train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], dist=dist) if graph else None
     for it in range(2):
-        if it == 0:                                          # the body of train_step, with a look at the reduced gradient
+        if g is not None:                                    # the captured iteration: three graphs around the two all-reduces
+            g.step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=100 + it,
+                   lrs=(1e-3, 1e-3, 1e-3))
+            if it == 0:
+                np.save(os.path.join(out_dir, f"gsum_{rank}.npy"), trn.flat_grad.cpu().numpy())
+        elif it == 0:                                        # the body of train_step, with a look at the reduced gradient
             trn.forward_train(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=100)
             trn.backward()
             dist.all_reduce(trn.flat_grad)
@@ -46,13 +52,14 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_step(tmp_path):
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_rank_data_parallel_step(tmp_path, graph):
     import torch.multiprocessing as mp
     from mgsv_amd import synth
     from mgsv_amd.config import cfg_native
     from mgsv_amd.trainer import MadeTrainer
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), graph), nprocs=2, join=True)
     p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
     assert np.array_equal(p0, p1), "ranks diverged"
     # single-process emulation: sum of the two batches' gradients, scaled by 1/2 inside the optimizer

@@ -224,3 +224,59 @@ def test_mlp_aggregator_running_buffers_and_eval_after_a_step():
     torch.cuda.synchronize()
     assert float((out["video_feats"].cpu() - e["video_feats"]).abs().max()) <= 2e-5
     assert float((out["music_feats"].cpu() - e["music_feats"]).abs().max()) <= 2e-5
+
+
+def _batch(cfg, B, Tv, Ta, seed):
+    from mgsv_amd import synth
+    inp = synth.make_inputs(cfg, B, Tv, Ta, seed=seed)
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    return (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_captured_train_step_follows_the_eager_steps(dtype):
+    """the iteration as one hipGraph.  The replay reads the dropout seed, the Adam step count and the learning rates
+    from device memory: three graph steps on three batches with three seeds and a moving schedule must land where three eager
+    train_step calls land (same kernels, same order: the only freedom is the order of the f32 atomic gradient sums)."""
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, _ = _setup(4, 20, 40)
+    eager, graph = MadeTrainer(cfg, sd, dtype=dtype), MadeTrainer(cfg, sd, dtype=dtype)
+    batches = [_batch(cfg, 4, 20, 40, seed=10 + i) for i in range(3)]
+    g = graph.capture_train_step(*batches[2])
+    assert graph.opt_step == 0
+    for k, v in eager.master.items():                        # capturing (and its warm-up step) left the state alone
+        assert torch.equal(v, graph.master[k]), k
+    tol = 2e-5 if dtype == "f32" else 2e-2
+    for i, b in enumerate(batches):
+        lrs = (1e-3 * (i + 1), 5e-4, 2e-3 / (i + 1))
+        oe = eager.train_step(*b, seed=100 + i, lrs=lrs)
+        le = (float(oe["retrieval_loss"]), float(oe["localization_loss"]))
+        og = g.step(*b, seed=100 + i, lrs=lrs)
+        lg = (float(og["retrieval_loss"]), float(og["localization_loss"]))
+        assert abs(le[0] - lg[0]) <= tol * max(1.0, abs(le[0])) and abs(le[1] - lg[1]) <= tol * max(1.0, abs(le[1])), (i, le, lg)
+    assert graph.opt_step == eager.opt_step == 3
+    assert int(g.adam_state[0]) == 3
+    # Adam moves every weight by at most ~lr per step whatever the gradient's size: a wrong step count, learning rate or mask would
+    # show as a difference of that order; atomic-order noise in the gradients moves the update by a small fraction of it
+    num = den = 0.0
+    for k, v in eager.master.items():
+        num += float((v - graph.master[k]).double().pow(2).sum()); den += float((v - torch.from_numpy(np.asarray(sd[k])).cuda()).double().pow(2).sum())
+    assert num <= (1e-3 if dtype == "f32" else 0.3) * den, (num, den)
+
+
+def test_captured_train_step_reads_seed_and_learning_rates_from_the_device():
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, _ = _setup(4, 20, 40)
+    trn = MadeTrainer(cfg, sd, dtype="f32")
+    b = _batch(cfg, 4, 20, 40, seed=3)
+    g = trn.capture_train_step(*b)
+    before = trn.flat_param.clone()
+    l1 = float(g.step(*b, seed=1, lrs=(0.0, 0.0, 0.0))["localization_loss"])
+    assert torch.equal(trn.flat_param, before)               # zero learning rates: the replay leaves the weights alone
+    l1b = float(g.step(*b, seed=1, lrs=(0.0, 0.0, 0.0))["localization_loss"])
+    l2 = float(g.step(*b, seed=2, lrs=(0.0, 0.0, 0.0))["localization_loss"])
+    assert abs(l1 - l1b) <= 1e-5 * abs(l1) and abs(l1 - l2) > 1e-4 * abs(l1), (l1, l1b, l2)     # same seed, same masks; new seed, new masks
+    g.step(*b, seed=3, lrs=(1e-3, 0.0, 0.0))
+    r0 = trn.group_ranges[0]
+    moved = (trn.flat_param != before)
+    assert bool(moved[r0[0]:r0[1]].any()) and not bool(moved[r0[1]:].any())                         # only the temporal group has a rate

@@ -1,5 +1,4 @@
-"""Experiment: how fast is the training step when replayed as a hipGraph (fixed dropout seed / Adam step -> NOT a valid training
-loop, only a measurement of how much of the eager step time is launch overhead)."""
+"""Training step: eager launches against the captured iteration (MadeTrainer.capture_train_step), alternating, 3 rounds of 40 steps."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,25 +11,26 @@ B, Tv, Ta = 64, cfg.max_v_frames, cfg.max_snippet_num
 trn = MadeTrainer(cfg, synth.make_state_dict(cfg, seed=0), dtype="bf16")
 inp = synth.make_inputs(cfg, B, Tv, Ta, seed=1)
 t = {k: torch.from_numpy(v).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
-step = lambda: trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=5)
-for _ in range(3): step()
+batch = (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+it = [0]
+def eager():
+    it[0] += 1
+    trn.train_step(*batch, seed=it[0])
+for _ in range(100): eager()
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(20): step()
-torch.cuda.synchronize()
-print("eager  ms/step", (time.perf_counter() - t0) / 20 * 1e3)
-t0 = time.perf_counter()
-for _ in range(20): step()
-print("eager  CPU issue ms/step (no sync)", (time.perf_counter() - t0) / 20 * 1e3)
-torch.cuda.synchronize()
-side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side): step()
-torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g): step()
-for _ in range(3): g.replay()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(20): g.replay()
-torch.cuda.synchronize()
-print("graph  ms/step", (time.perf_counter() - t0) / 20 * 1e3)
+g = trn.capture_train_step(*batch)
+def graph():
+    it[0] += 1
+    g.step(*batch, seed=it[0])
+def timeit(f, n=40):
+    for _ in range(5): f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): f()
+    cpu = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, cpu / n * 1e3
+for r in range(3):
+    e, ec = timeit(eager)
+    gr, gc = timeit(graph)
+    print(f"round {r}: eager {e:.3f} ms/step (host issue {ec:.3f}), graph {gr:.3f} ms/step (host issue {gc:.3f})")
