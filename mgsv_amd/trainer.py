@@ -21,6 +21,7 @@ so the gradients of in_proj / out_proj come out of ordinary Linear backward step
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -474,9 +475,10 @@ class MadeTrainer(MadeEngine):
                       g_ffn=E(nd, BQ, D), g_z=E(nd, BQ, Fd), g_ca=E(nd, BQ, D), g_attc=E(nd, BQ, D), g_q=E(nd, B, HQ, D), g_qc=E(nd, BQ, D),
                       g_sa=E(nd, BQ, D), g_qkv=E(nd, BQ, 3 * D))
         ws["dstack"] = stacks
+        ws["s_stack"] = E(nd, BQ, H, dtype=f32)               # sums of the dropped cross-attention weights, one row per (layer, query)
         for l in range(nd):
             ws.update({f"d.{l}.{k}": v[l] for k, v in stacks.items() if not k.startswith("g_")})
-            ws.update({f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.s": E(B * Q, H, dtype=f32), f"d.{l}.t3": stacks["tgt"][l + 1]})
+            ws.update({f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.s": ws["s_stack"][l], f"d.{l}.t3": stacks["tgt"][l + 1]})
         if c.contrastive_align_loss:
             Dc = c.contrastive_hdim
             if c.audio_short_cut:                             # normalize(normalize(p) + music), a second time for the auxiliary layers
@@ -638,7 +640,12 @@ class MadeTrainer(MadeEngine):
         hs = ws["hs"]
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
         n_split = max(1, min(8, 256 // max(B, 1)))           # few queries, long memory: keys split over workgroups
-        for l in range(nd):
+        fused = self._dec_fused(B, L)
+        if fused:
+            # one moment query: every sample's chain through the six layers is independent -- one workgroup per sample walks the
+            # whole stack in ONE launch (made_dec_train_fwd) and fills the same stacks the launches below fill
+            self._dec_fused_launch("made_dec_train_fwd", B, L, ws, tw, mem3, mempos3, fus_mask, ca_scale, pd)
+        for l in range(0 if fused else nd):
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
             tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
             qkv = tw[d + ".qkv"]
@@ -812,6 +819,72 @@ class MadeTrainer(MadeEngine):
                    segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
         ops.masked_mean(local, mask, out=tw[tag + ".mean"])
         ops.l2norm_rows(tw[tag + ".mean"], out_f32=vec)
+
+    # ------------------------------------------------------------------ fused decoder (one moment query)
+    def _dec_fused(self, B: int, L: int) -> bool:
+        c = self.cfg
+        # OPT-IN (MADE_DEC_FUSED=1): parity-green but measured SLOWER than the chain of 64-row launches it replaces (1.15 ms against
+        # ~0.9 ms per forward at B = 64, D = 512, L = 542 -- DESIGN.md 3b has the phase timeline: the per-sample streams are
+        # latency-serialised by the compiler's scheduling and the memory-space attention re-reads 71 MB of memory rows per layer)
+        if os.environ.get("MADE_DEC_FUSED", "0") != "1":
+            return False
+        D, H, Fd = c.D, c.detr_nheads, c.detr_dim_feedforward
+        lds = 4 * (D + 2048 + 2048 + D + 2 * H * D + 64 + H * ((L + 3) & ~3) + L * H)
+        return (c.num_moment_queries == 1 and "regression" not in c.mml_localization and D in (256, 512) and H == 8 and Fd % D == 0
+                and Fd <= 2048 and lds <= 160 * 1024 - 512)
+
+    def _dec_layers_desc(self) -> Tensor:
+        """device array of MadeDecTrainLayer: the kernel-facing weights, biases, norm parameters, gradient accumulators and dropout
+        sites of every decoder layer (all in buffers allocated once: the pointers never change)."""
+        if getattr(self, "_dec_desc", None) is None:
+            c, P, G = self.cfg, self.P, self.G
+            D, nd = c.D, c.detr_dec_layers
+            arr = (_lib.MadeDecTrainLayer * nd)()
+            for l in range(nd):
+                p, d = f"detr_transformer.decoder.layers.{l}", arr[l]
+                Wsa, Wsat, Win, Wint = P[p + ".sa.in.w"], P[p + ".sa.in.wt"], P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
+                for t_ in (Wsa, Wsat, Win, Wint, P[p + ".sa.out.wt"], P[p + ".ca.out.wt"], P[p + ".ff1.wt"], P[p + ".ff2.wt"]):
+                    assert t_.is_contiguous()
+                assert Wsat.shape == (D, 3 * D) and Wint.shape == (D, 3 * D) and P[p + ".sa.out.wt"].shape == (D, D)
+                d.sa_v_w, d.sa_out_w = Wsa[2 * D:].data_ptr(), P[p + ".sa.out.w"].data_ptr()
+                d.ca_q_w, d.ca_k_w, d.ca_v_w, d.ca_out_w = Win.data_ptr(), Win[D:].data_ptr(), Win[2 * D:].data_ptr(), P[p + ".ca.out.w"].data_ptr()
+                d.ff1_w, d.ff2_w = P[p + ".ff1.w"].data_ptr(), P[p + ".ff2.w"].data_ptr()
+                d.sa_v_wt, d.sa_out_wt, d.ca_in_wt = Wsat[:, 2 * D:].data_ptr(), P[p + ".sa.out.wt"].data_ptr(), Wint.data_ptr()
+                d.ca_out_wt, d.ff1_wt, d.ff2_wt = P[p + ".ca.out.wt"].data_ptr(), P[p + ".ff1.wt"].data_ptr(), P[p + ".ff2.wt"].data_ptr()
+                bsa, bin_ = P[p + ".sa.in.b"], P[p + ".ca.in.b"]
+                d.sa_v_b, d.sa_out_b, d.ca_q_b, d.ca_v_b = bsa[2 * D:].data_ptr(), P[p + ".sa.out.b"].data_ptr(), bin_.data_ptr(), bin_[2 * D:].data_ptr()
+                d.ca_out_b, d.ff1_b, d.ff2_b = P[p + ".ca.out.b"].data_ptr(), P[p + ".ff1.b"].data_ptr(), P[p + ".ff2.b"].data_ptr()
+                for k in ("ln1", "ln2", "ln3"):
+                    setattr(d, k + "_g", P[f"{p}.{k}.g"].data_ptr()); setattr(d, k + "_b", P[f"{p}.{k}.b"].data_ptr())
+                    setattr(d, f"g_{k}_g", G[f"{p}.{k}.g"].data_ptr()); setattr(d, f"g_{k}_b", G[f"{p}.{k}.b"].data_ptr())
+                d.g_ca_v_b = G[p + ".ca.in.b"][2 * D:].data_ptr()
+                for k in ("sa_attn", "drop1", "ca_attn", "drop2", "ffn_act", "drop3"):
+                    setattr(d, "site_" + k, dr.site_id(f"dec.{l}.{k}"))
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self._dec_desc = torch.from_numpy(raw).to(self.device)
+        return self._dec_desc
+
+    def _dec_fused_launch(self, fn: str, B: int, L: int, ws, tw, mem3: Tensor, mempos3: Tensor, fus_mask: Tensor, ca_scale: float, pd: float) -> None:
+        import ctypes as C
+        c, P = self.cfg, self.P
+        st = tw["dstack"]
+        a = _lib.MadeDecTrainArgs()
+        a.layers = self._dec_layers_desc().data_ptr()
+        a.n_layers, a.dtype, a.B, a.L, a.D, a.H, a.Fd = c.detr_dec_layers, ops.dt_of(mem3), B, L, c.D, c.detr_nheads, c.detr_dim_feedforward
+        assert mem3.is_contiguous() and mempos3.is_contiguous() and fus_mask.is_contiguous()
+        a.mem, a.mempos, a.key_mask = mem3.data_ptr(), mempos3.data_ptr(), fus_mask.data_ptr()
+        a.query_pos, a.norm_g, a.norm_b = P["query_embed"].data_ptr(), P["dec.norm.g"].data_ptr(), P["dec.norm.b"].data_ptr()
+        for k in ("tgt", "qkv", "att", "t_a", "t1", "t1q", "qc", "pooled", "attc", "t_b", "t2", "h", "t_c"):
+            setattr(a, k, st[k].data_ptr())
+        a.hs, a.GQ, a.s_sum = ws["hs"].data_ptr(), tw["GQ"].data_ptr(), tw["s_stack"].data_ptr()
+        a.scale, a.eps = float(ca_scale), 1e-5
+        drop = self._drop("dec.0.drop1", pd)
+        if drop is not None:
+            ops.set_drop(a.drop, drop)
+        stamps = getattr(self, "_dec_stamps", None)          # tools/dec_fused_stamps.py
+        if stamps is not None:
+            a.stamps = stamps[fn].data_ptr()
+        _lib.check(getattr(_lib.lib(), fn)(C.byref(a), torch.cuda.current_stream().cuda_stream), fn)
 
     def _xpool_train(self, video: Tensor, seg: Tensor, seg_mask: Optional[Tensor], ws, tw, B: int, S: int, key: str = "xa", pre: str = "x",
                      sims_out: Optional[Tensor] = None) -> None:

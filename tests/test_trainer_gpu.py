@@ -280,3 +280,29 @@ def test_captured_train_step_reads_seed_and_learning_rates_from_the_device():
     r0 = trn.group_ranges[0]
     moved = (trn.flat_param != before)
     assert bool(moved[r0[0]:r0[1]].any()) and not bool(moved[r0[1]:].any())                         # only the temporal group has a rate
+
+
+@pytest.mark.parametrize("dtype,dropout", [("f32", True), ("f32", False), ("bf16", True)])
+def test_fused_decoder_forward_kernel_matches_the_launch_chain(dtype, dropout, monkeypatch):
+    """made_dec_train_fwd (one workgroup per sample walks all decoder layers; opt-in, MADE_DEC_FUSED=1) fills the same stacks as
+    the chain of made_linear / made_layernorm / made_attention_wide launches: same losses, same hs, same gradients downstream."""
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, inp = _setup(4, 20, 40)
+    trn = MadeTrainer(cfg, sd, dtype=dtype)
+    trn.training_dropout = dropout
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    args = (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MADE_DEC_FUSED", mode)
+        assert trn._dec_fused(4, 60) == (mode == "1")
+        o = trn.forward_train(*args, seed=11, v_duration=t.get("v_duration"))
+        trn.backward()
+        torch.cuda.synchronize()
+        res[mode] = (float(o["localization_loss"]), o["hs"].float().clone(), trn.flat_grad.clone())
+    tol = 2e-5 if dtype == "f32" else 3e-2
+    assert abs(res["0"][0] - res["1"][0]) <= tol * abs(res["0"][0])
+    assert float((res["0"][1] - res["1"][1]).abs().max()) <= tol * float(res["0"][1].abs().max()) * 4
+    g0, g1 = res["0"][2], res["1"][2]
+    cos = float(torch.nn.functional.cosine_similarity(g0, g1, dim=0))
+    assert cos >= (1 - 1e-6 if dtype == "f32" else 0.995), cos
