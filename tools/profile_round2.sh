@@ -6,9 +6,9 @@ TAG=${1:-r02x}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2>$O/bench_default.err
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $R/bench.py --workload train --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_under_rocprof.json 2>/dev/null
-cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_train_bf16.csv; python3 $R/tools/trace_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 15 70 > $O/train_trace_summary.txt
+cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_train_bf16.csv; python3 $R/tools/trace_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) adam_update_kernel 70 > $O/train_trace_summary.txt
 rm -rf /tmp/p2; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python3 $R/bench.py --workload forward --steps 10 --warmup 3 --no-cpu-baseline --launch eager --in-flight 1 > $O/bench_eval_under_rocprof.json 2>/dev/null
-cp $(find /tmp/p2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_eval_eager_bf16.csv; python3 $R/tools/trace_summary.py $(find /tmp/p2 -name "*kernel_trace.csv" | head -1) 17 50 > $O/eval_trace_summary.txt
+cp $(find /tmp/p2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_eval_eager_bf16.csv; python3 $R/tools/trace_summary.py $(find /tmp/p2 -name "*kernel_trace.csv" | head -1) sine_pe_kernel 50 > $O/eval_trace_summary.txt
 rm -rf /tmp/p3; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python3 $R/bench.py --workload retrieval --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_retrieval_under_rocprof.json 2>/dev/null
 cp $(find /tmp/p3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_retrieval_bf16.csv
 rm -rf /tmp/p4; rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p4 -- python3 $R/bench.py --workload train --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1

@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 kernel_trace.csv: per (kernel, grid) launches, average duration and time per step.
-usage: python tools/trace_summary.py <kernel_trace.csv> <steps> [top]"""
+usage: python tools/trace_summary.py <kernel_trace.csv> <steps | marker-kernel-substring> [top]
+(a marker = a kernel launched exactly once per step, e.g. adam_update_kernel / sine_pe_kernel: the step count is its launch count)"""
 import collections, csv, re, sys
 
 def short(name):
@@ -13,7 +14,11 @@ def short(name):
     return base
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = float(sys.argv[2])
+try:
+    steps = float(sys.argv[2])
+except ValueError:
+    steps = float(sum(1 for r in rows if sys.argv[2] in r["Kernel_Name"]))
+    print(f"steps in the trace ({sys.argv[2]} launches): {steps:.0f}")
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 agg = collections.defaultdict(lambda: [0, 0.0])
 byname = collections.defaultdict(float)
