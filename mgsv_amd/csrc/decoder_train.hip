@@ -150,12 +150,18 @@ __device__ __forceinline__ void matvec(const TC* __restrict__ W, int64_t ldw, in
     };
     // (the prefetches are unconditional -- past the end they re-read the last batch: a load under a branch makes the waitcnt pass
     // assume it may not have been issued, and every wait for the current batch then drains the prefetch as well)
+    // sched_barrier: hipcc otherwise sinks the next batch's loads below the current batch's arithmetic (one buffer, load-all /
+    // wait-all / multiply: every batch pays a full memory round trip)
     load(0, 0, 0);
     for (int t = 0; t < total; t += 2) {
         { const int t1 = t + 1 < total ? t + 1 : total - 1; load(1, t1 / nch, t1 % nch); }
+        __builtin_amdgcn_sched_barrier(0);
         step(std::integral_constant<int, 0>{}, t);
+        __builtin_amdgcn_sched_barrier(0);
         { const int t2 = t + 2 < total ? t + 2 : total - 1; load(0, t2 / nch, t2 % nch); }
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < total) step(std::integral_constant<int, 1>{}, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -202,9 +208,13 @@ __device__ __forceinline__ void multidot(const TC* __restrict__ M, int64_t ld, i
     load(0, 0);
     for (int it = 0; it < nit; it += 2) {
         load(1, it + 1 < nit ? it + 1 : nit - 1);
+        __builtin_amdgcn_sched_barrier(0);
         step(std::integral_constant<int, 0>{}, it);
+        __builtin_amdgcn_sched_barrier(0);
         load(0, it + 2 < nit ? it + 2 : nit - 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -280,9 +290,13 @@ __device__ __forceinline__ void wsum(const TC* __restrict__ M, int64_t ld, int R
     load(0, 0);                                                      // (R >= 1; rows past the end are clamped inside load)
     for (int it = 0; it < nit; it += 2) {
         load(1, it + 1 < nit ? it + 1 : nit - 1);
+        __builtin_amdgcn_sched_barrier(0);
         step(std::integral_constant<int, 0>{}, it);
+        __builtin_amdgcn_sched_barrier(0);
         load(0, it + 2 < nit ? it + 2 : nit - 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h)
@@ -331,9 +345,13 @@ __device__ __forceinline__ void headfold(const TC* __restrict__ M, int64_t ld, i
     load(0, 0);
     for (int it = 0; it < nit; it += 2) {
         load(1, it + 1 < nit ? it + 1 : nit - 1);
+        __builtin_amdgcn_sched_barrier(0);
         step(std::integral_constant<int, 0>{}, it);
+        __builtin_amdgcn_sched_barrier(0);
         load(0, it + 2 < nit ? it + 2 : nit - 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (RPW > 1) {                                                    // RPW == 2: the two half-waves hold the even / odd rows' sums
 #pragma unroll

@@ -5,6 +5,7 @@ import numpy as np, torch
 from mgsv_amd import synth
 from mgsv_amd.config import cfg_headline
 from mgsv_amd.trainer import MadeTrainer
+os.environ["MADE_DEC_FUSED"] = "1"
 cfg = cfg_headline()
 B, Tv, Ta = 64, cfg.max_v_frames, cfg.max_snippet_num
 trn = MadeTrainer(cfg, synth.make_state_dict(cfg, seed=0), dtype="bf16")
