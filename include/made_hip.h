@@ -591,6 +591,44 @@ int made_add3(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, cons
 /* out[c] += sum over rows of x[row, c]  (f32, accumulated): gradient of a row vector that was broadcast over the rows. */
 int made_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream);
 
+/* made_chain: a CHAIN of dependent 64-row stages in ONE launch.  The decoder of the training step is ~250 such stages (Linears on
+ * B*Q rows, row-wise LayerNorms / gates between them), each waiting for the one before: launched one by one they cost 10-12 us
+ * apiece on this part, 4 us of it for an empty kernel.  Here `n_workgroups` (16 by default: what a 512-wide 64-row Linear fills)
+ * co-resident workgroups walk the stage list in device memory and meet at an atomic grid barrier between stages (~1.5 us for 16
+ * workgroups; tools/probes/grid_barrier_probe.hip).  A stage is either a made_linear problem that the tiny-M kernel serves
+ * (M <= 64, K a multiple of 64, bf16 operands; all its epilogue options) or a row operation:
+ *   MADE_CHAIN_LAYERNORM: out = LN(x) (g, b), out2 = out + add (optional; ld_add 0 = one row for all), out3 = LN2(out) (optional)
+ *   MADE_CHAIN_GATE_ROWS: out = dropout(x)  (element index row * drop_ld + col / drop_col_div), as made_gate_rows without a gate
+ *   MADE_CHAIN_HEAD_BIAS: x[r, c] += s[r, c / hd] * bias[c]                                    (made_head_bias)
+ * `barrier` is a device word the caller zeroes once; `barrier_base` is the value it holds before this launch (every launch adds
+ * n_stages * n_workgroups), so consecutive launches need no reset.  Stage outputs become visible to the next stage through
+ * agent-scope release / acquire fences around the barrier (the workgroups sit on different XCDs).
+ * Status: correct (bit-identical to the separate launches) and NOT faster on MI355X -- a stage costs ~10 us either way, the chain of
+ * memory round trips inside a dependent stage, not the launch, is what takes the time.  Kept as an opt-in path. */
+enum MadeChainOp { MADE_CHAIN_LINEAR = 1, MADE_CHAIN_LAYERNORM = 2, MADE_CHAIN_GATE_ROWS = 3, MADE_CHAIN_HEAD_BIAS = 4 };
+typedef struct MadeChainRowOp {
+    const void* x; int64_t ldx;
+    void* out; int64_t ldo;
+    void* out2; int64_t ldo2;
+    void* out3; int64_t ldo3;
+    const void* add; int64_t ld_add;
+    const float *g, *b, *g2, *b2;
+    const float *s, *bias;
+    int64_t rows, cols, drop_ld;
+    int32_t dtype, drop_col_div, H, _pad;
+    float eps, _padf;
+    MadeDropout drop;
+} MadeChainRowOp;
+typedef struct MadeChainStage {
+    int32_t op, _pad;
+    MadeLinearArgs lin;
+    MadeChainRowOp row;
+} MadeChainStage;
+int made_chain(const MadeChainStage* stages_device, int32_t n_stages, int32_t n_workgroups, uint32_t* barrier, uint32_t barrier_base,
+               void* stream);
+/* host-side check that a made_linear problem may be a MADE_CHAIN_LINEAR stage (returns MADE_OK or MADE_ERR_UNSUPPORTED) */
+int made_chain_linear_ok(const MadeLinearArgs* args);
+
 /* made_dec_train_fwd: the moment-DETR decoder of the training step for ONE moment query (Q = 1), every layer in one launch: one
  * workgroup per sample walks the stack (reference music_detr/transformer.py:119-145, :273-307 forward_post, model.train()).  It
  * writes what the unfused chain of made_linear / made_layernorm / made_attention_wide launches writes -- every activation the

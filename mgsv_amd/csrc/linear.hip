@@ -1197,17 +1197,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void linear_skinny_kernel(const MadeLi
 constexpr int T_BN = 32, T_BM = 64, T_CH = 4;
 constexpr int T_CT_LD = T_BN + 4;
 
+// (a device function: the kernel below runs it on its own blockIdx, made_chain's executor on the tiles of a stage)
 template <bool TRAIN>
-__global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearArgs a) {
-    __shared__ __attribute__((aligned(16))) float Ct[4 * T_BM * T_CT_LD];
+__device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const int bx, const int bz, float* Ct /* [4 * T_BM * T_CT_LD] LDS */) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
     const int n_tiles = (N + T_BN - 1) / T_BN;
-    const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+    const int tile_m = bx / n_tiles, tile_n = bx % n_tiles;
     const int m0 = tile_m * T_BM, n0 = tile_n * T_BN;
-    const int64_t z = blockIdx.z;
+    const int64_t z = bz;
     int Mv = M;
     if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
     if (m0 >= Mv) return;
@@ -1321,6 +1321,168 @@ __global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearA
     store8(outp, seg.out_dtype, out_z + orow + (n - colb), v, nvalid, out_vec);
 }
 
+template <bool TRAIN>
+__global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ct[4 * T_BM * T_CT_LD];
+    linear_tiny_body<TRAIN>(a, blockIdx.x, blockIdx.z, Ct);
+}
+
+// =================================================================================================
+// made_chain: dependent 64-row stages behind one launch (see include/made_hip.h)
+__device__ __forceinline__ f32x4 chain_ld4(const void* p, int dtype, int64_t idx) {
+    f32x4 v;
+    if (dtype == MADE_F32) {
+        v = *(const f32x4*)((const float*)p + idx);
+    } else {
+        const bf16x4 t = *(const bf16x4*)((const bf16_t*)p + idx);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    return v;
+}
+__device__ __forceinline__ void chain_st4(void* p, int dtype, int64_t idx, f32x4 v) {
+    if (dtype == MADE_F32) {
+        *(f32x4*)((float*)p + idx) = v;
+    } else {
+        bf16x4 t;
+        t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+        *(bf16x4*)((bf16_t*)p + idx) = t;
+    }
+}
+__device__ __forceinline__ f32x4 chain_round(f32x4 v, int dtype) {            // the value a store in `dtype` keeps
+    if (dtype == MADE_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)(bf16_t)v[j];
+    }
+    return v;
+}
+
+constexpr int CH_NV = 8;                                   // row ops: up to 64 * 4 * 8 = 2048 columns, one wave per row
+
+// LayerNorm of the row held as v[i] (columns (i * 64 + lane) * 4 ..): two passes over the registers, as made_layernorm does
+__device__ __forceinline__ void chain_wave_ln(f32x4 (&v)[CH_NV], int nv, int D, int lane, const float* g, const float* b, float eps) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH_NV; ++i)
+        if (i < nv && (i * WAVE + lane) * 4 < D) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH_NV; ++i)
+        if (i < nv && (i * WAVE + lane) * 4 < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < CH_NV; ++i) {
+        const int c = (i * WAVE + lane) * 4;
+        if (i < nv && c < D) {
+            const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(b + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+        }
+    }
+}
+
+__device__ __forceinline__ void chain_row_stage(const int op, const MadeChainRowOp& o) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = (int)o.cols, dt = o.dtype;
+    const int nv = (D + 255) / 256;
+    for (int64_t row = (int64_t)blockIdx.x * (NTHREADS / WAVE) + wave; row < o.rows; row += (int64_t)gridDim.x * (NTHREADS / WAVE)) {
+        if (op == MADE_CHAIN_LAYERNORM) {
+            f32x4 v[CH_NV];
+#pragma unroll
+            for (int i = 0; i < CH_NV; ++i) {
+                const int c = (i * WAVE + lane) * 4;
+                if (i < nv && c < D) v[i] = chain_ld4(o.x, dt, row * o.ldx + c);
+            }
+            chain_wave_ln(v, nv, D, lane, o.g, o.b, o.eps);
+#pragma unroll
+            for (int i = 0; i < CH_NV; ++i) {
+                const int c = (i * WAVE + lane) * 4;
+                if (i < nv && c < D) {
+                    if (o.out) chain_st4(o.out, dt, row * o.ldo + c, v[i]);
+                    v[i] = chain_round(v[i], dt);                  // what follows is built from the value `out` holds
+                    if (o.out2) {
+                        const f32x4 ad = chain_ld4(o.add, dt, row * o.ld_add + c);
+                        f32x4 t = v[i];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] += ad[j];
+                        chain_st4(o.out2, dt, row * o.ldo2 + c, t);
+                    }
+                }
+            }
+            if (o.out3) {
+                chain_wave_ln(v, nv, D, lane, o.g2, o.b2, o.eps);
+#pragma unroll
+                for (int i = 0; i < CH_NV; ++i) {
+                    const int c = (i * WAVE + lane) * 4;
+                    if (i < nv && c < D) chain_st4(o.out3, dt, row * o.ldo3 + c, v[i]);
+                }
+            }
+        } else if (op == MADE_CHAIN_GATE_ROWS) {
+            const uint32_t thr = made_drop_threshold(o.drop.p);
+            const uint64_t seed = o.drop.p > 0.f ? made_drop_seed(o.drop) : 0;
+            const float dsc = o.drop.p > 0.f ? 1.f / (1.f - o.drop.p) : 1.f;
+            for (int c = lane * 4; c < D; c += 256) {
+                f32x4 v = chain_ld4(o.x, dt, row * o.ldx + c);
+                if (o.drop.p > 0.f) {
+                    const uint64_t base = (uint64_t)row * (uint64_t)o.drop_ld;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = (made_rng_mix(seed, o.drop.site, base + (uint64_t)((c + j) / o.drop_col_div)) >> 8) >= thr ? v[j] * dsc : 0.f;
+                }
+                chain_st4(o.out, dt, row * o.ldo + c, v);
+            }
+        } else {                                                   // MADE_CHAIN_HEAD_BIAS (in place on x)
+            const int hd = D / o.H;
+            for (int c = lane * 4; c < D; c += 256) {
+                f32x4 v = chain_ld4(o.x, dt, row * o.ldx + c);
+                const f32x4 bb = *(const f32x4*)(o.bias + c);
+                const float sh = o.s[row * o.H + c / hd];          // hd is a multiple of 4: the four columns share a head
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += sh * bb[j];
+                chain_st4(const_cast<void*>(o.x), dt, row * o.ldx + c, v);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void chain_kernel(const MadeChainStage* __restrict__ stages, const int n_stages, unsigned* barrier,
+                                                         const unsigned barrier_base) {
+    __shared__ __attribute__((aligned(16))) float Ct[4 * T_BM * T_CT_LD];
+    for (int s = 0; s < n_stages; ++s) {
+        const MadeChainStage& st = stages[s];
+        if (st.op == MADE_CHAIN_LINEAR) {
+            const MadeLinearArgs& a = st.lin;
+            const int tiles = (int)(((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN));
+            const int total = tiles * (int)a.batch;
+            for (int t = blockIdx.x; t < total; t += gridDim.x) {
+                linear_tiny_body<true>(a, t % tiles, t / tiles, Ct);
+                __syncthreads();                                   // Ct is reused by the next tile
+            }
+        } else {
+            chain_row_stage(st.op, st.row);
+        }
+        if (s + 1 < n_stages) {
+            // ---- grid barrier.  Release: every wave's stores must have left for memory before the workgroup signs in; acquire:
+            // the other XCDs' results are fetched past this XCD's caches afterwards.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned target = barrier_base + (unsigned)(s + 1) * gridDim.x;
+                while ((int)(__hip_atomic_load(barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    // the last stage's count keeps `barrier` at base + n_stages * gridDim.x whatever n_stages is
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 // tuning knob for the micro-benchmarks and tests: MADE_LINEAR_TILE=64|128 forces the single-stage direct-to-LDS kernels of round 1,
@@ -1367,9 +1529,8 @@ static int pick_variant(const MadeLinearArgs& a) {
     return MADE_LINEAR_GLDS64;
 }
 
-extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
-    MADE_REQUIRE(args != nullptr, "made_linear: null args");
-    const MadeLinearArgs& a = *args;
+// argument checks of made_linear (shared with made_chain, whose stages are made_linear problems)
+static int linear_validate(const MadeLinearArgs& a) {
     MADE_REQUIRE(a.A && a.W, "made_linear: null A or W");
     MADE_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "made_linear: bad dims M=%lld N=%lld K=%lld",
                  (long long)a.M, (long long)a.N, (long long)a.K);
@@ -1410,6 +1571,13 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
         for (int s = 0; s < a.nseg; ++s)
             MADE_UNSUPPORTED(!a.seg[s].transposed, "made_linear: gate / Zout / dropout are not available on transposed segments");
     }
+    return MADE_OK;
+}
+
+extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
+    MADE_REQUIRE(args != nullptr, "made_linear: null args");
+    const MadeLinearArgs& a = *args;
+    { const int rc = linear_validate(a); if (rc != MADE_OK) return rc; }
     if (a.M == 0) return MADE_OK;
     const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     MADE_UNSUPPORTED(tiles < (1LL << 31), "made_linear: too many tiles");
@@ -1469,4 +1637,22 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
 
 extern "C" int made_linear_variant(const MadeLinearArgs* args) {
     return args ? pick_variant(*args) : -1;
+}
+
+extern "C" int made_chain_linear_ok(const MadeLinearArgs* args) {
+    MADE_REQUIRE(args != nullptr, "made_chain_linear_ok: null args");
+    { const int rc = linear_validate(*args); if (rc != MADE_OK) return rc; }
+    MADE_UNSUPPORTED(pick_variant(*args) == MADE_LINEAR_TINY && args->M > 0, "made_chain: not a tiny-M made_linear problem");
+    return MADE_OK;
+}
+
+extern "C" int made_chain(const MadeChainStage* stages_device, int32_t n_stages, int32_t n_workgroups, uint32_t* barrier,
+                          uint32_t barrier_base, void* stream) {
+    MADE_REQUIRE(stages_device && barrier, "made_chain: null pointer");
+    MADE_REQUIRE(n_stages >= 1 && n_stages <= 4096, "made_chain: n_stages=%d out of range", n_stages);
+    // every workgroup must be resident at once (they wait for each other): one per CU at most, far below the 256 CUs
+    MADE_REQUIRE(n_workgroups >= 1 && n_workgroups <= 128, "made_chain: n_workgroups=%d out of [1, 128]", n_workgroups);
+    hipLaunchKernelGGL(chain_kernel, dim3((unsigned)n_workgroups), dim3(NTHREADS), 0, (hipStream_t)stream, stages_device, (int)n_stages, barrier,
+                       barrier_base);
+    return made_check_launch("made_chain");
 }

@@ -367,7 +367,16 @@ class MadeTrainer(MadeEngine):
         if not self.training_dropout or p <= 0.0:
             return None
         seed_dev = getattr(self, "_seed_dev", None)           # set while a TrainStepGraph is captured: the kernels read the seed there
+        if seed_dev is None:
+            seed_dev = getattr(self, "_chain_seed", None)    # chained decoder stages (made_chain): stage lists must not change per step
         return (seed_dev if seed_dev is not None else self.seed, dr.site_id(site), float(p))
+
+    def _chain_on(self) -> bool:
+        """The decoder's dependent 64-row launches as made_chain stages (one moment query; not while a graph is being captured: the
+        barrier base of a chain launch is a host-side count).  OPT-IN (MADE_CHAIN=1): bit-identical to the separate launches and
+        no faster -- a stage behind a grid barrier costs the same ~10 us as a stage behind a kernel boundary."""
+        return (os.environ.get("MADE_CHAIN", "0") == "1" and self.cfg.num_moment_queries == 1 and self.tc == torch.bfloat16
+                and getattr(self, "_seed_dev", None) is None and not torch.cuda.is_current_stream_capturing())
 
     # ------------------------------------------------------------------ training workspace
     def _train_buffers(self, B: int, Tv: int, Ta: int) -> Dict[str, Tensor]:
@@ -513,6 +522,14 @@ class MadeTrainer(MadeEngine):
         if c.predict_center == 1 and v_duration is None:
             raise ValueError("predict_center=1 needs v_duration (reference model/model_Uni.py:280-282)")
         self.seed = int(seed)
+        if self._chain_on():
+            if getattr(self, "_chain_seed_buf", None) is None:
+                self._chain_seed_buf = torch.zeros(1, device=self.device, dtype=torch.int64)
+                self._chain_fwd, self._chain_bwd = {}, {}
+            self._chain_seed = self._chain_seed_buf
+            self._chain_seed.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        else:
+            self._chain_seed = None
         B, Tv, _ = frame_feats.shape
         Ta = segment_feats.shape[1]
         concat = "concat" in c.mml_fusion
@@ -645,7 +662,12 @@ class MadeTrainer(MadeEngine):
             # one moment query: every sample's chain through the six layers is independent -- one workgroup per sample walks the
             # whole stack in ONE launch (made_dec_train_fwd) and fills the same stacks the launches below fill
             self._dec_fused_launch("made_dec_train_fwd", B, L, ws, tw, mem3, mempos3, fus_mask, ca_scale, pd)
-        for l in range(0 if fused else nd):
+        # the chain of dependent 64-row launches below is recorded and launched as made_chain stages (grid barriers instead of kernel
+        # boundaries); the wide attention in the middle of every layer is a launch of its own and splits the chain there
+        import contextlib
+        rec = ops.ChainRecorder(self._chain_fwd, self.device) if (self._chain_seed is not None and not fused) else contextlib.nullcontext()
+        with rec:
+          for l in range(0 if fused else nd):
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
             tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
             qkv = tw[d + ".qkv"]

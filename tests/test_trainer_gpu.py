@@ -306,3 +306,22 @@ def test_fused_decoder_forward_kernel_matches_the_launch_chain(dtype, dropout, m
     g0, g1 = res["0"][2], res["1"][2]
     cos = float(torch.nn.functional.cosine_similarity(g0, g1, dim=0))
     assert cos >= (1 - 1e-6 if dtype == "f32" else 0.995), cos
+
+
+def test_chained_decoder_stages_leave_the_step_bit_identical(monkeypatch):
+    """MADE_CHAIN=1: the decoder forward's 64-row launches recorded into made_chain stage lists (7 launches instead of ~90) -- same
+    kernels' bodies behind grid barriers, so the outputs and the gradients downstream are the separate launches' bit for bit."""
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, inp = _setup(4, 20, 40)
+    trn = MadeTrainer(cfg, sd, dtype="bf16")
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    args = (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+    res = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("MADE_CHAIN", mode)
+        o = trn.forward_train(*args, seed=21, v_duration=t.get("v_duration"))
+        torch.cuda.synchronize()
+        res.setdefault(mode, []).append((o["hs"].clone(), o["pred_logits"].clone(), float(o["localization_loss"])))
+    assert len(trn._chain_fwd["cache"]) >= 2                  # stage lists were recorded and uploaded (once)
+    for got in res["1"]:
+        assert torch.equal(got[0], res["0"][0][0]) and torch.equal(got[1], res["0"][0][1]) and got[2] == res["0"][0][2]
