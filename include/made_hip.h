@@ -626,6 +626,9 @@ typedef struct MadeChainStage {
 } MadeChainStage;
 int made_chain(const MadeChainStage* stages_device, int32_t n_stages, int32_t n_workgroups, uint32_t* barrier, uint32_t barrier_base,
                void* stream);
+/* profiling aid: the following made_chain launches write 4 s_memtime stamps per stage (workgroup 0: stage start, work done, release
+ * done, barrier passed) into `stamps` (device memory, 4 * n_stages words); NULL switches it off */
+int made_chain_debug_stamps(uint64_t* stamps);
 /* host-side check that a made_linear problem may be a MADE_CHAIN_LINEAR stage (returns MADE_OK or MADE_ERR_UNSUPPORTED) */
 int made_chain_linear_ok(const MadeLinearArgs* args);
 

@@ -207,6 +207,7 @@ SIGNATURES = {
     "made_dec_train_fwd": (C.c_int, [C.POINTER(MadeDecTrainArgs), vp]),
     "made_chain": (C.c_int, [vp, i32, i32, vp, C.c_uint32, vp]),
     "made_chain_linear_ok": (C.c_int, [C.POINTER(MadeLinearArgs)]),
+    "made_chain_debug_stamps": (C.c_int, [vp]),
     "made_posbn_relu_fwd": (C.c_int, [vp, i32, i64, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, i32, i64, i64, i64, i64, vp]),
     "made_posbn_relu_bwd": (C.c_int, [vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, vp, i32, i64, vp, vp, i64, i64, i64, vp]),
     "made_set_criterion_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp,

@@ -1198,8 +1198,30 @@ constexpr int T_BN = 32, T_BM = 64, T_CH = 4;
 constexpr int T_CT_LD = T_BN + 4;
 
 // (a device function: the kernel below runs it on its own blockIdx, made_chain's executor on the tiles of a stage)
-template <bool TRAIN>
-__device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const int bx, const int bz, float* Ct /* [4 * T_BM * T_CT_LD] LDS */) {
+// the first 2 * T_CH weight fragments of a tile (what linear_tiny_body's first two loads would fetch): weights do not depend on the
+// previous stage, so made_chain's executor requests them BEFORE it waits at the grid barrier
+__device__ __forceinline__ void linear_tiny_prefetch_w(const MadeLinearArgs& a, const int bx, const int bz, bf16x8 (&fwp)[2][T_CH]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int N = (int)a.N, K = (int)a.K;
+    const int n_tiles = (N + T_BN - 1) / T_BN;
+    const int n0 = (bx % n_tiles) * T_BN;
+    const int steps = K / 64;
+    const int kw = wave * steps * 16 + hh * 8;
+    int gn = n0 + r; gn = gn < N ? gn : N - 1;
+    const bf16_t* pw = (const bf16_t*)a.W + (int64_t)bz * a.w_z_stride + (int64_t)gn * a.ldw + kw;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < T_CH; ++i) {
+            const int st = b * T_CH + i < steps ? b * T_CH + i : steps - 1;
+            fwp[b][i] = *(const bf16x8*)(pw + st * 16);
+        }
+}
+
+template <bool TRAIN, bool PRE = false>
+__device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const int bx, const int bz, float* Ct /* [4 * T_BM * T_CT_LD] LDS */,
+                                                 const bf16x8 (*fwp)[T_CH] = nullptr /* PRE: the tile's first 2 * T_CH weight fragments */) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -1275,12 +1297,35 @@ __device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const 
             }
         }
     };
-    load(0, 0);
-    for (int s0 = 0; s0 < steps; s0 += 2 * T_CH) {
-        if (s0 + T_CH < steps) load(1, s0 + T_CH);
-        mul(0, s0);
-        if (s0 + 2 * T_CH < steps) load(0, s0 + 2 * T_CH);
-        if (s0 + T_CH < steps) mul(1, s0 + T_CH);
+    auto load_a = [&](int buf, int s0) __attribute__((always_inline)) {       // PRE: the weights of the first two batches are already here
+#pragma unroll
+        for (int i = 0; i < T_CH; ++i) {
+            const int s = s0 + i < steps ? s0 + i : steps - 1;
+            fw[buf][i] = fwp[buf][i];
+            fa[buf][i][0] = *(const bf16x8*)(pa[0] + s * 16);
+            fa[buf][i][1] = *(const bf16x8*)(pa[1] + s * 16);
+        }
+    };
+    if constexpr (PRE) {
+        load_a(0, 0);
+        load_a(1, T_CH);                                       // (past the end when steps <= T_CH: re-read, never multiplied)
+        mul(0, 0);
+        if (2 * T_CH < steps) load(0, 2 * T_CH);
+        mul(1, T_CH);
+        for (int s0 = 2 * T_CH; s0 < steps; s0 += 2 * T_CH) {
+            if (s0 + T_CH < steps) load(1, s0 + T_CH);
+            mul(0, s0);
+            if (s0 + 2 * T_CH < steps) load(0, s0 + 2 * T_CH);
+            if (s0 + T_CH < steps) mul(1, s0 + T_CH);
+        }
+    } else {
+        load(0, 0);
+        for (int s0 = 0; s0 < steps; s0 += 2 * T_CH) {
+            if (s0 + T_CH < steps) load(1, s0 + T_CH);
+            mul(0, s0);
+            if (s0 + 2 * T_CH < steps) load(0, s0 + 2 * T_CH);
+            if (s0 + T_CH < steps) mul(1, s0 + T_CH);
+        }
     }
 
     float* mine = Ct + wave * (T_BM * T_CT_LD);
@@ -1359,7 +1404,8 @@ __device__ __forceinline__ f32x4 chain_round(f32x4 v, int dtype) {            //
 constexpr int CH_NV = 8;                                   // row ops: up to 64 * 4 * 8 = 2048 columns, one wave per row
 
 // LayerNorm of the row held as v[i] (columns (i * 64 + lane) * 4 ..): two passes over the registers, as made_layernorm does
-__device__ __forceinline__ void chain_wave_ln(f32x4 (&v)[CH_NV], int nv, int D, int lane, const float* g, const float* b, float eps) {
+// (g / b: fragments the caller loaded together with the row -- behind the reductions they would be a second round trip)
+__device__ __forceinline__ void chain_wave_ln(f32x4 (&v)[CH_NV], int nv, int D, int lane, const f32x4 (&gv)[CH_NV], const f32x4 (&bv)[CH_NV], float eps) {
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < CH_NV; ++i)
@@ -1377,9 +1423,8 @@ __device__ __forceinline__ void chain_wave_ln(f32x4 (&v)[CH_NV], int nv, int D, 
     for (int i = 0; i < CH_NV; ++i) {
         const int c = (i * WAVE + lane) * 4;
         if (i < nv && c < D) {
-            const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(b + c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+            for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * gv[i][j] + bv[i][j];
         }
     }
 }
@@ -1390,13 +1435,17 @@ __device__ __forceinline__ void chain_row_stage(const int op, const MadeChainRow
     const int nv = (D + 255) / 256;
     for (int64_t row = (int64_t)blockIdx.x * (NTHREADS / WAVE) + wave; row < o.rows; row += (int64_t)gridDim.x * (NTHREADS / WAVE)) {
         if (op == MADE_CHAIN_LAYERNORM) {
-            f32x4 v[CH_NV];
+            f32x4 v[CH_NV], gv[CH_NV], bv[CH_NV], g2v[CH_NV], b2v[CH_NV];
 #pragma unroll
             for (int i = 0; i < CH_NV; ++i) {
                 const int c = (i * WAVE + lane) * 4;
-                if (i < nv && c < D) v[i] = chain_ld4(o.x, dt, row * o.ldx + c);
+                if (i < nv && c < D) {
+                    v[i] = chain_ld4(o.x, dt, row * o.ldx + c);
+                    gv[i] = *(const f32x4*)(o.g + c); bv[i] = *(const f32x4*)(o.b + c);
+                    if (o.out3) { g2v[i] = *(const f32x4*)(o.g2 + c); b2v[i] = *(const f32x4*)(o.b2 + c); }
+                }
             }
-            chain_wave_ln(v, nv, D, lane, o.g, o.b, o.eps);
+            chain_wave_ln(v, nv, D, lane, gv, bv, o.eps);
 #pragma unroll
             for (int i = 0; i < CH_NV; ++i) {
                 const int c = (i * WAVE + lane) * 4;
@@ -1413,7 +1462,7 @@ __device__ __forceinline__ void chain_row_stage(const int op, const MadeChainRow
                 }
             }
             if (o.out3) {
-                chain_wave_ln(v, nv, D, lane, o.g2, o.b2, o.eps);
+                chain_wave_ln(v, nv, D, lane, g2v, b2v, o.eps);
 #pragma unroll
                 for (int i = 0; i < CH_NV; ++i) {
                     const int c = (i * WAVE + lane) * 4;
@@ -1449,26 +1498,66 @@ __device__ __forceinline__ void chain_row_stage(const int op, const MadeChainRow
 }
 
 __global__ __launch_bounds__(NTHREADS) void chain_kernel(const MadeChainStage* __restrict__ stages, const int n_stages, unsigned* barrier,
-                                                         const unsigned barrier_base) {
+                                                         const unsigned barrier_base, unsigned long long* stamps) {
     __shared__ __attribute__((aligned(16))) float Ct[4 * T_BM * T_CT_LD];
+    // profiling aid (made_chain_debug_stamps): workgroup 0 writes s_memtime at stage start / work done / release done / barrier passed
+    auto stamp = [&](int s, int k) __attribute__((always_inline)) {
+        if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[s * 4 + k] = __builtin_readcyclecounter();
+    };
+    // The stage descriptors are read through LDS, the next one copied in while this workgroup waits at the barrier: read from global
+    // memory at the start of its stage, a descriptor is two dependent round trips (~1.3 us each right after the acquire) before
+    // the first operand load can even be addressed.
+    __shared__ __attribute__((aligned(16))) MadeChainStage sst[2];
+    constexpr int ST_WORDS = (int)(sizeof(MadeChainStage) / 4);
+    static_assert(sizeof(MadeChainStage) % 4 == 0 && ST_WORDS <= 2 * NTHREADS, "descriptor copy");
+    auto fetch_stage = [&](int s) __attribute__((always_inline)) {
+        const uint32_t* src = (const uint32_t*)(stages + s);
+        uint32_t* dst = (uint32_t*)&sst[s & 1];
+        for (int i = threadIdx.x; i < ST_WORDS; i += NTHREADS) dst[i] = src[i];
+    };
+    fetch_stage(0);
+    __syncthreads();
+    bf16x8 fwp[2][T_CH];                                       // the next Linear stage's first weight fragments (this workgroup's first tile)
+    bool have_pre = false;
     for (int s = 0; s < n_stages; ++s) {
-        const MadeChainStage& st = stages[s];
+        const MadeChainStage& st = sst[s & 1];
+        stamp(s, 0);
         if (st.op == MADE_CHAIN_LINEAR) {
             const MadeLinearArgs& a = st.lin;
             const int tiles = (int)(((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN));
             const int total = tiles * (int)a.batch;
             for (int t = blockIdx.x; t < total; t += gridDim.x) {
-                linear_tiny_body<true>(a, t % tiles, t / tiles, Ct);
+                if (have_pre && t == (int)blockIdx.x) linear_tiny_body<true, true>(a, t % tiles, t / tiles, Ct, fwp);
+                else linear_tiny_body<true>(a, t % tiles, t / tiles, Ct);
                 __syncthreads();                                   // Ct is reused by the next tile
             }
         } else {
             chain_row_stage(st.op, st.row);
         }
+        __syncthreads();
+        stamp(s, 1);
         if (s + 1 < n_stages) {
             // ---- grid barrier.  Release: every wave's stores must have left for memory before the workgroup signs in; acquire:
             // the other XCDs' results are fetched past this XCD's caches afterwards.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
+            stamp(s, 2);
+            fetch_stage(s + 1);                                    // (the other buffer: this stage's readers are past the __syncthreads above)
+            __syncthreads();
+            {
+                // the next stage's WEIGHTS do not depend on this one: request this workgroup's first fragments now, they arrive
+                // while it waits for the others
+                const MadeChainStage& nx = sst[(s + 1) & 1];
+                have_pre = false;
+                if (nx.op == MADE_CHAIN_LINEAR) {
+                    const MadeLinearArgs& na = nx.lin;
+                    const int ntiles = (int)(((na.M + T_BM - 1) / T_BM) * ((na.N + T_BN - 1) / T_BN));
+                    if ((int)blockIdx.x < ntiles * (int)na.batch) {
+                        linear_tiny_prefetch_w(na, blockIdx.x % ntiles, blockIdx.x / ntiles, fwp);
+                        have_pre = true;
+                    }
+                }
+            }
             if (threadIdx.x == 0) {
                 __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned target = barrier_base + (unsigned)(s + 1) * gridDim.x;
@@ -1476,6 +1565,7 @@ __global__ __launch_bounds__(NTHREADS) void chain_kernel(const MadeChainStage* _
             }
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            stamp(s, 3);
         }
     }
     // the last stage's count keeps `barrier` at base + n_stages * gridDim.x whatever n_stages is
@@ -1646,6 +1736,10 @@ extern "C" int made_chain_linear_ok(const MadeLinearArgs* args) {
     return MADE_OK;
 }
 
+static unsigned long long* g_chain_stamps = nullptr;
+// profiling aid: the next made_chain launches write 4 cycle stamps per stage (workgroup 0) into `stamps` (device, >= 4 * n_stages words)
+extern "C" int made_chain_debug_stamps(uint64_t* stamps) { g_chain_stamps = (unsigned long long*)stamps; return MADE_OK; }
+
 extern "C" int made_chain(const MadeChainStage* stages_device, int32_t n_stages, int32_t n_workgroups, uint32_t* barrier,
                           uint32_t barrier_base, void* stream) {
     MADE_REQUIRE(stages_device && barrier, "made_chain: null pointer");
@@ -1653,6 +1747,6 @@ extern "C" int made_chain(const MadeChainStage* stages_device, int32_t n_stages,
     // every workgroup must be resident at once (they wait for each other): one per CU at most, far below the 256 CUs
     MADE_REQUIRE(n_workgroups >= 1 && n_workgroups <= 128, "made_chain: n_workgroups=%d out of [1, 128]", n_workgroups);
     hipLaunchKernelGGL(chain_kernel, dim3((unsigned)n_workgroups), dim3(NTHREADS), 0, (hipStream_t)stream, stages_device, (int)n_stages, barrier,
-                       barrier_base);
+                       barrier_base, g_chain_stamps);
     return made_check_launch("made_chain");
 }

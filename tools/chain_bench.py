@@ -57,3 +57,27 @@ for nwg in (16, 32, 64, 128):
         with ops.ChainRecorder(state, dev):
             program()
     print(f"made_chain, {nwg} workgroups: {timeit(chained):.1f} us")
+
+# ---- where a stage's time goes (workgroup 0's cycle stamps; 16 workgroups)
+from mgsv_amd import _lib
+ops.ChainRecorder.N_WG = 16
+stamps = torch.zeros(4 * 14 * NL + 64, dtype=torch.int64, device=dev)
+state = {}
+def chained_one():
+    with ops.ChainRecorder(state, dev):
+        program()
+for _ in range(3): chained_one()
+torch.cuda.synchronize()
+_lib.lib().made_chain_debug_stamps(stamps.data_ptr())
+chained_one()
+torch.cuda.synchronize()
+_lib.lib().made_chain_debug_stamps(None)
+st = stamps.cpu().numpy().reshape(-1, 4)[:14 * NL]
+names = ["v", "gate", "sa_out", "ln1+add", "q", "q'fold(z=8)", "vproj(z=8)", "head_bias", "ca_out", "ln2", "ff1", "ff2", "ln3+add", "norm"]
+import numpy as np
+work = (st[:, 1] - st[:, 0]).reshape(NL, 14)[1:].mean(0)
+rel = (st[:, 2] - st[:, 1]).reshape(NL, 14)[1:].mean(0)
+bar = (st[:, 3] - st[:, 2]).reshape(NL, 14)[1:].mean(0)
+print("cycles per stage (workgroup 0): work / release fence / barrier + acquire")
+for n, w, r, b in zip(names, work, rel, bar):
+    print(f"  {n:12s} {w:8.0f} {r:8.0f} {b:8.0f}")
