@@ -25,12 +25,12 @@ def graph():
 def timeit(f, n=40):
     for _ in range(5): f()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.thread_time()
     for _ in range(n): f()
-    cpu = time.perf_counter() - t0
+    wall_issue, busy = time.perf_counter() - t0, time.thread_time() - c0       # busy: CPU time of THIS thread (a blocked launch does not count)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3, cpu / n * 1e3
+    return (time.perf_counter() - t0) / n * 1e3, wall_issue / n * 1e3, busy / n * 1e3
 for r in range(3):
-    e, ec = timeit(eager)
-    gr, gc = timeit(graph)
-    print(f"round {r}: eager {e:.3f} ms/step (host issue {ec:.3f}), graph {gr:.3f} ms/step (host issue {gc:.3f})")
+    e, ec, eb = timeit(eager)
+    gr, gc, gb = timeit(graph)
+    print(f"round {r}: eager {e:.3f} ms/step (issue loop {ec:.3f} ms wall, {eb:.3f} ms of CPU), graph {gr:.3f} ms/step (issue loop {gc:.3f} ms wall, {gb:.3f} ms of CPU)")
