@@ -1154,9 +1154,11 @@ class MadeTrainer(MadeEngine):
                 ops.linear(dq2[:, :D], Win[D:D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
                            segs=[Seg(out=g_qc, ldo=D, out_z_stride=hd)])
                 # qc = W_q (t1 + qp) + b_q
-                dt1q = ops.linear(g_qc, Wt[:, :D], None, out=g4)
+                # dt1 = residual path + query path in the Linear's epilogue; the query path alone (the pre-residual value) is kept for
+                # the query embedding's gradient
+                ops.linear(g_qc, Wt[:, :D], None, out=g1, R=g2, Zout=g4)
+                dt1q = g4
                 tr.colsum(dt1q.view(B, Q * D), G["query_embed"].view(-1))
-                tr.add3(g1, g2, dt1q)                             # dt1 = residual path + query path
                 # t1 = LN1(tgt + drop1(self-attention))
                 tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
                                  dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
