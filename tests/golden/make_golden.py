@@ -228,6 +228,51 @@ def train_fixture(cfg: MadeConfig, B: int, T_v: int, T_a: int, name: str, cfg_ov
     print("wrote", name, len(fix), "entries")
 
 
+TRAIN_VARIANTS = {   # round-2 training variants: overrides on cfg_native, B = 3, T_v = 20, T_a = 40
+    "cls": {"with_cls_token": 1},
+    "mlp": {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_depth": 0, "max_v_frames": 20, "max_snippet_num": 40},
+    "tower2": {"vmr_fusion": "XA-video-music", "vmr_loss": "single"},
+    "xpool_query": {"moment_query_type": "xpool"},
+    "feature_fuse": {"vmr_loss": "dual_single_feature_fuse"},
+}
+
+
+def train_variants_fixture(seed: int = 1234, sample: int = 48):
+    """The reference's train()-mode losses and float64 parameter gradients (norm + a strided sample per parameter) for the
+    round-2 training variants, one file; for the mlp aggregator also its BatchNorm buffers after the step."""
+    from oracle import made_oracle as O
+    from oracle.validate_against_reference import _RecordingDrop
+    fix = dict(meta_B=3, meta_T_v=20, meta_T_a=40, meta_dropout_seed=seed, meta_sample=sample)
+    for tag, ov in TRAIN_VARIANTS.items():
+        cfg = cfg_native()
+        for k, v in ov.items():
+            setattr(cfg, k, v)
+        sd = synth.make_state_dict(cfg, seed=0)
+        inp = synth.make_inputs(cfg, 3, 20, 40, seed=1)
+        ref = ref_import.build_reference_model(cfg, sd).double()
+        P = {k: (v.double() if v.is_floating_point() else v) for k, v in O.to_torch_params(sd).items()}
+        drop = _RecordingDrop(seed)
+        drop.p_detr = cfg.detr_dropout
+        with torch.no_grad():
+            O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"],
+                      inp["spans_target"], v_duration=inp["v_duration"], drop=drop)
+        lm, grads = ref_import.reference_grads(ref, inp, True, schedule=drop.calls, seed=seed, dtype=torch.float64)
+        fix[f"{tag}.overrides"] = np.array(repr(sorted(ov.items())))
+        fix[f"{tag}.retrieval_loss"] = np.float64(lm["retrieval_loss"].detach())
+        fix[f"{tag}.localization_loss"] = np.float64(lm["localization_loss"].detach())
+        for n, g in grads.items():
+            flat = g.reshape(-1).numpy()
+            step = max(1, flat.size // sample)
+            fix[f"{tag}.gnorm.{n}"] = np.float64(np.sqrt((flat ** 2).sum()))
+            fix[f"{tag}.gsample.{n}"] = flat[::step][:sample].astype(np.float32)
+        for k, v in ref.state_dict().items():
+            if k.endswith((".running_mean", ".running_var")):
+                fix[f"{tag}.buffer.{k}"] = v.double().numpy()
+        print("variant", tag, len(grads), "gradients")
+    np.savez_compressed(os.path.join(HERE, "train_variants_B3.npz"), **fix)
+    print("wrote train_variants_B3", len(fix), "entries")
+
+
 def metrics_fixture():
     """Evaluation metrics of the reference's drivers on seeded inputs (utils/util_test.py, music_detr/span_utils.py)."""
     import argparse
@@ -283,9 +328,12 @@ def main():
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "bench_shapes":
         return bench_shape_fixtures()
+    if len(sys.argv) > 1 and sys.argv[1] == "train_variants":
+        return train_variants_fixture()
     variants_fixture()
     metrics_fixture()
     train_fixture(cfg_native(), 3, 20, 40, "train_native_B3", {})
+    train_variants_fixture()
     forward_fixture(cfg_plumbing(), 2, 30, 200, "forward_cfg1_B2", {})
     c = cfg_native(); c.num_moment_queries = 3
     forward_fixture(c, 4, 50, 96, "forward_native_Q3_B4", {"num_moment_queries": 3})

@@ -236,3 +236,46 @@ def test_option_variants_match_reference_fixture(golden_dir, name):
            if k in ("pred_logits", "pred_spans", "proj_queries", "moment_feats", "video_feats", "music_feats")}
     got.update(retrieval_loss=r["retrieval_loss"], localization_loss=r["localization_loss"], loss_dict=r["loss_dict"])
     check_variant(fix, name, got, tol=2e-5)
+
+
+TRAIN_VARIANT_TAGS = ["cls", "mlp", "tower2", "xpool_query", "feature_fuse"]
+
+
+def _variant_setup(fix, tag):
+    cfg = cfg_native()
+    for k, v in ast.literal_eval(str(fix[f"{tag}.overrides"])):
+        setattr(cfg, k, v)
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"]), seed=1)
+    names = [k[len(tag) + 7:] for k in fix.files if k.startswith(tag + ".gnorm.")]
+    return cfg, sd, inp, names
+
+
+@pytest.mark.parametrize("tag", TRAIN_VARIANT_TAGS)
+def test_oracle_train_variants_match_reference_fixture(golden_dir, tag):
+    """Round-2 training variants (CLS token, mlp aggregator with train-mode BatchNorm, second X-Pool tower, xpool query, feature fuse):
+    float64 oracle autograd in train mode == the reference's (tests/golden/train_variants_B3.npz, made by make_golden.py with the
+    reference's dropout replaced by the build's masks), and the BatchNorm running buffers after the step."""
+    fix = _load(golden_dir, "train_variants_B3")
+    cfg, sd, inp, names = _variant_setup(fix, tag)
+    P = {k: (v.double() if v.is_floating_point() else v) for k, v in O.to_torch_params(sd).items()}
+    for n in names:
+        P[n].requires_grad_(True)
+    r = O.forward(P, cfg, inp["frame_feats"], inp["segment_feats"], inp["frame_masks"], inp["segment_masks"], inp["spans_target"],
+                  v_duration=inp["v_duration"], drop=O.Drop(int(fix["meta_dropout_seed"]), p_detr=cfg.detr_dropout))
+    (r["retrieval_loss"] + r["localization_loss"]).backward()
+    assert abs(float(r["retrieval_loss"]) - float(fix[f"{tag}.retrieval_loss"])) < 1e-6
+    assert abs(float(r["localization_loss"]) - float(fix[f"{tag}.localization_loss"])) < 1e-6
+    assert len(names) > 150
+    sample = int(fix["meta_sample"])
+    for n in names:
+        g = (P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])).reshape(-1).numpy()
+        step = max(1, g.size // sample)
+        ref = fix[f"{tag}.gsample.{n}"].astype(np.float64)
+        nr = float(fix[f"{tag}.gnorm.{n}"])
+        assert np.abs(g[::step][:sample] - ref).max() <= 1e-5 * max(float(np.abs(ref).max()), 1e-4) + 1e-9, n
+        assert abs(np.sqrt((g ** 2).sum()) - nr) <= 1e-5 * max(nr, 1e-4), n
+    bufs = [k for k in fix.files if k.startswith(tag + ".buffer.")]
+    assert (len(bufs) == 8) == (tag == "mlp")
+    for k in bufs:
+        assert np.abs(r["buffer_updates"][k[len(tag) + 8:]].numpy() - fix[k]).max() < 1e-9, k

@@ -325,3 +325,33 @@ def test_chained_decoder_stages_leave_the_step_bit_identical(monkeypatch):
     assert len(trn._chain_fwd["cache"]) >= 2                  # stage lists were recorded and uploaded (once)
     for got in res["1"]:
         assert torch.equal(got[0], res["0"][0][0]) and torch.equal(got[1], res["0"][0][1]) and got[2] == res["0"][0][2]
+
+
+@pytest.mark.parametrize("tag", ["cls", "mlp", "tower2", "xpool_query", "feature_fuse"])
+def test_f32_variant_gradients_match_reference_fixture(golden_dir, tag):
+    """The round-2 training variants straight against the reference's own train()-mode autograd (float64 fixture
+    tests/golden/train_variants_B3.npz): losses, every parameter gradient's norm and a strided sample, the BatchNorm buffers."""
+    import ast
+    from mgsv_amd.trainer import MadeTrainer
+    fix = np.load(os.path.join(golden_dir, "train_variants_B3.npz"))
+    ov = dict(ast.literal_eval(str(fix[f"{tag}.overrides"])))
+    cfg, sd, inp = _setup(int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"]), ov)
+    trn = MadeTrainer(cfg, sd, dtype="f32")
+    res = trn.loss_and_grads(inp, seed=int(fix["meta_dropout_seed"]))
+    assert abs(res["retrieval_loss"] - float(fix[f"{tag}.retrieval_loss"])) <= 1e-4
+    assert abs(res["localization_loss"] - float(fix[f"{tag}.localization_loss"])) <= 2e-4
+    names = [k[len(tag) + 7:] for k in fix.files if k.startswith(tag + ".gnorm.")]
+    sample = int(fix["meta_sample"])
+    gmax = max(float(fix[f"{tag}.gnorm.{n}"]) / np.sqrt(res["grads"][n].size) for n in names)
+    for n in names:
+        g = res["grads"][n].reshape(-1).astype(np.float64)
+        nr = float(fix[f"{tag}.gnorm.{n}"])
+        if nr < 1e-6 * gmax * np.sqrt(g.size):
+            continue
+        assert abs(np.linalg.norm(g) - nr) <= 2e-3 * nr, (tag, n)
+        step = max(1, g.size // sample)
+        ref = fix[f"{tag}.gsample.{n}"].astype(np.float64)
+        assert np.linalg.norm(g[::step][:sample] - ref) <= 5e-3 * max(np.linalg.norm(ref), 1e-3 * nr), (tag, n)
+    now = trn.state_dict_numpy()
+    for k in [k for k in fix.files if k.startswith(tag + ".buffer.")]:
+        assert np.abs(now[k[len(tag) + 8:]] - fix[k]).max() <= 1e-5 * max(1.0, np.abs(fix[k]).max()), k
