@@ -656,7 +656,7 @@ class MadeTrainer(MadeEngine):
         tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
         hs = ws["hs"]
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
-        n_split = max(1, min(8, 256 // max(B, 1)))           # few queries, long memory: keys split over workgroups
+        n_split = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))   # few queries, long memory: keys split over workgroups (knob for measurements)
         fused = self._dec_fused(B, L)
         if fused:
             # one moment query: every sample's chain through the six layers is independent -- one workgroup per sample walks the
