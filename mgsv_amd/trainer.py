@@ -445,7 +445,7 @@ class MadeTrainer(MadeEngine):
             dfus=E(rows, D),
             # decoder (rows = B*Q)
             s_raw=E(B * HQ, dtype=f32), dds_raw=E(B * HQ, dtype=f32), gq_raw=E(B, HQ, D),
-            d_tq0=E(B * Q, D), GQ=Z(B, 2, nd, HQ, D), PdS=Z(B, 2, nd, HQ, Lp), dS_S=E(B * HQ, Lp, dtype=f32), dS_dP=E(B * HQ, Lp, dtype=f32),
+            d_tq0=E(B * Q, D), GQ=Z(B, 2, nd, HQ, D), PdS=Z(B, 2, nd, HQ, Lp), dS_S=E(nd, B * HQ, Lp, dtype=f32), dS_dP=E(B * HQ, Lp, dtype=f32),
             dSt=E(B, L, HQ), d_ds=E(B * Q, H, dtype=f32), d_delta=E(B * H * Q, dtype=f32),
             dg1=E(B * Q, D), dg2=E(B * Q, D), dg3=E(B * Q, D), dg4=E(B * Q, D), dgqkv=E(B * Q, 3 * D), dgffn=E(B * Q, Fd),
             dgq=E(B, HQ, D), dtgt=E(B * Q, D), dhs=E(nd * B * Q, D),
@@ -1109,6 +1109,11 @@ class MadeTrainer(MadeEngine):
             ca_scale = 1.0 / math.sqrt(hd)
             st = tw["dstack"]
             dtgt = None
+            # the scores of every layer's memory-space attention depend on forward values only (q', memory + pos): ONE batched
+            # product for all layers ([nd, B, H*Q, L] rows) ahead of the dependent chain instead of one launch inside every layer
+            S_all = tw["dS_S"]
+            ops.linear(GQ[0, 1].reshape(nd * HQ, D), mempos3[0], None, M=nd * HQ, N=L, K=D, batch=B, a_z_stride=GQ.stride(0), w_z_stride=L * D,
+                       segs=[Seg(out=S_all, ldo=Lp, rows_per_batch=HQ, out_batch_stride=B * HQ * Lp, out_z_stride=HQ * Lp)])
             for l in range(nd - 1, -1, -1):
                 p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
                 g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
@@ -1136,9 +1141,7 @@ class MadeTrainer(MadeEngine):
                            segs=[Seg(out=dpooled, ldo=D, rows_per_batch=Q, out_batch_stride=dpooled.stride(0), out_z_stride=Q * D)])
                 # scores and dPd of the memory-space attention (few rows per sample: materialised)
                 qprime = GQ[:, 1, l]
-                S, dP = tw["dS_S"], tw["dS_dP"]
-                ops.linear(qprime[0], mempos3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=qprime.stride(0), w_z_stride=L * D,
-                           segs=[Seg(out=S, ldo=Lp, out_z_stride=HQ * Lp)])
+                S, dP = S_all[l], tw["dS_dP"]
                 ops.linear(dpooled[0], mem3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=dpooled.stride(0), w_z_stride=L * D,
                            segs=[Seg(out=dP, ldo=Lp, out_z_stride=HQ * Lp)])
                 tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=d_ds.view(-1),
