@@ -482,7 +482,7 @@ class MadeTrainer(MadeEngine):
                       t1q=E(nd, BQ, D), qc=E(nd, BQ, D), pooled=E(nd, BQ, H * D), attc=E(nd, BQ, D), t_b=E(nd, BQ, D), t2=E(nd, BQ, D),
                       h=E(nd, BQ, Fd), t_c=E(nd, BQ, D),
                       g_ffn=E(nd, BQ, D), g_z=E(nd, BQ, Fd), g_ca=E(nd, BQ, D), g_attc=E(nd, BQ, D), g_q=E(nd, B, HQ, D), g_qc=E(nd, BQ, D),
-                      g_sa=E(nd, BQ, D), g_qkv=E(nd, BQ, 3 * D))
+                      g_sa=E(nd, BQ, D), g_qkv=E(nd, BQ, 3 * D), dt1q=E(nd, BQ, D))
         ws["dstack"] = stacks
         ws["s_stack"] = E(nd, BQ, H, dtype=f32)               # sums of the dropped cross-attention weights, one row per (layer, query)
         for l in range(nd):
@@ -653,7 +653,8 @@ class MadeTrainer(MadeEngine):
             tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
         else:                                                # "zero" / "random": reference music_detr/transformer.py:73-74
             tgt.zero_()
-        tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
+        if Q > 1:                                            # (a single query's q / k projections are never formed: see the loop)
+            tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
         hs = ws["hs"]
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
         n_split = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))   # few queries, long memory: keys split over workgroups (knob for measurements)
@@ -1165,9 +1166,8 @@ class MadeTrainer(MadeEngine):
                 # qc = W_q (t1 + qp) + b_q
                 # dt1 = residual path + query path in the Linear's epilogue; the query path alone (the pre-residual value) is kept for
                 # the query embedding's gradient
-                ops.linear(g_qc, Wt[:, :D], None, out=g1, R=g2, Zout=g4)
-                dt1q = g4
-                tr.colsum(dt1q.view(B, Q * D), G["query_embed"].view(-1))
+                dt1q = st["dt1q"][l]                               # (summed over the batch into the query embedding's gradient after the loop)
+                ops.linear(g_qc, Wt[:, :D], None, out=g1, R=g2, Zout=dt1q)
                 # t1 = LN1(tgt + drop1(self-attention))
                 tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
                                  dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
@@ -1186,6 +1186,7 @@ class MadeTrainer(MadeEngine):
                     dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
                     tr.colsum(dqk.view(B, Q * D), G["query_embed"].view(-1))
             dtgt0 = dtgt                                          # gradient of the decoder's content query = the clip-level vector
+            tr.colsum(st["dt1q"].view(nd * B, Q * D), G["query_embed"].view(-1))     # every layer's query path at once
 
             # ---- weight gradients of all decoder layers: one layer-batched product per parameter (the layers' parameters, and
             # the [nd, ...] stacks, are equally spaced)
