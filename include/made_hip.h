@@ -134,7 +134,10 @@ typedef struct MadeLinearArgs {
     const void*  A;  int32_t a_dtype; int32_t w_dtype;
     int64_t      lda;
     const void*  A2; int64_t lda2; int64_t a2_row_mod;      /* A2 has a_dtype; may be NULL */
-    int32_t      a2_replace; int32_t _pad;                  /* 1: flagged segments read A2 INSTEAD of A (e.g. src+pos) */
+    int32_t      a2_replace;                                /* 1: flagged segments read A2 INSTEAD of A (e.g. src+pos) */
+    int32_t      drop_col_div;                              /* > 1: dropout draws once per `drop_col_div` columns -- element index
+                                                               row * drop_ld + col / drop_col_div (one attention-weight draw per head
+                                                               on the value path of a one-query self-attention); 0 / 1: per element */
     const float* a_row_mask;                                /* [M] or NULL */
     const void*  W;  int64_t ldw;
     const float* bias;                                      /* [N] f32 or NULL */

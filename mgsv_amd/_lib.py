@@ -31,7 +31,7 @@ class MadeLinearSeg(C.Structure):
 class MadeLinearArgs(C.Structure):
     _fields_ = [("A", vp), ("a_dtype", i32), ("w_dtype", i32), ("lda", i64),
                 ("A2", vp), ("lda2", i64), ("a2_row_mod", i64),
-                ("a2_replace", i32), ("_pad", i32),
+                ("a2_replace", i32), ("drop_col_div", i32),
                 ("a_row_mask", vp),
                 ("W", vp), ("ldw", i64),
                 ("bias", vp),

@@ -220,10 +220,17 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
     if (TRAIN && a.drop.p > 0.f) {
         const uint32_t thr = made_drop_threshold(a.drop.p);
         const float sc = 1.f / (1.f - a.drop.p);
-        const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
+        if (a.drop_col_div > 1) {                            // one draw per group of columns (per attention head): index row * drop_ld + col / div
+            const uint64_t rb = (uint64_t)m * (uint64_t)a.drop_ld;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+            for (int j = 0; j < 8; ++j)
+                v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, rb + (uint64_t)((n + j) / a.drop_col_div)) >> 8) >= thr ? v[j] * sc : 0.f;
+        } else {
+            const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+        }
     }
     if (a.R) {
         float rv[8];
@@ -1024,10 +1031,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void linear_ring_kernel(const Made
             if (a.drop.p > 0.f) {
                 const uint32_t thr = made_drop_threshold(a.drop.p);
                 const float sc = 1.f / (1.f - a.drop.p);
-                const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
+                if (a.drop_col_div > 1) {
+                    const uint64_t rb = (uint64_t)m * (uint64_t)a.drop_ld;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+                    for (int j = 0; j < 8; ++j)
+                        v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, rb + (uint64_t)((n + j) / a.drop_col_div)) >> 8) >= thr ? v[j] * sc : 0.f;
+                } else {
+                    const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+                }
             }
         }
         if (a.R) {

@@ -244,7 +244,7 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
            r_row_mod: int = 0, out_row_mask: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
            tile_skip_mask: Optional[Tensor] = None, batch: int = 1, a_z_stride: int = 0, w_z_stride: int = 0, M: Optional[int] = None,
            N: Optional[int] = None, K: Optional[int] = None, gate: int = 0, G: Optional[Tensor] = None, gate_scale: float = 1.0,
-           Zout: Optional[Tensor] = None, drop=None, drop_ld: Optional[int] = None, rows=None) -> Tensor:
+           Zout: Optional[Tensor] = None, drop=None, drop_ld: Optional[int] = None, rows=None, drop_col_div: int = 1) -> Tensor:
     """out = act(A' W^T + bias) (+R).  A [M,K] (row stride free, unit inner stride), W [N,K].
     Training extras: Zout receives the pre-activation; gate/G multiply by act'(G) * gate_scale; drop = (seed, site, p)
     applies the stateless dropout of include/made_hip.h after act/gate (element index row * drop_ld + col)."""
@@ -278,6 +278,7 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
         a.drop_ld = N if drop_ld is None else drop_ld
+        a.drop_col_div = int(drop_col_div)
     if rows is not None:                                      # row gather: (row_index int32 [M], n_rows int32 [1]) from row_index()
         a.row_index, a.n_rows = _p(rows[0]), _p(rows[1])
     if segs is None:

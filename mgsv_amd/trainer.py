@@ -676,9 +676,9 @@ class MadeTrainer(MadeEngine):
             if Q == 1:
                 # one query, one key: the softmax weight is 1, so the block is the value path; its attention-weight dropout is one
                 # draw per (sample, head) (element index (b*H + h)*1*1), and q / k get no gradient
+                # (the draw is the value Linear's epilogue: the undropped value itself is needed by nobody)
                 Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
-                ops.linear(tgt, Wsa[2 * D:], bsa[2 * D:], segs=[Seg(out=qkv[:, 2 * D:], ldo=qkv.stride(0))])
-                tr.gate_rows(qkv[:, 2 * D:], tw[d + ".att"], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+                ops.linear(tgt, Wsa[2 * D:], bsa[2 * D:], out=tw[d + ".att"], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
             else:
                 ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
                            segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
@@ -1171,11 +1171,12 @@ class MadeTrainer(MadeEngine):
                 # t1 = LN1(tgt + drop1(self-attention))
                 tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
                                  dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
-                datt = ops.linear(g_sa, P[p + ".sa.out.wt"], None, out=g4)
-                if Q == 1:                                        # value path only (see the forward): dv = datt under the same per-head mask
-                    tr.gate_rows(datt, gqkv[:, 2 * D:], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+                if Q == 1:                                        # value path only (see the forward): dv = datt under the same per-head mask,
+                    ops.linear(g_sa, P[p + ".sa.out.wt"], None, segs=[Seg(out=gqkv[:, 2 * D:], ldo=gqkv.stride(0))],       # drawn in the epilogue
+                               drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
                     dtgt = ops.linear(gqkv[:, 2 * D:], P[p + ".sa.in.wt"][:, 2 * D:], None, R=g2, out=tw["dtgt"])
                 else:
+                    datt = ops.linear(g_sa, P[p + ".sa.out.wt"], None, out=g4)
                     qkv = tw[d + ".qkv"]
                     q3, g3v = qkv.view(B, Q, 3 * D), gqkv.view(B, Q, 3 * D)
                     tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), datt.view(B, Q, D),
