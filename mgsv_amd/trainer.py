@@ -541,25 +541,28 @@ class MadeTrainer(MadeEngine):
         self._inputs = (frame_feats.contiguous(), segment_feats.contiguous(), fm, sm, spans_target.contiguous())
 
         fus, fus_mask = ws["fus"], ws["fus_mask"]
-        ops.concat_cols(fm if concat else None, sm, fus_mask)
-        # valid-token lists: every large GEMM (forward, dX and dW) gathers the valid rows only, so padding costs nothing
-        self._groups = {}
-        self._rows = {fus_mask.data_ptr(): ops.row_index(fus_mask, out=tw["rows_f"]), fm.data_ptr(): ops.row_index(fm, out=tw["rows_v"]),
-                      sm.data_ptr(): ops.row_index(sm, out=tw["rows_a"])}
-        rows_f = self._rows[fus_mask.data_ptr()]
-        # issue order of the attention workgroups: longest sample first (a padded batch otherwise waits on whichever long sample
-        # happens to start last)
-        self._order = {fus_mask.data_ptr(): ops.batch_order(fus_mask, out=tw["order_f"]), fm.data_ptr(): ops.batch_order(fm, out=tw["order_v"]),
-                       sm.data_ptr(): ops.batch_order(sm, out=tw["order_a"])}
-        # the video branch (B*T_v rows: launches far smaller than the chip) runs on a second HIP stream beside the audio branch;
+        # valid-token lists: every large GEMM (forward, dX and dW) gathers the valid rows only, so padding costs nothing; issue order of
+        # the attention workgroups: longest sample first (a padded batch otherwise waits on whichever long sample happens to start
+        # last).  These are single-workgroup scans of ~10 us each at the very head of the step: only the audio branch's two stay on the
+        # main stream, the other five (+ the position embedding) go to the second stream with the video branch.
+        # The video branch (B*T_v rows: launches far smaller than the chip) runs on a second HIP stream beside the audio branch;
         # so does the X-Pool / similarity / retrieval-loss branch beside the DETR stack (joined at the end of the step)
+        self._groups = {}
         cur, side = torch.cuda.current_stream(), self._side_stream()
         side.wait_stream(cur)
+        self._rows = {sm.data_ptr(): ops.row_index(sm, out=tw["rows_a"])}
+        self._order = {sm.data_ptr(): ops.batch_order(sm, out=tw["order_a"])}
         with torch.cuda.stream(side):
+            ops.concat_cols(fm if concat else None, sm, fus_mask)
+            self._rows[fm.data_ptr()] = ops.row_index(fm, out=tw["rows_v"])
+            self._order[fm.data_ptr()] = ops.batch_order(fm, out=tw["order_v"])
+            self._rows[fus_mask.data_ptr()] = ops.row_index(fus_mask, out=tw["rows_f"])
+            self._order[fus_mask.data_ptr()] = ops.batch_order(fus_mask, out=tw["order_f"])
             pos = ops.sine_pe(fus_mask, P["dim_t"], out=ws["pos"])
             self._encode_train(self._inputs[0], fm, "video", ws, tw, 0)
         self._encode_train(self._inputs[1], sm, "audio", ws, tw, Tv)
         cur.wait_stream(side)
+        rows_f = self._rows[fus_mask.data_ptr()]
         if concat:
             frame, seg = fus[:, :Tv], fus[:, Tv:]
         else:
