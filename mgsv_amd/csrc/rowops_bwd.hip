@@ -548,6 +548,63 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
     const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t base = (uint64_t)row * (uint64_t)a.L;
+    const int64_t z = row / a.rpb, i = row % a.rpb;
+    constexpr int SM_MAXC = 17;                              // rows of up to 1088 keys live in registers: ONE pass over S / dP / mask
+    if (a.L <= 64 * SM_MAXC) {
+        // (the three-pass form below reads S, dP and the mask with conditional 4-byte loads three times over: ~20 us for a 542-key row
+        // of the decoder's memory-space attention, all of it latency)
+        const int L = (int)a.L, nch = (L + 63) >> 6;
+        float sv[SM_MAXC], gv[SM_MAXC];
+        uint32_t okbits = 0;
+#pragma unroll
+        for (int c = 0; c < SM_MAXC; ++c) {
+            if (c < nch) {
+                const int k = c * 64 + lane, kc = k < L ? k : L - 1;          // unconditional loads from a clamped index
+                sv[c] = s[kc]; gv[c] = g[kc];
+                const float m = mk ? mk[kc] : 1.f;
+                okbits |= (k < L && m != 0.f) ? (1u << c) : 0u;
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < SM_MAXC; ++c)
+            if (c < nch) mx = fmaxf(mx, (okbits >> c) & 1u ? sv[c] * a.scale : -INFINITY);
+        mx = wave_max(mx);
+        float se = 0.f, dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < SM_MAXC; ++c) {
+            if (c < nch) {
+                const bool ok = (okbits >> c) & 1u;
+                const float p = ok ? expf(sv[c] * a.scale - mx) : 0.f;
+                float dp = ok ? gv[c] + ex : 0.f;              // masked keys may hold stale (non-finite) products: never touch them
+                bool kp = true;
+                if (a.drop.p > 0.f) { kp = keep_at(drop_seed, a.drop.site, thr, base + (uint64_t)(c * 64 + lane)); dp = kp ? dp * dsc : 0.f; }
+                se += p; dot += p * dp;
+                sv[c] = p; gv[c] = dp;
+                okbits = kp ? okbits : (okbits & ~(1u << c));  // (bit c now: the key is valid AND kept)
+            }
+        }
+        se = wave_sum(se); dot = wave_sum(dot);
+        const float inv = 1.f / se;
+        dot *= inv;
+#pragma unroll
+        for (int c = 0; c < SM_MAXC; ++c) {
+            const int k = c * 64 + lane;
+            if (k < a.ldo) {
+                float pd = 0.f, ds = 0.f;
+                if (c < nch && k < L) {
+                    const float p = sv[c] * inv;
+                    pd = (okbits >> c) & 1u ? p * dsc : 0.f;  // dropped (or masked: p == 0) keys carry no weight
+                    if (!(a.drop.p > 0.f)) pd = p;
+                    ds = a.scale * p * (gv[c] - dot);
+                }
+                store_from_f32(a.Pd, a.odt, z * a.obs + i * a.ldo + k, pd);
+                store_from_f32(a.dS, a.odt, z * a.obs + i * a.ldo + k, ds);
+                if (a.dSt && k < L) store_from_f32(a.dSt, a.odt, z * a.tbs + (int64_t)k * a.ldt + i, ds);
+            }
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int64_t k = lane; k < a.L; k += 64) {
         const bool ok = mk == nullptr || mk[k] != 0.f;
@@ -565,7 +622,6 @@ __global__ __launch_bounds__(RT) void softmax_bwd_kernel(const SmBwdArgs a) {
     se = wave_sum(se); dot = wave_sum(dot);
     const float inv = 1.f / se;
     dot *= inv;
-    const int64_t z = row / a.rpb, i = row % a.rpb;
     for (int64_t k = lane; k < a.ldo; k += 64) {
         float pd = 0.f, ds = 0.f;
         if (k < a.L) {
