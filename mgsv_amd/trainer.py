@@ -36,6 +36,11 @@ Tensor = torch.Tensor
 XA = "video_guided_to_music_pooling_cross_transformer"
 
 
+# The two-column heads (class logits, span) hand a [rows, 2] gradient back through W^T: as a K = 2 product it falls to the general
+# kernel (18.5 us on the backward's critical path, twice); zero-padded to K = 64 it is a tiny-M MFMA launch like its neighbours.
+HEAD_PAD = 64
+
+
 class MadeTrainer(MadeEngine):
     def __init__(self, cfg: MadeConfig, state_dict: Dict[str, object], device="cuda:0", dtype: str = "f32"):
         super().__init__(cfg, state_dict, device, dtype)
@@ -270,7 +275,7 @@ class MadeTrainer(MadeEngine):
                 wt = None
                 if key not in ("query_embed", "vit_proj.w", "ast_proj.w"):
                     base = key[:-2] if key.endswith(".w") else key
-                    wt = torch.zeros(cols, max(rows, 8), device=dev, dtype=tc)     # tiny heads (N = 2): reduction dim zero-padded to 8
+                    wt = torch.zeros(cols, max(rows, HEAD_PAD), device=dev, dtype=tc)  # tiny heads (N = 2): reduction dim zero-padded (see HEAD_PAD)
                     P[base + ".wt"] = wt
                 if w is None and wt is None:
                     continue
@@ -451,7 +456,7 @@ class MadeTrainer(MadeEngine):
             dgq=E(B, HQ, D), dtgt=E(B * Q, D), dhs=E(nd * B * Q, D),
             # heads
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D), hg1=E(nd * B * Q, D), hg2=E(nd * B * Q, D),
-            dlog=Z(nd * B * Q, 8, dtype=f32), dsp=Z(nd * B * Q, 8, dtype=f32), dlog_c=Z(nd * B * Q, 8), dsp_c=Z(nd * B * Q, 8),
+            dlog=Z(nd * B * Q, HEAD_PAD, dtype=f32), dsp=Z(nd * B * Q, HEAD_PAD, dtype=f32), dlog_c=Z(nd * B * Q, HEAD_PAD), dsp_c=Z(nd * B * Q, HEAD_PAD),
         )
         if "video" in c.vmr_fusion:                             # second X-Pool tower: music vectors attend to the frames ("y" = "x" with S = T_v)
             Svp = round_up(Tv, 8)
@@ -1076,7 +1081,7 @@ class MadeTrainer(MadeEngine):
                 tw["dvid_sum"].zero_()
             tr.set_criterion_bwd(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"], c.foreground_label, P["crit_weights"], g_loc,
                                  tw["dlog"], tw["dsp"], tw["dpq"] if pq is not None else None, tw["dvid_sum"] if pq is not None else None,
-                                 ld_out=8, through_sigmoid=True)
+                                 ld_out=HEAD_PAD, through_sigmoid=True)
             hs2 = ws["hs"].view(nd * B * Q, D)
             dhs = tw["dhs"]
             dlog, dsp = tw["dlog"], tw["dsp"]
@@ -1338,7 +1343,7 @@ class MadeTrainer(MadeEngine):
         g = torch.sign(spans - tg.view(B, 2)) * scale
         if g_loc is not None:
             g = g * g_loc.to(torch.float32).view(())
-        dz = torch.zeros(B, 8, device=self.device, dtype=self.tc)  # through the sigmoid; reduction dim padded like reg_mlp.2.wt
+        dz = torch.zeros(B, HEAD_PAD, device=self.device, dtype=self.tc)  # through the sigmoid; reduction dim padded like reg_mlp.2.wt
         dz[:, :n] = (g * spans * (1.0 - spans))[:, :n].to(self.tc)
         tr.gemm_tn(dz[:, :n], h2, G["reg_mlp.2.w"], accumulate=True, colsum=G["reg_mlp.2.b"])
         dh2 = ops.linear(dz, P["reg_mlp.2.wt"], None, out=torch.empty_like(h2), gate=_lib.GATE_RELU_OUT, G=h2)
