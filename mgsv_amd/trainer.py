@@ -667,7 +667,7 @@ class MadeTrainer(MadeEngine):
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
         n_split = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))   # few queries, long memory: keys split over workgroups (knob for measurements)
         fused = self._dec_fused(B, L)
-        fused_hs = tw["dstack"]["tgt"][1:]                   # [nd, B*Q, D]: slot l + 1 = layer l's output (t3)
+        t3_stack = tw["dstack"]["tgt"][1:]                   # [nd, B*Q, D]: slot l + 1 = layer l's output (t3)
         if fused:
             # one moment query: every sample's chain through the six layers is independent -- one workgroup per sample walks the
             # whole stack in ONE launch (made_dec_train_fwd) and fills the same stacks the launches below fill
@@ -722,12 +722,10 @@ class MadeTrainer(MadeEngine):
                 ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t3, tw[f"d.{l + 1}.tq"])
             else:
                 ops.layernorm(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], out=t3)
-            if fused_hs is None:
-                ops.layernorm(t3, P["dec.norm.g"], P["dec.norm.b"], out=hs[l])
-        if fused_hs is not None and not fused:
+        if not fused:
             # the shared output norm of every layer feeds the heads only, not the next layer: one launch over the [nd, B*Q] stack
             # of layer outputs after the chain instead of one inside every layer
-            ops.layernorm(fused_hs.reshape(nd * B * Q, D), P["dec.norm.g"], P["dec.norm.b"], out=hs.view(nd * B * Q, D))
+            ops.layernorm(t3_stack.reshape(nd * B * Q, D), P["dec.norm.g"], P["dec.norm.b"], out=hs.view(nd * B * Q, D))
         out["hs"] = hs.view(nd, B, Q, D)
 
         # ---- heads
