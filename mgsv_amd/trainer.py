@@ -1193,10 +1193,22 @@ class MadeTrainer(MadeEngine):
                     dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
                     tr.colsum(dqk.view(B, Q * D), G["query_embed"].view(-1))
             dtgt0 = dtgt                                          # gradient of the decoder's content query = the clip-level vector
-            tr.colsum(st["dt1q"].view(nd * B, Q * D), G["query_embed"].view(-1))     # every layer's query path at once
+            # gradient of the memory: values path (Pd^T dpooled) + keys path (dS^T q'), all layers in one product per sample -- the
+            # one thing the DETR encoder's backward waits for
+            dmem = tw["eg1"]
+            tr.gemm_tn(PdS.view(B, 2 * nd * HQ, Lp)[0, :, :L], GQ.view(B, 2 * nd * HQ, D)[0], dmem.view(B, L, D)[0], batch=(B, 1),
+                       a_zs=(PdS.stride(0), 0), b_zs=(GQ.stride(0), 0), c_zs=(L * D, 0))
 
             # ---- weight gradients of all decoder layers: one layer-batched product per parameter (the layers' parameters, and
-            # the [nd, ...] stacks, are equally spaced)
+            # the [nd, ...] stacks, are equally spaced).  Nothing on the main stream needs them before the optimizer: they go to the
+            # second stream (a dozen launches of modest size, ~0.35 ms of kernel time) and run beside the DETR encoder's backward;
+            # the join in front of grad_sync below covers them.
+            dw_side = os.environ.get("MADE_DEC_DW_SIDE", "1") != "0"       # (knob for A/B measurements)
+            if dw_side:
+                side.wait_stream(cur)
+            dec_dw = torch.cuda.stream(side if dw_side else cur)
+            dec_dw.__enter__()
+            tr.colsum(st["dt1q"].view(nd * B, Q * D), G["query_embed"].view(-1))     # every layer's query path at once
             p0, p1 = "detr_transformer.decoder.layers.0", "detr_transformer.decoder.layers.1"
             BQ = B * Q
 
@@ -1234,10 +1246,7 @@ class MadeTrainer(MadeEngine):
             gq2 = st["g_q"].view(nd, BQ, H * D)
             tr.gemm_tn(st["qc"][0][:, :hd], gq2[0][:, :D], gWin0[D:D + hd], accumulate=True, batch=(nd, H),
                        a_zs=(st["qc"].stride(0), hd), b_zs=(gq2.stride(0), D), c_zs=(ls, hd * D))
-            # gradient of the memory: values path (Pd^T dpooled) + keys path (dS^T q'), all layers in one product per sample
-            dmem = tw["eg1"]
-            tr.gemm_tn(PdS.view(B, 2 * nd * HQ, Lp)[0, :, :L], GQ.view(B, 2 * nd * HQ, D)[0], dmem.view(B, L, D)[0], batch=(B, 1),
-                       a_zs=(PdS.stride(0), 0), b_zs=(GQ.stride(0), 0), c_zs=(L * D, 0))
+            dec_dw.__exit__(None, None, None)
 
 
         # ---------------- DETR encoder
