@@ -1009,12 +1009,17 @@ class MadeTrainer(MadeEngine):
 
     def _lin_bwd(self, dz: Tensor, x: Tensor, key: str, *, dx_out: Optional[Tensor] = None, row_mask: Optional[Tensor] = None,
                  skip: Optional[Tensor] = None, gw: Optional[Tensor] = None, gb: Optional[Tensor] = None, wt: Optional[Tensor] = None,
-                 defer: Optional[list] = None, **kw) -> Optional[Tensor]:
-        """Linear backward: dW += dz^T x, db += colsum(dz), dx = dz W (with the epilogue options of ops.linear)."""
+                 defer: Optional[list] = None, later: Optional[list] = None, **kw) -> Optional[Tensor]:
+        """Linear backward: dW += dz^T x, db += colsum(dz), dx = dz W (with the epilogue options of ops.linear).
+        later: a list that receives the weight-gradient launch as a closure instead (the caller runs it when and where it likes --
+        dz and x must stay untouched until then)."""
         rows = self._rw(row_mask)                             # the mask's valid-row list: gather instead of masking
         gw_ = self.G[key + ".w"] if gw is None else gw
         gb_ = self.G.get(key + ".b") if gb is None else gb
-        if defer is not None and self._groupable(dz, x, gw_):
+        if later is not None:
+            later.append(lambda: tr.gemm_tn(dz, x, gw_, accumulate=True, colsum=gb_, row_mask=row_mask if rows is None else None,
+                                            row_groups=self._rg(row_mask), rows=rows))
+        elif defer is not None and self._groupable(dz, x, gw_):
             defer.append((dz, x, gw_, gb_))                   # launched with the layer's other weight gradients (_flush_dw): the caller
         else:                                                 # keeps dz and x untouched until then
             tr.gemm_tn(dz, x, gw_, accumulate=True, colsum=gb_,
@@ -1085,13 +1090,16 @@ class MadeTrainer(MadeEngine):
             dlog, dsp = tw["dlog"], tw["dsp"]
             if self.tc != torch.float32:                          # same dtype as the activations for the A^T B products
                 dlog, dsp = tr.add3(tw["dlog_c"], dlog), tr.add3(tw["dsp_c"], dsp)
-            tr.gemm_tn(dlog[:, :2], hs2, G["class_embed.w"], accumulate=True, colsum=G["class_embed.b"])
+            # the heads' weight gradients wait for nobody on the main stream: they are launched with the decoder's (second stream,
+            # after the loop below); their operands (dlog / dsp / hg1 / hg2 / h1 / h2 / hs) are not touched in between
+            heads_dw: list = []
+            heads_dw.append(lambda: tr.gemm_tn(dlog[:, :2], hs2, G["class_embed.w"], accumulate=True, colsum=G["class_embed.b"]))
             ops.linear(dlog, P["class_embed.wt"], None, out=dhs)
             n_span = 1 if c.predict_center == 1 else 2             # predict_center: the width column is a constant, its gradient is dropped
-            tr.gemm_tn(dsp[:, :n_span], tw["h2"], G["span_embed.2.w"], accumulate=True, colsum=G["span_embed.2.b"])
+            heads_dw.append(lambda: tr.gemm_tn(dsp[:, :n_span], tw["h2"], G["span_embed.2.w"], accumulate=True, colsum=G["span_embed.2.b"]))
             dz2 = ops.linear(dsp, P["span_embed.2.wt"], None, out=tw["hg1"], gate=_lib.GATE_RELU_OUT, G=tw["h2"])
-            dz1 = self._lin_bwd(dz2, tw["h1"], "span_embed.1", dx_out=tw["hg2"], gate=_lib.GATE_RELU_OUT, G=tw["h1"])
-            self._lin_bwd(dz1, hs2, "span_embed.0", dx_out=dhs, R=dhs)
+            dz1 = self._lin_bwd(dz2, tw["h1"], "span_embed.1", dx_out=tw["hg2"], gate=_lib.GATE_RELU_OUT, G=tw["h1"], later=heads_dw)
+            self._lin_bwd(dz1, hs2, "span_embed.0", dx_out=dhs, R=dhs, later=heads_dw)
             if c.contrastive_align_loss:
                 Dc = pq.shape[-1]
                 dn = tw["dpq"]
@@ -1106,7 +1114,7 @@ class MadeTrainer(MadeEngine):
                     dmusic.add_(tw["dpq_s"].view(nd, B, Q, D).sum((0, 2)))
                     dn = tw["dpq_s"]
                 tr.l2norm_bwd(ws["pq_raw"], dn, dx_alt=tw["dpq_raw"])
-                self._lin_bwd(tw["dpq_raw"], hs2, "proj_q", dx_out=dhs, R=dhs)
+                self._lin_bwd(tw["dpq_raw"], hs2, "proj_q", dx_out=dhs, R=dhs, later=heads_dw)
                 # proj_vid_mem: every frame (padded ones too) receives d vid_sum (reference loss_detr.py:118)
                 tr.l2norm_bwd(ws["pv_raw"], tw["dvid_sum"], dx_alt=tw["dpv_raw"], dy_rows_per=Tv)
                 tr.gemm_tn(tw["dpv_raw"][:Tv], frame[0], G["proj_v.w"], accumulate=True, colsum=G["proj_v.b"], batch=(B, 1),
@@ -1208,6 +1216,8 @@ class MadeTrainer(MadeEngine):
                 side.wait_stream(cur)
             dec_dw = torch.cuda.stream(side if dw_side else cur)
             dec_dw.__enter__()
+            for launch in heads_dw:
+                launch()
             tr.colsum(st["dt1q"].view(nd * B, Q * D), G["query_embed"].view(-1))     # every layer's query path at once
             p0, p1 = "detr_transformer.decoder.layers.0", "detr_transformer.decoder.layers.1"
             BQ = B * Q
