@@ -447,6 +447,9 @@ class MadeTrainer(MadeEngine):
             # DETR encoder
             e_delta=E(B * H * L, dtype=f32), eg1=E(rows, D), eg2=E(rows, D), eg2b=E(rows, D), eg3=E(rows, D), eg3b=E(rows, D), eg3c=E(rows, D),
             egqkv=E(rows, 3 * D), egffn=E(rows, Fd),
+            # a second set of the four gradients a layer's weight-gradient launch reads: that launch runs on the second stream while
+            # the next layer's backward (odd / even layers alternate between the sets) already writes its own
+            eg2b_2=E(rows, D), eg3_2=E(rows, D), egqkv_2=E(rows, 3 * D), egffn_2=E(rows, Fd),
             dfus=E(rows, D),
             # decoder (rows = B*Q)
             s_raw=E(B * HQ, dtype=f32), dds_raw=E(B * HQ, dtype=f32), gq_raw=E(B, HQ, D),
@@ -1261,10 +1264,17 @@ class MadeTrainer(MadeEngine):
 
         # ---------------- DETR encoder
         dsrc = dmem
+        enc_dw_side = os.environ.get("MADE_ENC_DW_SIDE", "1") != "0"         # (knob for A/B measurements)
+        enc_dw_done = [None, None]
         for l in range(ne - 1, -1, -1):
             p, e = f"detr_transformer.encoder.layers.{l}", f"e.{l}"
             # (every gradient that feeds a weight-gradient product keeps a buffer of its own until the layer's grouped launch)
             g2, g2b, g3, g3b, g3c, gq, gf = tw["eg2"], tw["eg2b"], tw["eg3"], tw["eg3b"], tw["eg3c"], tw["egqkv"], tw["egffn"]
+            if enc_dw_side:
+                if l & 1:
+                    g2b, g3, gq, gf = tw["eg2b_2"], tw["eg3_2"], tw["egqkv_2"], tw["egffn_2"]
+                if enc_dw_done[l & 1] is not None:               # (more than two layers: the set's previous weight-gradient launch)
+                    cur.wait_event(enc_dw_done[l & 1])
             pend: list = []
             src = fus.view(rows, D) if l == 0 else tw[e + ".src"]
             srcpos = tw[e + ".srcpos"]
@@ -1294,7 +1304,16 @@ class MadeTrainer(MadeEngine):
                 tr.gemm_tn(gq[:, 2 * D:], src, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], rows=self._rw(fskip))
             nxt = tw["dfus"] if dx is tw["eg1"] else tw["eg1"]
             dsrc = ops.linear(gq, P[p + ".in.wt"], None, R=dx, out=nxt, rows=self._rw(fskip))
-            self._flush_dw(pend, fskip)
+            if enc_dw_side:
+                # the layer's grouped weight-gradient launch (~170 us of MFMA work) needs nothing but this layer's gradients and
+                # nobody on the main stream needs it: second stream, beside the next layer's (bandwidth- and VALU-heavy) data chain
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._flush_dw(pend, fskip)
+                    enc_dw_done[l & 1] = torch.cuda.Event()
+                    enc_dw_done[l & 1].record(side)
+            else:
+                self._flush_dw(pend, fskip)
         dfus = dsrc.view(B, L, D)
         if concat:
             dl_v, dl_a = dfus[:, :Tv], dfus[:, Tv:]
