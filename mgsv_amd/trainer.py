@@ -580,9 +580,65 @@ class MadeTrainer(MadeEngine):
         video, music = ws["video"], ws["music"]
         out: Dict[str, Tensor] = dict(video_feats=video, music_feats=music, frame_feats=frame, segment_feats=seg)
 
+        # ---- the decoder's query side (defined here: layer 0's runs on the second stream beside the DETR encoder, see below)
+        qp = P["query_embed"]
+        hd = D // H
+        ca_scale = 1.0 / math.sqrt(hd)
+        GQ = tw.get("GQ")                                    # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
+        regression = "regression" in c.mml_localization
+
+        def dec_fill_tgt() -> None:
+            tgt = tw["d.0.tgt"]
+            if c.moment_query_type in ("video", "music", "xpool"):
+                if c.moment_query_type == "xpool":
+                    cur.wait_stream(side)                    # the X-Pool branch (second stream) produces the query
+                src_vec = video if c.moment_query_type == "video" else (music if c.moment_query_type == "music" else tw["xpool_q"])
+                tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+            else:                                            # "zero" / "random": reference music_detr/transformer.py:73-74
+                tgt.zero_()
+            if Q > 1:                                        # (a single query's q / k projections are never formed: see the loop)
+                tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
+
+        def dec_query_side(l: int) -> None:
+            """the part of decoder layer l in front of its cross-attention: self-attention block, LayerNorm, cross-attention query and
+            its per-head fold -- it reads the layer's input and the weights, nothing the DETR encoder produces"""
+            p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
+            tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
+            qkv = tw[d + ".qkv"]
+            if Q == 1:
+                # one query, one key: the softmax weight is 1, so the block is the value path; its attention-weight dropout is one
+                # draw per (sample, head) (element index (b*H + h)*1*1), and q / k get no gradient
+                # (the draw is the value Linear's epilogue: the undropped value itself is needed by nobody)
+                Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
+                ops.linear(tgt, Wsa[2 * D:], bsa[2 * D:], out=tw[d + ".att"], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+            else:
+                ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
+                           segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
+                q3 = qkv.view(B, Q, 3 * D)
+                ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), H, lse=tw[d + ".lse"],
+                              drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+            ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
+            t1 = tw[d + ".t1"]
+            ops.layernorm_add(ta, P[p + ".ln1.g"], P[p + ".ln1.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t1, tw[d + ".t1q"])
+            Win, bin_ = P[p + ".ca.in.w"], P[p + ".ca.in.b"]
+            Wt = P[p + ".ca.in.wt"]                           # [D, 3D] = in_proj^T
+            qc = ops.linear(tw[d + ".t1q"], Win[:D], bin_[:D], out=tw[d + ".qc"])
+            qprime = GQ[:, 1, l]                              # [B, H*Q, D] view; q'_h = W_k,h^T qc_h  (b_k shifts all keys alike)
+            ops.linear(qc[:, :hd], Wt[:, D:D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
+                       segs=[Seg(out=qprime, ldo=D, rows_per_batch=Q, out_batch_stride=qprime.stride(0), out_z_stride=Q * D)])
+
+        dec_early = None
         # ---- X-Pool (in-batch) + similarities + retrieval loss
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            if (Q == 1 and not regression and c.moment_query_type != "xpool" and c.detr_enc_layers > 0 and not self._dec_fused(B, L)
+                    and self._chain_seed is None and os.environ.get("MADE_DEC_EARLY", "1") != "0"):
+                # the query side of decoder layer 0 depends on the clip-level vector and the weights only: here, beside the DETR encoder,
+                # instead of at the head of the decoder's chain of dependent launches (as MadeEngine does for the eval path)
+                dec_fill_tgt()
+                dec_query_side(0)
+                dec_early = torch.cuda.Event()
+                dec_early.record(side)
             xmask = sm if c.fusion_mask == 1 else None
             if "music" in c.vmr_fusion:
                 self._xpool_train(video, seg, xmask, ws, tw, B, Ta)
@@ -653,19 +709,8 @@ class MadeTrainer(MadeEngine):
 
         # ---- DETR decoder (memory-space cross-attention, per-head products written out)
         mem3, mempos3 = memory.view(B, L, D), mempos.view(B, L, D)
-        qp = P["query_embed"]
-        hd = D // H
-        ca_scale = 1.0 / math.sqrt(hd)
-        tgt = tw["d.0.tgt"]
-        if c.moment_query_type in ("video", "music", "xpool"):
-            if c.moment_query_type == "xpool":
-                cur.wait_stream(side)                        # the X-Pool branch (second stream) produces the query
-            src_vec = video if c.moment_query_type == "video" else (music if c.moment_query_type == "music" else tw["xpool_q"])
-            tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
-        else:                                                # "zero" / "random": reference music_detr/transformer.py:73-74
-            tgt.zero_()
-        if Q > 1:                                            # (a single query's q / k projections are never formed: see the loop)
-            tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
+        if dec_early is None:
+            dec_fill_tgt()
         hs = ws["hs"]
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
         n_split = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))   # few queries, long memory: keys split over workgroups (knob for measurements)
@@ -684,27 +729,12 @@ class MadeTrainer(MadeEngine):
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
             tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
             qkv = tw[d + ".qkv"]
-            if Q == 1:
-                # one query, one key: the softmax weight is 1, so the block is the value path; its attention-weight dropout is one
-                # draw per (sample, head) (element index (b*H + h)*1*1), and q / k get no gradient
-                # (the draw is the value Linear's epilogue: the undropped value itself is needed by nobody)
-                Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
-                ops.linear(tgt, Wsa[2 * D:], bsa[2 * D:], out=tw[d + ".att"], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+            if l == 0 and dec_early is not None:
+                cur.wait_event(dec_early)                      # layer 0's query side ran beside the DETR encoder (second stream)
             else:
-                ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
-                           segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
-                q3 = qkv.view(B, Q, 3 * D)
-                ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), H, lse=tw[d + ".lse"],
-                              drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
-            ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
-            t1 = tw[d + ".t1"]
-            ops.layernorm_add(ta, P[p + ".ln1.g"], P[p + ".ln1.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t1, tw[d + ".t1q"])
+                dec_query_side(l)
             Win, bin_ = P[p + ".ca.in.w"], P[p + ".ca.in.b"]
-            Wt = P[p + ".ca.in.wt"]                           # [D, 3D] = in_proj^T
-            qc = ops.linear(tw[d + ".t1q"], Win[:D], bin_[:D], out=tw[d + ".qc"])
-            qprime = GQ[:, 1, l]                              # [B, H*Q, D] view; q'_h = W_k,h^T qc_h  (b_k shifts all keys alike)
-            ops.linear(qc[:, :hd], Wt[:, D:D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
-                       segs=[Seg(out=qprime, ldo=D, rows_per_batch=Q, out_batch_stride=qprime.stride(0), out_z_stride=Q * D)])
+            qprime, t1 = GQ[:, 1, l], tw[d + ".t1"]
             pooled = tw[d + ".pooled"]                        # [B*Q, H*D]: row (b, q), head-major columns
             s_out = tw[d + ".s"] if Q == 1 else tw["s_raw"]   # the kernel numbers its rows (b, h, q); the Linears below (b, q, h)
             ops.attention_wide(qprime.view(B, H, Q, D), mempos3, mem3, pooled.view(B, Q, H, D).permute(0, 2, 1, 3), scale=ca_scale,
