@@ -594,79 +594,6 @@ int made_add3(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, cons
 /* out[c] += sum over rows of x[row, c]  (f32, accumulated): gradient of a row vector that was broadcast over the rows. */
 int made_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream);
 
-/* made_chain: a CHAIN of dependent 64-row stages in ONE launch.  The decoder of the training step is ~250 such stages (Linears on
- * B*Q rows, row-wise LayerNorms / gates between them), each waiting for the one before: launched one by one they cost 10-12 us
- * apiece on this part, 4 us of it for an empty kernel.  Here `n_workgroups` (16 by default: what a 512-wide 64-row Linear fills)
- * co-resident workgroups walk the stage list in device memory and meet at an atomic grid barrier between stages (~1.5 us for 16
- * workgroups; tools/probes/grid_barrier_probe.hip).  A stage is either a made_linear problem that the tiny-M kernel serves
- * (M <= 64, K a multiple of 64, bf16 operands; all its epilogue options) or a row operation:
- *   MADE_CHAIN_LAYERNORM: out = LN(x) (g, b), out2 = out + add (optional; ld_add 0 = one row for all), out3 = LN2(out) (optional)
- *   MADE_CHAIN_GATE_ROWS: out = dropout(x)  (element index row * drop_ld + col / drop_col_div), as made_gate_rows without a gate
- *   MADE_CHAIN_HEAD_BIAS: x[r, c] += s[r, c / hd] * bias[c]                                    (made_head_bias)
- * `barrier` is a device word the caller zeroes once; `barrier_base` is the value it holds before this launch (every launch adds
- * n_stages * n_workgroups), so consecutive launches need no reset.  Stage outputs become visible to the next stage through
- * agent-scope release / acquire fences around the barrier (the workgroups sit on different XCDs).
- * Status: correct (bit-identical to the separate launches) and NOT faster on MI355X -- a stage costs ~10 us either way, the chain of
- * memory round trips inside a dependent stage, not the launch, is what takes the time.  Kept as an opt-in path. */
-enum MadeChainOp { MADE_CHAIN_LINEAR = 1, MADE_CHAIN_LAYERNORM = 2, MADE_CHAIN_GATE_ROWS = 3, MADE_CHAIN_HEAD_BIAS = 4 };
-typedef struct MadeChainRowOp {
-    const void* x; int64_t ldx;
-    void* out; int64_t ldo;
-    void* out2; int64_t ldo2;
-    void* out3; int64_t ldo3;
-    const void* add; int64_t ld_add;
-    const float *g, *b, *g2, *b2;
-    const float *s, *bias;
-    int64_t rows, cols, drop_ld;
-    int32_t dtype, drop_col_div, H, _pad;
-    float eps, _padf;
-    MadeDropout drop;
-} MadeChainRowOp;
-typedef struct MadeChainStage {
-    int32_t op, _pad;
-    MadeLinearArgs lin;
-    MadeChainRowOp row;
-} MadeChainStage;
-int made_chain(const MadeChainStage* stages_device, int32_t n_stages, int32_t n_workgroups, uint32_t* barrier, uint32_t barrier_base,
-               void* stream);
-/* profiling aid: the following made_chain launches write 4 s_memtime stamps per stage (workgroup 0: stage start, work done, release
- * done, barrier passed) into `stamps` (device memory, 4 * n_stages words); NULL switches it off */
-int made_chain_debug_stamps(uint64_t* stamps);
-/* host-side check that a made_linear problem may be a MADE_CHAIN_LINEAR stage (returns MADE_OK or MADE_ERR_UNSUPPORTED) */
-int made_chain_linear_ok(const MadeLinearArgs* args);
-
-/* made_dec_train_fwd: the moment-DETR decoder of the training step for ONE moment query (Q = 1), every layer in one launch: one
- * workgroup per sample walks the stack (reference music_detr/transformer.py:119-145, :273-307 forward_post, model.train()).  It
- * writes what the unfused chain of made_linear / made_layernorm / made_attention_wide launches writes -- every activation the
- * backward needs, as [layer, sample, ...] stacks in the compute dtype -- with the same stateless dropout masks (site ids per
- * layer below; element indices: sa_attn (b*H + h), drop1/2/3 b*D + n, ffn_act b*Fd + n, ca_attn (b*H + h)*L + key).
- *   tgt [n_layers + 1, B, D]: slot 0 = the content queries (input), slot l + 1 = layer l's output; hs [n_layers, B, D] = the shared
- *   output norm of every layer; qkv [n_layers, B, 3D] (only the value third is written: one query's softmax weight is 1);
- *   GQ [B, 2, n_layers, H, D]: part 1 receives q'_h = W_k,h^T qc_h; s_sum [n_layers, B, H] f32 = sum of the dropped attention
- *   weights; pooled [n_layers, B, H*D]; h [n_layers, B, Fd]; every other stack [n_layers, B, D].
- * mem / mempos [B, L, D]: memory and memory + position (values / keys of the cross-attention), key_mask [B, L] (1 = valid). */
-typedef struct MadeDecTrainLayer {
-    const void *sa_v_w, *sa_out_w, *ca_q_w, *ca_k_w, *ca_v_w, *ca_out_w, *ff1_w, *ff2_w;        /* compute dtype, row-major [out, in] */
-    const void *sa_v_wt, *sa_out_wt, *ca_in_wt, *ca_out_wt, *ff1_wt, *ff2_wt;                    /* transposes (the backward's operands); ca_in_wt: [D, 3D] */
-    const float *sa_v_b, *sa_out_b, *ca_q_b, *ca_v_b, *ca_out_b, *ff1_b, *ff2_b;
-    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
-    float *g_ln1_g, *g_ln1_b, *g_ln2_g, *g_ln2_b, *g_ln3_g, *g_ln3_b, *g_ca_v_b;                 /* gradient accumulators (backward) */
-    uint32_t site_sa_attn, site_drop1, site_ca_attn, site_drop2, site_ffn_act, site_drop3;
-} MadeDecTrainLayer;
-typedef struct MadeDecTrainArgs {
-    const MadeDecTrainLayer* layers;     /* device array [n_layers] */
-    int32_t n_layers, dtype, B, L, D, H, Fd, _pad;
-    const void *mem, *mempos; const float* key_mask;
-    const void* query_pos;               /* [D], compute dtype */
-    const float *norm_g, *norm_b;        /* the decoder's output norm */
-    void *tgt, *qkv, *att, *t_a, *t1, *t1q, *qc, *pooled, *attc, *t_b, *t2, *h, *t_c, *hs, *GQ;
-    float* s_sum;
-    float scale, eps;
-    MadeDropout drop;                    /* seed + p of every site (site ids per layer) */
-    uint64_t* stamps;                    /* profiling aid (NULL in production): workgroup 0 writes s_memtime at its phase boundaries */
-} MadeDecTrainArgs;
-int made_dec_train_fwd(const MadeDecTrainArgs* args, void* stream);
-
 /* made_posbn_relu_fwd / _bwd: y = relu(BatchNorm1d_over_positions(x)) of the EmbeddingNet aggregator (agg_module = "mlp", reference
  *   model/model_Base.py:216-249: nn.BatchNorm1d(num_features = T) applied to [B, T, F], so position t is the channel and its
  *   statistics run over the B * F values there).  x / y: rows b * T + t of pitch ldx / ldy, F columns.  batch_stats != 0

@@ -130,37 +130,6 @@ class MadeAdamGroup(C.Structure):
     _fields_ = [("begin", i64), ("end", i64), ("lr", f32), ("max_norm", f32)]
 
 
-class MadeChainRowOp(C.Structure):
-    _fields_ = [("x", vp), ("ldx", i64), ("out", vp), ("ldo", i64), ("out2", vp), ("ldo2", i64), ("out3", vp), ("ldo3", i64),
-                ("add", vp), ("ld_add", i64), ("g", vp), ("b", vp), ("g2", vp), ("b2", vp), ("s", vp), ("bias", vp),
-                ("rows", i64), ("cols", i64), ("drop_ld", i64),
-                ("dtype", i32), ("drop_col_div", i32), ("H", i32), ("_pad", i32),
-                ("eps", f32), ("_padf", f32), ("drop", MadeDropout)]
-
-
-class MadeChainStage(C.Structure):
-    _fields_ = [("op", i32), ("_pad", i32), ("lin", MadeLinearArgs), ("row", MadeChainRowOp)]
-
-
-CHAIN_LINEAR, CHAIN_LAYERNORM, CHAIN_GATE_ROWS, CHAIN_HEAD_BIAS = 1, 2, 3, 4
-
-
-class MadeDecTrainLayer(C.Structure):
-    _fields_ = ([(k, vp) for k in ("sa_v_w", "sa_out_w", "ca_q_w", "ca_k_w", "ca_v_w", "ca_out_w", "ff1_w", "ff2_w",
-                                   "sa_v_wt", "sa_out_wt", "ca_in_wt", "ca_out_wt", "ff1_wt", "ff2_wt",
-                                   "sa_v_b", "sa_out_b", "ca_q_b", "ca_v_b", "ca_out_b", "ff1_b", "ff2_b",
-                                   "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b",
-                                   "g_ln1_g", "g_ln1_b", "g_ln2_g", "g_ln2_b", "g_ln3_g", "g_ln3_b", "g_ca_v_b")] +
-                [(k, C.c_uint32) for k in ("site_sa_attn", "site_drop1", "site_ca_attn", "site_drop2", "site_ffn_act", "site_drop3")])
-
-
-class MadeDecTrainArgs(C.Structure):
-    _fields_ = ([("layers", vp)] + [(k, i32) for k in ("n_layers", "dtype", "B", "L", "D", "H", "Fd", "_pad")] +
-                [(k, vp) for k in ("mem", "mempos", "key_mask", "query_pos", "norm_g", "norm_b",
-                                   "tgt", "qkv", "att", "t_a", "t1", "t1q", "qc", "pooled", "attc", "t_b", "t2", "h", "t_c", "hs", "GQ", "s_sum")] +
-                [("scale", f32), ("eps", f32), ("drop", MadeDropout), ("stamps", vp)])
-
-
 class MadeAdamDeviceState(C.Structure):
     _fields_ = [("step", i64), ("lr", f32 * 4), ("bc1", f32), ("bc2_sqrt", f32)]
 
@@ -204,10 +173,6 @@ SIGNATURES = {
     "made_head_bias_bwd": (C.c_int, [vp, i32, i64, vp, vp, vp, vp, i64, i64, i64, vp]),
     "made_add3": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, i64, vp]),
     "made_colsum": (C.c_int, [vp, i32, i64, i64, i64, vp, vp]),
-    "made_dec_train_fwd": (C.c_int, [C.POINTER(MadeDecTrainArgs), vp]),
-    "made_chain": (C.c_int, [vp, i32, i32, vp, C.c_uint32, vp]),
-    "made_chain_linear_ok": (C.c_int, [C.POINTER(MadeLinearArgs)]),
-    "made_chain_debug_stamps": (C.c_int, [vp]),
     "made_posbn_relu_fwd": (C.c_int, [vp, i32, i64, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, i32, i64, i64, i64, i64, vp]),
     "made_posbn_relu_bwd": (C.c_int, [vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, vp, i32, i64, vp, vp, i64, i64, i64, vp]),
     "made_set_criterion_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp,
@@ -242,14 +207,9 @@ class MadeError(RuntimeError):
     pass
 
 
-_before_call = None      # set while a chain of stages is being recorded (ops.ChainRecorder): any other library call launches it first
-
-
 def lib() -> C.CDLL:
     """Load libmade_hip.so (once).  Raises if it has not been built -- there is no fallback."""
     global _lib
-    if _before_call is not None:
-        _before_call()
     if _lib is None:
         if not os.path.isfile(LIB_PATH):
             raise MadeError(f"{LIB_PATH} not found: build the HIP library first (make -C mgsv_amd/csrc); "

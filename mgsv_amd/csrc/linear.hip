@@ -1211,31 +1211,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void linear_skinny_kernel(const MadeLi
 constexpr int T_BN = 32, T_BM = 64, T_CH = 4;
 constexpr int T_CT_LD = T_BN + 4;
 
-// (a device function: the kernel below runs it on its own blockIdx, made_chain's executor on the tiles of a stage)
-// the first 2 * T_CH weight fragments of a tile (what linear_tiny_body's first two loads would fetch): weights do not depend on the
-// previous stage, so made_chain's executor requests them BEFORE it waits at the grid barrier
-__device__ __forceinline__ void linear_tiny_prefetch_w(const MadeLinearArgs& a, const int bx, const int bz, bf16x8 (&fwp)[2][T_CH]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int N = (int)a.N, K = (int)a.K;
-    const int n_tiles = (N + T_BN - 1) / T_BN;
-    const int n0 = (bx % n_tiles) * T_BN;
-    const int steps = K / 64;
-    const int kw = wave * steps * 16 + hh * 8;
-    int gn = n0 + r; gn = gn < N ? gn : N - 1;
-    const bf16_t* pw = (const bf16_t*)a.W + (int64_t)bz * a.w_z_stride + (int64_t)gn * a.ldw + kw;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < T_CH; ++i) {
-            const int st = b * T_CH + i < steps ? b * T_CH + i : steps - 1;
-            fwp[b][i] = *(const bf16x8*)(pw + st * 16);
-        }
-}
-
-template <bool TRAIN, bool PRE = false>
-__device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const int bx, const int bz, float* Ct /* [4 * T_BM * T_CT_LD] LDS */,
-                                                 const bf16x8 (*fwp)[T_CH] = nullptr /* PRE: the tile's first 2 * T_CH weight fragments */) {
+template <bool TRAIN>
+__device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const int bx, const int bz, float* Ct /* [4 * T_BM * T_CT_LD] LDS */) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -1311,35 +1288,12 @@ __device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const 
             }
         }
     };
-    auto load_a = [&](int buf, int s0) __attribute__((always_inline)) {       // PRE: the weights of the first two batches are already here
-#pragma unroll
-        for (int i = 0; i < T_CH; ++i) {
-            const int s = s0 + i < steps ? s0 + i : steps - 1;
-            fw[buf][i] = fwp[buf][i];
-            fa[buf][i][0] = *(const bf16x8*)(pa[0] + s * 16);
-            fa[buf][i][1] = *(const bf16x8*)(pa[1] + s * 16);
-        }
-    };
-    if constexpr (PRE) {
-        load_a(0, 0);
-        load_a(1, T_CH);                                       // (past the end when steps <= T_CH: re-read, never multiplied)
-        mul(0, 0);
-        if (2 * T_CH < steps) load(0, 2 * T_CH);
-        mul(1, T_CH);
-        for (int s0 = 2 * T_CH; s0 < steps; s0 += 2 * T_CH) {
-            if (s0 + T_CH < steps) load(1, s0 + T_CH);
-            mul(0, s0);
-            if (s0 + 2 * T_CH < steps) load(0, s0 + 2 * T_CH);
-            if (s0 + T_CH < steps) mul(1, s0 + T_CH);
-        }
-    } else {
-        load(0, 0);
-        for (int s0 = 0; s0 < steps; s0 += 2 * T_CH) {
-            if (s0 + T_CH < steps) load(1, s0 + T_CH);
-            mul(0, s0);
-            if (s0 + 2 * T_CH < steps) load(0, s0 + 2 * T_CH);
-            if (s0 + T_CH < steps) mul(1, s0 + T_CH);
-        }
+    load(0, 0);
+    for (int s0 = 0; s0 < steps; s0 += 2 * T_CH) {
+        if (s0 + T_CH < steps) load(1, s0 + T_CH);
+        mul(0, s0);
+        if (s0 + 2 * T_CH < steps) load(0, s0 + 2 * T_CH);
+        if (s0 + T_CH < steps) mul(1, s0 + T_CH);
     }
 
     float* mine = Ct + wave * (T_BM * T_CT_LD);
@@ -1384,207 +1338,6 @@ template <bool TRAIN>
 __global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearArgs a) {
     __shared__ __attribute__((aligned(16))) float Ct[4 * T_BM * T_CT_LD];
     linear_tiny_body<TRAIN>(a, blockIdx.x, blockIdx.z, Ct);
-}
-
-// =================================================================================================
-// made_chain: dependent 64-row stages behind one launch (see include/made_hip.h)
-__device__ __forceinline__ f32x4 chain_ld4(const void* p, int dtype, int64_t idx) {
-    f32x4 v;
-    if (dtype == MADE_F32) {
-        v = *(const f32x4*)((const float*)p + idx);
-    } else {
-        const bf16x4 t = *(const bf16x4*)((const bf16_t*)p + idx);
-        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
-    }
-    return v;
-}
-__device__ __forceinline__ void chain_st4(void* p, int dtype, int64_t idx, f32x4 v) {
-    if (dtype == MADE_F32) {
-        *(f32x4*)((float*)p + idx) = v;
-    } else {
-        bf16x4 t;
-        t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
-        *(bf16x4*)((bf16_t*)p + idx) = t;
-    }
-}
-__device__ __forceinline__ f32x4 chain_round(f32x4 v, int dtype) {            // the value a store in `dtype` keeps
-    if (dtype == MADE_BF16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (float)(bf16_t)v[j];
-    }
-    return v;
-}
-
-constexpr int CH_NV = 8;                                   // row ops: up to 64 * 4 * 8 = 2048 columns, one wave per row
-
-// LayerNorm of the row held as v[i] (columns (i * 64 + lane) * 4 ..): two passes over the registers, as made_layernorm does
-// (g / b: fragments the caller loaded together with the row -- behind the reductions they would be a second round trip)
-__device__ __forceinline__ void chain_wave_ln(f32x4 (&v)[CH_NV], int nv, int D, int lane, const f32x4 (&gv)[CH_NV], const f32x4 (&bv)[CH_NV], float eps) {
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < CH_NV; ++i)
-        if (i < nv && (i * WAVE + lane) * 4 < D) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = wave_sum(sum) / (float)D;
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < CH_NV; ++i)
-        if (i < nv && (i * WAVE + lane) * 4 < D) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq += d * d; }
-        }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
-#pragma unroll
-    for (int i = 0; i < CH_NV; ++i) {
-        const int c = (i * WAVE + lane) * 4;
-        if (i < nv && c < D) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * gv[i][j] + bv[i][j];
-        }
-    }
-}
-
-__device__ __forceinline__ void chain_row_stage(const int op, const MadeChainRowOp& o) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int D = (int)o.cols, dt = o.dtype;
-    const int nv = (D + 255) / 256;
-    for (int64_t row = (int64_t)blockIdx.x * (NTHREADS / WAVE) + wave; row < o.rows; row += (int64_t)gridDim.x * (NTHREADS / WAVE)) {
-        if (op == MADE_CHAIN_LAYERNORM) {
-            f32x4 v[CH_NV], gv[CH_NV], bv[CH_NV], g2v[CH_NV], b2v[CH_NV];
-#pragma unroll
-            for (int i = 0; i < CH_NV; ++i) {
-                const int c = (i * WAVE + lane) * 4;
-                if (i < nv && c < D) {
-                    v[i] = chain_ld4(o.x, dt, row * o.ldx + c);
-                    gv[i] = *(const f32x4*)(o.g + c); bv[i] = *(const f32x4*)(o.b + c);
-                    if (o.out3) { g2v[i] = *(const f32x4*)(o.g2 + c); b2v[i] = *(const f32x4*)(o.b2 + c); }
-                }
-            }
-            chain_wave_ln(v, nv, D, lane, gv, bv, o.eps);
-#pragma unroll
-            for (int i = 0; i < CH_NV; ++i) {
-                const int c = (i * WAVE + lane) * 4;
-                if (i < nv && c < D) {
-                    if (o.out) chain_st4(o.out, dt, row * o.ldo + c, v[i]);
-                    v[i] = chain_round(v[i], dt);                  // what follows is built from the value `out` holds
-                    if (o.out2) {
-                        const f32x4 ad = chain_ld4(o.add, dt, row * o.ld_add + c);
-                        f32x4 t = v[i];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) t[j] += ad[j];
-                        chain_st4(o.out2, dt, row * o.ldo2 + c, t);
-                    }
-                }
-            }
-            if (o.out3) {
-                chain_wave_ln(v, nv, D, lane, g2v, b2v, o.eps);
-#pragma unroll
-                for (int i = 0; i < CH_NV; ++i) {
-                    const int c = (i * WAVE + lane) * 4;
-                    if (i < nv && c < D) chain_st4(o.out3, dt, row * o.ldo3 + c, v[i]);
-                }
-            }
-        } else if (op == MADE_CHAIN_GATE_ROWS) {
-            const uint32_t thr = made_drop_threshold(o.drop.p);
-            const uint64_t seed = o.drop.p > 0.f ? made_drop_seed(o.drop) : 0;
-            const float dsc = o.drop.p > 0.f ? 1.f / (1.f - o.drop.p) : 1.f;
-            for (int c = lane * 4; c < D; c += 256) {
-                f32x4 v = chain_ld4(o.x, dt, row * o.ldx + c);
-                if (o.drop.p > 0.f) {
-                    const uint64_t base = (uint64_t)row * (uint64_t)o.drop_ld;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        v[j] = (made_rng_mix(seed, o.drop.site, base + (uint64_t)((c + j) / o.drop_col_div)) >> 8) >= thr ? v[j] * dsc : 0.f;
-                }
-                chain_st4(o.out, dt, row * o.ldo + c, v);
-            }
-        } else {                                                   // MADE_CHAIN_HEAD_BIAS (in place on x)
-            const int hd = D / o.H;
-            for (int c = lane * 4; c < D; c += 256) {
-                f32x4 v = chain_ld4(o.x, dt, row * o.ldx + c);
-                const f32x4 bb = *(const f32x4*)(o.bias + c);
-                const float sh = o.s[row * o.H + c / hd];          // hd is a multiple of 4: the four columns share a head
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += sh * bb[j];
-                chain_st4(const_cast<void*>(o.x), dt, row * o.ldx + c, v);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(NTHREADS) void chain_kernel(const MadeChainStage* __restrict__ stages, const int n_stages, unsigned* barrier,
-                                                         const unsigned barrier_base, unsigned long long* stamps) {
-    __shared__ __attribute__((aligned(16))) float Ct[4 * T_BM * T_CT_LD];
-    // profiling aid (made_chain_debug_stamps): workgroup 0 writes s_memtime at stage start / work done / release done / barrier passed
-    auto stamp = [&](int s, int k) __attribute__((always_inline)) {
-        if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[s * 4 + k] = __builtin_readcyclecounter();
-    };
-    // The stage descriptors are read through LDS, the next one copied in while this workgroup waits at the barrier: read from global
-    // memory at the start of its stage, a descriptor is two dependent round trips (~1.3 us each right after the acquire) before
-    // the first operand load can even be addressed.
-    __shared__ __attribute__((aligned(16))) MadeChainStage sst[2];
-    constexpr int ST_WORDS = (int)(sizeof(MadeChainStage) / 4);
-    static_assert(sizeof(MadeChainStage) % 4 == 0 && ST_WORDS <= 2 * NTHREADS, "descriptor copy");
-    auto fetch_stage = [&](int s) __attribute__((always_inline)) {
-        const uint32_t* src = (const uint32_t*)(stages + s);
-        uint32_t* dst = (uint32_t*)&sst[s & 1];
-        for (int i = threadIdx.x; i < ST_WORDS; i += NTHREADS) dst[i] = src[i];
-    };
-    fetch_stage(0);
-    __syncthreads();
-    bf16x8 fwp[2][T_CH];                                       // the next Linear stage's first weight fragments (this workgroup's first tile)
-    bool have_pre = false;
-    for (int s = 0; s < n_stages; ++s) {
-        const MadeChainStage& st = sst[s & 1];
-        stamp(s, 0);
-        if (st.op == MADE_CHAIN_LINEAR) {
-            const MadeLinearArgs& a = st.lin;
-            const int tiles = (int)(((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN));
-            const int total = tiles * (int)a.batch;
-            for (int t = blockIdx.x; t < total; t += gridDim.x) {
-                if (have_pre && t == (int)blockIdx.x) linear_tiny_body<true, true>(a, t % tiles, t / tiles, Ct, fwp);
-                else linear_tiny_body<true>(a, t % tiles, t / tiles, Ct);
-                __syncthreads();                                   // Ct is reused by the next tile
-            }
-        } else {
-            chain_row_stage(st.op, st.row);
-        }
-        __syncthreads();
-        stamp(s, 1);
-        if (s + 1 < n_stages) {
-            // ---- grid barrier.  Release: every wave's stores must have left for memory before the workgroup signs in; acquire:
-            // the other XCDs' results are fetched past this XCD's caches afterwards.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            stamp(s, 2);
-            fetch_stage(s + 1);                                    // (the other buffer: this stage's readers are past the __syncthreads above)
-            __syncthreads();
-            {
-                // the next stage's WEIGHTS do not depend on this one: request this workgroup's first fragments now, they arrive
-                // while it waits for the others
-                const MadeChainStage& nx = sst[(s + 1) & 1];
-                have_pre = false;
-                if (nx.op == MADE_CHAIN_LINEAR) {
-                    const MadeLinearArgs& na = nx.lin;
-                    const int ntiles = (int)(((na.M + T_BM - 1) / T_BM) * ((na.N + T_BN - 1) / T_BN));
-                    if ((int)blockIdx.x < ntiles * (int)na.batch) {
-                        linear_tiny_prefetch_w(na, blockIdx.x % ntiles, blockIdx.x / ntiles, fwp);
-                        have_pre = true;
-                    }
-                }
-            }
-            if (threadIdx.x == 0) {
-                __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned target = barrier_base + (unsigned)(s + 1) * gridDim.x;
-                while ((int)(__hip_atomic_load(barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
-            }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            stamp(s, 3);
-        }
-    }
-    // the last stage's count keeps `barrier` at base + n_stages * gridDim.x whatever n_stages is
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -1633,7 +1386,7 @@ static int pick_variant(const MadeLinearArgs& a) {
     return MADE_LINEAR_GLDS64;
 }
 
-// argument checks of made_linear (shared with made_chain, whose stages are made_linear problems)
+// argument checks of made_linear
 static int linear_validate(const MadeLinearArgs& a) {
     MADE_REQUIRE(a.A && a.W, "made_linear: null A or W");
     MADE_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "made_linear: bad dims M=%lld N=%lld K=%lld",
@@ -1741,26 +1494,4 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
 
 extern "C" int made_linear_variant(const MadeLinearArgs* args) {
     return args ? pick_variant(*args) : -1;
-}
-
-extern "C" int made_chain_linear_ok(const MadeLinearArgs* args) {
-    MADE_REQUIRE(args != nullptr, "made_chain_linear_ok: null args");
-    { const int rc = linear_validate(*args); if (rc != MADE_OK) return rc; }
-    MADE_UNSUPPORTED(pick_variant(*args) == MADE_LINEAR_TINY && args->M > 0, "made_chain: not a tiny-M made_linear problem");
-    return MADE_OK;
-}
-
-static unsigned long long* g_chain_stamps = nullptr;
-// profiling aid: the next made_chain launches write 4 cycle stamps per stage (workgroup 0) into `stamps` (device, >= 4 * n_stages words)
-extern "C" int made_chain_debug_stamps(uint64_t* stamps) { g_chain_stamps = (unsigned long long*)stamps; return MADE_OK; }
-
-extern "C" int made_chain(const MadeChainStage* stages_device, int32_t n_stages, int32_t n_workgroups, uint32_t* barrier,
-                          uint32_t barrier_base, void* stream) {
-    MADE_REQUIRE(stages_device && barrier, "made_chain: null pointer");
-    MADE_REQUIRE(n_stages >= 1 && n_stages <= 4096, "made_chain: n_stages=%d out of range", n_stages);
-    // every workgroup must be resident at once (they wait for each other): one per CU at most, far below the 256 CUs
-    MADE_REQUIRE(n_workgroups >= 1 && n_workgroups <= 128, "made_chain: n_workgroups=%d out of [1, 128]", n_workgroups);
-    hipLaunchKernelGGL(chain_kernel, dim3((unsigned)n_workgroups), dim3(NTHREADS), 0, (hipStream_t)stream, stages_device, (int)n_stages, barrier,
-                       barrier_base, g_chain_stamps);
-    return made_check_launch("made_chain");
 }

@@ -62,92 +62,6 @@ def set_drop(d, drop) -> None:
     d.site, d.p = int(site) & 0xFFFFFFFF, float(p)
 
 
-class ChainRecorder:
-    """Collects dependent 64-row stages (tiny-M Linears and the row operations between them) and launches them as ONE made_chain
-    call: `with ChainRecorder(state): ...` around ordinary ops.* / ops_train.* calls.  A call the chain cannot hold -- or any other
-    library call -- first launches what was recorded, so the order of work on the stream is the program order either way.
-    `state` (a dict the owner keeps) caches the device copies of the stage lists -- the buffers of a training workspace are fixed,
-    so after the first step nothing is uploaded -- and holds the barrier word.  Dropout seeds must live in device memory
-    (MadeDropout.seed_device): a seed passed by value would change the stage bytes every step."""
-    N_WG = 16
-
-    def __init__(self, state: dict, device):
-        self.state, self.device = state, device
-        self.stages = []
-        if "barrier" not in state:
-            state.update(barrier=torch.zeros(1, device=device, dtype=torch.int32), count=0, cache={}, seq=0)
-
-    def __enter__(self):
-        global _REC
-        assert _REC is None, "chains do not nest"
-        _REC = self
-        self.state["seq"] = 0
-        _lib._before_call = self.flush
-        return self
-
-    def __exit__(self, *exc):
-        global _REC
-        try:
-            if exc[0] is None:
-                self.flush()
-        finally:
-            _REC = None
-            _lib._before_call = None
-
-    def add(self, op: int, lin=None, row=None) -> None:
-        st = _lib.MadeChainStage()
-        st.op = op
-        if lin is not None:
-            st.lin = lin
-        if row is not None:
-            st.row = row
-        self.stages.append(st)
-
-    def try_linear(self, a) -> bool:
-        saved = _lib._before_call
-        _lib._before_call = None                         # (the eligibility check is a library call itself)
-        try:
-            ok = lib().made_chain_linear_ok(C.byref(a)) == 0
-        finally:
-            _lib._before_call = saved
-        if ok:
-            self.add(_lib.CHAIN_LINEAR, lin=a)
-        return ok
-
-    def flush(self) -> None:
-        if not self.stages:
-            return
-        stages, self.stages = self.stages, []
-        saved = _lib._before_call
-        _lib._before_call = None
-        try:
-            n = len(stages)
-            arr = (_lib.MadeChainStage * n)(*stages)
-            raw = bytes(arr)
-            st = self.state
-            key = st["seq"]
-            st["seq"] += 1
-            ent = st["cache"].get(key)
-            if ent is None or ent[0] != raw:
-                import numpy as np
-                ent = (raw, torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self.device))
-                st["cache"][key] = ent
-            check(lib().made_chain(ent[1].data_ptr(), n, self.N_WG, st["barrier"].data_ptr(), st["count"] & 0xFFFFFFFF, _stream()), "made_chain")
-            st["count"] = (st["count"] + n * self.N_WG) & 0xFFFFFFFF
-        finally:
-            _lib._before_call = saved
-
-
-_REC: Optional[ChainRecorder] = None
-
-
-def _row_stage(**kw):
-    r = _lib.MadeChainRowOp()
-    for k, v in kw.items():
-        setattr(r, k, v)
-    return r
-
-
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -301,8 +215,6 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     flops = 2.0 * M * N * K * batch
     nbytes = batch * (M * K * (4 if a.a_dtype == F32 else 2) + N * K * esz + M * N * esz)
     desc = f"M={M} N={N} K={K} z={batch} nseg={len(segs)} a2={int(A2 is not None)} R={int(R is not None)} act={act} tr={int(any(s_.transposed for s_ in segs))}"
-    if _REC is not None and _timer is None and _REC.try_linear(a):       # a stage of the chain being recorded (launched with it)
-        return segs[0].out
     _timed(kind, flops, nbytes, lambda: check(lib().made_linear(C.byref(a), _stream()), "made_linear"),
            ("rows", rows[1], M) if rows is not None else ((desc, tile_skip_mask, 128) if tile_skip_mask is not None else desc))
     return segs[0].out
@@ -521,11 +433,6 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, out: Optional[Tensor] = No
     if out is None:
         out = torch.empty((rows, D), device=x.device, dtype=out_dtype or x.dtype)
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= rows
-    if (_REC is not None and x.dim() == 2 and row_skip is None and out.dtype == x.dtype and D % 4 == 0 and D <= 2048
-            and ldx % 4 == 0 and out.stride(0) % 4 == 0):
-        _REC.add(_lib.CHAIN_LAYERNORM, row=_row_stage(x=_p(x), ldx=ldx, out=_p(out), ldo=out.stride(0), g=_p(_f32(gamma, "gamma")),
-                                                      b=_p(_f32(beta, "beta")), rows=rows, cols=D, dtype=dt_of(x), eps=eps))
-        return out
     check(lib().made_layernorm(_p(x), dt_of(x), ldx, rpb, xbs, _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
                                _p(out), dt_of(out), out.stride(0), rows, D, eps, _p(_f32(row_skip, "row_skip")), _stream()),
           "made_layernorm")
@@ -540,12 +447,6 @@ def layernorm_add(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ad
     ydt = dt_of(out2)
     if out is not None:
         assert out.dtype == out2.dtype and out.stride(1) == 1
-    if (_REC is not None and gamma is not None and row_skip is None and x.dtype == out2.dtype == add.dtype and D % 4 == 0 and D <= 2048
-            and x.stride(0) % 4 == 0 and out2.stride(0) % 4 == 0 and add.stride(0) % 4 == 0 and (out is None or out.stride(0) % 4 == 0)):
-        _REC.add(_lib.CHAIN_LAYERNORM, row=_row_stage(x=_p(x), ldx=x.stride(0), out=_p(out), ldo=out.stride(0) if out is not None else 0,
-                                                      out2=_p(out2), ldo2=out2.stride(0), add=_p(add), ld_add=add.stride(0),
-                                                      g=_p(_f32(gamma, "gamma")), b=_p(_f32(beta, "beta")), rows=rows, cols=D, dtype=ydt, eps=eps))
-        return out2
     check(lib().made_layernorm_add(_p(x), dt_of(x), x.stride(0), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
                                    _p(out), ydt, out.stride(0) if out is not None else 0, _p(add), dt_of(add), add.stride(0),
                                    _p(out2), out2.stride(0), rows, D, eps, _p(_f32(row_skip, "row_skip")), _stream()), "made_layernorm_add")

@@ -237,11 +237,6 @@ def softmax_bwd(S: Tensor, dP: Tensor, mask: Optional[Tensor], rows_per_mask: in
 
 def head_bias(x: Tensor, s: Tensor, bias: Tensor, H: int) -> None:
     rows, D = x.shape
-    from . import ops as _ops
-    if _ops._REC is not None and D % 4 == 0 and (D // H) % 4 == 0 and x.stride(0) % 4 == 0 and x.stride(1) == 1:
-        _ops._REC.add(_ops._lib.CHAIN_HEAD_BIAS, row=_ops._row_stage(x=_p(x), ldx=x.stride(0), s=_p(_f32(s, "s")), bias=_p(_f32(bias, "bias")),
-                                                                      rows=rows, cols=D, dtype=dt_of(x), H=H))
-        return
     check(lib().made_head_bias(_p(x), dt_of(x), x.stride(0), _p(_f32(s, "s")), _p(bias), rows, H, D // H, _stream()), "made_head_bias")
 
 
@@ -264,15 +259,6 @@ def gate_rows(x: Tensor, out: Tensor, *, G: Optional[Tensor] = None, gate: int =
     element index row*drop_ld + col // drop_col_div."""
     rows, cols = x.shape
     assert x.stride(1) == 1 and out.stride(1) == 1 and out.shape == x.shape and (G is None or (G.shape == x.shape and G.stride(1) == 1))
-    from . import ops as _ops
-    if (_ops._REC is not None and G is None and gate == 0 and scale == 1.0 and row_skip is None and x.dtype == out.dtype and cols % 4 == 0
-            and x.stride(0) % 4 == 0 and out.stride(0) % 4 == 0):
-        r = _ops._row_stage(x=_p(x), ldx=x.stride(0), out=_p(out), ldo=out.stride(0), rows=rows, cols=cols, dtype=dt_of(x),
-                            drop_ld=drop_ld, drop_col_div=max(int(drop_col_div), 1))
-        if drop is not None and drop[2] > 0.0:
-            set_drop(r.drop, drop)
-        _ops._REC.add(_ops._lib.CHAIN_GATE_ROWS, row=r)
-        return out
     check(lib().made_gate_rows(_p(x), dt_of(x), x.stride(0), _p(G), _dt(G), G.stride(0) if G is not None else 0, gate, scale,
                                _drop_ptr(drop), drop_ld, drop_col_div, _p(out), dt_of(out), out.stride(0), _p(_f32(row_skip, "row_skip")), rows, cols,
                                _stream()), "made_gate_rows")

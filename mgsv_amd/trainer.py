@@ -372,16 +372,7 @@ class MadeTrainer(MadeEngine):
         if not self.training_dropout or p <= 0.0:
             return None
         seed_dev = getattr(self, "_seed_dev", None)           # set while a TrainStepGraph is captured: the kernels read the seed there
-        if seed_dev is None:
-            seed_dev = getattr(self, "_chain_seed", None)    # chained decoder stages (made_chain): stage lists must not change per step
         return (seed_dev if seed_dev is not None else self.seed, dr.site_id(site), float(p))
-
-    def _chain_on(self) -> bool:
-        """The decoder's dependent 64-row launches as made_chain stages (one moment query; not while a graph is being captured: the
-        barrier base of a chain launch is a host-side count).  OPT-IN (MADE_CHAIN=1): bit-identical to the separate launches and
-        no faster -- a stage behind a grid barrier costs the same ~10 us as a stage behind a kernel boundary."""
-        return (os.environ.get("MADE_CHAIN", "0") == "1" and self.cfg.num_moment_queries == 1 and self.tc == torch.bfloat16
-                and getattr(self, "_seed_dev", None) is None and not torch.cuda.is_current_stream_capturing())
 
     # ------------------------------------------------------------------ training workspace
     def _train_buffers(self, B: int, Tv: int, Ta: int) -> Dict[str, Tensor]:
@@ -530,14 +521,6 @@ class MadeTrainer(MadeEngine):
         if c.predict_center == 1 and v_duration is None:
             raise ValueError("predict_center=1 needs v_duration (reference model/model_Uni.py:280-282)")
         self.seed = int(seed)
-        if self._chain_on():
-            if getattr(self, "_chain_seed_buf", None) is None:
-                self._chain_seed_buf = torch.zeros(1, device=self.device, dtype=torch.int64)
-                self._chain_fwd, self._chain_bwd = {}, {}
-            self._chain_seed = self._chain_seed_buf
-            self._chain_seed.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
-        else:
-            self._chain_seed = None
         B, Tv, _ = frame_feats.shape
         Ta = segment_feats.shape[1]
         concat = "concat" in c.mml_fusion
@@ -631,8 +614,8 @@ class MadeTrainer(MadeEngine):
         # ---- X-Pool (in-batch) + similarities + retrieval loss
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            if (Q == 1 and not regression and c.moment_query_type != "xpool" and c.detr_enc_layers > 0 and not self._dec_fused(B, L)
-                    and self._chain_seed is None and os.environ.get("MADE_DEC_EARLY", "1") != "0"):
+            if (Q == 1 and not regression and c.moment_query_type != "xpool" and c.detr_enc_layers > 0
+                    and os.environ.get("MADE_DEC_EARLY", "1") != "0"):
                 # the query side of decoder layer 0 depends on the clip-level vector and the weights only: here, beside the DETR encoder,
                 # instead of at the head of the decoder's chain of dependent launches (as MadeEngine does for the eval path)
                 dec_fill_tgt()
@@ -714,18 +697,8 @@ class MadeTrainer(MadeEngine):
         hs = ws["hs"]
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
         n_split = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))   # few queries, long memory: keys split over workgroups (knob for measurements)
-        fused = self._dec_fused(B, L)
         t3_stack = tw["dstack"]["tgt"][1:]                   # [nd, B*Q, D]: slot l + 1 = layer l's output (t3)
-        if fused:
-            # one moment query: every sample's chain through the six layers is independent -- one workgroup per sample walks the
-            # whole stack in ONE launch (made_dec_train_fwd) and fills the same stacks the launches below fill
-            self._dec_fused_launch("made_dec_train_fwd", B, L, ws, tw, mem3, mempos3, fus_mask, ca_scale, pd)
-        # the chain of dependent 64-row launches below is recorded and launched as made_chain stages (grid barriers instead of kernel
-        # boundaries); the wide attention in the middle of every layer is a launch of its own and splits the chain there
-        import contextlib
-        rec = ops.ChainRecorder(self._chain_fwd, self.device) if (self._chain_seed is not None and not fused) else contextlib.nullcontext()
-        with rec:
-          for l in range(0 if fused else nd):
+        for l in range(nd):
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
             tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
             qkv = tw[d + ".qkv"]
@@ -755,10 +728,9 @@ class MadeTrainer(MadeEngine):
                 ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t3, tw[f"d.{l + 1}.tq"])
             else:
                 ops.layernorm(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], out=t3)
-        if not fused:
-            # the shared output norm of every layer feeds the heads only, not the next layer: one launch over the [nd, B*Q] stack
-            # of layer outputs after the chain instead of one inside every layer
-            ops.layernorm(t3_stack.reshape(nd * B * Q, D), P["dec.norm.g"], P["dec.norm.b"], out=hs.view(nd * B * Q, D))
+        # the shared output norm of every layer feeds the heads only, not the next layer: one launch over the [nd, B*Q] stack
+        # of layer outputs after the chain instead of one inside every layer
+        ops.layernorm(t3_stack.reshape(nd * B * Q, D), P["dec.norm.g"], P["dec.norm.b"], out=hs.view(nd * B * Q, D))
         out["hs"] = hs.view(nd, B, Q, D)
 
         # ---- heads
@@ -887,72 +859,6 @@ class MadeTrainer(MadeEngine):
                    segs=[Seg(out=local, ldo=local.stride(1), rows_per_batch=T, out_batch_stride=local.stride(0))])
         ops.masked_mean(local, mask, out=tw[tag + ".mean"])
         ops.l2norm_rows(tw[tag + ".mean"], out_f32=vec)
-
-    # ------------------------------------------------------------------ fused decoder (one moment query)
-    def _dec_fused(self, B: int, L: int) -> bool:
-        c = self.cfg
-        # OPT-IN (MADE_DEC_FUSED=1): parity-green but measured SLOWER than the chain of 64-row launches it replaces (1.15 ms against
-        # ~0.9 ms per forward at B = 64, D = 512, L = 542 -- DESIGN.md 3b has the phase timeline: the per-sample streams are
-        # latency-serialised by the compiler's scheduling and the memory-space attention re-reads 71 MB of memory rows per layer)
-        if os.environ.get("MADE_DEC_FUSED", "0") != "1":
-            return False
-        D, H, Fd = c.D, c.detr_nheads, c.detr_dim_feedforward
-        lds = 4 * (D + 2048 + 2048 + D + 2 * H * D + 64 + H * ((L + 3) & ~3) + L * H)
-        return (c.num_moment_queries == 1 and "regression" not in c.mml_localization and D in (256, 512) and H == 8 and Fd % D == 0
-                and Fd <= 2048 and lds <= 160 * 1024 - 512)
-
-    def _dec_layers_desc(self) -> Tensor:
-        """device array of MadeDecTrainLayer: the kernel-facing weights, biases, norm parameters, gradient accumulators and dropout
-        sites of every decoder layer (all in buffers allocated once: the pointers never change)."""
-        if getattr(self, "_dec_desc", None) is None:
-            c, P, G = self.cfg, self.P, self.G
-            D, nd = c.D, c.detr_dec_layers
-            arr = (_lib.MadeDecTrainLayer * nd)()
-            for l in range(nd):
-                p, d = f"detr_transformer.decoder.layers.{l}", arr[l]
-                Wsa, Wsat, Win, Wint = P[p + ".sa.in.w"], P[p + ".sa.in.wt"], P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
-                for t_ in (Wsa, Wsat, Win, Wint, P[p + ".sa.out.wt"], P[p + ".ca.out.wt"], P[p + ".ff1.wt"], P[p + ".ff2.wt"]):
-                    assert t_.is_contiguous()
-                assert Wsat.shape == (D, 3 * D) and Wint.shape == (D, 3 * D) and P[p + ".sa.out.wt"].shape == (D, D)
-                d.sa_v_w, d.sa_out_w = Wsa[2 * D:].data_ptr(), P[p + ".sa.out.w"].data_ptr()
-                d.ca_q_w, d.ca_k_w, d.ca_v_w, d.ca_out_w = Win.data_ptr(), Win[D:].data_ptr(), Win[2 * D:].data_ptr(), P[p + ".ca.out.w"].data_ptr()
-                d.ff1_w, d.ff2_w = P[p + ".ff1.w"].data_ptr(), P[p + ".ff2.w"].data_ptr()
-                d.sa_v_wt, d.sa_out_wt, d.ca_in_wt = Wsat[:, 2 * D:].data_ptr(), P[p + ".sa.out.wt"].data_ptr(), Wint.data_ptr()
-                d.ca_out_wt, d.ff1_wt, d.ff2_wt = P[p + ".ca.out.wt"].data_ptr(), P[p + ".ff1.wt"].data_ptr(), P[p + ".ff2.wt"].data_ptr()
-                bsa, bin_ = P[p + ".sa.in.b"], P[p + ".ca.in.b"]
-                d.sa_v_b, d.sa_out_b, d.ca_q_b, d.ca_v_b = bsa[2 * D:].data_ptr(), P[p + ".sa.out.b"].data_ptr(), bin_.data_ptr(), bin_[2 * D:].data_ptr()
-                d.ca_out_b, d.ff1_b, d.ff2_b = P[p + ".ca.out.b"].data_ptr(), P[p + ".ff1.b"].data_ptr(), P[p + ".ff2.b"].data_ptr()
-                for k in ("ln1", "ln2", "ln3"):
-                    setattr(d, k + "_g", P[f"{p}.{k}.g"].data_ptr()); setattr(d, k + "_b", P[f"{p}.{k}.b"].data_ptr())
-                    setattr(d, f"g_{k}_g", G[f"{p}.{k}.g"].data_ptr()); setattr(d, f"g_{k}_b", G[f"{p}.{k}.b"].data_ptr())
-                d.g_ca_v_b = G[p + ".ca.in.b"][2 * D:].data_ptr()
-                for k in ("sa_attn", "drop1", "ca_attn", "drop2", "ffn_act", "drop3"):
-                    setattr(d, "site_" + k, dr.site_id(f"dec.{l}.{k}"))
-            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-            self._dec_desc = torch.from_numpy(raw).to(self.device)
-        return self._dec_desc
-
-    def _dec_fused_launch(self, fn: str, B: int, L: int, ws, tw, mem3: Tensor, mempos3: Tensor, fus_mask: Tensor, ca_scale: float, pd: float) -> None:
-        import ctypes as C
-        c, P = self.cfg, self.P
-        st = tw["dstack"]
-        a = _lib.MadeDecTrainArgs()
-        a.layers = self._dec_layers_desc().data_ptr()
-        a.n_layers, a.dtype, a.B, a.L, a.D, a.H, a.Fd = c.detr_dec_layers, ops.dt_of(mem3), B, L, c.D, c.detr_nheads, c.detr_dim_feedforward
-        assert mem3.is_contiguous() and mempos3.is_contiguous() and fus_mask.is_contiguous()
-        a.mem, a.mempos, a.key_mask = mem3.data_ptr(), mempos3.data_ptr(), fus_mask.data_ptr()
-        a.query_pos, a.norm_g, a.norm_b = P["query_embed"].data_ptr(), P["dec.norm.g"].data_ptr(), P["dec.norm.b"].data_ptr()
-        for k in ("tgt", "qkv", "att", "t_a", "t1", "t1q", "qc", "pooled", "attc", "t_b", "t2", "h", "t_c"):
-            setattr(a, k, st[k].data_ptr())
-        a.hs, a.GQ, a.s_sum = ws["hs"].data_ptr(), tw["GQ"].data_ptr(), tw["s_stack"].data_ptr()
-        a.scale, a.eps = float(ca_scale), 1e-5
-        drop = self._drop("dec.0.drop1", pd)
-        if drop is not None:
-            ops.set_drop(a.drop, drop)
-        stamps = getattr(self, "_dec_stamps", None)          # tools/dec_fused_stamps.py
-        if stamps is not None:
-            a.stamps = stamps[fn].data_ptr()
-        _lib.check(getattr(_lib.lib(), fn)(C.byref(a), torch.cuda.current_stream().cuda_stream), fn)
 
     def _xpool_train(self, video: Tensor, seg: Tensor, seg_mask: Optional[Tensor], ws, tw, B: int, S: int, key: str = "xa", pre: str = "x",
                      sims_out: Optional[Tensor] = None) -> None:

@@ -517,61 +517,3 @@ def test_posbn_relu_forward_backward_match_torch_batchnorm(T, dtype, tol, B, Tn,
     else:
         cos = torch.nn.functional.cosine_similarity(dx.float().reshape(-1), xr.grad.reshape(-1), dim=0)
         assert float(cos) >= 0.995
-
-
-@pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_chain_of_64_row_stages_matches_the_separate_launches(T, p_drop):
-    """made_chain: tiny-M Linears (plain, batched per head, with residual + dropout, ReLU + dropout, K = 1024) and the row operations
-    between them (LayerNorm with the `+ add` output, a second plain LayerNorm, per-head gate, head bias) behind ONE launch with
-    grid barriers between the stages -- bit-identical to launching them one by one, repeatedly (the barrier word keeps counting)."""
-    ops, tr = T
-    dev = "cuda"
-    Bq, D, H, Fd = 64, 512, 8, 1024
-    hd = D // H
-    g = torch.Generator(device="cpu").manual_seed(0)
-    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
-    W = {k: rnd(n, kk, sc=kk ** -0.5).bfloat16() for k, (n, kk) in dict(v=(D, D), o=(D, D), q=(D, D), f1=(Fd, D), f2=(D, Fd), kt=(D, D), vh=(D, D)).items()}
-    bias = {k: rnd(n, sc=0.1) for k, n in dict(v=D, o=D, q=D, f1=Fd, f2=D, vh=D).items()}
-    ln = [(1 + rnd(D, sc=0.1), rnd(D, sc=0.1)) for _ in range(3)]
-    x0, qp, s_h = rnd(Bq, D).bfloat16(), rnd(1, D, sc=0.3).bfloat16(), torch.rand(Bq, H, device=dev) + 0.5
-    seed = torch.full((1,), 1234, device=dev, dtype=torch.int64)
-    drop = lambda site: (seed, site, p_drop) if p_drop > 0 else None
-    E = lambda *s: torch.full(s, float("nan"), device=dev, dtype=torch.bfloat16)
-
-    def program():
-        v, att, ta, t1, t1q, qc, qpr, attc, tb, t2, hh, tcx, t3, hs = (E(Bq, D), E(Bq, D), E(Bq, D), E(Bq, D), E(Bq, D), E(Bq, D), E(Bq, H, D), E(Bq, D),
-                                                                       E(Bq, D), E(Bq, D), E(Bq, Fd), E(Bq, D), E(Bq, D), E(Bq, D))
-        ops.linear(x0, W["v"], bias["v"], out=v)
-        tr.gate_rows(v, att, drop=drop(1), drop_ld=H, drop_col_div=hd)
-        ops.linear(att, W["o"], bias["o"], R=x0, out=ta, drop=drop(2))
-        ops.layernorm_add(ta, ln[0][0], ln[0][1], qp.expand(Bq, D), t1, t1q)
-        ops.linear(t1q, W["q"], bias["q"], out=qc)
-        # per-head fold: q'_h = W_k,h^T qc_h (batch = heads, K = hd)
-        ops.linear(qc[:, :hd], W["kt"][:, :hd], None, M=Bq, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
-                   segs=[ops.Seg(out=qpr, ldo=D, rows_per_batch=1, out_batch_stride=qpr.stride(0), out_z_stride=D)])
-        # per-head projection back (batch = heads, N = hd) + head bias
-        pooled = qpr.view(Bq, H * D)
-        ops.linear(pooled[:, :D], W["vh"][:hd], None, M=Bq, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
-                   segs=[ops.Seg(out=attc, ldo=D, out_z_stride=hd)])
-        tr.head_bias(attc, s_h, bias["vh"], H)
-        ops.linear(attc, W["o"], bias["o"], R=t1, out=tb, drop=drop(3))
-        ops.layernorm(tb, ln[1][0], ln[1][1], out=t2)
-        ops.linear(t2, W["f1"], bias["f1"], act=ops.ACT_RELU, out=hh, drop=drop(4))
-        ops.linear(hh, W["f2"], bias["f2"], R=t2, out=tcx, drop=drop(5))
-        ops.layernorm_add(tcx, ln[2][0], ln[2][1], qp.expand(Bq, D), t3, t1q)
-        ops.layernorm(t3, ln[0][0], ln[0][1], out=hs)
-        return [v, att, ta, t1, t1q, qc, qpr, attc, tb, t2, hh, tcx, t3, hs]
-
-    ref = program()
-    torch.cuda.synchronize()
-    state = {}
-    for rep in range(3):
-        with ops.ChainRecorder(state, dev) as ch:
-            got = program()
-            n_rec = len(ch.stages)
-        assert n_rec == 14                                      # everything was held: one launch
-        torch.cuda.synchronize()
-        for i, (a, b) in enumerate(zip(ref, got)):
-            assert torch.equal(a, b), (rep, i, float((a.float() - b.float()).abs().max()))
-    assert state["count"] == 3 * 14 * ops.ChainRecorder.N_WG and int(state["barrier"]) == state["count"]
-    assert len(state["cache"]) == 1                             # the stage list was uploaded once

@@ -282,51 +282,6 @@ def test_captured_train_step_reads_seed_and_learning_rates_from_the_device():
     assert bool(moved[r0[0]:r0[1]].any()) and not bool(moved[r0[1]:].any())                         # only the temporal group has a rate
 
 
-@pytest.mark.parametrize("dtype,dropout", [("f32", True), ("f32", False), ("bf16", True)])
-def test_fused_decoder_forward_kernel_matches_the_launch_chain(dtype, dropout, monkeypatch):
-    """made_dec_train_fwd (one workgroup per sample walks all decoder layers; opt-in, MADE_DEC_FUSED=1) fills the same stacks as
-    the chain of made_linear / made_layernorm / made_attention_wide launches: same losses, same hs, same gradients downstream."""
-    from mgsv_amd.trainer import MadeTrainer
-    cfg, sd, inp = _setup(4, 20, 40)
-    trn = MadeTrainer(cfg, sd, dtype=dtype)
-    trn.training_dropout = dropout
-    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
-    args = (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("MADE_DEC_FUSED", mode)
-        assert trn._dec_fused(4, 60) == (mode == "1")
-        o = trn.forward_train(*args, seed=11, v_duration=t.get("v_duration"))
-        trn.backward()
-        torch.cuda.synchronize()
-        res[mode] = (float(o["localization_loss"]), o["hs"].float().clone(), trn.flat_grad.clone())
-    tol = 2e-5 if dtype == "f32" else 3e-2
-    assert abs(res["0"][0] - res["1"][0]) <= tol * abs(res["0"][0])
-    assert float((res["0"][1] - res["1"][1]).abs().max()) <= tol * float(res["0"][1].abs().max()) * 4
-    g0, g1 = res["0"][2], res["1"][2]
-    cos = float(torch.nn.functional.cosine_similarity(g0, g1, dim=0))
-    assert cos >= (1 - 1e-6 if dtype == "f32" else 0.995), cos
-
-
-def test_chained_decoder_stages_leave_the_step_bit_identical(monkeypatch):
-    """MADE_CHAIN=1: the decoder forward's 64-row launches recorded into made_chain stage lists (7 launches instead of ~90) -- same
-    kernels' bodies behind grid barriers, so the outputs and the gradients downstream are the separate launches' bit for bit."""
-    from mgsv_amd.trainer import MadeTrainer
-    cfg, sd, inp = _setup(4, 20, 40)
-    trn = MadeTrainer(cfg, sd, dtype="bf16")
-    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
-    args = (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
-    res = {}
-    for mode in ("0", "1", "1"):
-        monkeypatch.setenv("MADE_CHAIN", mode)
-        o = trn.forward_train(*args, seed=21, v_duration=t.get("v_duration"))
-        torch.cuda.synchronize()
-        res.setdefault(mode, []).append((o["hs"].clone(), o["pred_logits"].clone(), float(o["localization_loss"])))
-    assert len(trn._chain_fwd["cache"]) >= 2                  # stage lists were recorded and uploaded (once)
-    for got in res["1"]:
-        assert torch.equal(got[0], res["0"][0][0]) and torch.equal(got[1], res["0"][0][1]) and got[2] == res["0"][0][2]
-
-
 @pytest.mark.parametrize("tag", ["cls", "mlp", "tower2", "xpool_query", "feature_fuse"])
 def test_f32_variant_gradients_match_reference_fixture(golden_dir, tag):
     """The round-2 training variants straight against the reference's own train()-mode autograd (float64 fixture
