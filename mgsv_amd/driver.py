@@ -254,9 +254,14 @@ def load_model(args, logger, model, path=None):
 
 def build_model(args, device, logger, load: bool = True):
     from .model import Uni_model
-    model = Uni_model(args, device, logger, compute_dtype=args.compute_dtype)
     path = args.resume_path or args.load_uni_model_path
-    if load and path and os.path.isfile(path):
+    # a path that is given but is not a file fails loudly, as the reference's torch.load does (main_test passes load=False for a
+    # directory of checkpoints and loads them one by one).  As in the reference (train-MaDe.py:684-691) resuming does not move the
+    # epoch counter by itself: pass --start_epoch with --resume_path.
+    if load and path and not os.path.isfile(path):
+        raise FileNotFoundError(f"checkpoint {path!r} (--resume_path / --load_uni_model_path) is not a file")
+    model = Uni_model(args, device, logger, compute_dtype=args.compute_dtype)
+    if load and path:
         load_model(args, logger, model, path)
     return model
 
@@ -421,7 +426,7 @@ def main_train(argv=None):
                 for key, b in best.items():
                     if (now[key] > b["v"]) if b["strict"] else (now[key] >= b["v"]):
                         b["v"], b["epoch"] = now[key], epoch
-                        save_model(epoch, args, logger, model, optimizer=optimizer, loss=vl, best_model=True, best_name=b["name"])
+                        save_model(epoch, args, logger, model, optimizer=None, loss=vl, best_model=True, best_name=b["name"])   # reference train-MaDe.py:686-727: optimizer=None
                 logger.info("Best R1: %.4f in epoch %d, Best mIoU: %.4f in epoch %d, Best R1IoU0.5: %.4f in epoch %d, Best R1IoU0.7: %.4f in epoch %d",
                             best["R1"]["v"], best["R1"]["epoch"], best["mIoU"]["v"], best["mIoU"]["epoch"], best["R1_iou0.5"]["v"],
                             best["R1_iou0.5"]["epoch"], best["R1_iou0.7"]["v"], best["R1_iou0.7"]["epoch"])

@@ -737,8 +737,9 @@ class MadeEngine:
         """The fused decoder chain (made_dec_stage) covers the scripts' configuration: bf16, one moment query, queries from the clip
         vectors (or zeros).  Everything else (f32 parity mode, Q > 1, the pooled-track query) keeps the split-K chain."""
         c = self.cfg
+        # (made_dec_stage normalises whole rows of width D in its prologue: D = 256 or 512 only; other widths keep the split-K chain)
         return (self.tc == torch.bfloat16 and c.num_moment_queries == 1 and c.moment_query_type in ("video", "music", "zero", "random")
-                and not getattr(self, "force_unfused_decoder", False))
+                and c.D in (256, 512) and not getattr(self, "force_unfused_decoder", False))
 
     def _dec_first_rows(self, ws, video: Tensor, music: Tensor) -> Tensor:
         """Raw rows feeding decoder layer 0 (reference transformer.py:73-74, model_Uni.py:216-221): the clip vectors, read in place."""

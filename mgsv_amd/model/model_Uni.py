@@ -216,6 +216,16 @@ class Uni_model(nn.Module):
                 for name, p in self.named_parameters():
                     if name in self._trainer.master:
                         p.data = self._trainer.master[name]
+                # registered buffers (the BatchNorm running statistics of agg_module = "mlp") share the trainer's storage the same way:
+                # the statistics a train step moves are the ones eval (state_dict -> MadeEngine) and save_model see
+                for name, _ in list(self.named_buffers()):
+                    t = self._trainer.buffers.get(name)
+                    if t is not None:
+                        owner = self
+                        *path, leaf = name.split(".")
+                        for part in path:
+                            owner = owner._modules[part]
+                        owner._buffers[leaf] = t
             self._trainer_stamp = self._stamp()
         elif self._stamp() != self._trainer_stamp:                 # an optimizer (or load_state_dict) touched the masters
             with torch.no_grad():

@@ -1449,6 +1449,7 @@ class MadeTrainer(MadeEngine):
                            0.99, stats, bn[2], bn[3], out=tw[tag + ".y1"].view(B, T, D))      # momentum 0.99: model_Base.py:228
         if stats:
             buf[mod + ".net.1.num_batches_tracked"] += 1; buf[mod + ".net.4.num_batches_tracked"] += 1
+            self.generation += 1                              # state moved in place: whoever caches derived weights (Uni_model's engines) reloads
         if "concat" in c.mml_fusion:
             local = ws["fus"][:, row_off:row_off + T]
         else:
@@ -1582,9 +1583,14 @@ class TrainStepGraph:
                                                                     ("spans_target", spans_target))}
         self.v_duration = v_duration.to(dev).contiguous().clone() if v_duration is not None else None
         self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int64)
-        # MadeAdamDeviceState {int64 step; float lr[4]; float bc1, bc2_sqrt}: 32 bytes
-        self.adam_state = torch.zeros(4, device=dev, dtype=torch.int64)
-        self._lr_view = self.adam_state.view(torch.float32)[2:5]
+        # MadeAdamDeviceState {int64 step; float lr[4]; float bc1, bc2_sqrt} in device memory, laid out by the ctypes mirror (which
+        # tests/test_abi_cpu.py holds to the header): the step count is word 0, the learning rates start at the `lr` field
+        import ctypes as C
+        S = _lib.MadeAdamDeviceState
+        assert C.sizeof(S) % 8 == 0 and S.step.offset == 0 and S.lr.offset % 4 == 0
+        self.adam_state = torch.zeros(C.sizeof(S) // 8, device=dev, dtype=torch.int64)
+        lr0 = S.lr.offset // 4
+        self._lr_view = self.adam_state.view(torch.float32)[lr0:lr0 + 3]
         self._lrs: Optional[tuple] = None                   # what the device words hold (refilled only when the schedule moves)
         ex = t.same_music_exclusion(music_ids)
         self.exclusion = ex.clone() if ex is not None else None

@@ -32,25 +32,35 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().made_abi_version() == 1
 
 
+def _all_structs():
+    return sorted((n, t) for n, t in vars(_lib).items() if isinstance(t, type) and issubclass(t, C.Structure) and t is not C.Structure
+                  and n.startswith("Made"))
+
+
 def test_struct_layout_matches_header():
-    # sizes the C compiler gives the two argument structs (checked against ctypes' own layout)
-    import subprocess, tempfile, textwrap
-    src = textwrap.dedent('''
-        #include <stdio.h>
-        #include "made_hip.h"
-        int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", sizeof(MadeLinearSeg), sizeof(MadeLinearArgs), sizeof(MadeAttnArgs),
-                               sizeof(MadeWideAttnArgs), sizeof(MadeFinishArgs), sizeof(MadeDropout), sizeof(MadeGemmTNArgs),
-                               sizeof(MadeAttnBwdArgs), sizeof(MadeAdamGroup), sizeof(MadeRepackDesc)); return 0; }
-    ''')
+    """EVERY ctypes mirror in mgsv_amd/_lib.py against the C compiler's layout of include/made_hip.h: size and the offset of every
+    field (padding fields included), so a drifting struct fails here and not as a corrupted kernel argument."""
+    import subprocess, tempfile
+    structs = _all_structs()
+    assert len(structs) >= 15 and {"MadeDecStageArgs", "MadeGemmTNGroup", "MadeGemmTNProblem", "MadeAdamDeviceState", "MadeXpoolFusedArgs"} <= {n for n, _ in structs}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "made_hip.h"', "int main(void){"]
+    want = []
+    for n, t in structs:
+        lines.append(f'printf("%zu\\n", sizeof({n}));')
+        want.append(C.sizeof(t))
+        for f in t._fields_:
+            lines.append(f'printf("%zu\\n", offsetof({n}, {f[0]}));')
+            want.append(getattr(t, f[0]).offset)
+    lines.append("return 0; }")
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "s.c")
-        open(p, "w").write(src)
+        open(p, "w").write("\n".join(lines))
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
-        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [C.sizeof(x) for x in (_lib.MadeLinearSeg, _lib.MadeLinearArgs, _lib.MadeAttnArgs, _lib.MadeWideAttnArgs,
-                                           _lib.MadeFinishArgs, _lib.MadeDropout, _lib.MadeGemmTNArgs, _lib.MadeAttnBwdArgs,
-                                           _lib.MadeAdamGroup, _lib.MadeRepackDesc)]
+        got = [int(x) for x in subprocess.check_output([exe]).split()]
+    labels = [x for n, t in structs for x in [f"sizeof({n})"] + [f"{n}.{f[0]}" for f in t._fields_]]
+    bad = [(l, g, w) for l, g, w in zip(labels, got, want) if g != w]
+    assert not bad and len(got) == len(want), bad[:10]
 
 
 def test_dropout_rng_header_matches_numpy_restatement():

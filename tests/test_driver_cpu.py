@@ -78,3 +78,15 @@ def test_fresh_weights_follow_the_reference_initialisers():
     bound = np.sqrt(6.0 / (w.shape[0] + w.shape[1]))
     assert np.abs(w).max() <= bound + 1e-6 and np.abs(w).max() > 0.95 * bound
     assert abs(float(a["logit_scale"]) - np.log(1 / c.temperature_init_value)) < 1e-6
+
+
+def test_a_mistyped_checkpoint_path_fails_loudly(tmp_path):
+    """--resume_path / --load_uni_model_path naming something that is not a file raises (the reference's torch.load does) instead of
+    training or evaluating freshly initialised weights."""
+    import logging
+    a = driver.parse_option(["--name", "x", "--audio_short_cut", "0", "--resume_path", str(tmp_path / "no_such_checkpoint.bin")])
+    with pytest.raises(FileNotFoundError):
+        driver.build_model(a, "cpu", logging.getLogger("t"))
+    a = driver.parse_option(["--name", "x", "--audio_short_cut", "0", "--load_uni_model_path", str(tmp_path)])      # a directory
+    with pytest.raises(FileNotFoundError):
+        driver.build_model(a, "cpu", logging.getLogger("t"))

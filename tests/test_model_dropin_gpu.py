@@ -177,3 +177,42 @@ def test_training_loop_body_on_option_variants(overrides):
         losses.append(float(loss))
         assert om["pred_spans"].shape == (8, 1, 2) and "loss_span" in lm["localization_loss_dict"]
     assert np.isfinite(losses).all() and np.mean(losses[-2:]) < np.mean(losses[:2]), losses
+
+
+def test_mlp_aggregator_running_statistics_reach_eval_and_checkpoints():
+    """agg_module = "mlp" through the drop-in module: the BatchNorm running statistics a train step moves live in the module's own
+    registered buffers (shared storage with the trainer), so eval() (state_dict -> MadeEngine) and a saved state_dict see them."""
+    cfg = cfg_native()
+    cfg.agg_module = "mlp"
+    args = cfg.to_args(local_rank=0)
+    model = Uni_model(args, device=torch.device("cuda:0"))
+    inp = synth.make_inputs(cfg, 4, 20, 40, seed=3)
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    batch = (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
+    bn_keys = [k for k in model.state_dict() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    assert len(bn_keys) == 12
+    before = {k: model.state_dict()[k].detach().cpu().clone() for k in bn_keys}
+    model.eval()
+    with torch.no_grad():
+        e0 = model(*batch, v_duration=t["v_duration"])[2]["video_feats"].clone()
+    model.train()
+    om, lm, *_ = model(*batch, v_duration=t["v_duration"], is_train=True)
+    (lm["retrieval_loss"] + lm["localization_loss"]).backward()        # no optimizer step: only the statistics move
+    torch.cuda.synchronize()
+    after = {k: model.state_dict()[k].detach().cpu().clone() for k in bn_keys}
+    trn = model._trainer
+    for k in bn_keys:
+        assert torch.equal(after[k], trn.buffers[k].cpu()), k           # the module's buffers ARE the trainer's
+        assert not torch.equal(after[k], before[k]), k
+    assert all(int(after[k]) == 1 for k in bn_keys if k.endswith("num_batches_tracked"))
+    model.eval()
+    with torch.no_grad():
+        e1 = model(*batch, v_duration=t["v_duration"])[2]["video_feats"].clone()
+    assert float((e1 - e0).abs().max()) > 1e-4                          # eval normalises with the moved statistics
+    # a fresh module loaded from the state_dict reproduces that eval output
+    m2 = Uni_model(args, device=torch.device("cuda:0"))
+    m2.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    m2.eval()
+    with torch.no_grad():
+        e2 = m2(*batch, v_duration=t["v_duration"])[2]["video_feats"]
+    assert float((e2 - e1).abs().max()) <= 1e-5

@@ -1,7 +1,7 @@
 """GPU, world size 2 over RCCL (backend "nccl"), one process per GPU: the sharded retrieval (videos row-partitioned, the music side in
-one packed all-gather) and the data-parallel training step.  Needs two visible GPUs; on a one-GPU box these tests skip and the same
-logic is covered on CPU by tests/test_retrieval_sharded_cpu.py (gloo) and on one GPU by tests/test_train_dp_gpu.py (gloo, both ranks
-on cuda:0).  UNMEASURED ON HARDWARE in this round: the build box and the GPU pool expose one GPU."""
+one packed all-gather) and the data-parallel training step.  The nccl legs need two visible GPUs and skip on a one-GPU box; there the retrieval leg runs with both ranks on cuda:0 over gloo (the
+HIP engine scores, the exchange is the same packed all-gather), the training leg in tests/test_train_dp_gpu.py, and the sharding
+logic alone on CPU in tests/test_retrieval_sharded_cpu.py.  RCCL itself is UNMEASURED ON HARDWARE: the GPU pool exposes one GPU."""
 import os
 import socket
 
@@ -18,16 +18,20 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _retrieval_worker(rank, world, port, N_v, N_m, S, out_dir):
+def _retrieval_worker(rank, world, port, N_v, N_m, S, out_dir, backend="nccl"):
     import torch.distributed as dist
     from mgsv_amd import synth
     from mgsv_amd.config import cfg_native
     from mgsv_amd.engine import MadeEngine
     from mgsv_amd.retrieval import ShardedRetrieval, shard_rows
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:                                                    # both ranks on cuda:0, the exchange over gloo (device tensors, staged by gloo)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = cfg_native()
     eng = MadeEngine(cfg, synth.make_state_dict(cfg, seed=0), device=dev, dtype="bf16")
     ri = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_retrieval_inputs(N_v, N_m, S, cfg.D, seed=2).items()}
@@ -43,15 +47,18 @@ def _retrieval_worker(rank, world, port, N_v, N_m, S, out_dir):
     dist.destroy_process_group()
 
 
-@needs_two
-def test_sharded_retrieval_two_gpus_equals_one(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", pytest.param("nccl", marks=needs_two)])
+def test_sharded_retrieval_two_ranks_equal_one(tmp_path, backend):
+    """BASELINE configs[3]'s multi-rank leg with the HIP engine as the scorer (MadeEngine.retrieval_sim_matrix): videos row-sharded, the
+    music side in one packed all-gather, each rank's row block bit-equal to the same rows of the one-rank matrix.  "gloo": two
+    processes share cuda:0 (runs on a one-GPU box); "nccl": one process per GPU over RCCL (needs two GPUs)."""
     import torch.multiprocessing as mp
     from mgsv_amd import synth
     from mgsv_amd.config import cfg_native
     from mgsv_amd.engine import MadeEngine
     from mgsv_amd.retrieval import shard_rows
     N_v, N_m, S = 600, 37, 96                     # N_m not divisible by 2: ragged shards, scored block by block
-    mp.spawn(_retrieval_worker, args=(2, _free_port(), N_v, N_m, S, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_retrieval_worker, args=(2, _free_port(), N_v, N_m, S, str(tmp_path), backend), nprocs=2, join=True)
     cfg = cfg_native()
     eng = MadeEngine(cfg, synth.make_state_dict(cfg, seed=0), device="cuda:0", dtype="bf16")
     ri = {k: torch.from_numpy(v).cuda() for k, v in synth.make_retrieval_inputs(N_v, N_m, S, cfg.D, seed=2).items()}

@@ -654,6 +654,9 @@ def test_xpool_tail_and_clip_loss(dev):
 
 
 # -------------------------------------------------------------------------------- matcher + criterion
+MATCHER_FIXTURE_TIE_SAMPLES = -1      # filled in from the first MI355X run of this round
+
+
 def test_matcher_golden_fixture_bit_exact(dev, golden_dir):
     fix = np.load(os.path.join(golden_dir, "matcher.npz"))
     lg, sp, tg = (torch.from_numpy(fix[k]).to(dev) for k in ("kat_logits", "kat_spans", "kat_targets"))
@@ -661,7 +664,8 @@ def test_matcher_golden_fixture_bit_exact(dev, golden_dir):
         pi, ti, cnt, status, _ = ops.hungarian_match(lg, sp, tg, fg, 1.0, 1.0, 1.0)
         torch.cuda.synchronize()
         assert pi.cpu().tolist() == [[0, 2]] and ti.cpu().tolist() == [[1, 0]] and int(status) == 0
-    n_fused_equal = 0
+    from scipy.optimize import linear_sum_assignment as scipy_lsa
+    n_fused_equal, differing = 0, []
     for n in range(int(fix["n_cases"])):
         lg, sp, tg = (torch.from_numpy(fix[f"c{n}_{k}"]).to(dev) for k in ("logits", "spans", "targets"))
         fg = int(fix[f"c{n}_fg"])
@@ -679,25 +683,35 @@ def test_matcher_golden_fixture_bit_exact(dev, golden_dir):
         assert int(status) == 0
         assert np.array_equal(pi.cpu().numpy(), fix[f"c{n}_pred_idx"][:, :w]), n
         assert np.array_equal(ti.cpu().numpy(), fix[f"c{n}_tgt_idx"][:, :w]), n
-        # (2) fused cost + assignment: the cost block matches the oracle to the last bits of exp(); the
-        # assignment is identical unless two solutions tie to ~1e-6 (then it must still be optimal)
+        # (2) fused cost + assignment: the cost block matches the oracle to the last bits of exp() (the reference's CPU softmax is a
+        # 1-ulp SLEEF expf whose bits differ between AVX2 and AVX-512 hosts; the kernel rounds the exact value once), and the
+        # assignment is SciPy's on THAT block, bit-exact
         pi2, ti2, cnt2, status2, cost = ops.hungarian_match(lg, sp, tg, fg)
         torch.cuda.synchronize()
-        np.testing.assert_allclose(np.where(cost_in.numpy() != 0, cost.cpu().numpy(), 0), cost_in.numpy(), atol=2e-6, rtol=0)
+        cost_np = cost.cpu().numpy()
+        np.testing.assert_allclose(np.where(cost_in.numpy() != 0, cost_np, 0), cost_in.numpy(), atol=2e-6, rtol=0)
         for b_ in range(B_):
             k = int(cnt2[b_])
             assert k == int(cnt[b_])
             a, bb = pi2[b_, :k].cpu().numpy(), ti2[b_, :k].cpu().numpy()
+            g_kept = int((fix[f"c{n}_targets"][b_, :, 1] != 0).sum())
+            si, sj = scipy_lsa(cost_np[b_, :, :g_kept])
+            assert np.array_equal(a, si) and np.array_equal(bb, sj), (n, b_)
             ra, rb = fix[f"c{n}_pred_idx"][b_, :k], fix[f"c{n}_tgt_idx"][b_, :k]
-            tot = float(cost_in[b_].numpy()[a, bb].sum()), float(cost_in[b_].numpy()[ra, rb].sum())
-            assert abs(tot[0] - tot[1]) <= 2e-5, (n, b_, tot)
-            n_fused_equal += int(np.array_equal(a, ra) and np.array_equal(bb, rb))
+            same = np.array_equal(a, ra) and np.array_equal(bb, rb)
+            n_fused_equal += int(same)
+            if not same:
+                # a sample assigned differently from the fixture: both assignments must be optimal on the REFERENCE's f32 costs up to
+                # the rounding of those costs (one f32 ulp of a cost of magnitude <= 16 per matched pair), i.e. the reference's own
+                # cost block does not separate them -- a tie that SciPy breaks by the last bit of exp()
+                c64 = cost_in[b_].numpy().astype(np.float64)
+                tot = float(c64[a, bb].sum()), float(c64[ra, rb].sum())
+                assert abs(tot[0] - tot[1]) <= k * 2.0 ** -20, (n, b_, tot)
+                differing.append((n, b_, tot[0] - tot[1]))
     total = sum(fix[f"c{n}_logits"].shape[0] for n in range(int(fix["n_cases"])))
-    # The fused cost evaluates the class probability in f64 and rounds once (correctly rounded); torch's CPU softmax is a 1-ulp f32
-    # evaluation.  A sample's assignment can only differ where two assignments tie to the last bits of the cost (checked above: the
-    # totals agree to 2e-5); the count is recorded so that a change of it is seen.
-    print(f"matcher fixture: {total - n_fused_equal} of {total} samples assigned differently from SciPy-on-torch-CPU-costs (all exact-cost ties)")
-    assert n_fused_equal >= total - 3, (n_fused_equal, total)      # near-ties are rare even in the adversarial cases
+    print(f"matcher fixture: {total - n_fused_equal} of {total} samples assigned differently from SciPy-on-torch-CPU-costs: {differing}")
+    # asserted constant (recorded on MI355X, round 3): a change of this count means the cost arithmetic moved
+    assert total - n_fused_equal == MATCHER_FIXTURE_TIE_SAMPLES, (total - n_fused_equal, differing)
 
 
 def test_matcher_layers_ties_and_invalid(dev):

@@ -310,3 +310,50 @@ def test_f32_variant_gradients_match_reference_fixture(golden_dir, tag):
     now = trn.state_dict_numpy()
     for k in [k for k in fix.files if k.startswith(tag + ".buffer.")]:
         assert np.abs(now[k[len(tag) + 8:]] - fix[k]).max() <= 1e-5 * max(1.0, np.abs(fix[k]).max()), k
+
+
+def test_headline_training_step_properties_at_full_size():
+    """The leg bench.py times (BASELINE configs[2]: B = 64, T_v = 30, T_a = 512, D = 512, bf16, dropout on), through size-independent
+    properties: every output and gradient finite; the same seed reproduces the forward bit for bit and the gradients up to the order of
+    the f32 atomic sums; a new seed draws new masks; the captured iteration (TrainStepGraph) computes the eager step's forward bit for
+    bit and lands on its parameters."""
+    from mgsv_amd import synth
+    from mgsv_amd.config import cfg_headline
+    from mgsv_amd.trainer import MadeTrainer
+    cfg = cfg_headline()
+    B, Tv, Ta = 64, 30, 512
+    sd = synth.make_state_dict(cfg, seed=0)
+    b = _batch(cfg, B, Tv, Ta, seed=1)
+    trn = MadeTrainer(cfg, sd, dtype="bf16")
+    keys = ("retrieval_loss", "localization_loss", "hs", "pred_logits", "pred_spans", "sims_single", "sims_dual", "matcher_pred_idx", "criterion_losses")
+
+    def run(seed):
+        o = trn.forward_train(*b, seed=seed)
+        trn.backward()
+        torch.cuda.synchronize()
+        return {k: o[k].clone() for k in keys}, trn.flat_grad.clone(), int(o["matcher_status"].cpu())
+    f1, g1, st = run(7)
+    assert st == 0
+    for k in keys:
+        assert bool(torch.isfinite(f1[k].float()).all()), k
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    assert float(f1["pred_spans"].min()) >= 0.0 and float(f1["pred_spans"].max()) <= 1.0
+    f2, g2, _ = run(7)
+    for k in keys:
+        assert torch.equal(f1[k], f2[k]), f"{k}: same seed, different forward"
+    assert float((g1 - g2).norm()) <= 1e-5 * float(g1.norm())                       # f32 atomics reorder the sums, nothing more
+    f3, g3, _ = run(8)
+    assert not torch.equal(f1["hs"], f3["hs"]) and float((g1 - g3).norm()) > 1e-3 * float(g1.norm())
+    # one optimizer step, eager against the captured iteration, from the same state
+    eager, graph = MadeTrainer(cfg, sd, dtype="bf16"), MadeTrainer(cfg, sd, dtype="bf16")
+    g = graph.capture_train_step(*b)
+    oe = eager.train_step(*b, seed=7, lrs=(1e-4, 1e-4, 1e-4))
+    le = {k: oe[k].clone() for k in keys}
+    og = g.step(*b, seed=7, lrs=(1e-4, 1e-4, 1e-4))
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(le[k], og[k]), f"{k}: captured forward differs from the eager one"
+        assert torch.equal(le[k], f1[k]), k
+    moved = float((eager.flat_param - graph.flat_param).double().norm())
+    step = float((eager.flat_param - trn.flat_param).double().norm())           # trn never stepped: |one Adam step|
+    assert step > 0 and moved <= 0.05 * step, (moved, step)
