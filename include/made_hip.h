@@ -163,6 +163,10 @@ typedef struct MadeLinearArgs {
        (residual, dropout index, rows_per_batch addressing) keeps using the PHYSICAL row, so valid rows are bit-identical to
        the ungathered call and padded rows are simply never read or written.  M stays the physical row count. */
     const int32_t* row_index; const int32_t* n_rows;
+    /* per-(row, problem) scaled bias (tiny-M kernel only): the bias term is bias[z * bias_z_stride + col] * bias_row_scale[row * batch + z]
+       for problem z of a batched call -- the value-projection bias of the memory-space cross-attention, whose dropped attention
+       weights no longer sum to 1 (reference music_detr/transformer.py:293-296 under dropout; replaces a made_head_bias launch) */
+    const float* bias_row_scale; int64_t bias_z_stride;
 } MadeLinearArgs;
 
 int made_linear(const MadeLinearArgs* args, void* stream);
@@ -184,14 +188,14 @@ int made_linear_variant(const MadeLinearArgs* args);
 
 /* One stage of the moment-DETR decoder's chain of B*Q-row Linears with the PREVIOUS stage's LayerNorm in its prologue
  * (reference music_detr/transformer.py:273-307, forward_post; :136 for the shared output norm):
- *     x   = LayerNorm(Zin; ln_g, ln_b)          Zin raw f32 rows [M, K]; ln_g == NULL: x = Zin
+ *     x   = LayerNorm(Zin; ln_g, ln_b)          Zin raw rows [M, K] (f32, or bf16 in the training chain); ln_g == NULL: x = Zin
  *     x2  = LayerNorm(x; ln2_g, ln2_b)          optional -> x2_out (bf16): the decoder output of the previous layer
  *     A   = bf16(x) (+ add[row % add_row_mod])  add: bf16 rows of K elements (query_pos) or NULL; x itself -> x_out (bf16) or NULL
  *     out = act(A W^T + bias) + R               R: bf16 [M, N] or NULL; res_from_x: + bf16(x) instead (needs N == K, no add)
  * bf16 MFMA, f32 accumulate; K (the LayerNorm width) is 256 or 512; out is f32 (raw rows for the next stage's norm) or bf16.
  * One launch of ceil(N / 32) x ceil(M / 64) workgroups, no split-K workspace, no finish launch. */
 typedef struct MadeDecStageArgs {
-    const float* Zin; int64_t ldz;
+    const void*  Zin; int64_t ldz;                 /* f32 rows (zin_dtype = MADE_F32, the eval chain) or bf16 rows (MADE_BF16, the training chain) */
     const float* ln_g; const float* ln_b;
     const float* ln2_g; const float* ln2_b; void* x2_out; int64_t ldx2;
     const void*  add; int64_t add_row_mod;
@@ -201,6 +205,11 @@ typedef struct MadeDecStageArgs {
     void*        out; int64_t ldo;
     int32_t      out_dtype; int32_t act; int32_t res_from_x; float eps;
     int64_t      M, N, K;
+    /* training chain (bf16 Zin only): A = bf16(x) + add is also stored (a_out: the weight gradient's operand), and the stateless
+       dropout of this header follows the activation -- element index row * drop_ld + col / max(drop_col_div, 1) */
+    int32_t      zin_dtype; int32_t drop_col_div;
+    void*        a_out; int64_t lda_out;
+    MadeDropout  drop; int64_t drop_ld;
 } MadeDecStageArgs;
 int made_dec_stage(const MadeDecStageArgs* args, void* stream);
 
@@ -283,9 +292,40 @@ typedef struct MadeWideAttnArgs {
     /* training path */
     MadeDropout drop;          /* dropout on the attention weights, element index ((b*NQ1 + i1)*NQ2 + i2)*L + key */
     float*  sum_out;           /* [B, NQ1*NQ2] f32 or NULL: sum of the dropped weights of each row (1 without dropout) */
+    float*  lse_out;           /* [B, NQ1*NQ2] f32 or NULL: log-sum-exp of the scaled scores of each row (saved for made_attention_wide_bwd) */
+    uint32_t* tickets;         /* n_split > 1: NULL = a second launch merges the key slices; else [B * query tiles] words, zero before the
+                                  first call, and the workgroup that finishes an (entry, query tile) last merges its slices in this launch
+                                  (in slice order: deterministic) and leaves the word at zero */
 } MadeWideAttnArgs;
 
 int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
+
+/* made_attention_wide_bwd: backward of made_attention_wide for the decoder's memory-space cross-attention (few query rows per sample,
+ * bf16), one launch per decoder layer (reference music_detr/transformer.py:293-296 under model.train(); replaces a batched Linear,
+ * made_softmax_bwd, a batched made_gemm_tn and made_head_bias_bwd on the backward's critical path):
+ *   P_j = exp(scale <Q_q, K_j> - lse_q) on valid keys, Pd = dropout(P) (the forward's mask: index (b*NQ + q)*L + j),
+ *   dPd_j = <dO_q, V_j> + extra_q,  dS_j = scale P_j (dropout'(dPd_j) - delta_q),  delta_q = <dO_q, O_q> + extra_q ssum_q,
+ *   dQ_q = sum_j dS_j K_j.   Pd and dS ([B, NQ, ld_p] bf16, zero on masked keys and on the pad columns L..ld_p-1) are written for
+ *   the memory-gradient products dV = Pd^T dO, dK = dS^T Q that follow as one batched made_gemm_tn over all layers.
+ * extra_q = gradient of the sum of row q's dropped weights (the value bias enters the forward as ssum_q b_v): `extra` [B, NQ] f32, or,
+ * when `extra` is NULL and `dattc` is given, reduced here as <dattc[b, q*hd .. q*hd+hd), vbias[q*hd ..)> (one head per query row).
+ * O = the forward's output rows, lse / ssum = its lse_out / sum_out.  Keys may be split over workgroups (n_split, part_dq
+ * [B, n_split, NQ, D] f32, tickets [B] zeroed words left at zero); the slices' dQ are summed in slice order. NQ <= 8, D in {256, 512}. */
+typedef struct MadeWideAttnBwdArgs {
+    const void *Q, *dO, *O, *K, *V;
+    const float* key_mask;                 /* [B, L] or NULL */
+    const float *lse, *ssum;               /* [B, NQ]; ssum may be NULL (= 1) */
+    const float* extra;                    /* [B, NQ] or NULL */
+    const void* dattc; int64_t ld_dattc; const float* vbias; int64_t hd;
+    void *Pd, *dS; int64_t p_bs, ld_p;
+    void* dQ; int64_t dq_bs, ld_dq;
+    int64_t B, NQ, L, D;
+    int64_t q_bs, ld_q, do_bs, ld_do, o_bs, ld_o, k_bs, ldk, v_bs, ldv;
+    float scale; int32_t _pad;
+    int64_t n_split; float* part_dq; uint32_t* tickets;
+    MadeDropout drop;
+} MadeWideAttnBwdArgs;
+int made_attention_wide_bwd(const MadeWideAttnBwdArgs* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).                                                                   */
@@ -577,6 +617,16 @@ int made_head_bias(void* x, int32_t x_dtype, int64_t ldx, const float* s, const 
                    void* stream);
 int made_head_bias_bwd(const void* dy, int32_t dtype, int64_t ld, const float* s, const float* bias, float* dbias, float* ds,
                        int64_t rows, int64_t H, int64_t hd, void* stream);
+
+/* made_layernorm_bwd2: two chained LayerNorms backward in one pass -- the decoder layer's norm 3 followed by the shared output norm
+ * (reference music_detr/transformer.py:306 and :136): with t3 = LN_a(xa) and hs = LN_b(xb = the saved t3),
+ *   g = LN_b'(dy) + add,  dx = LN_a'(g),  dx_drop = dropout(dx)  (element index row * drop_ld + col);
+ * dgamma / dbeta of both norms are accumulated.  All row tensors share `dtype`; D <= 1024. */
+int made_layernorm_bwd2(const void* xa, const float* gamma_a, int64_t ldxa, const void* xb, const float* gamma_b, int64_t ldxb,
+                        const void* dy, int64_t lddy, const void* add, int64_t ld_add, void* dx, int64_t lddx,
+                        void* dx_drop, int64_t lddxd, const MadeDropout* drop, int64_t drop_ld, int32_t dtype,
+                        float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, int64_t rows, int64_t D, float eps,
+                        void* stream);
 
 /* made_gate_rows: out[r, c] = dropout(x[r, c] * act'(G[r, c]) * scale)  (element index of the dropout r*drop_ld + c/drop_col_div,
  * drop_col_div <= 0 meaning 1: with drop_col_div = head width and drop_ld = H the mask is one draw per (row, head) -- the

@@ -45,7 +45,8 @@ class MadeLinearArgs(C.Structure):
                 ("split_ws", vp),
                 ("seg", MadeLinearSeg * 4),
                 ("G", vp), ("g_dtype", i32), ("gate", i32), ("ldg", i64), ("gate_scale", f32), ("z_dtype", i32),
-                ("Zout", vp), ("ldz", i64), ("drop", MadeDropout), ("drop_ld", i64), ("row_index", vp), ("n_rows", vp)]
+                ("Zout", vp), ("ldz", i64), ("drop", MadeDropout), ("drop_ld", i64), ("row_index", vp), ("n_rows", vp),
+                ("bias_row_scale", vp), ("bias_z_stride", i64)]
 
 
 class MadeFinishArgs(C.Structure):
@@ -64,7 +65,8 @@ class MadeDecStageArgs(C.Structure):
                 ("add", vp), ("add_row_mod", i64), ("x_out", vp), ("ldx", i64),
                 ("W", vp), ("ldw", i64), ("bias", vp), ("R", vp), ("ldr", i64), ("out", vp), ("ldo", i64),
                 ("out_dtype", i32), ("act", i32), ("res_from_x", i32), ("eps", f32),
-                ("M", i64), ("N", i64), ("K", i64)]
+                ("M", i64), ("N", i64), ("K", i64),
+                ("zin_dtype", i32), ("drop_col_div", i32), ("a_out", vp), ("lda_out", i64), ("drop", MadeDropout), ("drop_ld", i64)]
 
 
 class MadeAttnArgs(C.Structure):
@@ -103,7 +105,15 @@ class MadeWideAttnArgs(C.Structure):
                 ("q_bs", i64), ("q_s1", i64), ("q_s2", i64), ("k_bs", i64), ("ldk", i64), ("kadd_bs", i64), ("ldkadd", i64),
                 ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("o_s1", i64), ("o_s2", i64),
                 ("scale", f32), ("_pad", i32),
-                ("n_split", i64), ("part_o", vp), ("part_ml", vp), ("drop", MadeDropout), ("sum_out", vp)]
+                ("n_split", i64), ("part_o", vp), ("part_ml", vp), ("drop", MadeDropout), ("sum_out", vp),
+                ("lse_out", vp), ("tickets", vp)]
+
+
+class MadeWideAttnBwdArgs(C.Structure):
+    _fields_ = ([(k, vp) for k in ("Q", "dO", "O", "K", "V", "key_mask", "lse", "ssum", "extra", "dattc")] + [("ld_dattc", i64), ("vbias", vp), ("hd", i64),
+                ("Pd", vp), ("dS", vp), ("p_bs", i64), ("ld_p", i64), ("dQ", vp), ("dq_bs", i64), ("ld_dq", i64)] +
+                [(k, i64) for k in ("B", "NQ", "L", "D", "q_bs", "ld_q", "do_bs", "ld_do", "o_bs", "ld_o", "k_bs", "ldk", "v_bs", "ldv")] +
+                [("scale", f32), ("_pad", i32), ("n_split", i64), ("part_dq", vp), ("tickets", vp), ("drop", MadeDropout)])
 
 
 class MadeGemmTNArgs(C.Structure):
@@ -149,6 +159,7 @@ SIGNATURES = {
     "made_dec_stage": (C.c_int, [C.POINTER(MadeDecStageArgs), vp]),
     "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
     "made_attention_wide": (C.c_int, [C.POINTER(MadeWideAttnArgs), vp]),
+    "made_attention_wide_bwd": (C.c_int, [C.POINTER(MadeWideAttnBwdArgs), vp]),
     "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp, vp]),
     "made_layernorm_add": (C.c_int, [vp, i32, i64, vp, vp, vp, i32, i64, vp, i32, i64, vp, i64, i64, i64, f32, vp, vp]),
     "made_cast_mask_rows": (C.c_int, [vp, i64, vp, vp, i32, i64, i64, i64, vp]),
@@ -162,6 +173,8 @@ SIGNATURES = {
     "made_attention_bwd": (C.c_int, [C.POINTER(MadeAttnBwdArgs), vp]),
     "made_layernorm_bwd": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i64,
                                      C.POINTER(MadeDropout), i64, vp, vp, i64, i64, f32, vp, vp]),
+    "made_layernorm_bwd2": (C.c_int, [vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, C.POINTER(MadeDropout), i64, i32,
+                                      vp, vp, vp, vp, i64, i64, f32, vp]),
     "made_pool_bwd": (C.c_int, [vp, vp, vp, vp, i32, i64, i64, vp, i32, i64, i64, vp, i32, i64, i64, i64, i64, i64, f32, vp]),
     "made_l2norm_bwd": (C.c_int, [vp, i32, i64, vp, i64, i64, vp, i64, i32, vp, i32, i64, i64, i64, f32, vp]),
     "made_clip_loss_bwd": (C.c_int, [vp, i64, i64, vp, f32, vp, vp, vp, vp, i32, vp, vp, vp]),

@@ -352,21 +352,93 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
     const float sd_tot = sd_run + __shfl_xor(sd_run, 32);
-    if (my_q >= nq_total) return;
-    if (a.sum_out && nsplit == 1 && sl == 0 && hh == 0) a.sum_out[b * nq_total + my_q] = a.drop.p > 0.f ? sd_tot * inv : 1.f;
+    const bool live_q = my_q < nq_total;
+    if (nsplit == 1 && !live_q) return;
+    if (nsplit == 1 && sl == 0 && hh == 0) {
+        if (a.sum_out) a.sum_out[b * nq_total + my_q] = a.drop.p > 0.f ? sd_tot * inv : 1.f;
+        if (a.lse_out) a.lse_out[b * nq_total + my_q] = m_run + logf(l_tot);
+    }
     if (nsplit > 1) {
-        // un-normalised partial result of this key slice; made_attention_wide_combine merges the slices
-        const int64_t prow = (b * nsplit + blockIdx.z) * nq_total + my_q;
-        float* po = a.part_o + prow * D + sl * DS;
+        // un-normalised partial result of this key slice
+        const int64_t prow = (b * nsplit + blockIdx.z) * nq_total + (live_q ? my_q : 0);
+        if (live_q) {
+            float* po = a.part_o + prow * D + sl * DS;
 #pragma unroll
-        for (int d = 0; d < NDT; ++d)
+            for (int d = 0; d < NDT; ++d)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4 pk; pk[0] = o[d][4 * g4]; pk[1] = o[d][4 * g4 + 1]; pk[2] = o[d][4 * g4 + 2]; pk[3] = o[d][4 * g4 + 3];
-                *(f32x4*)(po + d * 32 + 8 * g4 + 4 * hh) = pk;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 pk; pk[0] = o[d][4 * g4]; pk[1] = o[d][4 * g4 + 1]; pk[2] = o[d][4 * g4 + 2]; pk[3] = o[d][4 * g4 + 3];
+                    *(f32x4*)(po + d * 32 + 8 * g4 + 4 * hh) = pk;
+                }
+            if (sl == 0 && hh == 0) {
+                a.part_ml[prow * 4] = m_run; a.part_ml[prow * 4 + 1] = l_tot; a.part_ml[prow * 4 + 2] = a.drop.p > 0.f ? sd_tot : l_tot;
             }
-        if (sl == 0 && hh == 0) {
-            a.part_ml[prow * 4] = m_run; a.part_ml[prow * 4 + 1] = l_tot; a.part_ml[prow * 4 + 2] = a.drop.p > 0.f ? sd_tot : l_tot;
+        }
+        if (a.tickets == nullptr) return;                   // the slices are merged by made_attention_wide_combine (a second launch)
+        // ---- merge in the same launch: every workgroup of this (entry, query tile) signs in after releasing its slice; the one that
+        // signs in last fetches all slices past its XCD's caches and merges them in slice order (so the result does not depend on
+        // which workgroup that was).  The ticket word is left at zero for the next launch.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        int* flag = (int*)lds_s;
+        const int64_t qtile = batch_fast ? blockIdx.y : blockIdx.x;
+        const int64_t n_qt = (nq_total + WQB - 1) / WQB;
+        if (tid == 0) {
+            uint32_t* tk = a.tickets + b * n_qt + qtile;
+            const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == (uint32_t)(nsplit - 1);
+            if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[0] = last;
+        }
+        __syncthreads();
+        if (flag[0] == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // one wave per query row, the tile's rows round-robin over the four waves
+        const int64_t q_lo = qtile * WQB;
+        const int64_t q_hi = q_lo + WQB < nq_total ? q_lo + WQB : nq_total;
+        for (int64_t q = q_lo + wave; q < q_hi; q += 4) {
+            float M = -INFINITY;
+            for (int64_t sp = 0; sp < nsplit; ++sp) M = fmaxf(M, a.part_ml[((b * nsplit + sp) * nq_total + q) * 4]);
+            const float Muse = (M == -INFINITY) ? 0.f : M;
+            float Lsum = 0.f, Dsum = 0.f;
+            f32x4 acc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
+            for (int64_t sp = 0; sp < nsplit; ++sp) {
+                const int64_t pr = (b * nsplit + sp) * nq_total + q;
+                const float w = expf(a.part_ml[pr * 4] - Muse);
+                Lsum += a.part_ml[pr * 4 + 1] * w;
+                Dsum += a.part_ml[pr * 4 + 2] * w;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    if (c < D) {
+                        const f32x4 t = *(const f32x4*)(a.part_o + pr * D + c);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] += t[j] * w;
+                    }
+                }
+            }
+            const float minv = 1.f / Lsum;
+            if (lane == 0) {
+                if (a.sum_out) a.sum_out[b * nq_total + q] = Dsum * minv;      // sum of the dropped weights (1 without dropout)
+                if (a.lse_out) a.lse_out[b * nq_total + q] = Muse + logf(Lsum);
+            }
+            const int64_t ob = b * a.o_bs + (q / a.NQ2) * a.o_s1 + (q % a.NQ2) * a.o_s2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < D) {
+                    if (a.o_dtype == MADE_F32) {
+                        f32x4 pk; pk[0] = acc[i][0] * minv; pk[1] = acc[i][1] * minv; pk[2] = acc[i][2] * minv; pk[3] = acc[i][3] * minv;
+                        *(f32x4*)((float*)a.O + ob + c) = pk;
+                    } else {
+                        bf16x4 pk; pk[0] = (bf16_t)(acc[i][0] * minv); pk[1] = (bf16_t)(acc[i][1] * minv);
+                        pk[2] = (bf16_t)(acc[i][2] * minv); pk[3] = (bf16_t)(acc[i][3] * minv);
+                        *(bf16x4*)((bf16_t*)a.O + ob + c) = pk;
+                    }
+                }
+            }
         }
         return;
     }
@@ -419,6 +491,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_combine_kernel(const 
     }
     const float inv = 1.f / Lsum;
     if (a.sum_out && lane == 0) a.sum_out[b * nq_total + q] = Dsum * inv;     // sum of the dropped weights (1 without dropout)
+    if (a.lse_out && lane == 0) a.lse_out[b * nq_total + q] = Muse + logf(Lsum);
     const int64_t obase = b * a.o_bs + (q / a.NQ2) * a.o_s1 + (q % a.NQ2) * a.o_s2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -466,7 +539,7 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(batch_fast ? a.B : qtiles), (unsigned)(batch_fast ? qtiles : a.B), (unsigned)nsplit), block(NTHREADS);
     hipLaunchKernelGGL((attention_wide_kernel<TC, D, DB, NSL>), grid, block, lds_bytes, st, a);
     int rc = made_check_launch("made_attention_wide");
-    if (rc != MADE_OK || nsplit == 1) return rc;
+    if (rc != MADE_OK || nsplit == 1 || a.tickets != nullptr) return rc;      // (tickets: merged inside the launch)
     const int64_t rows = a.B * nq;
     hipLaunchKernelGGL(attention_wide_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTHREADS), 0, st, a);
     return made_check_launch("made_attention_wide(combine)");

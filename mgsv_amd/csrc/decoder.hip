@@ -23,7 +23,10 @@ __device__ __forceinline__ float ds_act(float x, int act) {   // (ReLU is all th
     return act == MADE_ACT_RELU ? fmaxf(x, 0.f) : x;
 }
 
-template <int NV>                                               // K = 64 * NV (NV = 4: D = 256, NV = 8: D = 512)
+// ZB16: Zin holds bf16 rows (the training chain keeps its pre-norm rows in the compute dtype: they are also what the LayerNorm
+// backward reads); TRAIN: the stateless dropout of include/made_hip.h after the activation, and the GEMM input A = x + add is
+// also written out (a_out: the backward's weight-gradient operand).
+template <int NV, bool ZB16, bool TRAIN>                        // K = 64 * NV (NV = 4: D = 256, NV = 8: D = 512)
 __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStageArgs a) {
     constexpr int K = 64 * NV;
     constexpr int LDA = K * 2 + 16;                             // bytes per row of the LDS A tile (padded: conflict-free 16-byte reads)
@@ -59,11 +62,24 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         int gm = m0 + wave * RPW + i; gm = gm < M ? gm : M - 1;
-        const float* zp = a.Zin + (int64_t)gm * a.ldz + c0;
+        if constexpr (ZB16) {
+            const bf16_t* zp = (const bf16_t*)a.Zin + (int64_t)gm * a.ldz + c0;
+            if constexpr (NV == 8) {
+                const bf16x8 t = *(const bf16x8*)zp;
 #pragma unroll
-        for (int j = 0; j < NV; j += 4) {
-            const f32x4 t = *(const f32x4*)(zp + j);
-            v[i][j] = t[0]; v[i][j + 1] = t[1]; v[i][j + 2] = t[2]; v[i][j + 3] = t[3];
+                for (int u = 0; u < 8; ++u) v[i][u] = (float)t[u];
+            } else {
+                const bf16x4 t = *(const bf16x4*)zp;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[i][u] = (float)t[u];
+            }
+        } else {
+            const float* zp = (const float*)a.Zin + (int64_t)gm * a.ldz + c0;
+#pragma unroll
+            for (int j = 0; j < NV; j += 4) {
+                const f32x4 t = *(const f32x4*)(zp + j);
+                v[i][j] = t[0]; v[i][j + 1] = t[1]; v[i][j + 2] = t[2]; v[i][j + 3] = t[3];
+            }
         }
     }
     float g1[NV], b1[NV], g2[NV], b2[NV];
@@ -178,6 +194,11 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
             if constexpr (NV == 8) { bf16x8 t; for (int u = 0; u < 8; ++u) t[u] = (bf16_t)v[i][u]; *(bf16x8*)xp = t; }
             else { bf16x4 t; for (int u = 0; u < 4; ++u) t[u] = (bf16_t)v[i][u]; *(bf16x4*)xp = t; }
         }
+        if (TRAIN && a.a_out) {                                   // A = bf16(x) + add, exactly what went into the LDS tile
+            bf16_t* ap = (bf16_t*)a.a_out + (int64_t)gm * a.lda_out + c0;
+            if constexpr (NV == 8) { bf16x8 t; for (int u = 0; u < 8; ++u) t[u] = a.add ? (bf16_t)((float)(bf16_t)v[i][u] + ad[i][u]) : (bf16_t)v[i][u]; *(bf16x8*)ap = t; }
+            else { bf16x4 t; for (int u = 0; u < 4; ++u) t[u] = a.add ? (bf16_t)((float)(bf16_t)v[i][u] + ad[i][u]) : (bf16_t)v[i][u]; *(bf16x4*)ap = t; }
+        }
         if (has_ln2) {
             bf16_t* yp = (bf16_t*)a.x2_out + (int64_t)gm * a.ldx2 + c0;
             if constexpr (NV == 8) { bf16x8 t; for (int u = 0; u < 8; ++u) t[u] = (bf16_t)y2[i][u]; *(bf16x8*)yp = t; }
@@ -247,7 +268,21 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
     }
     const int act = a.act;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v8[j] = ds_act(v8[j] + bv[j], act) + rv[j];
+    for (int j = 0; j < 8; ++j) v8[j] = ds_act(v8[j] + bv[j], act);
+    if constexpr (TRAIN) {
+        if (a.drop.p > 0.f) {                                   // element index row * drop_ld + col (/ drop_col_div: one draw per head)
+            const uint32_t thr = made_drop_threshold(a.drop.p);
+            const float sc = 1.f / (1.f - a.drop.p);
+            const uint64_t seed = made_drop_seed(a.drop);
+            const uint64_t rb = (uint64_t)ml * (uint64_t)a.drop_ld;
+            const int div = a.drop_col_div > 1 ? a.drop_col_div : 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v8[j] = (made_rng_mix(seed, a.drop.site, rb + (uint64_t)((n + j) / div)) >> 8) >= thr ? v8[j] * sc : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v8[j] += rv[j];
     if (a.out_dtype == MADE_F32) {
         float* op = (float*)a.out + (int64_t)ml * a.ldo + n;
         if (vec && (a.ldo % 4 == 0) && (((uintptr_t)a.out & 15) == 0)) {
@@ -287,16 +322,27 @@ extern "C" int made_dec_stage(const MadeDecStageArgs* args, void* stream) {
     if (a.x2_out) MADE_UNSUPPORTED(a.ldx2 % 8 == 0 && ((uintptr_t)a.x2_out % 16) == 0, "made_dec_stage: x2_out rows must be 16-byte aligned");
     if (a.add) MADE_REQUIRE(a.add_row_mod >= 1 && ((uintptr_t)a.add % 16) == 0, "made_dec_stage: add needs add_row_mod >= 1 and 16-byte alignment");
     if (a.res_from_x) MADE_REQUIRE(a.N == a.K && a.add == nullptr && a.R == nullptr, "made_dec_stage: res_from_x needs N == K, no add, no R");
+    const bool train = a.drop.p > 0.f || a.a_out != nullptr;
+    MADE_REQUIRE(a.zin_dtype == MADE_F32 || a.zin_dtype == MADE_BF16, "made_dec_stage: bad zin_dtype %d", a.zin_dtype);
+    MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_dec_stage: dropout p out of [0,1)");
+    if (a.a_out) MADE_UNSUPPORTED(a.lda_out % 8 == 0 && ((uintptr_t)a.a_out % 16) == 0, "made_dec_stage: a_out rows must be 16-byte aligned");
+    if (a.zin_dtype == MADE_BF16) MADE_UNSUPPORTED(a.ldz % 8 == 0, "made_dec_stage: bf16 Zin rows must be 16-byte aligned");
+    // two instances per width: the eval chain (f32 raw rows, no dropout) and the training chain (bf16 rows, dropout, a_out)
+    MADE_UNSUPPORTED((a.zin_dtype == MADE_BF16) == train || !train, "made_dec_stage: dropout / a_out need bf16 Zin rows");
+    const bool tr = a.zin_dtype == MADE_BF16;
     const dim3 grid((unsigned)((a.N + DS_BN - 1) / DS_BN), (unsigned)((a.M + DS_BM - 1) / DS_BM)), block(DS_THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (a.K == 512) {
         constexpr int LDSB = DS_BM * (512 * 2 + 16);
-        static const bool once = hipFuncSetAttribute((const void*)dec_stage_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+        static const bool once = hipFuncSetAttribute((const void*)dec_stage_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)dec_stage_kernel<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
         (void)once;
-        hipLaunchKernelGGL((dec_stage_kernel<8>), grid, block, LDSB, st, a);
+        if (tr) hipLaunchKernelGGL((dec_stage_kernel<8, true, true>), grid, block, LDSB, st, a);
+        else hipLaunchKernelGGL((dec_stage_kernel<8, false, false>), grid, block, LDSB, st, a);
     } else {
         constexpr int LDSB = 4 * DS_BM * DS_CT_LD * 4;          // the partial tiles are larger than the 256-wide A tile
-        hipLaunchKernelGGL((dec_stage_kernel<4>), grid, block, LDSB, st, a);
+        if (tr) hipLaunchKernelGGL((dec_stage_kernel<4, true, true>), grid, block, LDSB, st, a);
+        else hipLaunchKernelGGL((dec_stage_kernel<4, false, false>), grid, block, LDSB, st, a);
     }
     return made_check_launch("made_dec_stage");
 }

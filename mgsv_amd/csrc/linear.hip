@@ -1254,7 +1254,9 @@ __device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const 
     int e_m = e_ml < Mv ? e_ml : Mv - 1;
     if (a.row_index) e_m = a.row_index[e_m];
     float e_bv[8];
-    load_bias8(a.bias, e_n, N, e_bv);
+    load_bias8(a.bias_row_scale ? a.bias + z * a.bias_z_stride : a.bias, e_n, N, e_bv);
+    float e_bsc = 1.f;                                      // per-(row, problem) bias scale (MadeLinearArgs.bias_row_scale)
+    if (a.bias_row_scale) e_bsc = a.bias_row_scale[(int64_t)e_m * a.batch + z];
     const int e_rmod = (int)a.r_row_mod;
     const bool e_rpref = a.R && a.r_dtype == MADE_BF16 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0) && e_nvalid == 8;
     const bool e_gpref = TRAIN && a.gate != MADE_GATE_NONE && a.g_dtype == MADE_BF16 && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0) && e_nvalid == 8;
@@ -1323,6 +1325,10 @@ __device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const 
                          (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
     const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
     const int m = e_m;
+    if (a.bias_row_scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e_bv[j] *= e_bsc;
+    }
     epilogue8<TRAIN>(a, m, n, nvalid, v, e_bv, rmod, r_vec, e_rpref ? &e_r : nullptr, e_gpref ? &e_g : nullptr, &e_om);
     int64_t orow;
     if (rpb > 0) {
@@ -1420,6 +1426,10 @@ static int linear_validate(const MadeLinearArgs& a) {
         MADE_UNSUPPORTED(a.split_k <= 1 && a.batch == 1, "made_linear: row gather is not available with split-K or batches");
         for (int s = 0; s < a.nseg; ++s)
             MADE_UNSUPPORTED(!a.seg[s].transposed, "made_linear: row gather is not available on transposed segments");
+    }
+    if (a.bias_row_scale) {
+        MADE_REQUIRE(a.bias != nullptr, "made_linear: bias_row_scale without bias");
+        MADE_UNSUPPORTED(pick_variant(a) == MADE_LINEAR_TINY, "made_linear: bias_row_scale is served by the tiny-M kernel only");
     }
     if (a.gate != MADE_GATE_NONE) MADE_REQUIRE(a.G != nullptr, "made_linear: gate without G");
     if (a.gate != MADE_GATE_NONE || a.Zout || a.drop.p > 0.f) {

@@ -229,6 +229,122 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs 
     flush_cols<NV, NW>(a.dbeta, db, D, lane, wave, sm);
 }
 
+// ---- two chained LayerNorms backward in one pass (the decoder's per-layer norm 3 followed by the shared output norm) -----------
+//   forward: t3 = LN_a(x_a) (+ nothing),  hs = LN_b(t3)      x_b = the saved t3
+//   g  = LN_b'(dy; x_b, gamma_b) + add        (add: the gradient arriving at t3 from the next layer)
+//   dx = LN_a'(g;  x_a, gamma_a);  dx_drop = dropout(dx);  parameter gradients of both norms accumulated
+// One wave per row, every row of the launch independent: a 64-row link of the decoder's backward chain instead of two.
+struct LnBwd2Args {
+    const void* xa; const float* gamma_a; const void* xb; const float* gamma_b;
+    const void* dy; const void* add; void* dx; void* dxd;
+    int64_t ldxa, ldxb, lddy, ldadd, lddx, lddxd;
+    int dt; MadeDropout drop; int64_t drop_ld;
+    float *dgamma_a, *dbeta_a, *dgamma_b, *dbeta_b;
+    int64_t rows; int D; float eps;
+};
+
+template <int NV>
+__device__ __forceinline__ void ln_bwd_row(f32x4 (&xv)[NV], f32x4 (&gy)[NV], const float* gamma, int D, int lane, float eps,
+                                           f32x4 (&dg)[NV], f32x4 (&db)[NV], f32x4 (&o)[NV]) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if ((i * WAVE + lane) * 4 >= D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[i][j] = 0.f; gy[i][j] = 0.f; }
+        }
+        sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if ((i * WAVE + lane) * 4 < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = xv[i][j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * WAVE + lane) * 4;
+        if (c < D) {
+            const f32x4 gm = *(const f32x4*)(gamma + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[i][j] - mean) * rstd;
+                const float g = gy[i][j] * gm[j];
+                dg[i][j] += gy[i][j] * xh;
+                db[i][j] += gy[i][j];
+                xv[i][j] = xh;
+                gy[i][j] = g;
+                s1 += g; s2 += g * xh;
+            }
+        }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[i][j] = rstd * (gy[i][j] - s1 - xv[i][j] * s2);
+}
+
+template <int NV>
+__global__ __launch_bounds__(RT) void layernorm_bwd2_kernel(const LnBwd2Args a) {
+    __shared__ float sm[4 * NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D;
+    f32x4 dga[NV], dba[NV], dgb[NV], dbb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dga[i][j] = 0.f; dba[i][j] = 0.f; dgb[i][j] = 0.f; dbb[i][j] = 0.f; }
+    const uint32_t thr = made_drop_threshold(a.drop.p);
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
+    const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+        f32x4 xa[NV], xb[NV], gy[NV], ad[NV], g[NV], o[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {                          // every load of the row before the first reduction
+            const int c = (i * WAVE + lane) * 4;
+            const int cc = c < D ? c : 0;
+            xb[i] = ld4(a.xb, a.dt, row * a.ldxb + cc);
+            gy[i] = ld4(a.dy, a.dt, row * a.lddy + cc);
+            xa[i] = ld4(a.xa, a.dt, row * a.ldxa + cc);
+            if (a.add) ad[i] = ld4(a.add, a.dt, row * a.ldadd + cc);
+            else { ad[i][0] = ad[i][1] = ad[i][2] = ad[i][3] = 0.f; }
+        }
+        ln_bwd_row<NV>(xb, gy, a.gamma_b, D, lane, a.eps, dgb, dbb, g);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[i][j] += ad[i][j];
+        ln_bwd_row<NV>(xa, g, a.gamma_a, D, lane, a.eps, dga, dba, o);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * WAVE + lane) * 4;
+            if (c < D) {
+                st4(a.dx, a.dt, row * a.lddx + c, o[i]);
+                if (a.dxd) {
+                    f32x4 od = o[i];
+                    if (a.drop.p > 0.f) {
+                        const uint64_t base = (uint64_t)row * (uint64_t)a.drop_ld + (uint64_t)c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) od[j] = keep_at(drop_seed, a.drop.site, thr, base + j) ? od[j] * dsc : 0.f;
+                    }
+                    st4(a.dxd, a.dt, row * a.lddxd + c, od);
+                }
+            }
+        }
+    }
+    flush_cols<NV, 4>(a.dgamma_a, dga, D, lane, wave, sm);
+    flush_cols<NV, 4>(a.dbeta_a, dba, D, lane, wave, sm);
+    flush_cols<NV, 4>(a.dgamma_b, dgb, D, lane, wave, sm);
+    flush_cols<NV, 4>(a.dbeta_b, dbb, D, lane, wave, sm);
+}
+
 // ---- clip-level vector backward: vec = normalize(masked mean(local)) --------------------------------
 //   dmean = (dvec - vhat (vhat . dvec)) / max(|mean|, eps);  out[b,t,:] = mask[b,t] * (in1 + in2 + dmean / count_b)
 struct PoolBwdArgs {
@@ -736,6 +852,36 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
         DISPATCH_NVB(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 4>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a));
     }
     return made_check_launch("made_layernorm_bwd");
+}
+
+extern "C" int made_layernorm_bwd2(const void* xa, const float* gamma_a, int64_t ldxa, const void* xb, const float* gamma_b, int64_t ldxb,
+                                   const void* dy, int64_t lddy, const void* add, int64_t ld_add, void* dx, int64_t lddx,
+                                   void* dx_drop, int64_t lddxd, const MadeDropout* drop, int64_t drop_ld, int32_t dtype,
+                                   float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, int64_t rows, int64_t D, float eps,
+                                   void* stream) {
+    MADE_REQUIRE(xa && gamma_a && xb && gamma_b && dy && dx, "made_layernorm_bwd2: null pointer");
+    MADE_REQUIRE(dtype == MADE_F32 || dtype == MADE_BF16, "made_layernorm_bwd2: bad dtype %d", dtype);
+    MADE_UNSUPPORTED(D > 0 && D % 4 == 0 && D <= 64 * 4 * 4, "made_layernorm_bwd2: D=%lld must be a multiple of 4 and <= 1024", (long long)D);
+    MADE_UNSUPPORTED(ldxa % 4 == 0 && ldxb % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ld_add % 4 == 0 && lddxd % 4 == 0,
+                     "made_layernorm_bwd2: row strides must be multiples of 4");
+    if (rows <= 0) return MADE_OK;
+    LnBwd2Args a;
+    a.xa = xa; a.gamma_a = gamma_a; a.xb = xb; a.gamma_b = gamma_b; a.dy = dy; a.add = add; a.dx = dx; a.dxd = dx_drop;
+    a.ldxa = ldxa; a.ldxb = ldxb; a.lddy = lddy; a.ldadd = ld_add; a.lddx = lddx; a.lddxd = lddxd;
+    a.dt = dtype;
+    a.drop.seed = 0; a.drop.site = 0; a.drop.p = 0.f; a.drop.seed_device = nullptr;
+    if (drop) a.drop = *drop;
+    a.drop_ld = drop_ld > 0 ? drop_ld : D;
+    a.dgamma_a = dgamma_a; a.dbeta_a = dbeta_a; a.dgamma_b = dgamma_b; a.dbeta_b = dbeta_b;
+    a.rows = rows; a.D = (int)D; a.eps = eps;
+    int64_t nb = (rows + 3) / 4;
+    if (nb > 1024) nb = 1024;
+    switch ((D + 255) / 256) {
+        case 1: hipLaunchKernelGGL((layernorm_bwd2_kernel<1>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL((layernorm_bwd2_kernel<2>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL((layernorm_bwd2_kernel<4>), dim3((unsigned)nb), dim3(RT), 0, (hipStream_t)stream, a); break;
+    }
+    return made_check_launch("made_layernorm_bwd2");
 }
 
 extern "C" int made_gate_rows(const void* x, int32_t x_dtype, int64_t ldx, const void* G, int32_t g_dtype, int64_t ldg, int32_t gate,

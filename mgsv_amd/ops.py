@@ -158,7 +158,8 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
            r_row_mod: int = 0, out_row_mask: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
            tile_skip_mask: Optional[Tensor] = None, batch: int = 1, a_z_stride: int = 0, w_z_stride: int = 0, M: Optional[int] = None,
            N: Optional[int] = None, K: Optional[int] = None, gate: int = 0, G: Optional[Tensor] = None, gate_scale: float = 1.0,
-           Zout: Optional[Tensor] = None, drop=None, drop_ld: Optional[int] = None, rows=None, drop_col_div: int = 1) -> Tensor:
+           Zout: Optional[Tensor] = None, drop=None, drop_ld: Optional[int] = None, rows=None, drop_col_div: int = 1,
+           bias_row_scale: Optional[Tensor] = None, bias_z_stride: int = 0) -> Tensor:
     """out = act(A' W^T + bias) (+R).  A [M,K] (row stride free, unit inner stride), W [N,K].
     Training extras: Zout receives the pre-activation; gate/G multiply by act'(G) * gate_scale; drop = (seed, site, p)
     applies the stateless dropout of include/made_hip.h after act/gate (element index row * drop_ld + col)."""
@@ -195,6 +196,9 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
         a.drop_col_div = int(drop_col_div)
     if rows is not None:                                      # row gather: (row_index int32 [M], n_rows int32 [1]) from row_index()
         a.row_index, a.n_rows = _p(rows[0]), _p(rows[1])
+    if bias_row_scale is not None:                            # bias[z * bias_z_stride + col] * bias_row_scale[row, z] (tiny-M kernel)
+        assert tuple(bias_row_scale.shape) == (M, batch)
+        a.bias_row_scale, a.bias_z_stride = _p(_f32(bias_row_scale, "bias_row_scale")), bias_z_stride
     if segs is None:
         if out is None:
             out = torch.empty((M, N) if batch == 1 else (batch, M, N), device=A.device,
@@ -301,17 +305,19 @@ def splitk_finish(ws: Tensor, split_k: int, M: int, N: int, bias: Optional[Tenso
 
 def dec_stage(Zin: Tensor, W: Tensor, bias: Optional[Tensor], out: Tensor, *, ln=None, ln2=None, x2_out: Optional[Tensor] = None,
               add: Optional[Tensor] = None, x_out: Optional[Tensor] = None, R: Optional[Tensor] = None, res_from_x: bool = False,
-              act: int = ACT_NONE, eps: float = 1e-5) -> Tensor:
+              act: int = ACT_NONE, eps: float = 1e-5, a_out: Optional[Tensor] = None, drop=None, drop_ld: Optional[int] = None,
+              drop_col_div: int = 1) -> Tensor:
     """One decoder stage with the previous stage's LayerNorm in its prologue (made_dec_stage): x = LayerNorm(Zin; ln) (ln = (gamma,
-    beta) or None: x = Zin), x2_out = LayerNorm(x; ln2), x_out = bf16(x), out = act((x + add) W^T + bias) + R (or + x).
-    Zin [M, K] f32; W [N, K] bf16; add [rows, K] bf16 (row modulo); R [M, N] bf16; out [M, N] f32 or bf16."""
-    assert Zin.dim() == 2 and W.dim() == 2 and out.dim() == 2 and Zin.dtype == torch.float32 and W.dtype == torch.bfloat16
+    beta) or None: x = Zin), x2_out = LayerNorm(x; ln2), x_out = bf16(x), out = dropout(act((x + add) W^T + bias)) + R (or + x).
+    Zin [M, K] f32 (eval chain) or bf16 (training chain: then a_out = bf16(x) + add and drop = (seed, site, p) are available);
+    W [N, K] bf16; add [rows, K] bf16 (row modulo); R [M, N] bf16; out [M, N] f32 or bf16."""
+    assert Zin.dim() == 2 and W.dim() == 2 and out.dim() == 2 and W.dtype == torch.bfloat16
     assert Zin.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1
     M, K = Zin.shape
     N = W.shape[0]
     assert W.shape[1] == K and tuple(out.shape) == (M, N)
     a = MadeDecStageArgs()
-    a.Zin, a.ldz = _p(Zin), Zin.stride(0)
+    a.Zin, a.ldz, a.zin_dtype = _p(Zin), Zin.stride(0), dt_of(Zin)
     if ln is not None:
         a.ln_g, a.ln_b = _p(_f32(ln[0], "ln.g")), _p(_f32(ln[1], "ln.b"))
     if ln2 is not None:
@@ -323,6 +329,14 @@ def dec_stage(Zin: Tensor, W: Tensor, bias: Optional[Tensor], out: Tensor, *, ln
     if x_out is not None:
         assert x_out.dtype == torch.bfloat16 and x_out.stride(1) == 1 and tuple(x_out.shape) == (M, K)
         a.x_out, a.ldx = _p(x_out), x_out.stride(0)
+    if a_out is not None:
+        assert a_out.dtype == torch.bfloat16 and a_out.stride(1) == 1 and tuple(a_out.shape) == (M, K) and Zin.dtype == torch.bfloat16
+        a.a_out, a.lda_out = _p(a_out), a_out.stride(0)
+    if drop is not None and drop[2] > 0.0:
+        assert Zin.dtype == torch.bfloat16
+        set_drop(a.drop, drop)
+        a.drop_ld = N if drop_ld is None else drop_ld
+        a.drop_col_div = int(drop_col_div)
     a.W, a.ldw, a.bias = _p(W), W.stride(0), _p(_f32(bias, "bias"))
     if R is not None:
         assert R.dtype == torch.bfloat16 and R.stride(1) == 1 and tuple(R.shape) == (M, N)
@@ -330,7 +344,7 @@ def dec_stage(Zin: Tensor, W: Tensor, bias: Optional[Tensor], out: Tensor, *, ln
     a.out, a.ldo, a.out_dtype = _p(out), out.stride(0), dt_of(out)
     a.act, a.res_from_x, a.eps = act, 1 if res_from_x else 0, eps
     a.M, a.N, a.K = M, N, K
-    _timed("dec_stage_kernel", 2.0 * M * N * K, float(M * K * 4 * ((N + 31) // 32) + N * K * 2 + M * N * out.element_size()),
+    _timed("dec_stage_kernel", 2.0 * M * N * K, float(M * K * Zin.element_size() * ((N + 31) // 32) + N * K * 2 + M * N * out.element_size()),
            lambda: check(lib().made_dec_stage(C.byref(a), _stream()), "made_dec_stage"), f"M={M} N={N} K={K}")
     return out
 
@@ -379,7 +393,7 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
 def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, Kadd: Optional[Tensor] = None,
                    key_mask: Optional[Tensor] = None, shared_q: bool = False, n_split: int = 1,
                    part_o: Optional[Tensor] = None, part_ml: Optional[Tensor] = None, drop=None,
-                   sum_out: Optional[Tensor] = None) -> Tensor:
+                   sum_out: Optional[Tensor] = None, lse_out: Optional[Tensor] = None, tickets: Optional[Tensor] = None) -> Tensor:
     """Single-head attention with head dim = D.  Q [B|1, NQ1, NQ2, D], K/Kadd/V [B, L, D], O [B, NQ1, NQ2, D]
     (strided views fine, unit inner stride).  shared_q: the same queries for every batch entry (Q.shape[0] == 1)."""
     assert Q.dim() == 4 and O.dim() == 4 and K.dim() == 3 and V.dim() == 3
@@ -406,8 +420,14 @@ def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, 
             part_ml = torch.empty(B * n_split * nq * 4, device=Q.device, dtype=torch.float32)
         assert part_o.numel() >= B * n_split * nq * D and part_ml.numel() >= B * n_split * nq * 4
         a.n_split, a.part_o, a.part_ml = n_split, _p(_f32(part_o, "part_o")), _p(_f32(part_ml, "part_ml"))
+        if tickets is not None:      # merge the key slices inside the launch (zeroed int32 words, one per (entry, query tile); left at zero)
+            assert tickets.dtype == torch.int32 and tickets.is_contiguous() and tickets.numel() >= B * ((nq + 31) // 32)
+            a.tickets = _p(tickets)
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
+    if lse_out is not None:
+        assert lse_out.dtype == torch.float32 and lse_out.is_contiguous() and lse_out.numel() >= B * nq
+        a.lse_out = _p(lse_out)
     if sum_out is not None:
         assert sum_out.dtype == torch.float32 and sum_out.is_contiguous() and sum_out.numel() >= B * nq
         a.sum_out = _p(sum_out)

@@ -180,6 +180,21 @@ def layernorm_bwd(x: Tensor, gamma: Tensor, dy: Tensor, dx: Tensor, *, dgamma: O
     return dx
 
 
+def layernorm_bwd2(xa: Tensor, gamma_a: Tensor, xb: Tensor, gamma_b: Tensor, dy: Tensor, dx: Tensor, *, dgamma_a: Tensor, dbeta_a: Tensor,
+                   dgamma_b: Tensor, dbeta_b: Tensor, add: Optional[Tensor] = None, dx_drop: Optional[Tensor] = None, drop=None,
+                   drop_ld: int = 0, eps: float = 1e-5) -> Tensor:
+    """Two chained LayerNorms backward (made_layernorm_bwd2): g = LN_b'(dy; xb) + add, dx = LN_a'(g; xa), dx_drop = dropout(dx)."""
+    rows, D = xa.shape
+    for t in (xa, xb, dy, dx, add, dx_drop):
+        assert t is None or (t.dim() == 2 and t.dtype == xa.dtype and t.stride(1) == 1 and t.shape[0] >= rows)
+    check(lib().made_layernorm_bwd2(_p(xa), _p(_f32(gamma_a, "gamma_a")), xa.stride(0), _p(xb), _p(_f32(gamma_b, "gamma_b")), xb.stride(0),
+                                    _p(dy), dy.stride(0), _p(add), add.stride(0) if add is not None else 0, _p(dx), dx.stride(0),
+                                    _p(dx_drop), dx_drop.stride(0) if dx_drop is not None else 0, _drop_ptr(drop), drop_ld, dt_of(xa),
+                                    _p(_f32(dgamma_a, "dgamma_a")), _p(_f32(dbeta_a, "dbeta_a")), _p(_f32(dgamma_b, "dgamma_b")),
+                                    _p(_f32(dbeta_b, "dbeta_b")), rows, D, eps, _stream()), "made_layernorm_bwd2")
+    return dx
+
+
 def pool_bwd(mean: Tensor, dvec: Tensor, mask: Tensor, out: Tensor, in1: Optional[Tensor] = None, in2: Optional[Tensor] = None,
              eps: float = 1e-12) -> Tensor:
     """out[b,t,:] = mask * (in1 + in2 + d masked-mean / normalise); in1 / in2 / out are [B,T,D] views."""
@@ -233,6 +248,41 @@ def softmax_bwd(S: Tensor, dP: Tensor, mask: Optional[Tensor], rows_per_mask: in
                                  _p(extra), float(scale), _drop_ptr(drop), _p(Pd), _p(dS), _p(dSt), dt_of(Pd),
                                  Pd.stride(-2) if ldo is None else ldo, ldt, out_batch_stride, t_batch_stride,
                                  rows, rows_per_batch, L, _stream()), "made_softmax_bwd")
+
+
+def attention_wide_bwd(Q: Tensor, dO: Tensor, O: Tensor, K: Tensor, V: Tensor, lse: Tensor, Pd: Tensor, dS: Tensor, dQ: Tensor, *, scale: float,
+                       key_mask: Optional[Tensor] = None, ssum: Optional[Tensor] = None, extra: Optional[Tensor] = None,
+                       dattc: Optional[Tensor] = None, vbias: Optional[Tensor] = None, hd: int = 0, drop=None, n_split: int = 1,
+                       part_dq: Optional[Tensor] = None, tickets: Optional[Tensor] = None) -> Tensor:
+    """Backward of the decoder's memory-space cross-attention in ONE launch (made_attention_wide_bwd).  Q / dO / O / dQ [B, NQ, D] bf16
+    (NQ <= 8), K / V [B, L, D] bf16, lse / ssum / extra [B, NQ] f32, Pd / dS [B, NQ, ld_p >= L] bf16 views."""
+    assert Q.dim() == 3 and dO.shape == Q.shape and O.shape == Q.shape and dQ.shape == Q.shape and K.dim() == 3 and V.shape == K.shape
+    B, NQ, D = Q.shape
+    L = K.shape[1]
+    for t in (Q, dO, O, K, V, Pd, dS, dQ):
+        assert t.dtype == torch.bfloat16 and t.stride(-1) == 1
+    assert Pd.dim() == 3 and dS.dim() == 3 and Pd.stride() == dS.stride() and Pd.shape[0] == B and Pd.shape[1] == NQ
+    a = _lib.MadeWideAttnBwdArgs()
+    a.Q, a.dO, a.O, a.K, a.V = _p(Q), _p(dO), _p(O), _p(K), _p(V)
+    a.key_mask, a.lse, a.ssum, a.extra = _p(_f32(key_mask, "key_mask")), _p(_f32(lse, "lse")), _p(_f32(ssum, "ssum")), _p(_f32(extra, "extra"))
+    if dattc is not None:
+        assert dattc.dim() == 2 and dattc.dtype == torch.bfloat16 and dattc.stride(1) == 1 and vbias is not None
+        a.dattc, a.ld_dattc, a.vbias, a.hd = _p(dattc), dattc.stride(0), _p(_f32(vbias, "vbias")), hd
+    a.Pd, a.dS, a.p_bs, a.ld_p = _p(Pd), _p(dS), Pd.stride(0), Pd.stride(1)
+    a.dQ, a.dq_bs, a.ld_dq = _p(dQ), dQ.stride(0), dQ.stride(1)
+    a.B, a.NQ, a.L, a.D = B, NQ, L, D
+    a.q_bs, a.ld_q, a.do_bs, a.ld_do, a.o_bs, a.ld_o = Q.stride(0), Q.stride(1), dO.stride(0), dO.stride(1), O.stride(0), O.stride(1)
+    a.k_bs, a.ldk, a.v_bs, a.ldv = K.stride(0), K.stride(1), V.stride(0), V.stride(1)
+    a.scale = float(scale)
+    if n_split > 1:
+        assert part_dq is not None and part_dq.dtype == torch.float32 and part_dq.numel() >= B * n_split * NQ * D
+        assert tickets is not None and tickets.dtype == torch.int32 and tickets.numel() >= B
+        a.n_split, a.part_dq, a.tickets = n_split, _p(part_dq), _p(tickets)
+    if drop is not None and drop[2] > 0.0:
+        set_drop(a.drop, drop)
+    _timed("made_attention_wide_bwd", 6.0 * B * NQ * L * D, 2.0 * B * (2 * L * D + 4 * NQ * D + 2 * NQ * L),
+                lambda: check(lib().made_attention_wide_bwd(C.byref(a), _stream()), "made_attention_wide_bwd"), f"B={B} NQ={NQ} L={L} D={D}")
+    return dQ
 
 
 def head_bias(x: Tensor, s: Tensor, bias: Tensor, H: int) -> None:

@@ -484,6 +484,8 @@ class MadeTrainer(MadeEngine):
                       g_sa=E(nd, BQ, D), g_qkv=E(nd, BQ, 3 * D), dt1q=E(nd, BQ, D))
         ws["dstack"] = stacks
         ws["s_stack"] = E(nd, BQ, H, dtype=f32)               # sums of the dropped cross-attention weights, one row per (layer, query)
+        ws["ca_lse"] = E(nd, B * HQ, dtype=f32)               # log-sum-exp of the memory-space attention's scaled scores (fused backward)
+        ws["wide_tickets"] = Z(B * ((HQ + 31) // 32), dtype=i32)   # made_attention_wide merges its key slices in the same launch
         for l in range(nd):
             ws.update({f"d.{l}.{k}": v[l] for k, v in stacks.items() if not k.startswith("g_")})
             ws.update({f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.s": ws["s_stack"][l], f"d.{l}.t3": stacks["tgt"][l + 1]})
@@ -582,30 +584,48 @@ class MadeTrainer(MadeEngine):
             if Q > 1:                                        # (a single query's q / k projections are never formed: see the loop)
                 tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
 
+        # bf16, one moment query: the chain's LayerNorms run in the prologue of the Linear that consumes them (made_dec_stage, as on
+        # the eval path; dropout and the saved GEMM input in its epilogue / prologue), the key slices of the memory-space attention
+        # are merged inside its launch and the value bias is the per-head Linear's epilogue: 9 launches per layer instead of 14
+        stage = self._dec_stage_chain()
+
         def dec_query_side(l: int) -> None:
             """the part of decoder layer l in front of its cross-attention: self-attention block, LayerNorm, cross-attention query and
             its per-head fold -- it reads the layer's input and the weights, nothing the DETR encoder produces"""
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
             tgt, tq = tw[d + ".tgt"], tw[d + ".tq"]
             qkv = tw[d + ".qkv"]
-            if Q == 1:
-                # one query, one key: the softmax weight is 1, so the block is the value path; its attention-weight dropout is one
-                # draw per (sample, head) (element index (b*H + h)*1*1), and q / k get no gradient
-                # (the draw is the value Linear's epilogue: the undropped value itself is needed by nobody)
-                Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
-                ops.linear(tgt, Wsa[2 * D:], bsa[2 * D:], out=tw[d + ".att"], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
-            else:
-                ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
-                           segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
-                q3 = qkv.view(B, Q, 3 * D)
-                ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), H, lse=tw[d + ".lse"],
-                              drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
-            ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
-            t1 = tw[d + ".t1"]
-            ops.layernorm_add(ta, P[p + ".ln1.g"], P[p + ".ln1.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t1, tw[d + ".t1q"])
             Win, bin_ = P[p + ".ca.in.w"], P[p + ".ca.in.b"]
             Wt = P[p + ".ca.in.wt"]                           # [D, 3D] = in_proj^T
-            qc = ops.linear(tw[d + ".t1q"], Win[:D], bin_[:D], out=tw[d + ".qc"])
+            if stage:
+                Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
+                sa_drop = dict(drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+                if l == 0:
+                    ops.dec_stage(tgt, Wsa[2 * D:], bsa[2 * D:], tw[d + ".att"], **sa_drop)
+                else:                                         # the previous layer's norm 3 in the prologue: t3 = this layer's input
+                    q_ = f"detr_transformer.decoder.layers.{l - 1}"
+                    ops.dec_stage(tw[f"d.{l - 1}.t_c"], Wsa[2 * D:], bsa[2 * D:], tw[d + ".att"], ln=(P[q_ + ".ln3.g"], P[q_ + ".ln3.b"]),
+                                  x_out=tgt, **sa_drop)
+                ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
+                qc = ops.dec_stage(ta, Win[:D], bin_[:D], tw[d + ".qc"], ln=(P[p + ".ln1.g"], P[p + ".ln1.b"]), add=qp,
+                                   x_out=tw[d + ".t1"], a_out=tw[d + ".t1q"])
+            else:
+                if Q == 1:
+                    # one query, one key: the softmax weight is 1, so the block is the value path; its attention-weight dropout is one
+                    # draw per (sample, head) (element index (b*H + h)*1*1), and q / k get no gradient
+                    # (the draw is the value Linear's epilogue: the undropped value itself is needed by nobody)
+                    Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
+                    ops.linear(tgt, Wsa[2 * D:], bsa[2 * D:], out=tw[d + ".att"], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+                else:
+                    ops.linear(tgt, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
+                               segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
+                    q3 = qkv.view(B, Q, 3 * D)
+                    ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), H, lse=tw[d + ".lse"],
+                                  drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+                ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
+                t1 = tw[d + ".t1"]
+                ops.layernorm_add(ta, P[p + ".ln1.g"], P[p + ".ln1.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t1, tw[d + ".t1q"])
+                qc = ops.linear(tw[d + ".t1q"], Win[:D], bin_[:D], out=tw[d + ".qc"])
             qprime = GQ[:, 1, l]                              # [B, H*Q, D] view; q'_h = W_k,h^T qc_h  (b_k shifts all keys alike)
             ops.linear(qc[:, :hd], Wt[:, D:D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
                        segs=[Seg(out=qprime, ldo=D, rows_per_batch=Q, out_batch_stride=qprime.stride(0), out_z_stride=Q * D)])
@@ -712,19 +732,32 @@ class MadeTrainer(MadeEngine):
             s_out = tw[d + ".s"] if Q == 1 else tw["s_raw"]   # the kernel numbers its rows (b, h, q); the Linears below (b, q, h)
             ops.attention_wide(qprime.view(B, H, Q, D), mempos3, mem3, pooled.view(B, Q, H, D).permute(0, 2, 1, 3), scale=ca_scale,
                                key_mask=fus_mask, drop=self._drop(f"dec.{l}" + ".ca_attn", pd), sum_out=s_out,
-                               n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
+                               n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"],
+                               tickets=tw["wide_tickets"] if stage else None, lse_out=tw["ca_lse"][l] if stage else None)
             if Q > 1:
                 tw[d + ".s"].view(B, Q, H).copy_(s_out.view(B, H, Q).permute(0, 2, 1))
             attc = tw[d + ".attc"]
-            ops.linear(pooled[:, :D], Win[2 * D:2 * D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
-                       segs=[Seg(out=attc, ldo=D, out_z_stride=hd)])
-            tr.head_bias(attc, tw[d + ".s"], bin_[2 * D:], H)
+            if stage:                                         # the value bias s_h * b_v,h is the per-head Linear's epilogue
+                ops.linear(pooled[:, :D], Win[2 * D:2 * D + hd], bin_[2 * D:], M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
+                           segs=[Seg(out=attc, ldo=D, out_z_stride=hd)], bias_row_scale=tw[d + ".s"], bias_z_stride=hd)
+            else:
+                ops.linear(pooled[:, :D], Win[2 * D:2 * D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
+                           segs=[Seg(out=attc, ldo=D, out_z_stride=hd)])
+                tr.head_bias(attc, tw[d + ".s"], bin_[2 * D:], H)
             tb = ops.linear(attc, P[p + ".ca.out.w"], P[p + ".ca.out.b"], R=t1, out=tw[d + ".t_b"], drop=self._drop(f"dec.{l}" + ".drop2", pd))
-            t2 = ops.layernorm(tb, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[d + ".t2"])
-            h = ops.linear(t2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[d + ".h"], drop=self._drop(f"dec.{l}" + ".ffn_act", pd))
+            if stage:
+                h = ops.dec_stage(tb, P[p + ".ff1.w"], P[p + ".ff1.b"], tw[d + ".h"], ln=(P[p + ".ln2.g"], P[p + ".ln2.b"]), x_out=tw[d + ".t2"],
+                                  act=ops.ACT_RELU, drop=self._drop(f"dec.{l}" + ".ffn_act", pd))
+                t2 = tw[d + ".t2"]
+            else:
+                t2 = ops.layernorm(tb, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[d + ".t2"])
+                h = ops.linear(t2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[d + ".h"], drop=self._drop(f"dec.{l}" + ".ffn_act", pd))
             tcx = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=t2, out=tw[d + ".t_c"], drop=self._drop(f"dec.{l}" + ".drop3", pd))
             t3 = tw[d + ".t3"]                                # = the content query of layer l + 1 (slot l + 1 of the tgt stack)
-            if l + 1 < nd:
+            if stage:
+                if l + 1 == nd:                               # (inside the chain norm 3 is the next layer's prologue; the last one has no consumer)
+                    ops.layernorm(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], out=t3)
+            elif l + 1 < nd:
                 ops.layernorm_add(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1), t3, tw[f"d.{l + 1}.tq"])
             else:
                 ops.layernorm(tcx, P[p + ".ln3.g"], P[p + ".ln3.b"], out=t3)
@@ -789,6 +822,13 @@ class MadeTrainer(MadeEngine):
                    matcher_status=status, criterion_losses=losses, localization_loss=total)
         cur.wait_stream(side)
         return out
+
+    def _dec_stage_chain(self) -> bool:
+        """The training decoder's fused chain (made_dec_stage with the training options, in-launch merge of the memory-space attention,
+        fused attention backward): bf16, one moment query, D = 256 / 512.  MADE_DEC_STAGE=0 keeps round 2's chain (A/B measurements);
+        f32 and Q > 1 always take it."""
+        c = self.cfg
+        return (self.tc == torch.bfloat16 and c.num_moment_queries == 1 and c.D in (256, 512) and os.environ.get("MADE_DEC_STAGE", "1") != "0")
 
     def _encode_train(self, feats: Tensor, mask: Tensor, which: str, ws, tw, row_off: int) -> None:
         """reference model/model_Base.py:544-617 in train mode (dropout 0.8 inside the temporal block)."""
@@ -1071,47 +1111,68 @@ class MadeTrainer(MadeEngine):
             dtgt = None
             # the scores of every layer's memory-space attention depend on forward values only (q', memory + pos): ONE batched
             # product for all layers ([nd, B, H*Q, L] rows) ahead of the dependent chain instead of one launch inside every layer
+            stage = self._dec_stage_chain()                    # fused chain: see forward_train
             S_all = tw["dS_S"]
-            ops.linear(GQ[0, 1].reshape(nd * HQ, D), mempos3[0], None, M=nd * HQ, N=L, K=D, batch=B, a_z_stride=GQ.stride(0), w_z_stride=L * D,
-                       segs=[Seg(out=S_all, ldo=Lp, rows_per_batch=HQ, out_batch_stride=B * HQ * Lp, out_z_stride=HQ * Lp)])
+            if not stage:
+                ops.linear(GQ[0, 1].reshape(nd * HQ, D), mempos3[0], None, M=nd * HQ, N=L, K=D, batch=B, a_z_stride=GQ.stride(0), w_z_stride=L * D,
+                           segs=[Seg(out=S_all, ldo=Lp, rows_per_batch=HQ, out_batch_stride=B * HQ * Lp, out_z_stride=HQ * Lp)])
+            n_split_b = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))
             for l in range(nd - 1, -1, -1):
                 p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
                 g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
                 Win, Wt = P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
                 g_ffn, g_z, g_ca, g_attc, g_q, g_qc, g_sa, gqkv = (st[k][l] for k in ("g_ffn", "g_z", "g_ca", "g_attc", "g_q", "g_qc", "g_sa", "g_qkv"))
-                # hs_l = dec.norm(t3); t3 also feeds the next layer
-                tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
-                # t3 = LN3(t2 + drop3(ffn))
-                tr.layernorm_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], g1, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"],
-                                 dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
+                if stage:
+                    # hs_l = dec.norm(t3), t3 = LN3(t2 + drop3(ffn)), t3 also feeds the next layer: both norms' backward in one launch
+                    tr.layernorm_bwd2(tw[d + ".t_c"], P[p + ".ln3.g"], tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g2,
+                                      dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], dgamma_b=G["dec.norm.g"], dbeta_b=G["dec.norm.b"],
+                                      add=dtgt, dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
+                else:
+                    # hs_l = dec.norm(t3); t3 also feeds the next layer
+                    tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
+                    # t3 = LN3(t2 + drop3(ffn))
+                    tr.layernorm_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], g1, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"],
+                                     dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
                 ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
                 dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1, R=g2)
                 # t2 = LN2(t1 + drop2(cross-attention))
                 tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"],
                                  dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
                 dattc = ops.linear(g_ca, P[p + ".ca.out.wt"], None, out=g_attc)
-                tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], G[p + ".ca.in.b"][2 * D:], tw["d_ds"], H)
-                d_ds = tw["d_ds"]                                 # rows (b, q), columns h; the softmax backward numbers its rows (b, h, q)
-                if Q > 1:
-                    tw["dds_raw"].view(B, H, Q).copy_(d_ds.view(B, Q, H).permute(0, 2, 1))
-                    d_ds = tw["dds_raw"]
-                # v_h = W_v,h pooled_h : dpooled_h = dattc_h W_v,h
                 dpooled = GQ[:, 0, l]                             # [B, H*Q, D] slice of the concatenated buffer
-                ops.linear(dattc[:, :hd], Wt[:, 2 * D:2 * D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
-                           segs=[Seg(out=dpooled, ldo=D, rows_per_batch=Q, out_batch_stride=dpooled.stride(0), out_z_stride=Q * D)])
-                # scores and dPd of the memory-space attention (few rows per sample: materialised)
                 qprime = GQ[:, 1, l]
-                S, dP = S_all[l], tw["dS_dP"]
-                ops.linear(dpooled[0], mem3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=dpooled.stride(0), w_z_stride=L * D,
-                           segs=[Seg(out=dP, ldo=Lp, out_z_stride=HQ * Lp)])
-                tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=d_ds.view(-1),
-                               drop=self._drop(f"dec.{l}" + ".ca_attn", pd), ldo=Lp, ldt=HQ, out_batch_stride=PdS.stride(0))
-                # dq'[b] = dS[b] (mem + pos)[b]
-                gq_out = g_q if Q == 1 else tw["gq_raw"]         # [B, (h, q), D] out of the product; [B, (q, h), D] for the Linears
-                tr.gemm_tn(tw["dSt"][0], mempos3[0], gq_out[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
-                           row_mask=fus_mask, mask_zs=(L, 0))
-                if Q > 1:
-                    g_q.view(B, Q, H, D).copy_(gq_out.view(B, H, Q, D).permute(0, 2, 1, 3))
+                if stage:
+                    # v_h = W_v,h pooled_h : dpooled_h = dattc_h W_v,h
+                    ops.linear(dattc[:, :hd], Wt[:, 2 * D:2 * D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
+                               segs=[Seg(out=dpooled, ldo=D, rows_per_batch=Q, out_batch_stride=dpooled.stride(0), out_z_stride=Q * D)])
+                    # the memory-space attention's backward in ONE launch: scores and probabilities recomputed from the saved lse, the
+                    # value-bias term reduced from dattc, Pd / dS written for the memory-gradient product after the loop, dq' = dS (mem + pos)
+                    # (the value bias' own gradient needs nothing of the chain: after the loop, second stream)
+                    tr.attention_wide_bwd(qprime, dpooled, tw[d + ".pooled"].view(B, HQ, D), mempos3, mem3, tw["ca_lse"][l].view(B, HQ),
+                                          PdS[:, 0, l], PdS[:, 1, l], g_q, scale=ca_scale, key_mask=fus_mask, ssum=tw[d + ".s"].view(B, HQ),
+                                          dattc=dattc, vbias=P[p + ".ca.in.b"][2 * D:], hd=hd, drop=self._drop(f"dec.{l}" + ".ca_attn", pd),
+                                          n_split=n_split_b, part_dq=ws["part_o"], tickets=tw["wide_tickets"])
+                else:
+                    tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], G[p + ".ca.in.b"][2 * D:], tw["d_ds"], H)
+                    d_ds = tw["d_ds"]                                 # rows (b, q), columns h; the softmax backward numbers its rows (b, h, q)
+                    if Q > 1:
+                        tw["dds_raw"].view(B, H, Q).copy_(d_ds.view(B, Q, H).permute(0, 2, 1))
+                        d_ds = tw["dds_raw"]
+                    # v_h = W_v,h pooled_h : dpooled_h = dattc_h W_v,h
+                    ops.linear(dattc[:, :hd], Wt[:, 2 * D:2 * D + hd], None, M=B * Q, N=D, K=hd, batch=H, a_z_stride=hd, w_z_stride=hd,
+                               segs=[Seg(out=dpooled, ldo=D, rows_per_batch=Q, out_batch_stride=dpooled.stride(0), out_z_stride=Q * D)])
+                    # scores and dPd of the memory-space attention (few rows per sample: materialised)
+                    S, dP = S_all[l], tw["dS_dP"]
+                    ops.linear(dpooled[0], mem3[0], None, M=HQ, N=L, K=D, batch=B, a_z_stride=dpooled.stride(0), w_z_stride=L * D,
+                               segs=[Seg(out=dP, ldo=Lp, out_z_stride=HQ * Lp)])
+                    tr.softmax_bwd(S, dP, fus_mask, HQ, ca_scale, PdS[:, 0, l], PdS[:, 1, l], tw["dSt"], HQ, L, extra=d_ds.view(-1),
+                                   drop=self._drop(f"dec.{l}" + ".ca_attn", pd), ldo=Lp, ldt=HQ, out_batch_stride=PdS.stride(0))
+                    # dq'[b] = dS[b] (mem + pos)[b]
+                    gq_out = g_q if Q == 1 else tw["gq_raw"]         # [B, (h, q), D] out of the product; [B, (q, h), D] for the Linears
+                    tr.gemm_tn(tw["dSt"][0], mempos3[0], gq_out[0], batch=(B, 1), a_zs=(L * HQ, 0), b_zs=(L * D, 0), c_zs=(HQ * D, 0),
+                               row_mask=fus_mask, mask_zs=(L, 0))
+                    if Q > 1:
+                        g_q.view(B, Q, H, D).copy_(gq_out.view(B, H, Q, D).permute(0, 2, 1, 3))
                 # q'_h = W_k,h^T qc_h : dqc_h = dq'_h W_k,h^T
                 dq2 = g_q.view(B * Q, H * D)
                 ops.linear(dq2[:, :D], Win[D:D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
@@ -1158,6 +1219,10 @@ class MadeTrainer(MadeEngine):
             for launch in heads_dw:
                 launch()
             tr.colsum(st["dt1q"].view(nd * B, Q * D), G["query_embed"].view(-1))     # every layer's query path at once
+            if stage:                                          # the value bias' gradient d b_v,h = sum_b s[b, h] dattc[b, h] of every layer
+                for l in range(nd):
+                    pl = f"detr_transformer.decoder.layers.{l}"
+                    tr.head_bias_bwd(st["g_attc"][l], tw[f"d.{l}.s"], P[pl + ".ca.in.b"][2 * D:], G[pl + ".ca.in.b"][2 * D:], tw["d_ds"], H)
             p0, p1 = "detr_transformer.decoder.layers.0", "detr_transformer.decoder.layers.1"
             BQ = B * Q
 

@@ -90,3 +90,14 @@ def test_a_mistyped_checkpoint_path_fails_loudly(tmp_path):
     a = driver.parse_option(["--name", "x", "--audio_short_cut", "0", "--load_uni_model_path", str(tmp_path)])      # a directory
     with pytest.raises(FileNotFoundError):
         driver.build_model(a, "cpu", logging.getLogger("t"))
+
+
+def test_bench_and_entry_scripts_parse_their_flags_without_a_gpu():
+    """`python bench.py --help` (and the two entry-point shims) must at least import and build their parsers here: a bench.py that
+    does not start is only seen at round end otherwise."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "--workload" in out.stdout and "--gpus" in out.stdout, out.stderr[-2000:]

@@ -654,7 +654,7 @@ def test_xpool_tail_and_clip_loss(dev):
 
 
 # -------------------------------------------------------------------------------- matcher + criterion
-MATCHER_FIXTURE_TIE_SAMPLES = -1      # filled in from the first MI355X run of this round
+MATCHER_FIXTURE_TIE_SAMPLES = 1       # case 26, sample 1: the two assignments differ by ONE f32 ulp (2^-22) of total cost on the reference's block
 
 
 def test_matcher_golden_fixture_bit_exact(dev, golden_dir):

@@ -517,3 +517,192 @@ def test_posbn_relu_forward_backward_match_torch_batchnorm(T, dtype, tol, B, Tn,
     else:
         cos = torch.nn.functional.cosine_similarity(dx.float().reshape(-1), xr.grad.reshape(-1), dim=0)
         assert float(cos) >= 0.995
+
+
+# -------------------------------------------------------------------------------- round 3: the fused training decoder chain
+@pytest.mark.parametrize("D,N,p", [(512, 512, 0.1), (512, 1024, 0.1), (256, 256, 0.0), (512, 512, 0.0)])
+def test_dec_stage_training_options_match_the_separate_launches(T, D, N, p):
+    """made_dec_stage with bf16 raw rows: LayerNorm prologue (+ add), x_out / a_out, ReLU, dropout per element and per group of
+    columns -- against made_layernorm_add + made_linear with the same stateless masks (reference music_detr/transformer.py:273-307
+    forward_post in train mode).  The dropout pattern is identical; values agree to bf16 rounding (one rounding point differs)."""
+    ops, tr = T
+    M = 64
+    z = _rand(M, D, dtype=torch.bfloat16, seed=1)
+    W = (_rand(N, D, dtype=torch.float32, seed=2) / math.sqrt(D)).bfloat16()
+    b = _rand(N, dtype=torch.float32, seed=3) * 0.1
+    g, be = 1 + 0.1 * _rand(D, dtype=torch.float32, seed=4), 0.1 * _rand(D, dtype=torch.float32, seed=5)
+    add = _rand(1, D, dtype=torch.bfloat16, seed=6)
+    R = _rand(M, N, dtype=torch.bfloat16, seed=7)
+    seed = torch.full((1,), 4242, device="cuda", dtype=torch.int64)
+    for col_div, act in ((1, ops.ACT_RELU), (64, ops.ACT_NONE)):
+        drop = (seed, 77, p) if p > 0 else None
+        kw = dict(drop=drop, drop_ld=(N // col_div if col_div > 1 else N), drop_col_div=col_div)
+        x_ref, a_ref = torch.empty(M, D, device="cuda", dtype=torch.bfloat16), torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+        ops.layernorm_add(z, g, be, add.expand(M, D), x_ref, a_ref)
+        y_ref = ops.linear(a_ref, W, b, act=act, R=R, out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16), **kw)
+        x_out, a_out = torch.full_like(x_ref, float("nan")), torch.full_like(a_ref, float("nan"))
+        y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.dec_stage(z, W, b, y, ln=(g, be), add=add, x_out=x_out, a_out=a_out, R=R, act=act, **kw)
+        torch.cuda.synchronize()
+        assert float((x_out.float() - x_ref.float()).abs().max()) <= 2 ** -6        # one bf16 ulp at |x| < 4
+        assert float((a_out.float() - a_ref.float()).abs().max()) <= 2 ** -5
+        assert float((y.float() - y_ref.float()).abs().max()) <= 0.08, float((y.float() - y_ref.float()).abs().max())
+        if p > 0:
+            # where the reference output is exactly R (the branch was dropped), so is the fused one: same mask
+            dropped_ref, dropped = (y_ref == R), (y == R)
+            assert float((dropped_ref != dropped).float().mean()) <= 2e-3 and 0.05 < float(dropped.float().mean()) < 0.6
+    # no LayerNorm, no add (layer 0's first stage reads the content query itself)
+    y0 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.dec_stage(z, W, b, y0)
+    y0_ref = ops.linear(z, W, b)
+    torch.cuda.synchronize()
+    assert float((y0.float() - y0_ref.float()).abs().max()) <= 2 ** -6 * max(1.0, float(y0_ref.float().abs().max()))
+
+
+@pytest.mark.parametrize("B,NQ,L,D,p", [(64, 8, 542, 512, 0.1), (5, 8, 97, 256, 0.0), (3, 24, 300, 512, 0.1)])
+def test_wide_attention_merges_its_key_slices_inside_the_launch(T, B, NQ, L, D, p):
+    """made_attention_wide with keys split over workgroups: merged by the last workgroup of every entry (tickets) == merged by the
+    second launch, bit for bit (same slices, same order), launch after launch with the ticket words left at zero; lse_out = the
+    log-sum-exp of the scaled scores."""
+    ops, tr = T
+    q = _rand(B, NQ, 1, D, dtype=torch.bfloat16, seed=1)
+    k, v = _rand(B, L, D, dtype=torch.bfloat16, seed=2), _rand(B, L, D, dtype=torch.bfloat16, seed=3)
+    lens = torch.randint(L // 3, L + 1, (B,), device="cuda")
+    mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).float()
+    scale, ns = 1 / math.sqrt(64), 4
+    drop = (123, 5, p) if p > 0 else None
+    o1, s1 = torch.empty(B, NQ, 1, D, device="cuda", dtype=torch.bfloat16), torch.empty(B * NQ, device="cuda")
+    ops.attention_wide(q, k, v, o1, scale=scale, key_mask=mask, n_split=ns, drop=drop, sum_out=s1)
+    tickets = torch.zeros(B * ((NQ + 31) // 32), device="cuda", dtype=torch.int32)
+    for rep in range(3):
+        o2, s2, lse = torch.full_like(o1, float("nan")), torch.full_like(s1, float("nan")), torch.empty(B * NQ, device="cuda")
+        ops.attention_wide(q, k, v, o2, scale=scale, key_mask=mask, n_split=ns, drop=drop, sum_out=s2, tickets=tickets, lse_out=lse)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o2) and torch.equal(s1, s2), rep
+        assert int(tickets.abs().sum()) == 0
+    S = torch.einsum("bqd,bld->bql", q[:, :, 0].float(), k.float()) * scale + torch.where(mask == 0, float("-inf"), 0.0)[:, None]
+    ref = torch.logsumexp(S, dim=-1).reshape(-1)
+    assert float((lse - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_linear_per_head_bias_scaled_by_a_row_factor(T):
+    """made_linear's bias_row_scale (the value bias of the memory-space cross-attention under dropout: bias[h*hd + j] * s[row, h])
+    against made_linear + made_head_bias."""
+    ops, tr = T
+    M, D, H = 64, 512, 8
+    hd = D // H
+    pooled = _rand(M, H * D, dtype=torch.bfloat16, seed=1)
+    Wv = (_rand(D, D, dtype=torch.float32, seed=2) / math.sqrt(D)).bfloat16()
+    bv = _rand(D, dtype=torch.float32, seed=3)
+    s = torch.rand(M, H, device="cuda") + 0.5
+    ref = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    ops.linear(pooled[:, :D], Wv[:hd], None, M=M, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D, segs=[ops.Seg(out=ref, ldo=D, out_z_stride=hd)])
+    tr.head_bias(ref, s, bv, H)
+    got = torch.full_like(ref, float("nan"))
+    ops.linear(pooled[:, :D], Wv[:hd], bv, M=M, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D, segs=[ops.Seg(out=got, ldo=D, out_z_stride=hd)],
+               bias_row_scale=s, bias_z_stride=hd)
+    torch.cuda.synchronize()
+    exact = torch.einsum("mhk,hjk->mhj", pooled.float().view(M, H, D), Wv.float().view(H, hd, D)) + s[:, :, None] * bv.view(1, H, hd)
+    assert float((got.float().view(M, H, hd) - exact).abs().max()) <= 2 ** -7 * float(exact.abs().max())
+    assert float((got.float() - ref.float()).abs().max()) <= 2 ** -6 * float(exact.abs().max())
+
+
+@pytest.mark.parametrize("B,L,D,p,ns", [(64, 542, 512, 0.1, 4), (5, 146, 256, 0.0, 2), (3, 60, 512, 0.1, 1), (7, 333, 256, 0.2, 4)])
+def test_wide_attention_backward_in_one_launch(T, B, L, D, p, ns):
+    """made_attention_wide_bwd against torch autograd of the same memory-space attention (reference music_detr/transformer.py:293-296
+    in train mode: softmax over the valid keys, dropout on the weights, value bias weighted by the dropped weights' sum): Pd, dS, dQ',
+    with lse / ssum / O taken from made_attention_wide's forward, the value-bias term reduced from d attc, keys split over workgroups
+    and merged in the launch; repeated launches leave the ticket words at zero and reproduce the result bit for bit."""
+    ops, tr = T
+    H = NQ = 8
+    hd = D // H
+    Lp = (L + 7) // 8 * 8
+    scale = 1 / math.sqrt(hd)
+    q = (_rand(B, NQ, D, dtype=torch.float32, seed=1) * 0.5).bfloat16()
+    k, v = _rand(B, L, D, dtype=torch.bfloat16, seed=2), _rand(B, L, D, dtype=torch.bfloat16, seed=3)
+    dO = (_rand(B, NQ, D, dtype=torch.float32, seed=4) * 0.3).bfloat16()
+    dattc = (_rand(B, D, dtype=torch.float32, seed=5) * 0.3).bfloat16()
+    bv = _rand(D, dtype=torch.float32, seed=6) * 0.2
+    lens = torch.randint(max(L // 3, 1), L + 1, (B,), device="cuda")
+    lens[0] = L
+    mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).float()
+    seed, site = 77, 31
+    drop = (seed, site, p) if p > 0 else None
+    # forward on the device: O, lse, ssum
+    O = torch.empty(B, NQ, 1, D, device="cuda", dtype=torch.bfloat16)
+    ssum, lse = torch.empty(B * NQ, device="cuda"), torch.empty(B * NQ, device="cuda")
+    tk = torch.zeros(B, device="cuda", dtype=torch.int32)
+    ops.attention_wide(q.view(B, NQ, 1, D), k, v, O, scale=scale, key_mask=mask, n_split=4, drop=drop, sum_out=ssum, lse_out=lse, tickets=tk)
+    # reference: autograd through the same forward in f32 on the bf16 operands
+    qr = q.float().requires_grad_(True)
+    S = torch.einsum("bqd,bld->bql", qr, k.float()) * scale
+    P = torch.softmax(S.masked_fill((mask == 0)[:, None, :], float("-inf")), -1)
+    keep = _keep(seed, site, p, (B * NQ, L)).float().view(B, NQ, L) if p > 0 else torch.ones(B, NQ, L, device="cuda")
+    Pd_ref = P * keep / (1 - p)
+    Pd_ref.retain_grad()
+    pooled = torch.einsum("bql,bld->bqd", Pd_ref, v.float())
+    extra = (dattc.float().view(B, H, hd) * bv.view(1, H, hd)).sum(-1)                   # [B, NQ]: d(sum of dropped weights)
+    loss = (pooled * dO.float()).sum() + (Pd_ref.sum(-1) * extra).sum()
+    gS, = torch.autograd.grad(loss, S, retain_graph=True)
+    gq, = torch.autograd.grad(loss, qr)
+    np.testing.assert_allclose(ssum.view(B, NQ).cpu().numpy(), Pd_ref.sum(-1).detach().cpu().numpy(), atol=2e-2)
+    Pd = torch.full((B, 2, NQ, Lp), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dQ = torch.full((B, NQ, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    part = torch.empty(B * max(ns, 1) * NQ * D, device="cuda")
+    outs = []
+    for rep in range(2):
+        Pd.fill_(float("nan")); dQ.fill_(float("nan"))
+        tr.attention_wide_bwd(q, dO, O.view(B, NQ, D), k, v, lse.view(B, NQ), Pd[:, 0], Pd[:, 1], dQ, scale=scale, key_mask=mask,
+                              ssum=ssum.view(B, NQ), dattc=dattc, vbias=bv, hd=hd, drop=drop, n_split=ns, part_dq=part, tickets=tk)
+        torch.cuda.synchronize()
+        outs.append((Pd.clone(), dQ.clone()))
+        assert int(tk.abs().sum()) == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    got_pd, got_ds = Pd[:, 0, :, :L].float(), Pd[:, 1, :, :L].float()
+    assert bool(torch.isfinite(Pd).all()) and float(Pd[:, :, :, L:].abs().max() if Lp > L else 0.0) == 0.0
+    assert float((got_pd - Pd_ref.detach()).abs().max()) <= 1e-2
+    assert float((got_ds - gS * 1.0).abs().max()) <= 2e-2 * max(float(gS.abs().max()), 1e-3) + 2e-3
+    assert float((dQ.float() - gq).abs().max()) <= 3e-2 * float(gq.abs().max()) + 1e-3
+    masked = (mask == 0)[:, None, :].expand(B, NQ, L)
+    assert float(got_pd[masked].abs().max() if masked.any() else 0.0) == 0.0 and float(got_ds[masked].abs().max() if masked.any() else 0.0) == 0.0
+    # the same with the value-bias term handed in
+    dQ2 = torch.empty_like(dQ)
+    tr.attention_wide_bwd(q, dO, O.view(B, NQ, D), k, v, lse.view(B, NQ), Pd[:, 0], Pd[:, 1], dQ2, scale=scale, key_mask=mask,
+                          ssum=ssum.view(B, NQ), extra=extra.contiguous(), drop=drop, n_split=ns, part_dq=part, tickets=tk)
+    torch.cuda.synchronize()
+    assert float((dQ2.float() - dQ.float()).abs().max()) <= 2e-2 * float(gq.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("rows,D", [(64, 512), (37, 256)])
+def test_two_chained_layernorms_backward(T, dtype, tol, rows, D):
+    """made_layernorm_bwd2 (norm 3 of a decoder layer followed by the shared output norm) against torch autograd; the dropped copy
+    carries the stateless mask."""
+    ops, tr = T
+    xa = _rand(rows, D, dtype=dtype, seed=1)
+    ga, ba = 1 + 0.1 * _rand(D, dtype=torch.float32, seed=2), 0.1 * _rand(D, dtype=torch.float32, seed=3)
+    gb = 1 + 0.1 * _rand(D, dtype=torch.float32, seed=4)
+    dy, add = _rand(rows, D, dtype=dtype, seed=5), _rand(rows, D, dtype=dtype, seed=6)
+    xr = xa.float().requires_grad_(True)
+    t3 = torch.nn.functional.layer_norm(xr, (D,), ga, ba, 1e-5)
+    xb = t3.detach().to(dtype)                                    # what the forward saved
+    t3b = xb.float().requires_grad_(True)
+    hs = torch.nn.functional.layer_norm(t3b, (D,), gb, torch.zeros(D, device="cuda"), 1e-5)
+    gbr = gb.clone().requires_grad_(True)
+    hs2 = torch.nn.functional.layer_norm(t3b, (D,), gbr, torch.zeros(D, device="cuda", requires_grad=True), 1e-5)
+    (hs2 * dy.float()).sum().backward()
+    g_mid = t3b.grad + add.float()
+    gar = ga.clone().requires_grad_(True); bar = ba.clone().requires_grad_(True)
+    t3r = torch.nn.functional.layer_norm(xr, (D,), gar, bar, 1e-5)
+    (t3r * g_mid).sum().backward()
+    dx, dxd = torch.empty(rows, D, device="cuda", dtype=dtype), torch.empty(rows, D, device="cuda", dtype=dtype)
+    dga, dba, dgb, dbb = (torch.ones(D, device="cuda") for _ in range(4))
+    p, seed, site = 0.1, 3, 4
+    tr.layernorm_bwd2(xa, ga, xb, gb, dy, dx, dgamma_a=dga, dbeta_a=dba, dgamma_b=dgb, dbeta_b=dbb, add=add, dx_drop=dxd, drop=(seed, site, p))
+    torch.cuda.synchronize()
+    sc = float(xr.grad.abs().max())
+    assert float((dx.float() - xr.grad).abs().max()) <= tol * sc
+    keep = _keep(seed, site, p, (rows, D)).float()
+    assert float((dxd.float() - dx.float() * keep / (1 - p)).abs().max()) <= tol * sc
+    for got, ref in ((dga, gar.grad), (dba, bar.grad), (dgb, gbr.grad), (dbb, dy.float().sum(0))):
+        assert float((got - 1 - ref).abs().max()) <= 5 * tol * max(float(ref.abs().max()), 1.0)

@@ -341,7 +341,8 @@ def test_headline_training_step_properties_at_full_size():
     f2, g2, _ = run(7)
     for k in keys:
         assert torch.equal(f1[k], f2[k]), f"{k}: same seed, different forward"
-    assert float((g1 - g2).norm()) <= 1e-5 * float(g1.norm())                       # f32 atomics reorder the sums, nothing more
+    # f32 atomics reorder the weight-gradient sums, and a few bf16 roundings downstream of atomically summed values flip with them
+    assert float((g1 - g2).norm()) <= 1e-3 * float(g1.norm()), float((g1 - g2).norm()) / float(g1.norm())
     f3, g3, _ = run(8)
     assert not torch.equal(f1["hs"], f3["hs"]) and float((g1 - g3).norm()) > 1e-3 * float(g1.norm())
     # one optimizer step, eager against the captured iteration, from the same state
@@ -357,3 +358,44 @@ def test_headline_training_step_properties_at_full_size():
     moved = float((eager.flat_param - graph.flat_param).double().norm())
     step = float((eager.flat_param - trn.flat_param).double().norm())           # trn never stepped: |one Adam step|
     assert step > 0 and moved <= 0.05 * step, (moved, step)
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_fused_decoder_chain_matches_the_separate_launches(dropout, monkeypatch):
+    """bf16, one moment query: the fused training chain (LayerNorms in the consumers' prologues, key slices merged in the attention's
+    launch, value bias in the per-head Linear, fused memory-space attention backward) against round 2's chain of separate launches
+    (MADE_DEC_STAGE=0) on the same weights, batch and dropout masks: same losses and decoder states to bf16 rounding, gradients
+    aligned tensor by tensor."""
+    from mgsv_amd.trainer import MadeTrainer
+    from mgsv_amd.config import cfg_headline
+    from mgsv_amd import synth
+    res = {}
+    for cfg, shape in ((cfg_native_(), (6, 20, 40)), (cfg_headline(), (8, 30, 512))):
+        sd = synth.make_state_dict(cfg, seed=0)
+        b = _batch(cfg, *shape, seed=5)
+        for mode in ("0", "1"):
+            monkeypatch.setenv("MADE_DEC_STAGE", mode)
+            trn = MadeTrainer(cfg, sd, dtype="bf16")
+            trn.training_dropout = dropout
+            assert trn._dec_stage_chain() == (mode == "1")
+            o = trn.forward_train(*b, seed=13)
+            trn.backward()
+            torch.cuda.synchronize()
+            res[mode] = (float(o["localization_loss"]), float(o["retrieval_loss"]), o["hs"].float().clone(), trn.grads_numpy())
+        a, f = res["0"], res["1"]
+        assert abs(a[0] - f[0]) <= 2e-2 * abs(a[0]) and abs(a[1] - f[1]) <= 1e-3 * abs(a[1]), (a[:2], f[:2])
+        err = (a[2] - f[2]).abs() - 2.0 ** -6 * a[2].abs()
+        assert float(err.max()) <= 6e-2, float(err.max())
+        gmax = max(float(np.abs(g).max()) for g in a[3].values())
+        for k, g0 in a[3].items():
+            g1 = f[3][k]
+            n0 = np.linalg.norm(g0)
+            if n0 < 1e-5 * gmax * np.sqrt(g0.size):
+                continue
+            cos = float((g0.reshape(-1) @ g1.reshape(-1)) / (n0 * np.linalg.norm(g1) + 1e-30))
+            assert cos >= 0.97, (k, cos)
+
+
+def cfg_native_():
+    from mgsv_amd.config import cfg_native
+    return cfg_native()
