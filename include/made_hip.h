@@ -293,9 +293,10 @@ typedef struct MadeWideAttnArgs {
     MadeDropout drop;          /* dropout on the attention weights, element index ((b*NQ1 + i1)*NQ2 + i2)*L + key */
     float*  sum_out;           /* [B, NQ1*NQ2] f32 or NULL: sum of the dropped weights of each row (1 without dropout) */
     float*  lse_out;           /* [B, NQ1*NQ2] f32 or NULL: log-sum-exp of the scaled scores of each row (saved for made_attention_wide_bwd) */
-    uint32_t* tickets;         /* n_split > 1: NULL = a second launch merges the key slices; else [B * query tiles] words, zero before the
-                                  first call, and the workgroup that finishes an (entry, query tile) last merges its slices in this launch
-                                  (in slice order: deterministic) and leaves the word at zero */
+    uint32_t* tickets;         /* n_split > 1: NULL = a second launch merges the key slices (the default: faster); else [B * query tiles]
+                                  words, zero before the first call, and the workgroup that finishes an (entry, query tile) last merges
+                                  its slices in this launch (in slice order: deterministic) and leaves the word at zero -- measured
+                                  15-35 us SLOWER per launch on MI355X (the agent-scope fences write back / invalidate the XCD's L2) */
 } MadeWideAttnArgs;
 
 int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
@@ -310,7 +311,8 @@ int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
  * extra_q = gradient of the sum of row q's dropped weights (the value bias enters the forward as ssum_q b_v): `extra` [B, NQ] f32, or,
  * when `extra` is NULL and `dattc` is given, reduced here as <dattc[b, q*hd .. q*hd+hd), vbias[q*hd ..)> (one head per query row).
  * O = the forward's output rows, lse / ssum = its lse_out / sum_out.  Keys may be split over workgroups (n_split, part_dq
- * [B, n_split, NQ, D] f32, tickets [B] zeroed words left at zero); the slices' dQ are summed in slice order. NQ <= 8, D in {256, 512}. */
+ * [B, n_split, NQ, D] f32); the slices' dQ are summed in slice order by a small second launch, or -- tickets [B] zeroed words, left
+ * at zero -- inside the launch by the workgroup that finishes a sample last (measured slower on MI355X).  NQ <= 8, D in {256, 512}. */
 typedef struct MadeWideAttnBwdArgs {
     const void *Q, *dO, *O, *K, *V;
     const float* key_mask;                 /* [B, L] or NULL */
@@ -326,6 +328,28 @@ typedef struct MadeWideAttnBwdArgs {
     MadeDropout drop;
 } MadeWideAttnBwdArgs;
 int made_attention_wide_bwd(const MadeWideAttnBwdArgs* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Launch tape: record the library's launches of one training (or eval) step once, replay them from one C loop.
+ * Between made_tape_begin() and made_tape_end() every kernel launch of the calling thread is executed as usual AND appended to the
+ * tape (function, grid, block, LDS bytes, stream, argument bytes); made_stream_wait / made_memset_async / made_copy_async are the
+ * stream-to-stream dependency, fill and device-to-device copy that are recorded the same way (use them instead of the framework's
+ * own calls inside a recorded region).  made_tape_replay re-issues the sequence to the same streams: everything that changes
+ * between replays must therefore live in device memory at fixed addresses (batch buffers, MadeDropout.seed_device,
+ * MadeAdamDeviceState).  Replaces what the reference gets from the framework's eager dispatch (train-MaDe.py:337-381: ~5 300 ATen
+ * dispatches per step); a replayed launch costs the host the HIP runtime's 2-3 us instead of ~10 us of interpreter + ctypes or
+ * ~9 us of hipGraphLaunch's node walk, and the two streams keep their overlap. */
+int made_tape_begin(void);
+int made_tape_end(uint64_t* handle);
+int made_tape_replay(uint64_t handle);
+int made_tape_free(uint64_t handle);
+int made_tape_count(uint64_t handle, int64_t* kernels, int64_t* waits, int64_t* others);
+int made_stream_wait(void* src_stream, void* dst_stream);            /* dst waits for all work queued on src so far */
+int made_tape_event(int32_t op_kind, int32_t slot, void* stream);    /* recording only, executes nothing: 0 = "record event `slot` on
+                                                                         stream", 1 = "stream waits for event `slot`" -- mirrors the
+                                                                         framework's own Event.record / Stream.wait_event calls */
+int made_memset_async(void* dst, int32_t value, int64_t nbytes, void* stream);
+int made_copy_async(void* dst, const void* src, int64_t nbytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).                                                                   */

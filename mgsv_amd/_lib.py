@@ -154,6 +154,15 @@ SIGNATURES = {
     "made_abi_version": (C.c_int, []),
     "made_last_error": (C.c_char_p, []),
     "made_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "made_tape_begin": (C.c_int, []),
+    "made_tape_end": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "made_tape_replay": (C.c_int, [C.c_uint64]),
+    "made_tape_free": (C.c_int, [C.c_uint64]),
+    "made_tape_count": (C.c_int, [C.c_uint64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "made_stream_wait": (C.c_int, [vp, vp]),
+    "made_tape_event": (C.c_int, [i32, i32, vp]),
+    "made_memset_async": (C.c_int, [vp, i32, i64, vp]),
+    "made_copy_async": (C.c_int, [vp, vp, i64, vp]),
     "made_linear": (C.c_int, [C.POINTER(MadeLinearArgs), vp]),
     "made_splitk_finish": (C.c_int, [C.POINTER(MadeFinishArgs), vp]),
     "made_dec_stage": (C.c_int, [C.POINTER(MadeDecStageArgs), vp]),

@@ -38,3 +38,170 @@ extern "C" int made_device_info(char* name, int name_len, int* cu_count, int* is
     if (is_gfx950) *is_gfx950 = strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
     return MADE_OK;
 }
+
+
+// =================================================================================================
+// Launch tape: a recorded sequence of the library's kernel launches (with the stream-to-stream dependencies, memsets and copies
+// between them) that one call replays from a C loop.  The training step is ~600 launches of 5-50 us: issued from Python (10 us of
+// interpreter + ctypes per launch) or through hipGraphLaunch (which walks its nodes on the host at ~9 us apiece on this ROCm) the
+// host, not the GPU, sets the pace of the decoder's chain of small launches; replayed from here a launch costs the runtime's own
+// 2-3 us and both streams keep their overlap.  Everything that changes between replays must live in device memory (the batch
+// buffers, MadeDropout.seed_device, MadeAdamDeviceState): the tape holds argument BYTES.
+#include <vector>
+
+namespace {
+enum { TAPE_KERNEL = 0, TAPE_WAIT = 1, TAPE_MEMSET = 2, TAPE_COPY = 3, TAPE_EV_RECORD = 4, TAPE_EV_WAIT = 5 };
+struct TapeOp {
+    int kind;
+    const void* fn; dim3 grid, block; unsigned lds; hipStream_t st, st2;
+    size_t arg_off; int nargs; size_t ptr_off;               // kernel: argument bytes in `blob`, offsets of the arguments in `offs`
+    hipEvent_t ev;                                           // wait: recorded on st, awaited by st2
+    void* dst; const void* src; size_t nbytes; int value;    // memset / copy
+};
+struct Tape {
+    std::vector<TapeOp> ops;
+    std::vector<unsigned char> blob;
+    std::vector<size_t> offs;
+    std::vector<void*> ptrs;                                 // scratch of replay
+    std::vector<hipEvent_t> slots;                           // events of made_tape_event, by slot
+};
+}  // namespace
+
+thread_local void* g_made_tape = nullptr;
+
+void made_tape_push_kernel(const void* fn, dim3 grid, dim3 block, unsigned lds, hipStream_t st, void** arg_ptrs, const size_t* arg_sizes, int n) {
+    Tape* t = (Tape*)g_made_tape;
+    TapeOp op{};
+    op.kind = TAPE_KERNEL; op.fn = fn; op.grid = grid; op.block = block; op.lds = lds; op.st = st;
+    op.nargs = n; op.ptr_off = t->offs.size();
+    for (int i = 0; i < n; ++i) {
+        size_t off = (t->blob.size() + 15) & ~(size_t)15;
+        t->blob.resize(off + arg_sizes[i]);
+        memcpy(t->blob.data() + off, arg_ptrs[i], arg_sizes[i]);
+        t->offs.push_back(off);
+    }
+    t->ops.push_back(op);
+}
+
+extern "C" int made_tape_begin(void) {
+    MADE_REQUIRE(g_made_tape == nullptr, "made_tape_begin: this thread is already recording");
+    g_made_tape = new Tape();
+    return MADE_OK;
+}
+
+extern "C" int made_tape_end(uint64_t* handle) {
+    MADE_REQUIRE(g_made_tape != nullptr && handle != nullptr, "made_tape_end: not recording");
+    *handle = (uint64_t)(uintptr_t)g_made_tape;
+    g_made_tape = nullptr;
+    return MADE_OK;
+}
+
+extern "C" int made_tape_free(uint64_t handle) {
+    Tape* t = (Tape*)(uintptr_t)handle;
+    if (t == nullptr) return MADE_OK;
+    for (auto& op : t->ops)
+        if (op.kind == TAPE_WAIT && op.ev) (void)hipEventDestroy(op.ev);
+    for (auto ev : t->slots)
+        if (ev) (void)hipEventDestroy(ev);
+    delete t;
+    return MADE_OK;
+}
+
+extern "C" int made_tape_count(uint64_t handle, int64_t* kernels, int64_t* waits, int64_t* others) {
+    Tape* t = (Tape*)(uintptr_t)handle;
+    MADE_REQUIRE(t != nullptr, "made_tape_count: null tape");
+    int64_t k = 0, w = 0, o = 0;
+    for (auto& op : t->ops) { if (op.kind == TAPE_KERNEL) ++k; else if (op.kind == TAPE_WAIT) ++w; else ++o; }
+    if (kernels) *kernels = k;
+    if (waits) *waits = w;
+    if (others) *others = o;
+    return MADE_OK;
+}
+
+// dst_stream waits for everything src_stream has been given so far (torch's Stream.wait_stream / Event.record + wait_event)
+extern "C" int made_stream_wait(void* src_stream, void* dst_stream) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { made_set_error("made_stream_wait: hipEventCreate failed"); return MADE_ERR_HIP; }
+    hipError_t e = hipEventRecord(ev, (hipStream_t)src_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)dst_stream, ev, 0);
+    if (e != hipSuccess) { (void)hipEventDestroy(ev); made_set_error("made_stream_wait: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
+    if (g_made_tape) {
+        TapeOp op{};
+        op.kind = TAPE_WAIT; op.st = (hipStream_t)src_stream; op.st2 = (hipStream_t)dst_stream; op.ev = ev;
+        ((Tape*)g_made_tape)->ops.push_back(op);
+    } else {
+        (void)hipEventDestroy(ev);                           // (destruction is deferred by the runtime until the event has completed)
+    }
+    return MADE_OK;
+}
+
+// Recording only (nothing is executed: the caller's own event call does that): "record event `slot` on `stream`" (op 0) or "`stream`
+// waits for event `slot`" (op 1) -- the framework's Event.record / Stream.wait_event pair, mirrored into the tape.
+extern "C" int made_tape_event(int32_t op_kind, int32_t slot, void* stream) {
+    Tape* t = (Tape*)g_made_tape;
+    MADE_REQUIRE(t != nullptr, "made_tape_event: not recording");
+    MADE_REQUIRE((op_kind == 0 || op_kind == 1) && slot >= 0 && slot < 65536, "made_tape_event: bad op / slot");
+    if ((size_t)slot >= t->slots.size()) t->slots.resize((size_t)slot + 1, nullptr);
+    if (t->slots[slot] == nullptr) {
+        MADE_REQUIRE(op_kind == 0, "made_tape_event: slot %d is waited for before it was recorded", slot);
+        if (hipEventCreateWithFlags(&t->slots[slot], hipEventDisableTiming) != hipSuccess) { made_set_error("made_tape_event: hipEventCreate failed"); return MADE_ERR_HIP; }
+    }
+    TapeOp op{};
+    op.kind = op_kind == 0 ? TAPE_EV_RECORD : TAPE_EV_WAIT; op.st = (hipStream_t)stream; op.ev = t->slots[slot];
+    t->ops.push_back(op);
+    return MADE_OK;
+}
+
+extern "C" int made_memset_async(void* dst, int32_t value, int64_t nbytes, void* stream) {
+    MADE_REQUIRE(dst != nullptr && nbytes >= 0, "made_memset_async: bad arguments");
+    if (nbytes == 0) return MADE_OK;
+    hipError_t e = hipMemsetAsync(dst, value, (size_t)nbytes, (hipStream_t)stream);
+    if (e != hipSuccess) { made_set_error("made_memset_async: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
+    if (g_made_tape) {
+        TapeOp op{};
+        op.kind = TAPE_MEMSET; op.st = (hipStream_t)stream; op.dst = dst; op.nbytes = (size_t)nbytes; op.value = value;
+        ((Tape*)g_made_tape)->ops.push_back(op);
+    }
+    return MADE_OK;
+}
+
+extern "C" int made_copy_async(void* dst, const void* src, int64_t nbytes, void* stream) {
+    MADE_REQUIRE(dst != nullptr && src != nullptr && nbytes >= 0, "made_copy_async: bad arguments");
+    if (nbytes == 0) return MADE_OK;
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { made_set_error("made_copy_async: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
+    if (g_made_tape) {
+        TapeOp op{};
+        op.kind = TAPE_COPY; op.st = (hipStream_t)stream; op.dst = dst; op.src = src; op.nbytes = (size_t)nbytes;
+        ((Tape*)g_made_tape)->ops.push_back(op);
+    }
+    return MADE_OK;
+}
+
+extern "C" int made_tape_replay(uint64_t handle) {
+    Tape* t = (Tape*)(uintptr_t)handle;
+    MADE_REQUIRE(t != nullptr, "made_tape_replay: null tape");
+    MADE_REQUIRE(g_made_tape == nullptr, "made_tape_replay: this thread is recording");
+    unsigned char* blob = t->blob.data();
+    for (auto& op : t->ops) {
+        hipError_t e = hipSuccess;
+        switch (op.kind) {
+            case TAPE_KERNEL: {
+                t->ptrs.resize((size_t)op.nargs > t->ptrs.size() ? (size_t)op.nargs : t->ptrs.size());
+                for (int i = 0; i < op.nargs; ++i) t->ptrs[i] = blob + t->offs[op.ptr_off + i];
+                e = hipLaunchKernel(op.fn, op.grid, op.block, t->ptrs.data(), op.lds, op.st);
+                break;
+            }
+            case TAPE_WAIT:
+                e = hipEventRecord(op.ev, op.st);
+                if (e == hipSuccess) e = hipStreamWaitEvent(op.st2, op.ev, 0);
+                break;
+            case TAPE_EV_RECORD: e = hipEventRecord(op.ev, op.st); break;
+            case TAPE_EV_WAIT: e = hipStreamWaitEvent(op.st, op.ev, 0); break;
+            case TAPE_MEMSET: e = hipMemsetAsync(op.dst, op.value, op.nbytes, op.st); break;
+            default: e = hipMemcpyAsync(op.dst, op.src, op.nbytes, hipMemcpyDeviceToDevice, op.st); break;
+        }
+        if (e != hipSuccess) { made_set_error("made_tape_replay: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
+    }
+    return MADE_OK;
+}

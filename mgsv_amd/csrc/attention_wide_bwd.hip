@@ -16,7 +16,8 @@
 //   * K and V tiles are staged global -> LDS directly (global_load_lds), two stages; K carries the 64-byte-group swizzle the
 //     transposing reads want (its row reads are then 2-way bank conflicted, which this latency-bound kernel does not notice),
 //     V the 16-byte-chunk swizzle of the row reads;
-//   * the key slices' partial dQ' meet in an f32 workspace and the workgroup that finishes a sample last sums them in slice order.
+//   * the key slices' partial dQ' meet in an f32 workspace and a small second launch sums them in slice order (summing them inside
+//     the launch behind a ticket -- `tickets` -- works and is slower: the fences cost more than the launch).
 #include "common.h"
 
 namespace {
@@ -284,6 +285,9 @@ __global__ __launch_bounds__(NT) void attention_wide_bwd_kernel(const MadeWideAt
                 *(f32x4*)(po + d * 32 + 8 * g4 + 4 * hh) = pk;
             }
     }
+    if (a.tickets == nullptr) return;                               // the slices are summed by wide_bwd_merge_kernel (a second launch)
+    // (merged inside the launch: measured SLOWER on MI355X -- the agent-scope release / acquire pair around the ticket writes back
+    //  and invalidates the XCD's L2 under the other workgroups' feet, +15-20 us per launch; kept for the record, off by default)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     int* flag = (int*)lds_x;
@@ -319,6 +323,35 @@ __global__ __launch_bounds__(NT) void attention_wide_bwd_kernel(const MadeWideAt
     }
 }
 
+// dQ[b, q, :] = sum over the key slices of part_dq[b, slice, q, :] (slice order), one wave per row
+__global__ __launch_bounds__(NT) void wide_bwd_merge_kernel(const MadeWideAttnBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.B * a.NQ) return;
+    const int64_t b = row / a.NQ, q = row % a.NQ;
+    const int D = (int)a.D;
+    const int per = D / 64;                                         // 8 or 4 columns per lane
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int64_t sp = 0; sp < a.n_split; ++sp) {
+        const float* pp = a.part_dq + ((b * a.n_split + sp) * a.NQ + q) * D + lane * per;
+        const f32x4 t0 = *(const f32x4*)pp;
+        acc[0] += t0[0]; acc[1] += t0[1]; acc[2] += t0[2]; acc[3] += t0[3];
+        if (per == 8) {
+            const f32x4 t1 = *(const f32x4*)(pp + 4);
+            acc[4] += t1[0]; acc[5] += t1[1]; acc[6] += t1[2]; acc[7] += t1[3];
+        }
+    }
+    bf16_t* dq = (bf16_t*)a.dQ + b * a.dq_bs + q * a.ld_dq + lane * per;
+    bf16x4 p0; p0[0] = (bf16_t)acc[0]; p0[1] = (bf16_t)acc[1]; p0[2] = (bf16_t)acc[2]; p0[3] = (bf16_t)acc[3];
+    *(bf16x4*)dq = p0;
+    if (per == 8) {
+        bf16x4 p1; p1[0] = (bf16_t)acc[4]; p1[1] = (bf16_t)acc[5]; p1[2] = (bf16_t)acc[6]; p1[3] = (bf16_t)acc[7];
+        *(bf16x4*)(dq + 4) = p1;
+    }
+}
+
 template <int D>
 int launch_wide_bwd(const MadeWideAttnBwdArgs& a, hipStream_t st) {
     constexpr size_t kBase = (size_t)2 * 2 * BK * D * 2 + (size_t)(4 * 2 * BK * MAXQ + 8 + 4 * MAXQ) * 4;
@@ -338,7 +371,10 @@ int launch_wide_bwd(const MadeWideAttnBwdArgs& a, hipStream_t st) {
     }
     const int64_t nsplit = a.n_split > 1 ? a.n_split : 1;
     hipLaunchKernelGGL((attention_wide_bwd_kernel<D>), dim3(1, (unsigned)a.B, (unsigned)nsplit), dim3(NT), lds_bytes, st, a);
-    return made_check_launch("made_attention_wide_bwd");
+    int rc = made_check_launch("made_attention_wide_bwd");
+    if (rc != MADE_OK || nsplit == 1 || a.tickets != nullptr) return rc;
+    hipLaunchKernelGGL(wide_bwd_merge_kernel, dim3((unsigned)((a.B * a.NQ + 3) / 4)), dim3(NT), 0, st, a);
+    return made_check_launch("made_attention_wide_bwd(merge)");
 }
 
 }  // namespace
@@ -363,7 +399,7 @@ extern "C" int made_attention_wide_bwd(const MadeWideAttnBwdArgs* args, void* st
         MADE_REQUIRE(a.vbias != nullptr && a.hd > 0 && a.hd % 8 == 0 && a.hd * a.NQ <= a.D, "made_attention_wide_bwd: dattc needs vbias and hd (a multiple of 8)");
     }
     if (a.n_split > 1) {
-        MADE_REQUIRE(a.part_dq != nullptr && a.tickets != nullptr, "made_attention_wide_bwd: n_split > 1 needs part_dq and tickets");
+        MADE_REQUIRE(a.part_dq != nullptr, "made_attention_wide_bwd: n_split > 1 needs part_dq");
         MADE_UNSUPPORTED(a.n_split <= 64, "made_attention_wide_bwd: n_split <= 64");
     }
     if (a.B == 0) return MADE_OK;

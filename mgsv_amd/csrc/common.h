@@ -34,6 +34,31 @@ void made_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// ---- launch tape (include/made_hip.h: made_tape_*) ------------------------------------------------
+// Every kernel of the library is launched through made_launch (the hipLaunchKernelGGL spelling below is redirected to it): the
+// launch goes to the stream as always and, while the calling thread records a tape, a copy of (function, grid, block, LDS bytes,
+// stream, argument bytes) is appended to it, so that the sequence can be replayed later from one C loop.
+extern thread_local void* g_made_tape;                      // the tape this thread is recording (NULL: none)
+void made_tape_push_kernel(const void* fn, dim3 grid, dim3 block, unsigned lds, hipStream_t st, void** arg_ptrs, const size_t* arg_sizes, int n);
+
+#include <tuple>
+#include <utility>
+template <typename... KArgs, size_t... I, typename Tup>
+inline void made_launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Tup& t, std::index_sequence<I...>) {
+    void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {(void*)&std::get<I>(t)...};
+    const size_t sizes[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {sizeof(std::get<I>(t))...};
+    if (g_made_tape) made_tape_push_kernel((const void*)kernel, grid, block, (unsigned)lds, st, ptrs, sizes, (int)sizeof...(KArgs));
+    (void)hipLaunchKernel((const void*)kernel, grid, block, ptrs, lds, st);
+}
+template <typename... KArgs, typename... Args>
+inline void made_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "made_launch: argument count");
+    std::tuple<KArgs...> t{static_cast<KArgs>(args)...};      // by value, in the kernel's own parameter types
+    made_launch_impl(kernel, grid, block, lds, st, t, std::index_sequence_for<KArgs...>{});
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) made_launch(kernel, grid, block, lds, stream, __VA_ARGS__)
+
 static inline int made_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

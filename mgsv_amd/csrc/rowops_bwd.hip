@@ -229,6 +229,134 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs 
     flush_cols<NV, NW>(a.dbeta, db, D, lane, wave, sm);
 }
 
+// ---- LayerNorm backward, the wide-access form for the step's large launches: bf16 rows of 512 columns -------------------------
+// A lane owns 8 CONSECUTIVE columns, so every tensor of a row moves as one 16-byte access per lane (1 KB per wave instruction;
+// the general kernel above moves 8 bytes per lane and needs two per tensor), and a wave keeps FOUR rows in flight: the loads of
+// all four are requested before the first reduction, and the four rows' dependent reduction chains interleave.
+template <int NW, int RF>
+__global__ __launch_bounds__(NW * 64) void layernorm_bwd_v8_kernel(const LnBwdArgs a) {
+    constexpr int D = 512;
+    __shared__ float sm[NW * D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * 8;
+    float dg[8], db[8], gm[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+    {
+        const f32x4 g0 = *(const f32x4*)(a.gamma + c0), g1 = *(const f32x4*)(a.gamma + c0 + 4);
+        gm[0] = g0[0]; gm[1] = g0[1]; gm[2] = g0[2]; gm[3] = g0[3]; gm[4] = g1[0]; gm[5] = g1[1]; gm[6] = g1[2]; gm[7] = g1[3];
+    }
+    const uint32_t thr = made_drop_threshold(a.drop.p);
+    const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
+    const float dsc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
+    const bf16_t* X = (const bf16_t*)a.x; const bf16_t* DY = (const bf16_t*)a.dy; const bf16_t* AD = (const bf16_t*)a.add;
+    bf16_t* DX = (bf16_t*)a.dx; bf16_t* DXD = (bf16_t*)a.dxd;
+    const int64_t stride = (int64_t)gridDim.x * NW;
+    for (int64_t base = (int64_t)blockIdx.x * NW + wave; base < a.rows; base += 64 * stride) {
+        const int64_t cand = base + (int64_t)lane * stride;
+        const bool ok = cand < a.rows && (!a.row_skip || a.row_skip[cand] != 0.f);
+        uint64_t todo = __ballot(ok);
+        while (todo) {
+            int64_t rw[RF]; bool on[RF];
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                on[k] = todo != 0;
+                const int j = on[k] ? __builtin_ctzll(todo) : 0;
+                if (on[k]) todo &= todo - 1;
+                rw[k] = on[k] ? base + (int64_t)j * stride : base;          // (an idle slot re-reads a valid row and stores nothing)
+            }
+            bf16x8 xr[RF], gr[RF], ar[RF];
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                xr[k] = *(const bf16x8*)(X + rw[k] * a.ldx + c0);
+                gr[k] = *(const bf16x8*)(DY + rw[k] * a.lddy + c0);
+                if (AD) ar[k] = *(const bf16x8*)(AD + rw[k] * a.ldadd + c0);
+            }
+            // the dropout draws need nothing of the rows: made while the loads are in flight
+            uint32_t kbits[RF];
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                kbits[k] = 0xFFu;
+                if (a.drop.p > 0.f) {
+                    const uint64_t dbase = (uint64_t)rw[k] * (uint64_t)a.drop_ld + (uint64_t)c0;
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m |= keep_at(drop_seed, a.drop.site, thr, dbase + j) ? (1u << j) : 0u;
+                    kbits[k] = m;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RF; ++k) asm volatile("" : "+v"(kbits[k]));      // (keep the draws in front of the first use of the loads)
+            float xv[RF][8], gy[RF][8], mean[RF], rstd[RF], s1[RF], s2[RF];
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xv[k][j] = (float)xr[k][j]; gy[k][j] = (float)gr[k][j]; sum += xv[k][j]; }
+                mean[k] = sum;
+            }
+#pragma unroll
+            for (int k = 0; k < RF; ++k) mean[k] = wave_sum(mean[k]) * (1.f / D);
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                float sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xv[k][j] -= mean[k]; sq += xv[k][j] * xv[k][j]; }
+                rstd[k] = sq;
+            }
+#pragma unroll
+            for (int k = 0; k < RF; ++k) rstd[k] = 1.0f / sqrtf(wave_sum(rstd[k]) * (1.f / D) + a.eps);
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = xv[k][j] * rstd[k];
+                    const float g = gy[k][j] * gm[j];
+                    if (on[k]) { dg[j] += gy[k][j] * xh; db[j] += gy[k][j]; }
+                    xv[k][j] = xh; gy[k][j] = g;
+                    t1 += g; t2 += g * xh;
+                }
+                s1[k] = t1; s2[k] = t2;
+            }
+#pragma unroll
+            for (int k = 0; k < RF; ++k) { s1[k] = wave_sum(s1[k]) * (1.f / D); s2[k] = wave_sum(s2[k]) * (1.f / D); }
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                if (!on[k]) continue;
+                bf16x8 o, od;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = rstd[k] * (gy[k][j] - s1[k] - xv[k][j] * s2[k]);
+                    if (AD) v += (float)ar[k][j];
+                    o[j] = (bf16_t)v;
+                    v = ((kbits[k] >> j) & 1u) ? v * dsc : 0.f;
+                    od[j] = (bf16_t)v;
+                }
+                *(bf16x8*)(DX + rw[k] * a.lddx + c0) = o;
+                if (DXD) *(bf16x8*)(DXD + rw[k] * a.lddxd + c0) = od;
+            }
+        }
+    }
+    // parameter gradients: the waves' column partials meet in LDS, one atomic per column and workgroup
+    for (int pass = 0; pass < 2; ++pass) {
+        float* dst = pass == 0 ? a.dgamma : a.dbeta;
+        if (dst == nullptr) continue;
+        const float* src = pass == 0 ? dg : db;
+        f32x4 p0, p1;
+        p0[0] = src[0]; p0[1] = src[1]; p0[2] = src[2]; p0[3] = src[3]; p1[0] = src[4]; p1[1] = src[5]; p1[2] = src[6]; p1[3] = src[7];
+        *(f32x4*)(sm + wave * D + c0) = p0; *(f32x4*)(sm + wave * D + c0 + 4) = p1;
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += NW * 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += sm[w * D + c];
+            unsafeAtomicAdd(dst + c, t);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- two chained LayerNorms backward in one pass (the decoder's per-layer norm 3 followed by the shared output norm) -----------
 //   forward: t3 = LN_a(x_a) (+ nothing),  hs = LN_b(t3)      x_b = the saved t3
 //   g  = LN_b'(dy; x_b, gamma_b) + add        (add: the gradient arriving at t3 from the next layer)
@@ -841,7 +969,25 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
     if (drop) a.drop = *drop;
     a.drop_ld = drop_ld > 0 ? drop_ld : D;
     a.dgamma = dgamma; a.dbeta = dbeta; a.rows = rows; a.D = (int)D; a.eps = eps; a.row_skip = row_skip;
-    if (rows > 256 && D <= 1024) {                              // each workgroup flushes 2*D same-address atomics: few, large workgroups
+    const bool v8 = rows > 256 && D == 512 && x_rows_per_batch == 0 && x_dtype == MADE_BF16 && dy_dtype == MADE_BF16 && dx_dtype == MADE_BF16 &&
+                    (add == nullptr || add_dtype == MADE_BF16) && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ld_add % 8 == 0 && lddxd % 8 == 0 &&
+                    ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)add % 16) == 0 &&
+                    ((uintptr_t)dx_drop % 16) == 0 && getenv("MADE_LNBWD_V8_OFF") == nullptr;
+    if (v8) {                                                   // bf16 rows of 512: 16-byte accesses, four rows in flight per wave
+        // measured (tools/r03_micro.py, 18 979 valid rows, dropout + flush): 16-wave workgroups with two rows in flight per wave, one per CU:
+        // 29.4 us; 8-wave workgroups with four rows in flight: 31.5 (256) / 34.0 us (512 workgroups); the 8-byte kernel: 36.9 us
+        static const int rf = [] { const char* e = getenv("MADE_LNBWD_RF"); return e ? atoi(e) : 2; }();          // knobs for measurements
+        static const int nb_cap8 = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();
+        if (rf == 2) {
+            int64_t nb = (rows + 15) / 16;
+            if (nb > nb_cap8) nb = nb_cap8;
+            hipLaunchKernelGGL((layernorm_bwd_v8_kernel<16, 2>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a);
+        } else {
+            int64_t nb = (rows + 7) / 8;
+            if (nb > nb_cap8) nb = nb_cap8;
+            hipLaunchKernelGGL((layernorm_bwd_v8_kernel<8, 4>), dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, a);
+        }
+    } else if (rows > 256 && D <= 1024) {                       // each workgroup flushes 2*D same-address atomics: few, large workgroups
         int64_t nb = (rows + 15) / 16;
         static const int nb_cap = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
         if (nb > nb_cap) nb = nb_cap;

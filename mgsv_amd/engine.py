@@ -241,7 +241,6 @@ class MadeEngine:
             dq_all=E(B * Q, c.detr_nheads * D), dpool=E(B * Q, c.detr_nheads * D),
             dws=E(32 * B * Q * max(D, 256) * 4 * max(1, nd // 4), dtype=torch.float32),   # split-K partials of the skinny GEMMs
             part_o=E(B * 8 * c.detr_nheads * Q * D, dtype=torch.float32), part_ml=E(B * 8 * c.detr_nheads * Q * 4, dtype=torch.float32),
-            wide_tickets=Z(B * ((c.detr_nheads * Q + 31) // 32), dtype=torch.int32),   # key slices merged inside made_attention_wide's launch
             vmean=E(B, D, dtype=torch.float32), mmean=E(B, D, dtype=torch.float32),
             video=E(B, D, dtype=torch.float32), music=E(B, D, dtype=torch.float32),
             tgt=E(B * Q, D), t1=E(B * Q, D), t2=E(B * Q, D), tx=E(B * Q, D),
@@ -637,7 +636,7 @@ class MadeEngine:
                 if l > 0 or dec_early is None:
                     self._dec_fused_query_side(ws, l, self._dec_first_rows(ws, video, music) if l == 0 else None)
                 ops.attention_wide(dq4, mempos3, mem3, dp4, scale=ca_scale, key_mask=fus_mask,
-                                   n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"], tickets=ws["wide_tickets"])
+                                   n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
                 dv = ws["dv"]
                 ops.linear(dpool[:, :D], P[p + ".ca.v.w"][:hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
                            segs=[Seg(out=dv, ldo=D, out_z_stride=hd)])                       # v_h = W_v,h pooled_h (b_v rides in ca.vo.b)
@@ -650,7 +649,7 @@ class MadeEngine:
             if l > 0 or dec_early is None:
                 self._decoder_query_side(ws, l, B)
             ops.attention_wide(dq4, mempos3, mem3, dp4, scale=ca_scale, key_mask=fus_mask,
-                               n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"], tickets=ws["wide_tickets"])
+                               n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
             skinny(dpool, p + ".ca.vo", R=t1, ln1=ln2, ln1_out=t2)
             skinny(t2, p + ".ff1", act=ops.ACT_RELU, out=ws["dffn"])
             skinny(ws["dffn"], p + ".ff2", R=t2, ln1=ln3, ln1_out=tgt, ln2=(P["dec.norm.g"], P["dec.norm.b"]), ln2_out=hs[l])

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from . import _lib
+from . import _lib, tape as _tape
 from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, BF16, F32,  # noqa: F401
                    MadeAttnArgs, MadeDecStageArgs, MadeFinishArgs, MadeLinearArgs, MadeLinearSeg, MadeWideAttnArgs, check, lib)
 
@@ -37,6 +37,8 @@ def _p(t: Optional[Tensor]):
         return None
     if not t.is_cuda:
         raise _lib.MadeError("libmade_hip ops need GPU tensors (no CPU fallback)")
+    if _tape._recording is not None:                          # a launch tape holds raw pointers: keep what it points at alive
+        _tape._recording._keep.append(t)
     return t.data_ptr()
 
 
@@ -631,7 +633,7 @@ def hungarian_match(pred_logits: Tensor, pred_spans: Tensor, targets: Tensor, fg
     pi = torch.empty((NS, width), device=dev, dtype=torch.int64)
     ti = torch.empty((NS, width), device=dev, dtype=torch.int64)
     cnt = torch.empty((NS,), device=dev, dtype=torch.int32)
-    status = torch.zeros((1,), device=dev, dtype=torch.int32)
+    status = _tape.zero_(torch.empty((1,), device=dev, dtype=torch.int32))
     check(lib().made_hungarian_match(_p(_f32(pred_logits, "pred_logits")), _p(_f32(pred_spans, "pred_spans")),
                                      _p(_f32(targets, "targets")), NS, B, Q, G, fg_label, w_span, w_giou, w_class,
                                      _p(cost), 1 if cost_in is not None else 0, _p(pi), _p(ti), _p(cnt), _p(status), _stream()), "made_hungarian_match")

@@ -276,8 +276,10 @@ def attention_wide_bwd(Q: Tensor, dO: Tensor, O: Tensor, K: Tensor, V: Tensor, l
     a.scale = float(scale)
     if n_split > 1:
         assert part_dq is not None and part_dq.dtype == torch.float32 and part_dq.numel() >= B * n_split * NQ * D
-        assert tickets is not None and tickets.dtype == torch.int32 and tickets.numel() >= B
-        a.n_split, a.part_dq, a.tickets = n_split, _p(part_dq), _p(tickets)
+        a.n_split, a.part_dq = n_split, _p(part_dq)
+        if tickets is not None:                               # (sum the slices inside the launch: slower, see include/made_hip.h)
+            assert tickets.dtype == torch.int32 and tickets.numel() >= B
+            a.tickets = _p(tickets)
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
     _timed("made_attention_wide_bwd", 6.0 * B * NQ * L * D, 2.0 * B * (2 * L * D + 4 * NQ * D + 2 * NQ * L),

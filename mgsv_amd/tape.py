@@ -1,0 +1,116 @@
+"""Launch tape: record the libmade_hip launches of one step once, replay them from one C loop (include/made_hip.h: made_tape_*).
+
+    with LaunchTape.record() as tape:      # the step runs normally (and is recorded)
+        trainer.train_step(...)
+    tape.replay()                          # re-issues the same launches on the same streams
+
+While recording, torch's stream dependencies (Stream.wait_stream / wait_event, Event.record) are mirrored into the tape, every
+tensor handed to a library call is kept alive (the tape holds raw pointers), and fills / contiguous copies go through `zero_` /
+`copy_` below.  Any OTHER device work of the framework inside the recorded region (an ATen kernel) would be missing from the replay:
+`LaunchTape.record(check=True)` counts them with the profiler and raises if there are any.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+_recording: Optional["LaunchTape"] = None
+
+
+def recording() -> bool:
+    return _recording is not None
+
+
+def keep(t) -> None:
+    """called by ops._p for every tensor a library call receives"""
+    if _recording is not None and t is not None:
+        _recording._keep.append(t)
+
+
+def zero_(t: Tensor) -> Tensor:
+    """t.zero_() as a recorded stream-ordered fill (made_memset_async); t must be contiguous."""
+    assert t.is_contiguous() and t.is_cuda
+    keep(t)
+    _lib.check(_lib.lib().made_memset_async(t.data_ptr(), 0, t.numel() * t.element_size(), torch.cuda.current_stream().cuda_stream), "made_memset_async")
+    return t
+
+
+def copy_(dst: Tensor, src: Tensor) -> Tensor:
+    """dst.copy_(src) for contiguous tensors of one dtype and size, as a recorded device-to-device copy."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel() and dst.is_cuda and src.is_cuda
+    keep(dst); keep(src)
+    _lib.check(_lib.lib().made_copy_async(dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), torch.cuda.current_stream().cuda_stream),
+               "made_copy_async")
+    return dst
+
+
+class LaunchTape:
+    def __init__(self):
+        self.handle = C.c_uint64(0)
+        self._keep: List[object] = []
+        self._slots = {}
+
+    # ---- recording
+    @classmethod
+    @contextlib.contextmanager
+    def record(cls):
+        global _recording
+        assert _recording is None, "tapes do not nest"
+        tape = cls()
+        lib = _lib.lib()
+        S, E = torch.cuda.Stream, torch.cuda.Event
+        o_ws, o_we, o_rec = S.wait_stream, S.wait_event, E.record
+
+        def slot_of(ev) -> int:
+            return tape._slots.setdefault(id(ev), len(tape._slots))
+
+        def wait_stream(self, other):
+            o_ws(self, other)
+            s = len(tape._slots)
+            tape._slots[("ws", s)] = s
+            _lib.check(lib.made_tape_event(0, s, other.cuda_stream), "made_tape_event")
+            _lib.check(lib.made_tape_event(1, s, self.cuda_stream), "made_tape_event")
+
+        def wait_event(self, ev):
+            o_we(self, ev)
+            tape._keep.append(ev)
+            _lib.check(lib.made_tape_event(1, slot_of(ev), self.cuda_stream), "made_tape_event")
+
+        def record(self, stream=None):
+            st = stream if stream is not None else torch.cuda.current_stream()
+            o_rec(self, st)
+            tape._keep.append(self)
+            _lib.check(lib.made_tape_event(0, slot_of(self), st.cuda_stream), "made_tape_event")
+
+        _lib.check(lib.made_tape_begin(), "made_tape_begin")
+        _recording = tape
+        S.wait_stream, S.wait_event, E.record = wait_stream, wait_event, record
+        try:
+            yield tape
+        finally:
+            S.wait_stream, S.wait_event, E.record = o_ws, o_we, o_rec
+            _recording = None
+            _lib.check(lib.made_tape_end(C.byref(tape.handle)), "made_tape_end")
+
+    # ---- replay
+    def replay(self) -> None:
+        _lib.check(_lib.lib().made_tape_replay(self.handle), "made_tape_replay")
+
+    def counts(self):
+        k, w, o = _lib.i64(0), _lib.i64(0), _lib.i64(0)
+        _lib.check(_lib.lib().made_tape_count(self.handle, C.byref(k), C.byref(w), C.byref(o)), "made_tape_count")
+        return int(k.value), int(w.value), int(o.value)
+
+    def __del__(self):
+        try:
+            if self.handle.value:
+                _lib.lib().made_tape_free(self.handle)
+                self.handle = C.c_uint64(0)
+        except Exception:
+            pass

@@ -27,7 +27,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib, dropout as dr, ops, ops_train as tr
+from . import _lib, dropout as dr, ops, ops_train as tr, tape as _tape
 from .config import MadeConfig
 from .engine import MadeEngine
 from .ops import Seg, round_up
@@ -352,11 +352,11 @@ class MadeTrainer(MadeEngine):
         return out
 
     def capture_train_step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, *, max_grad_norm: float = 1.0,
-                           music_ids=None, v_duration: Optional[Tensor] = None, dist=None) -> "TrainStepGraph":
+                           music_ids=None, v_duration: Optional[Tensor] = None, dist=None, mode: str = "graph") -> "TrainStepGraph":
         """The whole iteration (forward, backward, clip + Adam, repack) as hipGraph(s) over fixed buffers -- SURVEY 8(f)2.  The
         given batch only shapes the buffers and warms the kernels up: the trainer's state is the same before and after."""
         return TrainStepGraph(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, max_grad_norm=max_grad_norm,
-                              music_ids=music_ids, v_duration=v_duration, dist=dist)
+                              music_ids=music_ids, v_duration=v_duration, dist=dist, mode=mode)
 
     def state_dict_numpy(self) -> Dict[str, np.ndarray]:
         sd = {k: v.detach().cpu().numpy().copy() for k, v in self.master.items()}
@@ -485,7 +485,6 @@ class MadeTrainer(MadeEngine):
         ws["dstack"] = stacks
         ws["s_stack"] = E(nd, BQ, H, dtype=f32)               # sums of the dropped cross-attention weights, one row per (layer, query)
         ws["ca_lse"] = E(nd, B * HQ, dtype=f32)               # log-sum-exp of the memory-space attention's scaled scores (fused backward)
-        ws["wide_tickets"] = Z(B * ((HQ + 31) // 32), dtype=i32)   # made_attention_wide merges its key slices in the same launch
         for l in range(nd):
             ws.update({f"d.{l}.{k}": v[l] for k, v in stacks.items() if not k.startswith("g_")})
             ws.update({f"d.{l}.lse": E(B * H * Q, dtype=f32), f"d.{l}.s": ws["s_stack"][l], f"d.{l}.t3": stacks["tgt"][l + 1]})
@@ -578,15 +577,18 @@ class MadeTrainer(MadeEngine):
                 if c.moment_query_type == "xpool":
                     cur.wait_stream(side)                    # the X-Pool branch (second stream) produces the query
                 src_vec = video if c.moment_query_type == "video" else (music if c.moment_query_type == "music" else tw["xpool_q"])
-                tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
+                if Q == 1:
+                    tr.add3(tgt, src_vec)                     # (f32 clip vector -> compute dtype; no framework kernel inside the step)
+                else:
+                    tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
             else:                                            # "zero" / "random": reference music_detr/transformer.py:73-74
-                tgt.zero_()
+                _tape.zero_(tgt)
             if Q > 1:                                        # (a single query's q / k projections are never formed: see the loop)
                 tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
 
         # bf16, one moment query: the chain's LayerNorms run in the prologue of the Linear that consumes them (made_dec_stage, as on
-        # the eval path; dropout and the saved GEMM input in its epilogue / prologue), the key slices of the memory-space attention
-        # are merged inside its launch and the value bias is the per-head Linear's epilogue: 9 launches per layer instead of 14
+        # the eval path; dropout and the saved GEMM input in its epilogue / prologue), the value bias of the
+        # memory-space attention is the per-head Linear's epilogue: 10 launches per layer instead of 14
         stage = self._dec_stage_chain()
 
         def dec_query_side(l: int) -> None:
@@ -733,7 +735,7 @@ class MadeTrainer(MadeEngine):
             ops.attention_wide(qprime.view(B, H, Q, D), mempos3, mem3, pooled.view(B, Q, H, D).permute(0, 2, 1, 3), scale=ca_scale,
                                key_mask=fus_mask, drop=self._drop(f"dec.{l}" + ".ca_attn", pd), sum_out=s_out,
                                n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"],
-                               tickets=tw["wide_tickets"] if stage else None, lse_out=tw["ca_lse"][l] if stage else None)
+                               lse_out=tw["ca_lse"][l] if stage else None)
             if Q > 1:
                 tw[d + ".s"].view(B, Q, H).copy_(s_out.view(B, H, Q).permute(0, 2, 1))
             attc = tw[d + ".attc"]
@@ -911,8 +913,18 @@ class MadeTrainer(MadeEngine):
         s1 = ops.layernorm(seg, P[key + ".ln1.g"], P[key + ".ln1.b"], out=tw[pre + "s1"], row_skip=skip)
         ops.linear(s1, P[key + ".kv.w"], P[key + ".kv.b"], rows=self._rw(skip), tile_skip_mask=skip if self._rw(skip) is None else None,
                    segs=[Seg(out=tw[pre + "k"], col_begin=0), Seg(out=tw[pre + "u"], col_begin=D)])
+        # 64 videos x 64 tracks: one workgroup per track would leave three quarters of the chip idle on a kernel that streams 1 MB of
+        # K / U per track at one CU's rate -- the keys are split over workgroups (up to 256 of them), a second launch merges the slices
+        # (tools/xpool_qk_bench.py, profiles/r03_xpool_qk_microbench.txt: 56.8 us unsplit, 34.9 us split four ways)
+        xsplit = int(os.environ.get("MADE_XPOOL_NSPLIT", 0)) or (max(1, min(4, 256 // max(B, 1), S // 64)) if (B <= 64 and self.tc == torch.bfloat16) else 1)
+        if xsplit > 1:
+            need = B * xsplit * B
+            if tw.get("xpart_o") is None or tw["xpart_o"].numel() < need * D:
+                tw["xpart_o"] = torch.empty(need * D, device=self.device, dtype=torch.float32)
+                tw["xpart_ml"] = torch.empty(need * 4, device=self.device, dtype=torch.float32)
         ops.attention_wide(q.view(1, B, 1, D), tw[pre + "k"].view(B, S, D), tw[pre + "u"].view(B, S, D), tw[pre + "o"].view(B, B, 1, D),
-                           scale=1.0 / math.sqrt(D), key_mask=seg_mask, shared_q=True)
+                           scale=1.0 / math.sqrt(D), key_mask=seg_mask, shared_q=True, n_split=xsplit,
+                           part_o=tw.get("xpart_o") if xsplit > 1 else None, part_ml=tw.get("xpart_ml") if xsplit > 1 else None)
         a2 = ops.linear(tw[pre + "o"], P[key + ".out.w"], P[key + ".out.b"], out=tw[pre + "a2"])
         a3 = ops.layernorm(a2, P[key + ".ln2.g"], P[key + ".ln2.b"], out=tw[pre + "a3"])
         # (the oracle / reference masks name the site after the block class, not the tower)
@@ -1037,9 +1049,9 @@ class MadeTrainer(MadeEngine):
             fskip = qskip = None
         rows = B * L
         if zero_grad:
-            self.flat_grad.zero_()
+            _tape.zero_(self.flat_grad)
         dvideo, dmusic = tw["dvideo"], tw["dmusic"]
-        dvideo.zero_(); dmusic.zero_()
+        _tape.zero_(dvideo); _tape.zero_(dmusic)
         video, music = ws["video"], ws["music"]
         frame, seg_view = self._views
         # the X-Pool / similarity branch is independent of the DETR stack until the temporal encoders: its (latency-bound)
@@ -1060,7 +1072,7 @@ class MadeTrainer(MadeEngine):
             pq = ws["pq"] if c.contrastive_align_loss else None
             vid_sum = ws["vid_sum"] if c.contrastive_align_loss else None
             if c.contrastive_align_loss:
-                tw["dvid_sum"].zero_()
+                _tape.zero_(tw["dvid_sum"])
             tr.set_criterion_bwd(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"], c.foreground_label, P["crit_weights"], g_loc,
                                  tw["dlog"], tw["dsp"], tw["dpq"] if pq is not None else None, tw["dvid_sum"] if pq is not None else None,
                                  ld_out=HEAD_PAD, through_sigmoid=True)
@@ -1151,7 +1163,7 @@ class MadeTrainer(MadeEngine):
                     tr.attention_wide_bwd(qprime, dpooled, tw[d + ".pooled"].view(B, HQ, D), mempos3, mem3, tw["ca_lse"][l].view(B, HQ),
                                           PdS[:, 0, l], PdS[:, 1, l], g_q, scale=ca_scale, key_mask=fus_mask, ssum=tw[d + ".s"].view(B, HQ),
                                           dattc=dattc, vbias=P[p + ".ca.in.b"][2 * D:], hd=hd, drop=self._drop(f"dec.{l}" + ".ca_attn", pd),
-                                          n_split=n_split_b, part_dq=ws["part_o"], tickets=tw["wide_tickets"])
+                                          n_split=n_split_b, part_dq=ws["part_o"])
                 else:
                     tr.head_bias_bwd(dattc, tw[d + ".s"], P[p + ".ca.in.b"][2 * D:], G[p + ".ca.in.b"][2 * D:], tw["d_ds"], H)
                     d_ds = tw["d_ds"]                                 # rows (b, q), columns h; the softmax backward numbers its rows (b, h, q)
@@ -1423,22 +1435,22 @@ class MadeTrainer(MadeEngine):
         else:                                                # dual_single_sim_fuse: one loss on the summed similarities
             both = tr.add3(tw["sims_both"], ws["sims_dual"], ws["sims_single"])
             tr.clip_loss_bwd(both, ls, wgt, g_ret, cws, ds_d, ds_dt, gls)
-            ds_s.copy_(ds_d)
+            _tape.copy_(ds_s, ds_d)
             if ds_st is not None:
-                ds_st.copy_(ds_dt)
+                _tape.copy_(ds_st, ds_dt)
             single = dual = True
         frame, seg = self._views
         if (single or dpool is not None or fuse_dz is not None) and "music" in c.vmr_fusion:
             if not single:
-                ds_s.zero_()                                 # the tower feeds only the decoder's query / the fused similarity
+                _tape.zero_(ds_s)                            # the tower feeds only the decoder's query / the fused similarity
             self._xpool_bwd(tw, "xa", "x", ds_s, video, dvideo, seg, sm if c.fusion_mask == 1 else None, B, S, dpool=dpool, dz=fuse_dz)
         else:
-            tw["xdseg"].zero_()
+            _tape.zero_(tw["xdseg"])
         if "video" in c.vmr_fusion:
             if single and c.vmr_loss == "single":            # queries = the music vectors, pooled sequences = the frames
                 self._xpool_bwd(tw, "xav", "y", ds_st, music, dmusic, frame, self._inputs[2] if c.fusion_mask == 1 else None, B, frame.shape[1])
             else:
-                tw["ydseg"].zero_()
+                _tape.zero_(tw["ydseg"])
         if dual:
             tr.gemm_tn(ds_dt, tw["mn"], tw["dvn"])            # d vhat = dsims mhat
             tr.gemm_tn(ds_d, tw["vn"], tw["dmn"])             # d mhat = dsims^T vhat
@@ -1474,7 +1486,7 @@ class MadeTrainer(MadeEngine):
         # dU[m] = P[m]^T dO[m];  dK[m] = dS[m]^T q;  dq = sum_m dS[m] K[m]
         tr.gemm_tn(tw[pre + "P"][:B, :S], do[:B], dkv[:S, D:], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(B * D, 0), c_zs=(S * 2 * D, 0))
         tr.gemm_tn(tw[pre + "dS"][:B, :S], q, dkv[:S, :D], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(0, 0), c_zs=(S * 2 * D, 0))
-        tw[pre + "dq32"].zero_()
+        _tape.zero_(tw[pre + "dq32"])
         tr.gemm_tn(tw[pre + "dSt"][0], xk[:S], tw[pre + "dq32"], batch=(B, 1), a_zs=(S * B, 0), b_zs=(S * D, 0), c_zs=(0, 0), accumulate=True,
                    row_mask=seg_mask, mask_zs=(S, 0))
         ds1 = self._lin_bwd(dkv, tw[pre + "s1"], key + ".kv", dx_out=tw[pre + "ds1"], row_mask=skip, skip=skip)
@@ -1639,7 +1651,12 @@ class TrainStepGraph:
     the large bucket under the encoders' backward exactly as the eager path has it."""
 
     def __init__(self, trainer: MadeTrainer, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, *,
-                 max_grad_norm: float = 1.0, music_ids=None, v_duration: Optional[Tensor] = None, dist=None):
+                 max_grad_norm: float = 1.0, music_ids=None, v_duration: Optional[Tensor] = None, dist=None, mode: str = "graph"):
+        """mode = "graph": hipGraph capture (torch.cuda.CUDAGraph); mode = "tape": the library's own launch tape (mgsv_amd/tape.py,
+        made_tape_*): the step is EXECUTED once while every launch is recorded, then replayed from one C loop onto the same two
+        streams -- no framework kernel may run inside the step (none does), single process only."""
+        assert mode in ("graph", "tape")
+        self.mode = mode
         t = self.trainer = trainer
         dev = t.device
         self.dist = dist if (dist is not None and dist.get_world_size() > 1) else None
@@ -1693,7 +1710,23 @@ class TrainStepGraph:
             self.adam_state[0] = keep_step
             torch.cuda.synchronize()
             self.graphs = []
-            if self.dist is None:
+            if mode == "tape":
+                if self.dist is not None:
+                    raise NotImplementedError("TrainStepGraph(mode='tape') is single-process (data-parallel jobs capture three hipGraphs)")
+                keep2 = [x.clone() for x in (t.flat_param, t.exp_avg, t.exp_avg_sq)]
+                with _tape.LaunchTape.record() as tp:          # (runs the step for real: the state is put back below)
+                    self.out = fwd_bwd(); opt()
+                torch.cuda.synchronize()
+                self.tape = tp
+                for dst, src in zip((t.flat_param, t.exp_avg, t.exp_avg_sq), keep2):
+                    dst.copy_(src)
+                for k, v in keep_buf.items():
+                    t.buffers[k].copy_(v)
+                t.opt_step, t.generation = keep_step, keep_gen
+                t.repack()
+                self.adam_state[0] = keep_step
+                torch.cuda.synchronize()
+            elif self.dist is None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self.out = fwd_bwd(); opt()
@@ -1755,7 +1788,10 @@ class TrainStepGraph:
         if t.opt_step != self._dev_step:                      # eager optimizer steps in between: realign the device-side count
             self.adam_state[0:1].fill_(t.opt_step)
         t.seed = int(seed)
-        self.graphs[0].replay()
+        if self.mode == "tape":
+            self.tape.replay()
+        else:
+            self.graphs[0].replay()
         if self.dist is not None:
             cut = t.group_ranges[0][1]
             w1 = self.dist.all_reduce(t.flat_grad[cut:], async_op=True)      # travels under the encoders' backward

@@ -183,7 +183,8 @@ def test_mlp_aggregator_running_statistics_reach_eval_and_checkpoints():
     """agg_module = "mlp" through the drop-in module: the BatchNorm running statistics a train step moves live in the module's own
     registered buffers (shared storage with the trainer), so eval() (state_dict -> MadeEngine) and a saved state_dict see them."""
     cfg = cfg_native()
-    cfg.agg_module = "mlp"
+    cfg.agg_module, cfg.video_transformer_depth, cfg.audio_transformer_depth = "mlp", 0, 0          # (the reference asserts depth 0 with the EmbeddingNet)
+    cfg.max_v_frames, cfg.max_snippet_num = 20, 40                                                   # BatchNorm over the token positions: T is fixed
     args = cfg.to_args(local_rank=0)
     model = Uni_model(args, device=torch.device("cuda:0"))
     inp = synth.make_inputs(cfg, 4, 20, 40, seed=3)

@@ -204,7 +204,7 @@ def test_attention_forward_dropout_lse_and_backward(T, dtype, tol, B, H, hd, Lq,
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("rows,D", [(1000, 512), (333, 256), (64, 1024)])
+@pytest.mark.parametrize("rows,D", [(1000, 512), (333, 256), (64, 1024), (20011, 512)])
 def test_layernorm_bwd(T, dtype, tol, rows, D):
     ops, tr = T
     x, dy, add = _rand(rows, D, dtype=dtype, seed=1), _rand(rows, D, dtype=dtype, seed=2), _rand(rows, D, dtype=dtype, seed=3)
@@ -650,18 +650,19 @@ def test_wide_attention_backward_in_one_launch(T, B, L, D, p, ns):
     dQ = torch.full((B, NQ, D), float("nan"), device="cuda", dtype=torch.bfloat16)
     part = torch.empty(B * max(ns, 1) * NQ * D, device="cuda")
     outs = []
-    for rep in range(2):
+    for rep in range(3):                                          # (the slices summed inside the launch, then twice by the second launch)
         Pd.fill_(float("nan")); dQ.fill_(float("nan"))
         tr.attention_wide_bwd(q, dO, O.view(B, NQ, D), k, v, lse.view(B, NQ), Pd[:, 0], Pd[:, 1], dQ, scale=scale, key_mask=mask,
-                              ssum=ssum.view(B, NQ), dattc=dattc, vbias=bv, hd=hd, drop=drop, n_split=ns, part_dq=part, tickets=tk)
+                              ssum=ssum.view(B, NQ), dattc=dattc, vbias=bv, hd=hd, drop=drop, n_split=ns, part_dq=part, tickets=tk if rep == 0 else None)
         torch.cuda.synchronize()
         outs.append((Pd.clone(), dQ.clone()))
         assert int(tk.abs().sum()) == 0
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(outs[0][0], o_[0]) and torch.equal(outs[0][1], o_[1]) for o_ in outs[1:])
     got_pd, got_ds = Pd[:, 0, :, :L].float(), Pd[:, 1, :, :L].float()
     assert bool(torch.isfinite(Pd).all()) and float(Pd[:, :, :, L:].abs().max() if Lp > L else 0.0) == 0.0
     assert float((got_pd - Pd_ref.detach()).abs().max()) <= 1e-2
-    assert float((got_ds - gS * 1.0).abs().max()) <= 2e-2 * max(float(gS.abs().max()), 1e-3) + 2e-3
+    gS = gS * scale                                               # (the kernel's dS is the gradient of the RAW dot product)
+    assert float((got_ds - gS).abs().max()) <= 2e-2 * max(float(gS.abs().max()), 1e-3) + 5e-4
     assert float((dQ.float() - gq).abs().max()) <= 3e-2 * float(gq.abs().max()) + 1e-3
     masked = (mask == 0)[:, None, :].expand(B, NQ, L)
     assert float(got_pd[masked].abs().max() if masked.any() else 0.0) == 0.0 and float(got_ds[masked].abs().max() if masked.any() else 0.0) == 0.0

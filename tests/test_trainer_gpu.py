@@ -233,8 +233,9 @@ def _batch(cfg, B, Tv, Ta, seed):
     return (t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"])
 
 
+@pytest.mark.parametrize("mode", ["graph", "tape"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_captured_train_step_follows_the_eager_steps(dtype):
+def test_captured_train_step_follows_the_eager_steps(dtype, mode):
     """the iteration as one hipGraph.  The replay reads the dropout seed, the Adam step count and the learning rates
     from device memory: three graph steps on three batches with three seeds and a moving schedule must land where three eager
     train_step calls land (same kernels, same order: the only freedom is the order of the f32 atomic gradient sums)."""
@@ -242,7 +243,7 @@ def test_captured_train_step_follows_the_eager_steps(dtype):
     cfg, sd, _ = _setup(4, 20, 40)
     eager, graph = MadeTrainer(cfg, sd, dtype=dtype), MadeTrainer(cfg, sd, dtype=dtype)
     batches = [_batch(cfg, 4, 20, 40, seed=10 + i) for i in range(3)]
-    g = graph.capture_train_step(*batches[2])
+    g = graph.capture_train_step(*batches[2], mode=mode)
     assert graph.opt_step == 0
     for k, v in eager.master.items():                        # capturing (and its warm-up step) left the state alone
         assert torch.equal(v, graph.master[k]), k
@@ -346,18 +347,27 @@ def test_headline_training_step_properties_at_full_size():
     f3, g3, _ = run(8)
     assert not torch.equal(f1["hs"], f3["hs"]) and float((g1 - g3).norm()) > 1e-3 * float(g1.norm())
     # one optimizer step, eager against the captured iteration, from the same state
-    eager, graph = MadeTrainer(cfg, sd, dtype="bf16"), MadeTrainer(cfg, sd, dtype="bf16")
-    g = graph.capture_train_step(*b)
+    eager = MadeTrainer(cfg, sd, dtype="bf16")
     oe = eager.train_step(*b, seed=7, lrs=(1e-4, 1e-4, 1e-4))
     le = {k: oe[k].clone() for k in keys}
-    og = g.step(*b, seed=7, lrs=(1e-4, 1e-4, 1e-4))
-    torch.cuda.synchronize()
-    for k in keys:
-        assert torch.equal(le[k], og[k]), f"{k}: captured forward differs from the eager one"
-        assert torch.equal(le[k], f1[k]), k
-    moved = float((eager.flat_param - graph.flat_param).double().norm())
     step = float((eager.flat_param - trn.flat_param).double().norm())           # trn never stepped: |one Adam step|
-    assert step > 0 and moved <= 0.05 * step, (moved, step)
+    for mode in ("graph", "tape"):                                               # hipGraph capture / the library's launch tape
+        graph = MadeTrainer(cfg, sd, dtype="bf16")
+        g = graph.capture_train_step(*b, mode=mode)
+        og = g.step(*b, seed=7, lrs=(1e-4, 1e-4, 1e-4))
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(le[k], og[k]), f"{k}: captured ({mode}) forward differs from the eager one"
+            assert torch.equal(le[k], f1[k]), k
+        moved = float((eager.flat_param - graph.flat_param).double().norm())
+        assert step > 0 and moved <= 0.05 * step, (mode, moved, step)
+        if mode == "tape":
+            nk, nw, no = g.tape.counts()
+            assert nk > 300 and nw >= 10, (nk, nw, no)
+            og2 = g.step(*b, seed=8, lrs=(1e-4, 1e-4, 1e-4))                     # a second replay: new masks, a moved state
+            torch.cuda.synchronize()
+            assert not torch.equal(og2["hs"], le["hs"]) and bool(torch.isfinite(og2["localization_loss"]).all())
+        del g, graph
 
 
 @pytest.mark.parametrize("dropout", [False, True])
