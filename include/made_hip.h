@@ -213,6 +213,32 @@ typedef struct MadeDecStageArgs {
 } MadeDecStageArgs;
 int made_dec_stage(const MadeDecStageArgs* args, void* stream);
 
+/* made_dec_stage_bwd: a stage of the decoder's BACKWARD chain with a LayerNorm backward in the prologue of the dX product that
+ * consumes it (reference music_detr/transformer.py:273-307 read backwards; bf16 rows, K = the norm's width = 256 or 512):
+ *     g   = dy,  or with a second norm stacked on the first (xb != NULL: norm 3 + the shared output norm, :306 and :136)
+ *     g   = LN_b'(dy; xb, gamma_b) + add
+ *     dx  = LN_a'(g; xa, gamma_a)       -> dx_out [M, K] (may be NULL);  dgamma / dbeta of the norm(s) accumulated (may be NULL)
+ *     A   = dropout_a(dx)               -> a_out [M, K] (may be NULL): element index row * drop_a_ld + col
+ *     out = dropout_o((A W^T) * [G != 0] * gate_scale) + R        W [N, K] bf16; G, R, out [M, N] bf16; drop_o index row * drop_o_ld + col / drop_o_col_div
+ * One launch of ceil(N / 32) x ceil(M / 64) workgroups replaces made_layernorm_bwd (or made_layernorm_bwd2) + made_linear. */
+typedef struct MadeDecStageBwdArgs {
+    const void* xa; const float* gamma_a; int64_t ldxa;
+    const void* xb; const float* gamma_b; int64_t ldxb;      /* second (outer) norm or NULL */
+    const void* dy; int64_t lddy;
+    const void* add; int64_t ldadd;                          /* two-norm form only; may be NULL */
+    void* dx_out; int64_t lddx;
+    void* a_out; int64_t lda_out;
+    float *dgamma_a, *dbeta_a, *dgamma_b, *dbeta_b;
+    MadeDropout drop_a; int64_t drop_a_ld;
+    const void* W; int64_t ldw;
+    const void* G; int64_t ldg; float gate_scale; float eps;
+    MadeDropout drop_o; int64_t drop_o_ld; int32_t drop_o_col_div; int32_t _pad;
+    const void* R; int64_t ldr;
+    void* out; int64_t ldo;
+    int64_t M, N, K;
+} MadeDecStageBwdArgs;
+int made_dec_stage_bwd(const MadeDecStageBwdArgs* args, void* stream);
+
 /* y = act(sum_s ws[s] + bias) + R[row % r_row_mod]  -> out (any dtype, may be NULL);
  * then optionally z1 = LayerNorm(y; ln1) -> ln1_out, and z2 = LayerNorm(z1; ln2) -> ln2_out (the decoder's
  * per-layer norm followed by the shared output norm, reference music_detr/transformer.py:306,136).

@@ -69,6 +69,15 @@ class MadeDecStageArgs(C.Structure):
                 ("zin_dtype", i32), ("drop_col_div", i32), ("a_out", vp), ("lda_out", i64), ("drop", MadeDropout), ("drop_ld", i64)]
 
 
+class MadeDecStageBwdArgs(C.Structure):
+    _fields_ = [("xa", vp), ("gamma_a", vp), ("ldxa", i64), ("xb", vp), ("gamma_b", vp), ("ldxb", i64), ("dy", vp), ("lddy", i64),
+                ("add", vp), ("ldadd", i64), ("dx_out", vp), ("lddx", i64), ("a_out", vp), ("lda_out", i64),
+                ("dgamma_a", vp), ("dbeta_a", vp), ("dgamma_b", vp), ("dbeta_b", vp), ("drop_a", MadeDropout), ("drop_a_ld", i64),
+                ("W", vp), ("ldw", i64), ("G", vp), ("ldg", i64), ("gate_scale", f32), ("eps", f32),
+                ("drop_o", MadeDropout), ("drop_o_ld", i64), ("drop_o_col_div", i32), ("_pad", i32),
+                ("R", vp), ("ldr", i64), ("out", vp), ("ldo", i64), ("M", i64), ("N", i64), ("K", i64)]
+
+
 class MadeAttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp),
                 ("dtype", i32), ("hd", i32),
@@ -166,6 +175,7 @@ SIGNATURES = {
     "made_linear": (C.c_int, [C.POINTER(MadeLinearArgs), vp]),
     "made_splitk_finish": (C.c_int, [C.POINTER(MadeFinishArgs), vp]),
     "made_dec_stage": (C.c_int, [C.POINTER(MadeDecStageArgs), vp]),
+    "made_dec_stage_bwd": (C.c_int, [C.POINTER(MadeDecStageBwdArgs), vp]),
     "made_attention": (C.c_int, [C.POINTER(MadeAttnArgs), vp]),
     "made_attention_wide": (C.c_int, [C.POINTER(MadeWideAttnArgs), vp]),
     "made_attention_wide_bwd": (C.c_int, [C.POINTER(MadeWideAttnBwdArgs), vp]),

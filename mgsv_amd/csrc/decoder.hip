@@ -14,6 +14,7 @@
 // layer.  The four waves split K four ways (as linear_tiny_kernel does): weight fragments come straight from global memory
 // (16 contiguous bytes of one row per lane), A fragments from the normalised LDS tile, partial tiles meet in LDS.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -305,7 +306,300 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
     }
 }
 
+// =================================================================================================
+// made_dec_stage_bwd: the mirror image for the backward chain -- a LayerNorm BACKWARD in the prologue of the Linear (dX product)
+// that consumes its result (reference music_detr/transformer.py:273-307 read backwards: x = LN(t), t = res + dropout(branch)):
+//     g   = dy                                           or, with a second norm stacked on the first (norm 3 + the shared output norm):
+//     g   = LN_b'(dy; xb, gamma_b) + add
+//     dx  = LN_a'(g; xa, gamma_a)                        -> dx_out (the residual path's gradient), parameter gradients accumulated
+//     A   = dropout_a(dx)                                -> a_out (the branch's output gradient: a weight-gradient operand) and LDS
+//     out = dropout_o((A W^T) * gate'(G) * gate_scale) + R
+// Every workgroup (64 rows x 32 output columns) redoes the row work for its 64 rows -- 2 x 64 KB from L2 under the flight of its own
+// weight fragments, as made_dec_stage does for the forward norm -- so a 64-row link of the chain is ONE launch instead of two.
+template <int NV>
+__device__ __forceinline__ void dsb_ln_bwd_row(float (&xv)[NV], float (&gy)[NV], const float (&gm)[NV], float eps, float (&dg)[NV], float (&db)[NV], float (&o)[NV]) {
+    constexpr int K = 64 * NV;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += xv[j];
+    const float mean = wave_sum(s) * (1.f / K);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { xv[j] -= mean; q += xv[j] * xv[j]; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.f / K) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float xh = xv[j] * rstd;
+        const float g = gy[j] * gm[j];
+        dg[j] += gy[j] * xh; db[j] += gy[j];
+        xv[j] = xh; gy[j] = g;
+        s1 += g; s2 += g * xh;
+    }
+    s1 = wave_sum(s1) * (1.f / K);
+    s2 = wave_sum(s2) * (1.f / K);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) o[j] = rstd * (gy[j] - s1 - xv[j] * s2);
+}
+
+template <int NV>
+__device__ __forceinline__ void dsb_load_row(const void* p, int64_t off, float (&v)[NV]) {
+    if constexpr (NV == 8) {
+        const bf16x8 t = *(const bf16x8*)((const bf16_t*)p + off);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (float)t[u];
+    } else {
+        const bf16x4 t = *(const bf16x4*)((const bf16_t*)p + off);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (float)t[u];
+    }
+}
+template <int NV>
+__device__ __forceinline__ void dsb_store_row(void* p, int64_t off, const float (&v)[NV]) {
+    if constexpr (NV == 8) { bf16x8 t; for (int u = 0; u < 8; ++u) t[u] = (bf16_t)v[u]; *(bf16x8*)((bf16_t*)p + off) = t; }
+    else { bf16x4 t; for (int u = 0; u < 4; ++u) t[u] = (bf16_t)v[u]; *(bf16x4*)((bf16_t*)p + off) = t; }
+}
+
+template <int NV, bool TWO>
+__global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDecStageBwdArgs a) {
+    constexpr int K = 64 * NV;
+    constexpr int LDA = K * 2 + 16;
+    constexpr int STEPS = NV;
+    constexpr int TILE_BYTES = (DS_BM * LDA > 4 * DS_BM * DS_CT_LD * 4) ? DS_BM * LDA : 4 * DS_BM * DS_CT_LD * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
+    float* pgrad = (float*)(dlds + TILE_BYTES);                  // [8 waves][4 vectors][K]: parameter-gradient partials (workgroup x = 0 only)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int M = (int)a.M, N = (int)a.N;
+    const int n0 = blockIdx.x * DS_BN, m0 = blockIdx.y * DS_BM;
+    constexpr bool two = TWO;
+
+    // ---- 1. weight fragments (a quarter of K per GEMM wave), in flight before anything else
+    const int gw = wave & 3;
+    const int kw = gw * (K / 4) + hh * 8;
+    int gn = n0 + r; gn = gn < N ? gn : N - 1;
+    const bf16_t* pw = (const bf16_t*)a.W + (int64_t)gn * a.ldw + kw;
+    bf16x8 fw[STEPS];
+    if (wave < 4) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) fw[s] = *(const bf16x8*)(pw + s * 16);
+    }
+    // the epilogue's inputs (thread t < 256 finishes row t / 4, 8 columns)
+    const int cc = tid & 3, row = (tid >> 2) & 63;
+    const int n = n0 + cc * 8;
+    int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+    const int ml = m0 + row;
+    const int mlc = ml < M ? ml : M - 1;
+    const bool e_vec = nvalid == 8;
+    bf16x8 rpre, gpre;
+    const bool r_vec = a.R && e_vec && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+    const bool g_vec = a.G && e_vec && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0);
+    if (r_vec) rpre = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)mlc * a.ldr + n);
+    if (g_vec) gpre = *(const bf16x8*)((const bf16_t*)a.G + (int64_t)mlc * a.ldg + n);
+
+    // ---- 2. LayerNorm backward of this wave's 8 rows (lane l: columns NV*l .. NV*l + NV - 1)
+    const int c0 = NV * lane;
+    float gma[NV], gmb[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j += 4) {
+        const f32x4 g = *(const f32x4*)(a.gamma_a + c0 + j);
+        gma[j] = g[0]; gma[j + 1] = g[1]; gma[j + 2] = g[2]; gma[j + 3] = g[3];
+        if (two) { const f32x4 h = *(const f32x4*)(a.gamma_b + c0 + j); gmb[j] = h[0]; gmb[j + 1] = h[1]; gmb[j + 2] = h[2]; gmb[j + 3] = h[3]; }
+        else { gmb[j] = gmb[j + 1] = gmb[j + 2] = gmb[j + 3] = 1.f; }
+    }
+    float dga[NV], dba[NV], dgb[NV], dbb[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { dga[j] = 0.f; dba[j] = 0.f; dgb[j] = 0.f; dbb[j] = 0.f; }
+    const uint32_t thr = made_drop_threshold(a.drop_a.p);
+    const uint64_t seed_a = a.drop_a.p > 0.f ? made_drop_seed(a.drop_a) : 0;
+    const float sc_a = a.drop_a.p > 0.f ? 1.f / (1.f - a.drop_a.p) : 1.f;
+    constexpr int RPW = DS_RPW;
+    // every row of this wave is requested before the first reduction (raw bf16 vectors: 4 registers per row and tensor)
+    typedef typename std::conditional<NV == 8, bf16x8, bf16x4>::type raw_t;
+    raw_t rxa[RPW], rdy[RPW], rxb[TWO ? RPW : 1], rad[TWO ? RPW : 1];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        int gm = m0 + wave * RPW + i; gm = gm < M ? gm : M - 1;
+        rxa[i] = *(const raw_t*)((const bf16_t*)a.xa + (int64_t)gm * a.ldxa + c0);
+        rdy[i] = *(const raw_t*)((const bf16_t*)a.dy + (int64_t)gm * a.lddy + c0);
+    }
+    if constexpr (TWO) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            int gm = m0 + wave * RPW + i; gm = gm < M ? gm : M - 1;
+            rxb[i] = *(const raw_t*)((const bf16_t*)a.xb + (int64_t)gm * a.ldxb + c0);
+            rad[i] = *(const raw_t*)((const bf16_t*)(a.add ? a.add : a.xb) + (int64_t)gm * (a.add ? a.ldadd : a.ldxb) + c0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int rl = wave * RPW + i;
+        int gm = m0 + rl; gm = gm < M ? gm : M - 1;
+        const bool real = m0 + rl < M;
+        float xa[NV], gy[NV], o[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { xa[j] = (float)rxa[i][j]; gy[j] = (float)rdy[i][j]; }
+        if constexpr (TWO) {
+            float xb[NV], ad[NV], g[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { xb[j] = (float)rxb[i][j]; ad[j] = a.add ? (float)rad[i][j] : 0.f; }
+            float tg[NV], tb[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { tg[j] = 0.f; tb[j] = 0.f; }
+            dsb_ln_bwd_row<NV>(xb, gy, gmb, a.eps, tg, tb, g);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { if (real) { dgb[j] += tg[j]; dbb[j] += tb[j]; } gy[j] = g[j] + ad[j]; }
+        }
+        float tg[NV], tb[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { tg[j] = 0.f; tb[j] = 0.f; }
+        dsb_ln_bwd_row<NV>(xa, gy, gma, a.eps, tg, tb, o);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { if (real) { dga[j] += tg[j]; dba[j] += tb[j]; } }
+        // the branch's gradient: dropout of this site's forward mask (element index row * drop_a_ld + col)
+        float od[NV];
+        const uint64_t dbase = (uint64_t)gm * (uint64_t)a.drop_a_ld + (uint64_t)c0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            od[j] = a.drop_a.p > 0.f ? (((made_rng_mix(seed_a, a.drop_a.site, dbase + j) >> 8) >= thr) ? o[j] * sc_a : 0.f) : o[j];
+        dsb_store_row<NV>(dlds, (int64_t)rl * (LDA / 2) + c0, od);               // (LDA bytes = LDA / 2 bf16 elements per row)
+        const bool writer = real && ((m0 + rl) % (int)gridDim.x == (int)blockIdx.x);
+        if (writer) {
+            if (a.dx_out) dsb_store_row<NV>(a.dx_out, (int64_t)gm * a.lddx + c0, o);
+            if (a.a_out) dsb_store_row<NV>(a.a_out, (int64_t)gm * a.lda_out + c0, od);
+        }
+    }
+    // parameter gradients: the eight waves' column partials of workgroup x = 0 meet in LDS, one atomic per column
+    if (blockIdx.x == 0) {
+        float* mine = pgrad + wave * 4 * K;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { mine[c0 + j] = dga[j]; mine[K + c0 + j] = dba[j]; mine[2 * K + c0 + j] = dgb[j]; mine[3 * K + c0 + j] = dbb[j]; }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        const int nvec = two ? 4 : 2;
+        for (int c = tid; c < nvec * K; c += DS_THREADS) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += pgrad[w * 4 * K + c];
+            float* dst = c < K ? a.dgamma_a : (c < 2 * K ? a.dbeta_a : (c < 3 * K ? a.dgamma_b : a.dbeta_b));
+            if (dst) unsafeAtomicAdd(dst + (c % K), t);
+        }
+    }
+    const bool gemm_wave = wave < 4;
+
+    // ---- 3. 64 x 32 partial tile of this wave's K quarter
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    if (gemm_wave) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const bf16x8 fa0 = *(const bf16x8*)(dlds + r * LDA + (kw + s * 16) * 2);
+            const bf16x8 fa1 = *(const bf16x8*)(dlds + (r + 32) * LDA + (kw + s * 16) * 2);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fw[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fw[s], acc[1], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                            // everyone is done with the A tile: the partials take its place
+    float* Ct = (float*)dlds;
+    if (gemm_wave) {
+        float* mine = Ct + wave * (DS_BM * DS_CT_LD);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mine[(t * 32 + acc_row(e, hh)) * DS_CT_LD + r] = acc[t][e];
+    }
+    __syncthreads();
+    if (!gemm_wave || nvalid <= 0 || ml >= M) return;
+
+    // ---- 4. the four partial tiles meet; gate, dropout, residual, store
+    float v8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v8[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float* cp = Ct + w * (DS_BM * DS_CT_LD) + row * DS_CT_LD + cc * 8;
+        const f32x4 q0 = *(const f32x4*)cp, q1 = *(const f32x4*)(cp + 4);
+        v8[0] += q0[0]; v8[1] += q0[1]; v8[2] += q0[2]; v8[3] += q0[3];
+        v8[4] += q1[0]; v8[5] += q1[1]; v8[6] += q1[2]; v8[7] += q1[3];
+    }
+    if (a.G) {                                                  // ReLU gate from the saved (dropped) activation: act'(G) * gate_scale
+        float g8[8];
+        if (g_vec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g8[j] = (float)gpre[j];
+        } else {
+            for (int j = 0; j < 8; ++j) g8[j] = j < nvalid ? (float)((const bf16_t*)a.G)[(int64_t)ml * a.ldg + n + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = g8[j] != 0.f ? v8[j] * a.gate_scale : 0.f;
+    }
+    if (a.drop_o.p > 0.f) {
+        const uint32_t thr_o = made_drop_threshold(a.drop_o.p);
+        const float sc = 1.f / (1.f - a.drop_o.p);
+        const uint64_t seed_o = made_drop_seed(a.drop_o);
+        const uint64_t rb = (uint64_t)ml * (uint64_t)a.drop_o_ld;
+        const int div = a.drop_o_col_div > 1 ? a.drop_o_col_div : 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v8[j] = (made_rng_mix(seed_o, a.drop_o.site, rb + (uint64_t)((n + j) / div)) >> 8) >= thr_o ? v8[j] * sc : 0.f;
+    }
+    if (a.R) {
+        if (r_vec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v8[j] += (float)rpre[j];
+        } else {
+            for (int j = 0; j < nvalid; ++j) v8[j] += (float)((const bf16_t*)a.R)[(int64_t)ml * a.ldr + n + j];
+        }
+    }
+    bf16_t* op = (bf16_t*)a.out + (int64_t)ml * a.ldo + n;
+    if (e_vec && (a.ldo % 8 == 0) && (((uintptr_t)a.out & 15) == 0)) {
+        bf16x8 o8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = (bf16_t)v8[j];
+        *(bf16x8*)op = o8;
+    } else {
+        for (int j = 0; j < nvalid; ++j) op[j] = (bf16_t)v8[j];
+    }
+}
+
 }  // namespace
+
+extern "C" int made_dec_stage_bwd(const MadeDecStageBwdArgs* args, void* stream) {
+    MADE_REQUIRE(args != nullptr, "made_dec_stage_bwd: null args");
+    const MadeDecStageBwdArgs& a = *args;
+    MADE_REQUIRE(a.xa && a.gamma_a && a.dy && a.W && a.out, "made_dec_stage_bwd: null xa, gamma_a, dy, W or out");
+    MADE_REQUIRE((a.xb == nullptr) == (a.gamma_b == nullptr), "made_dec_stage_bwd: xb and gamma_b come together");
+    MADE_REQUIRE(a.M > 0 && a.N > 0, "made_dec_stage_bwd: bad dims M=%lld N=%lld", (long long)a.M, (long long)a.N);
+    MADE_UNSUPPORTED(a.K == 256 || a.K == 512, "made_dec_stage_bwd: K=%lld (the row width of the LayerNorm) must be 256 or 512", (long long)a.K);
+    MADE_UNSUPPORTED(a.ldxa % 8 == 0 && a.lddy % 8 == 0 && a.ldxb % 8 == 0 && a.ldadd % 8 == 0 && a.lddx % 8 == 0 && a.lda_out % 8 == 0 && a.ldw % 8 == 0 &&
+                     ((uintptr_t)a.xa % 16) == 0 && ((uintptr_t)a.dy % 16) == 0 && ((uintptr_t)a.xb % 16) == 0 && ((uintptr_t)a.add % 16) == 0 &&
+                     ((uintptr_t)a.dx_out % 16) == 0 && ((uintptr_t)a.a_out % 16) == 0 && ((uintptr_t)a.W % 16) == 0,
+                     "made_dec_stage_bwd: rows must be 16-byte aligned");
+    MADE_REQUIRE(a.drop_a.p >= 0.f && a.drop_a.p < 1.f && a.drop_o.p >= 0.f && a.drop_o.p < 1.f, "made_dec_stage_bwd: dropout p out of [0,1)");
+    const dim3 grid((unsigned)((a.N + DS_BN - 1) / DS_BN), (unsigned)((a.M + DS_BM - 1) / DS_BM)), block(DS_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.K == 512) {
+        constexpr int LDSB = DS_BM * (512 * 2 + 16) + 8 * 4 * 512 * 4;
+        static const bool once = hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+        (void)once;
+        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<8, true>), grid, block, LDSB, st, a);
+        else hipLaunchKernelGGL((dec_stage_bwd_kernel<8, false>), grid, block, LDSB, st, a);
+    } else {
+        constexpr int LDSB = 4 * DS_BM * DS_CT_LD * 4 + 8 * 4 * 256 * 4;
+        static const bool once = hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+        (void)once;
+        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<4, true>), grid, block, LDSB, st, a);
+        else hipLaunchKernelGGL((dec_stage_bwd_kernel<4, false>), grid, block, LDSB, st, a);
+    }
+    return made_check_launch("made_dec_stage_bwd");
+}
 
 extern "C" int made_dec_stage(const MadeDecStageArgs* args, void* stream) {
     MADE_REQUIRE(args != nullptr, "made_dec_stage: null args");

@@ -180,6 +180,52 @@ def layernorm_bwd(x: Tensor, gamma: Tensor, dy: Tensor, dx: Tensor, *, dgamma: O
     return dx
 
 
+def dec_stage_bwd(xa: Tensor, gamma_a: Tensor, dy: Tensor, W: Tensor, out: Tensor, *, dgamma_a: Optional[Tensor], dbeta_a: Optional[Tensor],
+                  xb: Optional[Tensor] = None, gamma_b: Optional[Tensor] = None, dgamma_b: Optional[Tensor] = None, dbeta_b: Optional[Tensor] = None,
+                  add: Optional[Tensor] = None, dx_out: Optional[Tensor] = None, a_out: Optional[Tensor] = None, drop_a=None,
+                  G: Optional[Tensor] = None, gate_scale: float = 1.0, drop_o=None, drop_o_ld: int = 0, drop_o_col_div: int = 1,
+                  R: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+    """A LayerNorm backward (or two stacked ones: xb / gamma_b / add) in the prologue of the dX product that consumes it
+    (made_dec_stage_bwd): dx = LN'(dy; xa, gamma_a) -> dx_out, A = dropout(dx; drop_a) -> a_out, out = dropout(A W^T * [G != 0] * gate_scale;
+    drop_o) + R.  All row tensors bf16; W [N, K]; the norm's width K = 256 or 512."""
+    from . import _lib as L
+    M, K = xa.shape
+    N = W.shape[0]
+    for t in (xa, dy, xb, add, dx_out, a_out, W, G, R, out):
+        assert t is None or (t.dim() == 2 and t.dtype == torch.bfloat16 and t.stride(1) == 1)
+    assert W.shape[1] == K and tuple(out.shape) == (M, N)
+    a = L.MadeDecStageBwdArgs()
+    a.xa, a.gamma_a, a.ldxa = _p(xa), _p(_f32(gamma_a, "gamma_a")), xa.stride(0)
+    if xb is not None:
+        a.xb, a.gamma_b, a.ldxb = _p(xb), _p(_f32(gamma_b, "gamma_b")), xb.stride(0)
+    a.dy, a.lddy = _p(dy), dy.stride(0)
+    if add is not None:
+        a.add, a.ldadd = _p(add), add.stride(0)
+    if dx_out is not None:
+        a.dx_out, a.lddx = _p(dx_out), dx_out.stride(0)
+    if a_out is not None:
+        a.a_out, a.lda_out = _p(a_out), a_out.stride(0)
+    a.dgamma_a, a.dbeta_a = _p(_f32(dgamma_a, "dgamma_a")), _p(_f32(dbeta_a, "dbeta_a"))
+    a.dgamma_b, a.dbeta_b = _p(_f32(dgamma_b, "dgamma_b")), _p(_f32(dbeta_b, "dbeta_b"))
+    if drop_a is not None and drop_a[2] > 0.0:
+        set_drop(a.drop_a, drop_a)
+    a.drop_a_ld = K
+    a.W, a.ldw = _p(W), W.stride(0)
+    if G is not None:
+        a.G, a.ldg = _p(G), G.stride(0)
+    a.gate_scale, a.eps = float(gate_scale), float(eps)
+    if drop_o is not None and drop_o[2] > 0.0:
+        set_drop(a.drop_o, drop_o)
+    a.drop_o_ld, a.drop_o_col_div = (drop_o_ld or N), int(drop_o_col_div)
+    if R is not None:
+        a.R, a.ldr = _p(R), R.stride(0)
+    a.out, a.ldo = _p(out), out.stride(0)
+    a.M, a.N, a.K = M, N, K
+    _timed("dec_stage_bwd_kernel", 2.0 * M * N * K, float(M * K * 2 * 2 * ((N + 31) // 32) + N * K * 2 + M * N * 2),
+           lambda: check(lib().made_dec_stage_bwd(C.byref(a), _stream()), "made_dec_stage_bwd"), f"M={M} N={N} K={K}")
+    return out
+
+
 def layernorm_bwd2(xa: Tensor, gamma_a: Tensor, xb: Tensor, gamma_b: Tensor, dy: Tensor, dx: Tensor, *, dgamma_a: Tensor, dbeta_a: Tensor,
                    dgamma_b: Tensor, dbeta_b: Tensor, add: Optional[Tensor] = None, dx_drop: Optional[Tensor] = None, drop=None,
                    drop_ld: int = 0, eps: float = 1e-5) -> Tensor:

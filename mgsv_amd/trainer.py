@@ -1134,7 +1134,14 @@ class MadeTrainer(MadeEngine):
                 g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
                 Win, Wt = P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
                 g_ffn, g_z, g_ca, g_attc, g_q, g_qc, g_sa, gqkv = (st[k][l] for k in ("g_ffn", "g_z", "g_ca", "g_attc", "g_q", "g_qc", "g_sa", "g_qkv"))
-                if stage:
+                if stage and D == 256:
+                    # hs_l = dec.norm(t3), t3 = LN3(t2 + drop3(ffn)), t3 also feeds the next layer: both norms' backward in the prologue
+                    # of the FFN's second dX product (made_dec_stage_bwd; at D = 512 the two-norm prologue does not fit the registers)
+                    tr.dec_stage_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], dhs[l * B * Q:(l + 1) * B * Q], P[p + ".ff2.wt"], g_z,
+                                     dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], xb=tw[d + ".t3"], gamma_b=P["dec.norm.g"],
+                                     dgamma_b=G["dec.norm.g"], dbeta_b=G["dec.norm.b"], add=dtgt, dx_out=g2, a_out=g_ffn,
+                                     drop_a=self._drop(f"dec.{l}" + ".drop3", pd), G=tw[d + ".h"], gate_scale=inv_keep)
+                elif stage:
                     # hs_l = dec.norm(t3), t3 = LN3(t2 + drop3(ffn)), t3 also feeds the next layer: both norms' backward in one launch
                     tr.layernorm_bwd2(tw[d + ".t_c"], P[p + ".ln3.g"], tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g2,
                                       dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], dgamma_b=G["dec.norm.g"], dbeta_b=G["dec.norm.b"],
@@ -1145,12 +1152,17 @@ class MadeTrainer(MadeEngine):
                     # t3 = LN3(t2 + drop3(ffn))
                     tr.layernorm_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], g1, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"],
                                      dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
-                ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
+                if not (stage and D == 256):
+                    ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
                 dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1, R=g2)
                 # t2 = LN2(t1 + drop2(cross-attention))
-                tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"],
-                                 dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
-                dattc = ops.linear(g_ca, P[p + ".ca.out.wt"], None, out=g_attc)
+                if stage:                                         # norm 2's backward in the prologue of the out-projection's dX product
+                    dattc = tr.dec_stage_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, P[p + ".ca.out.wt"], g_attc, dgamma_a=G[p + ".ln2.g"],
+                                             dbeta_a=G[p + ".ln2.b"], dx_out=g2, a_out=g_ca, drop_a=self._drop(f"dec.{l}" + ".drop2", pd))
+                else:
+                    tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"],
+                                     dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
+                    dattc = ops.linear(g_ca, P[p + ".ca.out.wt"], None, out=g_attc)
                 dpooled = GQ[:, 0, l]                             # [B, H*Q, D] slice of the concatenated buffer
                 qprime = GQ[:, 1, l]
                 if stage:
@@ -1195,6 +1207,14 @@ class MadeTrainer(MadeEngine):
                 dt1q = st["dt1q"][l]                               # (summed over the batch into the query embedding's gradient after the loop)
                 ops.linear(g_qc, Wt[:, :D], None, out=g1, R=g2, Zout=dt1q)
                 # t1 = LN1(tgt + drop1(self-attention))
+                if stage:
+                    # norm 1's backward in the prologue of the self-attention out-projection's dX product (value path only: dv = datt under
+                    # the same per-head mask, drawn in the epilogue)
+                    tr.dec_stage_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, P[p + ".sa.out.wt"], gqkv[:, 2 * D:], dgamma_a=G[p + ".ln1.g"],
+                                     dbeta_a=G[p + ".ln1.b"], dx_out=g2, a_out=g_sa, drop_a=self._drop(f"dec.{l}" + ".drop1", pd),
+                                     drop_o=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_o_ld=H, drop_o_col_div=hd)
+                    dtgt = ops.linear(gqkv[:, 2 * D:], P[p + ".sa.in.wt"][:, 2 * D:], None, R=g2, out=tw["dtgt"])
+                    continue
                 tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
                                  dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
                 if Q == 1:                                        # value path only (see the forward): dv = datt under the same per-head mask,

@@ -363,7 +363,7 @@ def test_headline_training_step_properties_at_full_size():
         assert step > 0 and moved <= 0.05 * step, (mode, moved, step)
         if mode == "tape":
             nk, nw, no = g.tape.counts()
-            assert nk > 300 and nw >= 10, (nk, nw, no)
+            assert nk > 300 and no >= 20, (nk, nw, no)            # kernels; event records / waits, fills and copies
             og2 = g.step(*b, seed=8, lrs=(1e-4, 1e-4, 1e-4))                     # a second replay: new masks, a moved state
             torch.cuda.synchronize()
             assert not torch.equal(og2["hs"], le["hs"]) and bool(torch.isfinite(og2["localization_loss"]).all())
