@@ -289,7 +289,45 @@ def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> di
            "cpu_baseline": (cpu_baseline_retrieval(cfg, synth.make_state_dict(cfg, seed=0), S) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None)}
     del eng, sr, rows, v, seg, mu
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and os.environ.get("MADE_BENCH_RETRIEVAL_512", "1") != "0":
+        # "also report S = 512, D = 512" -- the headline model's width and segment count.  made_xpool_fused is built for
+        # D = 256, so this shape takes the UNFUSED chain (per-track K / U projections, made_attention_wide, LayerNorm2, Linear,
+        # made_xpool_tail: three HBM round trips of [N_m * N_v, D]); a bounded problem, reported as measured.
+        try:
+            out["config"]["S512_D512_unfused"] = _retrieval_512(args)
+        except Exception as ex:                      # report, do not hide
+            out["config"]["S512_D512_unfused"] = {"error": f"{type(ex).__name__}: {ex}"}
     return out
+
+
+def _retrieval_512(args, n_v: int = 8192, n_m: int = 512, S: int = 512) -> dict:
+    cfg = cfg_headline()
+    dev = torch.device("cuda")
+    eng = MadeEngine(cfg, synth.make_state_dict(cfg, seed=0), device=dev, dtype=args.dtype)
+    D = cfg.D
+    g = torch.Generator(device=dev).manual_seed(5)
+    v = torch.nn.functional.normalize(torch.randn(n_v, D, device=dev, generator=g), dim=-1)
+    seg = torch.randn(n_m, S, D, device=dev, generator=g)
+    lens = torch.randint(12, S + 1, (n_m,), device=dev, generator=g)
+    mask = (torch.arange(S, device=dev)[None] < lens[:, None]).float()
+    seg = (seg * mask[:, :, None]).to(eng.tc)
+    mu = torch.nn.functional.normalize(torch.randn(n_m, D, device=dev, generator=g), dim=-1)
+    step = lambda: eng.retrieval_sim_matrix(v, seg, mask, mu)
+    sim = step()
+    torch.cuda.synchronize()
+    assert sim.shape == (n_v, n_m) and bool(torch.isfinite(sim).all())
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / 2
+    alg = 4.0 * (n_m * S * D + n_m * S + n_v * D + n_m * D + n_v * n_m)
+    flops = float(n_v) * n_m * (4.0 * float(mask.sum()) / n_m * D + 2.0 * D * D)
+    del eng
+    torch.cuda.empty_cache()
+    return {"workload": f"N_v={n_v}, N_m={n_m}, S={S}, D={D}, segment lengths U{{12..{S}}}, 1 GPU", "ms_per_pass": round(sec * 1e3, 2),
+            "GB_s": round(alg / sec / 1e9, 3), "pairs_per_s": round(n_v * n_m / sec, 1), "executed_tflops": round(flops / sec / 1e12, 1),
+            "path": "unfused (made_xpool_fused serves D = 256 only)"}
 
 
 def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
@@ -348,9 +386,12 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
         try:
             tape = trn.capture_train_step(*batch, max_grad_norm=1.0, mode="tape")
 
+            tbatch = tuple(tape.inputs[k] for k in ("frame_feats", "segment_feats", "frame_masks", "segment_masks", "spans_target"))   # the tape's own
+            # batch buffers (the same synthetic batch, resident in HBM): a loader would write the next batch there directly
+
             def tape_step():
                 it[0] += 1
-                return tape.step(*batch, seed=it[0], lrs=(1e-4, 1e-4, 1e-4))
+                return tape.step(*tbatch, seed=it[0], lrs=(1e-4, 1e-4, 1e-4))
             for _ in range(3):
                 eager_step()
             torch.cuda.synchronize()

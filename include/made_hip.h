@@ -215,7 +215,7 @@ int made_dec_stage(const MadeDecStageArgs* args, void* stream);
 
 /* made_dec_stage_bwd: a stage of the decoder's BACKWARD chain with a LayerNorm backward in the prologue of the dX product that
  * consumes it (reference music_detr/transformer.py:273-307 read backwards; bf16 rows, K = the norm's width = 256 or 512):
- *     g   = dy,  or with a second norm stacked on the first (xb != NULL: norm 3 + the shared output norm, :306 and :136)
+ *     g   = dy (+ add),  or with a second norm stacked on the first (xb != NULL: norm 3 + the shared output norm, :306 and :136)
  *     g   = LN_b'(dy; xb, gamma_b) + add
  *     dx  = LN_a'(g; xa, gamma_a)       -> dx_out [M, K] (may be NULL);  dgamma / dbeta of the norm(s) accumulated (may be NULL)
  *     A   = dropout_a(dx)               -> a_out [M, K] (may be NULL): element index row * drop_a_ld + col
@@ -225,7 +225,7 @@ typedef struct MadeDecStageBwdArgs {
     const void* xa; const float* gamma_a; int64_t ldxa;
     const void* xb; const float* gamma_b; int64_t ldxb;      /* second (outer) norm or NULL */
     const void* dy; int64_t lddy;
-    const void* add; int64_t ldadd;                          /* two-norm form only; may be NULL */
+    const void* add; int64_t ldadd;                          /* may be NULL */
     void* dx_out; int64_t lddx;
     void* a_out; int64_t lda_out;
     float *dgamma_a, *dbeta_a, *dgamma_b, *dbeta_b;
@@ -369,6 +369,9 @@ int made_tape_begin(void);
 int made_tape_end(uint64_t* handle);
 int made_tape_replay(uint64_t handle);
 int made_tape_free(uint64_t handle);
+/* re-orders the ISSUE order of a finished tape so that all its streams are fed at the same time (per-stream order, event order and
+ * hence every result unchanged): `main_weight` operations of the busiest stream for one of each other stream, round-robin */
+int made_tape_interleave(uint64_t handle, int32_t main_weight);
 int made_tape_count(uint64_t handle, int64_t* kernels, int64_t* waits, int64_t* others);
 int made_stream_wait(void* src_stream, void* dst_stream);            /* dst waits for all work queued on src so far */
 int made_tape_event(int32_t op_kind, int32_t slot, void* stream);    /* recording only, executes nothing: 0 = "record event `slot` on

@@ -167,6 +167,7 @@ SIGNATURES = {
     "made_tape_end": (C.c_int, [C.POINTER(C.c_uint64)]),
     "made_tape_replay": (C.c_int, [C.c_uint64]),
     "made_tape_free": (C.c_int, [C.c_uint64]),
+    "made_tape_interleave": (C.c_int, [C.c_uint64, i32]),
     "made_tape_count": (C.c_int, [C.c_uint64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "made_stream_wait": (C.c_int, [vp, vp]),
     "made_tape_event": (C.c_int, [i32, i32, vp]),

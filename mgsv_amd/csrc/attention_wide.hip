@@ -141,6 +141,10 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
     const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float drop_sc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t drop_base = (uint64_t)(b * nq_total + (my_q < nq_total ? my_q : nq_total - 1)) * (uint64_t)a.L;
+    // (the mix's key depends on the index's high word only: made once when the row's indices do not cross a 2^32 boundary)
+    const bool drop_fast = (uint32_t)drop_base <= 0xFFFFFFFFu - (uint32_t)(a.L + 64);
+    const uint32_t drop_key = made_rng_key(drop_seed, a.drop.site, (uint32_t)(drop_base >> 32));
+    const uint32_t drop_lo = (uint32_t)drop_base;
 
     // keys of this workgroup: all of them, or the blockIdx.z-th slice when the keys are split over workgroups
     // keys after the last valid one contribute exactly 0: stop there (padding is a suffix in the dataset's masks)
@@ -278,7 +282,9 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
             float dsum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const bool kp = (made_rng_mix(drop_seed, a.drop.site, drop_base + (uint64_t)(t * WKEY + acc_row(e, hh))) >> 8) >= drop_thr;
+                const uint32_t kidx = (uint32_t)(t * WKEY + acc_row(e, hh));
+                const uint32_t hsh = drop_fast ? made_rng_fmix32((drop_lo + kidx) ^ drop_key) : made_rng_mix(drop_seed, a.drop.site, drop_base + (uint64_t)kidx);
+                const bool kp = (hsh >> 8) >= drop_thr;
                 s[e] = kp ? s[e] * drop_sc : 0.f;
                 dsum += s[e];
             }

@@ -153,6 +153,9 @@ __global__ __launch_bounds__(NT) void attention_wide_bwd_kernel(const MadeWideAt
     const uint64_t drop_seed = a.drop.p > 0.f ? made_drop_seed(a.drop) : 0;
     const float drop_sc = a.drop.p > 0.f ? 1.f / (1.f - a.drop.p) : 1.f;
     const uint64_t drop_base = (uint64_t)(b * NQ + rq) * (uint64_t)a.L;
+    const bool drop_fast = (uint32_t)drop_base <= 0xFFFFFFFFu - (uint32_t)(a.L + 64);      // (the mix's key made once: see made_keep_bits)
+    const uint32_t drop_key = made_rng_key(drop_seed, a.drop.site, (uint32_t)(drop_base >> 32));
+    const uint32_t drop_lo = (uint32_t)drop_base;
     bf16_t* out_row = (wave == 0 ? (bf16_t*)a.Pd : (bf16_t*)a.dS) + b * a.p_bs + (int64_t)rq * a.ld_p;
 
     __builtin_amdgcn_s_waitcnt(0x0070);                             // (the fragment loads: hipcc does not see waits inside inline asm)
@@ -197,7 +200,11 @@ __global__ __launch_bounds__(NT) void attention_wide_bwd_kernel(const MadeWideAt
             const bool valid = (tbits >> kr) & 1u;
             const float p = valid ? __expf(S * a.scale - lse) : 0.f;
             bool kp = true;
-            if (a.drop.p > 0.f) kp = (made_rng_mix(drop_seed, a.drop.site, drop_base + (uint64_t)(t * BK + kr)) >> 8) >= drop_thr;
+            if (a.drop.p > 0.f) {
+                const uint32_t kidx = (uint32_t)(t * BK + kr);
+                const uint32_t hsh = drop_fast ? made_rng_fmix32((drop_lo + kidx) ^ drop_key) : made_rng_mix(drop_seed, a.drop.site, drop_base + (uint64_t)kidx);
+                kp = (hsh >> 8) >= drop_thr;
+            }
             pd[e] = kp ? p * drop_sc : 0.f;
             const float dpd = valid ? dP + extra : 0.f;
             const float dpu = kp ? dpd * drop_sc : 0.f;

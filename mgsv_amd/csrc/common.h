@@ -107,6 +107,25 @@ template <typename F> __device__ __forceinline__ F keep_or_zero(F x, bool keep) 
     return __builtin_bit_cast(F, b);
 }
 
+// Keep bits of N <= 8 CONSECUTIVE element indices idx0 .. idx0 + N - 1 of a dropout site (bit j = element idx0 + j is kept).  The mix
+// is fmix32(lo32(idx) ^ key(seed, site, hi32(idx))): called per element with a 64-bit index the compiler recomputes the key --
+// a second fmix32 round and the 64-bit carry chain, ~30 VALU instructions per element -- here it is made once per group
+// (made_rng_mix's definition, bit for bit; the slow path covers a group that straddles a 2^32 boundary).
+template <int N>
+__device__ __forceinline__ uint32_t made_keep_bits(uint64_t seed, uint32_t site, uint32_t thr, uint64_t idx0) {
+    const uint32_t lo = (uint32_t)idx0;
+    uint32_t m = 0;
+    if (lo <= 0xFFFFFFFFu - (uint32_t)N) {
+        const uint32_t k = made_rng_key(seed, site, (uint32_t)(idx0 >> 32));
+#pragma unroll
+        for (int j = 0; j < N; ++j) m |= ((made_rng_fmix32((lo + (uint32_t)j) ^ k) >> 8) >= thr) ? (1u << j) : 0u;
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) m |= ((made_rng_mix(seed, site, idx0 + (uint64_t)j) >> 8) >= thr) ? (1u << j) : 0u;
+    }
+    return m;
+}
+
 // Wave-wide reductions on the DPP path (VALU only).  The butterfly of six __shfl_xor compiles to six ds_bpermute_b32, which go
 // through the LDS crossbar: ~100 cycles each and one LDS unit per CU -- 96 of them per wave cost made_dec_stage 4 us of 10.
 // Here: four DPP steps reduce each row of 16 lanes (every lane of the row ends with the row's value), two row broadcasts chain the

@@ -131,16 +131,29 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
     for (int i = 0; i < RPW; ++i) {
         const int rl = wave * RPW + i;                          // row inside the tile (wave-uniform)
         if (has_ln) {
-            float s = 0.f;
+            if constexpr (ZB16) {
+                // training chain: sum x and sum x^2 in ONE round of two independent wave reductions (bf16 rows: the difference to the
+                // centred form is far below their rounding)
+                float s = 0.f, q = 0.f;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) s += v[i][j];
-            const float mean = wave_sum(s) * (1.f / K);
-            float q = 0.f;
+                for (int j = 0; j < NV; ++j) { s += v[i][j]; q += v[i][j] * v[i][j]; }
+                s = wave_sum(s); q = wave_sum(q);
+                const float mean = s * (1.f / K);
+                const float rstd = rsqrtf(fmaxf(q * (1.f / K) - mean * mean, 0.f) + a.eps);
 #pragma unroll
-            for (int j = 0; j < NV; ++j) { v[i][j] -= mean; q += v[i][j] * v[i][j]; }
-            const float rstd = rsqrtf(wave_sum(q) * (1.f / K) + a.eps);
+                for (int j = 0; j < NV; ++j) v[i][j] = (v[i][j] - mean) * rstd * g1[j] + b1[j];
+            } else {
+                float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) v[i][j] = v[i][j] * rstd * g1[j] + b1[j];
+                for (int j = 0; j < NV; ++j) s += v[i][j];
+                const float mean = wave_sum(s) * (1.f / K);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) { v[i][j] -= mean; q += v[i][j] * v[i][j]; }
+                const float rstd = rsqrtf(wave_sum(q) * (1.f / K) + a.eps);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v[i][j] = v[i][j] * rstd * g1[j] + b1[j];
+            }
         }
         if (has_ln2) {                                          // the decoder's output norm on top of this layer's norm
             float s = 0.f;
@@ -277,9 +290,15 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
             const uint64_t seed = made_drop_seed(a.drop);
             const uint64_t rb = (uint64_t)ml * (uint64_t)a.drop_ld;
             const int div = a.drop_col_div > 1 ? a.drop_col_div : 1;
+            if (div == 1) {
+                const uint32_t kb = made_keep_bits<8>(seed, a.drop.site, thr, rb + (uint64_t)n);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v8[j] = (made_rng_mix(seed, a.drop.site, rb + (uint64_t)((n + j) / div)) >> 8) >= thr ? v8[j] * sc : 0.f;
+                for (int j = 0; j < 8; ++j) v8[j] = ((kb >> j) & 1u) ? v8[j] * sc : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v8[j] = (made_rng_mix(seed, a.drop.site, rb + (uint64_t)((n + j) / div)) >> 8) >= thr ? v8[j] * sc : 0.f;
+            }
         }
     }
 #pragma unroll
@@ -309,37 +328,38 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
 // =================================================================================================
 // made_dec_stage_bwd: the mirror image for the backward chain -- a LayerNorm BACKWARD in the prologue of the Linear (dX product)
 // that consumes its result (reference music_detr/transformer.py:273-307 read backwards: x = LN(t), t = res + dropout(branch)):
-//     g   = dy                                           or, with a second norm stacked on the first (norm 3 + the shared output norm):
+//     g   = dy (+ add)                                   or, with a second norm stacked on the first (norm 3 + the shared output norm):
 //     g   = LN_b'(dy; xb, gamma_b) + add
 //     dx  = LN_a'(g; xa, gamma_a)                        -> dx_out (the residual path's gradient), parameter gradients accumulated
 //     A   = dropout_a(dx)                                -> a_out (the branch's output gradient: a weight-gradient operand) and LDS
 //     out = dropout_o((A W^T) * gate'(G) * gate_scale) + R
 // Every workgroup (64 rows x 32 output columns) redoes the row work for its 64 rows -- 2 x 64 KB from L2 under the flight of its own
 // weight fragments, as made_dec_stage does for the forward norm -- so a 64-row link of the chain is ONE launch instead of two.
+// One row of a LayerNorm backward with ALL FOUR row sums taken in one round (sum x, sum x^2, sum g, sum g x; g = dy * gamma): the four
+// wave reductions are independent and pipeline, where mean -> variance -> (mean g, mean g xhat) is three dependent rounds of ~150
+// cycles each, eight rows per wave (this prologue is what a 64-row stage of the backward chain spends its time in).
+//   mean = Sx / K,  var = Sxx / K - mean^2,  s1 = Sg / K,  s2 = rstd (Sgx - mean Sg) / K,  dx = rstd (g - s1 - xhat s2)
 template <int NV>
 __device__ __forceinline__ void dsb_ln_bwd_row(float (&xv)[NV], float (&gy)[NV], const float (&gm)[NV], float eps, float (&dg)[NV], float (&db)[NV], float (&o)[NV]) {
     constexpr int K = 64 * NV;
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) s += xv[j];
-    const float mean = wave_sum(s) * (1.f / K);
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { xv[j] -= mean; q += xv[j] * xv[j]; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.f / K) + eps);
-    float s1 = 0.f, s2 = 0.f;
+    float sx = 0.f, sxx = 0.f, sg = 0.f, sgx = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const float xh = xv[j] * rstd;
         const float g = gy[j] * gm[j];
-        dg[j] += gy[j] * xh; db[j] += gy[j];
-        xv[j] = xh; gy[j] = g;
-        s1 += g; s2 += g * xh;
+        sx += xv[j]; sxx += xv[j] * xv[j]; sg += g; sgx += g * xv[j];
     }
-    s1 = wave_sum(s1) * (1.f / K);
-    s2 = wave_sum(s2) * (1.f / K);
+    sx = wave_sum(sx); sxx = wave_sum(sxx); sg = wave_sum(sg); sgx = wave_sum(sgx);
+    const float mean = sx * (1.f / K);
+    const float var = fmaxf(sxx * (1.f / K) - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float s1 = sg * (1.f / K);
+    const float s2 = rstd * (sgx - mean * sg) * (1.f / K);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) o[j] = rstd * (gy[j] - s1 - xv[j] * s2);
+    for (int j = 0; j < NV; ++j) {
+        const float xh = (xv[j] - mean) * rstd;
+        dg[j] += gy[j] * xh; db[j] += gy[j];
+        o[j] = rstd * (gy[j] * gm[j] - s1 - xh * s2);
+    }
 }
 
 template <int NV>
@@ -360,8 +380,9 @@ __device__ __forceinline__ void dsb_store_row(void* p, int64_t off, const float 
     else { bf16x4 t; for (int u = 0; u < 4; ++u) t[u] = (bf16_t)v[u]; *(bf16x4*)((bf16_t*)p + off) = t; }
 }
 
-template <int NV, bool TWO>
+template <int NV, int MODE>                                   // MODE 0: one norm; 1: one norm, g = dy + add; 2: two stacked norms (+ add)
 __global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDecStageBwdArgs a) {
+    constexpr bool TWO = MODE == 2, ADD1 = MODE == 1;
     constexpr int K = 64 * NV;
     constexpr int LDA = K * 2 + 16;
     constexpr int STEPS = NV;
@@ -417,7 +438,7 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDec
     constexpr int RPW = DS_RPW;
     // every row of this wave is requested before the first reduction (raw bf16 vectors: 4 registers per row and tensor)
     typedef typename std::conditional<NV == 8, bf16x8, bf16x4>::type raw_t;
-    raw_t rxa[RPW], rdy[RPW], rxb[TWO ? RPW : 1], rad[TWO ? RPW : 1];
+    raw_t rxa[RPW], rdy[RPW], rxb[TWO ? RPW : 1], rad[(TWO || ADD1) ? RPW : 1];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         int gm = m0 + wave * RPW + i; gm = gm < M ? gm : M - 1;
@@ -432,6 +453,13 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDec
             rad[i] = *(const raw_t*)((const bf16_t*)(a.add ? a.add : a.xb) + (int64_t)gm * (a.add ? a.ldadd : a.ldxb) + c0);
         }
     }
+    if constexpr (ADD1) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            int gm = m0 + wave * RPW + i; gm = gm < M ? gm : M - 1;
+            rad[i] = *(const raw_t*)((const bf16_t*)a.add + (int64_t)gm * a.ldadd + c0);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int rl = wave * RPW + i;
@@ -440,6 +468,10 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDec
         float xa[NV], gy[NV], o[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) { xa[j] = (float)rxa[i][j]; gy[j] = (float)rdy[i][j]; }
+        if constexpr (ADD1) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) gy[j] += (float)rad[i][j];
+        }
         if constexpr (TWO) {
             float xb[NV], ad[NV], g[NV];
 #pragma unroll
@@ -460,9 +492,9 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDec
         // the branch's gradient: dropout of this site's forward mask (element index row * drop_a_ld + col)
         float od[NV];
         const uint64_t dbase = (uint64_t)gm * (uint64_t)a.drop_a_ld + (uint64_t)c0;
+        const uint32_t kb = a.drop_a.p > 0.f ? made_keep_bits<NV>(seed_a, a.drop_a.site, thr, dbase) : 0xFFu;
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
-            od[j] = a.drop_a.p > 0.f ? (((made_rng_mix(seed_a, a.drop_a.site, dbase + j) >> 8) >= thr) ? o[j] * sc_a : 0.f) : o[j];
+        for (int j = 0; j < NV; ++j) od[j] = ((kb >> j) & 1u) ? o[j] * sc_a : 0.f;
         dsb_store_row<NV>(dlds, (int64_t)rl * (LDA / 2) + c0, od);               // (LDA bytes = LDA / 2 bf16 elements per row)
         const bool writer = real && ((m0 + rl) % (int)gridDim.x == (int)blockIdx.x);
         if (writer) {
@@ -585,18 +617,22 @@ extern "C" int made_dec_stage_bwd(const MadeDecStageBwdArgs* args, void* stream)
     hipStream_t st = (hipStream_t)stream;
     if (a.K == 512) {
         constexpr int LDSB = DS_BM * (512 * 2 + 16) + 8 * 4 * 512 * 4;
-        static const bool once = hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
-                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+        static const bool once = hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
         (void)once;
-        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<8, true>), grid, block, LDSB, st, a);
-        else hipLaunchKernelGGL((dec_stage_bwd_kernel<8, false>), grid, block, LDSB, st, a);
+        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 2>), grid, block, LDSB, st, a);
+        else if (a.add) hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 1>), grid, block, LDSB, st, a);
+        else hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 0>), grid, block, LDSB, st, a);
     } else {
         constexpr int LDSB = 4 * DS_BM * DS_CT_LD * 4 + 8 * 4 * 256 * 4;
-        static const bool once = hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
-                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+        static const bool once = hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
         (void)once;
-        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<4, true>), grid, block, LDSB, st, a);
-        else hipLaunchKernelGGL((dec_stage_bwd_kernel<4, false>), grid, block, LDSB, st, a);
+        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 2>), grid, block, LDSB, st, a);
+        else if (a.add) hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 1>), grid, block, LDSB, st, a);
+        else hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 0>), grid, block, LDSB, st, a);
     }
     return made_check_launch("made_dec_stage_bwd");
 }

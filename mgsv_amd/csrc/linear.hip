@@ -227,9 +227,9 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
                 v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, rb + (uint64_t)((n + j) / a.drop_col_div)) >> 8) >= thr ? v[j] * sc : 0.f;
         } else {
             const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
+            const uint32_t kb = made_keep_bits<8>(made_drop_seed(a.drop), a.drop.site, thr, base);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * sc : 0.f;
         }
     }
     if (a.R) {
@@ -1038,9 +1038,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void linear_ring_kernel(const Made
                         v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, rb + (uint64_t)((n + j) / a.drop_col_div)) >> 8) >= thr ? v[j] * sc : 0.f;
                 } else {
                     const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
+                    const uint32_t kb = made_keep_bits<8>(made_drop_seed(a.drop), a.drop.site, thr, base);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, base + j) >> 8) >= thr ? v[j] * sc : 0.f;
+                    for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * sc : 0.f;
                 }
             }
         }

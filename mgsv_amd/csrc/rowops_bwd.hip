@@ -199,8 +199,9 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs 
                 if (a.dxd) {
                     if (a.drop.p > 0.f) {
                         const uint64_t base = (uint64_t)row * (uint64_t)a.drop_ld + (uint64_t)c;
+                        const uint32_t kb = made_keep_bits<4>(drop_seed, a.drop.site, thr, base);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = keep_at(drop_seed, a.drop.site, thr, base + j) ? o[j] * dsc : 0.f;
+                        for (int j = 0; j < 4; ++j) o[j] = ((kb >> j) & 1u) ? o[j] * dsc : 0.f;
                     }
                     st4(a.dxd, a.dxdt, row * a.lddxd + c, o);
                 }
@@ -279,48 +280,40 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_v8_kernel(const LnBwdAr
                 kbits[k] = 0xFFu;
                 if (a.drop.p > 0.f) {
                     const uint64_t dbase = (uint64_t)rw[k] * (uint64_t)a.drop_ld + (uint64_t)c0;
-                    uint32_t m = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) m |= keep_at(drop_seed, a.drop.site, thr, dbase + j) ? (1u << j) : 0u;
-                    kbits[k] = m;
+                    kbits[k] = made_keep_bits<8>(drop_seed, a.drop.site, thr, dbase);
                 }
             }
 #pragma unroll
             for (int k = 0; k < RF; ++k) asm volatile("" : "+v"(kbits[k]));      // (keep the draws in front of the first use of the loads)
-            float xv[RF][8], gy[RF][8], mean[RF], rstd[RF], s1[RF], s2[RF];
+            // all four row sums (x, x^2, g, g x; g = dy * gamma) in ONE round of independent wave reductions per row
+            float xv[RF][8], gy[RF][8], mean[RF], rstd[RF], s1[RF], s2[RF], t0[RF], t1[RF], t2[RF], t3[RF];
 #pragma unroll
             for (int k = 0; k < RF; ++k) {
-                float sum = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { xv[k][j] = (float)xr[k][j]; gy[k][j] = (float)gr[k][j]; sum += xv[k][j]; }
-                mean[k] = sum;
-            }
-#pragma unroll
-            for (int k = 0; k < RF; ++k) mean[k] = wave_sum(mean[k]) * (1.f / D);
-#pragma unroll
-            for (int k = 0; k < RF; ++k) {
-                float sq = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { xv[k][j] -= mean[k]; sq += xv[k][j] * xv[k][j]; }
-                rstd[k] = sq;
-            }
-#pragma unroll
-            for (int k = 0; k < RF; ++k) rstd[k] = 1.0f / sqrtf(wave_sum(rstd[k]) * (1.f / D) + a.eps);
-#pragma unroll
-            for (int k = 0; k < RF; ++k) {
-                float t1 = 0.f, t2 = 0.f;
+                float sx = 0.f, sxx = 0.f, sg = 0.f, sgx = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xh = xv[k][j] * rstd[k];
+                    xv[k][j] = (float)xr[k][j]; gy[k][j] = (float)gr[k][j];
                     const float g = gy[k][j] * gm[j];
-                    if (on[k]) { dg[j] += gy[k][j] * xh; db[j] += gy[k][j]; }
-                    xv[k][j] = xh; gy[k][j] = g;
-                    t1 += g; t2 += g * xh;
+                    sx += xv[k][j]; sxx += xv[k][j] * xv[k][j]; sg += g; sgx += g * xv[k][j];
                 }
-                s1[k] = t1; s2[k] = t2;
+                t0[k] = sx; t1[k] = sxx; t2[k] = sg; t3[k] = sgx;
             }
 #pragma unroll
-            for (int k = 0; k < RF; ++k) { s1[k] = wave_sum(s1[k]) * (1.f / D); s2[k] = wave_sum(s2[k]) * (1.f / D); }
+            for (int k = 0; k < RF; ++k) { t0[k] = wave_sum(t0[k]); t1[k] = wave_sum(t1[k]); t2[k] = wave_sum(t2[k]); t3[k] = wave_sum(t3[k]); }
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                mean[k] = t0[k] * (1.f / D);
+                const float var = fmaxf(t1[k] * (1.f / D) - mean[k] * mean[k], 0.f);
+                rstd[k] = 1.0f / sqrtf(var + a.eps);
+                s1[k] = t2[k] * (1.f / D);
+                s2[k] = rstd[k] * (t3[k] - mean[k] * t2[k]) * (1.f / D);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (xv[k][j] - mean[k]) * rstd[k];
+                    if (on[k]) { dg[j] += gy[k][j] * xh; db[j] += gy[k][j]; }
+                    xv[k][j] = xh; gy[k][j] *= gm[j];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < RF; ++k) {
                 if (!on[k]) continue;

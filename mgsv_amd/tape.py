@@ -102,6 +102,10 @@ class LaunchTape:
     def replay(self) -> None:
         _lib.check(_lib.lib().made_tape_replay(self.handle), "made_tape_replay")
 
+    def interleave(self, main_weight: int = 2) -> None:
+        """feed all streams at the same time on replay (made_tape_interleave): results unchanged, only the host's issue order moves"""
+        _lib.check(_lib.lib().made_tape_interleave(self.handle, int(main_weight)), "made_tape_interleave")
+
     def counts(self):
         k, w, o = _lib.i64(0), _lib.i64(0), _lib.i64(0)
         _lib.check(_lib.lib().made_tape_count(self.handle, C.byref(k), C.byref(w), C.byref(o)), "made_tape_count")

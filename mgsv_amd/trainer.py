@@ -447,7 +447,7 @@ class MadeTrainer(MadeEngine):
             d_tq0=E(B * Q, D), GQ=Z(B, 2, nd, HQ, D), PdS=Z(B, 2, nd, HQ, Lp), dS_S=E(nd, B * HQ, Lp, dtype=f32), dS_dP=E(B * HQ, Lp, dtype=f32),
             dSt=E(B, L, HQ), d_ds=E(B * Q, H, dtype=f32), d_delta=E(B * H * Q, dtype=f32),
             dg1=E(B * Q, D), dg2=E(B * Q, D), dg3=E(B * Q, D), dg4=E(B * Q, D), dgqkv=E(B * Q, 3 * D), dgffn=E(B * Q, Fd),
-            dgq=E(B, HQ, D), dtgt=E(B * Q, D), dhs=E(nd * B * Q, D),
+            dgq=E(B, HQ, D), dtgt=E(B * Q, D), dhs=E(nd * B * Q, D), dgN=E(nd * B * Q, D),
             # heads
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D), hg1=E(nd * B * Q, D), hg2=E(nd * B * Q, D),
             dlog=Z(nd * B * Q, HEAD_PAD, dtype=f32), dsp=Z(nd * B * Q, HEAD_PAD, dtype=f32), dlog_c=Z(nd * B * Q, HEAD_PAD), dsp_c=Z(nd * B * Q, HEAD_PAD),
@@ -1059,9 +1059,12 @@ class MadeTrainer(MadeEngine):
         cur, side = torch.cuda.current_stream(), self._side_stream()
         xq = c.moment_query_type == "xpool" and not regression
         side.wait_stream(cur)
+        ret_done = None
         if not xq:                                           # (with an xpool query it follows the decoder's backward: see below)
             with torch.cuda.stream(side):
                 self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
+                ret_done = torch.cuda.Event()
+                ret_done.record(side)
 
         if regression:
             dmem, dtgt0 = self._regression_bwd(ws, tw, g_loc, B, L), None
@@ -1129,30 +1132,29 @@ class MadeTrainer(MadeEngine):
                 ops.linear(GQ[0, 1].reshape(nd * HQ, D), mempos3[0], None, M=nd * HQ, N=L, K=D, batch=B, a_z_stride=GQ.stride(0), w_z_stride=L * D,
                            segs=[Seg(out=S_all, ldo=Lp, rows_per_batch=HQ, out_batch_stride=B * HQ * Lp, out_z_stride=HQ * Lp)])
             n_split_b = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))
+            if stage:
+                # the shared output norm's backward depends on the heads only: all layers in ONE launch ahead of the dependent chain
+                gN = tw["dgN"]
+                tr.layernorm_bwd(tw["dstack"]["tgt"][1:].reshape(nd * B * Q, D), P["dec.norm.g"], dhs, gN, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"])
             for l in range(nd - 1, -1, -1):
                 p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
                 g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
                 Win, Wt = P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
                 g_ffn, g_z, g_ca, g_attc, g_q, g_qc, g_sa, gqkv = (st[k][l] for k in ("g_ffn", "g_z", "g_ca", "g_attc", "g_q", "g_qc", "g_sa", "g_qkv"))
-                if stage and D == 256:
-                    # hs_l = dec.norm(t3), t3 = LN3(t2 + drop3(ffn)), t3 also feeds the next layer: both norms' backward in the prologue
-                    # of the FFN's second dX product (made_dec_stage_bwd; at D = 512 the two-norm prologue does not fit the registers)
-                    tr.dec_stage_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], dhs[l * B * Q:(l + 1) * B * Q], P[p + ".ff2.wt"], g_z,
-                                     dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], xb=tw[d + ".t3"], gamma_b=P["dec.norm.g"],
-                                     dgamma_b=G["dec.norm.g"], dbeta_b=G["dec.norm.b"], add=dtgt, dx_out=g2, a_out=g_ffn,
+                if stage:
+                    # hs_l = dec.norm(t3) (its backward: one launch for all layers ahead of the chain), t3 = LN3(t2 + drop3(ffn)) also feeds
+                    # the next layer: norm 3's backward of (d hs_l through the output norm + d tgt_{l+1}) in the prologue of the FFN's second
+                    # dX product
+                    tr.dec_stage_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], gN[l * B * Q:(l + 1) * B * Q], P[p + ".ff2.wt"], g_z,
+                                     dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], add=dtgt, dx_out=g2, a_out=g_ffn,
                                      drop_a=self._drop(f"dec.{l}" + ".drop3", pd), G=tw[d + ".h"], gate_scale=inv_keep)
-                elif stage:
-                    # hs_l = dec.norm(t3), t3 = LN3(t2 + drop3(ffn)), t3 also feeds the next layer: both norms' backward in one launch
-                    tr.layernorm_bwd2(tw[d + ".t_c"], P[p + ".ln3.g"], tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g2,
-                                      dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], dgamma_b=G["dec.norm.g"], dbeta_b=G["dec.norm.b"],
-                                      add=dtgt, dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
                 else:
                     # hs_l = dec.norm(t3); t3 also feeds the next layer
                     tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
                     # t3 = LN3(t2 + drop3(ffn))
                     tr.layernorm_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], g1, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"],
                                      dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
-                if not (stage and D == 256):
+                if not stage:
                     ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
                 dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1, R=g2)
                 # t2 = LN2(t1 + drop2(cross-attention))
@@ -1355,7 +1357,13 @@ class MadeTrainer(MadeEngine):
             dl_v, dl_a = tw["c_dframe"].view(B, Tv, D), tw["c_dseg"].view(B, Ta, D)
 
         # ---------------- join the X-Pool / similarity branch, merge the gradients of the clip-level vectors
-        cur.wait_stream(side)
+        # (one process: the main stream needs the retrieval branch's results here, not the weight-gradient products queued behind it on
+        #  the second stream -- joining the whole stream left it idle behind the last DETR layer's grouped product, 0.2 ms per step;
+        #  data-parallel jobs start their first all-reduce below and need every gradient of its range complete)
+        if ret_done is not None and grad_sync is None and os.environ.get("MADE_BWD_EVENT_JOIN", "1") != "0":
+            cur.wait_event(ret_done)
+        else:
+            cur.wait_stream(side)
         if xq:
             # the decoder's content query was the mean over the videos of each track's pooled vectors: its gradient enters the
             # X-Pool tail as dpool[m] / N_v for every video n
@@ -1376,7 +1384,9 @@ class MadeTrainer(MadeEngine):
             if "video" in c.vmr_fusion:
                 dxv = tw["ydseg"] if dxv is None else tr.add3(tw["dframe_sum"], dxv, tw["ydseg"])
             self._encode_bwd("video", ws, tw, dl_v, dxv.view(B, Tv, D) if dxv is not None else None, dvideo, fm, feats_v)
-        self._encode_bwd("audio", ws, tw, dl_a, tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a)
+        # (the audio tower's weight-gradient products have nobody waiting on the main stream either: second stream, behind the video tower)
+        self._encode_bwd("audio", ws, tw, dl_a, tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a,
+                         dw_stream=side if os.environ.get("MADE_AUDIO_DW_SIDE", "1") != "0" else None)
         cur.wait_stream(side)
 
     def _regression_train(self, out, ws, tw, mem3: Tensor, fus_mask: Tensor, v_duration, cur, side) -> Dict[str, Tensor]:
@@ -1584,7 +1594,10 @@ class MadeTrainer(MadeEngine):
         tr.gemm_tn(dx, xin, G[proj + ".w"], accumulate=True, rows=self._rw(mflat))
         tr.colsum(dx, G[proj + ".b"])
 
-    def _encode_bwd(self, which: str, ws, tw, d_local: Tensor, d_extra: Optional[Tensor], dvec: Tensor, mask: Tensor, feats: Tensor) -> None:
+    def _encode_bwd(self, which: str, ws, tw, d_local: Tensor, d_extra: Optional[Tensor], dvec: Tensor, mask: Tensor, feats: Tensor,
+                    dw_stream=None) -> None:
+        """dw_stream: run the weight-gradient products there instead of on the current stream (a one-layer block only: a deeper stack
+        reuses the gradient buffers they read from layer to layer)."""
         c, P, G = self.cfg, self.P, self.G
         if c.agg_module == "mlp":
             return self._encode_bwd_mlp(which, ws, tw, d_local, d_extra, dvec, mask, feats)
@@ -1636,6 +1649,13 @@ class MadeTrainer(MadeEngine):
                              key_mask=mask, q_skip_mask=mask, drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask.data_ptr()])
             dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3b, row_mask=mflat, skip=mflat, R=g1b, defer=pend)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
+            if dw_stream is not None and depth == 1 and not cls and not c.with_act_after_proj:
+                dw_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(dw_stream):
+                    self._flush_dw(pend, mflat)
+                    xin_ = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
+                    tr.gemm_tn(dx, xin_, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], rows=self._rw(mflat0))
+                return
             self._flush_dw(pend, mflat)
         xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
         if cls:                                              # x0 = [token + pe_0 ; proj(x) + pe_1..T]
@@ -1738,6 +1758,9 @@ class TrainStepGraph:
                     self.out = fwd_bwd(); opt()
                 torch.cuda.synchronize()
                 self.tape = tp
+                tw_ = int(os.environ.get("MADE_TAPE_INTERLEAVE", "2"))       # 0: replay in program order (knob for A/B measurements)
+                if tw_ > 0:
+                    tp.interleave(tw_)
                 for dst, src in zip((t.flat_param, t.exp_avg, t.exp_avg_sq), keep2):
                     dst.copy_(src)
                 for k, v in keep_buf.items():

@@ -709,15 +709,16 @@ def test_two_chained_layernorms_backward(T, dtype, tol, rows, D):
         assert float((got - 1 - ref).abs().max()) <= 5 * tol * max(float(ref.abs().max()), 1.0)
 
 
-@pytest.mark.parametrize("D,N,two,gate,col_div", [(512, 512, False, False, 1), (512, 512, False, False, 64), (512, 1024, True, True, 1),
-                                                   (256, 1024, True, True, 1), (256, 256, False, False, 32)])
-def test_dec_stage_bwd_matches_the_separate_launches(T, D, N, two, gate, col_div):
+@pytest.mark.parametrize("D,N,mode,gate,col_div", [(512, 512, 0, False, 1), (512, 512, 0, False, 64), (512, 1024, 2, True, 1), (512, 1024, 1, True, 1),
+                                                    (256, 1024, 2, True, 1), (256, 256, 0, False, 32), (256, 1024, 1, True, 1)])
+def test_dec_stage_bwd_matches_the_separate_launches(T, D, N, mode, gate, col_div):
     """made_dec_stage_bwd (a LayerNorm backward -- or norm 3 + the output norm -- in the prologue of the dX product that consumes it)
     against made_layernorm_bwd / made_layernorm_bwd2 + made_linear with the same stateless masks: same dropout pattern, values to
     bf16 rounding, parameter gradients to f32 summation order."""
     ops, tr = T
     from mgsv_amd import _lib
     M, p = 64, 0.1
+    two = mode == 2                                               # mode 0: one norm; 1: one norm, dy + add; 2: two stacked norms + add
     bf = torch.bfloat16
     xa, dy = _rand(M, D, dtype=bf, seed=1), (_rand(M, D, dtype=torch.float32, seed=2) * 0.3).to(bf)
     xb, add = _rand(M, D, dtype=bf, seed=3), (_rand(M, D, dtype=torch.float32, seed=4) * 0.3).to(bf)
@@ -735,22 +736,24 @@ def test_dec_stage_bwd_matches_the_separate_launches(T, D, N, two, gate, col_div
     if two:
         tr.layernorm_bwd2(xa, ga, xb, gb, dy, dx0, dgamma_a=pg0[0], dbeta_a=pg0[1], dgamma_b=pg0[2], dbeta_b=pg0[3], add=add, dx_drop=ad0, drop=drop_a)
     else:
-        tr.layernorm_bwd(xa, ga, dy, dx0, dgamma=pg0[0], dbeta=pg0[1], dx_drop=ad0, drop=drop_a)
+        dy_in = dy if mode == 0 else (dy.float() + add.float()).to(bf)      # (the fused form adds in f32: one bf16 rounding apart)
+        tr.layernorm_bwd(xa, ga, dy_in, dx0, dgamma=pg0[0], dbeta=pg0[1], dx_drop=ad0, drop=drop_a)
     ops.linear(ad0, W, None, out=out0, R=R, **(dict(gate=_lib.GATE_RELU_OUT, G=Gt, gate_scale=1.25) if gate else {}),
                **(dict(drop=drop_o, drop_ld=N // col_div, drop_col_div=col_div) if drop_o else {}))
     # fused
     dx1, ad1, out1 = E(M, D), E(M, D), E(M, N)
     pg1 = [Z(), Z(), Z(), Z()]
     tr.dec_stage_bwd(xa, ga, dy, W, out1, dgamma_a=pg1[0], dbeta_a=pg1[1], dx_out=dx1, a_out=ad1, drop_a=drop_a, R=R,
-                     **(dict(xb=xb, gamma_b=gb, dgamma_b=pg1[2], dbeta_b=pg1[3], add=add) if two else {}),
+                     **(dict(xb=xb, gamma_b=gb, dgamma_b=pg1[2], dbeta_b=pg1[3], add=add) if two else (dict(add=add) if mode == 1 else {})),
                      **(dict(G=Gt, gate_scale=1.25) if gate else {}),
                      **(dict(drop_o=drop_o, drop_o_ld=N // col_div, drop_o_col_div=col_div) if drop_o else {}))
     torch.cuda.synchronize()
     sc = float(dx0.float().abs().max())
-    assert float((dx1.float() - dx0.float()).abs().max()) <= 2 ** -7 * sc
-    assert float((ad1.float() - ad0.float()).abs().max()) <= 2 ** -7 * sc / (1 - p)
+    rt = 2 ** -7 if mode != 1 else 2 ** -5                        # (mode 1: the reference rounded dy + add to bf16 first)
+    assert float((dx1.float() - dx0.float()).abs().max()) <= rt * sc
+    assert float((ad1.float() - ad0.float()).abs().max()) <= rt * sc / (1 - p)
     assert float(((ad1 == 0) != (ad0 == 0)).float().mean()) <= 1e-3                       # the same mask
     so = float(out0.float().abs().max())
     assert float((out1.float() - out0.float()).abs().max()) <= 0.03 * so, float((out1.float() - out0.float()).abs().max()) / so
     for a_, b_ in zip(pg0, pg1):
-        assert float((a_ - b_).abs().max()) <= 1e-3 * max(float(a_.abs().max()), 1e-3) + 1e-5
+        assert float((a_ - b_).abs().max()) <= (1e-3 if mode != 1 else 2e-2) * max(float(a_.abs().max()), 1e-3) + 1e-5

@@ -1,10 +1,12 @@
 """Timeline of ONE step out of a rocprofv3 kernel_trace.csv: start offset, duration, queue, kernel, grid -- shows what overlaps what
-and where the GPU idles.  usage: python tools/trace_timeline.py <kernel_trace.csv> <marker kernel substring> <which occurrence>"""
+and where the GPU idles.  usage: python tools/trace_timeline.py <kernel_trace.csv> <marker kernel substring> <which occurrence (negative: from the end)>"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marker, occ = sys.argv[2], int(sys.argv[3])
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+if occ < 0:
+    occ += len(idx) - 1                     # negative: counted from the last complete step
 a, b = idx[occ], idx[occ + 1]
 
 
