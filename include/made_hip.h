@@ -182,7 +182,8 @@ enum MadeLinearVariant {
     MADE_LINEAR_GLDS3 = 5,          /* linear_glds_kernel<3, ., 128>: at most one workgroup per CU, three LDS stages */
     MADE_LINEAR_GLDS64 = 6,         /* linear_glds_kernel<1, ., 64>: 64 x 128 tiles */
     MADE_LINEAR_GLDS128 = 7,        /* linear_glds_kernel<1, ., 128>: 128 x 128 tiles */
-    MADE_LINEAR_RING128 = 8         /* linear_ring_kernel<128, 128>: two-stage LDS-DMA ring, one barrier per slab, two workgroups per CU */
+    MADE_LINEAR_RING128 = 8,        /* linear_ring_kernel<128, 128>: two-stage LDS-DMA ring, one barrier per slab, two workgroups per CU */
+    MADE_LINEAR_TINY16 = 9          /* linear_t16_kernel: at most 64 rows, 16 x 16 tiles (a third of the bytes per workgroup), 128 <= K <= 1024 */
 };
 int made_linear_variant(const MadeLinearArgs* args);
 
@@ -319,10 +320,6 @@ typedef struct MadeWideAttnArgs {
     MadeDropout drop;          /* dropout on the attention weights, element index ((b*NQ1 + i1)*NQ2 + i2)*L + key */
     float*  sum_out;           /* [B, NQ1*NQ2] f32 or NULL: sum of the dropped weights of each row (1 without dropout) */
     float*  lse_out;           /* [B, NQ1*NQ2] f32 or NULL: log-sum-exp of the scaled scores of each row (saved for made_attention_wide_bwd) */
-    uint32_t* tickets;         /* n_split > 1: NULL = a second launch merges the key slices (the default: faster); else [B * query tiles]
-                                  words, zero before the first call, and the workgroup that finishes an (entry, query tile) last merges
-                                  its slices in this launch (in slice order: deterministic) and leaves the word at zero -- measured
-                                  15-35 us SLOWER per launch on MI355X (the agent-scope fences write back / invalidate the XCD's L2) */
 } MadeWideAttnArgs;
 
 int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
@@ -337,8 +334,7 @@ int made_attention_wide(const MadeWideAttnArgs* args, void* stream);
  * extra_q = gradient of the sum of row q's dropped weights (the value bias enters the forward as ssum_q b_v): `extra` [B, NQ] f32, or,
  * when `extra` is NULL and `dattc` is given, reduced here as <dattc[b, q*hd .. q*hd+hd), vbias[q*hd ..)> (one head per query row).
  * O = the forward's output rows, lse / ssum = its lse_out / sum_out.  Keys may be split over workgroups (n_split, part_dq
- * [B, n_split, NQ, D] f32); the slices' dQ are summed in slice order by a small second launch, or -- tickets [B] zeroed words, left
- * at zero -- inside the launch by the workgroup that finishes a sample last (measured slower on MI355X).  NQ <= 8, D in {256, 512}. */
+ * [B, n_split, NQ, D] f32); the slices' dQ are summed in slice order by a small second launch.  NQ <= 8, D in {256, 512}. */
 typedef struct MadeWideAttnBwdArgs {
     const void *Q, *dO, *O, *K, *V;
     const float* key_mask;                 /* [B, L] or NULL */
@@ -350,7 +346,7 @@ typedef struct MadeWideAttnBwdArgs {
     int64_t B, NQ, L, D;
     int64_t q_bs, ld_q, do_bs, ld_do, o_bs, ld_o, k_bs, ldk, v_bs, ldv;
     float scale; int32_t _pad;
-    int64_t n_split; float* part_dq; uint32_t* tickets;
+    int64_t n_split; float* part_dq;
     MadeDropout drop;
 } MadeWideAttnBwdArgs;
 int made_attention_wide_bwd(const MadeWideAttnBwdArgs* args, void* stream);
@@ -373,6 +369,11 @@ int made_tape_free(uint64_t handle);
  * hence every result unchanged): `main_weight` operations of the busiest stream for one of each other stream, round-robin */
 int made_tape_interleave(uint64_t handle, int32_t main_weight);
 int made_tape_count(uint64_t handle, int64_t* kernels, int64_t* waits, int64_t* others);
+int made_tape_replay_range(uint64_t handle, int64_t first, int64_t count);   /* operations [first, first + count) only, in the tape's issue order:
+                                                                               one phase of a step on its own (measurements) */
+int made_tape_op(uint64_t handle, int64_t index, int32_t* kind, uint64_t* function, uint64_t* stream, uint32_t* grid3);
+                                                              /* what operation `index` is: kind 0 = kernel launch (function = its host-side
+                                                                 address, grid3 = workgroups per axis), other kinds: events, fills, copies */
 int made_stream_wait(void* src_stream, void* dst_stream);            /* dst waits for all work queued on src so far */
 int made_tape_event(int32_t op_kind, int32_t slot, void* stream);    /* recording only, executes nothing: 0 = "record event `slot` on
                                                                          stream", 1 = "stream waits for event `slot`" -- mirrors the
@@ -595,6 +596,8 @@ typedef struct MadeGemmTNGroup {
     const int32_t* row_index; const int32_t* n_rows;
     MadeGemmTNProblem p[MADE_GEMM_TN_MAX_GROUP];
     int32_t tile_end[MADE_GEMM_TN_MAX_GROUP];
+    int32_t tile_size; int32_t _pad;     /* 0 / 128: 128 x 128 output tiles (four waves, two workgroups per CU); 256: 256 x 256 tiles (eight waves, one
+                                            workgroup per CU, N and K multiples of 256): twice the flops per operand byte, a quarter of the atomics */
 } MadeGemmTNGroup;
 int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream);
 /* out[g] = 1 if any of mask[32g .. 32g+31] is nonzero else 0 (computed once per batch, shared by every weight-gradient product) */

@@ -115,14 +115,14 @@ class MadeWideAttnArgs(C.Structure):
                 ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("o_s1", i64), ("o_s2", i64),
                 ("scale", f32), ("_pad", i32),
                 ("n_split", i64), ("part_o", vp), ("part_ml", vp), ("drop", MadeDropout), ("sum_out", vp),
-                ("lse_out", vp), ("tickets", vp)]
+                ("lse_out", vp)]
 
 
 class MadeWideAttnBwdArgs(C.Structure):
     _fields_ = ([(k, vp) for k in ("Q", "dO", "O", "K", "V", "key_mask", "lse", "ssum", "extra", "dattc")] + [("ld_dattc", i64), ("vbias", vp), ("hd", i64),
                 ("Pd", vp), ("dS", vp), ("p_bs", i64), ("ld_p", i64), ("dQ", vp), ("dq_bs", i64), ("ld_dq", i64)] +
                 [(k, i64) for k in ("B", "NQ", "L", "D", "q_bs", "ld_q", "do_bs", "ld_do", "o_bs", "ld_o", "k_bs", "ldk", "v_bs", "ldv")] +
-                [("scale", f32), ("_pad", i32), ("n_split", i64), ("part_dq", vp), ("tickets", vp), ("drop", MadeDropout)])
+                [("scale", f32), ("_pad", i32), ("n_split", i64), ("part_dq", vp), ("drop", MadeDropout)])
 
 
 class MadeGemmTNArgs(C.Structure):
@@ -142,7 +142,7 @@ class MadeGemmTNProblem(C.Structure):
 
 class MadeGemmTNGroup(C.Structure):
     _fields_ = [("n_problems", i32), ("alpha", f32), ("M", i64), ("split_m", i64), ("row_index", vp), ("n_rows", vp),
-                ("p", MadeGemmTNProblem * 8), ("tile_end", i32 * 8)]
+                ("p", MadeGemmTNProblem * 8), ("tile_end", i32 * 8), ("tile_size", i32), ("_pad", i32)]
 
 
 class MadeAdamGroup(C.Structure):
@@ -169,6 +169,8 @@ SIGNATURES = {
     "made_tape_free": (C.c_int, [C.c_uint64]),
     "made_tape_interleave": (C.c_int, [C.c_uint64, i32]),
     "made_tape_count": (C.c_int, [C.c_uint64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "made_tape_replay_range": (C.c_int, [C.c_uint64, i64, i64]),
+    "made_tape_op": (C.c_int, [C.c_uint64, i64, C.POINTER(i32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "made_stream_wait": (C.c_int, [vp, vp]),
     "made_tape_event": (C.c_int, [i32, i32, vp]),
     "made_memset_async": (C.c_int, [vp, i32, i64, vp]),

@@ -242,12 +242,39 @@ extern "C" int made_tape_interleave(uint64_t handle, int32_t main_weight) {
     return MADE_OK;
 }
 
+extern "C" int made_tape_op(uint64_t handle, int64_t index, int32_t* kind, uint64_t* function, uint64_t* stream, uint32_t* grid3) {
+    Tape* t = (Tape*)(uintptr_t)handle;
+    MADE_REQUIRE(t != nullptr && index >= 0 && (size_t)index < t->ops.size(), "made_tape_op: bad tape or index");
+    const TapeOp& op = t->ops[(size_t)index];
+    if (kind) *kind = (int32_t)op.kind;
+    if (function) *function = (uint64_t)(uintptr_t)op.fn;
+    if (stream) *stream = (uint64_t)(uintptr_t)op.st;
+    if (grid3) { grid3[0] = op.grid.x; grid3[1] = op.grid.y; grid3[2] = op.grid.z; }
+    return MADE_OK;
+}
+
+static int tape_replay_range(Tape* t, size_t first, size_t count);
+
+extern "C" int made_tape_replay_range(uint64_t handle, int64_t first, int64_t count) {
+    Tape* t = (Tape*)(uintptr_t)handle;
+    MADE_REQUIRE(t != nullptr, "made_tape_replay_range: null tape");
+    MADE_REQUIRE(g_made_tape == nullptr, "made_tape_replay_range: this thread is recording");
+    MADE_REQUIRE(first >= 0 && count >= 0 && (size_t)(first + count) <= t->ops.size(), "made_tape_replay_range: [%lld, +%lld) outside the tape's %zu operations",
+                 (long long)first, (long long)count, t->ops.size());
+    return tape_replay_range(t, (size_t)first, (size_t)count);
+}
+
 extern "C" int made_tape_replay(uint64_t handle) {
     Tape* t = (Tape*)(uintptr_t)handle;
     MADE_REQUIRE(t != nullptr, "made_tape_replay: null tape");
     MADE_REQUIRE(g_made_tape == nullptr, "made_tape_replay: this thread is recording");
+    return tape_replay_range(t, 0, t->ops.size());
+}
+
+static int tape_replay_range(Tape* t, size_t first, size_t count) {
     unsigned char* blob = t->blob.data();
-    for (auto& op : t->ops) {
+    for (size_t oi = first; oi < first + count; ++oi) {
+        TapeOp& op = t->ops[oi];
         hipError_t e = hipSuccess;
         switch (op.kind) {
             case TAPE_KERNEL: {

@@ -380,125 +380,9 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                 a.part_ml[prow * 4] = m_run; a.part_ml[prow * 4 + 1] = l_tot; a.part_ml[prow * 4 + 2] = a.drop.p > 0.f ? sd_tot : l_tot;
             }
         }
-        // the slices are merged by made_attention_wide_combine (a second launch) -- always in the one-stage variants that serve many
-        // query tiles per entry: the merge code below would cost them a wave of occupancy for registers they never use
-        if (!DMA || a.tickets == nullptr) return;
-        // ---- merge in the same launch: every workgroup of this (entry, query tile) signs in after releasing its slice; the one that
-        // signs in last fetches all slices past its XCD's caches and merges them in slice order (so the result does not depend on
-        // which workgroup that was).  The ticket word is left at zero for the next launch.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        int* flag = (int*)lds_s;
-        const int64_t qtile = batch_fast ? blockIdx.y : blockIdx.x;
-        const int64_t n_qt = (nq_total + WQB - 1) / WQB;
-        if (tid == 0) {
-            uint32_t* tk = a.tickets + b * n_qt + qtile;
-            const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = t == (uint32_t)(nsplit - 1);
-            if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            flag[0] = last;
-        }
-        __syncthreads();
-        if (flag[0] == 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        // one wave per query row.  Few slices (the usual case): four rows of a wave are merged together with every slice's loads
-        // requested before the first use -- a row at a time the merge of a 64-query tile is 16 dependent round trips per wave
-        const int64_t q_lo = qtile * WQB;
-        const int64_t q_hi = q_lo + WQB < nq_total ? q_lo + WQB : nq_total;
-        auto merge_store = [&](int64_t q, const f32x4 (&acc)[2], float Lsum, float Dsum, float Muse) __attribute__((always_inline)) {
-            const float minv = 1.f / Lsum;
-            if (lane == 0) {
-                if (a.sum_out) a.sum_out[b * nq_total + q] = Dsum * minv;      // sum of the dropped weights (1 without dropout)
-                if (a.lse_out) a.lse_out[b * nq_total + q] = Muse + logf(Lsum);
-            }
-            const int64_t ob = b * a.o_bs + (q / a.NQ2) * a.o_s1 + (q % a.NQ2) * a.o_s2;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = (i * 64 + lane) * 4;
-                if (c < D) {
-                    if (a.o_dtype == MADE_F32) {
-                        f32x4 pk; pk[0] = acc[i][0] * minv; pk[1] = acc[i][1] * minv; pk[2] = acc[i][2] * minv; pk[3] = acc[i][3] * minv;
-                        *(f32x4*)((float*)a.O + ob + c) = pk;
-                    } else {
-                        bf16x4 pk; pk[0] = (bf16_t)(acc[i][0] * minv); pk[1] = (bf16_t)(acc[i][1] * minv);
-                        pk[2] = (bf16_t)(acc[i][2] * minv); pk[3] = (bf16_t)(acc[i][3] * minv);
-                        *(bf16x4*)((bf16_t*)a.O + ob + c) = pk;
-                    }
-                }
-            }
-        };
-        if (nsplit <= 4) {
-            constexpr int RG = 4, SG = 4;
-            for (int64_t qg = q_lo + wave * RG; qg < q_hi; qg += 4 * RG) {
-                f32x4 t[RG][SG][2];
-                float ml[RG][SG][3];
-#pragma unroll
-                for (int rr = 0; rr < RG; ++rr) {
-                    const int64_t q = qg + rr < q_hi ? qg + rr : q_hi - 1;
-#pragma unroll
-                    for (int sp = 0; sp < SG; ++sp) {
-                        const int64_t pr = (b * nsplit + (sp < nsplit ? sp : nsplit - 1)) * nq_total + q;
-                        ml[rr][sp][0] = a.part_ml[pr * 4]; ml[rr][sp][1] = a.part_ml[pr * 4 + 1]; ml[rr][sp][2] = a.part_ml[pr * 4 + 2];
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const int c = (i * 64 + lane) * 4;
-                            t[rr][sp][i] = *(const f32x4*)(a.part_o + pr * D + (c < D ? c : 0));
-                        }
-                    }
-                }
-#pragma unroll
-                for (int rr = 0; rr < RG; ++rr) {
-                    if (qg + rr >= q_hi) break;
-                    float M = -INFINITY;
-#pragma unroll
-                    for (int sp = 0; sp < SG; ++sp) if (sp < nsplit) M = fmaxf(M, ml[rr][sp][0]);
-                    const float Muse = (M == -INFINITY) ? 0.f : M;
-                    float Lsum = 0.f, Dsum = 0.f;
-                    f32x4 acc[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
-#pragma unroll
-                    for (int sp = 0; sp < SG; ++sp) {
-                        if (sp < nsplit) {                              // (slice order: the sums do not depend on who merges)
-                            const float w = expf(ml[rr][sp][0] - Muse);
-                            Lsum += ml[rr][sp][1] * w;
-                            Dsum += ml[rr][sp][2] * w;
-#pragma unroll
-                            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[i][j] += t[rr][sp][i][j] * w;
-                        }
-                    }
-                    merge_store(qg + rr, acc, Lsum, Dsum, Muse);
-                }
-            }
-            return;
-        }
-        for (int64_t q = q_lo + wave; q < q_hi; q += 4) {
-            float M = -INFINITY;
-            for (int64_t sp = 0; sp < nsplit; ++sp) M = fmaxf(M, a.part_ml[((b * nsplit + sp) * nq_total + q) * 4]);
-            const float Muse = (M == -INFINITY) ? 0.f : M;
-            float Lsum = 0.f, Dsum = 0.f;
-            f32x4 acc[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
-            for (int64_t sp = 0; sp < nsplit; ++sp) {
-                const int64_t pr = (b * nsplit + sp) * nq_total + q;
-                const float w = expf(a.part_ml[pr * 4] - Muse);
-                Lsum += a.part_ml[pr * 4 + 1] * w;
-                Dsum += a.part_ml[pr * 4 + 2] * w;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int c = (i * 64 + lane) * 4;
-                    if (c < D) {
-                        const f32x4 t = *(const f32x4*)(a.part_o + pr * D + c);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] += t[j] * w;
-                    }
-                }
-            }
-            merge_store(q, acc, Lsum, Dsum, Muse);
-        }
+        // the slices are merged by made_attention_wide_combine, a second launch (a merge inside the launch behind a ticket -- the last
+        // workgroup of an entry to sign in merges -- was built and measured in round 3: 15-35 us SLOWER per call, the agent-scope
+        // release / acquire pair costs more than the kernel boundary; profiles/r03_micro_merge_in_launch_vs_second_launch.txt)
         return;
     }
     const int64_t obase = b * a.o_bs + (my_q / a.NQ2) * a.o_s1 + (my_q % a.NQ2) * a.o_s2 + sl * DS;
@@ -632,7 +516,7 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(batch_fast ? a.B : qtiles), (unsigned)(batch_fast ? qtiles : a.B), (unsigned)nsplit), block(NTHREADS);
     hipLaunchKernelGGL((attention_wide_kernel<TC, D, DB, NSL>), grid, block, lds_bytes, st, a);
     int rc = made_check_launch("made_attention_wide");
-    if (rc != MADE_OK || nsplit == 1 || (DMA && a.tickets != nullptr)) return rc;      // (tickets: merged inside the launch)
+    if (rc != MADE_OK || nsplit == 1) return rc;
     const int64_t rows = a.B * nq;
     hipLaunchKernelGGL(attention_wide_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTHREADS), 0, st, a);
     return made_check_launch("made_attention_wide(combine)");

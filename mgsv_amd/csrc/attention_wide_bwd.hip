@@ -17,7 +17,8 @@
 //     transposing reads want (its row reads are then 2-way bank conflicted, which this latency-bound kernel does not notice),
 //     V the 16-byte-chunk swizzle of the row reads;
 //   * the key slices' partial dQ' meet in an f32 workspace and a small second launch sums them in slice order (summing them inside
-//     the launch behind a ticket -- `tickets` -- works and is slower: the fences cost more than the launch).
+//     the launch behind a ticket was built and measured in round 3: +15-20 us per launch, the agent-scope fences cost more than the
+//     kernel boundary; profiles/r03_micro_merge_in_launch_vs_second_launch.txt).
 #include "common.h"
 
 namespace {
@@ -292,42 +293,7 @@ __global__ __launch_bounds__(NT) void attention_wide_bwd_kernel(const MadeWideAt
                 *(f32x4*)(po + d * 32 + 8 * g4 + 4 * hh) = pk;
             }
     }
-    if (a.tickets == nullptr) return;                               // the slices are summed by wide_bwd_merge_kernel (a second launch)
-    // (merged inside the launch: measured SLOWER on MI355X -- the agent-scope release / acquire pair around the ticket writes back
-    //  and invalidates the XCD's L2 under the other workgroups' feet, +15-20 us per launch; kept for the record, off by default)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    int* flag = (int*)lds_x;
-    if (tid == 0) {
-        uint32_t* tk = a.tickets + b;
-        const uint32_t tkt = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = tkt == (uint32_t)(nsplit - 1);
-        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = last;
-    }
-    __syncthreads();
-    if (flag[0] == 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    constexpr int PER = D / 64;                                     // columns per lane: 8 (D = 512) or 4 (D = 256)
-    for (int q = wave; q < NQ; q += 4) {
-        float acc[PER];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) acc[j] = 0.f;
-        for (int64_t sp = 0; sp < nsplit; ++sp) {
-            const float* pp = a.part_dq + ((b * nsplit + sp) * NQ + q) * D + lane * PER;
-#pragma unroll
-            for (int j = 0; j < PER; j += 4) {
-                const f32x4 t4 = *(const f32x4*)(pp + j);
-                acc[j] += t4[0]; acc[j + 1] += t4[1]; acc[j + 2] += t4[2]; acc[j + 3] += t4[3];
-            }
-        }
-        bf16_t* dq = (bf16_t*)a.dQ + b * a.dq_bs + (int64_t)q * a.ld_dq + lane * PER;
-#pragma unroll
-        for (int j = 0; j < PER; j += 4) {
-            bf16x4 pk; pk[0] = (bf16_t)acc[j]; pk[1] = (bf16_t)acc[j + 1]; pk[2] = (bf16_t)acc[j + 2]; pk[3] = (bf16_t)acc[j + 3];
-            *(bf16x4*)(dq + j) = pk;
-        }
-    }
+    // (the slices are summed by wide_bwd_merge_kernel, a second launch)
 }
 
 // dQ[b, q, :] = sum over the key slices of part_dq[b, slice, q, :] (slice order), one wave per row
@@ -379,7 +345,7 @@ int launch_wide_bwd(const MadeWideAttnBwdArgs& a, hipStream_t st) {
     const int64_t nsplit = a.n_split > 1 ? a.n_split : 1;
     hipLaunchKernelGGL((attention_wide_bwd_kernel<D>), dim3(1, (unsigned)a.B, (unsigned)nsplit), dim3(NT), lds_bytes, st, a);
     int rc = made_check_launch("made_attention_wide_bwd");
-    if (rc != MADE_OK || nsplit == 1 || a.tickets != nullptr) return rc;
+    if (rc != MADE_OK || nsplit == 1) return rc;
     hipLaunchKernelGGL(wide_bwd_merge_kernel, dim3((unsigned)((a.B * a.NQ + 3) / 4)), dim3(NT), 0, st, a);
     return made_check_launch("made_attention_wide_bwd(merge)");
 }

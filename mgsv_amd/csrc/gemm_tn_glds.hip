@@ -248,6 +248,198 @@ __global__ __launch_bounds__(GT_NT, 2) void gemm_tn_glds_grouped_kernel(const Ma
     gemm_tn_glds_body(p, sh, lds);
 }
 
+// =================================================================================================
+// 256 x 256 output tiles (round 3).  The 128 x 128 kernel above moves 32 KB of operands per 2.1 MFLOP (65 flop / byte): at the
+// ~50 GB/s a CU takes in through LDS-DMA that is a third of the MFMA rate, and a layer's five products need 16 reduction splits to
+// fill the chip, each adding its whole f32 tile to the gradient with atomics (134 MB per layer).  Here a workgroup of EIGHT waves
+// owns a 256 x 256 tile (a wave: 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers): 64 KB per 8.4 MFLOP (131 flop / byte), a
+// layer's 32 tiles x 8 splits = one workgroup per CU, a quarter of the atomic traffic, and per k-step 12 transposing LDS reads feed 8
+// MFMAs (the LDS read rate stays below the MFMA rate).  Same slab ring, same source-side swizzle, same bias-gradient trick.
+constexpr int T2_BN = 256, T2_BK = 256, T2_BM = 64, T2_NT = 512, T2_NST = 2;
+constexpr int T2_ROW = 512;                               // bytes per LDS row (256 bf16)
+constexpr int T2_HALF = T2_BM * T2_ROW;                   // 32 KB: one operand of one stage
+constexpr int T2_STAGE = 2 * T2_HALF;                     // 64 KB
+constexpr int T2_MAX_ROWS = 4608;                         // row indices a block may hold (72 slabs)
+constexpr int T2_LDS = T2_NST * T2_STAGE + T2_MAX_ROWS * 4;   // 146 KB: one workgroup per CU
+
+__device__ __forceinline__ void t2_wait12(bf16x4 (&f)[12], int n_outstanding_is_12) {
+    if (n_outstanding_is_12)
+        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
+                     "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
+                     "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]));
+}
+
+__device__ __forceinline__ void gemm_tn_256_body(const GtProblem a, const GtShared sh, unsigned char* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 2, wk = wave & 3;                 // 2 x 4 waves: 128 output rows (n) x 64 output columns (k) each
+    const int tiles_k = a.tiles_k;
+    const int64_t split_y = sh.split_y;
+    const int tile_n = a.tile / tiles_k, tile_k = a.tile % tiles_k;
+    const int64_t n0 = (int64_t)tile_n * T2_BN, k0 = (int64_t)tile_k * T2_BK;
+    int64_t Mv = sh.M;
+    if (sh.n_rows) { const int64_t nv = *sh.n_rows; Mv = nv < sh.M ? nv : sh.M; }
+    const int64_t nslab = (Mv + T2_BM - 1) / T2_BM;
+    const int64_t sstep = sh.split_m;
+    const int64_t nloc = nslab > split_y ? (nslab - split_y + sstep - 1) / sstep : 0;   // slabs y, y + split, ...
+    if (nloc == 0) return;
+    const bf16_t* Ag = a.A;
+    const bf16_t* Bg = a.B;
+
+    int* lds_rows = (int*)(lds + T2_NST * T2_STAGE);         // physical rows of every slab this block reduces, resolved once
+    for (int64_t t = tid; t < nloc * T2_BM; t += T2_NT) {
+        const int64_t g = split_y + (t / T2_BM) * sstep;
+        const int64_t m = g * T2_BM + (t % T2_BM);
+        const int64_t ml = m < Mv ? m : Mv - 1;
+        lds_rows[t] = sh.row_index ? sh.row_index[ml] : (int)ml;
+    }
+    __syncthreads();
+
+    // wave w, instruction j (0..3) moves rows 8 w + 2 j + (lane >> 5) of the slab: 32 lanes x 16 B per 512-byte row
+    const int pos = lane & 31;                               // 16-byte slot inside the LDS row
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    auto issue = [&](int64_t i) __attribute__((always_inline)) {
+        unsigned char* st = lds + (i % T2_NST) * T2_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rowl = 8 * wave + 2 * j + (lane >> 5);
+            const int64_t pr = lds_rows[i * T2_BM + rowl];
+            const int chunk = (((pos >> 1) ^ (rowl & 3)) << 1) | (pos & 1);          // source-side swizzle of the 32-byte pairs
+            const int piece = (8 * wave + 2 * j) * T2_ROW;                           // 1 KB destination of this instruction (two rows)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ag + pr * a.lda + n0 + chunk * 8), (lds_ptr_t)(st + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bg + pr * a.ldb + k0 + chunk * 8), (lds_ptr_t)(st + T2_HALF + piece), 16, 0, 0);
+        }
+    };
+
+    // per-lane byte offsets of the transposing reads inside a stage (k-step 0; k-step ks adds ks * 16 rows as an immediate)
+    uint32_t offA[4], offB[2];
+    {
+        const int g = lane >> 4, i16 = lane & 15;
+        const int row = 4 * (g >> 1) + (i16 >> 2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pa = ((wn * 128 + t * 32) >> 4) + (g & 1);
+            offA[t] = (uint32_t)(row * T2_ROW + ((pa ^ (row & 3)) << 5) + 8 * (i16 & 3));
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int pb = ((wk * 64 + t * 32) >> 4) + (g & 1);
+            offB[t] = (uint32_t)(T2_HALF + row * T2_ROW + ((pb ^ (row & 3)) << 5) + 8 * (i16 & 3));
+        }
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};                    // bias gradient = column sums of A, from the A fragments (see the 128 x 128 body)
+    const bool do_colsum = a.colsum != nullptr && tile_k == 0 && wk == 0;
+
+    issue(0);
+    for (int64_t i = 0; i < nloc; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slab i (the only one in flight) has landed
+        asm volatile("s_barrier" ::: "memory");             // every wave's part landed; everyone is done with the other stage
+        if (i + 1 < nloc) issue(i + 1);
+        unsigned char* st = lds + (i % T2_NST) * T2_STAGE;
+        const int64_t g = split_y + i * sstep;
+        const int64_t live = Mv - g * T2_BM;                 // rows of this slab that exist
+        if (live < T2_BM) {
+            // last slab of the reduction: the clamped duplicate rows must not be summed -> zero them in LDS (both operands)
+            const int per_half = (T2_BM - (int)live) * (T2_ROW / 16);
+            for (int idx = tid; idx < per_half * 2; idx += T2_NT) {
+                const int half = idx / per_half, rem = idx % per_half;
+                const int row = (int)live + rem / (T2_ROW / 16), c16 = rem % (T2_ROW / 16);
+                f32x4 z; z[0] = z[1] = z[2] = z[3] = 0.f;
+                *(f32x4*)(st + half * T2_HALF + row * T2_ROW + c16 * 16) = z;
+            }
+            __syncthreads();
+        }
+        const uint32_t sbase = lds_base + (uint32_t)((i % T2_NST) * T2_STAGE);
+        bf16x4 fr[2][12];
+        auto read_step = [&](int buf, auto KS) __attribute__((always_inline)) {
+            constexpr int o = decltype(KS)::value * 16 * T2_ROW;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { fr[buf][2 * t] = gt_tr<o>(sbase + offA[t]); fr[buf][2 * t + 1] = gt_tr<o + 8 * T2_ROW>(sbase + offA[t]); }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { fr[buf][8 + 2 * t] = gt_tr<o>(sbase + offB[t]); fr[buf][8 + 2 * t + 1] = gt_tr<o + 8 * T2_ROW>(sbase + offB[t]); }
+        };
+        auto mul_step = [&](int buf) __attribute__((always_inline)) {
+            bf16x8 af[4], bfr[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = __builtin_shufflevector(fr[buf][2 * t], fr[buf][2 * t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bfr[t] = __builtin_shufflevector(fr[buf][8 + 2 * t], fr[buf][8 + 2 * t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2)
+                    acc[i2][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i2], bfr[j2], acc[i2][j2], 0, 0, 0);
+            if (do_colsum) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) csum[t] += (float)af[t][j];
+            }
+        };
+        read_step(0, std::integral_constant<int, 0>{});
+        read_step(1, std::integral_constant<int, 1>{});
+        t2_wait12(fr[0], 1); mul_step(0);
+        read_step(0, std::integral_constant<int, 2>{});
+        t2_wait12(fr[1], 1); mul_step(1);
+        read_step(1, std::integral_constant<int, 3>{});
+        t2_wait12(fr[0], 1); mul_step(0);
+        t2_wait12(fr[1], 0); mul_step(1);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t k = k0 + wk * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t n = n0 + wn * 128 + i * 32 + acc_row(e, hh);
+                const float v = acc[i][j][e] * a.alpha;
+                float* p = (float*)a.C + n * a.ldc + k;
+                if (a.accumulate) unsafeAtomicAdd(p, v); else *p = v;
+            }
+        }
+    if (do_colsum) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float tot = csum[t] + __shfl_xor(csum[t], 32);                     // the two lane halves hold different reduction rows
+            if (hh == 0) unsafeAtomicAdd(a.colsum + n0 + wn * 128 + t * 32 + r, tot * a.alpha);
+        }
+    }
+}
+
+__global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const MadeGemmTNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tiles = g.tile_end[g.n_problems - 1];
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;     // all tiles of one reduction split on ONE XCD (they read the same rows)
+    const int64_t split_y = xcd + 8 * (int64_t)(jx / tiles);
+    if (split_y >= g.split_m) return;
+    int tile = jx % tiles, pi = 0;
+#pragma unroll
+    for (int i = 0; i < MADE_GEMM_TN_MAX_GROUP - 1; ++i)
+        if (i + 1 < g.n_problems && tile >= g.tile_end[i]) pi = i + 1;
+    if (pi > 0) tile -= g.tile_end[pi - 1];
+    GtProblem p;
+    p.A = (const bf16_t*)g.p[pi].A; p.B = (const bf16_t*)g.p[pi].B; p.C = g.p[pi].C; p.colsum = g.p[pi].colsum;
+    p.lda = g.p[pi].lda; p.ldb = g.p[pi].ldb; p.ldc = g.p[pi].ldc; p.tiles_k = (int)(g.p[pi].K / T2_BK); p.tile = tile;
+    p.c_dtype = MADE_F32; p.accumulate = 1; p.alpha = g.alpha;
+    GtShared sh;
+    sh.M = g.M; sh.split_m = g.split_m; sh.split_y = split_y; sh.row_index = g.row_index; sh.n_rows = g.n_rows;
+    gemm_tn_256_body(p, sh, lds);
+}
+
 }  // namespace
 
 extern "C" int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream) {
@@ -257,6 +449,27 @@ extern "C" int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream) 
     MADE_REQUIRE(g.M >= 0 && g.split_m >= 1, "made_gemm_tn_grouped: bad M / split_m");
     MADE_REQUIRE((g.row_index == nullptr) == (g.n_rows == nullptr), "made_gemm_tn_grouped: row_index and n_rows come together");
     if (g.M == 0) return MADE_OK;
+    if (g.tile_size == 256) {                                 // 256 x 256 output tiles, eight waves, one workgroup per CU
+        int tiles2 = 0;
+        for (int i = 0; i < g.n_problems; ++i) {
+            const auto& p = g.p[i];
+            MADE_REQUIRE(p.A && p.B && p.C, "made_gemm_tn_grouped: problem %d has a null tensor", i);
+            MADE_UNSUPPORTED(p.N > 0 && p.K > 0 && p.N % T2_BN == 0 && p.K % T2_BK == 0, "made_gemm_tn_grouped(256): problem %d: N=%lld, K=%lld must be multiples of 256",
+                             i, (long long)p.N, (long long)p.K);
+            MADE_UNSUPPORTED(p.lda % 8 == 0 && p.ldb % 8 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
+                             "made_gemm_tn_grouped: problem %d: operand rows must be 16-byte aligned", i);
+            tiles2 += (int)((p.N / T2_BN) * (p.K / T2_BK));
+            g.tile_end[i] = tiles2;
+        }
+        MADE_UNSUPPORTED(((g.M + T2_BM - 1) / T2_BM + g.split_m - 1) / g.split_m * T2_BM <= T2_MAX_ROWS,
+                         "made_gemm_tn_grouped(256): split_m=%lld leaves more than %d rows per workgroup", (long long)g.split_m, T2_MAX_ROWS);
+        dim3 grid2((unsigned)(8 * (int64_t)tiles2 * ((g.split_m + 7) / 8)), 1, 1);
+        static const bool once2 = hipFuncSetAttribute((const void*)gemm_tn_256_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS) == hipSuccess;
+        (void)once2;
+        hipLaunchKernelGGL(gemm_tn_256_grouped_kernel, grid2, dim3(T2_NT), T2_LDS, (hipStream_t)stream, g);
+        return made_check_launch("made_gemm_tn_grouped(256)");
+    }
+    MADE_REQUIRE(g.tile_size == 0 || g.tile_size == 128, "made_gemm_tn_grouped: tile_size=%d (0 / 128 or 256)", g.tile_size);
     int tiles = 0;
     for (int i = 0; i < g.n_problems; ++i) {
         const auto& p = g.p[i];

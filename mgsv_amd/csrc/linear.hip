@@ -141,7 +141,9 @@ __device__ __forceinline__ void store8(void* out, int odt, int64_t off, const fl
             *(bf16x8*)((bf16_t*)out + off) = t;
         }
     } else {
-        for (int j = 0; j < nvalid; ++j) store_from_f32(out, odt, off + j, v[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)                          // (a run-time trip count would index v[] dynamically: scratch memory)
+            if (j < nvalid) store_from_f32(out, odt, off + j, v[j]);
     }
 }
 
@@ -183,10 +185,17 @@ __device__ __forceinline__ float act_grad(float g, int gate) {
 //   z = acc + bias  [-> Zout]   v = act(z)   v *= act'(G) * gate_scale   v = dropout(v)   v += R   row mask
 // rpre / gpre / om: residual, gate tensor and output row mask of these 8 outputs when the caller loaded them ahead of its K loop
 // (the 64-row kernels are one dependent memory round trip after another; whatever the epilogue needs is requested up front)
+// (by value: a pointer that is selected at run time -- `have ? &x : nullptr` -- pins x in scratch memory)
+struct EpiPre {
+    bool has_r = false, has_g = false, has_om = false, has_seed = false;
+    bf16x8 r, g;
+    float om = 1.f;
+    uint64_t seed = 0;
+};
+
 template <bool TRAIN>
 __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n, int nvalid, float* v, const float* bv,
-                                          int rmod, bool r_vec, const bf16x8* rpre = nullptr, const bf16x8* gpre = nullptr,
-                                          const float* om = nullptr) {
+                                          int rmod, bool r_vec, const EpiPre pre = EpiPre()) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += bv[j];
     if (TRAIN && a.Zout) {
@@ -208,9 +217,9 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
     }
     if (TRAIN && a.gate != MADE_GATE_NONE) {
         float g[8];
-        if (gpre) {
+        if (pre.has_g) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = (float)(*gpre)[j];
+            for (int j = 0; j < 8; ++j) g[j] = (float)pre.g[j];
         } else {
             load8(a.G, a.g_dtype, (int64_t)m * a.ldg + n, g, nvalid, (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0));
         }
@@ -220,23 +229,24 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
     if (TRAIN && a.drop.p > 0.f) {
         const uint32_t thr = made_drop_threshold(a.drop.p);
         const float sc = 1.f / (1.f - a.drop.p);
+        const uint64_t seed = pre.has_seed ? pre.seed : made_drop_seed(a.drop);   // (a device-side seed is a memory round trip: the 16-row kernel reads it up front)
         if (a.drop_col_div > 1) {                            // one draw per group of columns (per attention head): index row * drop_ld + col / div
             const uint64_t rb = (uint64_t)m * (uint64_t)a.drop_ld;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, rb + (uint64_t)((n + j) / a.drop_col_div)) >> 8) >= thr ? v[j] * sc : 0.f;
+                v[j] = (made_rng_mix(seed, a.drop.site, rb + (uint64_t)((n + j) / a.drop_col_div)) >> 8) >= thr ? v[j] * sc : 0.f;
         } else {
             const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
-            const uint32_t kb = made_keep_bits<8>(made_drop_seed(a.drop), a.drop.site, thr, base);
+            const uint32_t kb = made_keep_bits<8>(seed, a.drop.site, thr, base);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * sc : 0.f;
         }
     }
     if (a.R) {
         float rv[8];
-        if (rpre) {
+        if (pre.has_r) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rv[j] = (float)(*rpre)[j];
+            for (int j = 0; j < 8; ++j) rv[j] = (float)pre.r[j];
         } else {
             const int rr = rmod > 0 ? m % rmod : m;
             load8(a.R, a.r_dtype, (int64_t)rr * a.ldr + n, rv, nvalid, r_vec);
@@ -244,7 +254,7 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += rv[j];
     }
-    if (om ? (*om == 0.f) : (a.out_row_mask && a.out_row_mask[m] == 0.f)) {
+    if (pre.has_om ? (pre.om == 0.f) : (a.out_row_mask && a.out_row_mask[m] == 0.f)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
@@ -1329,7 +1339,9 @@ __device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const 
 #pragma unroll
         for (int j = 0; j < 8; ++j) e_bv[j] *= e_bsc;
     }
-    epilogue8<TRAIN>(a, m, n, nvalid, v, e_bv, rmod, r_vec, e_rpref ? &e_r : nullptr, e_gpref ? &e_g : nullptr, &e_om);
+    EpiPre pre;
+    pre.has_r = e_rpref; pre.r = e_r; pre.has_g = e_gpref; pre.g = e_g; pre.has_om = true; pre.om = e_om;
+    epilogue8<TRAIN>(a, m, n, nvalid, v, e_bv, rmod, r_vec, pre);
     int64_t orow;
     if (rpb > 0) {
         const int b = m / rpb, t = m - b * rpb;
@@ -1344,6 +1356,137 @@ template <bool TRAIN>
 __global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearArgs a) {
     __shared__ __attribute__((aligned(16))) float Ct[4 * T_BM * T_CT_LD];
     linear_tiny_body<TRAIN>(a, blockIdx.x, blockIdx.z, Ct);
+}
+
+// =================================================================================================
+// Tiny-M problems, third form (round 3): 16-row x 16-column output tiles.  What a 64-row stage of the decoder's chain costs is
+// the bytes ONE workgroup pulls through its CU's memory queue -- measured (tools/tiny_model_probe.py, chains of dependent launches):
+// t = 3.4 us + bytes / ~33 GB/s, i.e. 6.2 us for the 64 x 32 tiles above at K = 512 (64 KB of rows + 32 KB of weights per
+// workgroup) -- not the arithmetic.  Here a workgroup reads 16 rows + 16 weight rows (32 KB at K = 512) and there are eight times as
+// many of them; v_mfma_f32_16x16x32_bf16, the four waves take every fourth 32-deep K step, all of a lane's fragments (16 bytes of
+// one row each, up to 16 loads) are requested before the first wait, the four partial tiles meet in LDS and 32 lanes finish one row
+// x 8 columns each with epilogue8 (the element order of the dropout draws etc. does not depend on the tiling).
+// Workgroups b and b + 8 share an XCD (observed dispatch order; speed only): the row tiles of one weight slice are put there.
+constexpr int U_BM = 16, U_BN = 16, U_CT_LD = U_BN + 4;
+
+template <bool TRAIN, int SPW>                             // SPW: 32-deep K steps per wave (K <= 128 * SPW)
+__global__ __launch_bounds__(NTHREADS) void linear_t16_kernel(const MadeLinearArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ct[4 * U_BM * U_CT_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+    const int n_tiles = (N + U_BN - 1) / U_BN, m_tiles = (M + U_BM - 1) / U_BM;
+    int tile_m, tile_n;
+    {
+        const int bx = blockIdx.x;
+        if ((n_tiles & 7) == 0) { const int j = bx >> 3; tile_m = j % m_tiles; tile_n = (j / m_tiles) * 8 + (bx & 7); }
+        else { tile_m = bx % m_tiles; tile_n = bx / m_tiles; }
+    }
+    const int m0 = tile_m * U_BM, n0 = tile_n * U_BN;
+    const int64_t z = blockIdx.z;
+    int Mv = M;
+    if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
+    if (m0 >= Mv) return;
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+        if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
+    const MadeLinearSeg seg = a.seg[si];
+    const bool repl = seg.use_a2 && a.A2 && a.a2_replace;
+    const bf16_t* Abase = (repl ? (const bf16_t*)a.A2 : (const bf16_t*)a.A) + z * a.a_z_stride;
+    const int64_t lda = repl ? a.lda2 : a.lda;
+    const int steps = K / 32;                              // (K is a multiple of 32 on this path)
+    int gm = m0 + r16; gm = gm < Mv ? gm : Mv - 1;         // rows past the edge: a valid row, never stored
+    if (a.row_index) gm = a.row_index[gm];
+    int gn = n0 + r16; gn = gn < N ? gn : N - 1;
+    const bf16_t* pa = Abase + (int64_t)gm * lda + kq * 8;
+    const bf16_t* pw = (const bf16_t*)a.W + z * a.w_z_stride + (int64_t)gn * a.ldw + kq * 8;
+    bf16x8 fa[SPW], fw[SPW];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+        int s = wave + 4 * i; s = s < steps ? s : steps - 1;      // past the end: a harmless re-read, never multiplied
+        fw[i] = *(const bf16x8*)(pw + s * 32);
+        fa[i] = *(const bf16x8*)(pa + s * 32);
+    }
+    // the epilogue's inputs (lanes 0..31 of wave 0 finish row lane / 2, 8 columns each), requested with the fragments
+    const int e_cc = tid & 1, e_row = (tid >> 1) & 15;
+    const int e_n = n0 + e_cc * 8;
+    int e_nvalid = N - e_n; e_nvalid = e_nvalid > 8 ? 8 : e_nvalid;
+    const int e_ml = m0 + e_row;
+    int e_m = e_ml < Mv ? e_ml : Mv - 1;
+    if (a.row_index) e_m = a.row_index[e_m];
+    float e_bv[8];
+    load_bias8(a.bias_row_scale ? a.bias + z * a.bias_z_stride : a.bias, e_n, N, e_bv);
+    float e_bsc = 1.f;
+    if (a.bias_row_scale) e_bsc = a.bias_row_scale[(int64_t)e_m * a.batch + z];
+    const int e_rmod = (int)a.r_row_mod;
+    const bool e_rpref = a.R && a.r_dtype == MADE_BF16 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0) && e_nvalid == 8;
+    const bool e_gpref = TRAIN && a.gate != MADE_GATE_NONE && a.g_dtype == MADE_BF16 && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0) && e_nvalid == 8;
+    bf16x8 e_r, e_g;
+    if (e_rpref) e_r = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)(e_rmod > 0 ? e_m % e_rmod : e_m) * a.ldr + e_n);
+    if constexpr (TRAIN) { if (e_gpref) e_g = *(const bf16x8*)((const bf16_t*)a.G + (int64_t)e_m * a.ldg + e_n); }
+    float e_om = 1.f;
+    if (a.out_row_mask) e_om = a.out_row_mask[e_m];
+    uint64_t e_seed = 0;
+    if constexpr (TRAIN) { if (a.drop.p > 0.f) e_seed = made_drop_seed(a.drop); }
+
+    f32x4 acc;
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPW; ++i)
+        if (wave + 4 * i < steps) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fw[i], acc, 0, 0, 0);
+    float* mine = Ct + wave * (U_BM * U_CT_LD);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mine[(kq * 4 + e) * U_CT_LD + r16] = acc[e];
+    __syncthreads();
+    if (tid >= 32) return;
+    const int n = e_n, nvalid = e_nvalid;
+    if (nvalid <= 0 || e_ml >= Mv) return;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float* cp = Ct + w * (U_BM * U_CT_LD) + e_row * U_CT_LD + e_cc * 8;
+        const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+        v[0] += c0[0]; v[1] += c0[1]; v[2] += c0[2]; v[3] += c0[3];
+        v[4] += c1[0]; v[5] += c1[1]; v[6] += c1[2]; v[7] += c1[3];
+    }
+    unsigned char* outp = (unsigned char*)seg.out;
+    const int64_t out_z = z * seg.out_z_stride;
+    const int rpb = (int)seg.rows_per_batch, rmod = (int)a.r_row_mod;
+    const int colb = (int)seg.col_begin;
+    const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
+                         (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
+    const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+    const int m = e_m;
+    if (a.bias_row_scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e_bv[j] *= e_bsc;
+    }
+    EpiPre pre;
+    pre.has_r = e_rpref; pre.r = e_r; pre.has_g = e_gpref; pre.g = e_g; pre.has_om = true; pre.om = e_om;
+    pre.has_seed = TRAIN && a.drop.p > 0.f; pre.seed = e_seed;
+    epilogue8<TRAIN>(a, m, n, nvalid, v, e_bv, rmod, r_vec, pre);
+    int64_t orow;
+    if (rpb > 0) {
+        const int b = m / rpb, t = m - b * rpb;
+        orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo;
+    } else {
+        orow = (int64_t)m * seg.ldo;
+    }
+    store8(outp, seg.out_dtype, out_z + orow + (n - colb), v, nvalid, out_vec);
+}
+
+template <bool TRAIN>
+static void launch_t16(const MadeLinearArgs& a, hipStream_t st) {
+    const int steps = (int)(a.K / 32), spw = (steps + 3) / 4;
+    dim3 g((unsigned)(((a.M + U_BM - 1) / U_BM) * ((a.N + U_BN - 1) / U_BN)), 1, (unsigned)a.batch), block(NTHREADS);
+    if (spw <= 1) hipLaunchKernelGGL((linear_t16_kernel<TRAIN, 1>), g, block, 0, st, a);
+    else if (spw <= 2) hipLaunchKernelGGL((linear_t16_kernel<TRAIN, 2>), g, block, 0, st, a);
+    else if (spw <= 4) hipLaunchKernelGGL((linear_t16_kernel<TRAIN, 4>), g, block, 0, st, a);
+    else hipLaunchKernelGGL((linear_t16_kernel<TRAIN, 8>), g, block, 0, st, a);
 }
 
 }  // namespace
@@ -1366,6 +1509,10 @@ static int pick_variant(const MadeLinearArgs& a) {
     const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int64_t tiles64 = ((a.M + S_BM - 1) / S_BM) * ((a.N + S_BN - 1) / S_BN);
     const int64_t tiles32 = ((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN);
+    // one 64-row tile (the decoder's chain, its per-head batches): 16 x 16 tiles, a third of the bytes per workgroup
+    if (a.M <= 64 && a.K >= 128 && a.K <= 1024 && a.K % 32 == 0 && a.tile_skip_mask == nullptr && tile_pref() != 1 && tile_pref() != 32 &&
+        ((a.M + 15) / 16) * ((a.N + 15) / 16) * a.batch <= 4096)
+        return MADE_LINEAR_TINY16;
     if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) return MADE_LINEAR_TINY;
     if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) return MADE_LINEAR_SKINNY;
     if (tiles * a.batch <= 256) return MADE_LINEAR_GLDS3;                  // at most one workgroup per CU
@@ -1429,7 +1576,7 @@ static int linear_validate(const MadeLinearArgs& a) {
     }
     if (a.bias_row_scale) {
         MADE_REQUIRE(a.bias != nullptr, "made_linear: bias_row_scale without bias");
-        MADE_UNSUPPORTED(pick_variant(a) == MADE_LINEAR_TINY, "made_linear: bias_row_scale is served by the tiny-M kernel only");
+        MADE_UNSUPPORTED(pick_variant(a) == MADE_LINEAR_TINY || pick_variant(a) == MADE_LINEAR_TINY16, "made_linear: bias_row_scale is served by the tiny-M kernels only");
     }
     if (a.gate != MADE_GATE_NONE) MADE_REQUIRE(a.G != nullptr, "made_linear: gate without G");
     if (a.gate != MADE_GATE_NONE || a.Zout || a.drop.p > 0.f) {
@@ -1457,6 +1604,9 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool train = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
     switch (pick_variant(a)) {
+        case MADE_LINEAR_TINY16:
+            if (train) launch_t16<true>(a, st); else launch_t16<false>(a, st);
+            break;
         case MADE_LINEAR_TINY: {
             // latency-bound and short in K: fragments straight from global memory, K split over the four waves
             dim3 g32((unsigned)(((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN)), 1, (unsigned)a.batch);

@@ -151,7 +151,7 @@ class Seg:
 # made_linear_variant codes (include/made_hip.h: MadeLinearVariant) -> KernelTimer kinds = rocprofv3 kernel symbols
 LINEAR_VARIANTS = {0: "linear_f32", 1: "linear_f32in_bf16", 2: "linear_kernel<bf16,bf16>", 3: "linear_tiny_kernel", 4: "linear_skinny_kernel",
                    5: "linear_glds_kernel<3,.,128>", 6: "linear_glds_kernel<1,.,64>", 7: "linear_glds_kernel<1,.,128>",
-                   8: "linear_ring_kernel<128,128>"}
+                   8: "linear_ring_kernel<128,128>", 9: "linear_t16_kernel"}
 
 
 def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,
@@ -395,7 +395,7 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
 def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, Kadd: Optional[Tensor] = None,
                    key_mask: Optional[Tensor] = None, shared_q: bool = False, n_split: int = 1,
                    part_o: Optional[Tensor] = None, part_ml: Optional[Tensor] = None, drop=None,
-                   sum_out: Optional[Tensor] = None, lse_out: Optional[Tensor] = None, tickets: Optional[Tensor] = None) -> Tensor:
+                   sum_out: Optional[Tensor] = None, lse_out: Optional[Tensor] = None) -> Tensor:
     """Single-head attention with head dim = D.  Q [B|1, NQ1, NQ2, D], K/Kadd/V [B, L, D], O [B, NQ1, NQ2, D]
     (strided views fine, unit inner stride).  shared_q: the same queries for every batch entry (Q.shape[0] == 1)."""
     assert Q.dim() == 4 and O.dim() == 4 and K.dim() == 3 and V.dim() == 3
@@ -422,9 +422,6 @@ def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, 
             part_ml = torch.empty(B * n_split * nq * 4, device=Q.device, dtype=torch.float32)
         assert part_o.numel() >= B * n_split * nq * D and part_ml.numel() >= B * n_split * nq * 4
         a.n_split, a.part_o, a.part_ml = n_split, _p(_f32(part_o, "part_o")), _p(_f32(part_ml, "part_ml"))
-        if tickets is not None:      # merge the key slices inside the launch (zeroed int32 words, one per (entry, query tile); left at zero)
-            assert tickets.dtype == torch.int32 and tickets.is_contiguous() and tickets.numel() >= B * ((nq + 31) // 32)
-            a.tickets = _p(tickets)
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
     if lse_out is not None:

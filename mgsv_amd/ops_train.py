@@ -90,6 +90,20 @@ def gemm_tn_grouped(problems, rows=None, alpha: float = 1.0, split_m: Optional[i
         nbytes += float(M * (N + K) * 2 + N * K * 4)
     if rows is not None:
         g.row_index, g.n_rows = _p(rows[0]), _p(rows[1])
+    import os
+    big = (all(pr[0].shape[1] % 256 == 0 and pr[1].shape[1] % 256 == 0 for pr in problems) and M >= 4096
+           and os.environ.get("MADE_TN_TILE", "256") == "256")
+    if big and split_m is None:
+        # 256 x 256 tiles, one eight-wave workgroup per CU: the splits are spread over the 8 XCDs (a multiple of 8), about one round
+        tiles256 = sum((pr[0].shape[1] // 256) * (pr[1].shape[1] // 256) for pr in problems)
+        nslab = (M + 63) // 64
+        split_m = 8 if tiles256 >= 24 else (16 if tiles256 >= 12 else 32)
+        while (nslab + split_m - 1) // split_m > 72:          # a workgroup keeps at most 72 slabs' row indices in LDS
+            split_m += 8
+        split_m = min(split_m, max(1, nslab))
+        g.tile_size = 256
+    elif big:
+        g.tile_size = 256
     if split_m is None:
         nslab = (M + 63) // 64
         split_m = max(1, (2048 // max(tiles, 1)))            # two workgroups per CU resident, about four rounds of them: measured best
@@ -299,7 +313,7 @@ def softmax_bwd(S: Tensor, dP: Tensor, mask: Optional[Tensor], rows_per_mask: in
 def attention_wide_bwd(Q: Tensor, dO: Tensor, O: Tensor, K: Tensor, V: Tensor, lse: Tensor, Pd: Tensor, dS: Tensor, dQ: Tensor, *, scale: float,
                        key_mask: Optional[Tensor] = None, ssum: Optional[Tensor] = None, extra: Optional[Tensor] = None,
                        dattc: Optional[Tensor] = None, vbias: Optional[Tensor] = None, hd: int = 0, drop=None, n_split: int = 1,
-                       part_dq: Optional[Tensor] = None, tickets: Optional[Tensor] = None) -> Tensor:
+                       part_dq: Optional[Tensor] = None) -> Tensor:
     """Backward of the decoder's memory-space cross-attention in ONE launch (made_attention_wide_bwd).  Q / dO / O / dQ [B, NQ, D] bf16
     (NQ <= 8), K / V [B, L, D] bf16, lse / ssum / extra [B, NQ] f32, Pd / dS [B, NQ, ld_p >= L] bf16 views."""
     assert Q.dim() == 3 and dO.shape == Q.shape and O.shape == Q.shape and dQ.shape == Q.shape and K.dim() == 3 and V.shape == K.shape
@@ -323,9 +337,6 @@ def attention_wide_bwd(Q: Tensor, dO: Tensor, O: Tensor, K: Tensor, V: Tensor, l
     if n_split > 1:
         assert part_dq is not None and part_dq.dtype == torch.float32 and part_dq.numel() >= B * n_split * NQ * D
         a.n_split, a.part_dq = n_split, _p(part_dq)
-        if tickets is not None:                               # (sum the slices inside the launch: slower, see include/made_hip.h)
-            assert tickets.dtype == torch.int32 and tickets.numel() >= B
-            a.tickets = _p(tickets)
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
     _timed("made_attention_wide_bwd", 6.0 * B * NQ * L * D, 2.0 * B * (2 * L * D + 4 * NQ * D + 2 * NQ * L),

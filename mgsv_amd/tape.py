@@ -102,6 +102,20 @@ class LaunchTape:
     def replay(self) -> None:
         _lib.check(_lib.lib().made_tape_replay(self.handle), "made_tape_replay")
 
+    def replay_range(self, first: int, count: int) -> None:
+        """operations [first, first + count) only (one phase of the step on its own: measurements)"""
+        _lib.check(_lib.lib().made_tape_replay_range(self.handle, int(first), int(count)), "made_tape_replay_range")
+
+    def ops(self):
+        """[(kind, function address, stream, (gx, gy, gz))] in issue order; kind 0 = kernel launch"""
+        k, w, o = self.counts()
+        out = []
+        kind, fn, st, g3 = _lib.i32(0), C.c_uint64(0), C.c_uint64(0), (C.c_uint32 * 3)()
+        for i in range(k + w + o):
+            _lib.check(_lib.lib().made_tape_op(self.handle, i, C.byref(kind), C.byref(fn), C.byref(st), g3), "made_tape_op")
+            out.append((int(kind.value), int(fn.value), int(st.value), (int(g3[0]), int(g3[1]), int(g3[2]))))
+        return out
+
     def interleave(self, main_weight: int = 2) -> None:
         """feed all streams at the same time on replay (made_tape_interleave): results unchanged, only the host's issue order moves"""
         _lib.check(_lib.lib().made_tape_interleave(self.handle, int(main_weight)), "made_tape_interleave")

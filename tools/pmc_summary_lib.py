@@ -12,6 +12,8 @@ def kind(name):
         return "linear_glds_kernel<3,.,128>", True
     if "linear_skinny_kernel" in name:
         return "linear_skinny_kernel", True
+    if "linear_t16_kernel" in name:
+        return "linear_t16_kernel", True
     if "linear_tiny_kernel" in name:
         return "linear_tiny_kernel", True
     if "linear_kernelIDF16bDF16b" in name:

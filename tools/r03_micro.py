@@ -1,6 +1,6 @@
 """Round-3 micro-benchmarks (hipGraph replay of 20 calls each, so launch overhead stays out):
   * made_layernorm_bwd at the DETR-encoder shape with / without the parameter-gradient flush, grid caps via MADE_LNBWD_NB
-  * made_attention_wide at the decoder's cross-attention shape: key slices merged by a second launch / inside the launch
+  * made_attention_wide at the decoder's cross-attention shape: keys split over workgroups (merged by a second launch; the in-launch merge measured in profiles/r03_micro_merge_in_launch_vs_second_launch.txt was removed)
   * made_attention_wide_bwd at the same shape for several key splits
 usage: python tools/r03_micro.py [ln|wide|all]"""
 import math, os, sys
@@ -52,18 +52,15 @@ if what in ("wide", "all"):
     byts = 2.0 * nvalid * D * 2
     for ns in (1, 2, 4, 8):
         po, pml = torch.empty(B * ns * NQ * D, device=dev), torch.empty(B * ns * NQ * 4, device=dev)
-        for merged in ((False,) if ns == 1 else (False, True)):
-            tk = torch.zeros(B, device=dev, dtype=torch.int32) if merged else None
-            t = timeit(lambda: ops.attention_wide(q.view(B, NQ, 1, D), k, v, O, scale=scale, key_mask=mask2, n_split=ns, part_o=po, part_ml=pml,
-                                                  drop=(1, 2, 0.1), sum_out=ssum, lse_out=lse, tickets=tk))
-            print(f"attention_wide fwd B={B} NQ={NQ} L={L} D={D} n_split={ns} {'merged in the launch' if merged else 'second launch' if ns > 1 else ''}: "
-                  f"{t:7.1f} us  {byts / t / 1e3:7.1f} GB/s", flush=True)
+        t = timeit(lambda: ops.attention_wide(q.view(B, NQ, 1, D), k, v, O, scale=scale, key_mask=mask2, n_split=ns, part_o=po, part_ml=pml,
+                                              drop=(1, 2, 0.1), sum_out=ssum, lse_out=lse))
+        print(f"attention_wide fwd B={B} NQ={NQ} L={L} D={D} n_split={ns} {'+ merge launch' if ns > 1 else ''}: "
+              f"{t:7.1f} us  {byts / t / 1e3:7.1f} GB/s", flush=True)
     Lp = (L + 7) // 8 * 8
     Pd = torch.empty(B, 2, NQ, Lp, device=dev, dtype=dt); dQ = torch.empty(B, NQ, D, device=dev, dtype=dt)
     dattc = torch.randn(B, D, device=dev).to(dt); bv = torch.randn(D, device=dev)
-    tk = torch.zeros(B, device=dev, dtype=torch.int32)
     for ns in (1, 2, 4, 8):
         part = torch.empty(B * ns * NQ * D, device=dev)
         t = timeit(lambda: tr.attention_wide_bwd(q, dO, O.view(B, NQ, D), k, v, lse.view(B, NQ), Pd[:, 0], Pd[:, 1], dQ, scale=scale, key_mask=mask2,
-                                                 ssum=ssum.view(B, NQ), dattc=dattc, vbias=bv, hd=hd, drop=(1, 2, 0.1), n_split=ns, part_dq=part, tickets=tk))
+                                                 ssum=ssum.view(B, NQ), dattc=dattc, vbias=bv, hd=hd, drop=(1, 2, 0.1), n_split=ns, part_dq=part))
         print(f"attention_wide_bwd B={B} NQ={NQ} L={L} D={D} n_split={ns}: {t:7.1f} us  {byts / t / 1e3:7.1f} GB/s", flush=True)

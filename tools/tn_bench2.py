@@ -36,12 +36,12 @@ for N, K in ((512, 512), (1024, 512), (512, 1024), (1536, 512)):
     for sp in (8, 32):
         r[f"gather split{sp}"] = bench(lambda: tr.gemm_tn(A, B, C, accumulate=True, rows=rows, split_m=sp))
     print(f"N={N} K={K} valid rows {nv}: " + "  ".join(f"{k}: {v:.1f}us ({2.0 * nv * N * K / v / 1e6:.0f} TF)" for k, v in r.items()), flush=True)
-# one layer's five products, grouped
+# one layer's five products, grouped (MADE_TN_TILE=128 selects the 128 x 128-tile kernel)
 probs = []
 for N, K in ((512, 1024), (1024, 512), (512, 512), (1024, 512), (512, 512)):
     probs.append((mk(N), mk(K), torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)))
 fl = sum(2.0 * nv * p[0].shape[1] * p[1].shape[1] for p in probs)
-for sp in (None, 16, 24, 32):
+for sp in (None, 8, 16, 24, 32):
     t = bench(lambda: tr.gemm_tn_grouped(probs, rows=rows, split_m=sp), n=4)
     print(f"grouped x5 split={sp}: {t:.1f}us ({fl / t / 1e6:.0f} TF)")
 t = bench(lambda: tr.gemm_tn_grouped([(a, b, c, None) for a, b, c, _ in probs], rows=rows), n=4)

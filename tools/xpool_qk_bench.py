@@ -33,17 +33,13 @@ def run(Nv, Nm, S, D, splits):
         frac = 1.0 if mask is None else float(mask.mean())
         byts = 2.0 * Nm * S * D * 2 * frac + Nv * D * 2 + Nm * Nv * D * 2
         for ns in splits:
-            for merged in ((False,) if ns == 1 else (False, True)):       # key slices merged by a second launch / inside the launch (tickets)
-                if merged and Nv > 64:
-                    continue
-                part_o = torch.empty(Nm * ns * Nv * D, device=dev) if ns > 1 else None
-                part_ml = torch.empty(Nm * ns * Nv * 4, device=dev) if ns > 1 else None
-                tk = torch.zeros(Nm * ((Nv + 31) // 32), device=dev, dtype=torch.int32) if merged else None
-                t = timeit(lambda: ops.attention_wide(q.view(1, Nv, 1, D), k, u, o.view(Nm, Nv, 1, D), scale=1 / math.sqrt(D), key_mask=mask,
-                                                      shared_q=True, n_split=ns, part_o=part_o, part_ml=part_ml, tickets=tk))
-                print(f"  Nv={Nv} Nm={Nm} S={S} D={D} {name:32s} n_split={ns} {'merged in the launch' if merged else ('+ merge launch' if ns > 1 else '              ')}: "
-                      f"{t:8.1f} us  {byts / t / 1e3:7.1f} GB/s ({byts / t / 1e3 / 8000 * 100:4.1f}% of HBM peak)  "
-                      f"{flops * frac / t / 1e6:7.1f} TFLOP/s ({flops * frac / t / 1e6 / 2500 * 100:4.1f}% of bf16 MFMA peak)", flush=True)
+            part_o = torch.empty(Nm * ns * Nv * D, device=dev) if ns > 1 else None
+            part_ml = torch.empty(Nm * ns * Nv * 4, device=dev) if ns > 1 else None
+            t = timeit(lambda: ops.attention_wide(q.view(1, Nv, 1, D), k, u, o.view(Nm, Nv, 1, D), scale=1 / math.sqrt(D), key_mask=mask,
+                                                  shared_q=True, n_split=ns, part_o=part_o, part_ml=part_ml))
+            print(f"  Nv={Nv} Nm={Nm} S={S} D={D} {name:32s} n_split={ns} {'+ merge launch' if ns > 1 else '              '}: "
+                  f"{t:8.1f} us  {byts / t / 1e3:7.1f} GB/s ({byts / t / 1e3 / 8000 * 100:4.1f}% of HBM peak)  "
+                  f"{flops * frac / t / 1e6:7.1f} TFLOP/s ({flops * frac / t / 1e6 / 2500 * 100:4.1f}% of bf16 MFMA peak)", flush=True)
 
 
 print("in-batch X-Pool attention core, the shape north_star names:")
