@@ -597,7 +597,8 @@ typedef struct MadeGemmTNGroup {
     MadeGemmTNProblem p[MADE_GEMM_TN_MAX_GROUP];
     int32_t tile_end[MADE_GEMM_TN_MAX_GROUP];
     int32_t tile_size; int32_t _pad;     /* 0 / 128: 128 x 128 output tiles (four waves, two workgroups per CU); 256: 256 x 256 tiles (eight waves, one
-                                            workgroup per CU, N and K multiples of 256): twice the flops per operand byte, a quarter of the atomics */
+                                            workgroup per CU, N and K multiples of 256, M <= 36864): twice the flops per operand byte, a quarter of
+                                            the atomics; the (tile, 64-row slab) units are cut into equal ranges for the workgroups, split_m is not used */
 } MadeGemmTNGroup;
 int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream);
 /* out[g] = 1 if any of mask[32g .. 32g+31] is nonzero else 0 (computed once per batch, shared by every weight-gradient product) */
@@ -733,6 +734,8 @@ int made_set_criterion_bwd(const float* pred_logits, const float* pred_spans, co
  * torch.optim.Adam's update (amsgrad off, weight_decay 0) with the group's lr (host-side schedule) and the given step
  * count (>= 1, for the bias corrections).  Elements outside every group are left untouched (the reference keeps
  * decoder_query_embed out of the optimizer).  grad_scale folds the 1/world_size of a summed data-parallel all-reduce.
+ * A group with begin == end is skipped (nothing of it is read or written): a step may be applied in parts -- the groups whose gradients
+ * are final early, under the rest of the backward pass; the others at the end -- with the same step count in both calls.
  * norm_ws: [MADE_ADAM_MAX_GROUPS * (1 + MADE_ADAM_NORM_BLOCKS)] f32 device workspace; its first MADE_ADAM_MAX_GROUPS entries
  * return the squared group norms.  The norms are reduced in a fixed order (no atomics), so data-parallel ranks that hold the
  * same all-reduced gradients apply bit-identical updates. */
@@ -744,12 +747,13 @@ int made_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float grad_scale, float* norm_ws, void* stream);
 
 /* made_adam_step_device: the same tail with its per-step scalars in DEVICE memory, so that the whole training iteration can sit in
- * one captured hipGraph: `state->step` is incremented by the launch and then used for the bias corrections;
+ * one captured hipGraph: `state->step` is incremented by the launch (advance_state != 0: the first call of a step
+ * applied in parts; 0: a later part of the same step) and then used for the bias corrections;
  * `state->lr[g]` replaces groups[g].lr (the host-side LambdaLR schedule writes the three floats before it replays the graph). */
 typedef struct MadeAdamDeviceState { int64_t step; float lr[MADE_ADAM_MAX_GROUPS]; float bc1, bc2_sqrt; } MadeAdamDeviceState;
 int made_adam_step_device(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                           const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps,
-                          MadeAdamDeviceState* state_device, float grad_scale, float* norm_ws, void* stream);
+                          MadeAdamDeviceState* state_device, int32_t advance_state, float grad_scale, float* norm_ws, void* stream);
 
 /* made_repack: rebuild the kernel-facing copies of every matrix parameter from the f32 masters in one launch:
  * w (rows x cols, `dtype`; NULL = the kernels read the master itself) and wt = W^T (cols x wt_ld, wt_ld >= rows; NULL = not

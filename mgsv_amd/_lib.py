@@ -213,7 +213,7 @@ SIGNATURES = {
     "made_set_criterion_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, vp, vp,
                                          vp, vp, i64, i32, vp, vp, vp]),
     "made_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, i64, f32, vp, vp]),
-    "made_adam_step_device": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, vp, f32, vp, vp]),
+    "made_adam_step_device": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(MadeAdamGroup), i32, f32, f32, f32, vp, i32, f32, vp, vp]),
     "made_repack": (C.c_int, [vp, i32, i64, vp]),
     "made_row_groups": (C.c_int, [vp, i64, vp, vp]),
     "made_row_index": (C.c_int, [vp, i64, vp, vp, vp]),

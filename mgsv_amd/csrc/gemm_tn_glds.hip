@@ -252,9 +252,9 @@ __global__ __launch_bounds__(GT_NT, 2) void gemm_tn_glds_grouped_kernel(const Ma
 // 256 x 256 output tiles (round 3).  The 128 x 128 kernel above moves 32 KB of operands per 2.1 MFLOP (65 flop / byte): at the
 // ~50 GB/s a CU takes in through LDS-DMA that is a third of the MFMA rate, and a layer's five products need 16 reduction splits to
 // fill the chip, each adding its whole f32 tile to the gradient with atomics (134 MB per layer).  Here a workgroup of EIGHT waves
-// owns a 256 x 256 tile (a wave: 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers): 64 KB per 8.4 MFLOP (131 flop / byte), a
-// layer's 32 tiles x 8 splits = one workgroup per CU, a quarter of the atomic traffic, and per k-step 12 transposing LDS reads feed 8
-// MFMAs (the LDS read rate stays below the MFMA rate).  Same slab ring, same source-side swizzle, same bias-gradient trick.
+// owns a 256 x 256 tile (a wave: 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers): 64 KB per 8.4 MFLOP (131 flop / byte), one
+// workgroup per CU, a quarter of the atomic traffic, and per k-step 12 transposing LDS reads feed 8 MFMAs (the LDS read rate stays
+// below the MFMA rate).  Same slab ring, same source-side swizzle, same bias-gradient trick.
 constexpr int T2_BN = 256, T2_BK = 256, T2_BM = 64, T2_NT = 512, T2_NST = 2;
 constexpr int T2_ROW = 512;                               // bytes per LDS row (256 bf16)
 constexpr int T2_HALF = T2_BM * T2_ROW;                   // 32 KB: one operand of one stage
@@ -271,29 +271,53 @@ __device__ __forceinline__ void t2_wait12(bf16x4 (&f)[12], int n_outstanding_is_
                      "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]));
 }
 
-__device__ __forceinline__ void gemm_tn_256_body(const GtProblem a, const GtShared sh, unsigned char* lds) {
+// Work of a launch = (tile, 64-row slab) units.  The slabs are dealt over the 8 XCDs (slab s to the workgroups with blockIdx % 8 == s % 8:
+// under the observed round-robin placement the rows of a slab are then read through ONE L2 by all tiles), and the units of an XCD,
+// tile-major, are cut into equal consecutive ranges for its workgroups -- any number of tiles keeps all 256 CUs busy to within one
+// slab (36 tiles x 8 splits as whole tiles per workgroup were 288 workgroups = two rounds, the second one 12 % full).  A workgroup adds its
+// accumulators to C whenever its range leaves a tile (at most ceil(32 / tiles) + 1 times).
+struct T2Tile { const bf16_t* A; const bf16_t* B; float* C; float* colsum; int64_t lda, ldb, ldc, n0, k0; int first_k; };
+
+__device__ __forceinline__ T2Tile t2_tile(const MadeGemmTNGroup& g, int tile) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 0; i < MADE_GEMM_TN_MAX_GROUP - 1; ++i)
+        if (i + 1 < g.n_problems && tile >= g.tile_end[i]) pi = i + 1;
+    if (pi > 0) tile -= g.tile_end[pi - 1];
+    T2Tile t;
+    // (a dynamically indexed member of the kernel argument would be copied to scratch memory: select instead)
+    MadeGemmTNProblem p = g.p[0];
+#pragma unroll
+    for (int i = 1; i < MADE_GEMM_TN_MAX_GROUP; ++i)
+        if (pi == i) p = g.p[i];
+    const int tiles_k = (int)(p.K / T2_BK);
+    t.A = (const bf16_t*)p.A; t.B = (const bf16_t*)p.B; t.C = (float*)p.C; t.colsum = p.colsum;
+    t.lda = p.lda; t.ldb = p.ldb; t.ldc = p.ldc;
+    t.n0 = (int64_t)(tile / tiles_k) * T2_BN; t.k0 = (int64_t)(tile % tiles_k) * T2_BK; t.first_k = (tile % tiles_k) == 0;
+    return t;
+}
+
+__global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const MadeGemmTNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int wn = wave >> 2, wk = wave & 3;                 // 2 x 4 waves: 128 output rows (n) x 64 output columns (k) each
-    const int tiles_k = a.tiles_k;
-    const int64_t split_y = sh.split_y;
-    const int tile_n = a.tile / tiles_k, tile_k = a.tile % tiles_k;
-    const int64_t n0 = (int64_t)tile_n * T2_BN, k0 = (int64_t)tile_k * T2_BK;
-    int64_t Mv = sh.M;
-    if (sh.n_rows) { const int64_t nv = *sh.n_rows; Mv = nv < sh.M ? nv : sh.M; }
+    const int tiles = g.tile_end[g.n_problems - 1];
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+    int64_t Mv = g.M;
+    if (g.n_rows) { const int64_t nv = *g.n_rows; Mv = nv < g.M ? nv : g.M; }
     const int64_t nslab = (Mv + T2_BM - 1) / T2_BM;
-    const int64_t sstep = sh.split_m;
-    const int64_t nloc = nslab > split_y ? (nslab - split_y + sstep - 1) / sstep : 0;   // slabs y, y + split, ...
-    if (nloc == 0) return;
-    const bf16_t* Ag = a.A;
-    const bf16_t* Bg = a.B;
+    const int64_t S = nslab > xcd ? (nslab - xcd + 7) / 8 : 0;          // slabs xcd, xcd + 8, ... : this XCD's
+    const int64_t U = S * tiles;
+    const int64_t u0 = (U * wg) / nwg, u1 = (U * (wg + 1)) / nwg;       // this workgroup's units
+    if (u0 >= u1) return;
 
-    int* lds_rows = (int*)(lds + T2_NST * T2_STAGE);         // physical rows of every slab this block reduces, resolved once
-    for (int64_t t = tid; t < nloc * T2_BM; t += T2_NT) {
-        const int64_t g = split_y + (t / T2_BM) * sstep;
-        const int64_t m = g * T2_BM + (t % T2_BM);
+    int* lds_rows = (int*)(lds + T2_NST * T2_STAGE);         // physical rows of every slab of this XCD, resolved once
+    for (int64_t t = tid; t < S * T2_BM; t += T2_NT) {
+        const int64_t sl = xcd + (t / T2_BM) * 8;
+        const int64_t m = sl * T2_BM + (t % T2_BM);
         const int64_t ml = m < Mv ? m : Mv - 1;
-        lds_rows[t] = sh.row_index ? sh.row_index[ml] : (int)ml;
+        lds_rows[t] = g.row_index ? g.row_index[ml] : (int)ml;
     }
     __syncthreads();
 
@@ -301,55 +325,85 @@ __device__ __forceinline__ void gemm_tn_256_body(const GtProblem a, const GtShar
     const int pos = lane & 31;                               // 16-byte slot inside the LDS row
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    auto issue = [&](int64_t i) __attribute__((always_inline)) {
-        unsigned char* st = lds + (i % T2_NST) * T2_STAGE;
+    auto issue = [&](int64_t n, int64_t si, const T2Tile& t) __attribute__((always_inline)) {    // n: how many units this workgroup has issued
+        unsigned char* st = lds + (n % T2_NST) * T2_STAGE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int rowl = 8 * wave + 2 * j + (lane >> 5);
-            const int64_t pr = lds_rows[i * T2_BM + rowl];
+            const int64_t pr = lds_rows[si * T2_BM + rowl];
             const int chunk = (((pos >> 1) ^ (rowl & 3)) << 1) | (pos & 1);          // source-side swizzle of the 32-byte pairs
             const int piece = (8 * wave + 2 * j) * T2_ROW;                           // 1 KB destination of this instruction (two rows)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ag + pr * a.lda + n0 + chunk * 8), (lds_ptr_t)(st + piece), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bg + pr * a.ldb + k0 + chunk * 8), (lds_ptr_t)(st + T2_HALF + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(t.A + pr * t.lda + t.n0 + chunk * 8), (lds_ptr_t)(st + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(t.B + pr * t.ldb + t.k0 + chunk * 8), (lds_ptr_t)(st + T2_HALF + piece), 16, 0, 0);
         }
     };
 
     // per-lane byte offsets of the transposing reads inside a stage (k-step 0; k-step ks adds ks * 16 rows as an immediate)
     uint32_t offA[4], offB[2];
     {
-        const int g = lane >> 4, i16 = lane & 15;
-        const int row = 4 * (g >> 1) + (i16 >> 2);
+        const int gq = lane >> 4, i16 = lane & 15;
+        const int row = 4 * (gq >> 1) + (i16 >> 2);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int pa = ((wn * 128 + t * 32) >> 4) + (g & 1);
+            const int pa = ((wn * 128 + t * 32) >> 4) + (gq & 1);
             offA[t] = (uint32_t)(row * T2_ROW + ((pa ^ (row & 3)) << 5) + 8 * (i16 & 3));
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int pb = ((wk * 64 + t * 32) >> 4) + (g & 1);
+            const int pb = ((wk * 64 + t * 32) >> 4) + (gq & 1);
             offB[t] = (uint32_t)(T2_HALF + row * T2_ROW + ((pb ^ (row & 3)) << 5) + 8 * (i16 & 3));
         }
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     f32x16 acc[4][2];
+    float csum[4];                                           // bias gradient = column sums of A, from the A fragments (see the 128 x 128 body)
+    auto clear = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            csum[i] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};                    // bias gradient = column sums of A, from the A fragments (see the 128 x 128 body)
-    const bool do_colsum = a.colsum != nullptr && tile_k == 0 && wk == 0;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+    };
+    auto flush = [&](const T2Tile& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t k = t.k0 + wk * 64 + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t n = t.n0 + wn * 128 + i * 32 + acc_row(e, hh);
+                    unsafeAtomicAdd(t.C + n * t.ldc + k, acc[i][j][e] * g.alpha);
+                }
+            }
+        if (t.colsum != nullptr && t.first_k && wk == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float tot = csum[i] + __shfl_xor(csum[i], 32);                 // the two lane halves hold different reduction rows
+                if (hh == 0) unsafeAtomicAdd(t.colsum + t.n0 + wn * 128 + i * 32 + r, tot * g.alpha);
+            }
+        }
+    };
 
-    issue(0);
-    for (int64_t i = 0; i < nloc; ++i) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slab i (the only one in flight) has landed
+    int tile = (int)(u0 / S);
+    int64_t si = u0 % S;                                     // slab (index inside this XCD's list) of the current unit
+    T2Tile cur = t2_tile(g, tile), nxt = cur;
+    clear();
+    issue(0, si, cur);
+    for (int64_t u = u0, n = 0; u < u1; ++u, ++n) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this unit's slab (the only one in flight) has landed
         asm volatile("s_barrier" ::: "memory");             // every wave's part landed; everyone is done with the other stage
-        if (i + 1 < nloc) issue(i + 1);
-        unsigned char* st = lds + (i % T2_NST) * T2_STAGE;
-        const int64_t g = split_y + i * sstep;
-        const int64_t live = Mv - g * T2_BM;                 // rows of this slab that exist
+        const bool last_of_tile = si + 1 == S;
+        if (u + 1 < u1) {
+            if (last_of_tile) { nxt = t2_tile(g, tile + 1); issue(n + 1, 0, nxt); }
+            else issue(n + 1, si + 1, cur);
+        }
+        unsigned char* st = lds + (n % T2_NST) * T2_STAGE;
+        const int64_t live = Mv - (xcd + si * 8) * T2_BM;    // rows of this slab that exist
         if (live < T2_BM) {
             // last slab of the reduction: the clamped duplicate rows must not be summed -> zero them in LDS (both operands)
             const int per_half = (T2_BM - (int)live) * (T2_ROW / 16);
@@ -361,7 +415,8 @@ __device__ __forceinline__ void gemm_tn_256_body(const GtProblem a, const GtShar
             }
             __syncthreads();
         }
-        const uint32_t sbase = lds_base + (uint32_t)((i % T2_NST) * T2_STAGE);
+        const bool do_colsum = cur.colsum != nullptr && cur.first_k && wk == 0;
+        const uint32_t sbase = lds_base + (uint32_t)((n % T2_NST) * T2_STAGE);
         bf16x4 fr[2][12];
         auto read_step = [&](int buf, auto KS) __attribute__((always_inline)) {
             constexpr int o = decltype(KS)::value * 16 * T2_ROW;
@@ -396,48 +451,12 @@ __device__ __forceinline__ void gemm_tn_256_body(const GtProblem a, const GtShar
         read_step(1, std::integral_constant<int, 3>{});
         t2_wait12(fr[0], 1); mul_step(0);
         t2_wait12(fr[1], 0); mul_step(1);
-    }
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t k = k0 + wk * 64 + j * 32 + r;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t n = n0 + wn * 128 + i * 32 + acc_row(e, hh);
-                const float v = acc[i][j][e] * a.alpha;
-                float* p = (float*)a.C + n * a.ldc + k;
-                if (a.accumulate) unsafeAtomicAdd(p, v); else *p = v;
-            }
+        if (last_of_tile || u + 1 == u1) {                   // the range leaves this tile: add what was gathered to the gradient
+            flush(cur);
+            clear();
         }
-    if (do_colsum) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float tot = csum[t] + __shfl_xor(csum[t], 32);                     // the two lane halves hold different reduction rows
-            if (hh == 0) unsafeAtomicAdd(a.colsum + n0 + wn * 128 + t * 32 + r, tot * a.alpha);
-        }
+        if (last_of_tile) { cur = nxt; ++tile; si = 0; } else ++si;
     }
-}
-
-__global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const MadeGemmTNGroup g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tiles = g.tile_end[g.n_problems - 1];
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;     // all tiles of one reduction split on ONE XCD (they read the same rows)
-    const int64_t split_y = xcd + 8 * (int64_t)(jx / tiles);
-    if (split_y >= g.split_m) return;
-    int tile = jx % tiles, pi = 0;
-#pragma unroll
-    for (int i = 0; i < MADE_GEMM_TN_MAX_GROUP - 1; ++i)
-        if (i + 1 < g.n_problems && tile >= g.tile_end[i]) pi = i + 1;
-    if (pi > 0) tile -= g.tile_end[pi - 1];
-    GtProblem p;
-    p.A = (const bf16_t*)g.p[pi].A; p.B = (const bf16_t*)g.p[pi].B; p.C = g.p[pi].C; p.colsum = g.p[pi].colsum;
-    p.lda = g.p[pi].lda; p.ldb = g.p[pi].ldb; p.ldc = g.p[pi].ldc; p.tiles_k = (int)(g.p[pi].K / T2_BK); p.tile = tile;
-    p.c_dtype = MADE_F32; p.accumulate = 1; p.alpha = g.alpha;
-    GtShared sh;
-    sh.M = g.M; sh.split_m = g.split_m; sh.split_y = split_y; sh.row_index = g.row_index; sh.n_rows = g.n_rows;
-    gemm_tn_256_body(p, sh, lds);
 }
 
 }  // namespace
@@ -461,9 +480,11 @@ extern "C" int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream) 
             tiles2 += (int)((p.N / T2_BN) * (p.K / T2_BK));
             g.tile_end[i] = tiles2;
         }
-        MADE_UNSUPPORTED(((g.M + T2_BM - 1) / T2_BM + g.split_m - 1) / g.split_m * T2_BM <= T2_MAX_ROWS,
-                         "made_gemm_tn_grouped(256): split_m=%lld leaves more than %d rows per workgroup", (long long)g.split_m, T2_MAX_ROWS);
-        dim3 grid2((unsigned)(8 * (int64_t)tiles2 * ((g.split_m + 7) / 8)), 1, 1);
+        MADE_UNSUPPORTED(((g.M + T2_BM - 1) / T2_BM + 7) / 8 * T2_BM <= T2_MAX_ROWS,
+                         "made_gemm_tn_grouped(256): more than %d rows (a workgroup keeps an eighth of the row list in LDS)", 8 * T2_MAX_ROWS);
+        // one workgroup per CU; fewer when there is less than a slab for each (small M): 8 (the XCDs) x ceil(units of an XCD / 1) capped at 32
+        const int64_t per_xcd = (((g.M + T2_BM - 1) / T2_BM + 7) / 8) * tiles2;
+        dim3 grid2((unsigned)(8 * (per_xcd < 32 ? (per_xcd > 0 ? per_xcd : 1) : 32)), 1, 1);
         static const bool once2 = hipFuncSetAttribute((const void*)gemm_tn_256_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS) == hipSuccess;
         (void)once2;
         hipLaunchKernelGGL(gemm_tn_256_grouped_kernel, grid2, dim3(T2_NT), T2_LDS, (hipStream_t)stream, g);

@@ -1270,7 +1270,7 @@ __device__ __forceinline__ void linear_tiny_body(const MadeLinearArgs& a, const 
     const int e_rmod = (int)a.r_row_mod;
     const bool e_rpref = a.R && a.r_dtype == MADE_BF16 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0) && e_nvalid == 8;
     const bool e_gpref = TRAIN && a.gate != MADE_GATE_NONE && a.g_dtype == MADE_BF16 && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0) && e_nvalid == 8;
-    bf16x8 e_r, e_g;
+    bf16x8 e_r = {}, e_g = {};
     if (e_rpref) e_r = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)(e_rmod > 0 ? e_m % e_rmod : e_m) * a.ldr + e_n);
     if constexpr (TRAIN) { if (e_gpref) e_g = *(const bf16x8*)((const bf16_t*)a.G + (int64_t)e_m * a.ldg + e_n); }
     float e_om = 1.f;
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(NTHREADS) void linear_t16_kernel(const MadeLinearAr
     const int e_rmod = (int)a.r_row_mod;
     const bool e_rpref = a.R && a.r_dtype == MADE_BF16 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0) && e_nvalid == 8;
     const bool e_gpref = TRAIN && a.gate != MADE_GATE_NONE && a.g_dtype == MADE_BF16 && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0) && e_nvalid == 8;
-    bf16x8 e_r, e_g;
+    bf16x8 e_r = {}, e_g = {};
     if (e_rpref) e_r = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)(e_rmod > 0 ? e_m % e_rmod : e_m) * a.ldr + e_n);
     if constexpr (TRAIN) { if (e_gpref) e_g = *(const bf16x8*)((const bf16_t*)a.G + (int64_t)e_m * a.ldg + e_n); }
     float e_om = 1.f;

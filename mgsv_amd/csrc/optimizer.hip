@@ -31,6 +31,7 @@ __global__ __launch_bounds__(OT) void grad_norm_kernel(const AdamArgs a) {
 #pragma unroll
     for (int k = 0; k < MADE_ADAM_MAX_GROUPS; ++k) acc[k] = 0.f;
     for (int64_t i = ((int64_t)blockIdx.x * OT + threadIdx.x) * 4; i < a.n; i += (int64_t)gridDim.x * OT * 4) {
+        if (group_of(a, i) < 0 && group_of(a, i + 3) < 0) continue;   // (a call may cover some of the groups only: nothing is read outside them)
         const f32x4 g4 = *(const f32x4*)(a.grad + i);           // n is a multiple of 4 (parameters start on 64-element boundaries)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -56,9 +57,9 @@ __global__ __launch_bounds__(OT) void grad_norm_kernel(const AdamArgs a) {
     }
 }
 
-__global__ __launch_bounds__(OT) void norm_finish_kernel(float* norm_ws, int nblocks, MadeAdamDeviceState* st, float beta1, float beta2) {
+__global__ __launch_bounds__(OT) void norm_finish_kernel(float* norm_ws, int nblocks, MadeAdamDeviceState* st, float beta1, float beta2, int advance) {
     __shared__ float red[OT];
-    if (st && threadIdx.x == 0) {           // this single-workgroup launch also advances the device-side step count
+    if (st && advance && threadIdx.x == 0) {   // this single-workgroup launch also advances the device-side step count
         const int64_t step = ++st->step;
         st->bc1 = (float)(1.0 - pow((double)beta1, (double)step));
         st->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(OT) void repack_kernel(const MadeRepackDesc* descs,
 }  // namespace
 
 static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const MadeAdamGroup* groups,
-                       int32_t n_groups, float beta1, float beta2, float eps, int64_t step, MadeAdamDeviceState* state_device,
+                       int32_t n_groups, float beta1, float beta2, float eps, int64_t step, MadeAdamDeviceState* state_device, int advance,
                        float grad_scale, float* norm_ws, void* stream, const char* what) {
     AdamArgs a;
     a.param = param; a.grad = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.n_groups = n_groups;
@@ -166,7 +167,7 @@ static int adam_launch(float* param, const float* grad, float* exp_avg, float* e
     int64_t nb = (n / 4 + OT - 1) / OT;
     if (nb > MADE_ADAM_NORM_BLOCKS) nb = MADE_ADAM_NORM_BLOCKS;
     hipLaunchKernelGGL(grad_norm_kernel, dim3((unsigned)nb), dim3(OT), 0, st, a);
-    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(OT), 0, st, norm_ws, (int)nb, state_device, beta1, beta2);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(OT), 0, st, norm_ws, (int)nb, state_device, beta1, beta2, advance);
     hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nb), dim3(OT), 0, st, a);
     return made_check_launch(what);
 }
@@ -177,17 +178,17 @@ extern "C" int made_adam_step(float* param, const float* grad, float* exp_avg, f
     MADE_REQUIRE(param && grad && exp_avg && exp_avg_sq && groups && norm_ws, "made_adam_step: null pointer");
     MADE_REQUIRE(n_groups >= 1 && n_groups <= MADE_ADAM_MAX_GROUPS, "made_adam_step: n_groups=%d out of range", n_groups);
     MADE_REQUIRE(n > 0 && n % 4 == 0 && step >= 1, "made_adam_step: n must be a positive multiple of 4 and step >= 1");
-    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, groups, n_groups, beta1, beta2, eps, step, nullptr, grad_scale, norm_ws, stream,
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, groups, n_groups, beta1, beta2, eps, step, nullptr, 0, grad_scale, norm_ws, stream,
                        "made_adam_step");
 }
 
 extern "C" int made_adam_step_device(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                      const MadeAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps,
-                                     MadeAdamDeviceState* state_device, float grad_scale, float* norm_ws, void* stream) {
+                                     MadeAdamDeviceState* state_device, int32_t advance_state, float grad_scale, float* norm_ws, void* stream) {
     MADE_REQUIRE(param && grad && exp_avg && exp_avg_sq && groups && norm_ws && state_device, "made_adam_step_device: null pointer");
     MADE_REQUIRE(n_groups >= 1 && n_groups <= MADE_ADAM_MAX_GROUPS, "made_adam_step_device: n_groups=%d out of range", n_groups);
     MADE_REQUIRE(n > 0 && n % 4 == 0, "made_adam_step_device: n must be a positive multiple of 4");
-    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, groups, n_groups, beta1, beta2, eps, 0, state_device, grad_scale, norm_ws, stream,
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, groups, n_groups, beta1, beta2, eps, 0, state_device, advance_state != 0, grad_scale, norm_ws, stream,
                        "made_adam_step_device");
 }
 

@@ -91,19 +91,13 @@ def gemm_tn_grouped(problems, rows=None, alpha: float = 1.0, split_m: Optional[i
     if rows is not None:
         g.row_index, g.n_rows = _p(rows[0]), _p(rows[1])
     import os
-    big = (all(pr[0].shape[1] % 256 == 0 and pr[1].shape[1] % 256 == 0 for pr in problems) and M >= 4096
+    big = (all(pr[0].shape[1] % 256 == 0 and pr[1].shape[1] % 256 == 0 for pr in problems) and 4096 <= M <= 36864
            and os.environ.get("MADE_TN_TILE", "256") == "256")
-    if big and split_m is None:
-        # 256 x 256 tiles, one eight-wave workgroup per CU: the splits are spread over the 8 XCDs (a multiple of 8), about one round
-        tiles256 = sum((pr[0].shape[1] // 256) * (pr[1].shape[1] // 256) for pr in problems)
-        nslab = (M + 63) // 64
-        split_m = 8 if tiles256 >= 24 else (16 if tiles256 >= 12 else 32)
-        while (nslab + split_m - 1) // split_m > 72:          # a workgroup keeps at most 72 slabs' row indices in LDS
-            split_m += 8
-        split_m = min(split_m, max(1, nslab))
+    if big:
+        # 256 x 256 tiles, one eight-wave workgroup per CU, the (tile, slab) units dealt out evenly by the kernel itself
         g.tile_size = 256
-    elif big:
-        g.tile_size = 256
+        if split_m is None:
+            split_m = 1
     if split_m is None:
         nslab = (M + 63) // 64
         split_m = max(1, (2048 // max(tiles, 1)))            # two workgroups per CU resident, about four rounds of them: measured best

@@ -235,7 +235,7 @@ class MadeTrainer(MadeEngine):
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.opt_step = 0
-        self._norm_ws = torch.zeros(4 * (1 + 1024), device=dev, dtype=torch.float32)
+        self._norm_ws = torch.zeros(2 * 4 * (1 + 1024), device=dev, dtype=torch.float32)   # (two halves: a step applied in parts)
 
     def _view(self, store: Dict[str, Tensor], ref) -> Tensor:
         if isinstance(ref, tuple):                       # adjacent pair -> one view over both
@@ -246,10 +246,11 @@ class MadeTrainer(MadeEngine):
             return flat[o:o + a.numel() + b.numel()].view((rows,) + tuple(a.shape[1:]))
         return store[ref]
 
-    def repack(self):
+    def repack(self, part: Optional[str] = None):
         """Kernel-facing parameter copies from the f32 masters: W (compute dtype), W^T (for dX = dY W) -- one launch
         (made_repack) into buffers allocated once, so the pointers the kernels (and a captured hipGraph) see never change.
-        Vectors (biases, LayerNorm parameters) and, in f32 mode, the matrices themselves alias the masters."""
+        Vectors (biases, LayerNorm parameters) and, in f32 mode, the matrices themselves alias the masters.
+        part: None = every matrix; "early" / "rest" = the matching + detection groups' / the temporal group's (optimizer_step)."""
         import ctypes as C
         if getattr(self, "_pack_desc", None) is None:
             P, tc, dev = self.P, self.tc, self.device
@@ -262,6 +263,8 @@ class MadeTrainer(MadeEngine):
                 self.G[key] = g.view(-1) if g.dim() != 1 else g
             descs = []
             tiles = 0
+            cut = self.group_ranges[0][1]                     # masters below: the temporal group (final last in the backward pass)
+            part_of = []
             for key, ref in mats:
                 m = self._view(self.master, ref)
                 self.G[key] = self._view(self.grad, ref)
@@ -285,13 +288,27 @@ class MadeTrainer(MadeEngine):
                 d.dtype = ops.dt_of(wt if wt is not None else w)
                 tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
                 descs.append(d)
-            arr = (_lib.MadeRepackDesc * len(descs))(*descs)
-            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-            self._pack_desc = torch.from_numpy(raw).to(dev)
-            self._pack_n, self._pack_tiles = len(descs), tiles
-        _lib.check(_lib.lib().made_repack(self._pack_desc.data_ptr(), self._pack_n, self._pack_tiles,
-                                          torch.cuda.current_stream().cuda_stream), "made_repack")
-        if self.cfg.agg_module == "mlp":                      # the eval path's per-position affine (MadeEngine._encode_mlp) from the current
+                part_of.append("rest" if (m.data_ptr() - self.flat_param.data_ptr()) // 4 < cut else "early")
+
+            def pack(ds):
+                t0, out = 0, []
+                for d in ds:
+                    e = _lib.MadeRepackDesc()
+                    C.memmove(C.byref(e), C.byref(d), C.sizeof(e))
+                    e.tile_begin = t0
+                    t0 += ((e.rows + 31) // 32) * ((e.cols + 31) // 32)
+                    out.append(e)
+                if not out:
+                    return None
+                arr = (_lib.MadeRepackDesc * len(out))(*out)
+                return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev), len(out), t0
+            # the whole set, and the two parts of a step applied in parts (optimizer_step(part=...))
+            self._pack_desc = {None: pack(descs), "early": pack([d for d, q in zip(descs, part_of) if q == "early"]),
+                               "rest": pack([d for d, q in zip(descs, part_of) if q == "rest"])}
+        pk = self._pack_desc[part]
+        if pk is not None:
+            _lib.check(_lib.lib().made_repack(pk[0].data_ptr(), pk[1], pk[2], torch.cuda.current_stream().cuda_stream), "made_repack")
+        if self.cfg.agg_module == "mlp" and part != "early":  # the eval path's per-position affine (MadeEngine._encode_mlp) from the current
             P = self.P                                        # BatchNorm parameters and running buffers
             for key, mod, _ in self._mlp_towers():
                 for bn in ("1", "4"):
@@ -302,30 +319,40 @@ class MadeTrainer(MadeEngine):
                     sh.neg_().add_(P[f"{key}.{bn}.beta"])
 
     def optimizer_step(self, lr_temporal: float, lr_matching: float, lr_detection: float, max_grad_norm: float = 1.0,
-                       betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, device_state: Optional[Tensor] = None) -> None:
+                       betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, device_state: Optional[Tensor] = None,
+                       part: Optional[str] = None) -> None:
         """Three-group gradient clipping + Adam (reference train-MaDe.py:262-266,375-381) on the flat buffers, then repack().
         device_state (a MadeAdamDeviceState in device memory, see TrainStepGraph): the step count and the learning rates are read
-        there by the kernels -- the launch sequence no longer depends on host values and can be captured."""
+        there by the kernels -- the launch sequence no longer depends on host values and can be captured.
+        part: the groups are clipped and updated independently of each other, so a step may be applied in two parts --
+        "early": the matching + detection groups (~85 % of the parameters), whose gradients are final before the temporal encoders'
+        backward starts (backward(early_opt=...) runs this on a third stream under it); then "rest": the temporal group.
+        None: everything at once."""
         import ctypes as C
-        self.opt_step += 1
-        self.generation += 1
+        assert part in (None, "early", "rest")
+        if part != "rest":
+            self.opt_step += 1
+            self.generation += 1
         groups = (_lib.MadeAdamGroup * 3)()
         for i, lr in enumerate((lr_temporal, lr_matching, lr_detection)):
             groups[i].begin, groups[i].end = self.group_ranges[i]
+            if (part == "early" and i == 0) or (part == "rest" and i != 0):
+                groups[i].end = groups[i].begin             # (an empty group is skipped)
             groups[i].lr, groups[i].max_norm = float(lr), float(max_grad_norm)
+        ws = self._norm_ws[:self._norm_ws.numel() // 2] if part != "early" else self._norm_ws[self._norm_ws.numel() // 2:]
         if device_state is not None:
             _lib.check(_lib.lib().made_adam_step_device(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                                         self.exp_avg_sq.data_ptr(), self.flat_param.numel(), groups, 3, float(betas[0]),
-                                                        float(betas[1]), float(eps), device_state.data_ptr(), float(grad_scale),
-                                                        self._norm_ws.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                                                        float(betas[1]), float(eps), device_state.data_ptr(), 0 if part == "rest" else 1,
+                                                        float(grad_scale), ws.data_ptr(), torch.cuda.current_stream().cuda_stream),
                        "made_adam_step_device")
-            self.repack()
+            self.repack(part)
             return
         _lib.check(_lib.lib().made_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                              self.exp_avg_sq.data_ptr(), self.flat_param.numel(), groups, 3, float(betas[0]), float(betas[1]),
-                                             float(eps), self.opt_step, float(grad_scale), self._norm_ws.data_ptr(),
+                                             float(eps), self.opt_step, float(grad_scale), ws.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream), "made_adam_step")
-        self.repack()
+        self.repack(part)
 
     def train_step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed: int, lrs=(1e-4, 1e-4, 1e-4),
                    max_grad_norm: float = 1.0, w_ret: Optional[Tensor] = None, w_loc: Optional[Tensor] = None, dist=None,
@@ -346,10 +373,23 @@ class MadeTrainer(MadeEngine):
             for w in works:
                 w.wait()
             scale = 1.0 / dist.get_world_size()
+        elif self._early_opt_ok():
+            # (opt-in) the matching + detection groups' gradients (~85 % of the parameters) are final before the temporal encoders'
+            # backward starts -- their clip + Adam + repack run on a third stream under it, the temporal group's at the end
+            self.backward(w_ret, w_loc, early_opt=lambda: self.optimizer_step(*lrs, max_grad_norm=max_grad_norm, part="early"))
+            self.optimizer_step(*lrs, max_grad_norm=max_grad_norm, part="rest")
+            return out
         else:
             self.backward(w_ret, w_loc)
         self.optimizer_step(*lrs, max_grad_norm=max_grad_norm, grad_scale=scale)
         return out
+
+    def _early_opt_ok(self) -> bool:
+        """the step applied in two parts (see optimizer_step): MADE_EARLY_OPT=1.  Off by default -- measured on MI355X (B = 64 headline
+        step): 5.65 ms in two parts against 5.62 ms in one piece; the temporal encoders' backward is slowed down by as much as the
+        optimizer's tail gets shorter (both are bound by memory traffic).  The regression variant has no decoder and another group
+        layout: always one piece."""
+        return os.environ.get("MADE_EARLY_OPT", "0") == "1" and "regression" not in self.cfg.mml_localization
 
     def capture_train_step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, *, max_grad_norm: float = 1.0,
                            music_ids=None, v_duration: Optional[Tensor] = None, dist=None, mode: str = "graph") -> "TrainStepGraph":
@@ -825,6 +865,12 @@ class MadeTrainer(MadeEngine):
         cur.wait_stream(side)
         return out
 
+    def _opt_stream(self):
+        st = getattr(self, "_opt_st", None)
+        if st is None:
+            st = self._opt_st = torch.cuda.Stream(device=self.device)
+        return st
+
     def _dec_stage_chain(self) -> bool:
         """The training decoder's fused chain (made_dec_stage with the training options, in-launch merge of the memory-space attention,
         fused attention backward): bf16, one moment query, D = 256 / 512.  MADE_DEC_STAGE=0 keeps round 2's chain (A/B measurements);
@@ -1028,10 +1074,14 @@ class MadeTrainer(MadeEngine):
         return self._rows.get(mask.data_ptr()) if mask is not None else None
 
     @torch.no_grad()
-    def backward(self, g_ret: Optional[Tensor] = None, g_loc: Optional[Tensor] = None, zero_grad: bool = True, grad_sync=None) -> None:
+    def backward(self, g_ret: Optional[Tensor] = None, g_loc: Optional[Tensor] = None, zero_grad: bool = True, grad_sync=None,
+                 early_opt=None) -> None:
         """Gradients of g_ret * retrieval_loss + g_loc * localization_loss (device scalars, default 1) into `flat_grad`.
         grad_sync(): called once, at the point where every gradient except the temporal group's (the first range of the flat
-        buffer) is final -- data-parallel training starts that part's all-reduce there, under the encoders' backward."""
+        buffer) is final -- data-parallel training starts that part's all-reduce there, under the encoders' backward.
+        early_opt(): called at the same point on a THIRD stream that waits for everything queued so far on the two others (neither
+        of them waits for it until the end of the backward pass): optimizer_step(part="early") there applies the matching + detection
+        groups' update under the temporal encoders' backward, which reads none of their weights (opt-in, see _early_opt_ok)."""
         c, P, G = self.cfg, self.P, self.G
         B, Tv, Ta = self._shape
         ws, tw = self._buffers(B, Tv, Ta), self._train_buffers(B, Tv, Ta)
@@ -1376,6 +1426,14 @@ class MadeTrainer(MadeEngine):
 
         if grad_sync is not None:
             grad_sync()
+        opt_st = None
+        if early_opt is not None:
+            opt_st = self._opt_stream()
+            e_main, e_side = torch.cuda.Event(), torch.cuda.Event()
+            e_main.record(cur); e_side.record(side)            # (the last DETR layer's weight-gradient launch sits on the second stream)
+            opt_st.wait_event(e_main); opt_st.wait_event(e_side)
+            with torch.cuda.stream(opt_st):
+                early_opt()
         # ---------------- temporal encoders (video on the second stream)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
@@ -1388,6 +1446,8 @@ class MadeTrainer(MadeEngine):
         self._encode_bwd("audio", ws, tw, dl_a, tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a,
                          dw_stream=side if os.environ.get("MADE_AUDIO_DW_SIDE", "1") != "0" else None)
         cur.wait_stream(side)
+        if opt_st is not None:
+            cur.wait_stream(opt_st)
 
     def _regression_train(self, out, ws, tw, mem3: Tensor, fus_mask: Tensor, v_duration, cur, side) -> Dict[str, Tensor]:
         """reference model/model_Uni.py:228-232,290-300 in train mode: memory summed over all L positions / number of valid ones ->
@@ -1719,14 +1779,21 @@ class TrainStepGraph:
         scale = 1.0 / self.dist.get_world_size() if self.dist is not None else 1.0
         i = self.inputs
 
+        early = self.dist is None and t._early_opt_ok()       # (opt-in: the step applied in two parts, see MadeTrainer.train_step)
+
         def fwd_bwd():
             out = t.forward_train(i["frame_feats"], i["segment_feats"], i["frame_masks"], i["segment_masks"], i["spans_target"], seed=0,
                                   v_duration=self.v_duration)
-            t.backward(None, None)
+            if early:
+                t.backward(None, None, early_opt=lambda: t.optimizer_step(0.0, 0.0, 0.0, max_grad_norm=max_grad_norm, grad_scale=scale,
+                                                                           device_state=self.adam_state, part="early"))
+            else:
+                t.backward(None, None)
             return out
 
         def opt():
-            t.optimizer_step(0.0, 0.0, 0.0, max_grad_norm=max_grad_norm, grad_scale=scale, device_state=self.adam_state)
+            t.optimizer_step(0.0, 0.0, 0.0, max_grad_norm=max_grad_norm, grad_scale=scale, device_state=self.adam_state,
+                             part="rest" if early else None)
 
         # warm-up run (loads the kernels, allocates the workspaces, creates the side streams) on a copy of the state
         keep = [x.clone() for x in (t.flat_param, t.exp_avg, t.exp_avg_sq)]

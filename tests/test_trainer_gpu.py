@@ -183,6 +183,62 @@ def test_optimizer_step_matches_torch_adam_with_group_clipping():
     assert torch.equal(P["xa.kv.w"], kv.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("device_state", [False, True])
+def test_optimizer_step_applied_in_two_parts_is_the_same_step(device_state):
+    """optimizer_step(part="early") (matching + detection groups) followed by part="rest" (temporal group) == one optimizer_step, bit
+    for bit -- masters, both Adam moments, the compute-dtype copies and the step count (device-side state included)."""
+    import ctypes as C
+    from mgsv_amd import _lib
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, inp = _setup(3, 20, 40)
+    a, b = MadeTrainer(cfg, sd, dtype="bf16"), MadeTrainer(cfg, sd, dtype="bf16")
+    lrs = (1e-3, 2e-3, 5e-4)
+    st = []
+    for _ in range(2):
+        t_ = torch.zeros(C.sizeof(_lib.MadeAdamDeviceState) // 8, device="cuda", dtype=torch.int64)
+        t_.view(torch.float32)[_lib.MadeAdamDeviceState.lr.offset // 4:][:3] = torch.tensor(lrs)
+        st.append(t_ if device_state else None)
+    for it in range(3):
+        a.loss_and_grads(inp, seed=10 + it)
+        b.flat_grad.copy_(a.flat_grad)
+        a.optimizer_step(*lrs, max_grad_norm=0.7, grad_scale=0.5, device_state=st[0])
+        b.optimizer_step(*lrs, max_grad_norm=0.7, grad_scale=0.5, device_state=st[1], part="early")
+        b.optimizer_step(*lrs, max_grad_norm=0.7, grad_scale=0.5, device_state=st[1], part="rest")
+        torch.cuda.synchronize()
+        assert a.opt_step == b.opt_step == it + 1 and a.generation == b.generation
+        assert torch.equal(a.flat_param, b.flat_param) and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+        for k in a.P:
+            if isinstance(a.P[k], torch.Tensor):
+                assert torch.equal(a.P[k], b.P[k]), k
+        if device_state:
+            assert torch.equal(st[0], st[1]) and int(st[0][0]) == it + 1
+    # every step moved every group
+    assert float((a.flat_param[:a.group_ranges[0][1]] - MadeTrainer(cfg, sd, dtype="bf16").flat_param[:a.group_ranges[0][1]]).abs().max()) > 0
+
+
+def test_train_step_with_the_early_optimizer_part_tracks_the_one_piece_step(monkeypatch):
+    """MADE_EARLY_OPT=1: train_step applies the matching + detection groups' update on a third stream under the temporal encoders'
+    backward; the default applies the step in one piece at the end: the same losses step after step (within what the f32 atomics of
+    the weight-gradient products let two runs differ by)."""
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, inp = _setup(8, 20, 40)
+    t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
+    curves = []
+    for early in ("1", "0"):
+        monkeypatch.setenv("MADE_EARLY_OPT", early)
+        trn = MadeTrainer(cfg, sd, dtype="bf16")
+        losses = []
+        for it in range(6):
+            o = trn.train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=it,
+                               lrs=(3e-4, 3e-4, 3e-4))
+            losses.append(float(o["retrieval_loss"]) + float(o["localization_loss"]))
+        torch.cuda.synchronize()
+        assert trn.opt_step == 6
+        curves.append(losses)
+    assert np.isfinite(curves).all()
+    assert np.allclose(curves[0], curves[1], rtol=2e-2, atol=2e-2), curves
+
+
 def test_training_reduces_the_loss():
     """a few optimiser steps on one batch (dropout on): the total loss goes down."""
     from mgsv_amd.trainer import MadeTrainer
