@@ -649,8 +649,6 @@ class MadeTrainer(MadeEngine):
                     ops.dec_stage(tw[f"d.{l - 1}.t_c"], Wsa[2 * D:], bsa[2 * D:], tw[d + ".att"], ln=(P[q_ + ".ln3.g"], P[q_ + ".ln3.b"]),
                                   x_out=tgt, **sa_drop)
                 ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
-                if os.environ.get("MADE_EXP_DUMMY") == "1":
-                    tr.add3(tw["dxpool_q"], tw["xpool_q"])
                 qc = ops.dec_stage(ta, Win[:D], bin_[:D], tw[d + ".qc"], ln=(P[p + ".ln1.g"], P[p + ".ln1.b"]), add=qp,
                                    x_out=tw[d + ".t1"], a_out=tw[d + ".t1q"])
             else:

@@ -617,6 +617,37 @@ def test_wide_attention_key_slices_and_lse(T, B, NQ, L, D, p):
     assert float((lse - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("N,K,batch", [(512, 512, 1), (512, 1024, 1), (64, 512, 8), (512, 128, 1)])
+def test_linear_16x16_tile_kernel_matches_the_default_one(T, N, K, batch, monkeypatch):
+    """MADE_LINEAR_TILE=16 (opt-in): at most 64 rows, 16 x 16 tiles; the same result as the 64 x 32-tile kernel up to the order of the
+    K sums, training epilogue (dropout, residual, pre-activation output) included -- the draws do not depend on the tiling."""
+    ops, tr = T
+    from mgsv_amd import _lib
+    M = 64
+    A = _rand(M, K * batch, dtype=torch.bfloat16, seed=1)
+    W = _rand(N * batch, K, dtype=torch.bfloat16, seed=2) * 0.1
+    bias = _rand(N * batch, dtype=torch.float32, seed=3)
+    R = _rand(M, N * batch, dtype=torch.bfloat16, seed=4)
+    outs = []
+    for tile in ("0", "16"):
+        monkeypatch.setenv("MADE_LINEAR_TILE", tile)
+        if batch == 1:
+            o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            z = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            ops.linear(A, W, bias, out=o, R=R, Zout=z, act=ops.ACT_RELU, drop=(11, 7, 0.2))
+            outs.append((o, z))
+        else:
+            o = torch.empty(M, N * batch, device="cuda", dtype=torch.bfloat16)
+            ops.linear(A[:, :K], W[:N], bias, M=M, N=N, K=K, batch=batch, a_z_stride=K, w_z_stride=N * K,
+                       segs=[ops.Seg(out=o, ldo=N * batch, out_z_stride=N)])
+            outs.append((o,))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert float((a_.float() - b_.float()).abs().max()) <= 2e-2 * max(1.0, float(a_.float().abs().max()))
+    keep0, keep1 = outs[0][0] == R, outs[1][0] == R                    # (dropped elements leave the residual alone)
+    if batch == 1:
+        assert float((keep0 != keep1).float().mean()) < 1e-3
+
+
 def test_linear_per_head_bias_scaled_by_a_row_factor(T):
     """made_linear's bias_row_scale (the value bias of the memory-space cross-attention under dropout: bias[h*hd + j] * s[row, h])
     against made_linear + made_head_bias."""

@@ -1,4 +1,6 @@
-"""first captured step against the eager step from the same state, repeated with fresh trainers: which outputs differ, where."""
+"""first captured step (launch tape / hipGraph) against the eager step from the same state, repeated with fresh trainers: which forward
+outputs, decoder buffers and (atomics-free) gradient stacks of the decoder's backward chain differ, and in which rows.
+usage: python tools/race_probe3.py [tape] [graph]   (N = repetitions per mode)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
