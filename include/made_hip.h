@@ -182,9 +182,9 @@ enum MadeLinearVariant {
     MADE_LINEAR_GLDS3 = 5,          /* linear_glds_kernel<3, ., 128>: at most one workgroup per CU, three LDS stages */
     MADE_LINEAR_GLDS64 = 6,         /* linear_glds_kernel<1, ., 64>: 64 x 128 tiles */
     MADE_LINEAR_GLDS128 = 7,        /* linear_glds_kernel<1, ., 128>: 128 x 128 tiles */
-    MADE_LINEAR_RING128 = 8,        /* linear_ring_kernel<128, 128>: two-stage LDS-DMA ring, one barrier per slab, two workgroups per CU */
-    MADE_LINEAR_TINY16 = 9          /* linear_t16_kernel: at most 64 rows, 16 x 16 tiles (a third of the bytes per workgroup), 128 <= K <= 1024;
-                                       opt-in (MADE_LINEAR_TILE=16), see csrc/linear.hip */
+    MADE_LINEAR_RING128 = 8,        /* linear_ring_kernel<128, 128>: two-stage LDS-DMA ring, one barrier per slab, two workgroups per CU;
+                                       opt-in since round 3 (MADE_LINEAR_TILE=2128): rare garbage rows beside a second stream, see csrc/linear.hip */
+    MADE_LINEAR_TINY16 = 9          /* linear_t16_kernel: at most 64 rows, 16 x 16 tiles (a third of the bytes per workgroup), 128 <= K <= 1024 */
 };
 int made_linear_variant(const MadeLinearArgs* args);
 

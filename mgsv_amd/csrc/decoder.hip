@@ -8,17 +8,20 @@
 //     x2 = LayerNorm2(x)             optional (the decoder's shared output norm -> hs[l - 1])
 //     A  = x (+ add)                 bf16, e.g. + query_pos
 //     out = act(A W^T + bias) (+ R | + x)   f32 raw rows for the next norm, or bf16
-// computed by N / 32 workgroups of 64 rows x 32 columns; every workgroup normalises the rows itself (64 x 512 f32 = 128 KB from
-// L2, under the flight of its own weight fragments), the rows r with r % gridDim.x == blockIdx.x are also written out as x / x2
-// (the residual of a later stage, the decoder output).  No split-K, no finish launch, no partial sums in HBM: 8 launches per
-// layer.  The four waves split K four ways (as linear_tiny_kernel does): weight fragments come straight from global memory
-// (16 contiguous bytes of one row per lane), A fragments from the normalised LDS tile, partial tiles meet in LDS.
+// computed by (N / 16) x (M / 16) workgroups of 16 rows x 16 columns; every workgroup normalises its 16 rows itself (under the
+// flight of its own weight fragments), the rows r with r % gridDim.x == blockIdx.x are also written out as x / x2 (the residual of a
+// later stage, the decoder output).  No split-K, no finish launch, no partial sums in HBM.  The four waves split K four ways (as
+// linear_t16_kernel does, v_mfma_f32_16x16x32_bf16): weight fragments come straight from global memory (16 contiguous bytes of one
+// row per lane), A fragments from the normalised LDS tile, partial tiles meet in LDS.
+// Tile size (round 3): such a stage costs t = 3.4 us + (bytes ONE workgroup pulls in) / ~33 GB/s -- the arithmetic is nothing -- so
+// the 64 x 32 tiles of round 2 (64 KB of rows + 32 KB of weights per workgroup at K = 512) became 16 x 16 (16 + 16 KB) with eight
+// times as many workgroups; the column tiles that share a weight slice are blockIdx.x apart = on one XCD under the observed placement.
 #include "common.h"
 #include <type_traits>
 
 namespace {
 
-constexpr int DS_BM = 64, DS_BN = 32, DS_THREADS = 512, DS_RPW = 8, DS_CT_LD = DS_BN + 4;   // 8 waves, 8 rows each in the prologue
+constexpr int DS_BM = 16, DS_BN = 16, DS_THREADS = 256, DS_RPW = 4, DS_CT_LD = DS_BN + 4;   // 4 waves, 4 rows each in the prologue
 
 __device__ __forceinline__ float ds_act(float x, int act) {   // (ReLU is all the decoder uses; erf / exp code would double the kernel)
     return act == MADE_ACT_RELU ? fmaxf(x, 0.f) : x;
@@ -31,29 +34,27 @@ template <int NV, bool ZB16, bool TRAIN>                        // K = 64 * NV (
 __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStageArgs a) {
     constexpr int K = 64 * NV;
     constexpr int LDA = K * 2 + 16;                             // bytes per row of the LDS A tile (padded: conflict-free 16-byte reads)
-    constexpr int STEPS = NV;                                   // 16-deep MFMA k-steps per wave (K / 4 / 16)
-    extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
+    constexpr int STEPS = NV / 2;                               // 32-deep MFMA k-steps per wave (K / 4 / 32)
+    __shared__ __attribute__((aligned(16))) unsigned char dlds[DS_BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Ct[4 * DS_BM * DS_CT_LD];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
+    const int r16 = lane & 15, kq = lane >> 4;
     const int M = (int)a.M, N = (int)a.N;
     const int n0 = blockIdx.x * DS_BN, m0 = blockIdx.y * DS_BM;
 
     // What such a one-shot kernel pays for is dependent memory round trips (about 1 us each, and vmcnt counts STORES too: a load
     // issued after a store waits for the store to retire) and spills.  Hence: every global load is requested before the first
-    // wait, every global store of the prologue comes after its last load, and 8 waves (256 registers each) share the 64 rows.
-    // ---- 1. the GEMM waves' weight fragments (a quarter of K each), in flight before anything else
-    const int gw = wave & 3;
-    const int kw = gw * (K / 4) + hh * 8;
-    int gn = n0 + r; gn = gn < N ? gn : N - 1;
+    // wait, every global store of the prologue comes after its last load.
+    // ---- 1. this wave's weight fragments (a quarter of K), in flight before anything else
+    const int kw = wave * (K / 4) + kq * 8;
+    int gn = n0 + r16; gn = gn < N ? gn : N - 1;
     const bf16_t* pw = (const bf16_t*)a.W + (int64_t)gn * a.ldw + kw;
     bf16x8 fw[STEPS];
-    if (wave < 4) {
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) fw[s] = *(const bf16x8*)(pw + s * 16);
-    }
+    for (int s = 0; s < STEPS; ++s) fw[s] = *(const bf16x8*)(pw + s * 32);
 
-    // ---- 2. LayerNorm prologue: wave w normalises rows 8w .. 8w + 7, all 64 lanes on one row at a time (lane l: columns
+    // ---- 2. LayerNorm prologue: wave w normalises rows 4w .. 4w + 3, all 64 lanes on one row at a time (lane l: columns
     // NV*l .. NV*l + NV - 1): the norm parameters of a lane's columns are loaded once and shared by its rows, the rows' reductions
     // are independent chains the scheduler interleaves.
     constexpr int RPW = DS_RPW;
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
             *(bf16x4*)(dlds + rl * LDA + c0 * 2) = t;
         }
     }
-    // the epilogue's inputs (thread t < 256 finishes row t / 4, 8 columns)
-    const int cc = tid & 3, row = (tid >> 2) & 63;
+    // the epilogue's inputs (thread t < 32 finishes row t / 2, 8 columns)
+    const int cc = tid & 1, row = (tid >> 1) & 15;
     const int n = n0 + cc * 8;
     int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
     const int ml = m0 + row;
@@ -220,44 +221,32 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_kernel(const MadeDecStag
         }
     }
     __syncthreads();
-    const bool gemm_wave = wave < 4;                            // waves 4-7 only keep the barriers company from here on
 
-    // ---- 3. 64 x 32 partial tile of this wave's K quarter
-    f32x16 acc[2];
+    // ---- 3. 16 x 16 partial tile of this wave's K quarter (C layout: lane (r16, kq) holds rows 4 kq .. 4 kq + 3 of column r16)
+    f32x4 acc;
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    if (gemm_wave) {
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const bf16x8 fa0 = *(const bf16x8*)(dlds + r * LDA + (kw + s * 16) * 2);
-            const bf16x8 fa1 = *(const bf16x8*)(dlds + (r + 32) * LDA + (kw + s * 16) * 2);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fw[s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fw[s], acc[1], 0, 0, 0);
-        }
+    for (int s = 0; s < STEPS; ++s) {
+        const bf16x8 fa = *(const bf16x8*)(dlds + r16 * LDA + (kw + s * 32) * 2);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fw[s], acc, 0, 0, 0);
     }
 
     // ---- 4. the four partial tiles meet in LDS; bias, activation, residual, store
     float xres[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) xres[j] = 0.f;
-    if (gemm_wave && a.res_from_x && n + 8 <= K) {              // residual = the normalised input itself (N == K): still in the A tile
+    if (a.res_from_x && n + 8 <= K) {                           // residual = the normalised input itself (N == K): still in the A tile
         const bf16x8 t = *(const bf16x8*)(dlds + row * LDA + n * 2);
 #pragma unroll
         for (int j = 0; j < 8; ++j) xres[j] = (float)t[j];
     }
-    __syncthreads();                                            // everyone is done with the A tile: the partials take its place
-    float* Ct = (float*)dlds;
-    if (gemm_wave) {
+    {
         float* mine = Ct + wave * (DS_BM * DS_CT_LD);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mine[(t * 32 + acc_row(e, hh)) * DS_CT_LD + r] = acc[t][e];
+        for (int e = 0; e < 4; ++e) mine[(kq * 4 + e) * DS_CT_LD + r16] = acc[e];
     }
     __syncthreads();
-    if (!gemm_wave || nvalid <= 0 || ml >= M) return;
+    if (tid >= 32 || nvalid <= 0 || ml >= M) return;
     float v8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v8[j] = 0.f;
@@ -385,29 +374,27 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDec
     constexpr bool TWO = MODE == 2, ADD1 = MODE == 1;
     constexpr int K = 64 * NV;
     constexpr int LDA = K * 2 + 16;
-    constexpr int STEPS = NV;
-    constexpr int TILE_BYTES = (DS_BM * LDA > 4 * DS_BM * DS_CT_LD * 4) ? DS_BM * LDA : 4 * DS_BM * DS_CT_LD * 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
-    float* pgrad = (float*)(dlds + TILE_BYTES);                  // [8 waves][4 vectors][K]: parameter-gradient partials (workgroup x = 0 only)
+    constexpr int STEPS = NV / 2;                               // 32-deep MFMA k-steps per wave (K / 4 / 32)
+    __shared__ __attribute__((aligned(16))) unsigned char dlds[DS_BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Ct[4 * DS_BM * DS_CT_LD];
+    __shared__ float pgrad[4 * (TWO ? 4 : 2) * K];              // [4 waves][2 or 4 vectors][K]: parameter-gradient partials (workgroups x = 0 only)
+    constexpr int PV = TWO ? 4 : 2;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
+    const int r16 = lane & 15, kq = lane >> 4;
     const int M = (int)a.M, N = (int)a.N;
     const int n0 = blockIdx.x * DS_BN, m0 = blockIdx.y * DS_BM;
     constexpr bool two = TWO;
 
-    // ---- 1. weight fragments (a quarter of K per GEMM wave), in flight before anything else
-    const int gw = wave & 3;
-    const int kw = gw * (K / 4) + hh * 8;
-    int gn = n0 + r; gn = gn < N ? gn : N - 1;
+    // ---- 1. this wave's weight fragments (a quarter of K), in flight before anything else
+    const int kw = wave * (K / 4) + kq * 8;
+    int gn = n0 + r16; gn = gn < N ? gn : N - 1;
     const bf16_t* pw = (const bf16_t*)a.W + (int64_t)gn * a.ldw + kw;
     bf16x8 fw[STEPS];
-    if (wave < 4) {
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) fw[s] = *(const bf16x8*)(pw + s * 16);
-    }
-    // the epilogue's inputs (thread t < 256 finishes row t / 4, 8 columns)
-    const int cc = tid & 3, row = (tid >> 2) & 63;
+    for (int s = 0; s < STEPS; ++s) fw[s] = *(const bf16x8*)(pw + s * 32);
+    // the epilogue's inputs (thread t < 32 finishes row t / 2, 8 columns)
+    const int cc = tid & 1, row = (tid >> 1) & 15;
     const int n = n0 + cc * 8;
     int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
     const int ml = m0 + row;
@@ -419,7 +406,7 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDec
     if (r_vec) rpre = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)mlc * a.ldr + n);
     if (g_vec) gpre = *(const bf16x8*)((const bf16_t*)a.G + (int64_t)mlc * a.ldg + n);
 
-    // ---- 2. LayerNorm backward of this wave's 8 rows (lane l: columns NV*l .. NV*l + NV - 1)
+    // ---- 2. LayerNorm backward of this wave's 4 rows (lane l: columns NV*l .. NV*l + NV - 1)
     const int c0 = NV * lane;
     float gma[NV], gmb[NV];
 #pragma unroll
@@ -502,51 +489,41 @@ __global__ __launch_bounds__(DS_THREADS) void dec_stage_bwd_kernel(const MadeDec
             if (a.a_out) dsb_store_row<NV>(a.a_out, (int64_t)gm * a.lda_out + c0, od);
         }
     }
-    // parameter gradients: the eight waves' column partials of workgroup x = 0 meet in LDS, one atomic per column
+    // parameter gradients: the four waves' column partials of the workgroups x = 0 (one per 16 rows) meet in LDS, one atomic per column
     if (blockIdx.x == 0) {
-        float* mine = pgrad + wave * 4 * K;
+        float* mine = pgrad + wave * PV * K;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { mine[c0 + j] = dga[j]; mine[K + c0 + j] = dba[j]; mine[2 * K + c0 + j] = dgb[j]; mine[3 * K + c0 + j] = dbb[j]; }
+        for (int j = 0; j < NV; ++j) {
+            mine[c0 + j] = dga[j]; mine[K + c0 + j] = dba[j];
+            if constexpr (TWO) { mine[2 * K + c0 + j] = dgb[j]; mine[3 * K + c0 + j] = dbb[j]; }
+        }
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
-        const int nvec = two ? 4 : 2;
-        for (int c = tid; c < nvec * K; c += DS_THREADS) {
+
+    // ---- 3. 16 x 16 partial tile of this wave's K quarter (C layout: lane (r16, kq) holds rows 4 kq .. 4 kq + 3 of column r16)
+    f32x4 acc;
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const bf16x8 fa = *(const bf16x8*)(dlds + r16 * LDA + (kw + s * 32) * 2);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fw[s], acc, 0, 0, 0);
+    }
+    {
+        float* mine = Ct + wave * (DS_BM * DS_CT_LD);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine[(kq * 4 + e) * DS_CT_LD + r16] = acc[e];
+    }
+    if (blockIdx.x == 0) {                                      // (after the MFMAs are issued: the atomics' round trip is nobody's business)
+        for (int c = tid; c < PV * K; c += DS_THREADS) {
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) t += pgrad[w * 4 * K + c];
+            for (int w = 0; w < 4; ++w) t += pgrad[w * PV * K + c];
             float* dst = c < K ? a.dgamma_a : (c < 2 * K ? a.dbeta_a : (c < 3 * K ? a.dgamma_b : a.dbeta_b));
             if (dst) unsafeAtomicAdd(dst + (c % K), t);
         }
     }
-    const bool gemm_wave = wave < 4;
-
-    // ---- 3. 64 x 32 partial tile of this wave's K quarter
-    f32x16 acc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    if (gemm_wave) {
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const bf16x8 fa0 = *(const bf16x8*)(dlds + r * LDA + (kw + s * 16) * 2);
-            const bf16x8 fa1 = *(const bf16x8*)(dlds + (r + 32) * LDA + (kw + s * 16) * 2);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fw[s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fw[s], acc[1], 0, 0, 0);
-        }
-    }
-    __syncthreads();                                            // everyone is done with the A tile: the partials take its place
-    float* Ct = (float*)dlds;
-    if (gemm_wave) {
-        float* mine = Ct + wave * (DS_BM * DS_CT_LD);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mine[(t * 32 + acc_row(e, hh)) * DS_CT_LD + r] = acc[t][e];
-    }
     __syncthreads();
-    if (!gemm_wave || nvalid <= 0 || ml >= M) return;
+    if (tid >= 32 || nvalid <= 0 || ml >= M) return;
 
     // ---- 4. the four partial tiles meet; gate, dropout, residual, store
     float v8[8];
@@ -616,23 +593,13 @@ extern "C" int made_dec_stage_bwd(const MadeDecStageBwdArgs* args, void* stream)
     const dim3 grid((unsigned)((a.N + DS_BN - 1) / DS_BN), (unsigned)((a.M + DS_BM - 1) / DS_BM)), block(DS_THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (a.K == 512) {
-        constexpr int LDSB = DS_BM * (512 * 2 + 16) + 8 * 4 * 512 * 4;
-        static const bool once = hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
-                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
-                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
-        (void)once;
-        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 2>), grid, block, LDSB, st, a);
-        else if (a.add) hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 1>), grid, block, LDSB, st, a);
-        else hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 0>), grid, block, LDSB, st, a);
+        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 2>), grid, block, 0, st, a);
+        else if (a.add) hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((dec_stage_bwd_kernel<8, 0>), grid, block, 0, st, a);
     } else {
-        constexpr int LDSB = 4 * DS_BM * DS_CT_LD * 4 + 8 * 4 * 256 * 4;
-        static const bool once = hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
-                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
-                                 hipFuncSetAttribute((const void*)dec_stage_bwd_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
-        (void)once;
-        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 2>), grid, block, LDSB, st, a);
-        else if (a.add) hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 1>), grid, block, LDSB, st, a);
-        else hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 0>), grid, block, LDSB, st, a);
+        if (a.xb) hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 2>), grid, block, 0, st, a);
+        else if (a.add) hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((dec_stage_bwd_kernel<4, 0>), grid, block, 0, st, a);
     }
     return made_check_launch("made_dec_stage_bwd");
 }
@@ -663,16 +630,11 @@ extern "C" int made_dec_stage(const MadeDecStageArgs* args, void* stream) {
     const dim3 grid((unsigned)((a.N + DS_BN - 1) / DS_BN), (unsigned)((a.M + DS_BM - 1) / DS_BM)), block(DS_THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (a.K == 512) {
-        constexpr int LDSB = DS_BM * (512 * 2 + 16);
-        static const bool once = hipFuncSetAttribute((const void*)dec_stage_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
-                                 hipFuncSetAttribute((const void*)dec_stage_kernel<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
-        (void)once;
-        if (tr) hipLaunchKernelGGL((dec_stage_kernel<8, true, true>), grid, block, LDSB, st, a);
-        else hipLaunchKernelGGL((dec_stage_kernel<8, false, false>), grid, block, LDSB, st, a);
+        if (tr) hipLaunchKernelGGL((dec_stage_kernel<8, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((dec_stage_kernel<8, false, false>), grid, block, 0, st, a);
     } else {
-        constexpr int LDSB = 4 * DS_BM * DS_CT_LD * 4;          // the partial tiles are larger than the 256-wide A tile
-        if (tr) hipLaunchKernelGGL((dec_stage_kernel<4, true, true>), grid, block, LDSB, st, a);
-        else hipLaunchKernelGGL((dec_stage_kernel<4, false, false>), grid, block, LDSB, st, a);
+        if (tr) hipLaunchKernelGGL((dec_stage_kernel<4, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((dec_stage_kernel<4, false, false>), grid, block, 0, st, a);
     }
     return made_check_launch("made_dec_stage");
 }

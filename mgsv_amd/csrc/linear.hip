@@ -1367,13 +1367,6 @@ __global__ __launch_bounds__(NTHREADS) void linear_tiny_kernel(const MadeLinearA
 // one row each, up to 16 loads) are requested before the first wait, the four partial tiles meet in LDS and 32 lanes finish one row
 // x 8 columns each with epilogue8 (the element order of the dropout draws etc. does not depend on the tiling).
 // Workgroups b and b + 8 share an XCD (observed dispatch order; speed only): the row tiles of one weight slice are put there.
-// OPT-IN (MADE_LINEAR_TILE=16), not the default: with this kernel (and the 16-row decoder stages built the same way) the training step
-// measured 5.34 ms instead of 5.8 ms -- but with TWO streams of work resident on the chip (two eval batches in flight; the forked query
-// side of decoder layer 0 beside the DETR encoder) about 1 % of the forward passes came out with a damaged row somewhere else: garbage
-// rows in an LDS-staged GEMM epilogue of the OTHER stream, or a 64-row stage a few ulps off in one row.  Inputs, weights, the LDS tiles
-// and a repeated product were all checked identical inside the kernels, the register and LDS budgets in the kernel descriptors match the
-// code, padding the LDS or the wait states did not help, the 64 x 32-tile kernels never show it (0 of 8000 two-batch replays): not
-// explained (tools/race_probe_eval.py, tools/race_probe3.py, tools/race_probe5.py reproduce it).
 constexpr int U_BM = 16, U_BN = 16, U_CT_LD = U_BN + 4;
 
 template <bool TRAIN, int SPW>                             // SPW: 32-deep K steps per wave (K <= 128 * SPW)
@@ -1499,8 +1492,8 @@ static void launch_t16(const MadeLinearArgs& a, hipStream_t st) {
 }  // namespace
 
 // tuning knob for the micro-benchmarks and tests: MADE_LINEAR_TILE=64|128 forces the single-stage direct-to-LDS kernels of round 1,
-// 2128 | 2256 the ring kernel's tile (default: 128 x 128 ring), 1000 round 1's choice between its two kernels, 16 lets launches of at
-// most 64 rows use the 16 x 16-tile kernel (linear_t16_kernel: opt-in)
+// 2128 the ring kernel (opt-in, see pick_variant), 1000 round 1's choice between its two kernels, 32 the 64 x 32-tile kernel where the
+// 16 x 16-tile one is the default (at most 64 rows)
 static int tile_pref() {                                   // read on every call: the tests switch kernels inside one process
     const char* e = getenv("MADE_LINEAR_TILE");
     return e ? atoi(e) : 0;
@@ -1518,8 +1511,9 @@ static int pick_variant(const MadeLinearArgs& a) {
     const int64_t tiles64 = ((a.M + S_BM - 1) / S_BM) * ((a.N + S_BN - 1) / S_BN);
     const int64_t tiles32 = ((a.M + T_BM - 1) / T_BM) * ((a.N + T_BN - 1) / T_BN);
     // one 64-row tile (the decoder's chain, its per-head batches): 16 x 16 tiles, a third of the bytes per workgroup
-    // (opt-in, MADE_LINEAR_TILE=16: see the note at linear_t16_kernel -- faster, and withdrawn from the default path)
-    if (tile_pref() == 16 && a.M <= 64 && a.K >= 128 && a.K <= 1024 && a.K % 32 == 0 && a.tile_skip_mask == nullptr &&
+    // one 64-row tile (the decoder's chain, its per-head batches): 16 x 16 tiles, a third of the bytes per workgroup
+    // (MADE_LINEAR_TILE=32: the 64 x 32-tile kernel instead, for A/B measurements)
+    if (a.M <= 64 && a.K >= 128 && a.K <= 1024 && a.K % 32 == 0 && a.tile_skip_mask == nullptr && tile_pref() != 1 && tile_pref() != 32 &&
         ((a.M + 15) / 16) * ((a.N + 15) / 16) * a.batch <= 4096)
         return MADE_LINEAR_TINY16;
     if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) return MADE_LINEAR_TINY;
@@ -1532,7 +1526,13 @@ static int pick_variant(const MadeLinearArgs& a) {
     // (eval epilogues only: with two workgroups per CU the training epilogue's dropout hash / GELU' are not hidden: 90-124 us against
     // round 1's 48-70 us on the same launches, profiles/r02_b_train_trace_summary.txt)
     const bool train_epi = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
-    if (tile_pref() == 2128 || (tile_pref() == 0 && a.row_index && a.N <= 512 && !train_epi)) return MADE_LINEAR_RING128;
+    // NOT the default any more (round 3): with a second stream of work resident on the chip (two eval batches in flight; the training
+    // step's second stream) about 0.5 % of the forward passes had GARBAGE ROWS in one 128-row tile of a ring-kernel launch -- eight
+    // rows of the A slab (rows 8 / 20 of every 32, the same 128-byte pieces of the same LDS-DMA instructions in all four waves) --
+    // 24 of 5000 two-batch replays with the ring kernel, 0 of 5000 with any of the other kernels in its place (tools/race_probe_eval.py).
+    // The loop follows the ordering rules for LDS-DMA (counted vmcnt, then a barrier, then the reads); not explained, so: opt-in.
+    (void)train_epi;
+    if (tile_pref() == 2128) return MADE_LINEAR_RING128;
     // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
     const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
     if (tile_pref() == 64) return MADE_LINEAR_GLDS64;

@@ -75,7 +75,7 @@ def test_linear_basic(dev, mode, M, N, K, act):
         np.testing.assert_allclose(outb.float().cpu().numpy(), ref.numpy(), atol=BF16_TOL, rtol=2e-2)
 
 
-@pytest.mark.parametrize("tile", [0, 128, 64])
+@pytest.mark.parametrize("tile", [0, 128, 64, 2128])
 @pytest.mark.parametrize("M,N,gather", [(20000, 512, False), (33000, 1024, False), (40960, 512, True), (16385, 1024, False)])
 def test_linear_encoder_sized(dev, M, N, gather, tile, monkeypatch):
     """Encoder-sized bf16 Linears (tens of thousands of rows, K = 512: the LDS-DMA ring kernel at both tile sizes and round 1's

@@ -619,8 +619,8 @@ def test_wide_attention_key_slices_and_lse(T, B, NQ, L, D, p):
 
 @pytest.mark.parametrize("N,K,batch", [(512, 512, 1), (512, 1024, 1), (64, 512, 8), (512, 128, 1)])
 def test_linear_16x16_tile_kernel_matches_the_default_one(T, N, K, batch, monkeypatch):
-    """MADE_LINEAR_TILE=16 (opt-in): at most 64 rows, 16 x 16 tiles; the same result as the 64 x 32-tile kernel up to the order of the
-    K sums, training epilogue (dropout, residual, pre-activation output) included -- the draws do not depend on the tiling."""
+    """at most 64 rows: 16 x 16 tiles (the default) against the 64 x 32-tile kernel (MADE_LINEAR_TILE=32): the same result up to the
+    order of the K sums, training epilogue (dropout, residual, pre-activation output) included -- the draws do not depend on the tiling."""
     ops, tr = T
     from mgsv_amd import _lib
     M = 64
@@ -629,7 +629,7 @@ def test_linear_16x16_tile_kernel_matches_the_default_one(T, N, K, batch, monkey
     bias = _rand(N * batch, dtype=torch.float32, seed=3)
     R = _rand(M, N * batch, dtype=torch.bfloat16, seed=4)
     outs = []
-    for tile in ("0", "16"):
+    for tile in ("32", "0"):
         monkeypatch.setenv("MADE_LINEAR_TILE", tile)
         if batch == 1:
             o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
