@@ -359,8 +359,12 @@ class MadeTrainer(MadeEngine):
                    music_ids=None, v_duration: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """One iteration of the reference's loop body (train-MaDe.py:337-381): forward, backward, (data-parallel gradient
         average: one RCCL all-reduce of the flat buffer), clip + Adam, repack."""
-        out = self.forward_train(frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed=seed, music_ids=music_ids,
-                                 v_duration=v_duration)
+        self._zero_grad_in_forward = True
+        try:
+            out = self.forward_train(frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed=seed, music_ids=music_ids,
+                                     v_duration=v_duration)
+        finally:
+            self._zero_grad_in_forward = False
         scale = 1.0
         if dist is not None and dist.get_world_size() > 1:
             # two buckets of the flat f32 gradient buffer (RCCL all-reduce, sum; the 1/W goes into the optimizer's grad_scale): the
@@ -474,7 +478,7 @@ class MadeTrainer(MadeEngine):
             ones_bb=torch.ones(B, B, device=self.device, dtype=f32),
             dsims_s=E(B, B, dtype=f32), dsims_d=E(B, B, dtype=f32), dsims_dt=E(B, B, dtype=f32), clip_ws=E(2 * B, dtype=f32),
             sims_both=E(B, B, dtype=f32), sd_ws=E(16 * B * B, dtype=f32),
-            dvideo=E(B, D, dtype=f32), dmusic=E(B, D, dtype=f32),
+            dclip=E(2 * B * D + B * max(c.contrastive_hdim, 1), dtype=f32),   # dvideo | dmusic | dvid_sum: zeroed by ONE fill per backward
             # DETR encoder
             e_delta=E(B * H * L, dtype=f32), eg1=E(rows, D), eg2=E(rows, D), eg2b=E(rows, D), eg3=E(rows, D), eg3b=E(rows, D), eg3c=E(rows, D),
             egqkv=E(rows, 3 * D), egffn=E(rows, Fd),
@@ -492,6 +496,7 @@ class MadeTrainer(MadeEngine):
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D), hg1=E(nd * B * Q, D), hg2=E(nd * B * Q, D),
             dlog=Z(nd * B * Q, HEAD_PAD, dtype=f32), dsp=Z(nd * B * Q, HEAD_PAD, dtype=f32), dlog_c=Z(nd * B * Q, HEAD_PAD), dsp_c=Z(nd * B * Q, HEAD_PAD),
         )
+        ws["dvideo"], ws["dmusic"] = ws["dclip"][:B * D].view(B, D), ws["dclip"][B * D:2 * B * D].view(B, D)
         if "video" in c.vmr_fusion:                             # second X-Pool tower: music vectors attend to the frames ("y" = "x" with S = T_v)
             Svp = round_up(Tv, 8)
             ws.update(
@@ -533,7 +538,7 @@ class MadeTrainer(MadeEngine):
             if c.audio_short_cut:                             # normalize(normalize(p) + music), a second time for the auxiliary layers
                 ws.update(pq_n0=E(nd * B * Q, Dc, dtype=f32), pq_s1=E(nd * B * Q, Dc, dtype=f32), pq_s2=E(nd * B * Q, Dc, dtype=f32),
                           dpq_s=E(nd * B * Q, Dc, dtype=f32), dpq_s2=E(nd * B * Q, Dc, dtype=f32))
-            ws.update(dpq=E(nd * B * Q, Dc, dtype=f32), dvid_sum=E(B, Dc, dtype=f32), dpq_raw=E(nd * B * Q, Dc), dpv_raw=E(B * Tv, Dc),
+            ws.update(dpq=E(nd * B * Q, Dc, dtype=f32), dvid_sum=ws["dclip"][2 * B * D:2 * B * D + B * Dc].view(B, Dc), dpq_raw=E(nd * B * Q, Dc), dpv_raw=E(B * Tv, Dc),
                       dframe_x=E(B * Tv, D))
         self._tws[key] = ws
         return ws
@@ -676,6 +681,12 @@ class MadeTrainer(MadeEngine):
         # ---- X-Pool (in-batch) + similarities + retrieval loss
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            if getattr(self, "_zero_grad_in_forward", False):
+                # train_step: the 120 MB fill of the gradient buffer that opens the backward pass runs here, on the second stream beside
+                # the DETR encoder (the previous step's optimizer is behind us on the main stream; nothing writes a gradient before the
+                # streams join at the end of the forward)
+                _tape.zero_(self.flat_grad)
+                self._grads_zeroed = True
             if (Q == 1 and not regression and c.moment_query_type != "xpool" and c.detr_enc_layers > 0
                     and os.environ.get("MADE_DEC_EARLY", "0") == "1"):
                 # (opt-in, MADE_DEC_EARLY=1) the query side of decoder layer 0 depends on the clip-level vector and the weights only: here,
@@ -1102,10 +1113,11 @@ class MadeTrainer(MadeEngine):
         if regression:
             fskip = qskip = None
         rows = B * L
-        if zero_grad:
+        if zero_grad and not getattr(self, "_grads_zeroed", False):
             _tape.zero_(self.flat_grad)
+        self._grads_zeroed = False
         dvideo, dmusic = tw["dvideo"], tw["dmusic"]
-        _tape.zero_(dvideo); _tape.zero_(dmusic)
+        _tape.zero_(tw["dclip"])                              # dvideo, dmusic and the contrastive head's dvid_sum in one fill
         video, music = ws["video"], ws["music"]
         frame, seg_view = self._views
         # the X-Pool / similarity branch is independent of the DETR stack until the temporal encoders: its (latency-bound)
@@ -1128,8 +1140,6 @@ class MadeTrainer(MadeEngine):
             pi, ti, cnt = self._match
             pq = ws["pq"] if c.contrastive_align_loss else None
             vid_sum = ws["vid_sum"] if c.contrastive_align_loss else None
-            if c.contrastive_align_loss:
-                _tape.zero_(tw["dvid_sum"])
             tr.set_criterion_bwd(logits, spans, tg, pi, ti, cnt, pq, vid_sum, P["empty_weight"], c.foreground_label, P["crit_weights"], g_loc,
                                  tw["dlog"], tw["dsp"], tw["dpq"] if pq is not None else None, tw["dvid_sum"] if pq is not None else None,
                                  ld_out=HEAD_PAD, through_sigmoid=True)
@@ -1786,8 +1796,12 @@ class TrainStepGraph:
         early = self.dist is None and t._early_opt_ok()       # (opt-in: the step applied in two parts, see MadeTrainer.train_step)
 
         def fwd_bwd():
-            out = t.forward_train(i["frame_feats"], i["segment_feats"], i["frame_masks"], i["segment_masks"], i["spans_target"], seed=0,
-                                  v_duration=self.v_duration)
+            t._zero_grad_in_forward = True
+            try:
+                out = t.forward_train(i["frame_feats"], i["segment_feats"], i["frame_masks"], i["segment_masks"], i["spans_target"], seed=0,
+                                      v_duration=self.v_duration)
+            finally:
+                t._zero_grad_in_forward = False
             if early:
                 t.backward(None, None, early_opt=lambda: t.optimizer_step(0.0, 0.0, 0.0, max_grad_norm=max_grad_norm, grad_scale=scale,
                                                                            device_state=self.adam_state, part="early"))
