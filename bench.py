@@ -497,6 +497,12 @@ def eval_leg(args, rank, world, local, dist, dtype: str, n_lanes: int, steps: in
         with torch.cuda.stream(lane_stream[l]):
             graphs[l].replay() if graphs else step(l)
 
+    # the GPU idles through a CPU baseline or a capture in front of this leg and starts its next second of work at low clocks: bring it
+    # to its working state before the W warmup steps (as the training leg does)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.75:
+        run()
+    torch.cuda.synchronize()
     for _ in range(warmup):
         run()
     _barrier(dist)

@@ -183,7 +183,7 @@ enum MadeLinearVariant {
     MADE_LINEAR_GLDS64 = 6,         /* linear_glds_kernel<1, ., 64>: 64 x 128 tiles */
     MADE_LINEAR_GLDS128 = 7,        /* linear_glds_kernel<1, ., 128>: 128 x 128 tiles */
     MADE_LINEAR_RING128 = 8,        /* linear_ring_kernel<128, 128>: two-stage LDS-DMA ring, one barrier per slab, two workgroups per CU;
-                                       opt-in since round 3 (MADE_LINEAR_TILE=2128): rare garbage rows beside a second stream, see csrc/linear.hip */
+                                       opt-in since round 3 (MADE_LINEAR_TILE=2128), see csrc/linear.hip */
     MADE_LINEAR_TINY16 = 9          /* linear_t16_kernel: at most 64 rows, 16 x 16 tiles (a third of the bytes per workgroup), 128 <= K <= 1024 */
 };
 int made_linear_variant(const MadeLinearArgs* args);

@@ -124,7 +124,7 @@ __device__ __forceinline__ void gemm_tn_glds_body(const GtProblem a, const GtSha
     issue(0);
     for (int64_t i = 0; i < nloc; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slab i (the only one in flight) has landed
-        asm volatile("s_barrier" ::: "memory");             // every wave's part landed; everyone is done with the other stage
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // every wave's part landed; everyone is done with the other stage
         if (i + 1 < nloc) issue(i + 1);
         unsigned char* st = lds + (i % GT_NST) * GT_STAGE;
         const int64_t g = split_y + i * sstep;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
     issue(0, si, cur);
     for (int64_t u = u0, n = 0; u < u1; ++u, ++n) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this unit's slab (the only one in flight) has landed
-        asm volatile("s_barrier" ::: "memory");             // every wave's part landed; everyone is done with the other stage
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // every wave's part landed; everyone is done with the other stage
         const bool last_of_tile = si + 1 == S;
         if (u + 1 < u1) {
             if (last_of_tile) { nxt = t2_tile(g, tile + 1); issue(n + 1, 0, nxt); }

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 5 : 4) : 1) void 
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (kt + 2 < nk) issue(kt + 2, lds + ((kt + 2) % NST) * STAGE);
             multiply(lds + (kt % NST) * STAGE);
         }
@@ -939,14 +939,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void linear_ring_kernel(const Made
 
     // slab kt lives in stage kt & 1.  Per iteration: wait for slab kt (the only one in flight), barrier (everyone's pieces have landed AND
     // everyone is done reading the other stage), send slab kt + 1 into that other stage, multiply slab kt under its flight.
+    // The barrier is `s_waitcnt lgkmcnt(0); s_barrier` (round 3): hipcc ties the wait for a fragment's ds_read to the MFMA that consumes
+    // it, and it may schedule those MFMAs BEHIND this asm statement -- a wave then passes the barrier with fragment reads of the old slab
+    // still queued in the LDS unit, the next slab's LDS-DMA lands in that stage first, and the MFMA multiplies rows of the wrong slab.
+    // Rare (the reads usually run hundreds of cycles ahead of the DMA) and dependent on what else keeps the CU's LDS busy: with two
+    // batches in flight 0.5-0.8 % of the forward passes had garbage rows in one tile (tools/race_probe_eval.py; 0 of 8000 with the
+    // wait, and 0 of 5000 with the same loop staging through registers, where the compiler sees the dependency itself).  The same
+    // wait now sits in front of every raw barrier of the LDS-DMA kernels (this one, the three-stage and the eight-stage rings above
+    // and below, the weight-gradient kernels); with it, the training step's forked decoder stage that came out a few ulps off in a
+    // fifth of the steps (tools/race_probe3.py, MADE_DEC_EARLY) is bit-reproducible too: 0 of 80.
     for (int kt = 0; kt < nk - 1; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         issue(kt + 1);
         multiply(kt);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // in flight under the last slab's MFMAs and the LDS staging
     int rrow[RPT];                                         // row of the residual: the physical row, or its position in the table
 #pragma unroll
@@ -972,7 +981,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void linear_ring_kernel(const Made
         for (int i = 0; i < RPT; ++i) om[i] = a.out_row_mask[mrow[i]];
     }
     multiply(nk - 1);
-    asm volatile("s_barrier" ::: "memory");                 // the epilogue reuses the ring's LDS
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // the epilogue reuses the ring's LDS
 
     // ---- epilogue: accumulators -> swizzled f32 LDS tile (16-byte stores) -> row-contiguous vector I/O (bias, act, residual, ...)
     float* Ct = (float*)rlds;
@@ -1160,7 +1169,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void linear_skinny_kernel(const MadeLi
             case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
-        asm volatile("s_barrier" ::: "memory");            // also: every wave is done reading stage (kt - 1) % S_NST
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // also: every wave is done reading stage (kt - 1) % S_NST
         if (kt + S_NST - 1 < nk) issue(kt + S_NST - 1);
         const unsigned char* st = lds + (kt % S_NST) * S_STAGE;
 #pragma unroll
@@ -1526,11 +1535,11 @@ static int pick_variant(const MadeLinearArgs& a) {
     // (eval epilogues only: with two workgroups per CU the training epilogue's dropout hash / GELU' are not hidden: 90-124 us against
     // round 1's 48-70 us on the same launches, profiles/r02_b_train_trace_summary.txt)
     const bool train_epi = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
-    // NOT the default any more (round 3): with a second stream of work resident on the chip (two eval batches in flight; the training
-    // step's second stream) about 0.5 % of the forward passes had GARBAGE ROWS in one 128-row tile of a ring-kernel launch -- eight
-    // rows of the A slab (rows 8 / 20 of every 32, the same 128-byte pieces of the same LDS-DMA instructions in all four waves) --
-    // 24 of 5000 two-batch replays with the ring kernel, 0 of 5000 with any of the other kernels in its place (tools/race_probe_eval.py).
-    // The loop follows the ordering rules for LDS-DMA (counted vmcnt, then a barrier, then the reads); not explained, so: opt-in.
+    // The ring kernel is opt-in since round 3 (MADE_LINEAR_TILE=2128; round 2 chose it for gathered launches of at most 512 columns without a
+    // training epilogue).  Two reasons, both measured: (1) its raw barriers lacked `s_waitcnt lgkmcnt(0)` -- garbage rows in 0.5-0.8 % of
+    // the forward passes beside a second stream, see the kernel's K loop; fixed, 0 of 8000 since -- and (2) with the fix, A/B on one box:
+    // the training step 5.33-5.35 ms with it against 5.22-5.24 ms without (its two 64 KB workgroups per CU get in the way of the second
+    // stream's launches), the eval forward 1.109 against 1.117 ms.
     (void)train_epi;
     if (tile_pref() == 2128) return MADE_LINEAR_RING128;
     // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)

@@ -688,13 +688,12 @@ class MadeTrainer(MadeEngine):
                 _tape.zero_(self.flat_grad)
                 self._grads_zeroed = True
             if (Q == 1 and not regression and c.moment_query_type != "xpool" and c.detr_enc_layers > 0
-                    and os.environ.get("MADE_DEC_EARLY", "0") == "1"):
-                # (opt-in, MADE_DEC_EARLY=1) the query side of decoder layer 0 depends on the clip-level vector and the weights only: here,
-                # beside the DETR encoder, instead of at the head of the decoder's chain of dependent launches (as MadeEngine does for the
-                # eval path).  OFF by default since the 16 x 16-tile stages: squeezed in between the encoder's launches, the LayerNorm +
-                # query-projection stage came out a few ulps off in one or two of its 64 rows in about a fifth of the steps (inputs as
-                # read, weights, the normalised LDS tile and a repeated product all checked identical inside the kernel; not explained:
-                # DESIGN.md 3c, tools/race_probe3.py); at the head of the main stream's chain, with nothing else resident, it never does
+                    and os.environ.get("MADE_DEC_EARLY", "1") != "0"):
+                # the query side of decoder layer 0 depends on the clip-level vector and the weights only: here, beside the DETR encoder,
+                # instead of at the head of the decoder's chain of dependent launches (as MadeEngine does for the eval path).
+                # (MADE_DEC_EARLY=0: at the head of the chain.  While the raw barriers of the LDS-DMA GEMM kernels lacked their
+                # lgkmcnt(0) -- csrc/linear.hip, linear_ring_kernel -- this placement made one stage of the chain come out a few ulps off in
+                # a fifth of the steps; 0 of 80 since: tools/race_probe3.py)
                 dec_fill_tgt()
                 dec_query_side(0)
                 dec_early = torch.cuda.Event()

@@ -1,8 +1,8 @@
 """eval forward determinism: captured graphs of MadeEngine.forward replayed, one engine alone and two engines (two batches) in flight on
 two streams as bench.py runs them; every replay's outputs against the engine's first eager run; on a bad replay the first workspace
 buffer that differs, its damaged 1-KB blocks and where else those bytes exist.  Clean with the default kernels (0 of 6000 replays);
-MADE_LINEAR_TILE=2128 (the opt-in ring kernel, the default until round 3) shows about 0.5 % replays with garbage rows when two
-engines are in flight."""
+before the LDS-DMA kernels' raw barriers got their lgkmcnt(0), MADE_LINEAR_TILE=2128 (the ring kernel) showed 0.5-0.8 % replays with
+garbage rows when two engines are in flight."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
