@@ -492,6 +492,9 @@ class MadeTrainer(MadeEngine):
             dSt=E(B, L, HQ), d_ds=E(B * Q, H, dtype=f32), d_delta=E(B * H * Q, dtype=f32),
             dg1=E(B * Q, D), dg2=E(B * Q, D), dg3=E(B * Q, D), dg4=E(B * Q, D), dgqkv=E(B * Q, 3 * D), dgffn=E(B * Q, Fd),
             dgq=E(B, HQ, D), dtgt=E(B * Q, D), dhs=E(nd * B * Q, D), dgN=E(nd * B * Q, D),
+            # the fused backward chain's hand-off rows (residual-stream gradients between its stages): a buffer of their own per layer and
+            # stage -- see backward()
+            dchain=E(nd, 6, B * Q, D),
             # heads
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D), hg1=E(nd * B * Q, D), hg2=E(nd * B * Q, D),
             dlog=Z(nd * B * Q, HEAD_PAD, dtype=f32), dsp=Z(nd * B * Q, HEAD_PAD, dtype=f32), dlog_c=Z(nd * B * Q, HEAD_PAD), dsp_c=Z(nd * B * Q, HEAD_PAD),
@@ -1202,6 +1205,18 @@ class MadeTrainer(MadeEngine):
             for l in range(nd - 1, -1, -1):
                 p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
                 g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
+                if stage and os.environ.get("MADE_CHAIN_BUFS", "1") != "0":
+                    # every hand-off of the chain gets rows of its own instead of three scratch buffers rewritten and re-read a few launches
+                    # apart (MADE_CHAIN_BUFS=0: the shared buffers).  In about 1 of 10 first steps a workgroup of one stage reads a row of
+                    # the previous launch's output with OLDER contents (whole rows of two or three samples 1e-6...5e-4 off from layer 4
+                    # down, tools/race_probe3.py); with rows of their own the old contents are last step's values of the same quantity and
+                    # the deviation is smaller and rarer (6 of 80 against 6 of 40) -- a mitigation, the cause is open
+                    ch = tw["dchain"][l]
+                    g1a, g1b, g2a, g2b, g2c, dt_out = ch[0], ch[1], ch[2], ch[3], ch[4], ch[5]
+                else:
+                    g1a = g1b = g1
+                    g2a = g2b = g2c = g2
+                    dt_out = tw["dtgt"]
                 Win, Wt = P[p + ".ca.in.w"], P[p + ".ca.in.wt"]
                 g_ffn, g_z, g_ca, g_attc, g_q, g_qc, g_sa, gqkv = (st[k][l] for k in ("g_ffn", "g_z", "g_ca", "g_attc", "g_q", "g_qc", "g_sa", "g_qkv"))
                 if stage:
@@ -1209,7 +1224,7 @@ class MadeTrainer(MadeEngine):
                     # the next layer: norm 3's backward of (d hs_l through the output norm + d tgt_{l+1}) in the prologue of the FFN's second
                     # dX product
                     tr.dec_stage_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], gN[l * B * Q:(l + 1) * B * Q], P[p + ".ff2.wt"], g_z,
-                                     dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], add=dtgt, dx_out=g2, a_out=g_ffn,
+                                     dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], add=dtgt, dx_out=g2a, a_out=g_ffn,
                                      drop_a=self._drop(f"dec.{l}" + ".drop3", pd), G=tw[d + ".h"], gate_scale=inv_keep)
                 else:
                     # hs_l = dec.norm(t3); t3 also feeds the next layer
@@ -1219,11 +1234,11 @@ class MadeTrainer(MadeEngine):
                                      dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
                 if not stage:
                     ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
-                dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1, R=g2)
+                dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1a, R=g2a)
                 # t2 = LN2(t1 + drop2(cross-attention))
                 if stage:                                         # norm 2's backward in the prologue of the out-projection's dX product
                     dattc = tr.dec_stage_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, P[p + ".ca.out.wt"], g_attc, dgamma_a=G[p + ".ln2.g"],
-                                             dbeta_a=G[p + ".ln2.b"], dx_out=g2, a_out=g_ca, drop_a=self._drop(f"dec.{l}" + ".drop2", pd))
+                                             dbeta_a=G[p + ".ln2.b"], dx_out=g2b, a_out=g_ca, drop_a=self._drop(f"dec.{l}" + ".drop2", pd))
                 else:
                     tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, g2, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"],
                                      dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
@@ -1270,15 +1285,15 @@ class MadeTrainer(MadeEngine):
                 # dt1 = residual path + query path in the Linear's epilogue; the query path alone (the pre-residual value) is kept for
                 # the query embedding's gradient
                 dt1q = st["dt1q"][l]                               # (summed over the batch into the query embedding's gradient after the loop)
-                ops.linear(g_qc, Wt[:, :D], None, out=g1, R=g2, Zout=dt1q)
+                ops.linear(g_qc, Wt[:, :D], None, out=g1b, R=g2b, Zout=dt1q)
                 # t1 = LN1(tgt + drop1(self-attention))
                 if stage:
                     # norm 1's backward in the prologue of the self-attention out-projection's dX product (value path only: dv = datt under
                     # the same per-head mask, drawn in the epilogue)
-                    tr.dec_stage_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, P[p + ".sa.out.wt"], gqkv[:, 2 * D:], dgamma_a=G[p + ".ln1.g"],
-                                     dbeta_a=G[p + ".ln1.b"], dx_out=g2, a_out=g_sa, drop_a=self._drop(f"dec.{l}" + ".drop1", pd),
+                    tr.dec_stage_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1b, P[p + ".sa.out.wt"], gqkv[:, 2 * D:], dgamma_a=G[p + ".ln1.g"],
+                                     dbeta_a=G[p + ".ln1.b"], dx_out=g2c, a_out=g_sa, drop_a=self._drop(f"dec.{l}" + ".drop1", pd),
                                      drop_o=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_o_ld=H, drop_o_col_div=hd)
-                    dtgt = ops.linear(gqkv[:, 2 * D:], P[p + ".sa.in.wt"][:, 2 * D:], None, R=g2, out=tw["dtgt"])
+                    dtgt = ops.linear(gqkv[:, 2 * D:], P[p + ".sa.in.wt"][:, 2 * D:], None, R=g2c, out=dt_out)
                     continue
                 tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln1.g"], g1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"],
                                  dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
