@@ -1177,8 +1177,10 @@ class MadeTrainer(MadeEngine):
                 self._lin_bwd(tw["dpq_raw"], hs2, "proj_q", dx_out=dhs, R=dhs, later=heads_dw)
                 # proj_vid_mem: every frame (padded ones too) receives d vid_sum (reference loss_detr.py:118)
                 tr.l2norm_bwd(ws["pv_raw"], tw["dvid_sum"], dx_alt=tw["dpv_raw"], dy_rows_per=Tv)
-                tr.gemm_tn(tw["dpv_raw"][:Tv], frame[0], G["proj_v.w"], accumulate=True, colsum=G["proj_v.b"], batch=(B, 1),
-                           a_zs=(Tv * Dc, 0), b_zs=(frame.stride(0), 0), colsum_zs=(0, 0))
+                # (its weight gradient is nobody's input: with the heads' other weight gradients on the second stream, after the decoder's
+                #  chain -- it was 52 us at the head of the main stream's backward)
+                heads_dw.append(lambda: tr.gemm_tn(tw["dpv_raw"][:Tv], frame[0], G["proj_v.w"], accumulate=True, colsum=G["proj_v.b"], batch=(B, 1),
+                                                   a_zs=(Tv * Dc, 0), b_zs=(frame.stride(0), 0), colsum_zs=(0, 0)))
                 ops.linear(tw["dpv_raw"], P["proj_v.wt"], None, out=tw["dframe_x"])
 
             # ---------------- decoder, last layer first.  Inside the loop only the data-gradient chain runs; every output gradient a
