@@ -24,6 +24,11 @@ names = [k for k in tw if isinstance(tw[k], torch.Tensor) and k.startswith("d.")
 refb = {k: tw[k].clone() for k in names}
 gnames = [k for k in tw["dstack"] if k.startswith("g_") or k == "dt1q"]          # the backward chain's per-layer gradients (no atomics)
 refg = {k: tw["dstack"][k].clone() for k in gnames}
+refin = {k: tw[k].clone() for k in ("dgN", "dhs") if k in tw}                        # what the chain starts from
+refc = tw["dchain"].clone() if "dchain" in tw else None                             # [layer, hand-off, B*Q, D]: the chain's hand-off rows
+# slot of tw["dchain"][layer] -> what the backward writes there (trainer.py: g1a, g1b, g2a, g2b, g2c, dt_out)
+HANDOFF = ("FFN-1 dX + residual", "query dX + residual", "norm-3 stage dx", "norm-2 stage dx", "norm-1 stage dx", "layer output (d tgt)")
+ORDER = (2, 0, 3, 1, 4, 5)                                                           # slots in the order the backward of a layer writes them
 for mode in sys.argv[1:] or ("graph", "tape"):
     for rep in range(int(os.environ.get("N", "5"))):
         tr_ = MadeTrainer(cfg, sd, device=dev, dtype="bf16")
@@ -47,5 +52,46 @@ for mode in sys.argv[1:] or ("graph", "tape"):
                 d = (a_.float() - b_.float()).abs()
                 lay = sorted(set((d > 0).nonzero()[:, 0].tolist()))
                 msg.append(f"   gradient stack {k}: {int((d > 0).sum())} of {d.numel()} differ, max {float(d.max()):.3e}; layers {lay}")
-        print(mode, rep, "identical" if not msg else "\n  ".join(["DIFFERENT"] + msg[:14]), flush=True)
+        if refc is not None and "dchain" in tw2 and not torch.equal(tw2["dchain"], refc):
+            dd = (tw2["dchain"].float() - refc.float()).abs()
+            nd_ = dd.shape[0]
+            first = None
+            for l in range(nd_ - 1, -1, -1):
+                for slot in ORDER:
+                    if float(dd[l, slot].max()) > 0:
+                        rows = sorted(set((dd[l, slot] > 0).nonzero()[:, 0].tolist()))
+                        cols = (dd[l, slot] > 0).nonzero()[:, 1]
+                        first = f"layer {l}, {HANDOFF[slot]}: {int((dd[l, slot] > 0).sum())} elements, rows {rows[:6]}, columns {int(cols.min())}..{int(cols.max())}, max {float(dd[l, slot].max()):.2e}"
+                        break
+                if first: break
+            msg.insert(0, "   first hand-off of the backward chain that differs: " + str(first))
+        # the highest layer in which anything differs: every per-layer product of the chain in the order the layer's backward writes it,
+        # with the rows and the 16-column tiles that differ (a stage's workgroup owns 16 rows x 16 columns of its product)
+        top = None
+        for l in range(refg["g_z"].shape[0] - 1, -1, -1):
+            if any(not torch.equal(tw2["dstack"][k][l], refg[k][l]) for k in gnames):
+                top = l
+                break
+        if top is not None:
+            def where(a_, b_):
+                a2, b2 = a_.reshape(-1, a_.shape[-1]).float(), b_.reshape(-1, b_.shape[-1]).float()
+                nz = (a2 != b2).nonzero()
+                if nz.numel() == 0:
+                    return "same"
+                rows = sorted(set(nz[:, 0].tolist())); tiles = sorted(set((nz[:, 1] // 16).tolist()))
+                return f"{nz.shape[0]} elements, rows {rows[:8]}, 16-column tiles {tiles[:40]}, max {float((a2 - b2).abs().max()):.2e}"
+            det = [f"   layer {top} in the order of its backward:"]
+            seq = [("g_ffn", None), ("g_z", None), (None, 2), (None, 0), ("g_ca", None), ("g_attc", None), (None, 3), ("g_q", None), ("g_qc", None),
+                   ("dt1q", None), (None, 1), ("g_sa", None), (None, 4), (None, 5)]
+            for k, slot in seq:
+                if k is not None and k in refg:
+                    det.append(f"      {k}: " + where(tw2["dstack"][k][top], refg[k][top]))
+                elif slot is not None and refc is not None:
+                    det.append(f"      hand-off '{HANDOFF[slot]}': " + where(tw2["dchain"][top, slot], refc[top, slot]))
+            if refc is not None and top + 1 < refc.shape[0]:
+                det.append(f"      (layer {top + 1}'s output, this layer's `add`: " + where(tw2["dchain"][top + 1, 5], refc[top + 1, 5]) + ")")
+            for k in refin:
+                det.append(f"      ({k}, all layers: " + where(tw2[k], refin[k]) + ")")
+            msg[1:1] = det
+        print(mode, rep, "identical" if not msg else "\n  ".join(["DIFFERENT"] + msg[:40]), flush=True)
         del g, tr_
