@@ -184,7 +184,9 @@ enum MadeLinearVariant {
     MADE_LINEAR_GLDS128 = 7,        /* linear_glds_kernel<1, ., 128>: 128 x 128 tiles */
     MADE_LINEAR_RING128 = 8,        /* linear_ring_kernel<128, 128>: two-stage LDS-DMA ring, one barrier per slab, two workgroups per CU;
                                        opt-in since round 3 (MADE_LINEAR_TILE=2128), see csrc/linear.hip */
-    MADE_LINEAR_TINY16 = 9          /* linear_t16_kernel: at most 64 rows, 16 x 16 tiles (a third of the bytes per workgroup), 128 <= K <= 1024 */
+    MADE_LINEAR_TINY16 = 9,         /* linear_t16_kernel: at most 64 rows, 16 x 16 tiles (a third of the bytes per workgroup), 128 <= K <= 1024 */
+    MADE_LINEAR_WST = 10            /* linear_wst_kernel: W-stationary persistent kernel -- a 128 (or 64)-column weight panel stays in LDS, the waves
+                                       stream 16-row units past it straight from global memory into MFMA fragments; K = 256 / 512 / 1024, >= 4096 rows */
 };
 int made_linear_variant(const MadeLinearArgs* args);
 

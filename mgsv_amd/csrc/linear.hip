@@ -1503,6 +1503,220 @@ static void launch_t16(const MadeLinearArgs& a, hipStream_t st) {
 // tuning knob for the micro-benchmarks and tests: MADE_LINEAR_TILE=64|128 forces the single-stage direct-to-LDS kernels of round 1,
 // 2128 the ring kernel (opt-in, see pick_variant), 1000 round 1's choice between its two kernels, 32 the 64 x 32-tile kernel where the
 // 16 x 16-tile one is the default (at most 64 rows)
+
+// =================================================================================================
+// W-stationary path: the encoder-sized launches with a short reduction (K = 256 / 512 / 1024; tens of thousands of rows).
+// The single-stage kernels above move every operand byte global -> LDS -> register under two barriers per 64-deep slab and
+// park the accumulators in LDS for the write-out; at K = 512 a tile is 8 slabs long, so its fill and its write-out are as
+// long as its MFMAs, and only other workgroups of the CU hide them (measured in the step: 240-300 TFLOP/s).  Here the WEIGHTS
+// stand still: a persistent workgroup keeps one panel of PT x 16 output columns x K in LDS (128 KB at PT = 8, K = 512; loaded
+// once by LDS-DMA, XOR-swizzled on the source side) and its four waves stream row units of 16 rows past it on their own:
+//   * activation fragments go global -> register directly in the MFMA layout (lane (r16, kq): row r16, 16 bytes at k = 32 s + 8 kq),
+//     WS_PD k-steps ahead of the MFMAs that use them -- no LDS round trip, no barrier anywhere in the K loop;
+//   * v_mfma_f32_16x16x32_bf16 with the operands swapped (W fragment first): a lane ends with FOUR CONSECUTIVE output columns of
+//     ONE row per tile; the panel's columns are dealt to (tile, MFMA row) so that tiles 2p and 2p + 1 give a lane columns
+//     32 p + 8 kq .. + 7 -- eight consecutive outputs, exactly what the shared epilogue8 / store8 take: the write-out leaves
+//     from registers with 16-byte stores, and a wave's epilogue runs beside the other waves' MFMAs;
+//   * one ds_read_b128 per W fragment and RB x PT MFMAs per PT reads (RB <= 4 row units per pass): a quarter of the LDS read
+//     rate at which the MFMA pipe would start to wait (MI355X_MICROARCH.md, LDS).
+// Work split: the live rows (row gather: *n_rows) are cut into 8 contiguous ranges, one per XCD, so that all panels of a row
+// range pull it through ONE L2; inside an XCD the (panel, row unit) plane, panel-major, is cut into equal consecutive ranges for
+// its workgroups (N = 512 / 1024 at PT = 8: 4 / 8 panels divide the 32 CUs, a workgroup never changes its panel).
+constexpr int WS_THREADS = 512, WS_WAVES = 8;              // two waves per SIMD: one's write-out and first loads run beside the other's MFMAs
+constexpr int WS_RBMAX = 2;                                 // 16-row units per pass of a wave (accumulators: RB x PT x 4 registers)
+constexpr int WS_PDF = 8;                                   // activation fragments a lane keeps in flight (PD = WS_PDF / RB k-steps ahead)
+constexpr int WS_STG_LD = 36;                               // floats per row of a wave's 16 x 32 write-out patch (144 bytes)
+
+template <int KSTEPS, int PT, bool TRAIN, int RB>
+__device__ __forceinline__ void wst_block(const MadeLinearArgs& a, void* const seg_out, const int seg_odt, const int64_t seg_ldo, const int rpb,
+                                          const int64_t seg_obs, const int colb, const unsigned char* panel, const bf16_t* Abase,
+                                          const int64_t lda, const int u0, const int Mv, const int n0,
+                                          const int (&wb)[4], const bool out_vec, const bool r_vec, const bool b_vec, float* stg) {
+    constexpr int ROWB = KSTEPS * 64;
+    constexpr int PD = (WS_PDF / RB) < KSTEPS ? (WS_PDF / RB) : KSTEPS;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+    const int N = (int)a.N;
+    const bf16_t* pa[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+        const int ml = (u0 + u) * 16 + r16;
+        int g = ml < Mv ? ml : Mv - 1;                        // rows past the edge are fetched from a valid row and never stored
+        if (a.row_index) g = a.row_index[g];
+        pa[u] = Abase + (int64_t)g * lda + kq * 8;
+    }
+    bf16x8 fa[PD][RB];
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+#pragma unroll
+        for (int u = 0; u < RB; ++u) fa[s][u] = *(const bf16x8*)(pa[u] + s * 32);
+    // the write-out's row of this lane (4 lanes per row, 8 columns each), requested now: its index is a dependent load otherwise
+    const int erow = lane >> 2, c8 = (lane & 3) * 8;
+    int em[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+        const int ml = (u0 + u) * 16 + erow;
+        int g = ml < Mv ? ml : Mv - 1;
+        if (a.row_index) g = a.row_index[g];
+        em[u] = ml < Mv ? g : -1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[RB][PT];
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) { acc[u][t][0] = 0.f; acc[u][t][1] = 0.f; acc[u][t][2] = 0.f; acc[u][t][3] = 0.f; }
+    // the W fragments of k-step s + 1 are read from LDS ahead of the MFMAs of k-step s (two register sets)
+    bf16x8 fw[2][PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) fw[0][t] = *(const bf16x8*)(panel + wb[0] + ((t >> 1) * 32 + (t & 1) * 4) * ROWB);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        if (s + 1 < KSTEPS) {
+#pragma unroll
+            for (int t = 0; t < PT; ++t)
+                fw[(s + 1) & 1][t] = *(const bf16x8*)(panel + wb[(s + 1) & 3] + ((t >> 1) * 32 + (t & 1) * 4) * ROWB + ((s + 1) >> 2) * 256);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+#pragma unroll
+            for (int t = 0; t < PT; ++t)
+                acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s & 1][t], fa[s % PD][u], acc[u][t], 0, 0, 0);
+        if (s + PD < KSTEPS) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) fa[s % PD][u] = *(const bf16x8*)(pa[u] + (s + PD) * 32);
+        }
+        // (without this hipcc sinks every prefetch down to its first use -- a load, s_waitcnt vmcnt(0), eight MFMAs, the next load: the
+        //  K loop ran one memory round trip per k-step)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // write-out: 16 rows x 32 columns (two accumulator tiles) at a time through this wave's own LDS patch (no barrier: nobody else
+    // touches it), so that a lane ends with 8 consecutive outputs of one row for the shared epilogue8 / store8 and a row leaves as
+    // 64-byte (bf16) / 128-byte (f32) contiguous pieces.  The unit loop is a run-time loop (the epilogue's code exists PT / 2 times per
+    // instantiation, not RB x PT / 2 times); which accumulator goes to the patch is a per-register select.
+    const int rmod = (int)a.r_row_mod;
+    float* wr = stg + r16 * WS_STG_LD + kq * 8;
+    const float* rd = stg + erow * WS_STG_LD + c8;
+    constexpr int NQ = PT / 2;
+#pragma unroll 1
+    for (int uq = 0; uq < RB * NQ; ++uq) {
+        const int u = uq / NQ, q = uq % NQ;
+#define WST_PUT(K_)                                                                                                  \
+        case K_:                                                                                                     \
+            if constexpr (K_ < RB * NQ) { *(f32x4*)wr = acc[K_ / NQ][(K_ % NQ) * 2]; *(f32x4*)(wr + 4) = acc[K_ / NQ][(K_ % NQ) * 2 + 1]; } \
+            break;
+        switch (uq) { WST_PUT(0) WST_PUT(1) WST_PUT(2) WST_PUT(3) WST_PUT(4) WST_PUT(5) WST_PUT(6) WST_PUT(7) default: break; }
+#undef WST_PUT
+        const f32x4 q0 = *(const f32x4*)rd, q1 = *(const f32x4*)(rd + 4);
+        const int m = (RB > 1 && u) ? em[RB - 1] : em[0];
+        const int n = n0 + q * 32 + c8;
+        int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+        if (m < 0 || nvalid <= 0) continue;
+        int64_t orow;
+        if (rpb > 0) { const int b = m / rpb, t = m - b * rpb; orow = (int64_t)b * seg_obs + (int64_t)t * seg_ldo; }
+        else orow = (int64_t)m * seg_ldo;
+        float bh[8];
+        if (b_vec && nvalid == 8) {
+            const f32x4 b0 = *(const f32x4*)(a.bias + n), b1 = *(const f32x4*)(a.bias + n + 4);
+            bh[0] = b0[0]; bh[1] = b0[1]; bh[2] = b0[2]; bh[3] = b0[3]; bh[4] = b1[0]; bh[5] = b1[1]; bh[6] = b1[2]; bh[7] = b1[3];
+        } else {
+            load_bias8(a.bias, n, N, bh);
+        }
+        float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        epilogue8<TRAIN>(a, m, n, nvalid, v, bh, rmod, r_vec);
+        store8(seg_out, seg_odt, orow + (n - colb), v, nvalid, out_vec);
+    }
+}
+
+template <int KSTEPS, int PT, bool TRAIN>
+__global__ __launch_bounds__(WS_THREADS) void linear_wst_kernel(const MadeLinearArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wst_lds[];
+    constexpr int ROWB = KSTEPS * 64, PROWS = PT * 16, PIECES = PROWS * ROWB / 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int M = (int)a.M, N = (int)a.N;
+    int Mv = M;
+    if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
+    if (Mv <= 0) return;
+    const int NP = (N + PROWS - 1) / PROWS;                  // panels
+    const int U = (Mv + 15) >> 4;                            // 16-row units
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nx = gridDim.x >> 3;     // (the grid is a multiple of 8: workgroups go round-robin over the XCDs)
+    const int ux0 = (int)((int64_t)U * xcd / 8), ux1 = (int)((int64_t)U * (xcd + 1) / 8), UX = ux1 - ux0;
+    if (UX <= 0) return;
+    const int64_t Wk = (int64_t)NP * UX;
+    int64_t w0 = Wk * j / nx;
+    const int64_t w1 = Wk * (j + 1) / nx;
+    // fragment reads: tile t, MFMA row i = r16 is panel row (t / 2) * 32 + (i / 4) * 8 + (t & 1) * 4 + (i & 3); the 16-byte chunk c of a row
+    // sits at chunk (c & ~15) | ((c & 15) ^ i) (conflict-free ds_read_b128: the 16 lanes of a group hit 16 different bank quads)
+    int wb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wb[q] = ((r16 >> 2) * 8 + (r16 & 3)) * ROWB + (((q * 4 + kq) ^ r16) << 4);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    float* stg = (float*)(wst_lds + PROWS * ROWB) + wave * (16 * WS_STG_LD);
+    const bool b_vec = a.bias && (((uintptr_t)a.bias & 15) == 0);
+    bool first = true;
+    while (w0 < w1) {
+        const int p = (int)(w0 / UX);
+        const int a0 = (int)(w0 - (int64_t)p * UX);
+        int64_t e1 = w1 - (int64_t)p * UX;
+        const int a1 = e1 < UX ? (int)e1 : UX;
+        const int n0 = p * PROWS;
+        int si = 0;
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+            if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
+        void* const seg_out = a.seg[si].out;
+        const int seg_odt = a.seg[si].out_dtype, seg_rpb = (int)a.seg[si].rows_per_batch, seg_colb = (int)a.seg[si].col_begin;
+        const int64_t seg_ldo = a.seg[si].ldo, seg_obs = a.seg[si].out_batch_stride;
+        const bool repl = a.seg[si].use_a2 && a.A2 && a.a2_replace;
+        const bf16_t* Abase = repl ? (const bf16_t*)a.A2 : (const bf16_t*)a.A;
+        const int64_t lda = repl ? a.lda2 : a.lda;
+        if (!first) __syncthreads();                         // every wave is done with the previous panel
+        first = false;
+        for (int q = wave; q < PIECES; q += WS_WAVES) {      // 1 KB per wave instruction, straight into LDS
+            const int lb = q * 1024 + lane * 16;
+            const int row = lb / ROWB, pos = (lb % ROWB) >> 4;
+            const int key = ((row & 31) >> 3) * 4 + (row & 3);
+            const int ch = (pos & ~15) | ((pos & 15) ^ key);
+            int gn = n0 + row; gn = gn < N ? gn : N - 1;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)((const bf16_t*)a.W + (int64_t)gn * a.ldw + ch * 8), (lds_ptr_t)(wst_lds + q * 1024), 16, 0, 0);
+        }
+        const bool out_vec = (seg_ldo % 8 == 0) && (seg_obs % 8 == 0) && (((uintptr_t)seg_out & 15) == 0) && (seg_colb % 8 == 0);
+        const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+        __syncthreads();                                     // the panel has landed (the barrier waits for every wave's LDS-DMA)
+        const int nu = a1 - a0;
+        const int b0 = a0 + nu * wave / WS_WAVES, b1 = a0 + nu * (wave + 1) / WS_WAVES, nw = b1 - b0;
+        const int nb = (nw + WS_RBMAX - 1) / WS_RBMAX;
+        for (int ib = 0; ib < nb; ++ib) {
+            const int c0 = b0 + nw * ib / nb, c1 = b0 + nw * (ib + 1) / nb;
+            const int u0 = ux0 + c0;
+            if (c1 - c0 == 2) wst_block<KSTEPS, PT, TRAIN, 2>(a, seg_out, seg_odt, seg_ldo, seg_rpb, seg_obs, seg_colb, wst_lds, Abase, lda, u0, Mv, n0, wb, out_vec, r_vec, b_vec, stg);
+            else if (c1 - c0 == 1) wst_block<KSTEPS, PT, TRAIN, 1>(a, seg_out, seg_odt, seg_ldo, seg_rpb, seg_obs, seg_colb, wst_lds, Abase, lda, u0, Mv, n0, wb, out_vec, r_vec, b_vec, stg);
+        }
+        w0 += a1 - a0;
+    }
+}
+
+template <int KSTEPS, int PT, bool TRAIN>
+static void launch_wst_one(const MadeLinearArgs& a, hipStream_t st, int n_cu) {
+    constexpr int LDSB = PT * 16 * KSTEPS * 64 + WS_WAVES * 16 * WS_STG_LD * 4;
+    static const bool once = [] { return hipFuncSetAttribute((const void*)linear_wst_kernel<KSTEPS, PT, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess; }();
+    (void)once;
+    dim3 grid((unsigned)n_cu), block(WS_THREADS);            // one workgroup per CU (the panel is 64 - 128 KB)
+    hipLaunchKernelGGL((linear_wst_kernel<KSTEPS, PT, TRAIN>), grid, block, LDSB, st, a);
+}
+static int wst_cus() {
+    static const int n = [] { int dev = 0, c = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c >= 8 ? (c / 8) * 8 : 8; }();
+    return n;
+}
+template <bool TRAIN>
+static void launch_wst(const MadeLinearArgs& a, hipStream_t st) {
+    const int n_cu = wst_cus();
+    if (a.K == 1024) launch_wst_one<32, 4, TRAIN>(a, st, n_cu);          // 64-column panels: 128 KB
+    else if (a.K == 512) launch_wst_one<16, 8, TRAIN>(a, st, n_cu);      // 128-column panels: 128 KB
+    else launch_wst_one<8, 8, TRAIN>(a, st, n_cu);                       // K = 256: 64 KB
+}
+
 static int tile_pref() {                                   // read on every call: the tests switch kernels inside one process
     const char* e = getenv("MADE_LINEAR_TILE");
     return e ? atoi(e) : 0;
@@ -1542,6 +1756,14 @@ static int pick_variant(const MadeLinearArgs& a) {
     // stream's launches), the eval forward 1.109 against 1.117 ms.
     (void)train_epi;
     if (tile_pref() == 2128) return MADE_LINEAR_RING128;
+    // W-stationary persistent kernel (round 3, third part): bf16, K = 256 / 512 / 1024, one problem, no tile skipping.  Opt-in
+    // (MADE_LINEAR_TILE=4128, or MADE_WST=1 for every launch of at least 4096 rows): measured at parity with the single-stage kernels
+    // alone (tools/wst_bench.py: 34688 x 512 x 512 39.2 against 38.1 us, x 1024 62.3 against 71.5 us, K = 1024 75.9 against 61.1 us) and 3 %
+    // slower inside the training step (5.40 - 5.42 against 5.26 ms, A/B on one box: one 150 KB workgroup per CU and the second stream's
+    // launches keep each other off the CUs -- the ring kernel's finding again), see DESIGN.md 3c-3
+    const bool wst_ok = (a.K == 256 || a.K == 512 || a.K == 1024) && a.batch == 1 && a.tile_skip_mask == nullptr && a.ldw % 8 == 0;
+    static const bool wst_on = [] { const char* e = getenv("MADE_WST"); return e && atoi(e) == 1; }();     // (read once)
+    if (wst_ok && (tile_pref() == 4128 || (tile_pref() == 0 && a.M >= 4096 && wst_on))) return MADE_LINEAR_WST;
     // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
     const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
     if (tile_pref() == 64) return MADE_LINEAR_GLDS64;
@@ -1648,6 +1870,9 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
             else hipLaunchKernelGGL((linear_glds_kernel<1, false, 64>), g, block, 0, st, a);
             break;
         }
+        case MADE_LINEAR_WST:
+            if (train) launch_wst<true>(a, st); else launch_wst<false>(a, st);
+            break;
         case MADE_LINEAR_GLDS128:
             if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128>), grid, block, 0, st, a);

@@ -151,7 +151,7 @@ class Seg:
 # made_linear_variant codes (include/made_hip.h: MadeLinearVariant) -> KernelTimer kinds = rocprofv3 kernel symbols
 LINEAR_VARIANTS = {0: "linear_f32", 1: "linear_f32in_bf16", 2: "linear_kernel<bf16,bf16>", 3: "linear_tiny_kernel", 4: "linear_skinny_kernel",
                    5: "linear_glds_kernel<3,.,128>", 6: "linear_glds_kernel<1,.,64>", 7: "linear_glds_kernel<1,.,128>",
-                   8: "linear_ring_kernel<128,128>", 9: "linear_t16_kernel"}
+                   8: "linear_ring_kernel<128,128>", 9: "linear_t16_kernel", 10: "linear_wst_kernel"}
 
 
 def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,

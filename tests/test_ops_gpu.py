@@ -75,8 +75,8 @@ def test_linear_basic(dev, mode, M, N, K, act):
         np.testing.assert_allclose(outb.float().cpu().numpy(), ref.numpy(), atol=BF16_TOL, rtol=2e-2)
 
 
-@pytest.mark.parametrize("tile", [0, 128, 64, 2128])
-@pytest.mark.parametrize("M,N,gather", [(20000, 512, False), (33000, 1024, False), (40960, 512, True), (16385, 1024, False)])
+@pytest.mark.parametrize("tile", [0, 128, 64, 2128, 4128])                        # 0 / 4128: the W-stationary kernel
+@pytest.mark.parametrize("M,N,gather", [(20000, 512, False), (33000, 1024, False), (40960, 512, True), (16385, 1024, False), (20000, 640, False)])
 def test_linear_encoder_sized(dev, M, N, gather, tile, monkeypatch):
     """Encoder-sized bf16 Linears (tens of thousands of rows, K = 512: the LDS-DMA ring kernel at both tile sizes and round 1's
     single-stage kernels at both tile heights): bias + ReLU + residual + output row mask, two output segments, row gather, ragged

@@ -148,6 +148,48 @@ def test_linear_training_epilogue(T, dtype, tol):
     assert float((out.float() - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("K,N", [(512, 1024), (512, 512), (1024, 512), (256, 640)])
+def test_linear_wst_training_epilogue(T, K, N, monkeypatch):
+    """The W-stationary kernel (encoder-sized launches, csrc/linear.hip linear_wst_kernel) with the training epilogue: Zout, ReLU,
+    stateless dropout, residual, the backward's ReLU gate, row gather -- against f32 math on the bf16 operands, and against the
+    single-stage kernel (MADE_LINEAR_TILE=64) on the same call: the same dropout draws, sums within bf16 rounding of each other."""
+    ops, tr = T
+    from mgsv_amd import _lib
+    M, Tn = 12288, 512
+    dtype = torch.bfloat16
+    A, W = _rand(M, K, dtype=dtype, seed=1), _rand(N, K, dtype=dtype, seed=2) * (1.0 / math.sqrt(K))
+    bias = _rand(N, dtype=torch.float32, seed=3)
+    R = _rand(M, N, dtype=dtype, seed=4)
+    lens = torch.tensor([(53 * i) % Tn + 1 for i in range(M // Tn)])
+    mask = (torch.arange(Tn)[None] < lens[:, None]).float().cuda()
+    rows = ops.row_index(mask)
+    valid = mask.reshape(-1) != 0
+    seed, site, p = 77, 424242, 0.1
+    keep = _keep(seed, site, p, (M, N)).float()
+    z_ref = A.float() @ W.float().t() + bias
+    ref = torch.relu(z_ref) * keep / (1 - p) + R.float()
+    got = {}
+    for tile in ("4128", "64"):
+        monkeypatch.setenv("MADE_LINEAR_TILE", tile)
+        Z = torch.full((M, N), float("nan"), device="cuda", dtype=dtype)
+        out = torch.full((M, N), float("nan"), device="cuda", dtype=dtype)
+        ops.linear(A, W, bias, act=ops.ACT_RELU, R=R, Zout=Z, drop=(seed, site, p), out=out, rows=rows)
+        torch.cuda.synchronize()
+        assert torch.isnan(out[~valid].float()).all() and torch.isnan(Z[~valid].float()).all()      # rows outside the list stay untouched
+        assert float((Z[valid].float() - z_ref[valid]).abs().max()) <= 2e-2 * float(z_ref.abs().max())
+        assert float((out[valid].float() - ref[valid]).abs().max()) <= 2e-2 * float(ref.abs().max()) + 0.05
+        got[tile] = (out[valid].float(), Z[valid].float())
+    assert ((got["4128"][0] == 0) == (got["64"][0] == 0)).float().mean() > 0.999                   # the same draws
+    assert float((got["4128"][1] - got["64"][1]).abs().max()) <= 2e-2 * float(z_ref.abs().max())
+    # the backward's gate on the same kernel: out = (A W^T) * [G != 0] * scale, no gather
+    monkeypatch.setenv("MADE_LINEAR_TILE", "4128")
+    G = torch.relu(_rand(M, N, dtype=dtype, seed=5))
+    out = ops.linear(A, W, None, gate=_lib.GATE_RELU_OUT, G=G, gate_scale=1.0 / 0.9)
+    base = A.float() @ W.float().t()
+    refg = base * (G.float() != 0).float() / 0.9
+    assert float((out.float() - refg).abs().max()) <= 2e-2 * float(refg.abs().max()) + 1e-6
+
+
 def _attn_ref(q, k, v, H, key_mask, keep, p, scale=None):
     B, Lq, D = q.shape
     Lk, hd = k.shape[1], D // H

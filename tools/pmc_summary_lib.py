@@ -4,6 +4,8 @@
 def kind(name):
     """-> (KernelTimer kind of mgsv_amd/ops.py / ops_train.py, counts_as_launch).  A made_* entry point that launches several kernels
     (made_attention_bwd: delta + dq + dkv; made_gemm_tn: either of its two kernels) sums their bytes; one of them counts the launches."""
+    if "linear_wst_kernel" in name:
+        return "linear_wst_kernel", True
     if "linear_ring_kernel" in name:
         return "linear_ring_kernel<128,128>", True
     if "linear_glds_kernelILi1" in name or "linear_glds_kernel<1" in name:
