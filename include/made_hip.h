@@ -760,7 +760,8 @@ int made_adam_step_device(float* param, const float* grad, float* exp_avg, float
 
 /* made_repack: rebuild the kernel-facing copies of every matrix parameter from the f32 masters in one launch:
  * w (rows x cols, `dtype`; NULL = the kernels read the master itself) and wt = W^T (cols x wt_ld, wt_ld >= rows; NULL = not
- * needed).  `descs_device` is a device array sorted by tile_begin (prefix sum of ceil(rows/32)*ceil(cols/32)). */
+ * needed).  `descs_device` is a device array sorted by tile_begin (prefix sum of ceil(rows/64)*ceil(cols/64): one workgroup per
+ * 64 x 64 tile). */
 typedef struct MadeRepackDesc {
     const float* src; void* w; void* wt;
     int64_t rows, cols, wt_ld, tile_begin;

@@ -286,7 +286,7 @@ class MadeTrainer(MadeEngine):
                 d.src, d.w, d.wt = m.data_ptr(), (w.data_ptr() if w is not None else None), (wt.data_ptr() if wt is not None else None)
                 d.rows, d.cols, d.wt_ld, d.tile_begin = rows, cols, (wt.shape[1] if wt is not None else 0), tiles
                 d.dtype = ops.dt_of(wt if wt is not None else w)
-                tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+                tiles += ((rows + 63) // 64) * ((cols + 63) // 64)      # (made_repack: one workgroup per 64 x 64 tile)
                 descs.append(d)
                 part_of.append("rest" if (m.data_ptr() - self.flat_param.data_ptr()) // 4 < cut else "early")
 
@@ -296,7 +296,7 @@ class MadeTrainer(MadeEngine):
                     e = _lib.MadeRepackDesc()
                     C.memmove(C.byref(e), C.byref(d), C.sizeof(e))
                     e.tile_begin = t0
-                    t0 += ((e.rows + 31) // 32) * ((e.cols + 31) // 32)
+                    t0 += ((e.rows + 63) // 64) * ((e.cols + 63) // 64)
                     out.append(e)
                 if not out:
                     return None
