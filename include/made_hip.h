@@ -383,6 +383,10 @@ int made_tape_event(int32_t op_kind, int32_t slot, void* stream);    /* recordin
                                                                          framework's own Event.record / Stream.wait_event calls */
 int made_memset_async(void* dst, int32_t value, int64_t nbytes, void* stream);
 int made_copy_async(void* dst, const void* src, int64_t nbytes, void* stream);
+/* dst[0 .. n_words) = words[0 .. n_words) (n_words <= 4, 32-bit words, dst 4-byte aligned): the words travel as kernel arguments of a
+ * one-wave launch, so the call is stream-ordered and the host buffer may be reused at once -- the per-step scalars of a replayed
+ * training step (dropout seed, learning rates, step count; replaces the framework's fill kernels in TrainStepGraph.step). */
+int made_store_words(void* dst, const uint32_t* words, int32_t n_words, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).                                                                   */

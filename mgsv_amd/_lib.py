@@ -175,6 +175,7 @@ SIGNATURES = {
     "made_tape_event": (C.c_int, [i32, i32, vp]),
     "made_memset_async": (C.c_int, [vp, i32, i64, vp]),
     "made_copy_async": (C.c_int, [vp, vp, i64, vp]),
+    "made_store_words": (C.c_int, [vp, vp, i32, vp]),
     "made_linear": (C.c_int, [C.POINTER(MadeLinearArgs), vp]),
     "made_splitk_finish": (C.c_int, [C.POINTER(MadeFinishArgs), vp]),
     "made_dec_stage": (C.c_int, [C.POINTER(MadeDecStageArgs), vp]),

@@ -165,6 +165,20 @@ extern "C" int made_memset_async(void* dst, int32_t value, int64_t nbytes, void*
     return MADE_OK;
 }
 
+// a few 32-bit words handed over as KERNEL ARGUMENTS (stream-ordered, nothing for the host to keep alive): the per-step scalars of a
+// replayed training step -- dropout seed, learning rates, the device-side step count (mgsv_amd/trainer.py TrainStepGraph.step)
+struct StoreWords { uint32_t w[4]; };
+__global__ void store_words_kernel(uint32_t* dst, StoreWords v, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v.w[threadIdx.x];
+}
+extern "C" int made_store_words(void* dst, const uint32_t* words, int32_t n_words, void* stream) {
+    MADE_REQUIRE(dst != nullptr && words != nullptr && n_words >= 1 && n_words <= 4 && ((uintptr_t)dst & 3) == 0, "made_store_words: bad arguments");
+    StoreWords v{};
+    for (int i = 0; i < n_words; ++i) v.w[i] = words[i];
+    hipLaunchKernelGGL(store_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t*)dst, v, (int)n_words);
+    return made_check_launch("made_store_words");
+}
+
 extern "C" int made_copy_async(void* dst, const void* src, int64_t nbytes, void* stream) {
     MADE_REQUIRE(dst != nullptr && src != nullptr && nbytes >= 0, "made_copy_async: bad arguments");
     if (nbytes == 0) return MADE_OK;

@@ -1902,6 +1902,13 @@ class TrainStepGraph:
         finally:
             t._seed_dev, t._static_exclusion = None, None
 
+    @staticmethod
+    def _store_words(dst: Tensor, words) -> None:
+        """dst's first len(words) 32-bit words = words, stream-ordered (the values travel as kernel arguments: made_store_words)"""
+        import ctypes as C
+        arr = (C.c_uint32 * len(words))(*[int(w) & 0xFFFFFFFF for w in words])
+        _lib.check(_lib.lib().made_store_words(dst.data_ptr(), arr, len(words), torch.cuda.current_stream().cuda_stream), "made_store_words")
+
     def step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, seed: int, lrs=(1e-4, 1e-4, 1e-4),
              music_ids=None, v_duration: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """Same contract as MadeTrainer.train_step; the returned tensors are the graph's fixed output buffers."""
@@ -1923,14 +1930,17 @@ class TrainStepGraph:
             self.exclusion.copy_(ex, non_blocking=True)
         # the per-step scalars travel as kernel arguments of tiny fill launches (stream-ordered; a pinned staging word would be
         # overwritten by the host while earlier replays are still queued)
-        self.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        # (made_store_words: no framework kernel inside or around the replayed step)
+        sd = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self._store_words(self.seed_dev, (sd & 0xFFFFFFFF, sd >> 32))
         lrs = tuple(float(x) for x in lrs)
         if lrs != self._lrs:
-            for k in range(3):
-                self._lr_view[k:k + 1].fill_(lrs[k])
+            import struct
+            self._store_words(self._lr_view, tuple(struct.unpack("<I", struct.pack("<f", x))[0] for x in lrs))
             self._lrs = lrs
         if t.opt_step != self._dev_step:                      # eager optimizer steps in between: realign the device-side count
-            self.adam_state[0:1].fill_(t.opt_step)
+            st_ = int(t.opt_step)
+            self._store_words(self.adam_state[0:1], (st_ & 0xFFFFFFFF, (st_ >> 32) & 0xFFFFFFFF))
         t.seed = int(seed)
         if self.mode == "tape":
             self.tape.replay()
