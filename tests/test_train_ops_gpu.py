@@ -190,6 +190,46 @@ def test_linear_wst_training_epilogue(T, K, N, monkeypatch):
     assert float((out.float() - refg).abs().max()) <= 2e-2 * float(refg.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_repack_ragged_shapes_and_store_words(T, dtype):
+    """made_repack (64 x 64 tiles, vector and scalar paths): W and W^T copies of matrices with ragged shapes -- 2-row heads with a padded
+    reduction dimension, rows / columns that are not multiples of 4 or 64, masters at unaligned offsets of one flat buffer -- in ONE launch;
+    made_store_words: a few 32-bit words as kernel arguments."""
+    import ctypes as C
+    from mgsv_amd import _lib
+    ops, tr = T
+    shapes = [(2, 512), (130, 70), (512, 1024), (64, 64), (7, 5), (256, 258), (1, 64)]
+    total = sum(r * c for r, c in shapes) + 3 * len(shapes)
+    flat = _rand(total, dtype=torch.float32, seed=11)
+    descs, keep, off, tiles = [], [], 1, 0                  # (offset 1: the first master is 4-byte aligned only)
+    for r, c in shapes:
+        m = flat[off:off + r * c].view(r, c)
+        off += r * c + 3
+        w = torch.full((r, c), float("nan"), device="cuda", dtype=dtype)
+        ld = max(r, 64)
+        wt = torch.zeros(c, ld, device="cuda", dtype=dtype)
+        d = _lib.MadeRepackDesc()
+        d.src, d.w, d.wt = m.data_ptr(), w.data_ptr(), wt.data_ptr()
+        d.rows, d.cols, d.wt_ld, d.tile_begin = r, c, ld, tiles
+        d.dtype = ops.dt_of(w)
+        tiles += ((r + 63) // 64) * ((c + 63) // 64)
+        descs.append(d); keep.append((m, w, wt))
+    arr = (_lib.MadeRepackDesc * len(descs))(*descs)
+    dev_descs = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).cuda()
+    _lib.check(_lib.lib().made_repack(dev_descs.data_ptr(), len(descs), tiles, torch.cuda.current_stream().cuda_stream), "made_repack")
+    torch.cuda.synchronize()
+    for (m, w, wt), (r, c) in zip(keep, shapes):
+        assert torch.equal(w, m.to(dtype)), (r, c)
+        assert torch.equal(wt[:, :r], m.to(dtype).t()), (r, c)
+        assert bool((wt[:, r:] == 0).all())                 # the padded reduction columns stay zero
+    # made_store_words
+    buf = torch.zeros(6, device="cuda", dtype=torch.int32)
+    words = (C.c_uint32 * 3)(0xDEADBEEF, 7, 0x80000001)
+    _lib.check(_lib.lib().made_store_words(buf[1:].data_ptr(), words, 3, torch.cuda.current_stream().cuda_stream), "made_store_words")
+    torch.cuda.synchronize()
+    assert buf.cpu().numpy().astype(np.uint32).tolist() == [0, 0xDEADBEEF, 7, 0x80000001, 0, 0]
+
+
 def _attn_ref(q, k, v, H, key_mask, keep, p, scale=None):
     B, Lq, D = q.shape
     Lk, hd = k.shape[1], D // H
