@@ -550,11 +550,12 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 //          hides the ~2 us a slab takes to arrive.
 // TRAIN: the epilogue carries the training-path options (Zout / gate / dropout); the eval instantiation stays lean.
 // BMT = 128: 128 x 128 tiles, waves 2 x 2 (64 x 64 each).
-// BMT = 64 : 64 x 128 tiles, waves 1 x 4 (64 x 32 each), 24 KB of LDS: for grids that would leave the CUs with only one or
+// BMT = 64 : 64 x 128 tiles, waves 1 x 4 (64 x 32 each), 24 KB of LDS, SIX workgroups per CU (80 VGPRs, no spills; five until the end of
+//            round 3: 5.185 -> 5.145 ms per training step, A/B of the two builds on one box): for grids that would leave the CUs with only one or
 //            two 128-row workgroups each (a padded batch gathered down to its valid rows) -- with NST = 1 the only thing that
 //            hides a slab's latency is the OTHER workgroups of the CU, so twice as many, half as tall, run faster.
 template <int NST, bool TRAIN, int BMT>
-__global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 5 : 4) : 1) void linear_glds_kernel(const MadeLinearArgs a) {
+__global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : 4) : 1) void linear_glds_kernel(const MadeLinearArgs a) {
     constexpr int STAGE = (BMT + BN) * KB;
     constexpr int NT = BMT == 128 ? 2 : 1;                 // 32-column accumulator tiles per wave
     constexpr int AP = BMT / 32;                           // 1 KB A pieces per wave per slab
