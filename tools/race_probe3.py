@@ -29,9 +29,39 @@ refc = tw["dchain"].clone() if "dchain" in tw else None                         
 # slot of tw["dchain"][layer] -> what the backward writes there (trainer.py: g1a, g1b, g2a, g2b, g2c, dt_out)
 HANDOFF = ("FFN-1 dX + residual", "query dX + residual", "norm-3 stage dx", "norm-2 stage dx", "norm-1 stage dx", "layer output (d tgt)")
 ORDER = (2, 0, 3, 1, 4, 5)                                                           # slots in the order the backward of a layer writes them
+# UNCACHED=1: the backward chain's hand-off buffers (dchain, dgN, dhs, the g_* stacks) in UNCACHED device memory
+# (hipExtMallocWithFlags(hipDeviceMallocUncached)): does the deviation need a cache between a chain kernel and the next one?
+_uncached_keep = []
+def uncached_like(t):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    ptr = C.c_void_p()
+    nbytes = t.numel() * t.element_size()
+    rc = hip.hipExtMallocWithFlags(C.byref(ptr), C.c_size_t(nbytes), C.c_uint(3))
+    assert rc == 0 and ptr.value, f"hipExtMallocWithFlags failed: {rc}"
+    class H:
+        pass
+    h = H()
+    typestr = {torch.bfloat16: "<u2", torch.float32: "<f4", torch.int32: "<i4"}[t.dtype]
+    h.__cuda_array_interface__ = {"shape": tuple(t.shape), "typestr": typestr, "data": (ptr.value, False), "version": 2}
+    u = torch.as_tensor(h, device=dev)
+    if t.dtype == torch.bfloat16:
+        u = u.view(torch.bfloat16)
+    u.zero_()
+    _uncached_keep.append(h)
+    return u
+def make_uncached(tw_):
+    for k in ("dchain", "dgN", "dhs"):
+        if k in tw_:
+            tw_[k] = uncached_like(tw_[k])
+    for k in list(tw_["dstack"].keys()):
+        if k.startswith("g_") or k == "dt1q":
+            tw_["dstack"][k] = uncached_like(tw_["dstack"][k])
 for mode in sys.argv[1:] or ("graph", "tape"):
     for rep in range(int(os.environ.get("N", "5"))):
         tr_ = MadeTrainer(cfg, sd, device=dev, dtype="bf16")
+        if os.environ.get("UNCACHED", "0") == "1":
+            make_uncached(tr_._train_buffers(B, Tv, Ta))
         g = tr_.capture_train_step(*b, mode=mode)
         og = g.step(*b, seed=7, lrs=(1e-4, 1e-4, 1e-4))
         torch.cuda.synchronize()
