@@ -1723,6 +1723,11 @@ static int tile_pref() {                                   // read on every call
     return e ? atoi(e) : 0;
 }
 
+static int64_t t16_max() {                                 // (MADE_T16_MAX: knob for measurements)
+    static const int64_t v = [] { const char* e = getenv("MADE_T16_MAX"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    return v;
+}
+
 // which kernel made_linear runs for these arguments (one place: the launcher and made_linear_variant both ask here)
 static int pick_variant(const MadeLinearArgs& a) {
     if (a.w_dtype != MADE_BF16) return MADE_LINEAR_GENERAL_F32;
@@ -1738,7 +1743,7 @@ static int pick_variant(const MadeLinearArgs& a) {
     // one 64-row tile (the decoder's chain, its per-head batches): 16 x 16 tiles, a third of the bytes per workgroup
     // (MADE_LINEAR_TILE=32: the 64 x 32-tile kernel instead, for A/B measurements)
     if (a.M <= 64 && a.K >= 128 && a.K <= 1024 && a.K % 32 == 0 && a.tile_skip_mask == nullptr && tile_pref() != 1 && tile_pref() != 32 &&
-        ((a.M + 15) / 16) * ((a.N + 15) / 16) * a.batch <= 4096)
+        ((a.M + 15) / 16) * ((a.N + 15) / 16) * a.batch <= t16_max())
         return MADE_LINEAR_TINY16;
     if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) return MADE_LINEAR_TINY;
     if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) return MADE_LINEAR_SKINNY;

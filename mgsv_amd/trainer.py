@@ -1128,11 +1128,32 @@ class MadeTrainer(MadeEngine):
         xq = c.moment_query_type == "xpool" and not regression
         side.wait_stream(cur)
         ret_done = None
+        ret_gen = None
         if not xq:                                           # (with an xpool query it follows the decoder's backward: see below)
-            with torch.cuda.stream(side):
-                self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
-                ret_done = torch.cuda.Event()
-                ret_done.record(side)
+            # MADE_RET_BWD_MAIN=1: on the main stream, in front of the heads and the decoder's chain (tools/race_probe3.py: beside the
+            # first decoder layers of the backward chain these launches are what makes one element of a chain product come out one
+            # bf16 ulp off in ~15 % of the first steps -- 0 of 60 with them on the main stream or with one stream only)
+            ret_main = os.environ.get("MADE_RET_BWD_MAIN", "0") == "1"
+            # MADE_RET_SPLIT (default 1): the branch's backward is issued in two parts -- up to the X-Pool tower's batched score / dP
+            # products now, those and everything behind them on the second stream BEHIND the decoder's chain (see below)
+            ret_split = (os.environ.get("MADE_RET_SPLIT", "1") != "0" and not ret_main and not regression
+                         and os.environ.get("MADE_RET_HANDOFF", "") == "" and os.environ.get("MADE_RET_HANDOFF_REV", "") == "")
+            with torch.cuda.stream(cur if ret_main else side):
+                self._ret_main_stream = cur
+                try:
+                    self._ret_ck(0)
+                    if ret_split:
+                        ret_gen = self._retrieval_bwd_gen(ws, tw, g_ret, B, Ta, sm)
+                        if next(ret_gen, "done") == "done":          # (a configuration without the tower: nothing left for later)
+                            ret_gen = None
+                    else:
+                        self._retrieval_bwd(ws, tw, g_ret, B, Ta, sm)
+                    on_main = torch.cuda.current_stream() == cur
+                finally:
+                    self._ret_main_stream = None
+                if ret_gen is None:
+                    ret_done = torch.cuda.Event()
+                    ret_done.record(cur if on_main else side)
 
         if regression:
             dmem, dtgt0 = self._regression_bwd(ws, tw, g_loc, B, L), None
@@ -1209,10 +1230,9 @@ class MadeTrainer(MadeEngine):
                 g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
                 if stage and os.environ.get("MADE_CHAIN_BUFS", "1") != "0":
                     # every hand-off of the chain gets rows of its own instead of three scratch buffers rewritten and re-read a few launches
-                    # apart (MADE_CHAIN_BUFS=0: the shared buffers).  In about 1 of 10 first steps a workgroup of one stage reads a row of
-                    # the previous launch's output with OLDER contents (whole rows of two or three samples 1e-6...5e-4 off from layer 4
-                    # down, tools/race_probe3.py); with rows of their own the old contents are last step's values of the same quantity and
-                    # the deviation is smaller and rarer (6 of 80 against 6 of 40) -- a mitigation, the cause is open
+                    # apart (MADE_CHAIN_BUFS=0: the shared buffers) -- a leftover of the hunt for the chain's one-ulp deviation, which
+                    # turned out to need two launches of the retrieval branch beside the chain (MADE_RET_SPLIT above);
+                    # kept: tools/race_probe3.py reads the hand-offs from here
                     ch = tw["dchain"][l]
                     g1a, g1b, g2a, g2b, g2c, dt_out = ch[0], ch[1], ch[2], ch[3], ch[4], ch[5]
                 else:
@@ -1328,6 +1348,15 @@ class MadeTrainer(MadeEngine):
             dw_side = os.environ.get("MADE_DEC_DW_SIDE", "1") != "0"       # (knob for A/B measurements)
             if dw_side:
                 side.wait_stream(cur)
+            if ret_gen is not None:
+                # second part of the retrieval branch's backward: behind the chain (second stream), in front of the weight gradients
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    for _ in ret_gen:
+                        pass
+                    ret_done = torch.cuda.Event()
+                    ret_done.record(side)
+                ret_gen = None
             dec_dw = torch.cuda.stream(side if dw_side else cur)
             dec_dw.__enter__()
             for launch in heads_dw:
@@ -1522,7 +1551,11 @@ class MadeTrainer(MadeEngine):
         dmem.view(B, L, D).copy_((dfx.float() / cnt)[:, None, :].expand(B, L, D))
         return dmem
 
-    def _retrieval_bwd(self, ws, tw, g_ret: Optional[Tensor], B: int, S: int, sm: Tensor, dpool: Optional[Tensor] = None) -> None:
+    def _retrieval_bwd(self, *a, **k) -> None:
+        for _ in self._retrieval_bwd_gen(*a, **k):
+            pass
+
+    def _retrieval_bwd_gen(self, ws, tw, g_ret: Optional[Tensor], B: int, S: int, sm: Tensor, dpool: Optional[Tensor] = None):
         c, P, G, D = self.cfg, self.P, self.G, self.cfg.D
         video, music = ws["video"], ws["music"]
         dvideo, dmusic = tw["dvideo"], tw["dmusic"]
@@ -1563,7 +1596,7 @@ class MadeTrainer(MadeEngine):
         if (single or dpool is not None or fuse_dz is not None) and "music" in c.vmr_fusion:
             if not single:
                 _tape.zero_(ds_s)                            # the tower feeds only the decoder's query / the fused similarity
-            self._xpool_bwd(tw, "xa", "x", ds_s, video, dvideo, seg, sm if c.fusion_mask == 1 else None, B, S, dpool=dpool, dz=fuse_dz)
+            yield from self._xpool_bwd_gen(tw, "xa", "x", ds_s, video, dvideo, seg, sm if c.fusion_mask == 1 else None, B, S, dpool=dpool, dz=fuse_dz)
         else:
             _tape.zero_(tw["xdseg"])
         if "video" in c.vmr_fusion:
@@ -1571,16 +1604,43 @@ class MadeTrainer(MadeEngine):
                 self._xpool_bwd(tw, "xav", "y", ds_st, music, dmusic, frame, self._inputs[2] if c.fusion_mask == 1 else None, B, frame.shape[1])
             else:
                 _tape.zero_(tw["ydseg"])
+        self._ret_ck(9)
         if dual:
             tr.gemm_tn(ds_dt, tw["mn"], tw["dvn"])            # d vhat = dsims mhat
             tr.gemm_tn(ds_d, tw["vn"], tw["dmn"])             # d mhat = dsims^T vhat
             tr.l2norm_bwd(video, tw["dvn"], dvideo, accumulate=True)
             tr.l2norm_bwd(music, tw["dmn"], dmusic, accumulate=True)
 
-    def _xpool_bwd(self, tw, key: str, pre: str, ds: Tensor, qvec: Tensor, dqvec: Tensor, seg: Tensor, seg_mask: Optional[Tensor], B: int, S: int,
-                   dpool: Optional[Tensor] = None, dz: Optional[Tensor] = None) -> None:
+    def _ret_ck(self, i: int) -> None:
+        """measurement knob (MADE_RET_HANDOFF=i): from checkpoint i of the retrieval branch's backward on, its launches go to the MAIN
+        stream (the ones before stay on the second stream) -- which of them disturbs the decoder's backward chain"""
+        if getattr(self, "_ret_main_stream", None) is None:
+            return
+        main = self._ret_main_stream
+        if os.environ.get("MADE_RET_HANDOFF", "") == str(i) and torch.cuda.current_stream() != main:
+            main.wait_stream(torch.cuda.current_stream())
+            torch.cuda.set_stream(main)
+        # MADE_RET_HANDOFF_REV=i: the other way round -- the launches in front of checkpoint i on the main stream, the rest on the second
+        rev = os.environ.get("MADE_RET_HANDOFF_REV", "")
+        if rev != "":
+            side = self._side_stream()
+            if i == 0 and int(rev) > 0 and torch.cuda.current_stream() != main:
+                main.wait_stream(torch.cuda.current_stream())
+                torch.cuda.set_stream(main)
+            elif i == int(rev) and i > 0 and torch.cuda.current_stream() == main:
+                side.wait_stream(main)
+                torch.cuda.set_stream(side)
+
+    def _xpool_bwd(self, *a, **k) -> None:
+        for _ in self._xpool_bwd_gen(*a, **k):
+            pass
+
+    def _xpool_bwd_gen(self, tw, key: str, pre: str, ds: Tensor, qvec: Tensor, dqvec: Tensor, seg: Tensor, seg_mask: Optional[Tensor], B: int, S: int,
+                       dpool: Optional[Tensor] = None, dz: Optional[Tensor] = None):
         """backward of one X-Pool tower (_xpool_train): ds = d loss / d sims [query, sequence]; accumulates the gradient of the query
-        vectors into dqvec and writes the gradient of the pooled sequences to tw[pre + "dseg"]."""
+        vectors into dqvec and writes the gradient of the pooled sequences to tw[pre + "dseg"].  A generator: it yields once, in front
+        of the two batched score / dP products (64 problems of 64 x 512 x 512, 2 x 33 MB streamed), so that backward() can issue what
+        follows behind the decoder's chain (MADE_RET_SPLIT)."""
         P, G, D = self.P, self.G, self.cfg.D
         skip = seg_mask.reshape(-1) if seg_mask is not None else None
         g1, g2, g3 = tw[pre + "g1"], tw[pre + "g2"], tw[pre + "g3"]
@@ -1594,23 +1654,32 @@ class MadeTrainer(MadeEngine):
         else:
             tr.xpool_tail_bwd(tw[pre + "y"], P[key + ".ln3.g"], P[key + ".ln3.b"], qvec, ds, g1, B, B, dy_drop=g2, drop=self._drop("xa.linear_out", dr.P_XPOOL),
                               dgamma=G[key + ".ln3.g"], dbeta=G[key + ".ln3.b"], dvideo=dqvec, dpool=dpool, dpool_scale=1.0 / B)
+        self._ret_ck(1)
         da3 = self._lin_bwd(g2, tw[pre + "a3"], key + ".lin", dx_out=g3, R=g1)
         tr.layernorm_bwd(tw[pre + "a2"], P[key + ".ln2.g"], da3, g1, dgamma=G[key + ".ln2.g"], dbeta=G[key + ".ln2.b"])
+        self._ret_ck(2)
         do = self._lin_bwd(g1, tw[pre + "o"], key + ".out", dx_out=g2)
         Sp = tw[pre + "S"].shape[1]
+        yield
+        self._ret_ck(3)
         xk, xu, q = tw[pre + "k"], tw[pre + "u"], tw[pre + "q"]
         ops.linear(q, xk[:S], None, M=B, N=S, K=D, batch=B, a_z_stride=0, w_z_stride=S * D, segs=[Seg(out=tw[pre + "S"], ldo=Sp, out_z_stride=B * Sp)])
         ops.linear(do[:B], xu[:S], None, M=B, N=S, K=D, batch=B, a_z_stride=B * D, w_z_stride=S * D, segs=[Seg(out=tw[pre + "dP"], ldo=Sp, out_z_stride=B * Sp)])
+        self._ret_ck(4)
         tr.softmax_bwd(tw[pre + "S"], tw[pre + "dP"], seg_mask, B, 1.0 / math.sqrt(D), tw[pre + "P"], tw[pre + "dS"], tw[pre + "dSt"], B, S, ldo=Sp, ldt=B)
         dkv = tw[pre + "dkv"]
+        self._ret_ck(5)
         # dU[m] = P[m]^T dO[m];  dK[m] = dS[m]^T q;  dq = sum_m dS[m] K[m]
         tr.gemm_tn(tw[pre + "P"][:B, :S], do[:B], dkv[:S, D:], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(B * D, 0), c_zs=(S * 2 * D, 0))
         tr.gemm_tn(tw[pre + "dS"][:B, :S], q, dkv[:S, :D], batch=(B, 1), a_zs=(B * Sp, 0), b_zs=(0, 0), c_zs=(S * 2 * D, 0))
         _tape.zero_(tw[pre + "dq32"])
         tr.gemm_tn(tw[pre + "dSt"][0], xk[:S], tw[pre + "dq32"], batch=(B, 1), a_zs=(S * B, 0), b_zs=(S * D, 0), c_zs=(0, 0), accumulate=True,
                    row_mask=seg_mask, mask_zs=(S, 0))
+        self._ret_ck(6)
         ds1 = self._lin_bwd(dkv, tw[pre + "s1"], key + ".kv", dx_out=tw[pre + "ds1"], row_mask=skip, skip=skip)
+        self._ret_ck(7)
         tr.layernorm_bwd(seg, P[key + ".ln1.g"], ds1, tw[pre + "dseg"], dgamma=G[key + ".ln1.g"], dbeta=G[key + ".ln1.b"], row_skip=skip)
+        self._ret_ck(8)
         dq = tr.add3(tw[pre + "dq"], tw[pre + "dq32"])
         dv1 = self._lin_bwd(dq, tw[pre + "v1"], key + ".q", dx_out=tw[pre + "dv1"])
         tr.layernorm_bwd(qvec, P[key + ".ln1.g"], dv1, dqvec, dgamma=G[key + ".ln1.g"], dbeta=G[key + ".ln1.b"], add=dqvec)

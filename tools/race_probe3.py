@@ -29,6 +29,10 @@ refc = tw["dchain"].clone() if "dchain" in tw else None                         
 # slot of tw["dchain"][layer] -> what the backward writes there (trainer.py: g1a, g1b, g2a, g2b, g2c, dt_out)
 HANDOFF = ("FFN-1 dX + residual", "query dX + residual", "norm-3 stage dx", "norm-2 stage dx", "norm-1 stage dx", "layer output (d tgt)")
 ORDER = (2, 0, 3, 1, 4, 5)                                                           # slots in the order the backward of a layer writes them
+# SINGLE=1: the captured trainers run everything on ONE stream (their second stream is the current one): does the deviation need a
+# second stream's kernels beside the chain?
+if os.environ.get("SINGLE", "0") == "1":
+    _orig_side = MadeTrainer._side_stream
 # UNCACHED=1: the backward chain's hand-off buffers (dchain, dgN, dhs, the g_* stacks) in UNCACHED device memory
 # (hipExtMallocWithFlags(hipDeviceMallocUncached)): does the deviation need a cache between a chain kernel and the next one?
 _uncached_keep = []
@@ -60,10 +64,26 @@ def make_uncached(tw_):
 for mode in sys.argv[1:] or ("graph", "tape"):
     for rep in range(int(os.environ.get("N", "5"))):
         tr_ = MadeTrainer(cfg, sd, device=dev, dtype="bf16")
+        if os.environ.get("SINGLE", "0") == "1":
+            tr_._side_stream = lambda: torch.cuda.current_stream()
+        if os.environ.get("RETMAIN", "0") == "1":
+            # two streams as always, but the retrieval branch's backward (the only second-stream work beside the first decoder layers of
+            # the backward chain) is issued on the MAIN stream in front of the chain
+            main_ = torch.cuda.current_stream()
+            orig_ = tr_._retrieval_bwd
+            def on_main(*a_, _o=orig_, **k_):
+                cur_ = torch.cuda.current_stream()
+                main_.wait_stream(cur_)
+                with torch.cuda.stream(main_):
+                    _o(*a_, **k_)
+                cur_.wait_stream(main_)
+            tr_._retrieval_bwd = on_main
         if os.environ.get("UNCACHED", "0") == "1":
             make_uncached(tr_._train_buffers(B, Tv, Ta))
         g = tr_.capture_train_step(*b, mode=mode)
-        og = g.step(*b, seed=7, lrs=(1e-4, 1e-4, 1e-4))
+        # LR0=1: the captured step updates nothing (learning rates 0): whatever a later trainer finds in recycled memory -- e.g. the
+        # bf16 weight copies of the trainer before it -- then equals what it writes there itself
+        og = g.step(*b, seed=7, lrs=(0.0, 0.0, 0.0) if os.environ.get("LR0", "0") == "1" else (1e-4, 1e-4, 1e-4))
         torch.cuda.synchronize()
         msg = []
         for k in keys:
