@@ -542,7 +542,8 @@ int made_set_criterion(const float* pred_logits, const float* pred_spans, const 
  *   dQ = scale * dS K         dK = scale * dS^T Q
  * Replaces autograd through nn.MultiheadAttention (reference model/model_Base.py:87, music_detr/transformer.py:199,287,
  * 293-296).  All tensors use the addressing of made_attention (element (b,i,h,d) at base + b*bs + i*ld + h*hd + d); dQ, dK,
- * dV may be column blocks of one [rows, 3*H*hd] buffer.  `delta` is a [B,H,Lq] f32 workspace the call fills.  Rows of dQ
+ * dV may be column blocks of one [rows, 3*H*hd] buffer.  `delta` is a [B,H,Lq] f32 workspace the call fills (bf16: by the dQ kernel, for the
+ * dK / dV kernel behind it; f32: by a launch of its own).  Rows of dQ
  * whose q_skip_mask is 0 and rows of dK/dV whose key_mask is 0 are written as zeros.  The per-sample mask / log-sum-exp / delta
  * rows live in LDS for the duration of a workgroup: MADE_ERR_UNSUPPORTED beyond ~8 000 queries or ~24 000 keys (fewer at
  * f32 head dim 128). */

@@ -130,7 +130,25 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
         }
     }
     const float lse_q = my_valid ? a.lse[(b * a.H + h) * a.Lq + qc] : INFINITY;     // +inf: every probability is 0
-    const float delta_q = my_valid ? a.delta[(b * a.H + h) * a.Lq + qc] : 0.f;
+    // delta_q = dO_q . O_q: the bf16 path makes it here, from the dO fragments this lane holds anyway (its partner lane has the other
+    // half of the head's columns), and writes it for the dK / dV kernel behind it -- the separate delta launch (13 us per attention
+    // layer on the step's main stream) is gone.  The f32 parity path keeps that launch and its summation order.
+    float delta_q;
+    if constexpr (IS_BF16) {
+        const TC* op_ = (const TC*)a.O + b * a.o_bs + qc * a.ldo + h * HD;
+        float dacc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NQF; ++ks) {
+            const frag_t of = *(const frag_t*)(op_ + ks * 2 * PER16 + hh * PER16);
+#pragma unroll
+            for (int j = 0; j < PER16; ++j) dacc += (float)dof[ks][j] * (float)of[j];
+        }
+        dacc += __shfl_xor(dacc, 32);
+        delta_q = my_valid ? dacc : 0.f;
+        if (my_valid && hh == 0) a.delta[(b * a.H + h) * a.Lq + qc] = dacc;
+    } else {
+        delta_q = my_valid ? a.delta[(b * a.H + h) * a.Lq + qc] : 0.f;
+    }
 
     // load_tile only ISSUES the next tile's loads (a use right behind them would make the wave wait before multiplying the current
     // tile); masked keys are zeroed in store_tile, one iteration later, from the bias row staged in LDS at the start
@@ -570,7 +588,8 @@ int launch_bwd_hd(const MadeAttnBwdArgs& a, dim3 gq, dim3 gk, size_t lds_q, size
 template <typename TC>
 int launch_bwd(const MadeAttnBwdArgs& a, hipStream_t st) {
     const int64_t rows = a.B * a.Lq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTH), 0, st, a);
+    if (a.dtype != MADE_BF16)                               // (bf16: the dQ kernel makes delta itself and hands it to the dK / dV kernel)
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NTH), 0, st, a);
     const int64_t pairs8 = 8 * ((a.H * a.B + 7) / 8);
     dim3 gq((unsigned)(((a.Lq + 127) / 128) * pairs8)), gk((unsigned)(((a.Lk + 127) / 128) * pairs8));
     const size_t lds_q = (size_t)((a.Lk + BKEY - 1) / BKEY) * BKEY * 4, lds_k = (size_t)((a.Lq + BQT - 1) / BQT) * BQT * 12;
