@@ -9,7 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmade_hip.so")
+# MADE_LIB_PATH: another build of the same library (A/B measurements of two builds on one box, tools/ab_libs.sh); it must export the same
+# ABI version, checked below, so a stale or older build fails here instead of reading shifted struct fields
+LIB_PATH = os.environ.get("MADE_LIB_PATH") or os.path.join(_HERE, "libmade_hip.so")
+ABI_VERSION = 4                          # include/made_hip.h MADE_ABI_VERSION the ctypes mirrors in this file were written for
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SIGMOID = 0, 1, 2, 3, 4
@@ -255,8 +258,9 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if l.made_abi_version() != 1:
-            raise MadeError(f"ABI version mismatch: library {l.made_abi_version()} != binding 1")
+        if l.made_abi_version() != ABI_VERSION:
+            raise MadeError(f"ABI version mismatch: {LIB_PATH} is version {l.made_abi_version()}, this binding was written for {ABI_VERSION} "
+                            "(rebuild: make -C mgsv_amd/csrc)")
         _lib = l
     return _lib
 

@@ -369,7 +369,11 @@ extern "C" int made_attention_wide_bwd(const MadeWideAttnBwdArgs* args, void* st
     MADE_REQUIRE(a.ld_p >= a.L, "made_attention_wide_bwd: ld_p < L");
     MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_attention_wide_bwd: dropout p out of [0,1)");
     if (a.dattc && !a.extra) {
-        MADE_REQUIRE(a.vbias != nullptr && a.hd > 0 && a.hd % 8 == 0 && a.hd * a.NQ <= a.D, "made_attention_wide_bwd: dattc needs vbias and hd (a multiple of 8)");
+        MADE_REQUIRE(a.vbias != nullptr && a.hd > 0 && a.hd % 8 == 0, "made_attention_wide_bwd: dattc needs vbias and hd (a multiple of 8)");
+        // the value-bias term maps query ROW q to HEAD q (row q of a sample is head q of its one moment query): with several moment
+        // queries per sample (rows = heads x queries) the caller passes `extra` instead
+        MADE_UNSUPPORTED(a.hd * a.NQ == a.D, "made_attention_wide_bwd: dattc needs the one-query layout NQ * hd == D (NQ=%lld hd=%lld D=%lld); pass `extra` otherwise",
+                         (long long)a.NQ, (long long)a.hd, (long long)a.D);
     }
     if (a.n_split > 1) {
         MADE_REQUIRE(a.part_dq != nullptr, "made_attention_wide_bwd: n_split > 1 needs part_dq");

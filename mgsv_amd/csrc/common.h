@@ -135,6 +135,10 @@ __device__ __forceinline__ float dpp_f32(float old, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef MADE_DEBUG_WAVE_SUM_SHFL                                  // (bisection builds of tools/build_variants.sh: the same sums through ds_bpermute)
+    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2);
+    return v;
+#endif
     v += dpp_f32<0xB1, 0xF>(v, v);                               // quad_perm [1,0,3,2]
     v += dpp_f32<0x4E, 0xF>(v, v);                               // quad_perm [2,3,0,1]
     v += dpp_f32<0x124, 0xF>(v, v);                              // row_ror:4

@@ -7,7 +7,9 @@
 While recording, torch's stream dependencies (Stream.wait_stream / wait_event, Event.record) are mirrored into the tape, every
 tensor handed to a library call is kept alive (the tape holds raw pointers), and fills / contiguous copies go through `zero_` /
 `copy_` below.  Any OTHER device work of the framework inside the recorded region (an ATen kernel) would be missing from the replay:
-`LaunchTape.record(check=True)` counts them with the profiler and raises if there are any.
+`LaunchTape.record(check=True)` (the default) watches the dispatcher while the step is recorded and raises `ForeignKernelError` naming every
+framework operator that touched a device tensor (allocations and views aside) -- a configuration whose step still contains such an
+operator cannot be replayed from the tape and is refused instead of silently skipping that work.
 """
 from __future__ import annotations
 
@@ -21,6 +23,37 @@ from . import _lib
 
 Tensor = torch.Tensor
 _recording: Optional["LaunchTape"] = None
+
+
+class ForeignKernelError(_lib.MadeError):
+    """framework (ATen) device work inside a recorded step: it would be missing from every replay"""
+
+
+# operators that launch nothing: allocation, views, metadata, host reads of host tensors
+_NO_KERNEL = {"empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "view", "_unsafe_view", "reshape", "_reshape_alias", "slice", "select",
+              "as_strided", "permute", "transpose", "t", "expand", "unsqueeze", "squeeze", "detach", "alias", "unbind", "split", "split_with_sizes",
+              "chunk", "narrow", "unfold", "view_as", "contiguous", "lift_fresh", "resolve_conj", "resolve_neg", "size", "stride", "numel", "dim",
+              "is_contiguous", "storage_offset", "sym_size", "sym_stride", "sym_numel", "sym_storage_offset", "_to_copy_noop", "view_as_real",
+              "is_pinned", "set_", "record_stream", "flatten", "unflatten", "movedim", "swapaxes", "diagonal"}
+
+
+def _make_watcher(found: list, every_device: bool):
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class _Watcher(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            out = func(*args, **kwargs)
+            name = func.overloadpacket.__name__ if hasattr(func, "overloadpacket") else str(func)
+            if name not in _NO_KERNEL:
+                def on_dev(x):
+                    return isinstance(x, torch.Tensor) and (x.is_cuda or every_device)
+                flat = list(args) + list(kwargs.values()) + (list(out) if isinstance(out, (tuple, list)) else [out])
+                flat = [y for x in flat for y in (x if isinstance(x, (tuple, list)) else [x])]
+                if any(on_dev(x) for x in flat):
+                    found.append(name)
+            return out
+    return _Watcher()
 
 
 def recording() -> bool:
@@ -59,10 +92,14 @@ class LaunchTape:
     # ---- recording
     @classmethod
     @contextlib.contextmanager
-    def record(cls):
+    def record(cls, check: bool = True, _every_device: bool = False):
+        """check: refuse a step that contains framework kernels (see the module docstring); `tape.foreign_ops` lists them either way
+        when check is False.  (_every_device: the CPU test of the watcher counts host tensors too.)"""
         global _recording
         assert _recording is None, "tapes do not nest"
         tape = cls()
+        tape.foreign_ops = []
+        watcher = _make_watcher(tape.foreign_ops, _every_device)
         lib = _lib.lib()
         S, E = torch.cuda.Stream, torch.cuda.Event
         o_ws, o_we, o_rec = S.wait_stream, S.wait_event, E.record
@@ -92,11 +129,19 @@ class LaunchTape:
         _recording = tape
         S.wait_stream, S.wait_event, E.record = wait_stream, wait_event, record
         try:
-            yield tape
+            with watcher:
+                yield tape
         finally:
             S.wait_stream, S.wait_event, E.record = o_ws, o_we, o_rec
             _recording = None
             _lib.check(lib.made_tape_end(C.byref(tape.handle)), "made_tape_end")
+        if check and tape.foreign_ops:
+            import collections
+            c = collections.Counter(tape.foreign_ops)
+            tape.close()
+            raise ForeignKernelError("the recorded step contains framework kernels a replay would skip: "
+                                     + ", ".join(f"aten::{k} x{v}" for k, v in sorted(c.items()))
+                                     + " -- this configuration cannot run from the launch tape (use mode='graph' or the eager step)")
 
     # ---- replay
     def replay(self) -> None:
@@ -125,10 +170,18 @@ class LaunchTape:
         _lib.check(_lib.lib().made_tape_count(self.handle, C.byref(k), C.byref(w), C.byref(o)), "made_tape_count")
         return int(k.value), int(w.value), int(o.value)
 
+    def close(self) -> None:
+        """Frees the tape and drops the tensors it kept alive -- after the device has finished: the last replay's kernels may still be
+        queued on the tape's streams, and the caching allocator would hand the released memory to new allocations under them."""
+        if self.handle.value:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+            _lib.lib().made_tape_free(self.handle)
+            self.handle = C.c_uint64(0)
+        self._keep = []
+
     def __del__(self):
         try:
-            if self.handle.value:
-                _lib.lib().made_tape_free(self.handle)
-                self.handle = C.c_uint64(0)
+            self.close()
         except Exception:
             pass

@@ -1924,7 +1924,10 @@ class TrainStepGraph:
                 if self.dist is not None:
                     raise NotImplementedError("TrainStepGraph(mode='tape') is single-process (data-parallel jobs capture three hipGraphs)")
                 keep2 = [x.clone() for x in (t.flat_param, t.exp_avg, t.exp_avg_sq)]
-                with _tape.LaunchTape.record() as tp:          # (runs the step for real: the state is put back below)
+                # the tape replays only the library's launches: a step that still runs a framework kernel (some non-headline
+                # configurations do: the BatchNorm affine of agg_module='mlp', Q > 1 copies, the regression head ...) is refused here
+                # (ForeignKernelError names the operators) instead of silently skipping that work on every replay
+                with _tape.LaunchTape.record(check=os.environ.get("MADE_TAPE_CHECK", "1") != "0") as tp:   # (runs the step for real: the state is put back below)
                     self.out = fwd_bwd(); opt()
                 torch.cuda.synchronize()
                 self.tape = tp
@@ -1970,6 +1973,15 @@ class TrainStepGraph:
             self._dev_step = keep_step
         finally:
             t._seed_dev, t._static_exclusion = None, None
+
+    def close(self) -> None:
+        """Waits for the last replay, then releases the tape / graphs and every buffer they reference.  Dropping a TrainStepGraph without
+        this is safe too (LaunchTape.close synchronises before it frees), this just makes the point in time explicit."""
+        torch.cuda.synchronize()
+        if getattr(self, "tape", None) is not None:
+            self.tape.close()
+            self.tape = None
+        self.graphs = []
 
     @staticmethod
     def _store_words(dst: Tensor, words) -> None:
