@@ -182,11 +182,11 @@ enum MadeLinearVariant {
     MADE_LINEAR_GLDS3 = 5,          /* linear_glds_kernel<3, ., 128>: at most one workgroup per CU, three LDS stages */
     MADE_LINEAR_GLDS64 = 6,         /* linear_glds_kernel<1, ., 64>: 64 x 128 tiles */
     MADE_LINEAR_GLDS128 = 7,        /* linear_glds_kernel<1, ., 128>: 128 x 128 tiles */
-    MADE_LINEAR_RING128 = 8,        /* linear_ring_kernel<128, 128>: two-stage LDS-DMA ring, one barrier per slab, two workgroups per CU;
-                                       opt-in since round 3 (MADE_LINEAR_TILE=2128), see csrc/linear.hip */
+    MADE_LINEAR_BIG256 = 8,         /* linear_big_kernel<256>: persistent, 256 x 256 tiles, two LDS stages, register epilogue (round 4; the
+                                       slot was round 2's ring kernel, removed) */
     MADE_LINEAR_TINY16 = 9,         /* linear_t16_kernel: at most 64 rows, 16 x 16 tiles (a third of the bytes per workgroup), 128 <= K <= 1024 */
-    MADE_LINEAR_WST = 10            /* linear_wst_kernel: W-stationary persistent kernel -- a 128 (or 64)-column weight panel stays in LDS, the waves
-                                       stream 16-row units past it straight from global memory into MFMA fragments; K = 256 / 512 / 1024, >= 4096 rows */
+    MADE_LINEAR_BIG128 = 10         /* linear_big_kernel<128>: the same with 128 x 256 tiles (MADE_LINEAR_TILE=256; the slot was round 3's
+                                       W-stationary kernel, removed) */
 };
 int made_linear_variant(const MadeLinearArgs* args);
 
@@ -470,6 +470,29 @@ typedef struct MadeXpoolFusedArgs {
 } MadeXpoolFusedArgs;
 
 int made_xpool_fused(const MadeXpoolFusedArgs* args, void* stream);
+
+/* made_xpool_attention: the attention of the X-Pool block at retrieval scale (every video against the segments of every track, ONE head
+ * of width D = 256 or 512; reference modules/transformer.py:87-123 as called by Transformer_XA.forward :156-180 and test-MaDe.py:392-395)
+ * plus the normalisation of LayerNorm2 (:172) without its affine part:
+ *   o[m, n, :]   = softmax_s(<Q[n], K[m, s]> * scale + (key_mask[m, s] == 0 ? -inf : 0)) . U[m, s, :]
+ *   out[m, n, :] = normalize ? (o - mean(o)) * rsqrt(var(o) + eps) : o                       (bf16, row (m * Nv + n) * ldo)
+ * The caller folds LayerNorm2's gamma / beta into the Linear that follows (W'' = (W + I) diag(gamma), b'' = (W + I) beta + b), so the
+ * residual of modules/transformer.py:176 costs nothing.  Two passes per track with the probabilities parked in LDS (bf16), K / U rows
+ * through LDS-DMA; S <= 512 segments.  Q [Nv, D], K / U [Nm, S, D] (rows at m * {k,u}_bs + s * ld{k,u}), all bf16; key_mask [Nm, S] f32
+ * or NULL; ws: Nm * 32 ints (valid range and one bit per segment of every track), 16-byte aligned.  A track without a valid segment
+ * gives NaN rows, like the reference's softmax over -inf. */
+typedef struct MadeXpoolAttnArgs {
+    const void* Q; int64_t ldq;
+    const void* K; const void* U; int64_t k_bs, ldk, u_bs, ldu;
+    const float* key_mask;
+    void* out; int64_t ldo;
+    int64_t Nv, Nm, S, D;
+    float scale, eps;
+    int32_t normalize; int32_t _pad;
+    void* ws;
+} MadeXpoolAttnArgs;
+
+int made_xpool_attention(const MadeXpoolAttnArgs* args, void* stream);
 
 /* made_row_affine: out[r, :] = act(x[r, :] * scale[r % period] + shift[r % period]), act = none | ReLU.  Eval-mode
  * BatchNorm1d of the EmbeddingNet aggregator (reference model/model_Base.py:224-229): its input is [B, T, F], so the

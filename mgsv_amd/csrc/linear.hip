@@ -769,324 +769,208 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : 4) : 1) void 
 }
 
 // =================================================================================================
-// Ring path: the encoder-sized launches (tens of thousands of rows, K = 512 .. 1024).
-// Measured (tools/probes/gemm_ring_probe.hip, profiles/r02_a_gemm_ring_probe.txt): with one LDS stage and two barriers per slab a
-// workgroup's LDS-DMA and its MFMAs never overlap; what bounds these launches is the rate at which a CU takes operand bytes in
-// (about 40-55 GB/s per CU through global_load_lds), so the loop must keep a slab in flight ALL the time and the tile must be
-// large enough that a byte is used often.  Here: two 32 KB (128 x 128) / 64 KB (256 x 256) stages, slab kt + 1 in flight while slab
-// kt is multiplied, one raw s_barrier per slab (a __syncthreads would add vmcnt(0) to every barrier), the wait for a slab placed
-// at its first reader.  128 x 128: four waves (2 x 2), two workgroups per CU, so one workgroup's epilogue runs beside the
-// other's K loop.  256 x 256: eight waves (2 x 4, 128 x 64 each), one workgroup per CU, half the operand bytes per flop.
-// Operands are swapped (acc = W-fragment x A-fragment): a lane then holds FOUR CONSECUTIVE COLUMNS of one output row, so the
-// accumulators go to the f32 LDS tile as 16-byte stores (16 per wave tile instead of 64 four-byte ones); the LDS tile is XOR
-// swizzled by row so both those stores and the row-contiguous read-back are bank-conflict free.
-template <int RBM, int RBN, int WM, int WN, bool TRAIN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void linear_ring_kernel(const MadeLinearArgs a) {
-    constexpr int NST = 2, NW = WM * WN, NTH = NW * 64;
-    constexpr int TM = RBM / WM, TN = RBN / WN, MT = TM / 32, NTL = TN / 32;
-    constexpr int STAGE = (RBM + RBN) * KB;
-    constexpr int PA = RBM / 8 / NW, PWN = RBN / 8 / NW;   // 1 KB pieces (8 rows x 128 B) per wave per slab
-    constexpr int PROWS = NST * STAGE / (RBN * 4);          // rows of the f32 epilogue tile that fit in the ring's LDS
-    constexpr int NPASS = RBM / PROWS;
-    static_assert(RBM % PROWS == 0 && PROWS % 32 == 0, "epilogue passes cover whole MFMA tiles");
-    extern __shared__ __attribute__((aligned(16))) unsigned char rlds[];
+// Big tiles, persistent: BMB x 256 outputs per 512-thread workgroup (8 waves as 2 x 4, each BMB / 2 x 64), one workgroup per CU walking the
+// launch's tiles.  For launches whose tiles fill the chip many times over (the retrieval path's per-pair Linear: millions of rows) and,
+// with BMB = 128, the encoder-sized ones.  What it does differently from the single-stage kernels above:
+//   * 256 x 256 tiles take in 7.8 bytes of operands per kFLOP (128 x 256: 11.7; the 64 x 128 tiles: 23) -- these launches are bound by the
+//     LDS-DMA intake of a CU, not by the matrix pipe;
+//   * two 64 KB (48 KB) LDS stages, slab k + 1 in flight while slab k is multiplied, ONE barrier per slab (lgkmcnt(0) in front of it: the
+//     round-3 rule for raw barriers beside LDS-DMA), and the ring does not stop at a tile's end: the next tile's first slab is issued
+//     before the current tile's epilogue, so the epilogue's stores run under it;
+//   * operands swapped (acc = W-fragment x A-fragment): a lane holds one output ROW, its registers the columns; v_permlane32_swap pairs
+//     the two lane halves' 4-column groups into 8 consecutive columns, and the tile leaves through the shared 8-column epilogue as
+//     16-byte stores straight from registers -- no LDS pass, no barrier in the epilogue;
+//   * the bias row of the whole problem (N <= 2048) sits in LDS for the launch.
+// XCD-aware persistent order: in every round the workgroups of one XCD take consecutive tile numbers (column tile fastest), so the
+// column tiles of an activation panel read it through one L2.
+constexpr int BIG_BN = 256, BIG_THREADS = 512, BIG_NMAX = 2048;
+
+// FAST: bias (+ ReLU) only, plain row-major output with 16-byte-aligned rows, N a multiple of 8 -- the epilogue is 64 straight-line groups
+// of (swap, add, convert, store); the general one runs the shared 8-column epilogue with all its options per group.
+template <int BMB, bool TRAIN, bool FAST>
+__global__ __launch_bounds__(BIG_THREADS, 1) void linear_big_kernel(const MadeLinearArgs a) {
+    constexpr int STAGE = (BMB + BIG_BN) * KB;
+    constexpr int MT = BMB / 64;                           // 32-row tiles per wave
+    constexpr int PA = BMB / 64, PW = BIG_BN / 64;         // 1 KB pieces (8 rows x 128 B) per wave per slab
+    extern __shared__ __attribute__((aligned(16))) unsigned char blds[];
+    float* bias_l = (float*)(blds + 2 * STAGE);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-
+    const int wm = wave >> 2, wn = wave & 3;
     const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
-    const int n_tiles = (N + RBN - 1) / RBN;
-    int Mv = M;                                            // row gather (see linear_kernel)
+    const int n_tiles = (N + BIG_BN - 1) / BIG_BN;
+    int Mv = M;
     if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
-    const int nwg = ((Mv + RBM - 1) / RBM) * n_tiles;
-    if ((int)blockIdx.x >= nwg) return;
-    int tile_id;                                           // XCD-aware order: the n-tiles of one activation panel share an L2
-    {
-        const int xcd = blockIdx.x & 7, q = nwg >> 3, rem = nwg & 7;
-        tile_id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
-    }
-    const int tile_m = tile_id / n_tiles, tile_n = tile_id % n_tiles;
-    const int m0 = tile_m * RBM, n0 = tile_n * RBN;
-    const int64_t z = blockIdx.z;
+    const int nwg = ((Mv + BMB - 1) / BMB) * n_tiles;
+    const int G = (int)gridDim.x;                          // a multiple of 8
+    const int bperm = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+    if (bperm >= nwg) return;
+    for (int i = tid; i < BIG_NMAX; i += BIG_THREADS) bias_l[i] = (a.bias && i < N) ? a.bias[i] : 0.f;
 
-    int si = 0;
-#pragma unroll
-    for (int s = 1; s < 4; ++s)
-        if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
-    const MadeLinearSeg seg = a.seg[si];
-
-    // ---- padded tiles (see linear_glds_kernel): every wave checks all rows itself, so the answer is uniform without a barrier
-    if (a.tile_skip_mask) {
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < RBM / 64; ++i) {
-            const int g = m0 + 64 * i + lane;
-            any = any || (g < M && a.tile_skip_mask[g] != 0.f);
-        }
-        if (!__any(any)) {
-            if (a.out_row_mask && !seg.transposed && (a.split_k <= 1)) {       // consumers expect zeros in masked rows
-                const int rpb0 = (int)seg.rows_per_batch;
-                for (int idx = tid; idx < RBM * (RBN / 8); idx += NTH) {
-                    const int row = idx / (RBN / 8), c8 = idx % (RBN / 8);
-                    const int m = m0 + row, n = n0 + c8 * 8;
-                    if (m >= M || n >= N) continue;
-                    int64_t orow;
-                    if (rpb0 > 0) { const int b = m / rpb0, t = m - b * rpb0; orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo; }
-                    else orow = (int64_t)m * seg.ldo;
-                    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    int nv = N - n; nv = nv > 8 ? 8 : nv;
-                    store8(seg.out, seg.out_dtype, blockIdx.z * seg.out_z_stride + orow + (n - (int)seg.col_begin), zero8, nv, false);
-                }
-            }
-            return;
-        }
-    }
-
-    // ---- per-lane LDS-DMA sources: piece j = rows 8j..8j+7 of the slab; lane l -> row 8j + l/8, LDS slot l%8 <- global chunk (l%8) ^ swz(row)
-    const bool repl = seg.use_a2 && a.A2 && a.a2_replace;
-    const bf16_t* Abase = (repl ? (const bf16_t*)a.A2 : (const bf16_t*)a.A) + z * a.a_z_stride;
-    const int64_t lda = repl ? a.lda2 : a.lda;
-    const bf16_t* Wbase = (const bf16_t*)a.W + z * a.w_z_stride;
-    const bf16_t* pa[PA];
-    const bf16_t* pw[PWN];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int row = 8 * (PA * wave + i) + (lane >> 3);
-        const int chunk = (lane & 7) ^ swz(row);
-        int gm = m0 + row; gm = gm < Mv ? gm : Mv - 1;        // rows past the edge are fetched from a valid row and never stored
-        if (a.row_index) gm = a.row_index[gm];
-        pa[i] = Abase + (int64_t)gm * lda + chunk * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < PWN; ++i) {
-        const int row = 8 * (PWN * wave + i) + (lane >> 3);
-        const int chunk = (lane & 7) ^ swz(row);
-        int gn = n0 + row; gn = gn < N ? gn : N - 1;
-        pw[i] = Wbase + (int64_t)gn * a.ldw + chunk * 8;
-    }
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-    f32x16 acc[MT][NTL];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    int offa[MT], offw[NTL], sa[MT], sw[NTL];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) { const int ra = wm * TM + t * 32 + r; offa[t] = ra * KB; sa[t] = swz(ra); }
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) { const int rw = wn * TN + t * 32 + r; offw[t] = RBM * KB + rw * KB; sw[t] = swz(rw); }
-
     const int nk = K / 64;
-    auto issue = [&](int kt) __attribute__((always_inline)) {
-        unsigned char* st = rlds + (kt & 1) * STAGE;
+    const int rmod = (int)a.r_row_mod;
+    const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+
+    // fragment read offsets (see linear_glds_kernel): row rr, 16-byte chunk c = 2 ks + hh at rr * 128 + ((c ^ swz(rr)) << 4)
+    int offa[MT], offw[2], sa[MT], sw[2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { const int ra = wm * (BMB / 2) + t * 32 + r; offa[t] = ra * KB; sa[t] = swz(ra); }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { const int rw = wn * 64 + t * 32 + r; offw[t] = BMB * KB + rw * KB; sw[t] = swz(rw); }
+
+    // per-lane LDS-DMA sources of a tile: piece j = rows 8j .. 8j + 7 of the slab; lane l -> row 8j + l / 8, LDS slot l % 8 <- chunk (l % 8) ^ swz(row)
+    const bf16_t* pa[PA];
+    const bf16_t* pw[PW];
+    auto tile_of = [&](int L, int& m0, int& n0) __attribute__((always_inline)) { m0 = (L / n_tiles) * BMB; n0 = (L % n_tiles) * BIG_BN; };
+    auto seg_of = [&](int n0) __attribute__((always_inline)) {
+        int si = 0;
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+            if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
+        return si;
+    };
+    auto set_sources = [&](int m0, int n0) __attribute__((always_inline)) {
+        const MadeLinearSeg& sg = a.seg[seg_of(n0)];
+        const bool repl = sg.use_a2 && a.A2 && a.a2_replace;
+        const bf16_t* Abase = repl ? (const bf16_t*)a.A2 : (const bf16_t*)a.A;
+        const int64_t lda = repl ? a.lda2 : a.lda;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = 8 * (PA * wave + i) + (lane >> 3);
+            int gm = m0 + row; gm = gm < Mv ? gm : Mv - 1;    // rows past the edge are fetched from a valid row and never stored
+            if (a.row_index) gm = a.row_index[gm];
+            pa[i] = Abase + (int64_t)gm * lda + (((lane & 7) ^ swz(row)) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int row = 8 * (PW * wave + i) + (lane >> 3);
+            int gn = n0 + row; gn = gn < N ? gn : N - 1;
+            pw[i] = (const bf16_t*)a.W + (int64_t)gn * a.ldw + (((lane & 7) ^ swz(row)) * 8);
+        }
+    };
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        unsigned char* st = blds + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < PA; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(st + (PA * wave + i) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < PWN; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(st + RBM * KB + (PWN * wave + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < PW; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(st + BMB * KB + (PW * wave + i) * 1024), 16, 0, 0);
     };
-    auto multiply = [&](int kt) __attribute__((always_inline)) {
-        const unsigned char* st = rlds + (kt & 1) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[MT], fw[NTL];
-            const int c = 2 * ks + hh;
-#pragma unroll
-            for (int t = 0; t < MT; ++t) fa[t] = *(const bf16x8*)(st + offa[t] + ((c ^ sa[t]) << 4));
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) fw[t] = *(const bf16x8*)(st + offw[t] + ((c ^ sw[t]) << 4));
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTL; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
-        }
-    };
-    // ---- the rows this thread finishes in the epilogue (one row per 16 tile rows, 8 columns each): their physical row numbers
-    // are loaded now, under the flight of slab 0, so that the residual / gate / mask loads that depend on them can be sent
-    // before the LAST slab is multiplied and land while the accumulators move through LDS.  With two workgroups per CU nothing
-    // else would hide those two dependent round trips per row (they cost the first version of this kernel 11 us of a 26 us launch).
-    constexpr int TPR = RBN / 8;                           // threads per output row
-    constexpr int RSTEP = NTH / TPR;                       // tile rows between two rows of one thread
-    constexpr int RPT = PROWS / RSTEP;                     // rows per thread
-    static_assert(NPASS == 1, "the prefetching epilogue covers the tile in one pass");
-    const int cc = tid % TPR, rr = tid / TPR;
-    const int n = n0 + cc * 8;
-    int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
-    issue(0);
-    // (loads under a per-element condition are serialised by hipcc, one round trip each: every group of loads below sits under ONE
-    // uniform branch, addresses are clamped instead of guarded)
-    int mrow[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) { const int ml = m0 + rr + RSTEP * i; mrow[i] = ml < Mv ? ml : Mv - 1; }
-    if (a.row_index) {
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) mrow[i] = a.row_index[mrow[i]];
-    }
-    float bv[8];
-    load_bias8(a.bias, n, N, bv);
-    const int rmod = (int)a.r_row_mod;
-    const bool r_pref = a.R && a.r_dtype == MADE_BF16 && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0) && nvalid == 8;
-    const bool g_pref = TRAIN && a.gate != MADE_GATE_NONE && a.g_dtype == MADE_BF16 && (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0) && nvalid == 8;
-    bf16x8 rpre[RPT], gpre[TRAIN ? RPT : 1];
-    float om[RPT];
 
-    // slab kt lives in stage kt & 1.  Per iteration: wait for slab kt (the only one in flight), barrier (everyone's pieces have landed AND
-    // everyone is done reading the other stage), send slab kt + 1 into that other stage, multiply slab kt under its flight.
-    // The barrier is `s_waitcnt lgkmcnt(0); s_barrier` (round 3): hipcc ties the wait for a fragment's ds_read to the MFMA that consumes
-    // it, and it may schedule those MFMAs BEHIND this asm statement -- a wave then passes the barrier with fragment reads of the old slab
-    // still queued in the LDS unit, the next slab's LDS-DMA lands in that stage first, and the MFMA multiplies rows of the wrong slab.
-    // Rare (the reads usually run hundreds of cycles ahead of the DMA) and dependent on what else keeps the CU's LDS busy: with two
-    // batches in flight 0.5-0.8 % of the forward passes had garbage rows in one tile (tools/race_probe_eval.py; 0 of 8000 with the
-    // wait, and 0 of 5000 with the same loop staging through registers, where the compiler sees the dependency itself).  The same
-    // wait now sits in front of every raw barrier of the LDS-DMA kernels (this one, the three-stage and the eight-stage rings above
-    // and below, the weight-gradient kernels); with it, the training step's forked decoder stage that came out a few ulps off in a
-    // fifth of the steps (tools/race_probe3.py, MADE_DEC_EARLY) is bit-reproducible too: 0 of 80.
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        issue(kt + 1);
-        multiply(kt);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // in flight under the last slab's MFMAs and the LDS staging
-    int rrow[RPT];                                         // row of the residual: the physical row, or its position in the table
+    int L = bperm, stage = 0;
+    int m0, n0;
+    tile_of(L, m0, n0);
+    set_sources(m0, n0);
+    issue(0, 0);
+    while (true) {
+        f32x16 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) rrow[i] = mrow[i];
-    if (rmod > 0) {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) rrow[i] = mrow[i] % rmod;
-    }
-    if (r_pref) {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) rpre[i] = *(const bf16x8*)((const bf16_t*)a.R + (int64_t)rrow[i] * a.ldr + n);
-    }
-    if constexpr (TRAIN) {
-        if (g_pref) {
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        // the rows this lane finishes (one per 32-row tile): physical row numbers, requested under the flight of the first slab
+        int mrow[MT];
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) gpre[i] = *(const bf16x8*)((const bf16_t*)a.G + (int64_t)mrow[i] * a.ldg + n);
+        for (int mt = 0; mt < MT; ++mt) { const int ml = m0 + wm * (BMB / 2) + mt * 32 + r; mrow[mt] = ml < Mv ? ml : Mv - 1; }
+        if (a.row_index) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) mrow[mt] = a.row_index[mrow[mt]];
         }
-    }
+        const int cur_m0 = m0, cur_n0 = n0;
+        const int Ln = L + G;
+        const bool more = Ln < nwg;
+        for (int kt = 0; kt < nk; ++kt) {
+            // slab kt (the only LDS-DMA in flight) has landed; everyone is done reading the other stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+            else if (more) { tile_of(Ln, m0, n0); set_sources(m0, n0); issue(0, stage ^ 1); }   // the next tile's first slab flies under this tile's tail
+            const unsigned char* st = blds + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) om[i] = 1.f;
-    if (a.out_row_mask) {
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fa[MT], fw[2];
+                const int c = 2 * ks + hh;
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) om[i] = a.out_row_mask[mrow[i]];
-    }
-    multiply(nk - 1);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // the epilogue reuses the ring's LDS
-
-    // ---- epilogue: accumulators -> swizzled f32 LDS tile (16-byte stores) -> row-contiguous vector I/O (bias, act, residual, ...)
-    float* Ct = (float*)rlds;
-    unsigned char* outp = (unsigned char*)seg.out;
-    const int64_t out_z = z * seg.out_z_stride;
-    const int rpb = (int)seg.rows_per_batch;
-    const int colb = (int)seg.col_begin;
-    const int odt = seg.out_dtype;
-    const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (seg.out_z_stride % 8 == 0) &&
-                         (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
-    const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+                for (int t = 0; t < MT; ++t) fa[t] = *(const bf16x8*)(st + offa[t] + ((c ^ sa[t]) << 4));
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int rl = wm * TM + mt * 32 + r;
+                for (int t = 0; t < 2; ++t) fw[t] = *(const bf16x8*)(st + offw[t] + ((c ^ sw[t]) << 4));
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = (wn * TN + nt * 32) / 4 + 2 * g + hh;       // 16-byte chunk (4 columns) of the row
-                f32x4 v;
-                v[0] = acc[mt][nt][4 * g]; v[1] = acc[mt][nt][4 * g + 1]; v[2] = acc[mt][nt][4 * g + 2]; v[3] = acc[mt][nt][4 * g + 3];
-                *(f32x4*)(Ct + rl * RBN + ((c ^ (rl & 15)) << 2)) = v;
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
-    }
-    __syncthreads();
-    if (nvalid <= 0) return;
-    const int act = a.act;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int row = rr + RSTEP * i;
-        if (m0 + row >= Mv) break;
-        const int m = mrow[i];
-        const float* rp = Ct + row * RBN;
-        const int sx = row & 15;
-        const f32x4 c0 = *(const f32x4*)(rp + (((2 * cc) ^ sx) << 2)), c1 = *(const f32x4*)(rp + (((2 * cc + 1) ^ sx) << 2));
-        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        // z = acc + bias [-> Zout]   v = act(z)   v *= act'(G) * gate_scale   v = dropout(v)   v += R   row mask   (epilogue8's order)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bv[j];
-        if constexpr (TRAIN) {
-            if (a.Zout) store8(a.Zout, a.z_dtype, (int64_t)m * a.ldz + n, v, nvalid, (a.ldz % 8 == 0) && (((uintptr_t)a.Zout & 15) == 0));
+            stage ^= 1;
         }
-        switch (act) {
-            case MADE_ACT_NONE: break;
-            case MADE_ACT_RELU:
+        // ---- epilogue from registers: lane (r, hh) holds row r of each 32-row tile, columns {0-3, 8-11, 16-19, 24-27} + 4 hh of each 32-column
+        // tile; the lane halves swap 4-column groups (hh = 0 ends with columns 0-7 and 16-23, hh = 1 with 8-15 and 24-31)
+        {
+            const MadeLinearSeg& seg = a.seg[seg_of(cur_n0)];
+            unsigned char* outp = (unsigned char*)seg.out;
+            const int rpb = (int)seg.rows_per_batch, colb = (int)seg.col_begin, odt = seg.out_dtype;
+            const bool out_vec = (seg.ldo % 8 == 0) && (seg.out_batch_stride % 8 == 0) && (((uintptr_t)outp & 15) == 0) && (colb % 8 == 0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                break;
-            default:
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ml = cur_m0 + wm * (BMB / 2) + mt * 32 + r;
+                const int m = mrow[mt];
+                int64_t orow;
+                if (rpb > 0) { const int b = m / rpb, t = m - b * rpb; orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo; }
+                else orow = (int64_t)m * seg.ldo;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = apply_act_fast(v[j], act);
-                break;
-        }
-        if constexpr (TRAIN) {
-            if (a.gate != MADE_GATE_NONE) {
-                float g[8];
-                if (g_pref) {
+                for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) g[j] = (float)gpre[i][j];
-                } else {
-                    load8(a.G, a.g_dtype, (int64_t)m * a.ldg + n, g, nvalid, (a.ldg % 8 == 0) && (((uintptr_t)a.G & 15) == 0));
-                }
+                    for (int half = 0; half < 2; ++half) {
+                        float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= act_grad_fast(g[j], a.gate) * a.gate_scale;
-            }
-            if (a.drop.p > 0.f) {
-                const uint32_t thr = made_drop_threshold(a.drop.p);
-                const float sc = 1.f / (1.f - a.drop.p);
-                if (a.drop_col_div > 1) {
-                    const uint64_t rb = (uint64_t)m * (uint64_t)a.drop_ld;
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            // (through scalar temporaries: __builtin_bit_cast applied DIRECTLY to an element of an ext_vector_type value --
+                            // `__builtin_bit_cast(unsigned, acc[i])` -- reads element 0 whatever i is with this hipcc (ROCm 7.2, clang 22))
+                            const float f0 = acc[mt][nt][8 * half + w2], f1 = acc[mt][nt][8 * half + 4 + w2];
+                            const auto swp = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, f0), __builtin_bit_cast(unsigned, f1), false, false);
+                            const unsigned s0 = swp[0], s1 = swp[1];
+                            v[w2] = __builtin_bit_cast(float, s0); v[4 + w2] = __builtin_bit_cast(float, s1);
+                        }
+                        const int n = cur_n0 + wn * 64 + nt * 32 + 16 * half + 8 * hh;
+                        int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
+                        if constexpr (FAST) {
+                            const f32x4 b0 = *(const f32x4*)(bias_l + (n < BIG_NMAX - 8 ? n : BIG_NMAX - 8)), b1 = *(const f32x4*)(bias_l + (n < BIG_NMAX - 8 ? n : BIG_NMAX - 8) + 4);
+                            v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
+                            if (a.act == MADE_ACT_RELU) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        v[j] = (made_rng_mix(made_drop_seed(a.drop), a.drop.site, rb + (uint64_t)((n + j) / a.drop_col_div)) >> 8) >= thr ? v[j] * sc : 0.f;
-                } else {
-                    const uint64_t base = (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n;
-                    const uint32_t kb = made_keep_bits<8>(made_drop_seed(a.drop), a.drop.site, thr, base);
+                                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                            }
+                            if (ml < Mv && nvalid == 8) {
+                                if (odt == MADE_BF16) {
+                                    bf16x8 t8;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * sc : 0.f;
+                                    for (int j = 0; j < 8; ++j) t8[j] = (bf16_t)v[j];
+                                    *(bf16x8*)((bf16_t*)outp + orow + (n - colb)) = t8;
+                                } else {
+                                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                                    *(f32x4*)((float*)outp + orow + (n - colb)) = o0;
+                                    *(f32x4*)((float*)outp + orow + (n - colb) + 4) = o1;
+                                }
+                            }
+                            continue;
+                        }
+                        if (ml < Mv && nvalid > 0) {
+                            const f32x4 b0 = *(const f32x4*)(bias_l + (n < BIG_NMAX - 8 ? n : BIG_NMAX - 8)), b1 = *(const f32x4*)(bias_l + (n < BIG_NMAX - 8 ? n : BIG_NMAX - 8) + 4);
+                            const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                            epilogue8<TRAIN>(a, m, n, nvalid, v, bv, rmod, r_vec);
+                            store8(outp, odt, orow + (n - colb), v, nvalid, out_vec);
+                        }
+                    }
                 }
             }
         }
-        if (a.R) {
-            if (r_pref) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)rpre[i][j];
-            } else {
-                float rv[8];
-                load8(a.R, a.r_dtype, (int64_t)rrow[i] * a.ldr + n, rv, nvalid, r_vec);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += rv[j];
-            }
-        }
-        if (om[i] == 0.f) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        }
-        int64_t orow;
-        if (rpb > 0) {
-            const int b = m / rpb, t = m - b * rpb;
-            orow = (int64_t)b * seg.out_batch_stride + (int64_t)t * seg.ldo;
-        } else {
-            orow = (int64_t)m * seg.ldo;
-        }
-        store8(outp, odt, out_z + orow + (n - colb), v, nvalid, out_vec);
+        if (!more) break;
+        L = Ln;
     }
 }
 
@@ -1505,219 +1389,6 @@ static void launch_t16(const MadeLinearArgs& a, hipStream_t st) {
 // 2128 the ring kernel (opt-in, see pick_variant), 1000 round 1's choice between its two kernels, 32 the 64 x 32-tile kernel where the
 // 16 x 16-tile one is the default (at most 64 rows)
 
-// =================================================================================================
-// W-stationary path: the encoder-sized launches with a short reduction (K = 256 / 512 / 1024; tens of thousands of rows).
-// The single-stage kernels above move every operand byte global -> LDS -> register under two barriers per 64-deep slab and
-// park the accumulators in LDS for the write-out; at K = 512 a tile is 8 slabs long, so its fill and its write-out are as
-// long as its MFMAs, and only other workgroups of the CU hide them (measured in the step: 240-300 TFLOP/s).  Here the WEIGHTS
-// stand still: a persistent workgroup keeps one panel of PT x 16 output columns x K in LDS (128 KB at PT = 8, K = 512; loaded
-// once by LDS-DMA, XOR-swizzled on the source side) and its four waves stream row units of 16 rows past it on their own:
-//   * activation fragments go global -> register directly in the MFMA layout (lane (r16, kq): row r16, 16 bytes at k = 32 s + 8 kq),
-//     WS_PD k-steps ahead of the MFMAs that use them -- no LDS round trip, no barrier anywhere in the K loop;
-//   * v_mfma_f32_16x16x32_bf16 with the operands swapped (W fragment first): a lane ends with FOUR CONSECUTIVE output columns of
-//     ONE row per tile; the panel's columns are dealt to (tile, MFMA row) so that tiles 2p and 2p + 1 give a lane columns
-//     32 p + 8 kq .. + 7 -- eight consecutive outputs, exactly what the shared epilogue8 / store8 take: the write-out leaves
-//     from registers with 16-byte stores, and a wave's epilogue runs beside the other waves' MFMAs;
-//   * one ds_read_b128 per W fragment and RB x PT MFMAs per PT reads (RB <= 4 row units per pass): a quarter of the LDS read
-//     rate at which the MFMA pipe would start to wait (MI355X_MICROARCH.md, LDS).
-// Work split: the live rows (row gather: *n_rows) are cut into 8 contiguous ranges, one per XCD, so that all panels of a row
-// range pull it through ONE L2; inside an XCD the (panel, row unit) plane, panel-major, is cut into equal consecutive ranges for
-// its workgroups (N = 512 / 1024 at PT = 8: 4 / 8 panels divide the 32 CUs, a workgroup never changes its panel).
-constexpr int WS_THREADS = 512, WS_WAVES = 8;              // two waves per SIMD: one's write-out and first loads run beside the other's MFMAs
-constexpr int WS_RBMAX = 2;                                 // 16-row units per pass of a wave (accumulators: RB x PT x 4 registers)
-constexpr int WS_PDF = 8;                                   // activation fragments a lane keeps in flight (PD = WS_PDF / RB k-steps ahead)
-constexpr int WS_STG_LD = 36;                               // floats per row of a wave's 16 x 32 write-out patch (144 bytes)
-
-template <int KSTEPS, int PT, bool TRAIN, int RB>
-__device__ __forceinline__ void wst_block(const MadeLinearArgs& a, void* const seg_out, const int seg_odt, const int64_t seg_ldo, const int rpb,
-                                          const int64_t seg_obs, const int colb, const unsigned char* panel, const bf16_t* Abase,
-                                          const int64_t lda, const int u0, const int Mv, const int n0,
-                                          const int (&wb)[4], const bool out_vec, const bool r_vec, const bool b_vec, float* stg) {
-    constexpr int ROWB = KSTEPS * 64;
-    constexpr int PD = (WS_PDF / RB) < KSTEPS ? (WS_PDF / RB) : KSTEPS;
-    const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
-    const int N = (int)a.N;
-    const bf16_t* pa[RB];
-#pragma unroll
-    for (int u = 0; u < RB; ++u) {
-        const int ml = (u0 + u) * 16 + r16;
-        int g = ml < Mv ? ml : Mv - 1;                        // rows past the edge are fetched from a valid row and never stored
-        if (a.row_index) g = a.row_index[g];
-        pa[u] = Abase + (int64_t)g * lda + kq * 8;
-    }
-    bf16x8 fa[PD][RB];
-#pragma unroll
-    for (int s = 0; s < PD; ++s)
-#pragma unroll
-        for (int u = 0; u < RB; ++u) fa[s][u] = *(const bf16x8*)(pa[u] + s * 32);
-    // the write-out's row of this lane (4 lanes per row, 8 columns each), requested now: its index is a dependent load otherwise
-    const int erow = lane >> 2, c8 = (lane & 3) * 8;
-    int em[RB];
-#pragma unroll
-    for (int u = 0; u < RB; ++u) {
-        const int ml = (u0 + u) * 16 + erow;
-        int g = ml < Mv ? ml : Mv - 1;
-        if (a.row_index) g = a.row_index[g];
-        em[u] = ml < Mv ? g : -1;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[RB][PT];
-#pragma unroll
-    for (int u = 0; u < RB; ++u)
-#pragma unroll
-        for (int t = 0; t < PT; ++t) { acc[u][t][0] = 0.f; acc[u][t][1] = 0.f; acc[u][t][2] = 0.f; acc[u][t][3] = 0.f; }
-    // the W fragments of k-step s + 1 are read from LDS ahead of the MFMAs of k-step s (two register sets)
-    bf16x8 fw[2][PT];
-#pragma unroll
-    for (int t = 0; t < PT; ++t) fw[0][t] = *(const bf16x8*)(panel + wb[0] + ((t >> 1) * 32 + (t & 1) * 4) * ROWB);
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-        if (s + 1 < KSTEPS) {
-#pragma unroll
-            for (int t = 0; t < PT; ++t)
-                fw[(s + 1) & 1][t] = *(const bf16x8*)(panel + wb[(s + 1) & 3] + ((t >> 1) * 32 + (t & 1) * 4) * ROWB + ((s + 1) >> 2) * 256);
-        }
-#pragma unroll
-        for (int u = 0; u < RB; ++u)
-#pragma unroll
-            for (int t = 0; t < PT; ++t)
-                acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s & 1][t], fa[s % PD][u], acc[u][t], 0, 0, 0);
-        if (s + PD < KSTEPS) {
-#pragma unroll
-            for (int u = 0; u < RB; ++u) fa[s % PD][u] = *(const bf16x8*)(pa[u] + (s + PD) * 32);
-        }
-        // (without this hipcc sinks every prefetch down to its first use -- a load, s_waitcnt vmcnt(0), eight MFMAs, the next load: the
-        //  K loop ran one memory round trip per k-step)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // write-out: 16 rows x 32 columns (two accumulator tiles) at a time through this wave's own LDS patch (no barrier: nobody else
-    // touches it), so that a lane ends with 8 consecutive outputs of one row for the shared epilogue8 / store8 and a row leaves as
-    // 64-byte (bf16) / 128-byte (f32) contiguous pieces.  The unit loop is a run-time loop (the epilogue's code exists PT / 2 times per
-    // instantiation, not RB x PT / 2 times); which accumulator goes to the patch is a per-register select.
-    const int rmod = (int)a.r_row_mod;
-    float* wr = stg + r16 * WS_STG_LD + kq * 8;
-    const float* rd = stg + erow * WS_STG_LD + c8;
-    constexpr int NQ = PT / 2;
-#pragma unroll 1
-    for (int uq = 0; uq < RB * NQ; ++uq) {
-        const int u = uq / NQ, q = uq % NQ;
-#define WST_PUT(K_)                                                                                                  \
-        case K_:                                                                                                     \
-            if constexpr (K_ < RB * NQ) { *(f32x4*)wr = acc[K_ / NQ][(K_ % NQ) * 2]; *(f32x4*)(wr + 4) = acc[K_ / NQ][(K_ % NQ) * 2 + 1]; } \
-            break;
-        switch (uq) { WST_PUT(0) WST_PUT(1) WST_PUT(2) WST_PUT(3) WST_PUT(4) WST_PUT(5) WST_PUT(6) WST_PUT(7) default: break; }
-#undef WST_PUT
-        const f32x4 q0 = *(const f32x4*)rd, q1 = *(const f32x4*)(rd + 4);
-        const int m = (RB > 1 && u) ? em[RB - 1] : em[0];
-        const int n = n0 + q * 32 + c8;
-        int nvalid = N - n; nvalid = nvalid > 8 ? 8 : nvalid;
-        if (m < 0 || nvalid <= 0) continue;
-        int64_t orow;
-        if (rpb > 0) { const int b = m / rpb, t = m - b * rpb; orow = (int64_t)b * seg_obs + (int64_t)t * seg_ldo; }
-        else orow = (int64_t)m * seg_ldo;
-        float bh[8];
-        if (b_vec && nvalid == 8) {
-            const f32x4 b0 = *(const f32x4*)(a.bias + n), b1 = *(const f32x4*)(a.bias + n + 4);
-            bh[0] = b0[0]; bh[1] = b0[1]; bh[2] = b0[2]; bh[3] = b0[3]; bh[4] = b1[0]; bh[5] = b1[1]; bh[6] = b1[2]; bh[7] = b1[3];
-        } else {
-            load_bias8(a.bias, n, N, bh);
-        }
-        float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-        epilogue8<TRAIN>(a, m, n, nvalid, v, bh, rmod, r_vec);
-        store8(seg_out, seg_odt, orow + (n - colb), v, nvalid, out_vec);
-    }
-}
-
-template <int KSTEPS, int PT, bool TRAIN>
-__global__ __launch_bounds__(WS_THREADS) void linear_wst_kernel(const MadeLinearArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wst_lds[];
-    constexpr int ROWB = KSTEPS * 64, PROWS = PT * 16, PIECES = PROWS * ROWB / 1024;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int M = (int)a.M, N = (int)a.N;
-    int Mv = M;
-    if (a.n_rows) { const int nv = *a.n_rows; Mv = nv < M ? nv : M; }
-    if (Mv <= 0) return;
-    const int NP = (N + PROWS - 1) / PROWS;                  // panels
-    const int U = (Mv + 15) >> 4;                            // 16-row units
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nx = gridDim.x >> 3;     // (the grid is a multiple of 8: workgroups go round-robin over the XCDs)
-    const int ux0 = (int)((int64_t)U * xcd / 8), ux1 = (int)((int64_t)U * (xcd + 1) / 8), UX = ux1 - ux0;
-    if (UX <= 0) return;
-    const int64_t Wk = (int64_t)NP * UX;
-    int64_t w0 = Wk * j / nx;
-    const int64_t w1 = Wk * (j + 1) / nx;
-    // fragment reads: tile t, MFMA row i = r16 is panel row (t / 2) * 32 + (i / 4) * 8 + (t & 1) * 4 + (i & 3); the 16-byte chunk c of a row
-    // sits at chunk (c & ~15) | ((c & 15) ^ i) (conflict-free ds_read_b128: the 16 lanes of a group hit 16 different bank quads)
-    int wb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wb[q] = ((r16 >> 2) * 8 + (r16 & 3)) * ROWB + (((q * 4 + kq) ^ r16) << 4);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    float* stg = (float*)(wst_lds + PROWS * ROWB) + wave * (16 * WS_STG_LD);
-    const bool b_vec = a.bias && (((uintptr_t)a.bias & 15) == 0);
-    bool first = true;
-    while (w0 < w1) {
-        const int p = (int)(w0 / UX);
-        const int a0 = (int)(w0 - (int64_t)p * UX);
-        int64_t e1 = w1 - (int64_t)p * UX;
-        const int a1 = e1 < UX ? (int)e1 : UX;
-        const int n0 = p * PROWS;
-        int si = 0;
-#pragma unroll
-        for (int s = 1; s < 4; ++s)
-            if (s < a.nseg && n0 >= a.seg[s].col_begin) si = s;
-        void* const seg_out = a.seg[si].out;
-        const int seg_odt = a.seg[si].out_dtype, seg_rpb = (int)a.seg[si].rows_per_batch, seg_colb = (int)a.seg[si].col_begin;
-        const int64_t seg_ldo = a.seg[si].ldo, seg_obs = a.seg[si].out_batch_stride;
-        const bool repl = a.seg[si].use_a2 && a.A2 && a.a2_replace;
-        const bf16_t* Abase = repl ? (const bf16_t*)a.A2 : (const bf16_t*)a.A;
-        const int64_t lda = repl ? a.lda2 : a.lda;
-        if (!first) __syncthreads();                         // every wave is done with the previous panel
-        first = false;
-        for (int q = wave; q < PIECES; q += WS_WAVES) {      // 1 KB per wave instruction, straight into LDS
-            const int lb = q * 1024 + lane * 16;
-            const int row = lb / ROWB, pos = (lb % ROWB) >> 4;
-            const int key = ((row & 31) >> 3) * 4 + (row & 3);
-            const int ch = (pos & ~15) | ((pos & 15) ^ key);
-            int gn = n0 + row; gn = gn < N ? gn : N - 1;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)((const bf16_t*)a.W + (int64_t)gn * a.ldw + ch * 8), (lds_ptr_t)(wst_lds + q * 1024), 16, 0, 0);
-        }
-        const bool out_vec = (seg_ldo % 8 == 0) && (seg_obs % 8 == 0) && (((uintptr_t)seg_out & 15) == 0) && (seg_colb % 8 == 0);
-        const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
-        __syncthreads();                                     // the panel has landed (the barrier waits for every wave's LDS-DMA)
-        const int nu = a1 - a0;
-        const int b0 = a0 + nu * wave / WS_WAVES, b1 = a0 + nu * (wave + 1) / WS_WAVES, nw = b1 - b0;
-        const int nb = (nw + WS_RBMAX - 1) / WS_RBMAX;
-        for (int ib = 0; ib < nb; ++ib) {
-            const int c0 = b0 + nw * ib / nb, c1 = b0 + nw * (ib + 1) / nb;
-            const int u0 = ux0 + c0;
-            if (c1 - c0 == 2) wst_block<KSTEPS, PT, TRAIN, 2>(a, seg_out, seg_odt, seg_ldo, seg_rpb, seg_obs, seg_colb, wst_lds, Abase, lda, u0, Mv, n0, wb, out_vec, r_vec, b_vec, stg);
-            else if (c1 - c0 == 1) wst_block<KSTEPS, PT, TRAIN, 1>(a, seg_out, seg_odt, seg_ldo, seg_rpb, seg_obs, seg_colb, wst_lds, Abase, lda, u0, Mv, n0, wb, out_vec, r_vec, b_vec, stg);
-        }
-        w0 += a1 - a0;
-    }
-}
-
-template <int KSTEPS, int PT, bool TRAIN>
-static void launch_wst_one(const MadeLinearArgs& a, hipStream_t st, int n_cu) {
-    constexpr int LDSB = PT * 16 * KSTEPS * 64 + WS_WAVES * 16 * WS_STG_LD * 4;
-    static const bool once = [] { return hipFuncSetAttribute((const void*)linear_wst_kernel<KSTEPS, PT, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess; }();
-    (void)once;
-    dim3 grid((unsigned)n_cu), block(WS_THREADS);            // one workgroup per CU (the panel is 64 - 128 KB)
-    hipLaunchKernelGGL((linear_wst_kernel<KSTEPS, PT, TRAIN>), grid, block, LDSB, st, a);
-}
-static int wst_cus() {
-    static const int n = [] { int dev = 0, c = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c >= 8 ? (c / 8) * 8 : 8; }();
-    return n;
-}
-template <bool TRAIN>
-static void launch_wst(const MadeLinearArgs& a, hipStream_t st) {
-    const int n_cu = wst_cus();
-    if (a.K == 1024) launch_wst_one<32, 4, TRAIN>(a, st, n_cu);          // 64-column panels: 128 KB
-    else if (a.K == 512) launch_wst_one<16, 8, TRAIN>(a, st, n_cu);      // 128-column panels: 128 KB
-    else launch_wst_one<8, 8, TRAIN>(a, st, n_cu);                       // K = 256: 64 KB
-}
-
 static int tile_pref() {                                   // read on every call: the tests switch kernels inside one process
     const char* e = getenv("MADE_LINEAR_TILE");
     return e ? atoi(e) : 0;
@@ -1748,28 +1419,19 @@ static int pick_variant(const MadeLinearArgs& a) {
     if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) return MADE_LINEAR_TINY;
     if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) return MADE_LINEAR_SKINNY;
     if (tiles * a.batch <= 256) return MADE_LINEAR_GLDS3;                  // at most one workgroup per CU
-    // Ring kernel (round 2): measured per shape against round 1's kernels under graph replay (tools/ring_bench.py,
-    // profiles/r02_a_ring_bench.txt): it wins by 8-17 % on the gathered launches that are 512 columns wide (out-proj, the second FFN
-    // Linear, the encoders' final / input projections) and loses by 5-15 % on the wider ones, where round 1's 4-5 small
-    // workgroups per CU hide prologue, epilogue and the write burst better than two large ones.
-    // (eval epilogues only: with two workgroups per CU the training epilogue's dropout hash / GELU' are not hidden: 90-124 us against
-    // round 1's 48-70 us on the same launches, profiles/r02_b_train_trace_summary.txt)
-    const bool train_epi = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
-    // The ring kernel is opt-in since round 3 (MADE_LINEAR_TILE=2128; round 2 chose it for gathered launches of at most 512 columns without a
-    // training epilogue).  Two reasons, both measured: (1) its raw barriers lacked `s_waitcnt lgkmcnt(0)` -- garbage rows in 0.5-0.8 % of
-    // the forward passes beside a second stream, see the kernel's K loop; fixed, 0 of 8000 since -- and (2) with the fix, A/B on one box:
-    // the training step 5.33-5.35 ms with it against 5.22-5.24 ms without (its two 64 KB workgroups per CU get in the way of the second
-    // stream's launches), the eval forward 1.109 against 1.117 ms.
-    (void)train_epi;
-    if (tile_pref() == 2128) return MADE_LINEAR_RING128;
-    // W-stationary persistent kernel (round 3, third part): bf16, K = 256 / 512 / 1024, one problem, no tile skipping.  Opt-in
-    // (MADE_LINEAR_TILE=4128, or MADE_WST=1 for every launch of at least 4096 rows): measured at parity with the single-stage kernels
-    // alone (tools/wst_bench.py: 34688 x 512 x 512 39.2 against 38.1 us, x 1024 62.3 against 71.5 us, K = 1024 75.9 against 61.1 us) and 3 %
-    // slower inside the training step (5.40 - 5.42 against 5.26 ms, A/B on one box: one 150 KB workgroup per CU and the second stream's
-    // launches keep each other off the CUs -- the ring kernel's finding again), see DESIGN.md 3c-3
-    const bool wst_ok = (a.K == 256 || a.K == 512 || a.K == 1024) && a.batch == 1 && a.tile_skip_mask == nullptr && a.ldw % 8 == 0;
-    static const bool wst_on = [] { const char* e = getenv("MADE_WST"); return e && atoi(e) == 1; }();     // (read once)
-    if (wst_ok && (tile_pref() == 4128 || (tile_pref() == 0 && a.M >= 4096 && wst_on))) return MADE_LINEAR_WST;
+    // Persistent big-tile kernel (round 4; the ring / W-stationary kernels of rounds 2-3 lost inside the step and were removed):
+    // 256 x 256 tiles when the tiles fill the chip at least twice over and nothing is gathered (the retrieval path's per-pair Linear),
+    // 128 x 256 tiles on request (MADE_LINEAR_TILE=256; 512 forces the 256-row tiles).
+    {
+        bool big_ok = a.batch == 1 && a.tile_skip_mask == nullptr && a.N <= BIG_NMAX && a.ldw % 8 == 0;
+        for (int s = 0; s < a.nseg; ++s) big_ok = big_ok && (a.seg[s].col_begin % BIG_BN == 0) && a.seg[s].out_z_stride == 0;
+        if (big_ok) {
+            if (tile_pref() == 512) return MADE_LINEAR_BIG256;
+            if (tile_pref() == 256) return MADE_LINEAR_BIG128;
+            const int64_t tiles256 = ((a.M + 255) / 256) * ((a.N + BIG_BN - 1) / BIG_BN);
+            if (tile_pref() == 0 && !a.row_index && tiles256 >= 2 * 256) return MADE_LINEAR_BIG256;
+        }
+    }
     // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
     const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
     if (tile_pref() == 64) return MADE_LINEAR_GLDS64;
@@ -1876,22 +1538,45 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
             else hipLaunchKernelGGL((linear_glds_kernel<1, false, 64>), g, block, 0, st, a);
             break;
         }
-        case MADE_LINEAR_WST:
-            if (train) launch_wst<true>(a, st); else launch_wst<false>(a, st);
-            break;
         case MADE_LINEAR_GLDS128:
             if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128>), grid, block, 0, st, a);
             break;
-        case MADE_LINEAR_RING128: {                        // 128 x 128 tiles, two-stage LDS-DMA ring, two workgroups per CU
-            constexpr int LDSB = 2 * (128 + 128) * KB;
+        case MADE_LINEAR_BIG256:
+        case MADE_LINEAR_BIG128: {                         // persistent: one workgroup per CU (a multiple of 8: one eighth per XCD)
+            const bool b256 = pick_variant(a) == MADE_LINEAR_BIG256;
+            const int bmb = b256 ? 256 : 128;
+            const int ldsb = 2 * (bmb + BIG_BN) * KB + BIG_NMAX * 4;
+            static const int n_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 8 ? n : 256; }();
             static const bool once = [] {
-                return hipFuncSetAttribute((const void*)linear_ring_kernel<128, 128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess &&
-                       hipFuncSetAttribute((const void*)linear_ring_kernel<128, 128, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+                constexpr int l256 = 2 * (256 + BIG_BN) * KB + BIG_NMAX * 4, l128 = 2 * (128 + BIG_BN) * KB + BIG_NMAX * 4;
+                bool ok = true;
+                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l256) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l256) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l256) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
+                return ok;
             }();
             (void)once;
-            if (train) hipLaunchKernelGGL((linear_ring_kernel<128, 128, 2, 2, true>), grid, block, LDSB, st, a);
-            else hipLaunchKernelGGL((linear_ring_kernel<128, 128, 2, 2, false>), grid, block, LDSB, st, a);
+            const int64_t nt = ((a.M + bmb - 1) / bmb) * ((a.N + BIG_BN - 1) / BIG_BN);
+            int64_t g = (n_cu / 8) * 8;
+            if (nt < g) g = ((nt + 7) / 8) * 8;
+            dim3 gb((unsigned)g), bb(BIG_THREADS);
+            // the straight-line epilogue: bias (+ ReLU) only, plain row-major output rows of whole 16-byte groups
+            bool fastep = !train && a.R == nullptr && a.out_row_mask == nullptr && (a.act == MADE_ACT_NONE || a.act == MADE_ACT_RELU) && a.N % 8 == 0;
+            for (int s = 0; s < a.nseg; ++s)
+                fastep = fastep && a.seg[s].rows_per_batch == 0 && a.seg[s].ldo % 8 == 0 && a.seg[s].col_begin % 8 == 0 && (((uintptr_t)a.seg[s].out & 15) == 0);
+            if (b256) {
+                if (train) hipLaunchKernelGGL((linear_big_kernel<256, true, false>), gb, bb, ldsb, st, a);
+                else if (fastep) hipLaunchKernelGGL((linear_big_kernel<256, false, true>), gb, bb, ldsb, st, a);
+                else hipLaunchKernelGGL((linear_big_kernel<256, false, false>), gb, bb, ldsb, st, a);
+            } else {
+                if (train) hipLaunchKernelGGL((linear_big_kernel<128, true, false>), gb, bb, ldsb, st, a);
+                else if (fastep) hipLaunchKernelGGL((linear_big_kernel<128, false, true>), gb, bb, ldsb, st, a);
+                else hipLaunchKernelGGL((linear_big_kernel<128, false, false>), gb, bb, ldsb, st, a);
+            }
             break;
         }
         case MADE_LINEAR_GENERAL_F32IN: hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a); break;

@@ -3,10 +3,12 @@
 // The reference moves the cost matrix to the host and calls SciPy once per sample and decoder layer
 // (music_detr/matcher.py:89-91: 6 D2H syncs per forward).  Here one launch handles all
 // n_layers*B samples: a wave computes the sample's cost block in f32 with the reference's operation
-// order (explicit *_rn intrinsics, so hipcc cannot contract mul+add into FMA and change the bits),
+// order (explicit *_rn intrinsics AND contraction switched off for this file: HIP's __fadd_rn / __fmul_rn are plain + and *, which
+// the default -ffp-contract=fast may still fuse into an FMA -- which products it fused moved with an unrelated compile flag),
 // then lane 0 runs the shortest-augmenting-path LSAP (Crouse 2016, as SciPy implements it, same
 // tie-break) on the f64-promoted block.  Q, G <= 64, so all solver state lives in LDS.
 #include "common.h"
+#pragma clang fp contract(off)
 
 namespace {
 

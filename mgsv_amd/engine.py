@@ -19,6 +19,7 @@ Data layout in HBM (B = batch, L = T_v + T_a under concat fusion, D = dim_input)
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -142,6 +143,13 @@ class MadeEngine:
             vec(key + ".kv.b", torch.cat([T(xa + ".cross_attn.k_proj.bias"), T(xa + ".cross_attn.v_proj.bias")], 0))
             lin(key + ".out", xa + ".cross_attn.out_proj")
             lin(key + ".lin", xa + ".linear_proj")
+            # LayerNorm2's affine part and the residual of modules/transformer.py:176 folded into the Linear (float64 on the host), for
+            # the retrieval path whose attention kernel emits xhat = (o - mean) * rstd:
+            #   x = xhat g2 + b2,  x + (W x + b) = (W + I) diag(g2) xhat + ((W + I) b2 + b)
+            W64 = T(xa + ".linear_proj.weight").double().cpu() + torch.eye(D, dtype=torch.float64)
+            g2, b2 = T(xa + ".layer_norm2.weight").double().cpu(), T(xa + ".layer_norm2.bias").double().cpu()
+            mat(key + ".linf.w", (W64 * g2[None, :]).float().to(dev))
+            vec(key + ".linf.b", (W64 @ b2 + T(xa + ".linear_proj.bias").double().cpu()).float().to(dev))
         vec("logit_scale", T("logit_scale").view(1))
         if "CA" in c.mml_fusion:                                          # reference model/model_Base.py:99-213
             ca = "video_music_fusion_cross_transformer"
@@ -409,6 +417,7 @@ class MadeEngine:
         Nm, S, _ = seg.shape
         if sims_out is None:
             sims_out = torch.empty(Nv, Nm, device=dev, dtype=torch.float32)
+        chunk_m_given = chunk_m is not None
         if chunk_m is None:
             budget = 6 << 30                                             # bytes of per-pair intermediates per chunk
             per_m = Nv * 3 * D * tc.itemsize + 4 * S * D * tc.itemsize
@@ -438,6 +447,33 @@ class MadeEngine:
                                 (P[tower + ".ln2.g"], P[tower + ".ln2.b"]), P[tower + ".lin.w"], P[tower + ".lin.b"],
                                 (P[tower + ".ln3.g"], P[tower + ".ln3.b"]), vn, sims_out[:, m0:m0 + n], scale=1.0 / math.sqrt(D),
                                 ws=xws, prepare_ws=(m0 == 0))
+            return sims_out
+        if tc == torch.bfloat16 and D in (256, 512) and S <= 512 and pooled_out is None and Nv >= 256 and os.environ.get("MADE_XPOOL_ATTN", "1") != "0":
+            # retrieval scale at the widths / lengths made_xpool_fused does not serve (D = 512, or more than its segments): the attention
+            # as ONE two-pass kernel per chunk of tracks (made_xpool_attention: scores of a whole track in LDS, the normalisation of
+            # LayerNorm2 in its tail), then the folded Linear and LayerNorm3 + cosine.  Chunks of about 1 GB of per-pair rows per tensor:
+            # measured (tools/retr512_breakdown.py, 8192 x 512 x S 512), chunks small enough to stay in the Infinity Cache lose more to
+            # short launches (13.8 ms per pass at 12 tracks per chunk) than they gain (11.45 ms at 96).
+            cm = chunk_m if chunk_m is not None and chunk_m_given else max(1, min(Nm, (1 << 30) // max(Nv * D * tc.itemsize, 1)))
+            s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
+            kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
+            ubuf = torch.empty(cm * S, D, device=dev, dtype=tc)
+            ubuf2 = torch.empty(cm * S, D, device=dev, dtype=tc)
+            xh = torch.empty(cm * Nv, D, device=dev, dtype=tc)
+            y = torch.empty(cm * Nv, D, device=dev, dtype=tc)
+            iws = torch.empty(cm * 32, device=dev, dtype=torch.int32)
+            for m0 in range(0, Nm, cm):
+                n = min(cm, Nm - m0)
+                skip = seg_mask[m0:m0 + n].reshape(-1) if seg_mask is not None else None
+                ops.layernorm(seg[m0:m0 + n], P[tower + ".ln1.g"], P[tower + ".ln1.b"], out=s1[:n * S], row_skip=skip)
+                ops.linear(s1[:n * S], P[tower + ".kv.w"], P[tower + ".kv.b"], tile_skip_mask=skip,
+                           segs=[Seg(out=kbuf, col_begin=0), Seg(out=ubuf, col_begin=D)])
+                ops.linear(ubuf[:n * S], P[tower + ".out.w"], P[tower + ".out.b"], out=ubuf2[:n * S], tile_skip_mask=skip)
+                ops.xpool_attention(q, kbuf[:n * S].view(n, S, D), ubuf2[:n * S].view(n, S, D),
+                                    seg_mask[m0:m0 + n] if seg_mask is not None else None, xh[:n * Nv].view(n, Nv, D),
+                                    scale=1.0 / math.sqrt(D), ws=iws)
+                ops.linear(xh[:n * Nv], P[tower + ".linf.w"], P[tower + ".linf.b"], out=y[:n * Nv])
+                ops.xpool_tail(y[:n * Nv], P[tower + ".ln3.g"], P[tower + ".ln3.b"], video, sims_out[:, m0:m0 + n], n, Nv)
             return sims_out
         cm = min(chunk_m, Nm)
         s1 = torch.empty(cm * S, D, device=dev, dtype=tc)

@@ -151,7 +151,7 @@ class Seg:
 # made_linear_variant codes (include/made_hip.h: MadeLinearVariant) -> KernelTimer kinds = rocprofv3 kernel symbols
 LINEAR_VARIANTS = {0: "linear_f32", 1: "linear_f32in_bf16", 2: "linear_kernel<bf16,bf16>", 3: "linear_tiny_kernel", 4: "linear_skinny_kernel",
                    5: "linear_glds_kernel<3,.,128>", 6: "linear_glds_kernel<1,.,64>", 7: "linear_glds_kernel<1,.,128>",
-                   8: "linear_ring_kernel<128,128>", 9: "linear_t16_kernel", 10: "linear_wst_kernel"}
+                   8: "linear_big_kernel<256>", 9: "linear_t16_kernel", 10: "linear_big_kernel<128>"}
 
 
 def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,
@@ -601,6 +601,35 @@ def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2
     _timed("xpool_fused", flops, float(2 * (K.numel() + U.numel()) + 4 * Nv * Nm + 2 * Q.numel()),
            lambda: check(lib().made_xpool_fused(C.byref(a), _stream()), "made_xpool_fused"), desc)
     return sims
+
+
+def xpool_attention(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], out: Tensor, scale: float, normalize: bool = True,
+                    eps: float = 1e-5, ws: Optional[Tensor] = None) -> Tensor:
+    """The X-Pool attention at retrieval scale, head dim = D = 256 or 512, S <= 512 (made_xpool_attention): Q [Nv, D], K / U [Nm, S, D]
+    bf16 (unit inner stride), key_mask [Nm, S] or None -> out [Nm, Nv, D] bf16: softmax_s(Q K^T * scale + mask) U, then (normalize)
+    (x - mean) * rstd over D -- LayerNorm2 without its affine part, which the caller folds into the Linear behind it."""
+    from ._lib import MadeXpoolAttnArgs
+    Nv, D = Q.shape
+    Nm, S, _ = K.shape
+    assert Q.dtype == K.dtype == U.dtype == out.dtype == torch.bfloat16 and Q.stride(1) == 1 and K.stride(2) == 1 and U.stride(2) == 1
+    assert U.shape == K.shape and out.dim() == 3 and tuple(out.shape) == (Nm, Nv, D) and out.stride(2) == 1 and out.stride(0) == Nv * out.stride(1)
+    a = MadeXpoolAttnArgs()
+    a.Q, a.ldq = _p(Q), Q.stride(0)
+    a.K, a.U, a.k_bs, a.ldk, a.u_bs, a.ldu = _p(K), _p(U), K.stride(0), K.stride(1), U.stride(0), U.stride(1)
+    a.key_mask = _p(_f32(key_mask.contiguous(), "key_mask")) if key_mask is not None else None
+    a.out, a.ldo = _p(out), out.stride(1)
+    a.Nv, a.Nm, a.S, a.D, a.scale, a.eps, a.normalize = Nv, Nm, S, D, scale, eps, 1 if normalize else 0
+    if ws is None:
+        ws = torch.empty(Nm * 32, device=Q.device, dtype=torch.int32)
+    assert ws.dtype == torch.int32 and ws.is_contiguous() and ws.numel() >= Nm * 32
+    a.ws = _p(ws)
+    flops = 4.0 * Nv * Nm * S * D
+    desc = ""
+    if _timer is not None and key_mask is not None:             # executed work: the valid segments of each track only
+        desc = ("frac", float((key_mask != 0).sum().item()) / float(Nm * S))
+    _timed("xpool_attention", flops, float(2 * (K.numel() + U.numel()) + 2 * Nv * Nm * D + 2 * Q.numel()),
+           lambda: check(lib().made_xpool_attention(C.byref(a), _stream()), "made_xpool_attention"), desc)
+    return out
 
 
 def clip_loss(sims: Tensor, logit_scale: Tensor, loss_out: Tensor, weight: float = 1.0, accumulate: bool = False,

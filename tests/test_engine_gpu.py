@@ -307,6 +307,38 @@ def test_retrieval_bf16_fused_xpool_kernel(N_v, N_m, S):
     assert bool((sim.cpu().argmax(1)[clear] == top_ref.indices[:, 0][clear]).all())
 
 
+@pytest.mark.parametrize("N_v,N_m,S", [(300, 9, 200), (257, 5, 40), (512, 6, 512)])
+def test_retrieval_bf16_two_pass_xpool_attention_at_the_headline_width(N_v, N_m, S):
+    """Retrieval at D = 512 (BASELINE configs[1] / [2]'s width; reference test-MaDe.py:386-403 with modules/transformer.py:156-180): the
+    attention of every (video, track) pair in made_xpool_attention (two passes per track, probabilities in LDS, LayerNorm2's
+    normalisation in the tail), the folded Linear and LayerNorm3 + cosine behind it -- against the f32 oracle within the bf16 tolerance
+    of the similarity matrix, and against the separate-launch bf16 chain (taken below 256 videos)."""
+    cfg = cfg_headline()
+    assert cfg.D == 512
+    sd = synth.make_state_dict(cfg, seed=0)
+    eng = MadeEngine(cfg, sd, dtype="bf16")
+    dev = eng.device
+    ri = synth.make_retrieval_inputs(N_v, N_m, S, cfg.D, seed=7, min_len=3)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in ri.items()}
+    sim = eng.retrieval_sim_matrix(t["video_embeds"], t["segment_embeds"], t["segment_masks"], t["music_embeds"])
+    sim2 = eng.retrieval_sim_matrix(t["video_embeds"], t["segment_embeds"], t["segment_masks"], t["music_embeds"], chunk_m=2)
+    torch.cuda.synchronize()
+    assert torch.equal(sim, sim2)                                       # every pair is independent of the chunking of the tracks
+    with torch.no_grad():
+        ref = O.retrieval_sim_matrix(O.to_torch_params(sd), cfg, ri["video_embeds"], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
+    err = float((sim.cpu() - ref).abs().max())
+    assert err <= 3e-2, err
+    parts = [eng.retrieval_sim_matrix(t["video_embeds"][a:a + 200], t["segment_embeds"], t["segment_masks"], t["music_embeds"])
+             for a in range(0, N_v, 200)]
+    unfused = torch.cat(parts, 0)
+    torch.cuda.synchronize()
+    assert float((unfused.cpu() - ref).abs().max()) <= 3e-2
+    assert float((sim - unfused).abs().max()) <= 3e-2
+    top_ref = ref.topk(2, dim=1)
+    clear = (top_ref.values[:, 0] - top_ref.values[:, 1]) > 6e-2
+    assert bool((sim.cpu().argmax(1)[clear] == top_ref.indices[:, 0][clear]).all())
+
+
 def test_two_batches_in_flight_match_one_at_a_time():
     """bench.py --in-flight 2: two engines (own workspace, stream, captured graph) run different batches concurrently.  Every
     output of either lane must be bit-identical to the same engine running its batch alone, replay after replay: nothing in the

@@ -149,8 +149,8 @@ def test_linear_training_epilogue(T, dtype, tol):
 
 
 @pytest.mark.parametrize("K,N", [(512, 1024), (512, 512), (1024, 512), (256, 640)])
-def test_linear_wst_training_epilogue(T, K, N, monkeypatch):
-    """The W-stationary kernel (encoder-sized launches, csrc/linear.hip linear_wst_kernel) with the training epilogue: Zout, ReLU,
+def test_linear_big_tile_training_epilogue(T, K, N, monkeypatch):
+    """The persistent big-tile kernel (csrc/linear.hip linear_big_kernel, 128 x 256 tiles) with the training epilogue: Zout, ReLU,
     stateless dropout, residual, the backward's ReLU gate, row gather -- against f32 math on the bf16 operands, and against the
     single-stage kernel (MADE_LINEAR_TILE=64) on the same call: the same dropout draws, sums within bf16 rounding of each other."""
     ops, tr = T
@@ -169,7 +169,7 @@ def test_linear_wst_training_epilogue(T, K, N, monkeypatch):
     z_ref = A.float() @ W.float().t() + bias
     ref = torch.relu(z_ref) * keep / (1 - p) + R.float()
     got = {}
-    for tile in ("4128", "64"):
+    for tile in ("256", "64"):
         monkeypatch.setenv("MADE_LINEAR_TILE", tile)
         Z = torch.full((M, N), float("nan"), device="cuda", dtype=dtype)
         out = torch.full((M, N), float("nan"), device="cuda", dtype=dtype)
@@ -179,10 +179,10 @@ def test_linear_wst_training_epilogue(T, K, N, monkeypatch):
         assert float((Z[valid].float() - z_ref[valid]).abs().max()) <= 2e-2 * float(z_ref.abs().max())
         assert float((out[valid].float() - ref[valid]).abs().max()) <= 2e-2 * float(ref.abs().max()) + 0.05
         got[tile] = (out[valid].float(), Z[valid].float())
-    assert ((got["4128"][0] == 0) == (got["64"][0] == 0)).float().mean() > 0.999                   # the same draws
-    assert float((got["4128"][1] - got["64"][1]).abs().max()) <= 2e-2 * float(z_ref.abs().max())
+    assert ((got["256"][0] == 0) == (got["64"][0] == 0)).float().mean() > 0.999                   # the same draws
+    assert float((got["256"][1] - got["64"][1]).abs().max()) <= 2e-2 * float(z_ref.abs().max())
     # the backward's gate on the same kernel: out = (A W^T) * [G != 0] * scale, no gather
-    monkeypatch.setenv("MADE_LINEAR_TILE", "4128")
+    monkeypatch.setenv("MADE_LINEAR_TILE", "512")
     G = torch.relu(_rand(M, N, dtype=dtype, seed=5))
     out = ops.linear(A, W, None, gate=_lib.GATE_RELU_OUT, G=G, gate_scale=1.0 / 0.9)
     base = A.float() @ W.float().t()

@@ -4,10 +4,10 @@
 def kind(name):
     """-> (KernelTimer kind of mgsv_amd/ops.py / ops_train.py, counts_as_launch).  A made_* entry point that launches several kernels
     (made_attention_bwd: delta + dq + dkv; made_gemm_tn: either of its two kernels) sums their bytes; one of them counts the launches."""
-    if "linear_wst_kernel" in name:
-        return "linear_wst_kernel", True
-    if "linear_ring_kernel" in name:
-        return "linear_ring_kernel<128,128>", True
+    if "linear_big_kernel" in name:
+        return ("linear_big_kernel<256>" if ("ILi256E" in name or "<256" in name) else "linear_big_kernel<128>"), True
+    if "xpool_attn_kernel" in name:
+        return "xpool_attention", True
     if "linear_glds_kernelILi1" in name or "linear_glds_kernel<1" in name:
         return ("linear_glds_kernel<1,.,64>" if ("ELi64E" in name or ", 64>" in name) else "linear_glds_kernel<1,.,128>"), True
     if "linear_glds_kernel" in name:
