@@ -40,8 +40,8 @@ from mgsv_amd.engine import MadeEngine  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round3.sh), per leg
-ROCPROF_AVG_FILE = os.path.join(ROOT, "profiles", "r03_kernel_avg_us.json")   # per-leg, per-kernel average durations of the committed rocprofv3 --kernel-trace --stats runs
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round4.sh), per leg
+ROCPROF_AVG_FILE = os.path.join(ROOT, "profiles", "r04_kernel_avg_us.json")   # per-leg, per-kernel average durations of the committed rocprofv3 --kernel-trace --stats runs
 STEP_CEILING_PAIRS_S = {"train": 62000.0, "eval": 186000.0}          # MFMA ceilings of the whole step (fwd+bwd / fwd)
 
 
@@ -104,13 +104,12 @@ def parse():
 # ------------------------------------------------------------------------------------------------- helpers
 def _roofline(summ: dict, kind: str, dtype: str, per: int, leg: str, overhead_us: float = 0.0) -> dict:
     """Roofline entry of one timed kernel kind: achieved = algorithmic (executed: valid rows / valid keys only) flops or bytes / launch
-    time; the binding roof is the slower of the MFMA and the HBM floor for the kernel's algorithmic flops and bytes.  Launch time: the
-    HIP-event average with the event bracket's own cost calibrated out (see _event_pair_overhead_us); the raw event average and, when
-    the committed rocprofv3 summary of this leg holds the kernel, its average are reported beside it."""
+    time; the binding roof is the slower of the MFMA and the HBM floor for the kernel's algorithmic flops and bytes.  Launch time: the raw
+    HIP-event average of this run; the committed rocprofv3 average of the same leg and the event average with the bracket's own cost
+    calibrated out (see _event_pair_overhead_us) are reported beside it, each with the fraction it would give."""
     d = summ[kind]
     raw_us = d["ms"] / d["launches"] * 1e3
     cal_us = max(raw_us - overhead_us, 0.25 * raw_us)
-    sec = cal_us * 1e-6 * d["launches"]
     peak = PEAK_TFLOPS[dtype]
     t_mfma = d["flops"] / (peak * 1e12)
     t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
@@ -125,17 +124,28 @@ def _roofline(summ: dict, kind: str, dtype: str, per: int, leg: str, overhead_us
             rocprof_us = json.load(open(ROCPROF_AVG_FILE)).get(leg, {}).get(kind)
         except Exception:
             rocprof_us = None
-    common = dict(kernel=kind, launches_per_step=d["launches"] // per, avg_launch_us=round(cal_us, 2), avg_launch_us_event_raw=round(raw_us, 2),
-                  event_pair_overhead_us=round(overhead_us, 2), avg_launch_us_rocprof_committed=rocprof_us,
+    # `frac` / `achieved` stand on a DIRECTLY MEASURED time: the raw HIP-event average of this run.  Beside it: the same quantity on the
+    # committed rocprofv3 per-kernel average of this leg (another run of the same command: profiles/) and on the event average with the
+    # event bracket's own cost calibrated out (an estimate: the bracket's cost comes from a probe kernel, not from the kernel rated)
+    sec = raw_us * 1e-6 * d["launches"]
+    hbm_bound = t_hbm > t_mfma
+    work, roof = (d["bytes"] / 1e9, HBM_PEAK_GBS) if hbm_bound else (d["flops"] / 1e12, peak)
+    per_launch = work / d["launches"]
+
+    def frac_at(us):
+        return round(per_launch / (us * 1e-6) / roof, 4) if us else None
+    common = dict(kernel=kind, launches_per_step=d["launches"] // per, avg_launch_us=round(raw_us, 2), time_basis="HIP events around every launch, this run (raw)",
+                  avg_launch_us_rocprof_committed=rocprof_us, frac_at_rocprof_committed=frac_at(rocprof_us),
+                  avg_launch_us_event_calibrated=round(cal_us, 2), event_pair_overhead_us=round(overhead_us, 2), frac_at_event_calibrated=frac_at(cal_us),
                   algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
                   algorithmic_mb_per_launch=round(d["bytes"] / d["launches"] / 1e6, 3), traffic=traffic,
                   mfma_tflops=round(d["flops"] / sec / 1e12, 2), hbm_gbs=round(d["bytes"] / sec / 1e9, 1),
                   executed_fraction_of_nominal=round(d["flops"] / max(d["flops_nominal"], 1.0), 3),
                   measured="HIP events around every launch of 2-3 extra eager steps AFTER the timed region (not part of ms_per_step)")
-    if cal_us < 20.0 and d["flops"] / d["launches"] < 2e9:
+    if raw_us < 20.0 and d["flops"] / d["launches"] < 2e9:
         # a launch of a few workgroups that lasts one or two dependent memory round trips: neither roof binds it
         common["regime"] = "latency-bound (small launch: a few dependent memory round trips; the roofline fraction is nominal)"
-    if t_hbm > t_mfma:
+    if hbm_bound:
         a = d["bytes"] / sec / 1e9
         return dict(bound="hbm", achieved=round(a, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4), **common)
     a = d["flops"] / sec / 1e12
@@ -388,11 +398,12 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
         except Exception as ex:                      # report, do not hide
             print(f"[bench] hipGraph capture of the training step failed ({type(ex).__name__}: {ex})", file=sys.stderr)
     # The library's own launch tape (made_tape_*: the step's ~560 launches recorded once, replayed from one C loop onto the same two
-    # streams): what `value` is measured with when it is available (--launch graph, one process) -- the eager step beside it.
+    # streams): what `value` is measured with when it is available (--launch graph) -- the eager step beside it.
     launch, eager_ms = "eager", None
-    if args.launch == "graph" and world == 1 and os.environ.get("MADE_BENCH_TAPE", "1") != "0":
+    if args.launch == "graph" and os.environ.get("MADE_BENCH_TAPE", "1") != "0":
         try:
-            tape = trn.capture_train_step(*batch, max_grad_norm=1.0, mode="tape")
+            tape = trn.capture_train_step(*batch, max_grad_norm=1.0, mode="tape", dist=dist if world > 1 else None)   # (N > 1: the two
+            # gradient all-reduces are host callbacks of the tape)
 
             tbatch = tuple(tape.inputs[k] for k in ("frame_feats", "segment_feats", "frame_masks", "segment_masks", "spans_target"))   # the tape's own
             # batch buffers (the same synthetic batch, resident in HBM): a loader would write the next batch there directly
@@ -421,7 +432,7 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
     elapsed = _max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert bool(torch.isfinite(out["localization_loss"]).all()) and bool(torch.isfinite(out["retrieval_loss"]).all())
     assert bool(torch.isfinite(trn.flat_param).all())
-    per_kernel, roof = {}, None
+    per_kernel, roof, executed_gflop = {}, None, 0.0
     if rank == 0:
         with ops.KernelTimer() as kt:                # per-kernel HIP events need the eager launches (a replay is one launch)
             for _ in range(2):
@@ -434,17 +445,24 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
         fl, ms_ = sum(summ[k]["flops"] for k in mm), sum(summ[k]["ms"] for k in mm)
         roof["all_gemms_of_the_step"] = dict(tflops=round(fl / (ms_ * 1e-3) / 1e12, 2), frac=round(fl / (ms_ * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
                                              ms_per_step=round(ms_ / 2, 3), launches_per_step=sum(summ[k]["launches"] for k in mm) // 2)
+        executed_gflop = sum(v["flops"] for v in summ.values()) / 2 / 1e9        # every timed kernel kind: GEMMs, weight gradients, attention
     sec = elapsed / steps
     res = {"metric": "video-music pairs/s, full training step (fwd + bwd + matcher + clip/Adam), B=64 per GPU",
            "value": round(world * B / sec, 1), "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
            "data": "synthetic",
-           "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 4}]: B={B}/GPU, T_v={Tv}, T_a={Ta}, D={cfg.D}, train mode (dropout on), "
+           "config": {"workload": f"BASELINE.json configs[{2 if (world == 1 and not args.ta) else 4}]{' (per-GPU shape, one GPU)' if (world == 1 and args.ta) else ''}: B={B}/GPU, T_v={Tv}, T_a={Ta}, D={cfg.D}, train mode (dropout on), "
                                   "f32 master weights + Adam, f32 gradient accumulation",
                       "global_batch": world * B, "parallelism": f"dp{world}: the flat f32 gradient buffer all-reduced in two buckets, the large one under the encoders' backward",
                       "launch": launch, "eager_ms_per_step": eager_ms if launch == "tape" else round(sec * 1e3, 3), "captured_graph_ms_per_step": graph_ms, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+                      "batch_upload": ("excluded: the recorded step reads the batch from its own resident input buffers (a loader would write the next batch "
+                                       "there); the eager step beside it takes the same resident tensors") if launch == "tape" else "none: batch tensors resident in HBM",
                       "step_fraction_of_ceiling": round(B / sec / STEP_CEILING_PAIRS_S["train"], 4),
-                      "step_ceiling_pairs_s": STEP_CEILING_PAIRS_S["train"]},
+                      "step_ceiling_pairs_s": STEP_CEILING_PAIRS_S["train"],
+                      "step_ceiling_note": "SURVEY 8(d)'s ceiling counts the NOMINAL flops of the padded batch (2 575 GFLOP per step); the path executes "
+                                           "the valid rows / keys only -- mfma_frac_over_step is the executed work against the MFMA peak",
+                      "executed_gflop_per_step": round(executed_gflop, 1) if rank == 0 else None,
+                      "mfma_frac_over_step": round(executed_gflop / 1e3 / sec / PEAK_TFLOPS[args.dtype], 4) if rank == 0 else None},
            "roofline": roof,
            "cpu_baseline": (cpu_baseline_train(cfg, sd, inp) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None),
            "kernels": per_kernel}
@@ -587,6 +605,11 @@ def main():
         a32.dtype, a32.launch, a32.no_cpu_baseline = "f32", "eager", True
         t32 = train_leg(a32, rank, world, local, dist, max(3, min(args.steps, 10)), 2)
         line["train_f32_parity_mode"] = {k: t32[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline")}
+        # the per-GPU shape of BASELINE configs[4] (B = 64 per GPU, T_a = 1024 long music): the same training step, one GPU's share of it
+        a1k = copy.copy(args)
+        a1k.ta, a1k.no_cpu_baseline = 1024, True
+        t1k = train_leg(a1k, rank, world, local, dist, max(3, min(args.steps, 10)), 2)
+        line["train_ta1024"] = {k: t1k[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline")}
         r_steps = max(2, min(5, args.steps))
         line["retrieval"] = retrieval_leg(args, rank, world, local, dist, r_steps, 1)
         ev = {}

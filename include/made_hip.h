@@ -378,6 +378,12 @@ int made_tape_op(uint64_t handle, int64_t index, int32_t* kind, uint64_t* functi
                                                               /* what operation `index` is: kind 0 = kernel launch (function = its host-side
                                                                  address, grid3 = workgroups per axis), other kinds: events, fills, copies */
 int made_stream_wait(void* src_stream, void* dst_stream);            /* dst waits for all work queued on src so far */
+/* recording only, executes nothing: a HOST callback at this point of the issue order; a replay calls fn(user) there (non-zero return:
+ * the replay stops with an error).  For work the library does not launch itself but that must sit between the step's launches: the
+ * data-parallel gradient all-reduces (RCCL calls of the framework, reference train-MaDe.py:238-241,371).  made_tape_interleave moves
+ * nothing across a callback. */
+typedef int (*MadeTapeCallback)(void* user);
+int made_tape_callback(MadeTapeCallback fn, void* user);
 int made_tape_event(int32_t op_kind, int32_t slot, void* stream);    /* recording only, executes nothing: 0 = "record event `slot` on
                                                                          stream", 1 = "stream waits for event `slot`" -- mirrors the
                                                                          framework's own Event.record / Stream.wait_event calls */
@@ -409,6 +415,13 @@ int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_p
 int made_layernorm_add(const void* x, int32_t x_dtype, int64_t ldx, const float* gamma, const float* beta,
                        void* y, int32_t y_dtype, int64_t ldy, const void* add, int32_t add_dtype, int64_t ld_add,
                        void* y2, int64_t ldy2, int64_t rows, int64_t D, float eps, const float* row_skip, void* stream);
+
+/* The music side of the sharded retrieval as ONE buffer for ONE all-gather (reference test-MaDe.py:386-403 over the 8 GPUs of a node): a
+ * record per track, [S * D segment embeddings in pack_dtype | S mask floats | D floats of the pooled music vector | zero pad to rec_bytes
+ * (a multiple of 16)].  seg [n, S, D] (f32 or bf16, track stride seg_bs elements, S * D contiguous), mask [n, S] f32, music [n, D] f32;
+ * records n .. n_pad - 1 (the shards are padded to the largest) are zero-filled. */
+int made_pack_music_records(const void* seg, int32_t seg_dtype, int64_t seg_bs, const float* mask, int64_t ld_mask, const float* music, int64_t ld_music,
+                            void* out, int32_t pack_dtype, int64_t rec_bytes, int64_t n, int64_t n_pad, int64_t S, int64_t D, void* stream);
 
 /* y[r, :] = x[r, :] * (mask[r] != 0) converted to y_dtype: the masked_fill of reference model/model_Base.py:556,595
  * fused with the f32 -> bf16 conversion of the pre-extracted features, so the input projection can use the

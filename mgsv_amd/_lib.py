@@ -182,6 +182,7 @@ SIGNATURES = {
     "made_tape_op": (C.c_int, [C.c_uint64, i64, C.POINTER(i32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "made_stream_wait": (C.c_int, [vp, vp]),
     "made_tape_event": (C.c_int, [i32, i32, vp]),
+    "made_tape_callback": (C.c_int, [C.CFUNCTYPE(C.c_int, vp), vp]),
     "made_memset_async": (C.c_int, [vp, i32, i64, vp]),
     "made_copy_async": (C.c_int, [vp, vp, i64, vp]),
     "made_store_words": (C.c_int, [vp, vp, i32, vp]),
@@ -195,6 +196,7 @@ SIGNATURES = {
     "made_layernorm": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp, i32, i64, i64, i64, f32, vp, vp]),
     "made_layernorm_add": (C.c_int, [vp, i32, i64, vp, vp, vp, i32, i64, vp, i32, i64, vp, i64, i64, i64, f32, vp, vp]),
     "made_cast_mask_rows": (C.c_int, [vp, i64, vp, vp, i32, i64, i64, i64, vp]),
+    "made_pack_music_records": (C.c_int, [vp, i32, i64, vp, i64, vp, i64, vp, i32, i64, i64, i64, i64, i64, vp]),
     "made_masked_mean": (C.c_int, [vp, i32, i64, i64, vp, vp, i64, i64, i64, vp]),
     "made_l2norm_rows": (C.c_int, [vp, i32, i64, vp, vp, i32, i64, i64, i64, f32, vp]),
     "made_sine_pe": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, vp]),

@@ -50,13 +50,14 @@ extern "C" int made_device_info(char* name, int name_len, int* cu_count, int* is
 #include <vector>
 
 namespace {
-enum { TAPE_KERNEL = 0, TAPE_WAIT = 1, TAPE_MEMSET = 2, TAPE_COPY = 3, TAPE_EV_RECORD = 4, TAPE_EV_WAIT = 5 };
+enum { TAPE_KERNEL = 0, TAPE_WAIT = 1, TAPE_MEMSET = 2, TAPE_COPY = 3, TAPE_EV_RECORD = 4, TAPE_EV_WAIT = 5, TAPE_CALLBACK = 6 };
 struct TapeOp {
     int kind;
     const void* fn; dim3 grid, block; unsigned lds; hipStream_t st, st2;
     size_t arg_off; int nargs; size_t ptr_off;               // kernel: argument bytes in `blob`, offsets of the arguments in `offs`
     hipEvent_t ev;                                           // wait: recorded on st, awaited by st2
     void* dst; const void* src; size_t nbytes; int value;    // memset / copy
+    MadeTapeCallback cb; void* cb_user;                      // host callback (made_tape_callback)
 };
 struct Tape {
     std::vector<TapeOp> ops;
@@ -152,6 +153,20 @@ extern "C" int made_tape_event(int32_t op_kind, int32_t slot, void* stream) {
     return MADE_OK;
 }
 
+// Recording only: a HOST callback at this point of the issue order (the caller performs the action itself while recording).  What the
+// data-parallel training step uses it for: the gradient all-reduces are RCCL calls of the framework (their own stream, ordered against
+// the step's streams by events the framework records at call time), so a replay has to make the same calls at the same points --
+// after everything in front of them has been ISSUED, before anything behind them is.
+extern "C" int made_tape_callback(MadeTapeCallback fn, void* user) {
+    Tape* t = (Tape*)g_made_tape;
+    MADE_REQUIRE(t != nullptr, "made_tape_callback: not recording");
+    MADE_REQUIRE(fn != nullptr, "made_tape_callback: null function");
+    TapeOp op{};
+    op.kind = TAPE_CALLBACK; op.cb = fn; op.cb_user = user;
+    t->ops.push_back(op);
+    return MADE_OK;
+}
+
 extern "C" int made_memset_async(void* dst, int32_t value, int64_t nbytes, void* stream) {
     MADE_REQUIRE(dst != nullptr && nbytes >= 0, "made_memset_async: bad arguments");
     if (nbytes == 0) return MADE_OK;
@@ -203,6 +218,32 @@ extern "C" int made_tape_interleave(uint64_t handle, int32_t main_weight) {
     MADE_REQUIRE(t != nullptr, "made_tape_interleave: null tape");
     MADE_REQUIRE(main_weight >= 1 && main_weight <= 16, "made_tape_interleave: main_weight out of [1, 16]");
     const size_t n = t->ops.size();
+    // a host callback is a point of the ISSUE order: nothing moves across it.  Tapes with callbacks are re-ordered segment by segment.
+    {
+        bool has_cb = false;
+        for (size_t i = 0; i < n; ++i) has_cb = has_cb || t->ops[i].kind == TAPE_CALLBACK;
+        if (has_cb) {
+            for (size_t i = 0; i < n; ++i) if (t->ops[i].kind == TAPE_WAIT) return MADE_OK;
+            std::vector<TapeOp> all;
+            all.swap(t->ops);
+            std::vector<TapeOp> out;
+            out.reserve(n);
+            size_t b = 0;
+            int rc = MADE_OK;
+            while (b <= n && rc == MADE_OK) {
+                size_t e = b;
+                while (e < n && all[e].kind != TAPE_CALLBACK) ++e;
+                t->ops.assign(all.begin() + (long)b, all.begin() + (long)e);
+                if (t->ops.size() > 1) rc = made_tape_interleave(handle, main_weight);
+                out.insert(out.end(), t->ops.begin(), t->ops.end());
+                if (e < n) out.push_back(all[e]);
+                b = e + 1;
+            }
+            if (rc != MADE_OK) { t->ops.swap(all); return rc; }
+            t->ops.swap(out);
+            return MADE_OK;
+        }
+    }
     // streams in order of first appearance; (a TAPE_WAIT op -- made_stream_wait -- belongs to both of its streams: keep such tapes as they are)
     std::vector<hipStream_t> streams;
     std::vector<int> sid(n);
@@ -304,6 +345,11 @@ static int tape_replay_range(Tape* t, size_t first, size_t count) {
             case TAPE_EV_RECORD: e = hipEventRecord(op.ev, op.st); break;
             case TAPE_EV_WAIT: e = hipStreamWaitEvent(op.st, op.ev, 0); break;
             case TAPE_MEMSET: e = hipMemsetAsync(op.dst, op.value, op.nbytes, op.st); break;
+            case TAPE_CALLBACK: {
+                const int rc = op.cb(op.cb_user);
+                if (rc != 0) { made_set_error("made_tape_replay: the host callback of operation %zu returned %d", oi, rc); return MADE_ERR_INVALID_ARG; }
+                break;
+            }
             default: e = hipMemcpyAsync(op.dst, op.src, op.nbytes, hipMemcpyDeviceToDevice, op.st); break;
         }
         if (e != hipSuccess) { made_set_error("made_tape_replay: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }

@@ -587,6 +587,47 @@ inline int nv_for(int64_t D) { return D <= 512 ? 2 : (D <= 1024 ? 4 : 8); }
         default: { constexpr int NV = 8; constexpr bool FULL = false; CALL; } break; \
     }
 
+// One record per music track for the sharded retrieval's single all-gather (reference test-MaDe.py:386-403 run over 8 GPUs: the music side
+// is exchanged once): [S * D segment embeddings in the travel dtype | S mask floats | D floats of the pooled vector | pad to 16 bytes].
+// One workgroup per record; rows n .. n_pad - 1 (the shards are padded to the largest one) are zero-filled.
+__global__ __launch_bounds__(ROW_THREADS) void pack_music_records_kernel(const void* seg, int seg_dtype, int64_t seg_bs, const float* mask, int64_t ld_mask,
+                                                                          const float* music, int64_t ld_music, unsigned char* out, int pack_dtype,
+                                                                          int64_t rec, int64_t n, int S, int D) {
+    const int64_t m = blockIdx.x;
+    unsigned char* o = out + m * rec;
+    const int tid = threadIdx.x;
+    if (m >= n) {
+        for (int64_t i = tid; i < rec / 16; i += ROW_THREADS) ((u32x4*)o)[i] = (u32x4){0u, 0u, 0u, 0u};
+        return;
+    }
+    const int64_t ne = (int64_t)S * D;
+    const int64_t a = ne * (pack_dtype == MADE_F32 ? 4 : 2), b = a + (int64_t)S * 4, c = b + (int64_t)D * 4;
+    // segment embeddings: 8 elements per thread and step (ne is a multiple of 8: D is)
+    for (int64_t e = (int64_t)tid * 8; e < ne; e += (int64_t)ROW_THREADS * 8) {
+        float v[8];
+        if (seg_dtype == MADE_F32) {
+            const f32x4 x0 = *(const f32x4*)((const float*)seg + m * seg_bs + e), x1 = *(const f32x4*)((const float*)seg + m * seg_bs + e + 4);
+            v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3]; v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+        } else {
+            const bf16x8 x = *(const bf16x8*)((const bf16_t*)seg + m * seg_bs + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+        }
+        if (pack_dtype == MADE_F32) {
+            *(f32x4*)(o + e * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(o + e * 4 + 16) = (f32x4){v[4], v[5], v[6], v[7]};
+        } else {
+            bf16x8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[j];
+            *(bf16x8*)(o + e * 2) = t;
+        }
+    }
+    for (int i = tid; i < S; i += ROW_THREADS) ((float*)(o + a))[i] = mask[m * ld_mask + i];
+    for (int i = tid; i < D; i += ROW_THREADS) ((float*)(o + b))[i] = music[m * ld_music + i];
+    for (int64_t i = c + (int64_t)tid * 4; i < rec; i += (int64_t)ROW_THREADS * 4) *(uint32_t*)(o + i) = 0u;
+}
+
 }  // namespace
 
 extern "C" int made_layernorm(const void* x, int32_t x_dtype, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
@@ -733,4 +774,19 @@ extern "C" int made_concat_cols(const float* a, int64_t cols_a, const float* c, 
     if (n == 0) return MADE_OK;
     hipLaunchKernelGGL(concat_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (int)cols_a, c, (int)cols_c, out, rows);
     return made_check_launch("made_concat_cols");
+}
+
+extern "C" int made_pack_music_records(const void* seg, int32_t seg_dtype, int64_t seg_bs, const float* mask, int64_t ld_mask, const float* music, int64_t ld_music,
+                                       void* out, int32_t pack_dtype, int64_t rec_bytes, int64_t n, int64_t n_pad, int64_t S, int64_t D, void* stream) {
+    MADE_REQUIRE(out != nullptr && n >= 0 && n_pad >= n && S > 0 && D > 0, "made_pack_music_records: bad arguments");
+    MADE_REQUIRE(n == 0 || (seg && mask && music), "made_pack_music_records: null input");
+    MADE_REQUIRE((seg_dtype == MADE_F32 || seg_dtype == MADE_BF16) && (pack_dtype == MADE_F32 || pack_dtype == MADE_BF16), "made_pack_music_records: bad dtype");
+    const int64_t c = S * D * (pack_dtype == MADE_F32 ? 4 : 2) + S * 4 + D * 4;
+    MADE_UNSUPPORTED(D % 8 == 0 && rec_bytes % 16 == 0 && rec_bytes >= c && ((uintptr_t)out % 16) == 0 && ((uintptr_t)seg % 16) == 0 &&
+                     seg_bs % 8 == 0, "made_pack_music_records: D must be a multiple of 8, records of whole 16-byte groups, aligned buffers");
+    MADE_UNSUPPORTED(n_pad <= 0x7fffffff, "made_pack_music_records: too many records");
+    if (n_pad == 0) return MADE_OK;
+    hipLaunchKernelGGL(pack_music_records_kernel, dim3((unsigned)n_pad), dim3(ROW_THREADS), 0, (hipStream_t)stream, seg, (int)seg_dtype, seg_bs, mask, ld_mask,
+                       music, ld_music, (unsigned char*)out, (int)pack_dtype, rec_bytes, n, (int)S, (int)D);
+    return made_check_launch("made_pack_music_records");
 }

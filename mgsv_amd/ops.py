@@ -480,6 +480,18 @@ def cast_mask_rows(x: Tensor, mask: Optional[Tensor], out: Tensor) -> Tensor:
     return out
 
 
+def pack_music_records(seg: Tensor, mask: Tensor, music: Tensor, out: Tensor, pack_dtype: torch.dtype) -> Tensor:
+    """made_pack_music_records: out [n_pad, rec] uint8 <- per track [S * D embeddings in pack_dtype | S mask floats | D pooled floats | pad];
+    rows past seg.shape[0] are zero-filled (the sharded retrieval's one all-gather buffer, mgsv_amd/retrieval.py)."""
+    n, S, D = seg.shape
+    assert seg.stride(2) == 1 and seg.stride(1) == D and out.dtype == torch.uint8 and out.dim() == 2 and out.is_contiguous() and out.shape[0] >= n
+    mask, music = _f32(mask.contiguous(), "mask"), _f32(music.contiguous(), "music")
+    check(lib().made_pack_music_records(_p(seg), dt_of(seg), seg.stride(0) if n > 0 else S * D, _p(mask), S, _p(music), D, _p(out),
+                                        F32 if pack_dtype == torch.float32 else BF16, out.shape[1], n, out.shape[0], S, D, _stream()),
+          "made_pack_music_records")
+    return out
+
+
 def row_affine(x: Tensor, scale: Tensor, shift: Tensor, act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
     """out[r] = act(x[r] * scale[r % P] + shift[r % P]) with P = scale.numel() (made_row_affine); x [rows, cols], in place by default."""
     assert x.dim() == 2 and x.stride(1) == 1 and scale.numel() == shift.numel()

@@ -85,10 +85,16 @@ class ShardedRetrieval:
             counts = [int(x.item()) for x in cl]             # (pass `counts` to avoid this synchronisation)
         assert len(counts) == world and counts[dist.get_rank(self.group)] == n
         mx = max(counts)
-        send = torch.zeros(mx, rec, device=seg_local.device, dtype=torch.uint8)
-        send[:n, :a].view(sdt).view(n, S, D).copy_(seg_local)              # (converts to the travel dtype)
-        send[:n, a:b].view(torch.float32).view(n, S).copy_(mask_local)
-        send[:n, b:b + D * 4].view(torch.float32).view(n, D).copy_(music_local)
+        if seg_local.is_cuda and sdt in (torch.float32, torch.bfloat16) and seg_local.dtype in (torch.float32, torch.bfloat16) and D % 8 == 0:
+            # one launch of the library packs (and converts) the three tensors of every track into its record and zero-fills the padding
+            from . import ops
+            send = torch.empty(mx, rec, device=seg_local.device, dtype=torch.uint8)
+            ops.pack_music_records(seg_local.contiguous(), mask_local, music_local, send, sdt)
+        else:                                                               # (host tensors: the two-rank gloo tests of the exchange logic)
+            send = torch.zeros(mx, rec, device=seg_local.device, dtype=torch.uint8)
+            send[:n, :a].view(sdt).view(n, S, D).copy_(seg_local)          # (converts to the travel dtype)
+            send[:n, a:b].view(torch.float32).view(n, S).copy_(mask_local)
+            send[:n, b:b + D * 4].view(torch.float32).view(n, D).copy_(music_local)
         recv = torch.empty(world * mx, rec, device=seg_local.device, dtype=torch.uint8)
         dist.all_gather_into_tensor(recv, send, group=self.group)
 

@@ -45,7 +45,7 @@ def _make_watcher(found: list, every_device: bool):
             kwargs = kwargs or {}
             out = func(*args, **kwargs)
             name = func.overloadpacket.__name__ if hasattr(func, "overloadpacket") else str(func)
-            if name not in _NO_KERNEL:
+            if name not in _NO_KERNEL and not _in_callback:
                 def on_dev(x):
                     return isinstance(x, torch.Tensor) and (x.is_cuda or every_device)
                 flat = list(args) + list(kwargs.values()) + (list(out) if isinstance(out, (tuple, list)) else [out])
@@ -83,11 +83,55 @@ def copy_(dst: Tensor, src: Tensor) -> Tensor:
     return dst
 
 
+_in_callback = False
+
+
+def callback(fn) -> None:
+    """Run fn() now and, while a tape is being recorded, again at this point of the issue order in every replay (made_tape_callback):
+    host-side work that belongs BETWEEN the step's launches -- the data-parallel gradient all-reduces (the framework's RCCL calls order
+    themselves against the stream that is current when they are made, so the replay makes them under the stream that was current at
+    recording time).  What fn does to device tensors is not checked by the recorder's watcher (it IS replayed)."""
+    global _in_callback
+    tp = _recording
+    if tp is not None:
+        rec_stream = torch.cuda.current_stream() if torch.cuda.is_available() else None
+
+        def run():
+            global _in_callback
+            _in_callback = True
+            try:
+                if rec_stream is not None:
+                    with torch.cuda.stream(rec_stream):
+                        fn()
+                else:
+                    fn()
+            finally:
+                _in_callback = False
+
+        def trampoline(_user):
+            try:
+                run()
+                return 0
+            except Exception as ex:                           # (an exception must not cross the C frame: reported through the replay's status)
+                tp.callback_error = ex
+                return 1
+        cfn = _CB_TYPE(trampoline)
+        tp._keep.append(cfn)
+        _lib.check(_lib.lib().made_tape_callback(cfn, None), "made_tape_callback")
+        run()
+    else:
+        fn()
+
+
+_CB_TYPE = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
 class LaunchTape:
     def __init__(self):
         self.handle = C.c_uint64(0)
         self._keep: List[object] = []
         self._slots = {}
+        self.callback_error: Optional[BaseException] = None
 
     # ---- recording
     @classmethod
@@ -145,7 +189,11 @@ class LaunchTape:
 
     # ---- replay
     def replay(self) -> None:
-        _lib.check(_lib.lib().made_tape_replay(self.handle), "made_tape_replay")
+        rc = _lib.lib().made_tape_replay(self.handle)
+        if rc != 0 and self.callback_error is not None:
+            ex, self.callback_error = self.callback_error, None
+            raise ex
+        _lib.check(rc, "made_tape_replay")
 
     def replay_range(self, first: int, count: int) -> None:
         """operations [first, first + count) only (one phase of the step on its own: measurements)"""

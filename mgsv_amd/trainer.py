@@ -1921,9 +1921,31 @@ class TrainStepGraph:
             torch.cuda.synchronize()
             self.graphs = []
             if mode == "tape":
-                if self.dist is not None:
-                    raise NotImplementedError("TrainStepGraph(mode='tape') is single-process (data-parallel jobs capture three hipGraphs)")
                 keep2 = [x.clone() for x in (t.flat_param, t.exp_avg, t.exp_avg_sq)]
+                if self.dist is not None:
+                    # data parallel: the two bucketed all-reduces of the flat gradient buffer (RCCL calls of the framework) ride the tape
+                    # as host callbacks at the points where the eager step makes them -- the large bucket inside backward's grad_sync
+                    # hook (both streams joined, the temporal encoders' backward still to come), the temporal range behind backward,
+                    # then the wait that orders the optimizer's launches behind both (reference train-MaDe.py:238-241,371)
+                    dist_, works = self.dist, []
+                    cut = t.group_ranges[0][1]
+
+                    def fwd_bwd():                              # noqa: F811 (the data-parallel form of the step's first part)
+                        t._zero_grad_in_forward = True
+                        try:
+                            out = t.forward_train(i["frame_feats"], i["segment_feats"], i["frame_masks"], i["segment_masks"], i["spans_target"], seed=0,
+                                                  v_duration=self.v_duration)
+                        finally:
+                            t._zero_grad_in_forward = False
+                        t.backward(None, None, grad_sync=lambda: _tape.callback(lambda: works.append(dist_.all_reduce(t.flat_grad[cut:], async_op=True))))
+                        _tape.callback(lambda: works.append(dist_.all_reduce(t.flat_grad[:cut], async_op=True)))
+
+                        def wait_all():
+                            for w in works:
+                                w.wait()
+                            works.clear()
+                        _tape.callback(wait_all)
+                        return out
                 # the tape replays only the library's launches: a step that still runs a framework kernel (some non-headline
                 # configurations do: the BatchNorm affine of agg_module='mlp', Q > 1 copies, the regression head ...) is refused here
                 # (ForeignKernelError names the operators) instead of silently skipping that work on every replay
@@ -2027,7 +2049,7 @@ class TrainStepGraph:
             self.tape.replay()
         else:
             self.graphs[0].replay()
-        if self.dist is not None:
+        if self.dist is not None and self.mode != "tape":         # (the tape makes the all-reduces itself: host callbacks)
             cut = t.group_ranges[0][1]
             w1 = self.dist.all_reduce(t.flat_grad[cut:], async_op=True)      # travels under the encoders' backward
             self.graphs[1].replay()

@@ -845,3 +845,24 @@ def test_set_criterion(dev, Q, G):
         for k, nme in enumerate(names):
             np.testing.assert_allclose(losses[l, k], float(ref[nme + suffix]), rtol=2e-5, atol=2e-5, err_msg=f"{nme}{suffix}")
     np.testing.assert_allclose(float(total.cpu()), ref_total, rtol=2e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("sdt,pdt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+def test_pack_music_records_matches_the_tensor_copies(dev, sdt, pdt):
+    """made_pack_music_records (the sharded retrieval's one all-gather buffer, mgsv_amd/retrieval.py): byte for byte what the three
+    strided tensor copies into a zeroed buffer produce, padding records included."""
+    from mgsv_amd.retrieval import ShardedRetrieval
+    n, n_pad, S, D = 5, 8, 19, 72
+    seg = rnd(n, S, D, seed=1).to(dev).to(sdt)
+    mask = (rnd(n, S, seed=2) > 0).float().to(dev)
+    music = rnd(n, D, seed=3).to(dev)
+    esz = torch.empty((), dtype=pdt).element_size()
+    a, b, rec = ShardedRetrieval._layout(S, D, esz)
+    want = torch.zeros(n_pad, rec, device=dev, dtype=torch.uint8)
+    want[:n, :a].view(pdt).view(n, S, D).copy_(seg)
+    want[:n, a:b].view(torch.float32).view(n, S).copy_(mask)
+    want[:n, b:b + D * 4].view(torch.float32).view(n, D).copy_(music)
+    got = torch.full((n_pad, rec), 0xAB, device=dev, dtype=torch.uint8)
+    ops.pack_music_records(seg, mask, music, got, pdt)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -29,3 +29,32 @@ def test_a_framework_kernel_inside_the_recording_is_refused_by_name():
         x.zero_()
     assert tp.foreign_ops == ["zero_"]
     assert not T.recording()
+
+
+def test_host_callbacks_are_replayed_in_issue_order_and_are_not_counted_as_framework_kernels():
+    """made_tape_callback (the data-parallel step's gradient all-reduces ride the tape this way): the action runs once while recording and
+    once per replay, in order; what it does to tensors is not flagged by the watcher; an exception inside a replayed callback surfaces
+    from replay(); made_tape_interleave leaves a tape of callbacks as it is."""
+    log = []
+    x = torch.zeros(3)
+    with T.LaunchTape.record(check=True, _every_device=True) as tp:
+        T.callback(lambda: (log.append("a"), x.add_(1)))
+        T.callback(lambda: log.append("b"))
+    assert log == ["a", "b"] and tp.foreign_ops == [] and float(x[0]) == 1.0
+    assert tp.counts() == (0, 0, 2)
+    tp.interleave(2)
+    tp.replay(); tp.replay()
+    assert log == ["a", "b"] * 3 and float(x[0]) == 3.0
+    boom = {"on": False}
+
+    def maybe():
+        if boom["on"]:
+            raise ValueError("inside the replayed callback")
+    with T.LaunchTape.record() as tp2:
+        T.callback(maybe)
+    tp2.replay()
+    boom["on"] = True
+    with pytest.raises(ValueError, match="inside the replayed callback"):
+        tp2.replay()
+    T.callback(lambda: log.append("c"))                      # outside a recording: just runs
+    assert log[-1] == "c"

@@ -30,9 +30,11 @@ def _worker(rank, world, port, out_dir, graph=False):
     trn = MadeTrainer(cfg, synth.make_state_dict(cfg, seed=0), device="cuda:0", dtype="f32")
     inp = synth.make_inputs(cfg, 4, 20, 40, seed=1 + rank)
     t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
-    g = trn.capture_train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], dist=dist) if graph else None
+    g = (trn.capture_train_step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], dist=dist,
+                                mode="tape" if graph == "tape" else "graph") if graph else None)
     for it in range(2):
-        if g is not None:                                    # the captured iteration: three graphs around the two all-reduces
+        if g is not None:                                    # the captured iteration: three graphs around the two all-reduces, or the launch
+                                                             # tape with the all-reduces as host callbacks
             g.step(t["frame_feats"], t["segment_feats"], t["frame_masks"], t["segment_masks"], t["spans_target"], seed=100 + it,
                    lrs=(1e-3, 1e-3, 1e-3))
             if it == 0:
@@ -52,7 +54,7 @@ def _worker(rank, world, port, out_dir, graph=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, "tape"])
 def test_two_rank_data_parallel_step(tmp_path, graph):
     import torch.multiprocessing as mp
     from mgsv_amd import synth
