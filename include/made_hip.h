@@ -290,6 +290,12 @@ typedef struct MadeAttnArgs {
     const int32_t* batch_order; /* [B] or NULL: a permutation of the batch (made_batch_order: longest sequence first).  Only the
                                   ORDER in which workgroups are issued changes -- a padded batch then finishes with its short
                                   samples instead of waiting on a long one that started last; results are unchanged */
+    uint32_t* keep_bits;       /* NULL, or (with drop.p > 0) [B*H*Lq, ld_bits] words: the dropout decisions of this call, bit j % 32 of word
+                                  j / 32 of row (b*H + h)*Lq + i = element (i, j) is KEPT -- written for made_attention_bwd, whose two
+                                  kernels then test a bit per score instead of re-drawing it (the draw is ~11 VALU instructions, two
+                                  thirds of their per-score arithmetic).  ld_bits >= 2 * ceil(Lk / 64); words of keys behind the
+                                  sample's last valid key are not written (and not read) */
+    int64_t ld_bits;
 } MadeAttnArgs;
 
 int made_attention(const MadeAttnArgs* args, void* stream);
@@ -594,6 +600,8 @@ typedef struct MadeAttnBwdArgs {
     float scale; int32_t _pad;
     MadeDropout drop;
     const int32_t* batch_order; /* [B] or NULL: issue order of the batch, as in MadeAttnArgs */
+    const uint32_t* keep_bits; int64_t ld_bits;   /* NULL, or the forward's dropout decisions (MadeAttnArgs.keep_bits; bf16 path): the
+                                                     same mask as re-drawing it, bit for bit */
 } MadeAttnBwdArgs;
 
 int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream);

@@ -90,7 +90,7 @@ class MadeAttnArgs(C.Structure):
                 ("key_mask", vp), ("q_mask", vp),
                 ("scale", f32), ("_pad", i32),
                 ("q_skip_mask", vp),
-                ("lse", vp), ("drop", MadeDropout), ("batch_order", vp)]
+                ("lse", vp), ("drop", MadeDropout), ("batch_order", vp), ("keep_bits", vp), ("ld_bits", i64)]
 
 
 class MadeAttnBwdArgs(C.Structure):
@@ -100,7 +100,7 @@ class MadeAttnBwdArgs(C.Structure):
                 ("q_bs", i64), ("ldq", i64), ("k_bs", i64), ("ldk", i64), ("v_bs", i64), ("ldv", i64), ("o_bs", i64), ("ldo", i64),
                 ("do_bs", i64), ("lddo", i64), ("dq_bs", i64), ("lddq", i64), ("dk_bs", i64), ("lddk", i64), ("dv_bs", i64), ("lddv", i64),
                 ("key_mask", vp), ("q_skip_mask", vp), ("scale", f32), ("_pad", i32), ("drop", MadeDropout),
-                ("batch_order", vp)]
+                ("batch_order", vp), ("keep_bits", vp), ("ld_bits", i64)]
 
 
 class MadeXpoolFusedArgs(C.Structure):

@@ -255,6 +255,8 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
             int64_t qq = q0 + r; qq = qq < a.Lq ? qq : a.Lq - 1;
             const uint64_t base = (uint64_t)((b * a.H + h) * a.Lq + qq) * (uint64_t)a.Lk + (uint64_t)(t * BKEY);
             const uint32_t lo = (uint32_t)base;
+            // kb[kt]: this lane's 16 decisions of key block kt in register order (bit e = element e kept), for the backward's bit cache
+            uint32_t kb[2] = {0u, 0u};
             if (__all(lo <= 0xFFFFFFFFu - BKEY)) {           // the tile's indices share their high word: hoist the key
                 const uint32_t kk = made_rng_key(drop_seed, a.drop.site, (uint32_t)(base >> 32));
 #pragma unroll
@@ -262,7 +264,9 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const uint32_t hsh = made_rng_fmix32((lo + (uint32_t)(kt * 32 + acc_row(e, hh))) ^ kk);
-                        s[kt][e] = (hsh >> 8) >= thr ? s[kt][e] * sc : 0.f;
+                        const bool keep = (hsh >> 8) >= thr;
+                        s[kt][e] = keep ? s[kt][e] * sc : 0.f;
+                        kb[kt] |= keep ? (1u << e) : 0u;
                     }
             } else {
 #pragma unroll
@@ -270,8 +274,28 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const uint32_t hsh = made_rng_mix(drop_seed, a.drop.site, base + (uint64_t)(kt * 32 + acc_row(e, hh)));
-                        s[kt][e] = (hsh >> 8) >= thr ? s[kt][e] * sc : 0.f;
+                        const bool keep = (hsh >> 8) >= thr;
+                        s[kt][e] = keep ? s[kt][e] * sc : 0.f;
+                        kb[kt] |= keep ? (1u << e) : 0u;
                     }
+            }
+            if (a.keep_bits) {
+                // register order -> key order: nibble j (elements 4j .. 4j + 3) holds keys 8j + 4 hh .. + 3; the two lane halves hold
+                // disjoint keys of the block, the lower half stores the word pair of the tile
+                uint32_t w2[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    uint32_t x = kb[kt];
+                    x = (x | (x << 8)) & 0x00FF00FFu;
+                    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+                    x <<= 4 * hh;
+                    w2[kt] = x | (uint32_t)__shfl_xor((int)x, 32);
+                }
+                const int64_t qs = q0 + r;
+                if (hh == 0 && qs < a.Lq) {
+                    uint32_t* bp = a.keep_bits + ((b * a.H + h) * a.Lq + qs) * a.ld_bits + 2 * t;
+                    *(uint2*)bp = make_uint2(w2[0], w2[1]);
+                }
             }
         }
 
@@ -368,6 +392,9 @@ extern "C" int made_attention(const MadeAttnArgs* args, void* stream) {
     MADE_REQUIRE(a.Q && a.K && a.V && a.O, "made_attention: null tensor");
     MADE_REQUIRE(a.B >= 0 && a.H > 0 && a.Lq >= 0 && a.Lk > 0, "made_attention: bad dims");
     MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention: bad dtype %d", a.dtype);
+    if (a.keep_bits)
+        MADE_REQUIRE(a.ld_bits >= 2 * ((a.Lk + 63) / 64) && a.ld_bits % 2 == 0 && ((uintptr_t)a.keep_bits % 8) == 0,
+                     "made_attention: keep_bits rows need an even ld_bits >= 2 * ceil(Lk / 64) = %lld words and 8-byte alignment", (long long)(2 * ((a.Lk + 63) / 64)));
     MADE_UNSUPPORTED(((a.Lq + BQ - 1) / BQ) * a.H * a.B < (1LL << 31), "made_attention: too many workgroups");
     const int per16 = a.dtype == MADE_F32 ? 4 : 8;
     MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.ldo % 4 == 0 &&

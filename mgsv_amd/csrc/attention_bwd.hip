@@ -154,6 +154,10 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     // tile); masked keys are zeroed in store_tile, one iteration later, from the bias row staged in LDS at the start
     frag_t rk[NCH], rv[NCH];
     int64_t rkey0 = 0;
+    // the forward's dropout decisions of this lane's query (MadeAttnBwdArgs.keep_bits): two words per 64-key tile, loaded with the tile
+    const bool use_bits = IS_BF16 && a.keep_bits != nullptr && a.drop.p > 0.f;
+    const uint32_t* bits_q = use_bits ? a.keep_bits + ((b * a.H + h) * a.Lq + qc) * a.ld_bits : nullptr;
+    uint2 rbits = make_uint2(0u, 0u), cbits = make_uint2(0u, 0u);
     auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
         rkey0 = key0;
 #pragma unroll
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
             rk[i] = *(const frag_t*)(Kg + kcl * a.ldk + (c % CPR) * PER16);
             rv[i] = *(const frag_t*)(Vg + kcl * a.ldv + (c % CPR) * PER16);
         }
+        if (use_bits) rbits = *(const uint2*)(bits_q + (key0 / BKEY) * 2);
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     for (int64_t t = 0; t < ntiles; ++t) {
         __syncthreads();
         store_tile();
+        cbits = rbits;
         __syncthreads();
         if (t + 1 < ntiles) load_tile((t + 1) * BKEY);
         if (!wave_active) continue;
@@ -255,6 +261,19 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
 #pragma unroll
                     for (int e = 0; e < 16; ++e) s[kt][e] += tb[kt * 32 + acc_row(e, hh)];   // -inf * anything stays -inf below
             }
+            if (use_bits) {
+                // one bit test per score: bit acc_row(e, hh) of the tile's word kt (the forward stored its decisions in key order)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const uint32_t wq = (kt == 0 ? cbits.x : cbits.y) >> (4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nl));
+                        const float g = (wq & (1u << ((e & 3) + 8 * (e >> 2)))) ? dp[kt][e] * dsc : 0.f;
+                        s[kt][e] = p * __builtin_fmaf(g, a.scale, -dsq);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -268,6 +287,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                     }
                     s[kt][e] = p * __builtin_fmaf(g, a.scale, -dsq);
                 }
+            }
         } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -337,6 +357,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     constexpr int BK = 128;                       // keys per workgroup
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BQT * P + 32];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_bits[4 * BQT];  // the forward's dropout decisions of the tile: [32-key block of this workgroup][query]
     extern __shared__ __attribute__((aligned(16))) float lds_row[];      // per query of this (batch, head), whole tiles: see below
     unsigned char* lds_q = lds;
     unsigned char* lds_do = lds + BQT * P;
@@ -381,6 +402,11 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     // (as in the dq kernel: the next tile's loads are only issued here; padded queries are zeroed in store_tile from the rows in LDS)
     frag_t rq[NCH], rg[NCH];
     int64_t rqbase = 0;
+    // thread t stages the word of query t % 64 x key block t / 64 of this workgroup's 128 keys (MadeAttnBwdArgs.keep_bits)
+    const bool use_bits = IS_BF16 && a.keep_bits != nullptr && a.drop.p > 0.f;
+    const int64_t bword = (int64_t)kt_blk * 4 + (tid >> 6);
+    const uint32_t* bits_bh = use_bits ? a.keep_bits + (b * a.H + h) * a.Lq * a.ld_bits + (bword < a.ld_bits ? bword : a.ld_bits - 1) : nullptr;
+    uint32_t rb = 0u;
     auto load_tile = [&](int64_t qbase) __attribute__((always_inline)) {
         rqbase = qbase;
 #pragma unroll
@@ -391,6 +417,10 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
             rq[i] = *(const frag_t*)(Qg + qcl * a.ldq + (c % CPR) * PER16);
             rg[i] = *(const frag_t*)(Gg + qcl * a.lddo + (c % CPR) * PER16);
         }
+        if (use_bits) {
+            const int64_t qq = qbase + (tid & 63);
+            rb = bits_bh[(qq < a.Lq ? qq : a.Lq - 1) * a.ld_bits];
+        }
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -400,6 +430,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
             *(frag_t*)(lds_q + (c / CPR) * P + (c % CPR) * 16) = keep_or_zero(rq[i], keep);
             *(frag_t*)(lds_do + (c / CPR) * P + (c % CPR) * 16) = keep_or_zero(rg[i], keep);
         }
+        if (use_bits) lds_bits[tid] = rb;
     };
 
     f32x16 dk[NDT], dv[NDT];
@@ -481,13 +512,19 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                     // the 4 accumulator rows of a register quad are consecutive queries: one 16-byte LDS read each for -lse and delta
                     const f32x4 nl4 = *(const f32x4*)(lds_lse + qi * 32 + 8 * e4 + 4 * hh);
                     const f32x4 dl4 = *(const f32x4*)(lds_delta + qi * 32 + 8 * e4 + 4 * hh);
+                    u32x4 bw4 = {0u, 0u, 0u, 0u};
+                    if (use_bits) bw4 = *(const u32x4*)(lds_bits + wave * BQT + qi * 32 + 8 * e4 + 4 * hh);   // the words of these four queries, this wave's 32 keys
 #pragma unroll
                     for (int ej = 0; ej < 4; ++ej) {
                         const int e = 4 * e4 + ej;
                         const int ql = qi * 32 + acc_row(e, hh);
                         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c2, nl4[ej]) + bias_key);
                         float pd = p, g = dp[e];
-                        if (a.drop.p > 0.f) {
+                        if (use_bits) {
+                            const bool keep = (bw4[ej] >> r) & 1u;
+                            pd = keep ? p * dsc : 0.f;
+                            g = keep ? g * dsc : 0.f;
+                        } else if (a.drop.p > 0.f) {
                             const uint32_t hsh = fast_idx ? made_rng_fmix32((tlo + (uint32_t)ql * (uint32_t)a.Lk) ^ kk)
                                                           : made_rng_mix(drop_seed, a.drop.site, tfirst + (uint64_t)ql * (uint64_t)a.Lk + (uint64_t)keyc);
                             const bool keep = (hsh >> 8) >= thr;
@@ -615,6 +652,9 @@ extern "C" int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream) {
     MADE_REQUIRE(a.B >= 0 && a.H > 0 && a.Lq >= 0 && a.Lk > 0, "made_attention_bwd: bad dims");
     MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention_bwd: bad dtype %d", a.dtype);
     MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_attention_bwd: dropout p out of [0,1)");
+    if (a.keep_bits)
+        MADE_REQUIRE(a.ld_bits >= 2 * ((a.Lk + 63) / 64) && a.ld_bits % 2 == 0 && ((uintptr_t)a.keep_bits % 8) == 0,
+                     "made_attention_bwd: keep_bits rows need an even ld_bits >= 2 * ceil(Lk / 64) words and 8-byte alignment");
     const int per16 = a.dtype == MADE_F32 ? 4 : 8;
     MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.lddo % per16 == 0 && a.ldo % per16 == 0 &&
                      a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.v_bs % per16 == 0 && a.do_bs % per16 == 0 && a.o_bs % per16 == 0 &&

@@ -354,10 +354,11 @@ def dec_stage(Zin: Tensor, W: Tensor, bias: Optional[Tensor], out: Tensor, *, ln
 def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: Optional[Tensor] = None,
               q_mask: Optional[Tensor] = None, scale: Optional[float] = None, Lk: Optional[int] = None,
               q_skip_mask: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop=None,
-              order: Optional[Tensor] = None) -> Tensor:
+              order: Optional[Tensor] = None, keep_bits: Optional[Tensor] = None) -> Tensor:
     """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K / V [B,Lk,H*hd], O [B,Lq,H*hd]
     (any batch/row strides, unit inner stride).  Lk defaults to K.shape[1].
-    Training: lse [B,H,Lq] f32 receives the log-sum-exp, drop = (seed, site, p) drops attention weights."""
+    Training: lse [B,H,Lq] f32 receives the log-sum-exp, drop = (seed, site, p) drops attention weights; keep_bits
+    ([B*H*Lq, attention_bits_words(Lk)] int32) receives the decisions, one bit per score, for attention_bwd."""
     assert Q.dim() == 3 and K.dim() == 3 and V.dim() == 3 and O.dim() == 3
     assert Q.stride(2) == 1 and K.stride(2) == 1 and V.stride(2) == 1 and O.stride(2) == 1
     assert Q.dtype == K.dtype == V.dtype == O.dtype
@@ -383,6 +384,9 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
         a.lse = _p(lse)
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
+        if keep_bits is not None:                   # [B*H*Lq, ld] int32 words: the dropout decisions, for attention_bwd
+            assert keep_bits.dtype == torch.int32 and keep_bits.dim() == 2 and keep_bits.is_contiguous() and keep_bits.shape[0] >= B * H * Lq
+            a.keep_bits, a.ld_bits = _p(keep_bits), keep_bits.shape[1]
     esz = 4 if a.dtype == F32 else 2
     flops = 4.0 * B * H * Lq * a.Lk * hd
     nbytes = esz * B * D * (2 * Lq + 2 * a.Lk)
@@ -390,6 +394,11 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
            lambda: check(lib().made_attention(C.byref(a), _stream()), "made_attention"),
            ("attn", key_mask, q_skip_mask) if (key_mask is not None and key_mask.dim() == 2) else f"B={B} H={H} hd={hd} Lq={Lq} Lk={a.Lk}")
     return O
+
+
+def attention_bits_words(Lk: int) -> int:
+    """words per query row of the dropout-decision cache of made_attention / made_attention_bwd (two per 64-key tile)"""
+    return 2 * ((Lk + 63) // 64)
 
 
 def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, Kadd: Optional[Tensor] = None,

@@ -128,8 +128,9 @@ def dropout_desc(seed: int, site: int, p: float) -> MadeDropout:
 
 def attention_bwd(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, dO: Tensor, dQ: Tensor, dK: Tensor, dV: Tensor, lse: Tensor,
                   delta: Tensor, H: int, *, key_mask: Optional[Tensor] = None, q_skip_mask: Optional[Tensor] = None,
-                  scale: Optional[float] = None, drop=None, order: Optional[Tensor] = None) -> None:
-    """Gradients of ops.attention (made_attention_bwd).  All [B, L, H*hd] views with unit inner stride."""
+                  scale: Optional[float] = None, drop=None, order: Optional[Tensor] = None, keep_bits: Optional[Tensor] = None) -> None:
+    """Gradients of ops.attention (made_attention_bwd).  All [B, L, H*hd] views with unit inner stride.  keep_bits: the decisions the
+    forward call stored (same mask as re-drawing it; bf16 path)."""
     import math
     for t in (Q, K, V, O, dO, dQ, dK, dV):
         assert t.dim() == 3 and t.stride(2) == 1 and t.dtype == Q.dtype
@@ -152,6 +153,9 @@ def attention_bwd(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, dO: Tensor, dQ: Te
     a.scale = (1.0 / math.sqrt(hd)) if scale is None else scale
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
+        if keep_bits is not None:
+            assert keep_bits.dtype == torch.int32 and keep_bits.dim() == 2 and keep_bits.is_contiguous() and keep_bits.shape[0] >= B * H * Lq
+            a.keep_bits, a.ld_bits = _p(keep_bits), keep_bits.shape[1]
     flops = 10.0 * B * H * Lq * a.Lk * hd                # five products of 2*Lq*Lk*hd (S, dP, dV, dK, dQ): cdna_hip_programming.md, attention backward
     _timed("made_attention_bwd", flops, float(Q.element_size() * B * D * (4 * Lq + 4 * a.Lk)),
            lambda: check(lib().made_attention_bwd(C.byref(a), _stream()), "made_attention_bwd"),

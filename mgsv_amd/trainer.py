@@ -51,6 +51,9 @@ class MadeTrainer(MadeEngine):
         self.generation = 0                                  # bumped by every in-place update of the masters (optimizer_step)
         self.seed = 0
         self.training_dropout = True
+        # bf16: the flash-attention forward stores its dropout decisions (one bit per score) and the two backward kernels test the bit
+        # instead of re-drawing it (made_attention's keep_bits; MADE_ATTN_BITS=0: re-draw, for A/B measurements)
+        self._bits = dtype == "bf16" and os.environ.get("MADE_ATTN_BITS", "1") != "0"
 
     # ------------------------------------------------------------------ support matrix
     def _check_train_supported(self):
@@ -460,7 +463,7 @@ class MadeTrainer(MadeEngine):
                 ws[f"{tag}.mean"].fill_(1.0)                      # neutral operands of pool_bwd (dtok = 0): mask * (in1 + in2)
             for l in range(depth):
                 ws.update({f"{tag}.{l}.x0": E(r, D), f"{tag}.{l}.x1": E(r, D), f"{tag}.{l}.qkv": E(r, 3 * D), f"{tag}.{l}.att": E(r, D),
-                           f"{tag}.{l}.lse": E(B * Hh * T1, dtype=f32), f"{tag}.{l}.x2": E(r, D), f"{tag}.{l}.x3": E(r, D),
+                           f"{tag}.{l}.lse": E(B * Hh * T1, dtype=f32), f"{tag}.{l}.kbits": E(B * Hh * T1, ops.attention_bits_words(T1), dtype=torch.int32), f"{tag}.{l}.x2": E(r, D), f"{tag}.{l}.x3": E(r, D),
                            f"{tag}.{l}.z1": E(r, Ft), f"{tag}.{l}.h": E(r, Ft)})
         rows = B * L
         Lp = round_up(L, 8)
@@ -510,7 +513,7 @@ class MadeTrainer(MadeEngine):
                 dframe_sum=E(B * Tv, D))
         for l in range(ne):
             ws.update({f"e.{l}.src": E(rows, D), f"e.{l}.srcpos": E(rows, D), f"e.{l}.qkv": E(rows, 3 * D), f"e.{l}.att": E(rows, D),
-                       f"e.{l}.lse": E(B * H * L, dtype=f32), f"e.{l}.x": E(rows, D), f"e.{l}.s1": E(rows, D), f"e.{l}.h": E(rows, Fd),
+                       f"e.{l}.lse": E(B * H * L, dtype=f32), f"e.{l}.kbits": E(B * H * L, ops.attention_bits_words(L), dtype=torch.int32), f"e.{l}.x": E(rows, D), f"e.{l}.s1": E(rows, D), f"e.{l}.h": E(rows, Fd),
                        f"e.{l}.x2": E(rows, D)})
         ws.update(mem=E(rows, D), mempos=E(rows, D))
         if not concat:                                          # CA fusion block (query = segments, context = frames)
@@ -752,7 +755,7 @@ class MadeTrainer(MadeEngine):
             att = tw[e + ".att"]
             ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, L, D), H, key_mask=fus_mask,
                           q_skip_mask=qskip, lse=tw[e + ".lse"], drop=self._drop(f"enc.{l}" + ".attn", pd),
-                          order=self._order[fus_mask.data_ptr()])
+                          order=self._order[fus_mask.data_ptr()], keep_bits=tw[e + ".kbits"] if self._bits else None)
             x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=tw[e + ".x"], rows=rows_f,
                            drop=self._drop(f"enc.{l}" + ".drop1", pd))
             s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[e + ".s1"], row_skip=fskip)
@@ -943,7 +946,8 @@ class MadeTrainer(MadeEngine):
             q3 = qkv.view(B, T1, 3 * D)
             att = tw[t + ".att"]
             ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, T1, D), Hh, key_mask=mask1, q_skip_mask=mask1,
-                          lse=tw[t + ".lse"], drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask1.data_ptr()])
+                          lse=tw[t + ".lse"], drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask1.data_ptr()],
+                          keep_bits=tw[t + ".kbits"] if self._bits else None)
             x2 = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x1, out=tw[t + ".x2"], rows=rws)
             x3_ = ops.layernorm(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], out=tw[t + ".x3"], row_skip=mflat1)
             h = ops.linear(x3_, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_GELU, out=tw[t + ".h"], Zout=tw[t + ".z1"], rows=rws,
@@ -1438,7 +1442,7 @@ class MadeTrainer(MadeEngine):
             tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[e + ".att"].view(B, L, D), datt.view(B, L, D),
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[e + ".lse"], tw["e_delta"], H,
                              key_mask=fus_mask, q_skip_mask=qskip, drop=self._drop(f"enc.{l}" + ".attn", pd),
-                             order=self._order[fus_mask.data_ptr()])
+                             order=self._order[fus_mask.data_ptr()], keep_bits=tw[e + ".kbits"] if self._bits else None)
             gW, gb = G[p + ".in.w"], G[p + ".in.b"]
             if self._groupable(gq, srcpos, gW[:2 * D]) and self._rw(fskip) is not None:
                 pend.append((gq[:, :2 * D], srcpos, gW[:2 * D], gb[:2 * D]))
@@ -1805,7 +1809,8 @@ class MadeTrainer(MadeEngine):
             q3, gq3 = qkv.view(B, T1, 3 * D), gq.view(B, T1, 3 * D)
             tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[t + ".att"].view(B, T1, D), datt.view(B, T1, D),
                              gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[t + ".lse"], tw[tag + ".delta"], Hh,
-                             key_mask=mask, q_skip_mask=mask, drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask.data_ptr()])
+                             key_mask=mask, q_skip_mask=mask, drop=self._drop(f"{name}.{l}.attn", pt), order=self._order[mask.data_ptr()],
+                             keep_bits=tw[t + ".kbits"] if self._bits else None)
             dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3b, row_mask=mflat, skip=mflat, R=g1b, defer=pend)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
             if dw_stream is not None and depth == 1 and not cls and not c.with_act_after_proj:

@@ -18,9 +18,11 @@ pos = torch.arange(L)[None]
 mask = ((pos < lv[:, None]) | ((pos >= 30) & (pos < 30 + la[:, None]))).float().cuda()
 order = ops.batch_order(mask)
 drop = (1, 2, p)
+bits = torch.empty(B * H * L, ops.attention_bits_words(L), device="cuda", dtype=torch.int32) if os.environ.get("BITS", "1") != "0" else None
 def run():
-    ops.attention(q, k, v, O, H, key_mask=mask, q_skip_mask=mask, lse=lse, drop=drop, order=order)
-    tr.attention_bwd(q, k, v, O, dO, dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], lse, delta, H, key_mask=mask, q_skip_mask=mask, drop=drop, order=order)
+    ops.attention(q, k, v, O, H, key_mask=mask, q_skip_mask=mask, lse=lse, drop=drop, order=order, keep_bits=bits)
+    tr.attention_bwd(q, k, v, O, dO, dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], lse, delta, H, key_mask=mask, q_skip_mask=mask, drop=drop, order=order,
+                     keep_bits=bits)
 for _ in range(3): run()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,4 +33,4 @@ n = mask.sum(1)
 work = float((n * n).sum() / (B * L * L))
 gf = 4 * B * H * L * L * hd * work / 1e9
 us = s.elapsed_time(e) / 10 * 1e3
-print(f"attention fwd + bwd, ragged (executed fraction {work:.2f}), p = {p}: {us:.1f} us per pair of calls = {3.5 * gf / us * 1e3:.1f} TFLOP/s executed (fwd 1x + bwd 2.5x of {gf:.1f} GFLOP)")
+print(f"[bits {0 if bits is None else 1}] attention fwd + bwd, ragged (executed fraction {work:.2f}), p = {p}: {us:.1f} us per pair of calls = {3.5 * gf / us * 1e3:.1f} TFLOP/s executed (fwd 1x + bwd 2.5x of {gf:.1f} GFLOP)")
