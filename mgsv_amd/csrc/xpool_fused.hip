@@ -32,15 +32,20 @@ constexpr int XS_MAX = 1024;            // segments per track this kernel accept
 //   * LayerNorm2 is folded into that product: with k1 = rstd, k2 = -mean rstd of o^,
 //         y = W LN2(o^) + b + LN2(o^) = k1 (W'' o^) + k2 Bv + Av,   W'' = (W + I) diag(g2), Av = W b2 + b + b2, Bv = W g2 + g2
 //     (W'', Av, Bv prepared once per call), so the residual costs nothing and no normalised copy of O is ever formed;
-//   * per track only the K / U tiles move: global -> LDS directly (global_load_lds, two stages, the next tile -- or the next
-//     track's first tile -- in flight under the current one), rows XOR-swizzled on the source side so both the row reads (K) and
-//     the transposing reads (U) are bank-conflict free without padding; rows of masked segments are fetched from the track's
-//     first valid row instead (their probability is exactly 0, so the product stays 0 whatever the masked rows hold);
+//   * per track only the K / U tiles move.  Rounds 1-3: global -> LDS directly (global_load_lds), two stages, ONE tile in flight.  Round 4: the
+//     tile in flight lives in registers (32 per attention wave), two tiles ahead of the one being multiplied -- see the tile pipeline in the
+//     kernel.  Rows are XOR-swizzled on the source side so both the row reads (K) and the transposing reads (U) are bank-conflict free
+//     without padding; rows of masked segments are fetched from the track's first valid row instead (their probability is exactly 0, so the
+//     product stays 0 whatever the masked rows hold);
 //   * s_barrier is workgroup-wide, so both roles execute the same number of barriers per track: the tile barriers of the attention
-//     waves are matched by barriers between the linear waves' work items.  Per iteration j (track j for the attention waves):
+//     waves are matched by barriers between the linear waves' work units.  Per iteration j (track j for the attention waves):
 //         attention:  tile 0 | T | tile 1 | T | ... | X | publish o^(j) | Y
-//         linear:     (product + sums of video tile 0 of track j-1) | T | (video tile 1) | T ... | X | finish track j-1 | Y
-//     X = "o^(j-1) has been consumed", Y = "o^(j) is published".
+//         linear:     P0 S0 [T] P1 [T] S1 [T ..] | X | Y | finish track j-1      (P / S = product / sums of a video tile of track j-1;
+//                                                                                  one-tile tracks: S1 behind X, beside the publishing)
+//     X = "o^(j-1) has been consumed", Y = "o^(j) is published, the partial sums of track j-1 are complete".
+//   * the launch runs at the socket's power limit (profiles/r04_o_retrieval_clock_power.txt: 1.3 kW, sclk 2.26 GHz, MFMA pipe 32 % busy):
+//     cycles saved by better overlap come back as a lower clock; what would pay is less work per pair -- both waves of a video tile
+//     compute the same scores (a third of the attention waves' MFMAs), every attention wave reads the whole K tile from LDS.
 constexpr int PQ = 64;                             // videos per workgroup
 constexpr int PT = 512;                            // threads
 constexpr int PTILE_B = XKEY * XD * 2;             // one K (or U) tile: 32 rows x 512 B
@@ -48,12 +53,18 @@ constexpr int PSTAGE_B = 2 * PTILE_B;
 constexpr int POFF_A3 = 2 * PSTAGE_B;              // [2 video tiles][16 fragments][64 lanes] x 16 B
 constexpr int POFF_GV = POFF_A3 + 2 * 16 * 64 * 16;   // [4 waves][2 video tiles][2 row tiles][2][64 lanes] x 16 B
 constexpr int POFF_VEC = POFF_GV + 4 * 2 * 2 * 2 * 64 * 16;   // [4][256] f32: Av, Bv, g3^2, g3 b3
-constexpr int POFF_PART = POFF_VEC + 4 * XD * 4;   // [4 waves][2 lane halves][2 video tiles][32 videos][6] f32
-constexpr int POFF_STAT = POFF_PART + 4 * 2 * 2 * 32 * 6 * 4;     // [2 video tiles][2 halves][2 lane halves][32 videos][2] f32
+constexpr int POFF_PART = POFF_VEC + 4 * XD * 4;   // [2 tracks][4 waves][2 video tiles][32 videos][6] f32
+constexpr int PPART_B = 4 * 2 * 32 * 6 * 4;       // (two of them: tracks alternate)
+constexpr int POFF_STAT = POFF_PART + 2 * PPART_B;                // [2 video tiles][2 halves][2 lane halves][32 videos][2] f32
 constexpr int POFF_BIAS = POFF_STAT + 2 * 2 * 2 * 32 * 2 * 4;
 constexpr int POFF_INFO = POFF_BIAS + 2 * XKEY * 4;   // per track of the chunk: last valid + 1 | first valid << 11 | leading valid << 21
+#ifndef MADE_XPOOL_LATE_N
+#define MADE_XPOOL_LATE_N 1
+#endif
+constexpr int PLATE_N = MADE_XPOOL_LATE_N;          // tracks of at most this many tiles: the second video tile's sums run behind X (see the linear waves)
 constexpr int PMAX_TRACKS = 1024;                   // tracks per chunk (the table's size)
 constexpr int PLDS = POFF_INFO + PMAX_TRACKS * 4;
+static_assert(PLDS <= 160 * 1024, "made_xpool_fused: the LDS map does not fit a CU");
 // workspace sections behind the per-video ones (floats): Av, Bv, then W'' (bf16), then the per-track info
 constexpr int64_t WS_AV = 4, WS_BV = 4 + XD, WS_W2 = 4 + 2 * XD, WS_INFO = 4 + 2 * XD + XD * XD / 2;
 
@@ -112,48 +123,7 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
         s_eff = (int)(v & 2047u); first = (int)((v >> 11) & 1023u); nfull = (int)(v >> 21);
     };
     auto tiles_of = [&](int s_eff) __attribute__((always_inline)) { return s_eff > 0 ? (s_eff + XKEY - 1) / XKEY : 1; };
-    // K / U tile (m, t) -> stage p, straight into LDS (uniform 64-bit track base + 32-bit per-lane byte offset: the scalar-base form
-    // of the load).  The attention waves move rows 8 w4 .. 8 w4 + 7 of both tiles each (sharing the sixteen pieces with the linear
-    // waves was measured slower: a piece costs its issuer 60-180 cycles and the linear waves' segments are the longer ones).
     const uint32_t ldk_b = (uint32_t)a.ldk * 2u, ldu_b = (uint32_t)a.ldu * 2u;
-    auto issue = [&](int64_t m, int t, int p, int s_eff, int first, int nfull) __attribute__((always_inline)) {
-        const unsigned char* Kb = (const unsigned char*)a.K + m * a.k_bs * 2;
-        const unsigned char* Ub = (const unsigned char*)a.U + m * a.u_bs * 2;
-        unsigned char* st = lds + p * PSTAGE_B;
-        if ((t + 1) * XKEY <= nfull) {                 // every segment of the tile is valid: nothing to compute per piece
-            const unsigned char* Kt = Kb + (size_t)((uint32_t)(t * XKEY) * ldk_b);
-            const unsigned char* Ut = Ub + (size_t)((uint32_t)(t * XKEY) * ldu_b);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int jp = w4 * 4 + i;
-                const uint32_t cl = lane & 31, row = 2 * jp + hh;
-                const uint32_t ok = row * ldk_b + (cl ^ (row & 31)) * 16u, ou = row * ldu_b + ((((cl >> 2) ^ (row & 7)) << 2) | (cl & 3)) * 16u;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kt + (size_t)opaque(ok)), (lds_ptr_t)(st + jp * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ut + (size_t)opaque(ou)), (lds_ptr_t)(st + PTILE_B + jp * 1024), 16, 0, 0);
-            }
-            if (wave == 0 && lane < XKEY) ((float*)(lds + POFF_BIAS))[p * XKEY + lane] = 0.f;
-            return;
-        }
-        const float* maskg = a.key_mask ? a.key_mask + m * a.S : nullptr;
-        const uint32_t cl = lane & 31;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int jp = w4 * 4 + i, row = 2 * jp + hh, seg = t * XKEY + row;
-            bool valid = seg < nfull;
-            if (!valid && seg < s_eff) valid = *(const float*)((const unsigned char*)maskg + (size_t)opaque((uint32_t)seg * 4u)) != 0.f;   // (only behind the first masked segment of the track)
-            const uint32_t srow = (uint32_t)(valid ? seg : first);
-            const uint32_t ck = cl ^ (uint32_t)(row & 31);             // 16-byte chunks swizzled by row
-            const uint32_t cu = (((cl >> 2) ^ (uint32_t)(row & 7)) << 2) | (cl & 3);   // 64-byte groups swizzled by row (transposing reads)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kb + (size_t)(srow * ldk_b + ck * 16u)), (lds_ptr_t)(st + jp * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ub + (size_t)(srow * ldu_b + cu * 16u)), (lds_ptr_t)(st + PTILE_B + jp * 1024), 16, 0, 0);
-        }
-        if (wave == 0 && lane < XKEY) {
-            const int seg = t * XKEY + lane;
-            bool valid = seg < nfull;
-            if (!valid && seg < s_eff) valid = *(const float*)((const unsigned char*)maskg + (size_t)opaque((uint32_t)seg * 4u)) != 0.f;
-            ((float*)(lds + POFF_BIAS))[p * XKEY + lane] = valid ? 0.f : -INFINITY;
-        }
-    };
 
     if (!linear_role) {
         // ================================================================================================ attention waves
@@ -175,26 +145,101 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
         const int trow = 4 * (g >> 1) + (i16 >> 2);                                       // row of the transposing read within a 16-row half
         const uint32_t u_l0 = lbase + PTILE_B + trow * 512 + (g & 1) * 32 + (i16 & 3) * 8 + (((trow & 7) ^ (4 * dh)) << 6);   // 64-byte group d at ^ (d << 6)
 
+        // ---- the K / U tile pipeline (round 4).  Rounds 1-3 moved a tile global -> LDS directly (global_load_lds) into the stage the previous
+        // tile had just left: ONE tile in flight, and the stamps (profiles/r04_m_*) show a tile step lasting as long as that transfer --
+        // ~1300 cycles for the CU's texture path to take the four waves' 32 x 1 KB instructions, then the way back from L2 -- whoever issues
+        // it.  A third 32 KB stage does not fit beside the o^ and g3 v fragments.  So the tile in flight lives in REGISTERS (32 per attention
+        // wave: its four 2-row pieces of K and of U): at the top of step k the registers (tile k + 1, fetched a whole step ago) go to the stage
+        // tile k - 1 has just left, the loads of tile k + 2 are issued into them, and tile k is computed from the other stage -- two tiles
+        // ahead with two stages, plain loads (cheaper on the texture path than LDS-DMA), and nothing ever waited for.  The swizzle is applied on
+        // the global side as before, the LDS write is lane-linear; masked rows fetch the track's first valid row (their probability is 0).
+        bf16x8 kreg[4], ureg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) { kreg[i][jj] = (bf16_t)0.f; ureg[i][jj] = (bf16_t)0.f; }
+        float pend_bias = 0.f;                         // wave 0, lanes < 32: the mask bias of the tile in the registers
+        int lj = 0, lt = 0, l_seff = 0, l_first = 0, l_nfull = 0, l_nt = 1;   // the loader's cursor: tile lt of track lj is the next to fetch
+        // fetch, part 1: byte offsets (from the track's K / U base) of this wave's pieces of the cursor's tile, the tile's mask bias, and the
+        // cursor's advance.  Behind the chunk's last tile the offsets are those of that tile again (the loads are still issued, the data
+        // lands in a stage nobody reads): one code path, so the loaded registers are plain values and not the merge of two branches, which
+        // the compiler would wait for on the spot.
+        uint32_t offk[4], offu[4];
+        const unsigned char *Kb = (const unsigned char*)a.K, *Ub = (const unsigned char*)a.U;
+        float next_bias = 0.f;
+        auto fetch_prepare = [&]() __attribute__((always_inline)) {
+            const bool live = lj < T;
+            const int64_t m = m_begin + (live ? lj : T - 1);
+            Kb = (const unsigned char*)a.K + m * a.k_bs * 2;
+            Ub = (const unsigned char*)a.U + m * a.u_bs * 2;
+            const uint32_t cl = lane & 31;
+            if ((lt + 1) * XKEY <= l_nfull) {              // every segment of the tile is valid: nothing to compute per piece
+                const uint32_t tk = (uint32_t)(lt * XKEY) * ldk_b, tu = (uint32_t)(lt * XKEY) * ldu_b;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t row = 2 * (i * 4 + w4) + hh;
+                    offk[i] = tk + row * ldk_b + (cl ^ (row & 31)) * 16u;
+                    offu[i] = tu + row * ldu_b + ((((cl >> 2) ^ (row & 7)) << 2) | (cl & 3)) * 16u;
+                }
+                next_bias = 0.f;
+            } else {
+                const float* maskg = a.key_mask ? a.key_mask + m * a.S : nullptr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 2 * (i * 4 + w4) + hh, seg = lt * XKEY + row;
+                    bool valid = seg < l_nfull;
+                    if (!valid && seg < l_seff) valid = *(const float*)((const unsigned char*)maskg + (size_t)opaque((uint32_t)seg * 4u)) != 0.f;
+                    const uint32_t srow = (uint32_t)(valid ? seg : l_first);
+                    offk[i] = srow * ldk_b + (cl ^ (uint32_t)(row & 31)) * 16u;                                  // 16-byte chunks swizzled by row
+                    offu[i] = srow * ldu_b + ((((cl >> 2) ^ (uint32_t)(row & 7)) << 2) | (cl & 3)) * 16u;        // 64-byte groups swizzled by row
+                }
+                if (wave == 0) {
+                    const int seg = lt * XKEY + (lane & 31);
+                    bool valid = seg < l_nfull;
+                    if (!valid && seg < l_seff) valid = *(const float*)((const unsigned char*)maskg + (size_t)opaque((uint32_t)seg * 4u)) != 0.f;
+                    next_bias = valid ? 0.f : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { offk[i] = opaque(offk[i]); offu[i] = opaque(offu[i]); }   // (32-bit offsets from a uniform base: the scalar-base form of the load)
+            if (live && ++lt == l_nt) {
+                lt = 0; ++lj;
+                if (lj < T) { track_info(lj, l_seff, l_first, l_nfull); l_nt = tiles_of(l_seff); }
+            }
+        };
+        // fetch, part 2 (the loads) and the stash (registers -> stage p, lane-linear) are spelled out where they are used: inside the tile
+        // step they sit BETWEEN the MFMAs of the score product, one per MFMA -- issued back to back they cost the wave ~70-90 cycles each
+        // (the CU's one texture path takes the four waves' 32 KB at 64 B / cycle; the LDS pipe is shared with the fragment reads)
+        const uint32_t st_w0 = lbase + w4 * 1024 + 16 * lane;                              // piece i of K at + i * 4096, of U at + PTILE_B + i * 4096
+#define XP_LOADS() do { _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+            kreg[i] = *(const bf16x8*)(Kb + (size_t)offk[i]); ureg[i] = *(const bf16x8*)(Ub + (size_t)offu[i]); } } while (0)
+#define XP_STASH(st) do { _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+            lds_wr<bf16x8>((st) + i * 4096, kreg[i]); lds_wr<bf16x8>((st) + PTILE_B + i * 4096, ureg[i]); } } while (0)
+        auto stash_bias = [&](int p) __attribute__((always_inline)) {
+            if (wave == 0 && lane < XKEY) lds_wr<float>(opaque(lbase + POFF_BIAS + 4 * lane + p * (XKEY * 4)), pend_bias);
+        };
+
         int s_eff, first, nfull;
         int p = 0;
-        // every register load of the prologue has landed (a builtin, so that the compiler's own wait-count bookkeeping knows it: a load
-        // it believes pending would make it wait for vmcnt(0) -- i.e. for the tile in flight -- at the first use inside the loop)
+        // every register load of the prologue has landed (a builtin, so that the compiler's own wait-count bookkeeping knows it)
         __builtin_amdgcn_s_waitcnt(0x0070);
         XP_BARRIER();                                                    // B0: vec / gv / track table published
-        track_info(0, s_eff, first, nfull);
-        if (!(DBG & 16)) issue(m_begin, 0, 0, s_eff, first, nfull);
-        XP_BARRIER_VM();                                                 // B1: tile 0 of the first track has landed
+        track_info(0, l_seff, l_first, l_nfull); l_nt = tiles_of(l_seff);
+        if (!(DBG & 16)) {
+            fetch_prepare(); pend_bias = next_bias; XP_LOADS();
+            stash_bias(0); XP_STASH(opaque(st_w0));                      // tile 0 -> stage 0
+            fetch_prepare(); pend_bias = next_bias; XP_LOADS();          // tile 1 -> registers
+        }
+        XP_BARRIER();                                                    // B1: tile 0 of the first track is in LDS
 
         for (int j = 0; j <= T; ++j) {
-            const int64_t m = m_begin + j;
             f32x16 o[4];
             float l_tot = 1.f;
             XP_STAMP(0);
             if (j < T) {
+                track_info(j, s_eff, first, nfull);
                 const int ntiles = tiles_of(s_eff);
-                const int cur_seff = s_eff, cur_nfull = nfull, cur_first = first;
-                int nx_seff = 0, nx_first = 0, nx_nfull = 0;
-                if (j + 1 < T) track_info(j + 1, nx_seff, nx_first, nx_nfull);
+                const int cur_nfull = nfull;
 #pragma unroll
                 for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -202,15 +247,13 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
                 float m_run = -INFINITY, l_run = 0.f;
 
                 for (int t = 0; t < ntiles; ++t) {
-                    if (t > 0) XP_BARRIER_VM();                          // T: stage p landed; stage p ^ 1 is free
-                    if (!(DBG & 16)) {
-                        if (t + 1 < ntiles) issue(m, t + 1, p ^ 1, cur_seff, cur_first, cur_nfull);
-                        else if (j + 1 < T) issue(m + 1, 0, p ^ 1, nx_seff, nx_first, nx_nfull);
-                    }
+                    if (t > 0) XP_BARRIER();                             // T: every wave has left stage p ^ 1 (tile k - 1); tile k is in stage p
+                    if (!(DBG & 16)) { stash_bias(p ^ 1); fetch_prepare(); pend_bias = next_bias; }
                     if (t == 0) XP_STAMP(11);
                     const uint32_t k_l = opaque(k_l0 + p * PSTAGE_B), u_l = opaque(u_l0 + p * PSTAGE_B), bias_h = opaque(bias_h0 + p * (XKEY * 4));
 
-                    // ---- S^T [32 segments x 32 videos] (both waves of the video tile)
+                    // ---- S^T [32 segments x 32 videos] (both waves of the video tile); between its MFMAs: the registers (tile k + 1) -> stage
+                    // p ^ 1, then the loads of tile k + 2 into them
                     f32x16 s;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) s[e] = 0.f;
@@ -218,16 +261,24 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
                         // (the fragment reads run three ahead of the MFMAs)
                         constexpr int NK = (DBG & 8) ? 1 : XD / 16;
                         bf16x8 kf[NK];
+                        // program order IS the issue order here (a scheduling fence after every MFMA): fragment read three ahead, MFMA, then
+                        // one piece of the stash (MFMAs 0-7) or one load of the next fetch (MFMAs 8-15)
+                        const uint32_t st = opaque(st_w0 + (p ^ 1) * PSTAGE_B);
 #pragma unroll
-                        for (int ks = 0; ks < NK; ++ks) kf[ks] = lds_rd<bf16x8>(k_l ^ (ks << 5));
+                        for (int ks = 0; ks < (NK < 3 ? NK : 3); ++ks) kf[ks] = lds_rd<bf16x8>(k_l ^ (ks << 5));
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int ks = 0; ks < NK; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
-                        if (NK == 16) {
-                            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-                            for (int i = 0; i < 13; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        for (int ks = 0; ks < NK; ++ks) {
+                            if (ks + 3 < NK) kf[ks + 3] = lds_rd<bf16x8>(k_l ^ ((ks + 3) << 5));
+                            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+                            if (!(DBG & 16) && NK == 16) {
+                                const int i = (ks & 7) >> 1;
+                                if (ks < 8) { if (ks & 1) lds_wr<bf16x8>(st + PTILE_B + i * 4096, ureg[i]); else lds_wr<bf16x8>(st + i * 4096, kreg[i]); }
+                                else { if (ks & 1) ureg[i] = *(const bf16x8*)(Ub + (size_t)offu[i]); else kreg[i] = *(const bf16x8*)(Kb + (size_t)offk[i]); }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
+                        if (!(DBG & 16) && NK != 16) { XP_STASH(st); XP_LOADS(); }
                     }
                     if (t == 0) { asm volatile("" : "+v"(s[0])); XP_STAMP(12); }
                     // ---- online softmax (per video = per lane column; the two lane halves hold different segments)
@@ -294,8 +345,6 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
                     XP_STAMP(1 + (t < 3 ? t : 3));
                 }
                 l_tot = l_run + other_half(l_run);
-                s_eff = nx_seff; first = nx_first; nfull = nx_nfull;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the next track's first tile
             }
             XP_STAMP(5);
             XP_BARRIER();                                                // X: the linear waves have consumed o^ of the previous track
@@ -363,8 +412,8 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
         const uint32_t vec_w0 = lbase + POFF_VEC + 16 * hh + 4 * 64 * w4;                  // rows 64 w4 + 8 g4 + 4 hh ..
         const uint32_t a3r0 = lbase + POFF_A3 + 16 * lane;                                // fragment (v2, f) at + (v2*16 + f) * 1024
         const uint32_t gv0 = lbase + POFF_GV + w4 * 8 * 1024 + 16 * lane;                 // fragment (v2, rt, s2) at + ((v2*2 + rt)*2 + s2) * 1024
-        const uint32_t partw0 = lbase + POFF_PART + (((w4 * 2 + hh) * 2) * 32 + r) * 24; // [w4][hh][v2][r][6]: v2 at + v2 * 768
-        const uint32_t partr0 = lbase + POFF_PART + ((w4 & 1) * 32 + r) * 24;             // partial (w', hh') at + (w' * 2 + hh') * 1536
+        const uint32_t partw0 = lbase + POFF_PART + ((w4 * 2) * 32 + r) * 24;              // [w4][v2][r][6]: v2 at + v2 * 768
+        const uint32_t partr0 = lbase + POFF_PART + ((w4 & 1) * 32 + r) * 24;             // partial of wave w' at + w' * 1536
         const uint32_t statr0 = lbase + POFF_STAT + r * 8;                                // (v2, half, lane half) at + ((v2*2 + half)*2 + hh') * 256
 
         __builtin_amdgcn_s_waitcnt(0x0070);
@@ -380,7 +429,21 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
                 if (j + 1 < T) track_info(j + 1, s_eff, first, nfull);
             }
             XP_STAMP(0);
-            const uint32_t vec_w = opaque(vec_w0), a3r = opaque(a3r0), gvr = opaque(gv0), partw = opaque(partw0), statr = opaque(statr0);
+            // Per track (j - 1) this wave has four work units: per video tile the product (reads o^), then the sums (read only registers and
+            // constants).  The attention waves' barriers of this iteration -- n - 1 tile barriers, then X ("o^ may be overwritten") and Y
+            // ("o^ of track j is published") -- fall between them where the attention waves are about to arrive:
+            //   n <= 2 tiles:  P0 S0 [T] P1 | X | S1 | Y      the second sums run beside the attention waves' publishing of o^ (which this
+            //                                                 wave used to sit out); with one or two tiles this wave is the longer chain
+            //   n >= 3 tiles:  P0 S0 T P1 T S1 [T ..] | X | Y the attention waves are the longer chain
+            // (bit 2 of the schedule = a barrier behind the first sums, bit 3 = behind the second product).  LayerNorm3 / cosine of a track are
+            // finished behind Y from the partial sums of BOTH video tiles; the partial sums alternate between two buffers, so that the next
+            // track's first sums cannot overtake that finish.  (A barrier inside the sums, between the row tiles, would fit three tiles
+            // better still, but the compiler answers it with 164 bytes of spills.)
+            const bool late = n <= PLATE_N;
+            const unsigned bar_after = n >= 3 ? 0x0cu : n == 2 ? 0x04u : 0u;
+            const uint32_t par_off = (uint32_t)(j & 1) * (uint32_t)PPART_B;
+            const uint32_t vec_w = opaque(vec_w0), a3r = opaque(a3r0), gvr = opaque(gv0), partw = opaque(partw0 + par_off), statr = opaque(statr0);
+            if (j == 0) for (int t = 1; t < n; ++t) XP_BARRIER();           // (nothing to multiply yet)
 #pragma unroll
             for (int v2 = 0; v2 < 2; ++v2) {
                 if (j >= 1) {
@@ -407,14 +470,18 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
                             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                         }
                     }
-                    XP_STAMP(1 + 3 * v2);
-                    // LayerNorm2 of video (v2, r): the four partial sums
+                    // LayerNorm2 of video (v2, r): the four partial sums (read before X: the attention waves rewrite them while publishing)
                     f32x2_t st = lds_rd<f32x2_t>(statr + (v2 * 4) * 256);
 #pragma unroll
                     for (int q = 1; q < 4; ++q) st += lds_rd<f32x2_t>(statr + (v2 * 4 + q) * 256);
                     const float mean2 = st[0] * (1.f / XD);
                     const float var2 = fmaxf(st[1] * (1.f / XD) - mean2 * mean2, 0.f);
                     const float k1 = __builtin_amdgcn_rsqf(var2 + a.eps), k2 = -mean2 * k1;
+                    XP_STAMP(1 + 3 * v2);
+                    if (v2 == 1) {
+                        if ((bar_after >> 3) & 1u) XP_BARRIER();
+                        if (late) { XP_STAMP(7); XP_BARRIER(); XP_STAMP(8); }   // X: o^ of track j - 1 consumed
+                    }
                     // the six sums of LayerNorm3 + cosine (round 1's rule) restricted to these rows (and this lane half's rows)
                     float S1 = 0.f, S2 = 0.f, P1 = 0.f, C2 = 0.f, C1 = 0.f, E1 = 0.f;
                     if (DBG & 2) { S1 = acc[0][0] + acc[1][5] + k1; S2 = k2 + acc[0][9]; }
@@ -451,23 +518,27 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
                         }
                         S1 = s1[0] + s1[1]; S2 = s2[0] + s2[1]; P1 = p1[0] + p1[1]; C2 = c2[0] + c2[1]; C1 = c1[0] + c1[1]; E1 = e1[0] + e1[1];
                     }
-                    lds_wr<f32x2_t>(partw + v2 * 768, (f32x2_t){S1, S2}); lds_wr<f32x2_t>(partw + v2 * 768 + 8, (f32x2_t){P1, C2});
-                    lds_wr<f32x2_t>(partw + v2 * 768 + 16, (f32x2_t){C1, E1});
+                    S1 += other_half(S1); S2 += other_half(S2); P1 += other_half(P1); C2 += other_half(C2); C1 += other_half(C1); E1 += other_half(E1);
+                    if (hh == 0) {
+                        lds_wr<f32x2_t>(partw + v2 * 768, (f32x2_t){S1, S2}); lds_wr<f32x2_t>(partw + v2 * 768 + 8, (f32x2_t){P1, C2});
+                        lds_wr<f32x2_t>(partw + v2 * 768 + 16, (f32x2_t){C1, E1});
+                    }
                 }
                 XP_STAMP(2 + 3 * v2);
-                if (v2 == 0 && n > 1) XP_BARRIER();                      // (the attention waves' tile barrier)
+                if (j >= 1 && v2 == 0 && ((bar_after >> 2) & 1u)) XP_BARRIER();
                 XP_STAMP(3 + 3 * v2);
             }
-            for (int t = 2; t < n; ++t) XP_BARRIER();
-            XP_STAMP(7);
-            XP_BARRIER();                                                // X: o^ of track j - 1 consumed, partial sums in LDS
-            XP_STAMP(8);
+            if (j >= 1) for (int t = 3; t < n; ++t) XP_BARRIER();
+            if (!(j >= 1 && late)) { XP_STAMP(7); XP_BARRIER(); XP_STAMP(8); }   // X: o^ of track j - 1 consumed
+            XP_STAMP(9);
+            XP_BARRIER();                                                // Y: every wave's partial sums of track j - 1 are in LDS (and o^ of track j)
+            XP_STAMP(10);
             if (j >= 1 && w4 < 2 && hh == 0) {
-                // ---- the eight partial sums (four row blocks x two lane halves) of video (w4, r): LayerNorm3 + cosine
-                const uint32_t partr = opaque(partr0);
+                // ---- the four partial sums (one per row block = linear wave) of video (w4, r): LayerNorm3 + cosine
+                const uint32_t partr = opaque(partr0 + par_off);
                 float s1 = 0.f, s2 = 0.f, p1 = 0.f, c2 = 0.f, c1 = 0.f, e1 = 0.f;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < 4; ++q) {
                     const f32x2_t x0 = lds_rd<f32x2_t>(partr + q * 1536), x1 = lds_rd<f32x2_t>(partr + q * 1536 + 8), x2 = lds_rd<f32x2_t>(partr + q * 1536 + 16);
                     s1 += x0[0]; s2 += x0[1]; p1 += x1[0]; c2 += x1[1]; c1 += x2[0]; e1 += x2[1];
                 }
@@ -480,9 +551,6 @@ __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXp
                 // (a track without a valid segment: the attention waves produced 0 / 0 = NaN already, like the reference's softmax over -inf)
                 if (!(DBG & 1) && my_n < a.Nv) a.sims[my_n * a.ld_sims + (m_begin + j - 1)] = out;
             }
-            XP_STAMP(9);
-            XP_BARRIER();                                                // Y
-            XP_STAMP(10);
         }
     }
 }
