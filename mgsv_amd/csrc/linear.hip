@@ -787,6 +787,30 @@ constexpr int BIG_BN = 256, BIG_THREADS = 512, BIG_NMAX = 2048;
 
 // FAST: bias (+ ReLU) only, plain row-major output with 16-byte-aligned rows, N a multiple of 8 -- the epilogue is 64 straight-line groups
 // of (swap, add, convert, store); the general one runs the shared 8-column epilogue with all its options per group.
+// 8 consecutive values of a bf16 / f32 row at a 16-byte aligned offset (the straight-line epilogues of linear_big_kernel)
+__device__ __forceinline__ void big_load8(const void* p, int dt, int64_t off, float* v) {
+    if (dt == MADE_BF16) {
+        const bf16x8 t = *(const bf16x8*)((const bf16_t*)p + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+    } else {
+        const f32x4 t0 = *(const f32x4*)((const float*)p + off), t1 = *(const f32x4*)((const float*)p + off + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = t0[j]; v[4 + j] = t1[j]; }
+    }
+}
+__device__ __forceinline__ void big_store8(void* p, int dt, int64_t off, const float* v) {
+    if (dt == MADE_BF16) {
+        bf16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[j];
+        *(bf16x8*)((bf16_t*)p + off) = t;
+    } else {
+        *(f32x4*)((float*)p + off) = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)((float*)p + off + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    }
+}
+
 template <int BMB, bool TRAIN, bool FAST>
 __global__ __launch_bounds__(BIG_THREADS, 1) void linear_big_kernel(const MadeLinearArgs a) {
     constexpr int STAGE = (BMB + BIG_BN) * KB;
@@ -813,6 +837,9 @@ __global__ __launch_bounds__(BIG_THREADS, 1) void linear_big_kernel(const MadeLi
     const int nk = K / 64;
     const int rmod = (int)a.r_row_mod;
     const bool r_vec = a.R && (a.ldr % 8 == 0) && (((uintptr_t)a.R & 15) == 0);
+    const uint32_t drop_thr = made_drop_threshold(a.drop.p);
+    const float drop_sc = 1.f / (1.f - a.drop.p);
+    const uint64_t drop_seed = (TRAIN && FAST && a.drop.p > 0.f) ? made_drop_seed(a.drop) : 0;
 
     // fragment read offsets (see linear_glds_kernel): row rr, 16-byte chunk c = 2 ks + hh at rr * 128 + ((c ^ swz(rr)) << 4)
     int offa[MT], offw[2], sa[MT], sw[2];
@@ -941,9 +968,39 @@ __global__ __launch_bounds__(BIG_THREADS, 1) void linear_big_kernel(const MadeLi
                         if constexpr (FAST) {
                             const f32x4 b0 = *(const f32x4*)(bias_l + (n < BIG_NMAX - 8 ? n : BIG_NMAX - 8)), b1 = *(const f32x4*)(bias_l + (n < BIG_NMAX - 8 ? n : BIG_NMAX - 8) + 4);
                             v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
+                            if constexpr (TRAIN) {
+                                if (a.Zout && ml < Mv && nvalid == 8) big_store8(a.Zout, a.z_dtype, (int64_t)m * a.ldz + n, v);
+                            }
                             if (a.act == MADE_ACT_RELU) {
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                            }
+                            if constexpr (TRAIN) {
+                                // the training forms the step uses on its large launches, straight-line and on whole 16-byte groups (the launcher
+                                // checks the alignments): ReLU-output gate, dropout (one draw per element), residual, output row mask -- in
+                                // epilogue8's order.  Rows past the edge compute on row Mv - 1's operands and are not stored.
+                                const int nl = nvalid == 8 ? n : 0;           // (a column group past N: operands of group 0, nothing stored)
+                                if (a.gate == MADE_GATE_RELU_OUT) {
+                                    float g[8];
+                                    big_load8(a.G, a.g_dtype, (int64_t)m * a.ldg + nl, g);
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[j] *= (g[j] != 0.f ? 1.f : 0.f) * a.gate_scale;
+                                }
+                                if (a.drop.p > 0.f) {
+                                    const uint32_t kb = made_keep_bits<8>(drop_seed, a.drop.site, drop_thr, (uint64_t)m * (uint64_t)a.drop_ld + (uint64_t)n);
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * drop_sc : 0.f;
+                                }
+                                if (a.R) {
+                                    float rv[8];
+                                    big_load8(a.R, a.r_dtype, (int64_t)(rmod > 0 ? m % rmod : m) * a.ldr + nl, rv);
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[j] += rv[j];
+                                }
+                                if (a.out_row_mask && a.out_row_mask[m] == 0.f) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+                                }
                             }
                             if (ml < Mv && nvalid == 8) {
                                 if (odt == MADE_BF16) {
@@ -1394,9 +1451,28 @@ static int tile_pref() {                                   // read on every call
     return e ? atoi(e) : 0;
 }
 
+static int64_t big_train_min() {                           // read on every call (A/B inside one process)
+    const char* e = getenv("MADE_LINEAR_BIG_TRAIN");
+    return e ? (int64_t)atoll(e) : 0;
+}
+
 static int64_t t16_max() {                                 // (MADE_T16_MAX: knob for measurements)
     static const int64_t v = [] { const char* e = getenv("MADE_T16_MAX"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
     return v;
+}
+
+// linear_big_kernel's straight-line epilogues serve: bias, ReLU, and (training) pre-activation copy, ReLU-output gate, per-element dropout,
+// residual, output row mask -- on plain row-major rows of whole, 16-byte aligned groups of 8 outputs
+static bool big_fast_epilogue(const MadeLinearArgs& a) {
+    auto al = [](const void* p, int64_t ld, int dt) { return (((uintptr_t)p & 15) == 0) && ld % (dt == MADE_BF16 ? 8 : 4) == 0; };
+    bool ok = (a.act == MADE_ACT_NONE || a.act == MADE_ACT_RELU) && a.N % 8 == 0 && (a.gate == MADE_GATE_NONE || a.gate == MADE_GATE_RELU_OUT);
+    if (a.gate != MADE_GATE_NONE) ok = ok && al(a.G, a.ldg, a.g_dtype);
+    if (a.Zout) ok = ok && al(a.Zout, a.ldz, a.z_dtype);
+    if (a.R) ok = ok && al(a.R, a.ldr, a.r_dtype);
+    if (a.drop.p > 0.f) ok = ok && a.drop_col_div <= 1;
+    for (int s = 0; s < a.nseg; ++s)
+        ok = ok && a.seg[s].rows_per_batch == 0 && a.seg[s].col_begin % 8 == 0 && al(a.seg[s].out, a.seg[s].ldo, a.seg[s].out_dtype);
+    return ok;
 }
 
 // which kernel made_linear runs for these arguments (one place: the launcher and made_linear_variant both ask here)
@@ -1430,6 +1506,11 @@ static int pick_variant(const MadeLinearArgs& a) {
             if (tile_pref() == 256) return MADE_LINEAR_BIG128;
             const int64_t tiles256 = ((a.M + 255) / 256) * ((a.N + BIG_BN - 1) / BIG_BN);
             if (tile_pref() == 0 && !a.row_index && tiles256 >= 2 * 256) return MADE_LINEAR_BIG256;
+            // the training step's large launches (MADE_LINEAR_BIG_TRAIN=<least number of live 128 x 256 tiles>, 0 = off): the straight-line
+            // training epilogue only -- the general one costs the big tiles more than they gain
+            const int64_t tiles128 = ((a.M + 127) / 128) * ((a.N + BIG_BN - 1) / BIG_BN);
+            const int64_t live128 = a.row_index ? (tiles128 * 9) / 16 : tiles128;
+            if (tile_pref() == 0 && big_train_min() > 0 && a.N % BIG_BN == 0 && live128 >= big_train_min() && big_fast_epilogue(a)) return MADE_LINEAR_BIG128;
         }
     }
     // workgroups that will really run: a gathered batch keeps about half of its rows (the host does not know *n_rows)
@@ -1557,6 +1638,8 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
                 ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
                 ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
                 ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l256) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
                 return ok;
             }();
             (void)once;
@@ -1565,15 +1648,16 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
             if (nt < g) g = ((nt + 7) / 8) * 8;
             dim3 gb((unsigned)g), bb(BIG_THREADS);
             // the straight-line epilogue: bias (+ ReLU) only, plain row-major output rows of whole 16-byte groups
-            bool fastep = !train && a.R == nullptr && a.out_row_mask == nullptr && (a.act == MADE_ACT_NONE || a.act == MADE_ACT_RELU) && a.N % 8 == 0;
-            for (int s = 0; s < a.nseg; ++s)
-                fastep = fastep && a.seg[s].rows_per_batch == 0 && a.seg[s].ldo % 8 == 0 && a.seg[s].col_begin % 8 == 0 && (((uintptr_t)a.seg[s].out & 15) == 0);
+            const bool fastep = big_fast_epilogue(a);
+            const bool lite = fastep && (train || a.R != nullptr || a.out_row_mask != nullptr);   // the straight-line training epilogue
             if (b256) {
-                if (train) hipLaunchKernelGGL((linear_big_kernel<256, true, false>), gb, bb, ldsb, st, a);
+                if (lite) hipLaunchKernelGGL((linear_big_kernel<256, true, true>), gb, bb, ldsb, st, a);
+                else if (train) hipLaunchKernelGGL((linear_big_kernel<256, true, false>), gb, bb, ldsb, st, a);
                 else if (fastep) hipLaunchKernelGGL((linear_big_kernel<256, false, true>), gb, bb, ldsb, st, a);
                 else hipLaunchKernelGGL((linear_big_kernel<256, false, false>), gb, bb, ldsb, st, a);
             } else {
-                if (train) hipLaunchKernelGGL((linear_big_kernel<128, true, false>), gb, bb, ldsb, st, a);
+                if (lite) hipLaunchKernelGGL((linear_big_kernel<128, true, true>), gb, bb, ldsb, st, a);
+                else if (train) hipLaunchKernelGGL((linear_big_kernel<128, true, false>), gb, bb, ldsb, st, a);
                 else if (fastep) hipLaunchKernelGGL((linear_big_kernel<128, false, true>), gb, bb, ldsb, st, a);
                 else hipLaunchKernelGGL((linear_big_kernel<128, false, false>), gb, bb, ldsb, st, a);
             }

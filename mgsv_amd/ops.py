@@ -154,6 +154,9 @@ LINEAR_VARIANTS = {0: "linear_f32", 1: "linear_f32in_bf16", 2: "linear_kernel<bf
                    8: "linear_big_kernel<256>", 9: "linear_t16_kernel", 10: "linear_big_kernel<128>"}
 
 
+LINEAR_LOG = None                                             # a list: every linear() call appends its form (tools/linear_calls.py)
+
+
 def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,
            segs: Optional[Sequence[Seg]] = None, A2: Optional[Tensor] = None, a2_row_mod: int = 0,
            a2_replace: bool = False, a_row_mask: Optional[Tensor] = None, act: int = ACT_NONE, R: Optional[Tensor] = None,
@@ -221,6 +224,12 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     flops = 2.0 * M * N * K * batch
     nbytes = batch * (M * K * (4 if a.a_dtype == F32 else 2) + N * K * esz + M * N * esz)
     desc = f"M={M} N={N} K={K} z={batch} nseg={len(segs)} a2={int(A2 is not None)} R={int(R is not None)} act={act} tr={int(any(s_.transposed for s_ in segs))}"
+    if LINEAR_LOG is not None:                                # (tools/linear_calls.py: which forms of made_linear a step uses)
+        LINEAR_LOG.append((LINEAR_VARIANTS.get(lib().made_linear_variant(C.byref(a)), "?") if kind == "linear_bf16" else kind, M, N, K, batch,
+                           f"nseg={len(segs)} a2={int(A2 is not None)}/{int(bool(a2_replace))} R={None if R is None else str(R.dtype)[6:]}/{r_row_mod} act={act} gate={gate} "
+                           f"G={None if G is None else str(G.dtype)[6:]} Z={None if Zout is None else str(Zout.dtype)[6:]} "
+                           f"drop={0 if drop is None else drop[2]}/{drop_col_div} rows={int(rows is not None)} orm={int(out_row_mask is not None)} "
+                           f"arm={int(a_row_mask is not None)} out={str(segs[0].out.dtype)[6:]} rpb={segs[0].rows_per_batch} tr={int(any(s_.transposed for s_ in segs))}"))
     _timed(kind, flops, nbytes, lambda: check(lib().made_linear(C.byref(a), _stream()), "made_linear"),
            ("rows", rows[1], M) if rows is not None else ((desc, tile_skip_mask, 128) if tile_skip_mask is not None else desc))
     return segs[0].out

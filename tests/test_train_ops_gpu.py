@@ -188,6 +188,14 @@ def test_linear_big_tile_training_epilogue(T, K, N, monkeypatch):
     base = A.float() @ W.float().t()
     refg = base * (G.float() != 0).float() / 0.9
     assert float((out.float() - refg).abs().max()) <= 2e-2 * float(refg.abs().max()) + 1e-6
+    # gate + dropout + a row-periodic f32 residual + the output row mask, f32 output (the straight-line epilogue's remaining branches)
+    monkeypatch.setenv("MADE_LINEAR_TILE", "256")
+    Rp = _rand(Tn, N, dtype=torch.float32, seed=6)
+    orm = (torch.arange(M, device="cuda") % 7 != 3).float()
+    out32 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
+    ops.linear(A, W, bias, gate=_lib.GATE_RELU_OUT, G=G, gate_scale=0.5, drop=(seed, site, p), R=Rp, r_row_mod=Tn, out_row_mask=orm, out=out32)
+    ref32 = ((base + bias) * (G.float() != 0).float() * 0.5 * keep / (1 - p) + Rp.repeat(M // Tn, 1)) * orm[:, None]
+    assert float((out32 - ref32).abs().max()) <= 2e-2 * float(ref32.abs().max()) + 1e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
