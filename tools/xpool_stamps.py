@@ -24,4 +24,4 @@ for w in (0, 2, 4, 5):
     print(f"wave {w} ({'attention' if w < 4 else 'linear'}): cycles from the iteration's first stamp")
     for j in range(3, 9):
         row = st[w, j]; base = int(row[0])
-        print("   it", j, " ".join(f"{p}:{int(row[p]) - base:6d}" if int(row[p]) else f"{p}:     -" for p in list(range(11)) + ([15, 14, 11, 12, 13] if w < 4 else [])))
+        print("   it", j, " ".join(f"{p}:{int(row[p]) - base:6d}" if int(row[p]) else f"{p}:     -" for p in list(range(11)) + ([11, 12, 13] if w < 4 else [])))
