@@ -513,6 +513,25 @@ typedef struct MadeXpoolAttnArgs {
 
 int made_xpool_attention(const MadeXpoolAttnArgs* args, void* stream);
 
+/* made_xpool_inbatch: the in-batch X-Pool contraction for a batch of at most 64 videos -- out[m, n, :] = softmax_s(scale q_n . k_{m,s} + mask) U_m
+ * (reference modules/transformer.py:110-119, out projection hoisted onto the values; the north-star contraction).  Two launches of one
+ * workgroup per CU -- scores per (track, 128 segments) with the tile-local softmax pieces, then P.V per (track, 128 value columns) -- with only
+ * the bf16 probabilities between them; replaces made_attention_wide's key split + merge on this shape.  Q [Nv <= 64, D], K / U [Nm, S <= 512, D]
+ * (rows at m * {k,u}_bs + s * ld{k,u}), bf16, D = 256 / 512; key_mask [Nm, S] f32 or NULL; out[m * o_bs + n * ldo + d] bf16 or f32;
+ * ws: made_xpool_inbatch_ws_bytes(Nm, S) bytes, 16-byte aligned.  A track without a valid segment gives NaN rows (the reference's softmax). */
+typedef struct MadeXpoolInbatchArgs {
+    const void* Q; int64_t ldq;
+    const void* K; const void* U; int64_t k_bs, ldk, u_bs, ldu;
+    const float* key_mask;
+    void* out; int32_t out_dtype; int32_t _pad; int64_t o_bs, ldo;
+    int64_t Nv, Nm, S, D;
+    float scale; int32_t _pad2;
+    void* ws;
+} MadeXpoolInbatchArgs;
+
+int     made_xpool_inbatch(const MadeXpoolInbatchArgs* args, void* stream);
+int64_t made_xpool_inbatch_ws_bytes(int64_t Nm, int64_t S);
+
 /* made_row_affine: out[r, :] = act(x[r, :] * scale[r % period] + shift[r % period]), act = none | ReLU.  Eval-mode
  * BatchNorm1d of the EmbeddingNet aggregator (reference model/model_Base.py:224-229): its input is [B, T, F], so the
  * "channels" are the T token positions and the running statistics reduce to one (scale, shift) per position. */

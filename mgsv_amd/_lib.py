@@ -116,6 +116,12 @@ class MadeXpoolAttnArgs(C.Structure):
                 ("scale", f32), ("eps", f32), ("normalize", i32), ("_pad", i32), ("ws", vp)]
 
 
+class MadeXpoolInbatchArgs(C.Structure):
+    _fields_ = [("Q", vp), ("ldq", i64), ("K", vp), ("U", vp), ("k_bs", i64), ("ldk", i64), ("u_bs", i64), ("ldu", i64),
+                ("key_mask", vp), ("out", vp), ("out_dtype", i32), ("_pad", i32), ("o_bs", i64), ("ldo", i64),
+                ("Nv", i64), ("Nm", i64), ("S", i64), ("D", i64), ("scale", f32), ("_pad2", i32), ("ws", vp)]
+
+
 class MadeWideAttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("Kadd", vp), ("V", vp), ("O", vp), ("key_mask", vp),
                 ("dtype", i32), ("o_dtype", i32),
@@ -234,6 +240,8 @@ SIGNATURES = {
     "made_gate_rows": (C.c_int, [vp, i32, i64, vp, i32, i64, i32, f32, vp, i64, i64, vp, i32, i64, vp, i64, i64, vp]),
     "made_xpool_fused": (C.c_int, [C.POINTER(MadeXpoolFusedArgs), vp]),
     "made_xpool_attention": (C.c_int, [C.POINTER(MadeXpoolAttnArgs), vp]),
+    "made_xpool_inbatch": (C.c_int, [C.POINTER(MadeXpoolInbatchArgs), vp]),
+    "made_xpool_inbatch_ws_bytes": (C.c_int64, [i64, i64]),
     "made_batch_order": (C.c_int, [vp, i64, i64, vp, vp]),
     "made_recall_ranks": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp]),
     "made_span_iou": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, vp]),

@@ -1001,7 +1001,9 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
         int64_t nb = (rows + 15) / 16;
         static const int nb_cap = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
         if (nb > nb_cap) nb = nb_cap;
-        DISPATCH_NVB(D, hipLaunchKernelGGL((layernorm_bwd_kernel<(NV > 4 ? 4 : NV), 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a));
+        // (D > 512: eight waves per workgroup -- with sixteen the 128-register budget of four waves per SIMD spilled 132 bytes)
+        if (nv_of(D) <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((layernorm_bwd_kernel<4, 8>), dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, a);
     } else {
         int64_t nb = (rows + 3) / 4;
         if (nb > 1024) nb = 1024;
@@ -1117,7 +1119,8 @@ extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, 
         int64_t nb = (rows + 15) / 16;
         static const int nb_cap = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
         if (nb > nb_cap) nb = nb_cap;
-        DISPATCH_NVB(D, hipLaunchKernelGGL((xpool_tail_bwd_kernel<(NV > 4 ? 4 : NV), 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a));
+        if (nv_of(D) <= 2) hipLaunchKernelGGL((xpool_tail_bwd_kernel<2, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((xpool_tail_bwd_kernel<4, 8>), dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, a);   // (as made_layernorm_bwd)
     } else {
         int64_t nb = (rows + 3) / 4;
         if (nb > 1024) nb = 1024;

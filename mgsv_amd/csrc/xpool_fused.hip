@@ -91,8 +91,6 @@ __device__ __forceinline__ float other_half(float x) {
 template <int DBG>
 __global__ __launch_bounds__(PT, 1) void xpool_fused_persist_kernel(const MadeXpoolFusedArgs a, const int* __restrict__ info, int tracks_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w4 = wave & 3;
     const bool linear_role = wave >= 4;

@@ -484,6 +484,7 @@ class MadeEngine:
         o2 = torch.empty(cm * Nv, D, device=dev, dtype=tc)
         o3 = torch.empty(cm * Nv, D, device=dev, dtype=tc)
         scale = 1.0 / math.sqrt(D)
+        xib_ws = None
         for m0 in range(0, Nm, cm):
             n = min(cm, Nm - m0)
             skip = seg_mask[m0:m0 + n].reshape(-1) if seg_mask is not None else None    # masked segments are never attended to
@@ -494,11 +495,18 @@ class MadeEngine:
             if hoist:
                 u = ops.linear(ubuf[:n * S], P[tower + ".out.w"], P[tower + ".out.b"], out=ubuf2[:n * S], tile_skip_mask=skip)
             # all videos attend to each track's segments: softmax over segments, scores never leave the chip
-            ops.attention_wide(q.view(1, Nv, 1, D), kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D),
-                               o[:n * Nv].view(n, Nv, 1, D), scale=scale,
-                               key_mask=seg_mask[m0:m0 + n] if seg_mask is not None else None, shared_q=True,
-                               n_split=1)       # (splitting the keys over workgroups + a merge launch is no faster here and costs the other stream CUs:
-                               # 1.2 % of the eval throughput with two batches in flight)
+            if tc == torch.bfloat16 and Nv <= 64 and S <= 512 and D in (256, 512) and os.environ.get("MADE_XPOOL_INBATCH", "1") != "0":
+                # the in-batch shape (round 4): scores per (track, 128 segments), P.V per (track, 128 columns), bf16 probabilities between them
+                if xib_ws is None:
+                    xib_ws = torch.empty(ops.xpool_inbatch_ws_bytes(cm, S), device=dev, dtype=torch.uint8)
+                ops.xpool_inbatch(q, kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D), seg_mask[m0:m0 + n] if seg_mask is not None else None,
+                                  o[:n * Nv].view(n, Nv, D), scale=scale, ws=xib_ws)
+            else:
+                ops.attention_wide(q.view(1, Nv, 1, D), kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D),
+                                   o[:n * Nv].view(n, Nv, 1, D), scale=scale,
+                                   key_mask=seg_mask[m0:m0 + n] if seg_mask is not None else None, shared_q=True,
+                                   n_split=1)   # (splitting the keys over workgroups + a merge launch is no faster here and costs the other stream CUs:
+                                   # 1.2 % of the eval throughput with two batches in flight)
             rows = n * Nv
             if hoist:
                 a2 = o[:rows]

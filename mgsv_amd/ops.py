@@ -662,6 +662,38 @@ def xpool_attention(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor],
     return out
 
 
+def xpool_inbatch_ws_bytes(Nm: int, S: int) -> int:
+    return int(lib().made_xpool_inbatch_ws_bytes(Nm, S))
+
+
+def xpool_inbatch(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], out: Tensor, scale: float, ws: Optional[Tensor] = None) -> Tensor:
+    """The in-batch X-Pool contraction (made_xpool_inbatch; reference modules/transformer.py:110-119): Q [Nv <= 64, D], K / U [Nm, S <= 512, D]
+    bf16 (unit inner stride), key_mask [Nm, S] or None -> out [Nm, Nv, D] bf16 or f32 = softmax_s(Q K^T * scale + mask) U.  Two launches:
+    scores per (track, 128 segments), then P.V per (track, 128 value columns); ws: xpool_inbatch_ws_bytes(Nm, S) bytes."""
+    from ._lib import MadeXpoolInbatchArgs
+    Nv, D = Q.shape
+    Nm, S, _ = K.shape
+    assert Q.dtype == K.dtype == U.dtype == torch.bfloat16 and Q.stride(1) == 1 and K.stride(2) == 1 and U.stride(2) == 1
+    assert U.shape == K.shape and out.dim() == 3 and tuple(out.shape) == (Nm, Nv, D) and out.stride(2) == 1
+    a = MadeXpoolInbatchArgs()
+    a.Q, a.ldq = _p(Q), Q.stride(0)
+    a.K, a.U, a.k_bs, a.ldk, a.u_bs, a.ldu = _p(K), _p(U), K.stride(0), K.stride(1), U.stride(0), U.stride(1)
+    a.key_mask = _p(_f32(key_mask.contiguous(), "key_mask")) if key_mask is not None else None
+    a.out, a.out_dtype, a.o_bs, a.ldo = _p(out), dt_of(out), out.stride(0), out.stride(1)
+    a.Nv, a.Nm, a.S, a.D, a.scale = Nv, Nm, S, D, scale
+    need = xpool_inbatch_ws_bytes(Nm, S)
+    if ws is None:
+        ws = torch.empty(need, device=Q.device, dtype=torch.uint8)
+    assert ws.is_contiguous() and ws.numel() * ws.element_size() >= need
+    a.ws = _p(ws)
+    desc = ""
+    if _timer is not None and key_mask is not None:             # executed work: the valid segments of each track only
+        desc = ("frac", float((key_mask != 0).sum().item()) / float(Nm * S))
+    _timed("xpool_inbatch", 4.0 * Nv * Nm * S * D, float(2 * (K.numel() + U.numel()) + out.element_size() * Nv * Nm * D + 2 * Q.numel()),
+           lambda: check(lib().made_xpool_inbatch(C.byref(a), _stream()), "made_xpool_inbatch"), desc)
+    return out
+
+
 def clip_loss(sims: Tensor, logit_scale: Tensor, loss_out: Tensor, weight: float = 1.0, accumulate: bool = False,
               row_exclude: Optional[Tensor] = None) -> Tensor:
     """Symmetric cross entropy of a square similarity matrix; row_exclude [n, n] f32 (1 = same-track negative left out of the

@@ -983,15 +983,26 @@ class MadeTrainer(MadeEngine):
         # 64 videos x 64 tracks: one workgroup per track would leave three quarters of the chip idle on a kernel that streams 1 MB of
         # K / U per track at one CU's rate -- the keys are split over workgroups (up to 256 of them), a second launch merges the slices
         # (tools/xpool_qk_bench.py, profiles/r03_xpool_qk_microbench.txt: 56.8 us unsplit, 34.9 us split four ways)
+        inbatch = (self.tc == torch.bfloat16 and B <= 64 and S <= 512 and D in (256, 512) and os.environ.get("MADE_XPOOL_INBATCH", "1") != "0")
+        if inbatch:
+            # round 4: scores per (track, 128 segments), then P.V per (track, 128 value columns) -- two launches of one workgroup per CU, only the
+            # bf16 probabilities between them (made_xpool_inbatch; profiles/r04_*xpool_qk_microbench.txt)
+            if tw.get(pre + "xib_ws") is None or tw[pre + "xib_ws"].numel() < ops.xpool_inbatch_ws_bytes(B, S):    # (one per tower: they may run on two streams)
+                tw[pre + "xib_ws"] = torch.empty(ops.xpool_inbatch_ws_bytes(B, S), device=self.device, dtype=torch.uint8)
+            ops.xpool_inbatch(q, tw[pre + "k"].view(B, S, D), tw[pre + "u"].view(B, S, D), seg_mask, tw[pre + "o"].view(B, B, D),
+                              scale=1.0 / math.sqrt(D), ws=tw[pre + "xib_ws"])
         xsplit = int(os.environ.get("MADE_XPOOL_NSPLIT", 0)) or (max(1, min(4, 256 // max(B, 1), S // 64)) if (B <= 64 and self.tc == torch.bfloat16) else 1)
-        if xsplit > 1:
+        if inbatch:
+            pass
+        elif xsplit > 1:
             need = B * xsplit * B
             if tw.get("xpart_o") is None or tw["xpart_o"].numel() < need * D:
                 tw["xpart_o"] = torch.empty(need * D, device=self.device, dtype=torch.float32)
                 tw["xpart_ml"] = torch.empty(need * 4, device=self.device, dtype=torch.float32)
-        ops.attention_wide(q.view(1, B, 1, D), tw[pre + "k"].view(B, S, D), tw[pre + "u"].view(B, S, D), tw[pre + "o"].view(B, B, 1, D),
-                           scale=1.0 / math.sqrt(D), key_mask=seg_mask, shared_q=True, n_split=xsplit,
-                           part_o=tw.get("xpart_o") if xsplit > 1 else None, part_ml=tw.get("xpart_ml") if xsplit > 1 else None)
+        if not inbatch:
+            ops.attention_wide(q.view(1, B, 1, D), tw[pre + "k"].view(B, S, D), tw[pre + "u"].view(B, S, D), tw[pre + "o"].view(B, B, 1, D),
+                               scale=1.0 / math.sqrt(D), key_mask=seg_mask, shared_q=True, n_split=xsplit,
+                               part_o=tw.get("xpart_o") if xsplit > 1 else None, part_ml=tw.get("xpart_ml") if xsplit > 1 else None)
         a2 = ops.linear(tw[pre + "o"], P[key + ".out.w"], P[key + ".out.b"], out=tw[pre + "a2"])
         a3 = ops.layernorm(a2, P[key + ".ln2.g"], P[key + ".ln2.b"], out=tw[pre + "a3"])
         # (the oracle / reference masks name the site after the block class, not the tower)

@@ -104,3 +104,53 @@ def test_backward_chain_of_the_recorded_step_is_bit_reproducible_with_the_retrie
                              for k, v in watch.items()))
     g.close()
     assert differing == 0, f"{differing} of 500 replays differ from the first"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["xpool_inbatch", "xpool_attention", "xpool_fused"])
+def test_retrieval_kernels_bit_identical_beside_small_workgroups(which):
+    """The retrieval kernels hand LDS reads to inline assembly (transposing reads, counted waits).  A register that such a read has been given is an
+    ordinary value to the compiler: if it copies it before the data has arrived the kernel is right alone on the chip and wrong beside another
+    kernel's workgroups on the same CU (round 4: the first made_xpool_inbatch, 10-30 % of the launches).  Each kernel 60 times beside a stream of
+    64-row Linears, bit-identical to its solo run."""
+    import math
+    from mgsv_amd import ops
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(0)
+    if which == "xpool_inbatch":
+        Nv, Nm, S, D = 64, 64, 512, 512
+    elif which == "xpool_attention":
+        Nv, Nm, S, D = 1024, 16, 512, 512
+    else:
+        Nv, Nm, S, D = 2048, 64, 96, 256
+    q = torch.randn(Nv, D, device=dev, generator=g).to(dt)
+    k, u = torch.randn(Nm, S, D, device=dev, generator=g).to(dt), torch.randn(Nm, S, D, device=dev, generator=g).to(dt)
+    lens = torch.randint(12, S + 1, (Nm,), device=dev, generator=g)
+    mask = (torch.arange(S, device=dev)[None] < lens[:, None]).float()
+    if which == "xpool_fused":
+        W = (torch.randn(D, D, device=dev, generator=g) / math.sqrt(D)).to(dt)
+        vec = lambda: torch.randn(D, device=dev, generator=g) * 0.1
+        ln2, ln3, bl = (1 + vec(), vec()), (1 + vec(), vec()), vec()
+        vn = torch.nn.functional.normalize(torch.randn(Nv, D, device=dev, generator=g), dim=-1)
+        shape, odt = (Nv, Nm), torch.float32
+        run = lambda o: ops.xpool_fused(q, k, u, mask, ln2, W, bl, ln3, vn, o, scale=1 / math.sqrt(D))
+    elif which == "xpool_attention":
+        shape, odt = (Nm, Nv, D), dt
+        run = lambda o: ops.xpool_attention(q, k, u, mask, o, scale=1 / math.sqrt(D))
+    else:
+        shape, odt = (Nm, Nv, D), dt
+        ws = torch.empty(ops.xpool_inbatch_ws_bytes(Nm, S), device=dev, dtype=torch.uint8)
+        run = lambda o: ops.xpool_inbatch(q, k, u, mask, o, scale=1 / math.sqrt(D), ws=ws)
+    solo = torch.empty(shape, device=dev, dtype=odt)
+    run(solo); torch.cuda.synchronize()
+    x1, W1 = torch.randn(64, 512, device=dev, generator=g).to(dt), torch.randn(512, 512, device=dev, generator=g).to(dt)
+    side = torch.cuda.Stream()
+    outs = [torch.empty(shape, device=dev, dtype=odt) for _ in range(60)]
+    for o in outs:
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                ops.linear(x1, W1)
+        run(o)
+    torch.cuda.synchronize()
+    differing = sum(0 if torch.equal(o.view(torch.int32 if odt == torch.float32 else torch.int16), solo.view(torch.int32 if odt == torch.float32 else torch.int16)) else 1 for o in outs)
+    assert differing == 0, f"{which}: {differing} of 60 launches differ from the solo run"

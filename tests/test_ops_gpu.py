@@ -425,6 +425,64 @@ def test_attention_wide(dev, mode, B, NQ1, NQ2, L, D, shared, kadd, alias):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Nv,Nm,S,D", [(64, 64, 512, 512), (64, 5, 96, 256), (37, 7, 130, 512), (1, 3, 33, 256), (50, 4, 512, 256), (64, 6, 400, 512)])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_xpool_inbatch_two_launches(dev, Nv, Nm, S, D, odt):
+    """made_xpool_inbatch (reference modules/transformer.py:110-119 for a batch of videos x a batch of tracks, one head of width D; the
+    north-star contraction): scores per (track, 128 segments) then P.V per (track, 128 columns), against a plain f32 softmax attention on
+    the bf16-rounded operands and against made_attention_wide on the same call.  Prefix masks of every length class, a mask with holes, rows
+    behind the last valid segment holding NaN, a late score spike, fewer than 64 videos, strided K / U (the two halves of one kv buffer)."""
+    tdt = torch.bfloat16
+    q = rnd(Nv, D, seed=1)
+    kv = rnd(Nm, S, 2 * D, seed=2)
+    lens = torch.tensor([max(1, S - (37 * i) % S) for i in range(Nm)])
+    mask = (torch.arange(S)[None] < lens[:, None]).float()
+    if Nm > 1 and S >= 8:
+        mask[1, ::3] = 0
+        mask[1, 1] = 1
+    kv[0, int(lens[0]) - 1, :D] = q[min(2, Nv - 1)] * 0.5                    # a late spike on track 0
+    k, u = kv[..., :D], kv[..., D:]
+    scale = 1.0 / math.sqrt(D)
+    sc = torch.einsum("nd,msd->mns", bf(q), bf(k)) * scale
+    sc = sc.masked_fill((mask == 0)[:, None, :], float("-inf"))
+    ref = torch.einsum("mns,msd->mnd", torch.softmax(sc, -1), bf(u))
+    kvd = kv.clone()
+    for m in range(Nm):                                                      # rows after the last valid segment may hold anything
+        last = int(mask[m].nonzero().max())
+        kvd[m, last + 1:] = float("nan")
+    kvg = kvd.to(dev).to(tdt)
+    out = torch.full((Nm, Nv, D), float("nan"), device=dev, dtype=odt)
+    ops.xpool_inbatch(q.to(dev).to(tdt), kvg[..., :D], kvg[..., D:], mask.to(dev), out, scale=scale)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert bool(torch.isfinite(got).all())
+    err = float((got - ref).abs().max())
+    assert err <= BF16_TOL, err
+    assert float((got - ref).abs().mean()) <= BF16_TOL / 8
+    # the kernel it replaces on this shape, same operands (its probabilities are f32 until the P.V product; ours are bf16: within the tolerance of both)
+    kz = torch.nan_to_num(kvg, nan=0.0)
+    o_w = torch.empty(Nm, Nv, 1, D, device=dev, dtype=odt)
+    ops.attention_wide(q.to(dev).to(tdt).view(1, Nv, 1, D), kz[..., :D], kz[..., D:], o_w, scale=scale, key_mask=mask.to(dev), shared_q=True)
+    torch.cuda.synchronize()
+    assert float((got - o_w.view(Nm, Nv, D).float().cpu()).abs().max()) <= 2 * BF16_TOL
+    # no mask at all
+    out2 = torch.empty_like(out)
+    kg = kv.to(dev).to(tdt)
+    ops.xpool_inbatch(q.to(dev).to(tdt), kg[..., :D], kg[..., D:], None, out2, scale=scale)
+    torch.cuda.synchronize()
+    ref2 = torch.einsum("mns,msd->mnd", torch.softmax(torch.einsum("nd,msd->mns", bf(q), bf(k)) * scale, -1), bf(u))
+    assert float((out2.float().cpu() - ref2).abs().max()) <= BF16_TOL
+    # a track without a valid segment: NaN rows for that track only (the reference's softmax over -inf), the others untouched
+    if Nm > 2:
+        m3 = mask.clone(); m3[2] = 0
+        out3 = torch.empty_like(out)
+        ops.xpool_inbatch(q.to(dev).to(tdt), kvg[..., :D], kvg[..., D:], m3.to(dev), out3, scale=scale)
+        torch.cuda.synchronize()
+        g3 = out3.float().cpu()
+        assert bool(torch.isnan(g3[2]).all()) and torch.equal(g3[:2], got[:2]) and torch.equal(g3[3:], got[3:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("Nv,Nm,S,D", [(64, 3, 40, 512), (100, 5, 130, 512), (320, 4, 512, 512), (192, 6, 96, 256), (70, 3, 512, 256), (129, 17, 33, 512)])
 @pytest.mark.parametrize("normalize", [True, False])
 def test_xpool_attention_two_pass(dev, Nv, Nm, S, D, normalize):

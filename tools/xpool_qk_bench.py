@@ -42,9 +42,28 @@ def run(Nv, Nm, S, D, splits):
                   f"{flops * frac / t / 1e6:7.1f} TFLOP/s ({flops * frac / t / 1e6 / 2500 * 100:4.1f}% of bf16 MFMA peak)", flush=True)
 
 
+def run_inbatch(Nv, Nm, S, D):
+    """made_xpool_inbatch (round 4): scores per (track, 128 segments), P.V per (track, 128 value columns) -- two launches, no f32 partials."""
+    q = torch.randn(Nv, D, device=dev).to(dt)
+    k, u = torch.randn(Nm, S, D, device=dev).to(dt), torch.randn(Nm, S, D, device=dev).to(dt)
+    lens = torch.randint(12, S + 1, (Nm,), device=dev)
+    o = torch.empty(Nm, Nv, D, device=dev, dtype=dt)
+    ws = torch.empty(ops.xpool_inbatch_ws_bytes(Nm, S), device=dev, dtype=torch.uint8)
+    flops = 4.0 * Nv * Nm * S * D
+    for name, mask in (("full-length tracks", None), ("ragged tracks (12..S segments)", (torch.arange(S, device=dev)[None] < lens[:, None]).float())):
+        frac = 1.0 if mask is None else float(mask.mean())
+        byts = 2.0 * Nm * S * D * 2 * frac + Nv * D * 2 + Nm * Nv * D * 2
+        t = timeit(lambda: ops.xpool_inbatch(q, k, u, mask, o, scale=1 / math.sqrt(D), ws=ws))
+        print(f"  Nv={Nv} Nm={Nm} S={S} D={D} {name:32s} made_xpool_inbatch (2 launches): "
+              f"{t:8.1f} us  {byts / t / 1e3:7.1f} GB/s ({byts / t / 1e3 / 8000 * 100:4.1f}% of HBM peak)  "
+              f"{flops * frac / t / 1e6:7.1f} TFLOP/s ({flops * frac / t / 1e6 / 2500 * 100:4.1f}% of bf16 MFMA peak)", flush=True)
+
+
 print("in-batch X-Pool attention core, the shape north_star names:")
+run_inbatch(64, 64, 512, 512)
 run(64, 64, 512, 512, (1, 2, 4, 8))
 print("the scripts' native shape:")
+run_inbatch(64, 64, 96, 256)
 run(64, 64, 96, 256, (1, 2, 4))
 print("retrieval scale (unfused attention core only; the product path is made_xpool_fused, tools/xpool_only.py):")
 run(4096, 128, 96, 256, (1,))
