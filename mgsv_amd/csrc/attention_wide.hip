@@ -531,7 +531,7 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
     MADE_REQUIRE(a.B >= 0 && a.NQ1 >= 0 && a.NQ2 > 0 && a.L > 0, "made_attention_wide: bad dims");
     MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention_wide: bad dtype %d", a.dtype);
     MADE_REQUIRE(a.o_dtype == MADE_F32 || a.o_dtype == MADE_BF16, "made_attention_wide: bad o_dtype %d", a.o_dtype);
-    MADE_UNSUPPORTED(a.D == 256 || a.D == 512, "made_attention_wide: D=%lld not in {256, 512}", (long long)a.D);
+    MADE_UNSUPPORTED(a.D == 128 || a.D == 256 || a.D == 512, "made_attention_wide: D=%lld not in {128, 256, 512}", (long long)a.D);
     MADE_UNSUPPORTED(a.B <= 65535, "made_attention_wide: B too large for the grid");
     const int per16 = a.dtype == MADE_F32 ? 4 : 8;
     MADE_UNSUPPORTED(a.q_bs % per16 == 0 && a.q_s1 % per16 == 0 && a.q_s2 % per16 == 0 && a.k_bs % per16 == 0 && a.ldk % per16 == 0 &&
@@ -552,6 +552,7 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
         // few query tiles per batch entry: latency-bound, use the two-stage (LDS-DMA) variant -- which cannot add Kadd on the way
         const bool few = nq <= 64 && a.Kadd == nullptr;
         const bool pair = nq > 32 && nq <= 64 && a.Kadd == nullptr;   // exactly two query tiles per entry (in-batch X-Pool at B = 64): one workgroup
+        if (a.D == 128) return launch_wide<bf16_t, 128, false, 4>(a, st);     // (narrow models: the register-staged variant only -- correct, not tuned)
         if (a.D == 512) {
             if (pair) return launch_wide<bf16_t, 512, true, 2>(a, st);
             return few ? launch_wide<bf16_t, 512, true, 4>(a, st) : launch_wide<bf16_t, 512, false, 4>(a, st);
@@ -559,5 +560,6 @@ extern "C" int made_attention_wide(const MadeWideAttnArgs* args, void* stream) {
         if (pair) return launch_wide<bf16_t, 256, true, 2>(a, st);
         return few ? launch_wide<bf16_t, 256, true, 4>(a, st) : launch_wide<bf16_t, 256, false, 4>(a, st);
     }
+    if (a.D == 128) return launch_wide<float, 128, false, 4>(a, st);
     return a.D == 512 ? launch_wide<float, 512, false, 4>(a, st) : launch_wide<float, 256, false, 4>(a, st);
 }

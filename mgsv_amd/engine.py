@@ -70,8 +70,8 @@ class MadeEngine:
             unsupported.append(f"vmr_loss={c.vmr_loss}")
         if c.detr_dec_layers < 1:
             unsupported.append("detr_dec_layers=0")
-        if c.D not in (256, 512):
-            unsupported.append(f"dim_input={c.D} (the wide-head attention kernel is built for 256 and 512)")
+        if c.D not in (128, 256, 512):
+            unsupported.append(f"dim_input={c.D} (the wide-head attention kernel is built for 128, 256 and 512)")
         if unsupported:
             raise NotImplementedError("MadeEngine (HIP path) does not cover yet: " + "; ".join(unsupported))
 

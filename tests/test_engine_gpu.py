@@ -34,7 +34,9 @@ def _cases():
     c5 = cfg_native(); c5.moment_query_type = "music"; c5.contrastive_align_loss = 0; c5.vmr_loss = "single"
     c6 = cfg_native(); c6.mml_fusion = "CA"
     c7 = cfg_native(); c7.fusion_mask = 0; c7.moment_query_type = "zero"; c7.aux_loss = 1
+    c8 = cfg_native(); c8.dim_input = 128; c8.SA_temporal_heads = 4; c8.detr_nheads = 4    # a narrow model (32-wide heads): the slow-but-correct widths
     return {
+        "narrow_D128_B4": (c8, 4, 50, 96),
         "native_CA_fusion_B4": (c6, 4, 50, 96),
         "native_nomask_zeroquery_B4": (c7, 4, 50, 96),
         "cfg1_B2": (cfg_plumbing(), 2, 30, 200),
@@ -178,15 +180,29 @@ def test_bf16_forward_within_stated_tolerance(name):
 
 
 def test_widths_the_wide_attention_kernel_is_not_built_for_fail_at_construction():
-    """--dim_input is a free flag, but made_attention_wide (X-Pool, memory-space decoder attention) is built for D = 256 / 512: any
+    """--dim_input is a free flag, but made_attention_wide (X-Pool, memory-space decoder attention) is built for D = 128 / 256 / 512: any
     other width raises when the engine is constructed, in either dtype -- never inside a launch (so made_dec_stage's own 256 / 512
-    limit, which _fused_decoder also checks, cannot be reached with an unsupported width)."""
-    for D in (128, 384, 768):
+    limit, which _fused_decoder also checks, cannot be reached with an unsupported width).  D = 128 runs (test_f32_forward_matches_oracle
+    [narrow_D128_B4], test_bf16_narrow_model_matches_oracle): the register-staged wide attention and the unfused decoder chain."""
+    for D in (384, 768):
         cfg = cfg_native()
         cfg.dim_input = D
         for dtype in ("bf16", "f32"):
             with pytest.raises(NotImplementedError, match="dim_input"):
                 MadeEngine(cfg, synth.make_state_dict(cfg, seed=0), dtype=dtype)
+
+
+def test_bf16_narrow_model_matches_oracle():
+    """dim_input = 128 (heads of 32) in bf16: the path without the D = 256 / 512 specialisations (fused decoder stages, LDS-DMA wide attention,
+    made_xpool_inbatch): forward within the bf16 tolerance of the f32 oracle."""
+    cfg = cfg_native(); cfg.dim_input = 128; cfg.SA_temporal_heads = 4; cfg.detr_nheads = 4
+    sd = synth.make_state_dict(cfg, seed=0)
+    inp = synth.make_inputs(cfg, 6, 50, 96, seed=1)
+    out = MadeEngine(cfg, sd, dtype="bf16").forward_numpy(inp)
+    ref = _oracle(cfg, sd, inp)
+    for k in ("video_feats", "music_feats", "sims_single", "sims_dual", "pred_spans"):
+        np.testing.assert_allclose(out[k], ref[k].numpy(), atol=3e-2, rtol=0, err_msg=k)
+    assert np.isfinite(out["retrieval_loss"]) and abs(out["retrieval_loss"] - float(ref["retrieval_loss"])) <= 5e-2 * max(1.0, abs(float(ref["retrieval_loss"])))
 
 
 def test_retrieval_matches_reference_golden_and_oracle(golden_dir):
