@@ -218,6 +218,20 @@ __global__ __launch_bounds__(ROW_THREADS) void sine_pe_kernel(const float* mask,
             for (int i = threadIdx.x * 4; i < D; i += ROW_THREADS * 4) {
                 const f32x4 dt = *(const f32x4*)(dim_t + i);
                 f32x4 v;
+                if (odt == MADE_BF16) {
+                    // bf16 output (the bf16 engine / trainer): the hardware sine / cosine on the angle in revolutions (|angle| <= 2 pi here;
+                    // their error is ~1e-6, three orders below a bf16 ulp) instead of libm's sincosf -- 56 -> ~10 us per step at the headline
+                    // shape.  The f32 path below keeps the exact arithmetic the parity mode is pinned with.
+                    const float xr = xe * 0.15915494309189535f;
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const float a0 = xr * __builtin_amdgcn_rcpf(dt[2 * pr]);
+                        v[2 * pr] = __builtin_amdgcn_sinf(a0);
+                        v[2 * pr + 1] = __builtin_amdgcn_cosf(dt[2 * pr] == dt[2 * pr + 1] ? a0 : xr * __builtin_amdgcn_rcpf(dt[2 * pr + 1]));
+                    }
+                    store4(out, odt, (b * L + t) * (int64_t)D + i, v);
+                    continue;
+                }
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     const float a0 = __fdiv_rn(xe, dt[2 * pr]);
