@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -239,6 +240,40 @@ def cpu_baseline_train(cfg, sd, inp, B: int = 16):
     return dict(value=round(B / dt, 3), unit="pairs/s", cores=n, cpu_model=_cpu_model(), kind="port",
                 sample=f"one train-mode forward + backward of the first {B} samples (oracle/made_oracle.py autograd, torch CPU f32, {n} threads; "
                        f"no optimizer step), {dt:.2f} s")
+
+
+def north_star_contraction(dev) -> dict:
+    """The contraction BASELINE.json's north_star names -- X-Pool QK^T over the segments, softmax, P.V at B = 64 videos x 64 tracks,
+    T_a = 512, d = 512, bf16 (reference modules/transformer.py:110-119) -- as the product path runs it (made_xpool_inbatch: two launches),
+    timed by hipGraph replay (the ctypes call's host cost stays out).  HBM-bound by construction (4.3 GFLOP against 67 MB of
+    K / U): `frac` is against the 8 TB/s HBM peak; the MFMA figure is there because north_star quotes one."""
+    Nv, Nm, S, D = 64, 64, 512, 512
+    g = torch.Generator(device=dev).manual_seed(3)
+    q = torch.randn(Nv, D, device=dev, generator=g).bfloat16()
+    k, u = torch.randn(Nm, S, D, device=dev, generator=g).bfloat16(), torch.randn(Nm, S, D, device=dev, generator=g).bfloat16()
+    o = torch.empty(Nm, Nv, D, device=dev, dtype=torch.bfloat16)
+    ws = torch.empty(ops.xpool_inbatch_ws_bytes(Nm, S), device=dev, dtype=torch.uint8)
+    run = lambda: ops.xpool_inbatch(q, k, u, None, o, scale=1.0 / math.sqrt(D), ws=ws)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(20):
+            run()
+    gr.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); gr.replay(); gr.replay(); e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 40 * 1e3
+    byts = 2.0 * Nm * S * D * 2 + Nv * D * 2 + Nm * Nv * D * 2
+    flops = 4.0 * Nv * Nm * S * D
+    return {"workload": f"X-Pool QK^T . softmax . PV, {Nv} videos x {Nm} tracks x {S} segments, d = {D}, bf16, full-length tracks",
+            "path": "made_xpool_inbatch (scores per track and 128 segments, then P.V per track and 128 value columns)",
+            "us_per_call": round(us, 2), "launches_per_call": 2,
+            "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / us / 1e3 / 8000.0, 4),
+                         "algorithmic_mb": round(byts / 1e6, 2)},
+            "mfma_tflops": round(flops / us / 1e6, 1), "mfma_frac_of_bf16_peak": round(flops / us / 1e6 / 2500.0, 4),
+            "measured": "hipGraph replay of 20 calls, HIP events around two replays"}
 
 
 # ------------------------------------------------------------------------------------------------- legs
@@ -619,6 +654,11 @@ def main():
         ev["note"] = ("f32_parity_mode is the mode whose logits / spans meet north_star's <= 1e-4 gate against the oracle and the reference goldens "
                       "(tests/test_engine_gpu.py); the bf16 modes are checked at 5e-2 (logits) / 2e-2 (spans)")
         line["eval_fwd"] = ev
+        if rank == 0 and world == 1:
+            try:
+                line["north_star_contraction"] = north_star_contraction(torch.device("cuda", local))
+            except Exception as ex:                  # report, do not hide
+                line["north_star_contraction"] = {"error": f"{type(ex).__name__}: {ex}"}
         line["metric"] = "video-music pairs/s fwd+bwd at B=64 (full training step); sub-objects: retrieval sim-matrix GB/s, eval forward pairs/s"
     if rank == 0:
         print(json.dumps(line))

@@ -495,7 +495,7 @@ class MadeEngine:
             if hoist:
                 u = ops.linear(ubuf[:n * S], P[tower + ".out.w"], P[tower + ".out.b"], out=ubuf2[:n * S], tile_skip_mask=skip)
             # all videos attend to each track's segments: softmax over segments, scores never leave the chip
-            if tc == torch.bfloat16 and Nv <= 64 and S <= 512 and D in (256, 512) and os.environ.get("MADE_XPOOL_INBATCH", "1") != "0":
+            if tc == torch.bfloat16 and Nv <= 64 and S <= 512 and S * D >= 65536 and D in (256, 512) and os.environ.get("MADE_XPOOL_INBATCH", "1") != "0":
                 # the in-batch shape (round 4): scores per (track, 128 segments), P.V per (track, 128 columns), bf16 probabilities between them
                 if xib_ws is None:
                     xib_ws = torch.empty(ops.xpool_inbatch_ws_bytes(cm, S), device=dev, dtype=torch.uint8)

@@ -985,7 +985,7 @@ class MadeTrainer(MadeEngine):
         # 64 videos x 64 tracks: one workgroup per track would leave three quarters of the chip idle on a kernel that streams 1 MB of
         # K / U per track at one CU's rate -- the keys are split over workgroups (up to 256 of them), a second launch merges the slices
         # (tools/xpool_qk_bench.py, profiles/r03_xpool_qk_microbench.txt: 56.8 us unsplit, 34.9 us split four ways)
-        inbatch = (self.tc == torch.bfloat16 and B <= 64 and S <= 512 and D in (256, 512) and os.environ.get("MADE_XPOOL_INBATCH", "1") != "0")
+        inbatch = (self.tc == torch.bfloat16 and B <= 64 and S <= 512 and S * D >= 65536 and D in (256, 512) and os.environ.get("MADE_XPOOL_INBATCH", "1") != "0")   # (shorter / narrower tracks: one launch of made_attention_wide is faster -- 10.9 vs 12.3 us at S = 96, D = 256)
         if inbatch:
             # round 4: scores per (track, 128 segments), then P.V per (track, 128 value columns) -- two launches of one workgroup per CU, only the
             # bf16 probabilities between them (made_xpool_inbatch; profiles/r04_*xpool_qk_microbench.txt)
