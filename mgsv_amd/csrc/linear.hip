@@ -555,7 +555,7 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 //            two 128-row workgroups each (a padded batch gathered down to its valid rows) -- with NST = 1 the only thing that
 //            hides a slab's latency is the OTHER workgroups of the CU, so twice as many, half as tall, run faster.
 template <int NST, bool TRAIN, int BMT>
-__global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : 4) : 1) void linear_glds_kernel(const MadeLinearArgs a) {
+__global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : (TRAIN ? 3 : 4)) : 1) void linear_glds_kernel(const MadeLinearArgs a) {   // (128-row tiles with the training epilogue: three per CU -- at four the 128-register budget spilled 56 bytes)
     constexpr int STAGE = (BMT + BN) * KB;
     constexpr int NT = BMT == 128 ? 2 : 1;                 // 32-column accumulator tiles per wave
     constexpr int AP = BMT / 32;                           // 1 KB A pieces per wave per slab
@@ -1499,7 +1499,8 @@ static int pick_variant(const MadeLinearArgs& a) {
     // 256 x 256 tiles when the tiles fill the chip at least twice over and nothing is gathered (the retrieval path's per-pair Linear),
     // 128 x 256 tiles on request (MADE_LINEAR_TILE=256; 512 forces the 256-row tiles).
     {
-        bool big_ok = a.batch == 1 && a.tile_skip_mask == nullptr && a.N <= BIG_NMAX && a.ldw % 8 == 0;
+        const bool train_like = a.gate != MADE_GATE_NONE || a.Zout != nullptr || a.drop.p > 0.f;
+        bool big_ok = a.batch == 1 && a.tile_skip_mask == nullptr && a.N <= BIG_NMAX && a.ldw % 8 == 0 && (!train_like || big_fast_epilogue(a));   // (training forms: the straight-line epilogue only)
         for (int s = 0; s < a.nseg; ++s) big_ok = big_ok && (a.seg[s].col_begin % BIG_BN == 0) && a.seg[s].out_z_stride == 0;
         if (big_ok) {
             if (tile_pref() == 512) return MADE_LINEAR_BIG256;
@@ -1632,10 +1633,8 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
             static const bool once = [] {
                 constexpr int l256 = 2 * (256 + BIG_BN) * KB + BIG_NMAX * 4, l128 = 2 * (128 + BIG_BN) * KB + BIG_NMAX * 4;
                 bool ok = true;
-                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l256) == hipSuccess;
                 ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l256) == hipSuccess;
                 ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l256) == hipSuccess;
-                ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
                 ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
                 ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l128) == hipSuccess;
                 ok = ok && hipFuncSetAttribute((const void*)linear_big_kernel<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l256) == hipSuccess;
@@ -1652,12 +1651,10 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
             const bool lite = fastep && (train || a.R != nullptr || a.out_row_mask != nullptr);   // the straight-line training epilogue
             if (b256) {
                 if (lite) hipLaunchKernelGGL((linear_big_kernel<256, true, true>), gb, bb, ldsb, st, a);
-                else if (train) hipLaunchKernelGGL((linear_big_kernel<256, true, false>), gb, bb, ldsb, st, a);
                 else if (fastep) hipLaunchKernelGGL((linear_big_kernel<256, false, true>), gb, bb, ldsb, st, a);
                 else hipLaunchKernelGGL((linear_big_kernel<256, false, false>), gb, bb, ldsb, st, a);
             } else {
                 if (lite) hipLaunchKernelGGL((linear_big_kernel<128, true, true>), gb, bb, ldsb, st, a);
-                else if (train) hipLaunchKernelGGL((linear_big_kernel<128, true, false>), gb, bb, ldsb, st, a);
                 else if (fastep) hipLaunchKernelGGL((linear_big_kernel<128, false, true>), gb, bb, ldsb, st, a);
                 else hipLaunchKernelGGL((linear_big_kernel<128, false, false>), gb, bb, ldsb, st, a);
             }
