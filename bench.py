@@ -115,6 +115,10 @@ def _roofline(summ: dict, kind: str, dtype: str, per: int, leg: str, overhead_us
     t_mfma = d["flops"] / (peak * 1e12)
     t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
     traffic = rocprof_us = None
+    # the committed rocprofv3 / PMC files hold the bf16 legs (tools/profile_round4.sh): another dtype (the f32 parity legs) or another sequence
+    # length than the leg's default has no committed entry -- its launches of the same kernel kind are other problems
+    if dtype != "bf16":
+        leg = leg + "_" + dtype
     if os.path.isfile(PMC_FILE):
         try:
             traffic = json.load(open(PMC_FILE)).get(leg, {}).get(kind, {}).get("hbm_bytes_per_launch")
@@ -475,7 +479,7 @@ def train_leg(args, rank, world, local, dist, steps: int, warmup: int) -> dict:
         summ = kt.summary()
         per_kernel = _per_kernel(summ, 2)
         dom = _dominant(summ)
-        roof = _roofline(summ, dom, args.dtype, 2, "train", _event_pair_overhead_us())
+        roof = _roofline(summ, dom, args.dtype, 2, "train" if not args.ta else f"train_ta{args.ta}", _event_pair_overhead_us())
         mm = [k for k in summ if k.startswith("linear_") or k == "made_gemm_tn"]
         fl, ms_ = sum(summ[k]["flops"] for k in mm), sum(summ[k]["ms"] for k in mm)
         roof["all_gemms_of_the_step"] = dict(tflops=round(fl / (ms_ * 1e-3) / 1e12, 2), frac=round(fl / (ms_ * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
