@@ -185,8 +185,10 @@ enum MadeLinearVariant {
     MADE_LINEAR_BIG256 = 8,         /* linear_big_kernel<256>: persistent, 256 x 256 tiles, two LDS stages, register epilogue (round 4; the
                                        slot was round 2's ring kernel, removed) */
     MADE_LINEAR_TINY16 = 9,         /* linear_t16_kernel: at most 64 rows, 16 x 16 tiles (a third of the bytes per workgroup), 128 <= K <= 1024 */
-    MADE_LINEAR_BIG128 = 10         /* linear_big_kernel<128>: the same with 128 x 256 tiles (MADE_LINEAR_TILE=256; the slot was round 3's
+    MADE_LINEAR_BIG128 = 10,        /* linear_big_kernel<128>: the same with 128 x 256 tiles (MADE_LINEAR_TILE=256; the slot was round 3's
                                        W-stationary kernel, removed) */
+    MADE_LINEAR_GLDS64_F32 = 11,    /* linear_glds_kernel<1, ., 64, float>: the f32 parity mode's large Linears on the LDS-DMA loop (exact-f32 MFMA) */
+    MADE_LINEAR_GLDS128_F32 = 12    /* linear_glds_kernel<1, ., 128, float> */
 };
 int made_linear_variant(const MadeLinearArgs* args);
 

@@ -554,8 +554,11 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 //            round 3: 5.185 -> 5.145 ms per training step, A/B of the two builds on one box): for grids that would leave the CUs with only one or
 //            two 128-row workgroups each (a padded batch gathered down to its valid rows) -- with NST = 1 the only thing that
 //            hides a slab's latency is the OTHER workgroups of the CU, so twice as many, half as tall, run faster.
-template <int NST, bool TRAIN, int BMT>
+template <int NST, bool TRAIN, int BMT, typename TC = bf16_t>
 __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : (TRAIN ? 3 : 4)) : 1) void linear_glds_kernel(const MadeLinearArgs a) {   // (128-row tiles with the training epilogue: three per CU -- at four the 128-register budget spilled 56 bytes)
+    // TC = float (round 4): the f32 parity mode's large Linears on the same loop -- a 128-byte slab row is 32 f32, a 16-byte fragment four
+    // consecutive k of which v_mfma_f32_32x32x2_f32 takes one per instruction (the same k from both operands, so any k order is a valid sum)
+    constexpr int PER16 = 16 / (int)sizeof(TC), KE = KB / (int)sizeof(TC);
     constexpr int STAGE = (BMT + BN) * KB;
     constexpr int NT = BMT == 128 ? 2 : 1;                 // 32-column accumulator tiles per wave
     constexpr int AP = BMT / 32;                           // 1 KB A pieces per wave per slab
@@ -617,25 +620,25 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : (TRAIN ? 3 : 
 
     // ---- per-lane source pointers: wave w issues 1 KB pieces j = 4w+i (i = 0..3) of A and of W; piece j = rows
     // 8j..8j+7; lane l -> row 8j + l/8, LDS slot l%8 holding global chunk (l%8) ^ swz(row)
-    const bf16_t* Abase = ((seg.use_a2 && a.A2 && a.a2_replace) ? (const bf16_t*)a.A2 : (const bf16_t*)a.A) + z * a.a_z_stride;
+    const TC* Abase = ((seg.use_a2 && a.A2 && a.a2_replace) ? (const TC*)a.A2 : (const TC*)a.A) + z * a.a_z_stride;
     const int64_t lda = (seg.use_a2 && a.A2 && a.a2_replace) ? a.lda2 : a.lda;
-    const bf16_t* Wbase = (const bf16_t*)a.W + z * a.w_z_stride;
-    const bf16_t* pa[AP];
-    const bf16_t* pw[4];
+    const TC* Wbase = (const TC*)a.W + z * a.w_z_stride;
+    const TC* pa[AP];
+    const TC* pw[4];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int row = 8 * (AP * wave + i) + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(row);
         int gm = m0 + row; gm = gm < Mv ? gm : Mv - 1;        // rows past the edge are fetched from a valid row and never stored
         if (a.row_index) gm = a.row_index[gm];
-        pa[i] = Abase + (int64_t)gm * lda + chunk * 8;
+        pa[i] = Abase + (int64_t)gm * lda + chunk * PER16;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * (4 * wave + i) + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(row);
         int gn = n0 + row; gn = gn < N ? gn : N - 1;
-        pw[i] = Wbase + (int64_t)gn * a.ldw + chunk * 8;
+        pw[i] = Wbase + (int64_t)gn * a.ldw + chunk * PER16;
     }
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -661,16 +664,35 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : (TRAIN ? 3 : 
         offw[t] = BMT * KB + rw * KB; sw[t] = swz(rw);
     }
 
-    const int nk = K / 64;
+    const int nk = K / KE;
     auto issue = [&](int kt, unsigned char* st) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < AP; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * 64), (lds_ptr_t)(st + (AP * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + kt * KE), (lds_ptr_t)(st + (AP * wave + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * 64), (lds_ptr_t)(st + BMT * KB + (4 * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * KE), (lds_ptr_t)(st + BMT * KB + (4 * wave + i) * 1024), 16, 0, 0);
     };
     auto multiply = [&](const unsigned char* st) __attribute__((always_inline)) {
+        if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                f32x4 fa[2], fw[NT];
+                const int c = 2 * kq + hh;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fa[t] = *(const f32x4*)(st + offa[t] + ((c ^ sa[t]) << 4));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fw[t] = *(const f32x4*)(st + offw[t] + ((c ^ sw[t]) << 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][j], fw[nt][j], acc[mt][nt], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 fa[2], fw[NT];
@@ -1451,6 +1473,11 @@ static int tile_pref() {                                   // read on every call
     return e ? atoi(e) : 0;
 }
 
+static int64_t f32_glds_min() {                            // least number of 64 x 128 tiles for the f32 LDS-DMA kernel (MADE_LINEAR_F32_GLDS_MIN: knob for measurements)
+    const char* e = getenv("MADE_LINEAR_F32_GLDS_MIN");
+    return e ? (int64_t)atoll(e) : 1;                      // measured (f32 training step): 32 -> 27.8 ms, 8 -> 25.4 ms, 1 -> 19.5 ms (the general kernel: 35.2 ms)
+}
+
 static int64_t big_train_min() {                           // read on every call (A/B inside one process)
     const char* e = getenv("MADE_LINEAR_BIG_TRAIN");
     return e ? (int64_t)atoll(e) : 0;
@@ -1477,7 +1504,24 @@ static bool big_fast_epilogue(const MadeLinearArgs& a) {
 
 // which kernel made_linear runs for these arguments (one place: the launcher and made_linear_variant both ask here)
 static int pick_variant(const MadeLinearArgs& a) {
-    if (a.w_dtype != MADE_BF16) return MADE_LINEAR_GENERAL_F32;
+    if (a.w_dtype != MADE_BF16) {
+        // f32 weights (the parity mode).  Its large launches take the LDS-DMA loop (round 4: the register-staged general kernel ran them at
+        // 0.11 of the f32 MFMA peak); anything with an option that loop does not serve, and every small problem, stays on the general kernel.
+        bool fast = a.a_dtype == MADE_F32 && a.K % 32 == 0 && a.a_row_mask == nullptr && a.split_k <= 1 && (a.A2 == nullptr || a.a2_replace) &&
+                    ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && a.bias_row_scale == nullptr &&
+                    getenv("MADE_LINEAR_F32_GLDS_OFF") == nullptr;
+        for (int s = 0; s < a.nseg; ++s) fast = fast && !a.seg[s].transposed;
+        if (a.A2 && a.a2_replace) fast = fast && (a.a2_row_mod == 0) && (a.lda2 % 4 == 0) && ((uintptr_t)a.A2 % 16 == 0);
+        if (a.batch > 1) fast = fast && (a.a_z_stride % 4 == 0) && (a.w_z_stride % 4 == 0);
+        const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+        const int64_t tiles64 = ((a.M + 63) / 64) * ((a.N + BN - 1) / BN);
+        if (fast && tiles64 * a.batch >= f32_glds_min()) {    // (every such launch: even the decoder chain's four-workgroup problems run three times
+            // faster on the LDS-DMA loop than on the register-staged 128 x 128 tiles)
+            const int64_t live = a.row_index ? (tiles * a.batch * 9) / 16 : tiles * a.batch;
+            return live > 1280 ? MADE_LINEAR_GLDS128_F32 : MADE_LINEAR_GLDS64_F32;
+        }
+        return MADE_LINEAR_GENERAL_F32;
+    }
     bool fast = a.a_dtype == MADE_BF16 && a.K % 64 == 0 && a.a_row_mask == nullptr && a.split_k <= 1 &&
                 (a.A2 == nullptr || a.a2_replace) && ((uintptr_t)a.A % 16 == 0) && (a.lda % 8 == 0);
     for (int s = 0; s < a.nseg; ++s) fast = fast && !a.seg[s].transposed;
@@ -1623,6 +1667,16 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
         case MADE_LINEAR_GLDS128:
             if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128>), grid, block, 0, st, a);
+            break;
+        case MADE_LINEAR_GLDS64_F32: {
+            dim3 g((unsigned)(((a.M + 63) / 64) * ((a.N + BN - 1) / BN)), 1, (unsigned)a.batch);
+            if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 64, float>), g, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_glds_kernel<1, false, 64, float>), g, block, 0, st, a);
+            break;
+        }
+        case MADE_LINEAR_GLDS128_F32:
+            if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128, float>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128, float>), grid, block, 0, st, a);
             break;
         case MADE_LINEAR_BIG256:
         case MADE_LINEAR_BIG128: {                         // persistent: one workgroup per CU (a multiple of 8: one eighth per XCD)

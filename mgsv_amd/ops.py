@@ -151,7 +151,8 @@ class Seg:
 # made_linear_variant codes (include/made_hip.h: MadeLinearVariant) -> KernelTimer kinds = rocprofv3 kernel symbols
 LINEAR_VARIANTS = {0: "linear_f32", 1: "linear_f32in_bf16", 2: "linear_kernel<bf16,bf16>", 3: "linear_tiny_kernel", 4: "linear_skinny_kernel",
                    5: "linear_glds_kernel<3,.,128>", 6: "linear_glds_kernel<1,.,64>", 7: "linear_glds_kernel<1,.,128>",
-                   8: "linear_big_kernel<256>", 9: "linear_t16_kernel", 10: "linear_big_kernel<128>"}
+                   8: "linear_big_kernel<256>", 9: "linear_t16_kernel", 10: "linear_big_kernel<128>",
+                   11: "linear_glds_f32<64>", 12: "linear_glds_f32<128>"}
 
 
 LINEAR_LOG = None                                             # a list: every linear() call appends its form (tools/linear_calls.py)
@@ -221,11 +222,13 @@ def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, out: Optional
     kind = "linear_" + ("f32" if a.w_dtype == F32 else ("bf16" if a.a_dtype == BF16 else "f32in_bf16"))
     if _timer is not None and kind == "linear_bf16":          # timed runs label the launch with the kernel it dispatches to
         kind = LINEAR_VARIANTS[lib().made_linear_variant(C.byref(a))]
+    elif _timer is not None and kind == "linear_f32" and lib().made_linear_variant(C.byref(a)) >= 11:
+        kind = LINEAR_VARIANTS[lib().made_linear_variant(C.byref(a))]
     flops = 2.0 * M * N * K * batch
     nbytes = batch * (M * K * (4 if a.a_dtype == F32 else 2) + N * K * esz + M * N * esz)
     desc = f"M={M} N={N} K={K} z={batch} nseg={len(segs)} a2={int(A2 is not None)} R={int(R is not None)} act={act} tr={int(any(s_.transposed for s_ in segs))}"
     if LINEAR_LOG is not None:                                # (tools/linear_calls.py: which forms of made_linear a step uses)
-        LINEAR_LOG.append((LINEAR_VARIANTS.get(lib().made_linear_variant(C.byref(a)), "?") if kind == "linear_bf16" else kind, M, N, K, batch,
+        LINEAR_LOG.append((LINEAR_VARIANTS.get(lib().made_linear_variant(C.byref(a)), "?") if kind in ("linear_bf16", "linear_f32") else kind, M, N, K, batch,
                            f"nseg={len(segs)} a2={int(A2 is not None)}/{int(bool(a2_replace))} R={None if R is None else str(R.dtype)[6:]}/{r_row_mod} act={act} gate={gate} "
                            f"G={None if G is None else str(G.dtype)[6:]} Z={None if Zout is None else str(Zout.dtype)[6:]} "
                            f"drop={0 if drop is None else drop[2]}/{drop_col_div} rows={int(rows is not None)} orm={int(out_row_mask is not None)} "
