@@ -380,6 +380,16 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     const float* maskg = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
     const bool key_valid = key < a.Lk && (maskg == nullptr || maskg[keyc] != 0.f);
     const float bias_key = key_valid ? 0.f : -INFINITY;
+    if (!__syncthreads_or(key_valid ? 1 : 0)) {
+        // every key of this workgroup is padding (a ragged batch: about 40 % of the key blocks at the step's shapes): its dK / dV rows are zeros,
+        // and the query tiles need not be walked at all
+        if (key < a.Lk) {
+            TC* kz = (TC*)a.dK + b * a.dk_bs + key * a.lddk + h * HD;
+            TC* vz = (TC*)a.dV + b * a.dv_bs + key * a.lddv + h * HD;
+            for (int d = hh; d < HD; d += 2) { kz[d] = (TC)0.f; vz[d] = (TC)0.f; }
+        }
+        return;
+    }
 
     // K / V fragments of this lane's key (B operands): K[key][ks*2*PER16 + hh*PER16 ..]; invalid keys read as zero rows
     frag_t kf[NQF], vf[NQF];
