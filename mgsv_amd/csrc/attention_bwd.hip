@@ -517,6 +517,28 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
             // s <- Pd (dropped probabilities), dp <- dS
             if constexpr (IS_BF16) {
                 const float c2 = a.scale * 1.4426950408889634f;
+                if (use_bits) {
+                    // The keep-bit path as ONE straight-line block (round 4).  With the path chosen per element (the loop below: `if (use_bits) ..
+                    // else if (p > 0) ..` inside the unrolled loop) every score was a basic block of its own: its FMA -> exp2 -> select -> FMA
+                    // chain ran alone, 125 cycles per score (2 000 per half; the dQ kernel, whose paths are separate loops, needs 50).  Here the
+                    // sixteen chains of a half interleave.  The arithmetic is the loop's, operation for operation: the same bits.
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const f32x4 nl4 = *(const f32x4*)(lds_lse + qi * 32 + 8 * e4 + 4 * hh);
+                        const f32x4 dl4 = *(const f32x4*)(lds_delta + qi * 32 + 8 * e4 + 4 * hh);
+                        const u32x4 bw4 = *(const u32x4*)(lds_bits + wave * BQT + qi * 32 + 8 * e4 + 4 * hh);
+#pragma unroll
+                        for (int ej = 0; ej < 4; ++ej) {
+                            const int e = 4 * e4 + ej;
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c2, nl4[ej]) + bias_key);
+                            const bool keep = (bw4[ej] >> r) & 1u;
+                            const float pd = keep ? p * dsc : 0.f;
+                            const float g = keep ? dp[e] * dsc : 0.f;
+                            s[e] = pd;
+                            dp[e] = p * __builtin_fmaf(g, a.scale, -dl4[ej]);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     // the 4 accumulator rows of a register quad are consecutive queries: one 16-byte LDS read each for -lse and delta
@@ -544,6 +566,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                         s[e] = pd;
                         dp[e] = p * __builtin_fmaf(g, a.scale, -dl4[ej]);
                     }
+                }
                 }
             } else {
 #pragma unroll
