@@ -1473,6 +1473,11 @@ static int tile_pref() {                                   // read on every call
     return e ? atoi(e) : 0;
 }
 
+static int64_t tiny_max() {                                // most 64 x 32 tiles for which the fragments-from-global kernel is chosen (MADE_TINY_MAX: knob for measurements)
+    const char* e = getenv("MADE_TINY_MAX");
+    return e ? (int64_t)atoll(e) : 1024;
+}
+
 static int64_t f32_glds_min() {                            // least number of 64 x 128 tiles for the f32 LDS-DMA kernel (MADE_LINEAR_F32_GLDS_MIN: knob for measurements)
     const char* e = getenv("MADE_LINEAR_F32_GLDS_MIN");
     return e ? (int64_t)atoll(e) : 1;                      // measured (f32 training step): 32 -> 27.8 ms, 8 -> 25.4 ms, 1 -> 19.5 ms (the general kernel: 35.2 ms)
@@ -1536,7 +1541,7 @@ static int pick_variant(const MadeLinearArgs& a) {
     if (a.M <= 64 && a.K >= 128 && a.K <= 1024 && a.K % 32 == 0 && a.tile_skip_mask == nullptr && tile_pref() != 1 && tile_pref() != 32 &&
         ((a.M + 15) / 16) * ((a.N + 15) / 16) * a.batch <= t16_max())
         return MADE_LINEAR_TINY16;
-    if (tiles32 * a.batch <= 1024 && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) return MADE_LINEAR_TINY;
+    if (tiles32 * a.batch <= tiny_max() && a.K <= 1024 && a.tile_skip_mask == nullptr && tile_pref() != 1) return MADE_LINEAR_TINY;
     if (tiles64 * a.batch <= 256 && a.tile_skip_mask == nullptr) return MADE_LINEAR_SKINNY;
     if (tiles * a.batch <= 256) return MADE_LINEAR_GLDS3;                  // at most one workgroup per CU
     // Persistent big-tile kernel (round 4; the ring / W-stationary kernels of rounds 2-3 lost inside the step and were removed):
