@@ -515,6 +515,34 @@ typedef struct MadeXpoolAttnArgs {
 
 int made_xpool_attention(const MadeXpoolAttnArgs* args, void* stream);
 
+/* made_xpool_sims: all-pairs X-Pool scoring with the per-pair Linear moved onto the values (round 4; D = 256, S <= 512).  The chain of
+ * reference modules/transformer.py:156-180 + modules/metrics.py:10-24 after the attention is
+ *   y = W'' xhat + b'',  xhat = (o - mean(o)) rstd(o),  W'' = (W + I) diag(g2), b'' = (W + I) b2 + b          (LayerNorm2 + Linear + residual)
+ * and o = sum_s p_s u_s is a convex combination of the track's value rows, so W'' o = sum_s p_s (W'' u_s): with u''_s = W'' u_s made ONCE per
+ * segment by a GEMM over the tracks (the caller: columns [D, 2D) of the value rows), the per-pair 2 D^2 flops of the Linear become a second
+ * P.V product of 2 S D flops, and   y = k1 (P.U'') + k2 Bv + Av,   k1 = rstd(o), k2 = -mean(o) rstd(o), Av = b'', Bv = W'' 1.
+ * LayerNorm3 and the cosine with the video are the six sums of made_xpool_fused; nothing per pair is written but sims[n * ld_sims + m].
+ * Q [Nv, D] bf16; K [Nm, S, D] bf16 (rows at m * k_bs + s * ldk); UU [Nm, S, 2 D] bf16 (rows at m * u_bs + s * ldu: u_s | u''_s);
+ * key_mask [Nm, S] f32 or NULL; av, bv, ln3_g, ln3_b [D] f32; vn = video / |video| [Nv, D] f32; ws: made_xpool_sims_ws_bytes(Nv, Nm, D)
+ * bytes, 16-byte aligned (per-video terms of LayerNorm3 + cosine, filled when prepare_ws != 0; 32 ints per track, rebuilt by every call).
+ * A track without a valid segment gives NaN, like the reference's softmax over -inf. */
+typedef struct MadeXpoolSimsArgs {
+    const void* Q; int64_t ldq;
+    const void* K; const void* UU; int64_t k_bs, ldk, u_bs, ldu;
+    const float* key_mask;
+    const float* av; const float* bv;
+    const float* ln3_g; const float* ln3_b;
+    const float* vn; int64_t ldvn;
+    float* sims; int64_t ld_sims;
+    int64_t Nv, Nm, S, D;
+    float scale, eps;
+    void* ws;
+    int32_t prepare_ws; int32_t _pad;
+} MadeXpoolSimsArgs;
+
+int     made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream);
+int64_t made_xpool_sims_ws_bytes(int64_t Nv, int64_t Nm, int64_t D);
+
 /* made_xpool_inbatch: the in-batch X-Pool contraction for a batch of at most 64 videos -- out[m, n, :] = softmax_s(scale q_n . k_{m,s} + mask) U_m
  * (reference modules/transformer.py:110-119, out projection hoisted onto the values; the north-star contraction).  Two launches of one
  * workgroup per CU -- scores per (track, 128 segments) with the tile-local softmax pieces, then P.V per (track, 128 value columns) -- with only

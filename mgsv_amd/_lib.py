@@ -116,6 +116,13 @@ class MadeXpoolAttnArgs(C.Structure):
                 ("scale", f32), ("eps", f32), ("normalize", i32), ("_pad", i32), ("ws", vp)]
 
 
+class MadeXpoolSimsArgs(C.Structure):
+    _fields_ = [("Q", vp), ("ldq", i64), ("K", vp), ("UU", vp), ("k_bs", i64), ("ldk", i64), ("u_bs", i64), ("ldu", i64),
+                ("key_mask", vp), ("av", vp), ("bv", vp), ("ln3_g", vp), ("ln3_b", vp), ("vn", vp), ("ldvn", i64),
+                ("sims", vp), ("ld_sims", i64), ("Nv", i64), ("Nm", i64), ("S", i64), ("D", i64),
+                ("scale", f32), ("eps", f32), ("ws", vp), ("prepare_ws", i32), ("_pad", i32)]
+
+
 class MadeXpoolInbatchArgs(C.Structure):
     _fields_ = [("Q", vp), ("ldq", i64), ("K", vp), ("U", vp), ("k_bs", i64), ("ldk", i64), ("u_bs", i64), ("ldu", i64),
                 ("key_mask", vp), ("out", vp), ("out_dtype", i32), ("_pad", i32), ("o_bs", i64), ("ldo", i64),
@@ -240,6 +247,8 @@ SIGNATURES = {
     "made_gate_rows": (C.c_int, [vp, i32, i64, vp, i32, i64, i32, f32, vp, i64, i64, vp, i32, i64, vp, i64, i64, vp]),
     "made_xpool_fused": (C.c_int, [C.POINTER(MadeXpoolFusedArgs), vp]),
     "made_xpool_attention": (C.c_int, [C.POINTER(MadeXpoolAttnArgs), vp]),
+    "made_xpool_sims": (C.c_int, [C.POINTER(MadeXpoolSimsArgs), vp]),
+    "made_xpool_sims_ws_bytes": (C.c_int64, [i64, i64, i64]),
     "made_xpool_inbatch": (C.c_int, [C.POINTER(MadeXpoolInbatchArgs), vp]),
     "made_xpool_inbatch_ws_bytes": (C.c_int64, [i64, i64]),
     "made_batch_order": (C.c_int, [vp, i64, i64, vp, vp]),

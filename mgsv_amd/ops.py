@@ -636,6 +636,47 @@ def xpool_fused(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], ln2
     return sims
 
 
+def xpool_sims_ws_bytes(Nv: int, Nm: int, D: int = 256) -> int:
+    """Workspace of made_xpool_sims in bytes: per-video LayerNorm3 / cosine terms and 32 ints per track."""
+    return int(lib().made_xpool_sims_ws_bytes(Nv, Nm, D))
+
+
+def xpool_sims(Q: Tensor, K: Tensor, UU: Tensor, key_mask: Optional[Tensor], av: Tensor, bv: Tensor, ln3, vn: Tensor, sims: Tensor, scale: float,
+               eps: float = 1e-5, ws: Optional[Tensor] = None, prepare_ws: bool = True) -> Tensor:
+    """All-pairs X-Pool scoring with the per-pair Linear moved onto the values (made_xpool_sims; bf16, D = 256, S <= 512): Q [Nv, D],
+    K [Nm, S, D], UU [Nm, S, 2 D] = value rows u_s | W'' u_s (unit inner stride), key_mask [Nm, S] or None, av = b'' and bv = W'' 1 [D] f32,
+    ln3 = (gamma, beta) f32, vn [Nv, D] f32 (L2-normalised videos) -> sims[n, m] written into `sims` ([Nv, >= Nm] f32 view)."""
+    from ._lib import MadeXpoolSimsArgs
+    Nv, D = Q.shape
+    Nm, S, _ = K.shape
+    assert Q.dtype == K.dtype == UU.dtype == torch.bfloat16 and Q.stride(1) == 1 and K.stride(2) == 1 and UU.stride(2) == 1
+    assert UU.shape == (Nm, S, 2 * D) and vn.shape == (Nv, D) and vn.dtype == torch.float32 and av.shape == (D,) and bv.shape == (D,)
+    assert sims.dtype == torch.float32 and sims.stride(1) == 1 and sims.shape[0] == Nv and sims.shape[1] >= Nm
+    a = MadeXpoolSimsArgs()
+    a.Q, a.ldq = _p(Q), Q.stride(0)
+    a.K, a.UU, a.k_bs, a.ldk, a.u_bs, a.ldu = _p(K), _p(UU), K.stride(0), K.stride(1), UU.stride(0), UU.stride(1)
+    a.key_mask = _p(_f32(key_mask.contiguous(), "key_mask")) if key_mask is not None else None
+    a.av, a.bv = _p(_f32(av, "av")), _p(_f32(bv, "bv"))
+    a.ln3_g, a.ln3_b = _p(_f32(ln3[0], "ln3")), _p(_f32(ln3[1], "ln3"))
+    a.vn, a.ldvn = _p(vn), vn.stride(0)
+    a.sims, a.ld_sims = _p(sims), sims.stride(0)
+    a.Nv, a.Nm, a.S, a.D, a.scale, a.eps = Nv, Nm, S, D, scale, eps
+    need = int(lib().made_xpool_sims_ws_bytes(Nv, Nm, D))
+    if ws is None:
+        ws = torch.empty(need, device=Q.device, dtype=torch.uint8)
+        prepare_ws = True
+    assert ws.is_contiguous() and ws.numel() * ws.element_size() >= need
+    a.ws, a.prepare_ws = _p(ws), 1 if prepare_ws else 0
+    flops = 2.0 * Nv * Nm * (2 * S * D + D * D)                    # the reference's work per pair (the kernel executes 3 S D per pair)
+    desc = ""
+    if _timer is not None and key_mask is not None:
+        valid = float((key_mask != 0).sum().item())
+        desc = ("frac", (2.0 * Nv * (2 * valid * D + Nm * D * D)) / flops)
+    _timed("xpool_sims", flops, float(2 * (K.numel() + UU.numel()) + 4 * Nv * Nm + 2 * Q.numel()),
+           lambda: check(lib().made_xpool_sims(C.byref(a), _stream()), "made_xpool_sims"), desc)
+    return sims
+
+
 def xpool_attention(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], out: Tensor, scale: float, normalize: bool = True,
                     eps: float = 1e-5, ws: Optional[Tensor] = None) -> Tensor:
     """The X-Pool attention at retrieval scale, head dim = D = 256 or 512, S <= 512 (made_xpool_attention): Q [Nv, D], K / U [Nm, S, D]

@@ -107,7 +107,7 @@ def test_backward_chain_of_the_recorded_step_is_bit_reproducible_with_the_retrie
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["xpool_inbatch", "xpool_attention", "xpool_fused"])
+@pytest.mark.parametrize("which", ["xpool_inbatch", "xpool_attention", "xpool_fused", "xpool_sims", "xpool_sims_long"])
 def test_retrieval_kernels_bit_identical_beside_small_workgroups(which):
     """The retrieval kernels hand LDS reads to inline assembly (transposing reads, counted waits).  A register that such a read has been given is an
     ordinary value to the compiler: if it copies it before the data has arrived the kernel is right alone on the chip and wrong beside another
@@ -121,6 +121,8 @@ def test_retrieval_kernels_bit_identical_beside_small_workgroups(which):
         Nv, Nm, S, D = 64, 64, 512, 512
     elif which == "xpool_attention":
         Nv, Nm, S, D = 1024, 16, 512, 512
+    elif which == "xpool_sims_long":
+        Nv, Nm, S, D = 1024, 24, 200, 256
     else:
         Nv, Nm, S, D = 2048, 64, 96, 256
     q = torch.randn(Nv, D, device=dev, generator=g).to(dt)
@@ -134,6 +136,13 @@ def test_retrieval_kernels_bit_identical_beside_small_workgroups(which):
         vn = torch.nn.functional.normalize(torch.randn(Nv, D, device=dev, generator=g), dim=-1)
         shape, odt = (Nv, Nm), torch.float32
         run = lambda o: ops.xpool_fused(q, k, u, mask, ln2, W, bl, ln3, vn, o, scale=1 / math.sqrt(D))
+    elif which.startswith("xpool_sims"):
+        vec = lambda: torch.randn(D, device=dev, generator=g) * 0.1
+        ln3, av, bv = (1 + vec(), vec()), vec(), vec()
+        vn = torch.nn.functional.normalize(torch.randn(Nv, D, device=dev, generator=g), dim=-1)
+        uu = torch.cat([u, torch.randn(Nm, S, D, device=dev, generator=g).to(dt)], -1)
+        shape, odt = (Nv, Nm), torch.float32
+        run = lambda o: ops.xpool_sims(q, k, uu, mask, av, bv, ln3, vn, o, scale=1 / math.sqrt(D))
     elif which == "xpool_attention":
         shape, odt = (Nm, Nv, D), dt
         run = lambda o: ops.xpool_attention(q, k, u, mask, o, scale=1 / math.sqrt(D))

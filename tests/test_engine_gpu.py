@@ -294,10 +294,13 @@ def test_retrieval_parity_across_track_chunks_at_scale():
     assert float(gap.max()) <= 6e-2
 
 
+@pytest.mark.parametrize("sims_kernel", [False, True])
 @pytest.mark.parametrize("N_v,N_m,S", [(300, 37, 96), (257, 5, 40), (640, 12, 130)])
-def test_retrieval_bf16_fused_xpool_kernel(N_v, N_m, S):
+def test_retrieval_bf16_fused_xpool_kernel(N_v, N_m, S, sims_kernel, monkeypatch):
     """made_xpool_fused (bf16, D = 256, retrieval scale): the one-kernel per-pair chain against the f32 oracle within the bf16
-    tolerance of the similarity matrix, and against the unfused bf16 path (same tolerance class, different rounding points)."""
+    tolerance of the similarity matrix, and against the unfused bf16 path (same tolerance class, different rounding points).
+    sims_kernel: the same through made_xpool_sims (MADE_XPOOL_SIMS=1: the per-pair Linear as a second P.V product on u'' = W'' u)."""
+    monkeypatch.setenv("MADE_XPOOL_SIMS", "1" if sims_kernel else "0")
     cfg = cfg_native()
     sd = synth.make_state_dict(cfg, seed=0)
     eng = MadeEngine(cfg, sd, dtype="bf16")

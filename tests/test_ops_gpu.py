@@ -758,6 +758,74 @@ def test_xpool_fused_against_f32_math(dev, Nv, Nm, S, holes):
     assert torch.equal(torch.nan_to_num(s2, nan=5.0), torch.nan_to_num(got, nan=5.0))
 
 
+@pytest.mark.parametrize("Nv,Nm,S,holes", [(300, 21, 96, False), (64, 9, 40, True), (513, 70, 130, True), (129, 3, 17, False), (200, 11, 512, True),
+                                           (70, 300, 128, True)])
+def test_xpool_sims_linear_on_the_values(dev, Nv, Nm, S, holes):
+    """made_xpool_sims (the per-pair Linear of reference modules/transformer.py:172-178 moved onto the value rows: u'' = W'' u, one GEMM over the
+    tracks) against the reference's chain in f32 torch math on the same bf16 operands, and against made_xpool_fused on the same call:
+    prefix and non-prefix masks, NaN in the rows of masked segments, a track without a valid segment, ragged video counts, both
+    instantiations (at most 128 / 512 segments), several chunks of tracks, the per-video workspace reused."""
+    D = 256
+    g = torch.Generator(device=dev).manual_seed(Nv * 7 + Nm)
+    rn = lambda *s_: torch.randn(*s_, device=dev, generator=g)
+    Q, K, U = rn(Nv, D).bfloat16(), rn(Nm, S, D).bfloat16(), rn(Nm, S, D).bfloat16()
+    lens = torch.randint(1, S + 1, (Nm,), device=dev, generator=g)
+    mask = (torch.arange(S, device=dev)[None] < lens[:, None]).float()
+    if holes:
+        mask = mask * (torch.rand(Nm, S, device=dev, generator=g) > 0.3).float()
+        mask[:, 0] = 1.0
+        mask[1, :] = 0.0
+        mask[2, :5] = 0.0
+        mask[2, 5] = 1.0
+    Wl = (rn(D, D) / math.sqrt(D)).bfloat16()
+    ln2, ln3, bl = (1 + 0.1 * rn(D), 0.1 * rn(D)), (1 + 0.1 * rn(D), 0.1 * rn(D)), 0.1 * rn(D)
+    vn = torch.nn.functional.normalize(rn(Nv, D), dim=-1)
+    scale = 1 / math.sqrt(D)
+    # the caller's preparation (engine.py): W'' = (W + I) diag(g2) in the compute dtype, b'' = (W + I) b2 + b, W'' 1, u'' = W'' u
+    W64 = Wl.double() + torch.eye(D, dtype=torch.float64, device=dev)
+    W2 = (W64 * ln2[0].double()[None, :]).float().bfloat16()
+    av = (W64 @ ln2[1].double() + bl.double()).float()
+    bv = W2.double().sum(1).float()
+    UU = torch.cat([U, (U.float() @ W2.float().t()).bfloat16()], -1)
+    Kd, UUd = K.clone(), UU.clone()
+    Kd[mask == 0] = float("nan"); UUd[mask == 0] = float("nan")
+    sims = torch.full((Nv, Nm + 3), -7.0, device=dev)
+    ops.xpool_sims(Q, Kd, UUd, mask, av, bv, ln3, vn, sims[:, :Nm], scale=scale)
+    torch.cuda.synchronize()
+    assert bool((sims[:, Nm:] == -7.0).all())
+    Kf, Uf = K.float() * mask[..., None], U.float() * mask[..., None]
+    logits = torch.einsum("nd,msd->nms", Q.float(), Kf) * scale + torch.where(mask == 0, float("-inf"), 0.0)[None]
+    o = torch.einsum("nms,msd->nmd", torch.softmax(logits, -1), Uf)
+    a3 = torch.nn.functional.layer_norm(o, (D,), ln2[0], ln2[1], 1e-5)
+    y = a3 + a3 @ Wl.float().t() + bl
+    z = torch.nn.functional.layer_norm(y, (D,), ln3[0], ln3[1], 1e-5)
+    ref = (z * vn[:, None]).sum(-1) / z.norm(dim=-1)
+    got = sims[:, :Nm]
+    dead = mask.sum(1) == 0
+    assert bool(torch.isnan(got[:, dead]).all()) and bool(torch.isfinite(got[:, ~dead]).all())
+    err = float((got[:, ~dead] - ref[:, ~dead]).abs().max())
+    assert err <= 1.5e-2, err
+    if S <= 130:                                            # the one-kernel chain on the same call: both are bf16 paths of the same f32 math
+        Ud = U.clone(); Ud[mask == 0] = float("nan")
+        sf = torch.empty(Nv, Nm, device=dev)
+        ops.xpool_fused(Q, Kd, Ud, mask, ln2, Wl, bl, ln3, vn, sf, scale=scale)
+        assert float((got[:, ~dead] - sf[:, ~dead]).abs().max()) <= 2e-2
+    ws = torch.empty(ops.xpool_sims_ws_bytes(Nv, Nm, D), device=dev, dtype=torch.uint8)
+    s2 = torch.empty(Nv, Nm, device=dev)
+    h = Nm // 2
+    ops.xpool_sims(Q, Kd[:h], UUd[:h], mask[:h], av, bv, ln3, vn, s2[:, :h], scale=scale, ws=ws, prepare_ws=True)
+    ops.xpool_sims(Q, Kd[h:], UUd[h:], mask[h:], av, bv, ln3, vn, s2[:, h:], scale=scale, ws=ws, prepare_ws=False)
+    assert torch.equal(torch.nan_to_num(s2, nan=5.0), torch.nan_to_num(got, nan=5.0))
+    # no mask at all
+    s3 = torch.empty(Nv, Nm, device=dev)
+    ops.xpool_sims(Q, K, UU, None, av, bv, ln3, vn, s3, scale=scale)
+    lo3 = torch.einsum("nd,msd->nms", Q.float(), K.float()) * scale
+    o3 = torch.einsum("nms,msd->nmd", torch.softmax(lo3, -1), U.float())
+    a33 = torch.nn.functional.layer_norm(o3, (D,), ln2[0], ln2[1], 1e-5)
+    z3 = torch.nn.functional.layer_norm(a33 + a33 @ Wl.float().t() + bl, (D,), ln3[0], ln3[1], 1e-5)
+    assert float((s3 - (z3 * vn[:, None]).sum(-1) / z3.norm(dim=-1)).abs().max()) <= 1.5e-2
+
+
 def test_xpool_tail_and_clip_loss(dev):
     Nm, Nv, D = 9, 13, 256
     y = rnd(Nm * Nv, D, seed=1)
