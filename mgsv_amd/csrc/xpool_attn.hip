@@ -882,45 +882,44 @@ __device__ __forceinline__ void xs_dma16(const unsigned char* base, uint32_t vof
     const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(d), "v"(voff), "s"(base) : "memory");
 }
-// ---- made_xpool_sims for tracks of at most 96 segments (the retrieval set's S): the same passes with the memory side decoupled from the phases.
-// Stamps of the general kernel on such tracks: two or three tiles of arithmetic per track against five to eight dependent global round trips (track
-// length, valid bits, then the LDS-DMA they steer) and a value ring that could only be filled once the K stages it overlays were consumed.  Here
-//   * the chunk's track table (8 ints per track) is in LDS;
-//   * K tiles (3 x 16 KB) and the ring of four value half tiles (64 KB) have LDS of their own: track m + 1's K goes out as soon as track m's scores
-//     are done, its first four value half tiles while track m's tail runs -- nothing is requested at the point where it is needed.  Half tiles 4 and 5
-//     of a track longer than 64 segments land in the K stages once the scores are done (K of the next track then follows the last product);
-//   * every wave takes one (video half, K tile) unit of the scores at once, the second product advances 32 segments per barrier.
-template <int D> struct Xs96 {
-    using CK = XaCfg<D>;
-    using CU = XaCfg<2 * D>;
-    static constexpr int SMAX = 96;
-    static constexpr int PP = SMAX * 2 + 16;                     // 208: conflict-free 16-byte reads (52 dwords: sixteen rows tile the 64 banks)
-    static constexpr int U_OFF = 3 * CK::STG;
-    static constexpr int P_OFF = U_OFF + 4 * CU::HSTG;
-    static constexpr int MAX_OFF = P_OFF + XA_PQ * PP;
-    static constexpr int SUM_OFF = MAX_OFF + 4 * XA_PQ * 4;
-    static constexpr int STAT_OFF = SUM_OFF + 4 * XA_PQ * 4;
-    static constexpr int PART_OFF = STAT_OFF + 8 * XA_PQ * 8;
-    static constexpr int VEC_OFF = PART_OFF + 8 * XA_PQ * 24;
-    static constexpr int TBL_OFF = VEC_OFF + 4 * D * 4;
-    static constexpr int MAX_TRACKS = (160 * 1024 - TBL_OFF) / 32;
-    static_assert(CK::STG == CU::HSTG && CU::NDT == 2 && CU::PH == 2 && CK::PT == 16, "tile split");
-    static_assert(MAX_TRACKS >= 256, "made_xpool_sims: the LDS map does not fit a CU");
-};
-
 // DBG: workgroup (0, 0) writes s_memtime stamps of its phases into the sims buffer ([wave][track < 32][point < 16] int64) instead of similarities
 #define XS_STAMP(pt) do { if (DBG && stamp_on && jt < 32 && lane == 0) ((long long*)a.sims)[(wave * 32 + jt) * 16 + (pt)] = (long long)__builtin_readcyclecounter(); } while (0)
+// ---- made_xpool_sims for tracks of at most 96 segments (the retrieval set's S): 32 videos and FOUR waves per workgroup, TWO workgroups per CU.
+// A first short-track kernel (64 videos, eight waves, one workgroup per CU, K stages and value ring with LDS of their own; commit 179a265, stamps in
+// profiles/r04_ab_*) ran at 72 ms on the 53 k x 4 k set against this one's 63 and was removed.  Its stamps say what binds a track: the vector instructions of the softmax and of the tail (5 600 cycles of a SIMD's
+// vector issue per 64 videos and track, both waves of the SIMD in lockstep), then the matrix pipe (2 300) and the CU's vector-memory intake (2 300), one
+// after the other between nine workgroup barriers.  Two INDEPENDENT workgroups per CU drift apart and overlap these phases -- one is in its sums while
+// the other multiplies or waits for a barrier -- at the price of streaming K and the value rows once per 32 videos instead of once per 64 (80 KB of LDS and
+// 256 registers per wave are what a half-CU workgroup may hold, so the video tile halves: 4 output tiles of 32 x 32 per wave).
+//   LDS: K tiles (3 x 16 KB) and the ring of three value half tiles share 48 KB; probabilities 6.5 KB; the chunk's track table behind the exchange arrays.
+//   wave w: scores of K tile w (all 32 videos); rows [32 w, +32) and [128 + 32 w, +32) of o and the same rows of z in the second product and the tail.
+template <int D> struct Xs32 {
+    using CK = XaCfg<D>;
+    using CU = XaCfg<2 * D>;
+    static constexpr int NW = 4, PQ = 32, T = 256;
+    static constexpr int PP = 96 * 2 + 16;
+    static constexpr int P_OFF = 3 * CK::STG;
+    static constexpr int MAX_OFF = P_OFF + PQ * PP;
+    static constexpr int SUM_OFF = MAX_OFF + NW * PQ * 4;
+    static constexpr int STAT_OFF = SUM_OFF + NW * PQ * 4;       // [4][32][2] f32
+    static constexpr int PART_OFF = STAT_OFF + NW * PQ * 8;      // [4][32][6] f32
+    static constexpr int VEC_OFF = PART_OFF + NW * PQ * 24;      // [4][D] f32
+    static constexpr int TBL_OFF = VEC_OFF + 4 * D * 4;
+    static constexpr int MAX_TRACKS = (80 * 1024 - TBL_OFF) / 32;
+    static_assert(CK::STG == CU::HSTG && CK::PT == 16 && D == 256, "tile split");
+    static_assert(MAX_TRACKS >= 256, "made_xpool_sims: the LDS map does not fit half a CU");
+};
+
 template <int D, bool DBG>
-__global__ __launch_bounds__(XA_T, 1) void xpool_sims96_kernel(const MadeXpoolSimsArgs a, const int* __restrict__ info, int tracks_per_chunk) {
-    using X = Xs96<D>;
+__global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSimsArgs a, const int* __restrict__ info, int tracks_per_chunk) {
+    using X = Xs32<D>;
     using CK = typename X::CK;
     using CU = typename X::CU;
-    constexpr int PP = X::PP;
+    constexpr int PP = X::PP, PQ = X::PQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int vh = wave & 1, jw = wave >> 1;
-    const int64_t n0 = (int64_t)blockIdx.x * XA_PQ;
+    const int64_t n0 = (int64_t)blockIdx.x * PQ;
     const int64_t m_begin = (int64_t)blockIdx.y * tracks_per_chunk;
     const int64_t m_end = (m_begin + tracks_per_chunk < a.Nm) ? m_begin + tracks_per_chunk : a.Nm;
     if (m_begin >= m_end) return;
@@ -928,35 +927,37 @@ __global__ __launch_bounds__(XA_T, 1) void xpool_sims96_kernel(const MadeXpoolSi
     const uint32_t lbase = (uint32_t)(uintptr_t)(lds3_t)lds;
     const float* wsf = (const float*)a.ws;
     const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0;
+    const int64_t nv = n0 + r < a.Nv ? n0 + r : a.Nv - 1;            // this lane's video (both lane halves)
 
     bf16x8 qf[CK::NQF];
     {
-        const int64_t n = n0 + 32 * vh + r;
-        const bf16_t* qp = (const bf16_t*)a.Q + (n < a.Nv ? n : a.Nv - 1) * a.ldq + hh * 8;
+        const bf16_t* qp = (const bf16_t*)a.Q + nv * a.ldq + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < CK::NQF; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
     }
-    f32x4 gv[2][4];
+    // g3 * vn of this lane's video at the rows its two z tiles hold: 32 (w + 4 j) + 8 g + 4 hh + (0..3)
+    bf16x4 gv[2][4];
 #pragma unroll
-    for (int vt = 0; vt < 2; ++vt) {
-        const int64_t n = n0 + 32 * vt + r;
-        const float* gp = wsf + (n < a.Nv ? n : a.Nv - 1) * D + 32 * wave + 4 * hh;
+    for (int j = 0; j < 2; ++j) {
+        const float* gp = wsf + nv * D + 32 * (wave + 4 * j) + 4 * hh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gv[vt][g] = *(const f32x4*)(gp + 8 * g);
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 x = *(const f32x4*)(gp + 8 * g);
+            gv[j][g] = (bf16x4){(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
+        }
     }
     float p0, pb;
     {
-        const int64_t n = n0 + lane;
-        const float* pp = wsf + xs_ws_pp(a.Nv, D) + (n < a.Nv ? n : a.Nv - 1) * 2;
+        const float* pp = wsf + xs_ws_pp(a.Nv, D) + nv * 2;
         p0 = pp[0]; pb = pp[1];
     }
     const float c0 = wsf[xs_ws_c(a.Nv, D)], e0 = wsf[xs_ws_c(a.Nv, D) + 1], f0 = wsf[xs_ws_c(a.Nv, D) + 2];
-    if (tid < D) {
+    {
         float* vec = (float*)(lds + X::VEC_OFF);
-        const float g3 = a.ln3_g[tid], b3 = a.ln3_b[tid];
+        const float g3 = a.ln3_g[tid], b3 = a.ln3_b[tid];             // (256 threads = D)
         vec[tid] = a.av[tid]; vec[D + tid] = a.bv[tid]; vec[2 * D + tid] = g3 * g3; vec[3 * D + tid] = g3 * b3;
     }
-    for (int i = tid; i < T; i += XA_T) {
+    for (int i = tid; i < T; i += X::T) {
         const int* ip = info + (m_begin + i) * XA_INFO;
         *(u32x4*)(lds + X::TBL_OFF + i * 32) = (u32x4){(unsigned)ip[0], (unsigned)ip[1], 0u, 0u};
         *(u32x4*)(lds + X::TBL_OFF + i * 32 + 16) = *(const u32x4*)(ip + 16);
@@ -972,47 +973,43 @@ __global__ __launch_bounds__(XA_T, 1) void xpool_sims96_kernel(const MadeXpoolSi
     auto tile_word = [&](const Trk& t, int tile) __attribute__((always_inline)) -> unsigned { return tile == 0 ? t.w[0] : tile == 1 ? t.w[1] : t.w[2]; };
 
     const uint32_t ldk_b = (uint32_t)a.ldk * 2u, ldu_b = (uint32_t)a.ldu * 2u;
-    // every K tile of a track at once: wave w brings half of tile w >> 1 (eight pieces) if the track has that tile; returns the pieces it issued
-    auto issue_k_all = [&](int64_t m, const Trk& tk) __attribute__((always_inline)) -> int {
-        const int t = wave >> 1;
-        if (t * 32 >= (tk.s_eff > 0 ? tk.s_eff : 1)) return 0;
-        const uint32_t rip = (uint32_t)lane / CK::CPR, slot = (uint32_t)lane % CK::CPR;
+    // every K tile of the track: wave w brings pieces 4 w .. 4 w + 3 (rows 8 w .. 8 w + 7) of each
+    auto issue_k = [&](int64_t m, const Trk& tk) __attribute__((always_inline)) {
+        const uint32_t rip = xa_opaque((uint32_t)lane / CK::CPR), slot = xa_opaque((uint32_t)lane % CK::CPR);
         const unsigned char* Kb = (const unsigned char*)a.K + m * a.k_bs * 2;
-        const unsigned word = tile_word(tk, t);
+        const int ntl = tk.s_eff > 0 ? (tk.s_eff + 31) / 32 : 1;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int pit = (wave & 1) * 8 + i;
-            const uint32_t row = (uint32_t)pit * CK::RPP + rip;
-            const int seg = t * 32 + (int)row;
-            const bool valid = seg < tk.s_eff && ((word >> row) & 1u);
-            const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
-            const uint32_t chunk = slot ^ (row & 15u);
-            xs_dma16(Kb, srow * ldk_b + chunk * 16u, lbase + (uint32_t)(t * CK::STG + pit * 1024));
+        for (int t = 0; t < 3; ++t) {
+            if (t < ntl) {
+                const unsigned word = tile_word(tk, t);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pit = wave * 4 + i;
+                    const uint32_t row = (uint32_t)pit * CK::RPP + rip;
+                    const int seg = t * 32 + (int)row;
+                    const bool valid = seg < tk.s_eff && ((word >> row) & 1u);
+                    const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
+                    const uint32_t chunk = slot ^ (row & 15u);
+                    xs_dma16(Kb, __umul24(srow, ldk_b) + chunk * 16u, lbase + (uint32_t)(t * CK::STG + pit * 1024));
+                }
+            }
         }
-        return 8;
     };
-    // value half tile h (16 segments x 1 KB: u | u'') -> ring slot h (h < 4) or K stage h - 4; two pieces per wave
+    // value half tile h (16 segments x 1 KB) -> ring slot h % 3: wave w brings rows 4 w .. 4 w + 3
     auto issue_u = [&](int64_t m, int h, const Trk& tk) __attribute__((always_inline)) {
-        const uint32_t slot = (uint32_t)lane;
+        const uint32_t slot = xa_opaque((uint32_t)lane);
         const unsigned char* Ub = (const unsigned char*)a.UU + m * a.u_bs * 2;
-        const unsigned word = tile_word(tk, h >> 1);
-        const int dst = h < 4 ? X::U_OFF + h * CU::HSTG : (h - 4) * CU::HSTG;
+        const unsigned bits = (tile_word(tk, h >> 1) >> ((h & 1) * 16)) & 0xFFFFu;
+        const uint32_t dst = (uint32_t)((h % 3) * CU::HSTG);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint32_t row = (uint32_t)(wave * 2 + i);
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t row = (uint32_t)(wave * 4 + i);
             const int seg = h * 16 + (int)row;
-            const bool valid = seg < tk.s_eff && ((word >> ((h & 1) * 16 + row)) & 1u);
+            const bool valid = seg < tk.s_eff && ((bits >> row) & 1u);
             const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
             const uint32_t chunk = (((slot >> 2) ^ (row & 7u)) << 2) | (slot & 3u);
-            xs_dma16(Ub, srow * ldu_b + chunk * 16u, lbase + (uint32_t)dst + row * 1024u);
+            xs_dma16(Ub, __umul24(srow, ldu_b) + chunk * 16u, lbase + dst + row * 1024u);
         }
-    };
-    auto issue_u_first = [&](int64_t m, const Trk& tk) __attribute__((always_inline)) {
-        const int nh = tk.s_eff > 0 ? (tk.s_eff + 15) / 16 : 1;
-        issue_u(m, 0, tk);
-        if (nh > 1) issue_u(m, 1, tk);
-        if (nh > 2) issue_u(m, 2, tk);
-        if (nh > 3) issue_u(m, 3, tk);
     };
 
     const uint32_t k_rd = lbase + (uint32_t)r * CK::ROWB;
@@ -1020,16 +1017,17 @@ __global__ __launch_bounds__(XA_T, 1) void xpool_sims96_kernel(const MadeXpoolSi
     const int g4 = lane >> 4, i16 = lane & 15;
     const uint32_t trow = 4 * (g4 >> 1) + (i16 >> 2);
     const uint32_t u_rd = lbase + trow * CU::ROWB + (g4 & 1) * 32 + (i16 & 3) * 8;
-    const uint32_t ug0 = (((uint32_t)wave) ^ (trow & 7u)) << 6, ug1 = (((uint32_t)(8 + wave)) ^ (trow & 7u)) << 6;    // column groups of o and z
-    const uint32_t p_wr = lbase + X::P_OFF + (uint32_t)(32 * vh + r) * PP + hh * 16;
-    const uint32_t p_rd = lbase + X::P_OFF + (uint32_t)r * PP + hh * 16;
+    uint32_t ug[4];                                                // column groups of this wave's tiles: o rows 32 w, 128 + 32 w; z the same + 256
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ug[dt] = (((uint32_t)(wave + 4 * dt)) ^ (trow & 7u)) << 6;
+    const uint32_t p_wr = lbase + X::P_OFF + (uint32_t)r * PP + hh * 16;
+    const uint32_t p_rd = p_wr;
 
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();                                               // the track table and the constants are in LDS
     Trk tk;
     load_track(0, tk);
-    issue_k_all(m_begin, tk);
-    issue_u_first(m_begin, tk);
+    issue_k(m_begin, tk);
 
     for (int jt = 0; jt < T; ++jt) {
         const int64_t m = m_begin + jt;
@@ -1037,17 +1035,17 @@ __global__ __launch_bounds__(XA_T, 1) void xpool_sims96_kernel(const MadeXpoolSi
         const int ntiles = s_eff > 0 ? (s_eff + 31) / 32 : 1;
         const int NH = s_eff > 0 ? (s_eff + 15) / 16 : 1;
 
-        // ================================================================================================ pass 1: scores
+        // ================================================================================================ pass 1: scores of K tile `wave`
         f32x16 sacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
         XS_STAMP(0);
-        xs_wait_vm(2 * (NH < 4 ? NH : 4));                          // this wave's K pieces: only the first value half tiles are younger
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's K pieces
         XS_STAMP(1);
         XA_BARRIER();
         XS_STAMP(2);
-        if (jw < ntiles) {
-            const uint32_t kx = xa_opaque(k_rd + (uint32_t)jw * CK::STG + (((uint32_t)hh ^ ksw) << 4));
+        if (wave < ntiles) {
+            const uint32_t kx = xa_opaque(k_rd + (uint32_t)wave * CK::STG + (((uint32_t)hh ^ ksw) << 4));
             uint32_t ka[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) ka[q] = kx ^ (uint32_t)(q << 5);
@@ -1068,18 +1066,15 @@ __global__ __launch_bounds__(XA_T, 1) void xpool_sims96_kernel(const MadeXpoolSi
             }
         }
         XS_STAMP(3);
-        XA_BARRIER();                                               // the K stages are free
+        XA_BARRIER();                                               // the K tiles are consumed: their LDS is the value ring now
         XS_STAMP(4);
-        Trk nx; nx.s_eff = 0; nx.first = 0; nx.w[0] = nx.w[1] = nx.w[2] = 0u;
-        if (jt + 1 < T) load_track(jt + 1, nx);
-        int kn = 0;                                                 // K pieces of the next track this wave has in flight during the second product
-        if (NH > 4) { issue_u(m, 4, tk); if (NH > 5) issue_u(m, 5, tk); }
-        else if (jt + 1 < T) kn = issue_k_all(m + 1, nx);
-
+        issue_u(m, 0, tk);
+        if (NH > 1) issue_u(m, 1, tk);
         XS_STAMP(5);
+
         float mx = -INFINITY;
-        if (jw < ntiles) {
-            const unsigned word = tile_word(tk, jw) >> (4 * hh);
+        if (wave < ntiles) {
+            const unsigned word = tile_word(tk, wave) >> (4 * hh);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float sc = ((word >> ((e & 3) + 8 * (e >> 2))) & 1u) ? sacc[e] * c : -INFINITY;
@@ -1088,15 +1083,15 @@ __global__ __launch_bounds__(XA_T, 1) void xpool_sims96_kernel(const MadeXpoolSi
             }
         }
         mx = fmaxf(mx, xa_other_half(mx));
-        if (hh == 0) xa_wr<float>(lbase + X::MAX_OFF + (uint32_t)(jw * XA_PQ + 32 * vh + r) * 4, mx);
+        if (hh == 0) xa_wr<float>(lbase + X::MAX_OFF + (uint32_t)(wave * PQ + r) * 4, mx);
         XS_STAMP(6);
         XA_BARRIER();
         XS_STAMP(7);
-        float M = xa_rd<float>(lbase + X::MAX_OFF + (uint32_t)(32 * vh + r) * 4);
+        float M = xa_rd<float>(lbase + X::MAX_OFF + (uint32_t)r * 4);
 #pragma unroll
-        for (int q = 1; q < 4; ++q) M = fmaxf(M, xa_rd<float>(lbase + X::MAX_OFF + (uint32_t)(q * XA_PQ + 32 * vh + r) * 4));
+        for (int q = 1; q < 4; ++q) M = fmaxf(M, xa_rd<float>(lbase + X::MAX_OFF + (uint32_t)(q * PQ + r) * 4));
         float psum = 0.f;
-        if (jw < ntiles) {
+        if (wave < ntiles) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 pf;
@@ -1106,79 +1101,123 @@ __global__ __launch_bounds__(XA_T, 1) void xpool_sims96_kernel(const MadeXpoolSi
                     psum += pr_;
                     pf[jj] = (bf16_t)pr_;
                 }
-                xa_wr<bf16x8>(p_wr + (uint32_t)(2 * jw + s2) * 32, pf);
+                xa_wr<bf16x8>(p_wr + (uint32_t)(2 * wave + s2) * 32, pf);
             }
         }
         psum += xa_other_half(psum);
-        if (hh == 0) xa_wr<float>(lbase + X::SUM_OFF + (uint32_t)(jw * XA_PQ + 32 * vh + r) * 4, psum);
+        if (hh == 0) xa_wr<float>(lbase + X::SUM_OFF + (uint32_t)(wave * PQ + r) * 4, psum);
 
-        // ================================================================================================ pass 2: [O | Z]^T = [U | U'']^T P^T, 32 segments per step
-        f32x16 oacc[2][2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[dt][vt][e] = 0.f;
-        const int NQ = (NH + 1) / 2;
+        // ================================================================================================ pass 2: [O | Z]^T = [U | U'']^T P^T, 16 segments per step
         XS_STAMP(8);
-        for (int q = 0; q < NQ; ++q) {
-            const int rem = NH - 2 * (q + 1);                       // younger half tiles of this track in flight (+ the next track's K pieces)
-            xs_wait_vm(2 * (rem > 0 ? rem : 0) + kn);
+        f32x16 oacc[4];                                             // [0], [1]: rows 32 w .., 128 + 32 w .. of o; [2], [3]: the same rows of z
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+        for (int h = 0; h < NH; ++h) {
+            if (h + 1 < NH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // half tile h has landed (h + 1 may be in flight)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             XA_BARRIER();                                           // (the first one also publishes the probabilities and their sums)
-            const bool two = 2 * q + 1 < NH;
-            const uint32_t ub0 = u_rd + (uint32_t)(q < 2 ? X::U_OFF + 2 * q * CU::HSTG : 0);
-            const uint32_t ub1 = ub0 + CU::HSTG;
-            bf16x8 pa0 = xa_read128(p_rd + (uint32_t)(2 * q) * 32), pa1 = xa_read128(p_rd + 32 * PP + (uint32_t)(2 * q) * 32);
-            bf16x8 pc0 = xa_read128(p_rd + (uint32_t)(2 * q + 1) * 32), pc1 = xa_read128(p_rd + 32 * PP + (uint32_t)(2 * q + 1) * 32);
-            bf16x4 lo[2][2], hi[2][2];
+            if (h + 2 < NH) issue_u(m, h + 2, tk);                  // into the slot of half tile h - 1, which everyone has left
+            const uint32_t ub = u_rd + (uint32_t)((h % 3) * CU::HSTG);
+            bf16x8 pbf = xa_read128(p_rd + (uint32_t)h * 32);
+            bf16x4 lo[4], hi[4];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const uint32_t v0 = (hf ? ub1 : ub0) + ug0, v1 = (hf ? ub1 : ub0) + ug1;
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[hf][0]) : "v"(v0));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[hf][0]) : "v"(v0), "n"(8 * CU::ROWB));
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[hf][1]) : "v"(v1));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[hf][1]) : "v"(v1), "n"(8 * CU::ROWB));
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint32_t va = ub + ug[dt];
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[dt]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(va), "n"(8 * CU::ROWB));
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pa0), "+v"(pa1), "+v"(pc0), "+v"(pc1), "+v"(lo[0][0]), "+v"(lo[0][1]), "+v"(hi[0][0]), "+v"(hi[0][1]),
-                         "+v"(lo[1][0]), "+v"(lo[1][1]), "+v"(hi[1][0]), "+v"(hi[1][1]));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pbf), "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 uf = __builtin_shufflevector(lo[0][dt], hi[0][dt], 0, 1, 2, 3, 4, 5, 6, 7);
-                oacc[dt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pa0, oacc[dt][0], 0, 0, 0);
-                oacc[dt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pa1, oacc[dt][1], 0, 0, 0);
-            }
-            if (two) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 uf = __builtin_shufflevector(lo[1][dt], hi[1][dt], 0, 1, 2, 3, 4, 5, 6, 7);
-                    oacc[dt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pc0, oacc[dt][0], 0, 0, 0);
-                    oacc[dt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pc1, oacc[dt][1], 0, 0, 0);
-                }
-            }
+            for (int dt = 0; dt < 4; ++dt)
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(lo[dt], hi[dt], 0, 1, 2, 3, 4, 5, 6, 7), pbf, oacc[dt], 0, 0, 0);
         }
-
-        // ================================================================================================ tail
         XS_STAMP(9);
-        xs_tail1<X::SUM_OFF, X::STAT_OFF>(oacc, lbase, wave, r, hh);
+        XA_BARRIER();                                               // value ring and probabilities are free
         XS_STAMP(10);
-        XA_BARRIER();                                               // (also: every wave is done with the value tiles and the probabilities)
+        Trk nx; nx.s_eff = 0; nx.first = 0; nx.w[0] = nx.w[1] = nx.w[2] = 0u;
+        if (jt + 1 < T) { load_track(jt + 1, nx); issue_k(m + 1, nx); }
         XS_STAMP(11);
-        if (jt + 1 < T) {
-            if (NH > 4) issue_k_all(m + 1, nx);
-            issue_u_first(m + 1, nx);
+
+        // ================================================================================================ tail 1: o / l and its statistics, z / l
+        {
+            float l = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) l += xa_rd<float>(lbase + X::SUM_OFF + (uint32_t)(q * PQ + r) * 4);
+            const float inv_l = 1.f / l;
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float x = oacc[dt][e] * inv_l;
+                    su += x; sq = __builtin_fmaf(x, x, sq);
+                    oacc[2 + dt][e] *= inv_l;
+                }
+            su += xa_other_half(su); sq += xa_other_half(sq);
+            if (hh == 0) xa_wr<f32x2_t>(lbase + X::STAT_OFF + (uint32_t)((wave * PQ + r) * 8), (f32x2_t){su, sq});
         }
         XS_STAMP(12);
-        xs_tail2<D, X::STAT_OFF, X::PART_OFF, X::VEC_OFF>(oacc, gv, lbase, wave, r, hh, a.eps);
-        XS_STAMP(13);
         XA_BARRIER();
-        XS_STAMP(14);
-        if (!DBG && wave == (jt & 7)) {
-            const float out = xs_tail3<D, X::PART_OFF>(lbase, lane, a.eps, p0, pb, c0, e0, f0);
-            const int64_t n = n0 + lane;
-            if (n < a.Nv) a.sims[n * a.ld_sims + m] = out;
+        XS_STAMP(13);
+        // ================================================================================================ tail 2: y and the six sums over this wave's 64 rows
+        {
+            f32x2_t st = xa_rd<f32x2_t>(lbase + X::STAT_OFF + (uint32_t)(r * 8));
+#pragma unroll
+            for (int q = 1; q < 4; ++q) st += xa_rd<f32x2_t>(lbase + X::STAT_OFF + (uint32_t)((q * PQ + r) * 8));
+            const float mean = st[0] * (1.f / D);
+            const float var = fmaxf(st[1] * (1.f / D) - mean * mean, 0.f);
+            const float k1 = __builtin_amdgcn_rsqf(var + a.eps), k2 = -mean * k1;
+            f32x2_t s1 = {0.f, 0.f}, s2 = {0.f, 0.f}, p1 = {0.f, 0.f}, c2 = {0.f, 0.f}, c1 = {0.f, 0.f}, e1 = {0.f, 0.f};
+            const f32x2_t k1v = {k1, k1}, k2v = {k2, k2};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t vec_r = xa_opaque(lbase + X::VEC_OFF + (uint32_t)(32 * (wave + 4 * j) + 4 * hh) * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 av = xa_rd<f32x4>(vec_r + g * 32), bv = xa_rd<f32x4>(vec_r + D * 4 + g * 32);
+                    const f32x4 g2 = xa_rd<f32x4>(vec_r + 2 * D * 4 + g * 32), gb = xa_rd<f32x4>(vec_r + 3 * D * 4 + g * 32);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj += 2) {
+                        const f32x2_t z2 = {oacc[2 + j][4 * g + jj], oacc[2 + j][4 * g + jj + 1]};
+                        const f32x2_t yv = z2 * k1v + ((f32x2_t){bv[jj], bv[jj + 1]} * k2v + (f32x2_t){av[jj], av[jj + 1]});
+                        const f32x2_t yy = yv * yv;
+                        const f32x2_t gg = {g2[jj], g2[jj + 1]};
+                        s1 += yv; s2 += yy;
+                        p1 += yv * (f32x2_t){(float)gv[j][g][jj], (float)gv[j][g][jj + 1]};
+                        c2 += yy * gg; c1 += yv * gg;
+                        e1 += yv * (f32x2_t){gb[jj], gb[jj + 1]};
+                    }
+                }
+            }
+            float S1 = s1[0] + s1[1], S2 = s2[0] + s2[1], P1 = p1[0] + p1[1], C2 = c2[0] + c2[1], C1 = c1[0] + c1[1], E1 = e1[0] + e1[1];
+            S1 += xa_other_half(S1); S2 += xa_other_half(S2); P1 += xa_other_half(P1);
+            C2 += xa_other_half(C2); C1 += xa_other_half(C1); E1 += xa_other_half(E1);
+            if (hh == 0) {
+                const uint32_t pw = lbase + X::PART_OFF + (uint32_t)((wave * PQ + r) * 24);
+                xa_wr<f32x2_t>(pw, (f32x2_t){S1, S2}); xa_wr<f32x2_t>(pw + 8, (f32x2_t){P1, C2}); xa_wr<f32x2_t>(pw + 16, (f32x2_t){C1, E1});
+            }
         }
+        XS_STAMP(14);
+        XA_BARRIER();
         XS_STAMP(15);
+        // ================================================================================================ tail 3: LayerNorm3 + cosine of (r, m), one wave
+        if (!DBG && wave == (jt & 3) && hh == 0) {
+            const uint32_t pr = xa_opaque(lbase + X::PART_OFF + (uint32_t)r * 24);
+            float s1 = 0.f, s2 = 0.f, p1 = 0.f, c2 = 0.f, c1 = 0.f, e1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2_t x0 = xa_rd<f32x2_t>(pr + q * (PQ * 24)), x1 = xa_rd<f32x2_t>(pr + q * (PQ * 24) + 8), x2 = xa_rd<f32x2_t>(pr + q * (PQ * 24) + 16);
+                s1 += x0[0]; s2 += x0[1]; p1 += x1[0]; c2 += x1[1]; c1 += x2[0]; e1 += x2[1];
+            }
+            const float mu = s1 * (1.f / D);
+            const float var = fmaxf(s2 * (1.f / D) - mu * mu, 0.f);
+            const float rs = __builtin_amdgcn_rsqf(var + a.eps);
+            const float dot = rs * (p1 - mu * p0) + pb;
+            const float zz = rs * rs * (c2 - 2.f * mu * c1 + mu * mu * c0) + 2.f * rs * (e1 - mu * e0) + f0;
+            if (n0 + r < a.Nv) a.sims[(n0 + r) * a.ld_sims + m] = dot * __builtin_amdgcn_rsqf(zz);
+        }
         tk.s_eff = nx.s_eff; tk.first = nx.first; tk.w[0] = nx.w[0]; tk.w[1] = nx.w[1]; tk.w[2] = nx.w[2];
     }
 }
@@ -1263,8 +1302,6 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)xpool_sims_kernel<D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims96_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims96_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims_kernel<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, XsCfg<D, 4>::LDS_FIXED);
         if (e != hipSuccess) {
             made_set_error("made_xpool_sims: cannot reserve %d bytes of LDS: %s", 160 * 1024, hipGetErrorString(e));
@@ -1291,22 +1328,31 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
         }
     }
     int per = (int)((a.Nm + chunks - 1) / chunks);
-    static const bool no96 = getenv("MADE_XPOOL_SIMS96") && atoi(getenv("MADE_XPOOL_SIMS96")) == 0;
-    if (a.S <= 96 && !no96) {
-        // the retrieval set's tracks: at most Xs96::MAX_TRACKS per chunk (the track table in LDS), as few partial rounds of the chip as possible
-        const int64_t c_lo = (a.Nm + Xs96<D>::MAX_TRACKS - 1) / Xs96<D>::MAX_TRACKS;
+    const bool no96 = getenv("MADE_XPOOL_SIMS96") && atoi(getenv("MADE_XPOOL_SIMS96")) == 0;      // (read per call: the tests switch it)
+    if (a.S <= 96 && !no96 && a.ldk * 2 < (1 << 24) && a.ldu * 2 < (1 << 24)) {                     // (row offsets through 24-bit multiplies)
+        // the retrieval set's tracks: 32 videos and four waves per workgroup, two workgroups per CU; at most Xs32::MAX_TRACKS per chunk (the track
+        // table in LDS), as few partial rounds of the chip as possible
+        static bool attr32 = false;
+        if (!attr32) {
+            hipError_t e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) { made_set_error("made_xpool_sims: cannot reserve 80 KB of LDS: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
+            attr32 = true;
+        }
+        const int64_t nvt32 = (a.Nv + 31) / 32;
+        const int64_t c_lo = (a.Nm + Xs32<D>::MAX_TRACKS - 1) / Xs32<D>::MAX_TRACKS;
         double best = 1e30; int64_t bc = c_lo;
         for (int64_t cch = c_lo; cch <= c_lo + 24 && cch <= a.Nm; ++cch) {
-            const int64_t pr = (a.Nm + cch - 1) / cch, rounds = (nvt * ((a.Nm + pr - 1) / pr) + 255) / 256;
+            const int64_t pr = (a.Nm + cch - 1) / cch, rounds = (nvt32 * ((a.Nm + pr - 1) / pr) + 511) / 512;
             const double cost = (double)rounds * (double)(pr + 2);
             if (cost < best) { best = cost; bc = cch; }
         }
-        per = (int)((a.Nm + bc - 1) / bc);
-        dim3 g96((unsigned)nvt, (unsigned)((a.Nm + per - 1) / per));
-        // MADE_XPOOL_DBG=96: the phase-stamp build (tools/xpool_sims_stamps.py): workgroup (0, 0) writes cycle stamps into the sims buffer
-        static const bool stamps = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 96;
-        if (stamps) hipLaunchKernelGGL((xpool_sims96_kernel<D, true>), g96, dim3(XA_T), Xs96<D>::TBL_OFF + per * 32, st, a, (const int*)info, per);
-        else hipLaunchKernelGGL((xpool_sims96_kernel<D, false>), g96, dim3(XA_T), Xs96<D>::TBL_OFF + per * 32, st, a, (const int*)info, per);
+        const int per32 = (int)((a.Nm + bc - 1) / bc);
+        dim3 g32((unsigned)nvt32, (unsigned)((a.Nm + per32 - 1) / per32));
+        // MADE_XPOOL_DBG=32: the phase-stamp build (tools/xpool_sims_stamps.py): workgroup (0, 0) writes cycle stamps into the sims buffer, no similarity is written
+        const bool stamps32 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 32;
+        if (stamps32) hipLaunchKernelGGL((xpool_sims32_kernel<D, true>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32);
+        else hipLaunchKernelGGL((xpool_sims32_kernel<D, false>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32);
         return made_check_launch("made_xpool_sims");
     }
     if (a.S <= 128 && per > XsCfg<D, 1>::MAX_TRACKS) per = XsCfg<D, 1>::MAX_TRACKS;      // (the kernel's track table in LDS)

@@ -435,8 +435,8 @@ class MadeEngine:
             if S <= 512 and os.environ.get("MADE_XPOOL_SIMS", "0") == "1":
                 # round 4, opt-in: the per-pair Linear moved onto the values.  W'' o = sum_s p_s (W'' u_s), so u''_s = W'' u_s is made once per
                 # segment (one more GEMM over the tracks) and the pair costs a second P.V product (2 S D flops) instead of the Linear (2 D^2):
-                # 2.2x fewer flops per pair at S = 96 -- and 72 ms against made_xpool_fused's 60 on the 53 k x 4 k set, because the launch is bound
-                # by vector-instruction issue (softmax, the six sums, LDS-DMA addressing), not by the matrix pipe
+                # 2.2x fewer flops per pair at S = 96 -- and 63 ms against made_xpool_fused's 60 on the 53 k x 4 k set, because the launch is bound
+                # by vector-instruction issue (softmax, the six sums) and the CU's LDS-DMA intake, not by the matrix pipe
                 s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
                 kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
                 ubuf = torch.empty(cm * S, D, device=dev, dtype=tc)

@@ -758,14 +758,21 @@ def test_xpool_fused_against_f32_math(dev, Nv, Nm, S, holes):
     assert torch.equal(torch.nan_to_num(s2, nan=5.0), torch.nan_to_num(got, nan=5.0))
 
 
+@pytest.mark.parametrize("variant", ["default", "general"])
 @pytest.mark.parametrize("Nv,Nm,S,holes", [(300, 21, 96, False), (64, 9, 40, True), (513, 70, 130, True), (129, 3, 17, False), (200, 11, 512, True),
-                                           (70, 300, 128, True)])
-def test_xpool_sims_linear_on_the_values(dev, Nv, Nm, S, holes):
+                                           (70, 300, 128, True), (1000, 1200, 96, True)])
+def test_xpool_sims_linear_on_the_values(dev, Nv, Nm, S, holes, variant, monkeypatch):
     """made_xpool_sims (the per-pair Linear of reference modules/transformer.py:172-178 moved onto the value rows: u'' = W'' u, one GEMM over the
     tracks) against the reference's chain in f32 torch math on the same bf16 operands, and against made_xpool_fused on the same call:
-    prefix and non-prefix masks, NaN in the rows of masked segments, a track without a valid segment, ragged video counts, both
-    instantiations (at most 128 / 512 segments), several chunks of tracks, the per-video workspace reused."""
+    prefix and non-prefix masks, NaN in the rows of masked segments, a track without a valid segment, ragged video counts, every
+    kernel (short tracks; at most 128 / 512 segments), several chunks of tracks, the per-video workspace reused."""
     D = 256
+    # tracks of at most 96 segments have a kernel of their own (32 videos / four waves per workgroup, two workgroups per CU);
+    # "general" = made_xpool_attention's passes also for them
+    if variant != "default" and S > 96:
+        pytest.skip("the variants differ only for tracks of at most 96 segments")
+    if variant == "general":
+        monkeypatch.setenv("MADE_XPOOL_SIMS96", "0")
     g = torch.Generator(device=dev).manual_seed(Nv * 7 + Nm)
     rn = lambda *s_: torch.randn(*s_, device=dev, generator=g)
     Q, K, U = rn(Nv, D).bfloat16(), rn(Nm, S, D).bfloat16(), rn(Nm, S, D).bfloat16()

@@ -1,7 +1,8 @@
-"""In-kernel cycle stamps of made_xpool_sims' short-track kernel (MADE_XPOOL_DBG=96 build): phases of workgroup (0, 0), per wave, averaged over
+"""In-kernel cycle stamps of made_xpool_sims' short-track kernel (MADE_XPOOL_DBG=32 build): phases of workgroup (0, 0), per wave, averaged over
 tracks 8..31 of its chunk.  python tools/xpool_sims_stamps.py [S_fixed]   (S_fixed: every track that long; default: lengths U{12..96})"""
 import math, os, sys
-os.environ["MADE_XPOOL_DBG"] = "96"
+K32 = True
+os.environ["MADE_XPOOL_DBG"] = "32"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mgsv_amd import ops
@@ -23,11 +24,14 @@ for _ in range(2):
     ops.xpool_sims(Q, K, UU, mask, av, bv, ln3, vn, sims, scale=1 / math.sqrt(D))
 torch.cuda.synchronize()
 st = sims.view(-1)[:8 * 32 * 16 * 2].view(torch.int64).view(8, 32, 16).cpu()
-names = ["wait K", "barrier A", "scores", "barrier B", "next info + K / h4,5 issue", "mask + max", "barrier C", "exp + P", "second product", "tail 1", "barrier B1",
+NWAVES = 4 if K32 else 8
+names32 = ["wait K", "barrier A", "scores", "barrier B", "issue U 0,1", "mask + max", "barrier C", "exp + P", "second product", "barrier D", "next info + K issue",
+           "tail 1", "barrier", "tail 2", "barrier"]
+names = names32 if K32 else ["wait K", "barrier A", "scores", "barrier B", "next info + K / h4,5 issue", "mask + max", "barrier C", "exp + P", "second product", "tail 1", "barrier B1",
          "issue U (+K)", "tail 2", "barrier B2", "tail 3 / store"]
 print(f"track lengths: {lens[:32].tolist()}")
 print("wave " + " ".join(f"{n[:10]:>10s}" for n in names) + "      total")
-for w in range(8):
+for w in range(NWAVES):
     d = (st[w, 8:32, 1:] - st[w, 8:32, :-1]).float().mean(0)
     tot = (st[w, 9:32, 0] - st[w, 8:31, 0]).float().mean()
     print(f"{w:4d} " + " ".join(f"{float(x):10.0f}" for x in d) + f" {float(tot):10.0f}")
