@@ -551,10 +551,12 @@ template <int D, int NTI> struct XsCfg {
     static_assert(CU::NDT == 2 && CU::PH >= 1 && CK::PB >= 1 && CK::PT == 16, "tile split");
     static_assert(LDS_FIXED <= 160 * 1024 && (NTI == 4 || MAX_TRACKS >= 512), "made_xpool_sims: the LDS map does not fit a CU");
 };
-// workspace (floats): gv = g3 * vn [Nv][D], then (sum g3 vn, sum b3 vn) [Nv][2], then sum g3^2, sum g3 b3, sum b3^2, 0, then 32 ints per track
+// workspace (floats): gv = g3 * vn [Nv][D]; per video (sum gv, sum b3 vn, sum gv Bv, sum gv Av) [Nv][4]; sixteen model constants (XsConst); 32 ints per track
 __host__ __device__ inline int64_t xs_ws_pp(int64_t Nv, int64_t D) { return Nv * D; }
-__host__ __device__ inline int64_t xs_ws_c(int64_t Nv, int64_t D) { return Nv * (D + 2); }
-__host__ __device__ inline int64_t xs_ws_info(int64_t Nv, int64_t D) { return Nv * (D + 2) + 4; }
+__host__ __device__ inline int64_t xs_ws_c(int64_t Nv, int64_t D) { return Nv * (D + 4); }
+__host__ __device__ inline int64_t xs_ws_info(int64_t Nv, int64_t D) { return Nv * (D + 4) + 16; }
+// model constants: with g2 = g3^2, gb = g3 b3 and the folded Linear's vectors Av, Bv (y = k1 z + k2 Bv + Av)
+enum XsConst { XC_G2 = 0, XC_GB, XC_B2, XC_BV, XC_AV, XC_BV2, XC_BVAV, XC_AV2, XC_G2BV, XC_G2AV, XC_G2BV2, XC_G2BVAV, XC_G2AV2, XC_GBBV, XC_GBAV };
 
 // NTI: 32-segment score tiles per wave.  NTI = 1 (tracks of at most 128 segments: the retrieval set's 96): every K tile of a track is resident at
 // once and the eight waves take one (video half, tile) unit each; the chunk's track table lives in LDS -- with two or three tiles per track a
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(XA_T, 1) void xpool_sims_kernel(const MadeXpoolSims
     float p0, pb;
     {
         const int64_t n = n0 + lane;
-        const float* pp = wsf + xs_ws_pp(a.Nv, D) + (n < a.Nv ? n : a.Nv - 1) * 2;
+        const float* pp = wsf + xs_ws_pp(a.Nv, D) + (n < a.Nv ? n : a.Nv - 1) * 4;
         p0 = pp[0]; pb = pp[1];
     }
     const float c0 = wsf[xs_ws_c(a.Nv, D)], e0 = wsf[xs_ws_c(a.Nv, D) + 1], f0 = wsf[xs_ws_c(a.Nv, D) + 2];
@@ -901,9 +903,8 @@ template <int D> struct Xs32 {
     static constexpr int P_OFF = 3 * CK::STG;
     static constexpr int MAX_OFF = P_OFF + PQ * PP;
     static constexpr int SUM_OFF = MAX_OFF + NW * PQ * 4;
-    static constexpr int STAT_OFF = SUM_OFF + NW * PQ * 4;       // [4][32][2] f32
-    static constexpr int PART_OFF = STAT_OFF + NW * PQ * 8;      // [4][32][6] f32
-    static constexpr int VEC_OFF = PART_OFF + NW * PQ * 24;      // [4][D] f32
+    static constexpr int PART_OFF = SUM_OFF + NW * PQ * 4;       // [4][32][12] f32: a wave's partial sums of a video (see the tail)
+    static constexpr int VEC_OFF = PART_OFF + NW * PQ * 48;      // [4][D] f32
     static constexpr int TBL_OFF = VEC_OFF + 4 * D * 4;
     static constexpr int MAX_TRACKS = (80 * 1024 - TBL_OFF) / 32;
     static_assert(CK::STG == CU::HSTG && CK::PT == 16 && D == 256, "tile split");
@@ -946,12 +947,8 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
             gv[j][g] = (bf16x4){(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
         }
     }
-    float p0, pb;
-    {
-        const float* pp = wsf + xs_ws_pp(a.Nv, D) + nv * 2;
-        p0 = pp[0]; pb = pp[1];
-    }
-    const float c0 = wsf[xs_ws_c(a.Nv, D)], e0 = wsf[xs_ws_c(a.Nv, D) + 1], f0 = wsf[xs_ws_c(a.Nv, D) + 2];
+    const f32x4 pv4 = *(const f32x4*)(wsf + xs_ws_pp(a.Nv, D) + nv * 4);     // sum gv, sum b3 vn, sum gv Bv, sum gv Av of this lane's video
+    const float* mc = wsf + xs_ws_c(a.Nv, D);                                // the model's constants (XsConst)
     {
         float* vec = (float*)(lds + X::VEC_OFF);
         const float g3 = a.ln3_g[tid], b3 = a.ln3_b[tid];             // (256 threads = D)
@@ -1025,6 +1022,25 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
 
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();                                               // the track table and the constants are in LDS
+    // ---- the sums of the tail that are LINEAR in z -- sum z c_d for c = 1, Bv, Av, g2, g2 Bv, g2 Av, gb -- go through the matrix pipe: a z tile in
+    // accumulator order is the B operand of the next MFMA (k-slot (hh, jj) of k-step s2 = accumulator row 8 (2 s2 + (jj >> 2)) + 4 hh + (jj & 3)), the
+    // constants of this wave's rows in the same order are the A operand: row m of the product is functional m (rows 7 .. 31: zero)
+    bf16x8 afr[2][2];
+    {
+        const int mf = lane & 31;
+        const float* vec = (const float*)(lds + X::VEC_OFF);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int d = 32 * (wave + 4 * j) + 8 * (2 * s2 + (jj >> 2)) + 4 * hh + (jj & 3);
+                    const float Av = vec[d], Bv = vec[D + d], g2 = vec[2 * D + d], gb = vec[3 * D + d];
+                    const float val = mf == 0 ? 1.f : mf == 1 ? Bv : mf == 2 ? Av : mf == 3 ? g2 : mf == 4 ? g2 * Bv : mf == 5 ? g2 * Av : mf == 6 ? gb : 0.f;
+                    afr[j][s2][jj] = (bf16_t)val;
+                }
+    }
     Trk tk;
     load_track(0, tk);
     issue_k(m_begin, tk);
@@ -1140,111 +1156,127 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
         if (jt + 1 < T) { load_track(jt + 1, nx); issue_k(m + 1, nx); }
         XS_STAMP(11);
 
-        // ================================================================================================ tail 1: o / l and its statistics, z / l
+        // ================================================================================================ tail: this wave's partial sums of video r
+        // Over its 64 rows of o: sum o, sum o^2 (LayerNorm2's statistics; on the unnormalised accumulators, 1 / l applied to the sums).  Over its 64 rows
+        // of z = P~.U'' (unnormalised too: 1 / l rides on k1): with y = k1 z + k2 Bv + Av the six sums of LayerNorm3 + cosine expand into
+        //   vector work: Q1 = sum z^2, Q2 = sum g2 z^2, B1 = sum gv z                                 (4 packed instructions per pair of elements, not 9)
+        //   matrix work: F1..F7 = sum z, z Bv, z Av, g2 z, g2 z Bv, g2 z Av, gb z                       (4 MFMAs per track)
+        // none of which needs k1 / k2: ONE exchange and ONE barrier, then a single wave puts the pair together.
+        float inv_l;
         {
             float l = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) l += xa_rd<float>(lbase + X::SUM_OFF + (uint32_t)(q * PQ + r) * 4);
-            const float inv_l = 1.f / l;
-            float su = 0.f, sq = 0.f;
+            inv_l = 1.f / l;
+            f32x2_t su2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float x = oacc[dt][e] * inv_l;
-                    su += x; sq = __builtin_fmaf(x, x, sq);
-                    oacc[2 + dt][e] *= inv_l;
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2_t x2 = {oacc[dt][e], oacc[dt][e + 1]};
+                    su2 += x2; sq2 += x2 * x2;
                 }
+            float su = (su2[0] + su2[1]) * inv_l, sq = (sq2[0] + sq2[1]) * (inv_l * inv_l);
             su += xa_other_half(su); sq += xa_other_half(sq);
-            if (hh == 0) xa_wr<f32x2_t>(lbase + X::STAT_OFF + (uint32_t)((wave * PQ + r) * 8), (f32x2_t){su, sq});
+            f32x2_t q1 = {0.f, 0.f}, q2 = {0.f, 0.f}, b1 = {0.f, 0.f};
+            f32x16 facc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) facc[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t g2_r = xa_opaque(lbase + X::VEC_OFF + (uint32_t)(2 * D + 32 * (wave + 4 * j) + 4 * hh) * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 g2 = xa_rd<f32x4>(g2_r + g * 32);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj += 2) {
+                        const f32x2_t z2 = {oacc[2 + j][4 * g + jj], oacc[2 + j][4 * g + jj + 1]};
+                        const f32x2_t zz = z2 * z2;
+                        q1 += zz;
+                        q2 += zz * (f32x2_t){g2[jj], g2[jj + 1]};
+                        b1 += z2 * (f32x2_t){(float)gv[j][g][jj], (float)gv[j][g][jj + 1]};
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 zb;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) zb[jj] = (bf16_t)oacc[2 + j][8 * s2 + jj];
+                    facc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[j][s2], zb, facc, 0, 0, 0);
+                }
+            }
+            float Q1 = q1[0] + q1[1], Q2 = q2[0] + q2[1], B1 = b1[0] + b1[1];
+            Q1 += xa_other_half(Q1); Q2 += xa_other_half(Q2); B1 += xa_other_half(B1);
+            // [0..3] sum o / l, sum (o / l)^2, Q1, Q2; [4..7] F1..F4 (rows 0-3 of the product: lower lane half); [8..11] F5, F6, F7 (upper half), B1
+            const uint32_t pw = lbase + X::PART_OFF + (uint32_t)((wave * PQ + r) * 48);
+            if (hh == 0) { xa_wr<f32x4>(pw, (f32x4){su, sq, Q1, Q2}); xa_wr<f32x4>(pw + 16, (f32x4){facc[0], facc[1], facc[2], facc[3]}); }
+            else xa_wr<f32x4>(pw + 32, (f32x4){facc[0], facc[1], facc[2], B1});
         }
         XS_STAMP(12);
         XA_BARRIER();
         XS_STAMP(13);
-        // ================================================================================================ tail 2: y and the six sums over this wave's 64 rows
-        {
-            f32x2_t st = xa_rd<f32x2_t>(lbase + X::STAT_OFF + (uint32_t)(r * 8));
-#pragma unroll
-            for (int q = 1; q < 4; ++q) st += xa_rd<f32x2_t>(lbase + X::STAT_OFF + (uint32_t)((q * PQ + r) * 8));
-            const float mean = st[0] * (1.f / D);
-            const float var = fmaxf(st[1] * (1.f / D) - mean * mean, 0.f);
-            const float k1 = __builtin_amdgcn_rsqf(var + a.eps), k2 = -mean * k1;
-            f32x2_t s1 = {0.f, 0.f}, s2 = {0.f, 0.f}, p1 = {0.f, 0.f}, c2 = {0.f, 0.f}, c1 = {0.f, 0.f}, e1 = {0.f, 0.f};
-            const f32x2_t k1v = {k1, k1}, k2v = {k2, k2};
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t vec_r = xa_opaque(lbase + X::VEC_OFF + (uint32_t)(32 * (wave + 4 * j) + 4 * hh) * 4);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 av = xa_rd<f32x4>(vec_r + g * 32), bv = xa_rd<f32x4>(vec_r + D * 4 + g * 32);
-                    const f32x4 g2 = xa_rd<f32x4>(vec_r + 2 * D * 4 + g * 32), gb = xa_rd<f32x4>(vec_r + 3 * D * 4 + g * 32);
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj += 2) {
-                        const f32x2_t z2 = {oacc[2 + j][4 * g + jj], oacc[2 + j][4 * g + jj + 1]};
-                        const f32x2_t yv = z2 * k1v + ((f32x2_t){bv[jj], bv[jj + 1]} * k2v + (f32x2_t){av[jj], av[jj + 1]});
-                        const f32x2_t yy = yv * yv;
-                        const f32x2_t gg = {g2[jj], g2[jj + 1]};
-                        s1 += yv; s2 += yy;
-                        p1 += yv * (f32x2_t){(float)gv[j][g][jj], (float)gv[j][g][jj + 1]};
-                        c2 += yy * gg; c1 += yv * gg;
-                        e1 += yv * (f32x2_t){gb[jj], gb[jj + 1]};
-                    }
-                }
-            }
-            float S1 = s1[0] + s1[1], S2 = s2[0] + s2[1], P1 = p1[0] + p1[1], C2 = c2[0] + c2[1], C1 = c1[0] + c1[1], E1 = e1[0] + e1[1];
-            S1 += xa_other_half(S1); S2 += xa_other_half(S2); P1 += xa_other_half(P1);
-            C2 += xa_other_half(C2); C1 += xa_other_half(C1); E1 += xa_other_half(E1);
-            if (hh == 0) {
-                const uint32_t pw = lbase + X::PART_OFF + (uint32_t)((wave * PQ + r) * 24);
-                xa_wr<f32x2_t>(pw, (f32x2_t){S1, S2}); xa_wr<f32x2_t>(pw + 8, (f32x2_t){P1, C2}); xa_wr<f32x2_t>(pw + 16, (f32x2_t){C1, E1});
-            }
-        }
-        XS_STAMP(14);
-        XA_BARRIER();
-        XS_STAMP(15);
-        // ================================================================================================ tail 3: LayerNorm3 + cosine of (r, m), one wave
+        // ---- one wave (they take turns), lane = video: LayerNorm2's k1 / k2, the six sums, LayerNorm3 + cosine
         if (!DBG && wave == (jt & 3) && hh == 0) {
-            const uint32_t pr = xa_opaque(lbase + X::PART_OFF + (uint32_t)r * 24);
-            float s1 = 0.f, s2 = 0.f, p1 = 0.f, c2 = 0.f, c1 = 0.f, e1 = 0.f;
+            const uint32_t pr = xa_opaque(lbase + X::PART_OFF + (uint32_t)r * 48);
+            f32x4 A0 = xa_rd<f32x4>(pr), A1 = xa_rd<f32x4>(pr + 16), A2 = xa_rd<f32x4>(pr + 32);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x2_t x0 = xa_rd<f32x2_t>(pr + q * (PQ * 24)), x1 = xa_rd<f32x2_t>(pr + q * (PQ * 24) + 8), x2 = xa_rd<f32x2_t>(pr + q * (PQ * 24) + 16);
-                s1 += x0[0]; s2 += x0[1]; p1 += x1[0]; c2 += x1[1]; c1 += x2[0]; e1 += x2[1];
-            }
+            for (int q = 1; q < 4; ++q) { A0 += xa_rd<f32x4>(pr + q * (PQ * 48)); A1 += xa_rd<f32x4>(pr + q * (PQ * 48) + 16); A2 += xa_rd<f32x4>(pr + q * (PQ * 48) + 32); }
+            const float mean = A0[0] * (1.f / D);
+            const float var = fmaxf(A0[1] * (1.f / D) - mean * mean, 0.f);
+            const float k1n = __builtin_amdgcn_rsqf(var + a.eps), k2 = -mean * k1n, k1 = k1n * inv_l;
+            const float Q1 = A0[2], Q2 = A0[3], F1 = A1[0], F2 = A1[1], F3 = A1[2], F4 = A1[3], F5 = A2[0], F6 = A2[1], F7 = A2[2], B1 = A2[3];
+            const float s1 = k1 * F1 + k2 * mc[XC_BV] + mc[XC_AV];
+            const float s2 = k1 * k1 * Q1 + 2.f * k1 * (k2 * F2 + F3) + k2 * k2 * mc[XC_BV2] + 2.f * k2 * mc[XC_BVAV] + mc[XC_AV2];
+            const float p1 = k1 * B1 + k2 * pv4[2] + pv4[3];
+            const float c1 = k1 * F4 + k2 * mc[XC_G2BV] + mc[XC_G2AV];
+            const float c2 = k1 * k1 * Q2 + 2.f * k1 * (k2 * F5 + F6) + k2 * k2 * mc[XC_G2BV2] + 2.f * k2 * mc[XC_G2BVAV] + mc[XC_G2AV2];
+            const float e1 = k1 * F7 + k2 * mc[XC_GBBV] + mc[XC_GBAV];
             const float mu = s1 * (1.f / D);
-            const float var = fmaxf(s2 * (1.f / D) - mu * mu, 0.f);
-            const float rs = __builtin_amdgcn_rsqf(var + a.eps);
-            const float dot = rs * (p1 - mu * p0) + pb;
-            const float zz = rs * rs * (c2 - 2.f * mu * c1 + mu * mu * c0) + 2.f * rs * (e1 - mu * e0) + f0;
+            const float vy = fmaxf(s2 * (1.f / D) - mu * mu, 0.f);
+            const float rs = __builtin_amdgcn_rsqf(vy + a.eps);
+            const float dot = rs * (p1 - mu * pv4[0]) + pv4[1];
+            const float zz = rs * rs * (c2 - 2.f * mu * c1 + mu * mu * mc[XC_G2]) + 2.f * rs * (e1 - mu * mc[XC_GB]) + mc[XC_B2];
             if (n0 + r < a.Nv) a.sims[(n0 + r) * a.ld_sims + m] = dot * __builtin_amdgcn_rsqf(zz);
         }
+        XS_STAMP(14);
+        XS_STAMP(15);
         tk.s_eff = nx.s_eff; tk.first = nx.first; tk.w[0] = nx.w[0]; tk.w[1] = nx.w[1]; tk.w[2] = nx.w[2];
     }
 }
 
-// per video: gv = g3 * vn, (sum g3 vn, sum b3 vn); per model: sum g3^2, sum g3 b3, sum b3^2.  One wave per video.
+// per video: gv = g3 * vn, (sum gv, sum b3 vn, sum gv Bv, sum gv Av); per model: the XsConst sums.  One wave per video.
 template <int D>
-__global__ __launch_bounds__(256) void xpool_sims_prep_kernel(const float* vn, int64_t ldvn, const float* g3, const float* b3, float* ws, int64_t Nv) {
+__global__ __launch_bounds__(256) void xpool_sims_prep_kernel(const float* vn, int64_t ldvn, const float* g3, const float* b3, const float* av, const float* bv,
+                                                             float* ws, int64_t Nv) {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     static_assert(D == 256, "one f32x4 per lane");
     const f32x4 g = *(const f32x4*)(g3 + lane * 4), b = *(const f32x4*)(b3 + lane * 4);
+    const f32x4 A = *(const f32x4*)(av + lane * 4), B = *(const f32x4*)(bv + lane * 4);
     if (n < Nv) {
         const f32x4 v = *(const f32x4*)(vn + n * ldvn + lane * 4);
         f32x4 gvv;
-        float sg = 0.f, sb = 0.f;
+        float sg = 0.f, sb = 0.f, sgb = 0.f, sga = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { gvv[j] = g[j] * v[j]; sg += gvv[j]; sb += b[j] * v[j]; }
+        for (int j = 0; j < 4; ++j) { gvv[j] = g[j] * v[j]; sg += gvv[j]; sb += b[j] * v[j]; sgb += gvv[j] * B[j]; sga += gvv[j] * A[j]; }
         *(f32x4*)(ws + n * D + lane * 4) = gvv;
-        sg = wave_sum(sg); sb = wave_sum(sb);
-        if (lane == 0) { ws[xs_ws_pp(Nv, D) + n * 2] = sg; ws[xs_ws_pp(Nv, D) + n * 2 + 1] = sb; }
+        sg = wave_sum(sg); sb = wave_sum(sb); sgb = wave_sum(sgb); sga = wave_sum(sga);
+        if (lane == 0) *(f32x4*)(ws + xs_ws_pp(Nv, D) + n * 4) = (f32x4){sg, sb, sgb, sga};
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {
-        float c0 = 0.f, e0 = 0.f, f0 = 0.f;
+        float c[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { c0 += g[j] * g[j]; e0 += g[j] * b[j]; f0 += b[j] * b[j]; }
-        c0 = wave_sum(c0); e0 = wave_sum(e0); f0 = wave_sum(f0);
-        if (lane == 0) { float* cs = ws + xs_ws_c(Nv, D); cs[0] = c0; cs[1] = e0; cs[2] = f0; cs[3] = 0.f; }
+        for (int q = 0; q < 16; ++q) c[q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g2 = g[j] * g[j], gb = g[j] * b[j];
+            c[XC_G2] += g2; c[XC_GB] += gb; c[XC_B2] += b[j] * b[j];
+            c[XC_BV] += B[j]; c[XC_AV] += A[j]; c[XC_BV2] += B[j] * B[j]; c[XC_BVAV] += B[j] * A[j]; c[XC_AV2] += A[j] * A[j];
+            c[XC_G2BV] += g2 * B[j]; c[XC_G2AV] += g2 * A[j]; c[XC_G2BV2] += g2 * B[j] * B[j]; c[XC_G2BVAV] += g2 * B[j] * A[j]; c[XC_G2AV2] += g2 * A[j] * A[j];
+            c[XC_GBBV] += gb * B[j]; c[XC_GBAV] += gb * A[j];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const float t = wave_sum(c[q]); if (lane == 0) ws[xs_ws_c(Nv, D) + q] = t; }
     }
 }
 
@@ -1292,7 +1324,8 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     MADE_UNSUPPORTED(a.Nm <= 65535, "made_xpool_sims: more than 65535 tracks per call (chunk them)");
     MADE_UNSUPPORTED(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldu % 8 == 0 && a.k_bs % 8 == 0 && a.u_bs % 8 == 0 && a.ldvn % 4 == 0 &&
                      ((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.UU % 16) == 0 && ((uintptr_t)a.vn % 16) == 0 &&
-                     ((uintptr_t)a.ws % 16) == 0 && ((uintptr_t)a.ln3_g % 16) == 0 && ((uintptr_t)a.ln3_b % 16) == 0,
+                     ((uintptr_t)a.ws % 16) == 0 && ((uintptr_t)a.ln3_g % 16) == 0 && ((uintptr_t)a.ln3_b % 16) == 0 && ((uintptr_t)a.av % 16) == 0 &&
+                     ((uintptr_t)a.bv % 16) == 0,
                      "made_xpool_sims: pointers / strides must keep 16-byte alignment");
     MADE_UNSUPPORTED(a.ldu >= 2 * a.D && (uint64_t)a.S * (uint64_t)a.ldk * 2 < (1ull << 32) && (uint64_t)a.S * (uint64_t)a.ldu * 2 < (1ull << 32),
                      "made_xpool_sims: value rows hold u | u'' (ldu >= 2 D); a track's K / value rows must each span less than 4 GB");
@@ -1311,7 +1344,7 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     }
     float* wsf = (float*)a.ws;
     if (a.prepare_ws)
-        hipLaunchKernelGGL(xpool_sims_prep_kernel<D>, dim3((unsigned)((a.Nv + 3) / 4)), dim3(256), 0, st, a.vn, a.ldvn, a.ln3_g, a.ln3_b, wsf, a.Nv);
+        hipLaunchKernelGGL(xpool_sims_prep_kernel<D>, dim3((unsigned)((a.Nv + 3) / 4)), dim3(256), 0, st, a.vn, a.ldvn, a.ln3_g, a.ln3_b, a.av, a.bv, wsf, a.Nv);
     int* info = (int*)(wsf + xs_ws_info(a.Nv, D));
     hipLaunchKernelGGL(xpool_attn_info_kernel, dim3((unsigned)((a.Nm + 3) / 4)), dim3(256), 0, st, a.key_mask, a.S, a.Nm, info);
     // chunks of tracks per video tile: enough workgroups to fill the chip a few times over, as few partial rounds as possible (a workgroup's

@@ -26,7 +26,7 @@ torch.cuda.synchronize()
 st = sims.view(-1)[:8 * 32 * 16 * 2].view(torch.int64).view(8, 32, 16).cpu()
 NWAVES = 4 if K32 else 8
 names32 = ["wait K", "barrier A", "scores", "barrier B", "issue U 0,1", "mask + max", "barrier C", "exp + P", "second product", "barrier D", "next info + K issue",
-           "tail 1", "barrier", "tail 2", "barrier"]
+           "partial sums", "barrier", "pair (1 wave)", "-"]
 names = names32 if K32 else ["wait K", "barrier A", "scores", "barrier B", "next info + K / h4,5 issue", "mask + max", "barrier C", "exp + P", "second product", "tail 1", "barrier B1",
          "issue U (+K)", "tail 2", "barrier B2", "tail 3 / store"]
 print(f"track lengths: {lens[:32].tolist()}")
