@@ -8,6 +8,8 @@ def kind(name):
         return ("linear_big_kernel<256>" if ("ILi256E" in name or "<256" in name) else "linear_big_kernel<128>"), True
     if "xpool_attn_kernel" in name:
         return "xpool_attention", True
+    if "xpool_sims32_kernel" in name or "xpool_sims_kernel" in name:
+        return "xpool_sims", True
     if "linear_glds_kernelILi1" in name or "linear_glds_kernel<1" in name:
         return ("linear_glds_kernel<1,.,64>" if ("ELi64E" in name or ", 64>" in name) else "linear_glds_kernel<1,.,128>"), True
     if "linear_glds_kernel" in name:
