@@ -1373,7 +1373,13 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
             attr32 = true;
         }
         const int64_t nvt32 = (a.Nv + 31) / 32;
-        const int64_t c_lo = (a.Nm + Xs32<D>::MAX_TRACKS - 1) / Xs32<D>::MAX_TRACKS;
+        // Chunks of at most 64 tracks: the workgroups of an XCD walk a chunk together and share its rows through that XCD's L2 -- the shorter the
+        // chunk, the less they drift apart.  53 k x 4 k (profiles/r04_ao_*): 464 tracks per chunk 56.4 ms with 66 GB of L2 misses per launch, 128: 56.2 ms /
+        // 56 GB, 64: 57.2 ms / 31 GB, 32: 59.2 ms / 26 GB (a workgroup's prologue -- Q, g3 vn, the constant fragments -- costs about two tracks).
+        int64_t max_per = 64;
+        if (getenv("MADE_XPOOL_SIMS_PER") && atoi(getenv("MADE_XPOOL_SIMS_PER")) > 0) max_per = atoi(getenv("MADE_XPOOL_SIMS_PER"));
+        if (max_per > Xs32<D>::MAX_TRACKS) max_per = Xs32<D>::MAX_TRACKS;
+        const int64_t c_lo = (a.Nm + max_per - 1) / max_per;
         double best = 1e30; int64_t bc = c_lo;
         for (int64_t cch = c_lo; cch <= c_lo + 24 && cch <= a.Nm; ++cch) {
             const int64_t pr = (a.Nm + cch - 1) / cch, rounds = (nvt32 * ((a.Nm + pr - 1) / pr) + 511) / 512;

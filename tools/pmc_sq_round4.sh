@@ -19,5 +19,5 @@ run_target attention "attention_kernel,attn_bwd_dq_kernel,attn_bwd_dkv_kernel" p
 run_target xpool_fused "xpool_fused_persist_kernel" python3 $R/tools/xpool_only.py 8192 512
 # the training step's dominant family (encoder-sized Linears, tools/linear_tiles_bench.py: plain / residual / gathered rows) and the opt-in retrieval kernel
 MADE_LINEAR_TILE=64 run_target linear_glds "linear_glds_kernel" python3 $R/tools/linear_tiles_bench.py
-run_target xpool_sims "xpool_sims96_kernel" python3 $R/tools/xpool_sims_bench.py 8192 512 96
+run_target xpool_sims "xpool_sims32_kernel" python3 $R/tools/xpool_sims_bench.py 8192 512 96
 cat $O/sq_counters_attention.txt $O/sq_counters_xpool_fused.txt $O/sq_counters_linear_glds.txt $O/sq_counters_xpool_sims.txt
