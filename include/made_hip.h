@@ -515,7 +515,7 @@ typedef struct MadeXpoolAttnArgs {
 
 int made_xpool_attention(const MadeXpoolAttnArgs* args, void* stream);
 
-/* made_xpool_sims: all-pairs X-Pool scoring with the per-pair Linear moved onto the values (round 4; D = 256, S <= 512).  The chain of
+/* made_xpool_sims: all-pairs X-Pool scoring with the per-pair Linear moved onto the values (round 4; D = 256, tracks of at most 96 segments).  The chain of
  * reference modules/transformer.py:156-180 + modules/metrics.py:10-24 after the attention is
  *   y = W'' xhat + b'',  xhat = (o - mean(o)) rstd(o),  W'' = (W + I) diag(g2), b'' = (W + I) b2 + b          (LayerNorm2 + Linear + residual)
  * and o = sum_s p_s u_s is a convex combination of the track's value rows, so W'' o = sum_s p_s (W'' u_s): with u''_s = W'' u_s made ONCE per

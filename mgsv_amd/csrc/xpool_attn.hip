@@ -432,125 +432,10 @@ int launch_xpool_attn(const MadeXpoolAttnArgs& a, const int* info, dim3 grid, in
 // ================================================================================================================================
 // made_xpool_sims (round 4): the two passes above with value rows of width 2 D -- u_s | u''_s, u'' = W'' u -- and the whole rest of the pair
 // chain in the tail, so that the per-pair Linear (2 D^2 flops, 70 % of made_xpool_fused's work at S = 96) is a second P.V product (2 S D)
-// and nothing per pair leaves the chip but its similarity.  D = 256: K tiles are XaCfg<256>'s, value half tiles XaCfg<512>'s (one row = one
-// 1 KB LDS-DMA piece); the four K stages and the ring of four value half tiles are the same 64 KB, the probabilities have their own 65 KB.
-//   pass 2   wave w owns rows [32 w, 32 w + 32) of o (column group w of the value rows) and the same rows of z = P.U'' (column group 8 + w):
-//            every wave takes an equal share of both halves of the tail;
-//   tail 1   o / l: sum and sum of squares over the wave's rows -> LDS (LayerNorm2's statistics), z / l;
-//   tail 2   k1, k2 from the eight partial statistics; y = k1 z + k2 Bv + Av in registers and the six sums of LayerNorm3 + cosine
-//            (made_xpool_fused's rule: sum y, sum y^2, sum y g3 vn, sum y^2 g3^2, sum y g3^2, sum y g3 b3) over the wave's rows -> LDS;
-//   tail 3   one wave (they take turns) adds the eight partial sextuples of the 64 videos and writes sims[n, m].
+// and nothing per pair leaves the chip but its similarity.  D = 256, tracks of at most 96 segments (the retrieval set): K tiles are XaCfg<256>'s,
+// value half tiles XaCfg<512>'s (one row = one 1 KB LDS-DMA piece).  Longer tracks stay on made_xpool_fused: a 64-video / eight-wave form of these
+// passes for up to 512 segments existed (commit 4819965) and was not faster there.
 
-// ---- the tail of made_xpool_sims, shared by its kernels.  STAT / PART / VEC / SUM are LDS byte offsets of the kernel's map.
-// tail 1: o / l of this wave's 32 rows: sum and sum of squares per video -> STAT[wave][video]; z / l in place
-template <int SUM_OFF, int STAT_OFF>
-__device__ __forceinline__ void xs_tail1(f32x16 (&oacc)[2][2], uint32_t lbase, int wave, int r, int hh) {
-#pragma unroll
-    for (int vt = 0; vt < 2; ++vt) {
-        float l = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) l += xa_rd<float>(lbase + SUM_OFF + (uint32_t)(q * XA_PQ + 32 * vt + r) * 4);
-        const float inv_l = 1.f / l;
-        float su = 0.f, sq = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float x = oacc[0][vt][e] * inv_l;
-            su += x; sq = __builtin_fmaf(x, x, sq);
-            oacc[1][vt][e] *= inv_l;
-        }
-        su += xa_other_half(su); sq += xa_other_half(sq);
-        if (hh == 0) xa_wr<f32x2_t>(lbase + STAT_OFF + (uint32_t)((wave * XA_PQ + 32 * vt + r) * 8), (f32x2_t){su, sq});
-    }
-}
-// tail 2: k1, k2 from the eight partial statistics; y = k1 z + k2 Bv + Av and the six sums of LayerNorm3 + cosine over this wave's rows -> PART
-template <int D, int STAT_OFF, int PART_OFF, int VEC_OFF>
-__device__ __forceinline__ void xs_tail2(const f32x16 (&oacc)[2][2], const f32x4 (&gv)[2][4], uint32_t lbase, int wave, int r, int hh, float eps) {
-    const uint32_t vec_r = xa_opaque(lbase + VEC_OFF + (uint32_t)(32 * wave + 4 * hh) * 4);
-#pragma unroll
-    for (int vt = 0; vt < 2; ++vt) {
-        f32x2_t st = xa_rd<f32x2_t>(lbase + STAT_OFF + (uint32_t)((32 * vt + r) * 8));
-#pragma unroll
-        for (int q = 1; q < 8; ++q) st += xa_rd<f32x2_t>(lbase + STAT_OFF + (uint32_t)((q * XA_PQ + 32 * vt + r) * 8));
-        const float mean = st[0] * (1.f / D);
-        const float var = fmaxf(st[1] * (1.f / D) - mean * mean, 0.f);
-        const float k1 = __builtin_amdgcn_rsqf(var + eps), k2 = -mean * k1;
-        f32x2_t s1 = {0.f, 0.f}, s2 = {0.f, 0.f}, p1 = {0.f, 0.f}, c2 = {0.f, 0.f}, c1 = {0.f, 0.f}, e1 = {0.f, 0.f};
-        const f32x2_t k1v = {k1, k1}, k2v = {k2, k2};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 av = xa_rd<f32x4>(vec_r + g * 32), bv = xa_rd<f32x4>(vec_r + D * 4 + g * 32);
-            const f32x4 g2 = xa_rd<f32x4>(vec_r + 2 * D * 4 + g * 32), gb = xa_rd<f32x4>(vec_r + 3 * D * 4 + g * 32);
-#pragma unroll
-            for (int jj = 0; jj < 4; jj += 2) {
-                const f32x2_t z2 = {oacc[1][vt][4 * g + jj], oacc[1][vt][4 * g + jj + 1]};
-                const f32x2_t yv = z2 * k1v + ((f32x2_t){bv[jj], bv[jj + 1]} * k2v + (f32x2_t){av[jj], av[jj + 1]});
-                const f32x2_t yy = yv * yv;
-                const f32x2_t gg = {g2[jj], g2[jj + 1]};
-                s1 += yv; s2 += yy;
-                p1 += yv * (f32x2_t){gv[vt][g][jj], gv[vt][g][jj + 1]};
-                c2 += yy * gg; c1 += yv * gg;
-                e1 += yv * (f32x2_t){gb[jj], gb[jj + 1]};
-            }
-        }
-        float S1 = s1[0] + s1[1], S2 = s2[0] + s2[1], P1 = p1[0] + p1[1], C2 = c2[0] + c2[1], C1 = c1[0] + c1[1], E1 = e1[0] + e1[1];
-        S1 += xa_other_half(S1); S2 += xa_other_half(S2); P1 += xa_other_half(P1);
-        C2 += xa_other_half(C2); C1 += xa_other_half(C1); E1 += xa_other_half(E1);
-        if (hh == 0) {
-            const uint32_t pw = lbase + PART_OFF + (uint32_t)((wave * XA_PQ + 32 * vt + r) * 24);
-            xa_wr<f32x2_t>(pw, (f32x2_t){S1, S2}); xa_wr<f32x2_t>(pw + 8, (f32x2_t){P1, C2}); xa_wr<f32x2_t>(pw + 16, (f32x2_t){C1, E1});
-        }
-    }
-}
-// tail 3 (one wave, lane = video): the eight partial sextuples -> LayerNorm3 + cosine (made_xpool_fused's rule)
-template <int D, int PART_OFF>
-__device__ __forceinline__ float xs_tail3(uint32_t lbase, int lane, float eps, float p0, float pb, float c0, float e0, float f0) {
-    const uint32_t pr = xa_opaque(lbase + PART_OFF + (uint32_t)lane * 24);
-    float s1 = 0.f, s2 = 0.f, p1 = 0.f, c2 = 0.f, c1 = 0.f, e1 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const f32x2_t x0 = xa_rd<f32x2_t>(pr + q * (XA_PQ * 24)), x1 = xa_rd<f32x2_t>(pr + q * (XA_PQ * 24) + 8), x2 = xa_rd<f32x2_t>(pr + q * (XA_PQ * 24) + 16);
-        s1 += x0[0]; s2 += x0[1]; p1 += x1[0]; c2 += x1[1]; c1 += x2[0]; e1 += x2[1];
-    }
-    const float mu = s1 * (1.f / D);
-    const float var = fmaxf(s2 * (1.f / D) - mu * mu, 0.f);
-    const float rs = __builtin_amdgcn_rsqf(var + eps);
-    const float dot = rs * (p1 - mu * p0) + pb;
-    const float zz = rs * rs * (c2 - 2.f * mu * c1 + mu * mu * c0) + 2.f * rs * (e1 - mu * e0) + f0;
-    return dot * __builtin_amdgcn_rsqf(zz);
-}
-// counted wait for LDS-DMA pieces, any even count up to 16 (immediates)
-__device__ __forceinline__ void xs_wait_vm(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    }
-}
-
-template <int D, int NTI> struct XsCfg {
-    using CK = XaCfg<D>;
-    using CU = XaCfg<2 * D>;
-    static constexpr int SMAX = NTI * 128;                       // segments per track this instantiation serves
-    static constexpr int PP = SMAX * 2 + 16;                     // pitch of a video's probability row (16 mod 256: conflict-free 16-byte reads)
-    static constexpr int P_OFF = 4 * CK::STG;
-    static constexpr int MAX_OFF = P_OFF + XA_PQ * PP;
-    static constexpr int SUM_OFF = MAX_OFF + 4 * XA_PQ * 4;
-    static constexpr int STAT_OFF = SUM_OFF + 4 * XA_PQ * 4;     // [8][64][2] f32
-    static constexpr int PART_OFF = STAT_OFF + 8 * XA_PQ * 8;    // [8][64][6] f32
-    static constexpr int VEC_OFF = PART_OFF + 8 * XA_PQ * 24;    // [4][D] f32: Av, Bv, g3^2, g3 b3
-    static constexpr int TBL_OFF = VEC_OFF + 4 * D * 4;          // NTI = 1: the chunk's track table, 8 ints per track (s_eff, first, -, -, 4 words of valid bits)
-    static constexpr int LDS_FIXED = TBL_OFF;
-    static constexpr int MAX_TRACKS = NTI == 1 ? (160 * 1024 - LDS_FIXED) / 32 : 65535;
-    static_assert(4 * CK::STG == 4 * CU::HSTG, "the K stages and the value ring share their LDS");
-    static_assert(CU::NDT == 2 && CU::PH >= 1 && CK::PB >= 1 && CK::PT == 16, "tile split");
-    static_assert(LDS_FIXED <= 160 * 1024 && (NTI == 4 || MAX_TRACKS >= 512), "made_xpool_sims: the LDS map does not fit a CU");
-};
 // workspace (floats): gv = g3 * vn [Nv][D]; per video (sum gv, sum b3 vn, sum gv Bv, sum gv Av) [Nv][4]; sixteen model constants (XsConst); 32 ints per track
 __host__ __device__ inline int64_t xs_ws_pp(int64_t Nv, int64_t D) { return Nv * D; }
 __host__ __device__ inline int64_t xs_ws_c(int64_t Nv, int64_t D) { return Nv * (D + 4); }
@@ -558,328 +443,9 @@ __host__ __device__ inline int64_t xs_ws_info(int64_t Nv, int64_t D) { return Nv
 // model constants: with g2 = g3^2, gb = g3 b3 and the folded Linear's vectors Av, Bv (y = k1 z + k2 Bv + Av)
 enum XsConst { XC_G2 = 0, XC_GB, XC_B2, XC_BV, XC_AV, XC_BV2, XC_BVAV, XC_AV2, XC_G2BV, XC_G2AV, XC_G2BV2, XC_G2BVAV, XC_G2AV2, XC_GBBV, XC_GBAV };
 
-// NTI: 32-segment score tiles per wave.  NTI = 1 (tracks of at most 128 segments: the retrieval set's 96): every K tile of a track is resident at
-// once and the eight waves take one (video half, tile) unit each; the chunk's track table lives in LDS -- with two or three tiles per track a
-// global load of the track's length or valid bits in front of each LDS-DMA batch (five to eight dependent round trips per track) cost more
-// than the track's arithmetic.  NTI = 4 (at most 512 segments): made_xpool_attention's batches of two tiles, table in global memory.
-template <int D, int NTI>
-__global__ __launch_bounds__(XA_T, 1) void xpool_sims_kernel(const MadeXpoolSimsArgs a, const int* __restrict__ info, int tracks_per_chunk) {
-    using X = XsCfg<D, NTI>;
-    using CK = typename X::CK;
-    using CU = typename X::CU;
-    constexpr int PP = X::PP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
-    const int vh = wave & 1, jw = wave >> 1, grp = jw >> 1;
-    const int64_t n0 = (int64_t)blockIdx.x * XA_PQ;
-    const int64_t m_begin = (int64_t)blockIdx.y * tracks_per_chunk;
-    const int64_t m_end = (m_begin + tracks_per_chunk < a.Nm) ? m_begin + tracks_per_chunk : a.Nm;
-    if (m_begin >= m_end) return;
-    const int T = (int)(m_end - m_begin);
-    const uint32_t lbase = (uint32_t)(uintptr_t)(lds3_t)lds;
-    const float* wsf = (const float*)a.ws;
-
-    // ---- Q rows of this wave's 32 videos (pass 1's B operand)
-    bf16x8 qf[CK::NQF];
-    {
-        const int64_t n = n0 + 32 * vh + r;
-        const bf16_t* qp = (const bf16_t*)a.Q + (n < a.Nv ? n : a.Nv - 1) * a.ldq + hh * 8;
-#pragma unroll
-        for (int ks = 0; ks < CK::NQF; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-    }
-    // ---- g3 * vn of this lane's videos (r, 32 + r) at the rows its accumulators of the z tile hold: 32 w + 8 g + 4 hh + (0..3)
-    f32x4 gv[2][4];
-#pragma unroll
-    for (int vt = 0; vt < 2; ++vt) {
-        const int64_t n = n0 + 32 * vt + r;
-        const float* gp = wsf + (n < a.Nv ? n : a.Nv - 1) * D + 32 * wave + 4 * hh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gv[vt][g] = *(const f32x4*)(gp + 8 * g);
-    }
-    // ---- tail 3's per-video terms (video = lane) and the model's three constants
-    float p0, pb;
-    {
-        const int64_t n = n0 + lane;
-        const float* pp = wsf + xs_ws_pp(a.Nv, D) + (n < a.Nv ? n : a.Nv - 1) * 4;
-        p0 = pp[0]; pb = pp[1];
-    }
-    const float c0 = wsf[xs_ws_c(a.Nv, D)], e0 = wsf[xs_ws_c(a.Nv, D) + 1], f0 = wsf[xs_ws_c(a.Nv, D) + 2];
-    if (tid < D) {
-        float* vec = (float*)(lds + X::VEC_OFF);
-        const float g3 = a.ln3_g[tid], b3 = a.ln3_b[tid];
-        vec[tid] = a.av[tid]; vec[D + tid] = a.bv[tid]; vec[2 * D + tid] = g3 * g3; vec[3 * D + tid] = g3 * b3;
-    }
-    if constexpr (NTI == 1) {
-        for (int i = tid; i < T; i += XA_T) {
-            const int* ip = info + (m_begin + i) * XA_INFO;
-            *(u32x4*)(lds + X::TBL_OFF + i * 32) = (u32x4){(unsigned)ip[0], (unsigned)ip[1], 0u, 0u};
-            *(u32x4*)(lds + X::TBL_OFF + i * 32 + 16) = *(const u32x4*)(ip + 16);
-        }
-    }
-    const float c = a.scale * 1.4426950408889634f;
-
-    // a track's description: s_eff (last valid + 1), first valid segment, valid bits of its (first four) 32-segment tiles -- wave-uniform
-    struct Trk { int s_eff, first; unsigned w[4]; };
-    auto load_track = [&](int jt_, Trk& t) __attribute__((always_inline)) {
-        if constexpr (NTI == 1) {
-            const u32x4 h = xa_rd<u32x4>(lbase + X::TBL_OFF + (uint32_t)jt_ * 32), wv = xa_rd<u32x4>(lbase + X::TBL_OFF + (uint32_t)jt_ * 32 + 16);
-            t.s_eff = __builtin_amdgcn_readfirstlane((int)h[0]); t.first = __builtin_amdgcn_readfirstlane((int)h[1]);
-            t.w[0] = __builtin_amdgcn_readfirstlane(wv[0]); t.w[1] = __builtin_amdgcn_readfirstlane(wv[1]);
-            t.w[2] = __builtin_amdgcn_readfirstlane(wv[2]); t.w[3] = __builtin_amdgcn_readfirstlane(wv[3]);
-        } else {
-            const int* ip = info + (m_begin + jt_) * XA_INFO;
-            t.s_eff = __builtin_amdgcn_readfirstlane(ip[0]); t.first = __builtin_amdgcn_readfirstlane(ip[1]);
-            t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0u;
-        }
-    };
-    auto tile_word = [&](int64_t m, const Trk& t, int tile) __attribute__((always_inline)) -> unsigned {
-        if constexpr (NTI == 1) return tile == 0 ? t.w[0] : tile == 1 ? t.w[1] : tile == 2 ? t.w[2] : t.w[3];
-        else return ((const unsigned*)info + m * XA_INFO)[16 + tile];
-    };
-
-    const uint32_t ldk_b = (uint32_t)a.ldk * 2u, ldu_b = (uint32_t)a.ldu * 2u;
-    // NTI = 4: K tiles 2b, 2b + 1 -> stages (2b) & 3, (2b + 1) & 3 (made_xpool_attention's batches)
-    auto issue_k = [&](int64_t m, int b, const Trk& tk) __attribute__((always_inline)) {
-        const uint32_t rip = (uint32_t)lane / CK::CPR, slot = (uint32_t)lane % CK::CPR;
-        const unsigned char* Kb = (const unsigned char*)a.K + m * a.k_bs * 2;
-#pragma unroll
-        for (int i = 0; i < CK::PB; ++i) {
-            const int p = wave * CK::PB + i;
-            const int t = 2 * b + p / CK::PT, pit = p % CK::PT;
-            const unsigned word = tile_word(m, tk, t);
-            const uint32_t row = (uint32_t)pit * CK::RPP + rip;
-            const int seg = t * 32 + (int)row;
-            const bool valid = seg < tk.s_eff && ((word >> row) & 1u);
-            const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
-            const uint32_t chunk = slot ^ (row & 15u);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kb + (size_t)(srow * ldk_b + chunk * 16u)), (lds_ptr_t)(lds + (t & 3) * CK::STG + pit * 1024), 16, 0, 0);
-        }
-    };
-    // NTI = 1: every tile of the track at once; wave w brings half of tile w >> 1 (eight pieces) if the track has that tile
-    auto issue_k_all = [&](int64_t m, const Trk& tk) __attribute__((always_inline)) {
-        const int t = wave >> 1;
-        if (t * 32 < (tk.s_eff > 0 ? tk.s_eff : 1)) {
-            const uint32_t rip = (uint32_t)lane / CK::CPR, slot = (uint32_t)lane % CK::CPR;
-            const unsigned char* Kb = (const unsigned char*)a.K + m * a.k_bs * 2;
-            const unsigned word = tile_word(m, tk, t);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int pit = (wave & 1) * 8 + i;
-                const uint32_t row = (uint32_t)pit * CK::RPP + rip;
-                const int seg = t * 32 + (int)row;
-                const bool valid = seg < tk.s_eff && ((word >> row) & 1u);
-                const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
-                const uint32_t chunk = slot ^ (row & 15u);
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kb + (size_t)(srow * ldk_b + chunk * 16u)), (lds_ptr_t)(lds + t * CK::STG + pit * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto issue_u = [&](int64_t m, int h, const Trk& tk) __attribute__((always_inline)) {
-        const uint32_t rip = (uint32_t)lane / CU::CPR, slot = (uint32_t)lane % CU::CPR;
-        const unsigned char* Ub = (const unsigned char*)a.UU + m * a.u_bs * 2;
-        const unsigned word = tile_word(m, tk, h >> 1);
-#pragma unroll
-        for (int i = 0; i < CU::PH; ++i) {
-            const int p = wave * CU::PH + i;
-            const uint32_t row = (uint32_t)p * CU::RPP + rip;
-            const int seg = h * 16 + (int)row;
-            const bool valid = seg < tk.s_eff && ((word >> ((h & 1) * 16 + row)) & 1u);
-            const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
-            const uint32_t chunk = (((slot >> 2) ^ (row & 7u)) << 2) | (slot & 3u);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ub + (size_t)(srow * ldu_b + chunk * 16u)), (lds_ptr_t)(lds + (h & 3) * CU::HSTG + p * 1024), 16, 0, 0);
-        }
-    };
-
-    const uint32_t k_rd = lbase + (uint32_t)r * CK::ROWB;
-    const uint32_t ksw = (uint32_t)(r & 15);
-    const int g4 = lane >> 4, i16 = lane & 15;
-    const uint32_t trow = 4 * (g4 >> 1) + (i16 >> 2);
-    const uint32_t u_rd = lbase + trow * CU::ROWB + (g4 & 1) * 32 + (i16 & 3) * 8;
-    const uint32_t p_wr = lbase + X::P_OFF + (uint32_t)(32 * vh + r) * PP + hh * 16;
-    const uint32_t p_rd = lbase + X::P_OFF + (uint32_t)r * PP + hh * 16;
-
-    __builtin_amdgcn_s_waitcnt(0x0070);                            // the Q rows and g3 vn have landed
-    if constexpr (NTI == 1) __syncthreads();                       // ... and the track table
-    Trk tk;
-    load_track(0, tk);
-    if constexpr (NTI == 1) issue_k_all(m_begin, tk);
-    else {
-        const int nb0 = ((tk.s_eff > 0 ? (tk.s_eff + 31) / 32 : 1) + 1) / 2;
-        issue_k(m_begin, 0, tk);
-        if (nb0 > 1) issue_k(m_begin, 1, tk);
-    }
-
-    for (int jt = 0; jt < T; ++jt) {
-        const int64_t m = m_begin + jt;
-        const int s_eff = tk.s_eff;
-        const int ntiles = s_eff > 0 ? (s_eff + 31) / 32 : 1;
-        const int NB = (ntiles + 1) / 2;
-        const int NH = s_eff > 0 ? (s_eff + 15) / 16 : 1;
-
-        // ================================================================================================ pass 1: scores
-        f32x16 sacc[NTI];
-#pragma unroll
-        for (int ti = 0; ti < NTI; ++ti)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[ti][e] = 0.f;
-        auto score_tile = [&](int ti, int stage) __attribute__((always_inline)) {
-            // fragment ks of K row r is 16-byte chunk (2 ks + hh) ^ (r & 15) of the row: eight per-lane address registers made from an opaque
-            // base, the rest in the instruction's immediate offset; reads run four fragments ahead of their MFMAs
-            const uint32_t kx = xa_opaque(k_rd + (uint32_t)stage * CK::STG + (((uint32_t)hh ^ ksw) << 4));
-            uint32_t ka[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) ka[q] = kx ^ (uint32_t)(q << 5);
-            bf16x8 f[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) f[ks] = xa_read128(ka[ks]);
-#pragma unroll
-            for (int ks = 0; ks < CK::NQF; ++ks) {
-                if (ks + 3 < CK::NQF) xa_wait_lgkm<3>(f[ks & 3]);
-                else if (ks + 2 < CK::NQF) xa_wait_lgkm<2>(f[ks & 3]);
-                else if (ks + 1 < CK::NQF) xa_wait_lgkm<1>(f[ks & 3]);
-                else xa_wait_lgkm<0>(f[ks & 3]);
-                sacc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 3], qf[ks], sacc[ti], 0, 0, 0);
-                if (ks + 4 < CK::NQF) {
-                    switch ((ks + 4) >> 3) {
-                        case 0: f[ks & 3] = xa_read128_off<0>(ka[(ks + 4) & 7]); break;
-                        case 1: f[ks & 3] = xa_read128_off<256>(ka[(ks + 4) & 7]); break;
-                        case 2: f[ks & 3] = xa_read128_off<512>(ka[(ks + 4) & 7]); break;
-                        default: f[ks & 3] = xa_read128_off<768>(ka[(ks + 4) & 7]); break;
-                    }
-                }
-            }
-        };
-        if constexpr (NTI == 1) {
-            xa_wait_vm(0);                                          // this wave's K pieces (and whatever it stored for the last track)
-            XA_BARRIER();
-            if (jw < ntiles) score_tile(0, jw);
-            XA_BARRIER();                                           // the K stages are free: they become the value ring
-        } else {
-            xa_wait_vm(NB > 1 ? CK::PB : 0);
-            XA_BARRIER();
-#pragma unroll
-            for (int ti = 0; ti < NTI; ++ti) {
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    const int b = 2 * ti + bb;
-                    if (b < NB) {
-                        if (grp == bb) score_tile(ti, 2 * bb + (jw & 1));
-                        if (b + 1 < NB) xa_wait_vm(0);
-                        XA_BARRIER();
-                        if (b + 2 < NB) issue_k(m, b + 2, tk);
-                    }
-                }
-            }
-        }
-        // every K tile is consumed: the ring's first value half tiles go out into the K stages and fly under the softmax
-        issue_u(m, 0, tk);
-        if (NH > 1) issue_u(m, 1, tk);
-        if (NH > 2) issue_u(m, 2, tk);
-
-        float mx = -INFINITY;
-#pragma unroll
-        for (int ti = 0; ti < NTI; ++ti) {
-            const int t = jw + 4 * ti;
-            if (t < ntiles) {
-                const unsigned word = tile_word(m, tk, t) >> (4 * hh);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float s = ((word >> ((e & 3) + 8 * (e >> 2))) & 1u) ? sacc[ti][e] * c : -INFINITY;
-                    sacc[ti][e] = s;
-                    mx = fmaxf(mx, s);
-                }
-            }
-        }
-        mx = fmaxf(mx, xa_other_half(mx));
-        if (hh == 0) xa_wr<float>(lbase + X::MAX_OFF + (uint32_t)(jw * XA_PQ + 32 * vh + r) * 4, mx);
-        XA_BARRIER();
-        float M = xa_rd<float>(lbase + X::MAX_OFF + (uint32_t)(32 * vh + r) * 4);
-#pragma unroll
-        for (int q = 1; q < 4; ++q) M = fmaxf(M, xa_rd<float>(lbase + X::MAX_OFF + (uint32_t)(q * XA_PQ + 32 * vh + r) * 4));
-        float psum = 0.f;
-#pragma unroll
-        for (int ti = 0; ti < NTI; ++ti) {
-            const int t = jw + 4 * ti;
-            if (t < ntiles) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const float p = __builtin_amdgcn_exp2f(sacc[ti][8 * s2 + jj] - M);
-                        psum += p;
-                        pf[jj] = (bf16_t)p;
-                    }
-                    xa_wr<bf16x8>(p_wr + (uint32_t)(2 * t + s2) * 32, pf);
-                }
-            }
-        }
-        psum += xa_other_half(psum);
-        if (hh == 0) xa_wr<float>(lbase + X::SUM_OFF + (uint32_t)(jw * XA_PQ + 32 * vh + r) * 4, psum);
-
-        // ================================================================================================ pass 2: [O | Z]^T = [U | U'']^T P^T
-        f32x16 oacc[2][2];                                          // [0]: rows 32 w .. of o, [1]: the same rows of z; [.][video tile]
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[dt][vt][e] = 0.f;
-        for (int h = 0; h < NH; ++h) {
-            const int ahead = NH - 1 - h;
-            xa_wait_vm((ahead >= 2 ? 2 : ahead) * CU::PH);
-            XA_BARRIER();                                           // (the first one also publishes the probabilities and their sums)
-            if (h + 3 < NH) issue_u(m, h + 3, tk);
-            const uint32_t ub = u_rd + (uint32_t)(h & 3) * CU::HSTG;
-            bf16x8 pb0 = xa_read128(p_rd + (uint32_t)h * 32), pb1 = xa_read128(p_rd + 32 * PP + (uint32_t)h * 32);
-            bf16x4 lo[2], hi[2];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const uint32_t va = ub + ((((uint32_t)(8 * dt + wave)) ^ (trow & 7u)) << 6);
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[dt]) : "v"(va));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(va), "n"(8 * CU::ROWB));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb0), "+v"(pb1), "+v"(lo[0]), "+v"(lo[1]), "+v"(hi[0]), "+v"(hi[1]));
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 uf = __builtin_shufflevector(lo[dt], hi[dt], 0, 1, 2, 3, 4, 5, 6, 7);
-                oacc[dt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pb0, oacc[dt][0], 0, 0, 0);
-                oacc[dt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pb1, oacc[dt][1], 0, 0, 0);
-            }
-        }
-        XA_BARRIER();                                               // value ring and probabilities are free
-
-        // ---- the next track's K tiles go out before the tail
-        Trk nx; nx.s_eff = 0; nx.first = 0; nx.w[0] = nx.w[1] = nx.w[2] = nx.w[3] = 0u;
-        if (jt + 1 < T) {
-            load_track(jt + 1, nx);
-            if constexpr (NTI == 1) issue_k_all(m + 1, nx);
-            else {
-                const int nbn = ((nx.s_eff > 0 ? (nx.s_eff + 31) / 32 : 1) + 1) / 2;
-                issue_k(m + 1, 0, nx);
-                if (nbn > 1) issue_k(m + 1, 1, nx);
-            }
-        }
-
-        // ================================================================================================ tail
-        xs_tail1<X::SUM_OFF, X::STAT_OFF>(oacc, lbase, wave, r, hh);
-        XA_BARRIER();
-        xs_tail2<D, X::STAT_OFF, X::PART_OFF, X::VEC_OFF>(oacc, gv, lbase, wave, r, hh, a.eps);
-        XA_BARRIER();
-        if (wave == (jt & 7)) {
-            const float out = xs_tail3<D, X::PART_OFF>(lbase, lane, a.eps, p0, pb, c0, e0, f0);
-            const int64_t n = n0 + lane;
-            if (n < a.Nv) a.sims[n * a.ld_sims + m] = out;
-        }
-        tk = nx;
-    }
-}
-
 // One 1 KB LDS-DMA piece issued from inline assembly (lane l brings 16 bytes from base + voff to LDS byte lds_dst + 16 l).  The builtin makes every
 // later plain LDS access of the kernel wait for vmcnt(0) -- the compiler cannot know that the track table, the softmax exchange or the tail's sums
-// never overlap a stage that is being filled -- which put three full DMA round trips into every track of the short-track kernel (stamps: 840 cycles
-// of "mask + max", 2 700 of "tail 2").  Here the compiler does not see the transfer at all; the kernel waits by hand (xs_wait_vm, counted).
+// never overlap a stage that is being filled -- which puts full DMA round trips into every track.  Here the compiler does not see the transfer at all; the kernel waits by hand (counted s_waitcnt vmcnt).
 __device__ __forceinline__ void xs_dma16(const unsigned char* base, uint32_t voff, uint32_t lds_dst) {
     const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(d), "v"(voff), "s"(base) : "memory");
@@ -961,13 +527,15 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
     }
     const float c = a.scale * 1.4426950408889634f;
 
-    struct Trk { int s_eff, first; unsigned w[3]; };
+    struct Trk { int s_eff, first; unsigned w0, w1, w2; };       // (three scalars, not an array: the compiler turned the array behind a select chain into a scratch lookup -- a VMEM load whose wait also covered the LDS-DMA pieces just issued)
     auto load_track = [&](int jt_, Trk& t) __attribute__((always_inline)) {
         const u32x4 h = xa_rd<u32x4>(lbase + X::TBL_OFF + (uint32_t)jt_ * 32), wv = xa_rd<u32x4>(lbase + X::TBL_OFF + (uint32_t)jt_ * 32 + 16);
         t.s_eff = __builtin_amdgcn_readfirstlane((int)h[0]); t.first = __builtin_amdgcn_readfirstlane((int)h[1]);
-        t.w[0] = __builtin_amdgcn_readfirstlane(wv[0]); t.w[1] = __builtin_amdgcn_readfirstlane(wv[1]); t.w[2] = __builtin_amdgcn_readfirstlane(wv[2]);
+        t.w0 = __builtin_amdgcn_readfirstlane(wv[0]); t.w1 = __builtin_amdgcn_readfirstlane(wv[1]); t.w2 = __builtin_amdgcn_readfirstlane(wv[2]);
     };
-    auto tile_word = [&](const Trk& t, int tile) __attribute__((always_inline)) -> unsigned { return tile == 0 ? t.w[0] : tile == 1 ? t.w[1] : t.w[2]; };
+    auto tile_word = [&](const Trk& t, int tile) __attribute__((always_inline)) -> unsigned {       // (masks, not selects: see Trk)
+        return (t.w0 & (tile == 0 ? ~0u : 0u)) | (t.w1 & (tile == 1 ? ~0u : 0u)) | (t.w2 & (tile >= 2 ? ~0u : 0u));
+    };
 
     const uint32_t ldk_b = (uint32_t)a.ldk * 2u, ldu_b = (uint32_t)a.ldu * 2u;
     // every K tile of the track: wave w brings pieces 4 w .. 4 w + 3 (rows 8 w .. 8 w + 7) of each
@@ -1152,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
         XS_STAMP(9);
         XA_BARRIER();                                               // value ring and probabilities are free
         XS_STAMP(10);
-        Trk nx; nx.s_eff = 0; nx.first = 0; nx.w[0] = nx.w[1] = nx.w[2] = 0u;
+        Trk nx; nx.s_eff = 0; nx.first = 0; nx.w0 = nx.w1 = nx.w2 = 0u;
         if (jt + 1 < T) { load_track(jt + 1, nx); issue_k(m + 1, nx); }
         XS_STAMP(11);
 
@@ -1240,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
         }
         XS_STAMP(14);
         XS_STAMP(15);
-        tk.s_eff = nx.s_eff; tk.first = nx.first; tk.w[0] = nx.w[0]; tk.w[1] = nx.w[1]; tk.w[2] = nx.w[2];
+        tk = nx;
     }
 }
 
@@ -1320,7 +888,8 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     MADE_REQUIRE(a.Q && a.K && a.UU && a.av && a.bv && a.ln3_g && a.ln3_b && a.vn && a.sims && a.ws, "made_xpool_sims: null pointer");
     MADE_REQUIRE(a.Nv >= 0 && a.Nm >= 0 && a.S > 0, "made_xpool_sims: bad dims");
     MADE_UNSUPPORTED(a.D == 256, "made_xpool_sims: D=%lld (built for 256)", (long long)a.D);
-    MADE_UNSUPPORTED(a.S <= XA_SMAX, "made_xpool_sims: S=%lld segments per track (at most %d)", (long long)a.S, XA_SMAX);
+    MADE_UNSUPPORTED(a.S <= 96, "made_xpool_sims: S=%lld segments per track (at most 96: longer tracks take made_xpool_fused)", (long long)a.S);
+    MADE_UNSUPPORTED(a.ldk * 2 < (1 << 24) && a.ldu * 2 < (1 << 24), "made_xpool_sims: row strides of at most 8 M elements (row offsets through 24-bit multiplies)");
     MADE_UNSUPPORTED(a.Nm <= 65535, "made_xpool_sims: more than 65535 tracks per call (chunk them)");
     MADE_UNSUPPORTED(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldu % 8 == 0 && a.k_bs % 8 == 0 && a.u_bs % 8 == 0 && a.ldvn % 4 == 0 &&
                      ((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.UU % 16) == 0 && ((uintptr_t)a.vn % 16) == 0 &&
@@ -1332,71 +901,39 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     if (a.Nv == 0 || a.Nm == 0) return MADE_OK;
     hipStream_t st = (hipStream_t)stream;
     constexpr int D = 256;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)xpool_sims_kernel<D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims_kernel<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, XsCfg<D, 4>::LDS_FIXED);
-        if (e != hipSuccess) {
-            made_set_error("made_xpool_sims: cannot reserve %d bytes of LDS: %s", 160 * 1024, hipGetErrorString(e));
-            return MADE_ERR_HIP;
-        }
-        attr_done = true;
-    }
     float* wsf = (float*)a.ws;
     if (a.prepare_ws)
         hipLaunchKernelGGL(xpool_sims_prep_kernel<D>, dim3((unsigned)((a.Nv + 3) / 4)), dim3(256), 0, st, a.vn, a.ldvn, a.ln3_g, a.ln3_b, a.av, a.bv, wsf, a.Nv);
     int* info = (int*)(wsf + xs_ws_info(a.Nv, D));
     hipLaunchKernelGGL(xpool_attn_info_kernel, dim3((unsigned)((a.Nm + 3) / 4)), dim3(256), 0, st, a.key_mask, a.S, a.Nm, info);
-    // chunks of tracks per video tile: enough workgroups to fill the chip a few times over, as few partial rounds as possible (a workgroup's
-    // prologue -- Q, g3 vn, the constants -- costs about as much as a track or two)
-    const int64_t nvt = (a.Nv + XA_PQ - 1) / XA_PQ;
-    int64_t chunks = a.Nm;
-    if (nvt * a.Nm > 2048) {
-        const int64_t lo = (1024 + nvt - 1) / nvt, hi = lo + 24 < a.Nm ? lo + 24 : a.Nm;
-        double best = 1e30;
-        for (int64_t cch = lo; cch <= hi; ++cch) {
-            const int64_t per = (a.Nm + cch - 1) / cch, rounds = (nvt * ((a.Nm + per - 1) / per) + 255) / 256;
-            const double cost = (double)rounds * (double)(per + 2);
-            if (cost < best) { best = cost; chunks = (a.Nm + per - 1) / per; }
-        }
+    // the retrieval set's tracks: 32 videos and four waves per workgroup, two workgroups per CU; at most Xs32::MAX_TRACKS per chunk (the track
+    // table in LDS), as few partial rounds of the chip as possible
+    static bool attr32 = false;
+    if (!attr32) {
+        hipError_t e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) { made_set_error("made_xpool_sims: cannot reserve 80 KB of LDS: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
+        attr32 = true;
     }
-    int per = (int)((a.Nm + chunks - 1) / chunks);
-    const bool no96 = getenv("MADE_XPOOL_SIMS96") && atoi(getenv("MADE_XPOOL_SIMS96")) == 0;      // (read per call: the tests switch it)
-    if (a.S <= 96 && !no96 && a.ldk * 2 < (1 << 24) && a.ldu * 2 < (1 << 24)) {                     // (row offsets through 24-bit multiplies)
-        // the retrieval set's tracks: 32 videos and four waves per workgroup, two workgroups per CU; at most Xs32::MAX_TRACKS per chunk (the track
-        // table in LDS), as few partial rounds of the chip as possible
-        static bool attr32 = false;
-        if (!attr32) {
-            hipError_t e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            if (e != hipSuccess) { made_set_error("made_xpool_sims: cannot reserve 80 KB of LDS: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
-            attr32 = true;
-        }
-        const int64_t nvt32 = (a.Nv + 31) / 32;
-        // Chunks of at most 64 tracks: the workgroups of an XCD walk a chunk together and share its rows through that XCD's L2 -- the shorter the
-        // chunk, the less they drift apart.  53 k x 4 k (profiles/r04_ao_*): 464 tracks per chunk 56.4 ms with 66 GB of L2 misses per launch, 128: 56.2 ms /
-        // 56 GB, 64: 57.2 ms / 31 GB, 32: 59.2 ms / 26 GB (a workgroup's prologue -- Q, g3 vn, the constant fragments -- costs about two tracks).
-        int64_t max_per = 64;
-        if (getenv("MADE_XPOOL_SIMS_PER") && atoi(getenv("MADE_XPOOL_SIMS_PER")) > 0) max_per = atoi(getenv("MADE_XPOOL_SIMS_PER"));
-        if (max_per > Xs32<D>::MAX_TRACKS) max_per = Xs32<D>::MAX_TRACKS;
-        const int64_t c_lo = (a.Nm + max_per - 1) / max_per;
-        double best = 1e30; int64_t bc = c_lo;
-        for (int64_t cch = c_lo; cch <= c_lo + 24 && cch <= a.Nm; ++cch) {
-            const int64_t pr = (a.Nm + cch - 1) / cch, rounds = (nvt32 * ((a.Nm + pr - 1) / pr) + 511) / 512;
-            const double cost = (double)rounds * (double)(pr + 2);
-            if (cost < best) { best = cost; bc = cch; }
-        }
-        const int per32 = (int)((a.Nm + bc - 1) / bc);
-        dim3 g32((unsigned)nvt32, (unsigned)((a.Nm + per32 - 1) / per32));
-        // MADE_XPOOL_DBG=32: the phase-stamp build (tools/xpool_sims_stamps.py): workgroup (0, 0) writes cycle stamps into the sims buffer, no similarity is written
-        const bool stamps32 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 32;
-        if (stamps32) hipLaunchKernelGGL((xpool_sims32_kernel<D, true>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32);
-        else hipLaunchKernelGGL((xpool_sims32_kernel<D, false>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32);
-        return made_check_launch("made_xpool_sims");
+    const int64_t nvt32 = (a.Nv + 31) / 32;
+    // Chunks of at most 64 tracks: the workgroups of an XCD walk a chunk together and share its rows through that XCD's L2 -- the shorter the
+    // chunk, the less they drift apart.  53 k x 4 k (profiles/r04_ao_*): 464 tracks per chunk 56.4 ms with 66 GB of L2 misses per launch, 128: 56.2 ms /
+    // 56 GB, 64: 57.2 ms / 31 GB, 32: 59.2 ms / 26 GB (a workgroup's prologue -- Q, g3 vn, the constant fragments -- costs about two tracks).
+    int64_t max_per = 64;
+    if (getenv("MADE_XPOOL_SIMS_PER") && atoi(getenv("MADE_XPOOL_SIMS_PER")) > 0) max_per = atoi(getenv("MADE_XPOOL_SIMS_PER"));
+    if (max_per > Xs32<D>::MAX_TRACKS) max_per = Xs32<D>::MAX_TRACKS;
+    const int64_t c_lo = (a.Nm + max_per - 1) / max_per;
+    double best = 1e30; int64_t bc = c_lo;
+    for (int64_t cch = c_lo; cch <= c_lo + 24 && cch <= a.Nm; ++cch) {
+        const int64_t pr = (a.Nm + cch - 1) / cch, rounds = (nvt32 * ((a.Nm + pr - 1) / pr) + 511) / 512;
+        const double cost = (double)rounds * (double)(pr + 2);
+        if (cost < best) { best = cost; bc = cch; }
     }
-    if (a.S <= 128 && per > XsCfg<D, 1>::MAX_TRACKS) per = XsCfg<D, 1>::MAX_TRACKS;      // (the kernel's track table in LDS)
-    dim3 grid((unsigned)nvt, (unsigned)((a.Nm + per - 1) / per));
-    if (a.S <= 128) hipLaunchKernelGGL((xpool_sims_kernel<D, 1>), grid, dim3(XA_T), XsCfg<D, 1>::LDS_FIXED + per * 32, st, a, (const int*)info, per);
-    else hipLaunchKernelGGL((xpool_sims_kernel<D, 4>), grid, dim3(XA_T), XsCfg<D, 4>::LDS_FIXED, st, a, (const int*)info, per);
+    const int per32 = (int)((a.Nm + bc - 1) / bc);
+    dim3 g32((unsigned)nvt32, (unsigned)((a.Nm + per32 - 1) / per32));
+    // MADE_XPOOL_DBG=32: the phase-stamp build (tools/xpool_sims_stamps.py): workgroup (0, 0) writes cycle stamps into the sims buffer, no similarity is written
+    const bool stamps32 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 32;
+    if (stamps32) hipLaunchKernelGGL((xpool_sims32_kernel<D, true>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32);
+    else hipLaunchKernelGGL((xpool_sims32_kernel<D, false>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32);
     return made_check_launch("made_xpool_sims");
 }

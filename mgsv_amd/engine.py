@@ -432,13 +432,11 @@ class MadeEngine:
             # kernel, nothing per pair ever written to HBM (made_xpool_fused); the per-track K / U projections stay GEMMs
             vn = ops.l2norm_rows(video)
             cm = min(Nm, max(1, (2 << 30) // (3 * S * D * tc.itemsize)), 65535)
-            sims_env = os.environ.get("MADE_XPOOL_SIMS", "")
-            if (S <= 96 and sims_env != "0") or (S <= 512 and sims_env == "1"):
+            if S <= 96 and os.environ.get("MADE_XPOOL_SIMS", "1") != "0":
                 # round 4: the per-pair Linear moved onto the values.  W'' o = sum_s p_s (W'' u_s), so u''_s = W'' u_s is made once per
                 # segment (one more GEMM over the tracks) and the pair costs a second P.V product (2 S D flops) instead of the Linear (2 D^2):
-                # 2.2x fewer flops per pair at S = 96.  Default for tracks of at most 96 segments (made_xpool_sims' short-track kernel: 56.5 ms
-                # against made_xpool_fused's 59.7-61.5 on the 53 k x 4 k set); MADE_XPOOL_SIMS=0: the fused kernel,
-                # =1: also for 97-512 segments (its general kernel, not measured faster there)
+                # 2.2x fewer flops per pair at S = 96.  The default for tracks of at most 96 segments (made_xpool_sims: 56.5 ms against
+                # made_xpool_fused's 59.7-61.5 on the 53 k x 4 k set); MADE_XPOOL_SIMS=0: the fused kernel
                 s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
                 kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
                 ubuf = torch.empty(cm * S, D, device=dev, dtype=tc)

@@ -643,7 +643,7 @@ def xpool_sims_ws_bytes(Nv: int, Nm: int, D: int = 256) -> int:
 
 def xpool_sims(Q: Tensor, K: Tensor, UU: Tensor, key_mask: Optional[Tensor], av: Tensor, bv: Tensor, ln3, vn: Tensor, sims: Tensor, scale: float,
                eps: float = 1e-5, ws: Optional[Tensor] = None, prepare_ws: bool = True) -> Tensor:
-    """All-pairs X-Pool scoring with the per-pair Linear moved onto the values (made_xpool_sims; bf16, D = 256, S <= 512): Q [Nv, D],
+    """All-pairs X-Pool scoring with the per-pair Linear moved onto the values (made_xpool_sims; bf16, D = 256, S <= 96): Q [Nv, D],
     K [Nm, S, D], UU [Nm, S, 2 D] = value rows u_s | W'' u_s (unit inner stride), key_mask [Nm, S] or None, av = b'' and bv = W'' 1 [D] f32,
     ln3 = (gamma, beta) f32, vn [Nv, D] f32 (L2-normalised videos) -> sims[n, m] written into `sims` ([Nv, >= Nm] f32 view)."""
     from ._lib import MadeXpoolSimsArgs

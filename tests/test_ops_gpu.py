@@ -758,21 +758,13 @@ def test_xpool_fused_against_f32_math(dev, Nv, Nm, S, holes):
     assert torch.equal(torch.nan_to_num(s2, nan=5.0), torch.nan_to_num(got, nan=5.0))
 
 
-@pytest.mark.parametrize("variant", ["default", "general"])
-@pytest.mark.parametrize("Nv,Nm,S,holes", [(300, 21, 96, False), (64, 9, 40, True), (513, 70, 130, True), (129, 3, 17, False), (200, 11, 512, True),
-                                           (70, 300, 128, True), (1000, 1200, 96, True)])
-def test_xpool_sims_linear_on_the_values(dev, Nv, Nm, S, holes, variant, monkeypatch):
+@pytest.mark.parametrize("Nv,Nm,S,holes", [(300, 21, 96, False), (64, 9, 40, True), (129, 3, 17, False), (513, 70, 80, True), (70, 300, 64, True), (1000, 1200, 96, True)])
+def test_xpool_sims_linear_on_the_values(dev, Nv, Nm, S, holes):
     """made_xpool_sims (the per-pair Linear of reference modules/transformer.py:172-178 moved onto the value rows: u'' = W'' u, one GEMM over the
     tracks) against the reference's chain in f32 torch math on the same bf16 operands, and against made_xpool_fused on the same call:
-    prefix and non-prefix masks, NaN in the rows of masked segments, a track without a valid segment, ragged video counts, every
-    kernel (short tracks; at most 128 / 512 segments), several chunks of tracks, the per-video workspace reused."""
+    prefix and non-prefix masks, NaN in the rows of masked segments, a track without a valid segment, ragged video counts (32 videos per
+    workgroup), one to three K tiles, several chunks of tracks, the per-video workspace reused, no mask; longer tracks are refused."""
     D = 256
-    # tracks of at most 96 segments have a kernel of their own (32 videos / four waves per workgroup, two workgroups per CU);
-    # "general" = made_xpool_attention's passes also for them
-    if variant != "default" and S > 96:
-        pytest.skip("the variants differ only for tracks of at most 96 segments")
-    if variant == "general":
-        monkeypatch.setenv("MADE_XPOOL_SIMS96", "0")
     g = torch.Generator(device=dev).manual_seed(Nv * 7 + Nm)
     rn = lambda *s_: torch.randn(*s_, device=dev, generator=g)
     Q, K, U = rn(Nv, D).bfloat16(), rn(Nm, S, D).bfloat16(), rn(Nm, S, D).bfloat16()
@@ -812,11 +804,14 @@ def test_xpool_sims_linear_on_the_values(dev, Nv, Nm, S, holes, variant, monkeyp
     assert bool(torch.isnan(got[:, dead]).all()) and bool(torch.isfinite(got[:, ~dead]).all())
     err = float((got[:, ~dead] - ref[:, ~dead]).abs().max())
     assert err <= 1.5e-2, err
-    if S <= 130:                                            # the one-kernel chain on the same call: both are bf16 paths of the same f32 math
-        Ud = U.clone(); Ud[mask == 0] = float("nan")
-        sf = torch.empty(Nv, Nm, device=dev)
-        ops.xpool_fused(Q, Kd, Ud, mask, ln2, Wl, bl, ln3, vn, sf, scale=scale)
-        assert float((got[:, ~dead] - sf[:, ~dead]).abs().max()) <= 2e-2
+    Ud = U.clone(); Ud[mask == 0] = float("nan")            # the one-kernel chain on the same call: both are bf16 paths of the same f32 math
+    sf = torch.empty(Nv, Nm, device=dev)
+    ops.xpool_fused(Q, Kd, Ud, mask, ln2, Wl, bl, ln3, vn, sf, scale=scale)
+    assert float((got[:, ~dead] - sf[:, ~dead]).abs().max()) <= 2e-2
+    if (Nv, Nm) == (64, 9):
+        from mgsv_amd._lib import MadeError
+        with pytest.raises(MadeError, match="at most 96"):
+            ops.xpool_sims(Q, torch.cat([Kd, Kd, Kd], 1), torch.cat([UUd, UUd, UUd], 1), None, av, bv, ln3, vn, sims[:, :Nm], scale=scale)
     ws = torch.empty(ops.xpool_sims_ws_bytes(Nv, Nm, D), device=dev, dtype=torch.uint8)
     s2 = torch.empty(Nv, Nm, device=dev)
     h = Nm // 2
