@@ -514,7 +514,11 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
         }
     }
     const f32x4 pv4 = *(const f32x4*)(wsf + xs_ws_pp(a.Nv, D) + nv * 4);     // sum gv, sum b3 vn, sum gv Bv, sum gv Av of this lane's video
-    const float* mc = wsf + xs_ws_c(a.Nv, D);                                // the model's constants (XsConst)
+    // the model's constants (XsConst) in scalar registers: read through the pointer inside the track loop they were re-loaded from global memory for every
+    // track (the LDS-DMA statements clobber memory), a round trip -- and a vmcnt(0) that also covered the next track's K pieces -- in front of every store
+    float mc[16];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) mc[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wsf[xs_ws_c(a.Nv, D) + q])));
     {
         float* vec = (float*)(lds + X::VEC_OFF);
         const float g3 = a.ln3_g[tid], b3 = a.ln3_b[tid];             // (256 threads = D)
