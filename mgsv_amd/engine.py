@@ -435,8 +435,8 @@ class MadeEngine:
             if S <= 96 and os.environ.get("MADE_XPOOL_SIMS", "1") != "0":
                 # round 4: the per-pair Linear moved onto the values.  W'' o = sum_s p_s (W'' u_s), so u''_s = W'' u_s is made once per
                 # segment (one more GEMM over the tracks) and the pair costs a second P.V product (2 S D flops) instead of the Linear (2 D^2):
-                # 2.2x fewer flops per pair at S = 96.  The default for tracks of at most 96 segments (made_xpool_sims: 56.5 ms against
-                # made_xpool_fused's 59.7-61.5 on the 53 k x 4 k set); MADE_XPOOL_SIMS=0: the fused kernel
+                # 2.2x fewer flops per pair at S = 96.  The default for tracks of at most 96 segments (made_xpool_sims: 52.5 ms against
+                # made_xpool_fused's 60.7-61.3 on the 53 k x 4 k set); MADE_XPOOL_SIMS=0: the fused kernel
                 s1 = torch.empty(cm * S, D, device=dev, dtype=tc)
                 kbuf = torch.empty(cm * S, D, device=dev, dtype=tc)
                 ubuf = torch.empty(cm * S, D, device=dev, dtype=tc)
