@@ -478,7 +478,7 @@ template <int D> struct Xs32 {
 };
 
 template <int D, bool DBG>
-__global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSimsArgs a, const int* __restrict__ info, int tracks_per_chunk) {
+__global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSimsArgs a, const int* __restrict__ info, int tracks_per_chunk, int nvt, int nchunks) {
     using X = Xs32<D>;
     using CK = typename X::CK;
     using CU = typename X::CU;
@@ -486,14 +486,22 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int64_t n0 = (int64_t)blockIdx.x * PQ;
-    const int64_t m_begin = (int64_t)blockIdx.y * tracks_per_chunk;
+    // 1-D grid, XCD-aware: workgroups b, b + 8, b + 16, ... share an XCD and its L2.  A chunk of tracks belongs to ONE XCD -- chunk c to XCD c % 8 --
+    // which takes it through all its video tiles: the chunk's K / value rows are fetched into one L2 instead of eight (with fewer than eight chunks, or
+    // a count that is not a multiple of eight, the plain order: video tile fastest)
+    int vtile, chunk;
+    if ((nchunks & 7) == 0) {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        chunk = (jx / nvt) * 8 + xcd; vtile = jx % nvt;
+    } else { chunk = blockIdx.x / nvt; vtile = blockIdx.x % nvt; }
+    const int64_t n0 = (int64_t)vtile * PQ;
+    const int64_t m_begin = (int64_t)chunk * tracks_per_chunk;
     const int64_t m_end = (m_begin + tracks_per_chunk < a.Nm) ? m_begin + tracks_per_chunk : a.Nm;
     if (m_begin >= m_end) return;
     const int T = (int)(m_end - m_begin);
     const uint32_t lbase = (uint32_t)(uintptr_t)(lds3_t)lds;
     const float* wsf = (const float*)a.ws;
-    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0;
+    const bool stamp_on = blockIdx.x == 0;
     const int64_t nv = n0 + r < a.Nv ? n0 + r : a.Nv - 1;            // this lane's video (both lane halves)
 
     bf16x8 qf[CK::NQF];
@@ -933,11 +941,14 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
         const double cost = (double)rounds * (double)(pr + 2);
         if (cost < best) { best = cost; bc = cch; }
     }
+    if (bc >= 8) bc = (bc + 7) / 8 * 8;                              // whole chunks per XCD (see the kernel's workgroup order)
     const int per32 = (int)((a.Nm + bc - 1) / bc);
-    dim3 g32((unsigned)nvt32, (unsigned)((a.Nm + per32 - 1) / per32));
+    int nch = (int)((a.Nm + per32 - 1) / per32);
+    if (nch >= 8) nch = (nch + 7) / 8 * 8;                          // (chunks behind the last track exit at once)
+    dim3 g32((unsigned)(nvt32 * nch));
     // MADE_XPOOL_DBG=32: the phase-stamp build (tools/xpool_sims_stamps.py): workgroup (0, 0) writes cycle stamps into the sims buffer, no similarity is written
     const bool stamps32 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 32;
-    if (stamps32) hipLaunchKernelGGL((xpool_sims32_kernel<D, true>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32);
-    else hipLaunchKernelGGL((xpool_sims32_kernel<D, false>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32);
+    if (stamps32) hipLaunchKernelGGL((xpool_sims32_kernel<D, true>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
+    else hipLaunchKernelGGL((xpool_sims32_kernel<D, false>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
     return made_check_launch("made_xpool_sims");
 }
