@@ -332,6 +332,7 @@ def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> di
     if rank == 0 and world == 1:
         # the other D = 256 kernel (made_xpool_fused: the whole pair chain with the per-pair Linear, rounds 2-4's default) on the same pass, AFTER the
         # timed region: reported beside the default path (made_xpool_sims for tracks of at most 96 segments), not part of `value`
+        prev_env = os.environ.get("MADE_XPOOL_SIMS")
         os.environ["MADE_XPOOL_SIMS"] = "0"
         try:
             step(); torch.cuda.synchronize()
@@ -341,7 +342,10 @@ def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> di
         except Exception as ex:                      # report, do not hide
             other_ms = f"{type(ex).__name__}: {ex}"
         finally:
-            os.environ.pop("MADE_XPOOL_SIMS")
+            if prev_env is None:
+                os.environ.pop("MADE_XPOOL_SIMS")
+            else:
+                os.environ["MADE_XPOOL_SIMS"] = prev_env
     out = {"metric": "retrieval sim-matrix GB/s (all-pairs video x music, X-Pool + dual tower)", "value": round(alg_bytes / sec / 1e9, 3),
            "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(sec * 1e3, 3),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -446,6 +446,7 @@ enum XsConst { XC_G2 = 0, XC_GB, XC_B2, XC_BV, XC_AV, XC_BV2, XC_BVAV, XC_AV2, X
 // One 1 KB LDS-DMA piece issued from inline assembly (lane l brings 16 bytes from base + voff to LDS byte lds_dst + 16 l).  The builtin makes every
 // later plain LDS access of the kernel wait for vmcnt(0) -- the compiler cannot know that the track table, the softmax exchange or the tail's sums
 // never overlap a stage that is being filled -- which puts full DMA round trips into every track.  Here the compiler does not see the transfer at all; the kernel waits by hand (counted s_waitcnt vmcnt).
+// (M0 is written behind the compiler's back -- it refuses M0 in a clobber list: the kernel below has no other user of M0: no builtin LDS-DMA, no s_movrel, no GWS / sendmsg)
 __device__ __forceinline__ void xs_dma16(const unsigned char* base, uint32_t voff, uint32_t lds_dst) {
     const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(d), "v"(voff), "s"(base) : "memory");
