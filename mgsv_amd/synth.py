@@ -239,3 +239,23 @@ def make_retrieval_inputs(N_v: int, N_m: int, S: int, D: int, seed: int = 2, min
     m = seg.sum(1) / masks.sum(1, keepdims=True)
     m /= np.linalg.norm(m, axis=-1, keepdims=True)
     return dict(video_embeds=v, segment_embeds=seg, segment_masks=masks, music_embeds=m.astype(np.float32))
+
+
+def make_ranked_retrieval_inputs(N: int, S: int, D: int, seed: int = 21, hard: bool = False, sigma: float = 4.0, eps: float = 2e-3) -> dict:
+    """A split of N (video i, track i) samples whose similarity rows have a meaningful ranking (the metric test-MaDe.py reads through
+    utils/util_test.py:32-96): video i is a noisy copy of its track's pooled vector, so the ground truth ranks near the top but not
+    always first.  hard: tracks 2k and 2k + 1 are near-duplicates (the same segments up to eps relative noise), so every row has two
+    candidates whose similarities differ by far less than 1e-2 -- the case a reduced-precision scorer can rank the other way."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    seg = rng.standard_normal((N, S, D), dtype=np.float32)
+    lens = rng.integers(min(12, S), S + 1, size=N)
+    if hard:
+        seg[1::2] = seg[0::2][: len(seg[1::2])] + eps * rng.standard_normal(seg[1::2].shape, dtype=np.float32)
+        lens[1::2] = lens[0::2][: len(lens[1::2])]
+    masks = (np.arange(S)[None, :] < lens[:, None]).astype(np.float32)
+    seg *= masks[:, :, None]
+    m = seg.sum(1) / masks.sum(1, keepdims=True)
+    m /= np.linalg.norm(m, axis=-1, keepdims=True)
+    v = m + sigma / np.sqrt(D) * rng.standard_normal((N, D), dtype=np.float32)
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    return dict(video_embeds=v.astype(np.float32), segment_embeds=seg, segment_masks=masks, music_embeds=m.astype(np.float32))

@@ -108,12 +108,14 @@ def callback(fn) -> None:
             finally:
                 _in_callback = False
 
+        err = tp._cb_err                                      # (the closure holds this small holder, not the tape: tp._keep -> cfn -> closure
+                                                              #  would otherwise be a reference cycle only the cyclic GC frees, at a time of its choosing)
         def trampoline(_user):
             try:
                 run()
                 return 0
             except Exception as ex:                           # (an exception must not cross the C frame: reported through the replay's status)
-                tp.callback_error = ex
+                err[0] = ex
                 return 1
         cfn = _CB_TYPE(trampoline)
         tp._keep.append(cfn)
@@ -131,7 +133,15 @@ class LaunchTape:
         self.handle = C.c_uint64(0)
         self._keep: List[object] = []
         self._slots = {}
-        self.callback_error: Optional[BaseException] = None
+        self._cb_err: List[Optional[BaseException]] = [None]   # what a replayed host callback raised (see callback())
+
+    @property
+    def callback_error(self) -> Optional[BaseException]:
+        return self._cb_err[0]
+
+    @callback_error.setter
+    def callback_error(self, ex: Optional[BaseException]) -> None:
+        self._cb_err[0] = ex
 
     # ---- recording
     @classmethod
@@ -218,18 +228,21 @@ class LaunchTape:
         _lib.check(_lib.lib().made_tape_count(self.handle, C.byref(k), C.byref(w), C.byref(o)), "made_tape_count")
         return int(k.value), int(w.value), int(o.value)
 
-    def close(self) -> None:
+    def close(self, _sync: bool = True) -> None:
         """Frees the tape and drops the tensors it kept alive -- after the device has finished: the last replay's kernels may still be
         queued on the tape's streams, and the caching allocator would hand the released memory to new allocations under them."""
         if self.handle.value:
-            if torch.cuda.is_available() and torch.cuda.is_initialized():
+            if _sync and torch.cuda.is_available() and torch.cuda.is_initialized():
                 torch.cuda.synchronize()
             _lib.lib().made_tape_free(self.handle)
             self.handle = C.c_uint64(0)
         self._keep = []
 
     def __del__(self):
+        # A finaliser can run at any point of the host program -- inside a hipGraph capture or another tape's recording, where a device
+        # synchronize would invalidate the capture: there only the handle is freed (the explicit close() stays the synchronising path).
         try:
-            self.close()
+            busy = _recording is not None or (torch.cuda.is_available() and torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing())
+            self.close(_sync=not busy)
         except Exception:
             pass

@@ -1967,21 +1967,27 @@ class TrainStepGraph:
                 # the tape replays only the library's launches: a step that still runs a framework kernel (some non-headline
                 # configurations do: the BatchNorm affine of agg_module='mlp', Q > 1 copies, the regression head ...) is refused here
                 # (ForeignKernelError names the operators) instead of silently skipping that work on every replay
-                with _tape.LaunchTape.record(check=os.environ.get("MADE_TAPE_CHECK", "1") != "0") as tp:   # (runs the step for real: the state is put back below)
-                    self.out = fwd_bwd(); opt()
-                torch.cuda.synchronize()
-                self.tape = tp
-                tw_ = int(os.environ.get("MADE_TAPE_INTERLEAVE", "2"))       # 0: replay in program order (knob for A/B measurements)
-                if tw_ > 0:
-                    tp.interleave(tw_)
-                for dst, src in zip((t.flat_param, t.exp_avg, t.exp_avg_sq), keep2):
-                    dst.copy_(src)
-                for k, v in keep_buf.items():
-                    t.buffers[k].copy_(v)
-                t.opt_step, t.generation = keep_step, keep_gen
-                t.repack()
-                self.adam_state[0] = keep_step
-                torch.cuda.synchronize()
+                # The recording runs the step for real (in data-parallel mode: with its all-reduces), so the state is put back afterwards
+                # -- also when the recording is refused (ForeignKernelError on leaving the `with`) or fails: the caller's fallback
+                # (mode='graph' / the eager step) must start from the parameters, Adam moments and step count it had before.
+                try:
+                    with _tape.LaunchTape.record(check=os.environ.get("MADE_TAPE_CHECK", "1") != "0") as tp:
+                        self.out = fwd_bwd(); opt()
+                    torch.cuda.synchronize()
+                    self.tape = tp
+                    tw_ = int(os.environ.get("MADE_TAPE_INTERLEAVE", "2"))   # 0: replay in program order (knob for A/B measurements)
+                    if tw_ > 0:
+                        tp.interleave(tw_)
+                finally:
+                    torch.cuda.synchronize()
+                    for dst, src in zip((t.flat_param, t.exp_avg, t.exp_avg_sq), keep2):
+                        dst.copy_(src)
+                    for k, v in keep_buf.items():
+                        t.buffers[k].copy_(v)
+                    t.opt_step, t.generation = keep_step, keep_gen
+                    t.repack()
+                    self.adam_state[0] = keep_step
+                    torch.cuda.synchronize()
             elif self.dist is None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

@@ -3,7 +3,7 @@ oracle and the reference's golden vectors.
 
 f32 engine: <= 1e-4 on logits / spans / features / similarities (north_star), matcher indices
 identical.  bf16 engine (bf16 MFMA, f32 accumulate, bf16 activations in HBM): stated tolerance
-5e-2 on logits/spans (the reference's own CPU bf16 autocast moves pred_logits
+5e-2 on logits/spans, 5e-3 on retrieval similarities (the reference's own CPU bf16 autocast moves pred_logits
 by 6e-3 at one layer depth; here every activation between kernels is bf16)."""
 import ast
 import os
@@ -20,6 +20,11 @@ from mgsv_amd.engine import MadeEngine  # noqa: E402
 from oracle import made_oracle as O  # noqa: E402
 
 SUB = (slice(None), slice(None, None, 7), slice(None, None, 5))
+# bf16 retrieval similarities against the f32 oracle: 2x the largest error measured over every shape and kernel of this file
+# (tools/retrieval_parity_probe.py -> profiles/r05_retrieval_parity_probe.txt: D = 256 <= 2.5e-3 up to 53 000 x 4 000, D = 512 <= 1.1e-3).
+# The cosine similarities are divided by tau = 0.03 downstream (model_Uni.py:29), so 5e-3 is a sixth of one logit.
+BF16_SIM_TOL = 5e-3
+BF16_SIM_TOL_D512 = 2.5e-3
 
 
 def _oracle(cfg, sd, inp):
@@ -286,12 +291,14 @@ def test_retrieval_parity_across_track_chunks_at_scale():
         ref_r = O.retrieval_sim_matrix(P, cfg, ri["video_embeds"][rows], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
     err_c = float((sim[:, cols] - ref_c).abs().max())
     err_r = float((sim[rows] - ref_r).abs().max())
-    assert err_c <= 3e-2 and err_r <= 3e-2, (err_c, err_r)
+    # measured (profiles/r05_retrieval_parity_probe.txt): 1.8e-3 on the columns, 2.3e-3 on the rows; the bound is 2x that, a sixth of
+    # one logit at the model's temperature (tau = 0.03, model_Uni.py:29) where rounds 1-4 allowed a whole one (3e-2)
+    assert err_c <= BF16_SIM_TOL and err_r <= BF16_SIM_TOL, (err_c, err_r)
     # the ranking the metric reads: per video, the oracle's best track among the checked columns is (near-)best here too
     top_ref = ref_c.argmax(dim=1)
     got_c = sim[:, cols]
     gap = got_c.max(dim=1).values - got_c.gather(1, top_ref[:, None])[:, 0]
-    assert float(gap.max()) <= 6e-2
+    assert float(gap.max()) <= 2 * BF16_SIM_TOL
 
 
 @pytest.mark.parametrize("sims_kernel", [False, True])
@@ -312,17 +319,17 @@ def test_retrieval_bf16_fused_xpool_kernel(N_v, N_m, S, sims_kernel, monkeypatch
     with torch.no_grad():
         ref = O.retrieval_sim_matrix(O.to_torch_params(sd), cfg, ri["video_embeds"], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
     err = float((sim.cpu() - ref).abs().max())
-    assert err <= 3e-2, err
+    assert err <= BF16_SIM_TOL, err                  # measured 1.3e-3 ... 1.7e-3 over these shapes and both kernels
     # the unfused path (taken below 256 videos): same quantity, rows computed in two slices
     parts = [eng.retrieval_sim_matrix(t["video_embeds"][a:a + 200], t["segment_embeds"], t["segment_masks"], t["music_embeds"])
              for a in range(0, N_v, 200)]
     unfused = torch.cat(parts, 0)
     torch.cuda.synchronize()
-    assert float((unfused.cpu() - ref).abs().max()) <= 3e-2
-    assert float((sim - unfused).abs().max()) <= 3e-2
+    assert float((unfused.cpu() - ref).abs().max()) <= BF16_SIM_TOL
+    assert float((sim - unfused).abs().max()) <= 2 * BF16_SIM_TOL
     # ranking agreement with the oracle on the top-1 track of each video, where the margin is not a rounding tie
     top_ref = ref.topk(2, dim=1)
-    clear = (top_ref.values[:, 0] - top_ref.values[:, 1]) > 6e-2
+    clear = (top_ref.values[:, 0] - top_ref.values[:, 1]) > 2 * BF16_SIM_TOL
     assert bool((sim.cpu().argmax(1)[clear] == top_ref.indices[:, 0][clear]).all())
 
 
@@ -346,16 +353,79 @@ def test_retrieval_bf16_two_pass_xpool_attention_at_the_headline_width(N_v, N_m,
     with torch.no_grad():
         ref = O.retrieval_sim_matrix(O.to_torch_params(sd), cfg, ri["video_embeds"], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
     err = float((sim.cpu() - ref).abs().max())
-    assert err <= 3e-2, err
+    assert err <= BF16_SIM_TOL_D512, err             # measured 0.9e-3 ... 1.1e-3
     parts = [eng.retrieval_sim_matrix(t["video_embeds"][a:a + 200], t["segment_embeds"], t["segment_masks"], t["music_embeds"])
              for a in range(0, N_v, 200)]
     unfused = torch.cat(parts, 0)
     torch.cuda.synchronize()
-    assert float((unfused.cpu() - ref).abs().max()) <= 3e-2
-    assert float((sim - unfused).abs().max()) <= 3e-2
+    assert float((unfused.cpu() - ref).abs().max()) <= BF16_SIM_TOL_D512
+    assert float((sim - unfused).abs().max()) <= 2 * BF16_SIM_TOL_D512
     top_ref = ref.topk(2, dim=1)
-    clear = (top_ref.values[:, 0] - top_ref.values[:, 1]) > 6e-2
+    clear = (top_ref.values[:, 0] - top_ref.values[:, 1]) > 2 * BF16_SIM_TOL_D512
     assert bool((sim.cpu().argmax(1)[clear] == top_ref.indices[:, 0][clear]).all())
+
+
+@pytest.mark.parametrize("hard", [False, True])
+def test_retrieval_bf16_rank_agreement_with_the_oracle(hard):
+    """What the metric reads (reference test-MaDe.py:392-403 -> utils/util_test.py:32-96): R@1 / R@10 / MedianR of the bf16 HIP similarity
+    matrix against the f32 oracle's on the same 1 024-sample split, both through made_recall_ranks.  hard: tracks 2k and 2k + 1 are
+    near-duplicates, so EVERY row has two candidates closer than 1e-2 (median margin 1.2e-4) -- bf16 may order such a pair the other
+    way (R@1 moves by the pairs it flips), but whether the ground truth is inside the top 10 must agree for >= 99.5 % of the videos.
+    Measured (profiles/r05_retrieval_parity_probe.txt): easy 99.9 % / 100 % agreement on R@1 / R@10 membership, hard 85.9 % / 99.8 %;
+    R@10 and MedianR identical on both sets, R@1 40.23 against 40.33 (easy), 23.54 against 24.51 (hard)."""
+    from mgsv_amd.utils.util_test import Recall_metrics
+    cfg = cfg_native()
+    sd = synth.make_state_dict(cfg, seed=0)
+    eng = MadeEngine(cfg, sd, dtype="bf16")
+    ri = synth.make_ranked_retrieval_inputs(1024, 96, cfg.D, seed=22 if hard else 21, hard=hard)
+    t = {k: torch.from_numpy(v).to(eng.device) for k, v in ri.items()}
+    sim = eng.retrieval_sim_matrix(t["video_embeds"], t["segment_embeds"], t["segment_masks"], t["music_embeds"])
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.retrieval_sim_matrix(O.to_torch_params(sd), cfg, ri["video_embeds"], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
+    assert float((sim.cpu() - ref).abs().max()) <= BF16_SIM_TOL
+    srt = np.sort(ref.numpy(), axis=1)[:, ::-1]
+    if hard:
+        assert float(np.mean(srt[:, 0] - srt[:, 1] < 1e-2)) >= 0.99          # the set is what it claims to be
+    m_h, ind_h, _ = Recall_metrics(sim)
+    m_o, ind_o, _ = Recall_metrics(ref.numpy())
+    assert ind_o.tolist() == O.recall_ranks_plain(ref.numpy()).tolist()      # the device ranks of the oracle's matrix are the oracle's ranks
+    assert np.mean((ind_h < 10) == (ind_o < 10)) >= 0.995
+    assert abs(m_h["R10"] - m_o["R10"]) <= 0.2 and abs(float(m_h["MedianR"]) - float(m_o["MedianR"])) <= 0.5
+    assert int(np.abs(ind_h - ind_o).max()) <= 10                            # (measured: 5) no video's rank moves by more than a few places
+    if not hard:
+        assert np.mean((ind_h < 1) == (ind_o < 1)) >= 0.995 and abs(m_h["R1"] - m_o["R1"]) <= 0.3
+    else:
+        assert abs(m_h["R1"] - m_o["R1"]) <= 3.0                              # near-duplicate pairs flip: measured 0.98 points
+
+
+def test_retrieval_parity_sampled_at_the_timed_size():
+    """BASELINE configs[3]'s full size, 53 000 videos x 4 000 tracks (S = 96, D = 256): the bf16 similarity matrix of the timed launch
+    against the f32 oracle on 24 video rows x ALL tracks and ALL videos x 24 track columns (spread over the whole range, so every
+    video tile, every track chunk and both ends are sampled); then the f32 parity mode on the same inputs, held to north_star's 1e-4.
+    Measured: bf16 2.2e-3 / 2.4e-3 (rows / columns), f32 2.5e-7 / 3.1e-7 in 815 ms per pass."""
+    cfg = cfg_native()
+    sd = synth.make_state_dict(cfg, seed=0)
+    P = O.to_torch_params(sd)
+    N_v, N_m, S = 53000, 4000, 96
+    ri = synth.make_retrieval_inputs(N_v, N_m, S, cfg.D, seed=31, min_len=12)
+    rows = sorted(set(np.linspace(0, N_v - 1, 24).astype(int).tolist()))
+    cols = sorted(set(np.linspace(0, N_m - 1, 24).astype(int).tolist()))
+    with torch.no_grad():
+        ref_r = O.retrieval_sim_matrix(P, cfg, ri["video_embeds"][rows], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
+        ref_c = O.retrieval_sim_matrix(P, cfg, ri["video_embeds"], ri["segment_embeds"][cols], ri["segment_masks"][cols], ri["music_embeds"][cols])
+    for dtype, tol in (("bf16", BF16_SIM_TOL), ("f32", 1e-4)):
+        eng = MadeEngine(cfg, sd, dtype=dtype)
+        t = {k: torch.from_numpy(v).to(eng.device) for k, v in ri.items()}
+        sim = eng.retrieval_sim_matrix(t["video_embeds"], t["segment_embeds"], t["segment_masks"], t["music_embeds"])
+        torch.cuda.synchronize()
+        assert sim.shape == (N_v, N_m)
+        sim_r, sim_c = sim[rows].cpu(), sim[:, cols].cpu()
+        assert bool(torch.isfinite(sim).all())
+        err_r, err_c = float((sim_r - ref_r).abs().max()), float((sim_c - ref_c).abs().max())
+        assert err_r <= tol and err_c <= tol, (dtype, err_r, err_c)
+        del eng, t, sim
+        torch.cuda.empty_cache()
 
 
 def test_two_batches_in_flight_match_one_at_a_time():
