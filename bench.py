@@ -220,30 +220,45 @@ def cpu_baseline_retrieval(cfg, sd, S: int, n_v: int = 2048, n_m: int = 256):
                 sample=f"one pass over {n_v} videos x {n_m} tracks, S={S}, D={cfg.D} (oracle/made_oracle.py, torch CPU f32, {n} threads), {dt:.2f} s")
 
 
-def cpu_baseline_train(cfg, sd, inp, B: int = 16):
-    """The oracle's train-mode forward (dropout on) + autograd backward on a bounded sample: the first B samples of the batch."""
+def cpu_baseline_train(cfg, sd, inp):
+    """The same unit of work as `value`, on the host: ONE whole training iteration of the B = 64 batch through the oracle -- train-mode forward
+    (dropout on), autograd backward, the three per-group clip_grad_norm_ calls and the Adam step of reference train-MaDe.py:375-381 (groups as
+    model_Uni.py:73-114 forms them).  A 4-sample iteration warms the allocator and the thread pool; the timed sample is one full step."""
     from oracle import made_oracle as O
     P = O.to_torch_params(sd)
     names = [k for k, v in P.items() if v.is_floating_point() and not k.endswith(".pe") and k != "criterion.empty_weight"]
     for k in names:
         P[k].requires_grad_(True)
-    sub = {k: (v[:B] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
-    n = torch.get_num_threads()
 
-    def one(seed):
+    def group_of(k: str) -> int:
+        if k.startswith(("vit_proj.", "ast_proj.", "video_transformer.", "audio_transformer.", "share_transformer.")):
+            return 0
+        if k.startswith("video_guided_to_music_pooling_cross_transformer.") or k == "logit_scale":
+            return 1
+        return 2 if not k.startswith("decoder_query_embed") else 3
+    groups = [[P[k] for k in names if group_of(k) == g] for g in range(3)]
+    opt = torch.optim.Adam([{"params": g_, "lr": 1e-4} for g_ in groups if g_])
+    n = torch.get_num_threads()
+    B = inp["frame_feats"].shape[0]
+
+    def one(seed, rows):
+        sub = {k: (v[:rows] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+        opt.zero_grad(set_to_none=True)
         r = O.forward(P, cfg, sub["frame_feats"], sub["segment_feats"], sub["frame_masks"], sub["segment_masks"], sub["spans_target"],
                       v_duration=sub["v_duration"], drop=O.Drop(seed, p_detr=cfg.detr_dropout))
         (r["retrieval_loss"] + r["localization_loss"]).backward()
-        for k in names:
-            P[k].grad = None
+        for g_ in groups:
+            if g_:
+                torch.nn.utils.clip_grad_norm_(g_, 1.0)
+        opt.step()
 
-    one(1)
+    one(1, 4)
     t0 = time.perf_counter()
-    one(2)
+    one(2, B)
     dt = time.perf_counter() - t0
     return dict(value=round(B / dt, 3), unit="pairs/s", cores=n, cpu_model=_cpu_model(), kind="port",
-                sample=f"one train-mode forward + backward of the first {B} samples (oracle/made_oracle.py autograd, torch CPU f32, {n} threads; "
-                       f"no optimizer step), {dt:.2f} s")
+                sample=f"one whole training iteration of the B={B} batch (oracle/made_oracle.py: train-mode forward + autograd backward + 3 x clip_grad_norm_ "
+                       f"+ Adam step, torch CPU f32, {n} threads), {dt:.2f} s")
 
 
 def north_star_contraction(dev) -> dict:
@@ -403,7 +418,7 @@ def _retrieval_f32_pass(cfg, v, seg, mask, mu, alg_bytes: float) -> dict:
     torch.cuda.synchronize()
     sec = time.perf_counter() - t0
     assert sim.shape == (v.shape[0], seg.shape[0]) and bool(torch.isfinite(sim).all())
-    flops = float(v.shape[0]) * seg.shape[0] * (4.0 * float(mask.sum()) / seg.shape[0] * cfg.D + 4.0 * cfg.D * cfg.D)
+    flops = float(v.shape[0]) * seg.shape[0] * (4.0 * float(mask.sum()) / seg.shape[0] * cfg.D + 2.0 * cfg.D * cfg.D)
     del eng32, seg32, sim
     torch.cuda.empty_cache()
     return {"ms_per_pass": round(sec * 1e3, 1), "GB_s": round(alg_bytes / sec / 1e9, 3), "dtype": "f32", "passes_timed": 1,

@@ -3,8 +3,9 @@
 // The reference moves the cost matrix to the host and calls SciPy once per sample and decoder layer
 // (music_detr/matcher.py:89-91: 6 D2H syncs per forward).  Here one launch handles all
 // n_layers*B samples: a wave computes the sample's cost block in f32 with the reference's operation
-// order (explicit *_rn intrinsics AND contraction switched off for this file: HIP's __fadd_rn / __fmul_rn are plain + and *, which
-// the default -ffp-contract=fast may still fuse into an FMA -- which products it fused moved with an unrelated compile flag),
+// order (explicit *_rn intrinsics AND contraction switched off for this file ON THE COMMAND LINE, csrc/Makefile: -ffp-contract=off.  HIP's
+// __fadd_rn / __fmul_rn are plain + and * defined in headers, which the default -ffp-contract=fast fuses into FMAs; the pragma below
+// does not reach those header bodies -- rounds 3-4 shipped fused products here without knowing),
 // then lane 0 runs the shortest-augmenting-path LSAP (Crouse 2016, as SciPy implements it, same
 // tie-break) on the f64-promoted block.  Q, G <= 64, so all solver state lives in LDS.
 #include "common.h"
@@ -64,12 +65,17 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float* logits, cons
         }
         float l0 = lg[2 * q], l1 = lg[2 * q + 1];
         float mx = fmaxf(l0, l1);
-        // Foreground probability of the 2-class softmax, evaluated in f64 and rounded once: the CORRECTLY ROUNDED f32 value of the
-        // reference's formula (music_detr/matcher.py:58).  torch's CPU softmax evaluates it in f32 with SLEEF's 1-ulp expf, which is off
-        // the correctly rounded exponential in 1.1 % of the arguments (measured here over 3e6 arguments) and differs between AVX2 and
-        // AVX-512 hosts, so there is no single "reference bit pattern" to reproduce; the device expf differed from it far more often.
-        const double d0 = exp((double)l0 - (double)mx), d1 = exp((double)l1 - (double)mx);
-        float p = (float)((fg == 0 ? d0 : d1) / (d0 + d1));
+        // Foreground probability of the 2-class softmax in the operation order torch's CPU softmax runs for the reference's line
+        // (music_detr/matcher.py:58; aten vec_softmax_lastdim: e = exp(x - max) per element, s = sum, r = 1 / s, p = e * r, all f32),
+        // with a CORRECTLY ROUNDED f32 exponential (the f64 exp rounded once).  torch's own exp there is a <= 1-ulp (SLEEF, torch 1.13)
+        // or <= 2-ulp (exp_u20, torch 2.x) approximation whose bits differ between torch versions and between AVX2 and AVX-512 hosts,
+        // so it has no single bit pattern to copy; what can be copied is the order of the roundings around it.  With it all 127
+        // samples of the matcher fixture (SciPy on torch-CPU costs) are assigned identically; rounds 1-4 evaluated the quotient in
+        // f64 and rounded once, which is closer to the real number but differs from torch's bits in 41 % of random arguments
+        // (this form: 4.6 %, all of them torch's exp) and left two tie samples assigned the other way.
+        const float e0 = (float)exp((double)__fsub_rn(l0, mx)), e1 = (float)exp((double)__fsub_rn(l1, mx));
+        const float rs = __fdiv_rn(1.0f, __fadd_rn(e0, e1));
+        float p = __fmul_rn(fg == 0 ? e0 : e1, rs);
         float pc = sp[2 * q], pw = sp[2 * q + 1], tc = tg[2 * g], tw = tg[2 * g + 1];
         float cost_span = __fadd_rn(fabsf(__fsub_rn(pc, tc)), fabsf(__fsub_rn(pw, tw)));
         float ps, pe, ts, te;

@@ -436,10 +436,11 @@ int launch_xpool_attn(const MadeXpoolAttnArgs& a, const int* info, dim3 grid, in
 // value half tiles XaCfg<512>'s (one row = one 1 KB LDS-DMA piece).  Longer tracks stay on made_xpool_fused: a 64-video / eight-wave form of these
 // passes for up to 512 segments existed (commit 4819965) and was not faster there.
 
-// workspace (floats): gv = g3 * vn [Nv][D]; per video (sum gv, sum b3 vn, sum gv Bv, sum gv Av) [Nv][4]; sixteen model constants (XsConst); 32 ints per track
+// workspace (floats): gv = g3 * vn [Nv][D]; per video (sum gv, sum b3 vn, sum gv Bv, sum gv Av) [Nv][4]; sixteen model constants (XsConst); gv as bf16 [Nv][D] (round 5); 32 ints per track
 __host__ __device__ inline int64_t xs_ws_pp(int64_t Nv, int64_t D) { return Nv * D; }
 __host__ __device__ inline int64_t xs_ws_c(int64_t Nv, int64_t D) { return Nv * (D + 4); }
-__host__ __device__ inline int64_t xs_ws_info(int64_t Nv, int64_t D) { return Nv * (D + 4) + 16; }
+__host__ __device__ inline int64_t xs_ws_gvb(int64_t Nv, int64_t D) { return Nv * (D + 4) + 16; }       // gv once more as bf16, per video in the order the 64-video kernel's lanes read it: [wave][j][hh][g][4]
+__host__ __device__ inline int64_t xs_ws_info(int64_t Nv, int64_t D) { return Nv * (D + 4) + 16 + Nv * D / 2; }
 // model constants: with g2 = g3^2, gb = g3 b3 and the folded Linear's vectors Av, Bv (y = k1 z + k2 Bv + Av)
 enum XsConst { XC_G2 = 0, XC_GB, XC_B2, XC_BV, XC_AV, XC_BV2, XC_BVAV, XC_AV2, XC_G2BV, XC_G2AV, XC_G2BV2, XC_G2BVAV, XC_G2AV2, XC_GBBV, XC_GBAV };
 
@@ -825,6 +826,433 @@ __global__ __launch_bounds__(256, 2) void xpool_sims32_kernel(const MadeXpoolSim
     }
 }
 
+// ---- made_xpool_sims, 64 videos per workgroup (round 5; opt-in: MADE_XPOOL_SIMS_PQ=64).  Built to test what binds the 32-video kernel above.
+// Round 4 read its stamps as "the CU's LDS-DMA intake": a (32 videos, track) unit takes in 144 KB (K 48 KB, u | u'' 96 KB), two workgroups per CU,
+// 6.63 M units = 955 GB through 256 CUs x ~70 GB/s (what LDS-DMA reads L2-resident rows at) = 53 ms of the 54 it takes.  Twice the videos per
+// loaded tile halves those bytes per pair; what stood in the way was the register file: Q of the tile's videos as B operands of 32 x 32 score
+// tiles is 64 registers per 32 videos IN EVERY WAVE (wave w = K tile w).  Here the score product is turned: wave w owns 16 VIDEOS (16 w ..) and
+// all of the track's segments -- 16 x 16 x 32 MFMAs, A = K rows of a 16-segment tile out of LDS, B = its 16 videos' Q rows (32 registers) -- so
+//   * the softmax of a video is wave-local (two lane-group shuffles for the maximum and the sum; no exchange arrays, one barrier less),
+//   * all four waves share pass 1 evenly (the 32-video kernel idles wave 3 on tracks of at most 96 segments),
+//   * pass 2 and the tail are the 32-video kernel's with a second video tile: 8 accumulator tiles per wave, 8 MFMAs per 16-segment step on the
+//     same ten LDS reads, the same barriers per track for twice the pairs.
+// 128 accumulator registers leave no room for Q and g3 vn across a track: Q is re-read for the next track under the tail, g3 vn (a bf16 copy in
+// the workspace, in lane order) at the head of the tail.  LDS 68 KB: K tiles / value ring 48 KB, probabilities 13 KB (the tail's exchange on top
+// of them), softmax denominators, constants.
+// MEASURED (profiles/r05_xpool_sims64_*): bit-compatible with the 32-video kernel (9e-8), 53.1 against 53.8 ms on 53 k x 4 k, same box,
+// alternating.  Half the LDS-DMA bytes per pair, a quarter fewer vector instructions per pair (the literal-zero accumulators below), ten barriers
+// per 64 videos instead of eleven per 32 -- and the same time: neither the bytes nor the vector issue bind this loop.  Its stamps say what does:
+// of 18 900 cycles per (64 videos, track) a wave spends 8 000 parked -- on the round trips of a chain of dependent transfers (K, then the value
+// half tiles two at a time through a three-slot ring, then g3 vn: 560 + 2 500 + 1 640), on vector-memory ISSUE (100-135 cycles per 1 KB
+// piece or load, 28-44 of them per track: a wave with more than ~20 in flight blocks at issue, so earlier prefetches only move the wait), and on
+// the barriers between the phases (950).  What would shorten it is a deeper value ring (a fourth 16 KB slot does not fit 80 KB beside the
+// probabilities) or a third workgroup per CU (170 registers per wave: the accumulators alone are 128).  The default stays the 32-video kernel.
+template <int D> struct Xs64 {
+    using CK = XaCfg<D>;
+    using CU = XaCfg<2 * D>;
+    static constexpr int NW = 4, PQ = 64, T = 256;
+    static constexpr int PP = 96 * 2 + 16;
+    static constexpr int P_OFF = 3 * CK::STG;
+    static constexpr int PART_OFF = P_OFF;                       // [4][64][12] f32: a wave's partial sums of a video (see the tail) -- over the probabilities,
+                                                                 // which are dead between pass 2's last barrier and the next track's pass 1 (two barriers later)
+    static constexpr int L_OFF = P_OFF + PQ * PP;                // [64] f32: softmax denominators
+    static constexpr int G2_OFF = L_OFF + PQ * 4;                // [D] f32: g3^2
+    static constexpr int AFR_OFF = G2_OFF + D * 4;               // [4 waves][2][2][2 lane halves][8] 16-byte fragments: the tail's constant A operands (row 7: zeros)
+    static constexpr int TBL_OFF = AFR_OFF + NW * 4 * 2 * 8 * 16;
+    static constexpr int MAX_TRACKS = (80 * 1024 - TBL_OFF) / 32;
+    static_assert(NW * PQ * 48 <= PQ * PP, "the tail's exchange overlays the probabilities");
+    static_assert(CK::STG == CU::HSTG && CK::PT == 16 && D == 256, "tile split");
+};
+
+template <int ST_OFF> __device__ __forceinline__ bf16x8 xs_read_k(uint32_t addr) {
+    bf16x8 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(ST_OFF)); return v;
+}
+
+template <int D, bool DBG>
+__global__ __launch_bounds__(256, 2) void xpool_sims64_kernel(const MadeXpoolSimsArgs a, const int* __restrict__ info, int tracks_per_chunk, int nvt, int nchunks) {
+    using X = Xs64<D>;
+    using CK = typename X::CK;
+    using CU = typename X::CU;
+    constexpr int PP = X::PP, PQ = X::PQ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int v16 = lane & 15, g4 = lane >> 4;
+    int vtile, chunk;                                             // (workgroup order: see the 32-video kernel)
+    if ((nchunks & 7) == 0) {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        chunk = (jx / nvt) * 8 + xcd; vtile = jx % nvt;
+    } else { chunk = blockIdx.x / nvt; vtile = blockIdx.x % nvt; }
+    const int64_t n0 = (int64_t)vtile * PQ;
+    const int64_t m_begin = (int64_t)chunk * tracks_per_chunk;
+    const int64_t m_end = (m_begin + tracks_per_chunk < a.Nm) ? m_begin + tracks_per_chunk : a.Nm;
+    if (m_begin >= m_end) return;
+    const int T = (int)(m_end - m_begin);
+    const uint32_t lbase = (uint32_t)(uintptr_t)(lds3_t)lds;
+    const float* wsf = (const float*)a.ws;
+    const bool stamp_on = blockIdx.x == 0;                        // (DBG: XS_STAMP as in the 32-video kernel)
+    auto vid = [&](int64_t i) __attribute__((always_inline)) -> int64_t { return i < a.Nv ? i : a.Nv - 1; };
+
+    // pass 1's B operand: Q rows of this wave's 16 videos, k-slots 8 g4 .. 8 g4 + 7 of every 32-wide k-step
+    // (re-read from L2 at the head of every track: 32 registers that pass 2 and the tail need more -- 8 KB per wave and track beside the 144 KB
+    // of LDS-DMA pieces)
+    // (byte offsets in 32 bits beside the uniform base pointers -- the launcher checks the ranges: a 64-bit per-lane pointer is two registers)
+    const uint32_t q_off = (uint32_t)(vid(n0 + 16 * wave + v16) * a.ldq * 2 + g4 * 16);
+    // g3 * vn of the lane's two videos (r and 32 + r) at the rows its z tiles hold -- 32 (w + 4 j) + 8 g + 4 hh + (0..3) -- is read from the
+    // workspace's bf16 copy at the head of every tail (64 bytes per video and lane): 32 registers that pass 2 needs for its accumulators
+    // (its byte offsets, like the combine's per-video sums', are recomputed per track from the lane number: three registers)
+    float mc[16];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) mc[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wsf[xs_ws_c(a.Nv, D) + q])));
+    {
+        const float g3 = a.ln3_g[tid];                                // (256 threads = D)
+        ((float*)(lds + X::G2_OFF))[tid] = g3 * g3;
+    }
+    // the tail's constant A operands (see the 32-video kernel: functional m of the product = row m; rows 7 .. 31 are zero): built once and parked
+    // in LDS -- 16 registers this kernel does not have.  Lane (m < 8, hh) of wave w writes the fragments of its rows; row 7 stays zero for m >= 7.
+    if ((lane & 31) < 8) {
+        const int mf = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 fr;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int d = 32 * (wave + 4 * j) + 8 * (2 * s2 + (jj >> 2)) + 4 * hh + (jj & 3);
+                    const float g3 = a.ln3_g[d], Av = a.av[d], Bv = a.bv[d], g2 = g3 * g3, gb = g3 * a.ln3_b[d];
+                    const float val = mf == 0 ? 1.f : mf == 1 ? Bv : mf == 2 ? Av : mf == 3 ? g2 : mf == 4 ? g2 * Bv : mf == 5 ? g2 * Av : mf == 6 ? gb : 0.f;
+                    fr[jj] = (bf16_t)val;
+                }
+                *(bf16x8*)(lds + X::AFR_OFF + ((((wave * 2 + j) * 2 + s2) * 2 + hh) * 8 + mf) * 16) = fr;
+            }
+    }
+    for (int i = tid; i < T; i += X::T) {
+        const int* ip = info + (m_begin + i) * XA_INFO;
+        *(u32x4*)(lds + X::TBL_OFF + i * 32) = (u32x4){(unsigned)ip[0], (unsigned)ip[1], 0u, 0u};
+        *(u32x4*)(lds + X::TBL_OFF + i * 32 + 16) = *(const u32x4*)(ip + 16);
+    }
+    const float c = a.scale * 1.4426950408889634f;
+
+    struct Trk { int s_eff, first; unsigned w0, w1, w2; };
+    auto load_track = [&](int jt_, Trk& t) __attribute__((always_inline)) {
+        const u32x4 h = xa_rd<u32x4>(lbase + X::TBL_OFF + (uint32_t)jt_ * 32), wv = xa_rd<u32x4>(lbase + X::TBL_OFF + (uint32_t)jt_ * 32 + 16);
+        t.s_eff = __builtin_amdgcn_readfirstlane((int)h[0]); t.first = __builtin_amdgcn_readfirstlane((int)h[1]);
+        t.w0 = __builtin_amdgcn_readfirstlane(wv[0]); t.w1 = __builtin_amdgcn_readfirstlane(wv[1]); t.w2 = __builtin_amdgcn_readfirstlane(wv[2]);
+    };
+    auto tile_word = [&](const Trk& t, int tile) __attribute__((always_inline)) -> unsigned {
+        return (t.w0 & (tile == 0 ? ~0u : 0u)) | (t.w1 & (tile == 1 ? ~0u : 0u)) | (t.w2 & (tile >= 2 ? ~0u : 0u));
+    };
+    const uint32_t ldk_b = (uint32_t)a.ldk * 2u, ldu_b = (uint32_t)a.ldu * 2u;
+    // (the lane's part of a piece's address -- row in the piece, slot, swizzle -- is recomputed for every piece: kept in eight registers it was
+    // the first thing the allocator spilled, and the scratch reloads then sat between the pieces)
+    auto issue_k = [&](int64_t m, const Trk& tk) __attribute__((always_inline)) {
+        const uint32_t rip = xa_opaque((uint32_t)lane / CK::CPR), slot = xa_opaque((uint32_t)lane % CK::CPR);
+        const unsigned char* Kb = (const unsigned char*)a.K + m * a.k_bs * 2;
+        const int ntl = tk.s_eff > 0 ? (tk.s_eff + 31) / 32 : 1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (t < ntl) {
+                const unsigned word = tile_word(tk, t);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pit = wave * 4 + i;
+                    const uint32_t row = (uint32_t)pit * CK::RPP + rip;
+                    const int seg = t * 32 + (int)row;
+                    const bool valid = seg < tk.s_eff && ((word >> row) & 1u);
+                    const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
+                    const uint32_t chunk = slot ^ (row & 15u);
+                    xs_dma16(Kb, __umul24(srow, ldk_b) + chunk * 16u, lbase + (uint32_t)(t * CK::STG + pit * 1024));
+                }
+            }
+        }
+    };
+    auto issue_u = [&](int64_t m, int h, const Trk& tk) __attribute__((always_inline)) {
+        const uint32_t slot = xa_opaque((uint32_t)lane);
+        const unsigned char* Ub = (const unsigned char*)a.UU + m * a.u_bs * 2;
+        const unsigned bits = (tile_word(tk, h >> 1) >> ((h & 1) * 16)) & 0xFFFFu;
+        const uint32_t dst = (uint32_t)((h % 3) * CU::HSTG);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t row = (uint32_t)(wave * 4 + i);
+            const int seg = h * 16 + (int)row;
+            const bool valid = seg < tk.s_eff && ((bits >> row) & 1u);
+            const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
+            const uint32_t chunk = (((slot >> 2) ^ (row & 7u)) << 2) | (slot & 3u);
+            xs_dma16(Ub, __umul24(srow, ldu_b) + chunk * 16u, lbase + dst + row * 1024u);
+        }
+    };
+
+    // pass 1 reads: K row v16 of a 16-segment tile, 16-byte chunk 4 ks + g4, stored at slot chunk ^ (row & 15) (issue_k): the lane's address for
+    // ks = 0 with the slot's bits 2-3 folded in; ks & 3 flips those bits (XOR 64 bytes each), ks >> 2 and the tile are immediates
+    const uint32_t kx0 = lbase + (uint32_t)v16 * CK::ROWB + ((uint32_t)((g4 ^ (v16 & 3)) | (v16 & 12)) << 4);
+    // pass 2 reads (the 32-video kernel's)
+    const int i16 = lane & 15;
+    const uint32_t trow = 4 * (g4 >> 1) + (i16 >> 2);
+    const uint32_t u_rd = lbase + trow * CU::ROWB + (g4 & 1) * 32 + (i16 & 3) * 8;
+    // video 16 w + v16, segments 4 g4 .. 4 g4 + 3 of a 16-segment tile -- in the K-SLOT order pass 2's operands use (the 32 x 32 accumulator order
+    // the value fragments' transposing reads follow): slot (hh, jj) of a half tile is segment 8 (jj >> 2) + 4 hh + (jj & 3), so the four segments of
+    // lane group g4 sit at byte 16 (g4 & 1) + 8 (g4 >> 1) of the half tile's 32
+    const uint32_t p_wr = lbase + X::P_OFF + (uint32_t)(16 * wave + v16) * PP + (uint32_t)((g4 & 1) * 16 + (g4 >> 1) * 8);
+    const uint32_t p_rd = lbase + X::P_OFF + (uint32_t)r * PP + hh * 16;                              // video r (+ 32 vt), k-slots 8 hh .. of a half tile
+
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();                                               // the track table and the constants are in LDS
+    Trk tk;
+    load_track(0, tk);
+    // pass 1's Q fragments (this wave's 16 videos): not kept through pass 2 (its accumulators need the registers) but re-read for the NEXT track
+    // under the z tiles' sums, in front of that track's K pieces -- read at the head of the track they cost 2 400 cycles of it (stamps: the rows
+    // leave L2 between two tracks)
+    bf16x8 qf[D / 32];
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) qf[ks] = *(const bf16x8*)((const unsigned char*)a.Q + (q_off + (uint32_t)ks * 64u));
+    issue_k(m_begin, tk);
+
+    for (int jt = 0; jt < T; ++jt) {
+        const int64_t m = m_begin + jt;
+        const int s_eff = tk.s_eff;
+        const int NH = s_eff > 0 ? (s_eff + 15) / 16 : 1;          // 16-segment tiles of the track: score tiles of pass 1, half tiles of pass 2
+        XS_STAMP(0);
+
+        // ================================================================================================ pass 1: scores of this wave's 16 videos
+        f32x4 sacc[6];                                              // (a tile's first MFMA takes a literal zero accumulator: nothing to clear)
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        uint32_t ka[4];
+        {
+            const uint32_t kx = xa_opaque(kx0);                    // (recomputed per track: registers, not instructions, are what this kernel is short of)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ka[q] = kx ^ (uint32_t)(q << 6);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]) :: "memory");   // this wave's K pieces (and Q)
+        XS_STAMP(1);
+        XA_BARRIER();
+        XS_STAMP(2);
+#define XS64_TILE(ST)                                                                                                                   \
+        if (ST < NH) {                                                                                                                  \
+            constexpr int TO = (ST >> 1) * CK::STG + (ST & 1) * 16 * CK::ROWB;                                                          \
+            bf16x8 f[4];                                                                                                                \
+            f[0] = xs_read_k<TO>(ka[0]); f[1] = xs_read_k<TO>(ka[1]); f[2] = xs_read_k<TO>(ka[2]); f[3] = xs_read_k<TO>(ka[3]);          \
+            xa_wait_lgkm<3>(f[0]); sacc[ST] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], qf[0], z4, 0, 0, 0); f[0] = xs_read_k<TO + 256>(ka[0]); \
+            xa_wait_lgkm<3>(f[1]); sacc[ST] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], qf[1], sacc[ST], 0, 0, 0); f[1] = xs_read_k<TO + 256>(ka[1]); \
+            xa_wait_lgkm<3>(f[2]); sacc[ST] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], qf[2], sacc[ST], 0, 0, 0); f[2] = xs_read_k<TO + 256>(ka[2]); \
+            xa_wait_lgkm<3>(f[3]); sacc[ST] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[3], qf[3], sacc[ST], 0, 0, 0); f[3] = xs_read_k<TO + 256>(ka[3]); \
+            xa_wait_lgkm<3>(f[0]); sacc[ST] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], qf[4], sacc[ST], 0, 0, 0);                  \
+            xa_wait_lgkm<2>(f[1]); sacc[ST] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], qf[5], sacc[ST], 0, 0, 0);                  \
+            xa_wait_lgkm<1>(f[2]); sacc[ST] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], qf[6], sacc[ST], 0, 0, 0);                  \
+            xa_wait_lgkm<0>(f[3]); sacc[ST] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[3], qf[7], sacc[ST], 0, 0, 0);                  \
+        }
+        XS64_TILE(0) XS64_TILE(1) XS64_TILE(2) XS64_TILE(3) XS64_TILE(4) XS64_TILE(5)
+#undef XS64_TILE
+        XS_STAMP(3);
+        XA_BARRIER();                                               // the K tiles are consumed: their LDS is the value ring now
+        XS_STAMP(4);
+        issue_u(m, 0, tk);
+        if (NH > 1) issue_u(m, 1, tk);
+        XS_STAMP(5);
+
+        // the softmax of a video is this wave's own: lane (g4, v16) holds segments 16 st + 4 g4 + (0..3) of video 16 w + v16
+        float mx = -INFINITY;
+#pragma unroll
+        for (int st = 0; st < 6; ++st)
+            if (st < NH) {
+                const unsigned wbits = tile_word(tk, st >> 1) >> (16 * (st & 1) + 4 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sc = ((wbits >> e) & 1u) ? sacc[st][e] * c : -INFINITY;
+                    sacc[st][e] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, xa_other_half(mx));
+        float psum = 0.f;
+#pragma unroll
+        for (int st = 0; st < 6; ++st)
+            if (st < NH) {
+                bf16x4 pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pr_ = __builtin_amdgcn_exp2f(sacc[st][e] - mx);
+                    psum += pr_;
+                    pf[e] = (bf16_t)pr_;
+                }
+                xa_wr<bf16x4>(p_wr + (uint32_t)st * 32, pf);
+            }
+        psum += __shfl_xor(psum, 16);
+        psum += xa_other_half(psum);
+        if (g4 == 0) xa_wr<float>(lbase + X::L_OFF + (uint32_t)(16 * wave + v16) * 4, psum);
+        XS_STAMP(6);
+
+        // ================================================================================================ pass 2: [O | Z]^T = [U | U'']^T P^T, 16 segments per step
+        f32x16 oacc[4][2];                                          // [0], [1]: rows 32 w .., 128 + 32 w .. of o; [2], [3]: the same rows of z; x video tile
+        uint32_t ug[4];
+        {
+            const uint32_t tr7 = xa_opaque(trow & 7u);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) ug[dt] = (((uint32_t)(wave + 4 * dt)) ^ tr7) << 6;
+        }
+        // one step: half tile h (its pieces awaited, the barrier passed) times the probabilities of both video tiles.  FIRST: the accumulators
+        // start from a literal zero instead of being cleared (128 moves per track)
+#define XS64_STEP(FIRST)                                                                                                                         \
+        {                                                                                                                                        \
+            if (h + 1 < NH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      /* half tile h has landed (h + 1 may be in flight) */          \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                                \
+            XA_BARRIER();                                           /* (the first one also publishes the probabilities and their sums) */       \
+            if (h + 2 < NH) issue_u(m, h + 2, tk);                  /* into the slot of half tile h - 1, which everyone has left */              \
+            const uint32_t ub = u_rd + (uint32_t)((h % 3) * CU::HSTG);                                                                           \
+            bf16x8 pb0 = xa_read128(p_rd + (uint32_t)h * 32), pb1 = xa_read128_off<32 * PP>(p_rd + (uint32_t)h * 32);                            \
+            bf16x4 lo[4], hi[4];                                                                                                                 \
+            _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                                                   \
+                const uint32_t va = ub + ug[dt];                                                                                                 \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[dt]) : "v"(va));                                                              \
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(va), "n"(8 * CU::ROWB));                                 \
+            }                                                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb0), "+v"(pb1), "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])); \
+            _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                                                   \
+                const bf16x8 uf = __builtin_shufflevector(lo[dt], hi[dt], 0, 1, 2, 3, 4, 5, 6, 7);                                               \
+                oacc[dt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pb0, FIRST ? z16 : oacc[dt][0], 0, 0, 0);                              \
+                oacc[dt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pb1, FIRST ? z16 : oacc[dt][1], 0, 0, 0);                              \
+            }                                                                                                                                    \
+        }
+        {
+            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            { const int h = 0; XS64_STEP(true) }
+            for (int h = 1; h < NH; ++h) XS64_STEP(false)
+        }
+#undef XS64_STEP
+        XS_STAMP(7);
+        XA_BARRIER();                                               // value ring and probabilities are free
+        XS_STAMP(8);
+        // g3 * vn for the sums below ([video tile][j][g >> 1]: eight 16-byte loads, about 2 900 cycles from L2's far side by the stamps), in flight
+        // under the o tiles' sums.  Plain loads: the same loads from inline assembly with a counted wait further down (so that the next track's K
+        // pieces could go out in between) gave wrong pairs at scale -- between an assembly load and its wait the compiler is free to move the
+        // registers it was given -- and did not pay either: a wave with 28 loads in flight blocks at issue (3 800 cycles for the 12 K pieces).
+        bf16x8 gq[2][2][2];
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            const int rr = (int)xa_opaque((uint32_t)lane) & 31;
+            const uint32_t gv_off = (uint32_t)(xs_ws_gvb(a.Nv, D) * 4 + vid(n0 + 32 * vt + rr) * (D * 2) + (wave * 4 + hh) * 32);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) gq[vt][j][q] = *(const bf16x8*)((const unsigned char*)a.ws + (gv_off + (uint32_t)(j * 64 + q * 16)));
+        }
+        // the o tiles first (LayerNorm2's statistics are all that is read of them): their 64 registers are free before the z tiles' sums begin
+        float su_[2], sq_[2];
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            const float inv_l = 1.f / xa_rd<float>(lbase + X::L_OFF + (uint32_t)(32 * vt + r) * 4);
+            f32x2_t su2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2_t x2 = {oacc[dt][vt][e], oacc[dt][vt][e + 1]};
+                    su2 += x2; sq2 += x2 * x2;
+                }
+            float su = (su2[0] + su2[1]) * inv_l, sq = (sq2[0] + sq2[1]) * (inv_l * inv_l);
+            su += xa_other_half(su); sq += xa_other_half(sq);
+            su_[vt] = su; sq_[vt] = sq;
+        }
+        XS_STAMP(9);
+        // gv has arrived (nothing else of this wave is in flight); only now the next track's Q rows and K pieces go out -- issued earlier they
+        // would sit between these loads and their wait, which the compiler can only write as vmcnt(0)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(su_[0]), "+v"(su_[1]), "+v"(sq_[0]), "+v"(sq_[1]), "+v"(gq[0][0][0]), "+v"(gq[0][0][1]), "+v"(gq[0][1][0]), "+v"(gq[0][1][1]),
+                     "+v"(gq[1][0][0]), "+v"(gq[1][0][1]), "+v"(gq[1][1][0]), "+v"(gq[1][1][1]) :: "memory");
+        XS_STAMP(10);
+        Trk nx; nx.s_eff = 0; nx.first = 0; nx.w0 = nx.w1 = nx.w2 = 0u;
+        // (unconditionally: inside the `if` the old fragments would have to stay alive through pass 2 for the path that skips the load)
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) qf[ks] = *(const bf16x8*)((const unsigned char*)a.Q + (q_off + (uint32_t)ks * 64u));
+        if (jt + 1 < T) { load_track(jt + 1, nx); issue_k(m + 1, nx); }
+        XS_STAMP(11);
+        float Q1_[2], Q2_[2];
+        f32x16 facc[2];
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            f32x2_t q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
+            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t g2_r = xa_opaque(lbase + X::G2_OFF + (uint32_t)(32 * (wave + 4 * j) + 4 * hh) * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 g2 = xa_rd<f32x4>(g2_r + g * 32);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj += 2) {
+                        const f32x2_t z2 = {oacc[2 + j][vt][4 * g + jj], oacc[2 + j][vt][4 * g + jj + 1]};
+                        const f32x2_t zz = z2 * z2;
+                        q1 += zz;
+                        q2 += zz * (f32x2_t){g2[jj], g2[jj + 1]};
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 zb;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) zb[jj] = (bf16_t)oacc[2 + j][vt][8 * s2 + jj];
+                    const bf16x8 af = xa_rd<bf16x8>(lbase + X::AFR_OFF + (uint32_t)((((wave * 2 + j) * 2 + s2) * 2 + hh) * 8 + (r < 7 ? r : 7)) * 16);
+                    facc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, zb, (j == 0 && s2 == 0) ? z16 : facc[vt], 0, 0, 0);
+                }
+            }
+            float Q1 = q1[0] + q1[1], Q2 = q2[0] + q2[1];
+            Q1 += xa_other_half(Q1); Q2 += xa_other_half(Q2);
+            Q1_[vt] = Q1; Q2_[vt] = Q2;
+        }
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            f32x2_t b1 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj += 2) {
+                        const f32x2_t z2 = {oacc[2 + j][vt][4 * g + jj], oacc[2 + j][vt][4 * g + jj + 1]};
+                        b1 += z2 * (f32x2_t){(float)gq[vt][j][g >> 1][(g & 1) * 4 + jj], (float)gq[vt][j][g >> 1][(g & 1) * 4 + jj + 1]};
+                    }
+            float B1 = b1[0] + b1[1];
+            B1 += xa_other_half(B1);
+            const uint32_t pw = lbase + X::PART_OFF + (uint32_t)((wave * PQ + 32 * vt + r) * 48);
+            if (hh == 0) { xa_wr<f32x4>(pw, (f32x4){su_[vt], sq_[vt], Q1_[vt], Q2_[vt]}); xa_wr<f32x4>(pw + 16, (f32x4){facc[vt][0], facc[vt][1], facc[vt][2], facc[vt][3]}); }
+            else xa_wr<f32x4>(pw + 32, (f32x4){facc[vt][0], facc[vt][1], facc[vt][2], B1});
+        }
+        XS_STAMP(12);
+        XA_BARRIER();
+        XS_STAMP(13);
+        // ---- one wave (they take turns), lane = video: LayerNorm2's k1 / k2, the six sums, LayerNorm3 + cosine
+        if (!DBG && wave == (jt & 3)) {
+            const uint32_t pr = xa_opaque(lbase + X::PART_OFF + (uint32_t)lane * 48);
+            f32x4 A0 = xa_rd<f32x4>(pr), A1 = xa_rd<f32x4>(pr + 16), A2 = xa_rd<f32x4>(pr + 32);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) { A0 += xa_rd<f32x4>(pr + q * (PQ * 48)); A1 += xa_rd<f32x4>(pr + q * (PQ * 48) + 16); A2 += xa_rd<f32x4>(pr + q * (PQ * 48) + 32); }
+            const float inv_l = 1.f / xa_rd<float>(lbase + X::L_OFF + (uint32_t)lane * 4);
+            const uint32_t pv_off = (uint32_t)((xs_ws_pp(a.Nv, D) + vid(n0 + (int64_t)xa_opaque((uint32_t)lane)) * 4) * 4);   // sum gv, sum b3 vn, sum gv Bv, sum gv Av of video `lane`
+            const f32x4 pv4 = *(const f32x4*)((const unsigned char*)a.ws + pv_off);
+            const float mean = A0[0] * (1.f / D);
+            const float var = fmaxf(A0[1] * (1.f / D) - mean * mean, 0.f);
+            const float k1n = __builtin_amdgcn_rsqf(var + a.eps), k2 = -mean * k1n, k1 = k1n * inv_l;
+            const float Q1 = A0[2], Q2 = A0[3], F1 = A1[0], F2 = A1[1], F3 = A1[2], F4 = A1[3], F5 = A2[0], F6 = A2[1], F7 = A2[2], B1 = A2[3];
+            const float s1 = k1 * F1 + k2 * mc[XC_BV] + mc[XC_AV];
+            const float s2 = k1 * k1 * Q1 + 2.f * k1 * (k2 * F2 + F3) + k2 * k2 * mc[XC_BV2] + 2.f * k2 * mc[XC_BVAV] + mc[XC_AV2];
+            const float p1 = k1 * B1 + k2 * pv4[2] + pv4[3];
+            const float c1 = k1 * F4 + k2 * mc[XC_G2BV] + mc[XC_G2AV];
+            const float c2 = k1 * k1 * Q2 + 2.f * k1 * (k2 * F5 + F6) + k2 * k2 * mc[XC_G2BV2] + 2.f * k2 * mc[XC_G2BVAV] + mc[XC_G2AV2];
+            const float e1 = k1 * F7 + k2 * mc[XC_GBBV] + mc[XC_GBAV];
+            const float mu = s1 * (1.f / D);
+            const float vy = fmaxf(s2 * (1.f / D) - mu * mu, 0.f);
+            const float rs = __builtin_amdgcn_rsqf(vy + a.eps);
+            const float dot = rs * (p1 - mu * pv4[0]) + pv4[1];
+            const float zz = rs * rs * (c2 - 2.f * mu * c1 + mu * mu * mc[XC_G2]) + 2.f * rs * (e1 - mu * mc[XC_GB]) + mc[XC_B2];
+            const int64_t vrow = n0 + (int64_t)xa_opaque((uint32_t)lane);          // (not hoisted out of the track loop: it would live in two registers)
+            if (vrow < a.Nv) a.sims[vrow * a.ld_sims + m] = dot * __builtin_amdgcn_rsqf(zz);
+        }
+        XS_STAMP(14);
+        XS_STAMP(15);
+        tk = nx;
+    }
+}
+
 // per video: gv = g3 * vn, (sum gv, sum b3 vn, sum gv Bv, sum gv Av); per model: the XsConst sums.  One wave per video.
 template <int D>
 __global__ __launch_bounds__(256) void xpool_sims_prep_kernel(const float* vn, int64_t ldvn, const float* g3, const float* b3, const float* av, const float* bv,
@@ -841,6 +1269,11 @@ __global__ __launch_bounds__(256) void xpool_sims_prep_kernel(const float* vn, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) { gvv[j] = g[j] * v[j]; sg += gvv[j]; sb += b[j] * v[j]; sgb += gvv[j] * B[j]; sga += gvv[j] * A[j]; }
         *(f32x4*)(ws + n * D + lane * 4) = gvv;
+        {   // d = 4 lane = 32 (w + 4 j) + 8 g + 4 hh + i  ->  bf16 index (((w 2 + j) 2 + hh) 4 + g) 4 + i of the video's 256
+            const int d = 4 * lane, hh = (d >> 2) & 1, g = (d >> 3) & 3, blk = d >> 5, w = blk & 3, j = blk >> 2;
+            bf16_t* gb = (bf16_t*)(ws + xs_ws_gvb(Nv, D)) + n * D + ((((w * 2 + j) * 2 + hh) * 4 + g) * 4);
+            *(bf16x4*)gb = (bf16x4){(bf16_t)gvv[0], (bf16_t)gvv[1], (bf16_t)gvv[2], (bf16_t)gvv[3]};
+        }
         sg = wave_sum(sg); sb = wave_sum(sb); sgb = wave_sum(sgb); sga = wave_sum(sga);
         if (lane == 0) *(f32x4*)(ws + xs_ws_pp(Nv, D) + n * 4) = (f32x4){sg, sb, sgb, sga};
     }
@@ -911,6 +1344,8 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
                      "made_xpool_sims: pointers / strides must keep 16-byte alignment");
     MADE_UNSUPPORTED(a.ldu >= 2 * a.D && (uint64_t)a.S * (uint64_t)a.ldk * 2 < (1ull << 32) && (uint64_t)a.S * (uint64_t)a.ldu * 2 < (1ull << 32),
                      "made_xpool_sims: value rows hold u | u'' (ldu >= 2 D); a track's K / value rows must each span less than 4 GB");
+    MADE_UNSUPPORTED((uint64_t)a.Nv * (uint64_t)a.ldq * 2 < (1ull << 32) && (uint64_t)a.Nv * (uint64_t)(a.D + 4 + a.D / 2) * 4 + 64 < (1ull << 32),
+                     "made_xpool_sims: Q and the per-video workspace rows are addressed with 32-bit byte offsets (Nv * ldq * 2 and Nv * (1.5 D + 4) * 4 below 4 GB)");
     if (a.Nv == 0 || a.Nm == 0) return MADE_OK;
     hipStream_t st = (hipStream_t)stream;
     constexpr int D = 256;
@@ -919,22 +1354,31 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
         hipLaunchKernelGGL(xpool_sims_prep_kernel<D>, dim3((unsigned)((a.Nv + 3) / 4)), dim3(256), 0, st, a.vn, a.ldvn, a.ln3_g, a.ln3_b, a.av, a.bv, wsf, a.Nv);
     int* info = (int*)(wsf + xs_ws_info(a.Nv, D));
     hipLaunchKernelGGL(xpool_attn_info_kernel, dim3((unsigned)((a.Nm + 3) / 4)), dim3(256), 0, st, a.key_mask, a.S, a.Nm, info);
-    // the retrieval set's tracks: 32 videos and four waves per workgroup, two workgroups per CU; at most Xs32::MAX_TRACKS per chunk (the track
-    // table in LDS), as few partial rounds of the chip as possible
+    // the retrieval set's tracks: 32 videos (MADE_XPOOL_SIMS_PQ=64: round 5's 64-video kernel -- half the LDS-DMA bytes per pair, the same speed
+    // within 1.2 %: the comment in front of it) and four waves per workgroup, two workgroups per CU; at most MAX_TRACKS per chunk (the track table
+    // in LDS), as few partial rounds of the chip as possible
+    const bool pq64 = getenv("MADE_XPOOL_SIMS_PQ") && atoi(getenv("MADE_XPOOL_SIMS_PQ")) == 64;
     static bool attr32 = false;
     if (!attr32) {
         hipError_t e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims64_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims64_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) { made_set_error("made_xpool_sims: cannot reserve 80 KB of LDS: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
         attr32 = true;
     }
-    const int64_t nvt32 = (a.Nv + 31) / 32;
+    // MADE_XPOOL_DBG=32: the phase-stamp build of the 32-video kernel (tools/xpool_sims_stamps.py): workgroup (0, 0) writes cycle stamps into the sims buffer, no similarity is written
+    const bool stamps32 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 32;
+    const bool stamps64 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 64;      // the same for the 64-video kernel
+    const bool use64 = (pq64 && !stamps32) || stamps64;
+    const int64_t nvt32 = use64 ? (a.Nv + 63) / 64 : (a.Nv + 31) / 32;
     // Chunks of at most 64 tracks: the workgroups of an XCD walk a chunk together and share its rows through that XCD's L2 -- the shorter the
     // chunk, the less they drift apart.  53 k x 4 k (profiles/r04_ao_*): 464 tracks per chunk 56.4 ms with 66 GB of L2 misses per launch, 128: 56.2 ms /
     // 56 GB, 64: 57.2 ms / 31 GB, 32: 59.2 ms / 26 GB (a workgroup's prologue -- Q, g3 vn, the constant fragments -- costs about two tracks).
     int64_t max_per = 64;
     if (getenv("MADE_XPOOL_SIMS_PER") && atoi(getenv("MADE_XPOOL_SIMS_PER")) > 0) max_per = atoi(getenv("MADE_XPOOL_SIMS_PER"));
-    if (max_per > Xs32<D>::MAX_TRACKS) max_per = Xs32<D>::MAX_TRACKS;
+    const int64_t max_tracks = use64 ? Xs64<D>::MAX_TRACKS : Xs32<D>::MAX_TRACKS;
+    if (max_per > max_tracks) max_per = max_tracks;
     const int64_t c_lo = (a.Nm + max_per - 1) / max_per;
     double best = 1e30; int64_t bc = c_lo;
     for (int64_t cch = c_lo; cch <= c_lo + 24 && cch <= a.Nm; ++cch) {
@@ -947,9 +1391,9 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     int nch = (int)((a.Nm + per32 - 1) / per32);
     if (nch >= 8) nch = (nch + 7) / 8 * 8;                          // (chunks behind the last track exit at once)
     dim3 g32((unsigned)(nvt32 * nch));
-    // MADE_XPOOL_DBG=32: the phase-stamp build (tools/xpool_sims_stamps.py): workgroup (0, 0) writes cycle stamps into the sims buffer, no similarity is written
-    const bool stamps32 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 32;
-    if (stamps32) hipLaunchKernelGGL((xpool_sims32_kernel<D, true>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
+    if (use64 && stamps64) hipLaunchKernelGGL((xpool_sims64_kernel<D, true>), g32, dim3(256), Xs64<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
+    else if (use64) hipLaunchKernelGGL((xpool_sims64_kernel<D, false>), g32, dim3(256), Xs64<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
+    else if (stamps32) hipLaunchKernelGGL((xpool_sims32_kernel<D, true>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
     else hipLaunchKernelGGL((xpool_sims32_kernel<D, false>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
     return made_check_launch("made_xpool_sims");
 }

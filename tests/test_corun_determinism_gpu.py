@@ -107,8 +107,8 @@ def test_backward_chain_of_the_recorded_step_is_bit_reproducible_with_the_retrie
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["xpool_inbatch", "xpool_attention", "xpool_fused", "xpool_sims"])
-def test_retrieval_kernels_bit_identical_beside_small_workgroups(which):
+@pytest.mark.parametrize("which", ["xpool_inbatch", "xpool_attention", "xpool_fused", "xpool_sims", "xpool_sims_pq64"])
+def test_retrieval_kernels_bit_identical_beside_small_workgroups(which, monkeypatch):
     """The retrieval kernels hand LDS reads to inline assembly (transposing reads, counted waits).  A register that such a read has been given is an
     ordinary value to the compiler: if it copies it before the data has arrived the kernel is right alone on the chip and wrong beside another
     kernel's workgroups on the same CU (round 4: the first made_xpool_inbatch, 10-30 % of the launches).  Each kernel 60 times beside a stream of
@@ -135,6 +135,7 @@ def test_retrieval_kernels_bit_identical_beside_small_workgroups(which):
         shape, odt = (Nv, Nm), torch.float32
         run = lambda o: ops.xpool_fused(q, k, u, mask, ln2, W, bl, ln3, vn, o, scale=1 / math.sqrt(D))
     elif which.startswith("xpool_sims"):
+        monkeypatch.setenv("MADE_XPOOL_SIMS_PQ", "64" if which.endswith("pq64") else "32")       # round 5's 64-video kernel / the default
         vec = lambda: torch.randn(D, device=dev, generator=g) * 0.1
         ln3, av, bv = (1 + vec(), vec()), vec(), vec()
         vn = torch.nn.functional.normalize(torch.randn(Nv, D, device=dev, generator=g), dim=-1)

@@ -325,6 +325,44 @@ def test_captured_train_step_follows_the_eager_steps(dtype, mode):
     assert num <= (1e-3 if dtype == "f32" else 0.3) * den, (num, den)
 
 
+def test_refused_tape_recording_leaves_the_trainer_state_untouched(monkeypatch):
+    """The tape records by running the step for real (optimizer included).  When the recording is refused -- a framework kernel inside the
+    step: ForeignKernelError on leaving the recorder -- the caller falls back to mode='graph' or the eager step (bench.py does), and that
+    fallback must start from the parameters, Adam moments and step count it had: nothing of the recorded step may remain."""
+    from mgsv_amd import tape as T
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, _ = _setup(4, 20, 40)
+    ref, trn = MadeTrainer(cfg, sd, dtype="bf16"), MadeTrainer(cfg, sd, dtype="bf16")
+    b = _batch(cfg, 4, 20, 40, seed=12)
+    trn.train_step(*b, seed=3, lrs=(1e-3, 1e-3, 1e-3)); ref.train_step(*b, seed=3, lrs=(1e-3, 1e-3, 1e-3))   # moments and step count are non-trivial
+    torch.cuda.synchronize()
+    keep = [x.clone() for x in (trn.flat_param, trn.exp_avg, trn.exp_avg_sq)]
+    keep_buf = {k: v.clone() for k, v in trn.buffers.items()}
+    orig = trn.optimizer_step
+
+    def with_a_framework_kernel(*a, **kw):
+        if T.recording():
+            trn.flat_grad.mul_(1.0)                                              # an ATen kernel the replay would skip
+        return orig(*a, **kw)
+    monkeypatch.setattr(trn, "optimizer_step", with_a_framework_kernel)
+    with pytest.raises(T.ForeignKernelError, match="aten::mul"):
+        trn.capture_train_step(*b, mode="tape")
+    torch.cuda.synchronize()
+    assert trn.opt_step == 1 and trn.generation == ref.generation
+    for a, c in zip((trn.flat_param, trn.exp_avg, trn.exp_avg_sq), keep):
+        assert torch.equal(a, c)
+    for k, v in keep_buf.items():
+        assert torch.equal(trn.buffers[k], v), k
+    monkeypatch.setattr(trn, "optimizer_step", orig)
+    g = trn.capture_train_step(*b, mode="graph")                                 # the fallback, from the untouched state
+    og = g.step(*b, seed=4, lrs=(1e-3, 1e-3, 1e-3))
+    oe = ref.train_step(*b, seed=4, lrs=(1e-3, 1e-3, 1e-3))
+    torch.cuda.synchronize()
+    assert torch.equal(og["hs"], oe["hs"]) and trn.opt_step == ref.opt_step == 2
+    moved = float((ref.flat_param - trn.flat_param).double().norm())
+    assert moved <= 0.05 * float((ref.flat_param - keep[0]).double().norm()), moved
+
+
 def test_captured_train_step_reads_seed_and_learning_rates_from_the_device():
     from mgsv_amd.trainer import MadeTrainer
     cfg, sd, _ = _setup(4, 20, 40)

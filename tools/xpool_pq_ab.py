@@ -1,0 +1,35 @@
+"""made_xpool_sims: the 64-video kernel (default) against the 32-video kernel (MADE_XPOOL_SIMS_PQ=32) on the retrieval set, alternating, plus
+their difference.  python tools/xpool_pq_ab.py [Nv Nm S]"""
+import math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mgsv_amd import ops
+Nv, Nm, S, D = int(sys.argv[1]) if len(sys.argv) > 1 else 53000, int(sys.argv[2]) if len(sys.argv) > 2 else 4000, int(sys.argv[3]) if len(sys.argv) > 3 else 96, 256
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+Q = torch.randn(Nv, D, device=dev, generator=g).bfloat16()
+K = torch.randn(Nm, S, D, device=dev, generator=g).bfloat16()
+UU = torch.randn(Nm, S, 2 * D, device=dev, generator=g).bfloat16()
+lens = torch.randint(min(12, S), S + 1, (Nm,), device=dev, generator=g)
+mask = (torch.arange(S, device=dev)[None] < lens[:, None]).float()
+vec = lambda: torch.randn(D, device=dev, generator=g) * 0.1
+ln3, av, bv = (1 + vec(), vec()), vec(), vec()
+vn = torch.nn.functional.normalize(torch.randn(Nv, D, device=dev, generator=g), dim=-1)
+out = {"64": torch.empty(Nv, Nm, device=dev), "32": torch.empty(Nv, Nm, device=dev)}
+scale = 1 / math.sqrt(D)
+def run(pq):
+    if pq == "32": os.environ["MADE_XPOOL_SIMS_PQ"] = "32"
+    else: os.environ.pop("MADE_XPOOL_SIMS_PQ", None)
+    ops.xpool_sims(Q, K, UU, mask, av, bv, ln3, vn, out[pq], scale=scale)
+def timeit(pq, n=3):
+    run(pq); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): run(pq)
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+for rep in range(3):
+    t64, t32 = timeit("64"), timeit("32")
+    print(f"Nv={Nv} Nm={Nm} S={S}: 64-video kernel {t64:8.2f} ms   32-video kernel {t32:8.2f} ms   ratio {t32 / t64:.3f}", flush=True)
+d = (out["64"] - out["32"]).abs()
+print(f"max |pq64 - pq32| = {float(d.max()):.3e}, mean {float(d.mean()):.3e}; nan: {int(torch.isnan(out['64']).sum())} / {int(torch.isnan(out['32']).sum())}")

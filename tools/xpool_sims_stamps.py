@@ -1,8 +1,9 @@
 """In-kernel cycle stamps of made_xpool_sims' short-track kernel (MADE_XPOOL_DBG=32 build): phases of workgroup (0, 0), per wave, averaged over
 tracks 8..31 of its chunk.  python tools/xpool_sims_stamps.py [S_fixed]   (S_fixed: every track that long; default: lengths U{12..96})"""
 import math, os, sys
+K64 = os.environ.get("PQ", "64") == "64"                        # PQ=32: round 4's 32-video kernel
 K32 = True
-os.environ["MADE_XPOOL_DBG"] = "32"
+os.environ["MADE_XPOOL_DBG"] = "64" if K64 else "32"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mgsv_amd import ops
@@ -27,7 +28,9 @@ st = sims.view(-1)[:8 * 32 * 16 * 2].view(torch.int64).view(8, 32, 16).cpu()
 NWAVES = 4 if K32 else 8
 names32 = ["wait K", "barrier A", "scores", "barrier B", "issue U 0,1", "mask + max", "barrier C", "exp + P", "second product", "barrier D", "next info + K issue",
            "partial sums", "barrier", "pair (1 wave)", "-"]
-names = names32 if K32 else ["wait K", "barrier A", "scores", "barrier B", "next info + K / h4,5 issue", "mask + max", "barrier C", "exp + P", "second product", "tail 1", "barrier B1",
+names64 = ["wait K + Q", "barrier A", "scores", "barrier B", "issue U 0,1", "softmax + P", "second product", "barrier D", "gv issue, o sums", "wait gv", "next info + K issue",
+           "z sums", "barrier", "pair (1 wave)", "-"]
+names = names64 if K64 else names32 if K32 else ["wait K", "barrier A", "scores", "barrier B", "next info + K / h4,5 issue", "mask + max", "barrier C", "exp + P", "second product", "tail 1", "barrier B1",
          "issue U (+K)", "tail 2", "barrier B2", "tail 3 / store"]
 print(f"track lengths: {lens[:32].tolist()}")
 print("wave " + " ".join(f"{n[:10]:>10s}" for n in names) + "      total")
