@@ -524,7 +524,9 @@ int made_xpool_attention(const MadeXpoolAttnArgs* args, void* stream);
  * LayerNorm3 and the cosine with the video are the six sums of made_xpool_fused; nothing per pair is written but sims[n * ld_sims + m].
  * Q [Nv, D] bf16; K [Nm, S, D] bf16 (rows at m * k_bs + s * ldk); UU [Nm, S, 2 D] bf16 (rows at m * u_bs + s * ldu: u_s | u''_s);
  * key_mask [Nm, S] f32 or NULL; av, bv, ln3_g, ln3_b [D] f32; vn = video / |video| [Nv, D] f32; ws: made_xpool_sims_ws_bytes(Nv, Nm, D)
- * bytes, 16-byte aligned (per-video terms of LayerNorm3 + cosine, filled when prepare_ws != 0; 32 ints per track, rebuilt by every call).
+ * bytes, 16-byte aligned (per-video terms of LayerNorm3 + cosine -- since round 5 with a second, bf16 copy of g3 * vn in the order the 64-video kernel's lanes
+ * read it; Nv * ldq * 2 and Nv * (1.5 D + 4) * 4 must stay below 4 GB -- filled when prepare_ws != 0; 32 ints per track, rebuilt by every call).
+ * Two kernels serve the call: 32 videos per workgroup (the default) and 64 (MADE_XPOOL_SIMS_PQ=64: the same sums in the same order, results equal to 1e-7).
  * A track without a valid segment gives NaN, like the reference's softmax over -inf. */
 typedef struct MadeXpoolSimsArgs {
     const void* Q; int64_t ldq;

@@ -224,7 +224,7 @@ def test_train_step_with_the_early_optimizer_part_tracks_the_one_piece_step(monk
     cfg, sd, inp = _setup(8, 20, 40)
     t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
     curves = []
-    for early in ("1", "0"):
+    for early in ("1", "0", "0"):                                # the one-piece schedule twice: its own run-to-run spread is the yardstick
         monkeypatch.setenv("MADE_EARLY_OPT", early)
         trn = MadeTrainer(cfg, sd, dtype="bf16")
         losses = []
@@ -236,11 +236,14 @@ def test_train_step_with_the_early_optimizer_part_tracks_the_one_piece_step(monk
         assert trn.opt_step == 6
         curves.append(losses)
     assert np.isfinite(curves).all()
-    # the two schedules round differently from the third step on (the early part's update lands between launches that the one-piece step
-    # runs before it), and six steps at this learning rate on eight samples amplify a last-place difference: 2 % over the first four steps,
-    # 6 % over the last two (measured spread of the last step over repeated runs of the SAME schedule: 1.5 %)
-    assert np.allclose(curves[0][:4], curves[1][:4], rtol=2e-2, atol=2e-2), curves
-    assert np.allclose(curves[0][4:], curves[1][4:], rtol=6e-2, atol=2e-2), curves
+    early, one, one_again = (np.asarray(c) for c in curves)
+    # Two runs of the SAME schedule differ: the weight gradients are f32 atomic sums over workgroups (arrival order; csrc/gemm_tn*.hip), and six
+    # steps at this learning rate on eight samples amplify a last-place difference (measured: up to 1.5 % at the sixth step).  The early-optimizer
+    # schedule must stay within 2 % of the one-piece step, or within four times what the one-piece step differs from itself in this very run.
+    spread = np.abs(one - one_again) / np.maximum(np.abs(one), 1.0)
+    diff = np.abs(early - one) / np.maximum(np.abs(one), 1.0)
+    assert np.all(diff <= np.maximum(2e-2, 4.0 * spread) + 2e-2 / np.maximum(np.abs(one), 1.0)), (curves, spread.tolist(), diff.tolist())
+    assert np.all(spread <= 3e-2), spread.tolist()               # and that spread itself stays small
 
 
 def test_training_reduces_the_loss():

@@ -1,10 +1,10 @@
-# The round's profile set (run through gpurun from the repo root):  bash tools/profile_round3.sh <tag>
+# The round-5 profile set (the round-4 recipe under r05 names; run through gpurun from the repo root):  bash tools/profile_round5.sh <tag>
 # -> gpurun_out/<tag>/: the default bench line, rocprofv3 --kernel-trace --stats of the three legs (+ per-kind average launch durations:
 #    kernel_avg_us.json, what bench.py quotes as avg_launch_us_rocprof_committed), PMC passes (FETCH_SIZE / WRITE_SIZE, separately) of
 #    the training step, the eval forward and the retrieval pass -> pmc_summary.json, and the north-star micro-benchmark
 #    (tools/xpool_qk_bench.py) under --stats and the two PMC passes.
 set -x
-TAG=${1:-r03x}
+TAG=${1:-r05x}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2>$O/bench_default.err
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $R/bench.py --workload train --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_under_rocprof.json 2>/dev/null
@@ -49,4 +49,9 @@ rm -rf /tmp/qf /tmp/qw
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/qf -- python3 $R/tools/xpool_qk_bench.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/qw -- python3 $R/tools/xpool_qk_bench.py > /dev/null 2>&1
 python3 $R/tools/pmc_summary.py $(find /tmp/qf -name "*counter_collection.csv" | head -1) $(find /tmp/qw -name "*counter_collection.csv" | head -1) $O/xpool_qk_pmc.json > /dev/null
+ls -la $O
+# round 4 additions: clocks / socket power under the retrieval launch (the 53 k x 4 k made_xpool_fused launch runs at the power limit), the
+# SQ counters of the attention kernels and of the retrieval kernels (MFMA busy, VALU per MFMA, LDS conflicts)
+bash $R/tools/clock_probe.sh > $O/retrieval_clock_power.txt 2>&1
+bash $R/tools/pmc_sq_round4.sh $TAG > $O/pmc_sq.log 2>&1 || true
 ls -la $O

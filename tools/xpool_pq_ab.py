@@ -1,4 +1,4 @@
-"""made_xpool_sims: the 64-video kernel (default) against the 32-video kernel (MADE_XPOOL_SIMS_PQ=32) on the retrieval set, alternating, plus
+"""made_xpool_sims: the 64-video kernel (MADE_XPOOL_SIMS_PQ=64) against the 32-video kernel (the default) on the retrieval set, alternating, plus
 their difference.  python tools/xpool_pq_ab.py [Nv Nm S]"""
 import math, os, sys
 import torch
@@ -18,8 +18,7 @@ vn = torch.nn.functional.normalize(torch.randn(Nv, D, device=dev, generator=g), 
 out = {"64": torch.empty(Nv, Nm, device=dev), "32": torch.empty(Nv, Nm, device=dev)}
 scale = 1 / math.sqrt(D)
 def run(pq):
-    if pq == "32": os.environ["MADE_XPOOL_SIMS_PQ"] = "32"
-    else: os.environ.pop("MADE_XPOOL_SIMS_PQ", None)
+    os.environ["MADE_XPOOL_SIMS_PQ"] = pq
     ops.xpool_sims(Q, K, UU, mask, av, bv, ln3, vn, out[pq], scale=scale)
 def timeit(pq, n=3):
     run(pq); torch.cuda.synchronize()
