@@ -41,8 +41,8 @@ from mgsv_amd.engine import MadeEngine  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round4.sh), per leg
-ROCPROF_AVG_FILE = os.path.join(ROOT, "profiles", "r04_kernel_avg_us.json")   # per-leg, per-kernel average durations of the committed rocprofv3 --kernel-trace --stats runs
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round5.sh), per leg
+ROCPROF_AVG_FILE = os.path.join(ROOT, "profiles", "r05_kernel_avg_us.json")   # per-leg, per-kernel average durations of the committed rocprofv3 --kernel-trace --stats runs
 STEP_CEILING_PAIRS_S = {"train": 62000.0, "eval": 186000.0}          # MFMA ceilings of the whole step (fwd+bwd / fwd)
 
 
@@ -115,7 +115,7 @@ def _roofline(summ: dict, kind: str, dtype: str, per: int, leg: str, overhead_us
     t_mfma = d["flops"] / (peak * 1e12)
     t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
     traffic = rocprof_us = None
-    # the committed rocprofv3 / PMC files hold the bf16 legs (tools/profile_round4.sh): another dtype (the f32 parity legs) or another sequence
+    # the committed rocprofv3 / PMC files hold the bf16 legs (tools/profile_round5.sh): another dtype (the f32 parity legs) or another sequence
     # length than the leg's default has no committed entry -- its launches of the same kernel kind are other problems
     if dtype != "bf16":
         leg = leg + "_" + dtype
