@@ -103,7 +103,8 @@ class MadeConfig:
         if getattr(args, "span_loss_type", "l1") != "l1":
             bad.append(f"span_loss_type={args.span_loss_type} (only the l1 span head / matcher cost is built)")
         if getattr(args, "position_embedding", "sine") not in ("sine", "v2"):
-            bad.append(f"position_embedding={args.position_embedding}")
+            # the reference refuses it too, with this error (music_detr/position_encoding.py:98-105: the 'learned' branch is commented out)
+            raise ValueError(f"not supported {args.position_embedding}")
         if bad:
             raise NotImplementedError("MaDe HIP path does not cover: " + "; ".join(bad))
         if hasattr(args, "max_m_duration") and hasattr(args, "stride") and not hasattr(args, "max_snippet_num"):

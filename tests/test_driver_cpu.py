@@ -51,11 +51,16 @@ def test_flags_that_select_unbuilt_code_fail_loudly():
     """A legal reference flag the HIP path has no code for must raise when the configuration is built, never be dropped silently."""
     import pytest
     from mgsv_amd.config import MadeConfig, cfg_native
-    for k, v in (("detr_pre_norm", True), ("span_loss_type", "ce"), ("position_embedding", "learned")):
+    for k, v in (("detr_pre_norm", True), ("span_loss_type", "ce")):
         args = cfg_native().to_args(local_rank=0)
         setattr(args, k, v)
         with pytest.raises(NotImplementedError):
             MadeConfig.from_args(args)
+    # the reference itself refuses the learned position embedding (music_detr/position_encoding.py:98-105: ValueError "not supported learned")
+    args = cfg_native().to_args(local_rank=0)
+    args.position_embedding = "learned"
+    with pytest.raises(ValueError, match="not supported learned"):
+        MadeConfig.from_args(args)
     # encoder-variant flags are carried into the configuration (they used to be ignored)
     args = cfg_native().to_args(local_rank=0)
     args.with_cls_token, args.transformer_is_share, args.agg_module = 1, 1, "transf"
