@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MADE_ABI_VERSION 4
+#define MADE_ABI_VERSION 5
 
 enum MadeDtype { MADE_F32 = 0, MADE_BF16 = 1 };
 
