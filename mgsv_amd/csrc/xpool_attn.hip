@@ -1253,367 +1253,10 @@ __global__ __launch_bounds__(256, 2) void xpool_sims64_kernel(const MadeXpoolSim
     }
 }
 
-// ---- made_xpool_sims, 64 videos and EIGHT waves per workgroup (round 5; MADE_XPOOL_SIMS_PQ=648).  The counters of the kernels above say the loop is
-// neither byte- nor instruction-bound: a wave is parked 57 % of its cycles (SQ_WAIT_ANY 38 % + SQ_WAIT_INST_ANY 19 %), a SIMD's vector issue is 42 % busy,
-// its matrix pipe 17 %, with TWO waves per SIMD (two workgroups of four 256-register waves).  This form halves the registers instead of the bytes:
-// 64 videos over eight waves of at most 128 registers -- FOUR waves per SIMD from two independent workgroups, so that a parked wave has three others
-// behind it.  Wave w = (video group vq = w & 3, segment half sh = w >> 2):
-//   pass 1  16 x 16 x 32 score tiles of videos 16 vq .. for the 16-segment tiles 3 sh .. 3 sh + 2; the two waves of a video group exchange their
-//           maxima through LDS (one barrier), write their halves of the probability rows and their partial denominators;
-//   pass 2  wave w owns rows 32 w .. of o and of z for all 64 videos: 4 accumulator tiles (64 registers), 4 MFMAs per 16-segment step;
-//   tail    the 64-video kernel's sums on one o tile and one z tile per wave; one wave of eight (in turn) combines a track's pairs.
-// LDS 79 KB: K tiles / value ring 48 KB; the tail's exchange [8][64][12] f32 (24 KB) over the probabilities (13 KB); maxima / sums; constants.
-template <int D> struct Xs64w {
-    using CK = XaCfg<D>;
-    using CU = XaCfg<2 * D>;
-    static constexpr int NW = 8, PQ = 64, T = 512;
-    static constexpr int PP = 96 * 2 + 16;
-    static constexpr int P_OFF = 3 * CK::STG;
-    static constexpr int PART_OFF = P_OFF;                       // [8][64][12] f32 over the probabilities (dead between pass 2's last barrier and the next pass 1)
-    static constexpr int MAX_OFF = P_OFF + NW * PQ * 48;         // [2][64] f32: maxima of the two segment halves of a video
-    static constexpr int SUM_OFF = MAX_OFF + 2 * PQ * 4;         // [2][64] f32: their sums of exp2
-    static constexpr int G2_OFF = SUM_OFF + 2 * PQ * 4;          // [D] f32: g3^2
-    static constexpr int AFR_OFF = G2_OFF + D * 4;               // [8 waves][2 k-steps][2 lane halves][8] 16-byte fragments: the tail's constant A operands
-    static constexpr int TBL_OFF = AFR_OFF + NW * 2 * 2 * 8 * 16;
-    static constexpr int MAX_TRACKS = (80 * 1024 - TBL_OFF) / 32;
-    static_assert(PQ * PP <= NW * PQ * 48, "the probabilities sit inside the exchange region");
-    static_assert(CK::STG == CU::HSTG && CK::PT == 16 && D == 256, "tile split");
-    static_assert(MAX_TRACKS >= 64, "the LDS map does not fit half a CU");
-};
-
-template <int D>
-__global__ __launch_bounds__(512, 4) void xpool_sims64w_kernel(const MadeXpoolSimsArgs a, const int* __restrict__ info, int tracks_per_chunk, int nvt, int nchunks) {
-    using X = Xs64w<D>;
-    using CK = typename X::CK;
-    using CU = typename X::CU;
-    constexpr int PP = X::PP, PQ = X::PQ;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
-    const int v16 = lane & 15, g4 = lane >> 4;
-    const int vq = wave & 3, sh = wave >> 2;                      // pass 1: video group and segment half of this wave
-    int vtile, chunk;                                             // (workgroup order: see the 32-video kernel)
-    if ((nchunks & 7) == 0) {
-        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-        chunk = (jx / nvt) * 8 + xcd; vtile = jx % nvt;
-    } else { chunk = blockIdx.x / nvt; vtile = blockIdx.x % nvt; }
-    const int64_t n0 = (int64_t)vtile * PQ;
-    const int64_t m_begin = (int64_t)chunk * tracks_per_chunk;
-    const int64_t m_end = (m_begin + tracks_per_chunk < a.Nm) ? m_begin + tracks_per_chunk : a.Nm;
-    if (m_begin >= m_end) return;
-    const int T = (int)(m_end - m_begin);
-    const uint32_t lbase = (uint32_t)(uintptr_t)(lds3_t)lds;
-    const float* wsf = (const float*)a.ws;
-    auto vid = [&](int64_t i) __attribute__((always_inline)) -> int64_t { return i < a.Nv ? i : a.Nv - 1; };
-    const uint32_t q_off = (uint32_t)(vid(n0 + 16 * vq + v16) * a.ldq * 2 + g4 * 16);   // Q rows of this wave's 16 videos (re-read per track: see the 64-video kernel)
-    float mc[16];
-#pragma unroll
-    for (int q = 0; q < 15; ++q) mc[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wsf[xs_ws_c(a.Nv, D) + q])));
-    if (tid < D) {
-        const float g3 = a.ln3_g[tid];
-        ((float*)(lds + X::G2_OFF))[tid] = g3 * g3;
-    }
-    // the tail's constant A operands for this wave's z tile (rows 32 w ..; functional m of the product = row m, rows 7 .. 31 zero)
-    if ((lane & 31) < 8) {
-        const int mf = lane & 31;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 fr;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int d = 32 * wave + 8 * (2 * s2 + (jj >> 2)) + 4 * hh + (jj & 3);
-                const float g3 = a.ln3_g[d], Av = a.av[d], Bv = a.bv[d], g2 = g3 * g3, gb = g3 * a.ln3_b[d];
-                const float val = mf == 0 ? 1.f : mf == 1 ? Bv : mf == 2 ? Av : mf == 3 ? g2 : mf == 4 ? g2 * Bv : mf == 5 ? g2 * Av : mf == 6 ? gb : 0.f;
-                fr[jj] = (bf16_t)val;
-            }
-            *(bf16x8*)(lds + X::AFR_OFF + (((wave * 2 + s2) * 2 + hh) * 8 + mf) * 16) = fr;
-        }
-    }
-    for (int i = tid; i < T; i += X::T) {
-        const int* ip = info + (m_begin + i) * XA_INFO;
-        *(u32x4*)(lds + X::TBL_OFF + i * 32) = (u32x4){(unsigned)ip[0], (unsigned)ip[1], 0u, 0u};
-        *(u32x4*)(lds + X::TBL_OFF + i * 32 + 16) = *(const u32x4*)(ip + 16);
-    }
-    const float c = a.scale * 1.4426950408889634f;
-
-    struct Trk { int s_eff, first; unsigned w0, w1, w2; };
-    auto load_track = [&](int jt_, Trk& t) __attribute__((always_inline)) {
-        const u32x4 h = xa_rd<u32x4>(lbase + X::TBL_OFF + (uint32_t)jt_ * 32), wv = xa_rd<u32x4>(lbase + X::TBL_OFF + (uint32_t)jt_ * 32 + 16);
-        t.s_eff = __builtin_amdgcn_readfirstlane((int)h[0]); t.first = __builtin_amdgcn_readfirstlane((int)h[1]);
-        t.w0 = __builtin_amdgcn_readfirstlane(wv[0]); t.w1 = __builtin_amdgcn_readfirstlane(wv[1]); t.w2 = __builtin_amdgcn_readfirstlane(wv[2]);
-    };
-    auto tile_word = [&](const Trk& t, int tile) __attribute__((always_inline)) -> unsigned {
-        return (t.w0 & (tile == 0 ? ~0u : 0u)) | (t.w1 & (tile == 1 ? ~0u : 0u)) | (t.w2 & (tile >= 2 ? ~0u : 0u));
-    };
-    const uint32_t ldk_b = (uint32_t)a.ldk * 2u, ldu_b = (uint32_t)a.ldu * 2u;
-    // K tile t: 16 pieces of two rows; wave w brings pieces 2 w, 2 w + 1 of every tile
-    auto issue_k = [&](int64_t m, const Trk& tk) __attribute__((always_inline)) {
-        const uint32_t rip = xa_opaque((uint32_t)lane / CK::CPR), slot = xa_opaque((uint32_t)lane % CK::CPR);
-        const unsigned char* Kb = (const unsigned char*)a.K + m * a.k_bs * 2;
-        const int ntl = tk.s_eff > 0 ? (tk.s_eff + 31) / 32 : 1;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (t < ntl) {
-                const unsigned word = tile_word(tk, t);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int pit = wave * 2 + i;
-                    const uint32_t row = (uint32_t)pit * CK::RPP + rip;
-                    const int seg = t * 32 + (int)row;
-                    const bool valid = seg < tk.s_eff && ((word >> row) & 1u);
-                    const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
-                    const uint32_t chunk = slot ^ (row & 15u);
-                    xs_dma16(Kb, __umul24(srow, ldk_b) + chunk * 16u, lbase + (uint32_t)(t * CK::STG + pit * 1024));
-                }
-            }
-        }
-    };
-    // value half tile h (16 rows of 1 KB) -> ring slot h % 3: wave w brings rows 2 w, 2 w + 1
-    auto issue_u = [&](int64_t m, int h, const Trk& tk) __attribute__((always_inline)) {
-        const uint32_t slot = xa_opaque((uint32_t)lane);
-        const unsigned char* Ub = (const unsigned char*)a.UU + m * a.u_bs * 2;
-        const unsigned bits = (tile_word(tk, h >> 1) >> ((h & 1) * 16)) & 0xFFFFu;
-        const uint32_t dst = (uint32_t)((h % 3) * CU::HSTG);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint32_t row = (uint32_t)(wave * 2 + i);
-            const int seg = h * 16 + (int)row;
-            const bool valid = seg < tk.s_eff && ((bits >> row) & 1u);
-            const uint32_t srow = (uint32_t)(valid ? seg : tk.first);
-            const uint32_t chunk = (((slot >> 2) ^ (row & 7u)) << 2) | (slot & 3u);
-            xs_dma16(Ub, __umul24(srow, ldu_b) + chunk * 16u, lbase + dst + row * 1024u);
-        }
-    };
-
-    // (every per-lane address below is rebuilt from the lane number where it is used: at 128 registers a loop-invariant one is a spill, and a scratch
-    //  reload waits for vmcnt(0), i.e. for every piece this wave has in flight)
-
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();                                               // the track table and the constants are in LDS
-    Trk tk;
-    load_track(0, tk);
-    bf16x8 qf[D / 32];
-#pragma unroll
-    for (int ks = 0; ks < D / 32; ++ks) qf[ks] = *(const bf16x8*)((const unsigned char*)a.Q + ks * 64 + (uint64_t)q_off);
-    issue_k(m_begin, tk);
-
-    for (int jt = 0; jt < T; ++jt) {
-        const int64_t m = m_begin + jt;
-        const int s_eff = tk.s_eff;
-        const int NH = s_eff > 0 ? (s_eff + 15) / 16 : 1;
-
-        // ================================================================================================ pass 1: tiles 3 sh .. of this wave's 16 videos
-        f32x4 sacc[3];
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        uint32_t ka[4];
-        {
-            const uint32_t lo_ = xa_opaque((uint32_t)lane), v16_ = lo_ & 15u, g4_ = lo_ >> 4;
-            const uint32_t kx = lbase + v16_ * CK::ROWB + (((g4_ ^ (v16_ & 3u)) | (v16_ & 12u)) << 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ka[q] = kx ^ (uint32_t)(q << 6);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]) :: "memory");   // this wave's K pieces and Q
-        XA_BARRIER();
-        // (the tile offset is an immediate: one copy of the eight-step chain per (segment half, tile))
-#define XS8_TILE(ST3, ST)                                                                                                                \
-        if (ST < NH) {                                                                                                                  \
-            constexpr int TO = (ST >> 1) * CK::STG + (ST & 1) * 16 * CK::ROWB;                                                          \
-            bf16x8 f[4];                                                                                                                \
-            f[0] = xs_read_k<TO>(ka[0]); f[1] = xs_read_k<TO>(ka[1]); f[2] = xs_read_k<TO>(ka[2]); f[3] = xs_read_k<TO>(ka[3]);          \
-            xa_wait_lgkm<3>(f[0]); sacc[ST3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], qf[0], z4, 0, 0, 0); f[0] = xs_read_k<TO + 256>(ka[0]); \
-            xa_wait_lgkm<3>(f[1]); sacc[ST3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], qf[1], sacc[ST3], 0, 0, 0); f[1] = xs_read_k<TO + 256>(ka[1]); \
-            xa_wait_lgkm<3>(f[2]); sacc[ST3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], qf[2], sacc[ST3], 0, 0, 0); f[2] = xs_read_k<TO + 256>(ka[2]); \
-            xa_wait_lgkm<3>(f[3]); sacc[ST3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[3], qf[3], sacc[ST3], 0, 0, 0); f[3] = xs_read_k<TO + 256>(ka[3]); \
-            xa_wait_lgkm<3>(f[0]); sacc[ST3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], qf[4], sacc[ST3], 0, 0, 0);                \
-            xa_wait_lgkm<2>(f[1]); sacc[ST3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], qf[5], sacc[ST3], 0, 0, 0);                \
-            xa_wait_lgkm<1>(f[2]); sacc[ST3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], qf[6], sacc[ST3], 0, 0, 0);                \
-            xa_wait_lgkm<0>(f[3]); sacc[ST3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[3], qf[7], sacc[ST3], 0, 0, 0);                \
-        } else sacc[ST3] = z4;
-        if (sh == 0) { XS8_TILE(0, 0) XS8_TILE(1, 1) XS8_TILE(2, 2) }
-        else { XS8_TILE(0, 3) XS8_TILE(1, 4) XS8_TILE(2, 5) }
-#undef XS8_TILE
-        XA_BARRIER();                                               // the K tiles are consumed: their LDS is the value ring now
-        issue_u(m, 0, tk);
-        if (NH > 1) issue_u(m, 1, tk);
-
-        // this wave's half of the softmax: lane (g4, v16) holds segments 16 st + 4 g4 + (0..3), st = 3 sh + st3, of video 16 vq + v16
-        float mx = -INFINITY;
-        const uint32_t lo1 = xa_opaque((uint32_t)lane), g4s = lo1 >> 4, v16s = lo1 & 15u;
-#pragma unroll
-        for (int st3 = 0; st3 < 3; ++st3) {
-            const int st = 3 * sh + st3;
-            if (st < NH) {
-                const unsigned wbits = (tile_word(tk, st >> 1) >> (16 * (st & 1))) >> (4u * g4s);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sc = ((wbits >> e) & 1u) ? sacc[st3][e] * c : -INFINITY;
-                    sacc[st3][e] = sc;
-                    mx = fmaxf(mx, sc);
-                }
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, xa_other_half(mx));
-        const uint32_t mx_a = lbase + X::MAX_OFF + (uint32_t)(sh * PQ + 16 * vq) * 4 + v16s * 4u;
-        if (g4s == 0) xa_wr<float>(mx_a, mx);
-        XA_BARRIER();                                               // the two halves' maxima meet
-        mx = fmaxf(mx, xa_rd<float>(mx_a ^ (uint32_t)(PQ * 4)));
-        const uint32_t p_wr = lbase + X::P_OFF + (uint32_t)(16 * vq) * PP + v16s * PP + ((g4s & 1u) * 16u + (g4s >> 1) * 8u);
-        float psum = 0.f;
-#pragma unroll
-        for (int st3 = 0; st3 < 3; ++st3) {
-            const int st = 3 * sh + st3;
-            if (st < NH) {
-                bf16x4 pf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pr_ = __builtin_amdgcn_exp2f(sacc[st3][e] - mx);
-                    psum += pr_;
-                    pf[e] = (bf16_t)pr_;
-                }
-                xa_wr<bf16x4>(p_wr + (uint32_t)st * 32, pf);
-            }
-        }
-        psum += __shfl_xor(psum, 16);
-        psum += xa_other_half(psum);
-        if (g4s == 0) xa_wr<float>(mx_a + (uint32_t)(X::SUM_OFF - X::MAX_OFF), psum);
-
-        // ================================================================================================ pass 2: rows 32 w .. of o and of z, all 64 videos
-        f32x16 oacc[2][2];                                          // [o, z][video tile]
-        uint32_t ug[2], u_rd, p_rd;
-        {
-            const uint32_t lo2 = xa_opaque((uint32_t)lane), g4_ = lo2 >> 4, i16 = lo2 & 15u;
-            const uint32_t trow = 4u * (g4_ >> 1) + (i16 >> 2);
-            u_rd = lbase + trow * CU::ROWB + (g4_ & 1u) * 32u + (i16 & 3u) * 8u;
-            p_rd = lbase + X::P_OFF + (lo2 & 31u) * PP + (lo2 >> 5) * 16u;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) ug[dt] = (((uint32_t)(wave + 8 * dt)) ^ (trow & 7u)) << 6;
-        }
-#define XS8_STEP(FIRST)                                                                                                                          \
-        {                                                                                                                                        \
-            if (h + 1 < NH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      /* half tile h has landed (h + 1 may be in flight) */          \
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                                \
-            XA_BARRIER();                                           /* (the first one also publishes the probabilities and their sums) */       \
-            if (h + 2 < NH) issue_u(m, h + 2, tk);                                                                                               \
-            const uint32_t ub = u_rd + (uint32_t)((h % 3) * CU::HSTG);                                                                           \
-            bf16x8 pb0 = xa_read128(p_rd + (uint32_t)h * 32), pb1 = xa_read128_off<32 * PP>(p_rd + (uint32_t)h * 32);                            \
-            bf16x4 lo[2], hi[2];                                                                                                                 \
-            _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                                   \
-                const uint32_t va = ub + ug[dt];                                                                                                 \
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[dt]) : "v"(va));                                                              \
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(va), "n"(8 * CU::ROWB));                                 \
-            }                                                                                                                                    \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb0), "+v"(pb1), "+v"(lo[0]), "+v"(lo[1]), "+v"(hi[0]), "+v"(hi[1]));                    \
-            _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                                   \
-                const bf16x8 uf = __builtin_shufflevector(lo[dt], hi[dt], 0, 1, 2, 3, 4, 5, 6, 7);                                               \
-                oacc[dt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pb0, FIRST ? z16 : oacc[dt][0], 0, 0, 0);                              \
-                oacc[dt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, pb1, FIRST ? z16 : oacc[dt][1], 0, 0, 0);                              \
-            }                                                                                                                                    \
-        }
-        {
-            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            { const int h = 0; XS8_STEP(true) }
-            for (int h = 1; h < NH; ++h) XS8_STEP(false)
-        }
-#undef XS8_STEP
-        XA_BARRIER();                                               // value ring and probabilities are free
-        // g3 * vn of the lane's two videos at this wave's z rows (32 w + 8 g + 4 hh + i): [video tile][g >> 1], in flight under the o tile's sums
-        bf16x8 gq[2][2];
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            const int rr = (int)xa_opaque((uint32_t)lane) & 31;
-            const uint32_t gv_off = (uint32_t)(xs_ws_gvb(a.Nv, D) * 4 + vid(n0 + 32 * vt + rr) * (D * 2) + (wave * 2 + hh) * 32);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) gq[vt][q] = *(const bf16x8*)((const unsigned char*)a.ws + (gv_off + (uint32_t)(q * 16)));
-        }
-        float su_[2], sq_[2], il_[2];
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            const uint32_t la = lbase + X::SUM_OFF + (uint32_t)(32 * vt) * 4 + (xa_opaque((uint32_t)lane) & 31u) * 4u;
-            const float inv_l = 1.f / (xa_rd<float>(la) + xa_rd<float>(la + PQ * 4));
-            f32x2_t su2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const f32x2_t x2 = {oacc[0][vt][e], oacc[0][vt][e + 1]};
-                su2 += x2; sq2 += x2 * x2;
-            }
-            float su = (su2[0] + su2[1]) * inv_l, sq = (sq2[0] + sq2[1]) * (inv_l * inv_l);
-            su += xa_other_half(su); sq += xa_other_half(sq);
-            su_[vt] = su; sq_[vt] = sq; il_[vt] = inv_l;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(su_[0]), "+v"(su_[1]), "+v"(sq_[0]), "+v"(sq_[1]), "+v"(gq[0][0]), "+v"(gq[0][1]), "+v"(gq[1][0]), "+v"(gq[1][1]) :: "memory");
-        Trk nx; nx.s_eff = 0; nx.first = 0; nx.w0 = nx.w1 = nx.w2 = 0u;
-        if (jt + 1 < T) { load_track(jt + 1, nx); issue_k(m + 1, nx); }
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            f32x2_t q1 = {0.f, 0.f}, q2 = {0.f, 0.f}, b1 = {0.f, 0.f};
-            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 facc = z16;
-            const uint32_t g2_r = xa_opaque(lbase + X::G2_OFF + (uint32_t)(32 * wave + 4 * hh) * 4);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 g2 = xa_rd<f32x4>(g2_r + g * 32);
-#pragma unroll
-                for (int jj = 0; jj < 4; jj += 2) {
-                    const f32x2_t z2 = {oacc[1][vt][4 * g + jj], oacc[1][vt][4 * g + jj + 1]};
-                    const f32x2_t zz = z2 * z2;
-                    q1 += zz;
-                    q2 += zz * (f32x2_t){g2[jj], g2[jj + 1]};
-                    b1 += z2 * (f32x2_t){(float)gq[vt][g >> 1][(g & 1) * 4 + jj], (float)gq[vt][g >> 1][(g & 1) * 4 + jj + 1]};
-                }
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 zb;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) zb[jj] = (bf16_t)oacc[1][vt][8 * s2 + jj];
-                const bf16x8 af = xa_rd<bf16x8>(lbase + X::AFR_OFF + (uint32_t)((((wave * 2 + s2) * 2 + hh) * 8 + (r < 7 ? r : 7)) * 16));
-                facc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, zb, facc, 0, 0, 0);
-            }
-            float Q1 = q1[0] + q1[1], Q2 = q2[0] + q2[1], B1 = b1[0] + b1[1];
-            Q1 += xa_other_half(Q1); Q2 += xa_other_half(Q2); B1 += xa_other_half(B1);
-            const uint32_t pw = lbase + X::PART_OFF + (uint32_t)((wave * PQ + 32 * vt + r) * 48);
-            if (hh == 0) { xa_wr<f32x4>(pw, (f32x4){su_[vt], sq_[vt], Q1, Q2}); xa_wr<f32x4>(pw + 16, (f32x4){facc[0], facc[1], facc[2], facc[3]}); }
-            else xa_wr<f32x4>(pw + 32, (f32x4){facc[0], facc[1], facc[2], B1});
-        }
-        // (Q again, for the next track: 32 registers the tail above had no room for)
-#pragma unroll
-        for (int ks = 0; ks < D / 32; ++ks) qf[ks] = *(const bf16x8*)((const unsigned char*)a.Q + ks * 64 + (uint64_t)q_off);
-        XA_BARRIER();
-        // ---- one wave (they take turns), lane = video: LayerNorm2's k1 / k2, the six sums, LayerNorm3 + cosine
-        if (wave == (jt & 7)) {
-            const uint32_t pr = xa_opaque(lbase + X::PART_OFF + (uint32_t)lane * 48);
-            f32x4 A0 = xa_rd<f32x4>(pr), A1 = xa_rd<f32x4>(pr + 16), A2 = xa_rd<f32x4>(pr + 32);
-#pragma unroll
-            for (int q = 1; q < 8; ++q) {
-                if ((q & 3) == 0) asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2) :: "memory");   // four slices' reads in flight at a time (Q's 32 registers are in flight too)
-                A0 += xa_rd<f32x4>(pr + q * (PQ * 48)); A1 += xa_rd<f32x4>(pr + q * (PQ * 48) + 16); A2 += xa_rd<f32x4>(pr + q * (PQ * 48) + 32);
-            }
-            const uint32_t la = lbase + X::SUM_OFF + (uint32_t)lane * 4;
-            const float inv_l = 1.f / (xa_rd<float>(la) + xa_rd<float>(la + PQ * 4));
-            const uint32_t pv_off = (uint32_t)((xs_ws_pp(a.Nv, D) + vid(n0 + (int64_t)xa_opaque((uint32_t)lane)) * 4) * 4);
-            const f32x4 pv4 = *(const f32x4*)((const unsigned char*)a.ws + pv_off);
-            const float mean = A0[0] * (1.f / D);
-            const float var = fmaxf(A0[1] * (1.f / D) - mean * mean, 0.f);
-            const float k1n = __builtin_amdgcn_rsqf(var + a.eps), k2 = -mean * k1n, k1 = k1n * inv_l;
-            const float Q1 = A0[2], Q2 = A0[3], F1 = A1[0], F2 = A1[1], F3 = A1[2], F4 = A1[3], F5 = A2[0], F6 = A2[1], F7 = A2[2], B1 = A2[3];
-            const float s1 = k1 * F1 + k2 * mc[XC_BV] + mc[XC_AV];
-            const float s2 = k1 * k1 * Q1 + 2.f * k1 * (k2 * F2 + F3) + k2 * k2 * mc[XC_BV2] + 2.f * k2 * mc[XC_BVAV] + mc[XC_AV2];
-            const float p1 = k1 * B1 + k2 * pv4[2] + pv4[3];
-            const float c1 = k1 * F4 + k2 * mc[XC_G2BV] + mc[XC_G2AV];
-            const float c2 = k1 * k1 * Q2 + 2.f * k1 * (k2 * F5 + F6) + k2 * k2 * mc[XC_G2BV2] + 2.f * k2 * mc[XC_G2BVAV] + mc[XC_G2AV2];
-            const float e1 = k1 * F7 + k2 * mc[XC_GBBV] + mc[XC_GBAV];
-            const float mu = s1 * (1.f / D);
-            const float vy = fmaxf(s2 * (1.f / D) - mu * mu, 0.f);
-            const float rs = __builtin_amdgcn_rsqf(vy + a.eps);
-            const float dot = rs * (p1 - mu * pv4[0]) + pv4[1];
-            const float zz = rs * rs * (c2 - 2.f * mu * c1 + mu * mu * mc[XC_G2]) + 2.f * rs * (e1 - mu * mc[XC_GB]) + mc[XC_B2];
-            const int64_t vrow = n0 + (int64_t)xa_opaque((uint32_t)lane);
-            if (vrow < a.Nv) a.sims[vrow * a.ld_sims + m] = dot * __builtin_amdgcn_rsqf(zz);
-        }
-        tk = nx;
-    }
-}
+// (Round 5 also tried this kernel with EIGHT waves of <= 128 registers per workgroup -- four waves per SIMD from two workgroups, a wave per
+//  32 rows of o and of z, the softmax of a video split over two waves: 120 registers, no spill, the same sums to 1.2e-7 -- and measured
+//  60.1 ms against 53.9 ms on 53 000 x 4 000: the per-pair instruction work is what the loop costs, and the split adds an exchange barrier and
+//  reads every probability row twice.  profiles/r05_xpool_sims_8wave.txt; the source is in the history, commit "made_xpool_sims: 8-wave variant".)
 
 // per video: gv = g3 * vn, (sum gv, sum b3 vn, sum gv Bv, sum gv Av); per model: the XsConst sums.  One wave per video.
 template <int D>
@@ -1719,15 +1362,13 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     // the retrieval set's tracks: 32 videos (MADE_XPOOL_SIMS_PQ=64: round 5's 64-video kernel -- half the LDS-DMA bytes per pair, the same speed
     // within 1.2 %: the comment in front of it) and four waves per workgroup, two workgroups per CU; at most MAX_TRACKS per chunk (the track table
     // in LDS), as few partial rounds of the chip as possible
-    const bool pq64 = getenv("MADE_XPOOL_SIMS_PQ") && (atoi(getenv("MADE_XPOOL_SIMS_PQ")) == 64 || atoi(getenv("MADE_XPOOL_SIMS_PQ")) == 648);
-    const bool w8 = getenv("MADE_XPOOL_SIMS_PQ") && atoi(getenv("MADE_XPOOL_SIMS_PQ")) == 648;      // 64 videos, eight waves of <= 128 registers
+    const bool pq64 = getenv("MADE_XPOOL_SIMS_PQ") && atoi(getenv("MADE_XPOOL_SIMS_PQ")) == 64;
     static bool attr32 = false;
     if (!attr32) {
         hipError_t e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims64_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims64_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_sims64w_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) { made_set_error("made_xpool_sims: cannot reserve 80 KB of LDS: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
         attr32 = true;
     }
@@ -1741,7 +1382,7 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     // 56 GB, 64: 57.2 ms / 31 GB, 32: 59.2 ms / 26 GB (a workgroup's prologue -- Q, g3 vn, the constant fragments -- costs about two tracks).
     int64_t max_per = 64;
     if (getenv("MADE_XPOOL_SIMS_PER") && atoi(getenv("MADE_XPOOL_SIMS_PER")) > 0) max_per = atoi(getenv("MADE_XPOOL_SIMS_PER"));
-    const int64_t max_tracks = (use64 && w8) ? Xs64w<D>::MAX_TRACKS : use64 ? Xs64<D>::MAX_TRACKS : Xs32<D>::MAX_TRACKS;
+    const int64_t max_tracks = use64 ? Xs64<D>::MAX_TRACKS : Xs32<D>::MAX_TRACKS;
     if (max_per > max_tracks) max_per = max_tracks;
     const int64_t c_lo = (a.Nm + max_per - 1) / max_per;
     double best = 1e30; int64_t bc = c_lo;
@@ -1755,8 +1396,7 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     int nch = (int)((a.Nm + per32 - 1) / per32);
     if (nch >= 8) nch = (nch + 7) / 8 * 8;                          // (chunks behind the last track exit at once)
     dim3 g32((unsigned)(nvt32 * nch));
-    if (use64 && w8 && !stamps64) hipLaunchKernelGGL((xpool_sims64w_kernel<D>), g32, dim3(512), Xs64w<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
-    else if (use64 && stamps64) hipLaunchKernelGGL((xpool_sims64_kernel<D, true>), g32, dim3(256), Xs64<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
+    if (use64 && stamps64) hipLaunchKernelGGL((xpool_sims64_kernel<D, true>), g32, dim3(256), Xs64<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
     else if (use64) hipLaunchKernelGGL((xpool_sims64_kernel<D, false>), g32, dim3(256), Xs64<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
     else if (stamps32) hipLaunchKernelGGL((xpool_sims32_kernel<D, true>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);
     else hipLaunchKernelGGL((xpool_sims32_kernel<D, false>), g32, dim3(256), Xs32<D>::TBL_OFF + per32 * 32, st, a, (const int*)info, per32, (int)nvt32, nch);

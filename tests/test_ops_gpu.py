@@ -758,7 +758,7 @@ def test_xpool_fused_against_f32_math(dev, Nv, Nm, S, holes):
     assert torch.equal(torch.nan_to_num(s2, nan=5.0), torch.nan_to_num(got, nan=5.0))
 
 
-@pytest.mark.parametrize("pq", [32, 64, 648])
+@pytest.mark.parametrize("pq", [32, 64])
 @pytest.mark.parametrize("Nv,Nm,S,holes", [(300, 21, 96, False), (64, 9, 40, True), (129, 3, 17, False), (513, 70, 80, True), (70, 300, 64, True), (1000, 1200, 96, True)])
 def test_xpool_sims_linear_on_the_values(dev, Nv, Nm, S, holes, pq, monkeypatch):
     """pq: videos per workgroup -- round 4's 32-video kernel (the default) and round 5's 64-video kernel (MADE_XPOOL_SIMS_PQ=64: 16 x 16 score
@@ -796,7 +796,7 @@ def test_xpool_sims_linear_on_the_values(dev, Nv, Nm, S, holes, pq, monkeypatch)
     ops.xpool_sims(Q, Kd, UUd, mask, av, bv, ln3, vn, sims[:, :Nm], scale=scale)
     torch.cuda.synchronize()
     assert bool((sims[:, Nm:] == -7.0).all())
-    if pq != 32:                                             # the 64-video kernels (648: eight waves of <= 128 registers) against the 32-video one
+    if pq != 32:                                             # the two kernels against each other
         monkeypatch.setenv("MADE_XPOOL_SIMS_PQ", "32")
         s32 = torch.empty(Nv, Nm, device=dev)
         ops.xpool_sims(Q, Kd, UUd, mask, av, bv, ln3, vn, s32, scale=scale)

@@ -1,5 +1,5 @@
-"""made_xpool_sims: the 64-video kernels (MADE_XPOOL_SIMS_PQ=64: four waves of 256 registers; 648: eight waves of <= 128) against the 32-video
-kernel (the default) on the retrieval set, alternating, plus their differences.  python tools/xpool_pq_ab.py [Nv Nm S]"""
+"""made_xpool_sims: the 64-video kernel (MADE_XPOOL_SIMS_PQ=64) against the 32-video kernel (the default) on the retrieval set, alternating, plus
+their difference.  python tools/xpool_pq_ab.py [Nv Nm S]   (ARMS=64,648,... : other values of the knob the library knows)"""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,8 @@ mask = (torch.arange(S, device=dev)[None] < lens[:, None]).float()
 vec = lambda: torch.randn(D, device=dev, generator=g) * 0.1
 ln3, av, bv = (1 + vec(), vec()), vec(), vec()
 vn = torch.nn.functional.normalize(torch.randn(Nv, D, device=dev, generator=g), dim=-1)
-out = {k: torch.empty(Nv, Nm, device=dev) for k in ("648", "64", "32")}
+ARMS = os.environ.get("ARMS", "64").split(",")
+out = {k: torch.empty(Nv, Nm, device=dev) for k in ARMS + ["32"]}
 scale = 1 / math.sqrt(D)
 def run(pq):
     os.environ["MADE_XPOOL_SIMS_PQ"] = pq
@@ -28,8 +29,8 @@ def timeit(pq, n=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 for rep in range(3):
-    t8, t64, t32 = timeit("648"), timeit("64"), timeit("32")
-    print(f"Nv={Nv} Nm={Nm} S={S}: 64-video 8-wave kernel {t8:8.2f} ms   64-video kernel {t64:8.2f} ms   32-video kernel {t32:8.2f} ms   ratios {t32 / t8:.3f} {t32 / t64:.3f}", flush=True)
-for k in ("648", "64"):
+    ts = {k: timeit(k) for k in ARMS + ["32"]}
+    print(f"Nv={Nv} Nm={Nm} S={S}: " + "   ".join(f"PQ={k} {v:8.2f} ms" for k, v in ts.items()) + "   32 / arm: " + " ".join(f"{ts['32'] / ts[k]:.3f}" for k in ARMS), flush=True)
+for k in ARMS:
     d = (out[k] - out["32"]).abs()
     print(f"max |pq{k} - pq32| = {float(d.max()):.3e}, mean {float(d.mean()):.3e}; nan: {int(torch.isnan(out[k]).sum())} / {int(torch.isnan(out['32']).sum())}")
