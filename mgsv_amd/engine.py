@@ -216,6 +216,8 @@ class MadeEngine:
         self.P = P
 
     def _side_stream(self):
+        if os.environ.get("MADE_ONE_STREAM", "0") == "1":     # debugging: every branch on the caller's stream, in issue order
+            return torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side

@@ -64,6 +64,7 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None):
     return sorted(worst)[-3:]
 
 
+_NARROW = {"dim_input": 128, "SA_temporal_heads": 4, "detr_nheads": 4}      # heads of 32: the widths without the D = 256 / 512 specialisations
 _MLP = {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_depth": 0, "max_v_frames": 20, "max_snippet_num": 40}
 
 
@@ -85,16 +86,22 @@ _MLP = {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_de
                                        {"vmr_loss": "dual_single_feature_fuse"}, {"vmr_loss": "dual_single_feature_fuse", "moment_query_type": "xpool", "mml_fusion": "CA"},
                                        {"with_cls_token": 1}, {"with_cls_token": 1, "with_act_after_proj": 1, "video_transformer_depth": 2, "audio_transformer_depth": 2},
                                        {"with_cls_token": 1, "mml_fusion": "CA", "transformer_is_share": 1},
-                                       dict(_MLP), dict(_MLP, with_act_after_proj=1, mml_fusion="CA")])
+                                       dict(_MLP), dict(_MLP, with_act_after_proj=1, mml_fusion="CA"),
+                                       dict(_NARROW),
+                                       # (dropout seed 1: with 1234 one ReLU input of decoder layer 0's FFN -- unit 344, one of 6 rows -- lies within the
+                                       #  forward's 1e-5 of zero and takes the other side: 6e-2 on that layer's tensors at this width, every other
+                                       #  tensor and seeds 1 and 3 at 3e-5; tools/train_variant_probe.py with DUMP= shows the one element)
+                                       dict(_NARROW, mml_fusion="CA", num_moment_queries=2, vmr_fusion="XA-video-music", vmr_loss="single", _seed=1)])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     overrides = dict(overrides)
     shape = overrides.pop("_shape", (3, 20, 40))
+    seed = overrides.pop("_seed", 1234)
     cfg, sd, inp = _setup(*shape, overrides)
     trn = MadeTrainer(cfg, sd, dtype="f32")
     trn.training_dropout = dropout
-    res = trn.loss_and_grads(inp, seed=1234)
-    r, grads = _oracle(cfg, sd, inp, 1234, dropout, trn.param_names)
+    res = trn.loss_and_grads(inp, seed=seed)
+    r, grads = _oracle(cfg, sd, inp, seed, dropout, trn.param_names)
     print(_compare(res, r, grads, rel_tol=5e-3, loss_tol=1e-4))
 
 
@@ -124,7 +131,8 @@ def test_f32_gradients_match_reference_fixture(golden_dir):
 
 
 @pytest.mark.parametrize("dropout", [False, True])
-@pytest.mark.parametrize("overrides", [{}, {"with_cls_token": 1}, {"vmr_fusion": "XA-video-music", "vmr_loss": "single", "moment_query_type": "xpool"}])
+@pytest.mark.parametrize("overrides", [{}, {"with_cls_token": 1}, {"vmr_fusion": "XA-video-music", "vmr_loss": "single", "moment_query_type": "xpool"},
+                                       dict(_NARROW)])
 def test_bf16_gradients_close_to_oracle(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     cfg, sd, inp = _setup(4, 20, 40, overrides)
