@@ -51,6 +51,7 @@ class MadeConfig:
     detr_enc_layers: int = 2
     detr_dec_layers: int = 6
     detr_dropout: float = 0.1
+    detr_pre_norm: bool = False     # pre-norm DETR layers + a final encoder norm (music_detr/transformer.py:33-35,170-189,246-271)
     num_moment_queries: int = 1
     moment_query_type: str = "video"
     predict_center: int = 0
@@ -98,10 +99,10 @@ class MadeConfig:
         cfg = cls(**kw)
         # flags that select code this build does not have must fail loudly, not be ignored
         bad = []
-        if getattr(args, "detr_pre_norm", False):
-            bad.append("detr_pre_norm (pre-norm DETR layers, music_detr/transformer.py:180-189,246-271)")
         if getattr(args, "span_loss_type", "l1") != "l1":
-            bad.append(f"span_loss_type={args.span_loss_type} (only the l1 span head / matcher cost is built)")
+            # the reference cannot run it either: its matcher views the [B, Q, 2] spans as [B * Q, 2, snippet_num] and indexes with float
+            # targets (music_detr/matcher.py:83-86: RuntimeError / IndexError on the first iteration)
+            bad.append(f"span_loss_type={args.span_loss_type} (only the l1 span head / matcher cost exists; the reference's ce branch fails at its first matcher call)")
         if getattr(args, "position_embedding", "sine") not in ("sine", "v2"):
             # the reference refuses it too, with this error (music_detr/position_encoding.py:98-105: the 'learned' branch is commented out)
             raise ValueError(f"not supported {args.position_embedding}")
@@ -117,7 +118,7 @@ class MadeConfig:
         d.update(
             hidden_dim=self.dim_input,
             detr_hidden_dim=self.dim_input,
-            detr_pre_norm=False,
+            detr_pre_norm=bool(self.detr_pre_norm),
             decoder_SA=0,
             position_embedding="sine",
             input_dropout=0.5,

@@ -170,6 +170,8 @@ class MadeEngine:
             lin(p + ".out", p + ".self_attn.out_proj")
             lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
             ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2")
+        if c.detr_pre_norm and c.detr_enc_layers > 0:
+            ln("enc.norm", "detr_transformer.encoder.norm")              # (the reference has it with normalize_before only, transformer.py:34)
         H, hd = c.detr_nheads, D // c.detr_nheads
         for l in range(c.detr_dec_layers):
             p = f"detr_transformer.decoder.layers.{l}"
@@ -615,7 +617,7 @@ class MadeEngine:
         side.wait_stream(cur)
         dec_early = None
         with torch.cuda.stream(side):
-            if not regression and c.moment_query_type != "xpool":
+            if not regression and c.moment_query_type != "xpool" and not c.detr_pre_norm:
                 # The query side of decoder layer 0 (initial queries -> self-attention block -> the folded cross-attention
                 # query) reads nothing the DETR encoder produces: it runs here, beside the encoder, instead of at the head of
                 # the decoder's chain of dependent launches.
@@ -659,8 +661,27 @@ class MadeEngine:
             # the regression head sums the memory over ALL positions, padded ones included (reference model_Uni.py:229), so
             # here the encoder computes them too
             fskip = enc_rows = None
-        ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)      # layer 0: src + pos (no norm)
-        for l in range(c.detr_enc_layers):
+        if c.detr_pre_norm:
+            # reference music_detr/transformer.py:170-189 (forward_pre): the residual stream x is never normalised inside a layer; norm 1 feeds
+            # the attention (q = k = LN1(x) + pos, v = LN1(x)), norm 2 the FFN, and one more norm follows the last layer (:33-35,107-108)
+            x = src
+            for l in range(c.detr_enc_layers):
+                p = f"detr_transformer.encoder.layers.{l}"
+                n1 = ws["x2"][:rows]
+                ops.layernorm_add(x, P[p + ".ln1.g"], P[p + ".ln1.b"], pos2, n1, srcpos, row_skip=fskip)
+                att = self._mha_block(n1, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip, rows=enc_rows, order=order_e)
+                xa = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=x, out=ws["x1"][:rows], rows=enc_rows)
+                n2 = ops.layernorm(xa, P[p + ".ln2.g"], P[p + ".ln2.b"], out=ws["x2"][:rows], row_skip=fskip)
+                h = ops.linear(n2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=ws["ffn"][:rows, :c.detr_dim_feedforward], rows=enc_rows)
+                x = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=xa, out=ws["x0"][:rows], rows=enc_rows)
+            if c.detr_enc_layers > 0:
+                src = ws["x3"][:rows]
+                ops.layernorm_add(x, P["enc.norm.g"], P["enc.norm.b"], pos2, src, srcpos, row_skip=fskip)
+            else:
+                ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)
+        else:
+            ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)      # layer 0: src + pos (no norm)
+        for l in range(0 if c.detr_pre_norm else c.detr_enc_layers):
             p = f"detr_transformer.encoder.layers.{l}"
             att = self._mha_block(src, B, L, P[p + ".in.w"], P[p + ".in.b"], fus_mask, ws, H, pos=srcpos, skip=fskip, rows=enc_rows, order=order_e)
             x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=ws["x1"][:rows], rows=enc_rows)
@@ -700,6 +721,30 @@ class MadeEngine:
             p = f"detr_transformer.decoder.layers.{l}"
             ln2, ln3 = [(P[p + f".ln{i}.g"], P[p + f".ln{i}.b"]) for i in (2, 3)]
             t1, t2 = ws["t1"], ws["t2"]
+            if c.detr_pre_norm:
+                # reference music_detr/transformer.py:246-271 (forward_pre): tgt is the un-normalised residual stream; every branch reads a
+                # norm of it.  The self-attention always runs here.  hs[l] = decoder.norm(tgt after the layer) (:135-136).
+                ta, tb = ws["dz"][0], ws["dz"][1]                 # (f32 rows: the stream is rounded to the compute dtype nowhere)
+                tcur = tgt if l == 0 else ws["dz"][2]
+                ops.layernorm(tcur, P[p + ".ln1.g"], P[p + ".ln1.b"], out=t1)
+                if Q == 1:
+                    skinny(t1, p + ".sa.fold", R=tcur, out=ta)
+                else:
+                    dqkv = ws["dqkv"]
+                    ops.linear(t1, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=qp, a2_row_mod=Q,
+                               segs=[Seg(out=dqkv, col_begin=0, use_a2=True), Seg(out=dqkv[:, 2 * D:], col_begin=2 * D, ldo=dqkv.stride(0))])
+                    d3 = dqkv.view(B, Q, 3 * D)
+                    ops.attention(d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:], ws["datt"].view(B, Q, D), H)
+                    skinny(ws["datt"], p + ".sa.out", R=tcur, out=ta)
+                ops.layernorm(ta, ln2[0], ln2[1], out=t2)
+                skinny(t2, p + ".ca.qk", A2=qp, a2_row_mod=Q, out=ws["dq_all"])
+                ops.attention_wide(dq4, mempos3, mem3, dp4, scale=ca_scale, key_mask=fus_mask,
+                                   n_split=n_split, part_o=ws["part_o"], part_ml=ws["part_ml"])
+                skinny(dpool, p + ".ca.vo", R=ta, out=tb)
+                ops.layernorm(tb, ln3[0], ln3[1], out=t1)
+                skinny(t1, p + ".ff1", act=ops.ACT_RELU, out=ws["dffn"])
+                skinny(ws["dffn"], p + ".ff2", R=tb, out=ws["dz"][2], ln1=(P["dec.norm.g"], P["dec.norm.b"]), ln1_out=hs[l])
+                continue
             if fused:
                 # Fused chain (made_dec_stage): every LayerNorm runs in the prologue of the Linear that consumes it, so a layer is
                 # 8 launches instead of 12 and no split-K partial sums go through HBM.  z[0..2]: the raw rows before norm 1 / 2 / 3.
@@ -810,7 +855,7 @@ class MadeEngine:
         c = self.cfg
         # (made_dec_stage normalises whole rows of width D in its prologue: D = 256 or 512 only; other widths keep the split-K chain)
         return (self.tc == torch.bfloat16 and c.num_moment_queries == 1 and c.moment_query_type in ("video", "music", "zero", "random")
-                and c.D in (256, 512) and not getattr(self, "force_unfused_decoder", False))
+                and c.D in (256, 512) and not c.detr_pre_norm and not getattr(self, "force_unfused_decoder", False))
 
     def _dec_first_rows(self, ws, video: Tensor, music: Tensor) -> Tensor:
         """Raw rows feeding decoder layer 0 (reference transformer.py:73-74, model_Uni.py:216-221): the clip vectors, read in place."""

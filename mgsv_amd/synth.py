@@ -81,6 +81,8 @@ def param_shapes(cfg: MadeConfig) -> "OrderedDict[str, tuple]":
         lin(p + ".linear2", D, Fd)
         ln(p + ".norm1")
         ln(p + ".norm2")
+    if cfg.detr_enc_layers > 0 and getattr(cfg, "detr_pre_norm", False):
+        ln("detr_transformer.encoder.norm")                       # (music_detr/transformer.py:34: only with normalize_before)
     for l in range(cfg.detr_dec_layers):
         p = f"detr_transformer.decoder.layers.{l}"
         mha(p + ".self_attn")

@@ -75,6 +75,8 @@ class MadeTrainer(MadeEngine):
             bad.append(f"mml_localization={c.mml_localization}")
         if c.audio_short_cut and c.contrastive_align_loss and c.contrastive_hdim != c.D:
             bad.append("audio_short_cut with contrastive_dim != D (the reference's own add would not broadcast)")
+        if c.detr_pre_norm:
+            bad.append("detr_pre_norm (the eval engine serves it; the training path's backward is post-norm only)")
         if c.D not in (128, 256, 512):
             bad.append(f"dim_input={c.D} (the kernels are built for 128, 256 and 512; 128 trains through the chain of separate launches)")
         if bad:

@@ -300,6 +300,33 @@ def detr_encoder_layer(x: Tensor, pos: Tensor, pad: Tensor, P, p: str, H: int, d
     return layer_norm(x + _drop(drop, linear(h, P, p + ".linear2"), tag + ".drop2", pd), P, p + ".norm2")
 
 
+def detr_encoder_layer_pre(x: Tensor, pos: Tensor, pad: Tensor, P, p: str, H: int, drop: Optional[Drop] = None, tag: str = "") -> Tensor:
+    """reference: music_detr/transformer.py:170-189 (forward_pre): the norms sit in front of the attention and of the FFN, the residual stream
+    is never normalised inside the layer (TransformerEncoder applies one more norm behind the last layer, :33-35,107-108)."""
+    pd = drop.p_detr if drop is not None else 0.0
+    n1 = layer_norm(x, P, p + ".norm1")
+    qk = n1 + pos
+    x = x + _drop(drop, mha(qk, qk, n1, P, p + ".self_attn", H, pad, drop, tag + ".attn", pd), tag + ".drop1", pd)
+    n2 = layer_norm(x, P, p + ".norm2")
+    h = _drop(drop, torch.relu(linear(n2, P, p + ".linear1")), tag + ".ffn_act", pd)
+    return x + _drop(drop, linear(h, P, p + ".linear2"), tag + ".drop2", pd)
+
+
+def detr_decoder_layer_pre(t: Tensor, qp: Tensor, mem: Tensor, pos: Tensor, pad: Tensor, P, p: str, H: int,
+                           drop: Optional[Drop] = None, tag: str = "") -> Tensor:
+    """reference: music_detr/transformer.py:246-271 (forward_pre; self-attention always runs here, whatever decoder_SA says)."""
+    pd = drop.p_detr if drop is not None else 0.0
+    n1 = layer_norm(t, P, p + ".norm1")
+    q = n1 + qp
+    t = t + _drop(drop, mha(q, q, n1, P, p + ".self_attn", H, None, drop, tag + ".sa_attn", pd), tag + ".drop1", pd)
+    n2 = layer_norm(t, P, p + ".norm2")
+    c = mha(n2 + qp, mem + pos, mem, P, p + ".multihead_attn", H, pad, drop, tag + ".ca_attn", pd)
+    t = t + _drop(drop, c, tag + ".drop2", pd)
+    n3 = layer_norm(t, P, p + ".norm3")
+    h = _drop(drop, torch.relu(linear(n3, P, p + ".linear1")), tag + ".ffn_act", pd)
+    return t + _drop(drop, linear(h, P, p + ".linear2"), tag + ".drop3", pd)
+
+
 def detr_decoder_layer(t: Tensor, qp: Tensor, mem: Tensor, pos: Tensor, pad: Tensor, P, p: str, H: int,
                        drop: Optional[Drop] = None, tag: str = "") -> Tensor:
     """reference: music_detr/transformer.py:273-307 (forward_post; the self-attention
@@ -322,14 +349,18 @@ def detr_transformer(src: Tensor, mask: Tensor, pos: Tensor, target: Optional[Te
     pad = ~(mask.bool())
     H = cfg.detr_nheads
     mem = src
+    pre = bool(getattr(cfg, "detr_pre_norm", False))          # normalize_before (music_detr/transformer.py:325-335 <- args.detr_pre_norm)
+    enc_layer, dec_layer = (detr_encoder_layer_pre, detr_decoder_layer_pre) if pre else (detr_encoder_layer, detr_decoder_layer)
     for l in range(cfg.detr_enc_layers):
-        mem = detr_encoder_layer(mem, pos, pad, P, f"detr_transformer.encoder.layers.{l}", H, drop, f"enc.{l}")
+        mem = enc_layer(mem, pos, pad, P, f"detr_transformer.encoder.layers.{l}", H, drop, f"enc.{l}")
+    if pre and cfg.detr_enc_layers > 0:
+        mem = layer_norm(mem, P, "detr_transformer.encoder.norm")
     B = src.shape[0]
     qp = P["decoder_query_embed.weight"][None].expand(B, -1, -1)
     t = torch.zeros_like(qp) if target is None else target
     hs = []
     for l in range(cfg.detr_dec_layers):
-        t = detr_decoder_layer(t, qp, mem, pos, pad, P, f"detr_transformer.decoder.layers.{l}", H, drop, f"dec.{l}")
+        t = dec_layer(t, qp, mem, pos, pad, P, f"detr_transformer.decoder.layers.{l}", H, drop, f"dec.{l}")
         hs.append(layer_norm(t, P, "detr_transformer.decoder.norm"))
     return torch.stack(hs), mem
 

@@ -79,6 +79,8 @@ VARIANTS = {      # name -> cfg overrides (on cfg_native): the option variants o
     "shared_temporal_block": {"transformer_is_share": 1},
     "cls_token": {"with_cls_token": 1},
     "agg_mlp": {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_depth": 0},
+    "pre_norm": {"detr_pre_norm": True},                      # round 5: pre-norm DETR layers (music_detr/transformer.py:170-189,246-271)
+    "pre_norm_Q3_CA": {"detr_pre_norm": True, "num_moment_queries": 3, "mml_fusion": "CA"},
 }
 
 
@@ -234,6 +236,8 @@ TRAIN_VARIANTS = {   # round-2 training variants: overrides on cf
     "tower2": {"vmr_fusion": "XA-video-music", "vmr_loss": "single"},
     "xpool_query": {"moment_query_type": "xpool"},
     "feature_fuse": {"vmr_loss": "dual_single_feature_fuse"},
+    "pre_norm": {"detr_pre_norm": True},
+    "pre_norm_Q2": {"detr_pre_norm": True, "num_moment_queries": 2},
 }
 
 

@@ -239,7 +239,7 @@ def test_retrieval_matches_reference_golden_and_oracle(golden_dir):
 
 
 @pytest.mark.parametrize("name", ["xa_music_video_single", "xa_video_single", "predict_center", "audio_short_cut_fb10", "audio_short_cut_Q3", "xpool_query", "moment_embedding", "feature_fuse", "regression",
-                                  "regression_center_CA", "shared_temporal_block", "cls_token", "agg_mlp"])
+                                  "regression_center_CA", "shared_temporal_block", "cls_token", "agg_mlp", "pre_norm", "pre_norm_Q3_CA"])
 def test_option_variants_match_reference_fixture_and_oracle(golden_dir, name):
     """the second X-Pool tower, predict_center, audio_short_cut and the regression head, f32 engine
     against the reference's own outputs (tests/golden/variants.npz) and, for the similarities, the oracle."""

@@ -198,6 +198,8 @@ VARIANTS = {      # the same table as tests/golden/make_golden.py (SURVEY sectio
     "shared_temporal_block": {"transformer_is_share": 1},
     "cls_token": {"with_cls_token": 1},
     "agg_mlp": {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_depth": 0},
+    "pre_norm": {"detr_pre_norm": True},                      # round 5: pre-norm DETR layers (music_detr/transformer.py:170-189,246-271)
+    "pre_norm_Q3_CA": {"detr_pre_norm": True, "num_moment_queries": 3, "mml_fusion": "CA"},
 }
 
 
@@ -238,7 +240,7 @@ def test_option_variants_match_reference_fixture(golden_dir, name):
     check_variant(fix, name, got, tol=2e-5)
 
 
-TRAIN_VARIANT_TAGS = ["cls", "mlp", "tower2", "xpool_query", "feature_fuse"]
+TRAIN_VARIANT_TAGS = ["cls", "mlp", "tower2", "xpool_query", "feature_fuse", "pre_norm", "pre_norm_Q2"]
 
 
 def _variant_setup(fix, tag):
