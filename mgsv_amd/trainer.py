@@ -75,8 +75,6 @@ class MadeTrainer(MadeEngine):
             bad.append(f"mml_localization={c.mml_localization}")
         if c.audio_short_cut and c.contrastive_align_loss and c.contrastive_hdim != c.D:
             bad.append("audio_short_cut with contrastive_dim != D (the reference's own add would not broadcast)")
-        if c.detr_pre_norm:
-            bad.append("detr_pre_norm (the eval engine serves it; the training path's backward is post-norm only)")
         if c.D not in (128, 256, 512):
             bad.append(f"dim_input={c.D} (the kernels are built for 128, 256 and 512; 128 trains through the chain of separate launches)")
         if bad:
@@ -148,6 +146,8 @@ class MadeTrainer(MadeEngine):
             mats.append((p + ".in.w", p + ".self_attn.in_proj_weight")); vecs.append((p + ".in.b", p + ".self_attn.in_proj_bias"))
             lin(p + ".out", p + ".self_attn.out_proj"); lin(p + ".ff1", p + ".linear1"); lin(p + ".ff2", p + ".linear2")
             ln(p + ".ln1", p + ".norm1"); ln(p + ".ln2", p + ".norm2")
+        if c.detr_pre_norm and c.detr_enc_layers > 0:
+            ln("enc.norm", "detr_transformer.encoder.norm")        # (exists with normalize_before only, music_detr/transformer.py:34)
         for l in range(c.detr_dec_layers):
             p = f"detr_transformer.decoder.layers.{l}"
             mats.append((p + ".sa.in.w", p + ".self_attn.in_proj_weight")); vecs.append((p + ".sa.in.b", p + ".self_attn.in_proj_bias"))
@@ -535,6 +535,7 @@ class MadeTrainer(MadeEngine):
         stacks = dict(tgt=E(nd + 1, BQ, D), tq=E(nd + 1, BQ, D), qkv=E(nd, BQ, 3 * D), att=E(nd, BQ, D), t_a=E(nd, BQ, D), t1=E(nd, BQ, D),
                       t1q=E(nd, BQ, D), qc=E(nd, BQ, D), pooled=E(nd, BQ, H * D), attc=E(nd, BQ, D), t_b=E(nd, BQ, D), t2=E(nd, BQ, D),
                       h=E(nd, BQ, Fd), t_c=E(nd, BQ, D),
+                      **({"n1": E(nd, BQ, D)} if c.detr_pre_norm else {}),      # pre-norm: LN1(tgt), the self-attention's input
                       g_ffn=E(nd, BQ, D), g_z=E(nd, BQ, Fd), g_ca=E(nd, BQ, D), g_attc=E(nd, BQ, D), g_q=E(nd, B, HQ, D), g_qc=E(nd, BQ, D),
                       g_sa=E(nd, BQ, D), g_qkv=E(nd, BQ, 3 * D), dt1q=E(nd, BQ, D))
         ws["dstack"] = stacks
@@ -638,7 +639,7 @@ class MadeTrainer(MadeEngine):
                     tgt.view(B, Q, D).copy_(src_vec[:, None, :].expand(B, Q, D))
             else:                                            # "zero" / "random": reference music_detr/transformer.py:73-74
                 _tape.zero_(tgt)
-            if Q > 1:                                        # (a single query's q / k projections are never formed: see the loop)
+            if Q > 1 and not c.detr_pre_norm:                # (a single query's q / k projections are never formed: see the loop)
                 tr.add3(tw["d.0.tq"], tgt, qp, b_mod=Q * D)
 
         # bf16, one moment query: the chain's LayerNorms run in the prologue of the Linear that consumes them (made_dec_stage, as on
@@ -654,7 +655,27 @@ class MadeTrainer(MadeEngine):
             qkv = tw[d + ".qkv"]
             Win, bin_ = P[p + ".ca.in.w"], P[p + ".ca.in.b"]
             Wt = P[p + ".ca.in.wt"]                           # [D, 3D] = in_proj^T
-            if stage:
+            if c.detr_pre_norm:
+                # reference music_detr/transformer.py:246-257 (forward_pre): tgt is the un-normalised stream; the self-attention reads
+                # n1 = LN1(tgt) (q = k = n1 + query_pos, v = n1) and always runs; the cross-attention's query is LN2(stream) + query_pos.
+                # Buffers keep their roles: .t_a = stream after the self-attention, .t1 / .t1q = the cross-attention query's input.
+                n1 = tw[d + ".n1"]
+                qp_rows = qp.expand(B * Q, D) if Q == 1 else qp.repeat(B, 1)
+                if Q == 1:                                    # one query, one key: the value path only (see the post-norm branch below)
+                    Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
+                    ops.layernorm(tgt, P[p + ".ln1.g"], P[p + ".ln1.b"], out=n1)
+                    ops.linear(n1, Wsa[2 * D:], bsa[2 * D:], out=tw[d + ".att"], drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+                else:
+                    ops.layernorm_add(tgt, P[p + ".ln1.g"], P[p + ".ln1.b"], qp_rows, n1, tq)
+                    ops.linear(n1, P[p + ".sa.in.w"], P[p + ".sa.in.b"], A2=tq, a2_replace=True,
+                               segs=[Seg(out=qkv, col_begin=0, use_a2=True), Seg(out=qkv[:, 2 * D:], col_begin=2 * D, ldo=qkv.stride(0))])
+                    q3 = qkv.view(B, Q, 3 * D)
+                    ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), H, lse=tw[d + ".lse"],
+                                  drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+                ta = ops.linear(tw[d + ".att"], P[p + ".sa.out.w"], P[p + ".sa.out.b"], R=tgt, out=tw[d + ".t_a"], drop=self._drop(f"dec.{l}" + ".drop1", pd))
+                ops.layernorm_add(ta, P[p + ".ln2.g"], P[p + ".ln2.b"], qp_rows, tw[d + ".t1"], tw[d + ".t1q"])
+                qc = ops.linear(tw[d + ".t1q"], Win[:D], bin_[:D], out=tw[d + ".qc"])
+            elif stage:
                 Wsa, bsa = P[p + ".sa.in.w"], P[p + ".sa.in.b"]
                 sa_drop = dict(drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
                 if l == 0:
@@ -747,10 +768,19 @@ class MadeTrainer(MadeEngine):
             ops.layernorm_add(src, None, None, pos2, tw["mem"], tw["mempos"], row_skip=fskip)
         else:
             srcpos = tw["e.0.srcpos"]
-            ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)
+            if not c.detr_pre_norm:
+                ops.layernorm_add(src, None, None, pos2, None, srcpos, row_skip=fskip)
+        pre = bool(c.detr_pre_norm)
+        xin = src                                             # pre-norm: the un-normalised residual stream entering the layer
         for l in range(c.detr_enc_layers):
             p, e = f"detr_transformer.encoder.layers.{l}", f"e.{l}"
-            if l > 0:
+            if pre:
+                # reference music_detr/transformer.py:170-189 (forward_pre): norm 1 in front of the attention (q = k = LN1(x) + pos, v = LN1(x)), norm 2 in
+                # front of the FFN, both branches added to the un-normalised stream.  Buffers keep their roles: .src / .srcpos = the attention's
+                # input (+ pos), .x = stream after the attention, .s1 = the FFN's input, .x2 = stream after the FFN (= the next layer's input).
+                src, srcpos = tw[e + ".src"], tw[e + ".srcpos"]
+                ops.layernorm_add(xin, P[p + ".ln1.g"], P[p + ".ln1.b"], pos2, src, srcpos, row_skip=fskip)
+            elif l > 0:
                 src, srcpos = tw[e + ".src"], tw[e + ".srcpos"]
             qkv = tw[e + ".qkv"]
             ops.linear(src, P[p + ".in.w"], P[p + ".in.b"], A2=srcpos, a2_replace=True, rows=rows_f,
@@ -760,14 +790,19 @@ class MadeTrainer(MadeEngine):
             ops.attention(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], att.view(B, L, D), H, key_mask=fus_mask,
                           q_skip_mask=qskip, lse=tw[e + ".lse"], drop=self._drop(f"enc.{l}" + ".attn", pd),
                           order=self._order[fus_mask.data_ptr()], keep_bits=tw[e + ".kbits"] if self._bits else None)
-            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=src, out=tw[e + ".x"], rows=rows_f,
+            x = ops.linear(att, P[p + ".out.w"], P[p + ".out.b"], R=xin if pre else src, out=tw[e + ".x"], rows=rows_f,
                            drop=self._drop(f"enc.{l}" + ".drop1", pd))
-            s1 = ops.layernorm(x, P[p + ".ln1.g"], P[p + ".ln1.b"], out=tw[e + ".s1"], row_skip=fskip)
+            s1 = ops.layernorm(x, P[p + (".ln2.g" if pre else ".ln1.g")], P[p + (".ln2.b" if pre else ".ln1.b")], out=tw[e + ".s1"], row_skip=fskip)
             h = ops.linear(s1, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[e + ".h"], rows=rows_f,
                            drop=self._drop(f"enc.{l}" + ".ffn_act", pd))
-            x2 = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=s1, out=tw[e + ".x2"], rows=rows_f,
+            x2 = ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=x if pre else s1, out=tw[e + ".x2"], rows=rows_f,
                             drop=self._drop(f"enc.{l}" + ".drop2", pd))
             last = l == c.detr_enc_layers - 1
+            if pre:
+                xin = x2
+                if last:                                      # the encoder's own norm behind the last layer (:33-35,107-108)
+                    ops.layernorm_add(x2, P["enc.norm.g"], P["enc.norm.b"], pos2, tw["mem"], tw["mempos"], row_skip=fskip)
+                continue
             nsrc, nsp = (tw["mem"], tw["mempos"]) if last else (tw[f"e.{l + 1}.src"], tw[f"e.{l + 1}.srcpos"])
             ops.layernorm_add(x2, P[p + ".ln2.g"], P[p + ".ln2.b"], pos2, nsrc, nsp, row_skip=fskip)
         memory, mempos = tw["mem"], tw["mempos"]
@@ -810,6 +845,14 @@ class MadeTrainer(MadeEngine):
                 ops.linear(pooled[:, :D], Win[2 * D:2 * D + hd], None, M=B * Q, N=hd, K=D, batch=H, a_z_stride=D, w_z_stride=hd * D,
                            segs=[Seg(out=attc, ldo=D, out_z_stride=hd)])
                 tr.head_bias(attc, tw[d + ".s"], bin_[2 * D:], H)
+            if c.detr_pre_norm:
+                # (:258-271) the cross-attention and the FFN (input LN3(stream)) are added to the un-normalised stream; the layer's output is the
+                # stream itself (slot l + 1 of the tgt stack; decoder.norm of it -> hs[l] after the loop, as on the post-norm path)
+                tb = ops.linear(attc, P[p + ".ca.out.w"], P[p + ".ca.out.b"], R=tw[d + ".t_a"], out=tw[d + ".t_b"], drop=self._drop(f"dec.{l}" + ".drop2", pd))
+                t2 = ops.layernorm(tb, P[p + ".ln3.g"], P[p + ".ln3.b"], out=tw[d + ".t2"])
+                h = ops.linear(t2, P[p + ".ff1.w"], P[p + ".ff1.b"], act=ops.ACT_RELU, out=tw[d + ".h"], drop=self._drop(f"dec.{l}" + ".ffn_act", pd))
+                ops.linear(h, P[p + ".ff2.w"], P[p + ".ff2.b"], R=tb, out=tw[d + ".t3"], drop=self._drop(f"dec.{l}" + ".drop3", pd))
+                continue
             tb = ops.linear(attc, P[p + ".ca.out.w"], P[p + ".ca.out.b"], R=t1, out=tw[d + ".t_b"], drop=self._drop(f"dec.{l}" + ".drop2", pd))
             if stage:
                 h = ops.dec_stage(tb, P[p + ".ff1.w"], P[p + ".ff1.b"], tw[d + ".h"], ln=(P[p + ".ln2.g"], P[p + ".ln2.b"]), x_out=tw[d + ".t2"],
@@ -900,7 +943,8 @@ class MadeTrainer(MadeEngine):
         fused attention backward): bf16, one moment query, D = 256 / 512.  MADE_DEC_STAGE=0 keeps round 2's chain (A/B measurements);
         f32 and Q > 1 always take it."""
         c = self.cfg
-        return (self.tc == torch.bfloat16 and c.num_moment_queries == 1 and c.D in (256, 512) and os.environ.get("MADE_DEC_STAGE", "1") != "0")
+        return (self.tc == torch.bfloat16 and c.num_moment_queries == 1 and c.D in (256, 512) and not c.detr_pre_norm
+                and os.environ.get("MADE_DEC_STAGE", "1") != "0")
 
     def _encode_train(self, feats: Tensor, mask: Tensor, which: str, ws, tw, row_off: int) -> None:
         """reference model/model_Base.py:544-617 in train mode (dropout 0.8 inside the temporal block)."""
@@ -1235,6 +1279,7 @@ class MadeTrainer(MadeEngine):
             # the scores of every layer's memory-space attention depend on forward values only (q', memory + pos): ONE batched
             # product for all layers ([nd, B, H*Q, L] rows) ahead of the dependent chain instead of one launch inside every layer
             stage = self._dec_stage_chain()                    # fused chain: see forward_train
+            pre = bool(c.detr_pre_norm)                        # pre-norm layers (reference music_detr/transformer.py:246-271): separate launches
             S_all = tw["dS_S"]
             if not stage:
                 ops.linear(GQ[0, 1].reshape(nd * HQ, D), mempos3[0], None, M=nd * HQ, N=L, K=D, batch=B, a_z_stride=GQ.stride(0), w_z_stride=L * D,
@@ -1267,6 +1312,11 @@ class MadeTrainer(MadeEngine):
                     tr.dec_stage_bwd(tw[d + ".t_c"], P[p + ".ln3.g"], gN[l * B * Q:(l + 1) * B * Q], P[p + ".ff2.wt"], g_z,
                                      dgamma_a=G[p + ".ln3.g"], dbeta_a=G[p + ".ln3.b"], add=dtgt, dx_out=g2a, a_out=g_ffn,
                                      drop_a=self._drop(f"dec.{l}" + ".drop3", pd), G=tw[d + ".h"], gate_scale=inv_keep)
+                elif pre:
+                    # hs_l = dec.norm(stream); the stream (slot l + 1 of the tgt stack) also feeds the next layer: g1 = d stream
+                    tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
+                    # stream = t_b + drop3(ffn(LN3(t_b)))
+                    tr.gate_rows(g1, g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
                 else:
                     # hs_l = dec.norm(t3); t3 also feeds the next layer
                     tr.layernorm_bwd(tw[d + ".t3"], P["dec.norm.g"], dhs[l * B * Q:(l + 1) * B * Q], g1, dgamma=G["dec.norm.g"], dbeta=G["dec.norm.b"], add=dtgt)
@@ -1275,9 +1325,18 @@ class MadeTrainer(MadeEngine):
                                      dx_drop=g_ffn, drop=self._drop(f"dec.{l}" + ".drop3", pd))
                 if not stage:
                     ops.linear(g_ffn, P[p + ".ff2.wt"], None, out=g_z, gate=_lib.GATE_RELU_OUT, G=tw[d + ".h"], gate_scale=inv_keep)
-                dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1a, R=g2a)
+                if pre:
+                    dn3 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g4)
+                    # t_b = t_a + drop2(cross-attention): d t_b = LN3'(dn3) + d stream -> g2; its dropped copy feeds the out-projection
+                    tr.layernorm_bwd(tw[d + ".t_b"], P[p + ".ln3.g"], dn3, g2, dgamma=G[p + ".ln3.g"], dbeta=G[p + ".ln3.b"], add=g1,
+                                     dx_drop=g_ca, drop=self._drop(f"dec.{l}" + ".drop2", pd))
+                    dattc = ops.linear(g_ca, P[p + ".ca.out.wt"], None, out=g_attc)
+                else:
+                    dt2 = ops.linear(g_z, P[p + ".ff1.wt"], None, out=g1a, R=g2a)
                 # t2 = LN2(t1 + drop2(cross-attention))
-                if stage:                                         # norm 2's backward in the prologue of the out-projection's dX product
+                if pre:
+                    pass
+                elif stage:                                       # norm 2's backward in the prologue of the out-projection's dX product
                     dattc = tr.dec_stage_bwd(tw[d + ".t_b"], P[p + ".ln2.g"], dt2, P[p + ".ca.out.wt"], g_attc, dgamma_a=G[p + ".ln2.g"],
                                              dbeta_a=G[p + ".ln2.b"], dx_out=g2b, a_out=g_ca, drop_a=self._drop(f"dec.{l}" + ".drop2", pd))
                 else:
@@ -1326,6 +1385,29 @@ class MadeTrainer(MadeEngine):
                 # dt1 = residual path + query path in the Linear's epilogue; the query path alone (the pre-residual value) is kept for
                 # the query embedding's gradient
                 dt1q = st["dt1q"][l]                               # (summed over the batch into the query embedding's gradient after the loop)
+                if pre:
+                    # qc = W_q (LN2(t_a) + qp) + b_q: d (LN2(t_a) + qp) -> dt1q; d t_a = LN2'(dt1q) + d t_b -> g1, its dropped copy feeds the
+                    # self-attention's out-projection
+                    ops.linear(g_qc, Wt[:, :D], None, out=dt1q)
+                    tr.layernorm_bwd(tw[d + ".t_a"], P[p + ".ln2.g"], dt1q, g1, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"], add=g2,
+                                     dx_drop=g_sa, drop=self._drop(f"dec.{l}" + ".drop1", pd))
+                    if Q == 1:                                    # value path only (see the forward)
+                        ops.linear(g_sa, P[p + ".sa.out.wt"], None, segs=[Seg(out=gqkv[:, 2 * D:], ldo=gqkv.stride(0))],
+                                   drop=self._drop(f"dec.{l}" + ".sa_attn", pd), drop_ld=H, drop_col_div=hd)
+                        dn1 = ops.linear(gqkv[:, 2 * D:], P[p + ".sa.in.wt"][:, 2 * D:], None, out=g4)
+                    else:
+                        datt = ops.linear(g_sa, P[p + ".sa.out.wt"], None, out=g4)
+                        qkv = tw[d + ".qkv"]
+                        q3, g3v = qkv.view(B, Q, 3 * D), gqkv.view(B, Q, 3 * D)
+                        tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[d + ".att"].view(B, Q, D), datt.view(B, Q, D),
+                                         g3v[:, :, :D], g3v[:, :, D:2 * D], g3v[:, :, 2 * D:], tw[d + ".lse"], tw["d_delta"], H,
+                                         drop=self._drop(f"dec.{l}" + ".sa_attn", pd))
+                        dn1 = ops.linear(gqkv, P[p + ".sa.in.wt"], None, out=g2)       # q, k and v all read n1 (+ qp)
+                        dqk = ops.linear(gqkv[:, :2 * D], P[p + ".sa.in.wt"][:, :2 * D], None, out=g4)
+                        tr.colsum(dqk.view(B, Q * D), G["query_embed"].view(-1))        # the query embedding enters through q, k
+                    # n1 = LN1(tgt): d tgt = LN1'(dn1) + d t_a
+                    dtgt = tr.layernorm_bwd(tw[d + ".tgt"], P[p + ".ln1.g"], dn1, tw["dtgt"], dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], add=g1)
+                    continue
                 ops.linear(g_qc, Wt[:, :D], None, out=g1b, R=g2b, Zout=dt1q)
                 # t1 = LN1(tgt + drop1(self-attention))
                 if stage:
@@ -1411,7 +1493,7 @@ class MadeTrainer(MadeEngine):
             batched(st["g_sa"], st["att"], ".sa.out.w", ".sa.out.b")
             if Q > 1:                                             # (a single query's q / k projections get no gradient)
                 batched(st["g_qkv"], st["tq"], ".sa.in.w", ".sa.in.b", a_cols=(0, 2 * D), w_rows=(0, 2 * D))
-            batched(st["g_qkv"], st["tgt"], ".sa.in.w", ".sa.in.b", a_cols=(2 * D, 3 * D), w_rows=(2 * D, 3 * D))
+            batched(st["g_qkv"], st["n1"] if pre else st["tgt"], ".sa.in.w", ".sa.in.b", a_cols=(2 * D, 3 * D), w_rows=(2 * D, 3 * D))
             # per-head products of the memory-space cross-attention, batched over (layer, head)
             gWin0 = G[p0 + ".ca.in.w"]
             ls = lstride(".ca.in.w")
@@ -1439,6 +1521,47 @@ class MadeTrainer(MadeEngine):
                 if enc_dw_done[l & 1] is not None:               # (more than two layers: the set's previous weight-gradient launch)
                     cur.wait_event(enc_dw_done[l & 1])
             pend: list = []
+            if c.detr_pre_norm:
+                # reference music_detr/transformer.py:170-189 (forward_pre), backwards.  dsrc = gradient of the layer's output stream x2.
+                n1, n1pos = tw[e + ".src"], tw[e + ".srcpos"]                # the attention's input LN1(x_in) (+ pos)
+                xin = fus.view(rows, D) if l == 0 else tw[f"e.{l - 1}.x2"]
+                if l == ne - 1:                                # the encoder's own norm behind the last layer: dsrc = d memory here
+                    dsrc = tr.layernorm_bwd(tw[e + ".x2"], P["enc.norm.g"], dsrc, g2, dgamma=G["enc.norm.g"], dbeta=G["enc.norm.b"], row_skip=fskip)
+                # x2 = x + drop2(ffn(LN2(x)))
+                tr.gate_rows(dsrc, g3, drop=self._drop(f"enc.{l}" + ".drop2", pd), row_skip=fskip)
+                dz = self._lin_bwd(g3, tw[e + ".h"], p + ".ff2", dx_out=gf, row_mask=fskip, skip=fskip, gate=_lib.GATE_RELU_OUT, G=tw[e + ".h"],
+                                   gate_scale=inv_keep, defer=pend)
+                dn2 = self._lin_bwd(dz, tw[e + ".s1"], p + ".ff1", dx_out=g3b, row_mask=fskip, skip=fskip, defer=pend)
+                # x = x_in + drop1(attention(LN1(x_in))): d x = LN2'(dn2) + d x2; its dropped copy feeds the out-projection
+                dx = tw["eg1"] if dsrc is not tw["eg1"] else tw["dfus"]
+                tr.layernorm_bwd(tw[e + ".x"], P[p + ".ln2.g"], dn2, dx, dgamma=G[p + ".ln2.g"], dbeta=G[p + ".ln2.b"], add=dsrc, dx_drop=g2b,
+                                 drop=self._drop(f"enc.{l}" + ".drop1", pd), row_skip=fskip)
+                datt = self._lin_bwd(g2b, tw[e + ".att"], p + ".out", dx_out=g3c, row_mask=fskip, skip=fskip, defer=pend)
+                qkv = tw[e + ".qkv"]
+                q3, gq3 = qkv.view(B, L, 3 * D), gq.view(B, L, 3 * D)
+                tr.attention_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], tw[e + ".att"].view(B, L, D), datt.view(B, L, D),
+                                 gq3[:, :, :D], gq3[:, :, D:2 * D], gq3[:, :, 2 * D:], tw[e + ".lse"], tw["e_delta"], H,
+                                 key_mask=fus_mask, q_skip_mask=qskip, drop=self._drop(f"enc.{l}" + ".attn", pd),
+                                 order=self._order[fus_mask.data_ptr()], keep_bits=tw[e + ".kbits"] if self._bits else None)
+                gW, gb = G[p + ".in.w"], G[p + ".in.b"]
+                if self._groupable(gq, n1pos, gW[:2 * D]) and self._rw(fskip) is not None:
+                    pend.append((gq[:, :2 * D], n1pos, gW[:2 * D], gb[:2 * D]))
+                    pend.append((gq[:, 2 * D:], n1, gW[2 * D:], gb[2 * D:]))
+                else:
+                    tr.gemm_tn(gq[:, :2 * D], n1pos, gW[:2 * D], accumulate=True, colsum=gb[:2 * D], rows=self._rw(fskip))
+                    tr.gemm_tn(gq[:, 2 * D:], n1, gW[2 * D:], accumulate=True, colsum=gb[2 * D:], rows=self._rw(fskip))
+                dn1 = ops.linear(gq, P[p + ".in.wt"], None, out=g2, rows=self._rw(fskip))      # q, k and v all read LN1(x_in) (+ pos)
+                nxt = tw["dfus"] if dx is tw["eg1"] else tw["eg1"]
+                dsrc = tr.layernorm_bwd(xin, P[p + ".ln1.g"], dn1, nxt, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], add=dx, row_skip=fskip)
+                if enc_dw_side:
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        self._flush_dw(pend, fskip)
+                        enc_dw_done[l & 1] = torch.cuda.Event()
+                        enc_dw_done[l & 1].record(side)
+                else:
+                    self._flush_dw(pend, fskip)
+                continue
             src = fus.view(rows, D) if l == 0 else tw[e + ".src"]
             srcpos = tw[e + ".srcpos"]
             # src_{l+1} = LN2(s1 + drop2(ffn))

@@ -222,6 +222,10 @@ def main():
     report["native_cls_token_B4"] = compare_forward(c, 4, 50, 96, "native CLS-token pooling")
     c = cfg_native(); c.agg_module = "mlp"; c.video_transformer_depth = c.audio_transformer_depth = 0
     report["native_agg_mlp_B4"] = compare_forward(c, 4, 50, 96, "native EmbeddingNet aggregator (eval-mode BatchNorm)")
+    c = cfg_native(); c.detr_pre_norm = True
+    report["native_pre_norm_B4"] = compare_forward(c, 4, 50, 96, "native pre-norm DETR layers")
+    c = cfg_native(); c.detr_pre_norm = True; c.num_moment_queries = 3; c.mml_fusion = "CA"
+    report["native_pre_norm_Q3_CA_B4"] = compare_forward(c, 4, 50, 96, "native pre-norm / Q=3 / CA")
     c = cfg_headline()
     report["cfg2_B4"] = compare_forward(c, 4, 30, 512, "cfg2 shape B=4 Tv=30 Ta=512 D=512")
     report["grad_eval_native_B3"] = compare_backward(cfg_native(), 3, 20, 40, "native eval-mode grads", train=False)
@@ -253,6 +257,10 @@ def main():
     report["grad_train_native_agg_mlp_B3"] = compare_backward(c, 3, 20, 40, "native EmbeddingNet aggregator train-mode grads (batch statistics)", train=True)
     assert report["grad_train_native_agg_mlp_B3"]["buffers_worst_abs"] < 1e-9
     report["grad_eval_native_agg_mlp_B3"] = compare_backward(c, 3, 20, 40, "native EmbeddingNet aggregator eval-mode grads", train=False)
+    c = cfg_native(); c.detr_pre_norm = True
+    report["grad_train_native_pre_norm_B3"] = compare_backward(c, 3, 20, 40, "native pre-norm train-mode grads", train=True)
+    c = cfg_native(); c.detr_pre_norm = True; c.num_moment_queries = 3
+    report["grad_train_native_pre_norm_Q3_B4"] = compare_backward(c, 4, 20, 40, "native pre-norm Q=3 train-mode grads", train=True)
     report["lsap_vs_scipy"] = compare_lsap()
     report["retrieval_N48x40_S96"] = compare_retrieval(cfg_native(), 48, 40, 96)
     worst = max(v for k, sec in report.items() if isinstance(sec, dict) and not k.startswith("grad_")

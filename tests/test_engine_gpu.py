@@ -40,7 +40,11 @@ def _cases():
     c6 = cfg_native(); c6.mml_fusion = "CA"
     c7 = cfg_native(); c7.fusion_mask = 0; c7.moment_query_type = "zero"; c7.aux_loss = 1
     c8 = cfg_native(); c8.dim_input = 128; c8.SA_temporal_heads = 4; c8.detr_nheads = 4    # a narrow model (32-wide heads): the slow-but-correct widths
+    c9 = cfg_native(); c9.detr_pre_norm = True                  # pre-norm DETR layers (reference music_detr/transformer.py:170-189,246-271)
+    c10 = cfg_headline(); c10.detr_pre_norm = True; c10.num_moment_queries = 2
     return {
+        "pre_norm_B5": (c9, 5, 50, 96),
+        "pre_norm_Q2_cfg2_shape_B3": (c10, 3, 30, 512),
         "narrow_D128_B4": (c8, 4, 50, 96),
         "native_CA_fusion_B4": (c6, 4, 50, 96),
         "native_nomask_zeroquery_B4": (c7, 4, 50, 96),
@@ -169,7 +173,8 @@ def test_bf16_graph_replay_full_batch_properties():
         assert torch.equal(pick(k, og[k]), eager[k]), f"{k}: graph replay differs from the eager step"
 
 
-@pytest.mark.parametrize("name", ["native_B8", "cfg2_shape_B4", "native_nomask_zeroquery_B4", "native_musicquery_nocontrast_B3", "single_sample_B1_Tv3_Ta5"])
+@pytest.mark.parametrize("name", ["native_B8", "cfg2_shape_B4", "native_nomask_zeroquery_B4", "native_musicquery_nocontrast_B3", "single_sample_B1_Tv3_Ta5",
+                                  "pre_norm_B5", "pre_norm_Q2_cfg2_shape_B3"])
 def test_bf16_forward_within_stated_tolerance(name):
     cfg, B, Tv, Ta = _cases()[name]
     sd = synth.make_state_dict(cfg, seed=0)

@@ -114,7 +114,7 @@ def test_training_loop_body_of_the_reference_driver_runs_unchanged():
     assert float(lm["retrieval_loss"] + lm["localization_loss"]) < losses[0]
 
 
-@pytest.mark.parametrize("name", ["xa_music_video_single", "regression_center_CA", "agg_mlp", "cls_token", "shared_temporal_block"])
+@pytest.mark.parametrize("name", ["xa_music_video_single", "regression_center_CA", "agg_mlp", "cls_token", "shared_temporal_block", "pre_norm_Q3_CA"])
 def test_dropin_option_variants(golden_dir, name):
     """The drop-in module on two option variants (second X-Pool tower; regression head + predict_center + CA fusion): key layout,
     optimizer groups and outputs as the reference's (tests/golden/variants.npz)."""
@@ -142,7 +142,8 @@ def test_dropin_option_variants(golden_dir, name):
 
 
 @pytest.mark.parametrize("overrides", [{"mml_localization": "regression"}, {"mml_localization": "regression", "predict_center": 1, "mml_fusion": "CA"},
-                                       {"audio_short_cut": 1, "predict_center": 1, "moment_loss": 1}])
+                                       {"audio_short_cut": 1, "predict_center": 1, "moment_loss": 1},
+                                       {"detr_pre_norm": True}, {"dim_input": 128, "SA_temporal_heads": 4, "detr_nheads": 4}])
 def test_training_loop_body_on_option_variants(overrides):
     """The reference's loop body on the drop-in module for variants the scripts do not use: the regression localisation head (its
     own optimizer group: reg_mlp + the CA block), predict_center, the audio short-cut (the CLI's default), moment_loss."""

@@ -88,6 +88,10 @@ _MLP = {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_de
                                        {"with_cls_token": 1, "mml_fusion": "CA", "transformer_is_share": 1},
                                        dict(_MLP), dict(_MLP, with_act_after_proj=1, mml_fusion="CA"),
                                        dict(_NARROW),
+                                       # round 5: pre-norm DETR layers (reference music_detr/transformer.py:170-189,246-271)
+                                       {"detr_pre_norm": True}, {"detr_pre_norm": True, "num_moment_queries": 3, "mml_fusion": "CA"},
+                                       {"detr_pre_norm": True, "moment_query_type": "xpool", "_shape": (5, 33, 67)},
+                                       {"detr_pre_norm": True, "mml_localization": "regression"}, {"detr_pre_norm": True, "detr_enc_layers": 0, "mml_fusion": "CA"},
                                        # (dropout seed 1: with 1234 one ReLU input of decoder layer 0's FFN -- unit 344, one of 6 rows -- lies within the
                                        #  forward's 1e-5 of zero and takes the other side: 6e-2 on that layer's tensors at this width, every other
                                        #  tensor and seeds 1 and 3 at 3e-5; tools/train_variant_probe.py with DUMP= shows the one element)
@@ -132,7 +136,7 @@ def test_f32_gradients_match_reference_fixture(golden_dir):
 
 @pytest.mark.parametrize("dropout", [False, True])
 @pytest.mark.parametrize("overrides", [{}, {"with_cls_token": 1}, {"vmr_fusion": "XA-video-music", "vmr_loss": "single", "moment_query_type": "xpool"},
-                                       dict(_NARROW)])
+                                       dict(_NARROW), {"detr_pre_norm": True}])
 def test_bf16_gradients_close_to_oracle(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     cfg, sd, inp = _setup(4, 20, 40, overrides)
@@ -392,7 +396,7 @@ def test_captured_train_step_reads_seed_and_learning_rates_from_the_device():
     assert bool(moved[r0[0]:r0[1]].any()) and not bool(moved[r0[1]:].any())                         # only the temporal group has a rate
 
 
-@pytest.mark.parametrize("tag", ["cls", "mlp", "tower2", "xpool_query", "feature_fuse"])
+@pytest.mark.parametrize("tag", ["cls", "mlp", "tower2", "xpool_query", "feature_fuse", "pre_norm", "pre_norm_Q2"])
 def test_f32_variant_gradients_match_reference_fixture(golden_dir, tag):
     """The round-2 training variants straight against the reference's own train()-mode autograd (float64 fixture
     tests/golden/train_variants_B3.npz): losses, every parameter gradient's norm and a strided sample, the BatchNorm buffers."""
