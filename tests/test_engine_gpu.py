@@ -33,6 +33,13 @@ def _oracle(cfg, sd, inp):
                          inp["segment_masks"], inp["spans_target"], v_duration=inp["v_duration"])
 
 
+# bf16 engine against the f32 oracle: 2x the largest error measured over the 15 shapes of tools/bf16_error_probe.py (profiles/r05_bf16_error_probe.txt:
+# clip vectors 1.1e-3, dual similarities 1.1e-3, in-batch single similarities 8.9e-4, logits 2.2e-2, spans 3.4e-3, losses 9.2e-3 relative).
+# Rounds 1-4 allowed 5e-3 / 1e-2 / 3e-2 / 5e-2 / 2e-2 / 5e-2.
+BF16_FORWARD_TOL = dict(video_feats=2.5e-3, music_feats=2.5e-3, sims_dual=2.5e-3, sims_single=2e-3, pred_logits=4.5e-2, pred_spans=7e-3)
+BF16_LOSS_RTOL = 2e-2
+
+
 def _cases():
     c3 = cfg_native(); c3.num_moment_queries = 3
     c4 = cfg_native(); c4.fb_label = "10"; c4.with_act_after_proj = 1; c4.vmr_loss = "dual_single_sim_fuse"
@@ -181,12 +188,12 @@ def test_bf16_forward_within_stated_tolerance(name):
     inp = synth.make_inputs(cfg, B, Tv, Ta, seed=1)
     out = MadeEngine(cfg, sd, dtype="bf16").forward_numpy(inp)
     ref = _oracle(cfg, sd, inp)
-    for k, tol in (("video_feats", 5e-3), ("music_feats", 5e-3), ("sims_dual", 1e-2), ("sims_single", 3e-2),
-                   ("pred_logits", 5e-2), ("pred_spans", 2e-2)):
+    for k, tol in BF16_FORWARD_TOL.items():
         err = np.abs(out[k] - ref[k].numpy()).max()
         assert err <= tol, (k, float(err))
     assert np.isfinite(out["localization_loss"]) and np.isfinite(out["retrieval_loss"])
-    np.testing.assert_allclose(out["localization_loss"], float(ref["localization_loss"]), rtol=5e-2)
+    np.testing.assert_allclose(out["localization_loss"], float(ref["localization_loss"]), rtol=BF16_LOSS_RTOL)
+    np.testing.assert_allclose(out["retrieval_loss"], float(ref["retrieval_loss"]), rtol=BF16_LOSS_RTOL, atol=BF16_LOSS_RTOL)
 
 
 def test_widths_the_wide_attention_kernel_is_not_built_for_fail_at_construction():
@@ -210,9 +217,9 @@ def test_bf16_narrow_model_matches_oracle():
     inp = synth.make_inputs(cfg, 6, 50, 96, seed=1)
     out = MadeEngine(cfg, sd, dtype="bf16").forward_numpy(inp)
     ref = _oracle(cfg, sd, inp)
-    for k in ("video_feats", "music_feats", "sims_single", "sims_dual", "pred_spans"):
-        np.testing.assert_allclose(out[k], ref[k].numpy(), atol=3e-2, rtol=0, err_msg=k)
-    assert np.isfinite(out["retrieval_loss"]) and abs(out["retrieval_loss"] - float(ref["retrieval_loss"])) <= 5e-2 * max(1.0, abs(float(ref["retrieval_loss"])))
+    for k, tol in BF16_FORWARD_TOL.items():
+        np.testing.assert_allclose(out[k], ref[k].numpy(), atol=tol, rtol=0, err_msg=k)
+    assert np.isfinite(out["retrieval_loss"]) and abs(out["retrieval_loss"] - float(ref["retrieval_loss"])) <= BF16_LOSS_RTOL * max(1.0, abs(float(ref["retrieval_loss"])))
 
 
 def test_retrieval_matches_reference_golden_and_oracle(golden_dir):
