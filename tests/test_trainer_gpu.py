@@ -309,13 +309,14 @@ def _batch(cfg, B, Tv, Ta, seed):
 
 
 @pytest.mark.parametrize("mode", ["graph", "tape"])
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_captured_train_step_follows_the_eager_steps(dtype, mode):
+@pytest.mark.parametrize("dtype,overrides", [("f32", None), ("bf16", None), ("bf16", {"detr_pre_norm": True}), ("bf16", dict(_NARROW))])
+def test_captured_train_step_follows_the_eager_steps(dtype, overrides, mode):
     """the iteration as one hipGraph.  The replay reads the dropout seed, the Adam step count and the learning rates
     from device memory: three graph steps on three batches with three seeds and a moving schedule must land where three eager
-    train_step calls land (same kernels, same order: the only freedom is the order of the f32 atomic gradient sums)."""
+    train_step calls land (same kernels, same order: the only freedom is the order of the f32 atomic gradient sums).
+    Also on the two option paths of round 5 (pre-norm DETR layers, dim_input = 128: the decoder's chain of separate launches)."""
     from mgsv_amd.trainer import MadeTrainer
-    cfg, sd, _ = _setup(4, 20, 40)
+    cfg, sd, _ = _setup(4, 20, 40, overrides)
     eager, graph = MadeTrainer(cfg, sd, dtype=dtype), MadeTrainer(cfg, sd, dtype=dtype)
     batches = [_batch(cfg, 4, 20, 40, seed=10 + i) for i in range(3)]
     g = graph.capture_train_step(*batches[2], mode=mode)
