@@ -1036,7 +1036,7 @@ class MadeTrainer(MadeEngine):
             # round 4: scores per (track, 128 segments), then P.V per (track, 128 value columns) -- two launches of one workgroup per CU, only the
             # bf16 probabilities between them (made_xpool_inbatch; profiles/r04_*xpool_qk_microbench.txt)
             if tw.get(pre + "xib_ws") is None or tw[pre + "xib_ws"].numel() < ops.xpool_inbatch_ws_bytes(B, S):    # (one per tower: they may run on two streams)
-                tw[pre + "xib_ws"] = torch.empty(ops.xpool_inbatch_ws_bytes(B, S), device=self.device, dtype=torch.uint8)
+                tw[pre + "xib_ws"] = torch.zeros(ops.xpool_inbatch_ws_bytes(B, S), device=self.device, dtype=torch.uint8)
             ops.xpool_inbatch(q, tw[pre + "k"].view(B, S, D), tw[pre + "u"].view(B, S, D), seg_mask, tw[pre + "o"].view(B, B, D),
                               scale=1.0 / math.sqrt(D), ws=tw[pre + "xib_ws"])
         xsplit = int(os.environ.get("MADE_XPOOL_NSPLIT", 0)) or (max(1, min(4, 256 // max(B, 1), S // 64)) if (B <= 64 and self.tc == torch.bfloat16) else 1)
