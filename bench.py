@@ -271,20 +271,41 @@ def north_star_contraction(dev) -> dict:
     q = torch.randn(Nv, D, device=dev, generator=g).bfloat16()
     k, u = torch.randn(Nm, S, D, device=dev, generator=g).bfloat16(), torch.randn(Nm, S, D, device=dev, generator=g).bfloat16()
     o = torch.empty(Nm, Nv, D, device=dev, dtype=torch.bfloat16)
-    ws = torch.empty(ops.xpool_inbatch_ws_bytes(Nm, S), device=dev, dtype=torch.uint8)
+    ws = torch.zeros(ops.xpool_inbatch_ws_bytes(Nm, S), device=dev, dtype=torch.uint8)
     run = lambda: ops.xpool_inbatch(q, k, u, None, o, scale=1.0 / math.sqrt(D), ws=ws)
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        for _ in range(20):
+
+    def timed() -> float:
+        for _ in range(3):
             run()
-    gr.replay(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); gr.replay(); gr.replay(); e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 40 * 1e3
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(20):
+                run()
+        gr.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); gr.replay(); gr.replay(); e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 40 * 1e3
+
+    prev = os.environ.get("MADE_XPOOL_INBATCH_FUSED")
+    os.environ["MADE_XPOOL_INBATCH_FUSED"] = "0"
     byts = 2.0 * Nm * S * D * 2 + Nv * D * 2 + Nm * Nv * D * 2
+    try:
+        us = timed()
+        ref = o.clone()
+        one = None
+        try:                                               # the opt-in one-launch form (round 5): same words, exchanged inside the launch
+            os.environ["MADE_XPOOL_INBATCH_FUSED"] = "1"
+            us1 = timed()
+            one = {"us_per_call": round(us1, 2), "frac_of_hbm_peak": round(byts / us1 / 1e3 / 8000.0, 4), "bit_identical_to_two_launches": bool(torch.equal(o, ref)),
+                   "note": "MADE_XPOOL_INBATCH_FUSED=1, not the default (DESIGN.md section 5)"}
+        except Exception as ex:                            # noqa: BLE001
+            one = {"error": f"{type(ex).__name__}: {ex}"}
+    finally:
+        if prev is None:
+            os.environ.pop("MADE_XPOOL_INBATCH_FUSED", None)
+        else:
+            os.environ["MADE_XPOOL_INBATCH_FUSED"] = prev
     flops = 4.0 * Nv * Nm * S * D
     return {"workload": f"X-Pool QK^T . softmax . PV, {Nv} videos x {Nm} tracks x {S} segments, d = {D}, bf16, full-length tracks",
             "path": "made_xpool_inbatch (scores per track and 128 segments, then P.V per track and 128 value columns)",
@@ -292,6 +313,7 @@ def north_star_contraction(dev) -> dict:
             "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / us / 1e3 / 8000.0, 4),
                          "algorithmic_mb": round(byts / 1e6, 2)},
             "mfma_tflops": round(flops / us / 1e6, 1), "mfma_frac_of_bf16_peak": round(flops / us / 1e6 / 2500.0, 4),
+            "one_launch_form": one,
             "measured": "hipGraph replay of 20 calls, HIP events around two replays"}
 
 
