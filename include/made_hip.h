@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MADE_ABI_VERSION 6
+#define MADE_ABI_VERSION 7
 
 enum MadeDtype { MADE_F32 = 0, MADE_BF16 = 1 };
 
@@ -292,11 +292,14 @@ typedef struct MadeAttnArgs {
     const int32_t* batch_order; /* [B] or NULL: a permutation of the batch (made_batch_order: longest sequence first).  Only the
                                   ORDER in which workgroups are issued changes -- a padded batch then finishes with its short
                                   samples instead of waiting on a long one that started last; results are unchanged */
-    uint32_t* keep_bits;       /* NULL, or (with drop.p > 0) [B*H*Lq, ld_bits] words: the dropout decisions of this call, bit j % 32 of word
-                                  j / 32 of row (b*H + h)*Lq + i = element (i, j) is KEPT -- written for made_attention_bwd, whose two
-                                  kernels then test a bit per score instead of re-drawing it (the draw is ~11 VALU instructions, two
-                                  thirds of their per-score arithmetic).  ld_bits >= 2 * ceil(Lk / 64); words of keys behind the
-                                  sample's last valid key are not written (and not read) */
+    uint32_t* keep_bits;       /* NULL, or (with drop.p > 0) [B*H*ceil(Lk/32), ld_bits] words: the dropout decisions of this call, for
+                                  made_attention_bwd (which then tests a bit per score instead of re-drawing it: the draw is ~11 VALU
+                                  instructions).  Row (b*H + h)*ceil(Lk/32) + kt holds, for key tile kt (keys 32 kt .. 32 kt + 31), one word
+                                  per query: bit j of the word at slot 32 (i / 32) + s(i % 32) = element (i, 32 kt + j) is KEPT, with
+                                  s(q) = 2 ((q & 3) + 4 (q >> 3)) + ((q >> 2) & 1) -- the 32 words of a (key tile, query group) pair are
+                                  then the sixteen 64-lane masks of a 32 x 32 MFMA accumulator tile (register e: rows (e & 3) + 8 (e >> 2)
+                                  and + 4), which the single-pass backward loads with scalar loads.  ld_bits = a multiple of 32 >= Lq;
+                                  words of keys behind the sample's last valid key are not written (and not read) */
     int64_t ld_bits;
 } MadeAttnArgs;
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MADE_LIB_PATH: another build of the same library (A/B measurements of two builds on one box, tools/ab_libs.sh); it must export the same
 # ABI version, checked below, so a stale or older build fails here instead of reading shifted struct fields
 LIB_PATH = os.environ.get("MADE_LIB_PATH") or os.path.join(_HERE, "libmade_hip.so")
-ABI_VERSION = 6                          # include/made_hip.h MADE_ABI_VERSION the ctypes mirrors in this file were written for
+ABI_VERSION = 7                          # include/made_hip.h MADE_ABI_VERSION the ctypes mirrors in this file were written for
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SIGMOID = 0, 1, 2, 3, 4

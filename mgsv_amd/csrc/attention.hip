@@ -291,10 +291,14 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
                     x <<= 4 * hh;
                     w2[kt] = x | (uint32_t)__shfl_xor((int)x, 32);
                 }
+                // layout (made_hip.h, MadeAttnArgs.keep_bits): [pair][32-key tile][query slot], the 32 slots of a query group permuted so
+                // that the group's words are the 16 lane masks of a 32 x 32 accumulator tile (made_attention_bwd's single-pass kernel)
                 const int64_t qs = q0 + r;
                 if (hh == 0 && qs < a.Lq) {
-                    uint32_t* bp = a.keep_bits + ((b * a.H + h) * a.Lq + qs) * a.ld_bits + 2 * t;
-                    *(uint2*)bp = make_uint2(w2[0], w2[1]);
+                    const int64_t nkt = (a.Lk + 31) / 32;
+                    uint32_t* bp = a.keep_bits + ((b * a.H + h) * nkt + 2 * t) * a.ld_bits + q0 + made_keep_slot(r);
+                    bp[0] = w2[0];
+                    if (2 * t + 1 < nkt) bp[a.ld_bits] = w2[1];
                 }
             }
         }
@@ -393,8 +397,8 @@ extern "C" int made_attention(const MadeAttnArgs* args, void* stream) {
     MADE_REQUIRE(a.B >= 0 && a.H > 0 && a.Lq >= 0 && a.Lk > 0, "made_attention: bad dims");
     MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention: bad dtype %d", a.dtype);
     if (a.keep_bits)
-        MADE_REQUIRE(a.ld_bits >= 2 * ((a.Lk + 63) / 64) && a.ld_bits % 2 == 0 && ((uintptr_t)a.keep_bits % 8) == 0,
-                     "made_attention: keep_bits rows need an even ld_bits >= 2 * ceil(Lk / 64) = %lld words and 8-byte alignment", (long long)(2 * ((a.Lk + 63) / 64)));
+        MADE_REQUIRE(a.ld_bits >= 32 * ((a.Lq + 31) / 32) && a.ld_bits % 32 == 0 && ((uintptr_t)a.keep_bits % 8) == 0,
+                     "made_attention: keep_bits rows need ld_bits = a multiple of 32 >= Lq (%lld words per key tile) and 8-byte alignment", (long long)(32 * ((a.Lq + 31) / 32)));
     MADE_UNSUPPORTED(((a.Lq + BQ - 1) / BQ) * a.H * a.B < (1LL << 31), "made_attention: too many workgroups");
     const int per16 = a.dtype == MADE_F32 ? 4 : 8;
     MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.ldo % 4 == 0 &&

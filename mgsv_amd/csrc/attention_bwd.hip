@@ -11,6 +11,7 @@
 // Probabilities are recomputed as exp(scale * s + mask - lse) from the log-sum-exp the forward saved; the dropout mask is
 // regenerated from (seed, site, element index).  bf16: v_mfma_f32_32x32x16_bf16, f32: v_mfma_f32_32x32x2_f32.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     int64_t rkey0 = 0;
     // the forward's dropout decisions of this lane's query (MadeAttnBwdArgs.keep_bits): two words per 64-key tile, loaded with the tile
     const bool use_bits = IS_BF16 && a.keep_bits != nullptr && a.drop.p > 0.f;
-    const uint32_t* bits_q = use_bits ? a.keep_bits + ((b * a.H + h) * a.Lq + qc) * a.ld_bits : nullptr;
+    const int64_t nkt32 = (a.Lk + 31) / 32;
+    const uint32_t* bits_q = use_bits ? a.keep_bits + (b * a.H + h) * nkt32 * a.ld_bits + (qc & ~(int64_t)31) + made_keep_slot((int)(qc & 31)) : nullptr;
     uint2 rbits = make_uint2(0u, 0u), cbits = make_uint2(0u, 0u);
     auto load_tile = [&](int64_t key0) __attribute__((always_inline)) {
         rkey0 = key0;
@@ -168,7 +170,10 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
             rk[i] = *(const frag_t*)(Kg + kcl * a.ldk + (c % CPR) * PER16);
             rv[i] = *(const frag_t*)(Vg + kcl * a.ldv + (c % CPR) * PER16);
         }
-        if (use_bits) rbits = *(const uint2*)(bits_q + (key0 / BKEY) * 2);
+        if (use_bits) {
+            const int64_t kt0 = (key0 / BKEY) * 2, kt1 = kt0 + 1 < nkt32 ? kt0 + 1 : kt0;
+            rbits = make_uint2(bits_q[kt0 * a.ld_bits], bits_q[kt1 * a.ld_bits]);
+        }
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -414,8 +419,9 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
     int64_t rqbase = 0;
     // thread t stages the word of query t % 64 x key block t / 64 of this workgroup's 128 keys (MadeAttnBwdArgs.keep_bits)
     const bool use_bits = IS_BF16 && a.keep_bits != nullptr && a.drop.p > 0.f;
+    const int64_t nkt32 = (a.Lk + 31) / 32;
     const int64_t bword = (int64_t)kt_blk * 4 + (tid >> 6);
-    const uint32_t* bits_bh = use_bits ? a.keep_bits + (b * a.H + h) * a.Lq * a.ld_bits + (bword < a.ld_bits ? bword : a.ld_bits - 1) : nullptr;
+    const uint32_t* bits_bh = use_bits ? a.keep_bits + ((b * a.H + h) * nkt32 + (bword < nkt32 ? bword : nkt32 - 1)) * a.ld_bits : nullptr;
     uint32_t rb = 0u;
     auto load_tile = [&](int64_t qbase) __attribute__((always_inline)) {
         rqbase = qbase;
@@ -429,7 +435,8 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
         }
         if (use_bits) {
             const int64_t qq = qbase + (tid & 63);
-            rb = bits_bh[(qq < a.Lq ? qq : a.Lq - 1) * a.ld_bits];
+            const int64_t qb = qq < a.Lq ? qq : a.Lq - 1;
+            rb = bits_bh[(qb & ~(int64_t)31) + made_keep_slot((int)(qb & 31))];
         }
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
@@ -686,8 +693,8 @@ extern "C" int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream) {
     MADE_REQUIRE(a.dtype == MADE_F32 || a.dtype == MADE_BF16, "made_attention_bwd: bad dtype %d", a.dtype);
     MADE_REQUIRE(a.drop.p >= 0.f && a.drop.p < 1.f, "made_attention_bwd: dropout p out of [0,1)");
     if (a.keep_bits)
-        MADE_REQUIRE(a.ld_bits >= 2 * ((a.Lk + 63) / 64) && a.ld_bits % 2 == 0 && ((uintptr_t)a.keep_bits % 8) == 0,
-                     "made_attention_bwd: keep_bits rows need an even ld_bits >= 2 * ceil(Lk / 64) words and 8-byte alignment");
+        MADE_REQUIRE(a.ld_bits >= 32 * ((a.Lq + 31) / 32) && a.ld_bits % 32 == 0 && ((uintptr_t)a.keep_bits % 8) == 0,
+                     "made_attention_bwd: keep_bits rows need ld_bits = a multiple of 32 >= Lq and 8-byte alignment");
     const int per16 = a.dtype == MADE_F32 ? 4 : 8;
     MADE_UNSUPPORTED(a.ldq % per16 == 0 && a.ldk % per16 == 0 && a.ldv % per16 == 0 && a.lddo % per16 == 0 && a.ldo % per16 == 0 &&
                      a.q_bs % per16 == 0 && a.k_bs % per16 == 0 && a.v_bs % per16 == 0 && a.do_bs % per16 == 0 && a.o_bs % per16 == 0 &&
@@ -699,5 +706,11 @@ extern "C" int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream) {
                      "made_attention_bwd: too many workgroups");
     if (a.B == 0 || a.Lq == 0) return MADE_OK;
     hipStream_t st = (hipStream_t)stream;
+    // bf16, head dim 64: the single-pass kernel (attention_bwd_fused.hip).  MADE_ATTN_BWD=split keeps the two-kernel form (A/B measurements).
+    static const bool force_split = [] { const char* e = getenv("MADE_ATTN_BWD"); return e && e[0] == 's'; }();
+    if (!force_split) {
+        const int rc = made_attention_bwd_fused_try(a, st);
+        if (rc >= 0 || rc == MADE_ERR_HIP) return rc;
+    }
     return a.dtype == MADE_BF16 ? launch_bwd<bf16_t>(a, st) : launch_bwd<float>(a, st);
 }

@@ -97,6 +97,14 @@ __device__ __forceinline__ void store_from_f32(void* p, int dtype, int64_t idx, 
     else ((bf16_t*)p)[idx] = (bf16_t)v;
 }
 
+// Slot of query q (0 .. 31 inside its group of 32) in the dropout bit cache of made_attention (MadeAttnArgs.keep_bits): register e of
+// a 32 x 32 MFMA accumulator tile holds row (e & 3) + 8 (e >> 2) + 4 hh, so the words at slots 2 e and 2 e + 1 are the two halves of
+// the 64-lane keep mask of register e.
+__host__ __device__ __forceinline__ int made_keep_slot(int q) { return 2 * ((q & 3) + 4 * (q >> 3)) + ((q >> 2) & 1); }
+
+// made_attention_bwd's single-pass kernel (attention_bwd_fused.hip): MADE_OK after launching, a HIP error, or -1000 when it does not apply
+int made_attention_bwd_fused_try(const MadeAttnBwdArgs& a, hipStream_t st);
+
 // keep ? x : 0 on a 16-byte fragment without control flow (conditional LOADS make hipcc branch around every load and
 // wait for each one in turn -- cdna_hip_programming.md, "three .s-level traps" (c); load always, mask afterwards)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;

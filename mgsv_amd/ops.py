@@ -370,7 +370,7 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
     """softmax(Q K^T scale + mask) V.  Q [B,Lq,H*hd], K / V [B,Lk,H*hd], O [B,Lq,H*hd]
     (any batch/row strides, unit inner stride).  Lk defaults to K.shape[1].
     Training: lse [B,H,Lq] f32 receives the log-sum-exp, drop = (seed, site, p) drops attention weights; keep_bits
-    ([B*H*Lq, attention_bits_words(Lk)] int32) receives the decisions, one bit per score, for attention_bwd."""
+    (int32, shape attention_bits_shape(B, H, Lq, Lk)) receives the decisions, one bit per score, for attention_bwd."""
     assert Q.dim() == 3 and K.dim() == 3 and V.dim() == 3 and O.dim() == 3
     assert Q.stride(2) == 1 and K.stride(2) == 1 and V.stride(2) == 1 and O.stride(2) == 1
     assert Q.dtype == K.dtype == V.dtype == O.dtype
@@ -396,8 +396,9 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
         a.lse = _p(lse)
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
-        if keep_bits is not None:                   # [B*H*Lq, ld] int32 words: the dropout decisions, for attention_bwd
-            assert keep_bits.dtype == torch.int32 and keep_bits.dim() == 2 and keep_bits.is_contiguous() and keep_bits.shape[0] >= B * H * Lq
+        if keep_bits is not None:                   # [B*H*ceil(Lk/32), ld] int32 words: the dropout decisions, for attention_bwd
+            assert keep_bits.dtype == torch.int32 and keep_bits.dim() == 2 and keep_bits.is_contiguous()
+            assert keep_bits.shape[0] >= B * H * ((a.Lk + 31) // 32) and keep_bits.shape[1] >= Lq
             a.keep_bits, a.ld_bits = _p(keep_bits), keep_bits.shape[1]
     esz = 4 if a.dtype == F32 else 2
     flops = 4.0 * B * H * Lq * a.Lk * hd
@@ -408,9 +409,23 @@ def attention(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, H: int, *, key_mask: O
     return O
 
 
-def attention_bits_words(Lk: int) -> int:
-    """words per query row of the dropout-decision cache of made_attention / made_attention_bwd (two per 64-key tile)"""
-    return 2 * ((Lk + 63) // 64)
+def attention_bits_shape(B: int, H: int, Lq: int, Lk: int):
+    """shape of the dropout-decision cache of made_attention / made_attention_bwd (MadeAttnArgs.keep_bits): one row of
+    32 * ceil(Lq / 32) words per (batch, head, 32-key tile)"""
+    return (B * H * ((Lk + 31) // 32), 32 * ((Lq + 31) // 32))
+
+
+def attention_bits_decode(bits: Tensor, B: int, H: int, Lq: int, Lk: int) -> Tensor:
+    """keep_bits -> bool [B, H, Lq, Lk] (tests): word (b, h, key tile kt, slot(q)) bit j = element (q, 32 kt + j) is kept; the 32
+    slots of a query group are permuted (slot(q) = 2 ((q & 3) + 4 (q >> 3)) + ((q >> 2) & 1), csrc/common.h made_keep_slot)"""
+    nkt, ldq = (Lk + 31) // 32, bits.shape[1]
+    w = bits[:B * H * nkt].view(B, H, nkt, ldq)
+    q = torch.arange(Lq, device=bits.device)
+    ql = q & 31
+    slot = (q & ~31) + 2 * ((ql & 3) + 4 * (ql >> 3)) + ((ql >> 2) & 1)
+    w = w[:, :, :, slot]                                                   # [B, H, nkt, Lq]
+    b = (w[..., None] >> torch.arange(32, device=bits.device, dtype=torch.int32)) & 1     # [B, H, nkt, Lq, 32]
+    return b.permute(0, 1, 3, 2, 4).reshape(B, H, Lq, nkt * 32)[..., :Lk].bool()
 
 
 def attention_wide(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, *, scale: float, Kadd: Optional[Tensor] = None,

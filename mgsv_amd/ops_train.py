@@ -154,7 +154,8 @@ def attention_bwd(Q: Tensor, K: Tensor, V: Tensor, O: Tensor, dO: Tensor, dQ: Te
     if drop is not None and drop[2] > 0.0:
         set_drop(a.drop, drop)
         if keep_bits is not None:
-            assert keep_bits.dtype == torch.int32 and keep_bits.dim() == 2 and keep_bits.is_contiguous() and keep_bits.shape[0] >= B * H * Lq
+            assert keep_bits.dtype == torch.int32 and keep_bits.dim() == 2 and keep_bits.is_contiguous()
+            assert keep_bits.shape[0] >= B * H * ((a.Lk + 31) // 32) and keep_bits.shape[1] >= Lq
             a.keep_bits, a.ld_bits = _p(keep_bits), keep_bits.shape[1]
     flops = 10.0 * B * H * Lq * a.Lk * hd                # five products of 2*Lq*Lk*hd (S, dP, dV, dK, dQ): cdna_hip_programming.md, attention backward
     _timed("made_attention_bwd", flops, float(Q.element_size() * B * D * (4 * Lq + 4 * a.Lk)),

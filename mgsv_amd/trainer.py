@@ -467,7 +467,7 @@ class MadeTrainer(MadeEngine):
                 ws[f"{tag}.mean"].fill_(1.0)                      # neutral operands of pool_bwd (dtok = 0): mask * (in1 + in2)
             for l in range(depth):
                 ws.update({f"{tag}.{l}.x0": E(r, D), f"{tag}.{l}.x1": E(r, D), f"{tag}.{l}.qkv": E(r, 3 * D), f"{tag}.{l}.att": E(r, D),
-                           f"{tag}.{l}.lse": E(B * Hh * T1, dtype=f32), f"{tag}.{l}.kbits": E(B * Hh * T1, ops.attention_bits_words(T1), dtype=torch.int32), f"{tag}.{l}.x2": E(r, D), f"{tag}.{l}.x3": E(r, D),
+                           f"{tag}.{l}.lse": E(B * Hh * T1, dtype=f32), f"{tag}.{l}.kbits": E(*ops.attention_bits_shape(B, Hh, T1, T1), dtype=torch.int32), f"{tag}.{l}.x2": E(r, D), f"{tag}.{l}.x3": E(r, D),
                            f"{tag}.{l}.z1": E(r, Ft), f"{tag}.{l}.h": E(r, Ft)})
         rows = B * L
         Lp = round_up(L, 8)
@@ -517,7 +517,7 @@ class MadeTrainer(MadeEngine):
                 dframe_sum=E(B * Tv, D))
         for l in range(ne):
             ws.update({f"e.{l}.src": E(rows, D), f"e.{l}.srcpos": E(rows, D), f"e.{l}.qkv": E(rows, 3 * D), f"e.{l}.att": E(rows, D),
-                       f"e.{l}.lse": E(B * H * L, dtype=f32), f"e.{l}.kbits": E(B * H * L, ops.attention_bits_words(L), dtype=torch.int32), f"e.{l}.x": E(rows, D), f"e.{l}.s1": E(rows, D), f"e.{l}.h": E(rows, Fd),
+                       f"e.{l}.lse": E(B * H * L, dtype=f32), f"e.{l}.kbits": E(*ops.attention_bits_shape(B, H, L, L), dtype=torch.int32), f"e.{l}.x": E(rows, D), f"e.{l}.s1": E(rows, D), f"e.{l}.h": E(rows, Fd),
                        f"e.{l}.x2": E(rows, D)})
         ws.update(mem=E(rows, D), mempos=E(rows, D))
         if not concat:                                          # CA fusion block (query = segments, context = frames)

@@ -295,13 +295,12 @@ def test_attention_forward_dropout_lse_and_backward(T, dtype, tol, B, H, hd, Lq,
         # the forward's decision cache (one bit per score, made_attention's keep_bits): equal to the stateless mask where it is defined
         # (valid queries, keys up to the sample's last valid one), and a backward that reads it gives the gradients of the one that
         # re-draws the mask, bit for bit (bf16; the f32 parity path always re-draws)
-        W = ops.attention_bits_words(Lk)
-        bits = torch.full((B * H * Lq, W), 0x5A5A5A5A, device="cuda", dtype=torch.int32)
+        bits = torch.full(ops.attention_bits_shape(B, H, Lq, Lk), 0x5A5A5A5A, device="cuda", dtype=torch.int32)
         O2 = torch.zeros_like(O)
         ops.attention(q, k, v, O2, H, key_mask=key_mask, q_skip_mask=q_skip, lse=lse, drop=(seed, site, p), keep_bits=bits)
         torch.cuda.synchronize()
         assert torch.equal(O2, O)
-        got_bits = ((bits.view(B, H, Lq, W)[..., None] >> torch.arange(32, device="cuda", dtype=torch.int32)) & 1).reshape(B, H, Lq, W * 32)[..., :Lk].float()
+        got_bits = ops.attention_bits_decode(bits, B, H, Lq, Lk).float()
         defined = (key_mask[:, None, None, :] * valid_q[:, None, :, :]).bool().expand_as(keep)
         assert torch.equal(got_bits[defined], keep[defined])
         if dtype == torch.bfloat16:

@@ -18,7 +18,7 @@ pos = torch.arange(L)[None]
 mask = ((pos < lv[:, None]) | ((pos >= 30) & (pos < 30 + la[:, None]))).float().cuda()
 order = ops.batch_order(mask)
 drop = (1, 2, p)
-bits = torch.empty(B * H * L, ops.attention_bits_words(L), device="cuda", dtype=torch.int32) if os.environ.get("BITS", "1") != "0" else None
+bits = torch.empty(*ops.attention_bits_shape(B, H, L, L), device="cuda", dtype=torch.int32) if os.environ.get("BITS", "1") != "0" else None
 def run():
     ops.attention(q, k, v, O, H, key_mask=mask, q_skip_mask=mask, lse=lse, drop=drop, order=order, keep_bits=bits)
     tr.attention_bwd(q, k, v, O, dO, dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], lse, delta, H, key_mask=mask, q_skip_mask=mask, drop=drop, order=order,
