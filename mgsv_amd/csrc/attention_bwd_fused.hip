@@ -31,15 +31,17 @@
 
 namespace {
 
-constexpr int FT = 512;                  // threads per workgroup (8 waves)
+constexpr int FT = 512;                  // threads per workgroup: eight waves of at most 256 registers (with four waves of 512 hipcc parks the
+                                         // accumulators in AGPRs and moves them every step: 780 v_accvgpr_* per step, measured)
 constexpr int FHD = 64;
 constexpr int FP = FHD * 2 + 16;         // pitch of the query-tile images (Q, dO): row reads of 16 bytes conflict-free
 constexpr int KP = FHD * 2;              // pitch of the key-block image of K: read only through the transposing read; the four 32-byte
                                          // granules of row r sit at granule ^ (((r >> 1) & 1) | ((r >> 3) & 1) << 1): conflict-free
 constexpr int DSP = 64;                  // pitch of a dS^T exchange tile: 32 queries x 2 bytes, 16-query halves swapped on rows with bit 3 set
 constexpr int DQ_TILE_BYTES = 32 * FHD * 4;
-constexpr int IMG_BUF = 32 * FP;         // one image of a query tile; three buffers each for Q and dO (tile t in buffer t % 3)
-constexpr int NIMG = 3;
+constexpr int IMG_BUF = 32 * FP;         // one image of a query tile; Q and dO images are double-buffered
+constexpr int NIMG = 2;
+constexpr int DSX_BUF = 8 * 32 * DSP;    // one set of exchange tiles (double-buffered)
 constexpr float LOG2E = 1.4426950408889634f;
 #ifndef FUSED_STAMPS             // diagnostic build: cycles per section of a workgroup, written behind the B * H * Lq floats of `delta` (16 words per pair)
 #define FUSED_STAMPS 0
@@ -87,10 +89,10 @@ __host__ __device__ inline FusedLayout fused_layout(int qc, int lqp, int lkp) {
     L.imq = o;   o += NIMG * IMG_BUF;
     L.imdo = o;  o += NIMG * IMG_BUF;
     L.imk = o;   o += 256 * KP;
-    L.dsx = o;   o += 8 * 32 * DSP;
-    L.nl = o;    o += lqp * 4;
-    L.nd = o;    o += lqp * 4;
-    L.live = o;  o += lqp;
+    L.dsx = o;   o += 2 * DSX_BUF;
+    L.nl = o;    o += (lqp + 32) * 4;            // (+ 32: the all-dead tile that pads a sweep to a multiple of three steps)
+    L.nd = o;    o += (lqp + 32) * 4;
+    L.live = o;  o += lqp + 32;
     L.qflag = o; o += (lqp / 32 + 3) / 4 * 4;
     L.kflag = o; o += (lkp / 32 + 3) / 4 * 4;
     L.qlist = o; o += (lqp / 32) * 2 + 2; o = (o + 3) / 4 * 4;
@@ -118,7 +120,6 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
     float* nl = (float*)(lds + L.nl);
     float* nd = (float*)(lds + L.nd);
     unsigned char* live = lds + L.live;
-    unsigned char* qflag = lds + L.qflag;
     unsigned char* kflag = lds + L.kflag;
     unsigned short* qlist = (unsigned short*)(lds + L.qlist);
     unsigned short* klist = (unsigned short*)(lds + L.klist);
@@ -143,28 +144,43 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
     const float dsc = DROP ? 1.f / (1.f - a.drop.p) : 1.f;
     const float inv_dsc = DROP ? (1.f - a.drop.p) : 1.f;
 
-    // ---- per-query scalars: eight lanes per query row (16 bytes of O and of dO each), delta = dO . O of the head summed over the eight
+    // ---- per-query scalars: eight lanes per query row (16 bytes of O and of dO each), delta = dO . O of the head summed over the eight.
+    // A global round trip costs several thousand cycles here (one workgroup per CU, nothing else to run meanwhile): every row group's
+    // loads are requested before the first one is used (up to 64 x 8 = 512 queries per pass of the four waves).
     {
         const int sub = lane >> 3, ch = lane & 7;
-        for (int j0 = w * 8; j0 < lqp; j0 += 64) {
-            const int j = j0 + sub;
-            const int jc = j < Lq ? j : Lq - 1;
-            const bool ok = j < Lq && (skipg == nullptr || skipg[jc] != 0.f);
-            const bf16x8 o = *(const bf16x8*)(Og + (int64_t)jc * a.ldo + ch * 8), g = *(const bf16x8*)(Gg + (int64_t)jc * a.lddo + ch * 8);
-            const float l = a.lse[bh * a.Lq + jc];
-            float d = 0.f;
+        constexpr int NG = 9;
+        for (int j00 = 0; j00 < lqp; j00 += NG * 64) {
+            bf16x8 o[NG], g[NG];
+            float l[NG];
+            bool ok[NG];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d += (float)o[e] * (float)g[e];
-            d += dpp_f32<0xB1, 0xF>(d, d);                              // quad_perm [1,0,3,2]
-            d += dpp_f32<0x4E, 0xF>(d, d);                              // quad_perm [2,3,0,1]
-            d += __shfl_xor(d, 4);
-            if (ch == 0) {
-                nl[j] = ok ? -l * LOG2E : -INFINITY;
-                nd[j] = ok ? -d * inv_dsc : 0.f;
-                live[j] = ok ? 1 : 0;
-                if (ok) a.delta[bh * a.Lq + jc] = d;
+            for (int i = 0; i < NG; ++i) {
+                const int j = j00 + 64 * i + w * 8 + sub;
+                const int jc = j < Lq ? j : Lq - 1;
+                ok[i] = j < Lq && (skipg == nullptr || skipg[jc] != 0.f);
+                o[i] = *(const bf16x8*)(Og + (int64_t)jc * a.ldo + ch * 8);
+                g[i] = *(const bf16x8*)(Gg + (int64_t)jc * a.lddo + ch * 8);
+                l[i] = a.lse[bh * a.Lq + jc];
+            }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int j = j00 + 64 * i + w * 8 + sub;
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += (float)o[i][e] * (float)g[i][e];
+                d += dpp_f32<0xB1, 0xF>(d, d);                          // quad_perm [1,0,3,2]
+                d += dpp_f32<0x4E, 0xF>(d, d);                          // quad_perm [2,3,0,1]
+                d += __shfl_xor(d, 4);
+                if (ch == 0 && j < lqp) {
+                    nl[j] = ok[i] ? -l[i] * LOG2E : -INFINITY;
+                    nd[j] = ok[i] ? -d * inv_dsc : 0.f;
+                    live[j] = ok[i] ? 1 : 0;
+                    if (ok[i]) a.delta[bh * a.Lq + j] = d;
+                }
             }
         }
+        if (tid < 32) { nl[lqp + tid] = -INFINITY; nd[lqp + tid] = 0.f; live[lqp + tid] = 0; }
         for (int j = tid; j < lkp; j += FT) {
             const int jc = j < Lk ? j : Lk - 1;
             const bool ok = j < Lk && (maskg == nullptr || maskg[jc] != 0.f);
@@ -200,20 +216,20 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
         uint64_t dead = (nkt > 0 ? ~qmask : ~0ull) & (nqt_all >= 64 ? ~0ull : ((1ull << nqt_all) - 1ull));
         while (dead) {
             const int t0 = __builtin_ctzll(dead); dead &= dead - 1;
-            int t1 = t0;
+            int t1 = -1;
             if (dead) { t1 = __builtin_ctzll(dead); dead &= dead - 1; }
             const int t = row < 32 ? t0 : t1;
             const int q = t * 32 + (row & 31);
-            if ((row < 32 || t1 != t0) && q < Lq) *(bf16x8*)((bf16_t*)a.dQ + b * a.dq_bs + (int64_t)q * a.lddq + h * FHD + ch * 8) = z;
+            if (t >= 0 && q < Lq) *(bf16x8*)((bf16_t*)a.dQ + b * a.dq_bs + (int64_t)q * a.lddq + h * FHD + ch * 8) = z;
         }
         dead = (nqt > 0 ? ~kmask : ~0ull) & (nkt_all >= 64 ? ~0ull : ((1ull << nkt_all) - 1ull));
         while (dead) {
             const int t0 = __builtin_ctzll(dead); dead &= dead - 1;
-            int t1 = t0;
+            int t1 = -1;
             if (dead) { t1 = __builtin_ctzll(dead); dead &= dead - 1; }
             const int t = row < 32 ? t0 : t1;
             const int k = t * 32 + (row & 31);
-            if ((row < 32 || t1 != t0) && k < Lk) {
+            if (t >= 0 && k < Lk) {
                 *(bf16x8*)((bf16_t*)a.dK + b * a.dk_bs + (int64_t)k * a.lddk + h * FHD + ch * 8) = z;
                 *(bf16x8*)((bf16_t*)a.dV + b * a.dv_bs + (int64_t)k * a.lddv + h * FHD + ch * 8) = z;
             }
@@ -225,67 +241,103 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
     // ---- constants of the sweep
     const float c2 = a.scale * LOG2E;
     const int nkb = (nkt + 7) >> 3;
-    const int grp = w >> 2, u = w & 3;                      // ping-pong group; the wave's 16-column head-dim slice of dQ
     // staging role of this thread: tensor (Q / dO), row and 16-byte chunk of a query tile
     const int st_t = tid >> 8, st_row = (tid & 255) >> 3, st_ch = tid & 7;
     const bf16_t* st_base = (st_t ? Gg : Qg) + st_ch * 8;
     const int64_t st_ld = st_t ? a.lddo : a.ldq;
     unsigned char* st_dst = lds + (st_t ? L.imdo : L.imq) + st_row * FP + st_ch * 16;        // (+ buffer * IMG_BUF)
-    // dQ operands of this lane: K^T rows (the group's four key tiles) and dS^T rows (both 16-query halves)
+    // dQ role of this wave: head-dim slice hs (16 columns), query half qh; operands of this lane: K^T rows and dS^T rows, all 256 keys
     const int g16 = lane >> 4, i16 = lane & 15;
+    const int qh = w & 1, hs = w >> 1;
     const int skx = ((i16 >> 3) & 1) | ((g16 & 1) << 1);                                    // K image swizzle of the rows this lane addresses
-    const unsigned char* ka0 = img_k + (grp * 128 + 8 * g16 + (i16 >> 2)) * KP + ((u ^ skx) * 32) + (i16 & 3) * 8;
-    const unsigned char* sb0 = ds_x + grp * (4 * 32 * DSP) + (8 * g16 + (i16 >> 2)) * DSP + (((4 * (i16 & 3)) ^ ((g16 & 1) << 4)) * 2);       // queries 0 .. 15
-    const unsigned char* sb1 = ds_x + grp * (4 * 32 * DSP) + (8 * g16 + (i16 >> 2)) * DSP + (((16 + 4 * (i16 & 3)) ^ ((g16 & 1) << 4)) * 2);  // queries 16 .. 31
+    const unsigned char* ka0 = img_k + (8 * g16 + (i16 >> 2)) * KP + ((hs ^ skx) * 32) + (i16 & 3) * 8;
+    const unsigned char* sb0 = ds_x + (8 * g16 + (i16 >> 2)) * DSP + (((qh * 16 + 4 * (i16 & 3)) ^ ((g16 & 1) << 4)) * 2);
     // hashing path (no bit cache)
     const uint32_t thr = DROP ? made_drop_threshold(a.drop.p) : 0u;
     const uint64_t drop_seed = DROP ? made_drop_seed(a.drop) : 0;
 
-    const int nchunks = (nqt + qc - 1) / qc;
+    // dQ^T piece [16 head-dim columns x 16 queries] of a tile += K^T dS^T over the block's 256 keys (exchange buffer xb)
+    auto dq_phase = [&](int tile_in_chunk, int xb) __attribute__((always_inline)) {
+        unsigned char* cp = dq_acc + (tile_in_chunk * 8 + w) * 1024 + lane * 16;
+        const unsigned char* sb = sb0 + xb * DSX_BUF;
+        f32x4 c = *(const f32x4*)cp;
+#pragma unroll
+        for (int j = 0; j < ((FUSED_SKIP & 8) ? 0 : 8); ++j) {
+            const bf16x4 alo = tr4(ka0 + j * 32 * KP), ahi = tr4(ka0 + j * 32 * KP + 4 * KP);
+            const bf16x4 blo = tr4(sb + j * 32 * DSP), bhi = tr4(sb + j * 32 * DSP + 4 * DSP);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                        __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7), c, 0, 0, 0);
+        }
+        *(f32x4*)cp = c;
+    };
+
+    const int qc3 = qc - qc % 2;
+    const int nchunks = (nqt + qc3 - 1) / qc3;
     const int chunk_len = (nqt + nchunks - 1) / nchunks;                   // balanced chunks of query tiles
     for (int c0 = 0; c0 < nqt; c0 += chunk_len) {
         const int nq_c = (nqt - c0) < chunk_len ? (nqt - c0) : chunk_len;
+        const int nq_p = (nq_c + 1) / 2 * 2;                               // steps of a sweep: padded with an all-dead tile to a multiple of two
+        auto tile_q0 = [&](int pos) __attribute__((always_inline)) {       // first query of the tile at position pos of the (padded) chunk
+            const int t = (int)qlist[c0 + (pos < nq_c ? pos : 0)];
+            return (pos < nq_c ? t : nqt_all) * 32;
+        };
         // zero the dQ image of the chunk
         {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            for (int i = tid; i < nq_c * (DQ_TILE_BYTES / 16); i += FT) *(f32x4*)(dq_acc + i * 16) = z;
+            for (int i = tid; i < nq_p * (DQ_TILE_BYTES / 16); i += FT) *(f32x4*)(dq_acc + i * 16) = z;
         }
-        // The query tiles of the chunk are walked round and round (once per key block); tile T of that endless sequence
-        // (qlist[c0 + T % nq_c]) sits in image buffer T % 3.  Invariant at the start of a sweep: its tile 0 is in LDS, its tile 1 in
-        // the staging registers.
-        bf16x8 rq;
-        bool rq_live;
-        auto issue_tile = [&](int q0n) __attribute__((always_inline)) {
+        // The tiles of the (padded) chunk are walked round and round (once per key block); g counts the steps of the chunk, tile(g) sits in
+        // image buffer g & 1.  A global round trip (4 000 - 6 000 cycles here) takes longer than a step, so two tiles are on their way
+        // at any time: tile T travels in staging slot T & 1, requested at the top of step T - 3 and stored to LDS at the top of step
+        // T - 1.  The step loop is unrolled twice (a sweep is a multiple of two steps), so that a slot is a fixed set of registers and
+        // the compiler's own s_waitcnt vmcnt(N) before a slot's store lets the younger slot's load stay out.
+        u32x4 sl0, sl1;
+        auto ld1 = [&](u32x4& d_, int q0n) __attribute__((always_inline)) {
             const int q = q0n + st_row;
-            const int qcl = q < Lq ? q : Lq - 1;
-            rq = *(const bf16x8*)(st_base + (int64_t)qcl * st_ld);
-            rq_live = q < Lq && (skipg == nullptr || skipg[qcl] != 0.f);
+            d_ = *(const u32x4*)(st_base + (int64_t)(q < Lq ? q : Lq - 1) * st_ld);
         };
-        int it_next = nq_c > 1 ? 1 : 0;                                    // position in the chunk of the tile in the staging registers
-        issue_tile((int)qlist[c0] * 32);
-        *(bf16x8*)st_dst = keep_or_zero(rq, rq_live);                       // tile 0 -> buffer 0
-        issue_tile((int)qlist[c0 + it_next] * 32);
-        int tb = 0;                                                        // buffer of the sweep's tile 0
-        for (int kb = 0; kb < nkb; ++kb) {
-            const int ki = kb * 8 + w;
-            const bool wave_live = ki < nkt;                               // (wave-uniform)
-            const bool grp_live = kb * 8 + grp * 4 < nkt;                  // some wave of this group has keys
-            const int kt = __builtin_amdgcn_readfirstlane((int)klist[wave_live ? ki : nkt - 1]);
-            const int key = kt * 32 + r;
-            const int keyc = key < Lk ? key : Lk - 1;
-            const bool key_valid = wave_live && key < Lk && (maskg == nullptr || maskg[keyc] != 0.f);
-            const float bias_key = key_valid ? 0.f : -INFINITY;
-            const bool has_masked = !__all(key_valid);
-            bf16x8 kf[4], vf[4];
-            {
-                const bf16_t* kp = Kg + (int64_t)keyc * a.ldk;
-                const bf16_t* vp = Vg + (int64_t)keyc * a.ldv;
+        int it_load = 0;                                                   // position in the chunk of the next tile to request
+        auto next_q0 = [&]() __attribute__((always_inline)) {
+            const int q0n = tile_q0(it_load);
+            it_load = it_load + 1 < nq_p ? it_load + 1 : 0;
+            return q0n;
+        };
+        {
+            const int q00 = next_q0();
+            ld1(sl0, q00);                                                 // tile 0
+            ld1(sl1, next_q0());                                           // tiles 1, 2 -> slots 1, 0
+            *(u32x4*)st_dst = keep_or_zero(sl0, live[q00 + st_row] != 0);   // tile 0 -> buffer 0 (visible behind the key block's first barrier)
+            ld1(sl0, next_q0());
+        }
+        int it_n1 = 1;                                                     // position in the chunk of tile g + 1
+        int q0_n1 = __builtin_amdgcn_readfirstlane(tile_q0(it_n1));
+        bool live_n1 = live[q0_n1 + st_row] != 0;                          // this thread's row of tile g + 1 is computed
+        int g = 0;
+        // K / V fragments of the wave's key tile: requested one key block ahead (behind the sweep's last S / dP products, in front of the
+        // block's dK / dV stores), so that their round trip runs under the epilogue instead of behind it
+        bool wave_live, key_valid, has_masked;
+        int kt, key, keyc;
+        float bias_key;
+        bf16x8 kf[4], vf[4];
+        auto load_kv = [&](int kb_) __attribute__((always_inline)) {
+            const int ki = kb_ * 8 + w;
+            wave_live = ki < nkt;                                          // (wave-uniform)
+            kt = __builtin_amdgcn_readfirstlane((int)klist[wave_live ? ki : nkt - 1]);
+            key = kt * 32 + r;
+            keyc = key < Lk ? key : Lk - 1;
+            key_valid = wave_live && key < Lk && (maskg == nullptr || maskg[keyc] != 0.f);
+            bias_key = key_valid ? 0.f : -INFINITY;
+            has_masked = !__all(key_valid);
+            const bf16_t* kp = Kg + (int64_t)keyc * a.ldk;
+            const bf16_t* vp = Vg + (int64_t)keyc * a.ldv;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    kf[ks] = keep_or_zero(*(const bf16x8*)(kp + ks * 16 + hh * 8), key_valid);
-                    vf[ks] = keep_or_zero(*(const bf16x8*)(vp + ks * 16 + hh * 8), key_valid);
-                }
+            for (int ks = 0; ks < 4; ++ks) {
+                kf[ks] = keep_or_zero(*(const bf16x8*)(kp + ks * 16 + hh * 8), key_valid);
+                vf[ks] = keep_or_zero(*(const bf16x8*)(vp + ks * 16 + hh * 8), key_valid);
             }
+        };
+        load_kv(0);
+        for (int kb = 0; kb < nkb; ++kb) {
             // (the previous key block ended with a barrier: the K image and the exchange tiles are free)
             {
                 const int row = w * 32 + r;
@@ -295,160 +347,143 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
             }
             if (!wave_live) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                *(f32x4*)(ds_x + w * (32 * DSP) + lane * 16) = z;
-                *(f32x4*)(ds_x + w * (32 * DSP) + 1024 + lane * 16) = z;
+#pragma unroll
+                for (int xb = 0; xb < 2; ++xb) {
+                    *(f32x4*)(ds_x + xb * DSX_BUF + w * (32 * DSP) + lane * 16) = z;
+                    *(f32x4*)(ds_x + xb * DSX_BUF + w * (32 * DSP) + 1024 + lane * 16) = z;
+                }
             }
             f32x16 dk[2], dv[2];
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
-            f32x16 sc, dp;                                                 // S / dP of the tile between its M and its V phase
-            bf16x8 pf[2], sf[2];                                           // Pd / dS fragments between the V phase and the next M phase
-            uint64_t km[16];                                               // keep masks of the tile of the coming V phase
-            int q0_cur = __builtin_amdgcn_readfirstlane((int)qlist[c0] * 32);      // first query of the tile of this wave's current step
+            int q0 = __builtin_amdgcn_readfirstlane((int)qlist[c0] * 32);
+            // keep masks of the wave's (key tile, query tile): sixteen 64-lane masks, requested a step ahead (right behind their last use)
+            uint64_t km[16];
+            if constexpr (DROP && BITS) {
+                const uint64_t* mp = (const uint64_t*)(kbits + ((bh * nkt_all + kt) * a.ld_bits + q0));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) km[e] = mp[e];
+            }
             __syncthreads();
             STAMP(3);
+            int s = 0;
 
-            // half phases: group 0 runs M(s) at hp = 2 s and V(s) at hp = 2 s + 1, group 1 one half phase later
-            const int nhp = 2 * nq_c + 2;
-            for (int hp = 0; hp < nhp; ++hp) {
-                STAMP(4);
-                if (!(hp & 1) && hp < 2 * nq_c) {
-                    // staging: the sweep's tile hp / 2 + 1 (in the registers) -> its buffer; tile hp / 2 + 2 -> registers
-                    int bi = tb + (hp >> 1) + 1; bi -= 3 * (bi / 3);
-                    *(bf16x8*)(st_dst + bi * IMG_BUF) = keep_or_zero(rq, rq_live);
-                    it_next = it_next + 1 < nq_c ? it_next + 1 : 0;
-                    issue_tile((int)qlist[c0 + it_next] * 32);
-                }
-                const int ph = hp - grp;
-                STAMP(8);                                               // staging
-                if (ph >= 0 && ph <= 2 * nq_c) {
-                    const int s = ph >> 1;
-                    if (!(ph & 1)) {
-                        // ---- M phase: products of tile s - 1 that wait for its V phase, then S / dP of tile s
-                        if (s > 0) {
-                            int pb = tb + s - 1; pb -= 3 * (pb / 3);
-                            const unsigned char* iq = img_q + pb * IMG_BUF;
-                            const unsigned char* ig = img_do + pb * IMG_BUF;
-                            if (wave_live) {
+            auto step = [&](u32x4& slot_regs) __attribute__((always_inline)) {
+                const int buf = g & 1;
+                // tile g + 1 -> the other image buffer (read last during step g - 1); tile g + 4 -> the slot it leaves
+                *(u32x4*)(st_dst + (buf ^ 1) * IMG_BUF) = keep_or_zero(slot_regs, live_n1);
+                ld1(slot_regs, next_q0());
+                const int q0_next = q0_n1;                                 // first query of tile g + 1
+                it_n1 = it_n1 + 1 < nq_p ? it_n1 + 1 : 0;
+                q0_n1 = __builtin_amdgcn_readfirstlane(tile_q0(it_n1));
+                live_n1 = live[q0_n1 + st_row] != 0;
+                const unsigned char* iq = img_q + buf * IMG_BUF;
+                const unsigned char* ig = img_do + buf * IMG_BUF;
+                if (wave_live) {
+                    // ---- S = Q K^T, dP = dO V^T - delta / c
+                    f32x16 sc, dp;
 #pragma unroll
-                                for (int s2 = 0; s2 < 2; ++s2)
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const f32x4 n4 = *(const f32x4*)(nd + q0 + 8 * e4 + 4 * hh);
 #pragma unroll
-                                    for (int d = 0; d < ((FUSED_SKIP & 4) ? 0 : 2); ++d) {
-                                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(ig, FP, 16 * s2, d * 32, lane), pf[s2], dv[d], 0, 0, 0);
-                                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(iq, FP, 16 * s2, d * 32, lane), sf[s2], dk[d], 0, 0, 0);
-                                    }
-                            }
-                            if (grp_live) {
-                                // dQ^T [16 head-dim columns x 32 queries] of tile s - 1 += K^T dS^T over the group's 128 keys
-                                unsigned char* cp = dq_acc + ((s - 1) * 8 + u * 2) * 1024 + lane * 16;
-                                f32x4 cA = *(const f32x4*)cp, cB = *(const f32x4*)(cp + 1024);
-#pragma unroll
-                                for (int j = 0; j < ((FUSED_SKIP & 8) ? 0 : 4); ++j) {
-                                    const bf16x4 alo = tr4(ka0 + j * 32 * KP), ahi = tr4(ka0 + j * 32 * KP + 4 * KP);
-                                    const bf16x8 af = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
-                                    const bf16x4 b0l = tr4(sb0 + j * 32 * DSP), b0h = tr4(sb0 + j * 32 * DSP + 4 * DSP);
-                                    const bf16x4 b1l = tr4(sb1 + j * 32 * DSP), b1h = tr4(sb1 + j * 32 * DSP + 4 * DSP);
-                                    cA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_shufflevector(b0l, b0h, 0, 1, 2, 3, 4, 5, 6, 7), cA, 0, 0, 0);
-                                    cB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_shufflevector(b1l, b1h, 0, 1, 2, 3, 4, 5, 6, 7), cB, 0, 0, 0);
-                                }
-                                *(f32x4*)cp = cA;
-                                *(f32x4*)(cp + 1024) = cB;
-                            }
-                        }
-                        if (s < nq_c && wave_live) {
-                            int cb = tb + s; cb -= 3 * (cb / 3);
-                            const unsigned char* iq = img_q + cb * IMG_BUF;
-                            const unsigned char* ig = img_do + cb * IMG_BUF;
-#pragma unroll
-                            for (int e4 = 0; e4 < 4; ++e4) {
-                                const f32x4 n4 = *(const f32x4*)(nd + q0_cur + 8 * e4 + 4 * hh);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) { sc[4 * e4 + j] = 0.f; dp[4 * e4 + j] = n4[j]; }
-                            }
-#pragma unroll
-                            for (int ks = 0; ks < ((FUSED_SKIP & 1) ? 0 : 4); ++ks) {
-                                const bf16x8 qa = *(const bf16x8*)(iq + r * FP + ks * 32 + hh * 16);
-                                const bf16x8 ga = *(const bf16x8*)(ig + r * FP + ks * 32 + hh * 16);
-                                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sc, 0, 0, 0);
-                                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
-                            }
-                            // the tile's keep masks: requested behind the phase's last LDS wait, in flight over the barrier
-                            if constexpr (DROP && BITS) {
-                                const uint64_t* mp = (const uint64_t*)(kbits + ((bh * nkt_all + kt) * a.ld_bits + q0_cur));
-#pragma unroll
-                                for (int e = 0; e < 16; ++e) km[e] = mp[e];
-                            }
-                        }
-                    } else if (wave_live) {
-                        // ---- V phase of tile s: sc <- Pd, dp <- dS / scale; fragments for the next M phase; dS^T -> the exchange image
-                        f32x4 ndq[4], nlq[4];
-#pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) {
-                            nlq[e4] = *(const f32x4*)(nl + q0_cur + 8 * e4 + 4 * hh);
-                            ndq[e4] = *(const f32x4*)(nd + q0_cur + 8 * e4 + 4 * hh);
-                        }
-                        if (has_masked) {
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) sc[e] += bias_key;
-                        }
-                        if constexpr ((FUSED_SKIP & 2) != 0) {
-                        } else if constexpr (DROP && BITS) {
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c2, nlq[e >> 2][e & 3]));
-                                const float pc = p * dsc;
-                                sc[e] = sel0_m(pc, km[e]);
-                                dp[e] = pc * sel_m(ndq[e >> 2][e & 3], dp[e], km[e]);
-                            }
-                        } else if constexpr (DROP) {
-                            const uint64_t qbase = (uint64_t)(bh * a.Lq + q0_cur) * (uint64_t)a.Lk + (uint64_t)keyc;
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c2, nlq[e >> 2][e & 3]));
-                                const float pc = p * dsc;
-                                const bool keep = (made_rng_mix(drop_seed, a.drop.site, qbase + (uint64_t)acc_row(e, hh) * (uint64_t)a.Lk) >> 8) >= thr;
-                                sc[e] = keep ? pc : 0.f;
-                                dp[e] = pc * (keep ? dp[e] : ndq[e >> 2][e & 3]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c2, nlq[e >> 2][e & 3]));
-                                sc[e] = p;
-                                dp[e] = p * dp[e];
-                            }
-                        }
-                        unsigned char* row = ds_x + w * (32 * DSP) + r * DSP;
-                        const int sw = ((r >> 3) & 1) << 4;
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) { pf[s2][j] = (bf16_t)sc[8 * s2 + j]; sf[s2][j] = (bf16_t)dp[8 * s2 + j]; }
-                            // register quads 2 s2, 2 s2 + 1 of this lane's key row: queries 8 g + 4 hh .. + 3
-                            *(bf16x4*)(row + (((16 * s2 + 4 * hh) ^ sw) * 2)) = __builtin_shufflevector(sf[s2], sf[s2], 0, 1, 2, 3);
-                            *(bf16x4*)(row + (((16 * s2 + 8 + 4 * hh) ^ sw) * 2)) = __builtin_shufflevector(sf[s2], sf[s2], 4, 5, 6, 7);
-                        }
-                        // the next tile of this wave
-                        q0_cur = __builtin_amdgcn_readfirstlane((int)qlist[c0 + (s + 1 < nq_c ? s + 1 : 0)] * 32);
+                        for (int j = 0; j < 4; ++j) { sc[4 * e4 + j] = 0.f; dp[4 * e4 + j] = n4[j]; }
                     }
+                    {
+                        bf16x8 qa[4], ga[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            qa[ks] = *(const bf16x8*)(iq + r * FP + ks * 32 + hh * 16);
+                            ga[ks] = *(const bf16x8*)(ig + r * FP + ks * 32 + hh * 16);
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < ((FUSED_SKIP & 1) ? 0 : 4); ++ks) {
+                            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], sc, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks], vf[ks], dp, 0, 0, 0);
+                        }
+                    }
+                    // the dQ^T piece of the previous step, under this step's products and arithmetic
+                    if (s > 0) dq_phase(s - 1, buf ^ 1);
+                    // ---- sc <- Pd, dp <- dS / scale  (the row constants are read again here rather than held over the products)
+                    f32x4 ndq[4], nlq[4];
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        nlq[e4] = *(const f32x4*)(nl + q0 + 8 * e4 + 4 * hh);
+                        ndq[e4] = *(const f32x4*)(nd + q0 + 8 * e4 + 4 * hh);
+                    }
+                    if (has_masked) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) sc[e] += bias_key;
+                    }
+                    if constexpr ((FUSED_SKIP & 2) != 0) {
+                    } else if constexpr (DROP && BITS) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c2, nlq[e >> 2][e & 3]));
+                            const float pc = p * dsc;
+                            sc[e] = sel0_m(pc, km[e]);
+                            dp[e] = pc * sel_m(ndq[e >> 2][e & 3], dp[e], km[e]);
+                        }
+                        // the masks of the next step
+                        const uint64_t* mp = (const uint64_t*)(kbits + ((bh * nkt_all + kt) * a.ld_bits + (q0_next < lqp ? q0_next : lqp - 32)));
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) km[e] = mp[e];
+                    } else if constexpr (DROP) {
+                        const uint64_t qbase = (uint64_t)(bh * a.Lq + q0) * (uint64_t)a.Lk + (uint64_t)keyc;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c2, nlq[e >> 2][e & 3]));
+                            const float pc = p * dsc;
+                            const bool keep = (made_rng_mix(drop_seed, a.drop.site, qbase + (uint64_t)acc_row(e, hh) * (uint64_t)a.Lk) >> 8) >= thr;
+                            sc[e] = keep ? pc : 0.f;
+                            dp[e] = pc * (keep ? dp[e] : ndq[e >> 2][e & 3]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c2, nlq[e >> 2][e & 3]));
+                            sc[e] = p;
+                            dp[e] = p * dp[e];
+                        }
+                    }
+                    // ---- dV^T += dO^T Pd,  dK^T += Q^T dS;  dS^T -> the exchange image
+                    unsigned char* row = ds_x + buf * DSX_BUF + w * (32 * DSP) + r * DSP;
+                    const int sw = ((r >> 3) & 1) << 4;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 pf, sf;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { pf[j] = (bf16_t)sc[8 * s2 + j]; sf[j] = (bf16_t)dp[8 * s2 + j]; }
+#pragma unroll
+                        for (int d = 0; d < ((FUSED_SKIP & 4) ? 0 : 2); ++d) {
+                            dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(ig, FP, 16 * s2, d * 32, lane), pf, dv[d], 0, 0, 0);
+                            dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(iq, FP, 16 * s2, d * 32, lane), sf, dk[d], 0, 0, 0);
+                        }
+                        // register quads 2 s2, 2 s2 + 1 of this lane's key row: queries 8 g + 4 hh .. + 3
+                        *(bf16x4*)(row + (((16 * s2 + 4 * hh) ^ sw) * 2)) = __builtin_shufflevector(sf, sf, 0, 1, 2, 3);
+                        *(bf16x4*)(row + (((16 * s2 + 8 + 4 * hh) ^ sw) * 2)) = __builtin_shufflevector(sf, sf, 4, 5, 6, 7);
+                    }
+                } else if (s > 0) {
+                    dq_phase(s - 1, buf ^ 1);
                 }
-#if FUSED_STAMPS
-                __builtin_amdgcn_s_waitcnt(0);                          // (the phase's own memory latency counted inside the phase)
-                if (ph >= 0 && ph <= 2 * nq_c && !(ph & 1)) STAMP(9); else STAMP(10);      // M phase / V phase (or idle)
-#endif
-                __syncthreads();
-                STAMP(11);                                              // barrier wait
-            }
-            tb += nq_c; tb -= 3 * (tb / 3);
+                q0 = q0_next;
+                ++s; ++g;
+                __syncthreads();           // dS^T (step g) and the images of tile g + 1 are in place; buffers of step g - 1 are free
+                __builtin_amdgcn_sched_barrier(0);                         // (nothing of the next step is scheduled into this one: register pressure)
+            };
+            for (int s2 = 0; s2 < nq_p; s2 += 2) { step(sl1); step(sl0); }
             STAMP(4);
+            const bool e_live = wave_live, e_valid = key_valid;
+            const int e_key = key, e_keyc = keyc;
+            if (kb + 1 < nkb) load_kv(kb + 1);
+            dq_phase(nq_p - 1, (g - 1) & 1);
 
-            // dK / dV rows of this wave's key tile: the two lane halves exchange register quads (v_permlane32_swap) so that a lane stores
-            // 16 contiguous bytes: lane (r, 0) columns 8 g .. 8 g + 7 of g = 0, 2, lane (r, 1) those of g = 1, 3 (per 32-column half)
-            if (wave_live) {
-                bf16_t* kp = (bf16_t*)a.dK + b * a.dk_bs + (int64_t)keyc * a.lddk + h * FHD;
-                bf16_t* vp = (bf16_t*)a.dV + b * a.dv_bs + (int64_t)keyc * a.lddv + h * FHD;
+            // dK / dV rows of the wave's key tile: the two lane halves exchange register quads (v_permlane32_swap) so that a lane stores
+            // 16 contiguous bytes: lane (r, 0) columns 16 gp .. + 7, lane (r, 1) columns 16 gp + 8 .. + 15 (per 32-column half)
+            if (e_live) {
+                bf16_t* kp = (bf16_t*)a.dK + b * a.dk_bs + (int64_t)e_keyc * a.lddk + h * FHD;
+                bf16_t* vp = (bf16_t*)a.dV + b * a.dv_bs + (int64_t)e_keyc * a.lddv + h * FHD;
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
                     bf16_t* op = t2 ? vp : kp;
@@ -458,42 +493,43 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
                         for (int gp = 0; gp < 2; ++gp) {                   // quads 2 gp (kept by the lower half) and 2 gp + 1 (kept by the upper half)
                             const f32x16& acc = t2 ? dv[d] : dk[d];
                             const float m = t2 ? 1.f : a.scale;
+                            const int col = d * 32 + 16 * gp + 8 * hh;
+                            float x0[4], x1[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { x0[j] = acc[8 * gp + j] * m; x1[j] = acc[8 * gp + 4 + j] * m; }
+                            if (c0 > 0) {
+                                // a later chunk of query tiles: add to what the first one stored (this lane's own columns, before the exchange)
+                                const bf16x4 o0 = *(const bf16x4*)(op + d * 32 + 16 * gp + 4 * hh), o1 = *(const bf16x4*)(op + d * 32 + 16 * gp + 8 + 4 * hh);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { x0[j] += (float)o0[j]; x1[j] += (float)o1[j]; }
+                            }
                             bf16x4 qa, qb;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { qa[j] = (bf16_t)(acc[8 * gp + j] * m); qb[j] = (bf16_t)(acc[8 * gp + 4 + j] * m); }
+                            for (int j = 0; j < 4; ++j) { qa[j] = (bf16_t)x0[j]; qb[j] = (bf16_t)x1[j]; }
                             const uint2 ua = __builtin_bit_cast(uint2, qa), ub = __builtin_bit_cast(uint2, qb);
                             const auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
                             const auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
-                            // lower half: (own quad 2 gp, partner's quad 2 gp) = columns 16 gp .. + 7; upper half: (partner's quad 2 gp + 1, own) = 16 gp + 8 ..
-                            u32x4 pk = {s0[0], s1[0], s0[1], s1[1]};
-                            const int col = d * 32 + 16 * gp + 8 * hh;
-                            if (c0 > 0) {
-                                const bf16x8 old = *(const bf16x8*)(op + col);
-                                bf16x8 cur = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) cur[j] = (bf16_t)((float)cur[j] + (float)old[j]);
-                                pk = __builtin_bit_cast(u32x4, cur);
-                            }
-                            if (key < Lk) *(u32x4*)(op + col) = key_valid ? pk : u32x4{0u, 0u, 0u, 0u};
+                            const u32x4 pk = {s0[0], s1[0], s0[1], s1[1]};
+                            if (e_key < Lk) *(u32x4*)(op + col) = e_valid ? pk : u32x4{0u, 0u, 0u, 0u};
                         }
                 }
             }
-            __syncthreads();               // the K image and the exchange tiles may be rewritten
+            __syncthreads();               // the last dQ^T pieces are in; the K image and the exchange tiles may be rewritten
             STAMP(5);
         }
-        // dQ rows of the chunk: a tile's image is eight pieces (head-dim slice u, query half qh) of 1 KB, wave w flushes piece w:
-        // lane (g16, i16) holds head-dim columns 16 u + 4 g16 .. + 3 of query 16 qh + i16
+        // dQ rows of the chunk: a tile's image is eight pieces (head-dim slice hs, query half qh) of 1 KB, wave w flushes piece w:
+        // lane (g16, i16) holds head-dim columns 16 hs + 4 g16 .. + 3 of query 16 qh + i16
+#pragma unroll 3
         for (int s = 0; s < nq_c; ++s) {
             const int qt = qlist[c0 + s];
-            const int pu = w >> 1, pq = w & 1;
-            const int q = qt * 32 + pq * 16 + i16;
+            const int q = qt * 32 + qh * 16 + i16;
             const f32x4 c = *(const f32x4*)(dq_acc + (s * 8 + w) * 1024 + lane * 16);
             if (q < Lq) {
                 const bool ok = live[q] != 0;
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(ok ? c[j] * a.scale : 0.f);
-                *(bf16x4*)((bf16_t*)a.dQ + b * a.dq_bs + (int64_t)q * a.lddq + h * FHD + pu * 16 + 4 * g16) = o;
+                *(bf16x4*)((bf16_t*)a.dQ + b * a.dq_bs + (int64_t)q * a.lddq + h * FHD + hs * 16 + 4 * g16) = o;
             }
         }
         __syncthreads();
@@ -507,10 +543,6 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
         dst[9] = nqt; dst[10] = nkt; dst[11] = nchunks;
         dst[12] = (uint32_t)(st_first >> 8);                // start time (256-cycle units)
         uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); dst[13] = xcc & 15;
-    }
-    if (lane == 0) {                                        // per wave: staging / M phase / V phase / barrier wait
-        uint32_t* dst = (uint32_t*)(a.delta + a.B * a.H * a.Lq) + a.B * a.H * 16 + (pair * 8 + w) * 4;
-        for (int i = 0; i < 4; ++i) dst[i] = (uint32_t)st_acc[8 + i];
     }
 #endif
 }

@@ -236,7 +236,7 @@ def test_train_step_with_the_early_optimizer_part_tracks_the_one_piece_step(monk
     cfg, sd, inp = _setup(8, 20, 40)
     t = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in inp.items() if isinstance(v, np.ndarray)}
     curves = []
-    for early in ("1", "0", "0"):                                # the one-piece schedule twice: its own run-to-run spread is the yardstick
+    for early in ("1", "0"):
         monkeypatch.setenv("MADE_EARLY_OPT", early)
         trn = MadeTrainer(cfg, sd, dtype="bf16")
         losses = []
@@ -248,14 +248,15 @@ def test_train_step_with_the_early_optimizer_part_tracks_the_one_piece_step(monk
         assert trn.opt_step == 6
         curves.append(losses)
     assert np.isfinite(curves).all()
-    early, one, one_again = (np.asarray(c) for c in curves)
+    early, one = (np.asarray(c) for c in curves)
     # Two runs of the SAME schedule differ: the weight gradients are f32 atomic sums over workgroups (arrival order; csrc/gemm_tn*.hip), and six
-    # steps at this learning rate on eight samples amplify a last-place difference (measured: up to 1.5 % at the sixth step).  The early-optimizer
-    # schedule must stay within 2 % of the one-piece step, or within four times what the one-piece step differs from itself in this very run.
-    spread = np.abs(one - one_again) / np.maximum(np.abs(one), 1.0)
+    # steps at this learning rate on eight samples amplify a last-place difference.  FIXED bounds = 2 x the largest pairwise difference of
+    # sixteen runs (eight per schedule; tools/early_opt_spread_probe.py, profiles/r06_early_opt_spread.txt: 0, 0, 8.8e-4, 1.6e-2, 1.1e-2,
+    # 3.8e-2 per step): the first three steps -- where a wrong schedule would show first: step 1 already reads every updated group -- agree
+    # tightly, the later ones within the chaos of the curve itself.
+    bound = np.asarray([1e-4, 1e-4, 2e-3, 3.2e-2, 3.2e-2, 7.6e-2])
     diff = np.abs(early - one) / np.maximum(np.abs(one), 1.0)
-    assert np.all(diff <= np.maximum(2e-2, 4.0 * spread) + 2e-2 / np.maximum(np.abs(one), 1.0)), (curves, spread.tolist(), diff.tolist())
-    assert np.all(spread <= 3e-2), spread.tolist()               # and that spread itself stays small
+    assert np.all(diff <= bound), (curves, diff.tolist())
 
 
 def test_training_reduces_the_loss():

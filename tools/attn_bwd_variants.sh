@@ -11,6 +11,11 @@ if [ "$1" = stamps ]; then
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_ab/fstamps.so tools/_ab/fstamps.o $(ls $B/*.o | grep -v "/attention_bwd_fused.o")
   echo "built tools/_ab/fstamps.so (MADE_LIB_PATH=tools/_ab/fstamps.so python tools/attn_bwd_check.py stamps)"; exit 0
 fi
+if [ "$1" = flags ]; then   # bash tools/attn_bwd_variants.sh flags <name> "<-D flags>"
+  /opt/rocm/bin/hipcc $FLAGS $3 -c mgsv_amd/csrc/attention_bwd_fused.hip -o tools/_ab/$2.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_ab/$2.so tools/_ab/$2.o $(ls $B/*.o | grep -v "/attention_bwd_fused.o")
+  echo "built tools/_ab/$2.so"; exit 0
+fi
 for m in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS -DFUSED_SKIP=$m -c mgsv_amd/csrc/attention_bwd_fused.hip -o tools/_ab/fskip$m.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_ab/fskip$m.so tools/_ab/fskip$m.o $(ls $B/*.o | grep -v "/attention_bwd_fused.o")
