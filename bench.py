@@ -46,6 +46,26 @@ ROCPROF_AVG_FILE = os.path.join(ROOT, "profiles", "r05_kernel_avg_us.json")   # 
 STEP_CEILING_PAIRS_S = {"train": 62000.0, "eval": 186000.0}          # MFMA ceilings of the whole step (fwd+bwd / fwd)
 
 
+
+import contextlib
+
+
+@contextlib.contextmanager
+def _variant(**knobs):
+    """Run a comparison measurement on another kernel variant: the library's measurement knobs (honoured only under MADE_DEBUG_VARIANTS=1:
+    mgsv_amd/_lib.py variant_env, csrc/common.h made_variant_env) set for the duration, the caller's environment restored afterwards."""
+    knobs = dict(knobs, MADE_DEBUG_VARIANTS="1")
+    prev = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        yield
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
 def _cpu_model() -> str:
     try:
         for ln in open("/proc/cpuinfo"):
@@ -287,25 +307,8 @@ def north_star_contraction(dev) -> dict:
         e0.record(); gr.replay(); gr.replay(); e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 40 * 1e3
 
-    prev = os.environ.get("MADE_XPOOL_INBATCH_FUSED")
-    os.environ["MADE_XPOOL_INBATCH_FUSED"] = "0"
     byts = 2.0 * Nm * S * D * 2 + Nv * D * 2 + Nm * Nv * D * 2
-    try:
-        us = timed()
-        ref = o.clone()
-        one = None
-        try:                                               # the opt-in one-launch form (round 5): same words, exchanged inside the launch
-            os.environ["MADE_XPOOL_INBATCH_FUSED"] = "1"
-            us1 = timed()
-            one = {"us_per_call": round(us1, 2), "frac_of_hbm_peak": round(byts / us1 / 1e3 / 8000.0, 4), "bit_identical_to_two_launches": bool(torch.equal(o, ref)),
-                   "note": "MADE_XPOOL_INBATCH_FUSED=1, not the default (DESIGN.md section 5)"}
-        except Exception as ex:                            # noqa: BLE001
-            one = {"error": f"{type(ex).__name__}: {ex}"}
-    finally:
-        if prev is None:
-            os.environ.pop("MADE_XPOOL_INBATCH_FUSED", None)
-        else:
-            os.environ["MADE_XPOOL_INBATCH_FUSED"] = prev
+    us = timed()
     flops = 4.0 * Nv * Nm * S * D
     return {"workload": f"X-Pool QK^T . softmax . PV, {Nv} videos x {Nm} tracks x {S} segments, d = {D}, bf16, full-length tracks",
             "path": "made_xpool_inbatch (scores per track and 128 segments, then P.V per track and 128 value columns)",
@@ -313,7 +316,6 @@ def north_star_contraction(dev) -> dict:
             "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / us / 1e3 / 8000.0, 4),
                          "algorithmic_mb": round(byts / 1e6, 2)},
             "mfma_tflops": round(flops / us / 1e6, 1), "mfma_frac_of_bf16_peak": round(flops / us / 1e6 / 2500.0, 4),
-            "one_launch_form": one,
             "measured": "hipGraph replay of 20 calls, HIP events around two replays"}
 
 
@@ -369,20 +371,14 @@ def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> di
     if rank == 0 and world == 1:
         # the other D = 256 kernel (made_xpool_fused: the whole pair chain with the per-pair Linear, rounds 2-4's default) on the same pass, AFTER the
         # timed region: reported beside the default path (made_xpool_sims for tracks of at most 96 segments), not part of `value`
-        prev_env = os.environ.get("MADE_XPOOL_SIMS")
-        os.environ["MADE_XPOOL_SIMS"] = "0"
         try:
-            step(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            step(); step(); torch.cuda.synchronize()
-            other_ms = round((time.perf_counter() - t1) / 2 * 1e3, 3)
+            with _variant(MADE_XPOOL_SIMS="0"):
+                step(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step(); step(); torch.cuda.synchronize()
+                other_ms = round((time.perf_counter() - t1) / 2 * 1e3, 3)
         except Exception as ex:                      # report, do not hide
             other_ms = f"{type(ex).__name__}: {ex}"
-        finally:
-            if prev_env is None:
-                os.environ.pop("MADE_XPOOL_SIMS")
-            else:
-                os.environ["MADE_XPOOL_SIMS"] = prev_env
     out = {"metric": "retrieval sim-matrix GB/s (all-pairs video x music, X-Pool + dual tower)", "value": round(alg_bytes / sec / 1e9, 3),
            "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(sec * 1e3, 3),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -390,7 +386,7 @@ def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> di
                       "pairs_per_s": round(pairs / sec, 1), "algorithmic_gb": round(alg_bytes / 1e9, 3),
                       "sim_matrix_only_gbs": round(4.0 * N_v * N_m / sec / 1e9, 3),
                       "path": ("made_xpool_sims: u'' = W'' u GEMM over the tracks + one kernel per chunk of tracks (the per-pair Linear as a second P.V product)"
-                               if (S <= 96 and os.environ.get("MADE_XPOOL_SIMS", "") != "0") else "made_xpool_fused (one kernel per chunk of tracks)"),
+                               if S <= 96 else "made_xpool_fused (one kernel per chunk of tracks)"),
                       "made_xpool_fused_ms_per_step": other_ms},
            "roofline": roof, "kernels": per_kernel,
            "cpu_baseline": (cpu_baseline_retrieval(cfg, synth.make_state_dict(cfg, seed=0), S) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None)}
@@ -415,17 +411,11 @@ def retrieval_leg(args, rank, world, local, dist, steps: int, warmup: int) -> di
         except Exception as ex:                      # report, do not hide
             out["config"]["S512_D512"] = {"error": f"{type(ex).__name__}: {ex}"}
         else:
-            prev_attn = os.environ.get("MADE_XPOOL_ATTN")
-            os.environ["MADE_XPOOL_ATTN"] = "0"
             try:                                     # (its own try: a failure of the comparison run does not take the first result with it)
-                out["config"]["S512_D512"]["separate_launch_chain_ms_per_pass"] = _retrieval_512(args)["ms_per_pass"]
+                with _variant(MADE_XPOOL_ATTN="0"):
+                    out["config"]["S512_D512"]["separate_launch_chain_ms_per_pass"] = _retrieval_512(args)["ms_per_pass"]
             except Exception as ex:
                 out["config"]["S512_D512"]["separate_launch_chain_ms_per_pass"] = f"{type(ex).__name__}: {ex}"
-            finally:
-                if prev_attn is None:
-                    os.environ.pop("MADE_XPOOL_ATTN")
-                else:
-                    os.environ["MADE_XPOOL_ATTN"] = prev_attn
     return out
 
 
@@ -477,7 +467,7 @@ def _retrieval_512(args, n_v: int = 8192, n_m: int = 512, S: int = 512) -> dict:
     torch.cuda.empty_cache()
     return {"workload": f"N_v={n_v}, N_m={n_m}, S={S}, D={D}, segment lengths U{{12..{S}}}, 1 GPU", "ms_per_pass": round(sec * 1e3, 2),
             "GB_s": round(alg / sec / 1e9, 3), "pairs_per_s": round(n_v * n_m / sec, 1), "executed_tflops": round(flops / sec / 1e12, 1),
-            "path": ("made_xpool_attention + folded Linear + made_xpool_tail" if os.environ.get("MADE_XPOOL_ATTN", "1") != "0"
+            "path": ("made_xpool_attention + folded Linear + made_xpool_tail" if not (os.environ.get("MADE_DEBUG_VARIANTS", "0") not in ("", "0") and os.environ.get("MADE_XPOOL_ATTN", "1") == "0")
                      else "separate launches (made_attention_wide, LayerNorm2, Linear, made_xpool_tail)")}
 
 
@@ -726,50 +716,88 @@ def _self_launch(args) -> int:
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
-    procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=(subprocess.PIPE if r == 0 else sys.stderr), text=True))
+    import threading
+    procs, chunks = [], []
+    deadline = time.time() + float(os.environ.get("MADE_BENCH_LAUNCH_TIMEOUT", "3600"))
     rc = 0
-    pending = set(range(n))
-    out0 = None
-    while pending:
-        for r in sorted(pending):
-            p = procs[r]
-            if r == 0 and out0 is None and p.poll() is not None:
-                out0 = p.stdout.read()
-            code = p.poll()
-            if code is None:
-                continue
-            pending.discard(r)
-            if code != 0 and rc == 0:
-                rc = code
-                print(f"bench.py: rank {r} exited with code {code}; ending the other ranks", file=sys.stderr)
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=(subprocess.PIPE if r == 0 else sys.stderr), text=True))
+        # rank 0's stdout is drained as it is written (a reader thread): a line longer than the pipe buffer, or a library's banner on
+        # stdout (NCCL_DEBUG=INFO), must not block the rank in write() while this process only polls
+        reader = threading.Thread(target=lambda: chunks.extend(iter(lambda: procs[0].stdout.read(65536), "")), daemon=True)
+        reader.start()
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; ending the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            if pending and time.time() > deadline:
+                print(f"bench.py: ranks {sorted(pending)} still running at the launch timeout; ending them", file=sys.stderr)
+                rc = rc or 124
                 for q in pending:
                     procs[q].terminate()
-        time.sleep(0.05)
-    if out0 is None:
-        out0 = procs[0].stdout.read()
-    sys.stdout.write(out0)
+                deadline = float("inf")
+            time.sleep(0.05)
+        reader.join(timeout=10)
+    finally:
+        for p in procs:                                    # (an interrupt or an error here must not leave ranks behind)
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write("".join(chunks))
     sys.stdout.flush()
     return rc
 
 
-def _dry_run(rank: int, world: int) -> None:
-    """MADE_BENCH_DRY_RUN=1 (tests/test_bench_launch_cpu.py): the launcher and the rendezvous alone, on the host -- every rank joins a gloo
-    group under the environment it was given, one all-reduce, rank 0 prints the line's bookkeeping fields.  No kernel runs, nothing is
-    measured and the line says so."""
+def _dry_run(rank: int, world: int, args) -> None:
+    """MADE_BENCH_DRY_RUN=1 (tests/test_bench_launch_cpu.py): the launcher, the rendezvous and the workload's PARTITION alone, on the host --
+    every rank joins a gloo group under the environment it was given, one all-reduce; for the retrieval workload the ranks exchange a
+    stand-in music side through the production gather (mgsv_amd/retrieval.py: ragged shards, one packed all-gather) and rank 0 checks that
+    the shards tile N_v and N_m; for the train workload the ranks all-reduce a stand-in gradient buffer in the two buckets the trainer uses.
+    No kernel runs, nothing is measured and the line says so."""
     import torch.distributed as dist
+    from mgsv_amd import retrieval
     dist.init_process_group("gloo")
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
+    plan = {}
+    if args.workload in ("all", "retrieval"):
+        nv, nm = min(args.nv, 4096), min(args.nm, 301)      # (a small stand-in with the real partition arithmetic: ragged when world does not divide)
+        v0, v1 = retrieval.shard_rows(nv, world, rank)
+        m0, m1 = retrieval.shard_rows(nm, world, rank)
+        counts = [retrieval.shard_rows(nm, world, r)[1] - retrieval.shard_rows(nm, world, r)[0] for r in range(world)]
+        S, D = 4, 8
+        seg = torch.full((m1 - m0, S, D), float(rank)); mask = torch.ones(m1 - m0, S); mus = torch.full((m1 - m0, D), float(rank))
+        sr = retrieval.ShardedRetrieval(lambda v, sg, mk, mu: v @ mu.t(), pack_dtype=torch.float32)
+        blocks = sr.gather_music_side(seg, mask, mus, counts=counts)
+        got = sum(int(b[0].shape[0]) for b in blocks)
+        rows = torch.tensor([float(v1 - v0)]); dist.all_reduce(rows)
+        plan["retrieval"] = {"video_rows_this_rank": v1 - v0, "video_rows_all_ranks": int(rows[0]), "music_tracks_gathered": got, "n_v": nv, "n_m": nm}
+        assert int(rows[0]) == nv and got == nm, plan
+    if args.workload in ("all", "train"):
+        n = 1000 + 7                                        # stand-in flat gradient: two buckets (detection + matching range first, temporal range behind)
+        g = torch.full((n,), float(rank + 1))
+        cut = int(n * 0.85)
+        h1 = dist.all_reduce(g[:cut], async_op=True); h2 = dist.all_reduce(g[cut:], async_op=True)
+        h1.wait(); h2.wait()
+        plan["train"] = {"bucket_elems": [cut, n - cut], "grad_sum": float(g[0]), "expected": world * (world + 1) / 2}
+        assert float(g[0]) == float(g[-1]) == world * (world + 1) / 2, plan
     dist.barrier()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t[0]), "master_addr": os.environ.get("MASTER_ADDR"),
-                          "value": None, "note": "launcher / rendezvous check only; nothing was measured"}))
+                          "workload": args.workload, "plan": plan,
+                          "value": None, "note": "launcher / rendezvous / partition check only; nothing was measured"}))
     dist.destroy_process_group()
 
 
@@ -782,7 +810,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (or plainly: python bench.py --gpus N)"
     if os.environ.get("MADE_BENCH_DRY_RUN") == "1":
-        return _dry_run(rank, world)
+        return _dry_run(rank, world, args)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dist = None

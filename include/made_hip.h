@@ -553,10 +553,9 @@ int64_t made_xpool_sims_ws_bytes(int64_t Nv, int64_t Nm, int64_t D);
  * workgroup per CU -- scores per (track, 128 segments) with the tile-local softmax pieces, then P.V per (track, 128 value columns) -- with only
  * the bf16 probabilities between them; replaces made_attention_wide's key split + merge on this shape.  Q [Nv <= 64, D], K / U [Nm, S <= 512, D]
  * (rows at m * {k,u}_bs + s * ld{k,u}), bf16, D = 256 / 512; key_mask [Nm, S] f32 or NULL; out[m * o_bs + n * ldo + d] bf16 or f32;
- * ws: made_xpool_inbatch_ws_bytes(Nm, S) bytes, 16-byte aligned.  A track without a valid segment gives NaN rows (the reference's softmax).
- * MADE_XPOOL_INBATCH_FUSED=1 (opt-in, round 5): both roles in ONE launch -- a track's workgroups exchange the probabilities inside the launch through
- * agent-scope (sc1) loads / stores and two counters per track at the END of ws, which must be ZERO before the first call on that workspace (every
- * call leaves them zero); results bit-identical to the two launches. */
+ * ws: made_xpool_inbatch_ws_bytes(Nm, S) bytes, 16-byte aligned (a larger workspace may be reused for a smaller call).  A track without a valid
+ * segment gives NaN rows (the reference's softmax).  (Round 5's opt-in one-launch form -- both roles in one workgroup, the probabilities handed
+ * over inside the launch -- was 4 % faster alone and is gone: docs/EXPERIMENTS.md.) */
 typedef struct MadeXpoolInbatchArgs {
     const void* Q; int64_t ldq;
     const void* K; const void* U; int64_t k_bs, ldk, u_bs, ldu;

@@ -11,6 +11,16 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MADE_LIB_PATH: another build of the same library (A/B measurements of two builds on one box, tools/ab_libs.sh); it must export the same
 # ABI version, checked below, so a stale or older build fails here instead of reading shifted struct fields
+
+
+def variant_env(name: str, default: str = "") -> str:
+    """The value of a measurement knob (MADE_* variables that select a variant an A/B measurement once needed: docs/EXPERIMENTS.md) -- honoured
+    only under MADE_DEBUG_VARIANTS=1, like the library's own (csrc/common.h made_variant_env): production has one code path."""
+    if os.environ.get("MADE_DEBUG_VARIANTS", "0") in ("", "0"):
+        return default
+    return os.environ.get(name, default)
+
+
 LIB_PATH = os.environ.get("MADE_LIB_PATH") or os.path.join(_HERE, "libmade_hip.so")
 ABI_VERSION = 7                          # include/made_hip.h MADE_ABI_VERSION the ctypes mirrors in this file were written for
 

@@ -707,7 +707,7 @@ extern "C" int made_attention_bwd(const MadeAttnBwdArgs* args, void* stream) {
     if (a.B == 0 || a.Lq == 0) return MADE_OK;
     hipStream_t st = (hipStream_t)stream;
     // bf16, head dim 64: the single-pass kernel (attention_bwd_fused.hip).  MADE_ATTN_BWD=split keeps the two-kernel form (A/B measurements).
-    static const bool force_split = [] { const char* e = getenv("MADE_ATTN_BWD"); return e && e[0] == 's'; }();
+    static const bool force_split = [] { const char* e = made_variant_env("MADE_ATTN_BWD"); return e && e[0] == 's'; }();
     if (!force_split) {
         const int rc = made_attention_bwd_fused_try(a, st);
         if (rc >= 0 || rc == MADE_ERR_HIP) return rc;

@@ -34,6 +34,18 @@ void made_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// ---- measurement knobs ------------------------------------------------------------------------
+// Every MADE_* environment variable the library reads selects a VARIANT that an A/B measurement once needed (tile shapes, the split
+// attention backward, debug stamps ...; docs/EXPERIMENTS.md says what each one decided).  They are honoured only under
+// MADE_DEBUG_VARIANTS=1: a production process has ONE code path, whatever its environment holds.
+#include <stdlib.h>
+#include <string.h>
+static inline const char* made_variant_env(const char* name) {
+    const char* on = getenv("MADE_DEBUG_VARIANTS");
+    if (on == nullptr || on[0] == '\0' || strcmp(on, "0") == 0) return nullptr;
+    return getenv(name);
+}
+
 // ---- launch tape (include/made_hip.h: made_tape_*) ------------------------------------------------
 // Every kernel of the library is launched through made_launch (the hipLaunchKernelGGL spelling below is redirected to it): the
 // launch goes to the stream as always and, while the calling thread records a tape, a copy of (function, grid, block, LDS bytes,

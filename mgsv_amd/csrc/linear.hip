@@ -1469,27 +1469,27 @@ static void launch_t16(const MadeLinearArgs& a, hipStream_t st) {
 // 16 x 16-tile one is the default (at most 64 rows)
 
 static int tile_pref() {                                   // read on every call: the tests switch kernels inside one process
-    const char* e = getenv("MADE_LINEAR_TILE");
+    const char* e = made_variant_env("MADE_LINEAR_TILE");
     return e ? atoi(e) : 0;
 }
 
 static int64_t tiny_max() {                                // most 64 x 32 tiles for which the fragments-from-global kernel is chosen (MADE_TINY_MAX: knob for measurements)
-    const char* e = getenv("MADE_TINY_MAX");
+    const char* e = made_variant_env("MADE_TINY_MAX");
     return e ? (int64_t)atoll(e) : 1024;
 }
 
 static int64_t f32_glds_min() {                            // least number of 64 x 128 tiles for the f32 LDS-DMA kernel (MADE_LINEAR_F32_GLDS_MIN: knob for measurements)
-    const char* e = getenv("MADE_LINEAR_F32_GLDS_MIN");
+    const char* e = made_variant_env("MADE_LINEAR_F32_GLDS_MIN");
     return e ? (int64_t)atoll(e) : 1;                      // measured (f32 training step): 32 -> 27.8 ms, 8 -> 25.4 ms, 1 -> 19.5 ms (the general kernel: 35.2 ms)
 }
 
 static int64_t big_train_min() {                           // read on every call (A/B inside one process)
-    const char* e = getenv("MADE_LINEAR_BIG_TRAIN");
+    const char* e = made_variant_env("MADE_LINEAR_BIG_TRAIN");
     return e ? (int64_t)atoll(e) : 0;
 }
 
 static int64_t t16_max() {                                 // (MADE_T16_MAX: knob for measurements)
-    static const int64_t v = [] { const char* e = getenv("MADE_T16_MAX"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    static const int64_t v = [] { const char* e = made_variant_env("MADE_T16_MAX"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
     return v;
 }
 
@@ -1514,7 +1514,7 @@ static int pick_variant(const MadeLinearArgs& a) {
         // 0.11 of the f32 MFMA peak); anything with an option that loop does not serve, and every small problem, stays on the general kernel.
         bool fast = a.a_dtype == MADE_F32 && a.K % 32 == 0 && a.a_row_mask == nullptr && a.split_k <= 1 && (a.A2 == nullptr || a.a2_replace) &&
                     ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && a.bias_row_scale == nullptr &&
-                    getenv("MADE_LINEAR_F32_GLDS_OFF") == nullptr;
+                    made_variant_env("MADE_LINEAR_F32_GLDS_OFF") == nullptr;
         for (int s = 0; s < a.nseg; ++s) fast = fast && !a.seg[s].transposed;
         if (a.A2 && a.a2_replace) fast = fast && (a.a2_row_mod == 0) && (a.lda2 % 4 == 0) && ((uintptr_t)a.A2 % 16 == 0);
         if (a.batch > 1) fast = fast && (a.a_z_stride % 4 == 0) && (a.w_z_stride % 4 == 0);

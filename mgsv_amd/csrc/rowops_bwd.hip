@@ -982,12 +982,12 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
     const bool v8 = rows > 256 && D == 512 && x_rows_per_batch == 0 && x_dtype == MADE_BF16 && dy_dtype == MADE_BF16 && dx_dtype == MADE_BF16 &&
                     (add == nullptr || add_dtype == MADE_BF16) && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ld_add % 8 == 0 && lddxd % 8 == 0 &&
                     ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)add % 16) == 0 &&
-                    ((uintptr_t)dx_drop % 16) == 0 && getenv("MADE_LNBWD_V8_OFF") == nullptr;
+                    ((uintptr_t)dx_drop % 16) == 0 && made_variant_env("MADE_LNBWD_V8_OFF") == nullptr;
     if (v8) {                                                   // bf16 rows of 512: 16-byte accesses, four rows in flight per wave
         // measured (tools/r03_micro.py, 18 979 valid rows, dropout + flush): 16-wave workgroups with two rows in flight per wave, one per CU:
         // 29.4 us; 8-wave workgroups with four rows in flight: 31.5 (256) / 34.0 us (512 workgroups); the 8-byte kernel: 36.9 us
-        static const int rf = [] { const char* e = getenv("MADE_LNBWD_RF"); return e ? atoi(e) : 2; }();          // knobs for measurements
-        static const int nb_cap8 = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();
+        static const int rf = [] { const char* e = made_variant_env("MADE_LNBWD_RF"); return e ? atoi(e) : 2; }();          // knobs for measurements
+        static const int nb_cap8 = [] { const char* e = made_variant_env("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();
         if (rf == 2) {
             int64_t nb = (rows + 15) / 16;
             if (nb > nb_cap8) nb = nb_cap8;
@@ -999,7 +999,7 @@ extern "C" int made_layernorm_bwd(const void* x, int32_t x_dtype, int64_t ldx, i
         }
     } else if (rows > 256 && D <= 1024) {                       // each workgroup flushes 2*D same-address atomics: few, large workgroups
         int64_t nb = (rows + 15) / 16;
-        static const int nb_cap = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
+        static const int nb_cap = [] { const char* e = made_variant_env("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
         if (nb > nb_cap) nb = nb_cap;
         // (D > 512: eight waves per workgroup -- with sixteen the 128-register budget of four waves per SIMD spilled 132 bytes)
         if (nv_of(D) <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a);
@@ -1117,7 +1117,7 @@ extern "C" int made_xpool_tail_bwd(const void* y, int32_t y_dtype, int64_t ldy, 
     a.rows = rows; a.Nv = Nv; a.D = (int)D; a.eps = eps;
     if (rows > 256 && D <= 1024) {
         int64_t nb = (rows + 15) / 16;
-        static const int nb_cap = [] { const char* e = getenv("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
+        static const int nb_cap = [] { const char* e = made_variant_env("MADE_LNBWD_NB"); return e ? atoi(e) : 256; }();   // one 16-wave workgroup per CU (7.18 vs 7.27 ms per training step against 512); knob for measurements
         if (nb > nb_cap) nb = nb_cap;
         if (nv_of(D) <= 2) hipLaunchKernelGGL((xpool_tail_bwd_kernel<2, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((xpool_tail_bwd_kernel<4, 8>), dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, a);   // (as made_layernorm_bwd)

@@ -1362,7 +1362,7 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
     // the retrieval set's tracks: 32 videos (MADE_XPOOL_SIMS_PQ=64: round 5's 64-video kernel -- half the LDS-DMA bytes per pair, the same speed
     // within 1.2 %: the comment in front of it) and four waves per workgroup, two workgroups per CU; at most MAX_TRACKS per chunk (the track table
     // in LDS), as few partial rounds of the chip as possible
-    const bool pq64 = getenv("MADE_XPOOL_SIMS_PQ") && atoi(getenv("MADE_XPOOL_SIMS_PQ")) == 64;
+    const bool pq64 = made_variant_env("MADE_XPOOL_SIMS_PQ") && atoi(made_variant_env("MADE_XPOOL_SIMS_PQ")) == 64;
     static bool attr32 = false;
     if (!attr32) {
         hipError_t e = hipFuncSetAttribute((const void*)xpool_sims32_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -1373,15 +1373,15 @@ extern "C" int made_xpool_sims(const MadeXpoolSimsArgs* args, void* stream) {
         attr32 = true;
     }
     // MADE_XPOOL_DBG=32: the phase-stamp build of the 32-video kernel (tools/xpool_sims_stamps.py): workgroup (0, 0) writes cycle stamps into the sims buffer, no similarity is written
-    const bool stamps32 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 32;
-    const bool stamps64 = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 64;      // the same for the 64-video kernel
+    const bool stamps32 = made_variant_env("MADE_XPOOL_DBG") && atoi(made_variant_env("MADE_XPOOL_DBG")) == 32;
+    const bool stamps64 = made_variant_env("MADE_XPOOL_DBG") && atoi(made_variant_env("MADE_XPOOL_DBG")) == 64;      // the same for the 64-video kernel
     const bool use64 = (pq64 && !stamps32) || stamps64;
     const int64_t nvt32 = use64 ? (a.Nv + 63) / 64 : (a.Nv + 31) / 32;
     // Chunks of at most 64 tracks: the workgroups of an XCD walk a chunk together and share its rows through that XCD's L2 -- the shorter the
     // chunk, the less they drift apart.  53 k x 4 k (profiles/r04_ao_*): 464 tracks per chunk 56.4 ms with 66 GB of L2 misses per launch, 128: 56.2 ms /
     // 56 GB, 64: 57.2 ms / 31 GB, 32: 59.2 ms / 26 GB (a workgroup's prologue -- Q, g3 vn, the constant fragments -- costs about two tracks).
     int64_t max_per = 64;
-    if (getenv("MADE_XPOOL_SIMS_PER") && atoi(getenv("MADE_XPOOL_SIMS_PER")) > 0) max_per = atoi(getenv("MADE_XPOOL_SIMS_PER"));
+    if (made_variant_env("MADE_XPOOL_SIMS_PER") && atoi(made_variant_env("MADE_XPOOL_SIMS_PER")) > 0) max_per = atoi(made_variant_env("MADE_XPOOL_SIMS_PER"));
     const int64_t max_tracks = use64 ? Xs64<D>::MAX_TRACKS : Xs32<D>::MAX_TRACKS;
     if (max_per > max_tracks) max_per = max_tracks;
     const int64_t c_lo = (a.Nm + max_per - 1) / max_per;

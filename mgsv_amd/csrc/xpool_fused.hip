@@ -672,7 +672,7 @@ extern "C" int made_xpool_fused(const MadeXpoolFusedArgs* args, void* stream) {
     dim3 grid((unsigned)nvt, (unsigned)((a.Nm + per - 1) / per)), block(PT);
     // MADE_XPOOL_DBG=33: the phase-stamp build of the kernel (tools/xpool_stamps.py): no similarity is written, workgroup (0, 0)
     // writes cycle stamps into the sims buffer instead
-    static const bool stamps = getenv("MADE_XPOOL_DBG") && atoi(getenv("MADE_XPOOL_DBG")) == 33;
+    static const bool stamps = made_variant_env("MADE_XPOOL_DBG") && atoi(made_variant_env("MADE_XPOOL_DBG")) == 33;
     if (stamps) {
         hipFuncSetAttribute((const void*)xpool_fused_persist_kernel<33>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
         hipLaunchKernelGGL(xpool_fused_persist_kernel<33>, grid, block, PLDS, (hipStream_t)stream, a, (const int*)info, per);

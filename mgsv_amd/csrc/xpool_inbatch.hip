@@ -336,308 +336,11 @@ __global__ __launch_bounds__(IB_T, 1) void xpool_inbatch_pv_kernel(const Inbatch
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------- one launch (round 5)
-// Both roles in ONE workgroup: workgroup (track m, j) computes the scores of segment slice j, publishes its p~ tiles, and -- once the track's
-// other workgroups have published theirs -- multiplies value-column slice j.  What rounds 3 and 4 found slow in one-launch forms is avoided:
-//   * no second set of workgroups that can only become resident when the first retires (round 4: 54 us): a workgroup keeps its CU and its LDS
-//     image, the K slice's bytes are replaced by the U slice's as soon as the scores are out of the MFMAs, so the U transfer (4 us) runs under the
-//     exchange instead of behind a kernel boundary;
-//   * no agent-scope release / acquire fences (a write-back and an invalidate of a whole L2 each): the exchanged words -- p~ fragments and the
-//     tiles' (reference, sum) pairs -- are written and read with agent-scope (sc1) buffer instructions, which go through to the memory side and
-//     are therefore seen by every XCD; the publisher waits for its own stores' acknowledgements (vmcnt = 0), then signs in on the track's
-//     counter with a relaxed agent-scope atomic, the consumers poll that counter.
-// Counters: two 32-bit words per track in the workspace (arrived, departed), zero before the first call; the last workgroup of a track to depart
-// (all of them have read every tile by then) puts both back to zero, so a replayed launch (hipGraph, launch tape) finds them as the first did.
-// Deadlock: a workgroup waits only for workgroups of its own track, whose block numbers are adjacent: the dispatcher hands out blocks in order,
-// so when one of them is resident the others are resident or done; the poll is bounded all the same (a timeout is recorded in the workspace's
-// error word and the launch finishes with whatever it has).
-// Measured (profiles/r05_xpool_inbatch_one_launch.txt): the exchange is cheap (0.35 us for the acknowledgements, 1.5 us in the poll) and the result is
-// bit-identical to the two launches in every test, but the launch takes 23.8 us against 24.8 us: with one workgroup per CU the phases of a workgroup
-// are serial -- K + Q transfer 3.1 us, lower K half + 64 MFMAs 4.3, softmax pieces 1.7, U issue 2.9 (the four waves that would do something else are
-// the ones issuing it), poll 1.5, tiles + U landing 3.1, 64 MFMAs 2.5, store 0.8 -- where the two launches pay a kernel boundary instead.  Opt-in.
-// (A compiler pitfall met here: __builtin_amdgcn_raw_buffer_load_b64 is narrowed to its first word by this clang; the pairs are read as two b32.)
-struct InbatchSync { uint32_t* cnt; uint32_t* err; };
-
-template <int D, bool DBG>
-__global__ __launch_bounds__(IB_T, 1) void xpool_inbatch_fused_kernel(const InbatchArgs a, const InbatchSync sy, int G) {
-    // DBG: s_memtime stamps of ten points of workgroups 0, 101 and gridDim.x - 1 into sy.err + 4 (tools/xpool_qk_bench.py STAMPS=1)
-#define IBF_STAMP(i) do { if (DBG && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == gridDim.x - 1)) { \
-        const int w_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 101 ? 1 : 2); \
-        ((unsigned long long*)(sy.err + 4))[w_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
-    IBF_STAMP(0);
-    constexpr int KROWB = D * 2;                      // bytes of a K row
-    constexpr int RPP = 1024 / KROWB;
-    constexpr int NKS = D / 16;
-    constexpr int IMG = IB_SMAX * IB_COL * 2;         // 128 KB: the larger of the two LDS images (K slice at D = 512 / U column slice)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* flags = (float*)(lds + IMG);               // [IB_SMAX]
-    int* red = (int*)(flags + IB_SMAX);               // [12] + [1]: the poll's verdict
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
-    const int nsl = a.Tpad / 4, ncs = D / IB_COL;
-    const int m = (int)blockIdx.x / G, j = (int)blockIdx.x % G;
-    int first, s_eff; bool one_run;
-    ib_scan_mask(a.key_mask ? a.key_mask + (int64_t)m * a.S : nullptr, a.S, flags, red, first, s_eff, one_run);
-    // the exchanged words go through buffer instructions with sc1 (agent scope): see above
-    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wp + (int64_t)m * a.Tpad * 2 * 64 * 16), 0, a.Tpad * 2 * 64 * 16 * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_ml = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wml + (int64_t)m * a.Tpad * 64 * 2), 0, a.Tpad * 64 * 2 * 4, 0x00020000);
-    constexpr int SC1 = 16;
-    // ================================================================================================================ scores of slice j
-    if (j < nsl && (j * IB_SEG < s_eff || (s_eff == 0 && j == 0))) {
-        const int sl = j;
-        const int vb = wave & 1, sh = wave >> 1;
-        const unsigned char* Kb = (const unsigned char*)(a.K + (int64_t)m * a.k_bs);
-        const uint32_t ldk_b = (uint32_t)a.ldk * 2u, ldq_b = (uint32_t)a.ldq * 2u;
-        constexpr int HP = 64 * KROWB / 1024 / 4;
-        auto k_half_ = [&](int half, const bool arith) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < HP; ++i) {
-                const int piece = half * 4 * HP + wave * HP + i;
-                const int rr = piece * RPP + (RPP == 1 ? 0 : (lane >> 5));
-                const int cl = RPP == 1 ? lane : (lane & 31);
-                const int seg = sl * IB_SEG + rr;
-                const bool v = arith ? (seg >= first && seg < s_eff) : (flags[seg] != 0.f);
-                const uint32_t off = (uint32_t)(v ? seg : first) * ldk_b + (uint32_t)((cl ^ (rr & 31)) << 4);
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Kb + off), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
-            }
-        };
-        auto k_half = [&](int half) __attribute__((always_inline)) { if (one_run) k_half_(half, true); else k_half_(half, false); };
-        k_half(1);
-#pragma unroll
-        for (int i = 0; i < HP; ++i) {
-            const int piece = wave * HP + i;
-            const int rr = piece * RPP + (RPP == 1 ? 0 : (lane >> 5));
-            const int cl = RPP == 1 ? lane : (lane & 31);
-            const uint32_t off = (uint32_t)(rr < a.Nv ? rr : a.Nv - 1) * ldq_b + (uint32_t)((cl ^ (rr & 31)) << 4);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)((const unsigned char*)a.Q + off), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        IBF_STAMP(1);
-        bf16x8 qf[NKS];
-        {
-            const uint32_t qbase = (uint32_t)((vb * 32 + r) * KROWB);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(lds + qbase + ((uint32_t)(((2 * ks + hh) ^ r) & (KROWB / 16 - 1)) << 4));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(qf[0]), "+v"(qf[NKS - 1]) :: "memory");
-        k_half(0);
-        if (sh == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        f32x16 sa, sb;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
-        const uint32_t kbase = (uint32_t)((sh * 64 + r) * KROWB);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const uint32_t co = (uint32_t)(((2 * ks + hh) ^ r) & (KROWB / 16 - 1)) << 4;
-            const bf16x8 ka = *(const bf16x8*)(lds + kbase + co), kb = *(const bf16x8*)(lds + kbase + 32 * KROWB + co);
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[ks], sb, 0, 0, 0);
-        }
-        if (sh != 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : "+v"(sa[0]), "+v"(sb[0]) :: "memory");
-        IBF_STAMP(2);
-        const float c = a.scale * 1.4426950408889634f;
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            f32x16 s = tt == 0 ? sa : sb;
-            const int tile = sl * 4 + sh * 2 + tt;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int seg = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const bool v = one_run ? (seg >= first && seg < s_eff) : (flags[seg] != 0.f);
-                s[e] = v ? s[e] * c : -INFINITY;
-                mx = fmaxf(mx, s[e]);
-            }
-            mx = fmaxf(mx, ib_other_half(mx));
-            mx = mx == -INFINITY ? mx : __builtin_ceilf(mx);
-            const float us = mx == -INFINITY ? 0.f : mx;
-            float l = 0.f;
-            bf16x8 p[2];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(s[e] - us);
-                l += (float)pb;
-                p[e >> 3][e & 7] = pb;
-            }
-            l += ib_other_half(l);
-            const uint32_t po = (uint32_t)(((tile * 2 + vb) * 64 + lane) * 32);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p[0]), rs_p, po, 0, SC1);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p[1]), rs_p, po + 16, 0, SC1);
-            if (hh == 0) {
-                typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-                __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){__builtin_bit_cast(uint32_t, mx), __builtin_bit_cast(uint32_t, l)}, rs_ml,
-                                                      (uint32_t)((tile * 64 + vb * 32 + r) * 8), 0, SC1);
-            }
-        }
-    }
-    // ================================================================================================================ publish, fetch U, wait for the track
-    IBF_STAMP(3);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // this workgroup's tiles are acknowledged; the K image is free
-    IBF_STAMP(4);
-    uint32_t* cnt = sy.cnt + 2 * m;
-    if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int nt = s_eff > 0 ? (s_eff + 31) / 32 : 1;
-    const bool pv_role = j < ncs;
-    constexpr int ROWB = IB_COL * 2;
-    if (pv_role) {
-        const unsigned char* Ub = (const unsigned char*)(a.U + (int64_t)m * a.u_bs + j * IB_COL);
-        const uint32_t ldu_b = (uint32_t)a.ldu * 2u;
-        const int pieces = nt * 8;
-        const uint32_t coff = (uint32_t)(lane & 15);
-        const uint32_t sw = (uint32_t)(((((coff >> 2) ^ ((lane >> 4) & 3)) << 2) | (coff & 3)) << 4);
-        if (one_run) {
-            for (int piece = wave; piece < pieces; piece += 4) {
-                const int rr = piece * 4 + (lane >> 4);
-                const uint32_t off = (uint32_t)((rr >= first && rr < s_eff) ? rr : first) * ldu_b + sw;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ub + off), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
-            }
-        } else {
-            for (int piece = wave; piece < pieces; piece += 4) {
-                const int rr = piece * 4 + (lane >> 4);
-                const uint32_t off = (uint32_t)(flags[rr] != 0.f ? rr : first) * ldu_b + sw;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ub + off), (lds_ptr_t)(lds + piece * 1024), 16, 0, 0);
-            }
-        }
-    }
-    IBF_STAMP(5);
-    if (tid == 0) {
-        uint32_t spins = 0;
-        bool ok = true;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)G) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) { ok = false; break; }
-        }
-        if (!ok) __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    IBF_STAMP(6);
-    asm volatile("s_barrier" ::: "memory");                                        // (raw: the U pieces stay in flight)
-    // ================================================================================================================ P.V of column slice j
-    constexpr int TMAX = IB_SMAX / 32;
-    f32x2 ts[TMAX];
-    bf16x8 pq[TMAX][2];
-    const int vb = wave & 1, ch = wave >> 1;
-    if (pv_role) {
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            const int tc = t < a.Tpad ? t : a.Tpad - 1;
-            // (two 32-bit loads: this compiler narrows __builtin_amdgcn_raw_buffer_load_b64 to its first word and drops the second)
-            const uint32_t o_ml = (uint32_t)((tc * 64 + vb * 32 + r) * 8);
-            ts[t] = (f32x2){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ml, o_ml, 0, SC1)),
-                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ml, o_ml + 4, 0, SC1))};
-        }
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            const int tc = t < nt ? t : 0;                                          // (tiles behind the track's last valid one: never multiplied)
-            const uint32_t po = (uint32_t)(((tc * 2 + vb) * 64 + lane) * 32);
-            pq[t][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, 0, SC1));
-            pq[t][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po + 16, 0, SC1));
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the U slice has landed (and every exchanged word of this workgroup)
-    IBF_STAMP(7);
-    // everybody of this workgroup has read the track's tiles: sign out; the last workgroup of the track resets the counters
-    if (tid == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (uint32_t)G - 1) {
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (!pv_role) return;
-    float mg = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t)
-        if (t < nt) mg = fmaxf(mg, ts[t][0]);
-    const float ug = mg == -INFINITY ? 0.f : mg;
-    float l = 0.f;
-    uint32_t kk[TMAX];
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-        const float d = t < nt ? fminf(ug - ts[t][0], 255.f) : 255.f;
-        const uint32_t k = (uint32_t)d;
-        kk[t] = (k << 7) | (k << 23);
-        l = t < nt ? __builtin_fmaf(__builtin_amdgcn_exp2f(-d), ts[t][1], l) : l;
-    }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
-    const int g = lane >> 4, i16 = lane & 15;
-    const int trow = 4 * (g >> 1) + (i16 >> 2);
-    const uint32_t u_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + trow * ROWB + (g & 1) * 32 + (i16 & 3) * 8;
-    const uint32_t u_l0 = u_b + (((2 * ch) ^ (trow & 3)) << 6), u_l1 = u_b + (((2 * ch + 1) ^ (trow & 3)) << 6);
-#pragma unroll
-    for (int tp = 0; tp < TMAX / 2; ++tp) {
-        if (2 * tp < nt) {
-            const int ta = 2 * tp, tb = 2 * tp + 1;
-            const bool has_b = tb < nt;
-            const bf16x8 pa0 = pq[ta][0], pa1 = pq[ta][1], pb0 = pq[tb][0], pb1 = pq[tb][1];
-            bf16x4 u[16];
-            const uint32_t va = u_l0 + ta * (32 * ROWB), vb_ = u_l1 + ta * (32 * ROWB);
-            const uint32_t vc = u_l0 + (has_b ? tb : ta) * (32 * ROWB), vd = u_l1 + (has_b ? tb : ta) * (32 * ROWB);
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u[0]) : "v"(va));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(u[1]) : "v"(va));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(u[2]) : "v"(va));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(u[3]) : "v"(va));
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u[4]) : "v"(vb_));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(u[5]) : "v"(vb_));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(u[6]) : "v"(vb_));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(u[7]) : "v"(vb_));
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u[8]) : "v"(vc));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(u[9]) : "v"(vc));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(u[10]) : "v"(vc));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(u[11]) : "v"(vc));
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u[12]) : "v"(vd));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(u[13]) : "v"(vd));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(u[14]) : "v"(vd));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(u[15]) : "v"(vd));
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]),
-                                                  "+v"(u[8]), "+v"(u[9]), "+v"(u[10]), "+v"(u[11]), "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15]));
-            const uint32_t kb = has_b ? kk[tb] : 0xffffffffu;
-            const bf16x8 qa0 = ib_scale_pow2(pa0, kk[ta]), qa1 = ib_scale_pow2(pa1, kk[ta]);
-            const bf16x8 qb0 = ib_scale_pow2(pb0, kb), qb1 = ib_scale_pow2(pb1, kb);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(u[0], u[1], 0, 1, 2, 3, 4, 5, 6, 7), qa0, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(u[4], u[5], 0, 1, 2, 3, 4, 5, 6, 7), qa0, o1, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(u[2], u[3], 0, 1, 2, 3, 4, 5, 6, 7), qa1, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(u[6], u[7], 0, 1, 2, 3, 4, 5, 6, 7), qa1, o1, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(u[8], u[9], 0, 1, 2, 3, 4, 5, 6, 7), qb0, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(u[12], u[13], 0, 1, 2, 3, 4, 5, 6, 7), qb0, o1, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(u[10], u[11], 0, 1, 2, 3, 4, 5, 6, 7), qb1, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(u[14], u[15], 0, 1, 2, 3, 4, 5, 6, 7), qb1, o1, 0, 0, 0);
-        }
-    }
-    IBF_STAMP(8);
-    const float inv = 1.f / l;
-    const int n = vb * 32 + r;
-    if (n < a.Nv) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int64_t off = (int64_t)m * a.o_bs + (int64_t)n * a.ldo + j * IB_COL + (2 * ch + cb) * 32 + 4 * hh;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) v[jj] = (cb == 0 ? o0[4 * q + jj] : o1[4 * q + jj]) * inv;
-                if (a.out_dtype == MADE_BF16) {
-                    bf16x4 b;
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) b[jj] = (bf16_t)v[jj];
-                    *(bf16x4*)((bf16_t*)a.out + off + 8 * q) = b;
-                } else {
-                    *(f32x4*)((float*)a.out + off + 8 * q) = v;
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    IBF_STAMP(9);
-#undef IBF_STAMP
-}
-
 }  // namespace
 
 extern "C" int64_t made_xpool_inbatch_ws_bytes(int64_t Nm, int64_t S) {
     const int64_t tpad = ((S + IB_SEG - 1) / IB_SEG) * 4;
-    return Nm * tpad * (2 * 64 * 16 * 2 + 64 * 2 * 4) + ((Nm * 8 + 15) / 16) * 16 + 16;      // + the one-launch form's counters (two words per track) and its error word
+    return Nm * tpad * (2 * 64 * 16 * 2 + 64 * 2 * 4);
 }
 
 extern "C" int made_xpool_inbatch(const MadeXpoolInbatchArgs* args, void* stream) {
@@ -672,30 +375,6 @@ extern "C" int made_xpool_inbatch(const MadeXpoolInbatchArgs* args, void* stream
         attr_done = true;
     }
     const dim3 g1((unsigned)(a.Nm * (a.Tpad / 4))), g2((unsigned)(a.Nm * (x.D / IB_COL))), blk(IB_T);
-    // MADE_XPOOL_INBATCH_FUSED=1: the one-launch form (round 5; correct, bit-identical to the two launches, 23.8 against 24.8 us on the north-star
-    // shape -- not the default: profiles/r05_xpool_inbatch_one_launch.txt).  Its counters sit behind the tiles in the workspace and must be ZERO
-    // before the first call on that workspace (every call leaves them zero).
-    const int fmode = getenv("MADE_XPOOL_INBATCH_FUSED") ? atoi(getenv("MADE_XPOOL_INBATCH_FUSED")) : 0;     // 1: one launch; 4: with phase stamps
-    if (fmode == 1 || fmode == 4) {
-        static bool attr_f = false;
-        constexpr int lds_f = IB_SMAX * IB_COL * 2 + IB_SMAX * 4 + 64;
-        if (!attr_f) {
-            hipError_t e = hipFuncSetAttribute((const void*)xpool_inbatch_fused_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_inbatch_fused_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xpool_inbatch_fused_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);
-            if (e != hipSuccess) { made_set_error("made_xpool_inbatch: cannot reserve LDS: %s", hipGetErrorString(e)); return MADE_ERR_HIP; }
-            attr_f = true;
-        }
-        InbatchSync sy;
-        sy.cnt = (uint32_t*)((unsigned char*)x.ws + (int64_t)a.Nm * a.Tpad * (2 * 64 * 16 * 2 + 64 * 2 * 4));
-        sy.err = sy.cnt + ((a.Nm * 2 + 3) / 4) * 4;
-        const int G = (a.Tpad / 4) > (int)(x.D / IB_COL) ? (a.Tpad / 4) : (int)(x.D / IB_COL);
-        const dim3 gf((unsigned)(a.Nm * G));
-        if (x.D == 512 && fmode == 4) hipLaunchKernelGGL((xpool_inbatch_fused_kernel<512, true>), gf, blk, lds_f, (hipStream_t)stream, a, sy, G);   // stamps: the workspace needs 400 more bytes
-        else if (x.D == 512) hipLaunchKernelGGL((xpool_inbatch_fused_kernel<512, false>), gf, blk, lds_f, (hipStream_t)stream, a, sy, G);
-        else hipLaunchKernelGGL((xpool_inbatch_fused_kernel<256, false>), gf, blk, lds_f, (hipStream_t)stream, a, sy, G);
-        return made_check_launch("made_xpool_inbatch");
-    }
     if (x.D == 512) hipLaunchKernelGGL(xpool_inbatch_scores_kernel<512>, g1, blk, lds_s, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(xpool_inbatch_scores_kernel<256>, g1, blk, lds_s, (hipStream_t)stream, a);
     hipLaunchKernelGGL(xpool_inbatch_pv_kernel, g2, blk, lds_p, (hipStream_t)stream, a, (int)x.D);

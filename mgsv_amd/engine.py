@@ -25,7 +25,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .config import MadeConfig
 from .ops import Seg, round_up
 
@@ -218,7 +218,7 @@ class MadeEngine:
         self.P = P
 
     def _side_stream(self):
-        if os.environ.get("MADE_ONE_STREAM", "0") == "1":     # debugging: every branch on the caller's stream, in issue order
+        if _lib.variant_env("MADE_ONE_STREAM", "0") == "1":     # debugging: every branch on the caller's stream, in issue order
             return torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -436,7 +436,7 @@ class MadeEngine:
             # kernel, nothing per pair ever written to HBM (made_xpool_fused); the per-track K / U projections stay GEMMs
             vn = ops.l2norm_rows(video)
             cm = min(Nm, max(1, (2 << 30) // (3 * S * D * tc.itemsize)), 65535)
-            if S <= 96 and os.environ.get("MADE_XPOOL_SIMS", "1") != "0":
+            if S <= 96 and _lib.variant_env("MADE_XPOOL_SIMS", "1") != "0":
                 # round 4: the per-pair Linear moved onto the values.  W'' o = sum_s p_s (W'' u_s), so u''_s = W'' u_s is made once per
                 # segment (one more GEMM over the tracks) and the pair costs a second P.V product (2 S D flops) instead of the Linear (2 D^2):
                 # 2.2x fewer flops per pair at S = 96.  The default for tracks of at most 96 segments (made_xpool_sims: 52.5 ms against
@@ -477,7 +477,7 @@ class MadeEngine:
                                 (P[tower + ".ln3.g"], P[tower + ".ln3.b"]), vn, sims_out[:, m0:m0 + n], scale=1.0 / math.sqrt(D),
                                 ws=xws, prepare_ws=(m0 == 0))
             return sims_out
-        if tc == torch.bfloat16 and D in (256, 512) and S <= 512 and pooled_out is None and Nv >= 256 and os.environ.get("MADE_XPOOL_ATTN", "1") != "0":
+        if tc == torch.bfloat16 and D in (256, 512) and S <= 512 and pooled_out is None and Nv >= 256 and _lib.variant_env("MADE_XPOOL_ATTN", "1") != "0":
             # retrieval scale at the widths / lengths made_xpool_fused does not serve (D = 512, or more than its segments): the attention
             # as ONE two-pass kernel per chunk of tracks (made_xpool_attention: scores of a whole track in LDS, the normalisation of
             # LayerNorm2 in its tail), then the folded Linear and LayerNorm3 + cosine.  Chunks of about 1 GB of per-pair rows per tensor:
@@ -524,7 +524,7 @@ class MadeEngine:
             if hoist:
                 u = ops.linear(ubuf[:n * S], P[tower + ".out.w"], P[tower + ".out.b"], out=ubuf2[:n * S], tile_skip_mask=skip)
             # all videos attend to each track's segments: softmax over segments, scores never leave the chip
-            if tc == torch.bfloat16 and Nv <= 64 and S <= 512 and S * D >= 65536 and D in (256, 512) and os.environ.get("MADE_XPOOL_INBATCH", "1") != "0":
+            if tc == torch.bfloat16 and Nv <= 64 and S <= 512 and S * D >= 65536 and D in (256, 512) and _lib.variant_env("MADE_XPOOL_INBATCH", "1") != "0":
                 # the in-batch shape (round 4): scores per (track, 128 segments), P.V per (track, 128 columns), bf16 probabilities between them
                 if xib_ws is None:
                     xib_ws = torch.zeros(ops.xpool_inbatch_ws_bytes(cm, S), device=dev, dtype=torch.uint8)

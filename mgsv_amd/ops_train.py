@@ -92,7 +92,7 @@ def gemm_tn_grouped(problems, rows=None, alpha: float = 1.0, split_m: Optional[i
         g.row_index, g.n_rows = _p(rows[0]), _p(rows[1])
     import os
     big = (all(pr[0].shape[1] % 256 == 0 and pr[1].shape[1] % 256 == 0 for pr in problems) and 4096 <= M <= 36864
-           and os.environ.get("MADE_TN_TILE", "256") == "256")
+           and _lib.variant_env("MADE_TN_TILE", "256") == "256")
     if big:
         # 256 x 256 tiles, one eight-wave workgroup per CU, the (tile, slab) units dealt out evenly by the kernel itself
         g.tile_size = 256

@@ -23,6 +23,29 @@ from . import _lib
 
 Tensor = torch.Tensor
 _recording: Optional["LaunchTape"] = None
+_deferred: list = []          # (handle, kept tensors) of tapes whose finaliser ran where a synchronize was not allowed (LaunchTape.__del__)
+
+
+def _release_deferred() -> None:
+    """Frees what finalisers parked: behind a device synchronize, and only where one is allowed (no capture, no recording)."""
+    if not _deferred:
+        return
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        if _recording is not None or torch.cuda.is_current_stream_capturing():
+            return
+        torch.cuda.synchronize()
+    while _deferred:
+        handle, keep = _deferred.pop()
+        try:
+            _lib.lib().made_tape_free(handle)
+        except Exception:
+            pass
+        del keep
+
+
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(_release_deferred)
 
 
 class ForeignKernelError(_lib.MadeError):
@@ -151,6 +174,7 @@ class LaunchTape:
         when check is False.  (_every_device: the CPU test of the watcher counts host tensors too.)"""
         global _recording
         assert _recording is None, "tapes do not nest"
+        _release_deferred()
         tape = cls()
         tape.foreign_ops = []
         watcher = _make_watcher(tape.foreign_ops, _every_device)
@@ -189,6 +213,7 @@ class LaunchTape:
             S.wait_stream, S.wait_event, E.record = o_ws, o_we, o_rec
             _recording = None
             _lib.check(lib.made_tape_end(C.byref(tape.handle)), "made_tape_end")
+        _release_deferred()
         if check and tape.foreign_ops:
             import collections
             c = collections.Counter(tape.foreign_ops)
@@ -237,12 +262,20 @@ class LaunchTape:
             _lib.lib().made_tape_free(self.handle)
             self.handle = C.c_uint64(0)
         self._keep = []
+        if _sync:
+            _release_deferred()
 
     def __del__(self):
         # A finaliser can run at any point of the host program -- inside a hipGraph capture or another tape's recording, where a device
-        # synchronize would invalidate the capture: there only the handle is freed (the explicit close() stays the synchronising path).
+        # synchronize would invalidate the capture.  There nothing is freed: the handle and the tensors it keeps alive move to a module-level
+        # list and are released, behind a synchronize, at the next safe point (the next record() entry / exit, an explicit close(), or
+        # interpreter exit) -- the last replay's kernels may still be queued on the tape's streams.
         try:
             busy = _recording is not None or (torch.cuda.is_available() and torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing())
-            self.close(_sync=not busy)
+            if busy and self.handle.value:
+                _deferred.append((self.handle, self._keep))
+                self.handle, self._keep = C.c_uint64(0), []
+            else:
+                self.close(_sync=True)
         except Exception:
             pass

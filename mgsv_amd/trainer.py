@@ -53,7 +53,7 @@ class MadeTrainer(MadeEngine):
         self.training_dropout = True
         # bf16: the flash-attention forward stores its dropout decisions (one bit per score) and the two backward kernels test the bit
         # instead of re-drawing it (made_attention's keep_bits; MADE_ATTN_BITS=0: re-draw, for A/B measurements)
-        self._bits = dtype == "bf16" and os.environ.get("MADE_ATTN_BITS", "1") != "0"
+        self._bits = dtype == "bf16" and _lib.variant_env("MADE_ATTN_BITS", "1") != "0"
 
     # ------------------------------------------------------------------ support matrix
     def _check_train_supported(self):
@@ -400,7 +400,7 @@ class MadeTrainer(MadeEngine):
         step): 5.65 ms in two parts against 5.62 ms in one piece; the temporal encoders' backward is slowed down by as much as the
         optimizer's tail gets shorter (both are bound by memory traffic).  The regression variant has no decoder and another group
         layout: always one piece."""
-        return os.environ.get("MADE_EARLY_OPT", "0") == "1" and "regression" not in self.cfg.mml_localization
+        return _lib.variant_env("MADE_EARLY_OPT", "0") == "1" and "regression" not in self.cfg.mml_localization
 
     def capture_train_step(self, frame_feats, segment_feats, frame_masks, segment_masks, spans_target, *, max_grad_norm: float = 1.0,
                            music_ids=None, v_duration: Optional[Tensor] = None, dist=None, mode: str = "graph") -> "TrainStepGraph":
@@ -719,7 +719,7 @@ class MadeTrainer(MadeEngine):
                 _tape.zero_(self.flat_grad)
                 self._grads_zeroed = True
             if (Q == 1 and not regression and c.moment_query_type != "xpool" and c.detr_enc_layers > 0
-                    and os.environ.get("MADE_DEC_EARLY", "1") != "0"):
+                    and _lib.variant_env("MADE_DEC_EARLY", "1") != "0"):
                 # the query side of decoder layer 0 depends on the clip-level vector and the weights only: here, beside the DETR encoder,
                 # instead of at the head of the decoder's chain of dependent launches (as MadeEngine does for the eval path).
                 # (MADE_DEC_EARLY=0: at the head of the chain.  While the raw barriers of the LDS-DMA GEMM kernels lacked their
@@ -817,7 +817,7 @@ class MadeTrainer(MadeEngine):
             dec_fill_tgt()
         hs = ws["hs"]
         GQ = tw["GQ"]                                        # [B, 2, nd, H*Q, D]: part 1 holds the q' rows of every layer
-        n_split = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))   # few queries, long memory: keys split over workgroups (knob for measurements)
+        n_split = int(_lib.variant_env("MADE_WIDE_NSPLIT", "0")) or max(1, min(8, 256 // max(B, 1)))   # few queries, long memory: keys split over workgroups (knob for measurements)
         t3_stack = tw["dstack"]["tgt"][1:]                   # [nd, B*Q, D]: slot l + 1 = layer l's output (t3)
         for l in range(nd):
             p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
@@ -944,7 +944,7 @@ class MadeTrainer(MadeEngine):
         f32 and Q > 1 always take it."""
         c = self.cfg
         return (self.tc == torch.bfloat16 and c.num_moment_queries == 1 and c.D in (256, 512) and not c.detr_pre_norm
-                and os.environ.get("MADE_DEC_STAGE", "1") != "0")
+                and _lib.variant_env("MADE_DEC_STAGE", "1") != "0")
 
     def _encode_train(self, feats: Tensor, mask: Tensor, which: str, ws, tw, row_off: int) -> None:
         """reference model/model_Base.py:544-617 in train mode (dropout 0.8 inside the temporal block)."""
@@ -1031,7 +1031,7 @@ class MadeTrainer(MadeEngine):
         # 64 videos x 64 tracks: one workgroup per track would leave three quarters of the chip idle on a kernel that streams 1 MB of
         # K / U per track at one CU's rate -- the keys are split over workgroups (up to 256 of them), a second launch merges the slices
         # (tools/xpool_qk_bench.py, profiles/r03_xpool_qk_microbench.txt: 56.8 us unsplit, 34.9 us split four ways)
-        inbatch = (self.tc == torch.bfloat16 and B <= 64 and S <= 512 and S * D >= 65536 and D in (256, 512) and os.environ.get("MADE_XPOOL_INBATCH", "1") != "0")   # (shorter / narrower tracks: one launch of made_attention_wide is faster -- 10.9 vs 12.3 us at S = 96, D = 256)
+        inbatch = (self.tc == torch.bfloat16 and B <= 64 and S <= 512 and S * D >= 65536 and D in (256, 512) and _lib.variant_env("MADE_XPOOL_INBATCH", "1") != "0")   # (shorter / narrower tracks: one launch of made_attention_wide is faster -- 10.9 vs 12.3 us at S = 96, D = 256)
         if inbatch:
             # round 4: scores per (track, 128 segments), then P.V per (track, 128 value columns) -- two launches of one workgroup per CU, only the
             # bf16 probabilities between them (made_xpool_inbatch; profiles/r04_*xpool_qk_microbench.txt)
@@ -1039,7 +1039,7 @@ class MadeTrainer(MadeEngine):
                 tw[pre + "xib_ws"] = torch.zeros(ops.xpool_inbatch_ws_bytes(B, S), device=self.device, dtype=torch.uint8)
             ops.xpool_inbatch(q, tw[pre + "k"].view(B, S, D), tw[pre + "u"].view(B, S, D), seg_mask, tw[pre + "o"].view(B, B, D),
                               scale=1.0 / math.sqrt(D), ws=tw[pre + "xib_ws"])
-        xsplit = int(os.environ.get("MADE_XPOOL_NSPLIT", 0)) or (max(1, min(4, 256 // max(B, 1), S // 64)) if (B <= 64 and self.tc == torch.bfloat16) else 1)
+        xsplit = int(_lib.variant_env("MADE_XPOOL_NSPLIT", "0")) or (max(1, min(4, 256 // max(B, 1), S // 64)) if (B <= 64 and self.tc == torch.bfloat16) else 1)
         if inbatch:
             pass
         elif xsplit > 1:
@@ -1196,11 +1196,11 @@ class MadeTrainer(MadeEngine):
             # MADE_RET_BWD_MAIN=1: on the main stream, in front of the heads and the decoder's chain (tools/race_probe3.py: beside the
             # first decoder layers of the backward chain these launches are what makes one element of a chain product come out one
             # bf16 ulp off in ~15 % of the first steps -- 0 of 60 with them on the main stream or with one stream only)
-            ret_main = os.environ.get("MADE_RET_BWD_MAIN", "0") == "1"
+            ret_main = _lib.variant_env("MADE_RET_BWD_MAIN", "0") == "1"
             # MADE_RET_SPLIT (default 1): the branch's backward is issued in two parts -- up to the X-Pool tower's batched score / dP
             # products now, those and everything behind them on the second stream BEHIND the decoder's chain (see below)
-            ret_split = (os.environ.get("MADE_RET_SPLIT", "1") != "0" and not ret_main and not regression
-                         and os.environ.get("MADE_RET_HANDOFF", "") == "" and os.environ.get("MADE_RET_HANDOFF_REV", "") == "")
+            ret_split = (_lib.variant_env("MADE_RET_SPLIT", "1") != "0" and not ret_main and not regression
+                         and _lib.variant_env("MADE_RET_HANDOFF", "") == "" and _lib.variant_env("MADE_RET_HANDOFF_REV", "") == "")
             with torch.cuda.stream(cur if ret_main else side):
                 self._ret_main_stream = cur
                 try:
@@ -1284,7 +1284,7 @@ class MadeTrainer(MadeEngine):
             if not stage:
                 ops.linear(GQ[0, 1].reshape(nd * HQ, D), mempos3[0], None, M=nd * HQ, N=L, K=D, batch=B, a_z_stride=GQ.stride(0), w_z_stride=L * D,
                            segs=[Seg(out=S_all, ldo=Lp, rows_per_batch=HQ, out_batch_stride=B * HQ * Lp, out_z_stride=HQ * Lp)])
-            n_split_b = int(os.environ.get("MADE_WIDE_NSPLIT", 0)) or max(1, min(8, 256 // max(B, 1)))
+            n_split_b = int(_lib.variant_env("MADE_WIDE_NSPLIT", "0")) or max(1, min(8, 256 // max(B, 1)))
             if stage:
                 # the shared output norm's backward depends on the heads only: all layers in ONE launch ahead of the dependent chain
                 gN = tw["dgN"]
@@ -1292,7 +1292,7 @@ class MadeTrainer(MadeEngine):
             for l in range(nd - 1, -1, -1):
                 p, d = f"detr_transformer.decoder.layers.{l}", f"d.{l}"
                 g1, g2, g4 = tw["dg1"], tw["dg2"], tw["dg4"]
-                if stage and os.environ.get("MADE_CHAIN_BUFS", "1") != "0":
+                if stage and _lib.variant_env("MADE_CHAIN_BUFS", "1") != "0":
                     # every hand-off of the chain gets rows of its own instead of three scratch buffers rewritten and re-read a few launches
                     # apart (MADE_CHAIN_BUFS=0: the shared buffers) -- a leftover of the hunt for the chain's one-ulp deviation, which
                     # turned out to need two launches of the retrieval branch beside the chain (MADE_RET_SPLIT above);
@@ -1446,7 +1446,7 @@ class MadeTrainer(MadeEngine):
             # the [nd, ...] stacks, are equally spaced).  Nothing on the main stream needs them before the optimizer: they go to the
             # second stream (a dozen launches of modest size, ~0.35 ms of kernel time) and run beside the DETR encoder's backward;
             # the join in front of grad_sync below covers them.
-            dw_side = os.environ.get("MADE_DEC_DW_SIDE", "1") != "0"       # (knob for A/B measurements)
+            dw_side = _lib.variant_env("MADE_DEC_DW_SIDE", "1") != "0"       # (knob for A/B measurements)
             if dw_side:
                 side.wait_stream(cur)
             if ret_gen is not None:
@@ -1509,7 +1509,7 @@ class MadeTrainer(MadeEngine):
 
         # ---------------- DETR encoder
         dsrc = dmem
-        enc_dw_side = os.environ.get("MADE_ENC_DW_SIDE", "1") != "0"         # (knob for A/B measurements)
+        enc_dw_side = _lib.variant_env("MADE_ENC_DW_SIDE", "1") != "0"         # (knob for A/B measurements)
         enc_dw_done = [None, None]
         for l in range(ne - 1, -1, -1):
             p, e = f"detr_transformer.encoder.layers.{l}", f"e.{l}"
@@ -1611,7 +1611,7 @@ class MadeTrainer(MadeEngine):
         # (one process: the main stream needs the retrieval branch's results here, not the weight-gradient products queued behind it on
         #  the second stream -- joining the whole stream left it idle behind the last DETR layer's grouped product, 0.2 ms per step;
         #  data-parallel jobs start their first all-reduce below and need every gradient of its range complete)
-        if ret_done is not None and grad_sync is None and os.environ.get("MADE_BWD_EVENT_JOIN", "1") != "0":
+        if ret_done is not None and grad_sync is None and _lib.variant_env("MADE_BWD_EVENT_JOIN", "1") != "0":
             cur.wait_event(ret_done)
         else:
             cur.wait_stream(side)
@@ -1645,7 +1645,7 @@ class MadeTrainer(MadeEngine):
             self._encode_bwd("video", ws, tw, dl_v, dxv.view(B, Tv, D) if dxv is not None else None, dvideo, fm, feats_v)
         # (the audio tower's weight-gradient products have nobody waiting on the main stream either: second stream, behind the video tower)
         self._encode_bwd("audio", ws, tw, dl_a, tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a,
-                         dw_stream=side if os.environ.get("MADE_AUDIO_DW_SIDE", "1") != "0" else None)
+                         dw_stream=side if _lib.variant_env("MADE_AUDIO_DW_SIDE", "1") != "0" else None)
         cur.wait_stream(side)
         if opt_st is not None:
             cur.wait_stream(opt_st)
@@ -1759,11 +1759,11 @@ class MadeTrainer(MadeEngine):
         if getattr(self, "_ret_main_stream", None) is None:
             return
         main = self._ret_main_stream
-        if os.environ.get("MADE_RET_HANDOFF", "") == str(i) and torch.cuda.current_stream() != main:
+        if _lib.variant_env("MADE_RET_HANDOFF", "") == str(i) and torch.cuda.current_stream() != main:
             main.wait_stream(torch.cuda.current_stream())
             torch.cuda.set_stream(main)
         # MADE_RET_HANDOFF_REV=i: the other way round -- the launches in front of checkpoint i on the main stream, the rest on the second
-        rev = os.environ.get("MADE_RET_HANDOFF_REV", "")
+        rev = _lib.variant_env("MADE_RET_HANDOFF_REV", "")
         if rev != "":
             side = self._side_stream()
             if i == 0 and int(rev) > 0 and torch.cuda.current_stream() != main:
@@ -2100,7 +2100,7 @@ class TrainStepGraph:
                         self.out = fwd_bwd(); opt()
                     torch.cuda.synchronize()
                     self.tape = tp
-                    tw_ = int(os.environ.get("MADE_TAPE_INTERLEAVE", "2"))   # 0: replay in program order (knob for A/B measurements)
+                    tw_ = int(_lib.variant_env("MADE_TAPE_INTERLEAVE", "2"))   # 0: replay in program order (knob for A/B measurements)
                     if tw_ > 0:
                         tp.interleave(tw_)
                 finally:

@@ -15,11 +15,11 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True                              # (before anything of the reference is imported: no __pycache__ in its tree)
 
 from oracle import ref_import  # noqa: E402
 
-ref_import.import_reference()
+ref_import.import_reference()                               # (puts the reference root on sys.path)
 if "torch.utils.tensorboard" not in sys.modules:            # the drivers import SummaryWriter at module level; not installed here
     tb = types.ModuleType("torch.utils.tensorboard")
     tb.SummaryWriter = object
@@ -45,7 +45,7 @@ for script in ("train-MaDe.py", "test-MaDe.py"):
 
     argparse.ArgumentParser.parse_args = fake
     try:
-        spec = importlib.util.spec_from_file_location("ref_" + script[:4], os.path.join("/root/reference", script))
+        spec = importlib.util.spec_from_file_location("ref_" + script[:4], os.path.join(ref_import.REFERENCE_ROOT, script))
         mod = importlib.util.module_from_spec(spec)
         try:
             spec.loader.exec_module(mod)

@@ -27,6 +27,29 @@ def test_bench_gpus2_self_launch_rendezvous_dry_run():
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["rank_sum"] == 3.0 and d["master_addr"] == "127.0.0.1"
 
 
+def _one_line(r):
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus8_dry_run_every_workload_partitions_over_eight_ranks():
+    """The 8-GPU day (SCALE run: `python bench.py --gpus 8 ...`) must not die on plumbing: eight ranks rendezvous over gloo, and each workload's
+    partition runs on the host -- retrieval: videos row-sharded (ragged: 8 does not divide the stand-in sizes), the music side through the
+    production packed all-gather (mgsv_amd/retrieval.py); train: the gradient buffer all-reduced in the trainer's two buckets."""
+    for wl in ("retrieval", "train", "all"):
+        d = _one_line(_run({"MADE_BENCH_FAKE_GPUS": "8", "MADE_BENCH_DRY_RUN": "1"}, "--gpus", "8", "--steps", "1", "--warmup", "0", "--workload", wl,
+                           timeout=600))
+        assert d["dry_run"] is True and d["n_gpus"] == 8 and d["rank_sum"] == 36.0 and d["workload"] == wl
+        if wl in ("retrieval", "all"):
+            p = d["plan"]["retrieval"]
+            assert p["video_rows_all_ranks"] == p["n_v"] and p["music_tracks_gathered"] == p["n_m"] == 301
+        if wl in ("train", "all"):
+            p = d["plan"]["train"]
+            assert p["grad_sum"] == p["expected"] == 36.0 and sum(p["bucket_elems"]) == 1007
+
+
 def test_bench_gpus2_children_reach_the_gpu_assertion_and_the_parent_reports_it():
     r = _run({"MADE_BENCH_FAKE_GPUS": "2", "CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""}, "--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0

@@ -107,7 +107,7 @@ def test_backward_chain_of_the_recorded_step_is_bit_reproducible_with_the_retrie
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["xpool_inbatch", "xpool_inbatch_one_launch", "xpool_attention", "xpool_fused", "xpool_sims", "xpool_sims_pq64"])
+@pytest.mark.parametrize("which", ["xpool_inbatch", "xpool_attention", "xpool_fused", "xpool_sims", "xpool_sims_pq64"])
 def test_retrieval_kernels_bit_identical_beside_small_workgroups(which, monkeypatch):
     """The retrieval kernels hand LDS reads to inline assembly (transposing reads, counted waits).  A register that such a read has been given is an
     ordinary value to the compiler: if it copies it before the data has arrived the kernel is right alone on the chip and wrong beside another
@@ -147,9 +147,6 @@ def test_retrieval_kernels_bit_identical_beside_small_workgroups(which, monkeypa
         run = lambda o: ops.xpool_attention(q, k, u, mask, o, scale=1 / math.sqrt(D))
     else:
         shape, odt = (Nm, Nv, D), dt
-        # (one_launch: round 5's form whose workgroups wait for each other inside the launch -- beside other kernels' workgroups some of a
-        #  track's four become resident later than the others; the counters at the workspace's end must be back at zero and no poll may time out)
-        monkeypatch.setenv("MADE_XPOOL_INBATCH_FUSED", "1" if which.endswith("one_launch") else "0")
         ws = torch.zeros(ops.xpool_inbatch_ws_bytes(Nm, S), device=dev, dtype=torch.uint8)
         run = lambda o: ops.xpool_inbatch(q, k, u, mask, o, scale=1 / math.sqrt(D), ws=ws)
     solo = torch.empty(shape, device=dev, dtype=odt)
@@ -165,14 +162,3 @@ def test_retrieval_kernels_bit_identical_beside_small_workgroups(which, monkeypa
     torch.cuda.synchronize()
     differing = sum(0 if torch.equal(o.view(torch.int32 if odt == torch.float32 else torch.int16), solo.view(torch.int32 if odt == torch.float32 else torch.int16)) else 1 for o in outs)
     assert differing == 0, f"{which}: {differing} of 60 launches differ from the solo run"
-    if which.endswith("one_launch"):
-        # ... and beside launches that fill every CU (the chip's workgroup slots free up a few at a time)
-        Ab, Wb = torch.randn(32768, 512, device=dev, generator=g).to(dt), torch.randn(512, 512, device=dev, generator=g).to(dt)
-        for o in outs:
-            with torch.cuda.stream(side):
-                ops.linear(Ab, Wb)
-            run(o)
-        torch.cuda.synchronize()
-        assert all(torch.equal(o.view(torch.int16), solo.view(torch.int16)) for o in outs)
-        tail = ws[-(((Nm * 8 + 15) // 16) * 16 + 16):].view(torch.int32)
-        assert int(tail.abs().sum()) == 0, "counters back at zero, no poll timed out"

@@ -77,25 +77,3 @@ def test_matcher_cost_has_no_fma_contraction():
         assert any(w.startswith(("v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_rcp_f32")) for w in window), ins[max(0, k - 3):k + 3]
     n_div = sum(1 for i in ins if i.startswith("v_div_fixup_f32"))
     assert n_div == 3 and len(fma32) <= 7 * n_div, (n_div, len(fma32))   # the two GIoU quotients and 1 / (e0 + e1)
-
-
-def test_one_launch_inbatch_kernel_exchanges_through_agent_scope_accesses_only():
-    """xpool_inbatch_fused_kernel (csrc/xpool_inbatch.hip, opt-in) hands the probability tiles and the (reference, sum) pairs from one workgroup to
-    the track's others INSIDE the launch, without a fence: that is right only while every exchanged word is written and read with sc1 (agent scope)
-    and the sign-in / poll are agent-scope atomics.  Also: both words of a pair are loaded (this clang narrows __builtin_amdgcn_raw_buffer_load_b64
-    to its first word), and no acquire / release fence (buffer_wbl2 / buffer_inv: a write-back and an invalidate of a whole L2) crept in."""
-    text = _isa("xpool_inbatch.hip")
-    ks = {n: i for n, i in _kernels(text, r"xpool_inbatch_fused_kernel").items() if "ELb0E" in n}
-    assert len(ks) == 2, list(ks)                               # D = 512 and D = 256, without stamps
-    for name, ins in ks.items():
-        bl = [i for i in ins if i.startswith("buffer_load")]
-        bs = [i for i in ins if i.startswith("buffer_store")]
-        assert bl and bs, name
-        assert all(re.search(r"\bsc1\b", i) for i in bl + bs), (name, [i for i in bl + bs if "sc1" not in i][:3])
-        assert sum(1 for i in bl if i.startswith("buffer_load_dwordx4")) == 32, name          # 16 tiles x two 16-byte halves of a lane's fragment
-        pair_words = sum(1 for i in bl if i.startswith("buffer_load_dword ")) + 2 * sum(1 for i in bl if i.startswith("buffer_load_dwordx2"))
-        assert pair_words == 32, (name, pair_words)                                              # 16 tiles x (reference, sum): BOTH words are fetched
-        assert not [i for i in ins if i.startswith(("buffer_wbl2", "buffer_inv"))], name
-        assert sum(1 for i in ins if i.startswith("global_atomic_add")) >= 2, name            # sign in, sign out
-    meta = re.findall(r"\.name:\s+(\S*xpool_inbatch_fused_kernel\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)
-    assert meta and all(int(b) == 0 for _, b in meta), meta

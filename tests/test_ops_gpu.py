@@ -427,16 +427,12 @@ def test_attention_wide(dev, mode, B, NQ1, NQ2, L, D, shared, kadd, alias):
 @pytest.mark.gpu
 @pytest.mark.parametrize("Nv,Nm,S,D", [(64, 64, 512, 512), (64, 5, 96, 256), (37, 7, 130, 512), (1, 3, 33, 256), (50, 4, 512, 256), (64, 6, 400, 512)])
 @pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("fused", [0, 1])
-def test_xpool_inbatch_two_launches(dev, Nv, Nm, S, D, odt, fused, monkeypatch):
-    """fused = 1: the one-launch form (MADE_XPOOL_INBATCH_FUSED=1; both roles in one workgroup, the tiles exchanged inside the launch): same
-    checks, and bit-identical to the two launches (the same instructions on the same words).
-    made_xpool_inbatch (reference modules/transformer.py:110-119 for a batch of videos x a batch of tracks, one head of width D; the
+def test_xpool_inbatch_two_launches(dev, Nv, Nm, S, D, odt):
+    """made_xpool_inbatch (reference modules/transformer.py:110-119 for a batch of videos x a batch of tracks, one head of width D; the
     north-star contraction): scores per (track, 128 segments) then P.V per (track, 128 columns), against a plain f32 softmax attention on
     the bf16-rounded operands and against made_attention_wide on the same call.  Prefix masks of every length class, a mask with holes, rows
     behind the last valid segment holding NaN, a late score spike, fewer than 64 videos, strided K / U (the two halves of one kv buffer)."""
     tdt = torch.bfloat16
-    monkeypatch.setenv("MADE_XPOOL_INBATCH_FUSED", str(fused))
     q = rnd(Nv, D, seed=1)
     kv = rnd(Nm, S, 2 * D, seed=2)
     lens = torch.tensor([max(1, S - (37 * i) % S) for i in range(Nm)])
@@ -461,19 +457,13 @@ def test_xpool_inbatch_two_launches(dev, Nv, Nm, S, D, odt, fused, monkeypatch):
     torch.cuda.synchronize()
     got = out.float().cpu()
     assert bool(torch.isfinite(got).all())
-    if fused:
-        tail = ws[-(((Nm * 8 + 15) // 16) * 16 + 16):].view(torch.int32)
-        assert int(tail.abs().sum()) == 0, "the counters are back at zero and no poll timed out"
-        monkeypatch.setenv("MADE_XPOOL_INBATCH_FUSED", "0")
-        o2l = torch.empty_like(out)
-        ops.xpool_inbatch(q.to(dev).to(tdt), kvg[..., :D], kvg[..., D:], mask.to(dev), o2l, scale=scale)
+    # a workspace sized for a larger call serves a smaller one (engine.py's last chunk of tracks, the trainer's smaller batch)
+    if Nm > 2:
+        n2 = Nm - 2
+        o2 = torch.full((n2, Nv, D), float("nan"), device=dev, dtype=odt)
+        ops.xpool_inbatch(q.to(dev).to(tdt), kvg[:n2, :, :D], kvg[:n2, :, D:], mask[:n2].to(dev), o2, scale=scale, ws=ws)
         torch.cuda.synchronize()
-        monkeypatch.setenv("MADE_XPOOL_INBATCH_FUSED", "1")
-        assert torch.equal(o2l, out), "one launch == two launches, bit for bit"
-        for _ in range(20):                                                  # the same workspace again and again (counters reset in the launch)
-            ops.xpool_inbatch(q.to(dev).to(tdt), kvg[..., :D], kvg[..., D:], mask.to(dev), o2l, scale=scale, ws=ws)
-        torch.cuda.synchronize()
-        assert torch.equal(o2l, out) and int(tail.abs().sum()) == 0
+        assert torch.equal(o2, out[:n2])
     err = float((got - ref).abs().max())
     assert err <= BF16_TOL, err
     assert float((got - ref).abs().mean()) <= BF16_TOL / 8

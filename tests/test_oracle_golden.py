@@ -281,3 +281,16 @@ def test_oracle_train_variants_match_reference_fixture(golden_dir, tag):
     assert (len(bufs) == 8) == (tag == "mlp")
     for k in bufs:
         assert np.abs(r["buffer_updates"][k[len(tag) + 8:]].numpy() - fix[k]).max() < 1e-9, k
+
+
+def test_the_reference_tree_holds_no_bytecode():
+    """Every script that imports the reference goes through oracle/ref_import.import_reference(), which sets sys.dont_write_bytecode first
+    (SURVEY.md section 8(c) step 1): an ad-hoc `import` from /root/reference drops __pycache__ into a tree this repository must not write to.
+    Runs where the reference exists (the build container); nothing to check on the GPU box."""
+    import os
+    from oracle import ref_import
+    if not ref_import.reference_available():
+        pytest.skip("no reference tree here")
+    found = [os.path.join(d, n) for d, sub, files in os.walk(ref_import.REFERENCE_ROOT) for n in list(sub) + files
+             if n == "__pycache__" or n.endswith(".pyc")]
+    assert not found, f"bytecode under the reference tree (import it through oracle/ref_import.import_reference()): {found[:5]}"

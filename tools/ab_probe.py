@@ -1,6 +1,7 @@
 """A/B of an environment knob on the eager training step inside ONE process (alternating, so box-to-box and warm-up differences cancel):
    python tools/ab_probe.py MADE_DEC_DW_SIDE 0 1"""
 import sys, os, time
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mgsv_amd import synth

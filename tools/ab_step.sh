@@ -1,4 +1,5 @@
 # A/B of the training step over environment knobs on ONE box: bash tools/ab_step.sh <tag> "K1=V1" "K2=V2 K3=V3" ...  (first the default, then each setting, twice over)
+export MADE_DEBUG_VARIANTS=1          # (measurement knobs are honoured only under this switch)
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
 run() { env $2 timeout 200 python bench.py --workload train --no-cpu-baseline --steps 40 > $O/$1.json 2>$O/$1.err; python - <<PY

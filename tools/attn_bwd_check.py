@@ -2,6 +2,7 @@
 both forms at the step's shapes (GPU box):  python tools/attn_bwd_check.py [check|time|all]
 The split form is selected per process with MADE_ATTN_BWD=split, so the script runs itself twice for the comparison."""
 import os, sys, subprocess, json
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 

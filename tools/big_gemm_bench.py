@@ -1,6 +1,7 @@
 """made_linear on large regular problems and on the step's encoder-sized ones: the single-stage LDS-DMA kernels (MADE_LINEAR_TILE=64 / 128)
 against the persistent big-tile kernel (256 = 128 x 256 tiles, 512 = 256 x 256 tiles).  HIP events around back-to-back launches."""
 import math, os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mgsv_amd import ops

@@ -5,6 +5,7 @@
 #   dec_packed_nopk  the same with the packed-fp32-ops target feature off: SLP on, no packed instructions -- stable again
 #   dec_packed_o1 / dec_packed_forcezero / dec_packed_shfl: -O1 (no SLP: stable), every s_waitcnt forced to zero (still moves), the row sums
 #                    through ds_bpermute instead of DPP (still moves)
+export MADE_DEBUG_VARIANTS=1          # (measurement knobs are honoured only under this switch)
 set -e
 cd "$(dirname "$0")/.."
 make -C mgsv_amd/csrc -j8 > /dev/null

@@ -12,6 +12,7 @@ branch ran on the second stream beside the chain.)
 
 usage: python tools/dec_corun_probe.py micro|step [N]"""
 import math, os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mgsv_amd import ops, ops_train as tr, _lib

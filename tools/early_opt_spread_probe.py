@@ -1,6 +1,7 @@
 """How far two runs of six training steps differ (f32 atomic weight-gradient sums: arrival order), per schedule -- the measurement behind the
 fixed bounds of tests/test_trainer_gpu.py::test_train_step_with_the_early_optimizer_part_tracks_the_one_piece_step (GPU box)."""
 import os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch

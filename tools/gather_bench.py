@@ -1,6 +1,7 @@
 """Micro-benchmark of made_linear with the row gather at the DETR-encoder shapes (GPU box): M = 64 x 542 rows of which the
 valid ones (lengths as bench.py draws them) are computed.  MADE_LINEAR_TILE=64|128 forces the tile height."""
 import math, os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mgsv_amd import ops

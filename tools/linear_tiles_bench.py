@@ -1,6 +1,7 @@
 """Encoder-sized Linears for rocprofv3 --kernel-trace: run once as is (256 x 256 tiles) and once with MADE_LINEAR_TILE=64 / 128
 (the smaller direct-to-LDS tiles) and compare the per-launch durations (tools/linear_tiles_trace.sh)."""
 import math, os, sys, torch
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mgsv_amd import ops
 dev = torch.device("cuda"); dt = torch.bfloat16

@@ -1,3 +1,4 @@
+export MADE_DEBUG_VARIANTS=1          # (measurement knobs are honoured only under this switch)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/lintiles; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/wa; rocprofv3 --kernel-trace --output-format csv -d /tmp/wa -- python3 $R/tools/linear_tiles_bench.py > /dev/null 2>&1
 echo "default dispatch"; python3 - <<'PY'

@@ -1,6 +1,7 @@
 """made_layernorm_bwd at the DETR-encoder shape (34688 token rows, 54 % valid, D = 512, bf16) for rocprofv3 --kernel-trace;
 MADE_LNBWD_NB caps the grid (the per-column gradient flush is one atomic per workgroup and column)."""
 import os, sys, torch
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mgsv_amd import ops_train as tr
 dev = "cuda"

@@ -2,6 +2,7 @@
 layers are found by their memory-space attention launches, and those ranges alone are replayed in a loop -- the same kernels, arguments
 and buffers as inside the step, without the rest of the step around them.  usage: python tools/phase_replay.py"""
 import os, sys, time
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 os.environ["MADE_TAPE_INTERLEAVE"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

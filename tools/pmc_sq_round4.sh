@@ -1,5 +1,6 @@
 # SQ counters (MFMA busy, VALU busy, waits, LDS bank conflicts, instruction mix) of the step's flash-attention kernels and of made_xpool_fused,
 # one --pmc pass per counter group (rocprofv3 --pmc only: no trace domains beside it).  usage: bash tools/pmc_sq_round4.sh <tag>
+export MADE_DEBUG_VARIANTS=1          # (measurement knobs are honoured only under this switch)
 TAG=${1:-r04_a}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 GROUPS_=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE")

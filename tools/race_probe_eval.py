@@ -4,6 +4,7 @@ buffer that differs, its damaged 1-KB blocks and where else those bytes exist.  
 before the LDS-DMA kernels' raw barriers got their lgkmcnt(0), MADE_LINEAR_TILE=2128 (the ring kernel) showed 0.5-0.8 % replays with
 garbage rows when two engines are in flight."""
 import os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mgsv_amd import synth

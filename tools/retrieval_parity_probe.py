@@ -4,6 +4,7 @@ hard set (near-duplicate tracks, margins below 1e-2), a sampled check at 53 000 
     python tools/retrieval_parity_probe.py [quick]
 The numbers this prints are what the tests' bounds are derived from (2x the measured maximum)."""
 import os, sys, time
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from mgsv_amd import synth

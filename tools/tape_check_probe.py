@@ -1,6 +1,7 @@
 """Which framework (ATen) operators touch device tensors inside the recorded training step of a configuration?  (mgsv_amd/tape.py: the
 recorder's watcher; TrainStepGraph(mode='tape') refuses a step that has any.)  usage: python tools/tape_check_probe.py [headline|native]"""
 import collections, os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 os.environ["MADE_TAPE_CHECK"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

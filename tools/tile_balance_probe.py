@@ -2,6 +2,7 @@
 give the 128 x 256-tile kernel exactly 1 / 2 rounds of 256 workgroups (M = 16384 / 32768) and 1.09 / 2.1 rounds (M = 17920 / 34688), each
 kernel forced with MADE_LINEAR_TILE; arms interleaved per round, median of 7."""
 import math, os, statistics, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mgsv_amd import ops

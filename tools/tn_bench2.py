@@ -1,6 +1,7 @@
 """made_gemm_tn (direct-to-LDS kernel) under graph replay: with / without the fused bias gradient, with / without the row gather,
 single launches against the grouped launch of one layer's five products.  Shows where the weight-gradient time goes."""
 import sys, os
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mgsv_amd import ops, ops_train as tr

@@ -1,6 +1,7 @@
 """made_xpool_attention alone and the whole D = 512 retrieval pass (bench.py's S512_D512 problem): per-launch times (HIP events) and the
 executed TFLOP/s; MADE_XPOOL_ATTN=0 gives the separate-launch chain.  usage: python tools/xattn_bench.py [Nv Nm S D]"""
 import math, os, sys, time
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mgsv_amd import ops

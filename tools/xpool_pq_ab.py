@@ -1,6 +1,7 @@
 """made_xpool_sims: the 64-video kernel (MADE_XPOOL_SIMS_PQ=64) against the 32-video kernel (the default) on the retrieval set, alternating, plus
 their difference.  python tools/xpool_pq_ab.py [Nv Nm S]   (ARMS=64,648,... : other values of the knob the library knows)"""
 import math, os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mgsv_amd import ops

@@ -53,13 +53,10 @@ def run_inbatch(Nv, Nm, S, D):
     for name, mask in (("full-length tracks", None), ("ragged tracks (12..S segments)", (torch.arange(S, device=dev)[None] < lens[:, None]).float())):
         frac = 1.0 if mask is None else float(mask.mean())
         byts = 2.0 * Nm * S * D * 2 * frac + Nv * D * 2 + Nm * Nv * D * 2
-        for fused in ("0", "1"):
-            os.environ["MADE_XPOOL_INBATCH_FUSED"] = fused
-            t = timeit(lambda: ops.xpool_inbatch(q, k, u, mask, o, scale=1 / math.sqrt(D), ws=ws))
-            os.environ.pop("MADE_XPOOL_INBATCH_FUSED")
-            print(    f"  Nv={Nv} Nm={Nm} S={S} D={D} {name:32s} made_xpool_inbatch ({'1 launch  ' if fused == '1' else '2 launches'}): "
+        t = timeit(lambda: ops.xpool_inbatch(q, k, u, mask, o, scale=1 / math.sqrt(D), ws=ws))
+        print(    f"  Nv={Nv} Nm={Nm} S={S} D={D} {name:32s} made_xpool_inbatch (2 launches): "
                   f"{t:8.1f} us  {byts / t / 1e3:7.1f} GB/s ({byts / t / 1e3 / 8000 * 100:4.1f}% of HBM peak)  "
-                  f"{flops * frac / t / 1e6:7.1f} TFLOP/s ({flops * frac / t / 1e6 / 2500 * 100:4.1f}% of bf16 MFMA peak)", flush=True)
+              f"{flops * frac / t / 1e6:7.1f} TFLOP/s ({flops * frac / t / 1e6 / 2500 * 100:4.1f}% of bf16 MFMA peak)", flush=True)
 
 
 print("in-batch X-Pool attention core, the shape north_star names:")

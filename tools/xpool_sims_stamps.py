@@ -1,6 +1,7 @@
 """In-kernel cycle stamps of made_xpool_sims' short-track kernel (MADE_XPOOL_DBG=32 build): phases of workgroup (0, 0), per wave, averaged over
 tracks 8..31 of its chunk.  python tools/xpool_sims_stamps.py [S_fixed]   (S_fixed: every track that long; default: lengths U{12..96})"""
 import math, os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 K64 = os.environ.get("PQ", "64") == "64"                        # PQ=32: round 4's 32-video kernel
 K32 = True
 os.environ["MADE_XPOOL_DBG"] = "64" if K64 else "32"

@@ -1,6 +1,7 @@
 """Phase stamps of made_xpool_fused's persistent kernel (MADE_XPOOL_DBG=33: workgroup (0,0) writes s_memtime at its phase boundaries
 into the sims buffer): per wave and iteration, cycles between consecutive stamps."""
 import math, os, sys
+os.environ.setdefault("MADE_DEBUG_VARIANTS", "1")          # (measurement knobs are honoured only under this switch)
 os.environ["MADE_XPOOL_DBG"] = "33"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
