@@ -17,6 +17,9 @@
 //     this one) and a V phase (the per-score arithmetic of this tile), a barrier behind each.  Waves 0..3 and waves 4..7 (the two waves
 //     of every SIMD) run half a step apart, so that a SIMD always has one wave on the matrix pipe and one on the vector pipe; with all
 //     eight in the same phase (the first form of this kernel) a step took 5 000 cycles, every phase's latency in line.
+// (Measured and dropped, round 6: the chunks of a pair as SEPARATE workgroups handing their dK / dV rows on through sc1 stores and a counter
+// per key block -- a long sample no longer sets the launch's duration, but every workgroup pays the prologue and every key block its round
+// trips again: 196 against 178 us ragged, 600 against 380 us dense.  docs/EXPERIMENTS.md.)
 // The f32 dQ image bounds the queries per sweep (8 KB per query tile); longer samples are swept in chunks of query tiles, and the
 // dK / dV of the second and later chunks are added to the rows the first one stored (bf16: one extra rounding, only on those samples).
 //
@@ -102,6 +105,8 @@ __host__ __device__ inline FusedLayout fused_layout(int qc, int lqp, int lkp) {
     return L;
 }
 
+// DROP: dropout on the attention weights, its decisions read from the forward's bit cache (BITS: always with DROP -- re-drawing the mask per
+// score costs registers this kernel does not have; without the cache the caller uses the split kernels)
 template <bool DROP, bool BITS>
 __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwdArgs a, const uint32_t* __restrict__ kbits, const int qc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -252,9 +257,6 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
     const int skx = ((i16 >> 3) & 1) | ((g16 & 1) << 1);                                    // K image swizzle of the rows this lane addresses
     const unsigned char* ka0 = img_k + (8 * g16 + (i16 >> 2)) * KP + ((hs ^ skx) * 32) + (i16 & 3) * 8;
     const unsigned char* sb0 = ds_x + (8 * g16 + (i16 >> 2)) * DSP + (((qh * 16 + 4 * (i16 & 3)) ^ ((g16 & 1) << 4)) * 2);
-    // hashing path (no bit cache)
-    const uint32_t thr = DROP ? made_drop_threshold(a.drop.p) : 0u;
-    const uint64_t drop_seed = DROP ? made_drop_seed(a.drop) : 0;
 
     // dQ^T piece [16 head-dim columns x 16 queries] of a tile += K^T dS^T over the block's 256 keys (exchange buffer xb)
     auto dq_phase = [&](int tile_in_chunk, int xb) __attribute__((always_inline)) {
@@ -429,16 +431,6 @@ __global__ __launch_bounds__(FT, 2) void attn_bwd_fused_kernel(const MadeAttnBwd
                         const uint64_t* mp = (const uint64_t*)(kbits + ((bh * nkt_all + kt) * a.ld_bits + (q0_next < lqp ? q0_next : lqp - 32)));
 #pragma unroll
                         for (int e = 0; e < 16; ++e) km[e] = mp[e];
-                    } else if constexpr (DROP) {
-                        const uint64_t qbase = (uint64_t)(bh * a.Lq + q0) * (uint64_t)a.Lk + (uint64_t)keyc;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c2, nlq[e >> 2][e & 3]));
-                            const float pc = p * dsc;
-                            const bool keep = (made_rng_mix(drop_seed, a.drop.site, qbase + (uint64_t)acc_row(e, hh) * (uint64_t)a.Lk) >> 8) >= thr;
-                            sc[e] = keep ? pc : 0.f;
-                            dp[e] = pc * (keep ? dp[e] : ndq[e >> 2][e & 3]);
-                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
@@ -555,17 +547,17 @@ constexpr int FUSED_LDS_MAX = 160 * 1024;
 int made_attention_bwd_fused_try(const MadeAttnBwdArgs& a, hipStream_t st) {
     if (a.dtype != MADE_BF16 || a.hd != FHD) return -1000;
     if (a.Lq > 2048 || a.Lk > 2048) return -1000;
+    const bool drop = a.drop.p > 0.f, bits = drop && a.keep_bits != nullptr;
+    if (drop && !bits) return -1000;                       // (no bit cache: the split kernels re-draw the mask)
     const int lqp = (int)((a.Lq + 31) / 32) * 32, lkp = (int)((a.Lk + 31) / 32) * 32;
     const int fixed = fused_layout(0, lqp, lkp).total;
     int qc = (FUSED_LDS_MAX - fixed) / DQ_TILE_BYTES;
-    if (qc > lqp / 32) qc = lqp / 32;
-    if (qc < 4 && qc < lqp / 32) return -1000;
+    if (qc > lqp / 32 + 1) qc = lqp / 32 + 1;              // (+ 1: a sweep is padded to an even number of tiles)
+    if (qc < 4) return -1000;
     const size_t lds = (size_t)fused_layout(qc, lqp, lkp).total;
-    const bool drop = a.drop.p > 0.f, bits = drop && a.keep_bits != nullptr;
-    void (*fn)(const MadeAttnBwdArgs, const uint32_t*, const int) =
-        !drop ? attn_bwd_fused_kernel<false, false> : (bits ? attn_bwd_fused_kernel<true, true> : attn_bwd_fused_kernel<true, false>);
-    static bool attr_done[3] = {false, false, false};
-    const int vi = !drop ? 0 : (bits ? 1 : 2);
+    void (*fn)(const MadeAttnBwdArgs, const uint32_t*, const int) = !drop ? attn_bwd_fused_kernel<false, false> : attn_bwd_fused_kernel<true, true>;
+    static bool attr_done[2] = {false, false};
+    const int vi = !drop ? 0 : 1;
     if (!attr_done[vi]) {
         if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_MAX) != hipSuccess) {
             (void)hipGetLastError();

@@ -304,12 +304,20 @@ def test_attention_forward_dropout_lse_and_backward(T, dtype, tol, B, H, hd, Lq,
         defined = (key_mask[:, None, None, :] * valid_q[:, None, :, :]).bool().expand_as(keep)
         assert torch.equal(got_bits[defined], keep[defined])
         if dtype == torch.bfloat16:
+            # ... and a backward that reads the cache gives the gradients of the one that re-draws the mask: bit for bit where both run the split
+            # kernels (head dims 32 / 128), within bf16 rounding where the cache selects the single-pass kernel (head dim 64: one recomputation
+            # of the probabilities for dQ, dK and dV; other summation order)
             dqkv2 = torch.full_like(dqkv, float("nan"))
             tr.attention_bwd(q, k, v, O, dO, dqkv2[:, :Lq, :D], dqkv2[:, :Lk, D:2 * D], dqkv2[:, :Lk, 2 * D:], lse, delta, H, key_mask=key_mask,
                              q_skip_mask=q_skip, drop=(seed, site, p), keep_bits=bits)
             torch.cuda.synchronize()
-            for a_, b_ in ((dqkv2[:, :Lq, :D], dq), (dqkv2[:, :Lk, D:2 * D], dk), (dqkv2[:, :Lk, 2 * D:], dv)):
-                assert torch.equal(a_.view(torch.int16), b_.view(torch.int16))
+            for a_, b_, ref in ((dqkv2[:, :Lq, :D], dq, qf.grad), (dqkv2[:, :Lk, D:2 * D], dk, kf.grad), (dqkv2[:, :Lk, 2 * D:], dv, vf.grad)):
+                if hd == 64:
+                    assert torch.isfinite(a_.float()).all()
+                    err = float((a_.float() - ref).abs().max())
+                    assert err <= tol * max(float(ref.abs().max()), 0.05 * gscale) * 2, err
+                else:
+                    assert torch.equal(a_.contiguous().view(torch.int16), b_.contiguous().view(torch.int16))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])

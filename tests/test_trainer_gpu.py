@@ -43,10 +43,7 @@ _RATIOS = []
 BF16_NORM_RATIO_DROPOUT, BF16_NORM_RATIO_PLAIN = 0.09, 0.06    # 2 x the measured worst case over the ten configurations (0.0435 / 0.0299)
 
 
-def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None, norm_ratio_tol=0.5, flip_frac=0.0, flip_tol=0.0):
-    """flip_frac > 0: a ReLU whose input lies within the forward's rounding of zero may take the other side, which moves ONE row / column of the
-    layer's weight gradients by O(1): the relative error is then taken over the tensor WITHOUT its flip_frac largest deviations (bound rel_tol),
-    and over the whole tensor against the loose flip_tol -- a wrong kernel fails both, a flipped unit only the first without the exclusion."""
+def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None, norm_ratio_tol=0.5):
     assert abs(res["retrieval_loss"] - float(r["retrieval_loss"])) <= loss_tol * max(1.0, abs(float(r["retrieval_loss"])))
     assert abs(res["localization_loss"] - float(r["localization_loss"])) <= loss_tol * max(1.0, abs(float(r["localization_loss"])))
     gmax = max(float(g.abs().max()) for g in grads.values())
@@ -71,12 +68,6 @@ def _compare(res, r, grads, rel_tol, loss_tol, cos_min=None, norm_ratio_tol=0.5,
             assert abs(ratio - 1) <= norm_ratio_tol, (n, ratio)
         else:
             rel = float(np.linalg.norm(got - ref) / nr)
-            if flip_frac > 0 and rel > rel_tol:
-                assert rel <= flip_tol, (n, rel)
-                d = np.abs(got - ref)
-                k = max(1, int(np.ceil(flip_frac * d.size)))
-                keep = np.argsort(d)[:-k]
-                rel = float(np.linalg.norm(d[keep]) / nr)
             worst.append((rel, n))
             assert rel <= rel_tol, (n, rel)
     return sorted(worst)[-3:]
@@ -110,24 +101,24 @@ _MLP = {"agg_module": "mlp", "video_transformer_depth": 0, "audio_transformer_de
                                        {"detr_pre_norm": True}, {"detr_pre_norm": True, "num_moment_queries": 3, "mml_fusion": "CA"},
                                        {"detr_pre_norm": True, "moment_query_type": "xpool", "_shape": (5, 33, 67)},
                                        {"detr_pre_norm": True, "mml_localization": "regression"}, {"detr_pre_norm": True, "detr_enc_layers": 0, "mml_fusion": "CA"},
-                                       # (with the default dropout seed one ReLU input of decoder layer 0's FFN -- unit 344, one of 6 rows -- lies within the
-                                       #  forward's 1e-5 of zero and takes the other side: 6e-2 on that layer's tensors at this width, every other tensor
-                                       #  3e-5; tools/train_variant_probe.py with DUMP= shows the one element.  The default seed stays: the comparison
-                                       #  excludes the 1 % largest deviations of a tensor that misses the bound and holds the whole tensor to 1e-1)
-                                       dict(_NARROW, mml_fusion="CA", num_moment_queries=2, vmr_fusion="XA-video-music", vmr_loss="single", _flip=True),
-                                       dict(_NARROW, mml_fusion="CA", num_moment_queries=2, vmr_fusion="XA-video-music", vmr_loss="single", _seed=1)])
+                                       # (dropout seeds 1 and 3: with 1234 one ReLU input of decoder layer 0's FFN -- unit 344, one of 6 rows -- lies within the
+                                       #  forward's 1e-5 of zero and takes the other side: 6e-2 on that layer's tensors at this width and, through the gradient
+                                       #  that flows on from there, a little on EVERY upstream tensor -- so masking the flipped unit's row and column out of
+                                       #  the comparison (tried in round 6) does not repair the case; every other tensor and these two seeds sit at 3e-5.
+                                       #  tools/train_variant_probe.py with DUMP= shows the one element)
+                                       dict(_NARROW, mml_fusion="CA", num_moment_queries=2, vmr_fusion="XA-video-music", vmr_loss="single", _seed=1),
+                                       dict(_NARROW, mml_fusion="CA", num_moment_queries=2, vmr_fusion="XA-video-music", vmr_loss="single", _seed=3)])
 def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     from mgsv_amd.trainer import MadeTrainer
     overrides = dict(overrides)
     shape = overrides.pop("_shape", (3, 20, 40))
     seed = overrides.pop("_seed", 1234)
-    flip = overrides.pop("_flip", False)
     cfg, sd, inp = _setup(*shape, overrides)
     trn = MadeTrainer(cfg, sd, dtype="f32")
     trn.training_dropout = dropout
     res = trn.loss_and_grads(inp, seed=seed)
     r, grads = _oracle(cfg, sd, inp, seed, dropout, trn.param_names)
-    print(_compare(res, r, grads, rel_tol=5e-3, loss_tol=1e-4, flip_frac=0.01 if flip else 0.0, flip_tol=1e-1))
+    print(_compare(res, r, grads, rel_tol=5e-3, loss_tol=1e-4))
 
 
 def test_f32_gradients_match_reference_fixture(golden_dir):
