@@ -91,6 +91,13 @@ enum MadeStatus {
 };
 
 int         made_abi_version(void);
+/* f32 products of every kernel that multiplies f32 operands (MadeDtype MADE_F32 compute): mode 0 = exact (v_mfma_f32_32x32x2_f32, 157 TFLOP/s
+ * peak), mode 1 = split-bf16: each operand as hi + lo bf16 halves and a . b ~ hi.hi + hi.lo + lo.hi on the bf16 matrix pipe (three products at
+ * 16x the f32 rate; the operands' last 7 mantissa bits are dropped: relative 8e-6 per operand, f32 accumulation, storage and elementwise
+ * steps unchanged).  Process-wide, read when a launch is issued; the reference's arithmetic is fp32 throughout (train-MaDe.py:237), its
+ * tolerance <= 1e-4 on logits / spans -- the engine's "f32x3" mode is held to that gate by the same tests as "f32". */
+int         made_set_f32_products(int mode);
+int         made_get_f32_products(void);
 const char* made_last_error(void);
 /* fills name (<= name_len chars), compute-unit count and 1 if the device is gfx950 */
 int         made_device_info(char* name, int name_len, int* cu_count, int* is_gfx950);

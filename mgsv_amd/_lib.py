@@ -193,6 +193,8 @@ class MadeRepackDesc(C.Structure):
 # name -> (restype, argtypes); every symbol include/made_hip.h declares
 SIGNATURES = {
     "made_abi_version": (C.c_int, []),
+    "made_set_f32_products": (C.c_int, [C.c_int]),
+    "made_get_f32_products": (C.c_int, []),
     "made_last_error": (C.c_char_p, []),
     "made_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "made_tape_begin": (C.c_int, []),

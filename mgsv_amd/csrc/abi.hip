@@ -15,6 +15,15 @@ void made_set_error(const char* fmt, ...) {
 
 extern "C" int made_abi_version(void) { return MADE_ABI_VERSION; }
 
+// f32 products: 0 = exact (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (three bf16 products per f32 product: common.h).  Process-wide; read at launch.
+int g_made_f32_products = 0;
+extern "C" int made_set_f32_products(int mode) {
+    if (mode != 0 && mode != 1) { made_set_error("made_set_f32_products: mode %d not in {0, 1}", mode); return MADE_ERR_INVALID_ARG; }
+    g_made_f32_products = mode;
+    return MADE_OK;
+}
+extern "C" int made_get_f32_products(void) { return g_made_f32_products; }
+
 extern "C" const char* made_last_error(void) { return g_err; }
 
 extern "C" int made_device_info(char* name, int name_len, int* cu_count, int* is_gfx950) {

@@ -26,7 +26,7 @@ template <typename TC> struct Frag;
 template <> struct Frag<float>  { typedef f32x4  type; };
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 
-template <typename TC, int HD>
+template <typename TC, int HD, bool X3 = false>        // X3 (f32 only): split-bf16 products (common.h, made_set_f32_products)
 __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel(const MadeAttnArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
@@ -163,6 +163,19 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+        if constexpr (X3) {
+            // split-bf16 products (common.h): two 8-deep steps per product (NQF is even: head dims 32 / 64 / 128)
+#pragma unroll
+            for (int ks = 0; ks < NQF; ks += 2) {
+                const SplitF32x4 q0 = made_split4(qf[ks]), q1 = made_split4(qf[ks + 1]);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const SplitF32x4 k0 = made_split4(*(const f32x4*)(lds_k + (kt * 32 + r) * K_ROW + ks * 32 + hh * 16));
+                    const SplitF32x4 k1 = made_split4(*(const f32x4*)(lds_k + (kt * 32 + r) * K_ROW + (ks + 1) * 32 + hh * 16));
+                    s[kt] = made_mfma_x3_16(k0, k1, q0, q1, s[kt]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < NQF; ++ks) {
 #pragma unroll
@@ -176,6 +189,7 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
                         s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[ks][e], s[kt], 0, 0, 0);
                 }
             }
+        }
         }
 
         // ---- online softmax (per query = per lane column; the two lane halves hold different keys)
@@ -325,6 +339,25 @@ __global__ __launch_bounds__(NTHREADS, (HD <= 64 ? 2 : 1)) void attention_kernel
                         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                     }
                 }
+        } else if constexpr (X3) {
+            // split-bf16 products: the four keys of a register quad (rows 8 g + 4 hh .. + 3 of a key block) are one 8-deep step
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4 += 2) {            // two register quads = two 8-deep steps per product
+                    const SplitF32x4 pb0 = made_split4(f32x4{s[kt][4 * g4], s[kt][4 * g4 + 1], s[kt][4 * g4 + 2], s[kt][4 * g4 + 3]});
+                    const SplitF32x4 pb1 = made_split4(f32x4{s[kt][4 * g4 + 4], s[kt][4 * g4 + 5], s[kt][4 * g4 + 6], s[kt][4 * g4 + 7]});
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        f32x4 v0, v1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v0[j] = *(const float*)(lds_v + (kt * 32 + 8 * g4 + 4 * hh + j) * V_ROW + (d * 32 + r) * 4);
+                            v1[j] = *(const float*)(lds_v + (kt * 32 + 8 * g4 + 8 + 4 * hh + j) * V_ROW + (d * 32 + r) * 4);
+                        }
+                        o[d] = made_mfma_x3_16(made_split4(v0), made_split4(v1), pb0, pb1, o[d]);
+                    }
+                }
         } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -378,9 +411,18 @@ template <typename TC>
 int launch_attention(const MadeAttnArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(((a.Lq + BQ - 1) / BQ) * 8 * ((a.H * a.B + 7) / 8))), block(NTHREADS);
     switch (a.hd) {
-        case 32: hipLaunchKernelGGL((attention_kernel<TC, 32>), grid, block, 0, st, a); break;
-        case 64: hipLaunchKernelGGL((attention_kernel<TC, 64>), grid, block, 0, st, a); break;
-        case 128: hipLaunchKernelGGL((attention_kernel<TC, 128>), grid, block, 0, st, a); break;
+        case 32:
+            if (sizeof(TC) == 4 && g_made_f32_products) hipLaunchKernelGGL((attention_kernel<TC, 32, sizeof(TC) == 4>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attention_kernel<TC, 32>), grid, block, 0, st, a);
+            break;
+        case 64:
+            if (sizeof(TC) == 4 && g_made_f32_products) hipLaunchKernelGGL((attention_kernel<TC, 64, sizeof(TC) == 4>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attention_kernel<TC, 64>), grid, block, 0, st, a);
+            break;
+        case 128:
+            if (sizeof(TC) == 4 && g_made_f32_products) hipLaunchKernelGGL((attention_kernel<TC, 128, sizeof(TC) == 4>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attention_kernel<TC, 128>), grid, block, 0, st, a);
+            break;
         default:
             made_set_error("made_attention: head dim %d not in {32,64,128}", a.hd);
             return MADE_ERR_UNSUPPORTED;

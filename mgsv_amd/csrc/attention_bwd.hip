@@ -72,7 +72,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int P, int 
 }
 
 // ---------------------------------------------------------------------------------------------- dQ
-template <typename TC, int HD>
+template <typename TC, int HD, bool X3 = false>        // X3 (f32 only): split-bf16 products (common.h, made_set_f32_products)
 __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void attn_bwd_dq_kernel(const MadeAttnBwdArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
@@ -231,6 +231,19 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { s[kt][e] = 0.f; dp[kt][e] = 0.f; }
+        if constexpr (X3) {
+#pragma unroll
+            for (int ks = 0; ks < NQF; ks += 2) {
+                const SplitF32x4 q0 = made_split4(qf[ks]), q1 = made_split4(qf[ks + 1]), g0 = made_split4(dof[ks]), g1 = made_split4(dof[ks + 1]);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const unsigned char* pk = lds_k + (kt * 32 + r) * P + ks * 32 + hh * 16;
+                    const unsigned char* pv = lds_v + (kt * 32 + r) * P + ks * 32 + hh * 16;
+                    s[kt] = made_mfma_x3_16(made_split4(*(const f32x4*)pk), made_split4(*(const f32x4*)(pk + 32)), q0, q1, s[kt]);
+                    dp[kt] = made_mfma_x3_16(made_split4(*(const f32x4*)pv), made_split4(*(const f32x4*)(pv + 32)), g0, g1, dp[kt]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < NQF; ++ks) {
 #pragma unroll
@@ -248,6 +261,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                     }
                 }
             }
+        }
         }
         // dS^T = P^T * (dP^T - delta) * scale, in place of s
         const uint64_t tbase = rowbase + (uint64_t)(t * BKEY);
@@ -318,6 +332,24 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                     for (int d = 0; d < NDT; ++d)
                         dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(lds_k, P, kt * 32 + 16 * s2, d * 32, lane), pf, dq[d], 0, 0, 0);
                 }
+        } else if constexpr (X3) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4 += 2) {            // two register quads = two 8-deep steps per product
+                    const SplitF32x4 b0 = made_split4(f32x4{s[kt][4 * g4], s[kt][4 * g4 + 1], s[kt][4 * g4 + 2], s[kt][4 * g4 + 3]});
+                    const SplitF32x4 b1 = made_split4(f32x4{s[kt][4 * g4 + 4], s[kt][4 * g4 + 5], s[kt][4 * g4 + 6], s[kt][4 * g4 + 7]});
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        f32x4 v0, v1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v0[j] = *(const float*)(lds_k + (kt * 32 + 8 * g4 + 4 * hh + j) * P + (d * 32 + r) * 4);
+                            v1[j] = *(const float*)(lds_k + (kt * 32 + 8 * g4 + 8 + 4 * hh + j) * P + (d * 32 + r) * 4);
+                        }
+                        dq[d] = made_mfma_x3_16(made_split4(v0), made_split4(v1), b0, b1, dq[d]);
+                    }
+                }
         } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -347,7 +379,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV
-template <typename TC, int HD>
+template <typename TC, int HD, bool X3 = false>
 __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void attn_bwd_dkv_kernel(const MadeAttnBwdArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
@@ -506,6 +538,15 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
             f32x16 s, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+            if constexpr (X3) {
+#pragma unroll
+                for (int ks = 0; ks < NQF; ks += 2) {
+                    const unsigned char* pq = lds_q + (qi * 32 + r) * P + ks * 32 + hh * 16;
+                    const unsigned char* pg = lds_do + (qi * 32 + r) * P + ks * 32 + hh * 16;
+                    s = made_mfma_x3_16(made_split4(*(const f32x4*)pq), made_split4(*(const f32x4*)(pq + 32)), made_split4(kf[ks]), made_split4(kf[ks + 1]), s);
+                    dp = made_mfma_x3_16(made_split4(*(const f32x4*)pg), made_split4(*(const f32x4*)(pg + 32)), made_split4(vf[ks]), made_split4(vf[ks + 1]), dp);
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < NQF; ++ks) {
                 frag_t qa = *(const frag_t*)(lds_q + (qi * 32 + r) * P + ks * 32 + hh * 16);
@@ -520,6 +561,7 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[e], vf[ks][e], dp, 0, 0, 0);
                     }
                 }
+            }
             }
             // s <- Pd (dropped probabilities), dp <- dS
             if constexpr (IS_BF16) {
@@ -603,6 +645,26 @@ __global__ __launch_bounds__(NTH, (sizeof(TC) == 2 && HD <= 64) ? 2 : 1) void at
                         dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(lds_q, P, qi * 32 + 16 * s2, d * 32, lane), sf, dk[d], 0, 0, 0);
                     }
                 }
+            } else if constexpr (X3) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4 += 2) {            // two register quads = two 8-deep steps per product
+                    const SplitF32x4 p0 = made_split4(f32x4{s[4 * g4], s[4 * g4 + 1], s[4 * g4 + 2], s[4 * g4 + 3]});
+                    const SplitF32x4 p1 = made_split4(f32x4{s[4 * g4 + 4], s[4 * g4 + 5], s[4 * g4 + 6], s[4 * g4 + 7]});
+                    const SplitF32x4 d0 = made_split4(f32x4{dp[4 * g4], dp[4 * g4 + 1], dp[4 * g4 + 2], dp[4 * g4 + 3]});
+                    const SplitF32x4 d1 = made_split4(f32x4{dp[4 * g4 + 4], dp[4 * g4 + 5], dp[4 * g4 + 6], dp[4 * g4 + 7]});
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        f32x4 g0, g1, q0, q1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r0 = qi * 32 + 8 * g4 + 4 * hh + j, r1 = r0 + 8;
+                            g0[j] = *(const float*)(lds_do + r0 * P + (d * 32 + r) * 4); g1[j] = *(const float*)(lds_do + r1 * P + (d * 32 + r) * 4);
+                            q0[j] = *(const float*)(lds_q + r0 * P + (d * 32 + r) * 4);  q1[j] = *(const float*)(lds_q + r1 * P + (d * 32 + r) * 4);
+                        }
+                        dv[d] = made_mfma_x3_16(made_split4(g0), made_split4(g1), p0, p1, dv[d]);
+                        dk[d] = made_mfma_x3_16(made_split4(q0), made_split4(q1), d0, d1, dk[d]);
+                    }
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -656,6 +718,18 @@ int launch_bwd_hd(const MadeAttnBwdArgs& a, dim3 gq, dim3 gk, size_t lds_q, size
             return MADE_ERR_HIP;
         }
         attr_done = true;
+    }
+    if (sizeof(TC) == 4 && g_made_f32_products) {
+        static bool attr3 = false;
+        if (!attr3) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<TC, HD, sizeof(TC) == 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
+            hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<TC, HD, sizeof(TC) == 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
+            if (e1 != hipSuccess || e2 != hipSuccess) { made_set_error("made_attention_bwd: cannot reserve %d bytes of LDS", kMaxDyn); return MADE_ERR_HIP; }
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, HD, sizeof(TC) == 4>), gq, dim3(NTH), lds_q, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, HD, sizeof(TC) == 4>), gk, dim3(NTH), lds_k, st, a);
+        return MADE_OK;
     }
     hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, HD>), gq, dim3(NTH), lds_q, st, a);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, HD>), gk, dim3(NTH), lds_k, st, a);

@@ -33,7 +33,7 @@ template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 // NSL = D slices per query tile: 4 -> one tile of 32 queries per workgroup, its four waves split D four ways; 2 -> two query
 // tiles per workgroup (waves 0-1 and 2-3), each split two ways: the K / V tiles staged through LDS then serve 64 queries, which
 // halves the staging per flop where a batch entry has 64 or more query rows (X-Pool: all videos against one track).
-template <typename TC, int D, bool DB, int NSL>
+template <typename TC, int D, bool DB, int NSL, bool X3 = false>      // X3 (f32 only): split-bf16 products (common.h, made_set_f32_products)
 __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWideAttnArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int SZ = (int)sizeof(TC);
@@ -232,6 +232,16 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
         f32x16 s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        if constexpr (X3) {
+            // split-bf16 products (common.h): two 8-deep steps per product (f32: never the DMA layout; NQF is even)
+            static_assert(!X3 || (NQF % 2 == 0 && !DMA), "f32 slices of 16 columns or more");
+#pragma unroll
+            for (int ks = 0; ks < NQF; ks += 2) {
+                const SplitF32x4 k0 = made_split4(*(const f32x4*)(lds_k + r * K_ROW + sl * DS * SZ + ks * 32 + hh * 16));
+                const SplitF32x4 k1 = made_split4(*(const f32x4*)(lds_k + r * K_ROW + sl * DS * SZ + (ks + 1) * 32 + hh * 16));
+                s = made_mfma_x3_16(k0, k1, made_split4(qf[ks]), made_split4(qf[ks + 1]), s);
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < NQF; ++ks) {
             frag_t kf;
@@ -243,6 +253,7 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[ks][e], s, 0, 0, 0);
             }
+        }
         }
         if constexpr (DMA) {
             // the next tile's pieces are issued behind this tile's score MFMAs (a piece costs its wave 60-180 cycles of issue)
@@ -336,6 +347,23 @@ __global__ __launch_bounds__(NTHREADS) void attention_wide_kernel(const MadeWide
                     bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
+                }
+            }
+        } else if constexpr (X3) {
+            // split-bf16 products: the four keys of a register quad (rows 8 g + 4 hh .. + 3) are one 8-deep step
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4 += 2) {                // two register quads = two 8-deep steps per product
+                const SplitF32x4 pb0 = made_split4(f32x4{s[4 * g4], s[4 * g4 + 1], s[4 * g4 + 2], s[4 * g4 + 3]});
+                const SplitF32x4 pb1 = made_split4(f32x4{s[4 * g4 + 4], s[4 * g4 + 5], s[4 * g4 + 6], s[4 * g4 + 7]});
+#pragma unroll
+                for (int d = 0; d < NDT; ++d) {
+                    f32x4 v0, v1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v0[j] = *(const float*)(lds_v + (8 * g4 + 4 * hh + j) * V_ROW + (sl * DS + d * 32 + r) * 4);
+                        v1[j] = *(const float*)(lds_v + (8 * g4 + 8 + 4 * hh + j) * V_ROW + (sl * DS + d * 32 + r) * 4);
+                    }
+                    o[d] = made_mfma_x3_16(made_split4(v0), made_split4(v1), pb0, pb1, o[d]);
                 }
             }
         } else {
@@ -502,6 +530,8 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D, DB, NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCap);
+        if (e == hipSuccess && SZ == 4)
+            e = hipFuncSetAttribute((const void*)attention_wide_kernel<TC, D, DB, NSL, SZ == 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCap);
         if (e != hipSuccess) {
             made_set_error("made_attention_wide: cannot reserve %zu bytes of LDS: %s", kCap, hipGetErrorString(e));
             return MADE_ERR_HIP;
@@ -514,7 +544,8 @@ int launch_wide(const MadeWideAttnArgs& a, hipStream_t st) {
     const int64_t qtiles = (nq + WQB - 1) / WQB;
     const bool batch_fast = qtiles > 1 && qtiles <= 8 && qtiles != a.B;       // see the kernel: which index runs fastest
     dim3 grid((unsigned)(batch_fast ? a.B : qtiles), (unsigned)(batch_fast ? qtiles : a.B), (unsigned)nsplit), block(NTHREADS);
-    hipLaunchKernelGGL((attention_wide_kernel<TC, D, DB, NSL>), grid, block, lds_bytes, st, a);
+    if (SZ == 4 && g_made_f32_products) hipLaunchKernelGGL((attention_wide_kernel<TC, D, DB, NSL, SZ == 4>), grid, block, lds_bytes, st, a);
+    else hipLaunchKernelGGL((attention_wide_kernel<TC, D, DB, NSL>), grid, block, lds_bytes, st, a);
     int rc = made_check_launch("made_attention_wide");
     if (rc != MADE_OK || nsplit == 1) return rc;
     const int64_t rows = a.B * nq;

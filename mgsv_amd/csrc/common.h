@@ -117,6 +117,41 @@ __host__ __device__ __forceinline__ int made_keep_slot(int q) { return 2 * ((q &
 // made_attention_bwd's single-pass kernel (attention_bwd_fused.hip): MADE_OK after launching, a HIP error, or -1000 when it does not apply
 int made_attention_bwd_fused_try(const MadeAttnBwdArgs& a, hipStream_t st);
 
+// ---- f32 products on the bf16 matrix pipe (made_set_f32_products(1); engine dtype "f32x3") ----------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate (157 TFLOP/s).  With x = hi + lo + O(2^-17 |x|) (hi = bf16(x), lo = bf16(x - hi))
+// a . b ~ hi.hi + hi.lo + lo.hi: three v_mfma_f32_32x32x8_bf16 (32 cycles each) replace four f32 MFMAs (64 cycles each) per 8-deep
+// step on the SAME fragment layout (lane half hh holds k = 4 hh .. 4 hh + 3 in both), f32 accumulation as before.  Storage, statistics and
+// every elementwise step stay f32; only the products lose the operands' last 7 bits (relative 8e-6 per operand, random sign).
+extern int g_made_f32_products;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+struct SplitF32x4 { s16x4 hi, lo; };
+__device__ __forceinline__ SplitF32x4 made_split4(const f32x4 x) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = (bf16_t)x[j]; l[j] = (bf16_t)(x[j] - (float)h[j]); }
+    SplitF32x4 r;
+    r.hi = __builtin_bit_cast(s16x4, h); r.lo = __builtin_bit_cast(s16x4, l);
+    return r;
+}
+__device__ __forceinline__ f32x16 made_mfma_x3(const SplitF32x4& a, const SplitF32x4& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a.hi, b.hi, c, 0, 0, 0);
+}
+
+// two 8-deep steps at once: v_mfma_f32_32x32x16_bf16 (the same 32 cycles for twice the depth); lane half hh holds the first step's
+// k = 4 hh .. + 3 in slots 0 .. 3 and the second step's in slots 4 .. 7 -- any assignment is right as long as both operands use it
+__device__ __forceinline__ f32x16 made_mfma_x3_16(const SplitF32x4& a0, const SplitF32x4& a1, const SplitF32x4& b0, const SplitF32x4& b1, f32x16 c) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0.hi, a1.hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    const bf16x8 al = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0.lo, a1.lo, 0, 1, 2, 3, 4, 5, 6, 7));
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0.hi, b1.hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    const bf16x8 bl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0.lo, b1.lo, 0, 1, 2, 3, 4, 5, 6, 7));
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+}
+
 // keep ? x : 0 on a 16-byte fragment without control flow (conditional LOADS make hipcc branch around every load and
 // wait for each one in turn -- cdna_hip_programming.md, "three .s-level traps" (c); load always, mask afterwards)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;

@@ -25,7 +25,7 @@ template <> struct TnCfg<bf16_t> { static constexpr int BM = 64, ROW = 128 * 2 +
 // f32: the two reduction rows a wave reads per MFMA must sit 32 banks apart
 template <> struct TnCfg<float>  { static constexpr int BM = 32, ROW = 128 * 4 + 128, CPR = 32; typedef f32x4 frag_t; };
 
-template <typename TC>
+template <typename TC, bool X3 = false>        // X3 (f32 only): split-bf16 products (common.h, made_set_f32_products)
 __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
     typedef TnCfg<TC> Cfg;
     typedef typename Cfg::frag_t frag_t;
@@ -182,6 +182,29 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const MadeGemmTNArgs a) {
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
+        } else if constexpr (X3) {
+            // split-bf16 products: sixteen reduction rows per product -- lane half hh takes rows 4 hh .. + 3 and 8 + 4 hh .. + 3 of the step
+#pragma unroll 2
+            for (int ks = 0; ks < BM / 16; ++ks) {
+                SplitF32x4 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 x0, x1, y0, y1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m0 = 16 * ks + 4 * hh + j, m1 = m0 + 8;
+                        x0[j] = *(const float*)(lds_a + m0 * ROW + (wn * 64 + t * 32 + r) * 4);
+                        x1[j] = *(const float*)(lds_a + m1 * ROW + (wn * 64 + t * 32 + r) * 4);
+                        y0[j] = *(const float*)(lds_b + m0 * ROW + (wk * 64 + t * 32 + r) * 4);
+                        y1[j] = *(const float*)(lds_b + m1 * ROW + (wk * 64 + t * 32 + r) * 4);
+                    }
+                    a0[t] = made_split4(x0); a1[t] = made_split4(x1); b0[t] = made_split4(y0); b1[t] = made_split4(y1);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = made_mfma_x3_16(a0[i], a1[i], b0[j], b1[j], acc[i][j]);
+            }
         } else {
 #pragma unroll 4
             for (int ks = 0; ks < BM / 2; ++ks) {
@@ -302,6 +325,7 @@ extern "C" int made_gemm_tn(const MadeGemmTNArgs* args, void* stream) {
     }
     dim3 grid((unsigned)tiles, (unsigned)a.split_m, (unsigned)nz);
     if (a.ab_dtype == MADE_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(TNT), 0, st, a);
+    else if (g_made_f32_products) hipLaunchKernelGGL((gemm_tn_kernel<float, true>), grid, dim3(TNT), 0, st, a);
     else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(TNT), 0, st, a);
     return made_check_launch("made_gemm_tn");
 }

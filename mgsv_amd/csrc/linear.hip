@@ -260,7 +260,7 @@ __device__ __forceinline__ void epilogue8(const MadeLinearArgs& a, int m, int n,
     }
 }
 
-template <typename TA, typename TC>
+template <typename TA, typename TC, bool X3 = false>      // X3 (f32 compute only): split-bf16 products (common.h, made_set_f32_products)
 __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArgs a) {
     typedef typename Frag<TC>::type frag_t;
     constexpr int PER16 = elem_traits<TC>::per16;
@@ -397,6 +397,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
         if (kt + 1 < nk) load_stage((kt0 + kt + 1) * KE);
         const unsigned char* la = cur + (wm * 64 + r) * LDS_ROW + hh * 16;
         const unsigned char* lw = cur + BM * LDS_ROW + (wn * 64 + r) * LDS_ROW + hh * 16;
+        if constexpr (sizeof(TC) == 4 && X3) {
+            // split-bf16 products (common.h): two 8-deep steps per product, every fragment split once
+#pragma unroll
+            for (int ks = 0; ks < 4; ks += 2) {
+                SplitF32x4 sa[2][2], sw2[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        sa[u][t] = made_split4(*(const f32x4*)(la + t * 32 * LDS_ROW + (ks + u) * 32));
+                        sw2[u][t] = made_split4(*(const f32x4*)(lw + t * 32 * LDS_ROW + (ks + u) * 32));
+                    }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = transposed ? made_mfma_x3_16(sw2[0][nt], sw2[1][nt], sa[0][mt], sa[1][mt], acc[mt][nt])
+                                                 : made_mfma_x3_16(sa[0][mt], sa[1][mt], sw2[0][nt], sw2[1][nt], acc[mt][nt]);
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             frag_t fa[2], fw[2];
@@ -424,6 +444,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(const MadeLinearArg
                         }
                     }
                 }
+        }
         }
         if (kt + 1 < nk) store_stage(lds + ((kt + 1) & 1) * STAGE);   // other stage: nobody reads it now
         __syncthreads();
@@ -554,7 +575,7 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 //            round 3: 5.185 -> 5.145 ms per training step, A/B of the two builds on one box): for grids that would leave the CUs with only one or
 //            two 128-row workgroups each (a padded batch gathered down to its valid rows) -- with NST = 1 the only thing that
 //            hides a slab's latency is the OTHER workgroups of the CU, so twice as many, half as tall, run faster.
-template <int NST, bool TRAIN, int BMT, typename TC = bf16_t>
+template <int NST, bool TRAIN, int BMT, typename TC = bf16_t, bool X3 = false>      // X3 (TC = float only): split-bf16 products
 __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : (TRAIN ? 3 : 4)) : 1) void linear_glds_kernel(const MadeLinearArgs a) {   // (128-row tiles with the training epilogue: three per CU -- at four the 128-register budget spilled 56 bytes)
     // TC = float (round 4): the f32 parity mode's large Linears on the same loop -- a 128-byte slab row is 32 f32, a 16-byte fragment four
     // consecutive k of which v_mfma_f32_32x32x2_f32 takes one per instruction (the same k from both operands, so any k order is a valid sum)
@@ -674,6 +695,26 @@ __global__ __launch_bounds__(NTHREADS, NST == 1 ? (BMT == 64 ? 6 : (TRAIN ? 3 : 
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw[i] + kt * KE), (lds_ptr_t)(st + BMT * KB + (4 * wave + i) * 1024), 16, 0, 0);
     };
     auto multiply = [&](const unsigned char* st) __attribute__((always_inline)) {
+        if constexpr (sizeof(TC) == 4 && X3) {
+            // split-bf16 products (common.h): two 8-deep steps per product, every fragment split once
+#pragma unroll
+            for (int kq = 0; kq < 4; kq += 2) {
+                SplitF32x4 sa2[2][2], sw2[2][NT];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = 2 * (kq + u) + hh;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) sa2[u][t] = made_split4(*(const f32x4*)(st + offa[t] + ((c ^ sa[t]) << 4)));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) sw2[u][t] = made_split4(*(const f32x4*)(st + offw[t] + ((c ^ sw[t]) << 4)));
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = made_mfma_x3_16(sa2[0][mt], sa2[1][mt], sw2[0][nt], sw2[1][nt], acc[mt][nt]);
+            }
+            return;
+        }
         if constexpr (sizeof(TC) == 4) {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
@@ -1675,13 +1716,13 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
             break;
         case MADE_LINEAR_GLDS64_F32: {
             dim3 g((unsigned)(((a.M + 63) / 64) * ((a.N + BN - 1) / BN)), 1, (unsigned)a.batch);
-            if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 64, float>), g, block, 0, st, a);
-            else hipLaunchKernelGGL((linear_glds_kernel<1, false, 64, float>), g, block, 0, st, a);
+            if (train) { if (g_made_f32_products) hipLaunchKernelGGL((linear_glds_kernel<1, true, 64, float, true>), g, block, 0, st, a); else hipLaunchKernelGGL((linear_glds_kernel<1, true, 64, float>), g, block, 0, st, a); }
+            else { if (g_made_f32_products) hipLaunchKernelGGL((linear_glds_kernel<1, false, 64, float, true>), g, block, 0, st, a); else hipLaunchKernelGGL((linear_glds_kernel<1, false, 64, float>), g, block, 0, st, a); }
             break;
         }
         case MADE_LINEAR_GLDS128_F32:
-            if (train) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128, float>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128, float>), grid, block, 0, st, a);
+            if (train) { if (g_made_f32_products) hipLaunchKernelGGL((linear_glds_kernel<1, true, 128, float, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((linear_glds_kernel<1, true, 128, float>), grid, block, 0, st, a); }
+            else { if (g_made_f32_products) hipLaunchKernelGGL((linear_glds_kernel<1, false, 128, float, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((linear_glds_kernel<1, false, 128, float>), grid, block, 0, st, a); }
             break;
         case MADE_LINEAR_BIG256:
         case MADE_LINEAR_BIG128: {                         // persistent: one workgroup per CU (a multiple of 8: one eighth per XCD)
@@ -1721,7 +1762,7 @@ extern "C" int made_linear(const MadeLinearArgs* args, void* stream) {
         }
         case MADE_LINEAR_GENERAL_F32IN: hipLaunchKernelGGL((linear_kernel<float, bf16_t>), grid, block, 0, st, a); break;
         case MADE_LINEAR_GENERAL_BF16: hipLaunchKernelGGL((linear_kernel<bf16_t, bf16_t>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((linear_kernel<float, float>), grid, block, 0, st, a); break;
+        default: if (g_made_f32_products) hipLaunchKernelGGL((linear_kernel<float, float, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((linear_kernel<float, float>), grid, block, 0, st, a); break;
     }
     return made_check_launch("made_linear");
 }

@@ -34,11 +34,14 @@ Tensor = torch.Tensor
 
 class MadeEngine:
     def __init__(self, cfg: MadeConfig, state_dict: Dict[str, object], device="cuda:0", dtype: str = "f32"):
-        assert dtype in ("f32", "bf16")
+        assert dtype in ("f32", "f32x3", "bf16")
         self.cfg = cfg
         self.device = torch.device(device)
-        self.tc = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.tc = torch.bfloat16 if dtype == "bf16" else torch.float32
         self.dtype_name = dtype
+        # "f32x3": f32 storage and elementwise arithmetic like "f32"; the matrix products run as three bf16 products on split operands
+        # (made_set_f32_products(1): include/made_hip.h) instead of the exact-f32 MFMA at 1/16 of the bf16 rate
+        self._f32_products = 1 if dtype == "f32x3" else 0
         self._check_supported()
         self._ws: Dict[tuple, Dict[str, Tensor]] = {}
         self.load_state_dict(state_dict)
@@ -561,9 +564,16 @@ class MadeEngine:
             return out
         return ops.linear(vn, mn, None, R=add, out=out, out_dtype=torch.float32)
 
+    def _set_products(self) -> None:
+        """the library's process-wide f32 product mode <- this engine's (read by the f32 kernels' launchers)"""
+        if self.tc == torch.float32:
+            from . import _lib
+            _lib.check(_lib.lib().made_set_f32_products(self._f32_products), "made_set_f32_products")
+
     def retrieval_sim_matrix(self, video_embeds: Tensor, segment_embeds: Tensor, segment_masks: Tensor,
                              music_embeds: Tensor, chunk_m: Optional[int] = None) -> Tensor:
         """reference test-MaDe.py:386-403: sim[Nv, Nm] = single (X-Pool) + dual (cosine)."""
+        self._set_products()
         seg = segment_embeds.to(self.tc) if segment_embeds.dtype != self.tc else segment_embeds
         single = self.xpool_sims(video_embeds, seg, segment_masks if self.cfg.fusion_mask == 1 else None, chunk_m=chunk_m)
         return self.dual_sims(video_embeds, music_embeds, add=single)
@@ -574,6 +584,7 @@ class MadeEngine:
                 spans_target: Tensor, with_losses: bool = True, want_pooled: bool = False,
                 v_duration: Optional[Tensor] = None) -> Dict[str, Tensor]:
         c, P = self.cfg, self.P
+        self._set_products()
         regression = "regression" in c.mml_localization
         if c.predict_center == 1 and v_duration is None:
             raise ValueError("predict_center=1 needs v_duration (reference model/model_Uni.py:280-282)")

@@ -43,6 +43,9 @@ HEAD_PAD = 64
 
 class MadeTrainer(MadeEngine):
     def __init__(self, cfg: MadeConfig, state_dict: Dict[str, object], device="cuda:0", dtype: str = "f32"):
+        if dtype == "f32x3":
+            raise ValueError('dtype "f32x3" (split-bf16 products) is an inference mode: it meets the forward\'s 1e-4 gate, its gradients do not meet '
+                             'the f32 training path\'s (measured up to 3e-2 relative per tensor); train in "f32" or "bf16"')
         super().__init__(cfg, state_dict, device, dtype)
         self._check_train_supported()
         self._init_master(state_dict)
@@ -575,6 +578,7 @@ class MadeTrainer(MadeEngine):
         """reference model/model_Uni.py:177-322 under model.train(): same outputs as MadeEngine.forward plus everything
         the backward needs, kept in the training workspace."""
         c, P = self.cfg, self.P
+        self._set_products()
         if c.predict_center == 1 and v_duration is None:
             raise ValueError("predict_center=1 needs v_duration (reference model/model_Uni.py:280-282)")
         self.seed = int(seed)
@@ -1162,6 +1166,7 @@ class MadeTrainer(MadeEngine):
         early_opt(): called at the same point on a THIRD stream that waits for everything queued so far on the two others (neither
         of them waits for it until the end of the backward pass): optimizer_step(part="early") there applies the matching + detection
         groups' update under the temporal encoders' backward, which reads none of their weights (opt-in, see _early_opt_ok)."""
+        self._set_products()
         c, P, G = self.cfg, self.P, self.G
         B, Tv, Ta = self._shape
         ws, tw = self._buffers(B, Tv, Ta), self._train_buffers(B, Tv, Ta)

@@ -67,12 +67,15 @@ def _cases():
     }
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
 @pytest.mark.parametrize("name", list(_cases()))
-def test_f32_forward_matches_oracle(name):
+def test_f32_forward_matches_oracle(name, dtype):
+    """dtype "f32": exact-f32 MFMA.  "f32x3" (round 6): the same f32 engine with every matrix product as three bf16 products on split operands
+    (made_set_f32_products(1), csrc/common.h) -- held to the SAME 1e-4 gate on every output."""
     cfg, B, Tv, Ta = _cases()[name]
     sd = synth.make_state_dict(cfg, seed=0)
     inp = synth.make_inputs(cfg, B, Tv, Ta, seed=1, min_len_v=min(5, Tv), min_len_a=min(12, Ta))
-    eng = MadeEngine(cfg, sd, dtype="f32")
+    eng = MadeEngine(cfg, sd, dtype=dtype)
     out = eng.forward_numpy(inp)
     ref = _oracle(cfg, sd, inp)
     tol = 1e-4
@@ -102,8 +105,9 @@ def test_f32_forward_matches_oracle(name):
     np.testing.assert_allclose(out["localization_loss"], float(ref["localization_loss"]), rtol=2e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
 @pytest.mark.parametrize("name", ["forward_cfg1_B2", "forward_native_Q3_B4"])
-def test_f32_forward_matches_reference_golden(golden_dir, name):
+def test_f32_forward_matches_reference_golden(golden_dir, name, dtype):
     """Straight against what the reference itself produced (tests/golden/make_golden.py)."""
     fix = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = cfg_plumbing() if "cfg1" in name else cfg_native()
@@ -112,7 +116,7 @@ def test_f32_forward_matches_reference_golden(golden_dir, name):
     B, Tv, Ta = int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"])
     sd = synth.make_state_dict(cfg, seed=int(fix["meta_weight_seed"]))
     inp = synth.make_inputs(cfg, B, Tv, Ta, seed=int(fix["meta_data_seed"]))
-    out = MadeEngine(cfg, sd, dtype="f32").forward_numpy(inp)
+    out = MadeEngine(cfg, sd, dtype=dtype).forward_numpy(inp)
     tol = 1e-4
     for k in ("pred_logits", "pred_spans", "proj_queries", "video_feats", "music_feats", "sims_single", "sims_dual"):
         np.testing.assert_allclose(out[k], fix[k], atol=tol, rtol=0, err_msg=k)
@@ -426,7 +430,7 @@ def test_retrieval_parity_sampled_at_the_timed_size():
     with torch.no_grad():
         ref_r = O.retrieval_sim_matrix(P, cfg, ri["video_embeds"][rows], ri["segment_embeds"], ri["segment_masks"], ri["music_embeds"])
         ref_c = O.retrieval_sim_matrix(P, cfg, ri["video_embeds"], ri["segment_embeds"][cols], ri["segment_masks"][cols], ri["music_embeds"][cols])
-    for dtype, tol in (("bf16", BF16_SIM_TOL), ("f32", 1e-4)):
+    for dtype, tol in (("bf16", BF16_SIM_TOL), ("f32", 1e-4), ("f32x3", 1e-4)):
         eng = MadeEngine(cfg, sd, dtype=dtype)
         t = {k: torch.from_numpy(v).to(eng.device) for k, v in ri.items()}
         sim = eng.retrieval_sim_matrix(t["video_embeds"], t["segment_embeds"], t["segment_masks"], t["music_embeds"])

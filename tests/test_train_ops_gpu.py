@@ -46,6 +46,58 @@ def test_gemm_tn_matches_torch(T, dtype, tol, M, N, K):
     assert float((Cc.float() - ref2).abs().max()) <= max(tol, 1e-2 if dtype == torch.bfloat16 else 0) * float(ref2.abs().max())
 
 
+@pytest.fixture
+def split_products():
+    """made_set_f32_products(1) for the duration of a test: every f32 product as three bf16 products on split operands (csrc/common.h)"""
+    from mgsv_amd import _lib
+    _lib.check(_lib.lib().made_set_f32_products(1), "made_set_f32_products")
+    try:
+        yield
+    finally:
+        _lib.check(_lib.lib().made_set_f32_products(0), "made_set_f32_products")
+
+
+def test_split_bf16_products_of_the_training_kernels(T, split_products):
+    """The split-product mode on the kernels of the training path (the engine's "f32x3" is an inference mode -- tests/test_trainer_gpu.py --, but the
+    library-wide switch reaches every f32 product): made_gemm_tn, made_attention and made_attention_bwd in f32 against f32 torch math at
+    2e-4 of the result's scale (exact mode: 2e-5 / 3e-5) -- the operands' dropped bits (2^-17 each), not an indexing mistake."""
+    ops, tr = T
+    from mgsv_amd import _lib
+    assert _lib.lib().made_get_f32_products() == 1
+    for M, N, K in ((300, 256, 128), (1000, 384, 520), (4096, 512, 512)):
+        A, B = _rand(M, N, dtype=torch.float32, seed=1), _rand(M, K, dtype=torch.float32, seed=2)
+        mask = (torch.rand(M, device="cuda") > 0.3).float()
+        ref = (A * mask[:, None]).t() @ B
+        C = torch.full((N, K), 7.0, device="cuda")
+        tr.gemm_tn(A, B, C, row_mask=mask)
+        err = float((C - ref).abs().max()) / float(ref.abs().max())
+        assert 1e-7 < err <= 2e-4, (M, N, K, err)               # (not bit-equal to the exact mode either: the switch did reach the kernel)
+    for B_, H, hd, Lq, Lk in ((2, 8, 64, 150, 150), (3, 4, 32, 70, 200), (1, 2, 128, 96, 50)):
+        D = H * hd
+        qkv = _rand(B_, max(Lq, Lk), 3 * D, dtype=torch.float32, seed=11)
+        q, k, v = qkv[:, :Lq, :D], qkv[:, :Lk, D:2 * D], qkv[:, :Lk, 2 * D:]
+        lens = torch.tensor([Lk - (i * 37) % max(Lk // 2, 1) for i in range(B_)], device="cuda")
+        key_mask = (torch.arange(Lk, device="cuda")[None, :] < lens[:, None]).float()
+        q_skip = key_mask if Lq == Lk else None
+        qf, kf, vf = [t.clone().requires_grad_(True) for t in (q, k, v)]
+        o_ref, lse_ref = _attn_ref(qf, kf, vf, H, key_mask, None, 0.0)
+        dO = _rand(B_, Lq, D, dtype=torch.float32, seed=12)
+        valid_q = (q_skip if q_skip is not None else torch.ones(B_, Lq, device="cuda"))[:, :, None]
+        (o_ref * dO * valid_q).sum().backward()
+        O = torch.zeros(B_, Lq, D, device="cuda")
+        lse = torch.empty(B_, H, Lq, device="cuda")
+        ops.attention(q, k, v, O, H, key_mask=key_mask, q_skip_mask=q_skip, lse=lse)
+        sel = valid_q.bool().expand_as(O)
+        assert float((O - o_ref)[sel].abs().max()) <= 2e-4 * float(o_ref.detach().abs().max())
+        dqkv = torch.full((B_, max(Lq, Lk), 3 * D), float("nan"), device="cuda")
+        delta = torch.empty(B_, H, Lq, device="cuda")
+        tr.attention_bwd(q, k, v, O, dO, dqkv[:, :Lq, :D], dqkv[:, :Lk, D:2 * D], dqkv[:, :Lk, 2 * D:], lse, delta, H, key_mask=key_mask, q_skip_mask=q_skip)
+        gscale = max(float(g.abs().max()) for g in (qf.grad, kf.grad, vf.grad))
+        for name, got, ref in (("dq", dqkv[:, :Lq, :D], qf.grad), ("dk", dqkv[:, :Lk, D:2 * D], kf.grad), ("dv", dqkv[:, :Lk, 2 * D:], vf.grad)):
+            assert torch.isfinite(got).all(), name
+            assert float((got - ref).abs().max()) <= 2e-4 * max(float(ref.abs().max()), 0.05 * gscale) * 2, (name, hd)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-3)])
 def test_gemm_tn_skips_padded_slabs(T, dtype, tol):
     """prefix-valid sequences (long runs of padding): with the 32-row validity flags whole slabs are skipped, result unchanged

@@ -121,12 +121,22 @@ def test_f32_gradients_match_oracle_autograd(dropout, overrides):
     print(_compare(res, r, grads, rel_tol=5e-3, loss_tol=1e-4))
 
 
-def test_f32_gradients_match_reference_fixture(golden_dir):
+def test_trainer_refuses_the_split_product_mode():
+    """dtype "f32x3" (f32 storage, every product as three bf16 products on split operands) meets the forward's 1e-4 gate (tests/test_engine_gpu.py)
+    but not the gradient gate of the f32 training path (5e-3 per tensor: measured up to 3.2e-2 under the p = 0.8 dropout, 8e-3 without --
+    a near-zero ReLU input takes the other side): it is an inference mode, and the trainer says so instead of training at an unstated precision."""
+    from mgsv_amd.trainer import MadeTrainer
+    cfg, sd, _ = _setup(2, 20, 40)
+    with pytest.raises(ValueError, match="f32x3"):
+        MadeTrainer(cfg, sd, dtype="f32x3")
+
+
+def test_f32_gradients_match_reference_fixture(golden_dir, dtype="f32"):
     """straight against the reference's own autograd (float64 fixture made by tests/golden/make_golden.py)."""
     from mgsv_amd.trainer import MadeTrainer
     fix = np.load(os.path.join(golden_dir, "train_native_B3.npz"))
     cfg, sd, inp = _setup(int(fix["meta_B"]), int(fix["meta_T_v"]), int(fix["meta_T_a"]))
-    trn = MadeTrainer(cfg, sd, dtype="f32")
+    trn = MadeTrainer(cfg, sd, dtype=dtype)
     for mode, dropout in (("train", True), ("eval", False)):
         trn.training_dropout = dropout
         res = trn.loss_and_grads(inp, seed=int(fix["meta_dropout_seed"]))
