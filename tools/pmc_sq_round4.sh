@@ -16,7 +16,7 @@ run_target() {   # name, kernel-substrings (space separated), command...
   grep -v amdgpu.ids /tmp/p4_1.log | tail -2 >> $O/sq_counters_$name.txt
   rm -rf /tmp/p4_[0-9]*
 }
-run_target attention "attention_kernel,attn_bwd_dq_kernel,attn_bwd_dkv_kernel" python3 $R/tools/attn_pmc_target.py
+run_target attention "attention_kernel,attn_bwd_fused_kernel,attn_bwd_dq_kernel,attn_bwd_dkv_kernel" python3 $R/tools/attn_pmc_target.py
 run_target xpool_fused "xpool_fused_persist_kernel" python3 $R/tools/xpool_only.py 8192 512
 # the training step's dominant family (encoder-sized Linears, tools/linear_tiles_bench.py: plain / residual / gathered rows) and the opt-in retrieval kernel
 MADE_LINEAR_TILE=64 run_target linear_glds "linear_glds_kernel" python3 $R/tools/linear_tiles_bench.py
