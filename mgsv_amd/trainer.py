@@ -1514,7 +1514,10 @@ class MadeTrainer(MadeEngine):
 
         # ---------------- DETR encoder
         dsrc = dmem
-        enc_dw_side = _lib.variant_env("MADE_ENC_DW_SIDE", "1") != "0"         # (knob for A/B measurements)
+        # the encoder layers' grouped weight-gradient launches: on the main stream since round 6 (the single-pass attention backward shortened the
+        # main stream's chain; inside the step 4.80 against 4.88 ms with these and the audio tower's on the main stream: gpurun_out/ab_dw_side.txt,
+        # profiles/r06_ab_dw_side.txt).  MADE_ENC_DW_SIDE=1 (measurement knob): on the second stream, as rounds 3-5 had them
+        enc_dw_side = _lib.variant_env("MADE_ENC_DW_SIDE", "0") != "0"
         enc_dw_done = [None, None]
         for l in range(ne - 1, -1, -1):
             p, e = f"detr_transformer.encoder.layers.{l}", f"e.{l}"
@@ -1648,9 +1651,10 @@ class MadeTrainer(MadeEngine):
             if "video" in c.vmr_fusion:
                 dxv = tw["ydseg"] if dxv is None else tr.add3(tw["dframe_sum"], dxv, tw["ydseg"])
             self._encode_bwd("video", ws, tw, dl_v, dxv.view(B, Tv, D) if dxv is not None else None, dvideo, fm, feats_v)
-        # (the audio tower's weight-gradient products have nobody waiting on the main stream either: second stream, behind the video tower)
+        # (the audio tower's weight-gradient products stay on the main stream since round 6 -- it idles at the end of the step while the second
+        # stream is still in the video tower's chain; MADE_AUDIO_DW_SIDE=1: behind the video tower on the second stream, as before)
         self._encode_bwd("audio", ws, tw, dl_a, tw["xdseg"].view(B, Ta, D), dmusic, sm, feats_a,
-                         dw_stream=side if _lib.variant_env("MADE_AUDIO_DW_SIDE", "1") != "0" else None)
+                         dw_stream=side if _lib.variant_env("MADE_AUDIO_DW_SIDE", "0") != "0" else None)
         cur.wait_stream(side)
         if opt_st is not None:
             cur.wait_stream(opt_st)
