@@ -41,8 +41,8 @@ from mgsv_amd.engine import MadeEngine  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "f32x3": 2500.0 / 3}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (f32x3: three bf16 products per f32 product)
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round5.sh), per leg
-ROCPROF_AVG_FILE = os.path.join(ROOT, "profiles", "r05_kernel_avg_us.json")   # per-leg, per-kernel average durations of the committed rocprofv3 --kernel-trace --stats runs
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round6.sh), per leg
+ROCPROF_AVG_FILE = os.path.join(ROOT, "profiles", "r06_kernel_avg_us.json")   # per-leg, per-kernel average durations of the committed rocprofv3 --kernel-trace --stats runs
 STEP_CEILING_PAIRS_S = {"train": 62000.0, "eval": 186000.0}          # MFMA ceilings of the whole step (fwd+bwd / fwd)
 
 
