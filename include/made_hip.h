@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MADE_ABI_VERSION 7
+#define MADE_ABI_VERSION 8
 
 enum MadeDtype { MADE_F32 = 0, MADE_BF16 = 1 };
 
@@ -697,7 +697,7 @@ int made_gemm_tn(const MadeGemmTNArgs* args, void* stream);
 
 /* made_gemm_tn_grouped: up to 8 weight gradients that reduce over the same rows -- the Linears of one transformer layer
  * (reference music_detr/transformer.py:191-210, model/model_Base.py:64-91: dW_i += alpha * dY_i^T X_i, db_i += alpha * colsum(dY_i)) --
- * in ONE launch: bf16 operands, f32 C accumulated with atomics (the caller zeroes gradients once per step), N_i and K_i multiples
+ * in ONE launch: bf16 operands, f32 C accumulated (with atomics, or through the workspace below; the caller zeroes gradients once per step), N_i and K_i multiples
  * of 128, one row list (row_index / n_rows as in made_gemm_tn, or all M rows) and one split of the reduction for all problems.
  * tile_end is filled in by the library. */
 #define MADE_GEMM_TN_MAX_GROUP 8
@@ -714,8 +714,17 @@ typedef struct MadeGemmTNGroup {
     int32_t tile_size; int32_t _pad;     /* 0 / 128: 128 x 128 output tiles (four waves, two workgroups per CU); 256: 256 x 256 tiles (eight waves, one
                                             workgroup per CU, N and K multiples of 256, M <= 36864): twice the flops per operand byte, a quarter of
                                             the atomics; the (tile, 64-row slab) units are cut into equal ranges for the workgroups, split_m is not used */
+    void* workspace; int64_t workspace_bytes;   /* optional, 256 x 256 tiles only (ABI 8): with it the workgroups that share a tile's reduction STORE their f32
+                                            partials there and a second launch of the same call sums them in a fixed order and updates C with plain
+                                            accesses -- instead of adding every partial to C with atomics (67 MB of atomic adds per encoder layer at the
+                                            1.2 TB/s the atomic units sustain: 83 of the launch's 146 us).  At least
+                                            made_gemm_tn_grouped_workspace(group) bytes, 16-byte aligned, contents arbitrary; calls that share a
+                                            workspace, or update the same C, must be ordered on one stream.  The result is then bitwise
+                                            reproducible.  NULL: the atomics */
 } MadeGemmTNGroup;
 int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream);
+/* bytes of workspace the group's launch can use (0: none -- not the 256 x 256-tile form); reads n_problems, tile_size, M and the problems' N, K */
+int64_t made_gemm_tn_grouped_workspace(const MadeGemmTNGroup* group);
 /* out[g] = 1 if any of mask[32g .. 32g+31] is nonzero else 0 (computed once per batch, shared by every weight-gradient product) */
 int made_row_groups(const float* mask, int64_t M, float* out, void* stream);
 /* made_row_index: compaction of a [M] token mask: row_index[r] = index of the r-th nonzero entry (r < n), entries r >= n repeat

@@ -22,7 +22,7 @@ def variant_env(name: str, default: str = "") -> str:
 
 
 LIB_PATH = os.environ.get("MADE_LIB_PATH") or os.path.join(_HERE, "libmade_hip.so")
-ABI_VERSION = 7                          # include/made_hip.h MADE_ABI_VERSION the ctypes mirrors in this file were written for
+ABI_VERSION = 8                          # include/made_hip.h MADE_ABI_VERSION the ctypes mirrors in this file were written for
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SIGMOID = 0, 1, 2, 3, 4
@@ -174,7 +174,8 @@ class MadeGemmTNProblem(C.Structure):
 
 class MadeGemmTNGroup(C.Structure):
     _fields_ = [("n_problems", i32), ("alpha", f32), ("M", i64), ("split_m", i64), ("row_index", vp), ("n_rows", vp),
-                ("p", MadeGemmTNProblem * 8), ("tile_end", i32 * 8), ("tile_size", i32), ("_pad", i32)]
+                ("p", MadeGemmTNProblem * 8), ("tile_end", i32 * 8), ("tile_size", i32), ("_pad", i32),
+                ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class MadeAdamGroup(C.Structure):
@@ -268,6 +269,7 @@ SIGNATURES = {
     "made_span_iou": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp, vp]),
     "made_gemm_tn": (C.c_int, [C.POINTER(MadeGemmTNArgs), vp]),
     "made_gemm_tn_grouped": (C.c_int, [C.POINTER(MadeGemmTNGroup), vp]),
+    "made_gemm_tn_grouped_workspace": (i64, [C.POINTER(MadeGemmTNGroup)]),
     "made_concat_cols": (C.c_int, [vp, i64, vp, i64, vp, i64, vp]),
     "made_pooled_cosine": (C.c_int, [vp, i64, vp, i32, vp, i64, i64, i64, i64, i64, vp]),
     "made_scale_exp": (C.c_int, [vp, vp, vp, i64, vp]),

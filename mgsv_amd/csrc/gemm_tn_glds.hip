@@ -255,6 +255,9 @@ __global__ __launch_bounds__(GT_NT, 2) void gemm_tn_glds_grouped_kernel(const Ma
 // owns a 256 x 256 tile (a wave: 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers): 64 KB per 8.4 MFLOP (131 flop / byte), one
 // workgroup per CU, a quarter of the atomic traffic, and per k-step 12 transposing LDS reads feed 8 MFMAs (the LDS read rate stays
 // below the MFMA rate).  Same slab ring, same source-side swizzle, same bias-gradient trick.
+#ifndef TN256_SKIP
+#define TN256_SKIP 0          // elimination builds (tools/variant_build.sh ... "-DTN256_SKIP=<mask>"): 1 no flush, 2 no MFMAs, 4 no operand loads
+#endif
 constexpr int T2_BN = 256, T2_BK = 256, T2_BM = 64, T2_NT = 512, T2_NST = 2;
 constexpr int T2_ROW = 512;                               // bytes per LDS row (256 bf16)
 constexpr int T2_HALF = T2_BM * T2_ROW;                   // 32 KB: one operand of one stage
@@ -297,7 +300,18 @@ __device__ __forceinline__ T2Tile t2_tile(const MadeGemmTNGroup& g, int tile) {
     return t;
 }
 
-__global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const MadeGemmTNGroup g) {
+// The flush without atomics (round 6).  A tile's reduction is split over ~8 workgroups and each used to ADD its 256 x 256 f32 partial to the
+// gradient with atomics: 67 MB per encoder layer at the 1.2 TB/s the L2s' atomic units sustain (one dword per clock and channel; the same whether
+// the eight workgroups of a tile sit on one XCD or on eight: tools/probes/xcc_atomics_probe.hip) = 83 of the launch's 146 us.  With a workspace
+// (MadeGemmTNGroup.workspace) a workgroup instead STORES its partial (plain 16-byte stores in accumulator order: 4 us) and a second launch,
+// gemm_tn_256_reduce_kernel, sums the partials of every 32-row strip of every tile in a fixed order (block number, then flush number: the
+// gradient is bitwise reproducible -- the atomics' was not) and adds the sum to the gradient with plain accesses.  (Summing inside the launch by
+// each strip's last contributor -- a counter per strip, nobody waiting for anybody -- was built first and measured slower than the atomics: the
+// workgroups of a tile finish up to 20 us apart, the last one then sums the whole tile alone, 2 MB through one CU: 9 us per strip;
+// profiles/r06_tn256_flush.txt.)  C is updated with plain read-modify-write: launches that update the same C must be ordered (one stream), as the step's are.
+struct T2Ws { float* part; int F; };                        // partial slots of 256 x 256 f32 [gridDim * F], flushes a workgroup can make
+
+__global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const MadeGemmTNGroup g, const T2Ws w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -327,6 +341,7 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     auto issue = [&](int64_t n, int64_t si, const T2Tile& t) __attribute__((always_inline)) {    // n: how many units this workgroup has issued
         unsigned char* st = lds + (n % T2_NST) * T2_STAGE;
+        if (TN256_SKIP & 4) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int rowl = 8 * wave + 2 * j + (lane >> 5);
@@ -369,6 +384,20 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
         }
     };
     auto flush = [&](const T2Tile& t) __attribute__((always_inline)) {
+        if (TN256_SKIP & 1) {                                // (every accumulator stays live: with one of them tested the compiler drops the other MFMAs)
+            float z = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z += acc[i][j][e];
+            if (z == 123.456f) t.C[0] = 1.f;
+            return;
+        }
+        int ftid = threadIdx.x;                              // (see flush_ws: nothing of the flush parked in registers across the unit loop)
+        asm volatile("" : "+v"(ftid));
+        const int r = ftid & 31, hh = (ftid >> 5) & 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -384,6 +413,35 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float tot = csum[i] + __shfl_xor(csum[i], 32);                 // the two lane halves hold different reduction rows
+                if (hh == 0) unsafeAtomicAdd(t.colsum + t.n0 + wn * 128 + i * 32 + r, tot * g.alpha);
+            }
+        }
+    };
+    // ---- the flush through the workspace (see above the kernel)
+    int nflush = 0;
+    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc((void*)w.part, 0, w.part ? (int)((unsigned)gridDim.x * (unsigned)w.F * 262144u) : 0, 0x00020000);
+    auto flush_ws = [&](const T2Tile& t) __attribute__((always_inline)) {
+        // (what the flush derives from the thread's number is made here, not in front of the unit loop where the optimiser would park it in registers
+        //  the loop has none to spare: the loop spilled to scratch memory without this fence)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, r = lane & 31, hh = lane >> 5;
+        const uint32_t slot_b = ((uint32_t)blockIdx.x * (uint32_t)w.F + (uint32_t)nflush) * 262144u;
+        ++nflush;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 v = {acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+                    const uint32_t chunk = (uint32_t)(((wn * 4 + i) * 8 + wk * 2 + j) * 4 + g4);       // strip wn * 4 + i: 32 chunks of 1 KB
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_part, slot_b + chunk * 1024u + (uint32_t)lane * 16u, 0, 0);
+                }
+        if (t.colsum != nullptr && t.first_k && wk == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float tot = csum[i] + __shfl_xor(csum[i], 32);
                 if (hh == 0) unsafeAtomicAdd(t.colsum + t.n0 + wn * 128 + i * 32 + r, tot * g.alpha);
             }
         }
@@ -431,11 +489,13 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
             for (int t = 0; t < 4; ++t) af[t] = __builtin_shufflevector(fr[buf][2 * t], fr[buf][2 * t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int t = 0; t < 2; ++t) bfr[t] = __builtin_shufflevector(fr[buf][8 + 2 * t], fr[buf][8 + 2 * t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+            if (!(TN256_SKIP & 2)) {
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2)
                     acc[i2][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i2], bfr[j2], acc[i2][j2], 0, 0, 0);
+            } else { acc[0][0][0] += (float)af[0][0] + (float)bfr[0][0]; }
             if (do_colsum) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -452,14 +512,113 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
         t2_wait12(fr[0], 1); mul_step(0);
         t2_wait12(fr[1], 0); mul_step(1);
         if (last_of_tile || u + 1 == u1) {                   // the range leaves this tile: add what was gathered to the gradient
-            flush(cur);
+            if (w.part != nullptr && !(TN256_SKIP & 1)) flush_ws(cur);
+            else flush(cur);
             clear();
         }
         if (last_of_tile) { cur = nxt; ++tile; si = 0; } else ++si;
     }
 }
 
+// Second launch of the workspace form: workgroup (tile, strip) sums the strip's partials -- 32 rows x 256 columns, one 32 KB piece per contributor
+// in accumulator order -- over the tile's contributors in block order, and adds alpha * sum to C.  The contributors follow from the launch's
+// geometry alone: block b = (wg = b / 8, xcd = b % 8) of the first launch covered units [U wg / nwg, U (wg + 1) / nwg) of its XCD's S_x * tiles
+// (tile-major), and made one flush per tile it touched, in order.  Eight waves, wave v chunks 4 v .. 4 v + 3 of the strip's 32; all of a
+// lane's loads (4 per contributor, up to 32 in flight) are requested before the first use.
+__global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_reduce_kernel(const MadeGemmTNGroup g, const T2Ws w, int grid1) {
+    __shared__ int f_list[256];                              // slots of the tile's partials, in summing order
+    __shared__ int f_cnt[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int tile_idx = blockIdx.x >> 3, s8 = blockIdx.x & 7;
+    const int tiles = g.tile_end[g.n_problems - 1];
+    const int nwg = grid1 >> 3;
+    int64_t Mv = g.M;
+    if (g.n_rows) { const int64_t nv = *g.n_rows; Mv = nv < g.M ? nv : g.M; }
+    const int64_t nslab = (Mv + T2_BM - 1) / T2_BM;
+    const T2Tile t = t2_tile(g, tile_idx);
+    // this lane's C addresses first (their loads fly under the partials')
+    float cv[4][4];
+    float* cp[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = wave * 4 + c;                         // (wk, j, g4) of the chunk
+        const int g4 = ch & 3, j = (ch >> 2) & 1, wkc = ch >> 3;
+        cp[c] = t.C + (t.n0 + s8 * 32 + 8 * g4 + 4 * hh) * t.ldc + t.k0 + wkc * 64 + j * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv[c][e] = cp[c][e * t.ldc];
+    }
+    int hit = 0, slot = 0;
+    if (tid < grid1) {
+        const int bx = tid & 7, bw = tid >> 3;
+        const int64_t Sx = nslab > bx ? (nslab - bx + 7) / 8 : 0, Ux = Sx * tiles;
+        const int64_t b0 = (Ux * bw) / nwg, b1 = (Ux * (bw + 1)) / nwg;
+        if (b0 < b1 && b0 < (int64_t)(tile_idx + 1) * Sx && b1 > (int64_t)tile_idx * Sx) {
+            hit = 1;
+            slot = tid * w.F + (tile_idx - (int)(b0 / Sx));
+        }
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (wave < 4 && lane == 0) f_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (wave < 4 && hit) {
+        int base = 0;
+        for (int k = 0; k < wave; ++k) base += f_cnt[k];
+        f_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = slot;
+    }
+    if (tid == 0) f_cnt[4] = f_cnt[0] + f_cnt[1] + f_cnt[2] + f_cnt[3];
+    __syncthreads();
+    const int nc = f_cnt[4];
+    f32x4 sum[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sum[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < nc; k0 += 8) {                     // eight partials (32 loads of 16 bytes per lane) in flight
+        f32x4 v[8][4];
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8) {
+            const int kk = k0 + u8 < nc ? k0 + u8 : nc - 1;
+            const float* sp = w.part + (int64_t)f_list[kk] * 65536 + (s8 * 32 + wave * 4) * 256 + lane * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[u8][c] = *(const f32x4*)(sp + c * 256);
+        }
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8)
+            if (k0 + u8 < nc) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sum[c] += v[u8][c];
+            }
+    }
+    if (nc == 0) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cp[c][e * t.ldc] = cv[c][e] + sum[c][e] * g.alpha;
+}
+
 }  // namespace
+
+// workspace of the 256 x 256-tile form: gridDim * F partial slots of 256 KB
+static int t2_flushes(int tiles, int grid) { const int nwg = grid / 8 > 0 ? grid / 8 : 1; return (tiles + nwg - 1) / nwg + 1; }
+static int64_t t2_workspace_bytes(int tiles, int grid) { return (int64_t)grid * t2_flushes(tiles, grid) * 262144; }
+static bool t2_shape(const MadeGemmTNGroup& g, int* tiles_out, int* grid_out) {
+    int tiles2 = 0;
+    for (int i = 0; i < g.n_problems; ++i) {
+        const auto& p = g.p[i];
+        if (p.N <= 0 || p.K <= 0 || p.N % T2_BN != 0 || p.K % T2_BK != 0) return false;
+        tiles2 += (int)((p.N / T2_BN) * (p.K / T2_BK));
+    }
+    const int64_t per_xcd = (((g.M + T2_BM - 1) / T2_BM + 7) / 8) * tiles2;
+    const int64_t cap = 32;                                  // (fewer workgroups per XCD -- CUs left to the other stream's kernels -- gained nothing in the step: profiles/r06_ab_tn256.txt)
+    *tiles_out = tiles2;
+    *grid_out = (int)(8 * (per_xcd < cap ? (per_xcd > 0 ? per_xcd : 1) : cap));
+    return true;
+}
+
+extern "C" int64_t made_gemm_tn_grouped_workspace(const MadeGemmTNGroup* group) {
+    if (group == nullptr || group->tile_size != 256 || group->n_problems < 1 || group->n_problems > MADE_GEMM_TN_MAX_GROUP || group->M <= 0) return 0;
+    int tiles = 0, grid = 0;
+    if (!t2_shape(*group, &tiles, &grid)) return 0;
+    return t2_workspace_bytes(tiles, grid);
+}
 
 extern "C" int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream) {
     MADE_REQUIRE(group != nullptr, "made_gemm_tn_grouped: null args");
@@ -483,11 +642,27 @@ extern "C" int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream) 
         MADE_UNSUPPORTED(((g.M + T2_BM - 1) / T2_BM + 7) / 8 * T2_BM <= T2_MAX_ROWS,
                          "made_gemm_tn_grouped(256): more than %d rows (a workgroup keeps an eighth of the row list in LDS)", 8 * T2_MAX_ROWS);
         // one workgroup per CU; fewer when there is less than a slab for each (small M): 8 (the XCDs) x ceil(units of an XCD / 1) capped at 32
-        const int64_t per_xcd = (((g.M + T2_BM - 1) / T2_BM + 7) / 8) * tiles2;
-        dim3 grid2((unsigned)(8 * (per_xcd < 32 ? (per_xcd > 0 ? per_xcd : 1) : 32)), 1, 1);
+        int tiles_chk = 0, grid_n = 0;
+        t2_shape(g, &tiles_chk, &grid_n);                       // one workgroup per CU; fewer when there is less than a slab for each (small M)
+        dim3 grid2((unsigned)grid_n, 1, 1);
         static const bool once2 = hipFuncSetAttribute((const void*)gemm_tn_256_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS) == hipSuccess;
         (void)once2;
-        hipLaunchKernelGGL(gemm_tn_256_grouped_kernel, grid2, dim3(T2_NT), T2_LDS, (hipStream_t)stream, g);
+        T2Ws w; w.part = nullptr; w.F = 0;
+        if (g.workspace != nullptr && made_variant_env("MADE_TN256_ATOMIC_FLUSH") == nullptr) {
+            const int64_t need = t2_workspace_bytes(tiles2, (int)grid2.x);
+            MADE_REQUIRE(g.workspace_bytes >= need && ((uintptr_t)g.workspace % 16) == 0,
+                         "made_gemm_tn_grouped(256): workspace of %lld bytes, %lld needed (made_gemm_tn_grouped_workspace), 16-byte aligned",
+                         (long long)g.workspace_bytes, (long long)need);
+            w.part = (float*)g.workspace;
+            w.F = t2_flushes(tiles2, (int)grid2.x);
+        }
+        hipLaunchKernelGGL(gemm_tn_256_grouped_kernel, grid2, dim3(T2_NT), T2_LDS, (hipStream_t)stream, g, w);
+        if (w.part != nullptr && made_variant_env("MADE_TN256_NO_REDUCE") == nullptr) {      // (measurement knob: the first launch alone -- wrong results)
+            const int rc1 = made_check_launch("made_gemm_tn_grouped(256)");
+            if (rc1 != MADE_OK) return rc1;
+            hipLaunchKernelGGL(gemm_tn_256_reduce_kernel, dim3((unsigned)tiles2 * 8), dim3(T2_NT), 0, (hipStream_t)stream, g, w, (int)grid2.x);
+            return made_check_launch("made_gemm_tn_grouped(256, reduce)");
+        }
         return made_check_launch("made_gemm_tn_grouped(256)");
     }
     MADE_REQUIRE(g.tile_size == 0 || g.tile_size == 128, "made_gemm_tn_grouped: tile_size=%d (0 / 128 or 256)", g.tile_size);

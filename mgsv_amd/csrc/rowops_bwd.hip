@@ -234,6 +234,11 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const LnBwdArgs 
 // A lane owns 8 CONSECUTIVE columns, so every tensor of a row moves as one 16-byte access per lane (1 KB per wave instruction;
 // the general kernel above moves 8 bytes per lane and needs two per tensor), and a wave keeps FOUR rows in flight: the loads of
 // all four are requested before the first reduction, and the four rows' dependent reduction chains interleave.
+// (Round 6 dealt the valid rows out evenly instead -- a workgroup compacts its ~74 valid rows of 136 into an LDS list, every wave gets the same number
+// to within one and keeps two or three rows in flight: the body drops from 19 - 26 to 16 - 21 us, but then all 256 workgroups reach the
+// parameter-gradient flush together and its 256 same-address atomics per cache line, which the ragged finish of this kernel hides under its
+// stragglers, cost 5.7 us instead of 1.3: 21.4 / 21.9 / 26.1 us against 20.3 / 20.6 / 27.4 for the three forms the step launches.  Not kept:
+// profiles/r06_lnbwd_even_rows.txt, tools/lnbwd_variants.py.)
 template <int NW, int RF>
 __global__ __launch_bounds__(NW * 64) void layernorm_bwd_v8_kernel(const LnBwdArgs a) {
     constexpr int D = 512;

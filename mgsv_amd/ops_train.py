@@ -69,9 +69,16 @@ def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulat
     return Cout
 
 
-def gemm_tn_grouped(problems, rows=None, alpha: float = 1.0, split_m: Optional[int] = None) -> None:
+def gemm_tn_grouped_workspace(device, nbytes: int) -> Tensor:
+    """A workspace for gemm_tn_grouped (contents arbitrary).  One per stream: launches that share one must be ordered."""
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def gemm_tn_grouped(problems, rows=None, alpha: float = 1.0, split_m: Optional[int] = None, workspace=None) -> None:
     """Several weight gradients over the same rows in one launch (made_gemm_tn_grouped).  problems: list of (dY [M, N], X [M, K],
-    dW [N, K] f32, db [N] f32 or None); bf16 operands, N and K multiples of 128.  rows = (row_index, n_rows) or None."""
+    dW [N, K] f32, db [N] f32 or None); bf16 operands, N and K multiples of 128.  rows = (row_index, n_rows) or None.
+    workspace: a callable nbytes -> uint8 tensor (gemm_tn_grouped_workspace; the caller keeps one per stream) -- with it the 256 x 256-tile
+    form exchanges the tile partials through it instead of adding them to dW with atomics (include/made_hip.h: MadeGemmTNGroup.workspace)."""
     assert 1 <= len(problems) <= 8
     M = problems[0][0].shape[0]
     g = MadeGemmTNGroup()
@@ -98,6 +105,15 @@ def gemm_tn_grouped(problems, rows=None, alpha: float = 1.0, split_m: Optional[i
         g.tile_size = 256
         if split_m is None:
             split_m = 1
+        # the tile partials meet in a workspace instead of being added to the gradients with atomics (MADE_TN256_ATOMIC_FLUSH=1, measurement knob: the atomics)
+        if workspace is not None and _lib.variant_env("MADE_TN256_ATOMIC_FLUSH", "") in ("", "0"):
+            need = int(lib().made_gemm_tn_grouped_workspace(C.byref(g)))
+            if need > 0:
+                ws = workspace(need)
+                assert ws.dtype == torch.uint8 and ws.numel() >= need and ws.is_contiguous()
+                from . import tape as _tape
+                _tape.keep(ws)
+                g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     if split_m is None:
         nslab = (M + 63) // 64
         split_m = max(1, (2048 // max(tiles, 1)))            # two workgroups per CU resident, about four rounds of them: measured best

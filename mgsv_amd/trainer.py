@@ -1124,8 +1124,19 @@ class MadeTrainer(MadeEngine):
     def _flush_dw(self, pending: list, row_mask: Optional[Tensor]) -> None:
         """The weight gradients a layer's backward has queued (they reduce over the same rows) in one launch (made_gemm_tn_grouped)."""
         rows = self._rw(row_mask)
+        # the launch's workspace (tile partials: ops_train.gemm_tn_grouped): one for the trainer's second stream, one for whatever stream the step
+        # runs on -- the launches of a stream are ordered, so they can share one
+        lane = "side" if torch.cuda.current_stream() == getattr(self, "_side", None) else "main"
+
+        def workspace(nbytes: int) -> Tensor:
+            wsd = self.__dict__.setdefault("_tn_ws", {})
+            if lane not in wsd or wsd[lane].numel() < nbytes:
+                if _tape.recording() or torch.cuda.is_current_stream_capturing():
+                    raise _lib.MadeError("the weight-gradient workspace has to exist before the step is recorded (the warm-up run allocates it)")
+                wsd[lane] = tr.gemm_tn_grouped_workspace(self.device, nbytes)
+            return wsd[lane]
         for i in range(0, len(pending), 8):
-            tr.gemm_tn_grouped(pending[i:i + 8], rows=rows)
+            tr.gemm_tn_grouped(pending[i:i + 8], rows=rows, workspace=workspace)
         pending.clear()
 
     def _lin_bwd(self, dz: Tensor, x: Tensor, key: str, *, dx_out: Optional[Tensor] = None, row_mask: Optional[Tensor] = None,

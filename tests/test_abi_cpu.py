@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in made_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
-    assert _lib.lib().made_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib().made_abi_version() == _lib.ABI_VERSION == 8
 
 
 def _all_structs():

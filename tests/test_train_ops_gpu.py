@@ -653,6 +653,50 @@ def test_gemm_tn_grouped_tiles(T, M, tile, monkeypatch):
                     assert float((cs - (1.0 + 0.5 * rs)).abs().max()) <= 2e-3 * float(rs.abs().max()) + 0.05
 
 
+@pytest.mark.parametrize("M", [4096, 9000, 34688])
+@pytest.mark.parametrize("shapes", [[(512, 1024), (1024, 512), (256, 512), (512, 256)],
+                                    [(512, 1024), (1024, 512), (512, 512), (1024, 512), (512, 512)], [(256, 256)]])
+def test_gemm_tn_grouped_workspace_flush(T, M, shapes):
+    """the 256 x 256-tile weight-gradient launch with a workspace (tile partials stored, summed by a second launch instead of added with
+    atomics): same gradients as the f32 product, BITWISE the same from launch to launch (fixed summing order), the workspace reusable as it
+    is, tile counts that do and do not divide the workgroups of an XCD, row gather on and off."""
+    ops, tr = T
+    mask = (torch.rand(M, device="cuda") > 0.45).float()
+    rows = ops.row_index(mask)
+    holder = {}
+
+    def workspace(n):
+        if "ws" not in holder or holder["ws"].numel() < n:
+            holder["ws"] = tr.gemm_tn_grouped_workspace(torch.device("cuda"), n)
+        return holder["ws"]
+    for use_rows in (False, True):
+        probs, refs = [], []
+        for i, (N, K) in enumerate(shapes):
+            A, B = _rand(M, N, dtype=torch.bfloat16, seed=10 + i), _rand(M, K, dtype=torch.bfloat16, seed=20 + i)
+            Am = A.float() * mask[:, None] if use_rows else A.float()
+            refs.append((Am.t() @ B.float(), Am.sum(0)))
+            if use_rows:
+                A = A.clone(); A[mask == 0] = float("nan")
+            probs.append((A, B, torch.ones(N, K, device="cuda"), torch.ones(N, device="cuda") if i != 2 else None))
+        first = None
+        for rep in range(3):
+            for (A, B, Cw, cs) in probs:
+                Cw.fill_(1.0)
+                if cs is not None: cs.fill_(1.0)
+            tr.gemm_tn_grouped(probs, rows=rows if use_rows else None, alpha=0.5, workspace=workspace)
+            for (A, B, Cw, cs), (rC, rs) in zip(probs, refs):
+                assert torch.isfinite(Cw).all()
+                assert float((Cw - (1.0 + 0.5 * rC)).abs().max()) <= 2e-3 * float(rC.abs().max()), (use_rows, rep)
+                if cs is not None:
+                    assert float((cs - (1.0 + 0.5 * rs)).abs().max()) <= 2e-3 * float(rs.abs().max()) + 0.05
+            got = [p[2].clone() for p in probs]
+            if first is None:
+                first = got
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(first, got)), "the workspace flush sums in a fixed order"
+        assert "ws" in holder
+
+
 def test_clip_loss_same_music_exclusion_forward_and_backward(T):
     """row_exclude of made_clip_loss / made_clip_loss_bwd = the same-music-aware InfoNCE of reference modules/loss.py:90-114
     (oracle restatement info_nce_same_music): loss and d(loss)/d(sims), d/d(logit_scale) against its autograd."""
