@@ -212,12 +212,14 @@ __global__ __launch_bounds__(GT_NT, 2) void gemm_tn_glds_kernel(const MadeGemmTN
     // tiles from that XCD's L2 (with the tiles of a split spread over the XCDs every tile re-fetched its two panels)
     const int tiles_k = (int)(a.K / GT_BK);
     const int tiles = (int)(a.N / GT_BN) * tiles_k;
+    // (fewer than 8 splits -- short reductions, where the splits' atomic adds would outweigh the products: round 6 -- are dealt block by block,
+    //  tile-major: consecutive blocks = consecutive XCDs, every XCD busy; the operands of so short a reduction sit in every L2 anyway)
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int64_t split_y = xcd + 8 * (int64_t)(jx / tiles);
+    const int64_t split_y = a.split_m >= 8 ? xcd + 8 * (int64_t)(jx / tiles) : (int64_t)(blockIdx.x % (unsigned)a.split_m);
     if (split_y >= a.split_m) return;
     GtProblem p;
     p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.B; p.C = a.C; p.colsum = a.colsum;
-    p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.tiles_k = tiles_k; p.tile = jx % tiles;
+    p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.tiles_k = tiles_k; p.tile = a.split_m >= 8 ? jx % tiles : (int)(blockIdx.x / (unsigned)a.split_m);
     p.c_dtype = a.c_dtype; p.accumulate = a.accumulate; p.alpha = a.alpha;
     GtShared sh;
     sh.M = a.M; sh.split_m = a.split_m; sh.split_y = split_y; sh.row_index = a.row_index; sh.n_rows = a.n_rows;
@@ -232,9 +234,9 @@ __global__ __launch_bounds__(GT_NT, 2) void gemm_tn_glds_grouped_kernel(const Ma
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tiles = g.tile_end[g.n_problems - 1];
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int64_t split_y = xcd + 8 * (int64_t)(jx / tiles);
+    const int64_t split_y = g.split_m >= 8 ? xcd + 8 * (int64_t)(jx / tiles) : (int64_t)(blockIdx.x % (unsigned)g.split_m);   // (see gemm_tn_glds_kernel)
     if (split_y >= g.split_m) return;
-    int tile = jx % tiles, pi = 0;
+    int tile = g.split_m >= 8 ? jx % tiles : (int)(blockIdx.x / (unsigned)g.split_m), pi = 0;
 #pragma unroll
     for (int i = 0; i < MADE_GEMM_TN_MAX_GROUP - 1; ++i)
         if (i + 1 < g.n_problems && tile >= g.tile_end[i]) pi = i + 1;
@@ -679,7 +681,7 @@ extern "C" int made_gemm_tn_grouped(const MadeGemmTNGroup* group, void* stream) 
     }
     MADE_UNSUPPORTED(((g.M + GT_BM - 1) / GT_BM + g.split_m - 1) / g.split_m * GT_BM <= GT_MAX_ROWS,
                      "made_gemm_tn_grouped: split_m=%lld leaves more than %d rows per workgroup", (long long)g.split_m, GT_MAX_ROWS);
-    dim3 grid((unsigned)(8 * (int64_t)tiles * ((g.split_m + 7) / 8)), 1, 1);
+    dim3 grid((unsigned)(g.split_m >= 8 ? 8 * (int64_t)tiles * ((g.split_m + 7) / 8) : (int64_t)tiles * g.split_m), 1, 1);
     static const bool once = hipFuncSetAttribute((const void*)gemm_tn_glds_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS) == hipSuccess;
     (void)once;
     hipLaunchKernelGGL(gemm_tn_glds_grouped_kernel, grid, dim3(GT_NT), GT_LDS, (hipStream_t)stream, g);
@@ -695,7 +697,7 @@ int made_gemm_tn_fast(const MadeGemmTNArgs& a, hipStream_t st) {
                     ((a.M + GT_BM - 1) / GT_BM + a.split_m - 1) / a.split_m * GT_BM <= GT_MAX_ROWS;
     if (!ok) return 1;
     const int64_t tiles = (a.N / GT_BN) * (a.K / GT_BK);
-    dim3 grid((unsigned)(8 * tiles * ((a.split_m + 7) / 8)), 1, 1);
+    dim3 grid((unsigned)(a.split_m >= 8 ? 8 * tiles * ((a.split_m + 7) / 8) : tiles * a.split_m), 1, 1);
     static const bool once = hipFuncSetAttribute((const void*)gemm_tn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS) == hipSuccess;
     (void)once;
     hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(GT_NT), GT_LDS, st, a);

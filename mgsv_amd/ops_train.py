@@ -18,6 +18,35 @@ Tensor = torch.Tensor
 Pair = Tuple[int, int]
 
 
+_TN_SLAB_US = 1.3       # (0.7 / 2.5 / 4.0 alternated in the step: 4.70 / 4.72 / 4.73 against 4.69 ms; profiles/r06_ab_tn_splits.txt)
+
+
+def _tn_splits(tiles: int, nslab: int, gathered: bool, cap: int) -> int:
+    """Reduction splits of the 128 x 128-tile weight-gradient kernels (two workgroups per CU): the split count that minimises
+        rounds of 512 workgroups x slabs per workgroup x 1.3 us  +  tiles x splits x 64 KB of f32 atomic adds at 1.2 TB/s
+    (docs/EXPERIMENTS.md 3f-4: the atomic units' rate; a gathered batch keeps about 9 / 16 of its slabs).  Long reductions come out at the 16 splits
+    measured best in rounds 2-3; short ones (the video tower's 1 920 rows, the 4 096 pair rows) at 2-8 instead of 14-32, whose atomic adds cost several
+    times the products.  cap: most splits the caller allows; a workgroup holds at most 64 slabs' row indices."""
+    if _lib.variant_env("MADE_TN_SPLIT_MODEL", "1") == "0":   # (measurement knob: rounds 2-5's rule -- fill two workgroups per CU, at least 8 splits)
+        sp = max(8, (512 // max(tiles, 1)) // 8 * 8) if cap == 64 and tiles < 64 else max(1, 2048 // max(tiles, 1))
+        while (nslab + sp - 1) // sp > 64:
+            sp += 8
+        return min(sp, max(1, nslab))
+    live = max(1, (nslab * 9) // 16 if gathered else nslab)
+    best, best_t = 1, float("inf")
+    for sp in (1, 2, 3, 4, 6, 8, 16, 24, 32, 40, 48, 56, 64):
+        if sp > max(1, cap) or sp > nslab:
+            break
+        if (nslab + sp - 1) // sp > 64:
+            continue
+        t = ((tiles * sp + 511) // 512) * ((live + sp - 1) // sp) * _TN_SLAB_US + tiles * sp * 0.0546
+        if t < best_t:
+            best, best_t = sp, t
+    while (nslab + best - 1) // best > 64:                    # (nothing admissible above: take what the row-index budget needs)
+        best += 1 if best < 8 else 8
+    return best
+
+
 def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulate: bool = False, split_m: Optional[int] = None,
             row_mask: Optional[Tensor] = None, row_groups: Optional[Tensor] = None, rows=None, colsum: Optional[Tensor] = None,
             batch: Pair = (1, 1),
@@ -37,14 +66,11 @@ def gemm_tn(A: Tensor, B: Tensor, Cout: Tensor, *, alpha: float = 1.0, accumulat
             slab = 64 if A.dtype == torch.bfloat16 else 32
             tiles = ((N + 127) // 128) * ((K + 127) // 128) * nz
             fast = A.dtype == torch.bfloat16 and N % 128 == 0 and K % 128 == 0 and nz == 1 and (row_mask is None or rows is not None)
-            if fast:                                          # direct-to-LDS kernel: one workgroup per CU, all tiles of a split on one
-                split_m = max(8, (512 // max(tiles, 1)) // 8 * 8)   # two workgroups per CU; a multiple of 8 splits keeps the 8 XCDs evenly loaded
-                nslab = (M + slab - 1) // slab
-                while (nslab + split_m - 1) // split_m > 64:      # a workgroup keeps at most 64 slabs' row indices in LDS
-                    split_m += 8
-                split_m = min(split_m, max(1, nslab))
+            if fast:                                          # direct-to-LDS kernel, two workgroups per CU (8 splits or more: the tiles of a split on one XCD)
+                split_m = _tn_splits(tiles, (M + slab - 1) // slab, rows is not None, 64)
             else:
-                split_m = max(1, min(512 // max(tiles, 1), (M + slab - 1) // slab, 256))
+                # (at least eight slabs per split: fewer do not pay for a tile of atomic adds -- one slab per split until round 6: 4.70 against 4.72 ms)
+                split_m = max(1, min(512 // max(tiles, 1), ((M + slab - 1) // slab) // 8, 256))
     a = MadeGemmTNArgs()
     a.A, a.B, a.C = _p(A), _p(B), _p(Cout)
     a.ab_dtype, a.c_dtype = dt_of(A), dt_of(Cout)
@@ -115,12 +141,7 @@ def gemm_tn_grouped(problems, rows=None, alpha: float = 1.0, split_m: Optional[i
                 _tape.keep(ws)
                 g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     if split_m is None:
-        nslab = (M + 63) // 64
-        split_m = max(1, (2048 // max(tiles, 1)))            # two workgroups per CU resident, about four rounds of them: measured best
-                                                              # (one layer's five products: 212 / 179 / 164 us at 8 / 12 / 16 splits)
-        while (nslab + split_m - 1) // split_m > 64:          # a workgroup keeps at most 64 slabs' row indices in LDS
-            split_m += 1
-        split_m = min(split_m, max(1, nslab))
+        split_m = _tn_splits(tiles, (M + 63) // 64, rows is not None, 64)
     g.split_m = int(split_m)
     _timed("made_gemm_tn", flops, nbytes, lambda: check(lib().made_gemm_tn_grouped(C.byref(g), _stream()), "made_gemm_tn_grouped"),
            ("rows", rows[1], M) if rows is not None else f"grouped x{len(problems)} M={M}")
