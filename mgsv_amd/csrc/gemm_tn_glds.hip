@@ -283,18 +283,22 @@ __device__ __forceinline__ void t2_wait12(bf16x4 (&f)[12], int n_outstanding_is_
 // accumulators to C whenever its range leaves a tile (at most ceil(32 / tiles) + 1 times).
 struct T2Tile { const bf16_t* A; const bf16_t* B; float* C; float* colsum; int64_t lda, ldb, ldc, n0, k0; int first_k; };
 
-__device__ __forceinline__ T2Tile t2_tile(const MadeGemmTNGroup& g, int tile) {
-    int pi = 0;
+// (The group is read where the launch put it -- the kernel-argument segment, through scalar loads at a computed offset -- not from the by-value
+//  parameter: selecting a problem's members out of that costs ~150 scalar registers spilled to vector lanes, and indexing it with a run-time problem
+//  number makes the compiler copy all 672 bytes of it to scratch memory.)
+typedef const __attribute__((address_space(4))) MadeGemmTNGroup* T2GroupPtr;
+__device__ __forceinline__ T2GroupPtr t2_group() { return (T2GroupPtr)__builtin_amdgcn_kernarg_segment_ptr(); }      // the group is the kernels' FIRST parameter
+
+__device__ __forceinline__ T2Tile t2_tile(T2GroupPtr g, int tile) {
+    int pi = 0, base = 0;
 #pragma unroll
     for (int i = 0; i < MADE_GEMM_TN_MAX_GROUP - 1; ++i)
-        if (i + 1 < g.n_problems && tile >= g.tile_end[i]) pi = i + 1;
-    if (pi > 0) tile -= g.tile_end[pi - 1];
+        if (i + 1 < g->n_problems && tile >= g->tile_end[i]) { pi = i + 1; base = g->tile_end[i]; }
+    tile -= base;
     T2Tile t;
-    // (a dynamically indexed member of the kernel argument would be copied to scratch memory: select instead)
-    MadeGemmTNProblem p = g.p[0];
-#pragma unroll
-    for (int i = 1; i < MADE_GEMM_TN_MAX_GROUP; ++i)
-        if (pi == i) p = g.p[i];
+    MadeGemmTNProblem p;                                     // (member by member: the struct has no constructor from the constant address space)
+    p.A = g->p[pi].A; p.B = g->p[pi].B; p.C = g->p[pi].C; p.colsum = g->p[pi].colsum;
+    p.N = g->p[pi].N; p.K = g->p[pi].K; p.lda = g->p[pi].lda; p.ldb = g->p[pi].ldb; p.ldc = g->p[pi].ldc;
     const int tiles_k = (int)(p.K / T2_BK);
     t.A = (const bf16_t*)p.A; t.B = (const bf16_t*)p.B; t.C = (float*)p.C; t.colsum = p.colsum;
     t.lda = p.lda; t.ldb = p.ldb; t.ldc = p.ldc;
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
 
     int tile = (int)(u0 / S);
     int64_t si = u0 % S;                                     // slab (index inside this XCD's list) of the current unit
-    T2Tile cur = t2_tile(g, tile), nxt = cur;
+    T2Tile cur = t2_tile(t2_group(), tile), nxt = cur;
     clear();
     issue(0, si, cur);
     for (int64_t u = u0, n = 0; u < u1; ++u, ++n) {
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // every wave's part landed; everyone is done with the other stage
         const bool last_of_tile = si + 1 == S;
         if (u + 1 < u1) {
-            if (last_of_tile) { nxt = t2_tile(g, tile + 1); issue(n + 1, 0, nxt); }
+            if (last_of_tile) { nxt = t2_tile(t2_group(), tile + 1); issue(n + 1, 0, nxt); }
             else issue(n + 1, si + 1, cur);
         }
         unsigned char* st = lds + (n % T2_NST) * T2_STAGE;
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_reduce_kernel(const Made
     int64_t Mv = g.M;
     if (g.n_rows) { const int64_t nv = *g.n_rows; Mv = nv < g.M ? nv : g.M; }
     const int64_t nslab = (Mv + T2_BM - 1) / T2_BM;
-    const T2Tile t = t2_tile(g, tile_idx);
+    const T2Tile t = t2_tile(t2_group(), tile_idx);
     // this lane's C addresses first (their loads fly under the partials')
     float cv[4][4];
     float* cp[4];
