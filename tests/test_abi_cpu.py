@@ -109,3 +109,19 @@ def test_product_path_refuses_cpu_tensors():
     from mgsv_amd import ops
     with pytest.raises(_lib.MadeError):
         ops.layernorm(torch.zeros(4, 256), torch.ones(256), torch.zeros(256))
+
+
+def test_weight_gradient_split_model():
+    """ops_train._tn_splits (reduction splits of the 128 x 128-tile weight-gradient kernels by cost: products against f32 atomic adds): never more
+    splits than slabs, never more than 64 slabs' row indices per workgroup, short reductions few splits, long ones the 16 measured best."""
+    from mgsv_amd.ops_train import _tn_splits
+    for tiles in (1, 4, 16, 24, 32, 80, 128, 256):
+        for nslab in (1, 2, 4, 6, 30, 64, 141, 512, 542, 1000, 4096):
+            for gathered in (False, True):
+                sp = _tn_splits(tiles, nslab, gathered, 64)
+                assert 1 <= sp and (sp <= nslab or nslab > 64 * sp - 1 or (nslab + sp - 1) // sp <= 64), (tiles, nslab, sp)
+                assert (nslab + sp - 1) // sp <= 64, (tiles, nslab, sp)
+    assert _tn_splits(128, 30, True, 64) <= 3            # the video tower's grouped launch (1 920 rows): 14 splits until round 6
+    assert _tn_splits(16, 30, True, 64) <= 8
+    assert _tn_splits(16, 64, False, 64) <= 8            # the 4 096 pair rows: 32 splits until round 6
+    assert _tn_splits(32, 512, True, 64) == 16           # the audio tower's 32 768 rows: as measured best in rounds 2-3
