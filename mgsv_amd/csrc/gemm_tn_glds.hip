@@ -5,7 +5,9 @@
 // workgroups per CU), a second workgroup does (profiles/r02_c_tn_bench.txt).
 //
 // LDS image of a stage: A rows [64][256 B] then B rows [64][256 B], unpadded (the LDS-DMA writes 1 KB contiguous per wave
-// instruction = 4 rows), with the 32-byte column pairs of a row XOR-swizzled by (row & 3) on the SOURCE side, so the four rows a
+// instruction = 4 rows), with the 64-byte blocks of a row XOR-swizzled by (row & 3) on the SOURCE side (rounds 1-5: the 32-byte pairs, which
+// left rows r and r ^ 1 on the same banks -- a 32-lane half of the transposing read takes BOTH pairs of a block from each of four rows: 48 % of the
+// LDS cycles were conflicts, SQ_LDS_BANK_CONFLICT; profiles/r06_sq_counters_tn256.txt), so the four rows a
 // transposing read (ds_read_b64_tr_b16) touches fall on four different bank groups.
 #include "common.h"
 
@@ -86,7 +88,7 @@ __device__ __forceinline__ void gemm_tn_glds_body(const GtProblem a, const GtSha
         for (int j = 0; j < 4; ++j) {
             const int rowl = 16 * wave + 4 * j + (lane >> 4);
             const int64_t pr = lds_rows[i * GT_BM + rowl];
-            const int chunk = (((pos >> 1) ^ (rowl & 3)) << 1) | (pos & 1);          // source-side swizzle of the 32-byte pairs
+            const int chunk = (((pos >> 1) ^ ((rowl & 3) << 1)) << 1) | (pos & 1);   // source-side swizzle: the row's 64-byte blocks XORed with row & 3
             const int piece = (16 * wave + 4 * j) * GT_ROW;                          // 1 KB destination of this instruction
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ag + pr * a.lda + n0 + chunk * 8), (lds_ptr_t)(st + piece), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bg + pr * a.ldb + k0 + chunk * 8), (lds_ptr_t)(st + GT_HALF + piece), 16, 0, 0);
@@ -94,7 +96,7 @@ __device__ __forceinline__ void gemm_tn_glds_body(const GtProblem a, const GtSha
     };
 
     // per-lane byte offsets of the transposing reads inside a stage (k-step 0; k-step ks adds ks * 16 rows as an immediate):
-    // row = 4 * (g >> 1) + (i >> 2), 32-byte pair (c0 / 16 + (g & 1)) ^ (row & 3), 8 * (i & 3) inside the pair
+    // row = 4 * (g >> 1) + (i >> 2), 32-byte pair (c0 / 16 + (g & 1)) ^ 2 (row & 3), 8 * (i & 3) inside the pair
     uint32_t offA[2], offB[2];
     {
         const int g = lane >> 4, i16 = lane & 15;
@@ -102,8 +104,8 @@ __device__ __forceinline__ void gemm_tn_glds_body(const GtProblem a, const GtSha
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int pa = ((wn * 64 + t * 32) >> 4) + (g & 1), pb = ((wk * 64 + t * 32) >> 4) + (g & 1);
-            offA[t] = (uint32_t)(row * GT_ROW + ((pa ^ (row & 3)) << 5) + 8 * (i16 & 3));
-            offB[t] = (uint32_t)(GT_HALF + row * GT_ROW + ((pb ^ (row & 3)) << 5) + 8 * (i16 & 3));
+            offA[t] = (uint32_t)(row * GT_ROW + ((pa ^ ((row & 3) << 1)) << 5) + 8 * (i16 & 3));
+            offB[t] = (uint32_t)(GT_HALF + row * GT_ROW + ((pb ^ ((row & 3) << 1)) << 5) + 8 * (i16 & 3));
         }
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
         for (int j = 0; j < 4; ++j) {
             const int rowl = 8 * wave + 2 * j + (lane >> 5);
             const int64_t pr = lds_rows[si * T2_BM + rowl];
-            const int chunk = (((pos >> 1) ^ (rowl & 3)) << 1) | (pos & 1);          // source-side swizzle of the 32-byte pairs
+            const int chunk = (((pos >> 1) ^ ((rowl & 3) << 1)) << 1) | (pos & 1);   // source-side swizzle: the row's 64-byte blocks XORed with row & 3
             const int piece = (8 * wave + 2 * j) * T2_ROW;                           // 1 KB destination of this instruction (two rows)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(t.A + pr * t.lda + t.n0 + chunk * 8), (lds_ptr_t)(st + piece), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(t.B + pr * t.ldb + t.k0 + chunk * 8), (lds_ptr_t)(st + T2_HALF + piece), 16, 0, 0);
@@ -367,12 +369,12 @@ __global__ __launch_bounds__(T2_NT, 1) void gemm_tn_256_grouped_kernel(const Mad
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int pa = ((wn * 128 + t * 32) >> 4) + (gq & 1);
-            offA[t] = (uint32_t)(row * T2_ROW + ((pa ^ (row & 3)) << 5) + 8 * (i16 & 3));
+            offA[t] = (uint32_t)(row * T2_ROW + ((pa ^ ((row & 3) << 1)) << 5) + 8 * (i16 & 3));
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int pb = ((wk * 64 + t * 32) >> 4) + (gq & 1);
-            offB[t] = (uint32_t)(T2_HALF + row * T2_ROW + ((pb ^ (row & 3)) << 5) + 8 * (i16 & 3));
+            offB[t] = (uint32_t)(T2_HALF + row * T2_ROW + ((pb ^ ((row & 3) << 1)) << 5) + 8 * (i16 & 3));
         }
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
