@@ -99,8 +99,60 @@ extern "C" int made_tape_begin(void) {
     return MADE_OK;
 }
 
+// A program asks for the same cross-stream dependency more than once (two helpers in a row each make the second stream wait for the first):
+// every record + wait costs the waiting stream >= 6 us on this stack even when there is nothing to wait for (tools/probes/stream_value_probe.hip).
+// Dropped here, once, at the end of the recording:
+//   * a record on a stream that has been given nothing since its previous record marks the same point: its event becomes an alias of the earlier one;
+//   * a wait of a stream for an event it has already waited for (same record) adds nothing.
+static void tape_dedup(Tape* t) {
+    const size_t n = t->ops.size();
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> alias;                 // event -> the earlier event that marks the same point
+    auto canon = [&](hipEvent_t e) { for (auto& a : alias) if (a.first == e) return a.second; return e; };
+    std::vector<std::pair<hipStream_t, hipEvent_t>> last_rec;             // stream -> event of its latest record with nothing issued to the stream since
+    std::vector<std::pair<hipStream_t, std::vector<hipEvent_t>>> waited;  // stream -> events it has waited for
+    auto forget = [&](hipStream_t st) { for (auto& lr : last_rec) if (lr.first == st) lr.second = nullptr; };
+    std::vector<char> drop(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        TapeOp& op = t->ops[i];
+        if (op.kind == TAPE_EV_RECORD) {
+            hipEvent_t prev = nullptr;
+            for (auto& lr : last_rec) if (lr.first == op.st) prev = lr.second;
+            if (prev != nullptr) { alias.push_back({op.ev, prev}); drop[i] = 1; continue; }
+            bool found = false;
+            for (auto& lr : last_rec) if (lr.first == op.st) { lr.second = op.ev; found = true; }
+            if (!found) last_rec.push_back({op.st, op.ev});
+            for (auto& wd : waited) {                         // (an event recorded again: a later wait for it is a new dependency)
+                auto& v = wd.second;
+                for (size_t k = 0; k < v.size();) { if (v[k] == op.ev) v.erase(v.begin() + (long)k); else ++k; }
+            }
+        } else if (op.kind == TAPE_EV_WAIT) {
+            op.ev = canon(op.ev);
+            std::vector<hipEvent_t>* w = nullptr;
+            for (auto& wd : waited) if (wd.first == op.st) w = &wd.second;
+            if (w == nullptr) { waited.push_back({op.st, {}}); w = &waited.back().second; }
+            bool seen = false;
+            for (hipEvent_t e : *w) seen = seen || e == op.ev;
+            if (seen) { drop[i] = 1; continue; }
+            w->push_back(op.ev);
+            forget(op.st);                                    // (the stream's next record covers what it has just waited for as well)
+        } else if (op.kind == TAPE_CALLBACK) {
+            for (auto& lr : last_rec) lr.second = nullptr;    // (a host callback may put work of the framework on any stream)
+            for (auto& wd : waited) wd.second.clear();
+        } else if (op.kind == TAPE_WAIT) {
+            forget(op.st); forget(op.st2);
+        } else {
+            forget(op.st);
+        }
+    }
+    std::vector<TapeOp> out;
+    out.reserve(n);
+    for (size_t i = 0; i < n; ++i) if (!drop[i]) out.push_back(t->ops[i]);
+    t->ops.swap(out);
+}
+
 extern "C" int made_tape_end(uint64_t* handle) {
     MADE_REQUIRE(g_made_tape != nullptr && handle != nullptr, "made_tape_end: not recording");
+    if (made_variant_env("MADE_TAPE_NO_DEDUP") == nullptr) tape_dedup((Tape*)g_made_tape);
     *handle = (uint64_t)(uintptr_t)g_made_tape;
     g_made_tape = nullptr;
     return MADE_OK;

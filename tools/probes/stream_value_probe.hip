@@ -40,7 +40,33 @@ int main() {
         }
         printf("%s: %.2f us per kernel of the chain\n", mode == 0 ? "one stream" : (mode == 1 ? "two streams, event record + stream wait" : "two streams, write value + wait value"), best);
     }
+    {   // a chain on stream 0 whose every kernel first waits for an event of stream 1 that completed long ago
+        hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, s[1], x + 8);
+        CK(hipEventRecord(ev[0], s[1])); CK(hipDeviceSynchronize());
+        double best = 1e30;
+        for (int rep = 0; rep < REP + 1; ++rep) {
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < N; ++i) { CK(hipStreamWaitEvent(s[0], ev[0], 0)); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, s[0], x); }
+            CK(hipStreamSynchronize(s[0]));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
+            if (rep > 0 && us < best) best = us;
+        }
+        printf("one stream, every kernel behind a wait for a long-completed event of the other: %.2f us per kernel\n", best);
+        // ... and with a fresh record on the (idle) other stream in front of every wait: the hop's cost without any work to wait for
+        best = 1e30;
+        for (int rep = 0; rep < REP + 1; ++rep) {
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < N; ++i) { CK(hipEventRecord(ev[i], s[1])); CK(hipStreamWaitEvent(s[0], ev[i], 0)); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, s[0], x); }
+            CK(hipStreamSynchronize(s[0]));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
+            if (rep > 0 && us < best) best = us;
+        }
+        printf("one stream, every kernel behind record(idle other stream) + wait: %.2f us per kernel\n", best);
+    }
     float h; CK(hipMemcpy(&h, x, 4, hipMemcpyDeviceToHost));
     printf("kernels run: %.0f\n", h);
     return 0;
 }
+// (appended: what a wait costs when the event it waits for completed long ago -- the common case of the step's 20 waits)

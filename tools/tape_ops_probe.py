@@ -29,3 +29,12 @@ for i in range(max(0, last - 3), min(len(ops), last + 24)):
     print(f"  {i:4d}  {names[k]:13s} s{streams[st]}  {grid if k == 0 else ''}")
 import collections
 print("non-kernel operations of the whole step:", dict(collections.Counter(names[o[0]] for o in ops if o[0] != 0)))
+
+# every cross-stream operation of the step with the launches around it (grid of the last launch in front of it and the first behind it, per stream)
+print("cross-stream operations (index, kind, stream; last launch issued on that stream in front of it):")
+last = {}
+for i, (k, fn, st, grid) in enumerate(ops):
+    if k == 0:
+        last[st] = (i, grid)
+    elif k in (1, 4, 5):
+        print(f"  {i:4d} {names[k]:13s} s{streams[st]}  after {last.get(st)}")
