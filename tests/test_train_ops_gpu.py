@@ -1031,3 +1031,35 @@ def test_dec_stage_bwd_matches_the_separate_launches(T, D, N, mode, gate, col_di
     assert float((out1.float() - out0.float()).abs().max()) <= 0.03 * so, float((out1.float() - out0.float()).abs().max()) / so
     for a_, b_ in zip(pg0, pg1):
         assert float((a_ - b_).abs().max()) <= (1e-3 if mode != 1 else 2e-2) * max(float(a_.abs().max()), 1e-3) + 1e-5
+
+
+def test_launch_tape_drops_duplicate_cross_stream_dependencies(T):
+    """made_tape_end keeps ONE record + wait where a program asks for the same cross-stream dependency several times in a row (every pair costs the
+    waiting stream >= 6 us on this stack), a stream's later record is a dependency of its own, and the replayed result is the eager one."""
+    ops, tr = T
+    from mgsv_amd import tape as _tape
+    x = torch.arange(4096, device="cuda", dtype=torch.float32)
+    y, z = torch.zeros_like(x), torch.zeros_like(x)
+    cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
+
+    def program():
+        side.wait_stream(cur); side.wait_stream(cur); side.wait_stream(cur)        # three times the same dependency
+        with torch.cuda.stream(side):
+            tr.add3(y, x, x)                                                       # y = 2 x
+        tr.add3(z, x)                                                              # z = x (main stream, beside it)
+        cur.wait_stream(side); cur.wait_stream(side)                               # twice the same join
+        tr.add3(z, z, y)                                                           # z = 3 x
+        side.wait_stream(cur)                                                      # a NEW point of the main stream: kept
+        with torch.cuda.stream(side):
+            tr.add3(y, z, x)                                                       # y = 4 x
+        cur.wait_stream(side)
+    program(); torch.cuda.synchronize()
+    with _tape.LaunchTape.record() as tp:
+        program()
+    torch.cuda.synchronize()
+    k, w, o = tp.counts()
+    assert k == 4 and w == 0 and o == 8, (k, w, o)               # 4 record + wait pairs of the 7 asked for
+    y.zero_(); z.zero_(); torch.cuda.synchronize()
+    tp.replay(); torch.cuda.synchronize()
+    assert torch.equal(z, 3 * x) and torch.equal(y, 4 * x)
+    tp.close()
