@@ -1948,6 +1948,7 @@ class MadeTrainer(MadeEngine):
         # local = mask(final(x4)); x4 = x3 + drop(ffn2): the product dl W_f is needed raw (residual) and dropped (branch)
         x_last = tw[tag + ".xlast"]
         dx = None
+        proj_grouped = False
         for l in range(depth - 1, -1, -1):
             p, t = f"{mod}.layers.{l}", f"{tag}.{l}"
             x4 = x_last if l == depth - 1 else tw[f"{tag}.{l + 1}.x0"]
@@ -1971,14 +1972,23 @@ class MadeTrainer(MadeEngine):
                              keep_bits=tw[t + ".kbits"] if self._bits else None)
             dx1 = self._lin_bwd(gq, tw[t + ".x1"], p + ".in", dx_out=g3b, row_mask=mflat, skip=mflat, R=g1b, defer=pend)
             dx = tr.layernorm_bwd(tw[t + ".x0"], P[p + ".ln1.g"], dx1, g2, dgamma=G[p + ".ln1.g"], dbeta=G[p + ".ln1.b"], row_skip=mflat)
+            if (l == 0 and not cls and not c.with_act_after_proj and self.tc == torch.bfloat16 and len(pend) < 8 and Kin % 256 == 0 and D % 256 == 0
+                    and self._rw(mflat) is not None and self._groupable(dx, tw[tag + ".xin"], G[proj + ".w"])):
+                # the input projection's weight gradient reduces over the same rows as the first layer's: one more problem of its grouped launch
+                # instead of a launch of its own (round 6: 63 us at the very end of the main stream for the audio tower)
+                pend.append((dx, tw[tag + ".xin"], G[proj + ".w"], G[proj + ".b"]))
+                proj_grouped = True
             if dw_stream is not None and depth == 1 and not cls and not c.with_act_after_proj:
                 dw_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(dw_stream):
                     self._flush_dw(pend, mflat)
-                    xin_ = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
-                    tr.gemm_tn(dx, xin_, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], rows=self._rw(mflat0))
+                    if not proj_grouped:
+                        xin_ = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
+                        tr.gemm_tn(dx, xin_, G[proj + ".w"], accumulate=True, colsum=G[proj + ".b"], rows=self._rw(mflat0))
                 return
             self._flush_dw(pend, mflat)
+        if proj_grouped:
+            return
         xin = tw[tag + ".xin"] if self.tc == torch.bfloat16 else feats.view(rows, Kin)
         if cls:                                              # x0 = [token + pe_0 ; proj(x) + pe_1..T]
             dx3d = dx.view(B, T1, D)
