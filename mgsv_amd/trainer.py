@@ -507,8 +507,9 @@ class MadeTrainer(MadeEngine):
             dchain=E(nd, 6, B * Q, D),
             # heads
             h1=E(nd * B * Q, D), h2=E(nd * B * Q, D), hg1=E(nd * B * Q, D), hg2=E(nd * B * Q, D),
-            dlog=Z(nd * B * Q, HEAD_PAD, dtype=f32), dsp=Z(nd * B * Q, HEAD_PAD, dtype=f32), dlog_c=Z(nd * B * Q, HEAD_PAD), dsp_c=Z(nd * B * Q, HEAD_PAD),
+            dlogsp=Z(2, nd * B * Q, HEAD_PAD, dtype=f32), dlogsp_c=Z(2, nd * B * Q, HEAD_PAD),       # (one buffer per dtype: one cast launch for both)
         )
+        ws["dlog"], ws["dsp"], ws["dlog_c"], ws["dsp_c"] = ws["dlogsp"][0], ws["dlogsp"][1], ws["dlogsp_c"][0], ws["dlogsp_c"][1]
         ws["dvideo"], ws["dmusic"] = ws["dclip"][:B * D].view(B, D), ws["dclip"][B * D:2 * B * D].view(B, D)
         if "video" in c.vmr_fusion:                             # second X-Pool tower: music vectors attend to the frames ("y" = "x" with S = T_v)
             Svp = round_up(Tv, 8)
@@ -1249,7 +1250,8 @@ class MadeTrainer(MadeEngine):
             dhs = tw["dhs"]
             dlog, dsp = tw["dlog"], tw["dsp"]
             if self.tc != torch.float32:                          # same dtype as the activations for the A^T B products
-                dlog, dsp = tr.add3(tw["dlog_c"], dlog), tr.add3(tw["dsp_c"], dsp)
+                tr.add3(tw["dlogsp_c"], tw["dlogsp"])             # both casts in one launch
+                dlog, dsp = tw["dlog_c"], tw["dsp_c"]
             # the heads' weight gradients wait for nobody on the main stream: they are launched with the decoder's (second stream,
             # after the loop below); their operands (dlog / dsp / hg1 / hg2 / h1 / h2 / hs) are not touched in between
             heads_dw: list = []
