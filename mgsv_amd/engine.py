@@ -530,7 +530,7 @@ class MadeEngine:
             if tc == torch.bfloat16 and Nv <= 64 and S <= 512 and S * D >= 65536 and D in (256, 512) and _lib.variant_env("MADE_XPOOL_INBATCH", "1") != "0":
                 # the in-batch shape (round 4): scores per (track, 128 segments), P.V per (track, 128 columns), bf16 probabilities between them
                 if xib_ws is None:
-                    xib_ws = torch.zeros(ops.xpool_inbatch_ws_bytes(cm, S), device=dev, dtype=torch.uint8)
+                    xib_ws = torch.empty(ops.xpool_inbatch_ws_bytes(cm, S), device=dev, dtype=torch.uint8)      # (no counters in it since the one-launch form went: nothing to clear)
                 ops.xpool_inbatch(q, kbuf[:n * S].view(n, S, D), u[:n * S].view(n, S, D), seg_mask[m0:m0 + n] if seg_mask is not None else None,
                                   o[:n * Nv].view(n, Nv, D), scale=scale, ws=xib_ws)
             else:

@@ -742,7 +742,7 @@ def xpool_inbatch(Q: Tensor, K: Tensor, U: Tensor, key_mask: Optional[Tensor], o
     a.Nv, a.Nm, a.S, a.D, a.scale = Nv, Nm, S, D, scale
     need = xpool_inbatch_ws_bytes(Nm, S)
     if ws is None:
-        ws = torch.zeros(need, device=Q.device, dtype=torch.uint8)           # (zeros: the one-launch form's counters sit at its end)
+        ws = torch.empty(need, device=Q.device, dtype=torch.uint8)           # (contents arbitrary: the exchange tiles of the two launches)
     assert ws.is_contiguous() and ws.numel() * ws.element_size() >= need
     a.ws = _p(ws)
     desc = ""
